@@ -1,0 +1,140 @@
+/* oracle/lsdr_oracle.h — CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C restatement of the leandvb IQ hot path of pabr/leansdr
+ * (SURVEY.md §8a), written from the reference's behaviour, every function
+ * citing the reference file:line it follows (paths relative to
+ * /root/reference/src/leansdr unless stated).  Compiled -O3 -ffp-contract=off
+ * so that float arithmetic is evaluated exactly like the reference's x86-64
+ * SSE2 build (no FMA, no reassociation).
+ *
+ * PARITY PINNING: this oracle is pinned against the real reference compiled
+ * here (oracle/_ref/libleansdr_ref.so, built by oracle/Makefile from
+ * oracle/ref_harness.cc + the reference headers) by tests/test_oracle_vs_ref.py,
+ * and against the golden vectors under tests/golden/ (generated from the real
+ * reference by oracle/make_golden.py) by tests/test_oracle_golden.py.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.  The product (leansdr_amd/) never links or imports it.
+ */
+#ifndef LSDR_ORACLE_H
+#define LSDR_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float re, im; } lo_cf32;
+typedef struct { uint8_t re, im; } lo_cu8;
+/* sdr.h:287-290; 4 bytes, pad byte written as 0 by the oracle */
+typedef struct { int16_t cost; uint8_t symbol; uint8_t pad; } lo_softsymbol;
+
+/* ---- tables ------------------------------------------------------------ */
+void lo_trig16(lo_cf32 *lut /*[65536]*/);                 /* math.h:95-106 */
+unsigned lo_trig16_index(float a);                        /* math.h:108-110 */
+
+enum { LO_BPSK, LO_QPSK, LO_PSK8, LO_APSK16, LO_APSK32, LO_APSK64E,
+       LO_QAM16, LO_QAM64, LO_QAM256 };                   /* sdr.h:318-324 */
+/* code_rate, dvb.h:33-37 */
+enum { LO_FEC12, LO_FEC23, LO_FEC46, LO_FEC34, LO_FEC56, LO_FEC78,
+       LO_FEC45, LO_FEC89, LO_FEC910 };
+
+typedef struct {
+  int nsymbols, nrotations;
+  int8_t symbols[256][2];
+  int16_t cost[65536];          /* index [(u8)I][(u8)Q] = I8*256+Q8 */
+  uint8_t symbol[65536];
+  int16_t phase_error[65536];
+} lo_cstln_lut;
+/* sdr.h:326-468 + make_lut_from_symbols sdr.h:529-560 */
+int lo_cstln_lut_init(lo_cstln_lut *c, int predef, float g1, float g2, float g3);
+/* dvb.h:45-81 */
+int lo_make_dvbs2_constellation(lo_cstln_lut *c, int predef, int fec);
+void lo_cstln_harden(lo_cstln_lut *c);                    /* sdr.h:564-571 */
+unsigned lo_cstln_lookup_index(float I, float Q);         /* sdr.h:470-482 */
+
+int lo_lowpass(int order, float Fcut, float *coeffs, float gain); /* filtergen.h:45-62 */
+int lo_root_raised_cosine(int order, float Fs, float rolloff, float *coeffs); /* filtergen.h:68-92 */
+void lo_normalize_dcgain(int n, float *c, float gain);    /* filtergen.h:34-40 */
+void lo_normalize_power(int n, float *c, float gain);     /* filtergen.h:26-32 */
+
+/* ---- streaming blocks --------------------------------------------------- */
+void lo_cconverter_u8(const lo_cu8 *in, size_t n, lo_cf32 *out);   /* dsp.h:40-50 */
+void lo_scaler(float scale, const lo_cf32 *in, size_t n, lo_cf32 *out); /* dsp.h:149-156 */
+size_t lo_decimator(unsigned d, const lo_cf32 *in, size_t n, lo_cf32 *out, size_t cap); /* generic.h:256-262 */
+
+/* fir_filter<cf32,float>: dsp.h:219-285 */
+void lo_fir_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq,
+                         lo_cf32 *shifted);                /* set_freq dsp.h:271-280 */
+/* run() over one buffer, dsp.h:233-262.  *consumed = count*decim. returns count. */
+size_t lo_fir_filter(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
+                     const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
+                     size_t *consumed);
+/* fir_resampler<cf32,float> (interpolator): dsp.h:290-364 */
+void lo_fir_resampler_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq,
+                                   lo_cf32 *shifted);      /* dsp.h:351-360 */
+size_t lo_fir_resampler(unsigned ncoeffs, const lo_cf32 *shifted, int interp,
+                        const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
+                        size_t *consumed);
+
+/* cfft_engine<float>::inplace, dsp.h:56-116 (n power of 2) */
+void lo_cfft(int n, lo_cf32 *data, int reverse);
+
+/* auto_notch<f32>: sdr.h:46-154 */
+typedef struct lo_auto_notch lo_auto_notch;
+lo_auto_notch *lo_auto_notch_new(int nslots, int decimation, float k, float agc_rms_setpoint);
+void lo_auto_notch_free(lo_auto_notch *a);
+/* processes floor(n/4096) blocks; returns samples consumed (= produced) */
+size_t lo_auto_notch_run(lo_auto_notch *a, const lo_cf32 *in, size_t n, lo_cf32 *out);
+int lo_auto_notch_slot_bin(const lo_auto_notch *a, int slot);
+
+/* cnr_fft<f32>: sdr.h:1273-1345 */
+typedef struct lo_cnr_fft lo_cnr_fft;
+lo_cnr_fft *lo_cnr_fft_new(float bandwidth, int nfft, int decimation);
+void lo_cnr_fft_free(lo_cnr_fft *c);
+size_t lo_cnr_fft_run(lo_cnr_fft *c, float freq_tap, float tap_multiplier,
+                      const lo_cf32 *in, size_t n, float *out, size_t cap);
+
+/* ---- cstln_receiver<f32>: sdr.h:697-938 ---------------------------------- */
+enum { LO_SAMP_NEAREST, LO_SAMP_LINEAR, LO_SAMP_FIR };
+typedef struct {
+  int sampler;            /* LO_SAMP_* (sdr.h:600-689) */
+  int ncoeffs;            /* fir_sampler prototype */
+  const float *coeffs;
+  int subsampling;
+  int cstln, fec;         /* make_dvbs2_constellation(cstln, fec) */
+  float omega;            /* set_omega(), sdr.h:738-743 */
+  float freq;             /* set_freq(), sdr.h:745-749 (0 = untouched) */
+  float pll_adjustment;
+  int allow_drift;
+  unsigned long meas_decimation;
+  float kest;
+} lo_rx_params;
+
+typedef struct {
+  float mu, phase, freqw, agc_gain, est_insp, est_sp, est_ep, freq_tap;
+  float min_freqw, max_freqw;
+  unsigned long meas_count;
+  float hist[12];         /* hist[k] = {p.re,p.im,c.re,c.im}, k=0..2 (sdr.h:923-926) */
+} lo_rx_state;
+
+typedef struct lo_rx lo_rx;
+lo_rx *lo_rx_new(const lo_rx_params *p);
+void lo_rx_free(lo_rx *r);
+/* run() over one buffer (sdr.h:772-916): consumes whole chunks of 128 while
+ * n_in-pos >= 128+readahead and cap-produced >= 128.  Measurement outputs are
+ * appended to freq/ss/mer (one float per meas_decimation samples) and
+ * cstln_out (one cf32 per chunk that produced >=1 symbol); any may be NULL. */
+size_t lo_rx_run(lo_rx *r, const lo_cf32 *in, size_t n_in,
+                 lo_softsymbol *out, size_t cap, size_t *consumed,
+                 float *freq_out, float *ss_out, float *mer_out, size_t meas_cap, size_t *n_meas,
+                 lo_cf32 *cstln_out, size_t cstln_cap, size_t *n_cstln);
+void lo_rx_get_state(const lo_rx *r, lo_rx_state *st);
+void lo_rx_set_state(lo_rx *r, const lo_rx_state *st);
+int lo_rx_readahead(const lo_rx *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,375 @@
+"""oracle/pyoracle.py — ctypes bindings for the two CPU checkers.  TEST INFRASTRUCTURE.
+
+  * `Oracle`  -> oracle/liblsdr_oracle.so   (our plain-C restatement, travels)
+  * `Ref`     -> oracle/_ref/libleansdr_ref.so (the real reference behind
+                 oracle/ref_harness.cc; exists only where it was built)
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "liblsdr_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libleansdr_ref.so")
+REF_DIR = os.path.join(HERE, "_ref")
+
+c_f = C.c_float
+c_fp = C.POINTER(C.c_float)
+c_sz = C.c_size_t
+
+
+def build(ref=True):
+    """Compile the oracle (and, where /root/reference exists, oracle/_ref)."""
+    subprocess.check_call(["make", "-s", "-C", HERE, "liblsdr_oracle.so"])
+    if ref:
+        subprocess.check_call(["make", "-s", "-C", HERE, "ref"])
+
+
+def _p(a, t=None):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def cf32(a):
+    """complex64 ndarray (contiguous) view helper."""
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+SOFTSYM = np.dtype([("cost", "<i2"), ("symbol", "u1"), ("pad", "u1")])
+
+
+class RxParams(C.Structure):
+    _fields_ = [("sampler", C.c_int), ("ncoeffs", C.c_int), ("coeffs", C.c_void_p),
+                ("subsampling", C.c_int), ("cstln", C.c_int), ("fec", C.c_int),
+                ("omega", c_f), ("freq", c_f), ("pll_adjustment", c_f),
+                ("allow_drift", C.c_int), ("meas_decimation", C.c_ulong), ("kest", c_f)]
+
+
+class RxState(C.Structure):
+    _fields_ = [("mu", c_f), ("phase", c_f), ("freqw", c_f), ("agc_gain", c_f),
+                ("est_insp", c_f), ("est_sp", c_f), ("est_ep", c_f), ("freq_tap", c_f),
+                ("min_freqw", c_f), ("max_freqw", c_f), ("meas_count", C.c_ulong),
+                ("hist", c_f * 12)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "hist"}
+        d["hist"] = list(self.hist)
+        return d
+
+
+def rx_params(sampler=1, coeffs=None, subsampling=1, cstln=1, fec=0, omega=4.0, freq=0.0,
+              pll_adjustment=1.0, allow_drift=0, meas_decimation=1048576, kest=0.01):
+    p = RxParams()
+    p.sampler = sampler
+    if coeffs is not None:
+        coeffs = np.ascontiguousarray(coeffs, dtype=np.float32)
+        p._keep = coeffs
+        p.ncoeffs = len(coeffs)
+        p.coeffs = coeffs.ctypes.data
+    p.subsampling = subsampling
+    p.cstln, p.fec = cstln, fec
+    p.omega, p.freq, p.pll_adjustment = omega, freq, pll_adjustment
+    p.allow_drift, p.meas_decimation, p.kest = allow_drift, meas_decimation, kest
+    return p
+
+
+class CstlnLut(C.Structure):
+    _fields_ = [("nsymbols", C.c_int), ("nrotations", C.c_int),
+                ("symbols", (C.c_int8 * 2) * 256),
+                ("cost", C.c_int16 * 65536), ("symbol", C.c_uint8 * 65536),
+                ("phase_error", C.c_int16 * 65536)]
+
+
+class Oracle:
+    def __init__(self, path=ORACLE_SO):
+        if not os.path.exists(path):
+            build(ref=False)
+        self.lib = L = C.CDLL(path)
+        L.lo_trig16_index.restype = C.c_uint
+        L.lo_trig16_index.argtypes = [c_f]
+        L.lo_cstln_lookup_index.restype = C.c_uint
+        L.lo_cstln_lookup_index.argtypes = [c_f, c_f]
+        L.lo_cstln_lut_init.argtypes = [C.c_void_p, C.c_int, c_f, c_f, c_f]
+        L.lo_make_dvbs2_constellation.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.lo_lowpass.argtypes = [C.c_int, c_f, C.c_void_p, c_f]
+        L.lo_root_raised_cosine.argtypes = [C.c_int, c_f, c_f, C.c_void_p]
+        L.lo_normalize_dcgain.argtypes = [C.c_int, C.c_void_p, c_f]
+        L.lo_normalize_power.argtypes = [C.c_int, C.c_void_p, c_f]
+        L.lo_cconverter_u8.argtypes = [C.c_void_p, c_sz, C.c_void_p]
+        L.lo_scaler.argtypes = [c_f, C.c_void_p, c_sz, C.c_void_p]
+        L.lo_decimator.restype = c_sz
+        L.lo_decimator.argtypes = [C.c_uint, C.c_void_p, c_sz, C.c_void_p, c_sz]
+        L.lo_fir_shift_coeffs.argtypes = [C.c_uint, C.c_void_p, c_f, C.c_void_p]
+        L.lo_fir_filter.restype = c_sz
+        L.lo_fir_filter.argtypes = [C.c_uint, C.c_void_p, C.c_uint, C.c_void_p, c_sz,
+                                    C.c_void_p, c_sz, C.POINTER(c_sz)]
+        L.lo_fir_resampler_shift_coeffs.argtypes = [C.c_uint, C.c_void_p, c_f, C.c_void_p]
+        L.lo_fir_resampler.restype = c_sz
+        L.lo_fir_resampler.argtypes = [C.c_uint, C.c_void_p, C.c_int, C.c_void_p, c_sz,
+                                       C.c_void_p, c_sz, C.POINTER(c_sz)]
+        L.lo_cfft.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.lo_auto_notch_new.restype = C.c_void_p
+        L.lo_auto_notch_new.argtypes = [C.c_int, C.c_int, c_f, c_f]
+        L.lo_auto_notch_free.argtypes = [C.c_void_p]
+        L.lo_auto_notch_run.restype = c_sz
+        L.lo_auto_notch_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p]
+        L.lo_auto_notch_slot_bin.argtypes = [C.c_void_p, C.c_int]
+        L.lo_cnr_fft_new.restype = C.c_void_p
+        L.lo_cnr_fft_new.argtypes = [c_f, C.c_int, C.c_int]
+        L.lo_cnr_fft_free.argtypes = [C.c_void_p]
+        L.lo_cnr_fft_run.restype = c_sz
+        L.lo_cnr_fft_run.argtypes = [C.c_void_p, c_f, c_f, C.c_void_p, c_sz, C.c_void_p, c_sz]
+        L.lo_rx_new.restype = C.c_void_p
+        L.lo_rx_new.argtypes = [C.POINTER(RxParams)]
+        L.lo_rx_free.argtypes = [C.c_void_p]
+        L.lo_rx_run.restype = c_sz
+        L.lo_rx_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p, c_sz, C.POINTER(c_sz),
+                                C.c_void_p, C.c_void_p, C.c_void_p, c_sz, C.POINTER(c_sz),
+                                C.c_void_p, c_sz, C.POINTER(c_sz)]
+        L.lo_rx_get_state.argtypes = [C.c_void_p, C.POINTER(RxState)]
+        L.lo_rx_set_state.argtypes = [C.c_void_p, C.POINTER(RxState)]
+        L.lo_rx_readahead.argtypes = [C.c_void_p]
+
+    # -- tables
+    def trig16(self):
+        out = np.empty(65536, np.complex64)
+        self.lib.lo_trig16(_p(out))
+        return out
+
+    def cstln_lut(self, predef, fec=0):
+        c = CstlnLut()
+        n = self.lib.lo_make_dvbs2_constellation(C.byref(c), predef, fec)
+        assert n > 0
+        return dict(nsymbols=c.nsymbols, nrotations=c.nrotations,
+                    symbols=np.ctypeslib.as_array(c.symbols).reshape(256, 2)[:n].copy(),
+                    cost=np.ctypeslib.as_array(c.cost).copy(),
+                    symbol=np.ctypeslib.as_array(c.symbol).copy(),
+                    phase_error=np.ctypeslib.as_array(c.phase_error).copy())
+
+    def lowpass(self, order, fcut, renormalize=True):
+        out = np.empty(order + 1, np.float32)
+        n = self.lib.lo_lowpass(order, fcut, _p(out), 1.0)
+        if renormalize:
+            self.lib.lo_normalize_dcgain(n, _p(out), 1.0)
+        return out[:n]
+
+    def rrc(self, order, fs, rolloff):
+        out = np.empty(order + 3, np.float32)
+        n = self.lib.lo_root_raised_cosine(order, fs, rolloff, _p(out))
+        return out[:n].copy()
+
+    # -- blocks
+    def cconverter_u8(self, x):
+        x = np.ascontiguousarray(x, np.uint8).reshape(-1, 2)
+        out = np.empty(len(x), np.complex64)
+        self.lib.lo_cconverter_u8(_p(x), len(x), _p(out))
+        return out
+
+    def scaler(self, scale, x):
+        x = cf32(x)
+        out = np.empty_like(x)
+        self.lib.lo_scaler(scale, _p(x), len(x), _p(out))
+        return out
+
+    def fir_shift(self, coeffs, freq):
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        out = np.empty(len(coeffs), np.complex64)
+        self.lib.lo_fir_shift_coeffs(len(coeffs), _p(coeffs), freq, _p(out))
+        return out
+
+    def fir_filter(self, coeffs, decim, x, freq=0.0, shifted=None):
+        x = cf32(x)
+        sc = self.fir_shift(coeffs, freq) if shifted is None else cf32(shifted)
+        cap = max(0, (len(x) - len(sc)) // decim) + 1
+        out = np.empty(cap, np.complex64)
+        consumed = c_sz()
+        n = self.lib.lo_fir_filter(len(sc), _p(sc), decim, _p(x), len(x), _p(out), cap, C.byref(consumed))
+        return out[:n], consumed.value
+
+    def fir_resampler(self, coeffs, interp, x, freq=0.0):
+        x = cf32(x)
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        sc = np.empty(len(coeffs), np.complex64)
+        self.lib.lo_fir_resampler_shift_coeffs(len(coeffs), _p(coeffs), freq, _p(sc))
+        cap = len(x) * interp
+        out = np.empty(cap, np.complex64)
+        consumed = c_sz()
+        n = self.lib.lo_fir_resampler(len(sc), _p(sc), interp, _p(x), len(x), _p(out), cap, C.byref(consumed))
+        return out[:n], consumed.value
+
+    def cfft(self, x, reverse=False):
+        x = cf32(x).copy()
+        self.lib.lo_cfft(len(x), _p(x), int(reverse))
+        return x
+
+    def auto_notch(self, x, nslots=1, decimation=1024 * 4096, k=0.002, setpoint=0.0):
+        x = cf32(x)
+        h = self.lib.lo_auto_notch_new(nslots, decimation, k, setpoint)
+        out = np.empty_like(x)
+        n = self.lib.lo_auto_notch_run(h, _p(x), len(x), _p(out))
+        bins = [self.lib.lo_auto_notch_slot_bin(h, s) for s in range(nslots)]
+        self.lib.lo_auto_notch_free(h)
+        return out[:n], bins
+
+    def cnr_fft(self, x, bandwidth, nfft=4096, decimation=1048576, freq_tap=0.0, tap_multiplier=1.0):
+        x = cf32(x)
+        h = self.lib.lo_cnr_fft_new(bandwidth, nfft, decimation)
+        out = np.empty(len(x) // nfft + 1, np.float32)
+        n = self.lib.lo_cnr_fft_run(h, freq_tap, tap_multiplier, _p(x), len(x), _p(out), len(out))
+        self.lib.lo_cnr_fft_free(h)
+        return out[:n]
+
+    def rx(self, params, x, state_in=None, chunks=None):
+        """Run cstln_receiver over x.  Returns dict(sym, consumed, freq, ss, mer, cstln, state)."""
+        x = cf32(x)
+        h = self.lib.lo_rx_new(C.byref(params))
+        if state_in is not None:
+            self.lib.lo_rx_set_state(h, C.byref(state_in))
+        cap = len(x) + 256
+        out = np.zeros(cap, SOFTSYM)
+        mcap = len(x) // max(1, params.meas_decimation) + 8
+        ccap = len(x) // 128 + 8
+        fr, ss, mer = (np.empty(mcap, np.float32) for _ in range(3))
+        cst = np.empty(ccap, np.complex64)
+        consumed, nm, nc = c_sz(), c_sz(), c_sz()
+        n = self.lib.lo_rx_run(h, _p(x), len(x), _p(out), cap, C.byref(consumed),
+                               _p(fr), _p(ss), _p(mer), mcap, C.byref(nm),
+                               _p(cst), ccap, C.byref(nc))
+        st = RxState()
+        self.lib.lo_rx_get_state(h, C.byref(st))
+        self.lib.lo_rx_free(h)
+        return dict(sym=out[:n], consumed=consumed.value, freq=fr[:nm.value], ss=ss[:nm.value],
+                    mer=mer[:nm.value], cstln=cst[:nc.value], state=st)
+
+
+class Ref:
+    """The real reference, through oracle/ref_harness.cc.  Raises FileNotFoundError
+    when oracle/_ref was not built (no /root/reference on this machine)."""
+
+    def __init__(self, path=REF_SO):
+        if not os.path.exists(path):
+            raise FileNotFoundError(path)
+        self.lib = L = C.CDLL(path)
+        L.ref_trig16_index.restype = C.c_uint
+        L.ref_trig16_index.argtypes = [c_f]
+        L.ref_cstln_lut.argtypes = [C.c_int, c_f, c_f, c_f, C.c_int] + [C.c_void_p] * 5
+        L.ref_cstln_lookup.argtypes = [C.c_int, c_f, c_f, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.ref_make_dvbs2_constellation.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 4
+        L.ref_lowpass.argtypes = [C.c_int, c_f, C.c_int, C.c_void_p]
+        L.ref_root_raised_cosine.argtypes = [C.c_int, c_f, c_f, C.c_void_p]
+        L.ref_cconverter_u8.restype = C.c_long
+        L.ref_cconverter_u8.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        L.ref_scaler.restype = C.c_long
+        L.ref_scaler.argtypes = [c_f, C.c_void_p, C.c_long, C.c_void_p]
+        L.ref_fir_filter.restype = C.c_long
+        L.ref_fir_filter.argtypes = [C.c_int, C.c_void_p, C.c_uint, c_f, C.c_void_p, C.c_long,
+                                     C.c_void_p, C.c_long, C.c_void_p]
+        L.ref_fir_resampler.restype = C.c_long
+        L.ref_fir_resampler.argtypes = [C.c_int, C.c_void_p, C.c_int, c_f, C.c_void_p, C.c_long,
+                                        C.c_void_p, C.c_long]
+        L.ref_auto_notch.restype = C.c_long
+        L.ref_auto_notch.argtypes = [C.c_int, C.c_int, c_f, c_f, C.c_void_p, C.c_long, C.c_void_p, C.c_void_p]
+        L.ref_cfft.argtypes = [C.c_int, C.c_void_p, C.c_int]
+        L.ref_cnr_fft.restype = C.c_long
+        L.ref_cnr_fft.argtypes = [c_f, C.c_int, C.c_int, c_f, c_f, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        L.ref_cstln_receiver.restype = C.c_long
+        L.ref_cstln_receiver.argtypes = [C.POINTER(RxParams), C.c_void_p, C.c_long, C.c_void_p,
+                                         C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_long, C.POINTER(C.c_long),
+                                         C.POINTER(C.c_long), C.POINTER(RxState)]
+
+    def trig16(self):
+        out = np.empty(65536, np.complex64)
+        self.lib.ref_trig16(_p(out))
+        return out
+
+    def cstln_lut(self, predef, fec=0):
+        cost = np.empty(65536, np.int16)
+        sym = np.empty(65536, np.uint8)
+        pe = np.empty(65536, np.int16)
+        symbols = np.zeros((256, 2), np.int8)
+        n = self.lib.ref_make_dvbs2_constellation(predef, fec, _p(cost), _p(sym), _p(pe), _p(symbols))
+        return dict(nsymbols=n, symbols=symbols[:n].copy(), cost=cost, symbol=sym, phase_error=pe)
+
+    def lowpass(self, order, fcut, renormalize=True):
+        out = np.empty(order + 1, np.float32)
+        n = self.lib.ref_lowpass(order, fcut, int(renormalize), _p(out))
+        return out[:n]
+
+    def rrc(self, order, fs, rolloff):
+        out = np.empty(order + 3, np.float32)
+        n = self.lib.ref_root_raised_cosine(order, fs, rolloff, _p(out))
+        return out[:n].copy()
+
+    def cconverter_u8(self, x):
+        x = np.ascontiguousarray(x, np.uint8).reshape(-1, 2)
+        out = np.empty(len(x), np.complex64)
+        n = self.lib.ref_cconverter_u8(_p(x), len(x), _p(out))
+        return out[:n]
+
+    def scaler(self, scale, x):
+        x = cf32(x)
+        out = np.empty_like(x)
+        n = self.lib.ref_scaler(scale, _p(x), len(x), _p(out))
+        return out[:n]
+
+    def fir_filter(self, coeffs, decim, x, freq=0.0):
+        x = cf32(x)
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        cap = max(0, (len(x) - len(coeffs)) // decim) + 1
+        out = np.empty(cap, np.complex64)
+        sc = np.empty(len(coeffs), np.complex64)
+        n = self.lib.ref_fir_filter(len(coeffs), _p(coeffs), decim, freq, _p(x), len(x), _p(out), cap, _p(sc))
+        return out[:n], sc
+
+    def fir_resampler(self, coeffs, interp, x, freq=0.0):
+        x = cf32(x)
+        coeffs = np.ascontiguousarray(coeffs, np.float32)
+        cap = len(x) * interp
+        out = np.empty(cap, np.complex64)
+        n = self.lib.ref_fir_resampler(len(coeffs), _p(coeffs), interp, freq, _p(x), len(x), _p(out), cap)
+        return out[:n]
+
+    def cfft(self, x, reverse=False):
+        x = cf32(x).copy()
+        self.lib.ref_cfft(len(x), _p(x), int(reverse))
+        return x
+
+    def auto_notch(self, x, nslots=1, decimation=1024 * 4096, k=0.002, setpoint=0.0):
+        x = cf32(x)
+        out = np.empty_like(x)
+        bins = np.zeros(max(1, nslots), np.int32)
+        n = self.lib.ref_auto_notch(nslots, decimation, k, setpoint, _p(x), len(x), _p(out), _p(bins))
+        return out[:n], list(bins[:nslots])
+
+    def cnr_fft(self, x, bandwidth, nfft=4096, decimation=1048576, freq_tap=0.0, tap_multiplier=1.0):
+        x = cf32(x)
+        out = np.empty(len(x) // nfft + 1, np.float32)
+        n = self.lib.ref_cnr_fft(bandwidth, nfft, decimation, freq_tap, tap_multiplier, _p(x), len(x), _p(out), len(out))
+        return out[:n]
+
+    def rx(self, params, x):
+        x = cf32(x)
+        cap = len(x) + 256
+        cost = np.empty(cap, np.int16)
+        sym = np.empty(cap, np.uint8)
+        mcap = len(x) // max(1, params.meas_decimation) + 8
+        fr, ss, mer = (np.empty(mcap, np.float32) for _ in range(3))
+        ccap = len(x) // 128 + 8
+        cst = np.empty(ccap, np.complex64)
+        nm, nc = C.c_long(), C.c_long(ccap)
+        st = RxState()
+        n = self.lib.ref_cstln_receiver(C.byref(params), _p(x), len(x), _p(cost), _p(sym), cap,
+                                        _p(fr), _p(ss), _p(mer), _p(cst), mcap, C.byref(nm), C.byref(nc),
+                                        C.byref(st))
+        out = np.zeros(n, SOFTSYM)
+        out["cost"] = cost[:n]
+        out["symbol"] = sym[:n]
+        return dict(sym=out, freq=fr[:nm.value], ss=ss[:nm.value], mer=mer[:nm.value],
+                    cstln=cst[:nc.value], state=st)
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
