@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py — IQ MSamples/s demodulated on BASELINE config 2 (see BASELINE.json).
+
+Workload at N=1 ("configs[1]"): leandvb DVB-S QPSK 1/2, Fs = 240 MS/s cf32 input at
+120 samples/symbol, device-resident synthetic signal:
+    scaler(x75, fused) -> fir_filter(N=313, D=30) -> cstln_receiver(omega=4, linear sampler)
+One step = one pass of that hot path over one batch of `--batch-msamples` Mi input samples
+(the receiver's loop state is carried from step to step, as on an endless stream).
+`value` = input IQ samples consumed per second over all ranks (inputs already in HBM).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N>1: independent captures, one per GPU, no data-path collective -> weak scaling.
+
+Extra JSON objects: `roofline` for the dominant kernel (fir_filter; algorithmic bytes =
+8 B read per input sample + 8/30 B written) timed with HIP events on the
+kernel's own stream, and `cpu_baseline` = the oracle (plain-C port of the reference)
+timed on this host's cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, MI355X_MICROARCH.md
+FS, FM, ROLLOFF, REJ = 240e6, 2e6, 0.35, 10.0
+
+
+def c2_filter(capi):
+    """Filter design of leandvb.cc:353-378 for Fs=240e6, Fm=2e6 -> order 312, decim 30."""
+    decim = int(FS / (FM * 4))
+    transition = (FM / 2) * ROLLOFF
+    order = int(REJ * FS / (22 * transition))
+    order = ((order + 1) // 2) * 2
+    fcut = np.float32((FM / 2) * (1 + ROLLOFF / 2) / FS)
+    return capi.lowpass(order, fcut), decim
+
+
+def cpu_baseline(x, coeffs, decim, budget_s):
+    """The oracle (test infrastructure) as the timed CPU baseline: scaler -> fir_filter ->
+    cstln_receiver over a bounded sample, single thread."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as po
+    O = po.Oracle()
+    p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=1 << 20)
+    n_done, t0 = 0, time.perf_counter()
+    passes = 0
+    while True:
+        xs = O.scaler(75.0, x)
+        y, _ = O.fir_filter(coeffs, decim, xs)
+        O.rx(p, y)
+        n_done += len(x)
+        passes += 1
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=round(n_done / dt / 1e6, 3), unit="MS/s", cores=1, kind="port",
+                sample=f"{passes} pass(es) over {len(x)} samples of the same workload, {dt:.1f} s, "
+                       f"oracle/liblsdr_oracle.so (scaler+fir_filter+cstln_receiver), 1 thread")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per step per GPU")
+    ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, tiled)")
+    ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "serial"))
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        torch.cuda.set_device(local_rank)
+        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = dist_mod
+
+    import leansdr_amd.capi as capi
+    from leansdr_amd import synth
+
+    def barrier():
+        if dist is not None:
+            import torch
+            t = torch.zeros(1, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+
+    ctx = capi.Ctx(local_rank)
+    coeffs, decim = c2_filter(capi)
+    N = len(coeffs)
+
+    # ---- synthetic input, resident in HBM ----------------------------------
+    sps = int(FS / FM)
+    period = (args.period_msamples << 20) // sps * sps
+    reps = max(1, (args.batch_msamples << 20) // period)
+    B = period * reps
+    x, _ = synth.qpsk_baseband(period, sps, seed=1 + rank, rms=1.0, snr_db=20.0)
+    d_in = ctx.alloc(B * 8)
+    d_per = ctx.upload(x)
+    for r in range(reps):
+        capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * period * 8), d_per.ptr, period * 8))
+    ctx.sync()
+    d_per.free()
+    n_out_max = (B - N) // decim
+    d_dec = ctx.alloc(n_out_max * 8)
+    d_sym = ctx.alloc((n_out_max + 256) * 4)
+
+    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
+    rx = capi.CstlnReceiver(ctx, sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM),
+                            meas_decimation=int(FS / decim),
+                            mode=capi.RX_TILED if args.rx_mode == "tiled" else capi.RX_SERIAL)
+
+    e0, e1 = ctx.event(), ctx.event()
+    fir_ms = []
+    nsym = [0]
+
+    def step(timed):
+        if timed:
+            ctx.event_record(e0)
+        cons, prod = fir.run_dev(d_in.ptr, B, d_dec.ptr, n_out_max)
+        if timed:
+            ctx.event_record(e1)
+        o = rx.run_dev(d_dec.ptr, prod, d_sym.ptr, n_out_max + 256, meas=False)
+        if timed:
+            fir_ms.append(ctx.event_elapsed_ms(e0, e1))
+            nsym[0] += o["produced"]
+        return cons
+
+    for _ in range(args.warmup):
+        step(False)
+    ctx.sync()
+    barrier()
+    t0 = time.perf_counter()
+    consumed = 0
+    for _ in range(args.steps):
+        consumed += step(True)
+    ctx.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([float(consumed)], device="cuda", dtype=torch.float64)
+        dist.all_reduce(c)
+        total = float(c.item())
+    else:
+        total = float(consumed)
+
+    if rank == 0:
+        per_launch_samples = (n_out_max * decim)           # input samples one fir launch processes
+        alg_bytes = per_launch_samples * 8 + n_out_max * 8  # cf32 in + cf32 out
+        fir_avg_ms = float(np.mean(fir_ms))
+        achieved = alg_bytes / (fir_avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "IQ MSamples/s demodulated (leandvb QPSK 1/2)",
+            "value": round(total / dt / 1e6, 3),
+            "unit": "MS/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident; "
+                                   "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
+                       "batch_samples_per_gpu": B, "rx_mode": args.rx_mode,
+                       "parallelism": f"{world} independent capture(s), one per GPU, no collectives",
+                       "symbols_per_step": nsym[0] // max(1, args.steps)},
+            "roofline": {"kernel": "k_fir (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": None, "avg_launch_ms": round(fir_avg_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(x, coeffs, decim, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    fir.close(); rx.close()
+    d_in.free(); d_dec.free(); d_sym.free()
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

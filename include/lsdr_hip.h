@@ -1,0 +1,188 @@
+/* include/lsdr_hip.h — C ABI of the MI355X-native leandvb hot path.
+ *
+ * This is the drop-in boundary: the reference has no FFI layer,
+ * a "block" is a C++ `runnable` whose run() moves items between pipebufs
+ * (framework.h:124-131).  The host keeps that scheduler/pipebuf surface
+ * (leansdr_amd/host headers, same class names and constructor signatures) and each
+ * GPU-backed block's run() calls exactly one of the `*_run` entry points below.
+ * Every entry point names the reference interface it replaces.
+ *
+ * Conventions
+ *  - Plain C types only.  No torch / HIP types: a stream is passed as void*.
+ *  - All `in`/`out` data pointers are DEVICE pointers (HBM) unless the name
+ *    ends in `_host`.  lsdr_malloc/lsdr_memcpy_* exist so that a host without
+ *    any HIP binding can own device pipebufs.
+ *  - Every function returns 0 on success, <0 on error (LSDR_E_*); the message
+ *    is available from lsdr_last_error().  The C++ shim maps !=0 to the
+ *    reference's fail() (framework.h:33).  "Not enough input / no room" is not
+ *    an error: *produced == 0, exactly like a reference run() that returns
+ *    without progress (SURVEY §8b "Error convention").
+ *  - One lsdr_ctx = one device + one HIP stream; all calls on a ctx must come
+ *    from one thread (the scheduler thread, README.coding.md:29).
+ *  - Work is enqueued on the ctx stream.  Functions whose outputs have a
+ *    data-dependent size (cstln_receiver, the FEC tail) synchronise before
+ *    returning so that the scheduler's progress hash (framework.h:96-113)
+ *    never sees "no progress" while work is in flight.
+ *  - Item layouts are the reference's: cf32 {float re,im} 8 B,
+ *    cu8 {u8 re,im} 2 B, softsymbol {int16 cost; u8 symbol; u8 pad} 4 B,
+ *    rspacket 204 B, tspacket 188 B.
+ */
+#ifndef LSDR_HIP_H
+#define LSDR_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSDR_ABI_VERSION 1
+
+enum { LSDR_OK = 0, LSDR_E_HIP = -1, LSDR_E_ARG = -2, LSDR_E_NOMEM = -3, LSDR_E_UNSUPPORTED = -4 };
+
+typedef struct { float re, im; } lsdr_cf32;
+typedef struct { uint8_t re, im; } lsdr_cu8;
+typedef struct { int16_t cost; uint8_t symbol; uint8_t pad; } lsdr_softsymbol; /* sdr.h:287-290 */
+
+/* ------------------------------------------------------------------ context */
+typedef struct lsdr_ctx lsdr_ctx;
+int lsdr_abi_version(void);
+const char *lsdr_last_error(void);
+/* stream == NULL: the ctx creates (and owns) a non-blocking HIP stream. */
+int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **ctx);
+void lsdr_ctx_destroy(lsdr_ctx *ctx);
+int lsdr_ctx_sync(lsdr_ctx *ctx);
+void *lsdr_ctx_stream(lsdr_ctx *ctx);
+int lsdr_device_count(void);
+/* Device pipebuf storage (replaces `new T[size]` of pipebuf, framework.h:141-143). */
+int lsdr_malloc(lsdr_ctx *ctx, size_t bytes, void **dev_ptr);
+int lsdr_free(lsdr_ctx *ctx, void *dev_ptr);
+int lsdr_malloc_host(size_t bytes, void **pinned_ptr);   /* pinned staging for file_reader/writer */
+int lsdr_free_host(void *pinned_ptr);
+int lsdr_memcpy_h2d(lsdr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* async on ctx stream */
+int lsdr_memcpy_d2h(lsdr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* async on ctx stream */
+int lsdr_memcpy_d2d(lsdr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* pipebuf::pack() memmove, framework.h:153-159 (overlap-safe) */
+int lsdr_memset(lsdr_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* Stream timing for bench.py (HIP events recorded on the ctx stream). */
+int lsdr_timer_start(lsdr_ctx *ctx);
+int lsdr_timer_stop_ms(lsdr_ctx *ctx, float *ms); /* synchronises on the stop event */
+/* Free-standing HIP events on the ctx stream (per-kernel timing inside a timed region). */
+typedef struct lsdr_event lsdr_event;
+int lsdr_event_create(lsdr_ctx *ctx, lsdr_event **ev);
+void lsdr_event_destroy(lsdr_event *ev);
+int lsdr_event_record(lsdr_event *ev);
+int lsdr_event_elapsed_ms(lsdr_event *start, lsdr_event *stop, float *ms); /* synchronises on `stop` */
+
+/* ----------------------------------------------------- host-side table design
+ * Replaces filtergen.h (coefficients are *inputs* to the kernels and must be
+ * numerically identical to the reference's), math.h trig16 and the
+ * cstln_lut<256> constructor.  Pure host code using the same libm. */
+int lsdr_filtergen_lowpass(int order, float Fcut, float gain, float *coeffs_host);               /* filtergen.h:45-62; returns ncoeffs */
+int lsdr_filtergen_root_raised_cosine(int order, float Fs, float rolloff, float *coeffs_host);   /* filtergen.h:68-92; returns ncoeffs */
+void lsdr_filtergen_normalize_dcgain(int n, float *coeffs_host, float gain);                      /* filtergen.h:34-40 */
+void lsdr_filtergen_normalize_power(int n, float *coeffs_host, float gain);                       /* filtergen.h:26-32 */
+void lsdr_trig16_table(lsdr_cf32 *lut_host /*[65536]*/);                                         /* math.h:95-106 */
+enum { LSDR_BPSK, LSDR_QPSK, LSDR_PSK8, LSDR_APSK16, LSDR_APSK32, LSDR_APSK64E,
+       LSDR_QAM16, LSDR_QAM64, LSDR_QAM256 };                                                    /* sdr.h:318-324 */
+enum { LSDR_FEC12, LSDR_FEC23, LSDR_FEC46, LSDR_FEC34, LSDR_FEC56, LSDR_FEC78,
+       LSDR_FEC45, LSDR_FEC89, LSDR_FEC910 };                                                    /* dvb.h:37-41 */
+/* make_dvbs2_constellation (dvb.h:45-81) + cstln_lut<256> ctor (sdr.h:326-560).
+ * Arrays are indexed [(u8)I*256 + (u8)Q]; symbols is [nsymbols][2] (re,im). */
+int lsdr_cstln_lut_build(int predef, int fec, int16_t *cost_host, uint8_t *symbol_host,
+                         int16_t *phase_error_host, int8_t *symbols_host, int *nrotations); /* returns nsymbols */
+
+/* ------------------------------------------------------ elementwise blocks */
+/* cconverter<u8,128,f32,0,1,1>::run, dsp.h:40-50 */
+int lsdr_cconverter_u8_run(lsdr_ctx *ctx, const lsdr_cu8 *in, size_t n, lsdr_cf32 *out);
+/* scaler<float,cf32,cf32>::run, dsp.h:149-156 */
+int lsdr_scaler_run(lsdr_ctx *ctx, float scale, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out);
+/* decimator<cf32>::run, generic.h:256-262; *produced = min(n/d, cap), consumes produced*d */
+int lsdr_decimator_run(lsdr_ctx *ctx, unsigned d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out,
+                       size_t cap, size_t *produced);
+
+/* -------------------------------------------------------------- fir_filter
+ * fir_filter<cf32,float>, dsp.h:219-285 (decimating FIR, real prototype taps
+ * frequency-shifted to complex).  The optional input stage fuses the block in
+ * front of it in the leandvb graph so that its output never round-trips
+ * through HBM: cconverter (u8 input, leandvb.cc:215) or scaler (f32 input,
+ * leandvb.cc:255-256); results are bit-identical to running the two blocks
+ * separately. */
+enum { LSDR_IN_CF32 = 0, LSDR_IN_CU8 = 1 };
+enum {
+  LSDR_FIR_EXACT = 0, /* reference arithmetic: i-ascending accumulation, no FMA contraction → bit-exact */
+  LSDR_FIR_FMA = 1    /* same order, fused multiply-add (≤ 1 ulp/tap differences; tolerance-tested) */
+};
+typedef struct {
+  unsigned ncoeffs;          /* fir_filter ctor _ncoeffs */
+  const float *coeffs_host;  /* fir_filter ctor _coeffs (host) */
+  unsigned decim;            /* fir_filter ctor _decim */
+  int in_format;             /* LSDR_IN_* */
+  float in_scale;            /* 0 = no fused scaler; else samples are multiplied by it first */
+  int arith;                 /* LSDR_FIR_* */
+} lsdr_fir_filter_cfg;
+typedef struct lsdr_fir_filter lsdr_fir_filter;
+int lsdr_fir_filter_create(lsdr_ctx *ctx, const lsdr_fir_filter_cfg *cfg, lsdr_fir_filter **f);
+void lsdr_fir_filter_destroy(lsdr_fir_filter *f);
+/* set_freq(f), dsp.h:271-280 (host libm cosf/sinf, then upload). */
+int lsdr_fir_filter_set_freq(lsdr_fir_filter *f, float freq);
+/* The freq_tap prologue of run(), dsp.h:236-244: new=tap*mult; if |current-new|>tol → set_freq(new).
+ * *shifted (may be NULL) reports whether a re-shift happened. */
+int lsdr_fir_filter_track(lsdr_fir_filter *f, float freq_tap, float tap_multiplier, float freq_tol, int *shifted);
+float lsdr_fir_filter_current_freq(const lsdr_fir_filter *f);
+int lsdr_fir_filter_get_shifted_coeffs(const lsdr_fir_filter *f, lsdr_cf32 *shifted_host);
+/* run() body, dsp.h:233-262.  in: n_in items of in_format.  Needs n_in >= ncoeffs;
+ * *produced = min((n_in-ncoeffs)/decim, cap_out); *consumed = *produced*decim.
+ * Output m = Σ_i sc[i]·in[ncoeffs + m·decim − i].  Asynchronous on the ctx stream. */
+int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
+                        size_t *consumed, size_t *produced);
+
+/* ---------------------------------------------------------- cstln_receiver
+ * cstln_receiver<f32> + sampler_interface<f32>, sdr.h:589-938. */
+enum { LSDR_SAMP_NEAREST = 0, LSDR_SAMP_LINEAR = 1, LSDR_SAMP_FIR = 2 }; /* sdr.h:600-689 */
+enum {
+  LSDR_RX_SERIAL = 0, /* one sequential pass, the reference's exact arithmetic → bit-exact soft symbols */
+  LSDR_RX_TILED = 1   /* time-tiled with warm-up overlap (throughput mode; tolerance-tested) */
+};
+typedef struct {
+  int sampler;               /* LSDR_SAMP_* */
+  int ncoeffs;               /* fir_sampler(_ncoeffs,_coeffs,_subsampling), sdr.h:637-643 */
+  const float *coeffs_host;
+  int subsampling;
+  int cstln, fec;            /* demod.cstln = make_dvbs2_constellation(cstln, fec), leandvb.cc:476 */
+  int harden;                /* cstln->harden(), leandvb.cc:477-481 */
+  float omega;               /* set_omega(Fs/Fm), leandvb.cc:482 */
+  float freq;                /* set_freq(Ftune/Fs), leandvb.cc:483-487 (0: untouched) */
+  float pll_adjustment;      /* public member; /=6 with --viterbi, leandvb.cc:498-501 */
+  int allow_drift;           /* set_allow_drift() */
+  unsigned long meas_decimation; /* public member, leandvb.cc:502 */
+  float kest;                /* public member, default 0.01 */
+  int mode;                  /* LSDR_RX_* */
+  unsigned tile_len;         /* LSDR_RX_TILED: samples per tile (multiple of 128); 0 = default */
+  unsigned tile_warmup;      /* LSDR_RX_TILED: warm-up samples before each tile (multiple of 128); 0 = default */
+} lsdr_rx_cfg;
+typedef struct {             /* the receiver's loop state, sdr.h:923-935 */
+  float mu, phase, freqw, agc_gain, est_insp, est_sp, est_ep, freq_tap;
+  float min_freqw, max_freqw;
+  unsigned long meas_count;
+  float hist[12];            /* hist[k] = {p.re,p.im,c.re,c.im}, k = 0..2 */
+} lsdr_rx_state;
+typedef struct lsdr_rx lsdr_rx;
+int lsdr_rx_create(lsdr_ctx *ctx, const lsdr_rx_cfg *cfg, lsdr_rx **r);
+void lsdr_rx_destroy(lsdr_rx *r);
+int lsdr_rx_readahead(const lsdr_rx *r);                 /* sampler->readahead() */
+int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st);    /* includes freq_tap (sdr.h:918-921) */
+int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st);
+/* run(), sdr.h:772-916, over one buffer: consumes whole chunks of 128 samples while
+ * n_in-pos >= 128+readahead and cap_out-produced >= 128 (and the measurement
+ * outputs have room).  freq/ss/mer (meas_cap floats each, HOST pointers, may be
+ * NULL) receive one value per meas_decimation samples; cstln_out_host (may be
+ * NULL) one cf32 per chunk that produced a symbol.  Synchronous. */
+int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                size_t *consumed, size_t *produced,
+                float *freq_out_host, float *ss_out_host, float *mer_out_host, size_t meas_cap, size_t *n_meas,
+                lsdr_cf32 *cstln_out_host, size_t cstln_cap, size_t *n_cstln);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LSDR_HIP_H */

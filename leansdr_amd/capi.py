@@ -1,0 +1,377 @@
+"""ctypes driver for liblsdr_hip.so (include/lsdr_hip.h).  No CPU fallback."""
+import ctypes as C
+import os
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblsdr_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C leansdr_amd/csrc`). leansdr_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH)
+
+c_f, c_sz, vp = C.c_float, C.c_size_t, C.c_void_p
+psz = C.POINTER(c_sz)
+
+SOFTSYM = np.dtype([("cost", "<i2"), ("symbol", "u1"), ("pad", "u1")])
+
+(BPSK, QPSK, PSK8, APSK16, APSK32, APSK64E, QAM16, QAM64, QAM256) = range(9)
+(FEC12, FEC23, FEC46, FEC34, FEC56, FEC78, FEC45, FEC89, FEC910) = range(9)
+IN_CF32, IN_CU8 = 0, 1
+FIR_EXACT, FIR_FMA = 0, 1
+SAMP_NEAREST, SAMP_LINEAR, SAMP_FIR = 0, 1, 2
+RX_SERIAL, RX_TILED = 0, 1
+
+
+class LsdrError(RuntimeError):
+    pass
+
+
+class FirCfg(C.Structure):
+    _fields_ = [("ncoeffs", C.c_uint), ("coeffs_host", vp), ("decim", C.c_uint),
+                ("in_format", C.c_int), ("in_scale", c_f), ("arith", C.c_int)]
+
+
+class RxCfg(C.Structure):
+    _fields_ = [("sampler", C.c_int), ("ncoeffs", C.c_int), ("coeffs_host", vp), ("subsampling", C.c_int),
+                ("cstln", C.c_int), ("fec", C.c_int), ("harden", C.c_int), ("omega", c_f), ("freq", c_f),
+                ("pll_adjustment", c_f), ("allow_drift", C.c_int), ("meas_decimation", C.c_ulong),
+                ("kest", c_f), ("mode", C.c_int), ("tile_len", C.c_uint), ("tile_warmup", C.c_uint)]
+
+
+class RxState(C.Structure):
+    _fields_ = [("mu", c_f), ("phase", c_f), ("freqw", c_f), ("agc_gain", c_f), ("est_insp", c_f),
+                ("est_sp", c_f), ("est_ep", c_f), ("freq_tap", c_f), ("min_freqw", c_f), ("max_freqw", c_f),
+                ("meas_count", C.c_ulong), ("hist", c_f * 12)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_ if k != "hist"}
+        d["hist"] = list(self.hist)
+        return d
+
+
+def _sig(name, restype, argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = argtypes
+    return fn
+
+
+_sig("lsdr_abi_version", C.c_int, [])
+_sig("lsdr_last_error", C.c_char_p, [])
+_sig("lsdr_device_count", C.c_int, [])
+_sig("lsdr_ctx_create", C.c_int, [C.c_int, vp, C.POINTER(vp)])
+_sig("lsdr_ctx_destroy", None, [vp])
+_sig("lsdr_ctx_sync", C.c_int, [vp])
+_sig("lsdr_ctx_stream", vp, [vp])
+_sig("lsdr_malloc", C.c_int, [vp, c_sz, C.POINTER(vp)])
+_sig("lsdr_free", C.c_int, [vp, vp])
+_sig("lsdr_malloc_host", C.c_int, [c_sz, C.POINTER(vp)])
+_sig("lsdr_free_host", C.c_int, [vp])
+_sig("lsdr_memcpy_h2d", C.c_int, [vp, vp, vp, c_sz])
+_sig("lsdr_memcpy_d2h", C.c_int, [vp, vp, vp, c_sz])
+_sig("lsdr_memcpy_d2d", C.c_int, [vp, vp, vp, c_sz])
+_sig("lsdr_memset", C.c_int, [vp, vp, C.c_int, c_sz])
+_sig("lsdr_timer_start", C.c_int, [vp])
+_sig("lsdr_timer_stop_ms", C.c_int, [vp, C.POINTER(c_f)])
+_sig("lsdr_event_create", C.c_int, [vp, C.POINTER(vp)])
+_sig("lsdr_event_destroy", None, [vp])
+_sig("lsdr_event_record", C.c_int, [vp])
+_sig("lsdr_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(c_f)])
+_sig("lsdr_filtergen_lowpass", C.c_int, [C.c_int, c_f, c_f, vp])
+_sig("lsdr_filtergen_root_raised_cosine", C.c_int, [C.c_int, c_f, c_f, vp])
+_sig("lsdr_filtergen_normalize_dcgain", None, [C.c_int, vp, c_f])
+_sig("lsdr_filtergen_normalize_power", None, [C.c_int, vp, c_f])
+_sig("lsdr_trig16_table", None, [vp])
+_sig("lsdr_cstln_lut_build", C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, C.POINTER(C.c_int)])
+_sig("lsdr_cconverter_u8_run", C.c_int, [vp, vp, c_sz, vp])
+_sig("lsdr_scaler_run", C.c_int, [vp, c_f, vp, c_sz, vp])
+_sig("lsdr_decimator_run", C.c_int, [vp, C.c_uint, vp, c_sz, vp, c_sz, psz])
+_sig("lsdr_fir_filter_create", C.c_int, [vp, C.POINTER(FirCfg), C.POINTER(vp)])
+_sig("lsdr_fir_filter_destroy", None, [vp])
+_sig("lsdr_fir_filter_set_freq", C.c_int, [vp, c_f])
+_sig("lsdr_fir_filter_track", C.c_int, [vp, c_f, c_f, c_f, C.POINTER(C.c_int)])
+_sig("lsdr_fir_filter_current_freq", c_f, [vp])
+_sig("lsdr_fir_filter_get_shifted_coeffs", C.c_int, [vp, vp])
+_sig("lsdr_fir_filter_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_rx_create", C.c_int, [vp, C.POINTER(RxCfg), C.POINTER(vp)])
+_sig("lsdr_rx_destroy", None, [vp])
+_sig("lsdr_rx_readahead", C.c_int, [vp])
+_sig("lsdr_rx_get_state", C.c_int, [vp, C.POINTER(RxState)])
+_sig("lsdr_rx_set_state", C.c_int, [vp, C.POINTER(RxState)])
+_sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
+
+#: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [n for n in dir(lib) if n.startswith("lsdr_")]
+
+
+def check(rc):
+    if rc != 0:
+        raise LsdrError(f"lsdr error {rc}: {lib.lsdr_last_error().decode()}")
+
+
+def _np(a):
+    return a.ctypes.data_as(vp)
+
+
+# ---- host-side table design (no GPU needed) --------------------------------
+def lowpass(order, fcut, renormalize=True):
+    """filtergen::lowpass (+ the extra normalize_dcgain of leandvb.cc:377-378)."""
+    out = np.empty(order + 1, np.float32)
+    n = lib.lsdr_filtergen_lowpass(order, fcut, 1.0, _np(out))
+    if renormalize:
+        lib.lsdr_filtergen_normalize_dcgain(n, _np(out), 1.0)
+    return out[:n]
+
+
+def root_raised_cosine(order, fs, rolloff):
+    out = np.empty(order + 3, np.float32)
+    n = lib.lsdr_filtergen_root_raised_cosine(order, fs, rolloff, _np(out))
+    return out[:n].copy()
+
+
+def trig16():
+    out = np.empty(65536, np.complex64)
+    lib.lsdr_trig16_table(_np(out))
+    return out
+
+
+def cstln_lut(predef, fec=0):
+    cost = np.empty(65536, np.int16)
+    sym = np.empty(65536, np.uint8)
+    pe = np.empty(65536, np.int16)
+    symbols = np.zeros((256, 2), np.int8)
+    nrot = C.c_int()
+    n = lib.lsdr_cstln_lut_build(predef, fec, _np(cost), _np(sym), _np(pe), _np(symbols), C.byref(nrot))
+    if n < 0:
+        check(n)
+    return dict(nsymbols=n, nrotations=nrot.value, symbols=symbols[:n].copy(), cost=cost, symbol=sym,
+                phase_error=pe)
+
+
+# ---- device side ------------------------------------------------------------
+class DevBuf:
+    """A device allocation (what a device-resident pipebuf owns)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p = vp()
+        check(lib.lsdr_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            check(lib.lsdr_free(self.ctx.h, self.ptr))
+            self.ptr = None
+
+    def at(self, byte_offset):
+        return vp(self.ptr + int(byte_offset))
+
+
+class Ctx:
+    def __init__(self, device=0, stream=None):
+        h = vp()
+        check(lib.lsdr_ctx_create(device, stream, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_ctx_destroy(self.h)
+            self.h = None
+
+    def sync(self):
+        check(lib.lsdr_ctx_sync(self.h))
+
+    def alloc(self, nbytes):
+        return DevBuf(self, nbytes)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        b = DevBuf(self, max(arr.nbytes, 1))
+        check(lib.lsdr_memcpy_h2d(self.h, b.ptr, _np(arr), arr.nbytes))
+        self.sync()
+        return b
+
+    def download(self, buf, dtype, count, byte_offset=0):
+        out = np.empty(count, dtype)
+        check(lib.lsdr_memcpy_d2h(self.h, _np(out), buf.at(byte_offset), out.nbytes))
+        self.sync()
+        return out
+
+    def event(self):
+        e = vp()
+        check(lib.lsdr_event_create(self.h, C.byref(e)))
+        return e
+
+    @staticmethod
+    def event_record(e):
+        check(lib.lsdr_event_record(e))
+
+    @staticmethod
+    def event_elapsed_ms(a, b):
+        ms = c_f()
+        check(lib.lsdr_event_elapsed_ms(a, b, C.byref(ms)))
+        return ms.value
+
+    def timer_start(self):
+        check(lib.lsdr_timer_start(self.h))
+
+    def timer_stop_ms(self):
+        ms = c_f()
+        check(lib.lsdr_timer_stop_ms(self.h, C.byref(ms)))
+        return ms.value
+
+    # elementwise blocks on numpy arrays (test convenience)
+    def cconverter_u8(self, u8):
+        u8 = np.ascontiguousarray(u8, np.uint8).reshape(-1, 2)
+        din = self.upload(u8)
+        dout = self.alloc(len(u8) * 8)
+        check(lib.lsdr_cconverter_u8_run(self.h, din.ptr, len(u8), dout.ptr))
+        out = self.download(dout, np.complex64, len(u8))
+        din.free(); dout.free()
+        return out
+
+    def scaler(self, scale, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.upload(x)
+        dout = self.alloc(x.nbytes)
+        check(lib.lsdr_scaler_run(self.h, scale, din.ptr, len(x), dout.ptr))
+        out = self.download(dout, np.complex64, len(x))
+        din.free(); dout.free()
+        return out
+
+    def decimator(self, d, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.upload(x)
+        dout = self.alloc(x.nbytes)
+        prod = c_sz()
+        check(lib.lsdr_decimator_run(self.h, d, din.ptr, len(x), dout.ptr, len(x), C.byref(prod)))
+        out = self.download(dout, np.complex64, prod.value)
+        din.free(); dout.free()
+        return out
+
+
+class FirFilter:
+    """fir_filter<cf32,float> (dsp.h:219-285) on the GPU."""
+
+    def __init__(self, ctx, coeffs, decim=1, in_format=IN_CF32, in_scale=0.0, arith=FIR_EXACT):
+        self.ctx = ctx
+        self.coeffs = np.ascontiguousarray(coeffs, np.float32)
+        self.decim = decim
+        self.in_format = in_format
+        cfg = FirCfg(len(self.coeffs), self.coeffs.ctypes.data, decim, in_format, in_scale, arith)
+        h = vp()
+        check(lib.lsdr_fir_filter_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_fir_filter_destroy(self.h)
+            self.h = None
+
+    def set_freq(self, f):
+        check(lib.lsdr_fir_filter_set_freq(self.h, f))
+
+    def track(self, freq_tap, tap_multiplier, freq_tol):
+        s = C.c_int()
+        check(lib.lsdr_fir_filter_track(self.h, freq_tap, tap_multiplier, freq_tol, C.byref(s)))
+        return bool(s.value)
+
+    @property
+    def current_freq(self):
+        return lib.lsdr_fir_filter_current_freq(self.h)
+
+    def shifted_coeffs(self):
+        out = np.empty(len(self.coeffs), np.complex64)
+        check(lib.lsdr_fir_filter_get_shifted_coeffs(self.h, _np(out)))
+        return out
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap_out):
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_fir_filter_run(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run(self, x):
+        """numpy in → (numpy out, consumed)."""
+        if self.in_format == IN_CU8:
+            x = np.ascontiguousarray(x, np.uint8).reshape(-1, 2)
+        else:
+            x = np.ascontiguousarray(x, np.complex64)
+        n = len(x)
+        cap = max(0, (n - len(self.coeffs)) // self.decim) + 1
+        din = self.ctx.upload(x)
+        dout = self.ctx.alloc(cap * 8)
+        cons, prod = self.run_dev(din.ptr, n, dout.ptr, cap)
+        out = self.ctx.download(dout, np.complex64, prod)
+        din.free(); dout.free()
+        return out, cons
+
+
+class CstlnReceiver:
+    """cstln_receiver<f32> (sdr.h:697-938) on the GPU."""
+
+    def __init__(self, ctx, sampler=SAMP_LINEAR, coeffs=None, subsampling=1, cstln=QPSK, fec=FEC12, harden=0,
+                 omega=4.0, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=1048576, kest=0.01,
+                 mode=RX_SERIAL, tile_len=0, tile_warmup=0):
+        self.ctx = ctx
+        cfg = RxCfg()
+        cfg.sampler = sampler
+        if coeffs is not None:
+            self.coeffs = np.ascontiguousarray(coeffs, np.float32)
+            cfg.ncoeffs = len(self.coeffs)
+            cfg.coeffs_host = self.coeffs.ctypes.data
+        cfg.subsampling = subsampling
+        cfg.cstln, cfg.fec, cfg.harden = cstln, fec, harden
+        cfg.omega, cfg.freq, cfg.pll_adjustment = omega, freq, pll_adjustment
+        cfg.allow_drift, cfg.meas_decimation, cfg.kest = allow_drift, meas_decimation, kest
+        cfg.mode, cfg.tile_len, cfg.tile_warmup = mode, tile_len, tile_warmup
+        self.cfg = cfg
+        h = vp()
+        check(lib.lsdr_rx_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_rx_destroy(self.h)
+            self.h = None
+
+    @property
+    def readahead(self):
+        return lib.lsdr_rx_readahead(self.h)
+
+    def state(self):
+        st = RxState()
+        check(lib.lsdr_rx_get_state(self.h, C.byref(st)))
+        return st
+
+    def set_state(self, st):
+        check(lib.lsdr_rx_set_state(self.h, C.byref(st)))
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap_out, meas=True):
+        cons, prod, nm, nc = c_sz(), c_sz(), c_sz(), c_sz()
+        if meas:
+            mcap = n_in // max(1, self.cfg.meas_decimation) + 8
+            ccap = n_in // 128 + 8
+            fr, ss, mer = (np.empty(mcap, np.float32) for _ in range(3))
+            cst = np.empty(ccap, np.complex64)
+            check(lib.lsdr_rx_run(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons), C.byref(prod),
+                                  _np(fr), _np(ss), _np(mer), mcap, C.byref(nm), _np(cst), ccap, C.byref(nc)))
+            return dict(consumed=cons.value, produced=prod.value, freq=fr[:nm.value], ss=ss[:nm.value],
+                        mer=mer[:nm.value], cstln=cst[:nc.value])
+        check(lib.lsdr_rx_run(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons), C.byref(prod),
+                              None, None, None, 0, None, None, 0, None))
+        return dict(consumed=cons.value, produced=prod.value)
+
+    def run(self, x, meas=True):
+        x = np.ascontiguousarray(x, np.complex64)
+        cap = len(x) + 256
+        din = self.ctx.upload(x)
+        dout = self.ctx.alloc(cap * 4)
+        r = self.run_dev(din.ptr, len(x), dout.ptr, cap, meas)
+        r["sym"] = self.ctx.download(dout, SOFTSYM, r["produced"])
+        r["state"] = self.state()
+        din.free(); dout.free()
+        return r

@@ -1,0 +1,547 @@
+// leansdr_amd/csrc/cstln_receiver.hip — symbol timing + carrier recovery + slicer.
+//
+// Replaces cstln_receiver<f32>::run and the three sampler_interface<f32>
+// implementations (sdr.h:589-938).  The loop is a per-symbol decision-feedback
+// recurrence (PLL + Mueller&Müller timing + AGC): strictly sequential inside
+// one stream.  Two execution modes share one device routine
+// (rx_chunk, the body of the reference's 128-sample chunk):
+//
+//  LSDR_RX_SERIAL  one wavefront; lane 0 runs the recurrence with the
+//                  reference's exact float operation order (this file is
+//                  compiled -ffp-contract=off), the other 63 lanes stage the
+//                  next chunk of samples into LDS with coalesced loads.
+//                  Bit-exact soft symbols and loop state → parity anchor.
+//  LSDR_RX_TILED   the stream is cut into tiles of `tile_len` samples; one lane
+//                  per tile starts `tile_warmup` samples early from the
+//                  current tracking state (freqw, AGC) with mu=phase=0, lets the
+//                  loops converge, then emits its tile.  Seams are reconciled
+//                  afterwards (quadrant of the carrier phase, symbol count) and
+//                  the tiles are compacted.  Throughput mode: soft symbols agree
+//                  with the serial result within the tolerance stated in
+//                  tests/test_rx_tiled.py; see DESIGN.md §receiver.
+//
+// Look-up tables (trig16 512 KiB, constellation 512 KiB packed) are built on the
+// host with the reference's libm calls (host_tables.cpp) and live in HBM; the hot
+// region of both is L2-resident.  The constellation entry is packed to 8 bytes
+// {cost, symbol, 0, phase_error, point.re, point.im} so one gather serves the
+// slicer, the PLL and the timing detector.
+#include <cmath>
+#include "lsdr_internal.h"
+
+namespace {
+
+constexpr int kChunk = 128;   // cstln_receiver::chunk_size, sdr.h:706
+constexpr float kCstlnAmp = 75.0f;  // sdr.h:297
+
+struct __attribute__((aligned(8))) lut_entry {
+  int16_t cost;
+  uint8_t symbol;
+  uint8_t zero;
+  int16_t phase_error;
+  int8_t pt_re, pt_im;
+};
+
+struct rx_state_dev {            // sdr.h:923-935 + sampler state
+  float mu, phase, freqw, agc_gain, est_insp, est_sp, est_ep;
+  float min_freqw, max_freqw;
+  float samp_freqw;              // linear_sampler::freqw (sdr.h:625)
+  int update_freq_phase;         // fir_sampler::update_freq_phase (sdr.h:688)
+  unsigned long long meas_count;
+  float hist[12];
+};
+
+struct rx_meas { float freqw, est_insp, est_sp, est_ep; };
+
+struct rx_consts {
+  float omega, freq_alpha, freq_beta, gain_mu, kest;
+  int allow_drift, nsymbols;
+  unsigned long long meas_decimation;
+  // fir sampler
+  int ncoeffs, subsampling;
+};
+
+struct rx_tables {
+  const float2 *trig;            // [65536]
+  const lut_entry *lut;          // [65536]
+  const float *coeffs;           // fir sampler prototype
+  float2 *shifted;               // fir sampler shifted coefficients
+};
+
+// trig16::expi(float), math.h:108-110
+__device__ __forceinline__ unsigned trig_index(float a) { return (unsigned)(uint16_t)(int16_t)(int32_t)a; }
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {  // math.h:40-43
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// cstln_lut<256>::lookup(float,float), sdr.h:470-482
+__device__ __forceinline__ unsigned lut_index(float I, float Q) {
+  while (I < -128.f || I > 127.f || Q < -128.f || Q > 127.f) {
+    I *= 0.5f;
+    Q *= 0.5f;
+  }
+  return ((unsigned)(int)I & 255u) * 256u + ((unsigned)(int)Q & 255u);
+}
+
+// fmodf(x, 65536): exact (scaling by 2^16 and truncation are exact, the final
+// subtraction is exact because the true remainder is representable).
+__device__ __forceinline__ float fmod65536(float x) {
+  float q = __builtin_truncf(x * (1.0f / 65536.0f));
+  return x - q * 65536.0f;
+}
+
+// sampler_interface::interp — SAMP: 0 nearest (sdr.h:602-604), 1 linear
+// (sdr.h:614-623), 2 fir (sdr.h:646-665).
+template <int SAMP, typename SamplePtr>
+__device__ __forceinline__ float2 interp(const rx_tables &T, const rx_consts &C, const rx_state_dev &s,
+                                         SamplePtr pin, float mu, float phase) {
+  if (SAMP == 0) return cmul(pin[0], T.trig[trig_index(-phase)]);
+  if (SAMP == 1) {
+    float2 s0 = cmul(pin[0], T.trig[trig_index(-phase)]);
+    float2 s1 = cmul(pin[1], T.trig[trig_index(-(phase + s.samp_freqw))]);
+    float k0 = 1 - mu;
+    return make_float2(s0.x * k0 + s1.x * mu, s0.y * k0 + s1.y * mu);
+  }
+  float2 acc = make_float2(0.f, 0.f);
+  const int S = C.subsampling, N = C.ncoeffs;
+  int k = 0;
+  for (int pc = (int)((1 - mu) * S); pc < N; pc += S, ++k) {
+    float2 t = cmul(T.shifted[pc], pin[k]);
+    acc.x += t.x;
+    acc.y += t.y;
+  }
+  return cmul(T.trig[trig_index(-phase)], acc);
+}
+
+// One 128-sample chunk of cstln_receiver::run (sdr.h:790-913), run by ONE lane.
+// Emits symbols through `emit(softsymbol)`; returns the number emitted.
+// last_s / last_sg / had_symbol feed the per-chunk estimators.
+template <int SAMP, typename SamplePtr, typename Emit>
+__device__ __forceinline__ int rx_chunk(const rx_tables &T, const rx_consts &C, rx_state_dev &s, SamplePtr pin,
+                                        Emit emit, float2 *cstln_out_slot, bool *wrote_cstln) {
+  float mu = s.mu, phase = s.phase, freqw = s.freqw;
+  const float agc_gain = s.agc_gain;
+  float2 sg = make_float2(0.f, 0.f), sv = make_float2(0.f, 0.f);
+  int pt_re = 0, pt_im = 0;
+  bool had = false;
+  int nsym = 0;
+  float h0pr = s.hist[0], h0pi = s.hist[1], h0cr = s.hist[2], h0ci = s.hist[3];
+  float h1pr = s.hist[4], h1pi = s.hist[5], h1cr = s.hist[6], h1ci = s.hist[7];
+  float h2pr = s.hist[8], h2pi = s.hist[9], h2cr = s.hist[10], h2ci = s.hist[11];
+
+  for (int n = 0; n < kChunk; ++n) {
+    if (mu < 1) {
+      sg = interp<SAMP>(T, C, s, pin + n, mu, phase);
+      sv = make_float2(sg.x * agc_gain, sg.y * agc_gain);
+      const lut_entry e = T.lut[lut_index(sv.x, sv.y)];
+      lsdr_softsymbol ss;
+      ss.cost = e.cost; ss.symbol = e.symbol; ss.pad = 0;
+      emit(ss);
+      ++nsym;
+      // PLL, sdr.h:814-815
+      phase += e.phase_error * C.freq_alpha;
+      freqw += e.phase_error * C.freq_beta;
+      // Modified Mueller & Müller, sdr.h:822-840
+      h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;
+      h1pr = h0pr; h1pi = h0pi; h1cr = h0cr; h1ci = h0ci;
+      h0pr = sv.x; h0pi = sv.y;
+      pt_re = e.pt_re; pt_im = e.pt_im;
+      had = true;
+      h0cr = (float)pt_re; h0ci = (float)pt_im;
+      float muerr = ((h0pr - h2pr) * h1cr + (h0pi - h2pi) * h1ci) -
+                    ((h0cr - h2cr) * h1pr + (h0ci - h2ci) * h1pi);
+      float mucorr = muerr * C.gain_mu;
+      const float max_mucorr = 0.1f;
+      if (mucorr < -max_mucorr) mucorr = -max_mucorr;
+      if (mucorr > max_mucorr) mucorr = max_mucorr;
+      mu += mucorr;
+      mu += C.omega;
+    }
+    mu = mu - 1;
+    phase += freqw;
+  }
+  phase = fmod65536(phase);  // sdr.h:855
+
+  float est_insp = s.est_insp, est_sp = s.est_sp, est_ep = s.est_ep, agc = s.agc_gain;
+  if (had) {
+    if (cstln_out_slot) { *cstln_out_slot = sv; }
+    *wrote_cstln = true;
+    float insp = sg.x * sg.x + sg.y * sg.y;          // sdr.h:867-870
+    est_insp = insp * C.kest + est_insp * (1 - C.kest);
+    if (est_insp) agc = kCstlnAmp / __builtin_sqrtf(est_insp);
+    float evr = sv.x - pt_re, evi = sv.y - pt_im;     // sdr.h:873-889
+    float sig_power, ev_power;
+    if (C.nsymbols == 2) {
+      float sig_real = (float)((double)(pt_re + pt_im) * 0.707);
+      float ev_real = (float)((double)(evr + evi) * 0.707);
+      sig_power = sig_real * sig_real;
+      ev_power = ev_real * ev_real;
+    } else {
+      sig_power = (float)(pt_re * pt_re + pt_im * pt_im);
+      ev_power = evr * evr + evi * evi;
+    }
+    est_sp = sig_power * C.kest + est_sp * (1 - C.kest);
+    est_ep = ev_power * C.kest + est_ep * (1 - C.kest);
+  } else {
+    *wrote_cstln = false;
+  }
+  if (!C.allow_drift) {                                // sdr.h:895-898
+    if (freqw < s.min_freqw || freqw > s.max_freqw) freqw = (s.max_freqw + s.min_freqw) / 2;
+  }
+  s.mu = mu; s.phase = phase; s.freqw = freqw;
+  s.est_insp = est_insp; s.est_sp = est_sp; s.est_ep = est_ep; s.agc_gain = agc;
+  s.hist[0] = h0pr; s.hist[1] = h0pi; s.hist[2] = h0cr; s.hist[3] = h0ci;
+  s.hist[4] = h1pr; s.hist[5] = h1pi; s.hist[6] = h1cr; s.hist[7] = h1ci;
+  s.hist[8] = h2pr; s.hist[9] = h2pi; s.hist[10] = h2cr; s.hist[11] = h2ci;
+  return nsym;
+}
+
+struct rx_serial_args {
+  const float2 *in;
+  unsigned long long n_in;
+  lsdr_softsymbol *out;
+  unsigned long long cap_out;
+  rx_state_dev *state;
+  rx_meas *meas; unsigned long long meas_cap;
+  float2 *cstln; unsigned long long cstln_cap;
+  unsigned long long *counters;   // [0] consumed, [1] produced, [2] n_meas, [3] n_cstln
+  rx_consts C;
+  rx_tables T;
+  int readahead;
+};
+
+// One wavefront.  Lane 0 = the recurrence; all lanes = staging + coefficient refresh.
+template <int SAMP>
+__global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2 *buf = reinterpret_cast<float2 *>(smem_raw);     // [kChunk + readahead]
+  __shared__ rx_state_dev st;
+  __shared__ unsigned long long sh_nout, sh_nm, sh_nc;
+  const int lane = threadIdx.x;
+  if (lane == 0) { st = *a.state; sh_nout = 0; sh_nm = 0; sh_nc = 0; }
+  __syncthreads();
+
+  const unsigned long long max_meas = kChunk / a.C.meas_decimation + 1;
+  const int span = kChunk + a.readahead;
+  unsigned long long pos = 0;
+  while (true) {
+    // loop condition of sdr.h:783-788 (uniform: shared counters)
+    if (a.n_in - pos < (unsigned long long)span || a.n_in < pos) break;
+    if (a.cap_out - sh_nout < kChunk) break;
+    if (a.meas_cap - sh_nm < max_meas) break;
+    if (a.cstln_cap - sh_nc < max_meas) break;
+
+    for (int k = lane; k < span; k += 64) buf[k] = a.in[pos + k];
+
+    // sampler->update_freq(freqw), sdr.h:790
+    if (SAMP == 1) {
+      if (lane == 0) st.samp_freqw = st.freqw;
+    } else if (SAMP == 2) {
+      // fir_sampler::update_freq (sdr.h:667-674); do_update_freq (sdr.h:676-680)
+      // is a per-tap map, spread over the wave.
+      int ph = st.update_freq_phase - 128;
+      __syncthreads();
+      if (ph <= 0) {
+        float f = st.freqw / a.C.subsampling;
+        const int N = a.C.ncoeffs;
+        for (int i = lane; i < N; i += 64) {
+          float2 e = a.T.trig[trig_index(-f * (i - N / 2))];
+          float c = a.T.coeffs[i];
+          a.T.shifted[i] = make_float2(e.x * c, e.y * c);
+        }
+        ph = N * 16;
+        __threadfence_block();
+      }
+      if (lane == 0) st.update_freq_phase = ph;
+    }
+    __syncthreads();
+
+    if (lane == 0) {
+      lsdr_softsymbol *po = a.out + sh_nout;
+      int cnt = 0;
+      bool wrote = false;
+      int n = rx_chunk<SAMP>(a.T, a.C, st, (const float2 *)buf,
+                             [&](lsdr_softsymbol ss) { po[cnt++] = ss; },
+                             a.cstln ? a.cstln + sh_nc : nullptr, &wrote);
+      sh_nout += n;
+      if (wrote) sh_nc += 1;
+      // measurements, sdr.h:905-913 (values finalised on the host with libm)
+      st.meas_count += kChunk;
+      while (st.meas_count >= a.C.meas_decimation) {
+        st.meas_count -= a.C.meas_decimation;
+        rx_meas m; m.freqw = st.freqw; m.est_insp = st.est_insp; m.est_sp = st.est_sp; m.est_ep = st.est_ep;
+        a.meas[sh_nm++] = m;
+      }
+    }
+    pos += kChunk;
+    __syncthreads();
+  }
+  if (lane == 0) {
+    *a.state = st;
+    a.counters[0] = pos; a.counters[1] = sh_nout; a.counters[2] = sh_nm; a.counters[3] = sh_nc;
+  }
+}
+
+}  // namespace
+
+struct lsdr_rx {
+  lsdr_ctx *ctx;
+  lsdr_rx_cfg cfg;
+  std::vector<float> coeffs;
+  lsdr::cstln_tables tabs;
+  // receiver parameters kept on the host exactly like the reference's members
+  float omega, min_omega, max_omega;
+  rx_state_dev st;          // host mirror of the device state
+  bool st_dirty_host;       // host copy newer than device
+  // device
+  float2 *d_trig;
+  lut_entry *d_lut;
+  float *d_coeffs;
+  float2 *d_shifted;
+  rx_state_dev *d_state;
+  unsigned long long *d_counters;
+  rx_meas *d_meas; size_t meas_cap;
+  float2 *d_cstln; size_t cstln_cap;
+};
+
+// sdr.h:755-770
+static void rx_update_freq_limits(lsdr_rx *r, bool have_cstln) {
+  int n = 4;
+  if (have_cstln) {
+    switch (r->tabs.nsymbols) {
+      case 2: n = 2; break;
+      case 4: n = 4; break;
+      case 8: n = 8; break;
+      case 16: n = 12; break;
+      case 32: n = 16; break;
+      default: n = 4; break;
+    }
+  }
+  r->st.min_freqw = r->st.freqw - 65536 / r->max_omega / n / 2;
+  r->st.max_freqw = r->st.freqw + 65536 / r->max_omega / n / 2;
+}
+// sdr.h:738-743 (tol = 10e-6 as a float parameter)
+static void rx_set_omega(lsdr_rx *r, float omega, bool have_cstln) {
+  float tol = (float)10e-6;
+  r->omega = omega;
+  r->min_omega = omega * (1 - tol);
+  r->max_omega = omega * (1 + tol);
+  rx_update_freq_limits(r, have_cstln);
+}
+// sdr.h:745-749
+static void rx_set_freq(lsdr_rx *r, float freq, bool have_cstln) {
+  r->st.freqw = freq * 65536;
+  rx_update_freq_limits(r, have_cstln);
+}
+
+static int rx_push_state(lsdr_rx *r) {
+  if (!r->st_dirty_host) return LSDR_OK;
+  LSDR_HIP(hipMemcpyAsync(r->d_state, &r->st, sizeof(rx_state_dev), hipMemcpyHostToDevice, r->ctx->stream));
+  LSDR_HIP(hipStreamSynchronize(r->ctx->stream));
+  r->st_dirty_host = false;
+  return LSDR_OK;
+}
+
+extern "C" {
+
+int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
+  LSDR_ARG(c && cfg && out);
+  LSDR_ARG(cfg->sampler >= LSDR_SAMP_NEAREST && cfg->sampler <= LSDR_SAMP_FIR);
+  LSDR_ARG(cfg->sampler != LSDR_SAMP_FIR || (cfg->ncoeffs > 0 && cfg->coeffs_host && cfg->subsampling >= 1));
+  LSDR_ARG(cfg->omega > 0 && cfg->meas_decimation >= 1);
+  LSDR_ARG(cfg->mode == LSDR_RX_SERIAL || cfg->mode == LSDR_RX_TILED);
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_rx *r = new lsdr_rx();
+  r->ctx = c;
+  r->cfg = *cfg;
+  if (cfg->sampler == LSDR_SAMP_FIR) {
+    r->coeffs.assign(cfg->coeffs_host, cfg->coeffs_host + cfg->ncoeffs);
+    r->cfg.coeffs_host = r->coeffs.data();
+  }
+  int ns = lsdr::build_cstln(cfg->cstln, cfg->fec, r->tabs);
+  if (ns < 0) {
+    delete r;
+    lsdr_set_error("cstln_receiver: unsupported constellation/code rate %d/%d", cfg->cstln, cfg->fec);
+    return LSDR_E_ARG;
+  }
+  if (cfg->harden)  // cstln_lut::harden, sdr.h:564-571
+    for (auto &v : r->tabs.cost) v = v < 0 ? -1 : (v > 0 ? 1 : 0);
+
+  // Constructor sequence of the reference (sdr.h:709-736 then leandvb.cc:476-487):
+  // ctor: est_insp=amp², agc_gain=1, mu=phase=0, set_omega(1), set_freq(0) with cstln==NULL;
+  // then cstln is assigned, set_omega(Fs/Fm), optional set_freq(Ftune/Fs).
+  memset(&r->st, 0, sizeof(r->st));
+  r->st.est_insp = kCstlnAmp * kCstlnAmp;
+  r->st.agc_gain = 1;
+  rx_set_omega(r, 1, false);
+  rx_set_freq(r, 0, false);
+  rx_set_omega(r, cfg->omega, true);
+  if (cfg->freq) rx_set_freq(r, cfg->freq, true);
+  r->st_dirty_host = true;
+
+  // Tables → HBM.
+  std::vector<lsdr_cf32> trig(65536);
+  lsdr_trig16_table(trig.data());
+  std::vector<lut_entry> lut(65536);
+  for (int i = 0; i < 65536; ++i) {
+    lut_entry e;
+    e.cost = r->tabs.cost[i];
+    e.symbol = r->tabs.symbol[i];
+    e.zero = 0;
+    e.phase_error = r->tabs.phase_error[i];
+    e.pt_re = r->tabs.symbols[e.symbol][0];
+    e.pt_im = r->tabs.symbols[e.symbol][1];
+    lut[i] = e;
+  }
+  LSDR_HIP(hipMalloc((void **)&r->d_trig, 65536 * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&r->d_lut, 65536 * sizeof(lut_entry)));
+  LSDR_HIP(hipMemcpy(r->d_trig, trig.data(), 65536 * sizeof(float2), hipMemcpyHostToDevice));
+  LSDR_HIP(hipMemcpy(r->d_lut, lut.data(), 65536 * sizeof(lut_entry), hipMemcpyHostToDevice));
+  r->d_coeffs = nullptr;
+  r->d_shifted = nullptr;
+  if (cfg->sampler == LSDR_SAMP_FIR) {
+    LSDR_HIP(hipMalloc((void **)&r->d_coeffs, cfg->ncoeffs * sizeof(float)));
+    LSDR_HIP(hipMalloc((void **)&r->d_shifted, cfg->ncoeffs * sizeof(float2)));
+    LSDR_HIP(hipMemcpy(r->d_coeffs, r->coeffs.data(), cfg->ncoeffs * sizeof(float), hipMemcpyHostToDevice));
+    LSDR_HIP(hipMemset(r->d_shifted, 0, cfg->ncoeffs * sizeof(float2)));
+  }
+  LSDR_HIP(hipMalloc((void **)&r->d_state, sizeof(rx_state_dev)));
+  LSDR_HIP(hipMalloc((void **)&r->d_counters, 8 * sizeof(unsigned long long)));
+  r->d_meas = nullptr; r->meas_cap = 0;
+  r->d_cstln = nullptr; r->cstln_cap = 0;
+  *out = r;
+  return LSDR_OK;
+}
+
+void lsdr_rx_destroy(lsdr_rx *r) {
+  if (!r) return;
+  (void)hipStreamSynchronize(r->ctx->stream);
+  (void)hipFree(r->d_trig); (void)hipFree(r->d_lut);
+  (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
+  (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
+  (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
+  delete r;
+}
+
+int lsdr_rx_readahead(const lsdr_rx *r) {
+  if (!r) return 0;
+  switch (r->cfg.sampler) {
+    case LSDR_SAMP_NEAREST: return 0;
+    case LSDR_SAMP_LINEAR: return 1;
+    default: return r->cfg.ncoeffs - 1;
+  }
+}
+
+int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st) {
+  LSDR_ARG(r && st);
+  const rx_state_dev &s = r->st;  // host mirror is refreshed after every run
+  st->mu = s.mu; st->phase = s.phase; st->freqw = s.freqw; st->agc_gain = s.agc_gain;
+  st->est_insp = s.est_insp; st->est_sp = s.est_sp; st->est_ep = s.est_ep;
+  st->freq_tap = s.freqw / 65536;  // refresh_freq_tap, sdr.h:919-921
+  st->min_freqw = s.min_freqw; st->max_freqw = s.max_freqw;
+  st->meas_count = s.meas_count;
+  memcpy(st->hist, s.hist, sizeof(st->hist));
+  return LSDR_OK;
+}
+
+int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st) {
+  LSDR_ARG(r && st);
+  rx_state_dev &s = r->st;
+  s.mu = st->mu; s.phase = st->phase; s.freqw = st->freqw; s.agc_gain = st->agc_gain;
+  s.est_insp = st->est_insp; s.est_sp = st->est_sp; s.est_ep = st->est_ep;
+  s.min_freqw = st->min_freqw; s.max_freqw = st->max_freqw;
+  s.meas_count = st->meas_count;
+  memcpy(s.hist, st->hist, sizeof(s.hist));
+  r->st_dirty_host = true;
+  return LSDR_OK;
+}
+
+int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
+                size_t meas_cap, size_t *n_meas, lsdr_cf32 *cstln_out, size_t cstln_cap, size_t *n_cstln) {
+  LSDR_ARG(r && consumed && produced);
+  *consumed = 0; *produced = 0;
+  if (n_meas) *n_meas = 0;
+  if (n_cstln) *n_cstln = 0;
+  const int ra = lsdr_rx_readahead(r);
+  if (n_in < (size_t)(kChunk + ra) || cap_out < (size_t)kChunk) return LSDR_OK;
+  LSDR_ARG(in && out);
+  if (r->cfg.mode != LSDR_RX_SERIAL) {
+    lsdr_set_error("cstln_receiver: LSDR_RX_TILED not built into this library version");
+    return LSDR_E_UNSUPPORTED;
+  }
+  lsdr_ctx *c = r->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+
+  const size_t max_chunks = (n_in - ra) / kChunk;
+  // measurement scratch: the reference gates on pipe room (sdr.h:785-788); with
+  // NULL pipes there is no gate, so size the scratch for every chunk.
+  const bool want_meas = freq_out || ss_out || mer_out;
+  size_t need_meas = max_chunks * kChunk / r->cfg.meas_decimation + 2;
+  size_t eff_meas_cap = want_meas ? (meas_cap < need_meas ? meas_cap : need_meas) : need_meas;
+  size_t need_cstln = max_chunks + 1;
+  size_t eff_cstln_cap = cstln_out ? (cstln_cap < need_cstln ? cstln_cap : need_cstln) : need_cstln;
+  if (r->meas_cap < need_meas) {
+    (void)hipFree(r->d_meas);
+    LSDR_HIP(hipMalloc((void **)&r->d_meas, need_meas * sizeof(rx_meas)));
+    r->meas_cap = need_meas;
+  }
+  if (cstln_out && r->cstln_cap < need_cstln) {
+    (void)hipFree(r->d_cstln);
+    LSDR_HIP(hipMalloc((void **)&r->d_cstln, need_cstln * sizeof(float2)));
+    r->cstln_cap = need_cstln;
+  }
+  int rc = rx_push_state(r);
+  if (rc) return rc;
+
+  rx_serial_args a;
+  a.in = (const float2 *)in;
+  a.n_in = n_in;
+  a.out = out;
+  a.cap_out = cap_out;
+  a.state = r->d_state;
+  a.meas = r->d_meas; a.meas_cap = eff_meas_cap;
+  a.cstln = cstln_out ? r->d_cstln : nullptr; a.cstln_cap = eff_cstln_cap;
+  a.counters = r->d_counters;
+  a.C.omega = r->omega;
+  a.C.freq_alpha = (float)0.04;                                        // sdr.h:776
+  a.C.freq_beta = (float)(0.0012 / (double)r->omega * (double)r->cfg.pll_adjustment);  // sdr.h:777
+  a.C.gain_mu = (float)(0.02 / (double)(kCstlnAmp * kCstlnAmp) * 2);   // sdr.h:778
+  a.C.kest = r->cfg.kest;
+  a.C.allow_drift = r->cfg.allow_drift;
+  a.C.nsymbols = r->tabs.nsymbols;
+  a.C.meas_decimation = r->cfg.meas_decimation;
+  a.C.ncoeffs = r->cfg.ncoeffs;
+  a.C.subsampling = r->cfg.subsampling;
+  a.T.trig = r->d_trig; a.T.lut = r->d_lut; a.T.coeffs = r->d_coeffs; a.T.shifted = r->d_shifted;
+  a.readahead = ra;
+  size_t shmem = (size_t)(kChunk + ra) * sizeof(float2);
+  switch (r->cfg.sampler) {
+    case LSDR_SAMP_NEAREST: hipLaunchKernelGGL(k_rx_serial<0>, dim3(1), dim3(64), shmem, c->stream, a); break;
+    case LSDR_SAMP_LINEAR: hipLaunchKernelGGL(k_rx_serial<1>, dim3(1), dim3(64), shmem, c->stream, a); break;
+    default: hipLaunchKernelGGL(k_rx_serial<2>, dim3(1), dim3(64), shmem, c->stream, a); break;
+  }
+  LSDR_HIP(hipGetLastError());
+
+  unsigned long long cnt[4];
+  LSDR_HIP(hipMemcpyAsync(cnt, r->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  *consumed = cnt[0];
+  *produced = cnt[1];
+  if (want_meas && cnt[2]) {
+    std::vector<rx_meas> m(cnt[2]);
+    LSDR_HIP(hipMemcpy(m.data(), r->d_meas, cnt[2] * sizeof(rx_meas), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < cnt[2]; ++i) {
+      if (freq_out) freq_out[i] = m[i].freqw / 65536;                   // freq_tap
+      if (ss_out) ss_out[i] = sqrtf(m[i].est_insp);                      // sdr.h:910
+      if (mer_out) mer_out[i] = m[i].est_ep ? 10 * logf(m[i].est_sp / m[i].est_ep) / logf(10) : 0;  // sdr.h:912
+    }
+  }
+  if (n_meas) *n_meas = want_meas ? cnt[2] : 0;
+  if (cstln_out && cnt[3]) LSDR_HIP(hipMemcpy(cstln_out, r->d_cstln, cnt[3] * sizeof(float2), hipMemcpyDeviceToHost));
+  if (n_cstln) *n_cstln = cstln_out ? cnt[3] : 0;
+  return LSDR_OK;
+}
+
+}  // extern "C"

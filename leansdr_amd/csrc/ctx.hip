@@ -1,0 +1,172 @@
+// leansdr_amd/csrc/ctx.hip — context, device memory and stream timing of the C ABI.
+#include "lsdr_internal.h"
+
+static thread_local char g_err[512] = "";
+
+void lsdr_set_error(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int lsdr_hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  lsdr_set_error("%s:%d: %s failed: %s", file, line, what, hipGetErrorString(e));
+  return LSDR_E_HIP;
+}
+
+extern "C" {
+
+int lsdr_abi_version(void) { return LSDR_ABI_VERSION; }
+const char *lsdr_last_error(void) { return g_err; }
+
+int lsdr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) {
+  LSDR_ARG(out != nullptr);
+  int ndev = 0;
+  LSDR_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) {
+    lsdr_set_error("lsdr_ctx_create: no HIP device %d (found %d) - this library has no CPU fallback", device, ndev);
+    return LSDR_E_HIP;
+  }
+  LSDR_HIP(hipSetDevice(device));
+  lsdr_ctx *c = new lsdr_ctx();
+  c->device = device;
+  c->own_stream = (hip_stream == nullptr);
+  if (c->own_stream) LSDR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  else c->stream = (hipStream_t)hip_stream;
+  LSDR_HIP(hipEventCreate(&c->ev0));
+  LSDR_HIP(hipEventCreate(&c->ev1));
+  hipDeviceProp_t prop;
+  LSDR_HIP(hipGetDeviceProperties(&prop, device));
+  c->num_cu = prop.multiProcessorCount;
+  *out = c;
+  return LSDR_OK;
+}
+
+void lsdr_ctx_destroy(lsdr_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  if (c->own_stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int lsdr_ctx_sync(lsdr_ctx *c) {
+  LSDR_ARG(c);
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  return LSDR_OK;
+}
+
+void *lsdr_ctx_stream(lsdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int lsdr_malloc(lsdr_ctx *c, size_t bytes, void **p) {
+  LSDR_ARG(c && p);
+  LSDR_HIP(hipSetDevice(c->device));
+  LSDR_HIP(hipMalloc(p, bytes ? bytes : 1));
+  return LSDR_OK;
+}
+int lsdr_free(lsdr_ctx *c, void *p) {
+  LSDR_ARG(c);
+  if (!p) return LSDR_OK;
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  LSDR_HIP(hipFree(p));
+  return LSDR_OK;
+}
+int lsdr_malloc_host(size_t bytes, void **p) {
+  LSDR_ARG(p);
+  LSDR_HIP(hipHostMalloc(p, bytes ? bytes : 1, hipHostMallocDefault));
+  return LSDR_OK;
+}
+int lsdr_free_host(void *p) {
+  if (!p) return LSDR_OK;
+  LSDR_HIP(hipHostFree(p));
+  return LSDR_OK;
+}
+int lsdr_memcpy_h2d(lsdr_ctx *c, void *dst, const void *src, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  LSDR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+  return LSDR_OK;
+}
+int lsdr_memcpy_d2h(lsdr_ctx *c, void *dst, const void *src, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  LSDR_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+  return LSDR_OK;
+}
+int lsdr_memset(lsdr_ctx *c, void *dst, int value, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  LSDR_HIP(hipMemsetAsync(dst, value, bytes, c->stream));
+  return LSDR_OK;
+}
+
+// pipebuf::pack() moves the unread tail to the front of the buffer
+// (framework.h:153-159).  The ranges may overlap (dst < src), which a single
+// device memcpy does not define; copy forward in chunks no larger than the gap.
+int lsdr_memcpy_d2d(lsdr_ctx *c, void *dst, const void *src, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes || dst == src) return LSDR_OK;
+  char *d = (char *)dst;
+  const char *s = (const char *)src;
+  size_t gap = (d < s) ? (size_t)(s - d) : (size_t)(d - s);
+  if (gap >= bytes) {
+    LSDR_HIP(hipMemcpyAsync(d, s, bytes, hipMemcpyDeviceToDevice, c->stream));
+    return LSDR_OK;
+  }
+  LSDR_ARG(d < s);  // only the pack() direction is supported for overlapping ranges
+  for (size_t off = 0; off < bytes; off += gap) {
+    size_t n = bytes - off < gap ? bytes - off : gap;
+    LSDR_HIP(hipMemcpyAsync(d + off, s + off, n, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return LSDR_OK;
+}
+
+int lsdr_timer_start(lsdr_ctx *c) {
+  LSDR_ARG(c);
+  LSDR_HIP(hipEventRecord(c->ev0, c->stream));
+  return LSDR_OK;
+}
+int lsdr_timer_stop_ms(lsdr_ctx *c, float *ms) {
+  LSDR_ARG(c && ms);
+  LSDR_HIP(hipEventRecord(c->ev1, c->stream));
+  LSDR_HIP(hipEventSynchronize(c->ev1));
+  LSDR_HIP(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  return LSDR_OK;
+}
+
+
+int lsdr_event_create(lsdr_ctx *c, lsdr_event **ev) {
+  LSDR_ARG(c && ev);
+  lsdr_event *e = new lsdr_event();
+  e->ctx = c;
+  LSDR_HIP(hipEventCreate(&e->ev));
+  *ev = e;
+  return LSDR_OK;
+}
+void lsdr_event_destroy(lsdr_event *e) {
+  if (!e) return;
+  (void)hipEventDestroy(e->ev);
+  delete e;
+}
+int lsdr_event_record(lsdr_event *e) {
+  LSDR_ARG(e);
+  LSDR_HIP(hipEventRecord(e->ev, e->ctx->stream));
+  return LSDR_OK;
+}
+int lsdr_event_elapsed_ms(lsdr_event *a, lsdr_event *b, float *ms) {
+  LSDR_ARG(a && b && ms);
+  LSDR_HIP(hipEventSynchronize(b->ev));
+  LSDR_HIP(hipEventElapsedTime(ms, a->ev, b->ev));
+  return LSDR_OK;
+}
+
+}  // extern "C"

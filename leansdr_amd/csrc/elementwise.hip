@@ -1,0 +1,114 @@
+// leansdr_amd/csrc/elementwise.hip — pure streaming maps (HBM-bound).
+//   cconverter<u8,128,f32,0,1,1>   dsp.h:33-54
+//   scaler<float,cf32,cf32>        dsp.h:140-160
+//   decimator<cf32>                generic.h:247-267
+// 16 B per lane per access, grid-stride, grid capped at 8 blocks/CU
+// (cdna_hip_programming.md G11/G13).  Stand-alone forms of the stages that
+// fir_filter / cstln_receiver can also fuse into their loads.
+#include "lsdr_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline unsigned grid_for(const lsdr_ctx *c, size_t work_items) {
+  size_t blocks = (work_items + kBlock - 1) / kBlock;
+  size_t cap = (size_t)c->num_cu * 8;
+  if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// 4 samples (8 bytes of cu8) per lane-iteration -> 2 x float4 stores.
+__global__ __launch_bounds__(kBlock) void k_cconv_u8(const uint8_t *__restrict__ in, size_t n,
+                                                      float *__restrict__ out) {
+  size_t nvec = n / 4;  // groups of 4 complex samples
+  size_t stride = (size_t)gridDim.x * kBlock;
+  const bool aligned = (((uintptr_t)in) & 7) == 0 && (((uintptr_t)out) & 15) == 0;
+  if (aligned) {
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+      uint2 raw = *reinterpret_cast<const uint2 *>(in + v * 8);
+      float4 a, b;
+      // out = 0 + (in - 128)*1/1 evaluated in int, then converted (dsp.h:46-47)
+      a.x = (float)((int)(raw.x & 0xff) - 128);
+      a.y = (float)((int)((raw.x >> 8) & 0xff) - 128);
+      a.z = (float)((int)((raw.x >> 16) & 0xff) - 128);
+      a.w = (float)((int)(raw.x >> 24) - 128);
+      b.x = (float)((int)(raw.y & 0xff) - 128);
+      b.y = (float)((int)((raw.y >> 8) & 0xff) - 128);
+      b.z = (float)((int)((raw.y >> 16) & 0xff) - 128);
+      b.w = (float)((int)(raw.y >> 24) - 128);
+      float4 *o = reinterpret_cast<float4 *>(out + v * 8);
+      o[0] = a;
+      o[1] = b;
+    }
+  } else {
+    nvec = 0;
+  }
+  // tail (and the whole range when misaligned)
+  for (size_t i = nvec * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    out[2 * i] = (float)((int)in[2 * i] - 128);
+    out[2 * i + 1] = (float)((int)in[2 * i + 1] - 128);
+  }
+}
+
+// out = in * scale, complex*T = (re*k, im*k)  (math.h:45-48): one multiply per float.
+__global__ __launch_bounds__(kBlock) void k_scale(const float *__restrict__ in, size_t nfloat, float scale,
+                                                   float *__restrict__ out) {
+  size_t stride = (size_t)gridDim.x * kBlock;
+  size_t nvec = 0;
+  if ((((uintptr_t)in) & 15) == 0 && (((uintptr_t)out) & 15) == 0) {
+    nvec = nfloat / 4;
+    for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+      float4 x = reinterpret_cast<const float4 *>(in)[v];
+      x.x *= scale; x.y *= scale; x.z *= scale; x.w *= scale;
+      reinterpret_cast<float4 *>(out)[v] = x;
+    }
+  }
+  for (size_t i = nvec * 4 + (size_t)blockIdx.x * kBlock + threadIdx.x; i < nfloat; i += stride)
+    out[i] = in[i] * scale;
+}
+
+__global__ __launch_bounds__(kBlock) void k_decim(const float2 *__restrict__ in, unsigned d, size_t count,
+                                                   float2 *__restrict__ out) {
+  size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t m = (size_t)blockIdx.x * kBlock + threadIdx.x; m < count; m += stride) out[m] = in[m * d];
+}
+
+}  // namespace
+
+extern "C" {
+
+int lsdr_cconverter_u8_run(lsdr_ctx *c, const lsdr_cu8 *in, size_t n, lsdr_cf32 *out) {
+  LSDR_ARG(c && (n == 0 || (in && out)));
+  if (!n) return LSDR_OK;
+  hipLaunchKernelGGL(k_cconv_u8, dim3(grid_for(c, n / 4 + 1)), dim3(kBlock), 0, c->stream,
+                     (const uint8_t *)in, n, (float *)out);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+int lsdr_scaler_run(lsdr_ctx *c, float scale, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out) {
+  LSDR_ARG(c && (n == 0 || (in && out)));
+  if (!n) return LSDR_OK;
+  hipLaunchKernelGGL(k_scale, dim3(grid_for(c, n / 2 + 1)), dim3(kBlock), 0, c->stream, (const float *)in,
+                     2 * n, scale, (float *)out);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+int lsdr_decimator_run(lsdr_ctx *c, unsigned d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out, size_t cap,
+                       size_t *produced) {
+  LSDR_ARG(c && d >= 1 && produced);
+  size_t count = n / d;
+  if (count > cap) count = cap;
+  *produced = count;
+  if (!count) return LSDR_OK;
+  LSDR_ARG(in && out);
+  hipLaunchKernelGGL(k_decim, dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, (const float2 *)in, d,
+                     count, (float2 *)out);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+}  // extern "C"

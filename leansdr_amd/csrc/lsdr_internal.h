@@ -1,0 +1,50 @@
+// leansdr_amd/csrc/lsdr_internal.h — shared internals of liblsdr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include "../../include/lsdr_hip.h"
+
+struct lsdr_ctx {
+  int device;
+  hipStream_t stream;
+  bool own_stream;
+  hipEvent_t ev0, ev1;
+  int num_cu;
+};
+
+struct lsdr_event {
+  lsdr_ctx *ctx;
+  hipEvent_t ev;
+};
+
+void lsdr_set_error(const char *fmt, ...);
+int lsdr_hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define LSDR_HIP(call)                                                  \
+  do {                                                                  \
+    hipError_t e__ = (call);                                            \
+    if (e__ != hipSuccess) return lsdr_hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define LSDR_ARG(cond)                                                  \
+  do {                                                                  \
+    if (!(cond)) {                                                      \
+      lsdr_set_error("%s:%d: bad argument: %s", __FILE__, __LINE__, #cond); \
+      return LSDR_E_ARG;                                                \
+    }                                                                   \
+  } while (0)
+
+// Host-side table builders (host_tables.cpp)
+namespace lsdr {
+void fir_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq, lsdr_cf32 *shifted);
+struct cstln_tables {
+  int nsymbols, nrotations;
+  int8_t symbols[256][2];
+  std::vector<int16_t> cost, phase_error;
+  std::vector<uint8_t> symbol;
+};
+int build_cstln(int predef, int fec, cstln_tables &t);
+}  // namespace lsdr

@@ -1,0 +1,156 @@
+"""Parity of the HIP fir_filter / elementwise kernels (through the C ABI) with
+the oracle and the golden vectors.  Bit-exact in LSDR_FIR_EXACT mode; the
+LSDR_FIR_FMA variant is held to a stated tolerance."""
+import os
+import numpy as np
+import pytest
+from conftest import gold, bits_equal, iq16_to_cf32
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sig():
+    rng = np.random.default_rng(3)
+    n = 300000
+    return ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 40).astype(np.complex64)
+
+
+def test_elementwise(capi, ctx, oracle, sig):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 3, 4, 5, 1000, 65537):
+        u8 = rng.integers(0, 256, 2 * n, dtype=np.uint8)
+        assert bits_equal(ctx.cconverter_u8(u8), oracle.cconverter_u8(u8))
+        assert bits_equal(ctx.scaler(0.0123, sig[:n]), oracle.scaler(0.0123, sig[:n]))
+    assert bits_equal(ctx.decimator(7, sig[:10001]), sig[:10001:7][:10001 // 7])
+
+
+def test_golden_c2_geometry(capi, ctx):
+    """fir_filter at the C2 geometry (N=313, D=30) incl. the fused scaler, vs the reference's output."""
+    g, tab = gold("fir_filter.npz"), gold("tables.npz")
+    x = iq16_to_cf32(g["iq120"])
+    for tag, freq in [("f0", 0.0), ("fshift", 0.0123), ("fneg", -0.004)]:
+        f = capi.FirFilter(ctx, tab["lowpass_c2"], 30, in_scale=float(g["scale"]))
+        if freq:
+            f.set_freq(freq)
+        assert bits_equal(f.shifted_coeffs(), g[f"c2_{tag}_sc"])
+        y, cons = f.run(x)
+        assert bits_equal(y, g[f"c2_{tag}_out"]), tag
+        assert cons == 30 * len(y)
+        f.close()
+    f = capi.FirFilter(ctx, tab["lowpass_small"], 2, in_format=capi.IN_CU8)   # fused cconverter
+    y, _ = f.run(g["u8"])
+    assert bits_equal(y, g["u8_d2_out"])
+    f.close()
+
+
+GEOMS = [(313, 30), (313, 1), (21, 1), (21, 7), (2, 3), (64, 64), (1, 1), (1, 5), (40, 4), (100, 10), (33, 16),
+         (257, 8), (500, 30), (31, 31), (200, 2), (75, 5), (640, 64), (90, 9)]
+
+
+@pytest.mark.parametrize("n,d", GEOMS, ids=[f"N{n}_D{d}" for n, d in GEOMS])
+@pytest.mark.parametrize("freq", [0.0, 0.0123])
+def test_vs_oracle(capi, ctx, oracle, sig, n, d, freq):
+    c = oracle.lowpass(n - 1, np.float32(0.4 / d)) if n > 1 else np.array([0.75], np.float32)
+    x = sig[: min(len(sig), 2000 * d + n + 17)]
+    f = capi.FirFilter(ctx, c, d)
+    if freq:
+        f.set_freq(freq)
+    y, cons = f.run(x)
+    ref, rcons = oracle.fir_filter(c, d, x, freq)
+    assert cons == rcons and bits_equal(y, ref)
+    f.close()
+
+
+@pytest.mark.parametrize("force", ["generic", "complex"])
+def test_kernel_variants_agree(capi, ctx, oracle, sig, force):
+    """Run-time-D kernel and complex-coefficient kernel on a real-coefficient filter: same bits."""
+    env = {"generic": "LSDR_FIR_GENERIC", "complex": "LSDR_FIR_FORCE_COMPLEX"}[force]
+    os.environ[env] = "1"
+    try:
+        c = oracle.lowpass(312, np.float32(0.0049))
+        f = capi.FirFilter(ctx, c, 30)
+        y, _ = f.run(sig[:100000])
+        f.close()
+    finally:
+        del os.environ[env]
+    ref, _ = oracle.fir_filter(c, 30, sig[:100000])
+    assert bits_equal(y, ref)
+
+
+def test_edges(capi, ctx, oracle, sig):
+    c = oracle.lowpass(20, np.float32(0.2))
+    f = capi.FirFilter(ctx, c, 4)
+    for n in (0, 5, 20, 21, 24, 25, 28, 29):            # around ncoeffs and one decimation step
+        y, cons = f.run(sig[:n])
+        ref, rcons = oracle.fir_filter(c, 4, sig[:n])
+        assert cons == rcons and bits_equal(y, ref), n
+    # cap_out smaller than what the input allows: produce exactly cap, consume cap*decim
+    x = sig[:1000]
+    din = ctx.upload(x)
+    dout = ctx.alloc(8 * 10)
+    cons, prod = f.run_dev(din.ptr, len(x), dout.ptr, 10)
+    assert (cons, prod) == (40, 10)
+    ref, _ = oracle.fir_filter(c, 4, x)
+    assert bits_equal(ctx.download(dout, np.complex64, 10), ref[:10])
+    din.free(); dout.free(); f.close()
+
+
+def test_streaming_equals_one_shot(capi, ctx, oracle, sig):
+    """pipebuf-style use: consume what run() reports, keep the tail, feed more — same stream."""
+    c = oracle.lowpass(312, np.float32(0.0049))
+    f = capi.FirFilter(ctx, c, 30)
+    x = sig[:200000]
+    whole, _ = oracle.fir_filter(c, 30, x)
+    outs, pos, avail = [], 0, 0
+    for step in (5000, 313, 40000, 7, 100000, 1 << 30):
+        avail = min(len(x), avail + step)
+        y, cons = f.run(x[pos:avail])
+        outs.append(y)
+        pos += cons
+    assert bits_equal(np.concatenate(outs), whole)
+    f.close()
+
+
+def test_track_semantics(capi, ctx):
+    """freq_tap prologue of run(): re-shift only when |current-new| > tol (dsp.h:236-244)."""
+    c = np.ones(9, np.float32) / 9
+    f = capi.FirFilter(ctx, c, 1)
+    assert not f.track(0.001, 0.5, 0.01) and f.current_freq == 0.0
+    assert f.track(0.1, 0.5, 0.01) and abs(f.current_freq - 0.05) < 1e-9
+    assert not f.track(0.11, 0.5, 0.01)
+    f.close()
+
+
+def test_fma_variant_tolerance(capi, ctx, oracle, sig):
+    """LSDR_FIR_FMA: same order, fused ops.  Tolerance: |err| <= 4e-6 * sum|c|*max|x| (stated bound)."""
+    c = oracle.lowpass(312, np.float32(0.0049))
+    for freq in (0.0, 0.0123):
+        f = capi.FirFilter(ctx, c, 30, arith=capi.FIR_FMA)
+        if freq:
+            f.set_freq(freq)
+        y, _ = f.run(sig[:100000])
+        ref, _ = oracle.fir_filter(c, 30, sig[:100000], freq)
+        bound = 4e-6 * np.abs(c).sum() * np.abs(sig[:100000]).max() * 2
+        assert np.abs(y - ref).max() <= bound
+        f.close()
+
+
+def test_large_full_config_properties(capi, ctx, oracle):
+    """BASELINE config-2 size (N=313, D=30, 16 Mi samples): linearity-free exactness is checked
+    on random windows against the oracle, plus the DC-gain property (sum of taps = 1)."""
+    n = 1 << 24
+    rng = np.random.default_rng(5)
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 30).astype(np.complex64)
+    c = oracle.lowpass(312, np.float32((2e6 / 2) * (1 + 0.35 / 2) / 240e6))
+    f = capi.FirFilter(ctx, c, 30)
+    y, cons = f.run(x)
+    assert len(y) == (n - 313) // 30 and cons == len(y) * 30
+    for m0 in (0, 1234, len(y) // 2, len(y) - 700):
+        ref, _ = oracle.fir_filter(c, 30, x[m0 * 30: m0 * 30 + 313 + 30 * 600 + 29])
+        assert bits_equal(y[m0: m0 + len(ref)], ref)
+    f.close()
+    f = capi.FirFilter(ctx, c, 30)
+    y, _ = f.run(np.full(40000, 3 - 2j, np.complex64))
+    assert np.allclose(y, 3 - 2j, rtol=2e-5)
+    f.close()

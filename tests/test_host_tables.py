@@ -1,0 +1,32 @@
+"""The product's host-side table/coefficient design (leansdr_amd/csrc/host_tables.cpp,
+through the C ABI) against the oracle and the goldens.  CPU only."""
+import numpy as np
+import pytest
+from conftest import gold, bits_equal
+
+
+def test_trig_and_constellations(capi, oracle):
+    assert bits_equal(capi.trig16(), oracle.trig16())
+    for pre, fec in [(0, 0), (1, 0), (2, 1), (3, 1), (3, 3), (3, 8), (4, 3), (4, 8), (5, 0), (6, 0), (7, 0), (8, 0)]:
+        a, b = capi.cstln_lut(pre, fec), oracle.cstln_lut(pre, fec)
+        assert a["nsymbols"] == b["nsymbols"] and a["nrotations"] == b["nrotations"]
+        for k in ("symbols", "cost", "symbol", "phase_error"):
+            assert bits_equal(a[k], b[k]), (pre, fec, k)
+
+
+def test_unsupported_code_rate_is_an_error(capi):
+    with pytest.raises(capi.LsdrError):
+        capi.cstln_lut(capi.APSK16, capi.FEC12)   # "Code rate not supported with APSK16", dvb.h:60
+
+
+def test_filtergen(capi, oracle):
+    g = gold("tables.npz")
+    assert bits_equal(capi.lowpass(312, float(g["lowpass_c2_fcut"])), g["lowpass_c2"])
+    assert bits_equal(capi.root_raised_cosine(int(10 * 8e6 * 16 / (22 * (2e6 / 2) * 0.35)),
+                                              np.float32(2e6 / (8e6 * 16)), np.float32(0.35)), g["rrc_rx"])
+    for order, fc in [(14, 0.4895), (40, 0.1), (1, 0.3), (99, 0.02)]:
+        assert bits_equal(capi.lowpass(order, np.float32(fc)), oracle.lowpass(order, np.float32(fc)))
+        assert bits_equal(capi.lowpass(order, np.float32(fc), False), oracle.lowpass(order, np.float32(fc), False))
+    for order, fs, ro in [(41, 0.25, 0.35), (64, 0.25, 0.25), (100, 0.5, 0.2), (33, 1 / 3.0, 0.35)]:
+        assert bits_equal(capi.root_raised_cosine(order, np.float32(fs), np.float32(ro)),
+                          oracle.rrc(order, np.float32(fs), np.float32(ro)))
