@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per step per GPU")
     ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, tiled)")
     ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "serial"))
+    ap.add_argument("--tile-len", type=int, default=256)
+    ap.add_argument("--tile-warmup", type=int, default=1024)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -120,9 +122,17 @@ def main():
     d_sym = ctx.alloc((n_out_max + 256) * 4)
 
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
-    rx = capi.CstlnReceiver(ctx, sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM),
-                            meas_decimation=int(FS / decim),
-                            mode=capi.RX_TILED if args.rx_mode == "tiled" else capi.RX_SERIAL)
+    rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
+    rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED if args.rx_mode == "tiled" else capi.RX_SERIAL,
+                            tile_len=args.tile_len, tile_warmup=args.tile_warmup, **rx_kw)
+    if args.rx_mode == "tiled":
+        # Acquisition: the exact serial loop locks on the head of the stream, then the tiled
+        # (tracking) receiver takes over from that state.  Not timed (warm-up happens after it).
+        acq = capi.CstlnReceiver(ctx, mode=capi.RX_SERIAL, **rx_kw)
+        cons0, prod0 = fir.run_dev(d_in.ptr, min(B, 1 << 22), d_dec.ptr, n_out_max)
+        acq.run_dev(d_dec.ptr, prod0, d_sym.ptr, n_out_max + 256, meas=False)
+        rx.set_state(acq.state())
+        acq.close()
 
     e0, e1 = ctx.event(), ctx.event()
     fir_ms = []
@@ -184,6 +194,7 @@ def main():
             "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident; "
                                    "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
                        "batch_samples_per_gpu": B, "rx_mode": args.rx_mode,
+                       "rx_tiles": rx.tiled_stats() if args.rx_mode == "tiled" else None,
                        "parallelism": f"{world} independent capture(s), one per GPU, no collectives",
                        "symbols_per_step": nsym[0] // max(1, args.steps)},
             "roofline": {"kernel": "k_fir (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2),

@@ -172,6 +172,9 @@ void lsdr_rx_destroy(lsdr_rx *r);
 int lsdr_rx_readahead(const lsdr_rx *r);                 /* sampler->readahead() */
 int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st);    /* includes freq_tap (sdr.h:918-921) */
 int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st);
+/* LSDR_RX_TILED diagnostics of the last run: tiles, seams where a duplicated / lost symbol was
+ * repaired, seams whose timing or carrier-phase mismatch exceeded the lock criterion. */
+int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsigned *miss, unsigned *bad_seams);
 /* run(), sdr.h:772-916, over one buffer: consumes whole chunks of 128 samples while
  * n_in-pos >= 128+readahead and cap_out-produced >= 128 (and the measurement
  * outputs have room).  freq/ss/mer (meas_cap floats each, HOST pointers, may be

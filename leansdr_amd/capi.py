@@ -102,6 +102,7 @@ _sig("lsdr_rx_destroy", None, [vp])
 _sig("lsdr_rx_readahead", C.c_int, [vp])
 _sig("lsdr_rx_get_state", C.c_int, [vp, C.POINTER(RxState)])
 _sig("lsdr_rx_set_state", C.c_int, [vp, C.POINTER(RxState)])
+_sig("lsdr_rx_tiled_stats", C.c_int, [vp] + [C.POINTER(C.c_uint)] * 4)
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 
 #: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
@@ -349,6 +350,11 @@ class CstlnReceiver:
 
     def set_state(self, st):
         check(lib.lsdr_rx_set_state(self.h, C.byref(st)))
+
+    def tiled_stats(self):
+        v = [C.c_uint() for _ in range(4)]
+        check(lib.lsdr_rx_tiled_stats(self.h, *[C.byref(x) for x in v]))
+        return dict(zip(("tiles", "dup", "miss", "bad_seams"), [x.value for x in v]))
 
     def run_dev(self, in_ptr, n_in, out_ptr, cap_out, meas=True):
         cons, prod, nm, nc = c_sz(), c_sz(), c_sz(), c_sz()

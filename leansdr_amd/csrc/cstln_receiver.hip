@@ -282,6 +282,114 @@ __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
   }
 }
 
+
+// ---------------------------------------------------------------- LSDR_RX_TILED
+struct rx_tile_info {         // per tile, written by k_rx_tiles, reconciled on the host
+  float mu_begin, phase_begin;   // state at the start of the tile body (after warm-up)
+  float mu_end, phase_end;       // state at the end of the tile body
+  unsigned count;                // symbols emitted in the body
+  lsdr_softsymbol pre;           // last symbol of the warm-up (needed when a seam loses a symbol)
+  unsigned has_pre;
+};
+
+struct rx_tile_fix {          // per tile, produced by the host seam pass
+  unsigned long long out_offset; // where the tile's (fixed-up) symbols start in the output
+  unsigned rot;                  // quadrant correction (index into the relabel table)
+  unsigned drop_first;           // 1: first body symbol duplicates the previous tile's last
+  unsigned insert_pre;           // 1: the warm-up's last symbol belongs to this tile
+};
+
+struct rx_tiled_args {
+  const float2 *in;
+  unsigned long long total_chunks;     // chunks processed by this run
+  unsigned first_chunks, tile_chunks, warm_chunks;
+  unsigned n_tiles;
+  unsigned stage_stride;               // symbols reserved per tile in `stage`
+  lsdr_softsymbol *stage;
+  rx_tile_info *info;
+  rx_state_dev *state;                 // in: carried state; out: end state of the last tile
+  rx_meas *meas;                       // [n_meas] measurement slots (may be null)
+  unsigned long long meas_base;        // meas_count at the start of the run
+  rx_consts C;
+  rx_tables T;
+};
+
+// One lane per tile.  Tile 0 continues exactly from the carried state; tile j ≥ 1
+// starts `warm_chunks` early from the carried tracking state with mu = phase = 0.
+template <int SAMP>
+__global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
+  const unsigned j = blockIdx.x * 64 + threadIdx.x;
+  if (j >= a.n_tiles) return;
+  rx_state_dev s = *a.state;
+  unsigned long long c0, c1;     // body chunk range
+  if (j == 0) { c0 = 0; c1 = a.first_chunks; }
+  else { c0 = a.first_chunks + (unsigned long long)(j - 1) * a.tile_chunks; c1 = c0 + a.tile_chunks; }
+  if (c1 > a.total_chunks) c1 = a.total_chunks;
+  rx_tile_info ti;
+  ti.has_pre = 0;
+  ti.pre.cost = 0; ti.pre.symbol = 0; ti.pre.pad = 0;
+  bool wrote;
+  if (j > 0) {
+    s.mu = 0.f; s.phase = 0.f;
+    for (int k = 0; k < 12; ++k) s.hist[k] = 0.f;
+    lsdr_softsymbol last; last.cost = 0; last.symbol = 0; last.pad = 0;
+    unsigned got = 0;
+    for (unsigned long long c = c0 - a.warm_chunks; c < c0; ++c) {
+      if (SAMP == 1) s.samp_freqw = s.freqw;
+      got += rx_chunk<SAMP>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { last = ss; }, nullptr, &wrote);
+    }
+    ti.pre = last;
+    ti.has_pre = got ? 1u : 0u;
+  }
+  ti.mu_begin = s.mu; ti.phase_begin = s.phase;
+  lsdr_softsymbol *po = a.stage + (unsigned long long)j * a.stage_stride;
+  unsigned cnt = 0;
+  for (unsigned long long c = c0; c < c1; ++c) {
+    if (SAMP == 1) s.samp_freqw = s.freqw;
+    rx_chunk<SAMP>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, nullptr, &wrote);
+    if (a.meas) {     // measurements, sdr.h:905-913: one per meas_decimation samples of the stream
+      unsigned long long before = (a.meas_base + c * kChunk) / a.C.meas_decimation;
+      unsigned long long after = (a.meas_base + (c + 1) * kChunk) / a.C.meas_decimation;
+      unsigned long long first = a.meas_base / a.C.meas_decimation;
+      for (unsigned long long m = before; m < after; ++m) {
+        rx_meas mm; mm.freqw = s.freqw; mm.est_insp = s.est_insp; mm.est_sp = s.est_sp; mm.est_ep = s.est_ep;
+        a.meas[m - first] = mm;
+      }
+    }
+  }
+  ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
+  a.info[j] = ti;
+  if (j == a.n_tiles - 1) {
+    s.meas_count = (a.meas_base + a.total_chunks * kChunk) % a.C.meas_decimation;
+    *a.state = s;
+  }
+}
+
+// Compaction: one wavefront per tile copies the tile's symbols to their final place,
+// applying the seam fix-ups and the quadrant relabelling.
+__global__ __launch_bounds__(64) void k_rx_compact(const lsdr_softsymbol *stage, unsigned stage_stride,
+                                                   const rx_tile_info *info, const rx_tile_fix *fix,
+                                                   const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles,
+                                                   lsdr_softsymbol *out) {
+  const unsigned j = blockIdx.x;
+  if (j >= n_tiles) return;
+  const rx_tile_fix f = fix[j];
+  const rx_tile_info ti = info[j];
+  const uint8_t *map = relabel + f.rot * 256;
+  const lsdr_softsymbol *src = stage + (unsigned long long)j * stage_stride;
+  lsdr_softsymbol *dst = out + f.out_offset;
+  if (f.insert_pre) {
+    if (threadIdx.x == 0) { lsdr_softsymbol p = ti.pre; p.symbol = map[p.symbol]; dst[0] = p; }
+    dst += 1;
+  }
+  const unsigned skip = f.drop_first ? 1u : 0u;
+  for (unsigned k = threadIdx.x + skip; k < ti.count; k += 64) {
+    lsdr_softsymbol v = src[k];
+    v.symbol = map[v.symbol];
+    dst[k - skip] = v;
+  }
+}
+
 }  // namespace
 
 struct lsdr_rx {
@@ -302,6 +410,12 @@ struct lsdr_rx {
   unsigned long long *d_counters;
   rx_meas *d_meas; size_t meas_cap;
   float2 *d_cstln; size_t cstln_cap;
+  // tiled mode
+  lsdr_softsymbol *d_stage; size_t stage_cap;
+  rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
+  uint8_t *d_relabel;
+  std::vector<uint8_t> relabel;   // [nrotations][256]
+  unsigned last_tiles, last_dup, last_miss, last_badseam;  // diagnostics of the last tiled run
 };
 
 // sdr.h:755-770
@@ -339,6 +453,147 @@ static int rx_push_state(lsdr_rx *r) {
   LSDR_HIP(hipMemcpyAsync(r->d_state, &r->st, sizeof(rx_state_dev), hipMemcpyHostToDevice, r->ctx->stream));
   LSDR_HIP(hipStreamSynchronize(r->ctx->stream));
   r->st_dirty_host = false;
+  return LSDR_OK;
+}
+
+static void rx_fill_consts(const lsdr_rx *r, rx_consts &C, rx_tables &T) {
+  C.omega = r->omega;
+  C.freq_alpha = (float)0.04;                                                    // sdr.h:776
+  C.freq_beta = (float)(0.0012 / (double)r->omega * (double)r->cfg.pll_adjustment);  // sdr.h:777
+  C.gain_mu = (float)(0.02 / (double)(kCstlnAmp * kCstlnAmp) * 2);               // sdr.h:778
+  C.kest = r->cfg.kest;
+  C.allow_drift = r->cfg.allow_drift;
+  C.nsymbols = r->tabs.nsymbols;
+  C.meas_decimation = r->cfg.meas_decimation;
+  C.ncoeffs = r->cfg.ncoeffs;
+  C.subsampling = r->cfg.subsampling;
+  T.trig = r->d_trig; T.lut = r->d_lut; T.coeffs = r->d_coeffs; T.shifted = r->d_shifted;
+}
+
+// LSDR_RX_TILED: see the file header.  Not bit-exact: every tile but the first
+// re-acquires timing/phase during its warm-up; seams are reconciled here.
+static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                        size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
+                        size_t meas_cap, size_t *n_meas) {
+  lsdr_ctx *c = r->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  if (r->cfg.sampler == LSDR_SAMP_FIR) {
+    lsdr_set_error("cstln_receiver: LSDR_RX_TILED supports the nearest and linear samplers");
+    return LSDR_E_UNSUPPORTED;
+  }
+  const int ra = lsdr_rx_readahead(r);
+  const unsigned Lc = (r->cfg.tile_len ? r->cfg.tile_len : 512) / kChunk;
+  const unsigned Wc = (r->cfg.tile_warmup ? r->cfg.tile_warmup : 1024) / kChunk;
+  LSDR_ARG(Lc >= 1 && Wc >= 1);
+  // Symbols per chunk are bounded by 128/(omega - max_mucorr) + 1 (mu advances by at
+  // least omega-0.1 per symbol, sdr.h:834-840).
+  const unsigned sym_per_chunk = (unsigned)(kChunk / (r->omega - 0.1f)) + 2;
+  size_t chunks = (n_in - ra) / kChunk;
+  if ((size_t)sym_per_chunk * chunks > cap_out) chunks = cap_out / sym_per_chunk;
+  if (!chunks) return LSDR_OK;
+  const unsigned first = Lc > Wc ? Lc : Wc;
+  unsigned n_tiles = 1;
+  if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
+  const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
+
+  if (r->tiles_cap < n_tiles) {
+    (void)hipFree(r->d_info); (void)hipFree(r->d_fix);
+    LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
+    LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
+    r->tiles_cap = n_tiles;
+  }
+  if (r->stage_cap < (size_t)n_tiles * stage_stride) {
+    (void)hipFree(r->d_stage);
+    LSDR_HIP(hipMalloc((void **)&r->d_stage, (size_t)n_tiles * stage_stride * sizeof(lsdr_softsymbol)));
+    r->stage_cap = (size_t)n_tiles * stage_stride;
+  }
+  const bool want_meas = freq_out || ss_out || mer_out;
+  const unsigned long long md = r->cfg.meas_decimation;
+  const unsigned long long meas_base = r->st.meas_count;
+  size_t nm = (size_t)((meas_base + chunks * kChunk) / md - meas_base / md);
+  if (want_meas && nm > meas_cap) { lsdr_set_error("cstln_receiver(tiled): measurement buffers too small"); return LSDR_E_ARG; }
+  if (want_meas && r->meas_cap < nm + 1) {
+    (void)hipFree(r->d_meas);
+    LSDR_HIP(hipMalloc((void **)&r->d_meas, (nm + 1) * sizeof(rx_meas)));
+    r->meas_cap = nm + 1;
+  }
+  int rc = rx_push_state(r);
+  if (rc) return rc;
+
+  rx_tiled_args a;
+  a.in = (const float2 *)in;
+  a.total_chunks = chunks;
+  a.first_chunks = first; a.tile_chunks = Lc; a.warm_chunks = Wc;
+  a.n_tiles = n_tiles;
+  a.stage_stride = stage_stride;
+  a.stage = r->d_stage;
+  a.info = r->d_info;
+  a.state = r->d_state;
+  a.meas = want_meas ? r->d_meas : nullptr;
+  a.meas_base = meas_base;
+  rx_fill_consts(r, a.C, a.T);
+  const unsigned blocks = (n_tiles + 63) / 64;
+  if (r->cfg.sampler == LSDR_SAMP_NEAREST) hipLaunchKernelGGL(k_rx_tiles<0>, dim3(blocks), dim3(64), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_rx_tiles<1>, dim3(blocks), dim3(64), 0, c->stream, a);
+  LSDR_HIP(hipGetLastError());
+
+  // ---- seam pass (host): quadrant of the carrier phase, lost / duplicated symbols, offsets
+  std::vector<rx_tile_info> info(n_tiles);
+  LSDR_HIP(hipMemcpyAsync(info.data(), r->d_info, n_tiles * sizeof(rx_tile_info), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  std::vector<rx_tile_fix> fix(n_tiles);
+  const int R = r->tabs.nrotations;
+  const float quad = 65536.0f / R;
+  const float omega = r->omega;
+  unsigned rot = 0, ndup = 0, nmiss = 0, nbad = 0;
+  unsigned long long off = 0;
+  for (unsigned j = 0; j < n_tiles; ++j) {
+    rx_tile_fix f; f.drop_first = 0; f.insert_pre = 0;
+    if (j > 0) {
+      float d = info[j].mu_begin - info[j - 1].mu_end;
+      if (d > omega / 2 && info[j].has_pre) { f.insert_pre = 1; ++nmiss; }
+      else if (d < -omega / 2 && info[j].count > 0) { f.drop_first = 1; ++ndup; }
+      float dphi = fmodf(info[j].phase_begin - info[j - 1].phase_end, 65536.0f);
+      if (dphi < 0) dphi += 65536.0f;
+      int k = (int)floorf(dphi / quad + 0.5f);
+      float perr = fabsf(dphi - k * quad);
+      float dm = fabsf(d);
+      if (fabsf(dm - omega) < dm) dm = fabsf(dm - omega);
+      if (perr > quad / 4 || dm > 0.5f) ++nbad;
+      rot = (rot + (unsigned)k) % (unsigned)R;
+    }
+    f.rot = rot;
+    f.out_offset = off;
+    off += info[j].count + f.insert_pre - f.drop_first;
+    fix[j] = f;
+  }
+  if (off > cap_out) { lsdr_set_error("cstln_receiver(tiled): output overflow (%llu > %zu)", off, cap_out); return LSDR_E_ARG; }
+  r->last_tiles = n_tiles; r->last_dup = ndup; r->last_miss = nmiss; r->last_badseam = nbad;
+  LSDR_HIP(hipMemcpyAsync(r->d_fix, fix.data(), n_tiles * sizeof(rx_tile_fix), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_rx_compact, dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
+                     stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
+                     (const uint8_t *)r->d_relabel, n_tiles, out);
+  LSDR_HIP(hipGetLastError());
+  LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  // Bring the carried carrier phase back into the frame of tile 0 so that the next
+  // run continues with the same symbol labelling.
+  if (rot) {
+    r->st.phase = fmodf(r->st.phase - rot * quad, 65536.0f);
+    r->st_dirty_host = true;
+  }
+  *consumed = chunks * kChunk;
+  *produced = (size_t)off;
+  if (want_meas && nm) {
+    std::vector<rx_meas> m(nm);
+    LSDR_HIP(hipMemcpy(m.data(), r->d_meas, nm * sizeof(rx_meas), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nm; ++i) {
+      if (freq_out) freq_out[i] = m[i].freqw / 65536;
+      if (ss_out) ss_out[i] = sqrtf(m[i].est_insp);
+      if (mer_out) mer_out[i] = m[i].est_ep ? 10 * logf(m[i].est_sp / m[i].est_ep) / logf(10) : 0;
+    }
+  }
+  if (n_meas) *n_meas = want_meas ? nm : 0;
   return LSDR_OK;
 }
 
@@ -409,6 +664,31 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_HIP(hipMalloc((void **)&r->d_counters, 8 * sizeof(unsigned long long)));
   r->d_meas = nullptr; r->meas_cap = 0;
   r->d_cstln = nullptr; r->cstln_cap = 0;
+  r->d_stage = nullptr; r->stage_cap = 0;
+  r->d_info = nullptr; r->d_fix = nullptr; r->tiles_cap = 0;
+  r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
+  // Relabel tables for the tiled mode: relabel[k][s] = symbol whose constellation point is
+  // point[s] rotated by +k·(360°/nrotations) (nearest point; exact for the PSK/APSK/QAM sets).
+  {
+    const int R = r->tabs.nrotations, ns = r->tabs.nsymbols;
+    r->relabel.assign((size_t)R * 256, 0);
+    for (int k = 0; k < R; ++k) {
+      double ang = 2 * M_PI * k / R, ca = cos(ang), sa = sin(ang);
+      for (int s = 0; s < ns; ++s) {
+        double x = r->tabs.symbols[s][0] * ca - r->tabs.symbols[s][1] * sa;
+        double y = r->tabs.symbols[s][0] * sa + r->tabs.symbols[s][1] * ca;
+        int best = 0; double bd = 1e30;
+        for (int t = 0; t < ns; ++t) {
+          double dx = x - r->tabs.symbols[t][0], dy = y - r->tabs.symbols[t][1];
+          double d = dx * dx + dy * dy;
+          if (d < bd) { bd = d; best = t; }
+        }
+        r->relabel[(size_t)k * 256 + s] = (uint8_t)best;
+      }
+    }
+    LSDR_HIP(hipMalloc((void **)&r->d_relabel, r->relabel.size()));
+    LSDR_HIP(hipMemcpy(r->d_relabel, r->relabel.data(), r->relabel.size(), hipMemcpyHostToDevice));
+  }
   *out = r;
   return LSDR_OK;
 }
@@ -420,6 +700,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
+  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel);
   delete r;
 }
 
@@ -441,6 +722,15 @@ int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st) {
   st->min_freqw = s.min_freqw; st->max_freqw = s.max_freqw;
   st->meas_count = s.meas_count;
   memcpy(st->hist, s.hist, sizeof(st->hist));
+  return LSDR_OK;
+}
+
+int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsigned *miss, unsigned *bad_seams) {
+  LSDR_ARG(r);
+  if (tiles) *tiles = r->last_tiles;
+  if (dup) *dup = r->last_dup;
+  if (miss) *miss = r->last_miss;
+  if (bad_seams) *bad_seams = r->last_badseam;
   return LSDR_OK;
 }
 
@@ -466,10 +756,8 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
   const int ra = lsdr_rx_readahead(r);
   if (n_in < (size_t)(kChunk + ra) || cap_out < (size_t)kChunk) return LSDR_OK;
   LSDR_ARG(in && out);
-  if (r->cfg.mode != LSDR_RX_SERIAL) {
-    lsdr_set_error("cstln_receiver: LSDR_RX_TILED not built into this library version");
-    return LSDR_E_UNSUPPORTED;
-  }
+  if (r->cfg.mode == LSDR_RX_TILED)
+    return rx_run_tiled(r, in, n_in, out, cap_out, consumed, produced, freq_out, ss_out, mer_out, meas_cap, n_meas);
   lsdr_ctx *c = r->ctx;
   LSDR_HIP(hipSetDevice(c->device));
 
@@ -503,17 +791,7 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
   a.meas = r->d_meas; a.meas_cap = eff_meas_cap;
   a.cstln = cstln_out ? r->d_cstln : nullptr; a.cstln_cap = eff_cstln_cap;
   a.counters = r->d_counters;
-  a.C.omega = r->omega;
-  a.C.freq_alpha = (float)0.04;                                        // sdr.h:776
-  a.C.freq_beta = (float)(0.0012 / (double)r->omega * (double)r->cfg.pll_adjustment);  // sdr.h:777
-  a.C.gain_mu = (float)(0.02 / (double)(kCstlnAmp * kCstlnAmp) * 2);   // sdr.h:778
-  a.C.kest = r->cfg.kest;
-  a.C.allow_drift = r->cfg.allow_drift;
-  a.C.nsymbols = r->tabs.nsymbols;
-  a.C.meas_decimation = r->cfg.meas_decimation;
-  a.C.ncoeffs = r->cfg.ncoeffs;
-  a.C.subsampling = r->cfg.subsampling;
-  a.T.trig = r->d_trig; a.T.lut = r->d_lut; a.T.coeffs = r->d_coeffs; a.T.shifted = r->d_shifted;
+  rx_fill_consts(r, a.C, a.T);
   a.readahead = ra;
   size_t shmem = (size_t)(kChunk + ra) * sizeof(float2);
   switch (r->cfg.sampler) {

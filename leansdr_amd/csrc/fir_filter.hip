@@ -56,15 +56,24 @@ struct fir_args {
   float in_scale;        // 0 → none
 };
 
+// Staging is split into the global load (raw bits kept in two VGPRs) and the
+// conversion applied just before the LDS write.
 template <int IN_FMT>
-__device__ __forceinline__ float2 load_sample(const void *in, unsigned long long j, float scale) {
-  float2 v;
+__device__ __forceinline__ float2 load_raw(const void *in, unsigned long long j) {
   if (IN_FMT == LSDR_IN_CU8) {
-    uchar2 r = reinterpret_cast<const uchar2 *>(in)[j];
-    v.x = (float)((int)r.x - 128);  // dsp.h:46-47, int arithmetic then int→float
-    v.y = (float)((int)r.y - 128);
-  } else {
-    v = reinterpret_cast<const float2 *>(in)[j];
+    const unsigned short r = reinterpret_cast<const unsigned short *>(in)[j];
+    return make_float2(__uint_as_float((unsigned)r), 0.f);
+  }
+  return reinterpret_cast<const float2 *>(in)[j];
+}
+
+template <int IN_FMT>
+__device__ __forceinline__ float2 finish_sample(float2 raw, float scale) {
+  float2 v = raw;
+  if (IN_FMT == LSDR_IN_CU8) {
+    const unsigned r = __float_as_uint(raw.x);
+    v.x = (float)((int)(r & 0xffu) - 128);  // dsp.h:46-47: int arithmetic, then int→float
+    v.y = (float)((int)(r >> 8) - 128);
   }
   if (scale != 0.f) {  // scaler: complex*T = (re*k, im*k), math.h:45-48
     v.x = v.x * scale;
@@ -137,19 +146,40 @@ __global__ __launch_bounds__(kThreads) void k_fir(fir_args a) {
   const unsigned l = threadIdx.x;
 
   // ---- stage: tile-local t ∈ [0, T) ↔ global sample j = m0·D + t
+  // Consecutive lanes ↔ consecutive samples: coalesced loads; the (row, col) of
+  // consecutive t differ by one row → conflict-free ds_write_b64.  ALL of a
+  // lane's loads are issued before the first LDS write (≈64 KB in flight per
+  // workgroup): HBM latency is paid once per tile, not once per load.
   const unsigned T = (mv - 1) * D + N + 1;
   const unsigned long long j0 = m0 * D;
-  {
-    // consecutive lanes ↔ consecutive samples: coalesced loads; the (p,q) of
-    // consecutive t differ by one row → conflict-free ds_write_b64.
-    unsigned t = l;
-    unsigned p = t % D, q = t / D;
-    const unsigned dp = kThreads % D, dq = kThreads / D;
-    for (; t < T; t += kThreads) {
-      float2 v = load_sample<IN_FMT>(a.in, j0 + t, a.in_scale);
-      lds[p * S + q] = v;
-      p += dp; q += dq;
-      if (p >= D) { p -= D; q += 1; }
+  if (DT > 0) {
+    // N ≤ 12·D − 1 for specialised kernels (N/D + 2 ≤ kSpad) → T ≤ (M + 11)·D
+    constexpr int NL = DT > 0 ? (int)(((M + kSpad - 2) * (unsigned)(DT > 0 ? DT : 1) + kThreads - 1) / kThreads) : 1;
+    float2 v[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const unsigned t = l + k * kThreads;
+      if (t < T) v[k] = load_raw<IN_FMT>(a.in, j0 + t);
+    }
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const unsigned t = l + k * kThreads;
+      if (t < T) lds[(t % D) * S + (t / D)] = finish_sample<IN_FMT>(v[k], a.in_scale);
+    }
+  } else {
+    constexpr int NB = 8;
+    for (unsigned tb = 0; tb < T; tb += NB * kThreads) {
+      float2 v[NB];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const unsigned t = tb + l + k * kThreads;
+        if (t < T) v[k] = load_raw<IN_FMT>(a.in, j0 + t);
+      }
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+        const unsigned t = tb + l + k * kThreads;
+        if (t < T) lds[(t % D) * S + (t / D)] = finish_sample<IN_FMT>(v[k], a.in_scale);
+      }
     }
   }
   __syncthreads();
