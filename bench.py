@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per step per GPU")
     ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, tiled)")
-    ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "serial"))
+    ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "tiled"))
     ap.add_argument("--tile-len", type=int, default=256)
     ap.add_argument("--tile-warmup", type=int, default=1024)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
