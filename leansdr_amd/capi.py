@@ -4,7 +4,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblsdr_hip.so")
+LIB_PATH = os.environ.get("LSDR_HIP_LIB", os.path.join(HERE, "liblsdr_hip.so"))  # override: instrumented builds (tools/)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

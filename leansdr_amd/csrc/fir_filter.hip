@@ -48,12 +48,16 @@ struct fir_args {
   float2 *out;
   const float2 *sc;      // shifted coefficients [N]   (complex kernels)
   const float *rc;       // real coefficients   [N]   (real kernel)
+  const float2 *scp;     // zero-padded to ncols·D taps (persistent kernels)
+  const float *rcp;
+  unsigned ncols;
   unsigned N, D;
   unsigned S;            // LDS row stride in samples (odd)
   unsigned long long count;      // outputs to produce
   unsigned long long n_in;       // input samples available
   unsigned n_tiles, tiles_per_xcd;
-  float in_scale;        // 0 → none
+  float in_scale;        // 1.0f → none
+  unsigned long long *trace;   // LSDR_FIR_TRACE builds: per-wave phase cycle sums
 };
 
 // Staging is split into the global load (raw bits kept in two VGPRs) and the
@@ -75,20 +79,29 @@ __device__ __forceinline__ float2 finish_sample(float2 raw, float scale) {
     v.x = (float)((int)(r & 0xffu) - 128);  // dsp.h:46-47: int arithmetic, then int→float
     v.y = (float)((int)(r >> 8) - 128);
   }
-  if (scale != 0.f) {  // scaler: complex*T = (re*k, im*k), math.h:45-48
-    v.x = v.x * scale;
-    v.y = v.y * scale;
-  }
+  // scaler: complex*T = (re*k, im*k), math.h:45-48.  `scale` is 1.0f when no scaler is
+  // fused (x·1 is exact), so the staging code has no data-independent branch.
+  v.x = v.x * scale;
+  v.y = v.y * scale;
   return v;
 }
 
 // One tap for the R outputs of a lane.  MODE: 0 exact complex, 1 exact real-coefficient,
 // 2 FMA complex, 3 FMA real.  px points at the lane's sample for output r=0.
+// Coefficients are read through the CONSTANT address space: they are never written
+// while a kernel runs, and this guarantees wave-uniform scalar (s_load) access even in
+// the persistent kernel, where stores to `out` precede later coefficient loads.
+typedef float lsdr_v2f __attribute__((ext_vector_type(2)));
+typedef unsigned lsdr_v2u __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) lsdr_v2f *cptr2;
+typedef const __attribute__((address_space(4))) float *cptr1;
+
 template <int R, int MODE>
-__device__ __forceinline__ void fir_tap(const float2 *__restrict__ psc, const float *__restrict__ prc,
-                                        const float2 *px, float (&accr)[R], float (&acci)[R]) {
+__device__ __forceinline__ void fir_tap(cptr2 psc, cptr1 prc, const float2 *px, float (&accr)[R],
+                                        float (&acci)[R]) {
   if (MODE == 0 || MODE == 2) {
-    const float2 c = *psc;
+    const lsdr_v2f cc = *psc;
+    const float2 c = make_float2(cc.x, cc.y);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const float2 x = px[r * kThreads];
@@ -126,74 +139,18 @@ __device__ __forceinline__ void fir_tap(const float2 *__restrict__ psc, const fl
 // DT == 0: generic run-time D / S.
 constexpr unsigned kSpad = 13;
 
-template <int IN_FMT, int R, int MODE, int DT>
-__global__ __launch_bounds__(kThreads) void k_fir(fir_args a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float2 *lds = reinterpret_cast<float2 *>(smem_raw);
-
-  // XCD-aware tile mapping (block b is dispatched to XCD b % 8).
-  const unsigned b = blockIdx.x;
-  const unsigned tile = (b & 7u) * a.tiles_per_xcd + (b >> 3);
-  if (tile >= a.n_tiles) return;
-
-  constexpr unsigned M = kThreads * R;
-  const unsigned long long m0 = (unsigned long long)tile * M;
-  const unsigned long long rem = a.count - m0;
-  const unsigned mv = rem < M ? (unsigned)rem : M;  // valid outputs in this tile
-  const unsigned N = a.N;
-  const unsigned D = DT > 0 ? (unsigned)DT : a.D;
-  const unsigned S = DT > 0 ? (M + kSpad) : a.S;
-  const unsigned l = threadIdx.x;
-
-  // ---- stage: tile-local t ∈ [0, T) ↔ global sample j = m0·D + t
-  // Consecutive lanes ↔ consecutive samples: coalesced loads; the (row, col) of
-  // consecutive t differ by one row → conflict-free ds_write_b64.  ALL of a
-  // lane's loads are issued before the first LDS write (≈64 KB in flight per
-  // workgroup): HBM latency is paid once per tile, not once per load.
-  const unsigned T = (mv - 1) * D + N + 1;
-  const unsigned long long j0 = m0 * D;
-  if (DT > 0) {
-    // N ≤ 12·D − 1 for specialised kernels (N/D + 2 ≤ kSpad) → T ≤ (M + 11)·D
-    constexpr int NL = DT > 0 ? (int)(((M + kSpad - 2) * (unsigned)(DT > 0 ? DT : 1) + kThreads - 1) / kThreads) : 1;
-    float2 v[NL];
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const unsigned t = l + k * kThreads;
-      if (t < T) v[k] = load_raw<IN_FMT>(a.in, j0 + t);
-    }
-#pragma unroll
-    for (int k = 0; k < NL; ++k) {
-      const unsigned t = l + k * kThreads;
-      if (t < T) lds[(t % D) * S + (t / D)] = finish_sample<IN_FMT>(v[k], a.in_scale);
-    }
-  } else {
-    constexpr int NB = 8;
-    for (unsigned tb = 0; tb < T; tb += NB * kThreads) {
-      float2 v[NB];
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const unsigned t = tb + l + k * kThreads;
-        if (t < T) v[k] = load_raw<IN_FMT>(a.in, j0 + t);
-      }
-#pragma unroll
-      for (int k = 0; k < NB; ++k) {
-        const unsigned t = tb + l + k * kThreads;
-        if (t < T) lds[(t % D) * S + (t / D)] = finish_sample<IN_FMT>(v[k], a.in_scale);
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- taps.  Tap i ↔ u = N − i = col·D + row, visited col-major descending.
-  float accr[R], acci[R];
+// Tap phase for one staged tile: tap i ↔ u = N − i = col·D + row, visited
+// col-major descending (i ascending — the reference's accumulation order).
+template <int R, int MODE, int DT>
+__device__ __forceinline__ void fir_taps(const fir_args &a, const float2 *lds, unsigned l, unsigned N, unsigned D,
+                                         unsigned S, float (&accr)[R], float (&acci)[R]) {
 #pragma unroll
   for (int r = 0; r < R; ++r) { accr[r] = 0.f; acci[r] = 0.f; }
-
   const float2 *base = lds + l;
   // coefficient cursors (wave-uniform → scalar loads; pointer + constant offsets
   // lets the compiler merge a column's taps into wide s_load_dwordx8/x16)
-  const float2 *__restrict__ psc = a.sc;
-  const float *__restrict__ prc = a.rc;
+  cptr2 psc = (cptr2)a.sc;
+  cptr1 prc = (cptr1)a.rc;
   int col = (int)(N / D);
   // leading partial column: rows (N mod D) … 0 (… 1 when it is also column 0)
   {
@@ -219,7 +176,52 @@ __global__ __launch_bounds__(kThreads) void k_fir(fir_args a) {
     const float2 *px = base + (D - 1) * S;
     for (int row = (int)D - 1; row >= 1; --row, ++psc, ++prc, px -= S) fir_tap<R, MODE>(psc, prc, px, accr, acci);
   }
+}
 
+// ---- one tile per workgroup (any D; run-time D when DT == 0) ------------------
+template <int IN_FMT, int R, int MODE, int DT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fir(fir_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2 *lds = reinterpret_cast<float2 *>(smem_raw);
+
+  // XCD-aware tile mapping (block b is dispatched to XCD b % 8).
+  const unsigned b = blockIdx.x;
+  const unsigned tile = (b & 7u) * a.tiles_per_xcd + (b >> 3);
+  if (tile >= a.n_tiles) return;
+
+  constexpr unsigned M = kThreads * R;
+  const unsigned long long m0 = (unsigned long long)tile * M;
+  const unsigned long long rem = a.count - m0;
+  const unsigned mv = rem < M ? (unsigned)rem : M;  // valid outputs in this tile
+  const unsigned N = a.N;
+  const unsigned D = DT > 0 ? (unsigned)DT : a.D;
+  const unsigned S = DT > 0 ? (M + kSpad) : a.S;
+  const unsigned l = threadIdx.x;
+
+  // ---- stage: tile-local t ∈ [0, T) ↔ global sample j = m0·D + t
+  // Consecutive lanes ↔ consecutive samples: coalesced loads; the (row, col) of
+  // consecutive t differ by one row → conflict-free ds_write_b64.  Loads are
+  // issued in batches before the LDS writes so HBM latency is paid per batch.
+  const unsigned T = (mv - 1) * D + N + 1;
+  const unsigned long long j0 = m0 * D;
+  constexpr int NB = 8;
+  for (unsigned tb = 0; tb < T; tb += NB * kThreads) {
+    float2 v[NB];
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const unsigned t = tb + l + k * kThreads;
+      if (t < T) v[k] = load_raw<IN_FMT>(a.in, j0 + t);
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+      const unsigned t = tb + l + k * kThreads;
+      if (t < T) lds[(t % D) * S + (t / D)] = finish_sample<IN_FMT>(v[k], a.in_scale);
+    }
+  }
+  __syncthreads();
+
+  float accr[R], acci[R];
+  fir_taps<R, MODE, DT>(a, lds, l, N, D, S, accr, acci);
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     unsigned lm = l + r * kThreads;
@@ -227,10 +229,131 @@ __global__ __launch_bounds__(kThreads) void k_fir(fir_args a) {
   }
 }
 
+// ---- persistent, software-pipelined form for compile-time D --------------------
+// Each workgroup walks a strided sequence of tiles inside its XCD's contiguous
+// range.  The NEXT tile's samples are requested from HBM (≈64 KB in flight per
+// workgroup, held in VGPRs) before the CURRENT tile's tap phase starts and are
+// written to LDS after it: HBM latency hides behind the taps within every
+// workgroup, independent of what the co-resident workgroup is doing.
+//
+// The coefficient arrays are zero-padded on the host to a whole number of
+// polyphase columns (F = D−1−N%D zeros in front, one behind; a.scp / a.rcp,
+// a.ncols columns), so the tap phase is `ncols` identical straight-line blocks of
+// D taps: immediate LDS offsets, wide scalar coefficient loads, no vector-memory
+// instruction (nothing in the tap phase waits on the prefetch).  A zero tap adds
+// ±0 to an accumulator that is never −0, i.e. changes no bit, as long as the
+// sample it multiplies is finite; samples past the end of the input are replaced
+// by the last valid sample for that reason.
+template <int IN_FMT, int R, int MODE, int DT>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fir_persist(fir_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float2 *lds = reinterpret_cast<float2 *>(smem_raw);
+  constexpr unsigned M = kThreads * R;
+  constexpr unsigned D = DT > 0 ? DT : 1;
+  constexpr unsigned S = M + kSpad;
+  constexpr unsigned TMAX = (M + kSpad - 1) * D;           // staged span: all columns < S, whole rows
+  constexpr int NL = (int)((TMAX + kThreads - 1) / kThreads);
+  const unsigned l = threadIdx.x;
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+
+  float2 v[NL];
+  auto tile_of = [&](unsigned ti) { return xcd * a.tiles_per_xcd + ti; };
+  auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
+  // Prefetch through a per-tile buffer resource (base = first sample of the tile,
+  // extent = the rest of the input): one shared 32-bit lane offset, one scalar offset
+  // per load, and hardware bounds checking — reads past the end of the input return
+  // 0.0, which is exactly the "finite filler" the zero-padded taps need.
+  constexpr unsigned ES = IN_FMT == LSDR_IN_CU8 ? 2u : 8u;
+  auto issue = [&](unsigned tile) {
+    const unsigned long long j0 = (unsigned long long)tile * M * D;
+    const unsigned long long bytes = (a.n_in - j0) * ES;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.in)) + j0 * ES, 0,
+        (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
+    const unsigned voff = l * ES;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      if (IN_FMT == LSDR_IN_CU8) {
+        unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, k * kThreads * ES, 0);
+        v[k] = make_float2(__uint_as_float((unsigned)r), 0.f);
+      } else {
+        lsdr_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, k * kThreads * ES, 0);
+        v[k] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
+      }
+    }
+  };
+
+  unsigned ti = slot;
+  if (!valid(ti)) return;
+#ifdef LSDR_FIR_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_amdgcn_s_memtime();
+#define LSDR_TR(i) { unsigned long long now__ = __builtin_amdgcn_s_memtime(); tr[i] += now__ - tc; tc = now__; }
+#else
+#define LSDR_TR(i)
+#endif
+  issue(tile_of(ti));
+  LSDR_TR(0)
+  while (true) {
+    const unsigned tile = tile_of(ti);
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+      const unsigned t = l + k * kThreads;
+      if ((k + 1) * kThreads <= TMAX || t < TMAX)
+        lds[(t % D) * S + (t / D)] = finish_sample<IN_FMT>(v[k], a.in_scale);
+    }
+    LSDR_TR(1)
+    __syncthreads();
+    LSDR_TR(2)
+    const unsigned tn = ti + slots;
+    const bool more = valid(tn);
+    if (more) issue(tile_of(tn));          // in flight during the tap phase
+    __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the taps
+    LSDR_TR(3)
+
+    float accr[R], acci[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { accr[r] = 0.f; acci[r] = 0.f; }
+    cptr2 psc = (cptr2)a.scp;
+    cptr1 prc = (cptr1)a.rcp;
+    for (int col = (int)a.ncols - 1; col >= 0; --col, psc += D, prc += D) {
+      const float2 *px = lds + l + (D - 1) * S + (unsigned)col;
+#pragma unroll
+      for (int k = 0; k < (int)D; ++k) fir_tap<R, MODE>(psc + k, prc + k, px - k * (int)S, accr, acci);
+    }
+
+    LSDR_TR(4)
+    const unsigned long long m0 = (unsigned long long)tile * M;
+    const unsigned long long rem = a.count - m0;
+    const unsigned mv = rem < M ? (unsigned)rem : M;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      unsigned lm = l + r * kThreads;
+      if (lm < mv) a.out[m0 + lm] = make_float2(accr[r], acci[r]);
+    }
+    LSDR_TR(5)
+    if (!more) break;
+    ti = tn;
+    __syncthreads();                       // LDS is rewritten next
+    LSDR_TR(6)
+  }
+#ifdef LSDR_FIR_TRACE
+  if (a.trace && (l & 63) == 0)
+    for (int i = 0; i < 8; ++i) a.trace[((size_t)blockIdx.x * 4 + (l >> 6)) * 8 + i] = tr[i];
+#endif
+}
+
 typedef void (*fir_kernel_t)(fir_args);
 
 template <int IN_FMT, int R, int DT>
-fir_kernel_t pick_mode(int mode) {
+fir_kernel_t pick_mode(int mode, bool persist = false) {
+  if (persist && DT > 0) {
+    switch (mode) {
+      case 0: return k_fir_persist<IN_FMT, R, 0, DT>;
+      case 1: return k_fir_persist<IN_FMT, R, 1, DT>;
+      case 2: return k_fir_persist<IN_FMT, R, 2, DT>;
+      default: return k_fir_persist<IN_FMT, R, 3, DT>;
+    }
+  }
   switch (mode) {
     case 0: return k_fir<IN_FMT, R, 0, DT>;
     case 1: return k_fir<IN_FMT, R, 1, DT>;
@@ -245,8 +368,8 @@ fir_kernel_t pick_mode(int mode) {
 constexpr int spec_r(int D) { return D <= 8 ? 4 : (D <= 15 ? 2 : 1); }
 
 template <int IN_FMT>
-fir_kernel_t pick_spec(unsigned D, int mode, int *R_out) {
-#define LSDR_FIR_SPEC(DD) case DD: *R_out = spec_r(DD); return pick_mode<IN_FMT, spec_r(DD), DD>(mode);
+fir_kernel_t pick_spec(unsigned D, int mode, int *R_out, bool persist) {
+#define LSDR_FIR_SPEC(DD) case DD: *R_out = spec_r(DD); return pick_mode<IN_FMT, spec_r(DD), DD>(mode, persist);
   switch (D) {
     LSDR_FIR_SPEC(1) LSDR_FIR_SPEC(2) LSDR_FIR_SPEC(4) LSDR_FIR_SPEC(5) LSDR_FIR_SPEC(8)
     LSDR_FIR_SPEC(10) LSDR_FIR_SPEC(16) LSDR_FIR_SPEC(30)
@@ -266,6 +389,14 @@ fir_kernel_t pick_generic(int R, int mode) {
 
 }  // namespace
 
+#ifdef LSDR_FIR_TRACE
+static unsigned long long *g_fir_trace = nullptr;
+extern "C" int lsdr_fir_trace_read(unsigned long long *host, size_t n) {
+  if (!g_fir_trace) return -1;
+  return hipMemcpy(host, g_fir_trace, n * sizeof(unsigned long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+#endif
+
 struct lsdr_fir_filter {
   lsdr_ctx *ctx;
   lsdr_fir_filter_cfg cfg;
@@ -273,6 +404,9 @@ struct lsdr_fir_filter {
   std::vector<lsdr_cf32> shifted;   // host copy of shifted_coeffs
   float2 *d_sc;                     // device: shifted coefficients
   float *d_rc;                      // device: real parts (valid when all imag == 0)
+  float2 *d_scp;                    // device: column-padded copies for the persistent kernel
+  float *d_rcp;
+  unsigned ncols;
   bool all_real;
   float current_freq;
   int R;                            // outputs per lane
@@ -280,6 +414,8 @@ struct lsdr_fir_filter {
   size_t lds_bytes;
   int force_complex;                // test hook (env LSDR_FIR_FORCE_COMPLEX)
   bool spec;                        // compile-time-D kernel in use
+  bool persist;                     // persistent software-pipelined kernel (spec only)
+  unsigned persist_grid;            // workgroups launched by the persistent kernel
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -295,6 +431,13 @@ static int fir_upload(lsdr_fir_filter *f) {
   LSDR_HIP(hipStreamSynchronize(c->stream));
   LSDR_HIP(hipMemcpyAsync(f->d_sc, f->shifted.data(), N * sizeof(float2), hipMemcpyHostToDevice, c->stream));
   LSDR_HIP(hipMemcpyAsync(f->d_rc, rc.data(), N * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // column-padded copies: F = D-1-N%D zero taps in front, one behind → ncols·D taps
+  const unsigned D = f->cfg.decim, F = D - 1 - N % D;
+  std::vector<lsdr_cf32> scp((size_t)f->ncols * D, lsdr_cf32{0.f, 0.f});
+  std::vector<float> rcp((size_t)f->ncols * D, 0.f);
+  for (unsigned i = 0; i < N; ++i) { scp[F + i] = f->shifted[i]; rcp[F + i] = rc[i]; }
+  LSDR_HIP(hipMemcpyAsync(f->d_scp, scp.data(), scp.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+  LSDR_HIP(hipMemcpyAsync(f->d_rcp, rcp.data(), rcp.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));
   return LSDR_OK;
 }
@@ -333,8 +476,15 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   size_t bytes;
   int Rs = 0;
   f->spec = false;
-  if (!(fg && atoi(fg)) && N / D + 2 <= kSpad && pick_spec<LSDR_IN_CF32>(D, 0, &Rs) != nullptr) {
+  f->persist = false;
+  if (!(fg && atoi(fg)) && N / D + 2 <= kSpad && pick_spec<LSDR_IN_CF32>(D, 0, &Rs, false) != nullptr) {
     f->spec = true;
+    {
+      const char *fp = getenv("LSDR_FIR_PERSIST");   // test/bench hook: 0 disables, N>1 = workgroups per CU
+      int wpc = fp ? atoi(fp) : 2;
+      f->persist = wpc > 0;
+      f->persist_grid = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 2) + 7) / 8 * 8;
+    }
     R = Rs;
     S = kThreads * R + kSpad;
     bytes = (size_t)D * S * sizeof(float2);
@@ -350,6 +500,9 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   f->lds_bytes = bytes;
   LSDR_HIP(hipMalloc((void **)&f->d_sc, N * sizeof(float2)));
   LSDR_HIP(hipMalloc((void **)&f->d_rc, N * sizeof(float)));
+  f->ncols = N / D + 1;
+  LSDR_HIP(hipMalloc((void **)&f->d_scp, (size_t)f->ncols * D * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&f->d_rcp, (size_t)f->ncols * D * sizeof(float)));
   *out = f;
   return lsdr_fir_filter_set_freq(f, 0.0f);  // fir_filter ctor ends with set_freq(0), dsp.h:230
 }
@@ -359,6 +512,8 @@ void lsdr_fir_filter_destroy(lsdr_fir_filter *f) {
   (void)hipStreamSynchronize(f->ctx->stream);
   (void)hipFree(f->d_sc);
   (void)hipFree(f->d_rc);
+  (void)hipFree(f->d_scp);
+  (void)hipFree(f->d_rcp);
   delete f;
 }
 
@@ -408,6 +563,9 @@ int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf
   a.out = (float2 *)out;
   a.sc = f->d_sc;
   a.rc = f->d_rc;
+  a.scp = f->d_scp;
+  a.rcp = f->d_rcp;
+  a.ncols = f->ncols;
   a.N = N; a.D = D; a.S = f->S;
   a.count = count;
   a.n_in = n_in;
@@ -416,19 +574,31 @@ int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf
   LSDR_ARG(n_tiles < (1ull << 31));
   a.n_tiles = (unsigned)n_tiles;
   a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
-  a.in_scale = f->cfg.in_scale;
+  a.in_scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
+  a.trace = nullptr;
+#ifdef LSDR_FIR_TRACE
+  {
+    static unsigned long long *d_trace = nullptr;
+    if (!d_trace) LSDR_HIP(hipMalloc((void **)&d_trace, 4096 * 4 * 8 * sizeof(unsigned long long)));
+    LSDR_HIP(hipMemsetAsync(d_trace, 0, 4096 * 4 * 8 * sizeof(unsigned long long), f->ctx->stream));
+    a.trace = d_trace;
+    g_fir_trace = d_trace;
+  }
+#endif
 
   const bool real_path = f->all_real && !f->force_complex;
   int mode = (f->cfg.arith == LSDR_FIR_FMA ? 2 : 0) + (real_path ? 1 : 0);
   int Rs = 0;
   fir_kernel_t k;
   if (f->spec)
-    k = f->cfg.in_format == LSDR_IN_CU8 ? pick_spec<LSDR_IN_CU8>(D, mode, &Rs) : pick_spec<LSDR_IN_CF32>(D, mode, &Rs);
+    k = f->cfg.in_format == LSDR_IN_CU8 ? pick_spec<LSDR_IN_CU8>(D, mode, &Rs, f->persist) : pick_spec<LSDR_IN_CF32>(D, mode, &Rs, f->persist);
   else
     k = f->cfg.in_format == LSDR_IN_CU8 ? pick_generic<LSDR_IN_CU8>(f->R, mode) : pick_generic<LSDR_IN_CF32>(f->R, mode);
   if (f->lds_bytes > 64 * 1024)
     LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->lds_bytes));
-  hipLaunchKernelGGL(k, dim3(a.tiles_per_xcd * 8), dim3(kThreads), f->lds_bytes, f->ctx->stream, a);
+  unsigned grid = a.tiles_per_xcd * 8;
+  if (f->spec && f->persist && grid > f->persist_grid) grid = f->persist_grid;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kThreads), f->lds_bytes, f->ctx->stream, a);
   LSDR_HIP(hipGetLastError());
   *produced = count;
   *consumed = count * D;
