@@ -72,6 +72,9 @@ int lsdr_event_create(lsdr_ctx *ctx, lsdr_event **ev);
 void lsdr_event_destroy(lsdr_event *ev);
 int lsdr_event_record(lsdr_event *ev);
 int lsdr_event_elapsed_ms(lsdr_event *start, lsdr_event *stop, float *ms); /* synchronises on `stop` */
+/* Make all later work on `ctx` wait for `ev` (recorded on another ctx's stream): the edge between
+ * two blocks that run on different HIP streams (e.g. fir_filter of batch k+1 ‖ cstln_receiver of batch k). */
+int lsdr_ctx_wait_event(lsdr_ctx *ctx, lsdr_event *ev);
 
 /* ----------------------------------------------------- host-side table design
  * Replaces filtergen.h (coefficients are *inputs* to the kernels and must be

@@ -81,6 +81,7 @@ _sig("lsdr_event_create", C.c_int, [vp, C.POINTER(vp)])
 _sig("lsdr_event_destroy", None, [vp])
 _sig("lsdr_event_record", C.c_int, [vp])
 _sig("lsdr_event_elapsed_ms", C.c_int, [vp, vp, C.POINTER(c_f)])
+_sig("lsdr_ctx_wait_event", C.c_int, [vp, vp])
 _sig("lsdr_filtergen_lowpass", C.c_int, [C.c_int, c_f, c_f, vp])
 _sig("lsdr_filtergen_root_raised_cosine", C.c_int, [C.c_int, c_f, c_f, vp])
 _sig("lsdr_filtergen_normalize_dcgain", None, [C.c_int, vp, c_f])
@@ -216,6 +217,9 @@ class Ctx:
         ms = c_f()
         check(lib.lsdr_event_elapsed_ms(a, b, C.byref(ms)))
         return ms.value
+
+    def wait_event(self, e):
+        check(lib.lsdr_ctx_wait_event(self.h, e))
 
     def timer_start(self):
         check(lib.lsdr_timer_start(self.h))

@@ -31,6 +31,14 @@
 namespace {
 
 constexpr int kChunk = 128;   // cstln_receiver::chunk_size, sdr.h:706
+
+#ifdef LSDR_RX_TRACE   // instrumented builds only (tools/): per-phase cycle sums of the symbol body
+__device__ unsigned long long g_rx_probe[8];
+#define LSDR_RXP(i) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); unsigned long long t__ = __builtin_amdgcn_s_memtime(); \
+  if (i > 0 && threadIdx.x == 0 && blockIdx.x == 1) atomicAdd(&g_rx_probe[i], t__ - rxp_t); if (i == 3 && threadIdx.x == 0 && blockIdx.x == 1) atomicAdd(&g_rx_probe[0], 1ull); rxp_t = t__; }
+#else
+#define LSDR_RXP(i)
+#endif
 constexpr float kCstlnAmp = 75.0f;  // sdr.h:297
 
 struct __attribute__((aligned(8))) lut_entry {
@@ -129,11 +137,30 @@ __device__ __forceinline__ int rx_chunk(const rx_tables &T, const rx_consts &C, 
   float h1pr = s.hist[4], h1pi = s.hist[5], h1cr = s.hist[6], h1ci = s.hist[7];
   float h2pr = s.hist[8], h2pi = s.hist[9], h2cr = s.hist[10], h2ci = s.hist[11];
 
-  for (int n = 0; n < kChunk; ++n) {
-    if (mu < 1) {
+  // The reference walks the chunk sample by sample: `if (mu<1) {symbol}; ++pin; --mu;
+  // phase += freqw` (sdr.h:800-847).  Here the samples without a symbol are consumed by
+  // the short inner loop (the same two float operations per sample, in the same
+  // order), so the expensive symbol body is executed once per loop trip by every lane
+  // of a wavefront together — lanes of the tiled kernel hit their symbol instants at
+  // different sample indices and would otherwise serialise.  Bit-identical results.
+#ifdef LSDR_RX_TRACE
+  unsigned long long rxp_t = 0;
+#endif
+  int n = 0;
+  while (true) {
+    while (!(mu < 1) && n < kChunk) {
+      mu = mu - 1;
+      phase += freqw;
+      ++n;
+    }
+    if (n >= kChunk) break;
+    {
+      LSDR_RXP(0)
       sg = interp<SAMP>(T, C, s, pin + n, mu, phase);
       sv = make_float2(sg.x * agc_gain, sg.y * agc_gain);
+      LSDR_RXP(1)
       const lut_entry e = T.lut[lut_index(sv.x, sv.y)];
+      LSDR_RXP(2)
       lsdr_softsymbol ss;
       ss.cost = e.cost; ss.symbol = e.symbol; ss.pad = 0;
       emit(ss);
@@ -156,9 +183,11 @@ __device__ __forceinline__ int rx_chunk(const rx_tables &T, const rx_consts &C, 
       if (mucorr > max_mucorr) mucorr = max_mucorr;
       mu += mucorr;
       mu += C.omega;
+      LSDR_RXP(3)
     }
     mu = mu - 1;
     phase += freqw;
+    ++n;
   }
   phase = fmod65536(phase);  // sdr.h:855
 
@@ -304,6 +333,7 @@ struct rx_tiled_args {
   unsigned long long total_chunks;     // chunks processed by this run
   unsigned first_chunks, tile_chunks, warm_chunks;
   unsigned n_tiles;
+  unsigned lanes_per_wave;             // active lanes (tiles) per wavefront
   unsigned stage_stride;               // symbols reserved per tile in `stage`
   lsdr_softsymbol *stage;
   rx_tile_info *info;
@@ -318,7 +348,12 @@ struct rx_tiled_args {
 // starts `warm_chunks` early from the carried tracking state with mu = phase = 0.
 template <int SAMP>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
-  const unsigned j = blockIdx.x * 64 + threadIdx.x;
+  // Only `lanes_per_wave` lanes of each wavefront carry a tile: every table / sample access of
+  // this kernel is a fully divergent gather whose latency grows with the number of distinct
+  // cache lines per instruction (~1250 cycles at 64 lanes, measured), the recurrence is latency-
+  // bound and the GPU is otherwise idle — narrower waves, more of them.
+  if (threadIdx.x >= a.lanes_per_wave) return;
+  const unsigned j = blockIdx.x * a.lanes_per_wave + threadIdx.x;
   if (j >= a.n_tiles) return;
   rx_state_dev s = *a.state;
   unsigned long long c0, c1;     // body chunk range
@@ -362,6 +397,118 @@ __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
   if (j == a.n_tiles - 1) {
     s.meas_count = (a.meas_base + a.total_chunks * kChunk) % a.C.meas_decimation;
     *a.state = s;
+  }
+}
+
+// Seam pass: reconciles neighbouring tiles (device-side, one workgroup).
+//  * carrier quadrant: tile j locked k_j·(65536/R) away from where tile j−1 ended → running
+//    rotation (prefix sum mod R) used to relabel its symbols;
+//  * symbol timing: mu at the start of tile j vs mu at the end of tile j−1 differ by ≈ ±omega
+//    when the two tiles disagree on which side of the boundary one symbol instant falls →
+//    drop the duplicate / insert the lost symbol (the warm-up's last symbol);
+//  * output offsets: exclusive prefix sum of the adjusted counts.
+struct rx_seam_result { unsigned long long total; unsigned rot_final, ndup, nmiss, nbad; };
+
+struct seam_step { unsigned insert, drop, k, bad; };
+
+__device__ __forceinline__ seam_step seam_eval(const rx_tile_info &prev, const rx_tile_info &cur, float omega, int R,
+                                               float quad) {
+  seam_step r; r.insert = 0; r.drop = 0; r.bad = 0;
+  const float d = cur.mu_begin - prev.mu_end;
+  if (d > omega / 2 && cur.has_pre) r.insert = 1;
+  else if (d < -omega / 2 && cur.count > 0) r.drop = 1;
+  float dphi = fmodf(cur.phase_begin - prev.phase_end, 65536.0f);
+  if (dphi < 0) dphi += 65536.0f;
+  const int k = (int)floorf(dphi / quad + 0.5f);
+  const float perr = fabsf(dphi - k * quad);
+  float dm = fabsf(d);
+  if (fabsf(dm - omega) < dm) dm = fabsf(dm - omega);
+  if (perr > quad / 4 || dm > 0.5f) r.bad = 1;
+  r.k = (unsigned)(k % R);
+  return r;
+}
+
+// (A) per-seam evaluation, fully parallel: step[j] = what tile j contributes.
+struct rx_seam_stepv { int add; uint8_t k, insert, drop, bad; };
+
+__global__ __launch_bounds__(256) void k_rx_seam_eval(const rx_tile_info *info, rx_seam_stepv *step, unsigned n_tiles,
+                                                      float omega, int R, float quad) {
+  const unsigned j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n_tiles) return;
+  const rx_tile_info cur = info[j];
+  rx_seam_stepv v; v.add = (int)cur.count; v.k = 0; v.insert = 0; v.drop = 0; v.bad = 0;
+  if (j > 0) {
+    const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad);
+    v.add += (int)st.insert - (int)st.drop;
+    v.k = (uint8_t)st.k; v.insert = (uint8_t)st.insert; v.drop = (uint8_t)st.drop; v.bad = (uint8_t)st.bad;
+  }
+  step[j] = v;
+}
+
+// (B) one workgroup: exclusive scan of (add, k mod R) over the tiles in LDS-staged segments of
+// 8192 (coalesced loads, 8 consecutive tiles per thread), writes the per-tile fix-ups.
+__global__ __launch_bounds__(1024) void k_rx_seam_scan(const rx_seam_stepv *step, rx_tile_fix *fix, unsigned n_tiles, int R,
+                                                       rx_seam_result *res) {
+  constexpr unsigned SEG = 8192, PER = 8;
+  const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
+  __shared__ rx_seam_stepv s_step[SEG];
+  __shared__ unsigned long long s_cnt[16];
+  __shared__ unsigned s_rot[16], s_dup[16], s_miss[16], s_bad[16];
+  __shared__ unsigned long long s_carry_cnt;
+  __shared__ unsigned s_carry_rot, s_tot_dup, s_tot_miss, s_tot_bad;
+  const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { s_carry_cnt = 0; s_carry_rot = 0; s_tot_dup = 0; s_tot_miss = 0; s_tot_bad = 0; }
+  for (unsigned base = 0; base < n_tiles; base += SEG) {
+    __syncthreads();
+    for (unsigned i = tid; i < SEG; i += 1024) {
+      rx_seam_stepv z; z.add = 0; z.k = 0; z.insert = 0; z.drop = 0; z.bad = 0;
+      s_step[i] = (base + i < n_tiles) ? step[base + i] : z;
+    }
+    __syncthreads();
+    unsigned long long cnt = 0; unsigned rot = 0, nd = 0, nm = 0, nb = 0;
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q) {
+      const rx_seam_stepv v = s_step[tid * PER + q];
+      cnt += (unsigned long long)(long long)v.add; rot = (rot + v.k) & rmask;
+      nd += v.drop; nm += v.insert; nb += v.bad;
+    }
+    unsigned long long icnt = cnt; unsigned irot = rot;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned long long oc = __shfl_up(icnt, d, 64);
+      const unsigned orot = __shfl_up(irot, d, 64);
+      if (lane >= (unsigned)d) { icnt += oc; irot = (irot + orot) & rmask; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_down(nd, d, 64); nm += __shfl_down(nm, d, 64); nb += __shfl_down(nb, d, 64); }
+    if (lane == 63) { s_cnt[wv] = icnt; s_rot[wv] = irot; }
+    if (lane == 0) { s_dup[wv] = nd; s_miss[wv] = nm; s_bad[wv] = nb; }
+    __syncthreads();
+    const unsigned long long carry_cnt = s_carry_cnt;
+    const unsigned carry_rot = s_carry_rot;
+    unsigned long long woff = carry_cnt; unsigned wrot = carry_rot;
+    for (unsigned i = 0; i < wv; ++i) { woff += s_cnt[i]; wrot = (wrot + s_rot[i]) & rmask; }
+    unsigned long long off = woff + (icnt - cnt);
+    unsigned r = (wrot + irot + (unsigned)R - rot) & rmask;
+#pragma unroll
+    for (unsigned q = 0; q < PER; ++q) {
+      const unsigned j = base + tid * PER + q;
+      const rx_seam_stepv v = s_step[tid * PER + q];
+      r = (r + v.k) & rmask;
+      if (j < n_tiles) {
+        rx_tile_fix f; f.out_offset = off; f.rot = r; f.drop_first = v.drop; f.insert_pre = v.insert;
+        fix[j] = f;
+      }
+      off += (unsigned long long)(long long)v.add;
+    }
+    __syncthreads();
+    if (tid == 1023) { s_carry_cnt = off; s_carry_rot = r; }
+    if (tid == 0) for (int i = 0; i < 16; ++i) { s_tot_dup += s_dup[i]; s_tot_miss += s_miss[i]; s_tot_bad += s_bad[i]; }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    res->total = s_carry_cnt; res->rot_final = s_carry_rot;
+    res->ndup = s_tot_dup; res->nmiss = s_tot_miss; res->nbad = s_tot_bad;
   }
 }
 
@@ -414,6 +561,8 @@ struct lsdr_rx {
   lsdr_softsymbol *d_stage; size_t stage_cap;
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
   uint8_t *d_relabel;
+  struct rx_seam_result *d_seam;
+  struct rx_seam_stepv *d_step;
   std::vector<uint8_t> relabel;   // [nrotations][256]
   unsigned last_tiles, last_dup, last_miss, last_badseam;  // diagnostics of the last tiled run
 };
@@ -489,7 +638,8 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
   // least omega-0.1 per symbol, sdr.h:834-840).
   const unsigned sym_per_chunk = (unsigned)(kChunk / (r->omega - 0.1f)) + 2;
   size_t chunks = (n_in - ra) / kChunk;
-  if ((size_t)sym_per_chunk * chunks > cap_out) chunks = cap_out / sym_per_chunk;
+  // (+1 symbol per seam: a repaired seam may re-insert a warm-up symbol)
+  if ((size_t)(sym_per_chunk + 1) * chunks > cap_out) chunks = cap_out / (sym_per_chunk + 1);
   if (!chunks) return LSDR_OK;
   const unsigned first = Lc > Wc ? Lc : Wc;
   unsigned n_tiles = 1;
@@ -497,7 +647,8 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
   const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
 
   if (r->tiles_cap < n_tiles) {
-    (void)hipFree(r->d_info); (void)hipFree(r->d_fix);
+    (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_step);
+    LSDR_HIP(hipMalloc((void **)&r->d_step, n_tiles * sizeof(rx_seam_stepv)));
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
     r->tiles_cap = n_tiles;
@@ -532,50 +683,36 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
   a.meas = want_meas ? r->d_meas : nullptr;
   a.meas_base = meas_base;
   rx_fill_consts(r, a.C, a.T);
-  const unsigned blocks = (n_tiles + 63) / 64;
+  {
+    const char *e = getenv("LSDR_RX_LANES");   // tuning hook
+    int lpw = e ? atoi(e) : 4;
+    if (lpw < 1) lpw = 1;
+    if (lpw > 64) lpw = 64;
+    a.lanes_per_wave = (unsigned)lpw;
+  }
+  const unsigned blocks = (n_tiles + a.lanes_per_wave - 1) / a.lanes_per_wave;
   if (r->cfg.sampler == LSDR_SAMP_NEAREST) hipLaunchKernelGGL(k_rx_tiles<0>, dim3(blocks), dim3(64), 0, c->stream, a);
   else hipLaunchKernelGGL(k_rx_tiles<1>, dim3(blocks), dim3(64), 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
 
-  // ---- seam pass (host): quadrant of the carrier phase, lost / duplicated symbols, offsets
-  std::vector<rx_tile_info> info(n_tiles);
-  LSDR_HIP(hipMemcpyAsync(info.data(), r->d_info, n_tiles * sizeof(rx_tile_info), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipStreamSynchronize(c->stream));
-  std::vector<rx_tile_fix> fix(n_tiles);
+  // ---- seam pass + compaction, all on the stream (one synchronisation at the end)
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  const float omega = r->omega;
-  unsigned rot = 0, ndup = 0, nmiss = 0, nbad = 0;
-  unsigned long long off = 0;
-  for (unsigned j = 0; j < n_tiles; ++j) {
-    rx_tile_fix f; f.drop_first = 0; f.insert_pre = 0;
-    if (j > 0) {
-      float d = info[j].mu_begin - info[j - 1].mu_end;
-      if (d > omega / 2 && info[j].has_pre) { f.insert_pre = 1; ++nmiss; }
-      else if (d < -omega / 2 && info[j].count > 0) { f.drop_first = 1; ++ndup; }
-      float dphi = fmodf(info[j].phase_begin - info[j - 1].phase_end, 65536.0f);
-      if (dphi < 0) dphi += 65536.0f;
-      int k = (int)floorf(dphi / quad + 0.5f);
-      float perr = fabsf(dphi - k * quad);
-      float dm = fabsf(d);
-      if (fabsf(dm - omega) < dm) dm = fabsf(dm - omega);
-      if (perr > quad / 4 || dm > 0.5f) ++nbad;
-      rot = (rot + (unsigned)k) % (unsigned)R;
-    }
-    f.rot = rot;
-    f.out_offset = off;
-    off += info[j].count + f.insert_pre - f.drop_first;
-    fix[j] = f;
-  }
-  if (off > cap_out) { lsdr_set_error("cstln_receiver(tiled): output overflow (%llu > %zu)", off, cap_out); return LSDR_E_ARG; }
-  r->last_tiles = n_tiles; r->last_dup = ndup; r->last_miss = nmiss; r->last_badseam = nbad;
-  LSDR_HIP(hipMemcpyAsync(r->d_fix, fix.data(), n_tiles * sizeof(rx_tile_fix), hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_rx_seam_eval, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream,
+                     (const rx_tile_info *)r->d_info, r->d_step, n_tiles, r->omega, R, quad);
+  hipLaunchKernelGGL(k_rx_seam_scan, dim3(1), dim3(1024), 0, c->stream, (const rx_seam_stepv *)r->d_step, r->d_fix,
+                     n_tiles, R, r->d_seam);
   hipLaunchKernelGGL(k_rx_compact, dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
                      stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
                      (const uint8_t *)r->d_relabel, n_tiles, out);
   LSDR_HIP(hipGetLastError());
+  rx_seam_result sr;
+  LSDR_HIP(hipMemcpyAsync(&sr, r->d_seam, sizeof(sr), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));
+  const unsigned rot = sr.rot_final;
+  const unsigned long long off = sr.total;
+  r->last_tiles = n_tiles; r->last_dup = sr.ndup; r->last_miss = sr.nmiss; r->last_badseam = sr.nbad;
   // Bring the carried carrier phase back into the frame of tile 0 so that the next
   // run continues with the same symbol labelling.
   if (rot) {
@@ -598,6 +735,12 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
 }
 
 extern "C" {
+
+#ifdef LSDR_RX_TRACE
+int lsdr_rx_probe_read(unsigned long long *host) {
+  return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_rx_probe), sizeof(g_rx_probe)) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_ARG(c && cfg && out);
@@ -665,7 +808,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_meas = nullptr; r->meas_cap = 0;
   r->d_cstln = nullptr; r->cstln_cap = 0;
   r->d_stage = nullptr; r->stage_cap = 0;
-  r->d_info = nullptr; r->d_fix = nullptr; r->tiles_cap = 0;
+  r->d_info = nullptr; r->d_fix = nullptr; r->d_step = nullptr; r->tiles_cap = 0;
   r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
   // Relabel tables for the tiled mode: relabel[k][s] = symbol whose constellation point is
   // point[s] rotated by +k·(360°/nrotations) (nearest point; exact for the PSK/APSK/QAM sets).
@@ -686,6 +829,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
         r->relabel[(size_t)k * 256 + s] = (uint8_t)best;
       }
     }
+    LSDR_HIP(hipMalloc((void **)&r->d_seam, sizeof(rx_seam_result)));
     LSDR_HIP(hipMalloc((void **)&r->d_relabel, r->relabel.size()));
     LSDR_HIP(hipMemcpy(r->d_relabel, r->relabel.data(), r->relabel.size(), hipMemcpyHostToDevice));
   }
@@ -700,7 +844,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
-  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel);
+  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_step);
   delete r;
 }
 

@@ -162,6 +162,11 @@ int lsdr_event_record(lsdr_event *e) {
   LSDR_HIP(hipEventRecord(e->ev, e->ctx->stream));
   return LSDR_OK;
 }
+int lsdr_ctx_wait_event(lsdr_ctx *c, lsdr_event *e) {
+  LSDR_ARG(c && e);
+  LSDR_HIP(hipStreamWaitEvent(c->stream, e->ev, 0));
+  return LSDR_OK;
+}
 int lsdr_event_elapsed_ms(lsdr_event *a, lsdr_event *b, float *ms) {
   LSDR_ARG(a && b && ms);
   LSDR_HIP(hipEventSynchronize(b->ev));
