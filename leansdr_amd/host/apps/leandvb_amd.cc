@@ -1,0 +1,261 @@
+// leansdr_amd/host/apps/leandvb_amd.cc — the leandvb receive graph on MI355X.
+//
+// Mirrors the front half of the reference's graph builder (src/apps/leandvb.cc:157-515):
+//   stdin → [cconverter | scaler] → [fir_filter + decimation (--resample)] | [decimator]
+//         → cstln_receiver(sampler) → soft symbols
+// with the same option names and the same parameter arithmetic, built on the host
+// framework in ../leansdr (reference class surface) whose blocks call the HIP kernels
+// through the C ABI.  Device pipebufs are sized by --buf-factor (default 4096: large
+// batches, few launches).  Until the FEC tail (deconvolution/Viterbi → mpeg_sync →
+// deinterleaver → RS → derandomizer) is wired to its GPU blocks the program writes the
+// soft-symbol stream (4-byte softsymbol records) to stdout; `--fd-info N` prints the
+// FREQ/SS/MER lines of the reference (leandvb.cc:600-616).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "leansdr/framework.h"
+#include "leansdr/generic.h"
+#include "leansdr/dsp.h"
+#include "leansdr/sdr.h"
+#include "leansdr/filtergen.h"
+
+using namespace leansdr;
+
+struct config {
+  bool verbose, debug;
+  enum { INPUT_U8, INPUT_F32 } input_format;
+  float float_scale;
+  float Fs, Fm;
+  cstln_lut<256>::predef constellation;
+  int fec;  // LSDR_FEC*
+  float Ftune;
+  bool allow_drift;
+  bool viterbi;
+  bool resample;
+  float resample_rej;
+  int decim;
+  enum { SAMP_NEAREST, SAMP_LINEAR, SAMP_RRC } sampler;
+  int rrc_steps;
+  float rrc_rej, rolloff;
+  unsigned long buf_factor;
+  int fd_info;
+  float Finfo;
+  bool tiled;
+  unsigned tile_len, tile_warmup;
+  int device;
+  config()
+      : verbose(false), debug(false), input_format(INPUT_U8), float_scale(1.0), Fs(2.4e6), Fm(2e6),
+        constellation(cstln_lut<256>::QPSK), fec(LSDR_FEC12), Ftune(0), allow_drift(false), viterbi(false),
+        resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
+        buf_factor(4096), fd_info(-1), Finfo(5), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
+};
+
+static int decimation(float Fin, float Fout) {
+  int d = Fin / Fout;
+  return max(d, 1);
+}
+
+static int run(config &cfg) {
+  scheduler sch;
+  sch.verbose = cfg.verbose;
+  sch.debug = cfg.debug;
+  lsdr_ctx *ctx = NULL;
+  lsdr_check(lsdr_ctx_create(cfg.device, NULL, &ctx), "lsdr_ctx_create");
+
+  // Buffer sizes follow leandvb.cc:185-202.
+  unsigned long BUF_BASEBAND = 4096 * cfg.buf_factor;
+  unsigned long BUF_SYMBOLS = 1024 * cfg.buf_factor;
+  unsigned long BUF_SLOW = cfg.buf_factor;
+
+  // INPUT (host pipebuf) → HBM
+  pipebuf<cf32> *p_preprocessed = NULL;
+  float fuse_scale = 0;
+  pipebuf<cu8> *p_rawu8 = NULL;
+  if (cfg.input_format == config::INPUT_U8) {
+    pipebuf<cu8> *p_stdin = new pipebuf<cu8>(&sch, "stdin", BUF_BASEBAND);
+    new file_reader<cu8>(&sch, 0, *p_stdin);
+    p_rawu8 = new pipebuf<cu8>(&sch, "stdin(hbm)", BUF_BASEBAND, ctx);
+    new h2d_copier<cu8>(&sch, ctx, *p_stdin, *p_rawu8);
+    pipebuf<cf32> *p_rawiq = new pipebuf<cf32>(&sch, "rawiq", BUF_BASEBAND, ctx);
+    new cconverter<u8, 128, f32, 0, 1, 1>(&sch, *p_rawu8, *p_rawiq);
+    p_preprocessed = p_rawiq;
+  } else {
+    pipebuf<cf32> *p_stdin = new pipebuf<cf32>(&sch, "stdin", BUF_BASEBAND);
+    new file_reader<cf32>(&sch, 0, *p_stdin);
+    pipebuf<cf32> *p_dev = new pipebuf<cf32>(&sch, "stdin(hbm)", BUF_BASEBAND, ctx);
+    new h2d_copier<cf32>(&sch, ctx, *p_stdin, *p_dev);
+    if (cfg.resample) {
+      fuse_scale = cfg.float_scale;  // scaler fused into the fir_filter's load stage
+      p_preprocessed = p_dev;
+    } else {
+      pipebuf<cf32> *p_rawiq = new pipebuf<cf32>(&sch, "rawiq", BUF_BASEBAND, ctx);
+      new scaler<float, cf32, cf32>(&sch, cfg.float_scale, *p_dev, *p_rawiq);
+      p_preprocessed = p_rawiq;
+    }
+  }
+
+  // FILTERING (leandvb.cc:353-384)
+  fir_filter<cf32, float> *r_resample = NULL;
+  int decim = 1;
+  if (cfg.resample) {
+    if (cfg.decim > 1) decim = cfg.decim;
+    else {
+      float target_Fs = cfg.Fm * 4;
+      decim = cfg.Fs / target_Fs;
+      if (decim < 1) decim = 1;
+    }
+    float transition = (cfg.Fm / 2) * cfg.rolloff;
+    int order = cfg.resample_rej * cfg.Fs / (22 * transition);
+    order = ((order + 1) / 2) * 2;
+    if (cfg.verbose) fprintf(stderr, "Inserting filter: order %d, decimation %d.\n", order, decim);
+    pipebuf<cf32> *p_resampled = new pipebuf<cf32>(&sch, "resampled", BUF_BASEBAND, ctx);
+    float *coeffs;
+    float Fcut = (cfg.Fm / 2) * (1 + cfg.rolloff / 2) / cfg.Fs;
+    int ncoeffs = filtergen::lowpass(order, Fcut, &coeffs);
+    filtergen::normalize_dcgain(ncoeffs, coeffs, 1);
+    r_resample = new fir_filter<cf32, float>(&sch, ncoeffs, coeffs, *p_preprocessed, *p_resampled, decim, fuse_scale);
+    p_preprocessed = p_resampled;
+    cfg.Fs /= decim;
+  } else if (cfg.decim > 1) {
+    decim = cfg.decim;
+    pipebuf<cf32> *p_decimated = new pipebuf<cf32>(&sch, "decimated", BUF_BASEBAND, ctx);
+    new decimator<cf32>(&sch, decim, *p_preprocessed, *p_decimated);
+    p_preprocessed = p_decimated;
+    cfg.Fs /= decim;
+  }
+
+  // RECEIVER (leandvb.cc:425-502)
+  pipebuf<softsymbol> p_symbols(&sch, "PSK soft-symbols", BUF_SYMBOLS, ctx);
+  pipebuf<f32> p_freq(&sch, "freq", BUF_SLOW);
+  pipebuf<f32> p_ss(&sch, "SS", BUF_SLOW);
+  pipebuf<f32> p_mer(&sch, "MER", BUF_SLOW);
+  sampler_interface<f32> *sampler;
+  switch (cfg.sampler) {
+    case config::SAMP_NEAREST: sampler = new nearest_sampler<float>(); break;
+    case config::SAMP_LINEAR: sampler = new linear_sampler<float>(); break;
+    default: {
+      float *coeffs;
+      if (cfg.rrc_steps == 0) cfg.rrc_steps = max(1, (int)(64 * cfg.Fm / cfg.Fs));
+      float Frrc = cfg.Fs * cfg.rrc_steps;
+      float transition = (cfg.Fm / 2) * cfg.rolloff;
+      int order = cfg.rrc_rej * Frrc / (22 * transition);
+      int ncoeffs = filtergen::root_raised_cosine(order, cfg.Fm / Frrc, cfg.rolloff, &coeffs);
+      if (cfg.verbose) fprintf(stderr, "RRC interpolator: %d steps, %d coeffs.\n", cfg.rrc_steps, ncoeffs);
+      sampler = new fir_sampler<float, float>(ncoeffs, coeffs, cfg.rrc_steps);
+    }
+  }
+  cstln_receiver<f32> demod(&sch, sampler, *p_preprocessed, p_symbols, &p_freq, &p_ss, &p_mer, NULL);
+  demod.cstln = new cstln_lut<256>(cfg.constellation, cfg.fec);
+  demod.set_omega(cfg.Fs / cfg.Fm);
+  if (cfg.Ftune) demod.set_freq(cfg.Ftune / cfg.Fs);
+  if (cfg.allow_drift) demod.set_allow_drift(true);
+  if (cfg.viterbi) demod.pll_adjustment /= 6;
+  demod.meas_decimation = decimation(cfg.Fs, cfg.Finfo);
+  if (cfg.tiled) {
+    demod.mode = LSDR_RX_TILED;
+    demod.tile_len = cfg.tile_len;
+    demod.tile_warmup = cfg.tile_warmup;
+  }
+
+  // TRACKING FILTERS (leandvb.cc:506-510): the receiver→filter feedback edge stays on the host.
+  if (r_resample) {
+    r_resample->freq_tap = &demod.freq_tap;
+    r_resample->tap_multiplier = 1.0 / decim;
+    r_resample->freq_tol = cfg.Fm / (cfg.Fs * decim) * 0.1;
+  }
+
+  // OUTPUT: soft symbols back to the host, to stdout.
+  pipebuf<softsymbol> p_symbols_host(&sch, "soft-symbols(host)", BUF_SYMBOLS);
+  new d2h_copier<softsymbol>(&sch, ctx, p_symbols, p_symbols_host);
+  new file_writer<softsymbol>(&sch, p_symbols_host, 1);
+
+  if (cfg.fd_info >= 0) {
+    new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info);
+    new file_printer<f32>(&sch, "SS %f\n", p_ss, cfg.fd_info);
+    new file_printer<f32>(&sch, "MER %.1f\n", p_mer, cfg.fd_info);
+  } else {
+    // unread measurement pipes never block their writer (pipebuf with zero readers packs to empty)
+  }
+
+  sch.run();
+  sch.shutdown();
+  if (cfg.debug) sch.dump();
+  lsdr_ctx_destroy(ctx);
+  return 0;
+}
+
+static void usage(const char *name, FILE *f, int c) {
+  fprintf(f,
+          "Usage: %s [options]  < IQ  > soft-symbols\n"
+          "MI355X build of the leandvb receive path (front end + constellation receiver).\n"
+          "  --u8 | --f32           input format (default u8)\n"
+          "  --float-scale FLOAT    scale for --f32 input\n"
+          "  -f HZ, --sr HZ         sample rate, symbol rate\n"
+          "  --const STRING         QPSK (default), BPSK, 8PSK, 16APSK, 32APSK\n"
+          "  --cr STRING            1/2 (default), 2/3, 3/4, 5/6, 7/8 (APSK radii)\n"
+          "  --tune HZ, --drift     receiver bias, unlimited drift\n"
+          "  --resample, --resample-rej FLOAT, --decim N, --roll-off FLOAT\n"
+          "  --sampler nearest|linear|rrc, --rrc-steps N, --rrc-rej FLOAT\n"
+          "  --viterbi              PLL parameters for low SNR (pll_adjustment/6)\n"
+          "  --buf-factor N         pipebuf scale (default 4096)\n"
+          "  --tiled [--tile-len N --tile-warmup N]   throughput mode of the receiver\n"
+          "  --fd-info FD, --device N, -v, -d\n",
+          name);
+  exit(c);
+}
+
+int main(int argc, const char *argv[]) {
+  config cfg;
+  for (int i = 1; i < argc; ++i) {
+    const char *a = argv[i];
+    auto need = [&](void) -> const char * { if (i + 1 >= argc) usage(argv[0], stderr, 1); return argv[++i]; };
+    if (!strcmp(a, "-h")) usage(argv[0], stdout, 0);
+    else if (!strcmp(a, "-v")) cfg.verbose = true;
+    else if (!strcmp(a, "-d")) cfg.debug = true;
+    else if (!strcmp(a, "--u8")) cfg.input_format = config::INPUT_U8;
+    else if (!strcmp(a, "--f32")) cfg.input_format = config::INPUT_F32;
+    else if (!strcmp(a, "--float-scale")) cfg.float_scale = atof(need());
+    else if (!strcmp(a, "-f")) cfg.Fs = atof(need());
+    else if (!strcmp(a, "--sr")) cfg.Fm = atof(need());
+    else if (!strcmp(a, "--tune")) cfg.Ftune = atof(need());
+    else if (!strcmp(a, "--drift")) cfg.allow_drift = true;
+    else if (!strcmp(a, "--viterbi")) cfg.viterbi = true;
+    else if (!strcmp(a, "--resample")) cfg.resample = true;
+    else if (!strcmp(a, "--resample-rej")) cfg.resample_rej = atof(need());
+    else if (!strcmp(a, "--decim")) cfg.decim = atoi(need());
+    else if (!strcmp(a, "--roll-off")) cfg.rolloff = atof(need());
+    else if (!strcmp(a, "--rrc-steps")) cfg.rrc_steps = atoi(need());
+    else if (!strcmp(a, "--rrc-rej")) cfg.rrc_rej = atof(need());
+    else if (!strcmp(a, "--buf-factor")) cfg.buf_factor = atol(need());
+    else if (!strcmp(a, "--fd-info")) cfg.fd_info = atoi(need());
+    else if (!strcmp(a, "--device")) cfg.device = atoi(need());
+    else if (!strcmp(a, "--tiled")) cfg.tiled = true;
+    else if (!strcmp(a, "--tile-len")) cfg.tile_len = atoi(need());
+    else if (!strcmp(a, "--tile-warmup")) cfg.tile_warmup = atoi(need());
+    else if (!strcmp(a, "--sampler")) {
+      const char *s = need();
+      if (!strcmp(s, "nearest")) cfg.sampler = config::SAMP_NEAREST;
+      else if (!strcmp(s, "linear")) cfg.sampler = config::SAMP_LINEAR;
+      else if (!strcmp(s, "rrc")) cfg.sampler = config::SAMP_RRC;
+      else usage(argv[0], stderr, 1);
+    } else if (!strcmp(a, "--const")) {
+      const char *s = need();
+      static const struct { const char *n; cstln_lut<256>::predef v; } tab[] = {
+          {"BPSK", cstln_lut<256>::BPSK}, {"QPSK", cstln_lut<256>::QPSK}, {"8PSK", cstln_lut<256>::PSK8},
+          {"16APSK", cstln_lut<256>::APSK16}, {"32APSK", cstln_lut<256>::APSK32}, {"64APSKe", cstln_lut<256>::APSK64E},
+          {"16QAM", cstln_lut<256>::QAM16}, {"64QAM", cstln_lut<256>::QAM64}, {"256QAM", cstln_lut<256>::QAM256}};
+      bool ok = false;
+      for (auto &t : tab) if (!strcmp(s, t.n)) { cfg.constellation = t.v; ok = true; }
+      if (!ok) usage(argv[0], stderr, 1);
+    } else if (!strcmp(a, "--cr")) {
+      const char *s = need();
+      static const struct { const char *n; int v; } tab[] = {{"1/2", LSDR_FEC12}, {"2/3", LSDR_FEC23}, {"4/6", LSDR_FEC46},
+          {"3/4", LSDR_FEC34}, {"5/6", LSDR_FEC56}, {"7/8", LSDR_FEC78}, {"4/5", LSDR_FEC45}, {"8/9", LSDR_FEC89}, {"9/10", LSDR_FEC910}};
+      bool ok = false;
+      for (auto &t : tab) if (!strcmp(s, t.n)) { cfg.fec = t.v; ok = true; }
+      if (!ok) usage(argv[0], stderr, 1);
+    } else usage(argv[0], stderr, 1);
+  }
+  return run(cfg);
+}

@@ -1,0 +1,134 @@
+// leansdr_amd/host/leansdr/dsp.h — DSP blocks with the reference's class surface
+// (dsp.h:33-54 cconverter, :140-160 scaler, :219-285 fir_filter) whose run() is one
+// call through the C ABI into the HIP kernels.  All pipebufs of these blocks live
+// in HBM (constructed with the lsdr_ctx).  There is no CPU implementation here.
+#ifndef LEANSDR_AMD_DSP_H
+#define LEANSDR_AMD_DSP_H
+
+#include "leansdr/framework.h"
+#include "leansdr/math.h"
+
+namespace leansdr {
+
+inline lsdr_ctx *pipe_ctx(lsdr_ctx *a, lsdr_ctx *b, const char *who) {
+  if (!a || a != b) fail(who);
+  return a;
+}
+
+// cconverter<u8,128,f32,0,1,1>: the only instantiation leandvb uses (leandvb.cc:215).
+template <typename Tin, int Zin, typename Tout, int Zout, int Gn, int Gd>
+struct cconverter;
+
+template <>
+struct cconverter<u8, 128, float, 0, 1, 1> : runnable {
+  cconverter(scheduler *sch, pipebuf<complex<u8> > &i, pipebuf<complex<float> > &o)
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i.dev, o.dev, "cconverter: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {}
+  void run() {
+    unsigned long count = min(in.readable(), out.writable());
+    if (!count) return;
+    lsdr_check(lsdr_cconverter_u8_run(ctx, (const lsdr_cu8 *)in.rd(), count, (lsdr_cf32 *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<complex<u8> > in;
+  pipewriter<complex<float> > out;
+};
+
+template <typename Tscale, typename Tin, typename Tout>
+struct scaler;
+
+template <>
+struct scaler<float, complex<float>, complex<float> > : runnable {
+  float scale;
+  scaler(scheduler *sch, float s, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o)
+      : runnable(sch, "scaler"), scale(s), ctx(pipe_ctx(i.dev, o.dev, "scaler: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {}
+  void run() {
+    unsigned long count = min(in.readable(), out.writable());
+    if (!count) return;
+    lsdr_check(lsdr_scaler_run(ctx, scale, (const lsdr_cf32 *)in.rd(), count, (lsdr_cf32 *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<complex<float> > in;
+  pipewriter<complex<float> > out;
+};
+
+// fir_filter<cf32,float> — same constructor and public tracking members as dsp.h:219-285.
+// `fuse_u8` / `fuse_scale` (additions) let a graph builder drop the cconverter / scaler
+// block in front and have the filter read the raw stream (bit-identical result).
+template <typename T, typename Tc>
+struct fir_filter;
+
+template <>
+struct fir_filter<complex<float>, float> : runnable {
+  float *freq_tap;        // → cstln_receiver::freq_tap (leandvb.cc:506-510)
+  float tap_multiplier;
+  float freq_tol;
+
+  fir_filter(scheduler *sch, int ncoeffs, float *coeffs, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o,
+             unsigned int decim = 1, float fuse_scale = 0)
+      : runnable(sch, "fir_filter"), freq_tap(NULL), tap_multiplier(1), freq_tol(0.1),
+        ctx(pipe_ctx(i.dev, o.dev, "fir_filter: pipebufs must be device pipebufs of one ctx")), n(ncoeffs), d(decim), in(i), out(o) {
+    lsdr_fir_filter_cfg cfg;
+    cfg.ncoeffs = ncoeffs; cfg.coeffs_host = coeffs; cfg.decim = decim;
+    cfg.in_format = LSDR_IN_CF32; cfg.in_scale = fuse_scale; cfg.arith = LSDR_FIR_EXACT;
+    lsdr_check(lsdr_fir_filter_create(ctx, &cfg, &h), name);
+  }
+  void run() {
+    if (in.readable() < n) return;
+    if (freq_tap) {  // dsp.h:236-244
+      int shifted = 0;
+      float before = lsdr_fir_filter_current_freq(h);
+      lsdr_check(lsdr_fir_filter_track(h, *freq_tap, tap_multiplier, freq_tol, &shifted), name);
+      if (shifted && sch->verbose)
+        fprintf(stderr, "Shifting filter %f -> %f\n", before, lsdr_fir_filter_current_freq(h));
+    }
+    unsigned long room = out.writable();  // may pack(): take it before the read pointer
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_fir_filter_run(h, in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  unsigned n, d;
+  pipereader<complex<float> > in;
+  pipewriter<complex<float> > out;
+  lsdr_fir_filter *h;
+};
+
+// decimator<cf32> (generic.h:247-267 of the reference) on device pipebufs.
+template <typename T>
+struct decimator;
+
+template <>
+struct decimator<complex<float> > : runnable {
+  unsigned int d;
+  decimator(scheduler *sch, int _d, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o)
+      : runnable(sch, "decimator"), d(_d), ctx(pipe_ctx(i.dev, o.dev, "decimator: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {}
+  void run() {
+    unsigned long room = out.writable();
+    size_t produced = 0;
+    lsdr_check(lsdr_decimator_run(ctx, d, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &produced), name);
+    in.read(produced * d);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<complex<float> > in;
+  pipewriter<complex<float> > out;
+};
+
+}  // namespace leansdr
+#endif

@@ -1,0 +1,253 @@
+// leansdr_amd/host/leansdr/sdr.h — SDR blocks with the reference's class surface
+// (sdr.h:28-34 typedefs, :287-290 softsymbol, :299-573 cstln_lut, :589-689 samplers,
+// :697-938 cstln_receiver).  The receiver's run() is one C-ABI call; the constellation
+// table and the samplers are descriptors of what the device executes.
+#ifndef LEANSDR_AMD_SDR_H
+#define LEANSDR_AMD_SDR_H
+
+#include "leansdr/dsp.h"
+#include "leansdr/math.h"
+
+namespace leansdr {
+
+typedef float f32;
+typedef complex<u8> cu8;
+typedef complex<s8> cs8;
+typedef complex<u16> cu16;
+typedef complex<s16> cs16;
+typedef complex<f32> cf32;
+
+typedef uint16_t u_angle;
+typedef int16_t s_angle;
+
+struct softsymbol {
+  int16_t cost;
+  uint8_t symbol;
+};
+
+const float cstln_amp = 75;
+
+// Constellation descriptor.  Tables come from the C ABI builder (same values as the
+// reference's constructor); lookup()/harden() keep their meaning for host-side users
+// (e.g. a constellation viewer) while the receiver itself uses the device copy.
+template <int R>
+struct cstln_lut {
+  enum predef { BPSK, QPSK, PSK8, APSK16, APSK32, APSK64E, QAM16, QAM64, QAM256 };
+  struct result {
+    struct softsymbol ss;
+    s_angle phase_error;
+  };
+  complex<signed char> *symbols;
+  int nsymbols;
+  int nrotations;
+  predef type;
+  int fec;        // code rate used for the APSK radii (make_dvbs2_constellation)
+  bool hardened;
+
+  cstln_lut(predef t, int code_rate = 0) : type(t), fec(code_rate), hardened(false) {
+    static_assert(R == 256, "cstln_lut<256> only");
+    int16_t *cost = new int16_t[65536];
+    uint8_t *sym = new uint8_t[65536];
+    int16_t *pe = new int16_t[65536];
+    int8_t pts[512];
+    int n = lsdr_cstln_lut_build((int)t, code_rate, cost, sym, pe, pts, &nrotations);
+    if (n < 0) fail("Constellation / code rate not supported");
+    nsymbols = n;
+    symbols = new complex<signed char>[n];
+    for (int s = 0; s < n; ++s) symbols[s] = complex<signed char>(pts[2 * s], pts[2 * s + 1]);
+    lut = new result[65536];
+    for (int i = 0; i < 65536; ++i) {
+      lut[i].ss.cost = cost[i];
+      lut[i].ss.symbol = sym[i];
+      lut[i].phase_error = pe[i];
+    }
+    delete[] cost; delete[] sym; delete[] pe;
+  }
+  inline result *lookup(float I, float Q) {
+    while (I < -128 || I > 127 || Q < -128 || Q > 127) { I *= 0.5; Q *= 0.5; }
+    return &lut[(unsigned)(u8)(s8)I * 256 + (u8)(s8)Q];
+  }
+  inline result *lookup(int I, int Q) { return &lut[(unsigned)(u8)I * 256 + (u8)Q]; }
+  void harden() {
+    hardened = true;
+    for (int i = 0; i < 65536; ++i) {
+      if (lut[i].ss.cost < 0) lut[i].ss.cost = -1;
+      if (lut[i].ss.cost > 0) lut[i].ss.cost = 1;
+    }
+  }
+
+ private:
+  result *lut;
+};
+
+// Samplers: descriptors consumed by cstln_receiver (the interpolation itself runs on the GPU).
+template <typename T>
+struct sampler_interface {
+  virtual ~sampler_interface() {}
+  virtual int kind() = 0;          // LSDR_SAMP_*
+  virtual int readahead() { return 0; }
+  virtual int ncoeffs() { return 0; }
+  virtual float *coeffs() { return NULL; }
+  virtual int subsampling() { return 1; }
+};
+template <typename T>
+struct nearest_sampler : sampler_interface<T> {
+  int kind() { return LSDR_SAMP_NEAREST; }
+  int readahead() { return 0; }
+};
+template <typename T>
+struct linear_sampler : sampler_interface<T> {
+  int kind() { return LSDR_SAMP_LINEAR; }
+  int readahead() { return 1; }
+};
+template <typename T, typename Tc>
+struct fir_sampler : sampler_interface<T> {
+  fir_sampler(int n, Tc *c, int sub = 1) : n_(n), c_(c), sub_(sub) {}
+  int kind() { return LSDR_SAMP_FIR; }
+  int readahead() { return n_ - 1; }
+  int ncoeffs() { return n_; }
+  float *coeffs() { return c_; }
+  int subsampling() { return sub_; }
+
+ private:
+  int n_;
+  Tc *c_;
+  int sub_;
+};
+
+// cstln_receiver<f32>: constructor and public members as sdr.h:697-753,918.  The device
+// handle is created lazily at the first run(), after the graph builder has set cstln,
+// omega, pll_adjustment, meas_decimation … exactly as leandvb.cc:463-502 does.
+template <typename T>
+struct cstln_receiver;
+
+template <>
+struct cstln_receiver<f32> : runnable {
+  sampler_interface<f32> *sampler;
+  cstln_lut<256> *cstln;
+  unsigned long meas_decimation;
+  float omega, min_omega, max_omega;
+  float freqw, min_freqw, max_freqw;
+  float pll_adjustment;
+  bool allow_drift;
+  static const unsigned int chunk_size = 128;
+  float kest;
+  float freq_tap;
+  int mode;                 // addition: LSDR_RX_SERIAL (exact, default) or LSDR_RX_TILED
+  unsigned tile_len, tile_warmup;
+
+  cstln_receiver(scheduler *sch, sampler_interface<f32> *s, pipebuf<cf32> &i, pipebuf<softsymbol> &o,
+                 pipebuf<float> *freq_o = NULL, pipebuf<float> *ss_o = NULL, pipebuf<float> *mer_o = NULL,
+                 pipebuf<cf32> *cstln_o = NULL)
+      : runnable(sch, "Constellation receiver"), sampler(s), cstln(NULL), meas_decimation(1048576), pll_adjustment(1.0),
+        allow_drift(false), kest(0.01), freq_tap(0), mode(LSDR_RX_SERIAL), tile_len(0), tile_warmup(0),
+        ctx(pipe_ctx(i.dev, o.dev, "cstln_receiver: in/out must be device pipebufs of one ctx")), in(i),
+        out(o, chunk_size), h(NULL), freq0(0) {
+    set_omega(1);
+    set_freq(0);
+    freq_out = opt_writer(freq_o);
+    ss_out = opt_writer(ss_o);
+    mer_out = opt_writer(mer_o);
+    cstln_out = opt_writer(cstln_o);
+  }
+  void set_omega(float o, float tol = 10e-6) {
+    omega = o;
+    min_omega = omega * (1 - tol);
+    max_omega = omega * (1 + tol);
+    update_freq_limits();
+  }
+  void set_freq(float f) {
+    freq0 = f;
+    freqw = f * 65536;
+    update_freq_limits();
+    freq_tap = freqw / 65536;
+  }
+  void set_allow_drift(bool d) { allow_drift = d; }
+  void update_freq_limits() {
+    int n = 4;
+    if (cstln) switch (cstln->nsymbols) {
+        case 2: n = 2; break;
+        case 4: n = 4; break;
+        case 8: n = 8; break;
+        case 16: n = 12; break;
+        case 32: n = 16; break;
+        default: n = 4; break;
+      }
+    min_freqw = freqw - 65536 / max_omega / n / 2;
+    max_freqw = freqw + 65536 / max_omega / n / 2;
+  }
+
+  void run() {
+    if (!cstln) fail("constellation not set");
+    if (!h) create();
+    unsigned long max_meas = chunk_size / meas_decimation + 1;
+    unsigned long room = out.writable();
+    unsigned long meas_room = ~0ul;
+    if (freq_out) meas_room = min(meas_room, freq_out->writable());
+    if (ss_out) meas_room = min(meas_room, ss_out->writable());
+    if (mer_out) meas_room = min(meas_room, mer_out->writable());
+    if (meas_room > 65536) meas_room = 65536;  // scratch size
+    unsigned long cstln_room = cstln_out ? cstln_out->writable() : 0;
+    if (in.readable() < chunk_size + sampler->readahead() || room < chunk_size) return;
+    if ((freq_out || ss_out || mer_out) && meas_room < max_meas) return;
+    if (cstln_out && cstln_room < max_meas) return;
+    bool meas = freq_out || ss_out || mer_out;
+    size_t consumed = 0, produced = 0, n_meas = 0, n_cstln = 0;
+    lsdr_check(lsdr_rx_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_softsymbol *)out.wr(), room, &consumed,
+                           &produced, meas ? tmp_meas(0, meas_room) : NULL, meas ? tmp_meas(1, meas_room) : NULL,
+                           meas ? tmp_meas(2, meas_room) : NULL, meas ? meas_room : 0, &n_meas,
+                           cstln_out ? (lsdr_cf32 *)cstln_out->wr() : NULL, cstln_room, &n_cstln),
+               name);
+    in.read(consumed);
+    out.written(produced);
+    for (size_t k = 0; k < n_meas; ++k) {
+      if (freq_out) freq_out->write(scratch[0][k]);
+      if (ss_out) ss_out->write(scratch[1][k]);
+      if (mer_out) mer_out->write(scratch[2][k]);
+    }
+    if (cstln_out) cstln_out->written(n_cstln);
+    lsdr_rx_state st;
+    lsdr_check(lsdr_rx_get_state(h, &st), name);
+    freqw = st.freqw;
+    freq_tap = st.freq_tap;  // read by fir_filter / cnr_fft through their freq_tap pointers
+  }
+
+ private:
+  void create() {
+    lsdr_rx_cfg cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.sampler = sampler->kind();
+    cfg.ncoeffs = sampler->ncoeffs();
+    cfg.coeffs_host = sampler->coeffs();
+    cfg.subsampling = sampler->subsampling();
+    cfg.cstln = (int)cstln->type;
+    cfg.fec = cstln->fec;
+    cfg.harden = cstln->hardened;
+    cfg.omega = omega;
+    cfg.freq = freq0;
+    cfg.pll_adjustment = pll_adjustment;
+    cfg.allow_drift = allow_drift;
+    cfg.meas_decimation = meas_decimation;
+    cfg.kest = kest;
+    cfg.mode = mode;
+    cfg.tile_len = tile_len;
+    cfg.tile_warmup = tile_warmup;
+    lsdr_check(lsdr_rx_create(ctx, &cfg, &h), name);
+  }
+  float *tmp_meas(int which, unsigned long n) {
+    if (n > 65536) n = 65536;
+    if (!scratch[which]) scratch[which] = new float[65536];
+    return scratch[which];
+  }
+  lsdr_ctx *ctx;
+  pipereader<cf32> in;
+  pipewriter<softsymbol> out;
+  pipewriter<float> *freq_out, *ss_out, *mer_out;
+  pipewriter<cf32> *cstln_out;
+  lsdr_rx *h;
+  float freq0;
+  float *scratch[3] = {NULL, NULL, NULL};
+};
+
+}  // namespace leansdr
+#endif
