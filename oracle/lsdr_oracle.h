@@ -134,6 +134,46 @@ void lo_rx_get_state(const lo_rx *r, lo_rx_state *st);
 void lo_rx_set_state(lo_rx *r, const lo_rx_state *st);
 int lo_rx_readahead(const lo_rx *r);
 
+/* ---- FEC tail (lsdr_oracle_fec.c): dvb.h, viterbi.h, rs.h ------------------------ */
+typedef struct lo_deconv lo_deconv;                       /* deconvol_sync<u8,0>, dvb.h:122-476 */
+lo_deconv *lo_deconv_new(int rate, int fastlock);         /* make_deconvol_sync_simple, dvb.h:480-513 */
+void lo_deconv_free(lo_deconv *d);
+void lo_deconv_info(const lo_deconv *d, uint64_t *deconv, uint64_t *deconv2, int *period, int *weight);
+void lo_deconv_next_sync(lo_deconv *d);                   /* dvb.h:185-193 */
+int lo_deconv_locked(const lo_deconv *d);
+/* one run() call (dvb.h:419-470) */
+size_t lo_deconv_run(lo_deconv *d, const lo_softsymbol *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed);
+
+typedef struct lo_viterbi lo_viterbi;                     /* viterbi_sync, dvb.h:1173-1416 */
+lo_viterbi *lo_viterbi_new(int cstln, int rate);
+void lo_viterbi_free(lo_viterbi *s);
+void lo_viterbi_set_resync_period(lo_viterbi *s, int p);
+int lo_viterbi_current_sync(const lo_viterbi *s);
+int lo_viterbi_nsyncs(const lo_viterbi *s);
+void lo_viterbi_map(const lo_viterbi *s, int sync, uint8_t *map256);
+size_t lo_viterbi_run(lo_viterbi *s, const lo_softsymbol *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed);
+
+typedef struct lo_mpeg_sync lo_mpeg_sync;                 /* mpeg_sync<u8,0>, dvb.h:712-891 */
+lo_mpeg_sync *lo_mpeg_sync_new(int fastlock);
+void lo_mpeg_sync_free(lo_mpeg_sync *m);
+int lo_mpeg_sync_locked(const lo_mpeg_sync *m);
+size_t lo_mpeg_sync_run(lo_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed,
+                        int *state_out, size_t state_cap, size_t *n_state,
+                        unsigned long *locktime_out, size_t lt_cap, size_t *n_lt, int *call_next_sync);
+
+size_t lo_deinterleaver(const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_packets, size_t *consumed); /* dvb.h:926-948 */
+void lo_rs_tables(uint8_t *exp512, uint8_t *log256, uint8_t *G17);                   /* rs.h:47-105 */
+void lo_rs_encode(uint8_t *msg204);                                                     /* rs.h:141-167 */
+size_t lo_rs_decoder(uint8_t *in, size_t npackets, uint8_t *out, long *bits, long *errs); /* dvb.h:998-1053, rs.h:116-270 */
+void lo_derandomizer_pattern(uint8_t *pattern1504);                                     /* dvb.h:1116-1129 */
+typedef struct lo_derandomizer lo_derandomizer;
+lo_derandomizer *lo_derandomizer_new(void);
+void lo_derandomizer_free(lo_derandomizer *d);
+size_t lo_derandomizer_run(lo_derandomizer *d, const uint8_t *in, size_t npackets, uint8_t *out); /* dvb.h:1130-1157 */
+/* symbols → TS packets, the tail of leandvb.cc:519-596 */
+size_t lo_fec_chain(int cstln, int rate, int viterbi, int fastlock, const lo_softsymbol *sym, size_t n,
+                    uint8_t *ts_out, size_t cap_packets, long *bits, long *errs);
+
 #ifdef __cplusplus
 }
 #endif

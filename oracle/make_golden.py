@@ -60,6 +60,23 @@ def state_arr(st):
     return np.array([d[k] for k in keys] + d["hist"], np.float32), np.uint64(d["meas_count"])
 
 
+def fec_input(hard, err_permille):
+    """Soft symbols for the FEC goldens: integer formulas only.  Every symbol gets a cost in
+    [-11236, -1000]; `err_permille` of them (chosen by a multiplicative hash) are replaced by a
+    different symbol with a weak cost."""
+    n = len(hard)
+    i = np.arange(n, dtype=np.uint64)
+    sym = np.zeros(n, po.SOFTSYM)
+    sym["symbol"] = hard
+    sym["cost"] = -(1000 + (i * np.uint64(37)) % np.uint64(10237)).astype(np.int64)
+    if err_permille:
+        h = (i * np.uint64(2654435761)) % np.uint64(1 << 32)
+        bad = h < np.uint64((err_permille << 32) // 1000)
+        sym["symbol"][bad] = (hard[bad] ^ (1 + (h[bad] >> np.uint64(7)) % np.uint64(3)).astype(np.uint8)) & 3
+        sym["cost"][bad] = -(h[bad] % np.uint64(300)).astype(np.int64)
+    return sym
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = po.Ref()
@@ -173,6 +190,59 @@ def main():
     an["fft1024_fwd"] = R.cfft(xn[:1024], False)
     an["cnr"] = R.cnr_fft(xn, 0.2, 4096, 4096 * 2, 0.01, 0.5)
     np.savez_compressed(os.path.join(GOLD, "auto_notch.npz"), iq=iqn, scale=np.float32(1 / 64.0), **an)
+
+    # ---- FEC tail ------------------------------------------------------------------------
+    # Input: hard symbol decisions of a clean reference-TX stream (packed 2 bit/symbol) with a
+    # deterministic integer cost/error pattern applied by fec_input() below (no RNG involved).
+    O = po.Oracle()
+    xc = tx(130, 4, 0, -60)
+    r = O.rx(po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=1 << 20), O.scaler(75.0 / np.sqrt((np.abs(xc) ** 2).mean()), xc))
+    hard = r["sym"]["symbol"][4000:4000 + 204 * 8 * 110].copy()          # skip acquisition, 110 RS packets worth
+    packed = np.packbits(np.unpackbits(hard.reshape(-1, 1), axis=1)[:, 6:].reshape(-1))
+    fec = dict(hard_packed=packed, nsym=np.int64(len(hard)))
+    for tag, errp in [("clean", 0), ("noisy", 40)]:
+        sym = fec_input(hard, errp)
+        for ns in range(5):
+            b, dc, pp, pw = R.deconvol_sync(sym, 0, 0, ns)
+            fec[f"{tag}_deconv_ns{ns}_sha"] = np.frombuffer(bytes.fromhex(sha(b)), np.uint8)
+            fec[f"{tag}_deconv_ns{ns}_n"] = np.int64(len(b))
+        b, _, _, _ = R.deconvol_sync(sym, 0, 1, 0)
+        fec[f"{tag}_deconv_fastlock_sha"] = np.frombuffer(bytes.fromhex(sha(b)), np.uint8)
+        vb, cur = R.viterbi_sync(sym, 1, 0)
+        fec[f"{tag}_viterbi_sha"] = np.frombuffer(bytes.fromhex(sha(vb)), np.uint8)
+        fec[f"{tag}_viterbi_n"] = np.int64(len(vb))
+        fec[f"{tag}_viterbi_sync"] = np.int64(cur)
+        fec[f"{tag}_viterbi_head"] = vb[:512]
+        for nm, data in [("deconv", R.deconvol_sync(sym, 0, 0, 0)[0]), ("viterbi", vb)]:
+            m, st, lt = R.mpeg_sync(data)
+            fec[f"{tag}_{nm}_mpeg_sha"] = np.frombuffer(bytes.fromhex(sha(m)), np.uint8)
+            fec[f"{tag}_{nm}_mpeg_n"] = np.int64(len(m))
+            fec[f"{tag}_{nm}_mpeg_state"] = st
+            pk = R.deinterleaver(m)
+            fec[f"{tag}_{nm}_deint_sha"] = np.frombuffer(bytes.fromhex(sha(pk)), np.uint8)
+            ts, bits, errs = R.rs_decoder(pk)
+            fec[f"{tag}_{nm}_rs_sha"] = np.frombuffer(bytes.fromhex(sha(ts)), np.uint8)
+            fec[f"{tag}_{nm}_rs_counts"] = np.array([bits, errs], np.int64)
+            out, _ = R.derandomizer(ts)
+            fec[f"{tag}_{nm}_ts"] = out
+        for vit in (0, 1):
+            ts, bits, errs = R.fec_chain(sym, 1, 0, vit)
+            fec[f"{tag}_chain{vit}_ts"] = ts
+            fec[f"{tag}_chain{vit}_counts"] = np.array([bits, errs], np.int64)
+    e, l, g = R.rs_tables()
+    fec["rs_exp"], fec["rs_log"], fec["rs_G"] = e[:255], l, g
+    fec["derand_pattern"] = R.derandomizer(np.zeros((1, 188), np.uint8))[1]
+    fec["deconv12"] = R.deconvol_sync(sym[:2000], 0)[1]
+    fec["deconv34"] = R.deconvol_sync(sym[:2000], 3)[1]
+    # RS packets with 0..11 byte errors (deterministic positions)
+    pk = R.deinterleaver(R.mpeg_sync(R.viterbi_sync(fec_input(hard, 0), 1, 0)[0])[0])[:48].copy()
+    for i in range(len(pk)):
+        for k in range(i % 12):
+            pk[i, (i * 37 + k * 17) % 204] ^= np.uint8(1 + (i * 7 + k * 29) % 255)
+    fec["rs_bad_in"] = pk
+    ts, bits, errs = R.rs_decoder(pk)
+    fec["rs_bad_out"], fec["rs_bad_counts"] = ts, np.array([bits, errs], np.int64)
+    np.savez_compressed(os.path.join(GOLD, "fec.npz"), **fec)
 
     with open(os.path.join(GOLD, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)

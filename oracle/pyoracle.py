@@ -131,6 +131,37 @@ class Oracle:
         L.lo_rx_get_state.argtypes = [C.c_void_p, C.POINTER(RxState)]
         L.lo_rx_set_state.argtypes = [C.c_void_p, C.POINTER(RxState)]
         L.lo_rx_readahead.argtypes = [C.c_void_p]
+        # FEC tail
+        vp = C.c_void_p
+        L.lo_deconv_new.restype = vp; L.lo_deconv_new.argtypes = [C.c_int, C.c_int]
+        L.lo_deconv_free.argtypes = [vp]
+        L.lo_deconv_info.argtypes = [vp, vp, vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.lo_deconv_next_sync.argtypes = [vp]
+        L.lo_deconv_locked.argtypes = [vp]
+        L.lo_deconv_run.restype = c_sz; L.lo_deconv_run.argtypes = [vp, vp, c_sz, vp, c_sz, C.POINTER(c_sz)]
+        L.lo_viterbi_new.restype = vp; L.lo_viterbi_new.argtypes = [C.c_int, C.c_int]
+        L.lo_viterbi_free.argtypes = [vp]
+        L.lo_viterbi_set_resync_period.argtypes = [vp, C.c_int]
+        L.lo_viterbi_current_sync.argtypes = [vp]
+        L.lo_viterbi_nsyncs.argtypes = [vp]
+        L.lo_viterbi_map.argtypes = [vp, C.c_int, vp]
+        L.lo_viterbi_run.restype = c_sz; L.lo_viterbi_run.argtypes = [vp, vp, c_sz, vp, c_sz, C.POINTER(c_sz)]
+        L.lo_mpeg_sync_new.restype = vp; L.lo_mpeg_sync_new.argtypes = [C.c_int]
+        L.lo_mpeg_sync_free.argtypes = [vp]
+        L.lo_mpeg_sync_locked.argtypes = [vp]
+        L.lo_mpeg_sync_run.restype = c_sz
+        L.lo_mpeg_sync_run.argtypes = [vp, vp, c_sz, vp, c_sz, C.POINTER(c_sz), vp, c_sz, C.POINTER(c_sz), vp, c_sz,
+                                       C.POINTER(c_sz), C.POINTER(C.c_int)]
+        L.lo_deinterleaver.restype = c_sz; L.lo_deinterleaver.argtypes = [vp, c_sz, vp, c_sz, C.POINTER(c_sz)]
+        L.lo_rs_tables.argtypes = [vp, vp, vp]
+        L.lo_rs_encode.argtypes = [vp]
+        L.lo_rs_decoder.restype = c_sz; L.lo_rs_decoder.argtypes = [vp, c_sz, vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.lo_derandomizer_pattern.argtypes = [vp]
+        L.lo_derandomizer_new.restype = vp
+        L.lo_derandomizer_free.argtypes = [vp]
+        L.lo_derandomizer_run.restype = c_sz; L.lo_derandomizer_run.argtypes = [vp, vp, c_sz, vp]
+        L.lo_fec_chain.restype = c_sz
+        L.lo_fec_chain.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, vp, c_sz, vp, c_sz, C.POINTER(C.c_long), C.POINTER(C.c_long)]
 
     # -- tables
     def trig16(self):
@@ -244,6 +275,121 @@ class Oracle:
                     mer=mer[:nm.value], cstln=cst[:nc.value], state=st)
 
 
+    # -- FEC tail ------------------------------------------------------------
+    @staticmethod
+    def softsyms(symbol, cost=None):
+        out = np.zeros(len(symbol), SOFTSYM)
+        out["symbol"] = symbol
+        if cost is not None:
+            out["cost"] = cost
+        return out
+
+    def deconv_info(self, rate):
+        h = self.lib.lo_deconv_new(rate, 0)
+        d, d2 = np.zeros(8, np.uint64), np.zeros(8, np.uint64)
+        p, w = C.c_int(), C.c_int()
+        self.lib.lo_deconv_info(h, _p(d), _p(d2), C.byref(p), C.byref(w))
+        self.lib.lo_deconv_free(h)
+        return d[:p.value].copy(), d2[:p.value].copy(), p.value, w.value
+
+    def deconvol_sync(self, sym, rate=0, fastlock=0, next_syncs=0, pipe=4096):
+        """Whole-stream deconvolution: repeated run() calls on windows of at most `pipe` symbols,
+        output room 8192 like the reference pipes (leandvb.cc:185-202)."""
+        sym = np.ascontiguousarray(sym, SOFTSYM)
+        h = self.lib.lo_deconv_new(rate, fastlock)
+        for _ in range(next_syncs):
+            self.lib.lo_deconv_next_sync(h)
+        out = np.empty(len(sym) + 64, np.uint8)
+        pos, nout = 0, 0
+        while True:
+            c = c_sz()
+            avail = min(pipe, len(sym) - pos)
+            got = self.lib.lo_deconv_run(h, sym[pos:].ctypes.data, avail, out[nout:].ctypes.data, 8192, C.byref(c))
+            if not got and not c.value:
+                break
+            pos += c.value
+            nout += got
+        self.lib.lo_deconv_free(h)
+        return out[:nout].copy()
+
+    def viterbi_sync(self, sym, cstln=1, rate=0, resync_period=0):
+        sym = np.ascontiguousarray(sym, SOFTSYM)
+        h = self.lib.lo_viterbi_new(cstln, rate)
+        assert h
+        if resync_period:
+            self.lib.lo_viterbi_set_resync_period(h, resync_period)
+        out = np.empty(len(sym) + 64, np.uint8)
+        c = c_sz()
+        n = self.lib.lo_viterbi_run(h, _p(sym), len(sym), _p(out), len(out), C.byref(c))
+        cur = self.lib.lo_viterbi_current_sync(h)
+        self.lib.lo_viterbi_free(h)
+        return out[:n].copy(), c.value, cur
+
+    def mpeg_sync(self, data, fastlock=0):
+        data = np.ascontiguousarray(data, np.uint8)
+        h = self.lib.lo_mpeg_sync_new(fastlock)
+        out = np.empty(len(data) + 4096, np.uint8)
+        st = np.empty(len(data) // 204 + 64, np.int32)
+        lt = np.empty(len(data) // 204 + 64, np.uint64)
+        pos, nout, nst, nlt = 0, 0, 0, 0
+        while True:
+            c, ns, nl, cns = c_sz(), c_sz(), c_sz(), C.c_int()
+            got = self.lib.lo_mpeg_sync_run(h, data[pos:].ctypes.data, len(data) - pos, out[nout:].ctypes.data,
+                                            len(out) - nout, C.byref(c), st[nst:].ctypes.data, len(st) - nst, C.byref(ns),
+                                            lt[nlt:].ctypes.data, len(lt) - nlt, C.byref(nl), C.byref(cns))
+            nst += ns.value; nlt += nl.value
+            if not got and not c.value:
+                break
+            pos += c.value; nout += got
+        self.lib.lo_mpeg_sync_free(h)
+        return out[:nout].copy(), st[:nst].copy(), lt[:nlt].copy()
+
+    def deinterleaver(self, data):
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.empty((len(data) // 204 + 1, 204), np.uint8)
+        c = c_sz()
+        n = self.lib.lo_deinterleaver(_p(data), len(data), _p(out), len(out), C.byref(c))
+        return out[:n].copy()
+
+    def rs_tables(self):
+        e, l, g = np.empty(512, np.uint8), np.empty(256, np.uint8), np.empty(17, np.uint8)
+        self.lib.lo_rs_tables(_p(e), _p(l), _p(g))
+        return e, l, g
+
+    def rs_encode(self, msg188):
+        m = np.zeros(204, np.uint8)
+        m[:188] = msg188
+        self.lib.lo_rs_encode(_p(m))
+        return m
+
+    def rs_decoder(self, packets):
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 204).copy()
+        out = np.empty((len(packets), 188), np.uint8)
+        b, e = C.c_long(), C.c_long()
+        self.lib.lo_rs_decoder(_p(packets), len(packets), _p(out), C.byref(b), C.byref(e))
+        return out, b.value, e.value
+
+    def derandomizer_pattern(self):
+        p = np.empty(1504, np.uint8)
+        self.lib.lo_derandomizer_pattern(_p(p))
+        return p
+
+    def derandomizer(self, packets):
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 188)
+        h = self.lib.lo_derandomizer_new()
+        out = np.empty_like(packets)
+        n = self.lib.lo_derandomizer_run(h, _p(packets), len(packets), _p(out))
+        self.lib.lo_derandomizer_free(h)
+        return out[:n].copy()
+
+    def fec_chain(self, sym, cstln=1, rate=0, viterbi=0, fastlock=0):
+        sym = np.ascontiguousarray(sym, SOFTSYM)
+        out = np.empty((len(sym) // 800 + 16, 188), np.uint8)
+        b, e = C.c_long(), C.c_long()
+        n = self.lib.lo_fec_chain(cstln, rate, viterbi, fastlock, _p(sym), len(sym), _p(out), len(out), C.byref(b), C.byref(e))
+        return out[:n].copy(), b.value, e.value
+
+
 class Ref:
     """The real reference, through oracle/ref_harness.cc.  Raises FileNotFoundError
     when oracle/_ref was not built (no /root/reference on this machine)."""
@@ -279,6 +425,95 @@ class Ref:
                                          C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_long, C.POINTER(C.c_long),
                                          C.POINTER(C.c_long), C.POINTER(RxState)]
+
+    def _fec_sigs(self):
+        L, vp = self.lib, C.c_void_p
+        L.ref_deconvol_sync.restype = C.c_long
+        L.ref_deconvol_sync.argtypes = [C.c_int, C.c_int, C.c_int, vp, C.c_long, vp, C.c_long, vp, vp]
+        L.ref_viterbi_sync.restype = C.c_long
+        L.ref_viterbi_sync.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, C.c_long, vp, C.c_long, C.POINTER(C.c_int)]
+        L.ref_mpeg_sync.restype = C.c_long
+        L.ref_mpeg_sync.argtypes = [C.c_int, vp, C.c_long, vp, C.c_long, vp, C.c_long, C.POINTER(C.c_long), vp, C.POINTER(C.c_long)]
+        L.ref_deinterleaver.restype = C.c_long
+        L.ref_deinterleaver.argtypes = [vp, C.c_long, vp, C.c_long]
+        L.ref_rs_decoder.restype = C.c_long
+        L.ref_rs_decoder.argtypes = [vp, C.c_long, vp, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.ref_rs_tables.argtypes = [vp, vp, vp]
+        L.ref_rs_encode.argtypes = [vp]
+        L.ref_derandomizer.restype = C.c_long
+        L.ref_derandomizer.argtypes = [vp, C.c_long, vp, vp]
+        L.ref_fec_chain.restype = C.c_long
+        L.ref_fec_chain.argtypes = [C.c_int] * 5 + [vp, vp, C.c_long, vp, C.c_long, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+
+    def deconvol_sync(self, sym, rate=0, fastlock=0, next_syncs=0):
+        self._fec_sigs()
+        symbol = np.ascontiguousarray(sym["symbol"])
+        out = np.empty(len(symbol) + 64, np.uint8)
+        dc = np.zeros(8, np.uint64); pw = np.zeros(2, np.int32)
+        n = self.lib.ref_deconvol_sync(rate, fastlock, next_syncs, _p(symbol), len(symbol), _p(out), len(out), _p(dc), _p(pw))
+        return out[:n].copy(), dc[:pw[0]].copy(), int(pw[0]), int(pw[1])
+
+    def viterbi_sync(self, sym, cstln=1, rate=0, resync_period=0):
+        self._fec_sigs()
+        cost, symbol = np.ascontiguousarray(sym["cost"]), np.ascontiguousarray(sym["symbol"])
+        out = np.empty(len(symbol) + 64, np.uint8)
+        cur = C.c_int()
+        n = self.lib.ref_viterbi_sync(cstln, rate, resync_period, _p(cost), _p(symbol), len(symbol), _p(out), len(out), C.byref(cur))
+        return out[:n].copy(), cur.value
+
+    def mpeg_sync(self, data, fastlock=0):
+        self._fec_sigs()
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.empty(len(data) + 4096, np.uint8)
+        st = np.empty(len(data) // 204 + 64, np.int32)
+        lt = np.empty(len(data) // 204 + 64, np.uint64)
+        ns, nl = C.c_long(), C.c_long(len(lt))
+        n = self.lib.ref_mpeg_sync(fastlock, _p(data), len(data), _p(out), len(out), _p(st), len(st), C.byref(ns), _p(lt), C.byref(nl))
+        return out[:n].copy(), st[:ns.value].copy(), lt[:nl.value].copy()
+
+    def deinterleaver(self, data):
+        self._fec_sigs()
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.empty((len(data) // 204 + 1, 204), np.uint8)
+        n = self.lib.ref_deinterleaver(_p(data), len(data), _p(out), len(out))
+        return out[:n].copy()
+
+    def rs_tables(self):
+        self._fec_sigs()
+        e, l, g = np.empty(512, np.uint8), np.empty(256, np.uint8), np.empty(17, np.uint8)
+        self.lib.ref_rs_tables(_p(e), _p(l), _p(g))
+        return e, l, g
+
+    def rs_encode(self, msg188):
+        self._fec_sigs()
+        m = np.zeros(204, np.uint8)
+        m[:188] = msg188
+        self.lib.ref_rs_encode(_p(m))
+        return m
+
+    def rs_decoder(self, packets):
+        self._fec_sigs()
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 204)
+        out = np.empty((len(packets), 188), np.uint8)
+        b, e = C.c_long(), C.c_long()
+        self.lib.ref_rs_decoder(_p(packets), len(packets), _p(out), C.byref(b), C.byref(e))
+        return out, b.value, e.value
+
+    def derandomizer(self, packets):
+        self._fec_sigs()
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 188)
+        out = np.empty_like(packets)
+        pat = np.empty(1504, np.uint8)
+        n = self.lib.ref_derandomizer(_p(packets), len(packets), _p(out), _p(pat))
+        return out[:n].copy(), pat
+
+    def fec_chain(self, sym, cstln=1, rate=0, viterbi=0, fastlock=0, buf_factor=4):
+        self._fec_sigs()
+        cost, symbol = np.ascontiguousarray(sym["cost"]), np.ascontiguousarray(sym["symbol"])
+        out = np.empty((len(symbol) // 800 + 16, 188), np.uint8)
+        b, e = C.c_long(), C.c_long()
+        n = self.lib.ref_fec_chain(cstln, rate, viterbi, fastlock, buf_factor, _p(cost), _p(symbol), len(symbol), _p(out), len(out), C.byref(b), C.byref(e))
+        return out[:n].copy(), b.value, e.value
 
     def trig16(self):
         out = np.empty(65536, np.complex64)

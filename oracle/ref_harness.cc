@@ -24,6 +24,7 @@
 #include "leansdr/dvb.h"
 #include "leansdr/rs.h"
 #include "leansdr/filtergen.h"
+#include <new>
 #undef private
 #undef protected
 
@@ -342,6 +343,192 @@ long ref_cstln_receiver(const ref_rx_params *p, const float *in, long n,
     st->meas_count = demod.meas_count;
     memcpy(st->hist, demod.hist, sizeof(st->hist));
   }
+  return w.pos;
+}
+
+
+// ---------------------------------------------------------------- FEC tail (dvb.h, viterbi.h, rs.h)
+}  // extern "C" (templates below)
+
+namespace {
+// Blocks are built on zero-filled storage: rs_engine's lut_log[0] and a few other members are
+// never initialised by the reference (fresh-heap zeros in leandvb).
+template <typename T> void *zmem() { return calloc(1, sizeof(T)); }
+softsymbol *mk_symbols(const int16_t *cost, const uint8_t *symbol, long n) {
+  softsymbol *p = (softsymbol *)calloc(n + 1, sizeof(softsymbol));
+  for (long i = 0; i < n; ++i) { p[i].cost = cost ? cost[i] : 0; p[i].symbol = symbol[i]; }
+  return p;
+}
+}  // namespace
+
+extern "C" {
+
+// dvb.h:122-476  deconvol_sync<u8,0> via make_deconvol_sync_simple (dvb.h:480-513).
+// next_syncs: how many times mpeg_sync would have called next_sync() before this data.
+long ref_deconvol_sync(int rate, int fastlock, int next_syncs, const uint8_t *symbol, long n, uint8_t *out, long cap,
+                       unsigned long long *deconv_out /*[punctperiod]*/, int *punct /*period, weight*/) {
+  scheduler sch;
+  pipebuf<softsymbol> p_in(&sch, "in", BUF_SYMBOLS);
+  pipebuf<u8> p_out(&sch, "out", BUF_BYTES);
+  softsymbol *sym = mk_symbols(NULL, symbol, n);
+  buffer_reader<softsymbol> r(&sch, sym, n, p_in);
+  deconvol_sync_simple *d = make_deconvol_sync_simple(&sch, p_in, p_out, (code_rate)rate);
+  d->fastlock = fastlock != 0;
+  for (int i = 0; i < next_syncs; ++i) d->next_sync();
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  sch.run();
+  if (deconv_out) for (int b = 0; b < d->punctperiod; ++b) deconv_out[b] = d->deconv[b];
+  if (punct) { punct[0] = d->punctperiod; punct[1] = d->punctweight; }
+  free(sym);
+  return w.pos;
+}
+
+// dvb.h:1173-1416  viterbi_sync
+long ref_viterbi_sync(int cstln, int rate, int resync_period, const int16_t *cost, const uint8_t *symbol, long n,
+                      uint8_t *out, long cap, int *final_sync) {
+  scheduler sch;
+  pipebuf<softsymbol> p_in(&sch, "in", BUF_SYMBOLS);
+  pipebuf<u8> p_out(&sch, "out", BUF_BYTES);
+  softsymbol *sym = mk_symbols(cost, symbol, n);
+  buffer_reader<softsymbol> r(&sch, sym, n, p_in);
+  cstln_lut<256> *c = make_dvbs2_constellation((cstln_lut<256>::predef)cstln, (code_rate)rate);
+  viterbi_sync *v = new viterbi_sync(&sch, p_in, p_out, c, (code_rate)rate);
+  if (resync_period > 0) v->resync_period = resync_period;
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  sch.run();
+  if (final_sync) *final_sync = v->current_sync;
+  free(sym);
+  return w.pos;
+}
+
+// dvb.h:712-891  mpeg_sync<u8,0> (deconv == NULL, as with viterbi: leandvb.cc:561-566)
+long ref_mpeg_sync(int fastlock, const uint8_t *in, long n, uint8_t *out, long cap, int *state, long state_cap,
+                   long *n_state, unsigned long *locktime, long *n_locktime) {
+  scheduler sch;
+  pipebuf<u8> p_in(&sch, "in", BUF_BYTES);
+  pipebuf<u8> p_out(&sch, "out", BUF_MPEGBYTES);
+  pipebuf<int> p_lock(&sch, "lock", BUF_SLOW + 64);
+  pipebuf<u32> p_locktime(&sch, "locktime", BUF_PACKETS + 4096);
+  buffer_reader<u8> r(&sch, (u8 *)in, n, p_in);
+  mpeg_sync<u8, 0> m(&sch, p_in, p_out, NULL, &p_lock, &p_locktime);
+  m.fastlock = fastlock != 0;
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  buffer_writer<int> ws(&sch, p_lock, state, state_cap);
+  buffer_writer<u32> wl(&sch, p_locktime, locktime, *n_locktime);
+  sch.run();
+  *n_state = ws.pos;
+  *n_locktime = wl.pos;
+  return w.pos;
+}
+
+// dvb.h:926-948
+long ref_deinterleaver(const uint8_t *in, long n, uint8_t *out /*packets of 204*/, long cap_packets) {
+  scheduler sch;
+  pipebuf<u8> p_in(&sch, "in", BUF_MPEGBYTES);
+  pipebuf<rspacket<u8> > p_out(&sch, "out", BUF_PACKETS);
+  buffer_reader<u8> r(&sch, (u8 *)in, n, p_in);
+  deinterleaver<u8> d(&sch, p_in, p_out);
+  buffer_writer<rspacket<u8> > w(&sch, p_out, (rspacket<u8> *)out, cap_packets);
+  sch.run();
+  return w.pos;
+}
+
+// dvb.h:985-1058 + rs.h:84-272.  bits/errs: per-run() counter outputs (summed here).
+long ref_rs_decoder(const uint8_t *in, long npackets, uint8_t *out /*188 each*/, long *bits, long *errs) {
+  scheduler sch;
+  pipebuf<rspacket<u8> > p_in(&sch, "in", BUF_PACKETS);
+  pipebuf<tspacket> p_out(&sch, "out", BUF_PACKETS);
+  pipebuf<int> p_bits(&sch, "bits", 4096), p_errs(&sch, "errs", 4096);
+  uint8_t *copy = (uint8_t *)malloc(npackets * 204 + 1);   // the decoder corrects its input in place
+  memcpy(copy, in, npackets * 204);
+  buffer_reader<rspacket<u8> > r(&sch, (rspacket<u8> *)copy, npackets, p_in);
+  typedef rs_decoder<u8, 0> dec_t;
+  dec_t *d = new (zmem<dec_t>()) dec_t(&sch, p_in, p_out, &p_bits, &p_errs);
+  (void)d;
+  buffer_writer<tspacket> w(&sch, p_out, (tspacket *)out, npackets);
+  int *hb = new int[1 << 20], *he = new int[1 << 20];
+  buffer_writer<int> wb(&sch, p_bits, hb, 1 << 20), we(&sch, p_errs, he, 1 << 20);
+  sch.run();
+  long sb = 0, se = 0;
+  for (int i = 0; i < wb.pos; ++i) sb += hb[i];
+  for (int i = 0; i < we.pos; ++i) se += he[i];
+  if (bits) *bits = sb;
+  if (errs) *errs = se;
+  delete[] hb; delete[] he; free(copy);
+  return w.pos;
+}
+
+// RS tables: exp/log (rs.h:47-82) and the generator G (rs.h:93-105)
+void ref_rs_tables(uint8_t *exp512, uint8_t *log256, uint8_t *G17) {
+  rs_engine *rs = new (zmem<rs_engine>()) rs_engine();
+  for (int i = 0; i < 512; ++i) exp512[i] = rs->gf.exp(i < 510 ? i : 0);
+  for (int i = 0; i < 256; ++i) log256[i] = rs->gf.log(i);
+  memcpy(G17, rs->G, 17);
+}
+
+// rs.h:141-167 (used to build test packets)
+void ref_rs_encode(uint8_t *msg204) {
+  static rs_engine *rs = new (zmem<rs_engine>()) rs_engine();
+  rs->encode(msg204);
+}
+
+// dvb.h:1107-1163
+long ref_derandomizer(const uint8_t *in, long npackets, uint8_t *out, uint8_t *pattern1504) {
+  scheduler sch;
+  pipebuf<tspacket> p_in(&sch, "in", BUF_PACKETS);
+  pipebuf<tspacket> p_out(&sch, "out", BUF_PACKETS);
+  buffer_reader<tspacket> r(&sch, (tspacket *)in, npackets, p_in);
+  derandomizer d(&sch, p_in, p_out);
+  buffer_writer<tspacket> w(&sch, p_out, (tspacket *)out, npackets);
+  sch.run();
+  if (pattern1504) memcpy(pattern1504, d.pattern, 1504);
+  return w.pos;
+}
+
+// The whole FEC tail as leandvb wires it (leandvb.cc:519-596): symbols → [viterbi_sync | deconvol_sync]
+// → mpeg_sync → deinterleaver → rs_decoder → derandomizer → TS packets.
+long ref_fec_chain(int cstln, int rate, int viterbi, int fastlock, int buf_factor, const int16_t *cost,
+                   const uint8_t *symbol, long n, uint8_t *ts_out, long cap_packets, long *bits, long *errs) {
+  scheduler sch;
+  unsigned long bf = buf_factor;
+  pipebuf<softsymbol> p_symbols(&sch, "PSK soft-symbols", 1024 * bf);
+  pipebuf<u8> p_bytes(&sch, "bytes", 2048 * bf);
+  pipebuf<u8> p_mpegbytes(&sch, "mpegbytes", 2448 * bf);
+  pipebuf<rspacket<u8> > p_rspackets(&sch, "RS-enc packets", bf);
+  pipebuf<tspacket> p_rtspackets(&sch, "rand TS packets", bf);
+  pipebuf<tspacket> p_tspackets(&sch, "TS packets", bf);
+  pipebuf<int> p_lock(&sch, "lock", bf), p_vbitcount(&sch, "bits", bf), p_verrcount(&sch, "errs", bf);
+  pipebuf<u32> p_locktime(&sch, "locktime", bf);
+  softsymbol *sym = mk_symbols(cost, symbol, n);
+  buffer_reader<softsymbol> r(&sch, sym, n, p_symbols);
+  cstln_lut<256> *c = make_dvbs2_constellation((cstln_lut<256>::predef)cstln, (code_rate)rate);
+  deconvol_sync_simple *r_deconv = NULL;
+  if (viterbi) {
+    viterbi_sync *v = new viterbi_sync(&sch, p_symbols, p_bytes, c, (code_rate)rate);
+    if (fastlock) v->resync_period = 1;
+  } else {
+    r_deconv = make_deconvol_sync_simple(&sch, p_symbols, p_bytes, (code_rate)rate);
+    r_deconv->fastlock = fastlock != 0;
+  }
+  mpeg_sync<u8, 0> r_sync(&sch, p_bytes, p_mpegbytes, r_deconv, &p_lock, &p_locktime);
+  r_sync.fastlock = fastlock != 0;
+  deinterleaver<u8> r_deinter(&sch, p_mpegbytes, p_rspackets);
+  typedef rs_decoder<u8, 0> dec_t;
+  dec_t *r_rsdec = new (zmem<dec_t>()) dec_t(&sch, p_rspackets, p_rtspackets, &p_vbitcount, &p_verrcount);
+  (void)r_rsdec;
+  derandomizer r_derand(&sch, p_rtspackets, p_tspackets);
+  buffer_writer<tspacket> w(&sch, p_tspackets, (tspacket *)ts_out, cap_packets);
+  int *hb = new int[1 << 20], *he = new int[1 << 20], *hl = new int[1 << 20];
+  u32 *ht = new u32[1 << 22];
+  buffer_writer<int> wb(&sch, p_vbitcount, hb, 1 << 20), we(&sch, p_verrcount, he, 1 << 20), wl(&sch, p_lock, hl, 1 << 20);
+  buffer_writer<u32> wt(&sch, p_locktime, ht, 1 << 22);
+  sch.run();
+  long sb = 0, se = 0;
+  for (int i = 0; i < wb.pos; ++i) sb += hb[i];
+  for (int i = 0; i < we.pos; ++i) se += he[i];
+  if (bits) *bits = sb;
+  if (errs) *errs = se;
+  delete[] hb; delete[] he; delete[] hl; delete[] ht; free(sym);
   return w.pos;
 }
 
