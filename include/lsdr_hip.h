@@ -188,6 +188,56 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
                 float *freq_out_host, float *ss_out_host, float *mer_out_host, size_t meas_cap, size_t *n_meas,
                 lsdr_cf32 *cstln_out_host, size_t cstln_cap, size_t *n_cstln);
 
+/* ================================================================== DVB-S FEC tail
+ * Item layouts: bytes are u8; RS packets 204 B (rspacket<u8>), TS packets 188 B (tspacket). */
+
+/* ---- deconvol_sync<u8,0> via make_deconvol_sync_simple, dvb.h:122-513 (algebraic deconvolution).
+ * `rate` is LSDR_FEC12/23/46/34/56/78.  fastlock (dvb.h:428-454) is not implemented on the device:
+ * create fails with LSDR_E_UNSUPPORTED when requested. */
+typedef struct lsdr_deconv lsdr_deconv;
+int lsdr_deconv_create(lsdr_ctx *ctx, int rate, int fastlock, lsdr_deconv **d);
+void lsdr_deconv_destroy(lsdr_deconv *d);
+int lsdr_deconv_next_sync(lsdr_deconv *d);                       /* deconvol_sync::next_sync, dvb.h:185-193 */
+/* One run() call (run_decoding, dvb.h:419-470): skips `skip` symbols, needs >= 64 symbols of margin,
+ * produces n = min(maxrd, cap_out) bytes when n >= 32.  Asynchronous (sizes are data-independent). */
+int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                    size_t *consumed, size_t *produced);
+
+/* ---- mpeg_sync<u8,0>, dvb.h:712-891: bit alignment, polarity and 0x47/0xB8 sync search, lock tracking.
+ * One run() call.  *call_next_sync = 1 when the reference would call deconv->next_sync() (dvb.h:771-779);
+ * state_events (host, may be NULL) receives the values written to the lock-state pipe (0/1), at most 2.
+ * *locktime receives the running count of packets since lock (the last value written to the locktime
+ * pipe; one value per produced packet, consecutive).  Synchronous. */
+typedef struct lsdr_mpeg_sync lsdr_mpeg_sync;
+int lsdr_mpeg_sync_create(lsdr_ctx *ctx, int fastlock, lsdr_mpeg_sync **m);
+void lsdr_mpeg_sync_destroy(lsdr_mpeg_sync *m);
+int lsdr_mpeg_sync_run(lsdr_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out,
+                       size_t *consumed, size_t *produced, int *state_events_host, int *n_state_events,
+                       unsigned long *locktime, int *call_next_sync);
+int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m);
+
+/* ---- deinterleaver<u8>::run, dvb.h:932-944 (Forney I=12, M=17 as a gather).  Needs 2448 bytes per
+ * packet window; *produced packets of 204 B, *consumed = 204 * produced.  Asynchronous. */
+int lsdr_deinterleaver_run(lsdr_ctx *ctx, const uint8_t *in, size_t n_in, uint8_t *out_packets, size_t cap_packets,
+                           size_t *consumed, size_t *produced);
+
+/* ---- rs_decoder<u8,0>::run + rs_engine, dvb.h:998-1053, rs.h:84-272.  in: n packets of 204 B (corrected in
+ * place like the reference), out: n packets of 188 B (sync byte ^0x55 when uncorrectable).  `bits`/`errs`
+ * are the values of the bitcount/errcount pipes for this call.  Synchronous (counters). */
+int lsdr_rs_decoder_run(lsdr_ctx *ctx, uint8_t *in_packets, size_t n_packets, uint8_t *out_packets,
+                        long *bits, long *errs);
+
+/* ---- derandomizer, dvb.h:1107-1163: PRBS removal, resync on the inverted sync byte, drops packets whose
+ * restored sync byte is not 0x47.  Synchronous (output count is data dependent). */
+typedef struct lsdr_derandomizer lsdr_derandomizer;
+int lsdr_derandomizer_create(lsdr_ctx *ctx, lsdr_derandomizer **d);
+void lsdr_derandomizer_destroy(lsdr_derandomizer *d);
+int lsdr_derandomizer_run(lsdr_derandomizer *d, const uint8_t *in_packets, size_t n_packets, uint8_t *out_packets,
+                          size_t cap_packets, size_t *consumed, size_t *produced);
+/* host-side tables for tests: PRBS pattern (dvb.h:1116-1129), GF(256) exp/log and RS generator (rs.h:47-105) */
+void lsdr_derandomizer_pattern(uint8_t *pattern1504_host);
+void lsdr_rs_tables(uint8_t *exp512_host, uint8_t *log256_host, uint8_t *G17_host);
+
 #ifdef __cplusplus
 }
 #endif

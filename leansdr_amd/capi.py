@@ -104,6 +104,21 @@ _sig("lsdr_rx_readahead", C.c_int, [vp])
 _sig("lsdr_rx_get_state", C.c_int, [vp, C.POINTER(RxState)])
 _sig("lsdr_rx_set_state", C.c_int, [vp, C.POINTER(RxState)])
 _sig("lsdr_rx_tiled_stats", C.c_int, [vp] + [C.POINTER(C.c_uint)] * 4)
+_sig("lsdr_deconv_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
+_sig("lsdr_deconv_destroy", None, [vp])
+_sig("lsdr_deconv_next_sync", C.c_int, [vp])
+_sig("lsdr_deconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_mpeg_sync_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
+_sig("lsdr_mpeg_sync_destroy", None, [vp])
+_sig("lsdr_mpeg_sync_locked", C.c_int, [vp])
+_sig("lsdr_mpeg_sync_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, C.POINTER(C.c_int), C.POINTER(C.c_ulong), C.POINTER(C.c_int)])
+_sig("lsdr_deinterleaver_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_rs_decoder_run", C.c_int, [vp, vp, c_sz, vp, C.POINTER(C.c_long), C.POINTER(C.c_long)])
+_sig("lsdr_derandomizer_create", C.c_int, [vp, C.POINTER(vp)])
+_sig("lsdr_derandomizer_destroy", None, [vp])
+_sig("lsdr_derandomizer_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_derandomizer_pattern", None, [vp])
+_sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 
 #: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
@@ -385,3 +400,145 @@ class CstlnReceiver:
         r["state"] = self.state()
         din.free(); dout.free()
         return r
+
+
+# ---- FEC tail -----------------------------------------------------------------------
+def derandomizer_pattern():
+    out = np.empty(1504, np.uint8)
+    lib.lsdr_derandomizer_pattern(_np(out))
+    return out
+
+
+def rs_tables():
+    e, l, g = np.empty(512, np.uint8), np.empty(256, np.uint8), np.empty(17, np.uint8)
+    lib.lsdr_rs_tables(_np(e), _np(l), _np(g))
+    return e, l, g
+
+
+class Deconv:
+    """deconvol_sync<u8,0> (dvb.h:122-513) on the GPU."""
+
+    def __init__(self, ctx, rate=FEC12, fastlock=0):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_deconv_create(ctx.h, rate, fastlock, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_deconv_destroy(self.h)
+            self.h = None
+
+    def next_sync(self):
+        check(lib.lsdr_deconv_next_sync(self.h))
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap):
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_deconv_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run_stream(self, sym, pipe=4096, room=8192):
+        """Whole stream through repeated run() calls on windows of `pipe` symbols (like the reference pipes)."""
+        sym = np.ascontiguousarray(sym, SOFTSYM)
+        din = self.ctx.upload(sym)
+        dout = self.ctx.alloc(len(sym) + 64)
+        pos, nout = 0, 0
+        while True:
+            avail = min(pipe, len(sym) - pos)
+            cons, prod = self.run_dev(din.at(pos * 4), avail, dout.at(nout), room)
+            if not cons and not prod:
+                break
+            pos += cons
+            nout += prod
+        out = self.ctx.download(dout, np.uint8, nout)
+        din.free(); dout.free()
+        return out
+
+
+class MpegSync:
+    """mpeg_sync<u8,0> (dvb.h:712-891) on the GPU."""
+
+    def __init__(self, ctx, fastlock=0):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_mpeg_sync_create(ctx.h, fastlock, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_mpeg_sync_destroy(self.h)
+            self.h = None
+
+    @property
+    def locked(self):
+        return bool(lib.lsdr_mpeg_sync_locked(self.h))
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap):
+        cons, prod = c_sz(), c_sz()
+        ev = (C.c_int * 8)()
+        nev, lt, cns = C.c_int(), C.c_ulong(), C.c_int()
+        check(lib.lsdr_mpeg_sync_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod), ev, C.byref(nev),
+                                     C.byref(lt), C.byref(cns)))
+        return cons.value, prod.value, list(ev[:nev.value]), lt.value, cns.value
+
+    def run_stream(self, data):
+        data = np.ascontiguousarray(data, np.uint8)
+        din = self.ctx.upload(data)
+        dout = self.ctx.alloc(len(data) + 4096)
+        pos, nout, events = 0, 0, []
+        while True:
+            cons, prod, ev, lt, cns = self.run_dev(din.at(pos), len(data) - pos, dout.at(nout), len(data) + 4096 - nout)
+            events += ev
+            if not cons and not prod:
+                break
+            pos += cons
+            nout += prod
+        out = self.ctx.download(dout, np.uint8, nout)
+        din.free(); dout.free()
+        return out, events
+
+
+def deinterleaver(ctx, data):
+    data = np.ascontiguousarray(data, np.uint8)
+    din = ctx.upload(data)
+    cap = len(data) // 204 + 1
+    dout = ctx.alloc(cap * 204)
+    cons, prod = c_sz(), c_sz()
+    check(lib.lsdr_deinterleaver_run(ctx.h, din.ptr, len(data), dout.ptr, cap, C.byref(cons), C.byref(prod)))
+    out = ctx.download(dout, np.uint8, prod.value * 204).reshape(-1, 204)
+    din.free(); dout.free()
+    return out, cons.value
+
+
+def rs_decoder(ctx, packets):
+    packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 204)
+    din = ctx.upload(packets)
+    dout = ctx.alloc(max(1, len(packets)) * 188)
+    b, e = C.c_long(), C.c_long()
+    check(lib.lsdr_rs_decoder_run(ctx.h, din.ptr, len(packets), dout.ptr, C.byref(b), C.byref(e)))
+    out = ctx.download(dout, np.uint8, len(packets) * 188).reshape(-1, 188)
+    din.free(); dout.free()
+    return out, b.value, e.value
+
+
+class Derandomizer:
+    def __init__(self, ctx):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_derandomizer_create(ctx.h, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_derandomizer_destroy(self.h)
+            self.h = None
+
+    def run(self, packets):
+        packets = np.ascontiguousarray(packets, np.uint8).reshape(-1, 188)
+        din = self.ctx.upload(packets)
+        dout = self.ctx.alloc(max(1, len(packets)) * 188)
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_derandomizer_run(self.h, din.ptr, len(packets), dout.ptr, len(packets), C.byref(cons), C.byref(prod)))
+        out = self.ctx.download(dout, np.uint8, prod.value * 188).reshape(-1, 188)
+        din.free(); dout.free()
+        return out

@@ -1,0 +1,898 @@
+// leansdr_amd/csrc/fec.hip — DVB-S FEC tail on gfx950 (integer / byte work, bit-exact).
+//
+//   deconvol_sync   dvb.h:122-513   algebraic deconvolution: every output bit is a parity over a
+//                                   64-bit window of I/Q bits → one thread per output byte.
+//   mpeg_sync       dvb.h:712-891   bit phase / polarity / sync search + lock tracking: a sequential
+//                                   state machine over 204-byte packets; one workgroup, lane 0 keeps
+//                                   the reference's state, all lanes move and test bytes.
+//   deinterleaver   dvb.h:926-948   fixed gather, one thread per byte.
+//   rs_decoder      dvb.h:985-1058 + rs.h   one wavefront per packet: 16 lanes run the syndromes
+//                                   (Horner, log/exp tables in LDS), lane 0 runs Berlekamp-Massey /
+//                                   Chien / Forney for corrupted packets.
+//   derandomizer    dvb.h:1107-1163 PRBS XOR with resync and packet dropping: flags → scan → apply.
+//
+// These are HBM-streaming byte kernels (no MFMA, nothing to reshape into a GEMM); their rates are
+// 1/8…1/16 of the symbol rate, so the design goal is exactness with full parallelism per packet.
+#include "lsdr_internal.h"
+
+namespace {
+
+constexpr int kRS = 204, kTS = 188;
+constexpr int kSync = 0x47, kSyncInv = 0xb8, kCorrupt = 0x55;
+
+__device__ __forceinline__ int par64(unsigned long long x) { return __popcll(x) & 1; }
+
+// ======================================================================== deconvol_sync
+struct deconv_dev {
+  unsigned long long deconv[8];
+  unsigned char lut[4];   // I/Q bits per hard symbol for the locked alignment: lut[symbol] (dvb.h:377)
+  int pp, pw;             // punctperiod, punctweight
+};
+struct deconv_carry {      // sync_t fields that cross run() calls (dvb.h:297-306)
+  unsigned long long in;   // shift register of I/Q bits
+  unsigned long long out;  // pending decoded bits
+};
+
+// Decoding plan of one call, all derived on the host from (n_in0, n_out0, n):
+//   refill q (q = 0…R-1) shifts in m(q) symbols and emits pp bits; m(0) = m0, m(q>0) = pw/2.
+//   output bit stream = n_out0 carried bits ++ refill bits; byte k = bits [8k, 8k+8).
+struct deconv_plan {
+  const lsdr_softsymbol *in;
+  unsigned char *out;
+  unsigned long long n_bytes;
+  unsigned long long refills;      // R
+  unsigned m0;                     // symbols shifted in by refill 0
+  int n_out0;                      // carried bits in front of the stream
+  deconv_carry *carry;             // in: state at call start; out: state at call end
+  deconv_carry *carry_next;
+  int n_out_end;
+};
+
+// I/Q window after refill q: the 64 newest I/Q bits, newest symbol in the low bits (dvb.h:378-384).
+__device__ __forceinline__ unsigned long long deconv_window(const deconv_dev &D, const deconv_plan &P,
+                                                            unsigned long long in0, unsigned long long q) {
+  const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);   // symbols shifted in so far
+  unsigned long long w = 0;
+  const unsigned take = nsym < 32 ? (unsigned)nsym : 32u;
+  for (unsigned k = 0; k < take; ++k)   // oldest of the `take` first
+    w = (w << 2) | D.lut[P.in[nsym - take + k].symbol & 3];
+  if (take < 32) w |= in0 << (2 * take);
+  return w;
+}
+
+__global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
+  const unsigned long long in0 = P.carry->in, out0 = P.carry->out;
+  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  if (k < P.n_bytes) {
+    unsigned v = 0;
+    long long g = (long long)(8 * k) - P.n_out0;   // index into the refill bit stream (negative: carried bits)
+    unsigned long long q_cached = ~0ull, w = 0;
+    for (int b = 0; b < 8; ++b, ++g) {
+      unsigned bit;
+      if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;   // carried bits, MSB first
+      else {
+        const unsigned long long q = (unsigned long long)g / (unsigned)D.pp;
+        const int bi = D.pp - 1 - (int)((unsigned long long)g % (unsigned)D.pp);
+        if (q != q_cached) {
+          if (q_cached != ~0ull && q == q_cached + 1) {   // slide by one refill
+            const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);
+            for (int s = D.pw / 2; s > 0; --s) w = (w << 2) | D.lut[P.in[nsym - s].symbol & 3];
+          } else w = deconv_window(D, P, in0, q);
+          q_cached = q;
+        }
+        bit = (unsigned)par64(w & D.deconv[bi]);
+      }
+      v = (v << 1) | bit;
+    }
+    P.out[k] = (unsigned char)v;
+  }
+  if (k == 0) {   // state for the next call
+    deconv_carry c;
+    if (P.refills) {
+      c.in = deconv_window(D, P, in0, P.refills - 1);
+      unsigned long long o = out0;   // only the low n_out_end bits matter afterwards
+      const unsigned long long w = c.in;
+      // bits still pending come from the tail of the last refill(s); n_out_end < pp + 8
+      // rebuild the pending bits exactly: they are the last n_out_end bits of the stream
+      o = 0;
+      for (int t = P.n_out_end; t > 0; --t) {
+        const long long g = (long long)(P.refills * (unsigned)D.pp) - t;   // refill-stream index
+        unsigned bit;
+        if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;
+        else {
+          const unsigned long long q = (unsigned long long)g / (unsigned)D.pp;
+          const int bi = D.pp - 1 - (int)((unsigned long long)g % (unsigned)D.pp);
+          const unsigned long long wq = q == P.refills - 1 ? w : deconv_window(D, P, in0, q);
+          bit = (unsigned)par64(wq & D.deconv[bi]);
+        }
+        o = (o << 1) | bit;
+      }
+      c.out = o;
+    } else {
+      c.in = in0;
+      c.out = out0;
+    }
+    *P.carry_next = c;
+  }
+}
+
+// ======================================================================== mpeg_sync
+struct msync_state {    // mpeg_sync members, dvb.h:877-890
+  int scan_syncs, want_syncs, fastlock, resync_period;
+  unsigned lock_timeout;
+  unsigned polarity;
+  int resync_phase, bitphase, synchronized, next_sync_count, phase8;
+  unsigned lock_timeleft;
+  unsigned long long locktime;
+};
+struct msync_result {
+  unsigned long long consumed, produced;
+  int n_events, events[4];
+  int call_next_sync;
+};
+
+__device__ __forceinline__ unsigned char shift_byte(const unsigned char *p, int bitphase) {
+  // `w = (w<<8)|*pin; *pout = w >> bitphase` with a 16-bit w (dvb.h:803-807)
+  const unsigned short w = (unsigned short)((p[0] << 8) | p[1]);
+  return (unsigned char)(w >> bitphase);
+}
+
+// search_sync, dvb.h:798-840.  All lanes; returns (uniformly) whether a lock was found.
+__device__ bool msync_search(msync_state &S, const unsigned char *in, unsigned long long &pos, unsigned char *tmp,
+                             msync_result &R, int *s_best, int tid) {
+  const int chunk = kRS * S.scan_syncs;
+  for (int k = tid; k < chunk; k += 256) tmp[k] = shift_byte(in + pos + k, S.bitphase);
+  __syncthreads();
+  if (tid == 0) *s_best = 0x7fffffff;
+  __syncthreads();
+  int my_pol = 0, my_phase8 = -1;
+  if (tid < kRS) {
+    int np = 0, nn = 0, p8p = -1, p8n = -1;
+    for (int j = 0; j < S.scan_syncs; ++j) {
+      const unsigned char b = tmp[tid + j * kRS];
+      if (b == kSync) { ++np; p8n = (8 - j) & 7; }
+      if (b == kSyncInv) { ++nn; p8p = (8 - j) & 7; }
+    }
+    int nsyncs;
+    if (np > nn) { my_pol = 0; nsyncs = np; my_phase8 = p8p; }
+    else { my_pol = 0xff; nsyncs = nn; my_phase8 = p8n; }
+    if (nsyncs >= S.want_syncs && my_phase8 >= 0) atomicMin(s_best, tid);   // first offset wins
+  }
+  __syncthreads();
+  const int best = *s_best;
+  __syncthreads();
+  if (best == 0x7fffffff) {
+    // no lock: the reference leaves polarity/phase8 at the values of offset 203 (harmless, kept for state parity)
+    if (tid == kRS - 1) { S.polarity = (unsigned)my_pol; S.phase8 = my_phase8; }
+    __syncthreads();
+    return false;
+  }
+  if (tid == best) {
+    S.polarity = (unsigned)my_pol;
+    S.phase8 = my_phase8;
+    int i = best;
+    if (!i) { i = kRS; S.phase8 = (S.phase8 + 1) & 7; }
+    pos += i;
+    S.synchronized = 1;
+    S.lock_timeleft = S.lock_timeout;
+    S.locktime = 0;
+    R.events[R.n_events++] = 1;
+  }
+  __syncthreads();
+  return true;
+}
+
+// One mpeg_sync::run() call (dvb.h:743-754).
+__global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsigned char *in, unsigned long long n_in,
+                                                   unsigned char *out, unsigned long long cap, msync_result *gR) {
+  __shared__ msync_state S;
+  __shared__ msync_result R;
+  __shared__ unsigned long long pos, nout;
+  __shared__ int s_best, s_stop;
+  const int tid = threadIdx.x;
+  if (tid == 0) { S = *gS; R.consumed = R.produced = 0; R.n_events = 0; R.call_next_sync = 0; pos = 0; nout = 0; s_stop = 0; }
+  __syncthreads();
+  const int chunk = kRS * S.scan_syncs;
+  if (S.synchronized) {   // run_decoding, dvb.h:842-875
+    while (n_in - pos >= (unsigned long long)kRS + 1 && cap - nout >= (unsigned long long)kRS && !s_stop) {
+      const unsigned char *pin = in + pos;
+      unsigned char *pout = out + nout;
+      if (tid < kRS) pout[tid] = (unsigned char)(shift_byte(pin + tid, S.bitphase) ^ S.polarity);
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned char syncbyte = pout[0];
+        pos += kRS; nout += kRS;
+        ++S.locktime;
+        const unsigned char expected = S.phase8 ? kSync : kSyncInv;
+        if (syncbyte == expected) S.lock_timeleft = S.lock_timeout;
+        S.phase8 = (S.phase8 + 1) & 7;
+        --S.lock_timeleft;
+        if (!S.lock_timeleft) {
+          S.synchronized = 0;
+          S.next_sync_count = 0;
+          R.events[R.n_events++] = 0;
+          s_stop = 1;
+        }
+      }
+      __syncthreads();
+    }
+  } else if (S.fastlock) {   // run_searching_fast, dvb.h:782-796
+    bool done = false;
+    while (!done && n_in - pos >= (unsigned long long)chunk + 1 && cap - nout >= (unsigned long long)chunk) {
+      if (S.resync_phase == 0) {
+        for (int bp = 0; bp <= 7 && !done; ++bp) {
+          if (tid == 0) S.bitphase = bp;
+          __syncthreads();
+          done = msync_search(S, in, pos, out + nout, R, &s_best, tid);
+        }
+        if (!done && tid == 0) S.bitphase = 8;   // loop exit value of the reference's for(bitphase…)
+        __syncthreads();
+      }
+      if (done) break;
+      if (tid == 0) { pos += kRS; if (++S.resync_phase >= S.resync_period) S.resync_phase = 0; }
+      __syncthreads();
+    }
+  } else {   // run_searching, dvb.h:756-780
+    bool locked_now = false, next_sync = false;
+    while (n_in - pos >= (unsigned long long)chunk + 1 && cap - nout >= (unsigned long long)chunk) {
+      if (msync_search(S, in, pos, out + nout, R, &s_best, tid)) { locked_now = true; break; }
+      if (tid == 0) {
+        pos += chunk;
+        ++S.bitphase;
+        if (S.bitphase == 8) S.bitphase = 0;
+      }
+      __syncthreads();
+      if (S.bitphase == 0) next_sync = true;
+      __syncthreads();
+    }
+    if (!locked_now && next_sync && tid == 0) {
+      ++S.next_sync_count;
+      if (S.next_sync_count >= 3) { S.next_sync_count = 0; R.call_next_sync = 1; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { R.consumed = pos; R.produced = nout; *gS = S; *gR = R; }
+}
+
+// ======================================================================== deinterleaver
+// out[p][j] = in[p*204 + 2244 + j − 12·17·((11 − j) mod 12)]   (dvb.h:935-940)
+__global__ __launch_bounds__(256) void k_deinterleave(const unsigned char *in, unsigned long long n_packets,
+                                                      unsigned char *out) {
+  const unsigned long long total = n_packets * kRS;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+    const unsigned long long p = i / kRS;
+    const unsigned j = (unsigned)(i % kRS);
+    const unsigned delay = 17u * ((11u + 12u * 17u - j) % 12u);
+    out[i] = in[p * kRS + 2244 + j - 12ull * delay];
+  }
+}
+
+// ======================================================================== RS(204,188)
+struct gf_tables { unsigned char exp[512]; unsigned char log[256]; };
+
+__device__ __forceinline__ unsigned char gmul(const gf_tables &g, unsigned char x, unsigned char y) {
+  return (!x || !y) ? 0 : g.exp[g.log[x] + g.log[y]];
+}
+__device__ __forceinline__ unsigned char gdiv(const gf_tables &g, unsigned char x, unsigned char y) {
+  return !x ? 0 : g.exp[g.log[x] + 255 - g.log[y]];
+}
+__device__ __forceinline__ unsigned char ginv(const gf_tables &g, unsigned char x) { return g.exp[255 - g.log[x]]; }
+__device__ unsigned char eval_poly(const gf_tables &g, const unsigned char *p, int deg, unsigned char x) {
+  unsigned char a = 0;
+  for (; deg >= 0; --deg) a = gmul(g, a, x) ^ p[deg];
+  return a;
+}
+
+// rs_engine::correct, rs.h:173-270, run by one lane on the packet copy in LDS.
+__device__ void rs_correct(const gf_tables &g, const unsigned char *synd, unsigned char *pk /*204, in place*/,
+                           unsigned char *pout /*188*/, int *nerrs) {
+  unsigned char C[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned char B[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int L = 0, m = 1;
+  unsigned char b = 1;
+  for (int n = 0; n < 16; ++n) {
+    unsigned char d = synd[n];
+    for (int i = 1; i <= L; ++i) d ^= gmul(g, C[i], synd[n - i]);
+    if (!d) ++m;
+    else if (2 * L <= n) {
+      unsigned char T[16];
+      for (int i = 0; i < 16; ++i) T[i] = C[i];
+      for (int i = 0; i < 16 - m; ++i) C[m + i] ^= gmul(g, d, gmul(g, ginv(g, b), B[i]));
+      L = n + 1 - L;
+      for (int i = 0; i < 16; ++i) B[i] = T[i];
+      b = d;
+      m = 1;
+    } else {
+      for (int i = 0; i < 16 - m; ++i) C[m + i] ^= gmul(g, d, gmul(g, ginv(g, b), B[i]));
+      ++m;
+    }
+  }
+  unsigned char omega[16];
+  for (int i = 0; i < 16; ++i) omega[i] = 0;
+  for (int i = 0; i < 16; ++i)
+    for (int j = 0; j < 16; ++j)
+      if (i + j < 16) omega[i + j] ^= gmul(g, synd[i], C[j]);
+  unsigned char Cprime[15];
+  for (int i = 0; i < 15; ++i) Cprime[i] = (i & 1) ? 0 : C[i + 1];
+  int roots = 0;
+  for (int i = 0; i < 255; ++i) {
+    const unsigned char r = g.exp[i];
+    if (!eval_poly(g, C, L, r)) {
+      const unsigned char xk = ginv(g, r);
+      const int loc = (255 - i) % 255;
+      if (loc < 204) {
+        const unsigned char num = gmul(g, xk, eval_poly(g, omega, L, r));
+        const unsigned char den = eval_poly(g, Cprime, 14, r);
+        const unsigned char e = gdiv(g, num, den);
+        *nerrs += __popc((unsigned)e);
+        if (loc >= 16) pout[203 - loc] ^= e;
+        pk[203 - loc] ^= e;
+      }
+      if (++roots == L) break;
+    }
+  }
+}
+
+// One wavefront per packet, 4 packets per workgroup.
+__global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned long long n_packets, unsigned char *out,
+                                                   const gf_tables *gtab, unsigned long long *counters /*[0] errs*/) {
+  __shared__ gf_tables g;
+  __shared__ unsigned char pk[4][kRS + 4], po[4][kTS + 4], synd[4][16];
+  __shared__ int corrupted[4];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 512; i += 256) g.exp[i] = gtab->exp[i];
+  g.log[tid] = gtab->log[tid];
+  const unsigned long long p = (unsigned long long)blockIdx.x * 4 + wv;
+  const bool live = p < n_packets;
+  if (live)
+    for (int i = lane; i < kRS; i += 64) pk[wv][i] = in[p * kRS + i];
+  if (lane == 0) corrupted[wv] = 0;
+  __syncthreads();
+  if (live) {
+    for (int i = lane; i < kTS; i += 64) po[wv][i] = pk[wv][i];   // the message is the first 188 bytes
+    if (lane < 16) {   // synd[i] = P(alpha^i), Horner over the 204 bytes (rs.h:116-129)
+      const unsigned char x = g.exp[lane];
+      unsigned char acc = 0;
+      for (int i = 0; i < kRS; ++i) acc = gmul(g, acc, x) ^ pk[wv][i];
+      synd[wv][lane] = acc;
+      if (acc) corrupted[wv] = 1;
+    }
+  }
+  __syncthreads();
+  if (live && corrupted[wv]) {
+    if (lane == 0) {
+      int nerrs = 0;
+      rs_correct(g, synd[wv], pk[wv], po[wv], &nerrs);
+      if (nerrs) atomicAdd(&counters[0], (unsigned long long)nerrs);
+      corrupted[wv] = 0;
+    }
+  }
+  __syncthreads();
+  if (live) {   // re-check the corrected packet (correct() returns syndromes(pin), rs.h:266-269)
+    // (cheap to run unconditionally; only meaningful for packets that went through correct())
+    if (lane < 16) {
+      const unsigned char x = g.exp[lane];
+      unsigned char acc = 0;
+      for (int i = 0; i < kRS; ++i) acc = gmul(g, acc, x) ^ pk[wv][i];
+      if (acc) corrupted[wv] = 1;
+    }
+  }
+  __syncthreads();
+  if (live) {
+    if (lane == 0 && corrupted[wv]) po[wv][0] ^= kCorrupt;   // dvb.h:1045
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = po[wv][i];
+    for (int i = lane; i < kRS; i += 64) in[p * kRS + i] = pk[wv][i];   // in-place correction like the reference
+  }
+}
+
+// ======================================================================== derandomizer
+struct derand_result { unsigned long long produced; int pos_end; };
+
+// Single workgroup: per-packet PRBS offset (resets at 0xB8 / 0xB8^0x55), keep flags, output slots.
+__global__ __launch_bounds__(1024) void k_derand_scan(const unsigned char *in, unsigned n_packets, int pos0,
+                                                      const unsigned char *pattern, int *pkt_pos, long long *pkt_dst,
+                                                      derand_result *res) {
+  constexpr unsigned SEG = 8192, PER = 8;
+  __shared__ int s_last[16];       // per wave: index of the last reset (-1: none)
+  __shared__ unsigned s_cnt[16];
+  __shared__ int carry_last, carry_pos;   // last reset before this segment (absolute index) or -1 with pos0 at index 0
+  __shared__ unsigned long long carry_cnt;
+  __shared__ int s_last_seg[SEG / PER];
+  const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) { carry_last = -1; carry_pos = pos0; carry_cnt = 0; }
+  for (unsigned base = 0; base < n_packets; base += SEG) {
+    __syncthreads();
+    // pass 1: reset flags of my 8 packets, running "last reset" (absolute packet index)
+    int last = -1;
+    unsigned char first[PER];
+    for (unsigned q = 0; q < PER; ++q) {
+      const unsigned j = base + tid * PER + q;
+      unsigned char b0 = 0;
+      if (j < n_packets) {
+        b0 = in[(unsigned long long)j * kTS];
+        if (b0 == kSyncInv || b0 == (kSyncInv ^ kCorrupt)) last = (int)j;
+      }
+      first[q] = b0;
+    }
+    // inclusive max-scan of `last` across the workgroup
+    int ilast = last;
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(ilast, d, 64); if (lane >= (unsigned)d && o > ilast) ilast = o; }
+    if (lane == 63) s_last[wv] = ilast;
+    __syncthreads();
+    int before = carry_last;   // last reset strictly before my first packet
+    for (unsigned i = 0; i < wv; ++i) if (s_last[i] > before) before = s_last[i];
+    {
+      const int up = __shfl_up(ilast, 1, 64);
+      if (lane > 0 && up > before) before = up;
+    }
+    // pass 2: offsets and keep flags
+    unsigned keep_cnt = 0;
+    int poss[PER];
+    bool keeps[PER];
+    int cur_last = before;
+    for (unsigned q = 0; q < PER; ++q) {
+      const unsigned j = base + tid * PER + q;
+      keeps[q] = false; poss[q] = 0;
+      if (j < n_packets) {
+        const unsigned char b0 = first[q];
+        if (b0 == kSyncInv || b0 == (kSyncInv ^ kCorrupt)) cur_last = (int)j;
+        int pos;
+        if (cur_last >= 0) pos = (int)(((long long)(j - (unsigned)cur_last) * kTS) % 1504);
+        else pos = (int)(((long long)carry_pos + (long long)j * kTS) % 1504);   // no reset yet: continue from the carried offset
+        poss[q] = pos;
+        keeps[q] = (unsigned char)(b0 ^ pattern[pos]) == kSync;
+        keep_cnt += keeps[q] ? 1u : 0u;
+      }
+    }
+    unsigned icnt = keep_cnt;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(icnt, d, 64); if (lane >= (unsigned)d) icnt += o; }
+    if (lane == 63) s_cnt[wv] = icnt;
+    __syncthreads();
+    unsigned long long off = carry_cnt;
+    for (unsigned i = 0; i < wv; ++i) off += s_cnt[i];
+    off += icnt - keep_cnt;
+    for (unsigned q = 0; q < PER; ++q) {
+      const unsigned j = base + tid * PER + q;
+      if (j < n_packets) {
+        pkt_pos[j] = poss[q];
+        pkt_dst[j] = keeps[q] ? (long long)off : -1;
+        if (keeps[q]) ++off;
+      }
+    }
+    __syncthreads();
+    if (tid == 1023) {
+      unsigned long long tot = carry_cnt;
+      for (int i = 0; i < 16; ++i) tot += s_cnt[i];
+      carry_cnt = tot;
+      int l = carry_last;
+      for (int i = 0; i < 16; ++i) if (s_last[i] > l) l = s_last[i];
+      carry_last = l;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    res->produced = carry_cnt;
+    // PRBS offset after the last packet
+    long long pe;
+    if (carry_last >= 0) pe = ((long long)(n_packets - (unsigned)carry_last) * kTS) % 1504;
+    else pe = ((long long)pos0 + (long long)n_packets * kTS) % 1504;
+    res->pos_end = (int)pe;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_derand_apply(const unsigned char *in, unsigned n_packets, const unsigned char *pattern,
+                                                      const int *pkt_pos, const long long *pkt_dst, unsigned char *out) {
+  const unsigned p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const unsigned lane = threadIdx.x & 63;
+  if (p >= n_packets) return;
+  const long long dst = pkt_dst[p];
+  if (dst < 0) return;   // restored sync != 0x47: TEI would be set in a slot that is never committed (dvb.h:1149-1156)
+  const int pos = pkt_pos[p];
+  for (unsigned i = lane; i < (unsigned)kTS; i += 64)
+    out[(unsigned long long)dst * kTS + i] = in[(unsigned long long)p * kTS + i] ^ pattern[pos + i];
+}
+
+}  // namespace
+
+// ============================================================================ host side
+namespace {
+int log2u(unsigned long long x) { int n = -1; for (; x; ++n, x >>= 1); return n; }
+int hpar(unsigned long long x) { return __builtin_parityll(x); }
+
+struct deconv_host {
+  unsigned conv[2], punct[2];
+  int pp, pw;
+  unsigned long long response[64], deconv[8], deconv2[8];
+};
+unsigned long long dc_convolve(const deconv_host &d, unsigned long long s) {   // dvb.h:163-179
+  const int sbits = log2u(s) + 1;
+  unsigned long long iq = 0;
+  unsigned char state = 0;
+  for (int b = sbits - 1; b >= 0; --b) {
+    const unsigned char bit = (s >> b) & 1;
+    state = (unsigned char)((state >> 1) | (bit << 6));
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char xy = (unsigned char)hpar(state & d.conv[j]);
+      if (d.punct[j] & (1u << (b % d.pp))) iq = (iq << 1) | xy;
+    }
+  }
+  return iq;
+}
+void dc_solve(const deconv_host &d, unsigned long long prefix, int nprefix, unsigned long long exp, unsigned long long *best) {
+  if (prefix > *best) return;   // dvb.h:205-224
+  if (nprefix > 64) return;
+  bool solved = true;
+  for (int b = 0; b < 64; ++b)
+    if (hpar(prefix & d.response[b]) != (int)((exp >> b) & 1)) {
+      if (nprefix >= 64 || (d.response[b] >> nprefix) == 0) return;
+      solved = false;
+    }
+  if (solved) { *best = prefix; return; }
+  dc_solve(d, prefix, nprefix + 1, exp, best);
+  dc_solve(d, prefix | (1ull << nprefix), nprefix + 1, exp, best);
+}
+}  // namespace
+
+struct lsdr_deconv {
+  lsdr_ctx *ctx;
+  deconv_host H;
+  unsigned char luts[4][4];   // per alignment: I/Q bits by hard symbol
+  int locked, skip;
+  int n_in[4], n_out[4];      // sync_t counters per alignment (dvb.h:297-306); data-independent → host side
+  deconv_carry *d_carry[2];   // [ping-pong][4 alignments]: shift registers live on the device
+  int cur[4];
+};
+
+struct lsdr_mpeg_sync {
+  lsdr_ctx *ctx;
+  msync_state st;             // host mirror (refreshed after every run)
+  msync_state *d_state;
+  msync_result *d_res;
+  bool report_state;
+};
+
+struct lsdr_derandomizer {
+  lsdr_ctx *ctx;
+  unsigned char pattern[1504];
+  unsigned char *d_pattern;
+  int pos;                    // PRBS offset carried between calls
+  int *d_pkt_pos; long long *d_pkt_dst; size_t cap;
+  derand_result *d_res;
+};
+
+static void derand_pattern(unsigned char *pattern) {   // dvb.h:1116-1129
+  pattern[0] = 0xff;
+  unsigned short st = 000251;
+  for (int i = 1; i < 188 * 8; ++i) {
+    unsigned char o = 0;
+    for (int n = 8; n--;) {
+      int bit = ((st >> 13) ^ (st >> 14)) & 1;
+      o = (unsigned char)((o << 1) | bit);
+      st = (unsigned short)((st << 1) | bit);
+    }
+    pattern[i] = (i % 188) ? o : 0;
+  }
+}
+
+static void gf_build(gf_tables &g) {   // gf2x_p<u8,u16,0x11d,8,2>, rs.h:47-63
+  memset(&g, 0, sizeof(g));            // lut_log[0] is never written by the reference (fresh-heap zero)
+  unsigned a = 1;
+  for (unsigned i = 0; i < 256; ++i) {
+    g.exp[i] = (unsigned char)a;
+    g.exp[255 + i] = (unsigned char)a;
+    g.log[a] = (unsigned char)i;
+    a <<= 1;
+    if (a & 256) a ^= 0x11d;
+  }
+}
+
+static gf_tables *rs_device_tables(lsdr_ctx *c) {   // one copy per device, created on first use
+  static gf_tables *d_tab[64] = {nullptr};
+  if (c->device < 0 || c->device >= 64) return nullptr;
+  if (!d_tab[c->device]) {
+    gf_tables g;
+    gf_build(g);
+    if (hipMalloc((void **)&d_tab[c->device], sizeof(gf_tables)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d_tab[c->device], &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+  }
+  return d_tab[c->device];
+}
+
+extern "C" {
+
+// ------------------------------------------------------------------ deconvol_sync
+int lsdr_deconv_create(lsdr_ctx *c, int rate, int fastlock, lsdr_deconv **out) {
+  LSDR_ARG(c && out);
+  if (fastlock) { lsdr_set_error("deconvol_sync: fastlock is not implemented on the device"); return LSDR_E_UNSUPPORTED; }
+  unsigned pX, pY;
+  switch (rate) {   // make_deconvol_sync_simple, dvb.h:480-513
+    case LSDR_FEC12: pX = 0x1; pY = 0x1; break;
+    case LSDR_FEC23: case LSDR_FEC46: pX = 0xa; pY = 0xf; break;
+    case LSDR_FEC34: pX = 0x5; pY = 0x6; break;
+    case LSDR_FEC56: pX = 0x15; pY = 0x1a; break;
+    case LSDR_FEC78: pX = 0x45; pY = 0x7a; break;
+    default: pX = pY = 1;
+  }
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_deconv *d = new lsdr_deconv();
+  d->ctx = c;
+  deconv_host &H = d->H;
+  H.conv[0] = 0171; H.conv[1] = 0133;   // DVBS_G1, DVBS_G2 (dvb.h:84-85)
+  H.punct[0] = pX; H.punct[1] = pY;
+  H.pp = 0; H.pw = 0;
+  for (int i = 0; i < 2; ++i) {
+    int nbits = log2u(H.punct[i]) + 1;
+    if (nbits > H.pp) H.pp = nbits;
+    H.pw += __builtin_popcount(H.punct[i]);
+  }
+  for (int s = 0; s < 64; ++s) H.response[s] = dc_convolve(H, 1ull << s);
+  for (int b = 0; b < H.pp; ++b) {
+    H.deconv[b] = ~0ull;
+    dc_solve(H, 0, 0, (unsigned long long)(1 << b), &H.deconv[b]);
+    for (int i = 0; i < 64; ++i)   // D·C = e_b check of the reference (dvb.h:274-283)
+      if (hpar(dc_convolve(H, 1ull << i) & H.deconv[b]) != (b == i ? 1 : 0)) {
+        delete d;
+        lsdr_set_error("deconvol_sync: failed to inverse convolutional coding");
+        return LSDR_E_ARG;
+      }
+  }
+  // init_syncs, dvb.h:309-366: lut[re_pos][im_pos]; symbol bit1 ↔ first index, bit0 ↔ second (dvb.h:377)
+  for (int id = 0; id < 4; ++id)
+    for (int sym = 0; sym < 4; ++sym) {
+      const int re_pos = (sym & 2) ? 1 : 0, im_pos = sym & 1, re_neg = !re_pos;
+      int I = 0, Q = 0;
+      switch (id) {
+        case 0: I = re_pos ? 0 : 1; Q = im_pos ? 0 : 1; break;
+        case 1: I = im_pos ? 0 : 1; Q = re_neg ? 0 : 1; break;
+        case 2: I = re_pos ? 0 : 1; Q = im_pos ? 1 : 0; break;
+        case 3: I = im_pos ? 1 : 0; Q = re_neg ? 0 : 1; break;
+      }
+      d->luts[id][sym] = (unsigned char)((I << 1) | Q);
+    }
+  d->locked = 0; d->skip = 0;
+  for (int i = 0; i < 4; ++i) { d->n_in[i] = 0; d->n_out[i] = 0; d->cur[i] = 0; }
+  for (int i = 0; i < 2; ++i) {
+    LSDR_HIP(hipMalloc((void **)&d->d_carry[i], 4 * sizeof(deconv_carry)));
+    LSDR_HIP(hipMemset(d->d_carry[i], 0, 4 * sizeof(deconv_carry)));
+  }
+  *out = d;
+  return LSDR_OK;
+}
+
+void lsdr_deconv_destroy(lsdr_deconv *d) {
+  if (!d) return;
+  (void)hipStreamSynchronize(d->ctx->stream);
+  (void)hipFree(d->d_carry[0]); (void)hipFree(d->d_carry[1]);
+  delete d;
+}
+
+int lsdr_deconv_next_sync(lsdr_deconv *d) {   // dvb.h:185-193
+  LSDR_ARG(d);
+  ++d->locked;
+  if (d->locked == 4) { d->locked = 0; d->skip = 1; }
+  return LSDR_OK;
+}
+
+int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                    size_t *consumed, size_t *produced) {
+  LSDR_ARG(d && consumed && produced);
+  const deconv_host &H = d->H;
+  size_t pos = (size_t)d->skip;   // in.read(skip), dvb.h:420-421
+  d->skip = 0;
+  *produced = 0;
+  if (pos > n_in) pos = n_in;
+  *consumed = pos;
+  const size_t readable = n_in - pos;
+  if (readable < 64) return LSDR_OK;
+  const long long maxrd = (long long)((readable - 64) / (size_t)(H.pw / 2) * (size_t)H.pp / 8);
+  long long n = maxrd < (long long)cap_out ? maxrd : (long long)cap_out;
+  if (n < 32) return LSDR_OK;   // also covers n == 0
+  LSDR_ARG(in && out);
+  const int a = d->locked;
+  const int n_in0 = d->n_in[a], n_out0 = d->n_out[a];
+  long long need = 8 * n - n_out0;
+  const unsigned long long R = need > 0 ? (unsigned long long)((need + H.pp - 1) / H.pp) : 0;
+  const unsigned m0 = n_in0 < 64 ? (unsigned)((64 - n_in0 + 1) / 2) : 0u;
+  const unsigned long long used = R ? m0 + (R - 1) * (unsigned)(H.pw / 2) : 0;
+
+  deconv_dev D;
+  for (int b = 0; b < 8; ++b) D.deconv[b] = b < H.pp ? H.deconv[b] : 0;
+  for (int sidx = 0; sidx < 4; ++sidx) D.lut[sidx] = d->luts[a][sidx];
+  D.pp = H.pp; D.pw = H.pw;
+  deconv_plan P;
+  P.in = in + pos;
+  P.out = out;
+  P.n_bytes = (unsigned long long)n;
+  P.refills = R;
+  P.m0 = m0;
+  P.n_out0 = n_out0;
+  P.carry = d->d_carry[d->cur[a]] + a;
+  P.carry_next = d->d_carry[d->cur[a] ^ 1] + a;
+  P.n_out_end = (int)(n_out0 + (long long)R * H.pp - 8 * n);
+  hipLaunchKernelGGL(k_deconv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->ctx->stream, D, P);
+  LSDR_HIP(hipGetLastError());
+  d->cur[a] ^= 1;
+  if (R) d->n_in[a] = 64 - H.pw;
+  d->n_out[a] = P.n_out_end;
+  *consumed = pos + (size_t)used;
+  *produced = (size_t)n;
+  return LSDR_OK;
+}
+
+// ------------------------------------------------------------------ mpeg_sync
+int lsdr_mpeg_sync_create(lsdr_ctx *c, int fastlock, lsdr_mpeg_sync **out) {
+  LSDR_ARG(c && out);
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_mpeg_sync *m = new lsdr_mpeg_sync();
+  m->ctx = c;
+  memset(&m->st, 0, sizeof(m->st));
+  m->st.scan_syncs = 8; m->st.want_syncs = 4; m->st.lock_timeout = 4;   // dvb.h:727-731
+  m->st.fastlock = fastlock ? 1 : 0;
+  m->st.resync_period = 1;
+  m->report_state = true;
+  LSDR_HIP(hipMalloc((void **)&m->d_state, sizeof(msync_state)));
+  LSDR_HIP(hipMalloc((void **)&m->d_res, sizeof(msync_result)));
+  LSDR_HIP(hipMemcpy(m->d_state, &m->st, sizeof(msync_state), hipMemcpyHostToDevice));
+  *out = m;
+  return LSDR_OK;
+}
+void lsdr_mpeg_sync_destroy(lsdr_mpeg_sync *m) {
+  if (!m) return;
+  (void)hipStreamSynchronize(m->ctx->stream);
+  (void)hipFree(m->d_state); (void)hipFree(m->d_res);
+  delete m;
+}
+int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m) { return m ? m->st.synchronized : 0; }
+
+int lsdr_mpeg_sync_run(lsdr_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out,
+                       size_t *consumed, size_t *produced, int *events, int *n_events, unsigned long *locktime,
+                       int *call_next_sync) {
+  LSDR_ARG(m && consumed && produced);
+  *consumed = 0; *produced = 0;
+  int ne = 0;
+  if (m->report_state) {   // "Report unlocked state on first invocation", dvb.h:744-748
+    if (events) events[ne] = 0;
+    ++ne;
+    m->report_state = false;
+  }
+  if (call_next_sync) *call_next_sync = 0;
+  const size_t need_in = m->st.synchronized ? (size_t)kRS + 1 : (size_t)kRS * m->st.scan_syncs + 1;
+  const size_t need_out = m->st.synchronized ? (size_t)kRS : (size_t)kRS * m->st.scan_syncs;
+  if (n_in >= need_in && cap_out >= need_out) {
+    LSDR_ARG(in && out);
+    lsdr_ctx *c = m->ctx;
+    hipLaunchKernelGGL(k_mpeg_sync, dim3(1), dim3(256), 0, c->stream, m->d_state, in, (unsigned long long)n_in, out,
+                       (unsigned long long)cap_out, m->d_res);
+    LSDR_HIP(hipGetLastError());
+    msync_result r;
+    LSDR_HIP(hipMemcpyAsync(&r, m->d_res, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipMemcpyAsync(&m->st, m->d_state, sizeof(msync_state), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    *consumed = r.consumed;
+    *produced = r.produced;
+    for (int i = 0; i < r.n_events; ++i) { if (events) events[ne] = r.events[i]; ++ne; }
+    if (call_next_sync) *call_next_sync = r.call_next_sync;
+  }
+  if (n_events) *n_events = ne;
+  if (locktime) *locktime = (unsigned long)m->st.locktime;
+  return LSDR_OK;
+}
+
+// ------------------------------------------------------------------ deinterleaver
+int lsdr_deinterleaver_run(lsdr_ctx *c, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_packets,
+                           size_t *consumed, size_t *produced) {
+  LSDR_ARG(c && consumed && produced);
+  *consumed = 0; *produced = 0;
+  const size_t window = 17 * 11 * 12 + kRS;   // dvb.h:932
+  if (n_in < window) return LSDR_OK;
+  size_t n = (n_in - window) / kRS + 1;
+  if (n > cap_packets) n = cap_packets;
+  if (!n) return LSDR_OK;
+  LSDR_ARG(in && out);
+  size_t blocks = (n * kRS + 255) / 256;
+  const size_t capb = (size_t)c->num_cu * 8;
+  if (blocks > capb) blocks = capb;
+  hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)blocks), dim3(256), 0, c->stream, in, (unsigned long long)n, out);
+  LSDR_HIP(hipGetLastError());
+  *produced = n;
+  *consumed = n * kRS;
+  return LSDR_OK;
+}
+
+// ------------------------------------------------------------------ rs_decoder
+int lsdr_rs_decoder_run(lsdr_ctx *c, uint8_t *in, size_t n, uint8_t *out, long *bits, long *errs) {
+  LSDR_ARG(c);
+  if (bits) *bits = 0;
+  if (errs) *errs = 0;
+  if (!n) return LSDR_OK;
+  LSDR_ARG(in && out);
+  LSDR_HIP(hipSetDevice(c->device));
+  gf_tables *tab = rs_device_tables(c);
+  if (!tab) { lsdr_set_error("rs_decoder: cannot allocate GF tables"); return LSDR_E_NOMEM; }
+  static unsigned long long *d_cnt[64] = {nullptr};
+  if (!d_cnt[c->device]) LSDR_HIP(hipMalloc((void **)&d_cnt[c->device], sizeof(unsigned long long)));
+  LSDR_HIP(hipMemsetAsync(d_cnt[c->device], 0, sizeof(unsigned long long), c->stream));
+  hipLaunchKernelGGL(k_rs_decode, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, in, (unsigned long long)n, out,
+                     (const gf_tables *)tab, d_cnt[c->device]);
+  LSDR_HIP(hipGetLastError());
+  unsigned long long e = 0;
+  LSDR_HIP(hipMemcpyAsync(&e, d_cnt[c->device], sizeof(e), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  if (bits) *bits = (long)(n * kRS * 8);   // nbits += SIZE_RSPACKET*8 per packet, dvb.h:1007
+  if (errs) *errs = (long)e;
+  return LSDR_OK;
+}
+
+void lsdr_rs_tables(uint8_t *exp512, uint8_t *log256, uint8_t *G17) {
+  gf_tables g;
+  gf_build(g);
+  if (exp512) memcpy(exp512, g.exp, 512);
+  if (log256) memcpy(log256, g.log, 256);
+  if (G17) {   // G(X) = Π (X − α^d), rs.h:93-105
+    unsigned char G[17];
+    for (int i = 0; i <= 16; ++i) G[i] = (i == 16) ? 1 : 0;
+    auto mul = [&](unsigned char x, unsigned char y) -> unsigned char { return (!x || !y) ? 0 : g.exp[g.log[x] + g.log[y]]; };
+    for (int dd = 0; dd < 16; ++dd)
+      for (int i = 0; i <= 16; ++i) G[i] = (unsigned char)(((i == 16) ? 0 : G[i + 1]) ^ mul(g.exp[dd], G[i]));
+    memcpy(G17, G, 17);
+  }
+}
+
+// ------------------------------------------------------------------ derandomizer
+void lsdr_derandomizer_pattern(uint8_t *p) { derand_pattern(p); }
+
+int lsdr_derandomizer_create(lsdr_ctx *c, lsdr_derandomizer **out) {
+  LSDR_ARG(c && out);
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_derandomizer *d = new lsdr_derandomizer();
+  d->ctx = c;
+  derand_pattern(d->pattern);
+  d->pos = 0;
+  d->d_pkt_pos = nullptr; d->d_pkt_dst = nullptr; d->cap = 0;
+  // pattern + 188 bytes of wrap so that pattern[pos + i] never leaves the array
+  LSDR_HIP(hipMalloc((void **)&d->d_pattern, 1504 + 188));
+  LSDR_HIP(hipMemcpy(d->d_pattern, d->pattern, 1504, hipMemcpyHostToDevice));
+  LSDR_HIP(hipMemcpy(d->d_pattern + 1504, d->pattern, 188, hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&d->d_res, sizeof(derand_result)));
+  *out = d;
+  return LSDR_OK;
+}
+void lsdr_derandomizer_destroy(lsdr_derandomizer *d) {
+  if (!d) return;
+  (void)hipStreamSynchronize(d->ctx->stream);
+  (void)hipFree(d->d_pattern); (void)hipFree(d->d_res); (void)hipFree(d->d_pkt_pos); (void)hipFree(d->d_pkt_dst);
+  delete d;
+}
+
+int lsdr_derandomizer_run(lsdr_derandomizer *d, const uint8_t *in, size_t n, uint8_t *out, size_t cap, size_t *consumed,
+                          size_t *produced) {
+  LSDR_ARG(d && consumed && produced);
+  *consumed = 0; *produced = 0;
+  if (n > cap) n = cap;   // every input packet needs an output slot (dvb.h:1131)
+  if (!n) return LSDR_OK;
+  LSDR_ARG(in && out && n < (1ull << 31));
+  lsdr_ctx *c = d->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  if (d->cap < n) {
+    (void)hipFree(d->d_pkt_pos); (void)hipFree(d->d_pkt_dst);
+    LSDR_HIP(hipMalloc((void **)&d->d_pkt_pos, n * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&d->d_pkt_dst, n * sizeof(long long)));
+    d->cap = n;
+  }
+  hipLaunchKernelGGL(k_derand_scan, dim3(1), dim3(1024), 0, c->stream, in, (unsigned)n, d->pos, (const unsigned char *)d->d_pattern,
+                     d->d_pkt_pos, d->d_pkt_dst, d->d_res);
+  hipLaunchKernelGGL(k_derand_apply, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, in, (unsigned)n,
+                     (const unsigned char *)d->d_pattern, (const int *)d->d_pkt_pos, (const long long *)d->d_pkt_dst, out);
+  LSDR_HIP(hipGetLastError());
+  derand_result r;
+  LSDR_HIP(hipMemcpyAsync(&r, d->d_res, sizeof(r), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  d->pos = r.pos_end;
+  *consumed = n;
+  *produced = (size_t)r.produced;
+  return LSDR_OK;
+}
+
+}  // extern "C"

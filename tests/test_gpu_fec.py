@@ -1,0 +1,133 @@
+"""HIP FEC tail (deconvol_sync, mpeg_sync, deinterleaver, rs_decoder, derandomizer) through the C ABI
+against the oracle and the reference's golden vectors.  Integer/byte work: bit-exact."""
+import numpy as np
+import pytest
+from conftest import gold, bits_equal
+from fec_common import sha, hard_symbols, fec_input, CASES
+
+pytestmark = pytest.mark.gpu
+
+
+def hexs(a):
+    return bytes(a).hex()
+
+
+def test_host_tables(capi, oracle):
+    g = gold("fec.npz")
+    assert bits_equal(capi.derandomizer_pattern(), g["derand_pattern"])
+    e, l, G = capi.rs_tables()
+    assert bits_equal(e[:255], g["rs_exp"]) and bits_equal(l, g["rs_log"]) and bits_equal(G, g["rs_G"])
+
+
+@pytest.mark.parametrize("tag,errp", CASES)
+def test_deconvol_sync_golden(capi, ctx, tag, errp):
+    g = gold("fec.npz")
+    sym = fec_input(hard_symbols(), errp)
+    for ns in range(5):
+        d = capi.Deconv(ctx, capi.FEC12)
+        for _ in range(ns):
+            d.next_sync()
+        b = d.run_stream(sym)
+        d.close()
+        assert len(b) == int(g[f"{tag}_deconv_ns{ns}_n"]) and sha(b) == hexs(g[f"{tag}_deconv_ns{ns}_sha"]), ns
+
+
+@pytest.mark.parametrize("rate", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("pipe,room", [(4096, 8192), (1000, 300), (1 << 20, 1 << 20)])
+def test_deconvol_sync_rates_and_chunking_vs_oracle(capi, ctx, oracle, rate, pipe, room):
+    """Punctured rates exercise refills that straddle byte boundaries; any call pattern gives the same stream."""
+    sym = fec_input(hard_symbols()[:60000], 40)
+    d = capi.Deconv(ctx, rate)
+    got = d.run_stream(sym, pipe, room)
+    d.close()
+    import ctypes as C
+    # oracle with the same call pattern
+    h = oracle.lib.lo_deconv_new(rate, 0)
+    out = np.empty(len(sym) + 64, np.uint8)
+    pos = nout = 0
+    while True:
+        c = C.c_size_t()
+        avail = min(pipe, len(sym) - pos)
+        n = oracle.lib.lo_deconv_run(h, sym[pos:].ctypes.data, avail, out[nout:].ctypes.data, room, C.byref(c))
+        if not n and not c.value:
+            break
+        pos += c.value
+        nout += n
+    oracle.lib.lo_deconv_free(h)
+    assert bits_equal(got, out[:nout])
+
+
+def test_deconvol_fastlock_unsupported(capi, ctx):
+    with pytest.raises(capi.LsdrError):
+        capi.Deconv(ctx, capi.FEC12, fastlock=1)
+
+
+@pytest.mark.parametrize("tag,errp", CASES)
+@pytest.mark.parametrize("front", ["deconv", "viterbi"])
+def test_tail_blocks_golden(capi, ctx, oracle, tag, errp, front):
+    """mpeg_sync → deinterleaver → rs_decoder → derandomizer on the reference's own intermediate streams."""
+    g = gold("fec.npz")
+    sym = fec_input(hard_symbols(), errp)
+    data = oracle.deconvol_sync(sym, 0, 0, 0) if front == "deconv" else oracle.viterbi_sync(sym, 1, 0)[0]
+    ms = capi.MpegSync(ctx)
+    m, events = ms.run_stream(data)
+    ms.close()
+    assert len(m) == int(g[f"{tag}_{front}_mpeg_n"]) and sha(m) == hexs(g[f"{tag}_{front}_mpeg_sha"])
+    assert events == g[f"{tag}_{front}_mpeg_state"].tolist()
+    pk, cons = capi.deinterleaver(ctx, m)
+    assert sha(pk) == hexs(g[f"{tag}_{front}_deint_sha"]) and cons == 204 * len(pk)
+    ts, bits, errs = capi.rs_decoder(ctx, pk)
+    assert sha(ts) == hexs(g[f"{tag}_{front}_rs_sha"]) and [bits, errs] == g[f"{tag}_{front}_rs_counts"].tolist()
+    dr = capi.Derandomizer(ctx)
+    out = dr.run(ts)
+    dr.close()
+    assert bits_equal(out, g[f"{tag}_{front}_ts"])
+
+
+def test_mpeg_sync_fastlock_and_garbage_vs_oracle(capi, ctx, oracle):
+    rng = np.random.default_rng(9)
+    sym = fec_input(hard_symbols(), 40)
+    data = oracle.deconvol_sync(sym, 0, 0, 0)
+    streams = [data, np.concatenate([rng.integers(0, 256, 5000).astype(np.uint8), data[:30000],
+                                     rng.integers(0, 256, 9000).astype(np.uint8), data[30000:]]),
+               rng.integers(0, 256, 40000).astype(np.uint8), np.roll(data, 3) ^ np.uint8(0xff)]
+    for fl in (0, 1):
+        for s in streams:
+            ms = capi.MpegSync(ctx, fl)
+            got, ev = ms.run_stream(s)
+            ms.close()
+            want, st, _ = oracle.mpeg_sync(s, fl)
+            assert bits_equal(got, want) and ev == st.tolist()
+
+
+def test_rs_error_patterns(capi, ctx, oracle):
+    g = gold("fec.npz")
+    ts, bits, errs = capi.rs_decoder(ctx, g["rs_bad_in"])
+    assert bits_equal(ts, g["rs_bad_out"]) and [bits, errs] == g["rs_bad_counts"].tolist()
+    rng = np.random.default_rng(2)
+    msgs = rng.integers(0, 256, (1000, 188)).astype(np.uint8)
+    pk = np.stack([oracle.rs_encode(m) for m in msgs])
+    for i in range(len(pk)):
+        pos = rng.choice(204, i % 13, replace=False)
+        pk[i, pos] ^= rng.integers(1, 256, len(pos)).astype(np.uint8)
+    a = capi.rs_decoder(ctx, pk)
+    b = oracle.rs_decoder(pk)
+    assert bits_equal(a[0], b[0]) and a[1:] == b[1:]
+    ok = np.array([(i % 13) <= 8 for i in range(len(pk))])
+    assert bits_equal(a[0][ok], msgs[ok])          # ≤ 8 byte errors: recovered (property)
+
+
+def test_derandomizer_resync_and_drops(capi, ctx, oracle):
+    rng = np.random.default_rng(5)
+    sym = fec_input(hard_symbols(), 0)
+    ts = oracle.rs_decoder(oracle.deinterleaver(oracle.mpeg_sync(oracle.viterbi_sync(sym, 1, 0)[0])[0]))[0]
+    bad = ts.copy()
+    bad[7, 0] ^= 0x55          # a packet the RS decoder flagged
+    bad[20:23] = rng.integers(0, 256, (3, 188))
+    big = np.concatenate([bad] * 200)      # > 8192 packets: exercises the segmented scan
+    for data in (ts, bad, big):
+        dr = capi.Derandomizer(ctx)
+        a = dr.run(data[:31])               # state (PRBS offset) carried across calls
+        b = dr.run(data[31:])
+        dr.close()
+        assert bits_equal(np.concatenate([a, b]), oracle.derandomizer(data))
