@@ -19,6 +19,7 @@
 #include "leansdr/dsp.h"
 #include "leansdr/sdr.h"
 #include "leansdr/filtergen.h"
+#include "leansdr/dvb.h"
 
 using namespace leansdr;
 
@@ -41,6 +42,7 @@ struct config {
   unsigned long buf_factor;
   int fd_info;
   float Finfo;
+  bool out_symbols;   // write the soft-symbol stream instead of TS packets
   bool tiled;
   unsigned tile_len, tile_warmup;
   int device;
@@ -48,7 +50,7 @@ struct config {
       : verbose(false), debug(false), input_format(INPUT_U8), float_scale(1.0), Fs(2.4e6), Fm(2e6),
         constellation(cstln_lut<256>::QPSK), fec(LSDR_FEC12), Ftune(0), allow_drift(false), viterbi(false),
         resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
-        buf_factor(4096), fd_info(-1), Finfo(5), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
+        buf_factor(4096), fd_info(-1), Finfo(5), out_symbols(false), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
 };
 
 static int decimation(float Fin, float Fout) {
@@ -165,15 +167,45 @@ static int run(config &cfg) {
     r_resample->freq_tol = cfg.Fm / (cfg.Fs * decim) * 0.1;
   }
 
-  // OUTPUT: soft symbols back to the host, to stdout.
-  pipebuf<softsymbol> p_symbols_host(&sch, "soft-symbols(host)", BUF_SYMBOLS);
-  new d2h_copier<softsymbol>(&sch, ctx, p_symbols, p_symbols_host);
-  new file_writer<softsymbol>(&sch, p_symbols_host, 1);
+  unsigned long BUF_BYTES = 2048 * cfg.buf_factor;
+  unsigned long BUF_MPEGBYTES = 2448 * cfg.buf_factor;
+  unsigned long BUF_PACKETS = cfg.buf_factor;
+  pipebuf<int> p_lock(&sch, "lock", BUF_SLOW);
+  pipebuf<u32> p_locktime(&sch, "locktime", BUF_PACKETS);
+  pipebuf<int> p_vbitcount(&sch, "Bits processed", BUF_PACKETS);
+  pipebuf<int> p_verrcount(&sch, "Bits corrected", BUF_PACKETS);
+  pipebuf<float> p_vber(&sch, "VBER", BUF_SLOW);
+  if (cfg.out_symbols) {
+    // soft symbols back to the host, to stdout
+    pipebuf<softsymbol> *p_symbols_host = new pipebuf<softsymbol>(&sch, "soft-symbols(host)", BUF_SYMBOLS);
+    new d2h_copier<softsymbol>(&sch, ctx, p_symbols, *p_symbols_host);
+    new file_writer<softsymbol>(&sch, *p_symbols_host, 1);
+  } else {
+    // DECONVOLUTION AND SYNCHRONIZATION … TS OUTPUT (leandvb.cc:519-596), all in HBM
+    if (cfg.viterbi) fail("--viterbi: the Viterbi GPU block is not wired into this app yet; use --out-symbols");
+    pipebuf<u8> *p_bytes = new pipebuf<u8>(&sch, "bytes", BUF_BYTES, ctx);
+    deconvol_sync_simple *r_deconv = make_deconvol_sync_simple(&sch, p_symbols, *p_bytes, (code_rate)cfg.fec);
+    pipebuf<u8> *p_mpegbytes = new pipebuf<u8>(&sch, "mpegbytes", BUF_MPEGBYTES, ctx);
+    new mpeg_sync<u8, 0>(&sch, *p_bytes, *p_mpegbytes, r_deconv, &p_lock, &p_locktime);
+    pipebuf<rspacket<u8> > *p_rspackets = new pipebuf<rspacket<u8> >(&sch, "RS-enc packets", BUF_PACKETS, ctx);
+    new deinterleaver<u8>(&sch, *p_mpegbytes, *p_rspackets);
+    pipebuf<tspacket> *p_rtspackets = new pipebuf<tspacket>(&sch, "rand TS packets", BUF_PACKETS, ctx);
+    new rs_decoder<u8, 0>(&sch, *p_rspackets, *p_rtspackets, &p_vbitcount, &p_verrcount);
+    new rate_estimator<float>(&sch, p_verrcount, p_vbitcount, p_vber);
+    pipebuf<tspacket> *p_tspackets = new pipebuf<tspacket>(&sch, "TS packets", BUF_PACKETS, ctx);
+    new derandomizer(&sch, *p_rtspackets, *p_tspackets);
+    pipebuf<tspacket> *p_ts_host = new pipebuf<tspacket>(&sch, "TS packets(host)", BUF_PACKETS);
+    new d2h_copier<tspacket>(&sch, ctx, *p_tspackets, *p_ts_host);
+    new file_writer<tspacket>(&sch, *p_ts_host, 1);
+  }
 
   if (cfg.fd_info >= 0) {
     new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info);
     new file_printer<f32>(&sch, "SS %f\n", p_ss, cfg.fd_info);
     new file_printer<f32>(&sch, "MER %.1f\n", p_mer, cfg.fd_info);
+    new file_printer<int>(&sch, "LOCK %d\n", p_lock, cfg.fd_info);
+    new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, 10);
+    new file_printer<f32>(&sch, "VBER %.6f\n", p_vber, cfg.fd_info);
   } else {
     // unread measurement pipes never block their writer (pipebuf with zero readers packs to empty)
   }
@@ -187,8 +219,8 @@ static int run(config &cfg) {
 
 static void usage(const char *name, FILE *f, int c) {
   fprintf(f,
-          "Usage: %s [options]  < IQ  > soft-symbols\n"
-          "MI355X build of the leandvb receive path (front end + constellation receiver).\n"
+          "Usage: %s [options]  < IQ  > TS\n"
+          "MI355X build of the leandvb DVB-S receive path.\n"
           "  --u8 | --f32           input format (default u8)\n"
           "  --float-scale FLOAT    scale for --f32 input\n"
           "  -f HZ, --sr HZ         sample rate, symbol rate\n"
@@ -200,6 +232,7 @@ static void usage(const char *name, FILE *f, int c) {
           "  --viterbi              PLL parameters for low SNR (pll_adjustment/6)\n"
           "  --buf-factor N         pipebuf scale (default 4096)\n"
           "  --tiled [--tile-len N --tile-warmup N]   throughput mode of the receiver\n"
+          "  --out-symbols          write soft symbols instead of TS packets\n"
           "  --fd-info FD, --device N, -v, -d\n",
           name);
   exit(c);
@@ -231,6 +264,7 @@ int main(int argc, const char *argv[]) {
     else if (!strcmp(a, "--fd-info")) cfg.fd_info = atoi(need());
     else if (!strcmp(a, "--device")) cfg.device = atoi(need());
     else if (!strcmp(a, "--tiled")) cfg.tiled = true;
+    else if (!strcmp(a, "--out-symbols")) cfg.out_symbols = true;
     else if (!strcmp(a, "--tile-len")) cfg.tile_len = atoi(need());
     else if (!strcmp(a, "--tile-warmup")) cfg.tile_warmup = atoi(need());
     else if (!strcmp(a, "--sampler")) {

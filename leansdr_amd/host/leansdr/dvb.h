@@ -1,0 +1,199 @@
+// leansdr_amd/host/leansdr/dvb.h — DVB-S FEC blocks with the reference's class surface
+// (dvb.h:122-513 deconvol_sync / make_deconvol_sync_simple, :712-891 mpeg_sync, :926-948
+// deinterleaver, :985-1058 rs_decoder, :1107-1163 derandomizer) whose run() is one C-ABI call.
+// All data pipebufs are device pipebufs; the small int/float report pipes stay on the host.
+#ifndef LEANSDR_AMD_DVB_H
+#define LEANSDR_AMD_DVB_H
+
+#include "leansdr/framework.h"
+#include "leansdr/sdr.h"
+
+namespace leansdr {
+
+static const int SIZE_RSPACKET = 204;
+static const int SIZE_TSPACKET = 188;
+static const int MPEG_SYNC = 0x47;
+static const int MPEG_SYNC_INV = (MPEG_SYNC ^ 0xff);
+static const int MPEG_SYNC_CORRUPTED = 0x55;
+
+enum code_rate { FEC12, FEC23, FEC46, FEC34, FEC56, FEC78, FEC45, FEC89, FEC910, FEC_MAX };
+
+inline cstln_lut<256> *make_dvbs2_constellation(cstln_lut<256>::predef c, code_rate r) {
+  return new cstln_lut<256>(c, (int)r);   // radii per code rate are applied by the table builder (dvb.h:45-81)
+}
+
+template <typename Tbyte>
+struct rspacket { Tbyte data[SIZE_RSPACKET]; };
+struct tspacket { u8 data[SIZE_TSPACKET]; };
+
+template <typename Tbyte, Tbyte BYTE_ERASED>
+struct deconvol_sync;
+
+template <>
+struct deconvol_sync<u8, 0> : runnable {
+  bool fastlock;
+  deconvol_sync(scheduler *sch, pipebuf<softsymbol> &i, pipebuf<u8> &o, code_rate rate)
+      : runnable(sch, "deconvol_sync"), fastlock(false),
+        ctx(pipe_ctx(i.dev, o.dev, "deconvol_sync: pipebufs must be device pipebufs of one ctx")), in(i),
+        out(o, SIZE_RSPACKET), rate_(rate), h(NULL) {}
+  void run() {
+    if (!h) lsdr_check(lsdr_deconv_create(ctx, (int)rate_, fastlock, &h), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_deconv_run(h, (const lsdr_softsymbol *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+  void next_sync() {
+    if (fastlock) fail("Bug: next_sync() called with fastlock");
+    if (!h) lsdr_check(lsdr_deconv_create(ctx, (int)rate_, fastlock, &h), name);
+    lsdr_check(lsdr_deconv_next_sync(h), name);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<softsymbol> in;
+  pipewriter<u8> out;
+  code_rate rate_;
+  lsdr_deconv *h;
+};
+typedef deconvol_sync<u8, 0> deconvol_sync_simple;
+
+inline deconvol_sync_simple *make_deconvol_sync_simple(scheduler *sch, pipebuf<softsymbol> &in, pipebuf<u8> &out,
+                                                       enum code_rate rate) {
+  return new deconvol_sync_simple(sch, in, out, rate);
+}
+
+template <typename Tbyte, Tbyte BYTE_ERASED>
+struct mpeg_sync;
+
+template <>
+struct mpeg_sync<u8, 0> : runnable {
+  int scan_syncs, want_syncs;
+  unsigned long lock_timeout;
+  bool fastlock;
+  int resync_period;
+
+  mpeg_sync(scheduler *sch, pipebuf<u8> &i, pipebuf<u8> &o, deconvol_sync<u8, 0> *dc, pipebuf<int> *state_o = NULL,
+            pipebuf<unsigned long> *locktime_o = NULL)
+      : runnable(sch, "sync_detect"), scan_syncs(8), want_syncs(4), lock_timeout(4), fastlock(false), resync_period(1),
+        ctx(pipe_ctx(i.dev, o.dev, "mpeg_sync: pipebufs must be device pipebufs of one ctx")), in(i),
+        out(o, SIZE_RSPACKET * (scan_syncs + 1)), deconv(dc), h(NULL), last_locktime(0), first_run(true) {
+    state_out = opt_writer(state_o);
+    locktime_out = opt_writer(locktime_o);
+  }
+  void run() {
+    if (!h) lsdr_check(lsdr_mpeg_sync_create(ctx, fastlock, &h), name);
+    // one run() writes at most: the initial "unlocked" report plus one lock/unlock event (dvb.h:744-754)
+    if (state_out && state_out->writable() < (first_run ? 2ul : 1ul)) return;
+    first_run = false;
+    unsigned long room = out.writable();
+    if (locktime_out) {   // one locktime value per packet (dvb.h:858-859): bound the packets by the pipe's room
+      unsigned long lt_room = locktime_out->writable();
+      if (lsdr_mpeg_sync_locked(h) && room > lt_room * SIZE_RSPACKET) room = lt_room * SIZE_RSPACKET;
+    }
+    size_t consumed = 0, produced = 0;
+    int events[8], n_events = 0, call_next = 0;
+    unsigned long locktime = 0;
+    bool was_locked = lsdr_mpeg_sync_locked(h);
+    lsdr_check(lsdr_mpeg_sync_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced, events, &n_events,
+                                  &locktime, &call_next), name);
+    in.read(consumed);
+    out.written(produced);
+    for (int k = 0; k < n_events; ++k)
+      if (state_out) state_out->write(events[k]);
+    if (locktime_out && was_locked) {
+      unsigned long n = produced / SIZE_RSPACKET;
+      for (unsigned long k = 0; k < n; ++k) locktime_out->write(locktime - n + 1 + k);
+    }
+    if (call_next && deconv) deconv->next_sync();
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<u8> in;
+  pipewriter<u8> out;
+  deconvol_sync<u8, 0> *deconv;
+  lsdr_mpeg_sync *h;
+  unsigned long last_locktime;
+  bool first_run;
+  pipewriter<int> *state_out;
+  pipewriter<unsigned long> *locktime_out;
+};
+
+template <typename Tbyte>
+struct deinterleaver;
+
+template <>
+struct deinterleaver<u8> : runnable {
+  deinterleaver(scheduler *sch, pipebuf<u8> &i, pipebuf<rspacket<u8> > &o)
+      : runnable(sch, "deinterleaver"), ctx(pipe_ctx(i.dev, o.dev, "deinterleaver: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {}
+  void run() {
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_deinterleaver_run(ctx, in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<u8> in;
+  pipewriter<rspacket<u8> > out;
+};
+
+template <typename Tbyte, int BYTE_ERASED>
+struct rs_decoder;
+
+template <>
+struct rs_decoder<u8, 0> : runnable {
+  rs_decoder(scheduler *sch, pipebuf<rspacket<u8> > &i, pipebuf<tspacket> &o, pipebuf<int> *bitcount_o = NULL,
+             pipebuf<int> *errcount_o = NULL)
+      : runnable(sch, "RS decoder"), ctx(pipe_ctx(i.dev, o.dev, "rs_decoder: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {
+    bitcount = opt_writer(bitcount_o);
+    errcount = opt_writer(errcount_o);
+  }
+  void run() {
+    if (bitcount && bitcount->writable() < 1) return;
+    if (errcount && errcount->writable() < 1) return;
+    unsigned long n = min(in.readable(), out.writable());
+    if (!n) return;
+    long bits = 0, errs = 0;
+    lsdr_check(lsdr_rs_decoder_run(ctx, (uint8_t *)in.rd(), n, (uint8_t *)out.wr(), &bits, &errs), name);
+    in.read(n);
+    out.written(n);
+    if (bitcount) bitcount->write((int)bits);
+    if (errcount) errcount->write((int)errs);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<rspacket<u8> > in;
+  pipewriter<tspacket> out;
+  pipewriter<int> *bitcount, *errcount;
+};
+
+struct derandomizer : runnable {
+  derandomizer(scheduler *sch, pipebuf<tspacket> &i, pipebuf<tspacket> &o)
+      : runnable(sch, "derandomizer"), ctx(pipe_ctx(i.dev, o.dev, "derandomizer: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o), h(NULL) {}
+  void run() {
+    if (!h) lsdr_check(lsdr_derandomizer_create(ctx, &h), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_derandomizer_run(h, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<tspacket> in;
+  pipewriter<tspacket> out;
+  lsdr_derandomizer *h;
+};
+
+}  // namespace leansdr
+#endif
