@@ -203,6 +203,22 @@ int lsdr_deconv_next_sync(lsdr_deconv *d);                       /* deconvol_syn
 int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
                     size_t *consumed, size_t *produced);
 
+/* ---- viterbi_sync, dvb.h:1173-1416 (+ viterbi_dec / trellis / bitpath, viterbi.h).  Soft-decision Viterbi
+ * with the reference's partial-metric update and its alignment search (conjugation x rotation x shift).
+ * One run() call: all 128-block chunks that fit.  Bit-exact: the stream is decoded in tiles that start
+ * from zero metrics a few chunks early; every seam is verified against the previous tile's end state
+ * (all 64 path metrics and path registers) and anything unverified is re-decoded sequentially.
+ * Synchronous. */
+typedef struct lsdr_viterbi lsdr_viterbi;
+int lsdr_viterbi_create(lsdr_ctx *ctx, int cstln, int rate, lsdr_viterbi **v);
+void lsdr_viterbi_destroy(lsdr_viterbi *v);
+int lsdr_viterbi_set_resync_period(lsdr_viterbi *v, int period);   /* public member resync_period (dvb.h:1232) */
+int lsdr_viterbi_current_sync(const lsdr_viterbi *v);
+/* diagnostics of the last run: tiles decoded, seams that failed verification (re-decoded serially) */
+int lsdr_viterbi_stats(const lsdr_viterbi *v, unsigned *tiles, unsigned *bad_seams);
+int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                     size_t *consumed, size_t *produced);
+
 /* ---- mpeg_sync<u8,0>, dvb.h:712-891: bit alignment, polarity and 0x47/0xB8 sync search, lock tracking.
  * One run() call.  *call_next_sync = 1 when the reference would call deconv->next_sync() (dvb.h:771-779);
  * state_events (host, may be NULL) receives the values written to the lock-state pipe (0/1), at most 2.

@@ -108,6 +108,12 @@ _sig("lsdr_deconv_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
 _sig("lsdr_deconv_destroy", None, [vp])
 _sig("lsdr_deconv_next_sync", C.c_int, [vp])
 _sig("lsdr_deconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_viterbi_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
+_sig("lsdr_viterbi_destroy", None, [vp])
+_sig("lsdr_viterbi_set_resync_period", C.c_int, [vp, C.c_int])
+_sig("lsdr_viterbi_current_sync", C.c_int, [vp])
+_sig("lsdr_viterbi_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
+_sig("lsdr_viterbi_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_mpeg_sync_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
 _sig("lsdr_mpeg_sync_destroy", None, [vp])
 _sig("lsdr_mpeg_sync_locked", C.c_int, [vp])
@@ -453,6 +459,54 @@ class Deconv:
         out = self.ctx.download(dout, np.uint8, nout)
         din.free(); dout.free()
         return out
+
+
+class Viterbi:
+    """viterbi_sync (dvb.h:1173-1416) on the GPU."""
+
+    def __init__(self, ctx, cstln=QPSK, rate=FEC12, resync_period=0):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_viterbi_create(ctx.h, cstln, rate, C.byref(h)))
+        self.h = h
+        if resync_period:
+            check(lib.lsdr_viterbi_set_resync_period(h, resync_period))
+
+    def close(self):
+        if self.h:
+            lib.lsdr_viterbi_destroy(self.h)
+            self.h = None
+
+    @property
+    def current_sync(self):
+        return lib.lsdr_viterbi_current_sync(self.h)
+
+    def stats(self):
+        t, b = C.c_uint(), C.c_uint()
+        check(lib.lsdr_viterbi_stats(self.h, C.byref(t), C.byref(b)))
+        return dict(tiles=t.value, bad_seams=b.value)
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap):
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_viterbi_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run_stream(self, sym, pipe=None):
+        """Whole stream; repeated run() calls (a call stops early when the alignment switches)."""
+        sym = np.ascontiguousarray(sym, SOFTSYM)
+        din = self.ctx.upload(sym)
+        dout = self.ctx.alloc(len(sym) + 64)
+        pos, nout = 0, 0
+        while True:
+            avail = len(sym) - pos if pipe is None else min(pipe, len(sym) - pos)
+            cons, prod = self.run_dev(din.at(pos * 4), avail, dout.at(nout), len(sym) + 64 - nout)
+            if not cons and not prod:
+                break
+            pos += cons
+            nout += prod
+        out = self.ctx.download(dout, np.uint8, nout)
+        din.free(); dout.free()
+        return out, pos
 
 
 class MpegSync:

@@ -1,0 +1,556 @@
+// leansdr_amd/csrc/viterbi.hip — viterbi_sync (dvb.h:1173-1416) + viterbi_dec/trellis/bitpath (viterbi.h).
+//
+// 64-state trellis ↔ the 64 lanes of one wavefront: lane s owns path metric and path register of
+// state s; predecessors' values arrive by wave shuffles (add-compare-select), the best state by a
+// wave reduction.  The reference's arithmetic is kept exactly: int32 metrics, the labelled branch
+// first with its (negative) cost then every branch with cost 0, `<=` so the last candidate wins,
+// lowest-index best state, register-exchange paths of `depth` symbols.
+//
+// Parallelism comes from time tiling with verification.  A stream of chunks (128 FEC blocks each) is
+// cut into tiles; tile 0 continues from the carried decoder state, every other tile starts
+// `kWarm` chunks early from zero metrics.  Survivor paths merge within a few constraint lengths, after
+// which metrics (relative to the best) and path registers no longer depend on the starting point:
+// the tile then reproduces the sequential decoder bit for bit.  This is CHECKED, not assumed: the
+// state of tile j after its warm-up is compared (64 normalised metrics + 64 path registers) with the
+// end state of tile j−1; a mismatch makes the host re-decode from there sequentially.
+//
+// Work is skipped only where the reference's result cannot depend on it: the per-step "quality"
+// (second-best − best) is needed on resync chunks only (dvb.h:1386-1394), metrics are renormalised
+// once per chunk instead of every step (a common offset changes no comparison and cannot overflow in
+// 128 steps), and the best-state reduction is skipped when all 64 path registers already agree on
+// the output symbol.
+#include "lsdr_internal.h"
+
+namespace {
+
+constexpr int kChunkBlocks = 128;   // viterbi_sync::chunk_size, dvb.h:1229
+constexpr int kStates = 64;
+constexpr int kWarm = 4;            // warm-up chunks (512 trellis steps)
+constexpr int kMaxSyncs = 64;
+
+struct vit_code {           // fec_specs + typedefs, dvb.h:520-566,1179-1212
+  int bits_in, bits_out, nus, ncs, nbits, depth, pathbits;
+};
+
+struct vit_tables {         // trellis::init_convolutional (viterbi.h:59-92), branches sorted by coded symbol
+  unsigned char pred[kStates][128];
+  unsigned char us[kStates][128];
+  unsigned char lab[kStates][128];     // coded symbol of branch k
+  unsigned char by_label[kStates][256];  // branch index for a coded symbol, 255 = none
+};
+
+struct vit_state { int cost[kStates]; unsigned long long path[kStates]; };
+
+struct vit_job {            // one wavefront's work
+  unsigned long long first_chunk;    // first chunk to emit
+  unsigned n_chunks;                 // chunks to emit
+  unsigned warm;                     // warm-up chunks before first_chunk (0: start from init state)
+  int sync;                          // alignment index
+  int from_state;                    // index into states_in (warm == 0) or -1 (zero metrics)
+  int emit;                          // write decoded bytes
+  unsigned chunk_step;               // distance between emitted chunks (1: contiguous; P: the resync chunks only)
+};
+
+struct vit_args {
+  const lsdr_softsymbol *in;
+  unsigned char *out;
+  const vit_tables *T;
+  vit_code C;
+  int bits_per_symbol, nshifts;
+  int resync_phase0, resync_period;
+  const unsigned char *maps;         // [nsyncs][256]
+  const int *shifts;                 // [nsyncs]
+  const vit_job *jobs;
+  const vit_state *states_in;        // carried states, [nsyncs]
+  vit_state *begin_states;           // [njobs] state at first_chunk (after warm-up)
+  vit_state *end_states;             // [njobs] state after the job's last chunk
+  vit_state *first_chunk_states;     // [njobs] state after the job's FIRST emitted chunk (for alignment switches)
+  int *totals;                       // [njobs][n_chunks_max] totaldiscr per chunk (valid on resync chunks)
+  unsigned totals_stride;
+  vit_state *chunk_states;           // optional [njobs][totals_stride]: state after every chunk (sparse decoders)
+};
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+  return v;
+}
+
+// One wavefront = one job.  Lane = trellis state.
+__global__ __launch_bounds__(64) void k_viterbi(vit_args a) {
+  __shared__ vit_tables T;
+  const int lane = threadIdx.x;
+  {   // tables → LDS (≈41 KB)
+    const unsigned *src = reinterpret_cast<const unsigned *>(a.T);
+    unsigned *dst = reinterpret_cast<unsigned *>(&T);
+    for (unsigned i = lane; i < sizeof(vit_tables) / 4; i += 64) dst[i] = src[i];
+  }
+  __syncthreads();
+  const vit_job job = a.jobs[blockIdx.x];
+  const unsigned char *map = a.maps + job.sync * 256;
+  const int shift = a.shifts[job.sync];
+  const vit_code C = a.C;
+  const unsigned long long pmask = C.pathbits == 64 ? ~0ull : ((1ull << C.pathbits) - 1);
+  const int out_shift = (C.depth - 1) * C.nbits;
+  const unsigned us_mask = (1u << C.nbits) - 1;
+  const int discr_delay = 64 / C.bits_in;
+
+  int cost;
+  unsigned long long path;
+  if (job.from_state >= 0) { cost = a.states_in[job.from_state].cost[lane]; path = a.states_in[job.from_state].path[lane]; }
+  else { cost = 0; path = 0; }
+
+  for (long long q = -(long long)job.warm; q < (long long)job.n_chunks; ++q) {
+    const unsigned long long c = q < 0 ? job.first_chunk - (unsigned long long)(-q) : job.first_chunk + (unsigned long long)q * job.chunk_step;
+    const bool emitting = q >= 0;
+    if (q == 0) {   // (metrics are normalised at every chunk boundary)
+      a.begin_states[blockIdx.x].cost[lane] = cost;
+      a.begin_states[blockIdx.x].path[lane] = path;
+    }
+    const bool resync = ((c + (unsigned long long)a.resync_phase0) % (unsigned)a.resync_period) == 0;
+    const bool want_q = resync && emitting;
+    int total = 0;
+    unsigned long long outstream = 0;
+    int nout = 0;
+    unsigned char *pout = a.out + c * (unsigned)(kChunkBlocks * C.bits_in / 8);
+    const lsdr_softsymbol *pin = a.in + c * (unsigned)(kChunkBlocks * a.nshifts) + shift;
+    for (int b = 0; b < kChunkBlocks; ++b, pin += a.nshifts) {
+      // update_sync (dvb.h:1353-1364): coded symbol and summed cost of this FEC block (wave-uniform)
+      unsigned cs1 = 0;
+      int cost1 = 0;
+      for (int i = 0; i < a.nshifts; ++i) {
+        const lsdr_softsymbol ss = pin[i];
+        cs1 = ((cs1 << a.bits_per_symbol) | map[ss.symbol]) & 0xffu;
+        cost1 += ss.cost;
+      }
+      // viterbi_dec::update(nm = 1), viterbi.h:202-260
+      int best_m = 0x7fffffff, bk = 0;
+      {
+        const unsigned k1 = T.by_label[lane][cs1];
+        const unsigned kk = k1 == 255 ? 0u : k1;
+        const int pc = __shfl(cost, (int)T.pred[lane][kk], 64);
+        if (k1 != 255) { const int m = pc + cost1; if (m <= best_m) { best_m = m; bk = (int)k1; } }
+      }
+      for (int k = 0; k < C.nus; ++k) {
+        const int m = __shfl(cost, (int)T.pred[lane][k], 64);
+        if (m <= best_m) { best_m = m; bk = k; }
+      }
+      const int bp = T.pred[lane][bk];
+      const unsigned lo = __shfl((unsigned)path, bp, 64), hi = __shfl((unsigned)(path >> 32), bp, 64);
+      path = ((((unsigned long long)hi << 32 | lo) << C.nbits) | T.us[lane][bk]) & pmask;
+      cost = best_m;
+      // output symbol of the best state (lowest index among the minima); skip the search when all agree
+      unsigned sym_out = (unsigned)(path >> out_shift) & us_mask;
+      int best_tpm = 0;
+      bool have_best = false;
+      if (emitting || want_q) {
+        const unsigned s0 = __shfl(sym_out, 0, 64);
+        const bool all_same = __all(sym_out == s0);
+        if (!all_same || (want_q && b >= discr_delay)) {
+          best_tpm = wave_min(cost);
+          have_best = true;
+          const unsigned long long mask = __ballot(cost == best_tpm);
+          const int best_state = __ffsll((long long)mask) - 1;
+          sym_out = __shfl(sym_out, best_state, 64);
+          if (want_q && b >= discr_delay) {
+            // second-best in the reference's scan = 2nd smallest with multiplicity (viterbi.h:246-251)
+            const int second = __popcll(mask) > 1 ? best_tpm : wave_min(cost == best_tpm ? 0x7fffffff : cost);
+            total += second - best_tpm;
+          }
+        } else sym_out = s0;
+      }
+      (void)have_best;
+      if (emitting && job.emit) {
+        outstream = (outstream << C.bits_in) | sym_out;
+        nout += C.bits_in;
+        while (nout >= 8) {
+          if (lane == 0) *pout = (unsigned char)(outstream >> (nout - 8));
+          ++pout;
+          nout -= 8;
+        }
+      }
+    }
+    // renormalise once per chunk (the reference subtracts the best metric after every step)
+    cost -= wave_min(cost);
+    if (emitting) {
+      const unsigned ci = (unsigned)q;
+      if (lane == 0) a.totals[(size_t)blockIdx.x * a.totals_stride + ci] = total;
+      if (a.chunk_states) {
+        vit_state *st = a.chunk_states + (size_t)blockIdx.x * a.totals_stride + ci;
+        st->cost[lane] = cost; st->path[lane] = path;
+      }
+      if (ci == 0) { a.first_chunk_states[blockIdx.x].cost[lane] = cost; a.first_chunk_states[blockIdx.x].path[lane] = path; }
+    }
+  }
+  a.end_states[blockIdx.x].cost[lane] = cost;
+  a.end_states[blockIdx.x].path[lane] = path;
+}
+
+// seam check: begin state of job j (j ≥ 1) == end state of job j−1
+__global__ __launch_bounds__(64) void k_vit_verify(const vit_state *begin_states, const vit_state *end_states, unsigned njobs,
+                                                   int *bad) {
+  const unsigned j = blockIdx.x + 1;
+  if (j >= njobs) return;
+  const int lane = threadIdx.x;
+  const bool same = begin_states[j].cost[lane] == end_states[j - 1].cost[lane] &&
+                    begin_states[j].path[lane] == end_states[j - 1].path[lane];
+  if (!__all(same) && lane == 0) bad[j] = 1;
+}
+
+}  // namespace
+
+struct lsdr_viterbi {
+  lsdr_ctx *ctx;
+  vit_code C;
+  int cstln, rate, bits_per_symbol, nshifts, nsyncs;
+  int current_sync, resync_phase, resync_period;
+  std::vector<unsigned char> maps;   // [nsyncs][256]
+  std::vector<int> shifts;
+  vit_tables *d_T;
+  unsigned char *d_maps;
+  int *d_shifts;
+  std::vector<vit_state> states;     // host mirror of the carried decoder states [nsyncs]
+  vit_state *d_states;
+  // scratch
+  vit_job *d_jobs; vit_state *d_begin, *d_end, *d_first, *d_chunk; int *d_totals, *d_bad;
+  size_t jobs_cap, totals_cap, chunk_cap;
+  unsigned last_tiles, last_bad;
+};
+
+static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
+  static const unsigned short G1 = 0171, G2 = 0133;
+  static const unsigned short p12[] = {G1, G2};
+  static const unsigned short p23[] = {G1, G2, (unsigned short)(G2 << 1)};
+  static const unsigned short p46[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2), (unsigned short)(G2 << 2), (unsigned short)(G2 << 3)};
+  static const unsigned short p34[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2)};
+  static const unsigned short p45[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2), (unsigned short)(G1 << 3)};
+  static const unsigned short p56[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2), (unsigned short)(G2 << 3), (unsigned short)(G1 << 4)};
+  static const unsigned short p78[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G2 << 2), (unsigned short)(G2 << 3), (unsigned short)(G1 << 4), (unsigned short)(G2 << 5), (unsigned short)(G1 << 6)};
+  switch (rate) {   // {bits_in, bits_out, NUS, NCS, NBITS, DEPTH, path width}
+    case LSDR_FEC12: *c = {1, 2, 2, 4, 1, 32, 32}; *polys = p12; return 0;
+    case LSDR_FEC23: *c = {2, 3, 4, 8, 3, 21, 64}; *polys = p23; return 0;
+    case LSDR_FEC46: *c = {4, 6, 16, 64, 4, 16, 64}; *polys = p46; return 0;
+    case LSDR_FEC34: *c = {3, 4, 8, 16, 3, 21, 64}; *polys = p34; return 0;
+    case LSDR_FEC45: *c = {4, 5, 16, 32, 4, 16, 64}; *polys = p45; return 0;
+    case LSDR_FEC56: *c = {5, 6, 32, 64, 5, 12, 64}; *polys = p56; return 0;
+    case LSDR_FEC78: *c = {7, 8, 128, 256, 7, 9, 64}; *polys = p78; return 0;
+  }
+  return -1;
+}
+
+static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
+                      unsigned stride, bool chunk_states, int phase0) {
+  lsdr_ctx *c = v->ctx;
+  const size_t nj = jobs.size();
+  if (v->jobs_cap < nj) {
+    (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_first); (void)hipFree(v->d_bad);
+    LSDR_HIP(hipMalloc((void **)&v->d_jobs, nj * sizeof(vit_job)));
+    LSDR_HIP(hipMalloc((void **)&v->d_begin, nj * sizeof(vit_state)));
+    LSDR_HIP(hipMalloc((void **)&v->d_end, nj * sizeof(vit_state)));
+    LSDR_HIP(hipMalloc((void **)&v->d_first, nj * sizeof(vit_state)));
+    LSDR_HIP(hipMalloc((void **)&v->d_bad, nj * sizeof(int)));
+    v->jobs_cap = nj;
+  }
+  if (v->totals_cap < nj * stride) {
+    (void)hipFree(v->d_totals);
+    LSDR_HIP(hipMalloc((void **)&v->d_totals, nj * stride * sizeof(int)));
+    v->totals_cap = nj * stride;
+  }
+  if (chunk_states && v->chunk_cap < nj * stride) {
+    (void)hipFree(v->d_chunk);
+    LSDR_HIP(hipMalloc((void **)&v->d_chunk, nj * stride * sizeof(vit_state)));
+    v->chunk_cap = nj * stride;
+  }
+  LSDR_HIP(hipMemcpyAsync(v->d_jobs, jobs.data(), nj * sizeof(vit_job), hipMemcpyHostToDevice, c->stream));
+  LSDR_HIP(hipMemcpyAsync(v->d_states, v->states.data(), v->nsyncs * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
+  vit_args a;
+  a.in = in; a.out = out; a.T = v->d_T; a.C = v->C;
+  a.bits_per_symbol = v->bits_per_symbol; a.nshifts = v->nshifts;
+  a.resync_phase0 = phase0; a.resync_period = v->resync_period;
+  a.maps = v->d_maps; a.shifts = v->d_shifts;
+  a.jobs = v->d_jobs; a.states_in = v->d_states;
+  a.begin_states = v->d_begin; a.end_states = v->d_end; a.first_chunk_states = v->d_first;
+  a.totals = v->d_totals; a.totals_stride = stride;
+  a.chunk_states = chunk_states ? v->d_chunk : nullptr;
+  hipLaunchKernelGGL(k_viterbi, dim3((unsigned)nj), dim3(64), 0, c->stream, a);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+extern "C" {
+
+int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
+  LSDR_ARG(c && out);
+  vit_code C;
+  const unsigned short *polys = nullptr;
+  if (vit_code_for(rate, &C, &polys)) { lsdr_set_error("viterbi_sync: CR not supported"); return LSDR_E_UNSUPPORTED; }
+  lsdr::cstln_tables tab;
+  if (lsdr::build_cstln(cstln, rate, tab) < 0) { lsdr_set_error("viterbi_sync: constellation/code rate not supported"); return LSDR_E_ARG; }
+  int bps = 0;
+  while ((1 << (bps + 1)) <= tab.nsymbols) ++bps;   // log2i(nsymbols)
+  if (bps * (C.bits_out / bps) != C.bits_out) { lsdr_set_error("viterbi_sync: code rate not suitable for this constellation"); return LSDR_E_ARG; }
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_viterbi *v = new lsdr_viterbi();
+  v->ctx = c; v->C = C; v->cstln = cstln; v->rate = rate;
+  v->bits_per_symbol = bps;
+  const int nconj = tab.nsymbols == 2 ? 1 : 2;                                   // dvb.h:1248-1252
+  const int nrot = (tab.nsymbols == 2 || tab.nsymbols == 4) ? tab.nrotations / 2 : tab.nrotations;   // dvb.h:1254-1266
+  v->nshifts = C.bits_out / bps;
+  v->nsyncs = nconj * nrot * v->nshifts;
+  if (v->nsyncs > kMaxSyncs) { delete v; lsdr_set_error("viterbi_sync: too many alignments"); return LSDR_E_UNSUPPORTED; }
+  v->current_sync = 0; v->resync_phase = 0; v->resync_period = 32;
+  v->maps.assign((size_t)v->nsyncs * 256, 0);
+  v->shifts.assign(v->nsyncs, 0);
+  for (int s = 0; s < v->nsyncs; ++s) {   // [shift|conj|rot], init_map dvb.h:1336-1351
+    const int rot = s % nrot, conj = (s / nrot) % nconj, shift = s / nrot / nconj;
+    v->shifts[s] = shift;
+    const float angle = (float)(2 * M_PI * rot / tab.nrotations);
+    const float ca = cosf(angle), sa = sinf(angle);
+    for (int i = 0; i < tab.nsymbols; ++i) {
+      int8_t I = tab.symbols[i][0], Q = tab.symbols[i][1];
+      if (conj) Q = (int8_t)-Q;
+      const int8_t RI = (int8_t)(I * ca - Q * sa);
+      const int8_t RQ = (int8_t)(I * sa + Q * ca);
+      v->maps[(size_t)s * 256 + i] = tab.symbol[(size_t)(uint8_t)RI * 256 + (uint8_t)RQ];
+    }
+  }
+  // trellis (viterbi.h:59-92), branches of each state ordered by coded symbol
+  vit_tables *T = new vit_tables();
+  memset(T, 0, sizeof(*T));
+  memset(T->by_label, 255, sizeof(T->by_label));
+  int nbr[kStates] = {0};
+  int nG = 0;
+  while ((1 << nG) < C.ncs) ++nG;
+  struct br { int cs, pred, us; };
+  std::vector<br> all[kStates];
+  for (int s = 0; s < kStates; ++s)
+    for (int us = 0; us < C.nus; ++us) {
+      unsigned long long reg = (unsigned long long)s;
+      int us_rev = 0;
+      for (int b = 1; b < C.nus; b *= 2) if (us & b) us_rev |= (C.nus / 2 / b);
+      reg |= (unsigned long long)us_rev * kStates;
+      unsigned cs = 0;
+      for (int g = 0; g < nG; ++g) cs = (cs << 1) | (unsigned)__builtin_parityll(reg & polys[g]);
+      reg /= (unsigned)C.nus;
+      all[reg].push_back({(int)cs, s, us});
+    }
+  for (int s = 0; s < kStates; ++s) {
+    std::vector<br> &L = all[s];
+    for (size_t i = 0; i < L.size(); ++i) for (size_t j = i + 1; j < L.size(); ++j) if (L[j].cs < L[i].cs) { br t = L[i]; L[i] = L[j]; L[j] = t; }
+    if ((int)L.size() != C.nus) { delete T; delete v; lsdr_set_error("viterbi_sync: invalid convolutional code"); return LSDR_E_ARG; }
+    for (int k = 0; k < C.nus; ++k) {
+      T->pred[s][k] = (unsigned char)L[k].pred; T->us[s][k] = (unsigned char)L[k].us; T->lab[s][k] = (unsigned char)L[k].cs;
+      T->by_label[s][L[k].cs] = (unsigned char)k;
+    }
+    nbr[s] = C.nus;
+  }
+  (void)nbr;
+  LSDR_HIP(hipMalloc((void **)&v->d_T, sizeof(vit_tables)));
+  LSDR_HIP(hipMemcpy(v->d_T, T, sizeof(vit_tables), hipMemcpyHostToDevice));
+  delete T;
+  LSDR_HIP(hipMalloc((void **)&v->d_maps, v->maps.size()));
+  LSDR_HIP(hipMemcpy(v->d_maps, v->maps.data(), v->maps.size(), hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&v->d_shifts, v->nsyncs * sizeof(int)));
+  LSDR_HIP(hipMemcpy(v->d_shifts, v->shifts.data(), v->nsyncs * sizeof(int), hipMemcpyHostToDevice));
+  v->states.assign(v->nsyncs, vit_state());
+  for (auto &s : v->states) memset(&s, 0, sizeof(s));
+  LSDR_HIP(hipMalloc((void **)&v->d_states, v->nsyncs * sizeof(vit_state)));
+  v->d_jobs = nullptr; v->d_begin = v->d_end = v->d_first = v->d_chunk = nullptr; v->d_totals = nullptr; v->d_bad = nullptr;
+  v->jobs_cap = v->totals_cap = v->chunk_cap = 0;
+  v->last_tiles = v->last_bad = 0;
+  *out = v;
+  return LSDR_OK;
+}
+
+void lsdr_viterbi_destroy(lsdr_viterbi *v) {
+  if (!v) return;
+  (void)hipStreamSynchronize(v->ctx->stream);
+  (void)hipFree(v->d_T); (void)hipFree(v->d_maps); (void)hipFree(v->d_shifts); (void)hipFree(v->d_states);
+  (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_first);
+  (void)hipFree(v->d_chunk); (void)hipFree(v->d_totals); (void)hipFree(v->d_bad);
+  delete v;
+}
+
+int lsdr_viterbi_set_resync_period(lsdr_viterbi *v, int p) { LSDR_ARG(v && p >= 1); v->resync_period = p; return LSDR_OK; }
+int lsdr_viterbi_current_sync(const lsdr_viterbi *v) { return v ? v->current_sync : -1; }
+int lsdr_viterbi_stats(const lsdr_viterbi *v, unsigned *tiles, unsigned *bad) {
+  LSDR_ARG(v);
+  if (tiles) *tiles = v->last_tiles;
+  if (bad) *bad = v->last_bad;
+  return LSDR_OK;
+}
+
+int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                     size_t *consumed, size_t *produced) {
+  LSDR_ARG(v && consumed && produced);
+  *consumed = 0; *produced = 0;
+  const vit_code &C = v->C;
+  const size_t sym_per_chunk = (size_t)v->nshifts * kChunkBlocks;
+  const size_t bytes_per_chunk = (size_t)C.bits_in * kChunkBlocks / 8;
+  if (n_in < sym_per_chunk + (size_t)(v->nshifts - 1)) return LSDR_OK;   // dvb.h:1372-1373
+  size_t chunks = (n_in - (size_t)(v->nshifts - 1)) / sym_per_chunk;
+  if (chunks > cap_out / bytes_per_chunk) chunks = cap_out / bytes_per_chunk;
+  if (!chunks) return LSDR_OK;
+  LSDR_ARG(in && out);
+  lsdr_ctx *c = v->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+
+  const int P = v->resync_period, phase0 = v->resync_phase;
+  // resync chunks of this call: c with (c + phase0) % P == 0
+  std::vector<unsigned long long> rs;
+  for (unsigned long long cc = (unsigned long long)((P - phase0) % P); cc < chunks; cc += (unsigned)P) rs.push_back(cc);
+
+  // ---- jobs.  Current alignment: tiles of TL chunks (each starting kWarm chunks early) so that every
+  // resync chunk is the FIRST chunk of a tile; other alignments: one sequential job each over the resync chunks.
+  const unsigned TL = P >= 8 ? 8u : (unsigned)P;   // tile length divides the resync period when P ≥ 8
+  std::vector<vit_job> jobs;
+  const int cur = v->current_sync;
+  {
+    unsigned long long cstart = 0;
+    // first tile ends at the first resync chunk (or after TL chunks)
+    while (cstart < chunks) {
+      unsigned long long next_rs = chunks;
+      for (unsigned long long r : rs) if (r > cstart) { next_rs = r; break; }
+      unsigned long long cend = cstart + TL;
+      if (cend > next_rs) cend = next_rs;
+      if (cend > chunks) cend = chunks;
+      vit_job j;
+      j.first_chunk = cstart; j.n_chunks = (unsigned)(cend - cstart);
+      j.warm = cstart == 0 ? 0u : (unsigned)(cstart < (unsigned long long)kWarm ? cstart : (unsigned long long)kWarm);
+      j.sync = cur; j.from_state = cstart == 0 ? cur : -1; j.emit = 1; j.chunk_step = 1;
+      // tiles that cannot warm up fully (near the start) extend tile 0 instead
+      if (cstart != 0 && j.warm < (unsigned)kWarm) {
+        jobs.back().n_chunks += j.n_chunks;
+      } else jobs.push_back(j);
+      cstart = cend;
+    }
+  }
+  const size_t n_main = jobs.size();
+  unsigned stride = 1;
+  for (auto &j : jobs) if (j.n_chunks > stride) stride = j.n_chunks;
+  int rc = vit_launch(v, in, out, jobs, stride, false, phase0);
+  if (rc) return rc;
+  LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
+  if (n_main > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream,
+                                     (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
+  std::vector<int> bad(n_main, 0), totals_main(n_main * stride);
+  LSDR_HIP(hipMemcpyAsync(bad.data(), v->d_bad, n_main * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipMemcpyAsync(totals_main.data(), v->d_totals, n_main * stride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  v->last_tiles = (unsigned)n_main; v->last_bad = 0;
+  // ---- repair: the first seam that failed verification invalidates everything after it.  Re-decode
+  // sequentially from the previous tile's end state (exact by construction).
+  size_t first_bad = n_main;
+  for (size_t j = 1; j < n_main; ++j) if (bad[j]) { first_bad = j; break; }
+  std::vector<vit_state> main_first(n_main);   // state after the first chunk of each tile (alignment switches)
+  vit_state main_end;
+  if (first_bad < n_main) {
+    for (size_t j = first_bad; j < n_main; ++j) v->last_bad += bad[j] ? 1u : 0u;
+    // keep results of tiles < first_bad; redo the rest as ONE sequential job starting from end_states[first_bad-1]
+    std::vector<vit_state> ends(n_main);
+    LSDR_HIP(hipMemcpy(ends.data(), v->d_end, n_main * sizeof(vit_state), hipMemcpyDeviceToHost));
+    LSDR_HIP(hipMemcpy(main_first.data(), v->d_first, n_main * sizeof(vit_state), hipMemcpyDeviceToHost));
+    std::vector<vit_state> keep = v->states;
+    v->states[cur] = ends[first_bad - 1];
+    vit_job j;
+    j.first_chunk = jobs[first_bad].first_chunk; j.n_chunks = (unsigned)(chunks - j.first_chunk);
+    j.warm = 0; j.sync = cur; j.from_state = cur; j.emit = 1; j.chunk_step = 1;
+    std::vector<vit_job> redo(1, j);
+    rc = vit_launch(v, in, out, redo, j.n_chunks, true, phase0);
+    if (rc) return rc;
+    std::vector<int> tot(j.n_chunks);
+    std::vector<vit_state> cst(j.n_chunks);
+    LSDR_HIP(hipMemcpyAsync(tot.data(), v->d_totals, j.n_chunks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipMemcpyAsync(cst.data(), v->d_chunk, j.n_chunks * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipMemcpyAsync(&main_end, v->d_end, sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    v->states = keep;
+    // splice the sequential results back into the per-tile bookkeeping
+    for (size_t t = first_bad; t < n_main; ++t) {
+      const unsigned off = (unsigned)(jobs[t].first_chunk - j.first_chunk);
+      for (unsigned q = 0; q < jobs[t].n_chunks; ++q) totals_main[t * stride + q] = tot[off + q];
+      main_first[t] = cst[off];
+    }
+  } else {
+    LSDR_HIP(hipMemcpy(main_first.data(), v->d_first, n_main * sizeof(vit_state), hipMemcpyDeviceToHost));
+    LSDR_HIP(hipMemcpy(&main_end, v->d_end + (n_main - 1), sizeof(vit_state), hipMemcpyDeviceToHost));
+  }
+
+  // ---- other alignments: sequential over the resync chunks, exact carried state
+  size_t used_chunks = chunks;
+  int new_sync = cur;
+  std::vector<std::vector<vit_state> > other_states(v->nsyncs);
+  std::vector<std::vector<int> > other_totals(v->nsyncs);
+  if (!rs.empty() && v->nsyncs > 1) {
+    // one job per alignment walks its resync chunks in order (stride P), recording the decoder state and
+    // the quality total after every one of them
+    std::vector<vit_job> oj;
+    std::vector<int> which;
+    for (int s = 0; s < v->nsyncs; ++s) {
+      if (s == cur) continue;
+      vit_job j;
+      j.first_chunk = rs[0]; j.n_chunks = (unsigned)rs.size(); j.warm = 0; j.sync = s; j.from_state = s; j.emit = 0;
+      j.chunk_step = (unsigned)P;
+      oj.push_back(j); which.push_back(s);
+    }
+    rc = vit_launch(v, in, out, oj, (unsigned)rs.size(), true, phase0);
+    if (rc) return rc;
+    {
+      std::vector<vit_state> cst(oj.size() * rs.size());
+      std::vector<int> tot(oj.size() * rs.size());
+      LSDR_HIP(hipMemcpyAsync(cst.data(), v->d_chunk, cst.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipMemcpyAsync(tot.data(), v->d_totals, tot.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipStreamSynchronize(c->stream));
+      for (size_t k = 0; k < oj.size(); ++k) {
+        other_states[which[k]].assign(cst.begin() + k * rs.size(), cst.begin() + (k + 1) * rs.size());
+        other_totals[which[k]].assign(tot.begin() + k * rs.size(), tot.begin() + (k + 1) * rs.size());
+      }
+    }
+    std::vector<vit_state> st = v->states;
+    for (size_t r = 0; r < rs.size(); ++r) {
+      for (int s = 0; s < v->nsyncs; ++s) if (s != cur) st[s] = other_states[s][r];
+      // alignment decision after this resync chunk (dvb.h:1401-1410): s ascending from best = current, strict '>'
+      size_t tj = 0;
+      for (size_t t = 0; t < n_main; ++t) if (jobs[t].first_chunk <= rs[r] && rs[r] < jobs[t].first_chunk + jobs[t].n_chunks) tj = t;
+      const int tcur = totals_main[tj * stride + (unsigned)(rs[r] - jobs[tj].first_chunk)];
+      int best = cur, bt = tcur;
+      for (int s = 0; s < v->nsyncs; ++s) {
+        const int ts = s == cur ? tcur : other_totals[s][r];
+        if (ts > bt) { best = s; bt = ts; }
+      }
+      if (best != cur) {
+        // switch: everything after this chunk must be decoded with the new alignment → stop here
+        used_chunks = rs[r] + 1;
+        new_sync = best;
+        // carried states: other alignments as of this chunk; the old current one as of the end of this chunk
+        vit_state old_cur;
+        if (rs[r] == jobs[tj].first_chunk) old_cur = main_first[tj];
+        else {   // resync chunk inside tile 0 (its first chunk is not a resync chunk): recompute sequentially
+          if (tj != 0) { lsdr_set_error("viterbi_sync: internal tiling error"); return LSDR_E_ARG; }
+          vit_job j;
+          j.first_chunk = 0; j.n_chunks = (unsigned)(rs[r] + 1);
+          j.warm = 0; j.sync = cur; j.from_state = cur; j.emit = 1; j.chunk_step = 1;
+          std::vector<vit_job> one(1, j);
+          rc = vit_launch(v, in, out, one, j.n_chunks, false, phase0);
+          if (rc) return rc;
+          LSDR_HIP(hipMemcpy(&old_cur, v->d_end, sizeof(vit_state), hipMemcpyDeviceToHost));
+        }
+        for (int s = 0; s < v->nsyncs; ++s) v->states[s] = s == cur ? old_cur : st[s];
+        break;
+      }
+    }
+    if (new_sync == cur) {
+      for (int s = 0; s < v->nsyncs; ++s) if (s != cur) v->states[s] = st[s];
+      v->states[cur] = main_end;
+    }
+  } else {
+    v->states[cur] = main_end;
+  }
+  v->current_sync = new_sync;
+  v->resync_phase = (int)(((unsigned long long)phase0 + used_chunks) % (unsigned)P);
+  *consumed = used_chunks * sym_per_chunk;
+  *produced = used_chunks * bytes_per_chunk;
+  return LSDR_OK;
+}
+
+}  // extern "C"

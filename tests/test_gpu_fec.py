@@ -131,3 +131,91 @@ def test_derandomizer_resync_and_drops(capi, ctx, oracle):
         b = dr.run(data[31:])
         dr.close()
         assert bits_equal(np.concatenate([a, b]), oracle.derandomizer(data))
+
+
+# ------------------------------------------------------------------ viterbi_sync
+@pytest.mark.parametrize("tag,errp", CASES)
+def test_viterbi_golden(capi, ctx, tag, errp):
+    g = gold("fec.npz")
+    sym = fec_input(hard_symbols(), errp)
+    v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
+    vb, cons = v.run_stream(sym)
+    st = v.stats()
+    cur = v.current_sync
+    v.close()
+    assert len(vb) == int(g[f"{tag}_viterbi_n"]) and cur == int(g[f"{tag}_viterbi_sync"])
+    assert bits_equal(vb[:512], g[f"{tag}_viterbi_head"]) and sha(vb) == hexs(g[f"{tag}_viterbi_sha"])
+    assert st["tiles"] >= 1
+
+
+@pytest.mark.parametrize("errp", [0, 40, 120, 300])
+@pytest.mark.parametrize("pipe", [None, 4096, 40000])
+def test_viterbi_vs_oracle_qpsk12(capi, ctx, oracle, errp, pipe):
+    """Clean to hopeless inputs, several call patterns (the pipe size changes where calls start):
+    the tiled decoder with seam verification reproduces the sequential reference exactly."""
+    sym = fec_input(hard_symbols(), errp)
+    v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
+    got, cons = v.run_stream(sym, pipe)
+    cur = v.current_sync
+    v.close()
+    if pipe is None:
+        want, wcons, wcur = oracle.viterbi_sync(sym, 1, 0)
+    else:   # the reference consumes what fits per call; replay the same windows through the oracle
+        import ctypes as C
+        h = oracle.lib.lo_viterbi_new(1, 0)
+        out = np.empty(len(sym) + 64, np.uint8)
+        pos = nout = 0
+        while True:
+            c = C.c_size_t()
+            avail = min(pipe, len(sym) - pos)
+            n = oracle.lib.lo_viterbi_run(h, sym[pos:].ctypes.data, avail, out[nout:].ctypes.data, len(out) - nout, C.byref(c))
+            if not n and not c.value:
+                break
+            pos += c.value
+            nout += n
+        wcur = oracle.lib.lo_viterbi_current_sync(h)
+        oracle.lib.lo_viterbi_free(h)
+        want, wcons = out[:nout], pos
+    assert cons == wcons and cur == wcur
+    assert bits_equal(got, want)
+
+
+def test_viterbi_alignment_search(capi, ctx, oracle):
+    """Rotated / conjugated symbol streams make the decoder switch alignment (dvb.h:1401-1410)."""
+    hard = hard_symbols()
+    rot = np.array([2, 0, 3, 1], np.uint8)       # +90° relabelling
+    conj = np.array([1, 0, 3, 2], np.uint8)
+    for relabel in (rot, conj, rot[conj]):
+        sym = fec_input(relabel[hard], 40)
+        v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
+        got, cons = v.run_stream(sym)
+        cur = v.current_sync
+        v.close()
+        want, wcons, wcur = oracle.viterbi_sync(sym, 1, 0)
+        assert cur == wcur and cur != 0
+        assert cons == wcons and bits_equal(got, want)
+
+
+@pytest.mark.parametrize("cstln,rate", [(1, 2), (1, 3), (1, 4), (1, 5), (2, 1), (0, 0)])
+def test_viterbi_other_rates_vs_oracle(capi, ctx, oracle, cstln, rate):
+    rng = np.random.default_rng(4)
+    n = 50000
+    sym = np.zeros(n, capi.SOFTSYM)
+    nsym = {0: 2, 1: 4, 2: 8}[cstln]
+    sym["symbol"] = rng.integers(0, nsym, n)
+    sym["cost"] = -rng.integers(0, 9000, n)
+    v = capi.Viterbi(ctx, cstln, rate)
+    got, cons = v.run_stream(sym)
+    cur = v.current_sync
+    v.close()
+    want, wcons, wcur = oracle.viterbi_sync(sym, cstln, rate)
+    assert cons == wcons and cur == wcur and bits_equal(got, want)
+
+
+def test_viterbi_resync_period_1(capi, ctx, oracle):
+    sym = fec_input(hard_symbols()[:80000], 40)
+    v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12, resync_period=1)
+    got, cons = v.run_stream(sym)
+    v.close()
+    want, wcons, _ = oracle.viterbi_sync(sym, 1, 0, 1)
+    assert cons == wcons and bits_equal(got, want)
