@@ -182,9 +182,14 @@ static int run(config &cfg) {
     new file_writer<softsymbol>(&sch, *p_symbols_host, 1);
   } else {
     // DECONVOLUTION AND SYNCHRONIZATION … TS OUTPUT (leandvb.cc:519-596), all in HBM
-    if (cfg.viterbi) fail("--viterbi: the Viterbi GPU block is not wired into this app yet; use --out-symbols");
     pipebuf<u8> *p_bytes = new pipebuf<u8>(&sch, "bytes", BUF_BYTES, ctx);
-    deconvol_sync_simple *r_deconv = make_deconvol_sync_simple(&sch, p_symbols, *p_bytes, (code_rate)cfg.fec);
+    deconvol_sync_simple *r_deconv = NULL;
+    if (cfg.viterbi) {
+      if (cfg.fec == FEC23 && (demod.cstln->nsymbols == 4 || demod.cstln->nsymbols == 64)) cfg.fec = FEC46;   // leandvb.cc:533-537
+      new viterbi_sync(&sch, p_symbols, *p_bytes, demod.cstln, (code_rate)cfg.fec);
+    } else {
+      r_deconv = make_deconvol_sync_simple(&sch, p_symbols, *p_bytes, (code_rate)cfg.fec);
+    }
     pipebuf<u8> *p_mpegbytes = new pipebuf<u8>(&sch, "mpegbytes", BUF_MPEGBYTES, ctx);
     new mpeg_sync<u8, 0>(&sch, *p_bytes, *p_mpegbytes, r_deconv, &p_lock, &p_locktime);
     pipebuf<rspacket<u8> > *p_rspackets = new pipebuf<rspacket<u8> >(&sch, "RS-enc packets", BUF_PACKETS, ctx);

@@ -64,6 +64,30 @@ inline deconvol_sync_simple *make_deconvol_sync_simple(scheduler *sch, pipebuf<s
   return new deconvol_sync_simple(sch, in, out, rate);
 }
 
+// viterbi_sync (dvb.h:1173-1416): same constructor and the public resync_period.
+struct viterbi_sync : runnable {
+  int resync_period;
+  viterbi_sync(scheduler *sch, pipebuf<softsymbol> &i, pipebuf<unsigned char> &o, cstln_lut<256> *cstln, code_rate cr)
+      : runnable(sch, "viterbi_sync"), resync_period(32),
+        ctx(pipe_ctx(i.dev, o.dev, "viterbi_sync: pipebufs must be device pipebufs of one ctx")), in(i), out(o, 128), h(NULL) {
+    lsdr_check(lsdr_viterbi_create(ctx, (int)cstln->type, (int)cr, &h), name);
+  }
+  void run() {
+    lsdr_check(lsdr_viterbi_set_resync_period(h, resync_period), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_viterbi_run(h, (const lsdr_softsymbol *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<softsymbol> in;
+  pipewriter<unsigned char> out;
+  lsdr_viterbi *h;
+};
+
 template <typename Tbyte, Tbyte BYTE_ERASED>
 struct mpeg_sync;
 

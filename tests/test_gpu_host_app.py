@@ -92,3 +92,19 @@ def test_full_chain_ts_vs_oracle(oracle, buf_factor):
     sent = {bytes(t) for t in ts_in}
     assert sum(bytes(t) in sent for t in ts) >= len(ts) - 10   # a few packets around acquisition are false locks, as in the reference
     assert "LOCK 1" in err
+
+
+@pytest.mark.parametrize("buf_factor", [4, 256])
+def test_full_chain_viterbi_ts_vs_oracle(oracle, buf_factor):
+    """--viterbi: cstln_receiver(pll/6) → viterbi_sync → mpeg_sync → deinterleaver → RS → derandomizer on the GPU
+    == the oracle chain that tests/test_oracle_fec.py pins to `leandvb --viterbi`."""
+    from leansdr_amd import synth_dvbs
+    iq, ts_in = synth_dvbs.capture_u8(n_packets=300, sps_num=6, sps_den=5, seed=4)
+    ts, _ = run_ts(["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--viterbi", "--buf-factor", str(buf_factor)], iq)
+    x = oracle.cconverter_u8(iq)
+    p = po.rx_params(sampler=1, cstln=1, omega=float(np.float32(2400e3 / 2000e3)), meas_decimation=int(2400e3 / 5),
+                     pll_adjustment=1 / 6.0)
+    want = oracle.fec_chain(oracle.rx(p, x)["sym"], 1, 0, 1)[0]
+    assert len(want) > 200 and bits_equal(ts, want)
+    sent = {bytes(t) for t in ts_in}
+    assert sum(bytes(t) in sent for t in ts) >= len(ts) - 2
