@@ -83,26 +83,14 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist_mod
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        dist = dist_mod
+    from leansdr_amd.shard import Shard
+    shard = Shard()                       # one process per GPU; torch.distributed (RCCL) only when WORLD_SIZE > 1
+    rank, local_rank, world = shard.rank, shard.local_rank, shard.world
 
     import leansdr_amd.capi as capi
     from leansdr_amd import synth
 
-    def barrier():
-        if dist is not None:
-            import torch
-            t = torch.zeros(1, device="cuda")
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
+    barrier = shard.barrier
 
     ctx = capi.Ctx(local_rank)
     coeffs, decim = c2_filter(capi)
@@ -113,7 +101,7 @@ def main():
     period = (args.period_msamples << 20) // sps * sps
     reps = max(1, (args.batch_msamples << 20) // period)
     B = period * reps
-    x, _ = synth.qpsk_baseband(period, sps, seed=1 + rank, rms=1.0, snr_db=20.0)
+    x, _ = synth.qpsk_baseband(period, sps, seed=shard.capture_seed(), rms=1.0, snr_db=20.0)
     d_in = ctx.alloc(B * 8)
     d_per = ctx.upload(x)
     for r in range(reps):
@@ -197,16 +185,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
-    if dist is not None:
-        import torch
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        c = torch.tensor([float(consumed)], device="cuda", dtype=torch.float64)
-        dist.all_reduce(c)
-        total = float(c.item())
-    else:
-        total = float(consumed)
+    total, dt, _ = shard.aggregate(consumed, dt)   # all ranks' samples ÷ the slowest rank's time
 
     if rank == 0:
         per_launch_samples = (n_out_max * decim)           # input samples one fir launch processes
@@ -247,8 +226,7 @@ def main():
     if d_dec2 is not None:
         d_dec2.free()
     ctx.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    shard.close()
 
 
 if __name__ == "__main__":

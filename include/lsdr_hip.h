@@ -103,6 +103,33 @@ int lsdr_scaler_run(lsdr_ctx *ctx, float scale, const lsdr_cf32 *in, size_t n, l
 int lsdr_decimator_run(lsdr_ctx *ctx, unsigned d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out,
                        size_t cap, size_t *produced);
 
+/* -------------------------------------------------------------- auto_notch / cnr_fft / cfft
+ * auto_notch<f32>, sdr.h:46-154: every `decimation` samples the `nslots` strongest bins of a 4096-point
+ * spectrum are re-detected; every sample is cleaned by one first-order complex tracker per slot.
+ * The per-sample recurrence runs on the GPU (time tiles with warm-up; every seam is verified bit for
+ * bit against the previous tile's end state, unverified spans are redone sequentially → bit-exact);
+ * detect() is a once-per-millions-of-samples control step: the block is fetched to the host and the
+ * reference's FFT / hypotf / cosf / sinf sequence is evaluated there (exact libm). */
+typedef struct lsdr_auto_notch lsdr_auto_notch;
+int lsdr_auto_notch_create(lsdr_ctx *ctx, int nslots, float agc_rms_setpoint, lsdr_auto_notch **a);
+void lsdr_auto_notch_destroy(lsdr_auto_notch *a);
+int lsdr_auto_notch_set(lsdr_auto_notch *a, int decimation, float k);      /* public members, sdr.h:49-50 */
+int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot);
+int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *bad_seams);
+/* run(), sdr.h:64-75: whole 4096-sample blocks; *consumed == *produced.  Synchronous. */
+int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
+                        size_t *consumed, size_t *produced);
+/* cfft_engine<float>::inplace (dsp.h:56-116) on host data — exact restatement used by detect()/cnr_fft. */
+int lsdr_cfft_host(int n, lsdr_cf32 *data_host, int reverse);
+/* cnr_fft<f32>, sdr.h:1273-1345: consumes whole nfft blocks; every `decimation` samples one block is
+ * fetched and a CNR value (dB) is appended to cnr_out_host.  Synchronous only when a block is fetched. */
+typedef struct lsdr_cnr_fft lsdr_cnr_fft;
+int lsdr_cnr_fft_create(lsdr_ctx *ctx, float bandwidth, int nfft, lsdr_cnr_fft **c);
+void lsdr_cnr_fft_destroy(lsdr_cnr_fft *c);
+int lsdr_cnr_fft_set(lsdr_cnr_fft *c, int decimation, float kavg);         /* public members, sdr.h:1287-1288 */
+int lsdr_cnr_fft_run(lsdr_cnr_fft *c, float freq_tap, float tap_multiplier, const lsdr_cf32 *in, size_t n_in,
+                     float *cnr_out_host, size_t cap_out, size_t *consumed, size_t *produced);
+
 /* -------------------------------------------------------------- fir_filter
  * fir_filter<cf32,float>, dsp.h:219-285 (decimating FIR, real prototype taps
  * frequency-shifted to complex).  The optional input stage fuses the block in

@@ -91,6 +91,17 @@ _sig("lsdr_cstln_lut_build", C.c_int, [C.c_int, C.c_int, vp, vp, vp, vp, C.POINT
 _sig("lsdr_cconverter_u8_run", C.c_int, [vp, vp, c_sz, vp])
 _sig("lsdr_scaler_run", C.c_int, [vp, c_f, vp, c_sz, vp])
 _sig("lsdr_decimator_run", C.c_int, [vp, C.c_uint, vp, c_sz, vp, c_sz, psz])
+_sig("lsdr_auto_notch_create", C.c_int, [vp, C.c_int, c_f, C.POINTER(vp)])
+_sig("lsdr_auto_notch_destroy", None, [vp])
+_sig("lsdr_auto_notch_set", C.c_int, [vp, C.c_int, c_f])
+_sig("lsdr_auto_notch_slot_bin", C.c_int, [vp, C.c_int])
+_sig("lsdr_auto_notch_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
+_sig("lsdr_auto_notch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])
+_sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
+_sig("lsdr_cnr_fft_destroy", None, [vp])
+_sig("lsdr_cnr_fft_set", C.c_int, [vp, C.c_int, c_f])
+_sig("lsdr_cnr_fft_run", C.c_int, [vp, c_f, c_f, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_fir_filter_create", C.c_int, [vp, C.POINTER(FirCfg), C.POINTER(vp)])
 _sig("lsdr_fir_filter_destroy", None, [vp])
 _sig("lsdr_fir_filter_set_freq", C.c_int, [vp, c_f])
@@ -596,3 +607,73 @@ class Derandomizer:
         out = self.ctx.download(dout, np.uint8, prod.value * 188).reshape(-1, 188)
         din.free(); dout.free()
         return out
+
+
+# ---- auto_notch / cnr_fft / cfft ------------------------------------------------------
+def cfft_host(x, reverse=False):
+    x = np.ascontiguousarray(x, np.complex64).copy()
+    check(lib.lsdr_cfft_host(len(x), _np(x), int(reverse)))
+    return x
+
+
+class AutoNotch:
+    """auto_notch<f32> (sdr.h:46-154) on the GPU."""
+
+    def __init__(self, ctx, nslots=1, setpoint=0.0, decimation=1024 * 4096, k=0.002):
+        self.ctx, self.nslots = ctx, nslots
+        h = vp()
+        check(lib.lsdr_auto_notch_create(ctx.h, nslots, setpoint, C.byref(h)))
+        self.h = h
+        check(lib.lsdr_auto_notch_set(h, decimation, k))
+
+    def close(self):
+        if self.h:
+            lib.lsdr_auto_notch_destroy(self.h)
+            self.h = None
+
+    def bins(self):
+        return [lib.lsdr_auto_notch_slot_bin(self.h, s) for s in range(self.nslots)]
+
+    def stats(self):
+        t, b = C.c_uint(), C.c_uint()
+        check(lib.lsdr_auto_notch_stats(self.h, C.byref(t), C.byref(b)))
+        return dict(tiles=t.value, bad_seams=b.value)
+
+    def run_dev(self, in_ptr, n, out_ptr, cap):
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_auto_notch_run(self.h, in_ptr, n, out_ptr, cap, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.ctx.upload(x)
+        dout = self.ctx.alloc(max(8, x.nbytes))
+        cons, prod = self.run_dev(din.ptr, len(x), dout.ptr, len(x))
+        out = self.ctx.download(dout, np.complex64, prod)
+        din.free(); dout.free()
+        return out
+
+
+class CnrFft:
+    """cnr_fft<f32> (sdr.h:1273-1345)."""
+
+    def __init__(self, ctx, bandwidth, nfft=4096, decimation=1048576, kavg=0.1):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_cnr_fft_create(ctx.h, bandwidth, nfft, C.byref(h)))
+        self.h = h
+        check(lib.lsdr_cnr_fft_set(h, decimation, kavg))
+
+    def close(self):
+        if self.h:
+            lib.lsdr_cnr_fft_destroy(self.h)
+            self.h = None
+
+    def run(self, x, freq_tap=0.0, tap_multiplier=1.0):
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.ctx.upload(x)
+        out = np.empty(len(x) // 64 + 8, np.float32)
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_cnr_fft_run(self.h, freq_tap, tap_multiplier, din.ptr, len(x), _np(out), len(out), C.byref(cons), C.byref(prod)))
+        din.free()
+        return out[:prod.value].copy(), cons.value

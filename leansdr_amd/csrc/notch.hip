@@ -1,0 +1,445 @@
+// leansdr_amd/csrc/notch.hip — auto_notch<f32> (sdr.h:46-154), cnr_fft<f32> (sdr.h:1273-1345) and the
+// host restatement of cfft_engine<float> (dsp.h:56-116) they share.
+//
+// auto_notch::process() is, per slot, the recurrence   estim ← bb·k + estim·(1−k)   over every sample
+// (bb = x·conj(e_i), e_i restarts every 4096-sample block) followed by  out = gain·(x − Σ estim·e_i).
+// Float rounding makes a scan formulation inexact, so each GPU lane runs the reference's sequential
+// arithmetic over a time tile.  Lanes other than the first start `kWarmBlocks` blocks early from
+// estim = 0: the influence of the start value decays by (1−k) per sample (0.998^16384 ≈ 6e-15) and the
+// two trajectories then coincide BIT FOR BIT — which is verified at every seam (tile j's estimators
+// after warm-up == tile j−1's estimators at its end); anything that fails is redone sequentially.
+// Memory-bound streaming: 8 B in + 8 B out per sample; neighbouring lanes read different cache lines
+// but each line is reused by its lane for 16 consecutive samples (L1-resident).
+#include <cmath>
+#include "lsdr_internal.h"
+
+namespace {
+
+constexpr int kN = 4096;          // fft.n of auto_notch (sdr.h:55)
+constexpr int kMaxSlots = 8;
+constexpr int kTileBlocks = 2, kWarmBlocks = 4;
+
+struct notch_est { float re[kMaxSlots], im[kMaxSlots]; };
+
+struct notch_args {
+  const float2 *in;
+  float2 *out;
+  const float2 *expj;              // [nslots][4096]
+  int nslots;
+  float k, gain;
+  unsigned long long n_blocks;     // blocks of this launch
+  unsigned tile_blocks, warm_blocks;
+  unsigned n_tiles;
+  const notch_est *carry;          // estimators at block 0
+  notch_est *begin, *end;          // per tile
+  int serial_from;                 // ≥ 0: single sequential job starting at this block (repair); -1: tiled
+};
+
+template <int NS>
+__global__ __launch_bounds__(64) void k_notch(notch_args a) {
+  const unsigned t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= a.n_tiles) return;
+  unsigned long long b0, b1;
+  bool from_carry;
+  if (a.serial_from >= 0) { b0 = (unsigned long long)a.serial_from; b1 = a.n_blocks; from_carry = true; }
+  else {
+    b0 = (unsigned long long)t * a.tile_blocks;
+    b1 = b0 + a.tile_blocks;
+    if (b1 > a.n_blocks) b1 = a.n_blocks;
+    from_carry = t == 0;
+  }
+  float er[NS], ei[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { er[s] = from_carry ? a.carry->re[s] : 0.f; ei[s] = from_carry ? a.carry->im[s] : 0.f; }
+  const float k = a.k, omk = 1 - a.k, gain = a.gain;
+  unsigned long long bstart = b0;
+  if (!from_carry) bstart = b0 >= a.warm_blocks ? b0 - a.warm_blocks : 0;   // (tiles that cannot warm up fully are not created)
+  for (unsigned long long b = bstart; b < b1; ++b) {
+    if (b == b0) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) { a.begin[t].re[s] = er[s]; a.begin[t].im[s] = ei[s]; }
+    }
+    const bool emit = b >= b0;
+    const float2 *pin = a.in + b * kN;
+    float2 *pout = a.out + b * kN;
+    for (int i = 0; i < kN; ++i) {
+      const float2 x = pin[i];
+      float o_re = x.x, o_im = x.y;
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {   // sdr.h:124-134
+        const float2 e = a.expj[s * kN + i];
+        const float bbre = x.x * e.x + x.y * e.y;
+        const float bbim = -x.x * e.y + x.y * e.x;
+        er[s] = bbre * k + er[s] * omk;
+        ei[s] = bbim * k + ei[s] * omk;
+        const float subre = er[s] * e.x - ei[s] * e.y;
+        const float subim = er[s] * e.y + ei[s] * e.x;
+        o_re -= subre;
+        o_im -= subim;
+      }
+      if (emit) pout[i] = make_float2(gain * o_re, gain * o_im);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; ++s) { a.end[t].re[s] = er[s]; a.end[t].im[s] = ei[s]; }
+}
+
+__global__ __launch_bounds__(256) void k_notch_passthrough(const float2 *in, float2 *out, size_t n, float gain) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float2 x = in[i];
+    out[i] = make_float2(gain * x.x, gain * x.y);   // no active slot: out = gain·in (x − 0 = x)
+  }
+}
+
+// cfft_engine<float>::inplace, dsp.h:56-116 — host, exact.
+void cfft_host(int n, lsdr_cf32 *data, bool reverse) {
+  int logn = 0;
+  for (int t = n; t > 1; t >>= 1) ++logn;
+  std::vector<lsdr_cf32> om(n);
+  for (int i = 0; i < n; ++i) {
+    float a = (float)(2.0 * M_PI * i / n);
+    om[i].re = cosf(a);
+    om[i].im = reverse ? -sinf(a) : sinf(a);
+  }
+  for (int i = 0; i < n; ++i) {
+    int r = 0;
+    for (int b = 0; b < logn; ++b) r = (r << 1) | ((i >> b) & 1);
+    if (r < i) { lsdr_cf32 tmp = data[i]; data[i] = data[r]; data[r] = tmp; }
+  }
+  for (int i = 0; i < logn; ++i) {
+    const int hbs = 1 << i, dom = 1 << (logn - 1 - i);
+    for (int j = 0; j < dom; ++j) {
+      const int p = j * hbs * 2, q = p + hbs;
+      for (int k = 0; k < hbs; ++k) {
+        const lsdr_cf32 w = om[k * dom], d = data[q + k];
+        const float xr = w.re * d.re - w.im * d.im;
+        const float xi = w.re * d.im + w.im * d.re;
+        data[q + k].re = data[p + k].re - xr;
+        data[q + k].im = data[p + k].im - xi;
+        data[p + k].re = data[p + k].re + xr;
+        data[p + k].im = data[p + k].im + xi;
+      }
+    }
+  }
+  if (reverse) {
+    const float invn = (float)(1.0 / n);
+    for (int i = 0; i < n; ++i) { data[i].re *= invn; data[i].im *= invn; }
+  }
+}
+
+}  // namespace
+
+struct lsdr_auto_notch {
+  lsdr_ctx *ctx;
+  int nslots, decimation, phase;
+  float k, gain, agc_rms_setpoint;
+  int bins[kMaxSlots];
+  bool any_active;
+  std::vector<lsdr_cf32> expj;     // [nslots][4096] host copy
+  float2 *d_expj;
+  notch_est est;                   // carried estimators (host mirror)
+  notch_est *d_carry, *d_begin, *d_end;
+  size_t tiles_cap;
+  unsigned last_tiles, last_bad;
+};
+
+struct lsdr_cnr_fft {
+  lsdr_ctx *ctx;
+  float bandwidth, kavg;
+  int nfft, decimation, phase;
+  std::vector<float> avgpower;     // empty until the first spectrum
+};
+
+// detect(), sdr.h:76-118, on a host copy of the block
+static void notch_detect(lsdr_auto_notch *a, const lsdr_cf32 *pin) {
+  std::vector<lsdr_cf32> data(pin, pin + kN);
+  float m0 = 0, m2 = 0;
+  for (int i = 0; i < kN; ++i) {
+    m2 += (float)pin[i].re * pin[i].re + (float)pin[i].im * pin[i].im;
+    if (fabsf(pin[i].re) > m0) m0 = fabsf(pin[i].re);
+    if (fabsf(pin[i].im) > m0) m0 = fabsf(pin[i].im);
+  }
+  if (a->agc_rms_setpoint && m2) {
+    float rms = sqrtf(m2 / kN);
+    float new_gain = a->agc_rms_setpoint / rms;
+    a->gain = (float)((double)a->gain * 0.9 + (double)new_gain * 0.1);
+  }
+  cfft_host(kN, data.data(), true);
+  std::vector<float> amp(kN);
+  for (int i = 0; i < kN; ++i) amp[i] = hypotf(data[i].re, data[i].im);
+  for (int s = 0; s < a->nslots; ++s) {
+    int iamax = 0;
+    for (int i = 0; i < kN; ++i) if (amp[i] > amp[iamax]) iamax = i;
+    if (iamax != a->bins[s]) {
+      a->bins[s] = iamax;
+      a->est.re[s] = 0; a->est.im[s] = 0;
+      for (int i = 0; i < kN; ++i) {
+        float ang = (float)(2 * M_PI * iamax * i / kN);
+        a->expj[(size_t)s * kN + i].re = cosf(ang);
+        a->expj[(size_t)s * kN + i].im = sinf(ang);
+      }
+    }
+    amp[iamax] = 0;
+    if (iamax - 1 >= 0) amp[iamax - 1] = 0;
+    if (iamax + 1 < kN) amp[iamax + 1] = 0;
+  }
+  a->any_active = a->nslots > 0;
+}
+
+template <int NS>
+static void notch_launch_ns(hipStream_t st, unsigned grid, const notch_args &a) { hipLaunchKernelGGL(k_notch<NS>, dim3(grid), dim3(64), 0, st, a); }
+static void notch_launch(int ns, hipStream_t st, unsigned grid, const notch_args &a) {
+  switch (ns) {
+    case 1: notch_launch_ns<1>(st, grid, a); break;
+    case 2: notch_launch_ns<2>(st, grid, a); break;
+    case 3: notch_launch_ns<3>(st, grid, a); break;
+    case 4: notch_launch_ns<4>(st, grid, a); break;
+    case 5: notch_launch_ns<5>(st, grid, a); break;
+    case 6: notch_launch_ns<6>(st, grid, a); break;
+    case 7: notch_launch_ns<7>(st, grid, a); break;
+    default: notch_launch_ns<8>(st, grid, a); break;
+  }
+}
+
+// process() over `nb` blocks with fixed slots: tiled + verified
+static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out, size_t nb) {
+  lsdr_ctx *c = a->ctx;
+  if (!nb) return LSDR_OK;
+  if (!a->any_active) {
+    size_t n = nb * kN;
+    size_t blocks = (n + 255) / 256, capb = (size_t)c->num_cu * 8;
+    if (blocks > capb) blocks = capb;
+    hipLaunchKernelGGL(k_notch_passthrough, dim3((unsigned)blocks), dim3(256), 0, c->stream, (const float2 *)in, (float2 *)out, n, a->gain);
+    LSDR_HIP(hipGetLastError());
+    return LSDR_OK;
+  }
+  // tiles: tile 0 covers the first (kWarmBlocks + kTileBlocks) blocks so that every other tile can warm up fully
+  const unsigned TB = kTileBlocks, WB = kWarmBlocks;
+  unsigned n_tiles = (unsigned)((nb + TB - 1) / TB);
+  if (a->tiles_cap < n_tiles) {
+    (void)hipFree(a->d_begin); (void)hipFree(a->d_end);
+    LSDR_HIP(hipMalloc((void **)&a->d_begin, n_tiles * sizeof(notch_est)));
+    LSDR_HIP(hipMalloc((void **)&a->d_end, n_tiles * sizeof(notch_est)));
+    a->tiles_cap = n_tiles;
+  }
+  LSDR_HIP(hipMemcpyAsync(a->d_carry, &a->est, sizeof(notch_est), hipMemcpyHostToDevice, c->stream));
+  LSDR_HIP(hipMemcpyAsync(a->d_expj, a->expj.data(), (size_t)a->nslots * kN * sizeof(float2), hipMemcpyHostToDevice, c->stream));
+  notch_args na;
+  na.in = (const float2 *)in; na.out = (float2 *)out; na.expj = a->d_expj; na.nslots = a->nslots;
+  na.k = a->k; na.gain = a->gain; na.n_blocks = nb; na.tile_blocks = TB; na.warm_blocks = WB; na.n_tiles = n_tiles;
+  na.carry = a->d_carry; na.begin = a->d_begin; na.end = a->d_end; na.serial_from = -1;
+  notch_launch(a->nslots, c->stream, (n_tiles + 63) / 64, na);
+  LSDR_HIP(hipGetLastError());
+  std::vector<notch_est> hb(n_tiles), he(n_tiles);
+  LSDR_HIP(hipMemcpyAsync(hb.data(), a->d_begin, n_tiles * sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipMemcpyAsync(he.data(), a->d_end, n_tiles * sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  a->last_tiles += n_tiles;
+  // seam verification.  Tiles whose warm-up was cut short by the start of the span (t·TB < WB) always count as unverified.
+  unsigned first_bad = n_tiles;
+  for (unsigned t = 1; t < n_tiles; ++t) {
+    bool ok = (unsigned long long)t * TB >= WB;
+    for (int s = 0; ok && s < a->nslots; ++s)
+      ok = memcmp(&hb[t].re[s], &he[t - 1].re[s], 4) == 0 && memcmp(&hb[t].im[s], &he[t - 1].im[s], 4) == 0;
+    if (!ok) { first_bad = t; break; }
+  }
+  if (first_bad < n_tiles) {
+    // Re-verify after a sequential repair of the unverified head only: redo blocks [first_bad·TB, next verified seam)
+    // sequentially from tile first_bad−1's end state, and continue until a later seam checks out.
+    unsigned t = first_bad;
+    notch_est state = he[t - 1];
+    while (t < n_tiles) {
+      // find how far the sequential pass must go: until tile u (> t) whose begin state equals our running end state.
+      // Simple and exact: redo ONE tile sequentially, compare with the next tile's begin state, repeat.
+      ++a->last_bad;
+      LSDR_HIP(hipMemcpyAsync(a->d_carry, &state, sizeof(notch_est), hipMemcpyHostToDevice, c->stream));
+      notch_args ra = na;
+      ra.serial_from = (int)((unsigned long long)t * TB);
+      unsigned long long bend = (unsigned long long)(t + 1) * TB;
+      if (bend > nb) bend = nb;
+      ra.n_blocks = bend;
+      ra.n_tiles = 1;
+      notch_launch(a->nslots, c->stream, 1, ra);
+      LSDR_HIP(hipGetLastError());
+      LSDR_HIP(hipMemcpyAsync(&state, a->d_end, sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipStreamSynchronize(c->stream));
+      he[t] = state;
+      ++t;
+      if (t < n_tiles) {
+        bool ok = (unsigned long long)t * TB >= WB;
+        for (int s = 0; ok && s < a->nslots; ++s)
+          ok = memcmp(&hb[t].re[s], &state.re[s], 4) == 0 && memcmp(&hb[t].im[s], &state.im[s], 4) == 0;
+        if (ok) {   // the speculative tiles from here on started from the right state; keep scanning their seams
+          unsigned u = t + 1;
+          for (; u < n_tiles; ++u) {
+            bool ok2 = true;
+            for (int s = 0; ok2 && s < a->nslots; ++s)
+              ok2 = memcmp(&hb[u].re[s], &he[u - 1].re[s], 4) == 0 && memcmp(&hb[u].im[s], &he[u - 1].im[s], 4) == 0;
+            if (!ok2) break;
+          }
+          if (u >= n_tiles) { t = n_tiles; break; }
+          state = he[u - 1];
+          t = u;
+        }
+      }
+    }
+  }
+  a->est = he[n_tiles - 1];
+  return LSDR_OK;
+}
+
+extern "C" {
+
+int lsdr_cfft_host(int n, lsdr_cf32 *data, int reverse) {
+  LSDR_ARG(data && n >= 1 && (n & (n - 1)) == 0);
+  cfft_host(n, data, reverse != 0);
+  return LSDR_OK;
+}
+
+int lsdr_auto_notch_create(lsdr_ctx *c, int nslots, float setpoint, lsdr_auto_notch **out) {
+  LSDR_ARG(c && out && nslots >= 0 && nslots <= kMaxSlots);
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_auto_notch *a = new lsdr_auto_notch();
+  a->ctx = c; a->nslots = nslots;
+  a->decimation = 1024 * 4096; a->k = (float)0.002;   // sdr.h:54
+  a->phase = 0; a->gain = 1; a->agc_rms_setpoint = setpoint;
+  for (int s = 0; s < kMaxSlots; ++s) a->bins[s] = -1;
+  a->any_active = false;
+  a->expj.assign((size_t)(nslots > 0 ? nslots : 1) * kN, lsdr_cf32{0.f, 0.f});
+  memset(&a->est, 0, sizeof(a->est));
+  LSDR_HIP(hipMalloc((void **)&a->d_expj, (size_t)(nslots > 0 ? nslots : 1) * kN * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&a->d_carry, sizeof(notch_est)));
+  a->d_begin = a->d_end = nullptr; a->tiles_cap = 0;
+  a->last_tiles = a->last_bad = 0;
+  *out = a;
+  return LSDR_OK;
+}
+void lsdr_auto_notch_destroy(lsdr_auto_notch *a) {
+  if (!a) return;
+  (void)hipStreamSynchronize(a->ctx->stream);
+  (void)hipFree(a->d_expj); (void)hipFree(a->d_carry); (void)hipFree(a->d_begin); (void)hipFree(a->d_end);
+  delete a;
+}
+int lsdr_auto_notch_set(lsdr_auto_notch *a, int decimation, float k) {
+  LSDR_ARG(a && decimation >= 1);
+  a->decimation = decimation; a->k = k;
+  return LSDR_OK;
+}
+int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot) { return (a && slot >= 0 && slot < a->nslots) ? a->bins[slot] : -1; }
+int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *bad) {
+  LSDR_ARG(a);
+  if (tiles) *tiles = a->last_tiles;
+  if (bad) *bad = a->last_bad;
+  return LSDR_OK;
+}
+
+int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
+                        size_t *consumed, size_t *produced) {
+  LSDR_ARG(a && consumed && produced);
+  *consumed = 0; *produced = 0;
+  size_t nb = (n_in < cap_out ? n_in : cap_out) / kN;   // while readable>=4096 && writable>=4096, sdr.h:65
+  if (!nb) return LSDR_OK;
+  LSDR_ARG(in && out);
+  lsdr_ctx *c = a->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  a->last_tiles = a->last_bad = 0;
+  // Split at the blocks where detect() fires (phase += 4096; if phase >= decimation …, sdr.h:66-70).
+  size_t b = 0;
+  while (b < nb) {
+    // blocks until the next detect: detect fires at the START of block j when phase + 4096·(j−b+1) ≥ decimation
+    long long until = ((long long)a->decimation - a->phase + kN - 1) / kN - 1;   // blocks processed before the detecting block
+    if (until < 0) until = 0;
+    size_t run = (size_t)until < nb - b ? (size_t)until : nb - b;
+    int rc = notch_process(a, in + b * kN, out + b * kN, run);
+    if (rc) return rc;
+    a->phase += (int)(run * kN);
+    b += run;
+    if (b < nb) {   // this block triggers detect() on its own input, then is processed with the new slots
+      a->phase += kN;
+      if (a->phase >= a->decimation) {
+        a->phase -= a->decimation;
+        std::vector<lsdr_cf32> blk(kN);
+        LSDR_HIP(hipMemcpyAsync(blk.data(), in + b * kN, kN * sizeof(lsdr_cf32), hipMemcpyDeviceToHost, c->stream));
+        LSDR_HIP(hipStreamSynchronize(c->stream));
+        notch_detect(a, blk.data());
+      }
+      rc = notch_process(a, in + b * kN, out + b * kN, 1);
+      if (rc) return rc;
+      b += 1;
+    }
+  }
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  *consumed = nb * kN;
+  *produced = nb * kN;
+  return LSDR_OK;
+}
+
+// ------------------------------------------------------------------ cnr_fft
+int lsdr_cnr_fft_create(lsdr_ctx *c, float bandwidth, int nfft, lsdr_cnr_fft **out) {
+  LSDR_ARG(c && out && nfft >= 2 && (nfft & (nfft - 1)) == 0);
+  if (bandwidth > 0.25) { lsdr_set_error("CNR estimator requires Fsampling > 4x Fsignal"); return LSDR_E_ARG; }   // sdr.h:1282-1283
+  lsdr_cnr_fft *f = new lsdr_cnr_fft();
+  f->ctx = c; f->bandwidth = bandwidth; f->nfft = nfft;
+  f->decimation = 1048576; f->kavg = (float)0.1; f->phase = 0;
+  *out = f;
+  return LSDR_OK;
+}
+void lsdr_cnr_fft_destroy(lsdr_cnr_fft *f) { delete f; }
+int lsdr_cnr_fft_set(lsdr_cnr_fft *f, int decimation, float kavg) {
+  LSDR_ARG(f && decimation >= 1);
+  f->decimation = decimation; f->kavg = kavg;
+  return LSDR_OK;
+}
+
+int lsdr_cnr_fft_run(lsdr_cnr_fft *f, float freq_tap, float tap_multiplier, const lsdr_cf32 *in, size_t n_in,
+                     float *cnr_out, size_t cap_out, size_t *consumed, size_t *produced) {
+  LSDR_ARG(f && consumed && produced);
+  *consumed = 0; *produced = 0;
+  const int N = f->nfft;
+  size_t pos = 0, nout = 0;
+  lsdr_ctx *c = f->ctx;
+  // while in.readable()>=fft.n && out.writable()>=1 (sdr.h:1292)
+  while (n_in - pos >= (size_t)N && nout < cap_out) {
+    // skip ahead over the blocks that only advance the phase
+    long long until = ((long long)f->decimation - f->phase + N - 1) / N - 1;
+    if (until < 0) until = 0;
+    size_t avail = (n_in - pos) / N;
+    if ((size_t)until >= avail) { f->phase += (int)(avail * N); pos += avail * N; break; }
+    f->phase += (int)(until * N);
+    pos += (size_t)until * N;
+    f->phase += N;
+    if (f->phase >= f->decimation) {   // do_cnr, sdr.h:1303-1332
+      f->phase -= f->decimation;
+      LSDR_ARG(in && cnr_out);
+      std::vector<lsdr_cf32> data(N);
+      LSDR_HIP(hipMemcpyAsync(data.data(), in + pos, (size_t)N * sizeof(lsdr_cf32), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipStreamSynchronize(c->stream));
+      const float center_freq = freq_tap * tap_multiplier;
+      const int icf = (int)floor((double)(center_freq * N) + 0.5);
+      cfft_host(N, data.data(), true);
+      std::vector<float> power(N);
+      for (int i = 0; i < N; ++i) power[i] = data[i].re * data[i].re + data[i].im * data[i].im;
+      if (f->avgpower.empty()) f->avgpower = power;
+      for (int i = 0; i < N; ++i) f->avgpower[i] = f->avgpower[i] * (1 - f->kavg) + power[i] * f->kavg;
+      const int bwslots = (int)((f->bandwidth / 4) * N);
+      if (bwslots) {
+        auto avgslots = [&](int i0, int i1) {
+          float s = 0;
+          for (int i = i0; i <= i1; ++i) s += f->avgpower[i & (N - 1)];
+          return s / (i1 - i0 + 1);
+        };
+        const float c2plusn2 = avgslots(icf - bwslots, icf + bwslots);
+        const float n2 = (avgslots(icf - bwslots * 4, icf - bwslots * 3) + avgslots(icf + bwslots * 3, icf + bwslots * 4)) / 2;
+        const float c2 = c2plusn2 - n2;
+        cnr_out[nout++] = (c2 > 0 && n2 > 0) ? 10 * logf(c2 / n2) / logf(10) : -50;
+      }
+    }
+    pos += N;
+  }
+  *consumed = pos;
+  *produced = nout;
+  return LSDR_OK;
+}
+
+}  // extern "C"

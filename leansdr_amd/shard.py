@@ -1,0 +1,70 @@
+"""leansdr_amd/shard.py — multi-GPU plumbing for independent captures.
+
+The leandvb path shards by capture: every rank owns one GPU and one independent stream, there
+is NO data-path collective.  torch.distributed is used only for (1) a barrier before/after the
+timed region, (2) the max-over-ranks step time and (3) the sum of samples processed — three scalar
+all-reduces per benchmark run.  Works with backend "nccl" (= RCCL over xGMI on the MI355X node) and
+with "gloo" (CPU, used by tests/test_shard_gloo.py).
+"""
+import os
+
+
+class Shard:
+    def __init__(self, backend=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.dist = None
+        self.device = None
+        if self.world > 1:
+            import torch
+            import torch.distributed as dist
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            if backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+                self.device = torch.device("cuda", self.local_rank)
+                dist.init_process_group("nccl", device_id=self.device)
+            else:
+                self.device = torch.device("cpu")
+                dist.init_process_group("gloo")
+            self.dist = dist
+
+    def capture_seed(self, base=1):
+        """Every rank demodulates its own capture."""
+        return base + self.rank
+
+    def barrier(self):
+        if self.dist is None:
+            return
+        import torch
+        t = torch.zeros(1, device=self.device)
+        self.dist.all_reduce(t)
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+
+    def max_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, x):
+        if self.dist is None:
+            return float(x)
+        import torch
+        t = torch.tensor([float(x)], device=self.device, dtype=torch.float64)
+        self.dist.all_reduce(t)
+        return float(t.item())
+
+    def aggregate(self, units_this_rank, seconds_this_rank):
+        """Whole-job throughput: units over all ranks ÷ the slowest rank's time."""
+        total = self.sum_over_ranks(units_this_rank)
+        dt = self.max_over_ranks(seconds_this_rank)
+        return total, dt, total / dt
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+            self.dist = None
