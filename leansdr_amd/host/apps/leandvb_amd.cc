@@ -33,6 +33,8 @@ struct config {
   float Ftune;
   bool allow_drift;
   bool viterbi;
+  int anf;            // auto_notch slots (leandvb default 1)
+  bool cnr;
   bool resample;
   float resample_rej;
   int decim;
@@ -49,7 +51,7 @@ struct config {
   config()
       : verbose(false), debug(false), input_format(INPUT_U8), float_scale(1.0), Fs(2.4e6), Fm(2e6),
         constellation(cstln_lut<256>::QPSK), fec(LSDR_FEC12), Ftune(0), allow_drift(false), viterbi(false),
-        resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
+        anf(1), cnr(false), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
         buf_factor(4096), fd_info(-1), Finfo(5), out_symbols(false), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
 };
 
@@ -95,6 +97,27 @@ static int run(config &cfg) {
       new scaler<float, cf32, cf32>(&sch, cfg.float_scale, *p_dev, *p_rawiq);
       p_preprocessed = p_rawiq;
     }
+  }
+
+  // NOTCH FILTER (leandvb.cc:294-306).  A fused scaler cannot sit behind the notch: materialise it first.
+  if (cfg.anf) {
+    if (fuse_scale) {
+      pipebuf<cf32> *p_rawiq = new pipebuf<cf32>(&sch, "rawiq", BUF_BASEBAND, ctx);
+      new scaler<float, cf32, cf32>(&sch, cfg.float_scale, *p_preprocessed, *p_rawiq);
+      p_preprocessed = p_rawiq;
+      fuse_scale = 0;
+    }
+    pipebuf<cf32> *p_autonotched = new pipebuf<cf32>(&sch, "autonotched", BUF_BASEBAND, ctx);
+    new auto_notch<f32>(&sch, *p_preprocessed, *p_autonotched, cfg.anf, 0);
+    p_preprocessed = p_autonotched;
+  } else if (cfg.verbose) fprintf(stderr, "ANF is disabled (requires a clean signal).\n");
+
+  // CNR ESTIMATION (leandvb.cc:320-329)
+  pipebuf<f32> p_cnr(&sch, "cnr", BUF_SLOW);
+  cnr_fft<f32> *r_cnr = NULL;
+  if (cfg.cnr) {
+    r_cnr = new cnr_fft<f32>(&sch, *p_preprocessed, p_cnr, cfg.Fm / cfg.Fs);
+    r_cnr->decimation = decimation(cfg.Fs, cfg.Finfo);
   }
 
   // FILTERING (leandvb.cc:353-384)
@@ -160,6 +183,8 @@ static int run(config &cfg) {
     demod.tile_warmup = cfg.tile_warmup;
   }
 
+  if (r_cnr) { r_cnr->freq_tap = &demod.freq_tap; r_cnr->tap_multiplier = 1.0 / decim; }   // leandvb.cc:512-515
+
   // TRACKING FILTERS (leandvb.cc:506-510): the receiver→filter feedback edge stays on the host.
   if (r_resample) {
     r_resample->freq_tap = &demod.freq_tap;
@@ -208,6 +233,7 @@ static int run(config &cfg) {
     new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info);
     new file_printer<f32>(&sch, "SS %f\n", p_ss, cfg.fd_info);
     new file_printer<f32>(&sch, "MER %.1f\n", p_mer, cfg.fd_info);
+    if (cfg.cnr) new file_printer<f32>(&sch, "CNR %.1f\n", p_cnr, cfg.fd_info);
     new file_printer<int>(&sch, "LOCK %d\n", p_lock, cfg.fd_info);
     new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, 10);
     new file_printer<f32>(&sch, "VBER %.6f\n", p_vber, cfg.fd_info);
@@ -231,6 +257,7 @@ static void usage(const char *name, FILE *f, int c) {
           "  -f HZ, --sr HZ         sample rate, symbol rate\n"
           "  --const STRING         QPSK (default), BPSK, 8PSK, 16APSK, 32APSK\n"
           "  --cr STRING            1/2 (default), 2/3, 3/4, 5/6, 7/8 (APSK radii)\n"
+          "  --anf N, --cnr         auto-notch slots (default 1, 0 disables), CNR estimator\n"
           "  --tune HZ, --drift     receiver bias, unlimited drift\n"
           "  --resample, --resample-rej FLOAT, --decim N, --roll-off FLOAT\n"
           "  --sampler nearest|linear|rrc, --rrc-steps N, --rrc-rej FLOAT\n"
@@ -268,6 +295,8 @@ int main(int argc, const char *argv[]) {
     else if (!strcmp(a, "--buf-factor")) cfg.buf_factor = atol(need());
     else if (!strcmp(a, "--fd-info")) cfg.fd_info = atoi(need());
     else if (!strcmp(a, "--device")) cfg.device = atoi(need());
+    else if (!strcmp(a, "--anf")) cfg.anf = atoi(need());
+    else if (!strcmp(a, "--cnr")) cfg.cnr = true;
     else if (!strcmp(a, "--tiled")) cfg.tiled = true;
     else if (!strcmp(a, "--out-symbols")) cfg.out_symbols = true;
     else if (!strcmp(a, "--tile-len")) cfg.tile_len = atoi(need());

@@ -80,6 +80,68 @@ struct cstln_lut {
   result *lut;
 };
 
+// auto_notch<f32> (sdr.h:46-154): same constructor and public tunables (decimation, k).
+template <typename T>
+struct auto_notch;
+
+template <>
+struct auto_notch<f32> : runnable {
+  int decimation;
+  float k;
+  auto_notch(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o, int nslots, f32 agc_rms_setpoint)
+      : runnable(sch, "auto_notch"), decimation(1024 * 4096), k(0.002),
+        ctx(pipe_ctx(i.dev, o.dev, "auto_notch: pipebufs must be device pipebufs of one ctx")), in(i), out(o, 4096), h(NULL) {
+    lsdr_check(lsdr_auto_notch_create(ctx, nslots, agc_rms_setpoint, &h), name);
+  }
+  void run() {
+    lsdr_check(lsdr_auto_notch_set(h, decimation, k), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_auto_notch_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<cf32> in;
+  pipewriter<cf32> out;
+  lsdr_auto_notch *h;
+};
+
+// cnr_fft<f32> (sdr.h:1273-1345): device input pipe, host float output pipe.
+template <typename T>
+struct cnr_fft;
+
+template <>
+struct cnr_fft<f32> : runnable {
+  float bandwidth;
+  float *freq_tap, tap_multiplier;
+  int decimation;
+  float kavg;
+  cnr_fft(scheduler *sch, pipebuf<cf32> &i, pipebuf<float> &o, float bw, int nfft = 4096)
+      : runnable(sch, "cnr_fft"), bandwidth(bw), freq_tap(NULL), tap_multiplier(1), decimation(1048576), kavg(0.1),
+        ctx(i.dev), in(i), out(o), h(NULL) {
+    if (!ctx || o.dev) fail("cnr_fft: needs a device input pipebuf and a host output pipebuf");
+    lsdr_check(lsdr_cnr_fft_create(ctx, bw, nfft, &h), name);
+  }
+  void run() {
+    lsdr_check(lsdr_cnr_fft_set(h, decimation, kavg), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_cnr_fft_run(h, freq_tap ? *freq_tap : 0.f, tap_multiplier, (const lsdr_cf32 *)in.rd(), in.readable(),
+                                out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<cf32> in;
+  pipewriter<float> out;
+  lsdr_cnr_fft *h;
+};
+
 // Samplers: descriptors consumed by cstln_receiver (the interpolation itself runs on the GPU).
 template <typename T>
 struct sampler_interface {
