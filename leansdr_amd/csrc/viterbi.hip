@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void k_viterbi(vit_args a) {
   else { cost = 0; path = 0; }
 
   for (long long q = -(long long)job.warm; q < (long long)job.n_chunks; ++q) {
-    const unsigned long long c = q < 0 ? job.first_chunk - (unsigned long long)(-q) : job.first_chunk + (unsigned long long)q * job.chunk_step;
+    const unsigned long long c = (unsigned long long)((long long)job.first_chunk + q * (long long)job.chunk_step);
     const bool emitting = q >= 0;
     if (q == 0) {   // (metrics are normalised at every chunk boundary)
       a.begin_states[blockIdx.x].cost[lane] = cost;
@@ -213,7 +213,8 @@ struct lsdr_viterbi {
   vit_state *d_states;
   // scratch
   vit_job *d_jobs; vit_state *d_begin, *d_end, *d_first, *d_chunk; int *d_totals, *d_bad;
-  size_t jobs_cap, totals_cap, chunk_cap;
+  vit_state *d_fix;                   // explicit start states of fix-up jobs
+  size_t jobs_cap, totals_cap, chunk_cap, fix_cap;
   unsigned last_tiles, last_bad;
 };
 
@@ -239,9 +240,14 @@ static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
 }
 
 static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
-                      unsigned stride, bool chunk_states, int phase0) {
+                      unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr) {
   lsdr_ctx *c = v->ctx;
   const size_t nj = jobs.size();
+  if (start_states && v->fix_cap < start_states->size()) {
+    (void)hipFree(v->d_fix);
+    LSDR_HIP(hipMalloc((void **)&v->d_fix, start_states->size() * sizeof(vit_state)));
+    v->fix_cap = start_states->size();
+  }
   if (v->jobs_cap < nj) {
     (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_first); (void)hipFree(v->d_bad);
     LSDR_HIP(hipMalloc((void **)&v->d_jobs, nj * sizeof(vit_job)));
@@ -263,12 +269,14 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   }
   LSDR_HIP(hipMemcpyAsync(v->d_jobs, jobs.data(), nj * sizeof(vit_job), hipMemcpyHostToDevice, c->stream));
   LSDR_HIP(hipMemcpyAsync(v->d_states, v->states.data(), v->nsyncs * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
+  if (start_states)
+    LSDR_HIP(hipMemcpyAsync(v->d_fix, start_states->data(), start_states->size() * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
   vit_args a;
   a.in = in; a.out = out; a.T = v->d_T; a.C = v->C;
   a.bits_per_symbol = v->bits_per_symbol; a.nshifts = v->nshifts;
   a.resync_phase0 = phase0; a.resync_period = v->resync_period;
   a.maps = v->d_maps; a.shifts = v->d_shifts;
-  a.jobs = v->d_jobs; a.states_in = v->d_states;
+  a.jobs = v->d_jobs; a.states_in = start_states ? v->d_fix : v->d_states;
   a.begin_states = v->d_begin; a.end_states = v->d_end; a.first_chunk_states = v->d_first;
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
@@ -356,6 +364,7 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
   for (auto &s : v->states) memset(&s, 0, sizeof(s));
   LSDR_HIP(hipMalloc((void **)&v->d_states, v->nsyncs * sizeof(vit_state)));
   v->d_jobs = nullptr; v->d_begin = v->d_end = v->d_first = v->d_chunk = nullptr; v->d_totals = nullptr; v->d_bad = nullptr;
+  v->d_fix = nullptr; v->fix_cap = 0;
   v->jobs_cap = v->totals_cap = v->chunk_cap = 0;
   v->last_tiles = v->last_bad = 0;
   *out = v;
@@ -367,7 +376,7 @@ void lsdr_viterbi_destroy(lsdr_viterbi *v) {
   (void)hipStreamSynchronize(v->ctx->stream);
   (void)hipFree(v->d_T); (void)hipFree(v->d_maps); (void)hipFree(v->d_shifts); (void)hipFree(v->d_states);
   (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_first);
-  (void)hipFree(v->d_chunk); (void)hipFree(v->d_totals); (void)hipFree(v->d_bad);
+  (void)hipFree(v->d_chunk); (void)hipFree(v->d_totals); (void)hipFree(v->d_bad); (void)hipFree(v->d_fix);
   delete v;
 }
 
@@ -481,34 +490,106 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   int new_sync = cur;
   std::vector<std::vector<vit_state> > other_states(v->nsyncs);
   std::vector<std::vector<int> > other_totals(v->nsyncs);
+  std::vector<vit_state> other_end(v->nsyncs);
+  std::vector<int> other_ok(v->nsyncs, 1);
   if (!rs.empty() && v->nsyncs > 1) {
-    // one job per alignment walks its resync chunks in order (stride P), recording the decoder state and
-    // the quality total after every one of them
-    std::vector<vit_job> oj;
-    std::vector<int> which;
-    for (int s = 0; s < v->nsyncs; ++s) {
-      if (s == cur) continue;
-      vit_job j;
-      j.first_chunk = rs[0]; j.n_chunks = (unsigned)rs.size(); j.warm = 0; j.sync = s; j.from_state = s; j.emit = 0;
-      j.chunk_step = (unsigned)P;
-      oj.push_back(j); which.push_back(s);
-    }
-    rc = vit_launch(v, in, out, oj, (unsigned)rs.size(), true, phase0);
-    if (rc) return rc;
-    {
-      std::vector<vit_state> cst(oj.size() * rs.size());
-      std::vector<int> tot(oj.size() * rs.size());
-      LSDR_HIP(hipMemcpyAsync(cst.data(), v->d_chunk, cst.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+    // The other alignments decode only the resync chunks (stride P), each from its own carried state.  Their
+    // "virtual stream" is tiled and verified exactly like the main one; a decoder whose seams do not verify
+    // (wrong alignments see noise-like input, survivors may merge slowly) is redone sequentially.
+    const unsigned TLo = 4, Wo = (unsigned)kWarm;
+    const unsigned nrs = (unsigned)rs.size();
+    auto run_others = [&](bool sequential, std::vector<int> only) -> int {
+      std::vector<vit_job> oj;
+      std::vector<int> which, tile_first;   // tile_first: index into rs of the tile's first chunk
+      for (int s : only) {
+        if (sequential) {
+          vit_job j;
+          j.first_chunk = rs[0]; j.n_chunks = nrs; j.warm = 0; j.sync = s; j.from_state = s; j.emit = 0; j.chunk_step = (unsigned)P;
+          oj.push_back(j); which.push_back(s); tile_first.push_back(0);
+        } else {
+          unsigned r0 = 0;
+          while (r0 < nrs) {
+            unsigned r1 = r0 + TLo;
+            if (r0 == 0 && r1 < Wo + TLo) r1 = Wo + TLo;   // tile 0 is long enough for tile 1 to warm up fully
+            if (r1 > nrs) r1 = nrs;
+            vit_job j;
+            j.first_chunk = rs[r0]; j.n_chunks = r1 - r0; j.warm = r0 == 0 ? 0u : Wo; j.sync = s;
+            j.from_state = r0 == 0 ? s : -1; j.emit = 0; j.chunk_step = (unsigned)P;
+            oj.push_back(j); which.push_back(s); tile_first.push_back((int)r0);
+            r0 = r1;
+          }
+        }
+      }
+      unsigned ostride = 1;
+      for (auto &j : oj) if (j.n_chunks > ostride) ostride = j.n_chunks;
+      int rc2 = vit_launch(v, in, out, oj, ostride, sequential, phase0);
+      if (rc2) return rc2;
+      std::vector<int> tot(oj.size() * ostride);
+      std::vector<vit_state> hb(oj.size()), he(oj.size()), cst;
       LSDR_HIP(hipMemcpyAsync(tot.data(), v->d_totals, tot.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipMemcpyAsync(hb.data(), v->d_begin, oj.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipMemcpyAsync(he.data(), v->d_end, oj.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+      if (sequential) {
+        cst.resize(oj.size() * ostride);
+        LSDR_HIP(hipMemcpyAsync(cst.data(), v->d_chunk, cst.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+      }
       LSDR_HIP(hipStreamSynchronize(c->stream));
       for (size_t k = 0; k < oj.size(); ++k) {
-        other_states[which[k]].assign(cst.begin() + k * rs.size(), cst.begin() + (k + 1) * rs.size());
-        other_totals[which[k]].assign(tot.begin() + k * rs.size(), tot.begin() + (k + 1) * rs.size());
+        const int s = which[k];
+        if (tile_first[k] == 0) { other_totals[s].assign(nrs, 0); other_states[s].clear(); other_ok[s] = 1; }
+        for (unsigned q = 0; q < oj[k].n_chunks; ++q) other_totals[s][tile_first[k] + q] = tot[k * ostride + q];
+        if (sequential) other_states[s].assign(cst.begin() + k * ostride, cst.begin() + k * ostride + nrs);
       }
+      if (!sequential) {
+        // fix-up rounds: a tile whose speculative start state differs from its predecessor's true end state is
+        // re-decoded from that end state; a changed end state propagates to the next seam in the next round.
+        std::vector<vit_state> start_used = hb;
+        for (int round = 0;; ++round) {
+          std::vector<size_t> bad;
+          for (size_t k = 0; k < oj.size(); ++k)
+            if (tile_first[k] != 0 && memcmp(&start_used[k], &he[k - 1], sizeof(vit_state)) != 0) bad.push_back(k);
+          if (bad.empty()) break;
+          v->last_bad += (unsigned)bad.size();
+          if (round >= 6) { for (size_t k : bad) other_ok[which[k]] = 0; break; }   // pathological: sequential fallback
+          std::vector<vit_job> fj;
+          std::vector<vit_state> starts;
+          unsigned fstride = 1;
+          for (size_t k : bad) {
+            vit_job j = oj[k];
+            j.warm = 0; j.from_state = (int)starts.size();
+            starts.push_back(he[k - 1]);
+            fj.push_back(j);
+            if (j.n_chunks > fstride) fstride = j.n_chunks;
+          }
+          rc2 = vit_launch(v, in, out, fj, fstride, false, phase0, &starts);
+          if (rc2) return rc2;
+          std::vector<int> ftot(fj.size() * fstride);
+          std::vector<vit_state> fe(fj.size());
+          LSDR_HIP(hipMemcpyAsync(ftot.data(), v->d_totals, ftot.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+          LSDR_HIP(hipMemcpyAsync(fe.data(), v->d_end, fj.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+          LSDR_HIP(hipStreamSynchronize(c->stream));
+          for (size_t i = 0; i < bad.size(); ++i) {
+            const size_t k = bad[i];
+            start_used[k] = starts[i];
+            he[k] = fe[i];
+            for (unsigned q = 0; q < oj[k].n_chunks; ++q) other_totals[which[k]][tile_first[k] + q] = ftot[i * fstride + q];
+          }
+        }
+      }
+      for (size_t k = 0; k < oj.size(); ++k) other_end[which[k]] = he[k];
+      return LSDR_OK;
+    };
+    std::vector<int> all_others;
+    for (int s = 0; s < v->nsyncs; ++s) if (s != cur) all_others.push_back(s);
+    rc = run_others(false, all_others);
+    if (rc) return rc;
+    {
+      std::vector<int> redo;
+      for (int s : all_others) if (!other_ok[s]) redo.push_back(s);
+      if (!redo.empty()) { rc = run_others(true, redo); if (rc) return rc; }
     }
     std::vector<vit_state> st = v->states;
     for (size_t r = 0; r < rs.size(); ++r) {
-      for (int s = 0; s < v->nsyncs; ++s) if (s != cur) st[s] = other_states[s][r];
       // alignment decision after this resync chunk (dvb.h:1401-1410): s ascending from best = current, strict '>'
       size_t tj = 0;
       for (size_t t = 0; t < n_main; ++t) if (jobs[t].first_chunk <= rs[r] && rs[r] < jobs[t].first_chunk + jobs[t].n_chunks) tj = t;
@@ -522,7 +603,14 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
         // switch: everything after this chunk must be decoded with the new alignment → stop here
         used_chunks = rs[r] + 1;
         new_sync = best;
-        // carried states: other alignments as of this chunk; the old current one as of the end of this chunk
+        // carried states: other alignments as of this chunk (sequential re-run records them); the old current one
+        // as of the end of this chunk
+        {
+          std::vector<int> need;
+          for (int s2 : all_others) if (other_states[s2].size() != nrs) need.push_back(s2);
+          if (!need.empty()) { rc = run_others(true, need); if (rc) return rc; }
+          for (int s2 : all_others) st[s2] = other_states[s2][r];
+        }
         vit_state old_cur;
         if (rs[r] == jobs[tj].first_chunk) old_cur = main_first[tj];
         else {   // resync chunk inside tile 0 (its first chunk is not a resync chunk): recompute sequentially
@@ -540,7 +628,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       }
     }
     if (new_sync == cur) {
-      for (int s = 0; s < v->nsyncs; ++s) if (s != cur) v->states[s] = st[s];
+      for (int s = 0; s < v->nsyncs; ++s) if (s != cur) v->states[s] = other_end[s];
       v->states[cur] = main_end;
     }
   } else {

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""tools/chain_bench.py — end-to-end leandvb_amd (host framework + all GPU blocks) on a synthetic DVB-S capture.
+Writes the capture to /tmp, runs the app (optionally under rocprofv3), reports MS/s and checks the TS payload."""
+import os, subprocess, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from leansdr_amd import synth_dvbs
+npk = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
+flags = sys.argv[2:]
+path = f"/tmp/cap_{npk}.u8"
+if not os.path.exists(path):
+    chunks = []
+    # build in pieces of 1000 packets to bound memory; continuity across pieces is not needed for a throughput run
+    iq, ts = synth_dvbs.capture_u8(n_packets=npk, seed=7)
+    iq.tofile(path)
+n = os.path.getsize(path) // 2
+app = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
+cmd = [app, "--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"] + flags
+t0 = time.perf_counter()
+with open(path, "rb") as f:
+    p = subprocess.run(cmd, stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+dt = time.perf_counter() - t0
+ts = np.frombuffer(p.stdout, np.uint8).reshape(-1, 188)
+cnt = ts[:, 1].astype(int) * 65536 + ts[:, 2].astype(int) * 256 + ts[:, 3] if len(ts) else np.array([])
+print(f"{' '.join(flags) or '(default)'}: {n} samples in {dt:.3f} s = {n/dt/1e6:.1f} MS/s wall (incl. process start, file read, H2D/D2H); "
+      f"{len(ts)} TS packets, {int((np.diff(cnt)==1).sum()) if len(cnt)>1 else 0} consecutive; rc={p.returncode} {p.stderr.decode()[-200:]}")
