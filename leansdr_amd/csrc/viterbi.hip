@@ -216,6 +216,7 @@ struct lsdr_viterbi {
   vit_state *d_fix;                   // explicit start states of fix-up jobs
   size_t jobs_cap, totals_cap, chunk_cap, fix_cap;
   unsigned last_tiles, last_bad;
+  size_t budget_chunks;               // chunks attempted per call: shrinks after an alignment switch, regrows
 };
 
 static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
@@ -367,6 +368,7 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
   v->d_fix = nullptr; v->fix_cap = 0;
   v->jobs_cap = v->totals_cap = v->chunk_cap = 0;
   v->last_tiles = v->last_bad = 0;
+  v->budget_chunks = (size_t)1 << 40;
   *out = v;
   return LSDR_OK;
 }
@@ -401,6 +403,10 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   if (chunks > cap_out / bytes_per_chunk) chunks = cap_out / bytes_per_chunk;
   if (!chunks) return LSDR_OK;
   LSDR_ARG(in && out);
+  // Everything decoded after an alignment switch is thrown away (the new alignment has to redo it), so while the
+  // decoder keeps switching (no lock) a call only looks one resync period ahead; the look-ahead doubles again
+  // with every switch-free call.  The output does not depend on how the stream is cut into calls.
+  if (chunks > v->budget_chunks) chunks = v->budget_chunks;
   lsdr_ctx *c = v->ctx;
   LSDR_HIP(hipSetDevice(c->device));
 
@@ -634,6 +640,8 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   } else {
     v->states[cur] = main_end;
   }
+  if (new_sync != v->current_sync) v->budget_chunks = (size_t)v->resync_period;
+  else if (v->budget_chunks < ((size_t)1 << 40)) v->budget_chunks *= 2;
   v->current_sync = new_sync;
   v->resync_phase = (int)(((unsigned long long)phase0 + used_chunks) % (unsigned)P);
   *consumed = used_chunks * sym_per_chunk;
