@@ -130,6 +130,16 @@ int lsdr_cnr_fft_set(lsdr_cnr_fft *c, int decimation, float kavg);         /* pu
 int lsdr_cnr_fft_run(lsdr_cnr_fft *c, float freq_tap, float tap_multiplier, const lsdr_cf32 *in, size_t n_in,
                      float *cnr_out_host, size_t cap_out, size_t *consumed, size_t *produced);
 
+/* spectrum<f32>, sdr.h:1347-1404 (nfft = 1024): consumes whole 1024-sample blocks; every `decimation` samples one
+ * block is fetched, FFT'd on the host (cfft_engine), averaged (kavg) and written as one row of 1024 dB values,
+ * fftshifted, to spectrum_out_host[cap_rows][1024].  Replaces spectrum::run / do_spectrum (sdr.h:1361-1396). */
+typedef struct lsdr_spectrum lsdr_spectrum;
+int lsdr_spectrum_create(lsdr_ctx *ctx, lsdr_spectrum **s);
+void lsdr_spectrum_destroy(lsdr_spectrum *s);
+int lsdr_spectrum_set(lsdr_spectrum *s, int decimation, float kavg);      /* public members, sdr.h:1358-1359 */
+int lsdr_spectrum_run(lsdr_spectrum *s, const lsdr_cf32 *in, size_t n_in, float *spectrum_out_host, size_t cap_rows,
+                      size_t *consumed, size_t *produced_rows);
+
 /* -------------------------------------------------------------- fir_filter
  * fir_filter<cf32,float>, dsp.h:219-285 (decimating FIR, real prototype taps
  * frequency-shifted to complex).  The optional input stage fuses the block in

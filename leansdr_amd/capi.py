@@ -102,6 +102,10 @@ _sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
 _sig("lsdr_cnr_fft_destroy", None, [vp])
 _sig("lsdr_cnr_fft_set", C.c_int, [vp, C.c_int, c_f])
 _sig("lsdr_cnr_fft_run", C.c_int, [vp, c_f, c_f, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_spectrum_create", C.c_int, [vp, C.POINTER(vp)])
+_sig("lsdr_spectrum_destroy", None, [vp])
+_sig("lsdr_spectrum_set", C.c_int, [vp, C.c_int, c_f])
+_sig("lsdr_spectrum_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_fir_filter_create", C.c_int, [vp, C.POINTER(FirCfg), C.POINTER(vp)])
 _sig("lsdr_fir_filter_destroy", None, [vp])
 _sig("lsdr_fir_filter_set_freq", C.c_int, [vp, c_f])
@@ -652,6 +656,31 @@ class AutoNotch:
         out = self.ctx.download(dout, np.complex64, prod)
         din.free(); dout.free()
         return out
+
+
+class Spectrum:
+    """spectrum<f32> (sdr.h:1347-1404)."""
+
+    def __init__(self, ctx, decimation=1048576, kavg=0.1):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_spectrum_create(ctx.h, C.byref(h)))
+        self.h = h
+        check(lib.lsdr_spectrum_set(h, decimation, kavg))
+
+    def close(self):
+        if self.h:
+            lib.lsdr_spectrum_destroy(self.h)
+            self.h = None
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.ctx.upload(x)
+        out = np.empty((len(x) // 1024 + 1, 1024), np.float32)
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_spectrum_run(self.h, din.ptr, len(x), _np(out), len(out), C.byref(cons), C.byref(prod)))
+        din.free()
+        return out[:prod.value].copy(), cons.value
 
 
 class CnrFft:

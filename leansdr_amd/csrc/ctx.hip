@@ -38,7 +38,14 @@ int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) {
   lsdr_ctx *c = new lsdr_ctx();
   c->device = device;
   c->own_stream = (hip_stream == nullptr);
-  if (c->own_stream) LSDR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (c->own_stream) {
+    const char *pe = getenv("LSDR_STREAM_PRIORITY");   // tuning hook: "high" → highest stream priority
+    if (pe && !strcmp(pe, "high")) {
+      int lo = 0, hi = 0;
+      LSDR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      LSDR_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    } else LSDR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
   else c->stream = (hipStream_t)hip_stream;
   LSDR_HIP(hipEventCreate(&c->ev0));
   LSDR_HIP(hipEventCreate(&c->ev1));

@@ -116,6 +116,60 @@ __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
   }
 }
 
+// fastlock (dvb.h:428-452 + readerrors, dvb.h:396-417): for every alignment, the number of refills whose bit b
+// decodes differently with the alternate inverse polynomial deconv2[b].  readerrors() has its own shift
+// register / counters per alignment (in2, n_in2, n_out2); like readbyte its refill schedule is data-independent,
+// so refill q of alignment s is a pure function of the input → threads own runs of kErrRun consecutive refills.
+constexpr int kErrRun = 32;
+struct deconv_err_args {
+  unsigned long long deconv[8], deconv2[8];
+  unsigned char lut[4][4];
+  int pp, pw;
+  const lsdr_softsymbol *in;
+  unsigned long long refills[4];
+  unsigned m0[4];
+  deconv_carry *carry[4];        // .in = in2 at call start
+  deconv_carry *carry_next[4];
+  unsigned long long *errors;    // [4], zeroed by the host
+};
+
+__device__ __forceinline__ unsigned long long deconv_err_window(const deconv_err_args &A, int s, unsigned long long in0,
+                                                                unsigned long long q) {
+  const unsigned long long nsym = A.m0[s] + q * (unsigned)(A.pw / 2);
+  unsigned long long w = 0;
+  const unsigned take = nsym < 32 ? (unsigned)nsym : 32u;
+  for (unsigned k = 0; k < take; ++k) w = (w << 2) | A.lut[s][A.in[nsym - take + k].symbol & 3];
+  if (take < 32) w |= in0 << (2 * take);
+  return w;
+}
+
+__global__ __launch_bounds__(256) void k_deconv_errors(deconv_err_args A) {
+  const int s = blockIdx.y;
+  const unsigned long long R = A.refills[s];
+  const unsigned long long in0 = A.carry[s]->in;
+  const unsigned long long q0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * kErrRun;
+  unsigned errs = 0;
+  if (q0 < R) {
+    unsigned long long w = deconv_err_window(A, s, in0, q0);
+    for (int r = 0; r < kErrRun && q0 + r < R; ++r) {
+      if (r) {
+        const unsigned long long nsym = A.m0[s] + (q0 + r) * (unsigned)(A.pw / 2);
+        for (int t = A.pw / 2; t > 0; --t) w = (w << 2) | A.lut[s][A.in[nsym - t].symbol & 3];
+      }
+      for (int b = 0; b < A.pp; ++b) errs += (unsigned)(par64(w & A.deconv2[b]) != par64(w & A.deconv[b]));
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) errs += __shfl_down(errs, d, 64);
+  if ((threadIdx.x & 63) == 0 && errs) atomicAdd(A.errors + s, (unsigned long long)errs);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    deconv_carry c;
+    c.in = R ? deconv_err_window(A, s, in0, R - 1) : in0;
+    c.out = 0;
+    *A.carry_next[s] = c;
+  }
+}
+
 // ======================================================================== mpeg_sync
 struct msync_state {    // mpeg_sync members, dvb.h:877-890
   int scan_syncs, want_syncs, fastlock, resync_period;
@@ -543,6 +597,12 @@ struct lsdr_deconv {
   int n_in[4], n_out[4];      // sync_t counters per alignment (dvb.h:297-306); data-independent → host side
   deconv_carry *d_carry[2];   // [ping-pong][4 alignments]: shift registers live on the device
   int cur[4];
+  // fastlock: readerrors() state per alignment (in2 on the device, counters here) and the error totals
+  int fastlock;
+  unsigned long long deconv2[8];
+  int n_in2[4], n_out2[4], cur2[4];
+  deconv_carry *d_carry2[2];
+  unsigned long long *d_errors;
 };
 
 struct lsdr_mpeg_sync {
@@ -605,7 +665,6 @@ extern "C" {
 // ------------------------------------------------------------------ deconvol_sync
 int lsdr_deconv_create(lsdr_ctx *c, int rate, int fastlock, lsdr_deconv **out) {
   LSDR_ARG(c && out);
-  if (fastlock) { lsdr_set_error("deconvol_sync: fastlock is not implemented on the device"); return LSDR_E_UNSUPPORTED; }
   unsigned pX, pY;
   switch (rate) {   // make_deconvol_sync_simple, dvb.h:480-513
     case LSDR_FEC12: pX = 0x1; pY = 0x1; break;
@@ -652,11 +711,35 @@ int lsdr_deconv_create(lsdr_ctx *c, int rate, int fastlock, lsdr_deconv **out) {
       d->luts[id][sym] = (unsigned char)((I << 1) | Q);
     }
   d->locked = 0; d->skip = 0;
-  for (int i = 0; i < 4; ++i) { d->n_in[i] = 0; d->n_out[i] = 0; d->cur[i] = 0; }
+  d->fastlock = fastlock ? 1 : 0;
+  for (int b = 0; b < H.pp; ++b) {   // alternate inverse polynomials of the reference (dvb.h:236-264)
+    static const unsigned long long alt[][2] = {
+        {0x3baULL, 0x38ccaULL},
+        {0xf29ULL, 0x3c569329ULL}, {0x3c552ULL, 0x1dee1cULL}, {0x7948ULL, 0x1e2b49948ULL}, {0x1deULL, 0x1e2a90ULL},
+        {0xf247ULL, 0xfd6383bULL}, {0xfd9eeULL, 0xfd91392ULL}, {0xf248d8ULL, 0xfd9eef18ULL},
+        {0xf5727fULL, 0x3d5c909758fULL}, {0x3d5c90aaULL, 0x0f5727f0229c90aaULL}, {0x3daa371cULL, 0x3d5f45630ecULL},
+        {0xf5727ff48ULL, 0xf57d28260348ULL}, {0xf57d28260ULL, 0xf5727ff48128260ULL},
+        {0xfbeac76c454fULL, 0xfb11d6ba045a8fULL}, {0xfb11d6baULL, 0xfbea3c7d930e16baULL},
+        {0xfb112d5038dcULL, 0xfb112d5038271cULL}, {0xfbea3c7d68ULL, 0xfbeac7975462a8ULL},
+        {0xfb112d50ULL, 0xfbea3c86793290ULL}, {0xfb112dabd2e0ULL, 0xfb112d50c3cd20ULL},
+        {0xfb11d640ULL, 0xfbea3c8679c980ULL}};
+    d->deconv2[b] = H.deconv[b];
+    for (size_t i = 0; i < sizeof(alt) / sizeof(alt[0]); ++i)
+      if (H.deconv[b] == alt[i][0]) d->deconv2[b] = alt[i][1];
+    if (fastlock && d->deconv2[b] == H.deconv[b]) {
+      delete d;
+      lsdr_set_error("deconvol_sync: Alt polynomial not provided");   // fail() of dvb.h:265
+      return LSDR_E_UNSUPPORTED;
+    }
+  }
+  for (int i = 0; i < 4; ++i) { d->n_in[i] = 0; d->n_out[i] = 0; d->cur[i] = 0; d->n_in2[i] = 0; d->n_out2[i] = 0; d->cur2[i] = 0; }
   for (int i = 0; i < 2; ++i) {
     LSDR_HIP(hipMalloc((void **)&d->d_carry[i], 4 * sizeof(deconv_carry)));
     LSDR_HIP(hipMemset(d->d_carry[i], 0, 4 * sizeof(deconv_carry)));
+    LSDR_HIP(hipMalloc((void **)&d->d_carry2[i], 4 * sizeof(deconv_carry)));
+    LSDR_HIP(hipMemset(d->d_carry2[i], 0, 4 * sizeof(deconv_carry)));
   }
+  LSDR_HIP(hipMalloc((void **)&d->d_errors, 4 * sizeof(unsigned long long)));
   *out = d;
   return LSDR_OK;
 }
@@ -665,6 +748,7 @@ void lsdr_deconv_destroy(lsdr_deconv *d) {
   if (!d) return;
   (void)hipStreamSynchronize(d->ctx->stream);
   (void)hipFree(d->d_carry[0]); (void)hipFree(d->d_carry[1]);
+  (void)hipFree(d->d_carry2[0]); (void)hipFree(d->d_carry2[1]); (void)hipFree(d->d_errors);
   delete d;
 }
 
@@ -690,6 +774,42 @@ int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint
   long long n = maxrd < (long long)cap_out ? maxrd : (long long)cap_out;
   if (n < 32) return LSDR_OK;   // also covers n == 0
   LSDR_ARG(in && out);
+  if (d->fastlock) {   // dvb.h:428-452
+    deconv_err_args A;
+    for (int b = 0; b < 8; ++b) { A.deconv[b] = b < H.pp ? H.deconv[b] : 0; A.deconv2[b] = b < H.pp ? d->deconv2[b] : 0; }
+    A.pp = H.pp; A.pw = H.pw;
+    A.in = in + pos;
+    A.errors = d->d_errors;
+    unsigned long long maxR = 0;
+    for (int s = 0; s < 4; ++s) {
+      for (int k = 0; k < 4; ++k) A.lut[s][k] = d->luts[s][k];
+      const long long need2 = 8 * n - d->n_out2[s];
+      const unsigned long long R2 = need2 > 0 ? (unsigned long long)((need2 + H.pp - 1) / H.pp) : 0;
+      A.refills[s] = R2;
+      A.m0[s] = d->n_in2[s] < 64 ? (unsigned)((64 - d->n_in2[s] + 1) / 2) : 0u;
+      A.carry[s] = d->d_carry2[d->cur2[s]] + s;
+      A.carry_next[s] = d->d_carry2[d->cur2[s] ^ 1] + s;
+      if (R2 > maxR) maxR = R2;
+    }
+    LSDR_HIP(hipMemsetAsync(d->d_errors, 0, 4 * sizeof(unsigned long long), d->ctx->stream));
+    const unsigned long long threads = (maxR + kErrRun - 1) / kErrRun;
+    hipLaunchKernelGGL(k_deconv_errors, dim3((unsigned)((threads + 255) / 256 ? (threads + 255) / 256 : 1), 4), dim3(256), 0,
+                       d->ctx->stream, A);
+    LSDR_HIP(hipGetLastError());
+    unsigned long long errors[4];
+    LSDR_HIP(hipMemcpyAsync(errors, d->d_errors, sizeof(errors), hipMemcpyDeviceToHost, d->ctx->stream));
+    LSDR_HIP(hipStreamSynchronize(d->ctx->stream));
+    unsigned long errors_best = 1ul << 30;
+    int best = 0;
+    for (int s = 0; s < 4; ++s) {
+      if (A.refills[s]) d->n_in2[s] = 64 - H.pw;
+      d->n_out2[s] = (int)(d->n_out2[s] + (long long)A.refills[s] * H.pp - 8 * n);
+      d->cur2[s] ^= 1;
+      if (errors[s] < errors_best) { errors_best = (unsigned long)errors[s]; best = s; }
+    }
+    if (best != d->locked) d->locked = best;
+    if (errors_best > (unsigned long)(n * 8 / 3)) d->skip = 1;   // deconvolution BER > 33 %: try the next sample alignment
+  }
   const int a = d->locked;
   const int n_in0 = d->n_in[a], n_out0 = d->n_out[a];
   long long need = 8 * n - n_out0;

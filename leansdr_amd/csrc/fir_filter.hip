@@ -91,6 +91,10 @@ __device__ __forceinline__ float2 finish_sample(float2 raw, float scale) {
 // Coefficients are read through the CONSTANT address space: they are never written
 // while a kernel runs, and this guarantees wave-uniform scalar (s_load) access even in
 // the persistent kernel, where stores to `out` precede later coefficient loads.
+// cache policy of the streaming sample loads (buffer_load aux bits on gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef LSDR_FIR_LOAD_AUX
+#define LSDR_FIR_LOAD_AUX 2
+#endif
 typedef float lsdr_v2f __attribute__((ext_vector_type(2)));
 typedef unsigned lsdr_v2u __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) lsdr_v2f *cptr2;
@@ -274,10 +278,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
       if (IN_FMT == LSDR_IN_CU8) {
-        unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, k * kThreads * ES, 0);
+        unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, k * kThreads * ES, LSDR_FIR_LOAD_AUX);
         v[k] = make_float2(__uint_as_float((unsigned)r), 0.f);
       } else {
-        lsdr_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, k * kThreads * ES, 0);
+        lsdr_v2u r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, k * kThreads * ES, LSDR_FIR_LOAD_AUX);
         v[k] = make_float2(__uint_as_float(r.x), __uint_as_float(r.y));
       }
     }

@@ -144,6 +144,13 @@ struct lsdr_auto_notch {
   unsigned last_tiles, last_bad;
 };
 
+struct lsdr_spectrum {
+  lsdr_ctx *ctx;
+  int decimation, phase;
+  float kavg;
+  std::vector<float> avgpower;   // empty until the first spectrum
+};
+
 struct lsdr_cnr_fft {
   lsdr_ctx *ctx;
   float bandwidth, kavg;
@@ -434,6 +441,63 @@ int lsdr_cnr_fft_run(lsdr_cnr_fft *f, float freq_tap, float tap_multiplier, cons
         const float c2 = c2plusn2 - n2;
         cnr_out[nout++] = (c2 > 0 && n2 > 0) ? 10 * logf(c2 / n2) / logf(10) : -50;
       }
+    }
+    pos += N;
+  }
+  *consumed = pos;
+  *produced = nout;
+  return LSDR_OK;
+}
+
+// ------------------------------------------------------------------ spectrum
+int lsdr_spectrum_create(lsdr_ctx *c, lsdr_spectrum **out) {
+  LSDR_ARG(c && out);
+  lsdr_spectrum *f = new lsdr_spectrum();
+  f->ctx = c; f->decimation = 1048576; f->kavg = (float)0.1; f->phase = 0;   // sdr.h:1353
+  *out = f;
+  return LSDR_OK;
+}
+void lsdr_spectrum_destroy(lsdr_spectrum *f) { delete f; }
+int lsdr_spectrum_set(lsdr_spectrum *f, int decimation, float kavg) {
+  LSDR_ARG(f && decimation >= 1);
+  f->decimation = decimation; f->kavg = kavg;
+  return LSDR_OK;
+}
+
+int lsdr_spectrum_run(lsdr_spectrum *f, const lsdr_cf32 *in, size_t n_in, float *rows_out, size_t cap_rows,
+                      size_t *consumed, size_t *produced) {
+  LSDR_ARG(f && consumed && produced);
+  *consumed = 0; *produced = 0;
+  const int N = 1024;
+  size_t pos = 0, nout = 0;
+  lsdr_ctx *c = f->ctx;
+  // while in.readable()>=fft.n && out.writable()>=1 (sdr.h:1362)
+  while (n_in - pos >= (size_t)N && nout < cap_rows) {
+    // blocks that only advance the phase are skipped arithmetically
+    long long until = ((long long)f->decimation - f->phase + N - 1) / N - 1;
+    if (until < 0) until = 0;
+    size_t avail = (n_in - pos) / N;
+    if ((size_t)until >= avail) { f->phase += (int)(avail * N); pos += avail * N; break; }
+    f->phase += (int)(until * N);
+    pos += (size_t)until * N;
+    f->phase += N;
+    if (f->phase >= f->decimation) {   // do_spectrum, sdr.h:1374-1396
+      f->phase -= f->decimation;
+      LSDR_ARG(in && rows_out);
+      std::vector<lsdr_cf32> data(N);
+      LSDR_HIP(hipMemcpyAsync(data.data(), in + pos, (size_t)N * sizeof(lsdr_cf32), hipMemcpyDeviceToHost, c->stream));
+      LSDR_HIP(hipStreamSynchronize(c->stream));
+      cfft_host(N, data.data(), true);
+      std::vector<float> power(N);
+      for (int i = 0; i < N; ++i) power[i] = (float)data[i].re * data[i].re + (float)data[i].im * data[i].im;
+      if (f->avgpower.empty()) f->avgpower = power;
+      for (int i = 0; i < N; ++i) f->avgpower[i] = f->avgpower[i] * (1 - f->kavg) + power[i] * f->kavg;
+      float *row = rows_out + nout * N;
+      for (int i = 0; i < N / 2; ++i) {
+        row[i] = 10 * log10f(f->avgpower[N / 2 + i]);
+        row[N / 2 + i] = 10 * log10f(f->avgpower[i]);
+      }
+      ++nout;
     }
     pos += N;
   }

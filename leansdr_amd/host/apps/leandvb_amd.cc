@@ -35,6 +35,8 @@ struct config {
   bool viterbi;
   int anf;            // auto_notch slots (leandvb default 1)
   bool cnr;
+  bool fastlock;
+  int fd_spectrum;
   bool resample;
   float resample_rej;
   int decim;
@@ -51,7 +53,7 @@ struct config {
   config()
       : verbose(false), debug(false), input_format(INPUT_U8), float_scale(1.0), Fs(2.4e6), Fm(2e6),
         constellation(cstln_lut<256>::QPSK), fec(LSDR_FEC12), Ftune(0), allow_drift(false), viterbi(false),
-        anf(1), cnr(false), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
+        anf(1), cnr(false), fastlock(false), fd_spectrum(-1), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
         buf_factor(4096), fd_info(-1), Finfo(5), out_symbols(false), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
 };
 
@@ -118,6 +120,15 @@ static int run(config &cfg) {
   if (cfg.cnr) {
     r_cnr = new cnr_fft<f32>(&sch, *p_preprocessed, p_cnr, cfg.Fm / cfg.Fs);
     r_cnr->decimation = decimation(cfg.Fs, cfg.Finfo);
+  }
+
+  // SPECTRUM (leandvb.cc:331-343)
+  pipebuf<f32[1024]> *p_spectrum = NULL;
+  if (cfg.fd_spectrum >= 0) {
+    p_spectrum = new pipebuf<f32[1024]>(&sch, "spectrum", BUF_SLOW);
+    spectrum<f32> *r_spectrum = new spectrum<f32>(&sch, *p_preprocessed, *p_spectrum);
+    r_spectrum->decimation = decimation(cfg.Fs, 1);  // 1 Hz
+    r_spectrum->kavg = 0.5;
   }
 
   // FILTERING (leandvb.cc:353-384)
@@ -211,12 +222,15 @@ static int run(config &cfg) {
     deconvol_sync_simple *r_deconv = NULL;
     if (cfg.viterbi) {
       if (cfg.fec == FEC23 && (demod.cstln->nsymbols == 4 || demod.cstln->nsymbols == 64)) cfg.fec = FEC46;   // leandvb.cc:533-537
-      new viterbi_sync(&sch, p_symbols, *p_bytes, demod.cstln, (code_rate)cfg.fec);
+      viterbi_sync *r = new viterbi_sync(&sch, p_symbols, *p_bytes, demod.cstln, (code_rate)cfg.fec);
+      if (cfg.fastlock) r->resync_period = 1;   // leandvb.cc:540
     } else {
       r_deconv = make_deconvol_sync_simple(&sch, p_symbols, *p_bytes, (code_rate)cfg.fec);
+      r_deconv->fastlock = cfg.fastlock;        // leandvb.cc:543
     }
     pipebuf<u8> *p_mpegbytes = new pipebuf<u8>(&sch, "mpegbytes", BUF_MPEGBYTES, ctx);
-    new mpeg_sync<u8, 0>(&sch, *p_bytes, *p_mpegbytes, r_deconv, &p_lock, &p_locktime);
+    mpeg_sync<u8, 0> *r_sync = new mpeg_sync<u8, 0>(&sch, *p_bytes, *p_mpegbytes, r_deconv, &p_lock, &p_locktime);
+    r_sync->fastlock = cfg.fastlock;            // leandvb.cc:565
     pipebuf<rspacket<u8> > *p_rspackets = new pipebuf<rspacket<u8> >(&sch, "RS-enc packets", BUF_PACKETS, ctx);
     new deinterleaver<u8>(&sch, *p_mpegbytes, *p_rspackets);
     pipebuf<tspacket> *p_rtspackets = new pipebuf<tspacket>(&sch, "rand TS packets", BUF_PACKETS, ctx);
@@ -241,6 +255,9 @@ static int run(config &cfg) {
     // unread measurement pipes never block their writer (pipebuf with zero readers packs to empty)
   }
 
+  if (cfg.fd_spectrum >= 0)   // leandvb.cc:647-652
+    new file_vectorprinter<f32, 1024>(&sch, "SPECTRUM [", "%.3f", ",", "]\n", *p_spectrum, cfg.fd_spectrum);
+
   sch.run();
   sch.shutdown();
   if (cfg.debug) sch.dump();
@@ -258,6 +275,8 @@ static void usage(const char *name, FILE *f, int c) {
           "  --const STRING         QPSK (default), BPSK, 8PSK, 16APSK, 32APSK\n"
           "  --cr STRING            1/2 (default), 2/3, 3/4, 5/6, 7/8 (APSK radii)\n"
           "  --anf N, --cnr         auto-notch slots (default 1, 0 disables), CNR estimator\n"
+          "  --fastlock, --hq       synchronise more aggressively; --hq = --fastlock --viterbi --sampler rrc\n"
+          "  --fd-spectrum FD       SPECTRUM [..1024 dB values..] lines, one per second of signal\n"
           "  --tune HZ, --drift     receiver bias, unlimited drift\n"
           "  --resample, --resample-rej FLOAT, --decim N, --roll-off FLOAT\n"
           "  --sampler nearest|linear|rrc, --rrc-steps N, --rrc-rej FLOAT\n"
@@ -297,6 +316,9 @@ int main(int argc, const char *argv[]) {
     else if (!strcmp(a, "--device")) cfg.device = atoi(need());
     else if (!strcmp(a, "--anf")) cfg.anf = atoi(need());
     else if (!strcmp(a, "--cnr")) cfg.cnr = true;
+    else if (!strcmp(a, "--fastlock")) cfg.fastlock = true;
+    else if (!strcmp(a, "--hq")) { cfg.fastlock = true; cfg.viterbi = true; cfg.sampler = config::SAMP_RRC; }   // leandvb.cc:1154-1158
+    else if (!strcmp(a, "--fd-spectrum")) cfg.fd_spectrum = atoi(need());
     else if (!strcmp(a, "--tiled")) cfg.tiled = true;
     else if (!strcmp(a, "--out-symbols")) cfg.out_symbols = true;
     else if (!strcmp(a, "--tile-len")) cfg.tile_len = atoi(need());

@@ -102,6 +102,36 @@ struct file_printer : runnable {
   int phase;
 };
 
+// One text line per vector item: head, N formatted values joined by sep, tail (generic.h:191-222).
+template <typename T, int N>
+struct file_vectorprinter : runnable {
+  T scale;
+  file_vectorprinter(scheduler *sch, const char *head_, const char *format_, const char *sep_, const char *tail_,
+                     pipebuf<T[N]> &i, int fd)
+      : runnable(sch, i.name), scale(1), in(i), head(head_), format(format_), sep(sep_), tail(tail_) {
+    fout = fdopen(fd, "w");
+    if (!fout) fatal("fdopen");
+  }
+  void run() {
+    while (in.readable() >= 1) {
+      fprintf(fout, head, N);
+      T(*pin)[N] = in.rd();
+      for (int k = 0; k < N; ++k) {
+        if (k) fprintf(fout, "%s", sep);
+        fprintf(fout, format, (*pin)[k] * scale);
+      }
+      fprintf(fout, "%s", tail);
+      in.read(1);
+    }
+    fflush(fout);
+  }
+
+ private:
+  pipereader<T[N]> in;
+  const char *head, *format, *sep, *tail;
+  FILE *fout;
+};
+
 // Ratio of two accumulated integer streams, emitted once the denominator
 // reaches sample_size (generic.h:272-305) — VBER in leandvb.
 template <typename T>

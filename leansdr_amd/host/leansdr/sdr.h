@@ -142,6 +142,36 @@ struct cnr_fft<f32> : runnable {
   lsdr_cnr_fft *h;
 };
 
+// spectrum<f32> (sdr.h:1347-1404): device input pipe, host output pipe of float[1024] rows.
+template <typename T>
+struct spectrum;
+
+template <>
+struct spectrum<f32> : runnable {
+  static const int nfft = 1024;
+  int decimation;
+  float kavg;
+  spectrum(scheduler *sch, pipebuf<cf32> &i, pipebuf<float[nfft]> &o)
+      : runnable(sch, "spectrum"), decimation(1048576), kavg(0.1), ctx(i.dev), in(i), out(o), h(NULL) {
+    if (!ctx || o.dev) fail("spectrum: needs a device input pipebuf and a host output pipebuf");
+    lsdr_check(lsdr_spectrum_create(ctx, &h), name);
+  }
+  void run() {
+    lsdr_check(lsdr_spectrum_set(h, decimation, kavg), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_spectrum_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (float *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<cf32> in;
+  pipewriter<float[nfft]> out;
+  lsdr_spectrum *h;
+};
+
 // Samplers: descriptors consumed by cstln_receiver (the interpolation itself runs on the GPU).
 template <typename T>
 struct sampler_interface {

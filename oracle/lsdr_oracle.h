@@ -96,6 +96,12 @@ void lo_cnr_fft_free(lo_cnr_fft *c);
 size_t lo_cnr_fft_run(lo_cnr_fft *c, float freq_tap, float tap_multiplier,
                       const lo_cf32 *in, size_t n, float *out, size_t cap);
 
+/* spectrum<f32>: sdr.h:1347-1404 (nfft = 1024) */
+typedef struct lo_spectrum lo_spectrum;
+lo_spectrum *lo_spectrum_new(int decimation, float kavg);
+void lo_spectrum_free(lo_spectrum *c);
+size_t lo_spectrum_run(lo_spectrum *c, const lo_cf32 *in, size_t n, float *out /*[cap][1024]*/, size_t cap);
+
 /* ---- cstln_receiver<f32>: sdr.h:697-938 ---------------------------------- */
 enum { LO_SAMP_NEAREST, LO_SAMP_LINEAR, LO_SAMP_FIR };
 typedef struct {

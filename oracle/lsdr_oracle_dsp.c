@@ -310,3 +310,47 @@ size_t lo_cnr_fft_run(lo_cnr_fft *c, float freq_tap, float tap_multiplier,
   free(data); free(power);
   return nout;
 }
+
+/* ---- spectrum<f32>, sdr.h:1347-1404 ---------------------------------------- */
+struct lo_spectrum {
+  float kavg;
+  int decimation, phase;
+  float *avgpower; /* NULL until the first spectrum */
+};
+lo_spectrum *lo_spectrum_new(int decimation, float kavg) {
+  lo_spectrum *c = (lo_spectrum *)calloc(1, sizeof(*c));
+  c->decimation = decimation; c->kavg = kavg; c->phase = 0; c->avgpower = NULL;
+  return c;
+}
+void lo_spectrum_free(lo_spectrum *c) { free(c->avgpower); free(c); }
+
+/* run(), sdr.h:1361-1370 + do_spectrum(), :1374-1396; out = cap rows of 1024 floats; returns rows written */
+size_t lo_spectrum_run(lo_spectrum *c, const lo_cf32 *in, size_t n, float *out, size_t cap) {
+  enum { N = 1024 };
+  size_t pos = 0, nout = 0;
+  lo_cf32 *data = (lo_cf32 *)malloc(sizeof(lo_cf32) * N);
+  float power[N];
+  while (n - pos >= (size_t)N && nout < cap) {
+    c->phase += N;
+    if (c->phase >= c->decimation) {
+      c->phase -= c->decimation;
+      memcpy(data, in + pos, sizeof(lo_cf32) * N);
+      lo_cfft(N, data, 1);
+      for (int i = 0; i < N; ++i) power[i] = (float)data[i].re * data[i].re + (float)data[i].im * data[i].im;
+      if (!c->avgpower) {
+        c->avgpower = (float *)malloc(sizeof(float) * N);
+        memcpy(c->avgpower, power, sizeof(float) * N);
+      }
+      for (int i = 0; i < N; ++i) c->avgpower[i] = c->avgpower[i] * (1 - c->kavg) + power[i] * c->kavg;
+      float *row = out + nout * N;
+      for (int i = 0; i < N / 2; ++i) {        /* dB + fftshift, sdr.h:1390-1393 */
+        row[i] = 10 * log10f(c->avgpower[N / 2 + i]);
+        row[N / 2 + i] = 10 * log10f(c->avgpower[i]);
+      }
+      ++nout;
+    }
+    pos += N;
+  }
+  free(data);
+  return nout;
+}

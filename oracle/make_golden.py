@@ -77,6 +77,13 @@ def fec_input(hard, err_permille):
     return sym
 
 
+def golden_spectrum(R, xn):
+    """spectrum<f32> (sdr.h:1347-1404) on the auto_notch input: rows for two (decimation, kavg) settings."""
+    np.savez_compressed(os.path.join(GOLD, "spectrum.npz"),
+                        d4096_k05=R.spectrum(xn, 4096, 0.5),            # leandvb's kavg (leandvb.cc:342)
+                        d3000_k01=R.spectrum(xn, 3000, 0.1))            # default kavg, decimation not a multiple of 1024
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     R = po.Ref()
@@ -190,6 +197,7 @@ def main():
     an["fft1024_fwd"] = R.cfft(xn[:1024], False)
     an["cnr"] = R.cnr_fft(xn, 0.2, 4096, 4096 * 2, 0.01, 0.5)
     np.savez_compressed(os.path.join(GOLD, "auto_notch.npz"), iq=iqn, scale=np.float32(1 / 64.0), **an)
+    golden_spectrum(R, xn)
 
     # ---- FEC tail ------------------------------------------------------------------------
     # Input: hard symbol decisions of a clean reference-TX stream (packed 2 bit/symbol) with a
@@ -251,4 +259,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--only-spectrum" in sys.argv:   # added after the first fixture set: reuses the committed auto_notch input
+        g = np.load(os.path.join(GOLD, "auto_notch.npz"))
+        R = po.Ref()
+        golden_spectrum(R, R.scaler(np.float32(g["scale"]), iq16_to_cf32(g["iq"])))
+    else:
+        main()

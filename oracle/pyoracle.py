@@ -121,6 +121,11 @@ class Oracle:
         L.lo_cnr_fft_free.argtypes = [C.c_void_p]
         L.lo_cnr_fft_run.restype = c_sz
         L.lo_cnr_fft_run.argtypes = [C.c_void_p, c_f, c_f, C.c_void_p, c_sz, C.c_void_p, c_sz]
+        L.lo_spectrum_new.restype = C.c_void_p
+        L.lo_spectrum_new.argtypes = [C.c_int, c_f]
+        L.lo_spectrum_free.argtypes = [C.c_void_p]
+        L.lo_spectrum_run.restype = c_sz
+        L.lo_spectrum_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p, c_sz]
         L.lo_rx_new.restype = C.c_void_p
         L.lo_rx_new.argtypes = [C.POINTER(RxParams)]
         L.lo_rx_free.argtypes = [C.c_void_p]
@@ -250,6 +255,14 @@ class Oracle:
         out = np.empty(len(x) // nfft + 1, np.float32)
         n = self.lib.lo_cnr_fft_run(h, freq_tap, tap_multiplier, _p(x), len(x), _p(out), len(out))
         self.lib.lo_cnr_fft_free(h)
+        return out[:n]
+
+    def spectrum(self, x, decimation=1048576, kavg=0.1):
+        x = cf32(x)
+        h = self.lib.lo_spectrum_new(decimation, kavg)
+        out = np.empty((len(x) // 1024 + 1, 1024), np.float32)
+        n = self.lib.lo_spectrum_run(h, _p(x), len(x), _p(out), len(out))
+        self.lib.lo_spectrum_free(h)
         return out[:n]
 
     def rx(self, params, x, state_in=None, chunks=None):
@@ -420,6 +433,8 @@ class Ref:
         L.ref_cfft.argtypes = [C.c_int, C.c_void_p, C.c_int]
         L.ref_cnr_fft.restype = C.c_long
         L.ref_cnr_fft.argtypes = [c_f, C.c_int, C.c_int, c_f, c_f, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        L.ref_spectrum.restype = C.c_long
+        L.ref_spectrum.argtypes = [C.c_int, c_f, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
         L.ref_cstln_receiver.restype = C.c_long
         L.ref_cstln_receiver.argtypes = [C.POINTER(RxParams), C.c_void_p, C.c_long, C.c_void_p,
                                          C.c_void_p, C.c_long, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -583,6 +598,12 @@ class Ref:
         x = cf32(x)
         out = np.empty(len(x) // nfft + 1, np.float32)
         n = self.lib.ref_cnr_fft(bandwidth, nfft, decimation, freq_tap, tap_multiplier, _p(x), len(x), _p(out), len(out))
+        return out[:n]
+
+    def spectrum(self, x, decimation=1048576, kavg=0.1):
+        x = cf32(x)
+        out = np.empty((len(x) // 1024 + 1, 1024), np.float32)
+        n = self.lib.ref_spectrum(decimation, kavg, _p(x), len(x), _p(out), len(out))
         return out[:n]
 
     def rx(self, params, x):

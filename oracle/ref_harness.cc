@@ -263,6 +263,20 @@ long ref_cnr_fft(float bandwidth, int nfft, int decimation, float freq_tap,
   return w.pos;
 }
 
+// sdr.h:1347-1404   spectrum<f32>
+long ref_spectrum(int decimation, float kavg, const float *in, long n, float *out, long cap_rows) {
+  scheduler sch;
+  pipebuf<cf32> p_in(&sch, "in", BUF_BASEBAND);
+  pipebuf<float[1024]> p_out(&sch, "out", 64);
+  buffer_reader<cf32> r(&sch, (cf32 *)in, n, p_in);
+  spectrum<f32> c(&sch, p_in, p_out);
+  c.decimation = decimation;
+  c.kavg = kavg;
+  buffer_writer<float[1024]> w(&sch, p_out, (float(*)[1024])out, cap_rows);
+  sch.run();
+  return w.pos;
+}
+
 // ---------------------------------------------------------------- cstln_receiver
 
 struct ref_rx_params {

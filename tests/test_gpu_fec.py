@@ -57,9 +57,43 @@ def test_deconvol_sync_rates_and_chunking_vs_oracle(capi, ctx, oracle, rate, pip
     assert bits_equal(got, out[:nout])
 
 
-def test_deconvol_fastlock_unsupported(capi, ctx):
-    with pytest.raises(capi.LsdrError):
-        capi.Deconv(ctx, capi.FEC12, fastlock=1)
+@pytest.mark.parametrize("tag,errp", CASES)
+def test_deconvol_fastlock_golden(capi, ctx, tag, errp):
+    """fastlock (dvb.h:428-452): per call, all four alignments are scored with the alternate polynomial and the
+    best one decodes; the reference's own output for the reference's call pattern."""
+    g = gold("fec.npz")
+    sym = fec_input(hard_symbols(), errp)
+    d = capi.Deconv(ctx, capi.FEC12, fastlock=1)
+    b = d.run_stream(sym)
+    d.close()
+    assert sha(b) == hexs(g[f"{tag}_deconv_fastlock_sha"])
+
+
+@pytest.mark.parametrize("rate", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("pipe,room,rot", [(4096, 8192, 0), (1000, 300, 1), (1 << 20, 1 << 20, 2), (3000, 8192, 3)])
+def test_deconvol_fastlock_vs_oracle(capi, ctx, oracle, rate, pipe, room, rot):
+    """Every punctured rate, several call patterns, input rotated so that each alignment has to be found."""
+    import ctypes as C
+    sym = fec_input(hard_symbols()[:60000], 40).copy()
+    relabel = {0: [0, 1, 2, 3], 1: [1, 3, 0, 2], 2: [3, 2, 1, 0], 3: [2, 0, 3, 1]}[rot]
+    sym["symbol"] = np.array(relabel, np.uint8)[sym["symbol"]]
+    sym = sym[rot:]
+    d = capi.Deconv(ctx, rate, fastlock=1)
+    got = d.run_stream(sym, pipe, room)
+    d.close()
+    h = oracle.lib.lo_deconv_new(rate, 1)
+    out = np.empty(len(sym) + 64, np.uint8)
+    pos = nout = 0
+    while True:
+        c = C.c_size_t()
+        avail = min(pipe, len(sym) - pos)
+        n = oracle.lib.lo_deconv_run(h, sym[pos:].ctypes.data, avail, out[nout:].ctypes.data, room, C.byref(c))
+        if not n and not c.value:
+            break
+        pos += c.value
+        nout += n
+    oracle.lib.lo_deconv_free(h)
+    assert nout > 1000 and bits_equal(got, out[:nout])
 
 
 @pytest.mark.parametrize("tag,errp", CASES)

@@ -79,3 +79,21 @@ def test_cnr_fft_golden(capi, ctx, oracle):
     assert bits_equal(out, g["cnr"]) and cons == len(x)
     with pytest.raises(capi.LsdrError):
         capi.CnrFft(ctx, 0.3)                  # "CNR estimator requires Fsampling > 4x Fsignal"
+
+
+@pytest.mark.gpu
+def test_spectrum_golden(capi, ctx, oracle):
+    g = gold("auto_notch.npz")
+    s = gold("spectrum.npz")
+    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq"]))
+    for dec, k, key in [(4096, 0.5, "d4096_k05"), (3000, 0.1, "d3000_k01")]:
+        sp = capi.Spectrum(ctx, dec, k)
+        out, cons = sp.run(x)
+        sp.close()
+        assert bits_equal(out, s[key]) and cons == len(x)
+    # state carries across calls: two halves == one call
+    sp = capi.Spectrum(ctx, 3000, 0.1)
+    a, ca = sp.run(x[:10240])
+    b, cb = sp.run(x[ca:])
+    sp.close()
+    assert bits_equal(np.concatenate([a, b]), s["d3000_k01"])

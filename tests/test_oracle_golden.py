@@ -183,3 +183,13 @@ def test_auto_notch_fft_cnr(oracle):
     assert bits_equal(oracle.cfft(x[:4096], True), g["fft4096_rev"])
     assert bits_equal(oracle.cfft(x[:1024], False), g["fft1024_fwd"])
     assert bits_equal(oracle.cnr_fft(x, 0.2, 4096, 4096 * 2, 0.01, 0.5), g["cnr"])
+
+
+def test_spectrum(oracle):
+    """spectrum<f32> (sdr.h:1347-1404): dB rows, fftshifted, EMA across spectra."""
+    g = gold("auto_notch.npz")
+    s = gold("spectrum.npz")
+    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq"]))
+    assert bits_equal(oracle.spectrum(x, 4096, 0.5), s["d4096_k05"])
+    assert bits_equal(oracle.spectrum(x, 3000, 0.1), s["d3000_k01"])
+    assert s["d4096_k05"].shape == (8, 1024)

@@ -74,6 +74,8 @@ def test_fft_notch_cnr(oracle, ref, sig):
         b, bb = ref.auto_notch(x, ns, 4096 * 3, setpoint=sp)
         assert ba == [int(v) for v in bb] and bits_equal(a, b)
     assert bits_equal(oracle.cnr_fft(x, 0.2, 4096, 8192, 0.01, 0.5), ref.cnr_fft(x, 0.2, 4096, 8192, 0.01, 0.5))
+    for dec, k in [(2048, 0.5), (5000, 0.1), (1024, 0.9)]:
+        assert bits_equal(oracle.spectrum(x, dec, k), ref.spectrum(x, dec, k))
 
 
 def same_rx(a, b):

@@ -20,5 +20,15 @@ p = np.zeros(8, np.uint64)
 assert capi.lib.lsdr_rx_probe_read(C.c_void_p(p.ctypes.data)) == 0
 n = float(p[0])
 print("symbols probed", n, "stats", r.tiled_stats())
-for i, nm in [(1, "interp (samples + trig gathers + math)"), (2, "constellation LUT gather"), (3, "PLL + timing update")]:
-    print(f"  {nm:42s} {p[i]/n:8.1f} cycles/symbol")
+for i, nm in [(1, "interp (samples + trig + math)"), (2, "constellation LUT gather"), (3, "PLL + timing update"), (4, "between symbols (skip loop, emit, chunk end)"), (5, "probe overhead (per probe)")]:
+    print(f"  {nm:46s} {p[i]/n:8.1f} cycles/symbol")
+# the exact serial kernel, same probes
+capi.lib.lsdr_rx_probe_reset()
+ser = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=4.0)
+ser.set_state(acq.state())
+ser.run(x[:400000], meas=False)
+assert capi.lib.lsdr_rx_probe_read(C.c_void_p(p.ctypes.data)) == 0
+n = float(p[0])
+print("serial kernel: symbols probed", n)
+for i, nm in [(1, "interp (samples + trig + math)"), (2, "constellation LUT gather"), (3, "PLL + timing update"), (4, "between symbols (skip loop, emit, chunk end)"), (5, "probe overhead (per probe)")]:
+    print(f"  {nm:46s} {p[i]/n:8.1f} cycles/symbol")
