@@ -137,6 +137,8 @@ def main():
     ev_fir = [ctx.event(), ctx.event()]
     e0 = [ctx.event(), ctx.event()]
     e1 = [ctx.event(), ctx.event()]
+    ev_rx = [ctx_rx.event(), ctx_rx.event()]
+    ev_pool = []
     fir_ms = []
     nsym = [0]
 
@@ -154,6 +156,41 @@ def main():
                     fir_ms.append(ctx.event_elapsed_ms(e0[0], e1[0]))
                     nsym[0] += o["produced"]
                 consumed += cons
+            return consumed
+        if args.rx_mode == "tiled":
+            # Queued receiver runs (lsdr_rx_run_async): the host only enqueues.  Per step: fir_filter(k) on the fir
+            # stream (after the receiver has released that decimated buffer), cstln_receiver(k) on the rx stream
+            # (after fir_filter(k)); results are retired two steps later, so the GPU never waits for the host.
+            queued = []
+            while len(ev_pool) < 2 * k_steps:
+                ev_pool.append(ctx.event())
+            for k in range(k_steps):
+                i = k & 1
+                if k >= 2:
+                    ctx.wait_event(ev_rx[i])                 # dec[i] is free once receiver run k-2 has read it
+                ctx.event_record(ev_pool[2 * k])
+                cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)
+                ctx.event_record(ev_pool[2 * k + 1])
+                ctx.event_record(ev_fir[i])
+                consumed += cons
+                rx.ctx.wait_event(ev_fir[i])
+                rx.run_async(dec[i].ptr, prod, d_sym.ptr, n_out_max + 256)
+                rx.ctx.event_record(ev_rx[i])
+                queued.append(i)
+                if len(queued) > 2:
+                    j = queued.pop(0)
+                    nprod = rx.wait()
+                    if timed:
+                        nsym[0] += nprod
+            while queued:
+                queued.pop(0)
+                nprod = rx.wait()
+                if timed:
+                    nsym[0] += nprod
+            if timed:
+                ctx.sync()
+                for k in range(k_steps):   # HIP events around every fir_filter launch, on its own stream
+                    fir_ms.append(ctx.event_elapsed_ms(ev_pool[2 * k], ev_pool[2 * k + 1]))
             return consumed
         pending = None                      # (buffer index, produced) of the batch waiting for the receiver
         for k in range(k_steps + 1):

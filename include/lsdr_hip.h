@@ -224,6 +224,12 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
                 size_t *consumed, size_t *produced,
                 float *freq_out_host, float *ss_out_host, float *mer_out_host, size_t meas_cap, size_t *n_meas,
                 lsdr_cf32 *cstln_out_host, size_t cstln_cap, size_t *n_cstln);
+/* Queued variant of lsdr_rx_run for LSDR_RX_TILED (no measurement outputs): puts the run on the context's stream and
+ * returns at once with `consumed` (a pure function of the sizes); lsdr_rx_wait() retires the oldest queued run and
+ * yields its symbol count.  Up to 8 runs may be queued; the loop state is carried on the device from run to run, so
+ * the host never sits between two runs.  lsdr_rx_run / _set_state refuse to mix with outstanding queued runs. */
+int lsdr_rx_run_async(lsdr_rx *rx, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
+int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
 
 /* ================================================================== DVB-S FEC tail
  * Item layouts: bytes are u8; RS packets 204 B (rspacket<u8>), TS packets 188 B (tspacket). */

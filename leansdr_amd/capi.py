@@ -141,6 +141,8 @@ _sig("lsdr_derandomizer_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_derandomizer_pattern", None, [vp])
 _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
+_sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
+_sig("lsdr_rx_wait", C.c_int, [vp, psz])
 
 #: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [n for n in dir(lib) if n.startswith("lsdr_")]
@@ -395,6 +397,18 @@ class CstlnReceiver:
         v = [C.c_uint() for _ in range(4)]
         check(lib.lsdr_rx_tiled_stats(self.h, *[C.byref(x) for x in v]))
         return dict(zip(("tiles", "dup", "miss", "bad_seams"), [x.value for x in v]))
+
+    def run_async(self, in_ptr, n_in, out_ptr, cap_out):
+        """Queue one tiled run on the receiver's stream; returns the samples it will consume."""
+        cons = c_sz()
+        check(lib.lsdr_rx_run_async(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons)))
+        return cons.value
+
+    def wait(self):
+        """Retire the oldest queued run; returns its symbol count."""
+        prod = c_sz()
+        check(lib.lsdr_rx_wait(self.h, C.byref(prod)))
+        return prod.value
 
     def run_dev(self, in_ptr, n_in, out_ptr, cap_out, meas=True):
         cons, prod, nm, nc = c_sz(), c_sz(), c_sz(), c_sz()

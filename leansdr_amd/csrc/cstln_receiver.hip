@@ -572,87 +572,72 @@ __device__ __forceinline__ seam_step seam_eval(const rx_tile_info &prev, const r
   return r;
 }
 
-// (A) per-seam evaluation, fully parallel: step[j] = what tile j contributes.
-struct rx_seam_stepv { int add; uint8_t k, insert, drop, bad; };
-
-__global__ __launch_bounds__(256) void k_rx_seam_eval(const rx_tile_info *info, rx_seam_stepv *step, unsigned n_tiles,
-                                                      float omega, int R, float quad) {
-  const unsigned j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n_tiles) return;
-  const rx_tile_info cur = info[j];
-  rx_seam_stepv v; v.add = (int)cur.count; v.k = 0; v.insert = 0; v.drop = 0; v.bad = 0;
-  if (j > 0) {
-    const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad);
-    v.add += (int)st.insert - (int)st.drop;
-    v.k = (uint8_t)st.k; v.insert = (uint8_t)st.insert; v.drop = (uint8_t)st.drop; v.bad = (uint8_t)st.bad;
-  }
-  step[j] = v;
-}
-
-// (B) one workgroup: exclusive scan of (add, k mod R) over the tiles in LDS-staged segments of
-// 8192 (coalesced loads, 8 consecutive tiles per thread), writes the per-tile fix-ups.
-__global__ __launch_bounds__(1024) void k_rx_seam_scan(const rx_seam_stepv *step, rx_tile_fix *fix, unsigned n_tiles, int R,
-                                                       rx_seam_result *res) {
-  constexpr unsigned SEG = 8192, PER = 8;
+// Seam kernel (one workgroup of 1024): evaluates every seam and scans (symbol count, quadrant) over the
+// tiles in rows of 1024 — tile j is handled by thread j % 1024 in row j / 1024, so every load and store is
+// coalesced; a row costs one wave scan, one 16-entry cross-wave pass and two barriers.  The last thread
+// leaves the totals in *res and rotates the carried carrier phase back into the frame of tile 0 so that the
+// next run continues with the same symbol labelling (all on the device: runs can be queued back to back).
+__global__ __launch_bounds__(1024) void k_rx_seam(const rx_tile_info *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                                  int R, float quad, rx_state_dev *state, rx_seam_result *res) {
   const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
-  __shared__ rx_seam_stepv s_step[SEG];
   __shared__ unsigned long long s_cnt[16];
-  __shared__ unsigned s_rot[16], s_dup[16], s_miss[16], s_bad[16];
+  __shared__ unsigned s_rot[16];
   __shared__ unsigned long long s_carry_cnt;
-  __shared__ unsigned s_carry_rot, s_tot_dup, s_tot_miss, s_tot_bad;
+  __shared__ unsigned s_carry_rot;
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { s_carry_cnt = 0; s_carry_rot = 0; s_tot_dup = 0; s_tot_miss = 0; s_tot_bad = 0; }
-  for (unsigned base = 0; base < n_tiles; base += SEG) {
-    __syncthreads();
-    for (unsigned i = tid; i < SEG; i += 1024) {
-      rx_seam_stepv z; z.add = 0; z.k = 0; z.insert = 0; z.drop = 0; z.bad = 0;
-      s_step[i] = (base + i < n_tiles) ? step[base + i] : z;
+  if (tid == 0) { s_carry_cnt = 0; s_carry_rot = 0; }
+  unsigned nd = 0, nm = 0, nb = 0;
+  __syncthreads();
+  for (unsigned base = 0; base < n_tiles; base += 1024) {
+    const unsigned j = base + tid;
+    long long add = 0;
+    unsigned k = 0, ins = 0, drp = 0;
+    if (j < n_tiles) {
+      const rx_tile_info cur = info[j];
+      add = (long long)cur.count;
+      if (j > 0) {
+        const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad);
+        add += (long long)st.insert - (long long)st.drop;
+        k = st.k; ins = st.insert; drp = st.drop;
+        nd += st.drop; nm += st.insert; nb += st.bad;
+      }
     }
-    __syncthreads();
-    unsigned long long cnt = 0; unsigned rot = 0, nd = 0, nm = 0, nb = 0;
-#pragma unroll
-    for (unsigned q = 0; q < PER; ++q) {
-      const rx_seam_stepv v = s_step[tid * PER + q];
-      cnt += (unsigned long long)(long long)v.add; rot = (rot + v.k) & rmask;
-      nd += v.drop; nm += v.insert; nb += v.bad;
-    }
-    unsigned long long icnt = cnt; unsigned irot = rot;
+    long long icnt = add;
+    unsigned irot = k;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
-      const unsigned long long oc = __shfl_up(icnt, d, 64);
+      const long long oc = __shfl_up(icnt, d, 64);
       const unsigned orot = __shfl_up(irot, d, 64);
       if (lane >= (unsigned)d) { icnt += oc; irot = (irot + orot) & rmask; }
     }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_down(nd, d, 64); nm += __shfl_down(nm, d, 64); nb += __shfl_down(nb, d, 64); }
-    if (lane == 63) { s_cnt[wv] = icnt; s_rot[wv] = irot; }
-    if (lane == 0) { s_dup[wv] = nd; s_miss[wv] = nm; s_bad[wv] = nb; }
+    if (lane == 63) { s_cnt[wv] = (unsigned long long)icnt; s_rot[wv] = irot; }
     __syncthreads();
-    const unsigned long long carry_cnt = s_carry_cnt;
-    const unsigned carry_rot = s_carry_rot;
-    unsigned long long woff = carry_cnt; unsigned wrot = carry_rot;
+    unsigned long long woff = s_carry_cnt;
+    unsigned wrot = s_carry_rot;
     for (unsigned i = 0; i < wv; ++i) { woff += s_cnt[i]; wrot = (wrot + s_rot[i]) & rmask; }
-    unsigned long long off = woff + (icnt - cnt);
-    unsigned r = (wrot + irot + (unsigned)R - rot) & rmask;
-#pragma unroll
-    for (unsigned q = 0; q < PER; ++q) {
-      const unsigned j = base + tid * PER + q;
-      const rx_seam_stepv v = s_step[tid * PER + q];
-      r = (r + v.k) & rmask;
-      if (j < n_tiles) {
-        rx_tile_fix f; f.out_offset = off; f.rot = r; f.drop_first = v.drop; f.insert_pre = v.insert;
-        fix[j] = f;
-      }
-      off += (unsigned long long)(long long)v.add;
+    if (j < n_tiles) {
+      rx_tile_fix f;
+      f.out_offset = woff + (unsigned long long)(icnt - add);   // exclusive
+      f.rot = (wrot + irot) & rmask;                            // inclusive: tile j's own quadrant step applies to it
+      f.drop_first = drp; f.insert_pre = ins;
+      fix[j] = f;
     }
     __syncthreads();
-    if (tid == 1023) { s_carry_cnt = off; s_carry_rot = r; }
-    if (tid == 0) for (int i = 0; i < 16; ++i) { s_tot_dup += s_dup[i]; s_tot_miss += s_miss[i]; s_tot_bad += s_bad[i]; }
+    if (tid == 1023) { s_carry_cnt = woff + (unsigned long long)icnt; s_carry_rot = (wrot + irot) & rmask; }
+    __syncthreads();
   }
+  // totals of the diagnostics
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_down(nd, d, 64); nm += __shfl_down(nm, d, 64); nb += __shfl_down(nb, d, 64); }
+  __shared__ unsigned s_d[16], s_m[16], s_b[16];
+  if (lane == 0) { s_d[wv] = nd; s_m[wv] = nm; s_b[wv] = nb; }
   __syncthreads();
   if (tid == 0) {
+    unsigned td = 0, tm = 0, tb = 0;
+    for (int i = 0; i < 16; ++i) { td += s_d[i]; tm += s_m[i]; tb += s_b[i]; }
     res->total = s_carry_cnt; res->rot_final = s_carry_rot;
-    res->ndup = s_tot_dup; res->nmiss = s_tot_miss; res->nbad = s_tot_bad;
+    res->ndup = td; res->nmiss = tm; res->nbad = tb;
+    if (s_carry_rot) state->phase = fmod65536(state->phase - s_carry_rot * quad);
   }
 }
 
@@ -706,9 +691,15 @@ struct lsdr_rx {
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
   uint8_t *d_relabel;
   struct rx_seam_result *d_seam;
-  struct rx_seam_stepv *d_step;
   std::vector<uint8_t> relabel;   // [nrotations][256]
   unsigned last_tiles, last_dup, last_miss, last_badseam;  // diagnostics of the last tiled run
+  // queued (asynchronous) tiled runs: results land in a pinned ring, one event per slot
+  static const int kRing = 8;
+  struct rx_seam_result *h_res;        // pinned [kRing]
+  hipEvent_t ev[kRing];
+  unsigned ring_tiles[kRing];
+  int ring_head, ring_count;           // oldest outstanding slot, number outstanding
+  bool st_stale_host;                  // device state newer than the host mirror `st`
 };
 
 // sdr.h:755-770
@@ -763,17 +754,29 @@ static void rx_fill_consts(const lsdr_rx *r, rx_consts &C, rx_tables &T) {
   T.trig = r->d_trig; T.lut = r->d_lut; T.coeffs = r->d_coeffs; T.shifted = r->d_shifted;
 }
 
+static int rx_pull_state(lsdr_rx *r) {   // refresh the host mirror after queued runs
+  if (!r->st_stale_host) return LSDR_OK;
+  LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, r->ctx->stream));
+  LSDR_HIP(hipStreamSynchronize(r->ctx->stream));
+  r->st_stale_host = false;
+  return LSDR_OK;
+}
+
 // LSDR_RX_TILED: see the file header.  Not bit-exact: every tile but the first
-// re-acquires timing/phase during its warm-up; seams are reconciled here.
-static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
-                        size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
-                        size_t meas_cap, size_t *n_meas) {
+// re-acquires timing/phase during its warm-up; seams are reconciled on the device.
+// rx_tiled_enqueue puts one run on the stream (tiles → seam → compaction → results into a pinned ring
+// slot) without waiting; rx_tiled_wait retires the oldest queued run.
+static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                            size_t *consumed, bool want_meas, size_t meas_cap, size_t *nm_out) {
   lsdr_ctx *c = r->ctx;
   LSDR_HIP(hipSetDevice(c->device));
+  *consumed = 0;
+  if (nm_out) *nm_out = 0;
   if (r->cfg.sampler == LSDR_SAMP_FIR) {
     lsdr_set_error("cstln_receiver: LSDR_RX_TILED supports the nearest and linear samplers");
     return LSDR_E_UNSUPPORTED;
   }
+  if (r->ring_count == lsdr_rx::kRing) { lsdr_set_error("cstln_receiver: too many queued runs (lsdr_rx_wait first)"); return LSDR_E_ARG; }
   const int ra = lsdr_rx_readahead(r);
   const unsigned Lc = (r->cfg.tile_len ? r->cfg.tile_len : 512) / kChunk;
   const unsigned Wc = (r->cfg.tile_warmup ? r->cfg.tile_warmup : 1024) / kChunk;
@@ -781,18 +784,28 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
   // Symbols per chunk are bounded by 128/(omega - max_mucorr) + 1 (mu advances by at
   // least omega-0.1 per symbol, sdr.h:834-840).
   const unsigned sym_per_chunk = (unsigned)(kChunk / (r->omega - 0.1f)) + 2;
-  size_t chunks = (n_in - ra) / kChunk;
+  size_t chunks = n_in >= (size_t)(kChunk + ra) ? (n_in - ra) / kChunk : 0;
   // (+1 symbol per seam: a repaired seam may re-insert a warm-up symbol)
   if ((size_t)(sym_per_chunk + 1) * chunks > cap_out) chunks = cap_out / (sym_per_chunk + 1);
-  if (!chunks) return LSDR_OK;
+  const int slot = (r->ring_head + r->ring_count) % lsdr_rx::kRing;
+  if (!chunks) {   // nothing to do: still occupies a slot so that wait() pairs with run_async()
+    r->h_res[slot].total = 0; r->h_res[slot].rot_final = 0; r->h_res[slot].ndup = r->h_res[slot].nmiss = r->h_res[slot].nbad = 0;
+    r->ring_tiles[slot] = 0;
+    LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
+    ++r->ring_count;
+    return LSDR_OK;
+  }
   const unsigned first = Lc > Wc ? Lc : Wc;
   unsigned n_tiles = 1;
   if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
   const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
 
+  if (r->tiles_cap < n_tiles || r->stage_cap < (size_t)n_tiles * stage_stride) {
+    // scratch grows: queued runs may still be using the old buffers
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+  }
   if (r->tiles_cap < n_tiles) {
-    (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_step);
-    LSDR_HIP(hipMalloc((void **)&r->d_step, n_tiles * sizeof(rx_seam_stepv)));
+    (void)hipFree(r->d_info); (void)hipFree(r->d_fix);
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
     r->tiles_cap = n_tiles;
@@ -802,12 +815,12 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
     LSDR_HIP(hipMalloc((void **)&r->d_stage, (size_t)n_tiles * stage_stride * sizeof(lsdr_softsymbol)));
     r->stage_cap = (size_t)n_tiles * stage_stride;
   }
-  const bool want_meas = freq_out || ss_out || mer_out;
   const unsigned long long md = r->cfg.meas_decimation;
-  const unsigned long long meas_base = r->st.meas_count;
-  size_t nm = (size_t)((meas_base + chunks * kChunk) / md - meas_base / md);
+  const unsigned long long meas_base = r->st.meas_count;   // kept current on the host even while `st` is stale
+  const size_t nm = (size_t)((meas_base + chunks * kChunk) / md - meas_base / md);
   if (want_meas && nm > meas_cap) { lsdr_set_error("cstln_receiver(tiled): measurement buffers too small"); return LSDR_E_ARG; }
   if (want_meas && r->meas_cap < nm + 1) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(r->d_meas);
     LSDR_HIP(hipMalloc((void **)&r->d_meas, (nm + 1) * sizeof(rx_meas)));
     r->meas_cap = nm + 1;
@@ -846,32 +859,50 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
 #undef LSDR_RX_LAUNCH
   LSDR_HIP(hipGetLastError());
 
-  // ---- seam pass + compaction, all on the stream (one synchronisation at the end)
+  // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  hipLaunchKernelGGL(k_rx_seam_eval, dim3((n_tiles + 255) / 256), dim3(256), 0, c->stream,
-                     (const rx_tile_info *)r->d_info, r->d_step, n_tiles, r->omega, R, quad);
-  hipLaunchKernelGGL(k_rx_seam_scan, dim3(1), dim3(1024), 0, c->stream, (const rx_seam_stepv *)r->d_step, r->d_fix,
-                     n_tiles, R, r->d_seam);
+  hipLaunchKernelGGL(k_rx_seam, dim3(1), dim3(1024), 0, c->stream, (const rx_tile_info *)r->d_info, r->d_fix, n_tiles,
+                     r->omega, R, quad, r->d_state, r->d_seam);
   hipLaunchKernelGGL(k_rx_compact, dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
                      stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
                      (const uint8_t *)r->d_relabel, n_tiles, out);
   LSDR_HIP(hipGetLastError());
-  rx_seam_result sr;
-  LSDR_HIP(hipMemcpyAsync(&sr, r->d_seam, sizeof(sr), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipStreamSynchronize(c->stream));
-  const unsigned rot = sr.rot_final;
-  const unsigned long long off = sr.total;
-  r->last_tiles = n_tiles; r->last_dup = sr.ndup; r->last_miss = sr.nmiss; r->last_badseam = sr.nbad;
-  // Bring the carried carrier phase back into the frame of tile 0 so that the next
-  // run continues with the same symbol labelling.
-  if (rot) {
-    r->st.phase = fmodf(r->st.phase - rot * quad, 65536.0f);
-    r->st_dirty_host = true;
-  }
+  LSDR_HIP(hipMemcpyAsync(&r->h_res[slot], r->d_seam, sizeof(rx_seam_result), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
+  r->ring_tiles[slot] = n_tiles;
+  ++r->ring_count;
+  r->st_stale_host = true;
+  r->st.meas_count = (meas_base + chunks * kChunk) % md;   // what the last tile writes on the device
   *consumed = chunks * kChunk;
-  *produced = (size_t)off;
+  if (nm_out) *nm_out = nm;
+  return LSDR_OK;
+}
+
+static int rx_tiled_wait(lsdr_rx *r, size_t *produced) {
+  if (!r->ring_count) { lsdr_set_error("cstln_receiver: no queued run"); return LSDR_E_ARG; }
+  const int slot = r->ring_head;
+  LSDR_HIP(hipEventSynchronize(r->ev[slot]));
+  const rx_seam_result sr = r->h_res[slot];
+  r->ring_head = (r->ring_head + 1) % lsdr_rx::kRing;
+  --r->ring_count;
+  r->last_tiles = r->ring_tiles[slot]; r->last_dup = sr.ndup; r->last_miss = sr.nmiss; r->last_badseam = sr.nbad;
+  *produced = (size_t)sr.total;
+  return LSDR_OK;
+}
+
+static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                        size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
+                        size_t meas_cap, size_t *n_meas) {
+  if (r->ring_count) { lsdr_set_error("cstln_receiver: queued runs outstanding (lsdr_rx_wait first)"); return LSDR_E_ARG; }
+  const bool want_meas = freq_out || ss_out || mer_out;
+  size_t nm = 0;
+  int rc = rx_tiled_enqueue(r, in, n_in, out, cap_out, consumed, want_meas, meas_cap, &nm);
+  if (rc) return rc;
+  rc = rx_tiled_wait(r, produced);
+  if (rc) return rc;
+  rc = rx_pull_state(r);
+  if (rc) return rc;
   if (want_meas && nm) {
     std::vector<rx_meas> m(nm);
     LSDR_HIP(hipMemcpy(m.data(), r->d_meas, nm * sizeof(rx_meas), hipMemcpyDeviceToHost));
@@ -963,7 +994,9 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_meas = nullptr; r->meas_cap = 0;
   r->d_cstln = nullptr; r->cstln_cap = 0;
   r->d_stage = nullptr; r->stage_cap = 0;
-  r->d_info = nullptr; r->d_fix = nullptr; r->d_step = nullptr; r->tiles_cap = 0;
+  r->d_info = nullptr; r->d_fix = nullptr; r->tiles_cap = 0;
+  r->h_res = nullptr; r->ring_head = 0; r->ring_count = 0; r->st_stale_host = false;
+  for (int i = 0; i < lsdr_rx::kRing; ++i) r->ev[i] = nullptr;
   r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
   // Relabel tables for the tiled mode: relabel[k][s] = symbol whose constellation point is
   // point[s] rotated by +k·(360°/nrotations) (nearest point; exact for the PSK/APSK/QAM sets).
@@ -985,6 +1018,8 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
       }
     }
     LSDR_HIP(hipMalloc((void **)&r->d_seam, sizeof(rx_seam_result)));
+    LSDR_HIP(hipHostMalloc((void **)&r->h_res, lsdr_rx::kRing * sizeof(rx_seam_result), hipHostMallocDefault));
+    for (int i = 0; i < lsdr_rx::kRing; ++i) LSDR_HIP(hipEventCreateWithFlags(&r->ev[i], hipEventDisableTiming));
     LSDR_HIP(hipMalloc((void **)&r->d_relabel, r->relabel.size()));
     LSDR_HIP(hipMemcpy(r->d_relabel, r->relabel.data(), r->relabel.size(), hipMemcpyHostToDevice));
   }
@@ -999,7 +1034,9 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
-  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_step);
+  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam);
+  if (r->h_res) (void)hipHostFree(r->h_res);
+  for (int i = 0; i < lsdr_rx::kRing; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   delete r;
 }
 
@@ -1014,6 +1051,7 @@ int lsdr_rx_readahead(const lsdr_rx *r) {
 
 int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st) {
   LSDR_ARG(r && st);
+  { int rc = rx_pull_state(r); if (rc) return rc; }
   const rx_state_dev &s = r->st;  // host mirror is refreshed after every run
   st->mu = s.mu; st->phase = s.phase; st->freqw = s.freqw; st->agc_gain = s.agc_gain;
   st->est_insp = s.est_insp; st->est_sp = s.est_sp; st->est_ep = s.est_ep;
@@ -1035,6 +1073,8 @@ int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsign
 
 int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st) {
   LSDR_ARG(r && st);
+  if (r->ring_count) { lsdr_set_error("cstln_receiver: queued runs outstanding (lsdr_rx_wait first)"); return LSDR_E_ARG; }
+  { int rc = rx_pull_state(r); if (rc) return rc; }
   rx_state_dev &s = r->st;
   s.mu = st->mu; s.phase = st->phase; s.freqw = st->freqw; s.agc_gain = st->agc_gain;
   s.est_insp = st->est_insp; s.est_sp = st->est_sp; s.est_ep = st->est_ep;
@@ -1043,6 +1083,17 @@ int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st) {
   memcpy(s.hist, st->hist, sizeof(s.hist));
   r->st_dirty_host = true;
   return LSDR_OK;
+}
+
+int lsdr_rx_run_async(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed) {
+  LSDR_ARG(r && consumed && (in || !n_in) && out);
+  if (r->cfg.mode != LSDR_RX_TILED) { lsdr_set_error("cstln_receiver: lsdr_rx_run_async needs LSDR_RX_TILED"); return LSDR_E_UNSUPPORTED; }
+  return rx_tiled_enqueue(r, in, n_in, out, cap_out, consumed, false, 0, nullptr);
+}
+
+int lsdr_rx_wait(lsdr_rx *r, size_t *produced) {
+  LSDR_ARG(r && produced);
+  return rx_tiled_wait(r, produced);
 }
 
 int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
