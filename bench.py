@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, tiled)")
     ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "tiled"))
     ap.add_argument("--tile-len", type=int, default=256)
-    ap.add_argument("--tile-warmup", type=int, default=512)
+    ap.add_argument("--tile-warmup", type=int, default=256)
     ap.add_argument("--no-overlap", action="store_true",
                     help="run fir_filter and cstln_receiver back to back on one stream (default: two HIP streams, "
                          "fir_filter of batch k+1 overlaps cstln_receiver of batch k)")
@@ -245,7 +245,8 @@ def main():
             "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident; "
                                    "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
                        "batch_samples_per_gpu": B, "rx_mode": args.rx_mode,
-                       "streams": "fir_filter(k+1) || cstln_receiver(k) on two HIP streams" if overlap else "single stream",
+                       "streams": "fir_filter(k+1) || cstln_receiver(k) on two HIP streams, receiver runs queued (lsdr_rx_run_async)" if overlap else "single stream",
+                       "rx_tile": {"tile_len": args.tile_len, "warmup": args.tile_warmup},
                        "rx_tiles": rx.tiled_stats() if args.rx_mode == "tiled" else None,
                        "parallelism": f"{world} independent capture(s), one per GPU, no collectives",
                        "symbols_per_step": nsym[0] // max(1, args.steps)},

@@ -445,106 +445,68 @@ struct rx_tiled_args {
 };
 
 // One lane per tile.  Tile 0 continues exactly from the carried state (block 0, alone, exact table
-// look-ups); tile j ≥ 1 starts `warm_chunks` early from the carried tracking state with mu = phase = 0.
-// NT tiles share a wavefront: all 64 lanes fetch the NT tiles' next 128-sample chunks (coalesced, into
-// registers, while the current chunks are being demodulated) and park them in LDS, so the recurrence
-// lanes see LDS latency for their samples and one global round trip (the constellation gather) per symbol.
-constexpr int kRxStage = kChunk + 4;   // chunk + read-ahead of the nearest / linear samplers (≤ 1)
-
+// look-ups); tile j ≥ 1 starts `warm_chunks` early from the carried tracking state with mu = phase = 0
+// and uses the hardware-trig policy.  NT tiles share a wavefront.  The samples are read straight from
+// global memory (two adjacent cf32 per symbol): staging them through LDS was measured to help this kernel
+// alone by ~5 % but its LDS footprint (1 KB per tile) evicts one of fir_filter's two workgroups per CU when
+// the two kernels overlap, which costs far more (fir 0.15 → 0.25 ms per batch).
 template <int SAMP, int NT, typename LD>
-__device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, float2 (*sm)[kRxStage], unsigned j0, int lane) {
+__device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, unsigned j0, int lane) {
   const unsigned long long first = a.first_chunks, Lc = a.tile_chunks, Wc = a.warm_chunks, total = a.total_chunks;
-  // chunk range of tile jj: warm-up [cb, c0), body [c0, c1)
-  auto range = [&](unsigned jj, unsigned long long &cb, unsigned long long &c0, unsigned long long &c1) {
-    if (jj == 0) { cb = 0; c0 = 0; c1 = first; }
-    else { c0 = first + (unsigned long long)(jj - 1) * Lc; c1 = c0 + Lc; cb = c0 - Wc; }
-    if (c1 > total) c1 = total;
-  };
-  const unsigned n_it = j0 == 0 ? (unsigned)(first < total ? first : total) : (unsigned)(Wc + Lc);
-  const int span = kChunk + (SAMP == 1 ? 1 : 0);
-  float2 pre[NT][3];
-  auto prefetch = [&](unsigned it) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      unsigned long long cb, c0, c1;
-      range(j0 + t, cb, c0, c1);
-      if (j0 + t < a.n_tiles && cb + it < c1) {
-        const float2 *src = a.in + (cb + it) * kChunk;
-#pragma unroll
-        for (int q = 0; q < 3; ++q)
-          if (lane + 64 * q < span) pre[t][q] = src[lane + 64 * q];
-      }
-    }
-  };
-  const bool mine = lane < NT && j0 + lane < a.n_tiles;
+  if (lane >= NT || j0 + (unsigned)lane >= a.n_tiles) return;
   const unsigned j = j0 + (unsigned)lane;
-  unsigned long long cb = 0, c0 = 0, c1 = 0;
-  if (mine) range(j, cb, c0, c1);
+  // chunk range of tile j: warm-up [cb, c0), body [c0, c1)
+  unsigned long long cb, c0, c1;
+  if (j == 0) { cb = 0; c0 = 0; c1 = first; }
+  else { c0 = first + (unsigned long long)(j - 1) * Lc; c1 = c0 + Lc; cb = c0 - Wc; }
+  if (c1 > total) c1 = total;
   rx_state_dev s = *a.state;
   rx_tile_info ti;
   ti.has_pre = 0; ti.pre.cost = 0; ti.pre.symbol = 0; ti.pre.pad = 0;
   ti.mu_begin = ti.phase_begin = 0.f;
-  if (mine && j > 0) {
+  if (j > 0) {
     s.mu = 0.f; s.phase = 0.f;
     for (int k = 0; k < 12; ++k) s.hist[k] = 0.f;
   }
   lsdr_softsymbol last; last.cost = 0; last.symbol = 0; last.pad = 0;
   lsdr_softsymbol *po = a.stage + (unsigned long long)j * a.stage_stride;
   unsigned cnt = 0, got = 0;
-  prefetch(0);
-  for (unsigned it = 0; it < n_it; ++it) {
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        if (lane + 64 * q < span) sm[t][lane + 64 * q] = pre[t][q];
-    __syncthreads();
-    if (it + 1 < n_it) prefetch(it + 1);
-    const unsigned long long c = cb + it;
-    if (mine && c < c1) {
-      const bool body = c >= c0;
-      if (c == c0) {
-        ti.mu_begin = s.mu; ti.phase_begin = s.phase;
-        ti.pre = last; ti.has_pre = got ? 1u : 0u;
-      }
-      if (SAMP == 1) s.samp_freqw = s.freqw;
-      bool wrote;
-      const int n = rx_chunk<SAMP, LD>(a.T, a.C, s, (const float2 *)sm[lane],
-                                       [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else last = ss; }, nullptr, &wrote);
-      if (!body) got += (unsigned)n;
-      if (body && a.meas) {     // measurements, sdr.h:905-913: one per meas_decimation samples of the stream
-        unsigned long long before = (a.meas_base + c * kChunk) / a.C.meas_decimation;
-        unsigned long long after = (a.meas_base + (c + 1) * kChunk) / a.C.meas_decimation;
-        unsigned long long first_m = a.meas_base / a.C.meas_decimation;
-        for (unsigned long long m = before; m < after; ++m) {
-          rx_meas mm; mm.freqw = s.freqw; mm.est_insp = s.est_insp; mm.est_sp = s.est_sp; mm.est_ep = s.est_ep;
-          a.meas[m - first_m] = mm;
-        }
+  for (unsigned long long c = cb; c < c1; ++c) {
+    const bool body = c >= c0;
+    if (c == c0) {
+      ti.mu_begin = s.mu; ti.phase_begin = s.phase;
+      ti.pre = last; ti.has_pre = got ? 1u : 0u;
+    }
+    if (SAMP == 1) s.samp_freqw = s.freqw;
+    bool wrote;
+    const int n = rx_chunk<SAMP, LD>(a.T, a.C, s, a.in + c * kChunk,
+                                     [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else last = ss; }, nullptr, &wrote);
+    if (!body) got += (unsigned)n;
+    if (body && a.meas) {     // measurements, sdr.h:905-913: one per meas_decimation samples of the stream
+      unsigned long long before = (a.meas_base + c * kChunk) / a.C.meas_decimation;
+      unsigned long long after = (a.meas_base + (c + 1) * kChunk) / a.C.meas_decimation;
+      unsigned long long first_m = a.meas_base / a.C.meas_decimation;
+      for (unsigned long long m = before; m < after; ++m) {
+        rx_meas mm; mm.freqw = s.freqw; mm.est_insp = s.est_insp; mm.est_sp = s.est_sp; mm.est_ep = s.est_ep;
+        a.meas[m - first_m] = mm;
       }
     }
-    __syncthreads();
   }
-  if (mine) {
-    ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
-    a.info[j] = ti;
-    if (j == a.n_tiles - 1) {
-      s.meas_count = (a.meas_base + a.total_chunks * kChunk) % a.C.meas_decimation;
-      *a.state = s;
-    }
+  ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
+  a.info[j] = ti;
+  if (j == a.n_tiles - 1) {
+    s.meas_count = (a.meas_base + a.total_chunks * kChunk) % a.C.meas_decimation;
+    *a.state = s;
   }
 }
 
 template <int SAMP, int NT>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
-  __shared__ float2 sm[NT][kRxStage];
-#ifdef LSDR_RX_SETPRIO
-  __builtin_amdgcn_s_setprio(3);
-#endif
-  if (blockIdx.x == 0) rx_tiles_body<SAMP, 1, ld_uniform>(a, sm, 0u, (int)threadIdx.x);
-  else rx_tiles_body<SAMP, NT, ld_hwtrig>(a, sm, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
+  if (blockIdx.x == 0) rx_tiles_body<SAMP, 1, ld_uniform>(a, 0u, (int)threadIdx.x);
+  else rx_tiles_body<SAMP, NT, ld_hwtrig>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
 }
 
-// Seam pass: reconciles neighbouring tiles (device-side, one workgroup).
+// Seam pass: reconciles neighbouring tiles on the device.
 //  * carrier quadrant: tile j locked k_j·(65536/R) away from where tile j−1 ended → running
 //    rotation (prefix sum mod R) used to relabel its symbols;
 //  * symbol timing: mu at the start of tile j vs mu at the end of tile j−1 differ by ≈ ±omega
@@ -572,88 +534,91 @@ __device__ __forceinline__ seam_step seam_eval(const rx_tile_info &prev, const r
   return r;
 }
 
-// Seam kernel (one workgroup of 1024): evaluates every seam and scans (symbol count, quadrant) over the
-// tiles in rows of 1024 — tile j is handled by thread j % 1024 in row j / 1024, so every load and store is
-// coalesced; a row costs one wave scan, one 16-entry cross-wave pass and two barriers.  The last thread
-// leaves the totals in *res and rotates the carried carrier phase back into the frame of tile 0 so that the
-// next run continues with the same symbol labelling (all on the device: runs can be queued back to back).
+// Seam pass, two kernels, no single-workgroup scan:
+//  k_rx_seam     one block per 1024 consecutive tiles: evaluates the seams, block-local exclusive scan of
+//                (symbol count, quadrant step) → fix[] holds block-local offsets, part[] the block totals;
+//  k_rx_compact  one wavefront per tile: adds the (≤ a few dozen) preceding block totals, applies the seam
+//                fix-ups and the quadrant relabelling while copying the tile's symbols to their final place.
+//                Block 0 also leaves the run's totals in *res and rotates the carried carrier phase back into
+//                the frame of tile 0, so the next queued run continues with the same symbol labelling.
+struct rx_seam_part { unsigned long long cnt; unsigned rot, ndup, nmiss, nbad; };
+
 __global__ __launch_bounds__(1024) void k_rx_seam(const rx_tile_info *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
-                                                  int R, float quad, rx_state_dev *state, rx_seam_result *res) {
+                                                  int R, float quad, rx_seam_part *part) {
   const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
   __shared__ unsigned long long s_cnt[16];
-  __shared__ unsigned s_rot[16];
-  __shared__ unsigned long long s_carry_cnt;
-  __shared__ unsigned s_carry_rot;
+  __shared__ unsigned s_rot[16], s_d[16], s_m[16], s_b[16];
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) { s_carry_cnt = 0; s_carry_rot = 0; }
-  unsigned nd = 0, nm = 0, nb = 0;
-  __syncthreads();
-  for (unsigned base = 0; base < n_tiles; base += 1024) {
-    const unsigned j = base + tid;
-    long long add = 0;
-    unsigned k = 0, ins = 0, drp = 0;
-    if (j < n_tiles) {
-      const rx_tile_info cur = info[j];
-      add = (long long)cur.count;
-      if (j > 0) {
-        const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad);
-        add += (long long)st.insert - (long long)st.drop;
-        k = st.k; ins = st.insert; drp = st.drop;
-        nd += st.drop; nm += st.insert; nb += st.bad;
-      }
+  const unsigned j = blockIdx.x * 1024 + tid;
+  long long add = 0;
+  unsigned k = 0, ins = 0, drp = 0, bad = 0;
+  if (j < n_tiles) {
+    const rx_tile_info cur = info[j];
+    add = (long long)cur.count;
+    if (j > 0) {
+      const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad);
+      add += (long long)st.insert - (long long)st.drop;
+      k = st.k; ins = st.insert; drp = st.drop; bad = st.bad;
     }
-    long long icnt = add;
-    unsigned irot = k;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      const long long oc = __shfl_up(icnt, d, 64);
-      const unsigned orot = __shfl_up(irot, d, 64);
-      if (lane >= (unsigned)d) { icnt += oc; irot = (irot + orot) & rmask; }
-    }
-    if (lane == 63) { s_cnt[wv] = (unsigned long long)icnt; s_rot[wv] = irot; }
-    __syncthreads();
-    unsigned long long woff = s_carry_cnt;
-    unsigned wrot = s_carry_rot;
-    for (unsigned i = 0; i < wv; ++i) { woff += s_cnt[i]; wrot = (wrot + s_rot[i]) & rmask; }
-    if (j < n_tiles) {
-      rx_tile_fix f;
-      f.out_offset = woff + (unsigned long long)(icnt - add);   // exclusive
-      f.rot = (wrot + irot) & rmask;                            // inclusive: tile j's own quadrant step applies to it
-      f.drop_first = drp; f.insert_pre = ins;
-      fix[j] = f;
-    }
-    __syncthreads();
-    if (tid == 1023) { s_carry_cnt = woff + (unsigned long long)icnt; s_carry_rot = (wrot + irot) & rmask; }
-    __syncthreads();
   }
-  // totals of the diagnostics
+  long long icnt = add;
+  unsigned irot = k, nd = drp, nm = ins, nb = bad;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const long long oc = __shfl_up(icnt, d, 64);
+    const unsigned orot = __shfl_up(irot, d, 64);
+    if (lane >= (unsigned)d) { icnt += oc; irot = (irot + orot) & rmask; }
+  }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_down(nd, d, 64); nm += __shfl_down(nm, d, 64); nb += __shfl_down(nb, d, 64); }
-  __shared__ unsigned s_d[16], s_m[16], s_b[16];
+  if (lane == 63) { s_cnt[wv] = (unsigned long long)icnt; s_rot[wv] = irot; }
   if (lane == 0) { s_d[wv] = nd; s_m[wv] = nm; s_b[wv] = nb; }
   __syncthreads();
+  unsigned long long woff = 0;
+  unsigned wrot = 0;
+  for (unsigned i = 0; i < wv; ++i) { woff += s_cnt[i]; wrot = (wrot + s_rot[i]) & rmask; }
+  if (j < n_tiles) {
+    rx_tile_fix f;
+    f.out_offset = woff + (unsigned long long)(icnt - add);   // exclusive, block-local
+    f.rot = (wrot + irot) & rmask;                            // inclusive, block-local
+    f.drop_first = drp; f.insert_pre = ins;
+    fix[j] = f;
+  }
   if (tid == 0) {
-    unsigned td = 0, tm = 0, tb = 0;
-    for (int i = 0; i < 16; ++i) { td += s_d[i]; tm += s_m[i]; tb += s_b[i]; }
-    res->total = s_carry_cnt; res->rot_final = s_carry_rot;
-    res->ndup = td; res->nmiss = tm; res->nbad = tb;
-    if (s_carry_rot) state->phase = fmod65536(state->phase - s_carry_rot * quad);
+    rx_seam_part p; p.cnt = 0; p.rot = 0; p.ndup = 0; p.nmiss = 0; p.nbad = 0;
+    for (int i = 0; i < 16; ++i) { p.cnt += s_cnt[i]; p.rot = (p.rot + s_rot[i]) & rmask; p.ndup += s_d[i]; p.nmiss += s_m[i]; p.nbad += s_b[i]; }
+    part[blockIdx.x] = p;
   }
 }
 
-// Compaction: one wavefront per tile copies the tile's symbols to their final place,
-// applying the seam fix-ups and the quadrant relabelling.
 __global__ __launch_bounds__(64) void k_rx_compact(const lsdr_softsymbol *stage, unsigned stage_stride,
-                                                   const rx_tile_info *info, const rx_tile_fix *fix,
-                                                   const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles,
-                                                   lsdr_softsymbol *out) {
+                                                   const rx_tile_info *info, const rx_tile_fix *fix, const rx_seam_part *part,
+                                                   const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles, int R, float quad,
+                                                   lsdr_softsymbol *out, rx_state_dev *state, rx_seam_result *res) {
   const unsigned j = blockIdx.x;
   if (j >= n_tiles) return;
+  const unsigned rmask = (unsigned)R - 1;
+  const unsigned nparts = (n_tiles + 1023) / 1024, mypart = j / 1024;
+  // preceding block totals (lane-parallel, then wave-reduced; nparts is tiny)
+  unsigned long long base = 0;
+  unsigned brot = 0;
+  for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
+  if (j == 0 && threadIdx.x == 0) {
+    rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0;
+    for (unsigned i = 0; i < nparts; ++i) {
+      sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
+      sr.ndup += part[i].ndup; sr.nmiss += part[i].nmiss; sr.nbad += part[i].nbad;
+    }
+    *res = sr;
+    if (sr.rot_final) state->phase = fmod65536(state->phase - sr.rot_final * quad);
+  }
   const rx_tile_fix f = fix[j];
   const rx_tile_info ti = info[j];
-  const uint8_t *map = relabel + f.rot * 256;
+  const uint8_t *map = relabel + ((f.rot + brot) & rmask) * 256;
   const lsdr_softsymbol *src = stage + (unsigned long long)j * stage_stride;
-  lsdr_softsymbol *dst = out + f.out_offset;
+  lsdr_softsymbol *dst = out + base + f.out_offset;
   if (f.insert_pre) {
     if (threadIdx.x == 0) { lsdr_softsymbol p = ti.pre; p.symbol = map[p.symbol]; dst[0] = p; }
     dst += 1;
@@ -691,6 +656,7 @@ struct lsdr_rx {
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
   uint8_t *d_relabel;
   struct rx_seam_result *d_seam;
+  struct rx_seam_part *d_part;
   std::vector<uint8_t> relabel;   // [nrotations][256]
   unsigned last_tiles, last_dup, last_miss, last_badseam;  // diagnostics of the last tiled run
   // queued (asynchronous) tiled runs: results land in a pinned ring, one event per slot
@@ -805,7 +771,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
     LSDR_HIP(hipStreamSynchronize(c->stream));
   }
   if (r->tiles_cap < n_tiles) {
-    (void)hipFree(r->d_info); (void)hipFree(r->d_fix);
+    (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part);
+    LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + 1023) / 1024) * sizeof(rx_seam_part)));
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
     r->tiles_cap = n_tiles;
@@ -840,19 +807,20 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   a.meas = want_meas ? r->d_meas : nullptr;
   a.meas_base = meas_base;
   rx_fill_consts(r, a.C, a.T);
-  // 16 tiles per wavefront: the whole batch is resident in one round even while fir_filter's persistent
-  // workgroups hold most of the register file (measured: 189 vs 159 GS/s whole-job with the streams overlapped)
-  int lpw = 16;
+  // 32 tiles per wavefront: few enough wavefronts that the whole batch is resident in one round even while
+  // fir_filter's persistent workgroups hold most of the register file (C2 bench, streams overlapped: 8 → 292,
+  // 16 → 298, 32 → 310, 64 → 302 GS/s whole-job)
+  int lpw = 32;
   {
     const char *e = getenv("LSDR_RX_LANES");   // tuning hook: tiles per wavefront
     if (e) lpw = atoi(e);
-    if (lpw != 2 && lpw != 4 && lpw != 8 && lpw != 16) lpw = 16;
+    if (lpw != 2 && lpw != 4 && lpw != 8 && lpw != 16 && lpw != 32 && lpw != 64) lpw = 32;
     a.lanes_per_wave = (unsigned)lpw;
   }
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
 #define LSDR_RX_LAUNCH(S, N) hipLaunchKernelGGL((k_rx_tiles<S, N>), dim3(blocks), dim3(64), 0, c->stream, a)
 #define LSDR_RX_LAUNCH_S(S) \
-  do { if (lpw == 2) LSDR_RX_LAUNCH(S, 2); else if (lpw == 8) LSDR_RX_LAUNCH(S, 8); else if (lpw == 4) LSDR_RX_LAUNCH(S, 4); else LSDR_RX_LAUNCH(S, 16); } while (0)
+  do { if (lpw == 2) LSDR_RX_LAUNCH(S, 2); else if (lpw == 8) LSDR_RX_LAUNCH(S, 8); else if (lpw == 4) LSDR_RX_LAUNCH(S, 4); else if (lpw == 16) LSDR_RX_LAUNCH(S, 16); else if (lpw == 64) LSDR_RX_LAUNCH(S, 64); else LSDR_RX_LAUNCH(S, 32); } while (0)
   if (r->cfg.sampler == LSDR_SAMP_NEAREST) LSDR_RX_LAUNCH_S(0);
   else LSDR_RX_LAUNCH_S(1);
 #undef LSDR_RX_LAUNCH_S
@@ -862,11 +830,12 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  hipLaunchKernelGGL(k_rx_seam, dim3(1), dim3(1024), 0, c->stream, (const rx_tile_info *)r->d_info, r->d_fix, n_tiles,
-                     r->omega, R, quad, r->d_state, r->d_seam);
+  hipLaunchKernelGGL(k_rx_seam, dim3((n_tiles + 1023) / 1024), dim3(1024), 0, c->stream, (const rx_tile_info *)r->d_info,
+                     r->d_fix, n_tiles, r->omega, R, quad, r->d_part);
   hipLaunchKernelGGL(k_rx_compact, dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
                      stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
-                     (const uint8_t *)r->d_relabel, n_tiles, out);
+                     (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, R, quad, out, r->d_state,
+                     r->d_seam);
   LSDR_HIP(hipGetLastError());
   LSDR_HIP(hipMemcpyAsync(&r->h_res[slot], r->d_seam, sizeof(rx_seam_result), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
@@ -994,7 +963,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_meas = nullptr; r->meas_cap = 0;
   r->d_cstln = nullptr; r->cstln_cap = 0;
   r->d_stage = nullptr; r->stage_cap = 0;
-  r->d_info = nullptr; r->d_fix = nullptr; r->tiles_cap = 0;
+  r->d_info = nullptr; r->d_fix = nullptr; r->d_part = nullptr; r->tiles_cap = 0;
   r->h_res = nullptr; r->ring_head = 0; r->ring_count = 0; r->st_stale_host = false;
   for (int i = 0; i < lsdr_rx::kRing; ++i) r->ev[i] = nullptr;
   r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
@@ -1034,7 +1003,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
-  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam);
+  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part);
   if (r->h_res) (void)hipHostFree(r->h_res);
   for (int i = 0; i < lsdr_rx::kRing; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   delete r;

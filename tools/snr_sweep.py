@@ -7,16 +7,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from leansdr_amd import synth_dvbs
 npk = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
-extra = sys.argv[2:]
+extra = [a for a in sys.argv[2:] if a != "--tiled-only"]
+tiled_only = "--tiled-only" in sys.argv
+sps4 = "--sps4" in sys.argv   # 4 samples/symbol (the C2 receiver geometry) instead of 1.2
+extra = [a for a in extra if a != "--sps4"]
 app = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
-for noise in (7.5, 15.0, 25.0, 35.0, 45.0):
-    iq, ts = synth_dvbs.capture_u8(n_packets=npk, seed=11, noise_std=noise)
+for noise in (7.5, 15.0, 20.0, 25.0, 30.0):
+    iq, ts = synth_dvbs.capture_u8(n_packets=npk, seed=11, noise_std=noise, **(dict(sps_num=4, sps_den=1) if sps4 else {}))
     truth = {bytes(p[1:4]): bytes(p) for p in ts}
     path = "/tmp/snr.u8"
     iq.tofile(path)
     line = f"noise_std {noise:5.1f} (Es/N0 ≈ {20*np.log10(75/(noise*np.sqrt(2)))+10*np.log10(1.2):4.1f} dB): "
-    for flags in ([], ["--tiled"], ["--viterbi"], ["--tiled", "--viterbi"]):
-        cmd = [app, "--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"] + flags + extra
+    for flags in ([["--tiled"], ["--tiled", "--viterbi"]] if tiled_only else [[], ["--tiled"], ["--viterbi"], ["--tiled", "--viterbi"]]):
+        cmd = [app, "--u8", "-f", "8000e3" if sps4 else "2400e3", "--sr", "2000e3", "--cr", "1/2"] + flags + extra
         t0 = time.perf_counter()
         with open(path, "rb") as f:
             p = subprocess.run(cmd, stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
