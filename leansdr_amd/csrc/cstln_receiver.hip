@@ -611,7 +611,8 @@ __global__ __launch_bounds__(64) void k_rx_compact(const lsdr_softsymbol *stage,
       sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
       sr.ndup += part[i].ndup; sr.nmiss += part[i].nmiss; sr.nbad += part[i].nbad;
     }
-    *res = sr;
+    *res = sr;                 // host-pinned ring slot
+    __threadfence_system();
     if (sr.rot_final) state->phase = fmod65536(state->phase - sr.rot_final * quad);
   }
   const rx_tile_fix f = fix[j];
@@ -662,6 +663,7 @@ struct lsdr_rx {
   // queued (asynchronous) tiled runs: results land in a pinned ring, one event per slot
   static const int kRing = 8;
   struct rx_seam_result *h_res;        // pinned [kRing]
+  struct rx_seam_result *h_res_dev;    // the same memory as seen by the device
   hipEvent_t ev[kRing];
   unsigned ring_tiles[kRing];
   int ring_head, ring_count;           // oldest outstanding slot, number outstanding
@@ -835,9 +837,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   hipLaunchKernelGGL(k_rx_compact, dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
                      stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
                      (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, R, quad, out, r->d_state,
-                     r->d_seam);
+                     r->h_res_dev + slot);   // totals go straight into the pinned ring slot (no copy command)
   LSDR_HIP(hipGetLastError());
-  LSDR_HIP(hipMemcpyAsync(&r->h_res[slot], r->d_seam, sizeof(rx_seam_result), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
   r->ring_tiles[slot] = n_tiles;
   ++r->ring_count;
@@ -988,6 +989,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
     }
     LSDR_HIP(hipMalloc((void **)&r->d_seam, sizeof(rx_seam_result)));
     LSDR_HIP(hipHostMalloc((void **)&r->h_res, lsdr_rx::kRing * sizeof(rx_seam_result), hipHostMallocDefault));
+    LSDR_HIP(hipHostGetDevicePointer((void **)&r->h_res_dev, r->h_res, 0));
     for (int i = 0; i < lsdr_rx::kRing; ++i) LSDR_HIP(hipEventCreateWithFlags(&r->ev[i], hipEventDisableTiming));
     LSDR_HIP(hipMalloc((void **)&r->d_relabel, r->relabel.size()));
     LSDR_HIP(hipMemcpy(r->d_relabel, r->relabel.data(), r->relabel.size(), hipMemcpyHostToDevice));
