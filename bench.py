@@ -66,6 +66,19 @@ def cpu_baseline(x, coeffs, decim, budget_s):
                        f"oracle/liblsdr_oracle.so (scaler+fir_filter+cstln_receiver), 1 thread")
 
 
+def pmc_traffic(batch_samples):
+    """HBM bytes per fir_filter launch from the committed rocprofv3 PMC passes (profiles/r01_bench/pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE corrected ×2 for gfx950 as the microarch guide
+    prescribes).  Counters cannot be read from inside a normal run, so this is the recorded per-launch figure for the
+    same workload; None when the batch size differs from the profiled one."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_bench", "pmc_traffic.json")) as f:
+            d = json.load(f)
+        return d["traffic_bytes_per_launch"] if d["batch_samples"] == batch_samples else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -252,7 +265,7 @@ def main():
                        "symbols_per_step": nsym[0] // max(1, args.steps)},
             "roofline": {"kernel": "k_fir (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": None, "avg_launch_ms": round(fir_avg_ms, 4),
+                         "traffic": pmc_traffic(B), "avg_launch_ms": round(fir_avg_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu:
