@@ -197,8 +197,8 @@ typedef struct {
   unsigned long meas_decimation; /* public member, leandvb.cc:502 */
   float kest;                /* public member, default 0.01 */
   int mode;                  /* LSDR_RX_* */
-  unsigned tile_len;         /* LSDR_RX_TILED: samples per tile (multiple of 128); 0 = default */
-  unsigned tile_warmup;      /* LSDR_RX_TILED: warm-up samples before each tile (multiple of 128); 0 = default */
+  unsigned tile_len;         /* LSDR_RX_TILED: samples per tile (multiple of 128); 0 = default (twice the warm-up) */
+  unsigned tile_warmup;      /* LSDR_RX_TILED: warm-up samples before each tile (multiple of 128); 0 = default (≈ 64 symbols) */
 } lsdr_rx_cfg;
 typedef struct {             /* the receiver's loop state, sdr.h:923-935 */
   float mu, phase, freqw, agc_gain, est_insp, est_sp, est_ep, freq_tap;

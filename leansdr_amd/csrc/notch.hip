@@ -62,22 +62,35 @@ __global__ __launch_bounds__(64) void k_notch(notch_args a) {
     const bool emit = b >= b0;
     const float2 *pin = a.in + b * kN;
     float2 *pout = a.out + b * kN;
-    for (int i = 0; i < kN; ++i) {
-      const float2 x = pin[i];
-      float o_re = x.x, o_im = x.y;
+    // 8 samples per trip: the loads (one 64-byte line per lane) and the phasor fetches (wave-uniform) are issued
+    // together, the recurrence then runs on registers, the 8 results leave as one line.  The per-sample
+    // arithmetic and its order are the reference's (sdr.h:124-134).
+    for (int i0 = 0; i0 < kN; i0 += 8) {
+      float2 x8[8], o8[8];
 #pragma unroll
-      for (int s = 0; s < NS; ++s) {   // sdr.h:124-134
-        const float2 e = a.expj[s * kN + i];
-        const float bbre = x.x * e.x + x.y * e.y;
-        const float bbim = -x.x * e.y + x.y * e.x;
-        er[s] = bbre * k + er[s] * omk;
-        ei[s] = bbim * k + ei[s] * omk;
-        const float subre = er[s] * e.x - ei[s] * e.y;
-        const float subim = er[s] * e.y + ei[s] * e.x;
-        o_re -= subre;
-        o_im -= subim;
+      for (int j = 0; j < 8; ++j) x8[j] = pin[i0 + j];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float2 x = x8[j];
+        float o_re = x.x, o_im = x.y;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+          const float2 e = a.expj[s * kN + i0 + j];
+          const float bbre = x.x * e.x + x.y * e.y;
+          const float bbim = -x.x * e.y + x.y * e.x;
+          er[s] = bbre * k + er[s] * omk;
+          ei[s] = bbim * k + ei[s] * omk;
+          const float subre = er[s] * e.x - ei[s] * e.y;
+          const float subim = er[s] * e.y + ei[s] * e.x;
+          o_re -= subre;
+          o_im -= subim;
+        }
+        o8[j] = make_float2(gain * o_re, gain * o_im);
       }
-      if (emit) pout[i] = make_float2(gain * o_re, gain * o_im);
+      if (emit) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pout[i0 + j] = o8[j];
+      }
     }
   }
 #pragma unroll

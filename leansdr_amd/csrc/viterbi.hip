@@ -32,11 +32,14 @@ struct vit_code {           // fec_specs + typedefs, dvb.h:520-566,1179-1212
   int bits_in, bits_out, nus, ncs, nbits, depth, pathbits;
 };
 
-struct vit_tables {         // trellis::init_convolutional (viterbi.h:59-92), branches sorted by coded symbol
-  unsigned char pred[kStates][128];
-  unsigned char us[kStates][128];
-  unsigned char lab[kStates][128];     // coded symbol of branch k
-  unsigned char by_label[kStates][256];  // branch index for a coded symbol, 255 = none
+// trellis::init_convolutional (viterbi.h:59-92), branches sorted by coded symbol.  Branch-major / state-minor:
+// the 64 lanes (= states) of one LDS read touch 64 consecutive bytes (state-major rows of 128 / 256 bytes put
+// every lane on the same bank — a 32- to 64-way conflict on each of the ~6 table reads of a trellis step).
+struct vit_tables {
+  unsigned char pred[128][kStates];
+  unsigned char us[128][kStates];
+  unsigned char lab[128][kStates];       // coded symbol of branch k
+  unsigned char by_label[256][kStates];  // branch index for a coded symbol, 255 = none
 };
 
 struct vit_state { int cost[kStates]; unsigned long long path[kStates]; };
@@ -61,6 +64,7 @@ struct vit_args {
   const unsigned char *maps;         // [nsyncs][256]
   const int *shifts;                 // [nsyncs]
   const vit_job *jobs;
+  unsigned njobs;
   const vit_state *states_in;        // carried states, [nsyncs]
   vit_state *begin_states;           // [njobs] state at first_chunk (after warm-up)
   vit_state *end_states;             // [njobs] state after the job's last chunk
@@ -76,17 +80,20 @@ __device__ __forceinline__ int wave_min(int v) {
   return v;
 }
 
+constexpr int kVitWaves = 4;
 // One wavefront = one job.  Lane = trellis state.
-__global__ __launch_bounds__(64) void k_viterbi(vit_args a) {
+__global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   __shared__ vit_tables T;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const unsigned jid = blockIdx.x * kVitWaves + (threadIdx.x >> 6);   // one wavefront = one job; kVitWaves jobs share the LDS tables
   {   // tables → LDS (≈41 KB)
     const unsigned *src = reinterpret_cast<const unsigned *>(a.T);
     unsigned *dst = reinterpret_cast<unsigned *>(&T);
-    for (unsigned i = lane; i < sizeof(vit_tables) / 4; i += 64) dst[i] = src[i];
+    for (unsigned i = threadIdx.x; i < sizeof(vit_tables) / 4; i += kVitWaves * 64) dst[i] = src[i];
   }
   __syncthreads();
-  const vit_job job = a.jobs[blockIdx.x];
+  if (jid >= a.njobs) return;
+  const vit_job job = a.jobs[jid];
   const unsigned char *map = a.maps + job.sync * 256;
   const int shift = a.shifts[job.sync];
   const vit_code C = a.C;
@@ -104,8 +111,8 @@ __global__ __launch_bounds__(64) void k_viterbi(vit_args a) {
     const unsigned long long c = (unsigned long long)((long long)job.first_chunk + q * (long long)job.chunk_step);
     const bool emitting = q >= 0;
     if (q == 0) {   // (metrics are normalised at every chunk boundary)
-      a.begin_states[blockIdx.x].cost[lane] = cost;
-      a.begin_states[blockIdx.x].path[lane] = path;
+      a.begin_states[jid].cost[lane] = cost;
+      a.begin_states[jid].path[lane] = path;
     }
     const bool resync = ((c + (unsigned long long)a.resync_phase0) % (unsigned)a.resync_period) == 0;
     const bool want_q = resync && emitting;
@@ -114,30 +121,41 @@ __global__ __launch_bounds__(64) void k_viterbi(vit_args a) {
     int nout = 0;
     unsigned char *pout = a.out + c * (unsigned)(kChunkBlocks * C.bits_in / 8);
     const lsdr_softsymbol *pin = a.in + c * (unsigned)(kChunkBlocks * a.nshifts) + shift;
-    for (int b = 0; b < kChunkBlocks; ++b, pin += a.nshifts) {
-      // update_sync (dvb.h:1353-1364): coded symbol and summed cost of this FEC block (wave-uniform)
-      unsigned cs1 = 0;
-      int cost1 = 0;
+    // update_sync (dvb.h:1353-1364) for the whole chunk at once: lane l prepares FEC blocks l and l+64 (coded
+    // symbol = mapped bits of the block's `nshifts` symbols, cost = their summed costs); the trellis loop below
+    // then takes block b's pair with two v_readlane instead of dependent global loads on its critical path.
+    unsigned my_cs[2];
+    int my_cost[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const lsdr_softsymbol *pb = pin + (unsigned)(lane + 64 * h) * (unsigned)a.nshifts;
+      unsigned cs = 0;
+      int cst = 0;
       for (int i = 0; i < a.nshifts; ++i) {
-        const lsdr_softsymbol ss = pin[i];
-        cs1 = ((cs1 << a.bits_per_symbol) | map[ss.symbol]) & 0xffu;
-        cost1 += ss.cost;
+        const lsdr_softsymbol ss = pb[i];
+        cs = ((cs << a.bits_per_symbol) | map[ss.symbol]) & 0xffu;
+        cst += ss.cost;
       }
+      my_cs[h] = cs; my_cost[h] = cst;
+    }
+    for (int b = 0; b < kChunkBlocks; ++b) {
+      const unsigned cs1 = (unsigned)__builtin_amdgcn_readlane((int)(b < 64 ? my_cs[0] : my_cs[1]), b & 63);
+      const int cost1 = __builtin_amdgcn_readlane(b < 64 ? my_cost[0] : my_cost[1], b & 63);
       // viterbi_dec::update(nm = 1), viterbi.h:202-260
       int best_m = 0x7fffffff, bk = 0;
       {
-        const unsigned k1 = T.by_label[lane][cs1];
+        const unsigned k1 = T.by_label[cs1][lane];
         const unsigned kk = k1 == 255 ? 0u : k1;
-        const int pc = __shfl(cost, (int)T.pred[lane][kk], 64);
+        const int pc = __shfl(cost, (int)T.pred[kk][lane], 64);
         if (k1 != 255) { const int m = pc + cost1; if (m <= best_m) { best_m = m; bk = (int)k1; } }
       }
       for (int k = 0; k < C.nus; ++k) {
-        const int m = __shfl(cost, (int)T.pred[lane][k], 64);
+        const int m = __shfl(cost, (int)T.pred[k][lane], 64);
         if (m <= best_m) { best_m = m; bk = k; }
       }
-      const int bp = T.pred[lane][bk];
+      const int bp = T.pred[bk][lane];
       const unsigned lo = __shfl((unsigned)path, bp, 64), hi = __shfl((unsigned)(path >> 32), bp, 64);
-      path = ((((unsigned long long)hi << 32 | lo) << C.nbits) | T.us[lane][bk]) & pmask;
+      path = ((((unsigned long long)hi << 32 | lo) << C.nbits) | T.us[bk][lane]) & pmask;
       cost = best_m;
       // output symbol of the best state (lowest index among the minima); skip the search when all agree
       unsigned sym_out = (unsigned)(path >> out_shift) & us_mask;
@@ -174,16 +192,16 @@ __global__ __launch_bounds__(64) void k_viterbi(vit_args a) {
     cost -= wave_min(cost);
     if (emitting) {
       const unsigned ci = (unsigned)q;
-      if (lane == 0) a.totals[(size_t)blockIdx.x * a.totals_stride + ci] = total;
+      if (lane == 0) a.totals[(size_t)jid * a.totals_stride + ci] = total;
       if (a.chunk_states) {
-        vit_state *st = a.chunk_states + (size_t)blockIdx.x * a.totals_stride + ci;
+        vit_state *st = a.chunk_states + (size_t)jid * a.totals_stride + ci;
         st->cost[lane] = cost; st->path[lane] = path;
       }
-      if (ci == 0) { a.first_chunk_states[blockIdx.x].cost[lane] = cost; a.first_chunk_states[blockIdx.x].path[lane] = path; }
+      if (ci == 0) { a.first_chunk_states[jid].cost[lane] = cost; a.first_chunk_states[jid].path[lane] = path; }
     }
   }
-  a.end_states[blockIdx.x].cost[lane] = cost;
-  a.end_states[blockIdx.x].path[lane] = path;
+  a.end_states[jid].cost[lane] = cost;
+  a.end_states[jid].path[lane] = path;
 }
 
 // seam check: begin state of job j (j ≥ 1) == end state of job j−1
@@ -281,7 +299,8 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.begin_states = v->d_begin; a.end_states = v->d_end; a.first_chunk_states = v->d_first;
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
-  hipLaunchKernelGGL(k_viterbi, dim3((unsigned)nj), dim3(64), 0, c->stream, a);
+  a.njobs = (unsigned)nj;
+  hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((nj + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }
@@ -348,8 +367,8 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
     for (size_t i = 0; i < L.size(); ++i) for (size_t j = i + 1; j < L.size(); ++j) if (L[j].cs < L[i].cs) { br t = L[i]; L[i] = L[j]; L[j] = t; }
     if ((int)L.size() != C.nus) { delete T; delete v; lsdr_set_error("viterbi_sync: invalid convolutional code"); return LSDR_E_ARG; }
     for (int k = 0; k < C.nus; ++k) {
-      T->pred[s][k] = (unsigned char)L[k].pred; T->us[s][k] = (unsigned char)L[k].us; T->lab[s][k] = (unsigned char)L[k].cs;
-      T->by_label[s][L[k].cs] = (unsigned char)k;
+      T->pred[k][s] = (unsigned char)L[k].pred; T->us[k][s] = (unsigned char)L[k].us; T->lab[k][s] = (unsigned char)L[k].cs;
+      T->by_label[L[k].cs][s] = (unsigned char)k;
     }
     nbr[s] = C.nus;
   }
@@ -502,7 +521,8 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     // The other alignments decode only the resync chunks (stride P), each from its own carried state.  Their
     // "virtual stream" is tiled and verified exactly like the main one; a decoder whose seams do not verify
     // (wrong alignments see noise-like input, survivors may merge slowly) is redone sequentially.
-    const unsigned TLo = 4, Wo = (unsigned)kWarm;
+    const unsigned TLo = 4;
+    const unsigned Wo = getenv("LSDR_VIT_WO") ? (unsigned)atoi(getenv("LSDR_VIT_WO")) : (unsigned)kWarm;   // tuning hook
     const unsigned nrs = (unsigned)rs.size();
     auto run_others = [&](bool sequential, std::vector<int> only) -> int {
       std::vector<vit_job> oj;

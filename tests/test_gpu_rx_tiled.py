@@ -24,7 +24,7 @@ def stream():
     return x
 
 
-@pytest.mark.parametrize("tile_len,warm", [(512, 1024), (1024, 1024), (256, 1024), (128, 512)])
+@pytest.mark.parametrize("tile_len,warm", [(512, 1024), (1024, 1024), (256, 1024), (128, 512), (256, 256), (0, 0)])
 def test_tiled_vs_serial(capi, ctx, oracle, stream, tile_len, warm):
     p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=4096)
     acq = 40960
@@ -49,7 +49,7 @@ def test_tiled_vs_serial(capi, ctx, oracle, stream, tile_len, warm):
     assert dcost.mean() <= 0.03 * 11236, (dcost.mean(), stats)
     assert stats["bad_seams"] == 0 and stats["tiles"] > 10
     # first tile: exact continuation of the carried state
-    n0 = max(tile_len, warm) // 4 - 8
+    n0 = (max(tile_len, warm) or 256) // 4 - 8      # (0, 0) = library defaults: 256-sample warm-up at omega 4
     assert bits_equal(out["sym"]["cost"][:n0], ref["sym"]["cost"][:n0])
     # measurement stream has the reference's cadence
     assert len(out["freq"]) == len(ref["freq"])
@@ -60,7 +60,7 @@ def test_tiled_short_input_is_exact(capi, ctx, oracle, stream):
     """Fewer chunks than one tile: the tiled mode degenerates to the exact serial loop."""
     p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=4096)
     ref = oracle.rx(p, stream[:1000])
-    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=4.0, meas_decimation=4096, mode=capi.RX_TILED)
+    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=4.0, meas_decimation=4096, mode=capi.RX_TILED, tile_len=1024, tile_warmup=512)
     out = r.run(stream[:1000])
     r.close()
     assert out["consumed"] == ref["consumed"] == 896
