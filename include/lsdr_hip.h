@@ -274,6 +274,7 @@ int lsdr_mpeg_sync_run(lsdr_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_
                        size_t *consumed, size_t *produced, int *state_events_host, int *n_state_events,
                        unsigned long *locktime, int *call_next_sync);
 int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m);
+int lsdr_mpeg_sync_set_resync_period(lsdr_mpeg_sync *m, int period);   /* public member resync_period (dvb.h:717), used by --hs */
 
 /* ---- deinterleaver<u8>::run, dvb.h:932-944 (Forney I=12, M=17 as a gather).  Needs 2448 bytes per
  * packet window; *produced packets of 204 B, *consumed = 204 * produced.  Asynchronous. */
@@ -296,6 +297,29 @@ int lsdr_derandomizer_run(lsdr_derandomizer *d, const uint8_t *in_packets, size_
 /* host-side tables for tests: PRBS pattern (dvb.h:1116-1129), GF(256) exp/log and RS generator (rs.h:47-105) */
 void lsdr_derandomizer_pattern(uint8_t *pattern1504_host);
 void lsdr_rs_tables(uint8_t *exp512_host, uint8_t *log256_host, uint8_t *G17_host);
+
+/* -------------------------------------------------------------- `--hs` path (leandvb.cc:727-969)
+ * fast_qpsk_receiver<u8> (sdr.h:946-1189): cu8 samples → hard QPSK symbols {0,1,2,3}; optional FREQ measurements
+ * (one per meas_decimation samples) and one sampled constellation point per chunk, both to HOST buffers.
+ * _create = ctor + set_omega(omega) + set_freq(freq) + the public members; _run = run() over one buffer (needs
+ * 129 samples and room for 128 symbols).  Bit-exact incl. the carried loop state. */
+typedef struct lsdr_fastqpsk lsdr_fastqpsk;
+int lsdr_fastqpsk_create(lsdr_ctx *ctx, float omega, float freq, float pll_adjustment, int allow_drift,
+                         unsigned long meas_decimation, lsdr_fastqpsk **r);
+void lsdr_fastqpsk_destroy(lsdr_fastqpsk *r);
+int lsdr_fastqpsk_get_state(const lsdr_fastqpsk *r, float *mu, unsigned *phase, long long *freqw, long long *min_freqw,
+                            long long *max_freqw);
+int lsdr_fastqpsk_run(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
+                      size_t *produced, float *freq_out_host, size_t freq_cap, size_t *n_freq, lsdr_cu8 *cstln_out_host,
+                      size_t cstln_cap, size_t *n_cstln);
+/* dvb_deconvol_sync<u8> (dvb.h:612-707) on deconvol_poly2 (convolutional.h:80-192): 512 hard symbols → 64 bytes per
+ * chunk, the four alignments re-scored every resync_period chunks. */
+typedef struct lsdr_hsdeconv lsdr_hsdeconv;
+int lsdr_hsdeconv_create(lsdr_ctx *ctx, int resync_period, lsdr_hsdeconv **d);
+void lsdr_hsdeconv_destroy(lsdr_hsdeconv *d);
+int lsdr_hsdeconv_locked(const lsdr_hsdeconv *d);
+int lsdr_hsdeconv_run(lsdr_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
+                      size_t *produced);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,15 @@ _sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
 _sig("lsdr_cnr_fft_destroy", None, [vp])
 _sig("lsdr_cnr_fft_set", C.c_int, [vp, C.c_int, c_f])
 _sig("lsdr_cnr_fft_run", C.c_int, [vp, c_f, c_f, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_mpeg_sync_set_resync_period", C.c_int, [vp, C.c_int])
+_sig("lsdr_fastqpsk_create", C.c_int, [vp, c_f, c_f, c_f, C.c_int, C.c_ulong, C.POINTER(vp)])
+_sig("lsdr_fastqpsk_destroy", None, [vp])
+_sig("lsdr_fastqpsk_get_state", C.c_int, [vp, C.POINTER(c_f), C.POINTER(C.c_uint), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)])
+_sig("lsdr_fastqpsk_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, c_sz, psz, vp, c_sz, psz])
+_sig("lsdr_hsdeconv_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
+_sig("lsdr_hsdeconv_destroy", None, [vp])
+_sig("lsdr_hsdeconv_locked", C.c_int, [vp])
+_sig("lsdr_hsdeconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_spectrum_create", C.c_int, [vp, C.POINTER(vp)])
 _sig("lsdr_spectrum_destroy", None, [vp])
 _sig("lsdr_spectrum_set", C.c_int, [vp, C.c_int, c_f])
@@ -556,6 +565,9 @@ class MpegSync:
     def locked(self):
         return bool(lib.lsdr_mpeg_sync_locked(self.h))
 
+    def set_resync_period(self, period):
+        check(lib.lsdr_mpeg_sync_set_resync_period(self.h, period))
+
     def run_dev(self, in_ptr, n_in, out_ptr, cap):
         cons, prod = c_sz(), c_sz()
         ev = (C.c_int * 8)()
@@ -668,6 +680,78 @@ class AutoNotch:
         dout = self.ctx.alloc(max(8, x.nbytes))
         cons, prod = self.run_dev(din.ptr, len(x), dout.ptr, len(x))
         out = self.ctx.download(dout, np.complex64, prod)
+        din.free(); dout.free()
+        return out
+
+
+class FastQpsk:
+    """fast_qpsk_receiver<u8> (sdr.h:946-1189), the --hs receiver."""
+
+    def __init__(self, ctx, omega, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=0):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_fastqpsk_create(ctx.h, omega, freq, pll_adjustment, allow_drift, meas_decimation, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_fastqpsk_destroy(self.h)
+            self.h = None
+
+    def state(self):
+        mu, ph, fw, mn, mx = c_f(), C.c_uint(), C.c_longlong(), C.c_longlong(), C.c_longlong()
+        check(lib.lsdr_fastqpsk_get_state(self.h, C.byref(mu), C.byref(ph), C.byref(fw), C.byref(mn), C.byref(mx)))
+        return dict(mu=mu.value, phase=ph.value, freqw=fw.value, min_freqw=mn.value, max_freqw=mx.value)
+
+    def run(self, iq_u8, meas=True):
+        """Upload interleaved u8 I/Q, run once, download.  Returns dict(sym, consumed, freq, cstln)."""
+        iq = np.ascontiguousarray(iq_u8, np.uint8)
+        n = len(iq) // 2
+        din = self.ctx.upload(iq)
+        dout = self.ctx.alloc(n + 256)
+        fo = np.empty(n // 64 + 16, np.float32)
+        co = np.empty((n // 64 + 16, 2), np.uint8)
+        cons, prod, nf, nc = c_sz(), c_sz(), c_sz(), c_sz()
+        check(lib.lsdr_fastqpsk_run(self.h, din.ptr, n, dout.ptr, n + 256, C.byref(cons), C.byref(prod),
+                                    _np(fo) if meas else None, len(fo), C.byref(nf), _np(co) if meas else None, len(co), C.byref(nc)))
+        sym = self.ctx.download(dout, np.uint8, prod.value)
+        din.free(); dout.free()
+        return dict(sym=sym, consumed=cons.value, freq=fo[:nf.value].copy(), cstln=co[:nc.value].copy())
+
+
+class HsDeconv:
+    """dvb_deconvol_sync<u8> (dvb.h:612-707), the --hs deconvolver."""
+
+    def __init__(self, ctx, resync_period=32):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_hsdeconv_create(ctx.h, resync_period, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_hsdeconv_destroy(self.h)
+            self.h = None
+
+    @property
+    def locked(self):
+        return lib.lsdr_hsdeconv_locked(self.h)
+
+    def run_stream(self, symbols, pipe=None, room=None):
+        sym = np.ascontiguousarray(symbols, np.uint8)
+        din = self.ctx.upload(sym)
+        dout = self.ctx.alloc(len(sym) // 8 + 64)
+        pos = nout = 0
+        while True:
+            avail = len(sym) - pos if pipe is None else min(pipe, len(sym) - pos)
+            cap = len(sym) // 8 + 64 - nout if room is None else min(room, len(sym) // 8 + 64 - nout)
+            cons, prod = c_sz(), c_sz()
+            check(lib.lsdr_hsdeconv_run(self.h, din.at(pos), avail, dout.at(nout), cap, C.byref(cons), C.byref(prod)))
+            if not prod.value:
+                break
+            pos += cons.value
+            nout += prod.value
+        out = self.ctx.download(dout, np.uint8, nout)
         din.free(); dout.free()
         return out
 

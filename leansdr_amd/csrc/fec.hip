@@ -865,6 +865,15 @@ void lsdr_mpeg_sync_destroy(lsdr_mpeg_sync *m) {
   delete m;
 }
 int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m) { return m ? m->st.synchronized : 0; }
+int lsdr_mpeg_sync_set_resync_period(lsdr_mpeg_sync *m, int period) {
+  LSDR_ARG(m && period >= 1);
+  if (m->st.resync_period == period) return LSDR_OK;
+  LSDR_HIP(hipStreamSynchronize(m->ctx->stream));
+  LSDR_HIP(hipMemcpy(&m->st, m->d_state, sizeof(msync_state), hipMemcpyDeviceToHost));
+  m->st.resync_period = period;
+  LSDR_HIP(hipMemcpy(m->d_state, &m->st, sizeof(msync_state), hipMemcpyHostToDevice));
+  return LSDR_OK;
+}
 
 int lsdr_mpeg_sync_run(lsdr_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out,
                        size_t *consumed, size_t *produced, int *events, int *n_events, unsigned long *locktime,

@@ -93,6 +93,29 @@ static void qam(cstln_tables &t, int n) {
 }
 
 // make_dvbs2_constellation (dvb.h:45-81) + cstln_lut ctor (sdr.h:326-468)
+// fast_qpsk_receiver::init_lookup_tables, sdr.h:1154-1171.  Same libm calls and conversions as the reference:
+// atan2f(float,float)·65536 in float, /(2π) in double, → s_angle (the +π entries, 32768.0…, wrap to −32768 like the
+// reference build: via int32); hypotf → int; 128 + 75·cosf(float(2πa/65536)) → u8; (int)(128 + r·cos(2πa/256)) → u8.
+void build_fastqpsk_tables(unsigned *polar, unsigned short *rect, unsigned short *sincos) {
+  for (int i = 0; i < 256; ++i)
+    for (int q = 0; q < 256; ++q) {
+      const double v = atan2f((float)(q - 128), (float)(i - 128)) * 65536 / (2 * M_PI);
+      const unsigned a = (unsigned)(uint16_t)(int16_t)(int32_t)v;
+      const unsigned r = (unsigned)(uint8_t)(int)hypotf((float)(i - 128), (float)(q - 128));
+      polar[i * 256 + q] = a | (r << 16);
+    }
+  for (unsigned long a = 0; a < 65536; ++a) {
+    const float f = 2 * M_PI * a / 65536;
+    const unsigned re = (uint8_t)(128 + 75.0f * cosf(f)), im = (uint8_t)(128 + 75.0f * sinf(f));
+    sincos[a] = (unsigned short)(re | (im << 8));
+  }
+  for (int a = 0; a < 256; ++a)
+    for (int r = 0; r < 256; ++r) {
+      const unsigned re = (uint8_t)(int)(128 + r * cos(2 * M_PI * a / 256)), im = (uint8_t)(int)(128 + r * sin(2 * M_PI * a / 256));
+      rect[a * 256 + r] = (unsigned short)(re | (im << 8));
+    }
+}
+
 int build_cstln(int predef, int fec, cstln_tables &t) {
   float g1 = 1, g2 = 1, g3 = 1;
   if (predef == LSDR_APSK16) {

@@ -1,0 +1,458 @@
+// leansdr_amd/csrc/hs.hip — the `--hs` path of leandvb (leandvb.cc:727-969) on gfx950:
+//
+//   fast_qpsk_receiver<u8>  sdr.h:946-1189   all-integer QPSK receiver on cu8 samples (phase-only look-up tables,
+//                                            u16 carrier phase, 64-bit frequency word, float symbol clock).
+//                                            A decision-feedback recurrence like cstln_receiver: one lane runs it
+//                                            in the reference's exact operation order, its three dependent table
+//                                            look-ups go through the scalar cache; the other lanes stage samples.
+//   dvb_deconvol_sync<u8>   dvb.h:612-707    algebraic deconvolution by 32-bit bit-parallel XORs
+//                           convolutional.h:80-192 (deconvol_poly2<…,0x3ba,0x38f70>) with alignment search.
+//                                            Every 64-byte chunk is a pure function of its 512 symbols and the 32
+//                                            before them; the alignment in force after a resync chunk is the
+//                                            arg-min of the four error counts of that chunk (independent of the
+//                                            previous one) → two fully parallel kernels.
+//
+// Tables are built on the host with the reference's libm expressions (host_tables.cpp) and uploaded once.
+#include "lsdr_internal.h"
+
+namespace {
+
+constexpr int kChunk = 128;   // fast_qpsk_receiver::chunk_size, sdr.h:957
+
+typedef unsigned hs_u32c __attribute__((address_space(4)));
+typedef unsigned short hs_u16c __attribute__((address_space(4)));
+
+struct fq_state {               // members of fast_qpsk_receiver that cross run() calls
+  float mu;
+  unsigned phase;               // u_angle (low 16 bits)
+  long long freqw, min_freqw, max_freqw;
+  unsigned long long meas_count;
+  unsigned char hist_p[3][2], hist_c[3][2];
+};
+
+struct fq_args {
+  const unsigned char *in;      // cu8 samples
+  unsigned long long n_in;
+  unsigned char *out;           // hard symbols
+  unsigned long long cap_out;
+  fq_state *state;
+  float *freq; unsigned long long freq_cap;       // device scratch, may be null
+  unsigned char *cstln; unsigned long long cstln_cap;
+  unsigned long long *counters;                   // [0] consumed, [1] produced, [2] n_freq, [3] n_cstln
+  const unsigned *polar;        // [65536]  a | r << 16, index re*256+im
+  const unsigned short *rect;   // [256*256] re | im << 8, index a*256 + r
+  const unsigned short *sincos; // [65536]  re | im << 8
+  float omega, gain_mu;
+  long long freq_alpha, freq_beta;
+  unsigned long long meas_decimation;
+  int allow_drift;
+};
+
+__device__ __forceinline__ unsigned uload32(const unsigned *t, unsigned i) {
+  const unsigned si = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+  return ((const hs_u32c *)t)[si];
+}
+__device__ __forceinline__ unsigned uload16(const unsigned short *t, unsigned i) {
+  const unsigned si = (unsigned)__builtin_amdgcn_readfirstlane((int)i);
+  return ((const hs_u16c *)t)[si];
+}
+
+// One wavefront; lane 0 = the recurrence (sdr.h:997-1140), all lanes = staging.
+__global__ __launch_bounds__(64) void k_fastqpsk_serial(fq_args a) {
+  __shared__ unsigned short buf[kChunk + 2];      // cu8 samples of the chunk (+1 for interpolation)
+  __shared__ fq_state st;
+  __shared__ unsigned long long sh_nout, sh_nf, sh_nc;
+  const int lane = threadIdx.x;
+  if (lane == 0) { st = *a.state; sh_nout = 0; sh_nf = 0; sh_nc = 0; }
+  __syncthreads();
+  const unsigned short *in16 = reinterpret_cast<const unsigned short *>(a.in);
+  const unsigned long long max_meas = kChunk / a.meas_decimation + 1;
+  unsigned long long pos = 0;
+  while (true) {
+    if (a.n_in < pos || a.n_in - pos < (unsigned long long)(kChunk + 1)) break;   // sdr.h:1010-1013
+    if (a.cap_out - sh_nout < (unsigned long long)kChunk) break;
+    if (a.freq && a.freq_cap - sh_nf < max_meas) break;
+    if (a.cstln && a.cstln_cap - sh_nc < max_meas) break;
+    for (int k = lane; k < kChunk + 1; k += 64) buf[k] = in16[pos + k];
+    __syncthreads();
+    if (lane == 0) {
+      float mu = st.mu;
+      unsigned phase = st.phase & 0xffffu;
+      long long freqw = st.freqw;
+      unsigned char *po = a.out + sh_nout;
+      int cnt = 0;
+      unsigned s_re = 0, s_im = 0, symbol_arg = 0;
+      for (int n = 0; n < kChunk; ++n) {
+        if (mu < 1) {
+          const unsigned x0 = buf[n], x1 = buf[n + 1];             // re | im << 8
+          const unsigned p0 = uload32(a.polar, (x0 & 255u) * 256u + (x0 >> 8));
+          const unsigned p1 = uload32(a.polar, (x1 & 255u) * 256u + (x1 >> 8));
+          const unsigned a0 = (((p0 & 0xffffu) - phase) & 0xffffu) >> 8;
+          const unsigned a1 = (unsigned)(((long long)(p1 & 0xffffu) - ((long long)phase + freqw)) & 0xffff) >> 8;
+          const unsigned r0 = uload16(a.rect, a0 * 256u + ((p0 >> 16) >> 1));
+          const unsigned r1 = uload16(a.rect, a1 * 256u + ((p1 >> 16) >> 1));
+          const int p0re = (int)(r0 & 255u), p0im = (int)(r0 >> 8), p1re = (int)(r1 & 255u), p1im = (int)(r1 >> 8);
+          s_re = (unsigned)(int)((float)p0re + (float)(p1re - p0re) * mu) & 255u;    // (int)(int + int*float) → u8
+          s_im = (unsigned)(int)((float)p0im + (float)(p1im - p0im) * mu) & 255u;
+          symbol_arg = uload32(a.polar, s_re * 256u + s_im) & 0xffffu;
+          // quadrant → symbol {0,2,3,1}, sdr.h:1066-1069
+          po[cnt++] = (unsigned char)((0x1320u >> ((symbol_arg >> 14) * 4)) & 15u);
+          const long long phase_error = (long long)(int)(symbol_arg & 16383u) - 8192;           // sdr.h:1072
+          phase = (unsigned)((long long)phase + ((phase_error * a.freq_alpha + 32768) >> 16)) & 0xffffu;
+          freqw += (phase_error * a.freq_beta + 32768 * 256) >> 24;
+          st.hist_p[2][0] = st.hist_p[1][0]; st.hist_p[2][1] = st.hist_p[1][1];
+          st.hist_c[2][0] = st.hist_c[1][0]; st.hist_c[2][1] = st.hist_c[1][1];
+          st.hist_p[1][0] = st.hist_p[0][0]; st.hist_p[1][1] = st.hist_p[0][1];
+          st.hist_c[1][0] = st.hist_c[0][0]; st.hist_c[1][1] = st.hist_c[0][1];
+          st.hist_p[0][0] = (unsigned char)s_re; st.hist_p[0][1] = (unsigned char)s_im;
+          const unsigned c = uload16(a.sincos, ((symbol_arg & 49152u) + 8192u) & 0xffffu);
+          st.hist_c[0][0] = (unsigned char)(c & 255u); st.hist_c[0][1] = (unsigned char)(c >> 8);
+          const int muerr =
+              ((int)(signed char)(st.hist_p[0][0] - st.hist_p[2][0]) * ((int)st.hist_c[1][0] - 128) +
+               (int)(signed char)(st.hist_p[0][1] - st.hist_p[2][1]) * ((int)st.hist_c[1][1] - 128)) -
+              ((int)(signed char)(st.hist_c[0][0] - st.hist_c[2][0]) * ((int)st.hist_p[1][0] - 128) +
+               (int)(signed char)(st.hist_c[0][1] - st.hist_c[2][1]) * ((int)st.hist_p[1][1] - 128));
+          float mucorr = (float)muerr * a.gain_mu;
+          const float max_mucorr = 0.1f;
+          if (mucorr < -max_mucorr) mucorr = -max_mucorr;
+          if (mucorr > max_mucorr) mucorr = max_mucorr;
+          mu += mucorr;
+          mu += a.omega;
+        }
+        mu = mu - 1;
+        phase = (unsigned)((long long)phase + freqw) & 0xffffu;
+      }
+      sh_nout += (unsigned long long)cnt;
+      if (symbol_arg && a.cstln) { a.cstln[2 * sh_nc] = (unsigned char)s_re; a.cstln[2 * sh_nc + 1] = (unsigned char)s_im; ++sh_nc; }
+      if (!a.allow_drift)
+        if (freqw < st.min_freqw || freqw > st.max_freqw) freqw = (st.max_freqw + st.min_freqw) / 2;
+      st.mu = mu; st.phase = phase; st.freqw = freqw;
+      st.meas_count += kChunk;
+      while (st.meas_count >= a.meas_decimation) {
+        st.meas_count -= a.meas_decimation;
+        if (a.freq) a.freq[sh_nf++] = (float)freqw / 65536;
+      }
+    }
+    pos += kChunk;
+    __syncthreads();
+  }
+  if (lane == 0) {
+    *a.state = st;
+    a.counters[0] = pos; a.counters[1] = sh_nout; a.counters[2] = sh_nf; a.counters[3] = sh_nc;
+  }
+}
+
+// ---------------------------------------------------------------- dvb_deconvol_sync<u8>
+constexpr int kDcBytes = 64, kDcSyms = 512;    // chunk_size bytes ↔ symbols, dvb.h:618
+__constant__ unsigned char c_hs_lut[4][4] = {{0, 1, 2, 3}, {2, 0, 3, 1}, {1, 0, 3, 2}, {0, 2, 1, 3}};   // dvb.h:676-699
+
+// One 32-bit output word of deconvol_poly2::run (convolutional.h:101-185): histI/histQ after each of its 32
+// symbols are windows of the remapped I/Q bit streams; `prev` = the 32 symbols before the word (may be carried).
+__device__ __forceinline__ void hs_word(const unsigned char *sym32, unsigned histI, unsigned histQ, const unsigned char *lut,
+                                        unsigned &wd, unsigned &we) {
+  const unsigned long long PD = 0x3baull, PE = 0x38f70ull;
+  wd = 0; we = 0;
+#pragma unroll
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned iq = lut[sym32[31 - bit] & 3u];
+    histI = (histI << 1) | (iq >> 1);
+    histQ = (histQ << 1) | (iq & 1u);
+    if (PD & (2ull << (2 * bit))) wd ^= histI;
+    if (PD & (1ull << (2 * bit))) wd ^= histQ;
+    if (PE & (2ull << (2 * bit))) we ^= histI;
+    if (PE & (1ull << (2 * bit))) we ^= histQ;
+  }
+}
+// history registers of alignment `lut` after the 32 symbols ending just before `p` (p[-32..-1])
+__device__ __forceinline__ void hs_hist(const unsigned char *p, const unsigned char *lut, unsigned &hI, unsigned &hQ) {
+  hI = 0; hQ = 0;
+#pragma unroll
+  for (int k = 32; k >= 1; --k) {
+    const unsigned iq = lut[p[-k] & 3u];
+    hI = (hI << 1) | (iq >> 1);
+    hQ = (hQ << 1) | (iq & 1u);
+  }
+}
+
+struct hsd_args {
+  const unsigned char *in;
+  unsigned char *out;
+  unsigned long long n_chunks;
+  int resync_period, resync_phase0, locked0;
+  unsigned carryI[4], carryQ[4];   // deconv state of every alignment at chunk 0
+  unsigned char *lock_of;          // [n_chunks] alignment in force while chunk c is decoded
+  int *errors;                     // [n_resync][4]
+};
+
+// (A) error counts of the four alignments on every resync chunk (second half of the chunk's words only,
+// convolutional.h:184 — independent of the stale history a non-locked alignment carries).
+__global__ __launch_bounds__(256) void k_hsd_errors(hsd_args a, unsigned long long n_resync) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;   // (resync chunk, alignment, word 8..15)
+  const unsigned long long r = idx >> 5;
+  if (r >= n_resync) return;
+  const int s = (int)((idx >> 3) & 3), w = 8 + (int)(idx & 7);
+  const unsigned long long first = (unsigned long long)((a.resync_period - a.resync_phase0) % a.resync_period);
+  const unsigned long long c = first + r * (unsigned long long)a.resync_period;
+  const unsigned char *p = a.in + c * kDcSyms + (unsigned)w * 32u;
+  unsigned hI, hQ, wd, we;
+  hs_hist(p, c_hs_lut[s], hI, hQ);      // w ≥ 8: the 32 symbols before the word are inside the chunk
+  hs_word(p, hI, hQ, c_hs_lut[s], wd, we);
+  atomicAdd(a.errors + r * 4 + s, __popc(we));
+}
+
+// (B) decode: one thread per output word with the alignment in force for its chunk.
+__global__ __launch_bounds__(256) void k_hsd_decode(hsd_args a) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long c = idx >> 4;
+  if (c >= a.n_chunks) return;
+  const int w = (int)(idx & 15);
+  const int s = a.lock_of[c];
+  const unsigned char *p = a.in + c * kDcSyms + (unsigned)w * 32u;
+  unsigned hI, hQ, wd, we;
+  if (c == 0 && w == 0) { hI = a.carryI[s]; hQ = a.carryQ[s]; }
+  else hs_hist(p, c_hs_lut[s], hI, hQ);
+  hs_word(p, hI, hQ, c_hs_lut[s], wd, we);
+  unsigned char *po = a.out + c * kDcBytes + (unsigned)w * 4u;
+  po[0] = (unsigned char)(wd >> 24); po[1] = (unsigned char)(wd >> 16); po[2] = (unsigned char)(wd >> 8); po[3] = (unsigned char)wd;
+}
+
+}  // namespace
+
+struct lsdr_fastqpsk {
+  lsdr_ctx *ctx;
+  float omega, min_omega, max_omega, pll_adjustment;
+  int allow_drift;
+  unsigned long meas_decimation;
+  fq_state st;
+  bool st_dirty_host;
+  fq_state *d_state;
+  unsigned *d_polar; unsigned short *d_rect, *d_sincos;
+  unsigned long long *d_counters;
+  float *d_freq; size_t freq_cap;
+  unsigned char *d_cstln; size_t cstln_cap;
+};
+
+struct lsdr_hsdeconv {
+  lsdr_ctx *ctx;
+  int resync_period, resync_phase, locked;
+  unsigned inI[4], inQ[4];
+  unsigned char *d_lock; int *d_err; size_t lock_cap, err_cap;
+};
+
+static void fq_update_freq_limits(lsdr_fastqpsk *r) {          // sdr.h:987-992
+  r->st.min_freqw = (long long)((float)r->st.freqw - 65536 / r->max_omega / 8);
+  r->st.max_freqw = (long long)((float)r->st.freqw + 65536 / r->max_omega / 8);
+}
+
+extern "C" {
+
+int lsdr_fastqpsk_create(lsdr_ctx *c, float omega, float freq, float pll_adjustment, int allow_drift, unsigned long meas_decimation,
+                         lsdr_fastqpsk **out) {
+  LSDR_ARG(c && out && omega > 0);
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_fastqpsk *r = new lsdr_fastqpsk();
+  r->ctx = c;
+  r->pll_adjustment = pll_adjustment; r->allow_drift = allow_drift;
+  r->meas_decimation = meas_decimation ? meas_decimation : 1048576;
+  memset(&r->st, 0, sizeof(r->st));
+  const float tol = 10e-6;                                       // set_omega, sdr.h:975-980
+  r->omega = omega; r->min_omega = omega * (1 - tol); r->max_omega = omega * (1 + tol);
+  r->st.freqw = (long long)(freq * 65536);                       // set_freq, sdr.h:982-985
+  fq_update_freq_limits(r);
+  if ((long long)(0.0012 * 256 * 65536 / (double)r->omega * (double)r->pll_adjustment) == 0) {
+    delete r;
+    lsdr_set_error("fast_qpsk_receiver: Excessive oversampling");   // fail() of sdr.h:1002
+    return LSDR_E_ARG;
+  }
+  std::vector<unsigned> polar(65536);
+  std::vector<unsigned short> rect(65536), sincos(65536);
+  lsdr::build_fastqpsk_tables(polar.data(), rect.data(), sincos.data());
+  LSDR_HIP(hipMalloc((void **)&r->d_polar, polar.size() * 4));
+  LSDR_HIP(hipMalloc((void **)&r->d_rect, rect.size() * 2));
+  LSDR_HIP(hipMalloc((void **)&r->d_sincos, sincos.size() * 2));
+  LSDR_HIP(hipMemcpy(r->d_polar, polar.data(), polar.size() * 4, hipMemcpyHostToDevice));
+  LSDR_HIP(hipMemcpy(r->d_rect, rect.data(), rect.size() * 2, hipMemcpyHostToDevice));
+  LSDR_HIP(hipMemcpy(r->d_sincos, sincos.data(), sincos.size() * 2, hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&r->d_state, sizeof(fq_state)));
+  LSDR_HIP(hipMalloc((void **)&r->d_counters, 4 * sizeof(unsigned long long)));
+  r->d_freq = nullptr; r->freq_cap = 0; r->d_cstln = nullptr; r->cstln_cap = 0;
+  r->st_dirty_host = true;
+  *out = r;
+  return LSDR_OK;
+}
+
+void lsdr_fastqpsk_destroy(lsdr_fastqpsk *r) {
+  if (!r) return;
+  (void)hipStreamSynchronize(r->ctx->stream);
+  (void)hipFree(r->d_polar); (void)hipFree(r->d_rect); (void)hipFree(r->d_sincos); (void)hipFree(r->d_state);
+  (void)hipFree(r->d_counters); (void)hipFree(r->d_freq); (void)hipFree(r->d_cstln);
+  delete r;
+}
+
+int lsdr_fastqpsk_get_state(const lsdr_fastqpsk *r, float *mu, unsigned *phase, long long *freqw, long long *min_freqw,
+                            long long *max_freqw) {
+  LSDR_ARG(r);
+  if (mu) *mu = r->st.mu;
+  if (phase) *phase = r->st.phase & 0xffffu;
+  if (freqw) *freqw = r->st.freqw;
+  if (min_freqw) *min_freqw = r->st.min_freqw;
+  if (max_freqw) *max_freqw = r->st.max_freqw;
+  return LSDR_OK;
+}
+
+int lsdr_fastqpsk_run(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
+                      size_t *produced, float *freq_out_host, size_t freq_cap, size_t *n_freq, lsdr_cu8 *cstln_out_host,
+                      size_t cstln_cap, size_t *n_cstln) {
+  LSDR_ARG(r && consumed && produced);
+  *consumed = 0; *produced = 0;
+  if (n_freq) *n_freq = 0;
+  if (n_cstln) *n_cstln = 0;
+  if (n_in < (size_t)(kChunk + 1) || cap_out < (size_t)kChunk) return LSDR_OK;
+  LSDR_ARG(in && out);
+  lsdr_ctx *c = r->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  const size_t max_chunks = n_in / kChunk;
+  const size_t need = max_chunks * kChunk / r->meas_decimation + 2, need_c = max_chunks + 1;
+  if (freq_out_host && r->freq_cap < need) {
+    (void)hipFree(r->d_freq);
+    LSDR_HIP(hipMalloc((void **)&r->d_freq, need * sizeof(float)));
+    r->freq_cap = need;
+  }
+  if (cstln_out_host && r->cstln_cap < need_c) {
+    (void)hipFree(r->d_cstln);
+    LSDR_HIP(hipMalloc((void **)&r->d_cstln, need_c * 2));
+    r->cstln_cap = need_c;
+  }
+  if (r->st_dirty_host) {
+    LSDR_HIP(hipMemcpyAsync(r->d_state, &r->st, sizeof(fq_state), hipMemcpyHostToDevice, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    r->st_dirty_host = false;
+  }
+  fq_args a;
+  a.in = (const unsigned char *)in; a.n_in = n_in; a.out = out; a.cap_out = cap_out;
+  a.state = r->d_state;
+  a.freq = freq_out_host ? r->d_freq : nullptr; a.freq_cap = freq_out_host ? (freq_cap < need ? freq_cap : need) : 0;
+  a.cstln = cstln_out_host ? r->d_cstln : nullptr; a.cstln_cap = cstln_out_host ? (cstln_cap < need_c ? cstln_cap : need_c) : 0;
+  a.counters = r->d_counters;
+  a.polar = r->d_polar; a.rect = r->d_rect; a.sincos = r->d_sincos;
+  a.omega = r->omega;
+  a.gain_mu = (float)(0.02 / (double)(75.0f * 75.0f) * 2);                                            // sdr.h:1004
+  a.freq_alpha = (long long)(0.04 * 65536);                                                            // sdr.h:999
+  a.freq_beta = (long long)(0.0012 * 256 * 65536 / (double)r->omega * (double)r->pll_adjustment);      // sdr.h:1000
+  a.meas_decimation = r->meas_decimation;
+  a.allow_drift = r->allow_drift;
+  hipLaunchKernelGGL(k_fastqpsk_serial, dim3(1), dim3(64), 0, c->stream, a);
+  LSDR_HIP(hipGetLastError());
+  unsigned long long cnt[4];
+  LSDR_HIP(hipMemcpyAsync(cnt, r->d_counters, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(fq_state), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  if (freq_out_host && cnt[2]) LSDR_HIP(hipMemcpy(freq_out_host, r->d_freq, cnt[2] * sizeof(float), hipMemcpyDeviceToHost));
+  if (cstln_out_host && cnt[3]) LSDR_HIP(hipMemcpy(cstln_out_host, r->d_cstln, cnt[3] * 2, hipMemcpyDeviceToHost));
+  *consumed = (size_t)cnt[0]; *produced = (size_t)cnt[1];
+  if (n_freq) *n_freq = (size_t)cnt[2];
+  if (n_cstln) *n_cstln = (size_t)cnt[3];
+  return LSDR_OK;
+}
+
+// ---------------------------------------------------------------- dvb_deconvol_sync<u8>
+int lsdr_hsdeconv_create(lsdr_ctx *c, int resync_period, lsdr_hsdeconv **out) {
+  LSDR_ARG(c && out && resync_period >= 1);
+  lsdr_hsdeconv *d = new lsdr_hsdeconv();
+  d->ctx = c; d->resync_period = resync_period; d->resync_phase = 0; d->locked = 0;
+  memset(d->inI, 0, sizeof(d->inI)); memset(d->inQ, 0, sizeof(d->inQ));
+  d->d_lock = nullptr; d->d_err = nullptr; d->lock_cap = 0; d->err_cap = 0;
+  *out = d;
+  return LSDR_OK;
+}
+void lsdr_hsdeconv_destroy(lsdr_hsdeconv *d) {
+  if (!d) return;
+  (void)hipStreamSynchronize(d->ctx->stream);
+  (void)hipFree(d->d_lock); (void)hipFree(d->d_err);
+  delete d;
+}
+int lsdr_hsdeconv_locked(const lsdr_hsdeconv *d) { return d ? d->locked : 0; }
+
+int lsdr_hsdeconv_run(lsdr_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
+                      size_t *produced) {
+  LSDR_ARG(d && consumed && produced);
+  *consumed = 0; *produced = 0;
+  size_t chunks = n_in / kDcSyms;                      // while in.readable() >= 512 && out.writable() >= 64, dvb.h:636-637
+  if (chunks > cap_out / kDcBytes) chunks = cap_out / kDcBytes;
+  if (!chunks) return LSDR_OK;
+  LSDR_ARG(in && out);
+  lsdr_ctx *c = d->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  const int P = d->resync_period, ph0 = d->resync_phase;
+  const size_t first = (size_t)((P - ph0) % P);
+  const size_t n_resync = first < chunks ? (chunks - first + P - 1) / P : 0;
+  if (d->lock_cap < chunks) {
+    (void)hipFree(d->d_lock);
+    LSDR_HIP(hipMalloc((void **)&d->d_lock, chunks));
+    d->lock_cap = chunks;
+  }
+  if (d->err_cap < n_resync * 4 + 4) {
+    (void)hipFree(d->d_err);
+    LSDR_HIP(hipMalloc((void **)&d->d_err, (n_resync * 4 + 4) * sizeof(int)));
+    d->err_cap = n_resync * 4 + 4;
+  }
+  hsd_args a;
+  a.in = in; a.out = out; a.n_chunks = chunks;
+  a.resync_period = P; a.resync_phase0 = ph0; a.locked0 = d->locked;
+  for (int s = 0; s < 4; ++s) { a.carryI[s] = d->inI[s]; a.carryQ[s] = d->inQ[s]; }
+  a.lock_of = d->d_lock; a.errors = d->d_err;
+  std::vector<int> err(n_resync * 4);
+  if (n_resync) {
+    LSDR_HIP(hipMemsetAsync(d->d_err, 0, n_resync * 4 * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_hsd_errors, dim3((unsigned)((n_resync * 32 + 255) / 256)), dim3(256), 0, c->stream, a,
+                       (unsigned long long)n_resync);
+    LSDR_HIP(hipGetLastError());
+    LSDR_HIP(hipMemcpyAsync(err.data(), d->d_err, err.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+  }
+  // alignment in force per chunk: `locked` changes after a resync chunk to the first arg-min of its error counts
+  std::vector<unsigned char> lock_of(chunks);
+  int locked = d->locked;
+  size_t r = 0;
+  for (size_t cc = 0; cc < chunks; ++cc) {
+    lock_of[cc] = (unsigned char)locked;
+    if (r < n_resync && cc == first + r * (size_t)P) {
+      int best = 0, eb = 1 << 30;
+      for (int s = 0; s < 4; ++s) if (err[r * 4 + s] < eb) { eb = err[r * 4 + s]; best = s; }
+      locked = best;
+      ++r;
+    }
+  }
+  LSDR_HIP(hipMemcpyAsync(d->d_lock, lock_of.data(), chunks, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_hsd_decode, dim3((unsigned)((chunks * 16 + 255) / 256)), dim3(256), 0, c->stream, a);
+  LSDR_HIP(hipGetLastError());
+  // carried deconv state (inI/inQ) of every alignment = remapped last 32 symbols of the last chunk IT processed:
+  // the locked one processed every chunk, the others the last resync chunk of this call (if any).
+  std::vector<unsigned char> tail(32);
+  auto hist_of = [&](size_t chunk, int s) -> int {
+    LSDR_HIP(hipMemcpyAsync(tail.data(), in + (chunk + 1) * kDcSyms - 32, 32, hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    static const unsigned char luts[4][4] = {{0, 1, 2, 3}, {2, 0, 3, 1}, {1, 0, 3, 2}, {0, 2, 1, 3}};
+    unsigned hI = 0, hQ = 0;
+    for (int k = 0; k < 32; ++k) { const unsigned iq = luts[s][tail[k] & 3]; hI = (hI << 1) | (iq >> 1); hQ = (hQ << 1) | (iq & 1); }
+    d->inI[s] = hI; d->inQ[s] = hQ;
+    return LSDR_OK;
+  };
+  // Which chunk did each alignment process last?  Alignment s processes chunk cc iff cc is a resync chunk or s == lock_of[cc].
+  for (int s = 0; s < 4; ++s) {
+    long long last = -1;
+    for (long long cc = (long long)chunks - 1; cc >= 0; --cc) {
+      const bool resync = (size_t)cc >= first && ((size_t)cc - first) % (size_t)P == 0;
+      if (resync || lock_of[cc] == s) { last = cc; break; }
+    }
+    if (last >= 0) { int rc = hist_of((size_t)last, s); if (rc) return rc; }
+  }
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  d->locked = locked;
+  d->resync_phase = (int)(((size_t)ph0 + chunks) % (size_t)P);
+  *consumed = chunks * kDcSyms;
+  *produced = chunks * kDcBytes;
+  return LSDR_OK;
+}
+
+}  // extern "C"

@@ -47,4 +47,7 @@ struct cstln_tables {
   std::vector<uint8_t> symbol;
 };
 int build_cstln(int predef, int fec, cstln_tables &t);
+// fast_qpsk_receiver::init_lookup_tables (sdr.h:1154-1171), packed: polar[re*256+im] = a | r<<16,
+// rect[a*256+r] = re | im<<8, sincos[a] = re | im<<8.
+void build_fastqpsk_tables(unsigned *polar, unsigned short *rect, unsigned short *sincos);
 }  // namespace lsdr

@@ -163,6 +163,7 @@ typedef struct lo_mpeg_sync lo_mpeg_sync;                 /* mpeg_sync<u8,0>, dv
 lo_mpeg_sync *lo_mpeg_sync_new(int fastlock);
 void lo_mpeg_sync_free(lo_mpeg_sync *m);
 int lo_mpeg_sync_locked(const lo_mpeg_sync *m);
+void lo_mpeg_sync_set_resync_period(lo_mpeg_sync *m, int p);   /* public member, dvb.h:717 */
 size_t lo_mpeg_sync_run(lo_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed,
                         int *state_out, size_t state_cap, size_t *n_state,
                         unsigned long *locktime_out, size_t lt_cap, size_t *n_lt, int *call_next_sync);
@@ -179,6 +180,22 @@ size_t lo_derandomizer_run(lo_derandomizer *d, const uint8_t *in, size_t npacket
 /* symbols → TS packets, the tail of leandvb.cc:519-596 */
 size_t lo_fec_chain(int cstln, int rate, int viterbi, int fastlock, const lo_softsymbol *sym, size_t n,
                     uint8_t *ts_out, size_t cap_packets, long *bits, long *errs);
+
+/* ---- `--hs` path (lsdr_oracle_hs.c) ------------------------------------------------------ */
+typedef struct lo_fastqpsk lo_fastqpsk;                   /* fast_qpsk_receiver<u8>, sdr.h:946-1189 */
+lo_fastqpsk *lo_fastqpsk_new(float omega, float freq, float pll_adjustment, int allow_drift, unsigned long meas_decimation);
+void lo_fastqpsk_free(lo_fastqpsk *r);
+void lo_fastqpsk_set_omega(lo_fastqpsk *r, float omega);
+void lo_fastqpsk_set_freq(lo_fastqpsk *r, float freq);
+void lo_fastqpsk_tables(const lo_fastqpsk *r, uint16_t *polar_a, uint8_t *polar_r, uint8_t *rect, uint8_t *sincos);
+void lo_fastqpsk_get_state(const lo_fastqpsk *r, float *mu, unsigned *phase, long *freqw, long *min_freqw, long *max_freqw);
+size_t lo_fastqpsk_run(lo_fastqpsk *r, const lo_cu8 *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed,
+                       float *freq_out, size_t freq_cap, size_t *n_freq, lo_cu8 *cstln_out, size_t cstln_cap, size_t *n_cstln);
+typedef struct lo_hsdeconv lo_hsdeconv;                   /* dvb_deconvol_sync<u8>, dvb.h:612-707 */
+lo_hsdeconv *lo_hsdeconv_new(int resync_period);
+void lo_hsdeconv_free(lo_hsdeconv *d);
+int lo_hsdeconv_locked(const lo_hsdeconv *d);
+size_t lo_hsdeconv_run(lo_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed);
 
 #ifdef __cplusplus
 }

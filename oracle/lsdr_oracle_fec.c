@@ -386,6 +386,7 @@ lo_mpeg_sync *lo_mpeg_sync_new(int fastlock) {
   return m;
 }
 void lo_mpeg_sync_free(lo_mpeg_sync *m) { free(m); }
+void lo_mpeg_sync_set_resync_period(lo_mpeg_sync *m, int p) { m->resync_period = p; }
 int lo_mpeg_sync_locked(const lo_mpeg_sync *m) { return m->synchronized; }
 
 typedef struct { const uint8_t *in; size_t n_in, pos; uint8_t *out; size_t cap, nout; int *st; size_t st_cap, nst;

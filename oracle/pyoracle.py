@@ -265,6 +265,70 @@ class Oracle:
         self.lib.lo_spectrum_free(h)
         return out[:n]
 
+    def fast_qpsk(self, iq_u8, omega, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=0, return_tables=False):
+        """fast_qpsk_receiver<u8> over an interleaved u8 I/Q array.  Returns dict(sym, consumed, freq, cstln, mu, phase, freqw)."""
+        iq = np.ascontiguousarray(iq_u8, np.uint8)
+        n = len(iq) // 2
+        L = self.lib
+        L.lo_fastqpsk_new.restype = C.c_void_p
+        L.lo_fastqpsk_new.argtypes = [c_f, c_f, c_f, C.c_int, C.c_ulong]
+        L.lo_fastqpsk_free.argtypes = [C.c_void_p]
+        L.lo_fastqpsk_run.restype = c_sz
+        L.lo_fastqpsk_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p, c_sz, C.POINTER(c_sz), C.c_void_p, c_sz, C.POINTER(c_sz), C.c_void_p, c_sz, C.POINTER(c_sz)]
+        L.lo_fastqpsk_get_state.argtypes = [C.c_void_p, C.POINTER(c_f), C.POINTER(C.c_uint), C.POINTER(C.c_long), C.POINTER(C.c_long), C.POINTER(C.c_long)]
+        L.lo_fastqpsk_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 4
+        h = L.lo_fastqpsk_new(omega, freq, pll_adjustment, allow_drift, meas_decimation)
+        out = np.empty(n + 256, np.uint8)
+        fo = np.empty(n // 64 + 16, np.float32)
+        co = np.empty((n // 64 + 16, 2), np.uint8)
+        cons, nf, nc = c_sz(), c_sz(), c_sz()
+        k = L.lo_fastqpsk_run(h, _p(iq), n, _p(out), len(out), C.byref(cons), _p(fo), len(fo), C.byref(nf), _p(co), len(co), C.byref(nc))
+        mu, ph, fw, mn, mx = c_f(), C.c_uint(), C.c_long(), C.c_long(), C.c_long()
+        L.lo_fastqpsk_get_state(h, C.byref(mu), C.byref(ph), C.byref(fw), C.byref(mn), C.byref(mx))
+        res = dict(sym=out[:k].copy(), consumed=cons.value, freq=fo[:nf.value].copy(), cstln=co[:nc.value].copy(),
+                   mu=mu.value, phase=ph.value, freqw=fw.value, min_freqw=mn.value, max_freqw=mx.value)
+        if return_tables:
+            pa, pr = np.empty(65536, np.uint16), np.empty(65536, np.uint8)
+            re, sc = np.empty((256, 256, 2), np.uint8), np.empty((65536, 2), np.uint8)
+            L.lo_fastqpsk_tables(h, _p(pa), _p(pr), _p(re), _p(sc))
+            res.update(polar_a=pa, polar_r=pr, rect=re, sincos=sc)
+        L.lo_fastqpsk_free(h)
+        return res
+
+    def hs_chain(self, iq_u8, omega, fastlock=0):
+        """leandvb --hs (leandvb.cc:727-969): fast_qpsk_receiver → dvb_deconvol_sync_hard → mpeg_sync(fastlock, resync) →
+        deinterleaver → rs_decoder → derandomizer.  Returns TS packets."""
+        sym = self.fast_qpsk(iq_u8, omega)["sym"]
+        by = self.hs_deconvol(sym, 1 if fastlock else 32)
+        mb = self.mpeg_sync(by, fastlock=1, resync_period=1 if fastlock else 32)[0]
+        pk = self.deinterleaver(mb)
+        ts = self.rs_decoder(pk)[0]
+        return self.derandomizer(ts)
+
+    def hs_deconvol(self, symbols, resync_period=32, pipe=None, room=None):
+        """dvb_deconvol_sync<u8> over hard symbols; optional call pattern (pipe symbols per call, room bytes)."""
+        sym = np.ascontiguousarray(symbols, np.uint8)
+        L = self.lib
+        L.lo_hsdeconv_new.restype = C.c_void_p
+        L.lo_hsdeconv_new.argtypes = [C.c_int]
+        L.lo_hsdeconv_free.argtypes = [C.c_void_p]
+        L.lo_hsdeconv_run.restype = c_sz
+        L.lo_hsdeconv_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p, c_sz, C.POINTER(c_sz)]
+        h = L.lo_hsdeconv_new(resync_period)
+        out = np.empty(len(sym) // 8 + 64, np.uint8)
+        pos = nout = 0
+        while True:
+            c = c_sz()
+            avail = len(sym) - pos if pipe is None else min(pipe, len(sym) - pos)
+            cap = len(out) - nout if room is None else min(room, len(out) - nout)
+            k = L.lo_hsdeconv_run(h, sym[pos:].ctypes.data, avail, out[nout:].ctypes.data, cap, C.byref(c))
+            if not k:
+                break
+            pos += c.value
+            nout += k
+        L.lo_hsdeconv_free(h)
+        return out[:nout].copy()
+
     def rx(self, params, x, state_in=None, chunks=None):
         """Run cstln_receiver over x.  Returns dict(sym, consumed, freq, ss, mer, cstln, state)."""
         x = cf32(x)
@@ -338,9 +402,12 @@ class Oracle:
         self.lib.lo_viterbi_free(h)
         return out[:n].copy(), c.value, cur
 
-    def mpeg_sync(self, data, fastlock=0):
+    def mpeg_sync(self, data, fastlock=0, resync_period=0):
         data = np.ascontiguousarray(data, np.uint8)
         h = self.lib.lo_mpeg_sync_new(fastlock)
+        if resync_period:
+            self.lib.lo_mpeg_sync_set_resync_period.argtypes = [C.c_void_p, C.c_int]
+            self.lib.lo_mpeg_sync_set_resync_period(h, resync_period)
         out = np.empty(len(data) + 4096, np.uint8)
         st = np.empty(len(data) // 204 + 64, np.int32)
         lt = np.empty(len(data) // 204 + 64, np.uint64)
@@ -605,6 +672,37 @@ class Ref:
         out = np.empty((len(x) // 1024 + 1, 1024), np.float32)
         n = self.lib.ref_spectrum(decimation, kavg, _p(x), len(x), _p(out), len(out))
         return out[:n]
+
+    def fast_qpsk(self, iq_u8, omega, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=0, return_tables=False):
+        iq = np.ascontiguousarray(iq_u8, np.uint8)
+        n = len(iq) // 2
+        L = self.lib
+        L.ref_fast_qpsk.restype = C.c_long
+        L.ref_fast_qpsk.argtypes = [c_f, c_f, c_f, C.c_int, C.c_ulong, C.c_void_p, C.c_long, C.c_void_p, C.c_long, C.c_void_p, C.c_long,
+                                    C.POINTER(C.c_long), C.c_void_p, C.c_long, C.POINTER(C.c_long), C.POINTER(c_f), C.POINTER(C.c_uint),
+                                    C.POINTER(C.c_long), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        out = np.empty(n + 256, np.uint8)
+        fo = np.empty(n // 64 + 16, np.float32)
+        co = np.empty((n // 64 + 16, 2), np.uint8)
+        nf, nc = C.c_long(), C.c_long()
+        mu, ph, fw = c_f(), C.c_uint(), C.c_long()
+        pa, pr = np.empty(65536, np.uint16), np.empty(65536, np.uint8)
+        re, sc = np.empty((256, 256, 2), np.uint8), np.empty((65536, 2), np.uint8)
+        k = L.ref_fast_qpsk(omega, freq, pll_adjustment, allow_drift, meas_decimation, _p(iq), n, _p(out), len(out), _p(fo), len(fo),
+                            C.byref(nf), _p(co), len(co), C.byref(nc), C.byref(mu), C.byref(ph), C.byref(fw), _p(pa), _p(pr), _p(re), _p(sc))
+        res = dict(sym=out[:k].copy(), freq=fo[:nf.value].copy(), cstln=co[:nc.value].copy(), mu=mu.value, phase=ph.value, freqw=fw.value)
+        if return_tables:
+            res.update(polar_a=pa, polar_r=pr, rect=re, sincos=sc)
+        return res
+
+    def hs_deconvol(self, symbols, resync_period=32):
+        sym = np.ascontiguousarray(symbols, np.uint8)
+        L = self.lib
+        L.ref_hs_deconvol.restype = C.c_long
+        L.ref_hs_deconvol.argtypes = [C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        out = np.empty(len(sym) // 8 + 64, np.uint8)
+        k = L.ref_hs_deconvol(resync_period, _p(sym), len(sym), _p(out), len(out))
+        return out[:k].copy()
 
     def rx(self, params, x):
         x = cf32(x)

@@ -397,6 +397,53 @@ long ref_deconvol_sync(int rate, int fastlock, int next_syncs, const uint8_t *sy
   return w.pos;
 }
 
+// sdr.h:946-1189  fast_qpsk_receiver<u8>  (leandvb --hs, leandvb.cc:806-823)
+long ref_fast_qpsk(float omega, float freq, float pll_adjustment, int allow_drift, unsigned long meas_decimation,
+                   const uint8_t *in /*cu8*/, long n, uint8_t *out, long cap, float *freq_out, long freq_cap, long *n_freq,
+                   uint8_t *cstln_out /*cu8*/, long cstln_cap, long *n_cstln, float *mu_out, unsigned *phase_out,
+                   long *freqw_out, uint16_t *polar_a, uint8_t *polar_r, uint8_t *rect, uint8_t *sincos) {
+  scheduler sch;
+  pipebuf<cu8> p_in(&sch, "in", BUF_BASEBAND);
+  pipebuf<u8> p_out(&sch, "out", BUF_SYMBOLS);
+  pipebuf<f32> p_freq(&sch, "freq", 4096);
+  pipebuf<cu8> p_cstln(&sch, "cstln", 4096);
+  buffer_reader<cu8> r(&sch, (cu8 *)in, n, p_in);
+  fast_qpsk_receiver<u8> *d = new fast_qpsk_receiver<u8>(&sch, p_in, p_out, &p_freq, &p_cstln);
+  if (omega) d->set_omega(omega);
+  if (freq) d->set_freq(freq);
+  d->pll_adjustment = pll_adjustment;
+  d->allow_drift = allow_drift != 0;
+  if (meas_decimation) d->meas_decimation = meas_decimation;
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  buffer_writer<f32> wf(&sch, p_freq, freq_out, freq_cap);
+  buffer_writer<cu8> wc(&sch, p_cstln, (cu8 *)cstln_out, cstln_cap);
+  sch.run();
+  *n_freq = wf.pos; *n_cstln = wc.pos;
+  if (mu_out) *mu_out = d->mu;
+  if (phase_out) *phase_out = d->phase;
+  if (freqw_out) *freqw_out = d->freqw;
+  if (polar_a)
+    for (int i = 0; i < 256; ++i) for (int q = 0; q < 256; ++q) { polar_a[i * 256 + q] = d->lut_polar[i][q].a; polar_r[i * 256 + q] = d->lut_polar[i][q].r; }
+  if (rect) memcpy(rect, d->lut_rect, sizeof(d->lut_rect));
+  if (sincos) memcpy(sincos, d->lut_sincos, sizeof(d->lut_sincos));
+  long nout = w.pos;
+  delete d;
+  return nout;
+}
+
+// dvb.h:612-707  dvb_deconvol_sync<u8>  (leandvb --hs, leandvb.cc:846-853)
+long ref_hs_deconvol(int resync_period, const uint8_t *symbols, long n, uint8_t *out, long cap) {
+  scheduler sch;
+  pipebuf<u8> p_in(&sch, "in", BUF_SYMBOLS);
+  pipebuf<u8> p_out(&sch, "out", BUF_BYTES);
+  buffer_reader<u8> r(&sch, (u8 *)symbols, n, p_in);
+  dvb_deconvol_sync_hard d(&sch, p_in, p_out);
+  d.resync_period = resync_period;
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  sch.run();
+  return w.pos;
+}
+
 // dvb.h:1173-1416  viterbi_sync
 long ref_viterbi_sync(int cstln, int rate, int resync_period, const int16_t *cost, const uint8_t *symbol, long n,
                       uint8_t *out, long cap, int *final_sync) {
