@@ -25,9 +25,13 @@ def test_two_ranks_gloo(tmp_path):
         print(json.dumps(dict(rank=s.rank, seed=s.capture_seed(), total=total, dt=dt, rate=rate)), flush=True)
         s.close()
     """))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    import socket
+    with socket.socket() as sk:          # a free port: fixed ones collide with a rendezvous still in TIME_WAIT
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29577", str(script)],
+                        "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=280)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     import json
