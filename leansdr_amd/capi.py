@@ -106,6 +106,8 @@ _sig("lsdr_mpeg_sync_set_resync_period", C.c_int, [vp, C.c_int])
 _sig("lsdr_fastqpsk_create", C.c_int, [vp, c_f, c_f, c_f, C.c_int, C.c_ulong, C.POINTER(vp)])
 _sig("lsdr_fastqpsk_destroy", None, [vp])
 _sig("lsdr_fastqpsk_get_state", C.c_int, [vp, C.POINTER(c_f), C.POINTER(C.c_uint), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)])
+_sig("lsdr_fastqpsk_set_tiled", C.c_int, [vp, C.c_int, C.c_uint, C.c_uint])
+_sig("lsdr_fastqpsk_tiled_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
 _sig("lsdr_fastqpsk_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_hsdeconv_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
 _sig("lsdr_hsdeconv_destroy", None, [vp])
@@ -687,11 +689,22 @@ class AutoNotch:
 class FastQpsk:
     """fast_qpsk_receiver<u8> (sdr.h:946-1189), the --hs receiver."""
 
-    def __init__(self, ctx, omega, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=0):
+    def __init__(self, ctx, omega, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=0, tiled=False, tile_len=0,
+                 tile_warmup=0):
         self.ctx = ctx
         h = vp()
         check(lib.lsdr_fastqpsk_create(ctx.h, omega, freq, pll_adjustment, allow_drift, meas_decimation, C.byref(h)))
         self.h = h
+        if tiled:
+            check(lib.lsdr_fastqpsk_set_tiled(h, 1, tile_len, tile_warmup))
+
+    def set_tiled(self, enable, tile_len=0, tile_warmup=0):
+        check(lib.lsdr_fastqpsk_set_tiled(self.h, int(enable), tile_len, tile_warmup))
+
+    def tiled_stats(self):
+        t, d, m, b = C.c_uint(), C.c_uint(), C.c_uint(), C.c_uint()
+        check(lib.lsdr_fastqpsk_tiled_stats(self.h, C.byref(t), C.byref(d), C.byref(m), C.byref(b)))
+        return dict(tiles=t.value, dup=d.value, miss=m.value, bad_seams=b.value)
 
     def close(self):
         if self.h:

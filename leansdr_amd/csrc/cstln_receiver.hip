@@ -413,20 +413,18 @@ __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
 
 
 // ---------------------------------------------------------------- LSDR_RX_TILED
-struct rx_tile_info {         // per tile, written by k_rx_tiles, reconciled on the host
-  float mu_begin, phase_begin;   // state at the start of the tile body (after warm-up)
-  float mu_end, phase_end;       // state at the end of the tile body
-  unsigned count;                // symbols emitted in the body
-  lsdr_softsymbol pre;           // last symbol of the warm-up (needed when a seam loses a symbol)
-  unsigned has_pre;
-};
+// hooks of rx_tiling.h for this receiver
+struct rx_state_dev;
+__device__ __forceinline__ lsdr_softsymbol rx_relabel(lsdr_softsymbol v, const uint8_t *map) { v.symbol = map[v.symbol]; return v; }
+__device__ __forceinline__ unsigned rx_symbol_of(lsdr_softsymbol v) { return v.symbol; }
+__device__ __forceinline__ float fmod65536(float x);
+__device__ __forceinline__ void rx_rotate_back(rx_state_dev *st, unsigned rot, float quad);
+#include "rx_tiling.h"
+typedef rx_tile_info_t<lsdr_softsymbol> rx_tile_info;
 
-struct rx_tile_fix {          // per tile, produced by the host seam pass
-  unsigned long long out_offset; // where the tile's (fixed-up) symbols start in the output
-  unsigned rot;                  // quadrant correction (index into the relabel table)
-  unsigned drop_first;           // 1: first body symbol duplicates the previous tile's last
-  unsigned insert_pre;           // 1: the warm-up's last symbol belongs to this tile
-};
+__device__ __forceinline__ void rx_rotate_back(rx_state_dev *st, unsigned rot, float quad) {
+  st->phase = fmod65536(st->phase - rot * quad);
+}
 
 struct rx_tiled_args {
   const float2 *in;
@@ -436,6 +434,8 @@ struct rx_tiled_args {
   unsigned lanes_per_wave;             // active lanes (tiles) per wavefront
   unsigned stage_stride;               // symbols reserved per tile in `stage`
   lsdr_softsymbol *stage;
+  lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
+  unsigned wstride;
   rx_tile_info *info;
   rx_state_dev *state;                 // in: carried state; out: end state of the last tile
   rx_meas *meas;                       // [n_meas] measurement slots (may be null)
@@ -462,8 +462,9 @@ __device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, unsigned j
   if (c1 > total) c1 = total;
   rx_state_dev s = *a.state;
   rx_tile_info ti;
-  ti.has_pre = 0; ti.pre.cost = 0; ti.pre.symbol = 0; ti.pre.pad = 0;
+  ti.has_pre = 0; ti.pre.cost = 0; ti.pre.symbol = 0; ti.pre.pad = 0; ti.n_warm = 0;
   ti.mu_begin = ti.phase_begin = 0.f;
+  lsdr_softsymbol *pw = a.wstage + (unsigned long long)j * a.wstride;
   if (j > 0) {
     s.mu = 0.f; s.phase = 0.f;
     for (int k = 0; k < 12; ++k) s.hist[k] = 0.f;
@@ -479,9 +480,13 @@ __device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, unsigned j
     }
     if (SAMP == 1) s.samp_freqw = s.freqw;
     bool wrote;
+    const bool lastwarm = c + 1 == c0;
+    unsigned nw = 0;
     const int n = rx_chunk<SAMP, LD>(a.T, a.C, s, a.in + c * kChunk,
-                                     [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else last = ss; }, nullptr, &wrote);
+                                     [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else { last = ss; if (lastwarm) pw[nw++] = ss; } },
+                                     nullptr, &wrote);
     if (!body) got += (unsigned)n;
+    if (lastwarm) ti.n_warm = nw;
     if (body && a.meas) {     // measurements, sdr.h:905-913: one per meas_decimation samples of the stream
       unsigned long long before = (a.meas_base + c * kChunk) / a.C.meas_decimation;
       unsigned long long after = (a.meas_base + (c + 1) * kChunk) / a.C.meas_decimation;
@@ -506,132 +511,6 @@ __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
   else rx_tiles_body<SAMP, NT, ld_hwtrig>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
 }
 
-// Seam pass: reconciles neighbouring tiles on the device.
-//  * carrier quadrant: tile j locked k_j·(65536/R) away from where tile j−1 ended → running
-//    rotation (prefix sum mod R) used to relabel its symbols;
-//  * symbol timing: mu at the start of tile j vs mu at the end of tile j−1 differ by ≈ ±omega
-//    when the two tiles disagree on which side of the boundary one symbol instant falls →
-//    drop the duplicate / insert the lost symbol (the warm-up's last symbol);
-//  * output offsets: exclusive prefix sum of the adjusted counts.
-struct rx_seam_result { unsigned long long total; unsigned rot_final, ndup, nmiss, nbad; };
-
-struct seam_step { unsigned insert, drop, k, bad; };
-
-__device__ __forceinline__ seam_step seam_eval(const rx_tile_info &prev, const rx_tile_info &cur, float omega, int R,
-                                               float quad) {
-  seam_step r; r.insert = 0; r.drop = 0; r.bad = 0;
-  const float d = cur.mu_begin - prev.mu_end;
-  if (d > omega / 2 && cur.has_pre) r.insert = 1;
-  else if (d < -omega / 2 && cur.count > 0) r.drop = 1;
-  float dphi = fmodf(cur.phase_begin - prev.phase_end, 65536.0f);
-  if (dphi < 0) dphi += 65536.0f;
-  const int k = (int)floorf(dphi / quad + 0.5f);
-  const float perr = fabsf(dphi - k * quad);
-  float dm = fabsf(d);
-  if (fabsf(dm - omega) < dm) dm = fabsf(dm - omega);
-  if (perr > quad / 4 || dm > 0.5f) r.bad = 1;
-  r.k = (unsigned)(k % R);
-  return r;
-}
-
-// Seam pass, two kernels, no single-workgroup scan:
-//  k_rx_seam     one block per 1024 consecutive tiles: evaluates the seams, block-local exclusive scan of
-//                (symbol count, quadrant step) → fix[] holds block-local offsets, part[] the block totals;
-//  k_rx_compact  one wavefront per tile: adds the (≤ a few dozen) preceding block totals, applies the seam
-//                fix-ups and the quadrant relabelling while copying the tile's symbols to their final place.
-//                Block 0 also leaves the run's totals in *res and rotates the carried carrier phase back into
-//                the frame of tile 0, so the next queued run continues with the same symbol labelling.
-struct rx_seam_part { unsigned long long cnt; unsigned rot, ndup, nmiss, nbad; };
-
-__global__ __launch_bounds__(1024) void k_rx_seam(const rx_tile_info *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
-                                                  int R, float quad, rx_seam_part *part) {
-  const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
-  __shared__ unsigned long long s_cnt[16];
-  __shared__ unsigned s_rot[16], s_d[16], s_m[16], s_b[16];
-  const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const unsigned j = blockIdx.x * 1024 + tid;
-  long long add = 0;
-  unsigned k = 0, ins = 0, drp = 0, bad = 0;
-  if (j < n_tiles) {
-    const rx_tile_info cur = info[j];
-    add = (long long)cur.count;
-    if (j > 0) {
-      const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad);
-      add += (long long)st.insert - (long long)st.drop;
-      k = st.k; ins = st.insert; drp = st.drop; bad = st.bad;
-    }
-  }
-  long long icnt = add;
-  unsigned irot = k, nd = drp, nm = ins, nb = bad;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const long long oc = __shfl_up(icnt, d, 64);
-    const unsigned orot = __shfl_up(irot, d, 64);
-    if (lane >= (unsigned)d) { icnt += oc; irot = (irot + orot) & rmask; }
-  }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_down(nd, d, 64); nm += __shfl_down(nm, d, 64); nb += __shfl_down(nb, d, 64); }
-  if (lane == 63) { s_cnt[wv] = (unsigned long long)icnt; s_rot[wv] = irot; }
-  if (lane == 0) { s_d[wv] = nd; s_m[wv] = nm; s_b[wv] = nb; }
-  __syncthreads();
-  unsigned long long woff = 0;
-  unsigned wrot = 0;
-  for (unsigned i = 0; i < wv; ++i) { woff += s_cnt[i]; wrot = (wrot + s_rot[i]) & rmask; }
-  if (j < n_tiles) {
-    rx_tile_fix f;
-    f.out_offset = woff + (unsigned long long)(icnt - add);   // exclusive, block-local
-    f.rot = (wrot + irot) & rmask;                            // inclusive, block-local
-    f.drop_first = drp; f.insert_pre = ins;
-    fix[j] = f;
-  }
-  if (tid == 0) {
-    rx_seam_part p; p.cnt = 0; p.rot = 0; p.ndup = 0; p.nmiss = 0; p.nbad = 0;
-    for (int i = 0; i < 16; ++i) { p.cnt += s_cnt[i]; p.rot = (p.rot + s_rot[i]) & rmask; p.ndup += s_d[i]; p.nmiss += s_m[i]; p.nbad += s_b[i]; }
-    part[blockIdx.x] = p;
-  }
-}
-
-__global__ __launch_bounds__(64) void k_rx_compact(const lsdr_softsymbol *stage, unsigned stage_stride,
-                                                   const rx_tile_info *info, const rx_tile_fix *fix, const rx_seam_part *part,
-                                                   const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles, int R, float quad,
-                                                   lsdr_softsymbol *out, rx_state_dev *state, rx_seam_result *res) {
-  const unsigned j = blockIdx.x;
-  if (j >= n_tiles) return;
-  const unsigned rmask = (unsigned)R - 1;
-  const unsigned nparts = (n_tiles + 1023) / 1024, mypart = j / 1024;
-  // preceding block totals (lane-parallel, then wave-reduced; nparts is tiny)
-  unsigned long long base = 0;
-  unsigned brot = 0;
-  for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
-  if (j == 0 && threadIdx.x == 0) {
-    rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0;
-    for (unsigned i = 0; i < nparts; ++i) {
-      sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
-      sr.ndup += part[i].ndup; sr.nmiss += part[i].nmiss; sr.nbad += part[i].nbad;
-    }
-    *res = sr;                 // host-pinned ring slot
-    __threadfence_system();
-    if (sr.rot_final) state->phase = fmod65536(state->phase - sr.rot_final * quad);
-  }
-  const rx_tile_fix f = fix[j];
-  const rx_tile_info ti = info[j];
-  const uint8_t *map = relabel + ((f.rot + brot) & rmask) * 256;
-  const lsdr_softsymbol *src = stage + (unsigned long long)j * stage_stride;
-  lsdr_softsymbol *dst = out + base + f.out_offset;
-  if (f.insert_pre) {
-    if (threadIdx.x == 0) { lsdr_softsymbol p = ti.pre; p.symbol = map[p.symbol]; dst[0] = p; }
-    dst += 1;
-  }
-  const unsigned skip = f.drop_first ? 1u : 0u;
-  for (unsigned k = threadIdx.x + skip; k < ti.count; k += 64) {
-    lsdr_softsymbol v = src[k];
-    v.symbol = map[v.symbol];
-    dst[k - skip] = v;
-  }
-}
-
 }  // namespace
 
 struct lsdr_rx {
@@ -654,6 +533,7 @@ struct lsdr_rx {
   float2 *d_cstln; size_t cstln_cap;
   // tiled mode
   lsdr_softsymbol *d_stage; size_t stage_cap;
+  lsdr_softsymbol *d_wstage; size_t wstage_cap;
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
   uint8_t *d_relabel;
   struct rx_seam_result *d_seam;
@@ -771,7 +651,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
   const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
 
-  if (r->tiles_cap < n_tiles || r->stage_cap < (size_t)n_tiles * stage_stride) {
+  if (r->tiles_cap < n_tiles || r->stage_cap < (size_t)n_tiles * stage_stride || r->wstage_cap < (size_t)n_tiles * sym_per_chunk) {
     // scratch grows: queued runs may still be using the old buffers
     LSDR_HIP(hipStreamSynchronize(c->stream));
   }
@@ -786,6 +666,11 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
     (void)hipFree(r->d_stage);
     LSDR_HIP(hipMalloc((void **)&r->d_stage, (size_t)n_tiles * stage_stride * sizeof(lsdr_softsymbol)));
     r->stage_cap = (size_t)n_tiles * stage_stride;
+  }
+  if (r->wstage_cap < (size_t)n_tiles * sym_per_chunk) {
+    (void)hipFree(r->d_wstage);
+    LSDR_HIP(hipMalloc((void **)&r->d_wstage, (size_t)n_tiles * sym_per_chunk * sizeof(lsdr_softsymbol)));
+    r->wstage_cap = (size_t)n_tiles * sym_per_chunk;
   }
   const unsigned long long md = r->cfg.meas_decimation;
   const unsigned long long meas_base = r->st.meas_count;   // kept current on the host even while `st` is stale
@@ -807,6 +692,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   a.n_tiles = n_tiles;
   a.stage_stride = stage_stride;
   a.stage = r->d_stage;
+  a.wstage = r->d_wstage; a.wstride = sym_per_chunk;
   a.info = r->d_info;
   a.state = r->d_state;
   a.meas = want_meas ? r->d_meas : nullptr;
@@ -835,9 +721,11 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  hipLaunchKernelGGL(k_rx_seam, dim3((n_tiles + 1023) / 1024), dim3(1024), 0, c->stream, (const rx_tile_info *)r->d_info,
-                     r->d_fix, n_tiles, r->omega, R, quad, r->d_part);
-  hipLaunchKernelGGL(k_rx_compact, dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
+  hipLaunchKernelGGL((k_rx_seam<rx_tile_info, lsdr_softsymbol>), dim3((n_tiles + 1023) / 1024), dim3(1024), 0, c->stream,
+                     (const rx_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, R, quad, r->d_part,
+                     (const lsdr_softsymbol *)r->d_stage, stage_stride, (const lsdr_softsymbol *)r->d_wstage, sym_per_chunk,
+                     (const uint8_t *)r->d_relabel);
+  hipLaunchKernelGGL((k_rx_compact<lsdr_softsymbol, rx_state_dev>), dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
                      stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
                      (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, R, quad, out, r->d_state,
                      r->h_res_dev + slot);   // totals go straight into the pinned ring slot (no copy command)
@@ -968,6 +856,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_cstln = nullptr; r->cstln_cap = 0;
   r->d_stage = nullptr; r->stage_cap = 0;
   r->d_info = nullptr; r->d_fix = nullptr; r->d_part = nullptr; r->tiles_cap = 0;
+  r->d_wstage = nullptr; r->wstage_cap = 0;
   r->h_res = nullptr; r->ring_head = 0; r->ring_count = 0; r->st_stale_host = false;
   for (int i = 0; i < lsdr_rx::kRing; ++i) r->ev[i] = nullptr;
   r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
@@ -1008,7 +897,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
-  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part);
+  (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part); (void)hipFree(r->d_wstage);
   if (r->h_res) (void)hipHostFree(r->h_res);
   for (int i = 0; i < lsdr_rx::kRing; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   delete r;

@@ -142,6 +142,136 @@ __global__ __launch_bounds__(64) void k_fastqpsk_serial(fq_args a) {
   }
 }
 
+// ---------------------------------------------------------------- throughput mode (time-tiled, tolerance)
+// Same scheme as LSDR_RX_TILED of cstln_receiver (cstln_receiver.hip, rx_tiling.h): one lane per tile; tile 0 (a block
+// of its own) continues exactly from the carried state, tile j ≥ 1 starts `warm_chunks` early with mu = phase = 0,
+// history cleared and the carried frequency word; the seam kernels reconcile carrier quadrant (symbols relabelled by
+// the accumulated quadrant step), ±1 symbol at tile boundaries and output offsets.  Not bit-exact by construction; the
+// transport stream behind it is what the tests compare.
+__device__ __forceinline__ unsigned char rx_relabel(unsigned char v, const uint8_t *map) { return map[v]; }
+__device__ __forceinline__ unsigned rx_symbol_of(unsigned char v) { return v; }
+__device__ __forceinline__ void rx_rotate_back(fq_state *st, unsigned rot, float quad) {
+  st->phase = (st->phase - rot * (unsigned)quad) & 0xffffu;
+}
+#include "rx_tiling.h"
+typedef rx_tile_info_t<unsigned char> fq_tile_info;
+
+struct fq_tiled_args {
+  const unsigned char *in;
+  unsigned long long total_chunks;
+  unsigned first_chunks, tile_chunks, warm_chunks, n_tiles, stage_stride;
+  unsigned char *stage;
+  unsigned char *wstage; unsigned wstride;   // symbols of each tile's last warm-up chunk (seam vote)
+  fq_tile_info *info;
+  fq_state *state;
+  const unsigned *polar; const unsigned short *rect; const unsigned short *sincos;
+  float omega, gain_mu;
+  long long freq_alpha, freq_beta;
+  unsigned long long meas_decimation;
+  int allow_drift;
+  long long freq_window;
+};
+
+// One 128-sample chunk of fast_qpsk_receiver::run by ONE lane (vector table loads).  Same arithmetic as the serial kernel.
+// CLAMP (tolerance tiles only): the frequency word stays within ±a.freq_window of the carried value — a tile that
+// starts from scratch next to the PLL's unstable equilibrium can otherwise pump its frequency integrator into a false
+// lock that outlasts the tile (seen once in ~3000 tiles at 18 dB: phase ramping through the whole tile).
+template <bool CLAMP, typename Emit>
+__device__ __forceinline__ int fq_chunk(const fq_tiled_args &a, fq_state &st, const unsigned short *pin, Emit emit,
+                                        long long f_lo = 0, long long f_hi = 0) {
+  float mu = st.mu;
+  unsigned phase = st.phase & 0xffffu;
+  long long freqw = st.freqw;
+  int cnt = 0;
+  for (int n = 0; n < kChunk; ++n) {
+    if (mu < 1) {
+      const unsigned x0 = pin[n], x1 = pin[n + 1];
+      const unsigned p0 = a.polar[(x0 & 255u) * 256u + (x0 >> 8)];
+      const unsigned p1 = a.polar[(x1 & 255u) * 256u + (x1 >> 8)];
+      const unsigned a0 = (((p0 & 0xffffu) - phase) & 0xffffu) >> 8;
+      const unsigned a1 = (unsigned)(((long long)(p1 & 0xffffu) - ((long long)phase + freqw)) & 0xffff) >> 8;
+      const unsigned r0 = a.rect[a0 * 256u + ((p0 >> 16) >> 1)];
+      const unsigned r1 = a.rect[a1 * 256u + ((p1 >> 16) >> 1)];
+      const int p0re = (int)(r0 & 255u), p0im = (int)(r0 >> 8), p1re = (int)(r1 & 255u), p1im = (int)(r1 >> 8);
+      const unsigned s_re = (unsigned)(int)((float)p0re + (float)(p1re - p0re) * mu) & 255u;
+      const unsigned s_im = (unsigned)(int)((float)p0im + (float)(p1im - p0im) * mu) & 255u;
+      const unsigned symbol_arg = a.polar[s_re * 256u + s_im] & 0xffffu;
+      emit((unsigned char)((0x1320u >> ((symbol_arg >> 14) * 4)) & 15u));
+      ++cnt;
+      const long long phase_error = (long long)(int)(symbol_arg & 16383u) - 8192;
+      phase = (unsigned)((long long)phase + ((phase_error * a.freq_alpha + 32768) >> 16)) & 0xffffu;
+      freqw += (phase_error * a.freq_beta + 32768 * 256) >> 24;
+      if (CLAMP) { freqw = freqw < f_lo ? f_lo : freqw; freqw = freqw > f_hi ? f_hi : freqw; }
+      st.hist_p[2][0] = st.hist_p[1][0]; st.hist_p[2][1] = st.hist_p[1][1];
+      st.hist_c[2][0] = st.hist_c[1][0]; st.hist_c[2][1] = st.hist_c[1][1];
+      st.hist_p[1][0] = st.hist_p[0][0]; st.hist_p[1][1] = st.hist_p[0][1];
+      st.hist_c[1][0] = st.hist_c[0][0]; st.hist_c[1][1] = st.hist_c[0][1];
+      st.hist_p[0][0] = (unsigned char)s_re; st.hist_p[0][1] = (unsigned char)s_im;
+      const unsigned c = a.sincos[((symbol_arg & 49152u) + 8192u) & 0xffffu];
+      st.hist_c[0][0] = (unsigned char)(c & 255u); st.hist_c[0][1] = (unsigned char)(c >> 8);
+      const int muerr =
+          ((int)(signed char)(st.hist_p[0][0] - st.hist_p[2][0]) * ((int)st.hist_c[1][0] - 128) +
+           (int)(signed char)(st.hist_p[0][1] - st.hist_p[2][1]) * ((int)st.hist_c[1][1] - 128)) -
+          ((int)(signed char)(st.hist_c[0][0] - st.hist_c[2][0]) * ((int)st.hist_p[1][0] - 128) +
+           (int)(signed char)(st.hist_c[0][1] - st.hist_c[2][1]) * ((int)st.hist_p[1][1] - 128));
+      float mucorr = (float)muerr * a.gain_mu;
+      const float max_mucorr = 0.1f;
+      if (mucorr < -max_mucorr) mucorr = -max_mucorr;
+      if (mucorr > max_mucorr) mucorr = max_mucorr;
+      mu += mucorr;
+      mu += a.omega;
+    }
+    mu = mu - 1;
+    phase = (unsigned)((long long)phase + freqw) & 0xffffu;
+  }
+  if (!a.allow_drift)
+    if (freqw < st.min_freqw || freqw > st.max_freqw) freqw = (st.max_freqw + st.min_freqw) / 2;
+  st.mu = mu; st.phase = phase; st.freqw = freqw;
+  return cnt;
+}
+
+constexpr int kFqLanes = 32;   // tiles per wavefront
+__global__ __launch_bounds__(64) void k_fastqpsk_tiles(fq_tiled_args a) {
+  unsigned j;
+  if (blockIdx.x == 0) { if (threadIdx.x != 0) return; j = 0; }
+  else { if (threadIdx.x >= kFqLanes) return; j = 1u + (blockIdx.x - 1u) * kFqLanes + threadIdx.x; }
+  if (j >= a.n_tiles) return;
+  const unsigned long long first = a.first_chunks, Lc = a.tile_chunks, Wc = a.warm_chunks, total = a.total_chunks;
+  unsigned long long cb, c0, c1;
+  if (j == 0) { cb = 0; c0 = 0; c1 = first; }
+  else { c0 = first + (unsigned long long)(j - 1) * Lc; c1 = c0 + Lc; cb = c0 - Wc; }
+  if (c1 > total) c1 = total;
+  fq_state s = *a.state;
+  fq_tile_info ti;
+  ti.has_pre = 0; ti.pre = 0; ti.n_warm = 0; ti.mu_begin = ti.phase_begin = 0.f;
+  unsigned char *pw = a.wstage + (unsigned long long)j * a.wstride;
+  if (j > 0) {
+    s.mu = 0.f; s.phase = 0;
+    for (int k = 0; k < 3; ++k) { s.hist_p[k][0] = s.hist_p[k][1] = 0; s.hist_c[k][0] = s.hist_c[k][1] = 0; }
+  }
+  const long long f_lo = s.freqw - a.freq_window, f_hi = s.freqw + a.freq_window;
+  unsigned char last = 0;
+  unsigned char *po = a.stage + (unsigned long long)j * a.stage_stride;
+  unsigned cnt = 0, got = 0;
+  const unsigned short *in16 = reinterpret_cast<const unsigned short *>(a.in);
+  for (unsigned long long c = cb; c < c1; ++c) {
+    const bool body = c >= c0;
+    if (c == c0) { ti.mu_begin = s.mu; ti.phase_begin = (float)(s.phase & 0xffffu); ti.pre = last; ti.has_pre = got ? 1u : 0u; }
+    const bool lastwarm = c + 1 == c0;
+    unsigned nw = 0;
+    auto emit = [&](unsigned char v) { if (body) po[cnt++] = v; else { last = v; if (lastwarm) pw[nw++] = v; } };
+    const int n = j == 0 ? fq_chunk<false>(a, s, in16 + c * kChunk, emit) : fq_chunk<true>(a, s, in16 + c * kChunk, emit, f_lo, f_hi);
+    if (!body) got += (unsigned)n;
+    if (lastwarm) ti.n_warm = nw;
+  }
+  ti.mu_end = s.mu; ti.phase_end = (float)(s.phase & 0xffffu); ti.count = cnt;
+  a.info[j] = ti;
+  if (j == a.n_tiles - 1) {
+    s.meas_count = (a.state->meas_count + a.total_chunks * kChunk) % a.meas_decimation;
+    *a.state = s;
+  }
+}
+
 // ---------------------------------------------------------------- dvb_deconvol_sync<u8>
 constexpr int kDcBytes = 64, kDcSyms = 512;    // chunk_size bytes ↔ symbols, dvb.h:618
 __constant__ unsigned char c_hs_lut[4][4] = {{0, 1, 2, 3}, {2, 0, 3, 1}, {1, 0, 3, 2}, {0, 2, 1, 3}};   // dvb.h:676-699
@@ -230,6 +360,14 @@ struct lsdr_fastqpsk {
   unsigned long long *d_counters;
   float *d_freq; size_t freq_cap;
   unsigned char *d_cstln; size_t cstln_cap;
+  // throughput mode
+  int tiled; unsigned tile_len, tile_warmup;
+  unsigned char *d_stage; size_t stage_cap;
+  unsigned char *d_wstage; size_t wstage_cap;
+  fq_tile_info *d_info; rx_tile_fix *d_fix; rx_seam_part *d_part; size_t tiles_cap;
+  uint8_t *d_relabel;
+  rx_seam_result *h_res, *h_res_dev;
+  unsigned last_tiles, last_dup, last_miss, last_bad;
 };
 
 struct lsdr_hsdeconv {
@@ -276,6 +414,10 @@ int lsdr_fastqpsk_create(lsdr_ctx *c, float omega, float freq, float pll_adjustm
   LSDR_HIP(hipMalloc((void **)&r->d_state, sizeof(fq_state)));
   LSDR_HIP(hipMalloc((void **)&r->d_counters, 4 * sizeof(unsigned long long)));
   r->d_freq = nullptr; r->freq_cap = 0; r->d_cstln = nullptr; r->cstln_cap = 0;
+  r->tiled = 0; r->tile_len = 0; r->tile_warmup = 0;
+  r->d_stage = nullptr; r->stage_cap = 0; r->d_wstage = nullptr; r->wstage_cap = 0; r->d_info = nullptr; r->d_fix = nullptr; r->d_part = nullptr; r->tiles_cap = 0;
+  r->d_relabel = nullptr; r->h_res = nullptr; r->h_res_dev = nullptr;
+  r->last_tiles = r->last_dup = r->last_miss = r->last_bad = 0;
   r->st_dirty_host = true;
   *out = r;
   return LSDR_OK;
@@ -286,6 +428,8 @@ void lsdr_fastqpsk_destroy(lsdr_fastqpsk *r) {
   (void)hipStreamSynchronize(r->ctx->stream);
   (void)hipFree(r->d_polar); (void)hipFree(r->d_rect); (void)hipFree(r->d_sincos); (void)hipFree(r->d_state);
   (void)hipFree(r->d_counters); (void)hipFree(r->d_freq); (void)hipFree(r->d_cstln);
+  (void)hipFree(r->d_stage); (void)hipFree(r->d_wstage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part); (void)hipFree(r->d_relabel);
+  if (r->h_res) (void)hipHostFree(r->h_res);
   delete r;
 }
 
@@ -297,6 +441,102 @@ int lsdr_fastqpsk_get_state(const lsdr_fastqpsk *r, float *mu, unsigned *phase, 
   if (freqw) *freqw = r->st.freqw;
   if (min_freqw) *min_freqw = r->st.min_freqw;
   if (max_freqw) *max_freqw = r->st.max_freqw;
+  return LSDR_OK;
+}
+
+int lsdr_fastqpsk_set_tiled(lsdr_fastqpsk *r, int enable, unsigned tile_len, unsigned tile_warmup) {
+  LSDR_ARG(r && tile_len % kChunk == 0 && tile_warmup % kChunk == 0);
+  r->tiled = enable ? 1 : 0; r->tile_len = tile_len; r->tile_warmup = tile_warmup;
+  return LSDR_OK;
+}
+int lsdr_fastqpsk_tiled_stats(const lsdr_fastqpsk *r, unsigned *tiles, unsigned *dup, unsigned *miss, unsigned *bad_seams) {
+  LSDR_ARG(r);
+  if (tiles) *tiles = r->last_tiles;
+  if (dup) *dup = r->last_dup;
+  if (miss) *miss = r->last_miss;
+  if (bad_seams) *bad_seams = r->last_bad;
+  return LSDR_OK;
+}
+
+static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
+                        size_t *produced, const fq_args &sa) {
+  lsdr_ctx *c = r->ctx;
+  // default warm-up ≈ 192 symbols: the integer loops of this receiver settle more slowly than cstln_receiver's (TS yield
+  // of the 8000-packet chain: 107 symbols → 36 re-syncs, 213 and more → none; tools/chain_bench.py --hs --tiled)
+  unsigned Wc = r->tile_warmup ? r->tile_warmup / kChunk : (unsigned)((192.0f * r->omega + kChunk - 1) / kChunk);
+  if (Wc < 1) Wc = 1;
+  const unsigned Lc = r->tile_len ? r->tile_len / kChunk : 2 * Wc;
+  const unsigned sym_per_chunk = (unsigned)(kChunk / (r->omega - 0.1f)) + 2;   // mu advances by ≥ omega − 0.1 per symbol
+  size_t chunks = (n_in - 1) / kChunk;
+  if ((size_t)(sym_per_chunk + 1) * chunks > cap_out) chunks = cap_out / (sym_per_chunk + 1);
+  if (!chunks) return LSDR_OK;
+  const unsigned first = Lc > Wc ? Lc : Wc;
+  unsigned n_tiles = 1;
+  if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
+  const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
+  if (!r->d_relabel) {
+    // quadrant step K of a tile's carrier frame against tile 0's: symbol_arg_tile = symbol_arg − K·16384, so the true
+    // quadrant is the tile's + K; symbols are quadrant_to_symbol[] = {0,2,3,1} (sdr.h:1067).
+    static const unsigned char q2s[4] = {0, 2, 3, 1}, s2q[4] = {0, 3, 1, 2};
+    std::vector<uint8_t> rel(4 * 256, 0);
+    for (int K = 0; K < 4; ++K) for (int sy = 0; sy < 4; ++sy) rel[K * 256 + sy] = q2s[(s2q[sy] + K) & 3];
+    LSDR_HIP(hipMalloc((void **)&r->d_relabel, rel.size()));
+    LSDR_HIP(hipMemcpy(r->d_relabel, rel.data(), rel.size(), hipMemcpyHostToDevice));
+    LSDR_HIP(hipHostMalloc((void **)&r->h_res, sizeof(rx_seam_result), hipHostMallocDefault));
+    LSDR_HIP(hipHostGetDevicePointer((void **)&r->h_res_dev, r->h_res, 0));
+  }
+  if (r->tiles_cap < n_tiles) {
+    (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part);
+    LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(fq_tile_info)));
+    LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
+    LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + 1023) / 1024) * sizeof(rx_seam_part)));
+    r->tiles_cap = n_tiles;
+  }
+  if (r->stage_cap < (size_t)n_tiles * stage_stride) {
+    (void)hipFree(r->d_stage);
+    LSDR_HIP(hipMalloc((void **)&r->d_stage, (size_t)n_tiles * stage_stride));
+    r->stage_cap = (size_t)n_tiles * stage_stride;
+  }
+  if (r->wstage_cap < (size_t)n_tiles * sym_per_chunk) {
+    (void)hipFree(r->d_wstage);
+    LSDR_HIP(hipMalloc((void **)&r->d_wstage, (size_t)n_tiles * sym_per_chunk));
+    r->wstage_cap = (size_t)n_tiles * sym_per_chunk;
+  }
+  fq_tiled_args a;
+  a.in = (const unsigned char *)in; a.total_chunks = chunks;
+  a.first_chunks = first; a.tile_chunks = Lc; a.warm_chunks = Wc; a.n_tiles = n_tiles; a.stage_stride = stage_stride;
+  a.stage = r->d_stage; a.wstage = r->d_wstage; a.wstride = sym_per_chunk; a.info = r->d_info; a.state = r->d_state;
+  a.polar = sa.polar; a.rect = sa.rect; a.sincos = sa.sincos;
+  a.omega = sa.omega; a.gain_mu = sa.gain_mu; a.freq_alpha = sa.freq_alpha; a.freq_beta = sa.freq_beta;
+  a.meas_decimation = sa.meas_decimation; a.allow_drift = sa.allow_drift;
+  a.freq_window = (long long)(65536.0f / r->omega / 2048.0f);
+  if (a.freq_window < 8) a.freq_window = 8;
+  const unsigned blocks = 1 + (n_tiles - 1 + kFqLanes - 1) / kFqLanes;
+  hipLaunchKernelGGL(k_fastqpsk_tiles, dim3(blocks), dim3(64), 0, c->stream, a);
+  hipLaunchKernelGGL((k_rx_seam<fq_tile_info, unsigned char>), dim3((n_tiles + 1023) / 1024), dim3(1024), 0, c->stream,
+                     (const fq_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, 4, 16384.0f, r->d_part,
+                     (const unsigned char *)r->d_stage, stage_stride, (const unsigned char *)r->d_wstage, sym_per_chunk,
+                     (const uint8_t *)r->d_relabel);
+  hipLaunchKernelGGL((k_rx_compact<unsigned char, fq_state>), dim3(n_tiles), dim3(64), 0, c->stream,
+                     (const unsigned char *)r->d_stage, stage_stride, (const fq_tile_info *)r->d_info,
+                     (const rx_tile_fix *)r->d_fix, (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, 4,
+                     16384.0f, out, r->d_state, r->h_res_dev);
+  LSDR_HIP(hipGetLastError());
+  LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(fq_state), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  if (const char *e = getenv("LSDR_FQ_DEBUG")) {
+    const unsigned t0 = (unsigned)atoi(e);
+    std::vector<fq_tile_info> hi(n_tiles); std::vector<rx_tile_fix> hf(n_tiles);
+    LSDR_HIP(hipMemcpy(hi.data(), r->d_info, n_tiles * sizeof(fq_tile_info), hipMemcpyDeviceToHost));
+    LSDR_HIP(hipMemcpy(hf.data(), r->d_fix, n_tiles * sizeof(rx_tile_fix), hipMemcpyDeviceToHost));
+    for (unsigned t = t0; t < t0 + 6 && t < n_tiles; ++t)
+      fprintf(stderr, "tile %u: mu %.3f..%.3f phase %.0f..%.0f count %u n_warm %u has_pre %u | off %llu rot %u drop %u ins %u\n", t,
+              hi[t].mu_begin, hi[t].mu_end, hi[t].phase_begin, hi[t].phase_end, hi[t].count, hi[t].n_warm, hi[t].has_pre,
+              hf[t].out_offset, hf[t].rot, hf[t].drop_first, hf[t].insert_pre);
+  }
+  r->last_tiles = n_tiles; r->last_dup = r->h_res->ndup; r->last_miss = r->h_res->nmiss; r->last_bad = r->h_res->nbad;
+  *consumed = chunks * kChunk;
+  *produced = (size_t)r->h_res->total;
   return LSDR_OK;
 }
 
@@ -341,6 +581,7 @@ int lsdr_fastqpsk_run(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8_t
   a.freq_beta = (long long)(0.0012 * 256 * 65536 / (double)r->omega * (double)r->pll_adjustment);      // sdr.h:1000
   a.meas_decimation = r->meas_decimation;
   a.allow_drift = r->allow_drift;
+  if (r->tiled) return fq_run_tiled(r, in, n_in, out, cap_out, consumed, produced, a);   // (no FREQ / constellation reports)
   hipLaunchKernelGGL(k_fastqpsk_serial, dim3(1), dim3(64), 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
   unsigned long long cnt[4];

@@ -36,6 +36,7 @@ struct config {
   int anf;            // auto_notch slots (leandvb default 1)
   bool cnr;
   bool fastlock;
+  bool highspeed;
   int fd_spectrum;
   bool resample;
   float resample_rej;
@@ -53,13 +54,76 @@ struct config {
   config()
       : verbose(false), debug(false), input_format(INPUT_U8), float_scale(1.0), Fs(2.4e6), Fm(2e6),
         constellation(cstln_lut<256>::QPSK), fec(LSDR_FEC12), Ftune(0), allow_drift(false), viterbi(false),
-        anf(1), cnr(false), fastlock(false), fd_spectrum(-1), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
+        anf(1), cnr(false), fastlock(false), highspeed(false), fd_spectrum(-1), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
         buf_factor(4096), fd_info(-1), Finfo(5), out_symbols(false), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
 };
 
 static int decimation(float Fin, float Fout) {
   int d = Fin / Fout;
   return max(d, 1);
+}
+
+// leandvb --hs (leandvb.cc:727-969): fast_qpsk_receiver<u8> → dvb_deconvol_sync_hard → mpeg_sync(fastlock) → … → TS.
+static int run_highspeed(config &cfg) {
+  scheduler sch;
+  sch.verbose = cfg.verbose;
+  sch.debug = cfg.debug;
+  lsdr_ctx *ctx = NULL;
+  lsdr_check(lsdr_ctx_create(cfg.device, NULL, &ctx), "lsdr_ctx_create");
+  unsigned long BUF_BASEBAND = 4096 * cfg.buf_factor, BUF_SYMBOLS = 1024 * cfg.buf_factor, BUF_BYTES = 2048 * cfg.buf_factor;
+  unsigned long BUF_MPEGBYTES = 2448 * cfg.buf_factor, BUF_PACKETS = cfg.buf_factor, BUF_SLOW = cfg.buf_factor;
+  if (cfg.input_format != config::INPUT_U8) fail("--hs requires --u8");
+  if (cfg.fec != LSDR_FEC12) fail("--hs currently supports code rate 1/2 only");
+
+  pipebuf<cu8> p_stdin(&sch, "stdin", BUF_BASEBAND);
+  file_reader<cu8> r_stdin(&sch, 0, p_stdin);
+  pipebuf<cu8> p_rawiq(&sch, "rawiq", BUF_BASEBAND, ctx);
+  h2d_copier<cu8> r_h2d(&sch, ctx, p_stdin, p_rawiq);
+
+  pipebuf<f32> p_freq(&sch, "freq", BUF_SLOW);
+  pipebuf<u8> p_symbols(&sch, "PSK hard symbols", BUF_SYMBOLS, ctx);
+  fast_qpsk_receiver<u8> demod(&sch, p_rawiq, p_symbols, &p_freq, NULL);
+  demod.set_omega(cfg.Fs / cfg.Fm);
+  if (cfg.Ftune) demod.set_freq(cfg.Ftune / cfg.Fs);
+  if (cfg.allow_drift) demod.allow_drift = true;
+  demod.meas_decimation = decimation(cfg.Fs, cfg.Finfo);
+  demod.tiled = cfg.tiled; demod.tile_len = cfg.tile_len; demod.tile_warmup = cfg.tile_warmup;
+
+  pipebuf<u8> p_bytes(&sch, "bytes", BUF_BYTES, ctx);
+  dvb_deconvol_sync_hard r_deconv(&sch, p_symbols, p_bytes);
+  r_deconv.resync_period = cfg.fastlock ? 1 : 32;
+
+  pipebuf<u8> p_mpegbytes(&sch, "mpegbytes", BUF_MPEGBYTES, ctx);
+  pipebuf<int> p_lock(&sch, "lock", BUF_SLOW);
+  pipebuf<u32> p_locktime(&sch, "locktime", BUF_PACKETS);
+  mpeg_sync<u8, 0> r_sync(&sch, p_bytes, p_mpegbytes, NULL, &p_lock, &p_locktime);
+  r_sync.fastlock = true;
+  r_sync.resync_period = cfg.fastlock ? 1 : 32;
+
+  pipebuf<rspacket<u8> > p_rspackets(&sch, "RS-enc packets", BUF_PACKETS, ctx);
+  deinterleaver<u8> r_deinter(&sch, p_mpegbytes, p_rspackets);
+  pipebuf<int> p_vbitcount(&sch, "Bits processed", BUF_PACKETS);
+  pipebuf<int> p_verrcount(&sch, "Bits corrected", BUF_PACKETS);
+  pipebuf<tspacket> p_rtspackets(&sch, "rand TS packets", BUF_PACKETS, ctx);
+  rs_decoder<u8, 0> r_rsdec(&sch, p_rspackets, p_rtspackets, &p_vbitcount, &p_verrcount);
+  pipebuf<float> p_vber(&sch, "VBER", BUF_SLOW);
+  rate_estimator<float> r_vber(&sch, p_verrcount, p_vbitcount, p_vber);
+  pipebuf<tspacket> p_tspackets(&sch, "TS packets", BUF_PACKETS, ctx);
+  derandomizer r_derand(&sch, p_rtspackets, p_tspackets);
+  pipebuf<tspacket> p_ts_host(&sch, "TS packets(host)", BUF_PACKETS);
+  d2h_copier<tspacket> r_d2h(&sch, ctx, p_tspackets, p_ts_host);
+  file_writer<tspacket> r_stdout(&sch, p_ts_host, 1);
+
+  if (cfg.fd_info >= 0) {
+    new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info);
+    new file_printer<int>(&sch, "LOCK %d\n", p_lock, cfg.fd_info);
+    new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, 10);
+    new file_printer<float>(&sch, "VBER %.6f\n", p_vber, cfg.fd_info);
+  }
+  sch.run();
+  sch.shutdown();
+  lsdr_ctx_destroy(ctx);
+  return 0;
 }
 
 static int run(config &cfg) {
@@ -276,6 +340,7 @@ static void usage(const char *name, FILE *f, int c) {
           "  --cr STRING            1/2 (default), 2/3, 3/4, 5/6, 7/8 (APSK radii)\n"
           "  --anf N, --cnr         auto-notch slots (default 1, 0 disables), CNR estimator\n"
           "  --fastlock, --hq       synchronise more aggressively; --hq = --fastlock --viterbi --sampler rrc\n"
+          "  --hs                   high-speed path: --u8 QPSK 1/2, all-integer receiver (leandvb --hs)\n"
           "  --fd-spectrum FD       SPECTRUM [..1024 dB values..] lines, one per second of signal\n"
           "  --tune HZ, --drift     receiver bias, unlimited drift\n"
           "  --resample, --resample-rej FLOAT, --decim N, --roll-off FLOAT\n"
@@ -317,6 +382,7 @@ int main(int argc, const char *argv[]) {
     else if (!strcmp(a, "--anf")) cfg.anf = atoi(need());
     else if (!strcmp(a, "--cnr")) cfg.cnr = true;
     else if (!strcmp(a, "--fastlock")) cfg.fastlock = true;
+    else if (!strcmp(a, "--hs")) cfg.highspeed = true;
     else if (!strcmp(a, "--hq")) { cfg.fastlock = true; cfg.viterbi = true; cfg.sampler = config::SAMP_RRC; }   // leandvb.cc:1154-1158
     else if (!strcmp(a, "--fd-spectrum")) cfg.fd_spectrum = atoi(need());
     else if (!strcmp(a, "--tiled")) cfg.tiled = true;
@@ -347,5 +413,5 @@ int main(int argc, const char *argv[]) {
       if (!ok) usage(argv[0], stderr, 1);
     } else usage(argv[0], stderr, 1);
   }
-  return run(cfg);
+  return cfg.highspeed ? run_highspeed(cfg) : run(cfg);
 }

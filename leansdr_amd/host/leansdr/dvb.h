@@ -91,6 +91,36 @@ struct viterbi_sync : runnable {
 template <typename Tbyte, Tbyte BYTE_ERASED>
 struct mpeg_sync;
 
+// dvb_deconvol_sync<u8> (dvb.h:612-707), the --hs deconvolver: QPSK 1/2 only, hard symbols in.
+template <typename Tin>
+struct dvb_deconvol_sync;
+
+template <>
+struct dvb_deconvol_sync<u8> : runnable {
+  typedef u8 decoded_byte;
+  int resync_period;
+  static const int chunk_size = 64;
+  dvb_deconvol_sync(scheduler *sch, pipebuf<u8> &i, pipebuf<decoded_byte> &o)
+      : runnable(sch, "deconvol_sync_multipoly"), resync_period(32),
+        ctx(pipe_ctx(i.dev, o.dev, "dvb_deconvol_sync: pipebufs must be device pipebufs of one ctx")), in(i), out(o, chunk_size),
+        h(NULL) {}
+  void run() {
+    if (!h) lsdr_check(lsdr_hsdeconv_create(ctx, resync_period, &h), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_hsdeconv_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<u8> in;
+  pipewriter<decoded_byte> out;
+  lsdr_hsdeconv *h;
+};
+typedef dvb_deconvol_sync<u8> dvb_deconvol_sync_hard;
+
 template <>
 struct mpeg_sync<u8, 0> : runnable {
   int scan_syncs, want_syncs;
@@ -108,6 +138,7 @@ struct mpeg_sync<u8, 0> : runnable {
   }
   void run() {
     if (!h) lsdr_check(lsdr_mpeg_sync_create(ctx, fastlock, &h), name);
+    lsdr_check(lsdr_mpeg_sync_set_resync_period(h, resync_period), name);
     // one run() writes at most: the initial "unlocked" report plus one lock/unlock event (dvb.h:744-754)
     if (state_out && state_out->writable() < (first_run ? 2ul : 1ul)) return;
     first_run = false;

@@ -142,6 +142,89 @@ struct cnr_fft<f32> : runnable {
   lsdr_cnr_fft *h;
 };
 
+// fast_qpsk_receiver<u8> (sdr.h:946-1189), the --hs receiver: cu8 device pipe in, hard-symbol device pipe out, FREQ and
+// sampled-constellation reports to host pipes.
+template <typename T>
+struct fast_qpsk_receiver;
+
+template <>
+struct fast_qpsk_receiver<u8> : runnable {
+  typedef u8 hardsymbol;
+  unsigned long meas_decimation;
+  float omega, min_omega, max_omega;
+  signed long freqw, min_freqw, max_freqw;
+  float pll_adjustment;
+  bool allow_drift;
+  static const unsigned int chunk_size = 128;
+  bool tiled;               // addition: throughput mode (time-tiled, tolerance) instead of the exact recurrence
+  unsigned tile_len, tile_warmup;
+
+  fast_qpsk_receiver(scheduler *sch, pipebuf<cu8> &i, pipebuf<hardsymbol> &o, pipebuf<float> *freq_o = NULL,
+                     pipebuf<cu8> *cstln_o = NULL)
+      : runnable(sch, "Fast QPSK receiver"), meas_decimation(1048576), pll_adjustment(1.0), allow_drift(false),
+        tiled(false), tile_len(0), tile_warmup(0),
+        ctx(pipe_ctx(i.dev, o.dev, "fast_qpsk_receiver: in/out must be device pipebufs of one ctx")), in(i), out(o, chunk_size),
+        h(NULL), freq0(0) {
+    set_omega(1);
+    set_freq(0);
+    freq_out = opt_writer(freq_o);
+    cstln_out = opt_writer(cstln_o);
+  }
+  void set_omega(float o, float tol = 10e-6) {
+    omega = o;
+    min_omega = omega * (1 - tol);
+    max_omega = omega * (1 + tol);
+    update_freq_limits();
+  }
+  void set_freq(float f) {
+    freq0 = f;
+    freqw = f * 65536;
+    update_freq_limits();
+  }
+  void update_freq_limits() {   // ±SR/8 (sdr.h:987-992)
+    min_freqw = freqw - 65536 / max_omega / 8;
+    max_freqw = freqw + 65536 / max_omega / 8;
+  }
+  void run() {
+    if (!h) {
+      lsdr_check(lsdr_fastqpsk_create(ctx, omega, freq0, pll_adjustment, allow_drift, meas_decimation, &h), name);
+      acquired = 0;
+    }
+    // throughput mode: the exact recurrence acquires on the head of the stream (first 64 Ki samples), then tiles track
+    lsdr_check(lsdr_fastqpsk_set_tiled(h, tiled && acquired >= 65536, tile_len, tile_warmup), name);
+    unsigned long max_meas = chunk_size / meas_decimation + 1;
+    unsigned long room = out.writable();
+    unsigned long freq_room = freq_out ? freq_out->writable() : 0, cstln_room = cstln_out ? cstln_out->writable() : 0;
+    if (in.readable() < chunk_size + 1 || room < chunk_size) return;       // sdr.h:1010-1013
+    if (freq_out && freq_room < max_meas) return;
+    if (cstln_out && cstln_room < max_meas) return;
+    size_t consumed = 0, produced = 0, nf = 0, nc = 0;
+    unsigned long avail = in.readable();
+    if (tiled && acquired < 65536 && avail > 65536 - acquired + 1) avail = 65536 - acquired + 1;   // acquisition stays short
+    lsdr_check(lsdr_fastqpsk_run(h, (const lsdr_cu8 *)in.rd(), avail, out.wr(), room, &consumed, &produced,
+                                 freq_out ? freq_out->wr() : NULL, freq_room, &nf,
+                                 cstln_out ? (lsdr_cu8 *)cstln_out->wr() : NULL, cstln_room, &nc), name);
+    in.read(consumed);
+    out.written(produced);
+    acquired += consumed;
+    if (freq_out) freq_out->written(nf);
+    if (cstln_out) cstln_out->written(nc);
+    long long fw = 0;
+    lsdr_check(lsdr_fastqpsk_get_state(h, NULL, NULL, &fw, NULL, NULL), name);
+    freqw = (signed long)fw;
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<cu8> in;
+  pipewriter<hardsymbol> out;
+  pipewriter<float> *freq_out;
+  pipewriter<cu8> *cstln_out;
+  lsdr_fastqpsk *h;
+  float freq0;
+  unsigned long acquired;
+};
+
 // spectrum<f32> (sdr.h:1347-1404): device input pipe, host output pipe of float[1024] rows.
 template <typename T>
 struct spectrum;

@@ -166,3 +166,29 @@ def test_full_chain_fastlock(oracle, extra):
     assert good >= len(ts) - 10 and len(ts) >= len(want) - 8 and len(ts) > 500
     if bits_equal(ts, want):
         return   # same call pattern as the reference's pipes: identical stream
+
+
+@pytest.mark.parametrize("extra,key", [([], "ts"), (["--fastlock"], "ts_fastlock")])
+@pytest.mark.parametrize("buf_factor", [4, 64, 4096])
+def test_hs_app_equals_leandvb_hs(extra, key, buf_factor):
+    """leandvb_amd --hs (host framework + fast_qpsk_receiver / dvb_deconvol_sync / mpeg_sync(fastlock) / … on the GPU) ==
+    the TS the real `leandvb --hs` wrote for the same capture (tests/golden/hs.npz), for any pipe size."""
+    g = gold("hs.npz")
+    ts, err = run_ts(["--u8", "--hs", "-f", "2400e3", "--sr", "2000e3", "--buf-factor", str(buf_factor), "--fd-info", "2"] + extra,
+                     g["iq"])
+    assert bits_equal(ts, g[key]) and len(ts) > 20
+    assert "LOCK 1" in err and "VBER" in err
+
+
+def test_hs_tiled_app_ts_matches_exact_chain(oracle):
+    """leandvb_amd --hs --tiled: same transport stream as the exact --hs chain once locked."""
+    from leansdr_amd import synth_dvbs
+    iq, ts_in = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=5)
+    ts, _ = run_ts(["--u8", "--hs", "-f", "2400e3", "--sr", "2000e3", "--tiled"], iq)
+    want = oracle.hs_chain(iq, float(np.float32(2400e3 / 2000e3)))
+    assert len(want) > 900
+    got = [bytes(t) for t in ts]
+    tail = [bytes(t) for t in want[16:]]
+    assert tail[0] in got
+    i0 = got.index(tail[0])
+    assert got[i0:i0 + len(tail)] == tail

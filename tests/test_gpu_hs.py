@@ -87,3 +87,26 @@ def test_hs_chain_blocks_vs_leandvb_hs(capi, ctx):
         out = dr.run(ts)
         dr.close()
         assert bits_equal(out, g[key]), key
+
+
+def test_fast_qpsk_tiled_tracks_like_serial(capi, ctx, oracle):
+    """Throughput mode: after an exact acquisition the tiled receiver must deliver the same number of symbols and
+    (nearly) the same decisions as the exact recurrence — tolerance mode like LSDR_RX_TILED (tests/test_gpu_rx_tiled.py)."""
+    from leansdr_amd import synth_dvbs
+    iq, _ = synth_dvbs.capture_u8(n_packets=400, seed=12)
+    n = len(iq) // 2
+    acq = 65536
+    want = oracle.fast_qpsk(iq, 1.2)["sym"]
+    r = capi.FastQpsk(ctx, 1.2)
+    head = r.run(iq[:2 * (acq + 1)], meas=False)
+    assert head["consumed"] == acq
+    r.set_tiled(True)
+    tail = r.run(iq[2 * acq:], meas=False)
+    stats = r.tiled_stats()
+    r.close()
+    got = np.concatenate([head["sym"], tail["sym"]])
+    assert head["consumed"] + tail["consumed"] == (n - 1) // 128 * 128
+    assert len(got) == len(want), (len(got), len(want), stats)
+    assert bits_equal(got[:len(head["sym"])], want[:len(head["sym"])])          # acquisition part is the exact kernel
+    same = (got == want).mean()
+    assert same >= 0.999 and stats["tiles"] > 100 and stats["bad_seams"] == 0, (same, stats)
