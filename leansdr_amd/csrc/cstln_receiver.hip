@@ -181,9 +181,13 @@ __device__ __forceinline__ float2 interp(const rx_tables &T, const rx_consts &C,
 // One 128-sample chunk of cstln_receiver::run (sdr.h:790-913), run by ONE lane.
 // Emits symbols through `emit(softsymbol)`; returns the number emitted.
 // last_s / last_sg / had_symbol feed the per-chunk estimators.
-template <int SAMP, typename LD, typename SamplePtr, typename Emit>
+// WIN (tolerance tiles only): freqw is kept within [f_lo, f_hi] around the carried value — a tile that starts from
+// scratch next to the PLL's unstable equilibrium can otherwise pump the frequency integrator into a false lock that
+// outlasts the tile (observed with the integer receiver of hs.hip; same loop structure here).
+template <int SAMP, typename LD, bool WIN = false, typename SamplePtr, typename Emit>
 __device__ __forceinline__ int rx_chunk(const rx_tables &T, const rx_consts &C, rx_state_dev &s, SamplePtr pin,
-                                        Emit emit, float2 *cstln_out_slot, bool *wrote_cstln) {
+                                        Emit emit, float2 *cstln_out_slot, bool *wrote_cstln, float f_lo = 0.f,
+                                        float f_hi = 0.f) {
   float mu = s.mu, phase = s.phase, freqw = s.freqw;
   const float agc_gain = s.agc_gain;
   float2 sg = make_float2(0.f, 0.f), sv = make_float2(0.f, 0.f);
@@ -248,6 +252,7 @@ __device__ __forceinline__ int rx_chunk(const rx_tables &T, const rx_consts &C, 
       // PLL, sdr.h:814-815
       phase += e.phase_error * C.freq_alpha;
       freqw += e.phase_error * C.freq_beta;
+      if (WIN) { freqw = freqw < f_lo ? f_lo : freqw; freqw = freqw > f_hi ? f_hi : freqw; }
       // Modified Mueller & Müller, sdr.h:822-840
       h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;
       h1pr = h0pr; h1pi = h0pi; h1cr = h0cr; h1ci = h0ci;
@@ -469,6 +474,9 @@ __device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, unsigned j
     s.mu = 0.f; s.phase = 0.f;
     for (int k = 0; k < 12; ++k) s.hist[k] = 0.f;
   }
+  float fwin = 65536.0f / a.C.omega / 2048.0f;
+  if (fwin < 8.f) fwin = 8.f;
+  const float f_lo = s.freqw - fwin, f_hi = s.freqw + fwin;
   lsdr_softsymbol last; last.cost = 0; last.symbol = 0; last.pad = 0;
   lsdr_softsymbol *po = a.stage + (unsigned long long)j * a.stage_stride;
   unsigned cnt = 0, got = 0;
@@ -482,9 +490,9 @@ __device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, unsigned j
     bool wrote;
     const bool lastwarm = c + 1 == c0;
     unsigned nw = 0;
-    const int n = rx_chunk<SAMP, LD>(a.T, a.C, s, a.in + c * kChunk,
-                                     [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else { last = ss; if (lastwarm) pw[nw++] = ss; } },
-                                     nullptr, &wrote);
+    auto emit = [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else { last = ss; if (lastwarm) pw[nw++] = ss; } };
+    const int n = j == 0 ? rx_chunk<SAMP, LD>(a.T, a.C, s, a.in + c * kChunk, emit, nullptr, &wrote)
+                         : rx_chunk<SAMP, LD, true>(a.T, a.C, s, a.in + c * kChunk, emit, nullptr, &wrote, f_lo, f_hi);
     if (!body) got += (unsigned)n;
     if (lastwarm) ti.n_warm = nw;
     if (body && a.meas) {     // measurements, sdr.h:905-913: one per meas_decimation samples of the stream
