@@ -102,6 +102,12 @@ int lsdr_scaler_run(lsdr_ctx *ctx, float scale, const lsdr_cf32 *in, size_t n, l
 /* decimator<cf32>::run, generic.h:256-262; *produced = min(n/d, cap), consumes produced*d */
 int lsdr_decimator_run(lsdr_ctx *ctx, unsigned d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out,
                        size_t cap, size_t *produced);
+/* rotator<f32> (sdr.h:1226-1259): out[i] = in[i]·(cos, sin)(2π·i·ifreq/65536), ifreq = (int)(freq·65536); the 16-bit table
+ * index is carried across calls.  The table is built on the host with libm like the reference's constructor. */
+typedef struct lsdr_rotator lsdr_rotator;
+int lsdr_rotator_create(lsdr_ctx *ctx, float freq, lsdr_rotator **r);
+void lsdr_rotator_destroy(lsdr_rotator *r);
+int lsdr_rotator_run(lsdr_rotator *r, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out);
 
 /* -------------------------------------------------------------- auto_notch / cnr_fft / cfft
  * auto_notch<f32>, sdr.h:46-154: every `decimation` samples the `nslots` strongest bins of a 4096-point

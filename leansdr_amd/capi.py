@@ -113,6 +113,9 @@ _sig("lsdr_hsdeconv_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
 _sig("lsdr_hsdeconv_destroy", None, [vp])
 _sig("lsdr_hsdeconv_locked", C.c_int, [vp])
 _sig("lsdr_hsdeconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_rotator_create", C.c_int, [vp, c_f, C.POINTER(vp)])
+_sig("lsdr_rotator_destroy", None, [vp])
+_sig("lsdr_rotator_run", C.c_int, [vp, vp, c_sz, vp])
 _sig("lsdr_spectrum_create", C.c_int, [vp, C.POINTER(vp)])
 _sig("lsdr_spectrum_destroy", None, [vp])
 _sig("lsdr_spectrum_set", C.c_int, [vp, C.c_int, c_f])
@@ -765,6 +768,30 @@ class HsDeconv:
             pos += cons.value
             nout += prod.value
         out = self.ctx.download(dout, np.uint8, nout)
+        din.free(); dout.free()
+        return out
+
+
+class Rotator:
+    """rotator<f32> (sdr.h:1226-1259)."""
+
+    def __init__(self, ctx, freq):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_rotator_create(ctx.h, freq, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_rotator_destroy(self.h)
+            self.h = None
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.ctx.upload(x)
+        dout = self.ctx.alloc(max(8, len(x) * 8))
+        check(lib.lsdr_rotator_run(self.h, din.ptr, len(x), dout.ptr))
+        out = self.ctx.download(dout, np.complex64, len(x))
         din.free(); dout.free()
         return out
 

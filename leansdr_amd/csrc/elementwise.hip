@@ -75,6 +75,17 @@ __global__ __launch_bounds__(kBlock) void k_decim(const float2 *__restrict__ in,
   for (size_t m = (size_t)blockIdx.x * kBlock + threadIdx.x; m < count; m += stride) out[m] = in[m * d];
 }
 
+// rotator<f32>, sdr.h:1243-1254: out = in·(cos, sin)[index], 16-bit table index advancing by one per sample.
+__global__ __launch_bounds__(kBlock) void k_rotate(const float2 *__restrict__ in, size_t n, const float2 *__restrict__ lut,
+                                                   unsigned index0, float2 *__restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    const float2 cs = lut[(index0 + (unsigned)(i & 0xffffu)) & 0xffffu];
+    const float2 x = in[i];
+    out[i] = make_float2(x.x * cs.x - x.y * cs.y, x.x * cs.y + x.y * cs.x);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -108,6 +119,41 @@ int lsdr_decimator_run(lsdr_ctx *c, unsigned d, const lsdr_cf32 *in, size_t n, l
   hipLaunchKernelGGL(k_decim, dim3(grid_for(c, count)), dim3(kBlock), 0, c->stream, (const float2 *)in, d,
                      count, (float2 *)out);
   LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+// ------------------------------------------------------------------ rotator<f32> (sdr.h:1226-1259)
+struct lsdr_rotator { lsdr_ctx *ctx; float2 *d_lut; unsigned index; };
+
+int lsdr_rotator_create(lsdr_ctx *c, float freq, lsdr_rotator **out) {
+  LSDR_ARG(c && out);
+  LSDR_HIP(hipSetDevice(c->device));
+  std::vector<float2> lut(65536);
+  const int ifreq = (int)(freq * 65536);                    // sdr.h:1231
+  for (int i = 0; i < 65536; ++i) {                         // host libm, like the reference (sdr.h:1235-1238)
+    lut[i].x = cosf(2 * M_PI * i * ifreq / 65536);
+    lut[i].y = sinf(2 * M_PI * i * ifreq / 65536);
+  }
+  lsdr_rotator *r = new lsdr_rotator();
+  r->ctx = c; r->index = 0;
+  LSDR_HIP(hipMalloc((void **)&r->d_lut, lut.size() * sizeof(float2)));
+  LSDR_HIP(hipMemcpy(r->d_lut, lut.data(), lut.size() * sizeof(float2), hipMemcpyHostToDevice));
+  *out = r;
+  return LSDR_OK;
+}
+void lsdr_rotator_destroy(lsdr_rotator *r) {
+  if (!r) return;
+  (void)hipStreamSynchronize(r->ctx->stream);
+  (void)hipFree(r->d_lut);
+  delete r;
+}
+int lsdr_rotator_run(lsdr_rotator *r, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out) {
+  LSDR_ARG(r && (n == 0 || (in && out)));
+  if (!n) return LSDR_OK;
+  hipLaunchKernelGGL(k_rotate, dim3(grid_for(r->ctx, n)), dim3(kBlock), 0, r->ctx->stream, (const float2 *)in, n,
+                     (const float2 *)r->d_lut, r->index, (float2 *)out);
+  LSDR_HIP(hipGetLastError());
+  r->index = (r->index + (unsigned)(n & 0xffffu)) & 0xffffu;
   return LSDR_OK;
 }
 

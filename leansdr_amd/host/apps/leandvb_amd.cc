@@ -35,6 +35,9 @@ struct config {
   bool viterbi;
   int anf;            // auto_notch slots (leandvb default 1)
   bool cnr;
+  float Fderot;
+  int fd_const;
+  bool json;
   bool fastlock;
   bool highspeed;
   int fd_spectrum;
@@ -54,7 +57,7 @@ struct config {
   config()
       : verbose(false), debug(false), input_format(INPUT_U8), float_scale(1.0), Fs(2.4e6), Fm(2e6),
         constellation(cstln_lut<256>::QPSK), fec(LSDR_FEC12), Ftune(0), allow_drift(false), viterbi(false),
-        anf(1), cnr(false), fastlock(false), highspeed(false), fd_spectrum(-1), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
+        anf(1), cnr(false), Fderot(0), fd_const(-1), json(false), fastlock(false), highspeed(false), fd_spectrum(-1), resample(false), resample_rej(10), decim(1), sampler(SAMP_LINEAR), rrc_steps(0), rrc_rej(10), rolloff(0.35),
         buf_factor(4096), fd_info(-1), Finfo(5), out_symbols(false), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
 };
 
@@ -178,6 +181,20 @@ static int run(config &cfg) {
     p_preprocessed = p_autonotched;
   } else if (cfg.verbose) fprintf(stderr, "ANF is disabled (requires a clean signal).\n");
 
+  // FREQUENCY CORRECTION (leandvb.cc:308-318)
+  if (cfg.Fderot) {
+    if (fuse_scale) {
+      pipebuf<cf32> *p_rawiq = new pipebuf<cf32>(&sch, "rawiq", BUF_BASEBAND, ctx);
+      new scaler<float, cf32, cf32>(&sch, cfg.float_scale, *p_preprocessed, *p_rawiq);
+      p_preprocessed = p_rawiq;
+      fuse_scale = 0;
+    }
+    if (cfg.verbose) fprintf(stderr, "Derotating from %.3f kHz\n", cfg.Fderot / 1e3);
+    pipebuf<cf32> *p_derot = new pipebuf<cf32>(&sch, "derotated", BUF_BASEBAND, ctx);
+    new rotator<f32>(&sch, *p_preprocessed, *p_derot, -cfg.Fderot / cfg.Fs);
+    p_preprocessed = p_derot;
+  }
+
   // CNR ESTIMATION (leandvb.cc:320-329)
   pipebuf<f32> p_cnr(&sch, "cnr", BUF_SLOW);
   cnr_fft<f32> *r_cnr = NULL;
@@ -245,7 +262,9 @@ static int run(config &cfg) {
       sampler = new fir_sampler<float, float>(ncoeffs, coeffs, cfg.rrc_steps);
     }
   }
-  cstln_receiver<f32> demod(&sch, sampler, *p_preprocessed, p_symbols, &p_freq, &p_ss, &p_mer, NULL);
+  pipebuf<cf32> p_sampled(&sch, "PSK symbols", BUF_BASEBAND);   // host pipe: one constellation point per chunk (leandvb.cc:451)
+  cstln_receiver<f32> demod(&sch, sampler, *p_preprocessed, p_symbols, &p_freq, &p_ss, &p_mer,
+                            cfg.fd_const >= 0 ? &p_sampled : NULL);
   demod.cstln = new cstln_lut<256>(cfg.constellation, cfg.fec);
   demod.set_omega(cfg.Fs / cfg.Fm);
   if (cfg.Ftune) demod.set_freq(cfg.Ftune / cfg.Fs);
@@ -319,6 +338,25 @@ static int run(config &cfg) {
     // unread measurement pipes never block their writer (pipebuf with zero readers packs to empty)
   }
 
+  if (cfg.fd_const >= 0) {   // leandvb.cc:617-645
+    cstln_lut<256> *c = demod.cstln;
+    FILE *f = fdopen(dup(cfg.fd_const), "w");
+    if (!f) fatal("fdopen(fd_const)");
+    if (cfg.json) {
+      fprintf(f, "CONST [");
+      for (int i = 0; i < c->nsymbols; ++i) fprintf(f, "%s[%d,%d]", i ? "," : "", c->symbols[i].re, c->symbols[i].im);
+      fprintf(f, "]\n");
+    } else {
+      fprintf(f, "CONST %d", c->nsymbols);
+      for (int i = 0; i < c->nsymbols; ++i) fprintf(f, " %d,%d", c->symbols[i].re, c->symbols[i].im);
+      fprintf(f, "\n");
+    }
+    fclose(f);
+    file_carrayprinter<f32> *symbol_printer =
+        cfg.json ? new file_carrayprinter<f32>(&sch, "SYMBOLS [", "[%.0f,%.0f]", ",", "]\n", p_sampled, cfg.fd_const)
+                 : new file_carrayprinter<f32>(&sch, "SYMBOLS %d", " %.0f,%.0f", "", "\n", p_sampled, cfg.fd_const);
+    symbol_printer->fixed_size = 128;
+  }
   if (cfg.fd_spectrum >= 0)   // leandvb.cc:647-652
     new file_vectorprinter<f32, 1024>(&sch, "SPECTRUM [", "%.3f", ",", "]\n", *p_spectrum, cfg.fd_spectrum);
 
@@ -341,6 +379,8 @@ static void usage(const char *name, FILE *f, int c) {
           "  --anf N, --cnr         auto-notch slots (default 1, 0 disables), CNR estimator\n"
           "  --fastlock, --hq       synchronise more aggressively; --hq = --fastlock --viterbi --sampler rrc\n"
           "  --hs                   high-speed path: --u8 QPSK 1/2, all-integer receiver (leandvb --hs)\n"
+          "  --derotate HZ          frequency-shift the preprocessed signal (rotator)\n"
+          "  --fd-const FD [--json] CONST / SYMBOLS lines (constellation and sampled points)\n"
           "  --fd-spectrum FD       SPECTRUM [..1024 dB values..] lines, one per second of signal\n"
           "  --tune HZ, --drift     receiver bias, unlimited drift\n"
           "  --resample, --resample-rej FLOAT, --decim N, --roll-off FLOAT\n"
@@ -381,6 +421,9 @@ int main(int argc, const char *argv[]) {
     else if (!strcmp(a, "--device")) cfg.device = atoi(need());
     else if (!strcmp(a, "--anf")) cfg.anf = atoi(need());
     else if (!strcmp(a, "--cnr")) cfg.cnr = true;
+    else if (!strcmp(a, "--derotate")) cfg.Fderot = atof(need());
+    else if (!strcmp(a, "--fd-const")) cfg.fd_const = atoi(need());
+    else if (!strcmp(a, "--json")) cfg.json = true;
     else if (!strcmp(a, "--fastlock")) cfg.fastlock = true;
     else if (!strcmp(a, "--hs")) cfg.highspeed = true;
     else if (!strcmp(a, "--hq")) { cfg.fastlock = true; cfg.viterbi = true; cfg.sampler = config::SAMP_RRC; }   // leandvb.cc:1154-1158

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include "leansdr/framework.h"
+#include "leansdr/math.h"
 
 namespace leansdr {
 
@@ -100,6 +101,39 @@ struct file_printer : runnable {
   const char *format;
   int fdout;
   int phase;
+};
+
+// Batches of complex items as one text line each (generic.h:153-189) — SYMBOLS lines of --fd-const.
+template <typename T>
+struct file_carrayprinter : runnable {
+  T scale;
+  int fixed_size;   // items per batch, or 0
+  file_carrayprinter(scheduler *sch, const char *head_, const char *format_, const char *sep_, const char *tail_,
+                     pipebuf<complex<T> > &i, int fd)
+      : runnable(sch, i.name), scale(1), fixed_size(0), in(i), head(head_), format(format_), sep(sep_), tail(tail_),
+        fout(fdopen(fd, "w")) {}
+  void run() {
+    int n, nmin = fixed_size ? fixed_size : 1;
+    while ((n = in.readable()) >= nmin) {
+      if (fixed_size) n = fixed_size;
+      if (fout) {
+        fprintf(fout, head, n);
+        complex<T> *pin = in.rd();
+        for (int k = 0; k < n; ++k) {
+          if (k) fprintf(fout, "%s", sep);
+          fprintf(fout, format, pin[k].re * scale, pin[k].im * scale);
+        }
+        fprintf(fout, "%s", tail);
+      }
+      fflush(fout);
+      in.read(n);
+    }
+  }
+
+ private:
+  pipereader<complex<T> > in;
+  const char *head, *format, *sep, *tail;
+  FILE *fout;
 };
 
 // One text line per vector item: head, N formatted values joined by sep, tail (generic.h:191-222).

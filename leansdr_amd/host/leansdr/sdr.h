@@ -225,6 +225,33 @@ struct fast_qpsk_receiver<u8> : runnable {
   unsigned long acquired;
 };
 
+// rotator<f32> (sdr.h:1226-1259): frequency shifter on device pipes.
+template <typename T>
+struct rotator;
+
+template <>
+struct rotator<f32> : runnable {
+  rotator(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o, float freq)
+      : runnable(sch, "rotator"), ctx(pipe_ctx(i.dev, o.dev, "rotator: in/out must be device pipebufs of one ctx")), in(i), out(o),
+        h(NULL) {
+    lsdr_check(lsdr_rotator_create(ctx, freq, &h), name);
+  }
+  void run() {
+    unsigned long room = out.writable();
+    unsigned long count = min(in.readable(), room);
+    if (!count) return;
+    lsdr_check(lsdr_rotator_run(h, (const lsdr_cf32 *)in.rd(), count, (lsdr_cf32 *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<cf32> in;
+  pipewriter<cf32> out;
+  lsdr_rotator *h;
+};
+
 // spectrum<f32> (sdr.h:1347-1404): device input pipe, host output pipe of float[1024] rows.
 template <typename T>
 struct spectrum;

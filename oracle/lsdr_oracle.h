@@ -96,6 +96,12 @@ void lo_cnr_fft_free(lo_cnr_fft *c);
 size_t lo_cnr_fft_run(lo_cnr_fft *c, float freq_tap, float tap_multiplier,
                       const lo_cf32 *in, size_t n, float *out, size_t cap);
 
+/* rotator<f32>: sdr.h:1226-1259 (state: 16-bit table index) */
+typedef struct lo_rotator lo_rotator;
+lo_rotator *lo_rotator_new(float freq);
+void lo_rotator_free(lo_rotator *r);
+void lo_rotator_run(lo_rotator *r, const lo_cf32 *in, size_t n, lo_cf32 *out);
+
 /* spectrum<f32>: sdr.h:1347-1404 (nfft = 1024) */
 typedef struct lo_spectrum lo_spectrum;
 lo_spectrum *lo_spectrum_new(int decimation, float kavg);

@@ -354,3 +354,24 @@ size_t lo_spectrum_run(lo_spectrum *c, const lo_cf32 *in, size_t n, float *out, 
   free(data);
   return nout;
 }
+
+/* ---- rotator<f32>, sdr.h:1226-1259 ------------------------------------------- */
+struct lo_rotator { float lut_cos[65536], lut_sin[65536]; unsigned short index; };
+lo_rotator *lo_rotator_new(float freq) {
+  lo_rotator *r = (lo_rotator *)calloc(1, sizeof(*r));
+  int ifreq = freq * 65536;
+  for (int i = 0; i < 65536; ++i) {                       /* 2*M_PI * i * ifreq / 65536 in double, cosf of its float value */
+    r->lut_cos[i] = cosf(2 * M_PI * i * ifreq / 65536);
+    r->lut_sin[i] = sinf(2 * M_PI * i * ifreq / 65536);
+  }
+  r->index = 0;
+  return r;
+}
+void lo_rotator_free(lo_rotator *r) { free(r); }
+void lo_rotator_run(lo_rotator *r, const lo_cf32 *in, size_t n, lo_cf32 *out) {
+  for (size_t k = 0; k < n; ++k, ++r->index) {
+    const float c = r->lut_cos[r->index], s = r->lut_sin[r->index];
+    out[k].re = in[k].re * c - in[k].im * s;
+    out[k].im = in[k].re * s + in[k].im * c;
+  }
+}

@@ -257,6 +257,23 @@ class Oracle:
         self.lib.lo_cnr_fft_free(h)
         return out[:n]
 
+    def rotator(self, x, freq, splits=()):
+        """rotator<f32>; `splits` cuts the stream into several run() calls (the 16-bit index is carried)."""
+        x = cf32(x)
+        L = self.lib
+        L.lo_rotator_new.restype = C.c_void_p
+        L.lo_rotator_new.argtypes = [c_f]
+        L.lo_rotator_free.argtypes = [C.c_void_p]
+        L.lo_rotator_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p]
+        h = L.lo_rotator_new(freq)
+        out = np.empty_like(x)
+        pos = 0
+        for e in list(splits) + [len(x)]:
+            L.lo_rotator_run(h, x[pos:].ctypes.data, e - pos, out[pos:].ctypes.data)
+            pos = e
+        L.lo_rotator_free(h)
+        return out
+
     def spectrum(self, x, decimation=1048576, kavg=0.1):
         x = cf32(x)
         h = self.lib.lo_spectrum_new(decimation, kavg)
@@ -665,6 +682,14 @@ class Ref:
         x = cf32(x)
         out = np.empty(len(x) // nfft + 1, np.float32)
         n = self.lib.ref_cnr_fft(bandwidth, nfft, decimation, freq_tap, tap_multiplier, _p(x), len(x), _p(out), len(out))
+        return out[:n]
+
+    def rotator(self, x, freq):
+        x = cf32(x)
+        self.lib.ref_rotator.restype = C.c_long
+        self.lib.ref_rotator.argtypes = [c_f, C.c_void_p, C.c_long, C.c_void_p]
+        out = np.empty_like(x)
+        n = self.lib.ref_rotator(freq, _p(x), len(x), _p(out))
         return out[:n]
 
     def spectrum(self, x, decimation=1048576, kavg=0.1):

@@ -263,6 +263,19 @@ long ref_cnr_fft(float bandwidth, int nfft, int decimation, float freq_tap,
   return w.pos;
 }
 
+// sdr.h:1226-1259   rotator<f32>
+long ref_rotator(float freq, const float *in, long n, float *out) {
+  scheduler sch;
+  pipebuf<cf32> p_in(&sch, "in", BUF_BASEBAND), p_out(&sch, "out", BUF_BASEBAND);
+  buffer_reader<cf32> rd(&sch, (cf32 *)in, n, p_in);
+  rotator<f32> *ro = new rotator<f32>(&sch, p_in, p_out, freq);
+  buffer_writer<cf32> w(&sch, p_out, (cf32 *)out, n);
+  sch.run();
+  long k = w.pos;
+  delete ro;
+  return k;
+}
+
 // sdr.h:1347-1404   spectrum<f32>
 long ref_spectrum(int decimation, float kavg, const float *in, long n, float *out, long cap_rows) {
   scheduler sch;

@@ -192,3 +192,25 @@ def test_hs_tiled_app_ts_matches_exact_chain(oracle):
     assert tail[0] in got
     i0 = got.index(tail[0])
     assert got[i0:i0 + len(tail)] == tail
+
+
+def test_derotate_and_fd_const(oracle):
+    """--derotate (rotator<f32> in front of the receiver) and --fd-const (CONST line + SYMBOLS batches of 128 sampled
+    points): symbols == oracle rotator → receiver; the SYMBOLS lines carry the receiver's constellation output."""
+    g = gold("cstln_receiver.npz")
+    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq4"]))
+    p = subprocess.run([APP, "--out-symbols", "--anf", "0", "--f32", "--float-scale", str(float(g["scale"])), "-f", "8e6", "--sr", "2e6",
+                        "--derotate", "16000", "--fd-const", "2"], input=iq16_to_cf32(g["iq4"]).tobytes(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()
+    sym = np.frombuffer(p.stdout, SOFTSYM)
+    xr = oracle.rotator(x, float(np.float32(-16000.0) / np.float32(8e6)))
+    want = oracle.rx(po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=int(8e6 / 5)), xr)
+    assert bits_equal(sym["cost"], want["sym"]["cost"]) and bits_equal(sym["symbol"], want["sym"]["symbol"])
+    lines = p.stderr.decode().split("\n")
+    assert lines[0] == "CONST 4 53,53 53,-53 -53,53 -53,-53"
+    batches = [l for l in lines if l.startswith("SYMBOLS 128 ")]
+    assert len(batches) == len(want["cstln"]) // 128
+    first = [tuple(int(v) for v in t.split(",")) for t in batches[0].split()[2:]]
+    ref_pts = [(int(float("%.0f" % c.real)), int(float("%.0f" % c.imag))) for c in want["cstln"][:128]]
+    assert first == ref_pts

@@ -97,3 +97,17 @@ def test_spectrum_golden(capi, ctx, oracle):
     b, cb = sp.run(x[ca:])
     sp.close()
     assert bits_equal(np.concatenate([a, b]), s["d3000_k01"])
+
+
+@pytest.mark.gpu
+def test_rotator_golden(capi, ctx, oracle):
+    import hashlib
+    g = gold("rotator.npz")
+    t = np.arange(70000)
+    x = ((t % 251) - 125 + 1j * ((t * 7) % 199 - 99)).astype(np.complex64)
+    for name, f in (("p01", 0.01), ("m123", -0.123)):
+        r = capi.Rotator(ctx, f)
+        y = np.concatenate([r.run(x[:5]), r.run(x[5:40000]), r.run(x[40000:])])
+        r.close()
+        assert hashlib.sha256(y.tobytes()).digest() == bytes(g[name + "_sha"])
+        assert bits_equal(y, oracle.rotator(x, f))

@@ -193,3 +193,18 @@ def test_spectrum(oracle):
     assert bits_equal(oracle.spectrum(x, 4096, 0.5), s["d4096_k05"])
     assert bits_equal(oracle.spectrum(x, 3000, 0.1), s["d3000_k01"])
     assert s["d4096_k05"].shape == (8, 1024)
+
+
+def rotator_input():
+    t = np.arange(70000)
+    return ((t % 251) - 125 + 1j * ((t * 7) % 199 - 99)).astype(np.complex64)
+
+
+def test_rotator(oracle):
+    """rotator<f32> (sdr.h:1226-1259): table of cosf/sinf(2π·i·ifreq/65536), 16-bit index carried across calls."""
+    g = gold("rotator.npz")
+    x = rotator_input()
+    for name, f in (("p01", 0.01), ("m123", -0.123)):
+        y = oracle.rotator(x, f, splits=(5, 40000, 65536))
+        assert sha(y) == bytes(g[name + "_sha"]).hex()
+        assert bits_equal(y[:64], g[name + "_head"]) and bits_equal(y[65530:65546], g[name + "_wrap"])

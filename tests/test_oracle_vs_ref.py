@@ -115,3 +115,8 @@ def test_cstln_receiver_fir_sampler(oracle, ref, sig):
     rr1 = oracle.rrc(40, np.float32(0.25), np.float32(0.35))
     p = po.rx_params(sampler=2, coeffs=rr1, subsampling=1, cstln=1, omega=4.0, meas_decimation=4096)
     same_rx(oracle.rx(p, sig), ref.rx(p, sig))
+
+
+def test_rotator(oracle, ref, sig):
+    for f in (0.01, -0.123, 0.4999, 1e-5):
+        assert bits_equal(oracle.rotator(sig, f, splits=(7, 3000)), ref.rotator(sig, f))
