@@ -13,6 +13,8 @@ struct lsdr_ctx {
   bool own_stream;
   hipEvent_t ev0, ev1;
   int num_cu;
+  void *bounce;          // scratch of lsdr_memcpy_d2d for overlapping ranges (pipebuf::pack)
+  size_t bounce_cap;
 };
 
 struct lsdr_event {

@@ -8,12 +8,25 @@ sys.path.insert(0, ROOT)
 from leansdr_amd import synth_dvbs
 npk = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 flags = sys.argv[2:]
+repeat = 1
+if "--repeat" in flags:      # feed the capture N times back to back (steady-state throughput; the joints cost a re-lock)
+    i = flags.index("--repeat")
+    repeat = int(flags[i + 1])
+    del flags[i:i + 2]
 path = f"/tmp/cap_{npk}.u8"
 if not os.path.exists(path):
     chunks = []
     # build in pieces of 1000 packets to bound memory; continuity across pieces is not needed for a throughput run
     iq, ts = synth_dvbs.capture_u8(n_packets=npk, seed=7)
     iq.tofile(path)
+if repeat > 1:
+    rpath = f"/tmp/cap_{npk}x{repeat}.u8"
+    if not os.path.exists(rpath):
+        data = open(path, "rb").read()
+        with open(rpath, "wb") as f:
+            for _ in range(repeat):
+                f.write(data)
+    path = rpath
 n = os.path.getsize(path) // 2
 app = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
 cmd = [app, "--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"] + flags
