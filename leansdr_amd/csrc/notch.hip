@@ -17,7 +17,8 @@ namespace {
 
 constexpr int kN = 4096;          // fft.n of auto_notch (sdr.h:55)
 constexpr int kMaxSlots = 8;
-constexpr int kTileBlocks = 2, kWarmBlocks = 4;
+constexpr int kTrip = 32;          // samples per register trip of k_notch
+constexpr int kTileBlocks = 1, kWarmBlocks = 4;   // forgetting the start takes ≈ 8300 samples (0.998^n below float resolution) plus a few thousand for two nearby roundings to coincide; 3 blocks fail verification about once per run
 
 struct notch_est { float re[kMaxSlots], im[kMaxSlots]; };
 
@@ -35,25 +36,46 @@ struct notch_args {
   int serial_from;                 // ≥ 0: single sequential job starting at this block (repair); -1: tiled
 };
 
+typedef float notch_v2f __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) notch_v2f *notch_cptr;
+
+constexpr int kLdsSlots = 4;   // 32 KB of phasors per slot
+// Tiles (lanes) per wavefront.  Every lane walks its own stretch of memory, so a load/store instruction touches one cache
+// line per active lane and the address unit serialises them: with 64 lanes the 32 memory instructions of a trip cost
+// ≈ 64 cycles each (≈ 64 cycles/sample, twice the arithmetic).  The GPU is otherwise idle here (a run has a few hundred
+// tiles), so fewer lanes per wave and more waves is free.
+constexpr int kNotchLanes = 16;
+
 template <int NS>
-__global__ __launch_bounds__(64) void k_notch(notch_args a) {
-  const unsigned t = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(64) void k_notch(notch_args a) {   // 64 threads fill the LDS, kNotchLanes of them own a tile
+  extern __shared__ __attribute__((aligned(16))) char notch_smem[];
+  notch_v2f *lds_e = reinterpret_cast<notch_v2f *>(notch_smem);
+  if (NS <= kLdsSlots) {
+    for (int i = threadIdx.x; i < NS * kN; i += 64) { const float2 v = a.expj[i]; notch_v2f w = {v.x, v.y}; lds_e[i] = w; }
+    __syncthreads();
+  }
+  if (threadIdx.x >= kNotchLanes) return;
+  const unsigned t = blockIdx.x * kNotchLanes + threadIdx.x;
   if (t >= a.n_tiles) return;
   unsigned long long b0, b1;
   bool from_carry;
   if (a.serial_from >= 0) { b0 = (unsigned long long)a.serial_from; b1 = a.n_blocks; from_carry = true; }
-  else {
-    b0 = (unsigned long long)t * a.tile_blocks;
+  else if (t == 0) {   // tile 0 is long enough (warm-up + tile) for tile 1 to warm up fully inside this launch
+    b0 = 0; b1 = (unsigned long long)a.warm_blocks + a.tile_blocks;
+    if (b1 > a.n_blocks) b1 = a.n_blocks;
+    from_carry = true;
+  } else {
+    b0 = (unsigned long long)a.warm_blocks + a.tile_blocks + (unsigned long long)(t - 1) * a.tile_blocks;
     b1 = b0 + a.tile_blocks;
     if (b1 > a.n_blocks) b1 = a.n_blocks;
-    from_carry = t == 0;
+    from_carry = false;
   }
   float er[NS], ei[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) { er[s] = from_carry ? a.carry->re[s] : 0.f; ei[s] = from_carry ? a.carry->im[s] : 0.f; }
   const float k = a.k, omk = 1 - a.k, gain = a.gain;
   unsigned long long bstart = b0;
-  if (!from_carry) bstart = b0 >= a.warm_blocks ? b0 - a.warm_blocks : 0;   // (tiles that cannot warm up fully are not created)
+  if (!from_carry) bstart = b0 - a.warm_blocks;
   for (unsigned long long b = bstart; b < b1; ++b) {
     if (b == b0) {
 #pragma unroll
@@ -65,31 +87,52 @@ __global__ __launch_bounds__(64) void k_notch(notch_args a) {
     // 8 samples per trip: the loads (one 64-byte line per lane) and the phasor fetches (wave-uniform) are issued
     // together, the recurrence then runs on registers, the 8 results leave as one line.  The per-sample
     // arithmetic and its order are the reference's (sdr.h:124-134).
-    for (int i0 = 0; i0 < kN; i0 += 8) {
-      float2 x8[8], o8[8];
+    // Two trips (kTrip samples each) are kept in flight in alternating register sets.  gfx9 counts loads and stores in
+    // the same vmcnt and cannot wait on loads past younger stores, so every wait for a trip's samples also drains the
+    // previous trip's stores: long trips amortise that round trip (8-sample trips: ~120 cycles/sample, mostly drain).
+    auto trip = [&](const float2 (&x8)[kTrip], int i0) {
+      float2 o8[kTrip];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) x8[j] = pin[i0 + j];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float2 x = x8[j];
-        float o_re = x.x, o_im = x.y;
+      for (int j = 0; j < kTrip; ++j) {
+        // (re, im) pairs as 2-vectors → v_pk_mul_f32 / v_pk_add_f32: the same individually rounded products and sums
+        // as the scalar expressions of sdr.h:124-134 (negations are exact), half the instructions.
+        const notch_v2f xx = {x8[j].x, x8[j].x}, xy = {x8[j].y, x8[j].y};
+        notch_v2f o = {x8[j].x, x8[j].y};
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-          const float2 e = a.expj[s * kN + i0 + j];
-          const float bbre = x.x * e.x + x.y * e.y;
-          const float bbim = -x.x * e.y + x.y * e.x;
-          er[s] = bbre * k + er[s] * omk;
-          ei[s] = bbim * k + ei[s] * omk;
-          const float subre = er[s] * e.x - ei[s] * e.y;
-          const float subim = er[s] * e.y + ei[s] * e.x;
-          o_re -= subre;
-          o_im -= subim;
+          // slot phasors: wave-uniform.  LDS copy (broadcast ds_read, pipelined by the scheduler) when it fits, else s_load
+          const notch_v2f e = NS <= kLdsSlots ? lds_e[s * kN + i0 + j] : ((notch_cptr)a.expj)[s * kN + i0 + j];
+          const notch_v2f e_conj = {e.x, -e.y}, e_swap = {e.y, e.x}, e_rot = {-e.y, e.x};
+          const notch_v2f bb = xx * e_conj + xy * e_swap;              // x·conj(e)
+          notch_v2f est = {er[s], ei[s]};
+          est = bb * k + est * omk;
+          er[s] = est.x; ei[s] = est.y;
+          const notch_v2f ser = {est.x, est.x}, sei = {est.y, est.y};
+          const notch_v2f sub = ser * e + sei * e_rot;                 // estim·e
+          o = o - sub;
         }
-        o8[j] = make_float2(gain * o_re, gain * o_im);
+        o8[j] = make_float2(gain * o.x, gain * o.y);
       }
       if (emit) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) pout[i0 + j] = o8[j];
+        for (int j = 0; j < kTrip; ++j) pout[i0 + j] = o8[j];
+      }
+    };
+    float2 xa[kTrip], xb[kTrip];
+#pragma unroll
+    for (int j = 0; j < kTrip; ++j) xa[j] = pin[j];
+#pragma unroll
+    for (int j = 0; j < kTrip; ++j) xb[j] = pin[kTrip + j];
+    for (int i0 = 0; i0 < kN; i0 += 2 * kTrip) {
+      trip(xa, i0);
+      if (i0 + 2 * kTrip < kN) {
+#pragma unroll
+        for (int j = 0; j < kTrip; ++j) xa[j] = pin[i0 + 2 * kTrip + j];
+      }
+      trip(xb, i0 + kTrip);
+      if (i0 + 3 * kTrip < kN) {
+#pragma unroll
+        for (int j = 0; j < kTrip; ++j) xb[j] = pin[i0 + 3 * kTrip + j];
       }
     }
   }
@@ -208,7 +251,11 @@ static void notch_detect(lsdr_auto_notch *a, const lsdr_cf32 *pin) {
 }
 
 template <int NS>
-static void notch_launch_ns(hipStream_t st, unsigned grid, const notch_args &a) { hipLaunchKernelGGL(k_notch<NS>, dim3(grid), dim3(64), 0, st, a); }
+static void notch_launch_ns(hipStream_t st, unsigned grid, const notch_args &a) {
+  const size_t lds = NS <= kLdsSlots ? (size_t)NS * kN * sizeof(float2) : 0;
+  if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void *)k_notch<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_notch<NS>, dim3(grid), dim3(64), lds, st, a);
+}
 static void notch_launch(int ns, hipStream_t st, unsigned grid, const notch_args &a) {
   switch (ns) {
     case 1: notch_launch_ns<1>(st, grid, a); break;
@@ -236,7 +283,8 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
   }
   // tiles: tile 0 covers the first (kWarmBlocks + kTileBlocks) blocks so that every other tile can warm up fully
   const unsigned TB = kTileBlocks, WB = kWarmBlocks;
-  unsigned n_tiles = (unsigned)((nb + TB - 1) / TB);
+  auto tile_start = [&](unsigned t) -> unsigned long long { return t == 0 ? 0ull : (unsigned long long)WB + TB + (unsigned long long)(t - 1) * TB; };
+  unsigned n_tiles = nb > (size_t)(WB + TB) ? 1u + (unsigned)((nb - (WB + TB) + TB - 1) / TB) : 1u;
   if (a->tiles_cap < n_tiles) {
     (void)hipFree(a->d_begin); (void)hipFree(a->d_end);
     LSDR_HIP(hipMalloc((void **)&a->d_begin, n_tiles * sizeof(notch_est)));
@@ -249,17 +297,17 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
   na.in = (const float2 *)in; na.out = (float2 *)out; na.expj = a->d_expj; na.nslots = a->nslots;
   na.k = a->k; na.gain = a->gain; na.n_blocks = nb; na.tile_blocks = TB; na.warm_blocks = WB; na.n_tiles = n_tiles;
   na.carry = a->d_carry; na.begin = a->d_begin; na.end = a->d_end; na.serial_from = -1;
-  notch_launch(a->nslots, c->stream, (n_tiles + 63) / 64, na);
+  notch_launch(a->nslots, c->stream, (n_tiles + kNotchLanes - 1) / kNotchLanes, na);
   LSDR_HIP(hipGetLastError());
   std::vector<notch_est> hb(n_tiles), he(n_tiles);
   LSDR_HIP(hipMemcpyAsync(hb.data(), a->d_begin, n_tiles * sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipMemcpyAsync(he.data(), a->d_end, n_tiles * sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));
   a->last_tiles += n_tiles;
-  // seam verification.  Tiles whose warm-up was cut short by the start of the span (t·TB < WB) always count as unverified.
+  // seam verification
   unsigned first_bad = n_tiles;
   for (unsigned t = 1; t < n_tiles; ++t) {
-    bool ok = (unsigned long long)t * TB >= WB;
+    bool ok = true;
     for (int s = 0; ok && s < a->nslots; ++s)
       ok = memcmp(&hb[t].re[s], &he[t - 1].re[s], 4) == 0 && memcmp(&hb[t].im[s], &he[t - 1].im[s], 4) == 0;
     if (!ok) { first_bad = t; break; }
@@ -275,8 +323,8 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
       ++a->last_bad;
       LSDR_HIP(hipMemcpyAsync(a->d_carry, &state, sizeof(notch_est), hipMemcpyHostToDevice, c->stream));
       notch_args ra = na;
-      ra.serial_from = (int)((unsigned long long)t * TB);
-      unsigned long long bend = (unsigned long long)(t + 1) * TB;
+      ra.serial_from = (int)tile_start(t);
+      unsigned long long bend = tile_start(t + 1);
       if (bend > nb) bend = nb;
       ra.n_blocks = bend;
       ra.n_tiles = 1;
@@ -287,7 +335,7 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
       he[t] = state;
       ++t;
       if (t < n_tiles) {
-        bool ok = (unsigned long long)t * TB >= WB;
+        bool ok = true;
         for (int s = 0; ok && s < a->nslots; ++s)
           ok = memcmp(&hb[t].re[s], &state.re[s], 4) == 0 && memcmp(&hb[t].im[s], &state.im[s], 4) == 0;
         if (ok) {   // the speculative tiles from here on started from the right state; keep scanning their seams
