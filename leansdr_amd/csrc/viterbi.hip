@@ -25,7 +25,11 @@ namespace {
 
 constexpr int kChunkBlocks = 128;   // viterbi_sync::chunk_size, dvb.h:1229
 constexpr int kStates = 64;
-constexpr int kWarm = 4;            // warm-up chunks (512 trellis steps)
+static int vit_warm() {             // warm-up chunks of a tile (128 trellis steps each); LSDR_VIT_WARM is a tuning hook
+  static int w = getenv("LSDR_VIT_WARM") ? atoi(getenv("LSDR_VIT_WARM")) : 4;
+  return w < 1 ? 1 : w;
+}
+#define kWarm (vit_warm())
 constexpr int kMaxSyncs = 64;
 
 struct vit_code {           // fec_specs + typedefs, dvb.h:520-566,1179-1212
