@@ -248,25 +248,49 @@ __global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsign
   __syncthreads();
   const int chunk = kRS * S.scan_syncs;
   if (S.synchronized) {   // run_decoding, dvb.h:842-875
-    while (n_in - pos >= (unsigned long long)kRS + 1 && cap - nout >= (unsigned long long)kRS && !s_stop) {
+    // While locked, bit phase and polarity are constant: batches of up to kBatch packets are realigned by all threads,
+    // then thread 0 replays the per-packet bookkeeping (sync byte test, lock_timeleft, phase8) over the batch and cuts
+    // it where the reference would have dropped the lock.  Same bytes, same events; two barriers per batch, not per packet.
+    constexpr unsigned kBatch = 64;
+    __shared__ unsigned s_valid;
+    while (!s_stop) {
+      if (n_in - pos < (unsigned long long)kRS + 1 || cap - nout < (unsigned long long)kRS) break;
+      unsigned long long P = (n_in - pos - 1) / kRS;
+      if (P > (cap - nout) / kRS) P = (cap - nout) / kRS;
+      if (P > kBatch) P = kBatch;
       const unsigned char *pin = in + pos;
       unsigned char *pout = out + nout;
-      if (tid < kRS) pout[tid] = (unsigned char)(shift_byte(pin + tid, S.bitphase) ^ S.polarity);
+      const unsigned nbytes = (unsigned)P * kRS;
+      for (unsigned i = tid; i < nbytes; i += 256) pout[i] = (unsigned char)(shift_byte(pin + i, S.bitphase) ^ S.polarity);
       __syncthreads();
-      if (tid == 0) {
-        const unsigned char syncbyte = pout[0];
-        pos += kRS; nout += kRS;
-        ++S.locktime;
-        const unsigned char expected = S.phase8 ? kSync : kSyncInv;
-        if (syncbyte == expected) S.lock_timeleft = S.lock_timeout;
-        S.phase8 = (S.phase8 + 1) & 7;
-        --S.lock_timeleft;
-        if (!S.lock_timeleft) {
-          S.synchronized = 0;
-          S.next_sync_count = 0;
-          R.events[R.n_events++] = 0;
-          s_stop = 1;
+      // wave 0: lane p tests packet p's sync byte against the value the 8-packet phase counter predicts for it
+      unsigned long long okmask = 0;
+      if (tid < 64) {
+        bool ok = false;
+        if ((unsigned)tid < (unsigned)P) {
+          const unsigned char expected = ((S.phase8 + tid) & 7) ? kSync : kSyncInv;
+          ok = pout[(unsigned)tid * kRS] == expected;
         }
+        okmask = __ballot(ok);
+      }
+      if (tid == 0) {
+        unsigned p = 0;
+        for (; p < (unsigned)P; ++p) {
+          ++S.locktime;
+          if ((okmask >> p) & 1ull) S.lock_timeleft = S.lock_timeout;
+          S.phase8 = (S.phase8 + 1) & 7;
+          --S.lock_timeleft;
+          if (!S.lock_timeleft) {
+            S.synchronized = 0;
+            S.next_sync_count = 0;
+            R.events[R.n_events++] = 0;
+            s_stop = 1;
+            ++p;
+            break;
+          }
+        }
+        s_valid = p;
+        pos += (unsigned long long)p * kRS; nout += (unsigned long long)p * kRS;
       }
       __syncthreads();
     }
