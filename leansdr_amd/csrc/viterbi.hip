@@ -56,6 +56,7 @@ struct vit_job {            // one wavefront's work
   int from_state;                    // index into states_in (warm == 0) or -1 (zero metrics)
   int emit;                          // write decoded bytes
   unsigned chunk_step;               // distance between emitted chunks (1: contiguous; P: the resync chunks only)
+  unsigned slot;                     // where the job's begin/end/first states and totals go (normally its own index)
 };
 
 struct vit_args {
@@ -115,8 +116,8 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
     const unsigned long long c = (unsigned long long)((long long)job.first_chunk + q * (long long)job.chunk_step);
     const bool emitting = q >= 0;
     if (q == 0) {   // (metrics are normalised at every chunk boundary)
-      a.begin_states[jid].cost[lane] = cost;
-      a.begin_states[jid].path[lane] = path;
+      a.begin_states[job.slot].cost[lane] = cost;
+      a.begin_states[job.slot].path[lane] = path;
     }
     const bool resync = ((c + (unsigned long long)a.resync_phase0) % (unsigned)a.resync_period) == 0;
     const bool want_q = resync && emitting;
@@ -196,16 +197,16 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
     cost -= wave_min(cost);
     if (emitting) {
       const unsigned ci = (unsigned)q;
-      if (lane == 0) a.totals[(size_t)jid * a.totals_stride + ci] = total;
+      if (lane == 0) a.totals[(size_t)job.slot * a.totals_stride + ci] = total;
       if (a.chunk_states) {
-        vit_state *st = a.chunk_states + (size_t)jid * a.totals_stride + ci;
+        vit_state *st = a.chunk_states + (size_t)job.slot * a.totals_stride + ci;
         st->cost[lane] = cost; st->path[lane] = path;
       }
-      if (ci == 0) { a.first_chunk_states[jid].cost[lane] = cost; a.first_chunk_states[jid].path[lane] = path; }
+      if (ci == 0) { a.first_chunk_states[job.slot].cost[lane] = cost; a.first_chunk_states[job.slot].path[lane] = path; }
     }
   }
-  a.end_states[jid].cost[lane] = cost;
-  a.end_states[jid].path[lane] = path;
+  a.end_states[job.slot].cost[lane] = cost;
+  a.end_states[job.slot].path[lane] = path;
 }
 
 // seam check: begin state of job j (j ≥ 1) == end state of job j−1
@@ -263,9 +264,10 @@ static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
 }
 
 static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
-                      unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr) {
+                      unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr,
+                      const vit_state *dev_start_states = nullptr, bool keep_slots = false, size_t n_slots = 0) {
   lsdr_ctx *c = v->ctx;
-  const size_t nj = jobs.size();
+  const size_t nj = keep_slots ? (n_slots > jobs.size() ? n_slots : jobs.size()) : jobs.size();   // capacity of the slot arrays
   if (start_states && v->fix_cap < start_states->size()) {
     (void)hipFree(v->d_fix);
     LSDR_HIP(hipMalloc((void **)&v->d_fix, start_states->size() * sizeof(vit_state)));
@@ -290,7 +292,9 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
     LSDR_HIP(hipMalloc((void **)&v->d_chunk, nj * stride * sizeof(vit_state)));
     v->chunk_cap = nj * stride;
   }
-  LSDR_HIP(hipMemcpyAsync(v->d_jobs, jobs.data(), nj * sizeof(vit_job), hipMemcpyHostToDevice, c->stream));
+  std::vector<vit_job> up(jobs);
+  if (!keep_slots) for (size_t i = 0; i < up.size(); ++i) up[i].slot = (unsigned)i;
+  LSDR_HIP(hipMemcpyAsync(v->d_jobs, up.data(), up.size() * sizeof(vit_job), hipMemcpyHostToDevice, c->stream));
   LSDR_HIP(hipMemcpyAsync(v->d_states, v->states.data(), v->nsyncs * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
   if (start_states)
     LSDR_HIP(hipMemcpyAsync(v->d_fix, start_states->data(), start_states->size() * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
@@ -299,12 +303,12 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.bits_per_symbol = v->bits_per_symbol; a.nshifts = v->nshifts;
   a.resync_phase0 = phase0; a.resync_period = v->resync_period;
   a.maps = v->d_maps; a.shifts = v->d_shifts;
-  a.jobs = v->d_jobs; a.states_in = start_states ? v->d_fix : v->d_states;
+  a.jobs = v->d_jobs; a.states_in = dev_start_states ? dev_start_states : (start_states ? v->d_fix : v->d_states);
   a.begin_states = v->d_begin; a.end_states = v->d_end; a.first_chunk_states = v->d_first;
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
-  a.njobs = (unsigned)nj;
-  hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((nj + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
+  a.njobs = (unsigned)up.size();
+  hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }
@@ -476,11 +480,35 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   LSDR_HIP(hipMemcpyAsync(totals_main.data(), v->d_totals, n_main * stride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));
   v->last_tiles = (unsigned)n_main; v->last_bad = 0;
-  // ---- repair: the first seam that failed verification invalidates everything after it.  Re-decode
-  // sequentially from the previous tile's end state (exact by construction).
+  // ---- fix-up rounds: a tile whose speculative start state differs from its predecessor's end state is decoded
+  // again from that end state (read on the device from the slot array; results land in the tile's own slots); a changed
+  // end state shows up at the next seam in the next round.  The seam check is redone over all tiles after every round,
+  // and it compares the state each job actually started from, so the result is exact whatever the interleaving.
+  for (int round = 0; round < 6; ++round) {
+    std::vector<vit_job> fj;
+    for (size_t k = 1; k < n_main; ++k)
+      if (bad[k]) {
+        vit_job j = jobs[k];
+        j.warm = 0; j.from_state = (int)(k - 1); j.slot = (unsigned)k;
+        fj.push_back(j);
+      }
+    if (fj.empty()) break;
+    v->last_bad += (unsigned)fj.size();
+    rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_main);
+    if (rc) return rc;
+    LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream, (const vit_state *)v->d_begin,
+                       (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
+    LSDR_HIP(hipMemcpyAsync(bad.data(), v->d_bad, n_main * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipMemcpyAsync(totals_main.data(), v->d_totals, n_main * stride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+  }
+  // ---- last resort (seams that keep failing): everything from the first bad seam on, sequentially, from the previous
+  // tile's end state (exact by construction).
   size_t first_bad = n_main;
   for (size_t j = 1; j < n_main; ++j) if (bad[j]) { first_bad = j; break; }
   std::vector<vit_state> main_first(n_main);   // state after the first chunk of each tile (alignment switches)
+  bool main_first_on_device = false;
   vit_state main_end;
   if (first_bad < n_main) {
     for (size_t j = first_bad; j < n_main; ++j) v->last_bad += bad[j] ? 1u : 0u;
@@ -510,7 +538,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       main_first[t] = cst[off];
     }
   } else {
-    LSDR_HIP(hipMemcpy(main_first.data(), v->d_first, n_main * sizeof(vit_state), hipMemcpyDeviceToHost));
+    main_first_on_device = true;   // fetched per tile only if an alignment switch needs it (2.8 MB per call otherwise)
     LSDR_HIP(hipMemcpy(&main_end, v->d_end + (n_main - 1), sizeof(vit_state), hipMemcpyDeviceToHost));
   }
 
@@ -642,7 +670,10 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
           for (int s2 : all_others) st[s2] = other_states[s2][r];
         }
         vit_state old_cur;
-        if (rs[r] == jobs[tj].first_chunk) old_cur = main_first[tj];
+        if (rs[r] == jobs[tj].first_chunk) {
+          if (main_first_on_device) LSDR_HIP(hipMemcpy(&old_cur, v->d_first + tj, sizeof(vit_state), hipMemcpyDeviceToHost));
+          else old_cur = main_first[tj];
+        }
         else {   // resync chunk inside tile 0 (its first chunk is not a resync chunk): recompute sequentially
           if (tj != 0) { lsdr_set_error("viterbi_sync: internal tiling error"); return LSDR_E_ARG; }
           vit_job j;
