@@ -125,8 +125,11 @@ int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *b
 /* run(), sdr.h:64-75: whole 4096-sample blocks; *consumed == *produced.  Synchronous. */
 int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
                         size_t *consumed, size_t *produced);
-/* cfft_engine<float>::inplace (dsp.h:56-116) on host data — exact restatement used by detect()/cnr_fft. */
-int lsdr_cfft_host(int n, lsdr_cf32 *data_host, int reverse);
+/* cfft_engine<float>::inplace (dsp.h:56-116).  lsdr_cfft_run: the transform of one device block on the GPU (one workgroup,
+ * in LDS, bit-identical butterflies) with the spectrum delivered to the host — what auto_notch::detect, cnr_fft and spectrum
+ * use.  lsdr_cfft_host: the same arithmetic on host data (utility / cross-check). */
+int lsdr_cfft_run(lsdr_ctx *ctx, int n, int reverse, const lsdr_cf32 *in_dev, lsdr_cf32 *out_host);
+int lsdr_cfft_host(int n, lsdr_cf32 *data, int reverse);
 /* cnr_fft<f32>, sdr.h:1273-1345: consumes whole nfft blocks; every `decimation` samples one block is
  * fetched and a CNR value (dB) is appended to cnr_out_host.  Synchronous only when a block is fetched. */
 typedef struct lsdr_cnr_fft lsdr_cnr_fft;

@@ -113,6 +113,7 @@ _sig("lsdr_hsdeconv_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
 _sig("lsdr_hsdeconv_destroy", None, [vp])
 _sig("lsdr_hsdeconv_locked", C.c_int, [vp])
 _sig("lsdr_hsdeconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_cfft_run", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
 _sig("lsdr_rotator_create", C.c_int, [vp, c_f, C.POINTER(vp)])
 _sig("lsdr_rotator_destroy", None, [vp])
 _sig("lsdr_rotator_run", C.c_int, [vp, vp, c_sz, vp])
@@ -645,6 +646,16 @@ class Derandomizer:
 
 
 # ---- auto_notch / cnr_fft / cfft ------------------------------------------------------
+def cfft_dev(ctx, x, reverse=False):
+    """cfft_engine<float> on the GPU (k_cfft): upload one block, transform, spectrum back on the host."""
+    x = np.ascontiguousarray(x, np.complex64)
+    din = ctx.upload(x)
+    out = np.empty_like(x)
+    check(lib.lsdr_cfft_run(ctx.h, len(x), int(reverse), din.ptr, _np(out)))
+    din.free()
+    return out
+
+
 def cfft_host(x, reverse=False):
     x = np.ascontiguousarray(x, np.complex64).copy()
     check(lib.lsdr_cfft_host(len(x), _np(x), int(reverse)))

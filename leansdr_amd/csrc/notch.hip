@@ -184,6 +184,70 @@ void cfft_host(int n, lsdr_cf32 *data, bool reverse) {
   }
 }
 
+// cfft_engine<float>::inplace on the GPU: one workgroup, the whole transform in LDS, one barrier per radix-2 stage.
+// Every butterfly is the reference's expression (dsp.h:96-104) evaluated once, so the result is bit-identical to
+// cfft_host(); the twiddles om[] are the host-built cosf/sinf table of the engine's constructor (dsp.h:62-70).
+__global__ __launch_bounds__(1024) void k_cfft(const float2 *in, const float2 *om, float2 *out, int logn, int reverse, float invn) {
+  extern __shared__ __attribute__((aligned(16))) char cfft_smem[];
+  float2 *d = reinterpret_cast<float2 *>(cfft_smem);
+  const int n = 1 << logn, tid = threadIdx.x;
+  for (int i = tid; i < n; i += 1024) d[__brev((unsigned)i) >> (32 - logn)] = in[i];   // bit-reversal permutation (dsp.h:84-92)
+  __syncthreads();
+  for (int st = 0; st < logn; ++st) {
+    const int hbs = 1 << st, dom = 1 << (logn - 1 - st);
+    for (int b = tid; b < n / 2; b += 1024) {
+      const int j = b >> st, k = b & (hbs - 1);
+      const int p = j * hbs * 2 + k, q = p + hbs;
+      const float2 w = om[k * dom], dd = d[q], dp = d[p];
+      const float xr = w.x * dd.x - w.y * dd.y;
+      const float xi = w.x * dd.y + w.y * dd.x;
+      d[q] = make_float2(dp.x - xr, dp.y - xi);
+      d[p] = make_float2(dp.x + xr, dp.y + xi);
+    }
+    __syncthreads();
+  }
+  for (int i = tid; i < n; i += 1024) {
+    float2 v = d[i];
+    if (reverse) { v.x *= invn; v.y *= invn; }
+    out[i] = v;
+  }
+}
+
+// Per-(n, direction) device resources of the FFT: twiddle table + output scratch.
+struct cfft_dev {
+  int n, logn, reverse;
+  float2 *d_om, *d_out;
+  cfft_dev() : n(0), logn(0), reverse(0), d_om(nullptr), d_out(nullptr) {}
+};
+static int cfft_dev_init(cfft_dev *f, int n, bool reverse) {
+  if (f->d_om && f->n == n && f->reverse == (int)reverse) return LSDR_OK;
+  (void)hipFree(f->d_om); (void)hipFree(f->d_out);
+  f->n = n; f->reverse = reverse; f->logn = 0;
+  for (int t = n; t > 1; t >>= 1) ++f->logn;
+  std::vector<float2> om(n);
+  for (int i = 0; i < n; ++i) {
+    float a = (float)(2.0 * M_PI * i / n);
+    om[i].x = cosf(a);
+    om[i].y = reverse ? -sinf(a) : sinf(a);
+  }
+  LSDR_HIP(hipMalloc((void **)&f->d_om, (size_t)n * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&f->d_out, (size_t)n * sizeof(float2)));
+  LSDR_HIP(hipMemcpy(f->d_om, om.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
+  return LSDR_OK;
+}
+static void cfft_dev_free(cfft_dev *f) { (void)hipFree(f->d_om); (void)hipFree(f->d_out); f->d_om = f->d_out = nullptr; }
+// FFT of the device block `d_in` → host `spectrum` (n complex values).
+static int cfft_dev_run(lsdr_ctx *c, cfft_dev *f, const lsdr_cf32 *d_in, lsdr_cf32 *spectrum) {
+  const size_t lds = (size_t)f->n * sizeof(float2);
+  if (lds > 64 * 1024) LSDR_HIP(hipFuncSetAttribute((const void *)k_cfft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(k_cfft, dim3(1), dim3(1024), lds, c->stream, (const float2 *)d_in, (const float2 *)f->d_om, f->d_out, f->logn,
+                     f->reverse, (float)(1.0 / f->n));
+  LSDR_HIP(hipGetLastError());
+  LSDR_HIP(hipMemcpyAsync(spectrum, f->d_out, (size_t)f->n * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  return LSDR_OK;
+}
+
 }  // namespace
 
 struct lsdr_auto_notch {
@@ -198,6 +262,7 @@ struct lsdr_auto_notch {
   notch_est *d_carry, *d_begin, *d_end;
   size_t tiles_cap;
   unsigned last_tiles, last_bad;
+  cfft_dev fft;
 };
 
 struct lsdr_spectrum {
@@ -205,6 +270,7 @@ struct lsdr_spectrum {
   int decimation, phase;
   float kavg;
   std::vector<float> avgpower;   // empty until the first spectrum
+  cfft_dev fft;
 };
 
 struct lsdr_cnr_fft {
@@ -212,11 +278,11 @@ struct lsdr_cnr_fft {
   float bandwidth, kavg;
   int nfft, decimation, phase;
   std::vector<float> avgpower;     // empty until the first spectrum
+  cfft_dev fft;
 };
 
-// detect(), sdr.h:76-118, on a host copy of the block
-static void notch_detect(lsdr_auto_notch *a, const lsdr_cf32 *pin) {
-  std::vector<lsdr_cf32> data(pin, pin + kN);
+// detect(), sdr.h:76-118: AGC sums on a host copy of the block, peak search on its spectrum (FFT done by k_cfft)
+static void notch_detect(lsdr_auto_notch *a, const lsdr_cf32 *pin, const std::vector<lsdr_cf32> &data) {
   float m0 = 0, m2 = 0;
   for (int i = 0; i < kN; ++i) {
     m2 += (float)pin[i].re * pin[i].re + (float)pin[i].im * pin[i].im;
@@ -228,7 +294,6 @@ static void notch_detect(lsdr_auto_notch *a, const lsdr_cf32 *pin) {
     float new_gain = a->agc_rms_setpoint / rms;
     a->gain = (float)((double)a->gain * 0.9 + (double)new_gain * 0.1);
   }
-  cfft_host(kN, data.data(), true);
   std::vector<float> amp(kN);
   for (int i = 0; i < kN; ++i) amp[i] = hypotf(data[i].re, data[i].im);
   for (int s = 0; s < a->nslots; ++s) {
@@ -359,6 +424,16 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
 
 extern "C" {
 
+int lsdr_cfft_run(lsdr_ctx *c, int n, int reverse, const lsdr_cf32 *in_dev, lsdr_cf32 *out_host) {
+  LSDR_ARG(c && in_dev && out_host && n >= 2 && n <= 8192 && (n & (n - 1)) == 0);
+  LSDR_HIP(hipSetDevice(c->device));
+  cfft_dev f;
+  int rc = cfft_dev_init(&f, n, reverse != 0);
+  if (!rc) rc = cfft_dev_run(c, &f, in_dev, out_host);
+  cfft_dev_free(&f);
+  return rc;
+}
+
 int lsdr_cfft_host(int n, lsdr_cf32 *data, int reverse) {
   LSDR_ARG(data && n >= 1 && (n & (n - 1)) == 0);
   cfft_host(n, data, reverse != 0);
@@ -387,6 +462,7 @@ void lsdr_auto_notch_destroy(lsdr_auto_notch *a) {
   if (!a) return;
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->d_expj); (void)hipFree(a->d_carry); (void)hipFree(a->d_begin); (void)hipFree(a->d_end);
+  cfft_dev_free(&a->fft);
   delete a;
 }
 int lsdr_auto_notch_set(lsdr_auto_notch *a, int decimation, float k) {
@@ -430,7 +506,12 @@ int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, ls
         std::vector<lsdr_cf32> blk(kN);
         LSDR_HIP(hipMemcpyAsync(blk.data(), in + b * kN, kN * sizeof(lsdr_cf32), hipMemcpyDeviceToHost, c->stream));
         LSDR_HIP(hipStreamSynchronize(c->stream));
-        notch_detect(a, blk.data());
+        std::vector<lsdr_cf32> spec(kN);
+        rc = cfft_dev_init(&a->fft, kN, true);
+        if (rc) return rc;
+        rc = cfft_dev_run(c, &a->fft, in + b * kN, spec.data());
+        if (rc) return rc;
+        notch_detect(a, blk.data(), spec);
       }
       rc = notch_process(a, in + b * kN, out + b * kN, 1);
       if (rc) return rc;
@@ -453,7 +534,7 @@ int lsdr_cnr_fft_create(lsdr_ctx *c, float bandwidth, int nfft, lsdr_cnr_fft **o
   *out = f;
   return LSDR_OK;
 }
-void lsdr_cnr_fft_destroy(lsdr_cnr_fft *f) { delete f; }
+void lsdr_cnr_fft_destroy(lsdr_cnr_fft *f) { if (f) { cfft_dev_free(&f->fft); delete f; } }
 int lsdr_cnr_fft_set(lsdr_cnr_fft *f, int decimation, float kavg) {
   LSDR_ARG(f && decimation >= 1);
   f->decimation = decimation; f->kavg = kavg;
@@ -481,11 +562,9 @@ int lsdr_cnr_fft_run(lsdr_cnr_fft *f, float freq_tap, float tap_multiplier, cons
       f->phase -= f->decimation;
       LSDR_ARG(in && cnr_out);
       std::vector<lsdr_cf32> data(N);
-      LSDR_HIP(hipMemcpyAsync(data.data(), in + pos, (size_t)N * sizeof(lsdr_cf32), hipMemcpyDeviceToHost, c->stream));
-      LSDR_HIP(hipStreamSynchronize(c->stream));
+      { int rc = cfft_dev_init(&f->fft, N, true); if (rc) return rc; rc = cfft_dev_run(c, &f->fft, in + pos, data.data()); if (rc) return rc; }
       const float center_freq = freq_tap * tap_multiplier;
       const int icf = (int)floor((double)(center_freq * N) + 0.5);
-      cfft_host(N, data.data(), true);
       std::vector<float> power(N);
       for (int i = 0; i < N; ++i) power[i] = data[i].re * data[i].re + data[i].im * data[i].im;
       if (f->avgpower.empty()) f->avgpower = power;
@@ -518,7 +597,7 @@ int lsdr_spectrum_create(lsdr_ctx *c, lsdr_spectrum **out) {
   *out = f;
   return LSDR_OK;
 }
-void lsdr_spectrum_destroy(lsdr_spectrum *f) { delete f; }
+void lsdr_spectrum_destroy(lsdr_spectrum *f) { if (f) { cfft_dev_free(&f->fft); delete f; } }
 int lsdr_spectrum_set(lsdr_spectrum *f, int decimation, float kavg) {
   LSDR_ARG(f && decimation >= 1);
   f->decimation = decimation; f->kavg = kavg;
@@ -546,9 +625,7 @@ int lsdr_spectrum_run(lsdr_spectrum *f, const lsdr_cf32 *in, size_t n_in, float 
       f->phase -= f->decimation;
       LSDR_ARG(in && rows_out);
       std::vector<lsdr_cf32> data(N);
-      LSDR_HIP(hipMemcpyAsync(data.data(), in + pos, (size_t)N * sizeof(lsdr_cf32), hipMemcpyDeviceToHost, c->stream));
-      LSDR_HIP(hipStreamSynchronize(c->stream));
-      cfft_host(N, data.data(), true);
+      { int rc = cfft_dev_init(&f->fft, N, true); if (rc) return rc; rc = cfft_dev_run(c, &f->fft, in + pos, data.data()); if (rc) return rc; }
       std::vector<float> power(N);
       for (int i = 0; i < N; ++i) power[i] = (float)data[i].re * data[i].re + (float)data[i].im * data[i].im;
       if (f->avgpower.empty()) f->avgpower = power;

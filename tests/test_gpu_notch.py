@@ -111,3 +111,15 @@ def test_rotator_golden(capi, ctx, oracle):
         r.close()
         assert hashlib.sha256(y.tobytes()).digest() == bytes(g[name + "_sha"])
         assert bits_equal(y, oracle.rotator(x, f))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [4096, 1024, 64, 8192])
+def test_cfft_on_device_is_the_reference_fft(capi, ctx, oracle, n):
+    """k_cfft (what detect()/cnr_fft/spectrum run): same bits as cfft_engine<float>::inplace, both directions."""
+    g = gold("auto_notch.npz")
+    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq"]))[:n]
+    for rev in (True, False):
+        assert bits_equal(capi.cfft_dev(ctx, x, rev), oracle.cfft(x, rev))
+    if n == 4096:
+        assert bits_equal(capi.cfft_dev(ctx, x, True), g["fft4096_rev"])
