@@ -272,7 +272,7 @@ def main():
                          "traffic": pmc_traffic(B), "avg_launch_ms": round(fir_avg_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:   # reported at N=1 only
             out["cpu_baseline"] = cpu_baseline(x, coeffs, decim, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
