@@ -334,6 +334,38 @@ int lsdr_hsdeconv_locked(const lsdr_hsdeconv *d);
 int lsdr_hsdeconv_run(lsdr_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
                       size_t *produced);
 
+/* -------------------------------------------------------------- transmit chain (leandvbtx.cc:79-175)
+ * Device pointers throughout; every *_run is the body of the reference block's run() over one buffer. */
+typedef struct lsdr_randomizer lsdr_randomizer;          /* randomizer, dvb.h:1063-1102 (8-packet pattern position carried) */
+int lsdr_randomizer_create(lsdr_ctx *ctx, lsdr_randomizer **r);
+void lsdr_randomizer_destroy(lsdr_randomizer *r);
+int lsdr_randomizer_run(lsdr_randomizer *r, const uint8_t *in_packets, size_t n_packets, uint8_t *out_packets, size_t cap_packets,
+                        size_t *consumed, size_t *produced);
+/* rs_encoder, dvb.h:957-980 + rs_engine::encode, rs.h:141-167: 188-byte packets → 204-byte packets */
+int lsdr_rs_encoder_run(lsdr_ctx *ctx, const uint8_t *in_packets, size_t n_packets, uint8_t *out_packets, size_t cap_packets,
+                        size_t *consumed, size_t *produced);
+/* interleaver, dvb.h:899-921: needs 12 packets, consumes n−11 */
+int lsdr_interleaver_run(lsdr_ctx *ctx, const uint8_t *in_packets, size_t n_packets, uint8_t *out_bytes, size_t cap_bytes,
+                         size_t *consumed_packets, size_t *produced_bytes);
+typedef struct lsdr_convol lsdr_convol;                  /* dvb_convol, dvb.h:567-604 (16-bit history carried) */
+int lsdr_convol_create(lsdr_ctx *ctx, int rate, int bits_per_symbol, lsdr_convol **v);
+void lsdr_convol_destroy(lsdr_convol *v);
+int lsdr_convol_run(lsdr_convol *v, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed, size_t *produced);
+/* cstln_transmitter<f32,0>, sdr.h:1196-1222, with make_dvbs2_constellation(cstln, rate) */
+int lsdr_cstln_transmitter_run(lsdr_ctx *ctx, int cstln, int rate, const uint8_t *sym, size_t n, lsdr_cf32 *out);
+typedef struct lsdr_fir_resampler lsdr_fir_resampler;    /* fir_resampler<cf32,float>, dsp.h:290-364 (interpolator, decim = 1) */
+int lsdr_fir_resampler_create(lsdr_ctx *ctx, unsigned ncoeffs, const float *coeffs_host, unsigned interp, lsdr_fir_resampler **f);
+void lsdr_fir_resampler_destroy(lsdr_fir_resampler *f);
+int lsdr_fir_resampler_set_freq(lsdr_fir_resampler *f, float freq);
+int lsdr_fir_resampler_run(lsdr_fir_resampler *f, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed,
+                           size_t *produced);
+typedef struct lsdr_simple_agc lsdr_simple_agc;          /* simple_agc<f32>, sdr.h:238-274 (power estimate carried) */
+int lsdr_simple_agc_create(lsdr_ctx *ctx, float out_rms, float bw, lsdr_simple_agc **a);
+void lsdr_simple_agc_destroy(lsdr_simple_agc *a);
+int lsdr_simple_agc_set(lsdr_simple_agc *a, float out_rms, float bw);
+int lsdr_simple_agc_run(lsdr_simple_agc *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed,
+                        size_t *produced);
+
 #ifdef __cplusplus
 }
 #endif

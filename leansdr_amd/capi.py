@@ -114,6 +114,23 @@ _sig("lsdr_hsdeconv_destroy", None, [vp])
 _sig("lsdr_hsdeconv_locked", C.c_int, [vp])
 _sig("lsdr_hsdeconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_cfft_run", C.c_int, [vp, C.c_int, C.c_int, vp, vp])
+_sig("lsdr_randomizer_create", C.c_int, [vp, C.POINTER(vp)])
+_sig("lsdr_randomizer_destroy", None, [vp])
+_sig("lsdr_randomizer_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_rs_encoder_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_interleaver_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_convol_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
+_sig("lsdr_convol_destroy", None, [vp])
+_sig("lsdr_convol_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_cstln_transmitter_run", C.c_int, [vp, C.c_int, C.c_int, vp, c_sz, vp])
+_sig("lsdr_fir_resampler_create", C.c_int, [vp, C.c_uint, vp, C.c_uint, C.POINTER(vp)])
+_sig("lsdr_fir_resampler_destroy", None, [vp])
+_sig("lsdr_fir_resampler_set_freq", C.c_int, [vp, c_f])
+_sig("lsdr_fir_resampler_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_simple_agc_create", C.c_int, [vp, c_f, c_f, C.POINTER(vp)])
+_sig("lsdr_simple_agc_destroy", None, [vp])
+_sig("lsdr_simple_agc_set", C.c_int, [vp, c_f, c_f])
+_sig("lsdr_simple_agc_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_rotator_create", C.c_int, [vp, c_f, C.POINTER(vp)])
 _sig("lsdr_rotator_destroy", None, [vp])
 _sig("lsdr_rotator_run", C.c_int, [vp, vp, c_sz, vp])
@@ -186,6 +203,12 @@ def root_raised_cosine(order, fs, rolloff):
     out = np.empty(order + 3, np.float32)
     n = lib.lsdr_filtergen_root_raised_cosine(order, fs, rolloff, _np(out))
     return out[:n].copy()
+
+
+def normalize_power(coeffs, gain):
+    c = np.ascontiguousarray(coeffs, np.float32).copy()
+    lib.lsdr_filtergen_normalize_power(len(c), _np(c), gain)
+    return c
 
 
 def trig16():
@@ -855,3 +878,84 @@ class CnrFft:
         check(lib.lsdr_cnr_fft_run(self.h, freq_tap, tap_multiplier, din.ptr, len(x), _np(out), len(out), C.byref(cons), C.byref(prod)))
         din.free()
         return out[:prod.value].copy(), cons.value
+
+
+# ---- transmit chain (leandvbtx.cc:79-175) ------------------------------------------------
+class TxChain:
+    """randomizer → rs_encoder → interleaver → dvb_convol → cstln_transmitter → fir_resampler(RRC) → decimator [→ simple_agc]
+    on one context, device-resident between the blocks.  `run(ts)` feeds a batch of TS packets and returns the baseband
+    produced so far (state is carried: interleaver window, convolutional history, resampler history, AGC estimate)."""
+
+    def __init__(self, ctx, interp=2, decim=1, amp=1.0, rolloff=0.35, rrc_rej=10.0, agc=False, cstln=QPSK, rate=FEC12):
+        self.ctx, self.interp, self.decim, self.cstln, self.rate = ctx, interp, decim, cstln, rate
+        self.rand = vp(); check(lib.lsdr_randomizer_create(ctx.h, C.byref(self.rand)))
+        bps = {BPSK: 1, QPSK: 2, PSK8: 3}.get(cstln, 2)
+        self.conv = vp(); check(lib.lsdr_convol_create(ctx.h, rate, bps, C.byref(self.conv)))
+        order = int(interp * rrc_rej)
+        co = root_raised_cosine(order, float(np.float32(1.0) / np.float32(interp)), rolloff)
+        co = normalize_power(co, float(np.float32(amp) / np.float32(75.0)))
+        self.coeffs = co
+        self.res = vp(); check(lib.lsdr_fir_resampler_create(ctx.h, len(co), _np(co), interp, C.byref(self.res)))
+        self.agc = None
+        if agc:
+            self.agc = vp()
+            check(lib.lsdr_simple_agc_create(ctx.h, float(np.float32(amp) / np.sqrt(np.float32(np.float32(interp) / decim))),
+                                             float(np.float32(0.001 * decim / interp)), C.byref(self.agc)))
+        self.pk_hold = np.zeros((0, 204), np.uint8)      # interleaver window (host-side carry of unconsumed packets)
+        self.iq_hold = np.zeros(0, np.complex64)          # resampler input not yet consumed
+        self.dec_hold = np.zeros(0, np.complex64)         # decimator / AGC remainders
+        self.agc_hold = np.zeros(0, np.complex64)
+
+    def close(self):
+        lib.lsdr_randomizer_destroy(self.rand); lib.lsdr_convol_destroy(self.conv); lib.lsdr_fir_resampler_destroy(self.res)
+        if self.agc:
+            lib.lsdr_simple_agc_destroy(self.agc)
+
+    def _run2(self, fn, h, din, n_in, cap_items, out_dtype, item=1):
+        """One *_run call; `cap_items` / produced are in the block's output items of `item` elements of out_dtype."""
+        dout = self.ctx.alloc(max(16, cap_items * item * np.dtype(out_dtype).itemsize))
+        cons, prod = c_sz(), c_sz()
+        if h is None:
+            check(fn(self.ctx.h, din.ptr, n_in, dout.ptr, cap_items, C.byref(cons), C.byref(prod)))
+        else:
+            check(fn(h, din.ptr, n_in, dout.ptr, cap_items, C.byref(cons), C.byref(prod)))
+        out = self.ctx.download(dout, out_dtype, prod.value * item)
+        dout.free()
+        return out, cons.value
+
+    def run(self, ts):
+        ctx = self.ctx
+        ts = np.ascontiguousarray(ts, np.uint8).reshape(-1, 188)
+        d = ctx.upload(ts)
+        r, _ = self._run2(lib.lsdr_randomizer_run, self.rand, d, len(ts), len(ts), np.uint8, 188); d.free()
+        r = r.reshape(-1, 188)
+        d = ctx.upload(r)
+        pk, _ = self._run2(lib.lsdr_rs_encoder_run, None, d, len(r), len(r), np.uint8, 204); d.free()
+        pk = np.concatenate([self.pk_hold, pk.reshape(-1, 204)])
+        if len(pk) < 12:
+            self.pk_hold = pk
+            return np.zeros(0, np.complex64)
+        d = ctx.upload(pk)
+        il, cons = self._run2(lib.lsdr_interleaver_run, None, d, len(pk), len(pk) * 204, np.uint8); d.free()
+        self.pk_hold = pk[cons:]
+        d = ctx.upload(il)
+        sym, cons = self._run2(lib.lsdr_convol_run, self.conv, d, len(il), len(il) * 16 + 64, np.uint8); d.free()
+        assert cons == len(il)
+        d = ctx.upload(sym)
+        dq = ctx.alloc(max(16, len(sym) * 8))
+        check(lib.lsdr_cstln_transmitter_run(ctx.h, self.cstln, self.rate, d.ptr, len(sym), dq.ptr)); d.free()
+        iq = np.concatenate([self.iq_hold, ctx.download(dq, np.complex64, len(sym))]); dq.free()
+        d = ctx.upload(iq)
+        y, cons = self._run2(lib.lsdr_fir_resampler_run, self.res, d, len(iq), len(iq) * self.interp, np.complex64); d.free()
+        self.iq_hold = iq[cons:]
+        y = np.concatenate([self.dec_hold, y])
+        nd = len(y) // self.decim
+        self.dec_hold = y[nd * self.decim:]
+        y = np.ascontiguousarray(y[:nd * self.decim:self.decim]) if self.decim > 1 else y
+        if self.agc:
+            y = np.concatenate([self.agc_hold, y])
+            d = ctx.upload(y)
+            z, cons = self._run2(lib.lsdr_simple_agc_run, self.agc, d, len(y), len(y), np.complex64); d.free()
+            self.agc_hold = y[cons:]
+            y = z
+        return y

@@ -187,6 +187,16 @@ size_t lo_derandomizer_run(lo_derandomizer *d, const uint8_t *in, size_t npacket
 size_t lo_fec_chain(int cstln, int rate, int viterbi, int fastlock, const lo_softsymbol *sym, size_t n,
                     uint8_t *ts_out, size_t cap_packets, long *bits, long *errs);
 
+/* ---- transmit chain of leandvbtx (lsdr_oracle_tx.c) ------------------------------------------ */
+size_t lo_randomizer(unsigned *pos, const uint8_t *in, size_t npackets, uint8_t *out);                 /* dvb.h:1063-1102 */
+size_t lo_interleaver(const uint8_t *in_packets, size_t npackets, uint8_t *out, size_t cap_bytes, size_t *consumed); /* dvb.h:899-921 */
+typedef struct lo_convol lo_convol;                                                                     /* dvb.h:567-604 */
+lo_convol *lo_convol_new(int rate, int bits_per_symbol);
+void lo_convol_free(lo_convol *c);
+size_t lo_convol_run(lo_convol *c, const uint8_t *in, size_t n_in, uint8_t *out, size_t cap, size_t *consumed);
+void lo_cstln_transmitter(const lo_cstln_lut *c, const uint8_t *sym, size_t n, lo_cf32 *out);          /* sdr.h:1196-1222 */
+size_t lo_simple_agc(float *estimated, float out_rms, float bw, const lo_cf32 *in, size_t n, lo_cf32 *out); /* sdr.h:238-274 */
+
 /* ---- `--hs` path (lsdr_oracle_hs.c) ------------------------------------------------------ */
 typedef struct lo_fastqpsk lo_fastqpsk;                   /* fast_qpsk_receiver<u8>, sdr.h:946-1189 */
 lo_fastqpsk *lo_fastqpsk_new(float omega, float freq, float pll_adjustment, int allow_drift, unsigned long meas_decimation);

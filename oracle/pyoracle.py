@@ -224,6 +224,17 @@ class Oracle:
         n = self.lib.lo_fir_filter(len(sc), _p(sc), decim, _p(x), len(x), _p(out), cap, C.byref(consumed))
         return out[:n], consumed.value
 
+    def normalize_power(self, coeffs, gain):
+        c = np.ascontiguousarray(coeffs, np.float32).copy()
+        self.lib.lo_normalize_power(len(c), _p(c), gain)
+        return c
+
+    def decimator(self, d, x):
+        x = cf32(x)
+        out = np.empty(len(x) // d + 1, np.complex64)
+        n = self.lib.lo_decimator(d, _p(x), len(x), _p(out), len(out))
+        return out[:n].copy()
+
     def fir_resampler(self, coeffs, interp, x, freq=0.0):
         x = cf32(x)
         coeffs = np.ascontiguousarray(coeffs, np.float32)
@@ -311,6 +322,83 @@ class Oracle:
             res.update(polar_a=pa, polar_r=pr, rect=re, sincos=sc)
         L.lo_fastqpsk_free(h)
         return res
+
+    # ---- transmit chain (leandvbtx)
+    def randomizer(self, ts):
+        ts = np.ascontiguousarray(ts, np.uint8).reshape(-1, 188)
+        out = np.empty_like(ts)
+        pos = C.c_uint(0)
+        self.lib.lo_randomizer.argtypes = [C.POINTER(C.c_uint), C.c_void_p, c_sz, C.c_void_p]
+        self.lib.lo_randomizer(C.byref(pos), _p(ts), len(ts), _p(out))
+        return out
+
+    def rs_encoder(self, ts):
+        ts = np.ascontiguousarray(ts, np.uint8).reshape(-1, 188)
+        out = np.zeros((len(ts), 204), np.uint8)
+        out[:, :188] = ts
+        self.lib.lo_rs_encode.argtypes = [C.c_void_p]
+        for k in range(len(out)):
+            self.lib.lo_rs_encode(out[k].ctypes.data)
+        return out
+
+    def interleaver(self, packets):
+        pk = np.ascontiguousarray(packets, np.uint8).reshape(-1, 204)
+        out = np.empty(len(pk) * 204, np.uint8)
+        c = c_sz()
+        self.lib.lo_interleaver.restype = c_sz
+        self.lib.lo_interleaver.argtypes = [C.c_void_p, c_sz, C.c_void_p, c_sz, C.POINTER(c_sz)]
+        n = self.lib.lo_interleaver(_p(pk), len(pk), _p(out), len(out), C.byref(c))
+        return out[:n].copy()
+
+    def dvb_convol(self, data, rate=0, bps=2):
+        data = np.ascontiguousarray(data, np.uint8)
+        L = self.lib
+        L.lo_convol_new.restype = C.c_void_p
+        L.lo_convol_new.argtypes = [C.c_int, C.c_int]
+        L.lo_convol_free.argtypes = [C.c_void_p]
+        L.lo_convol_run.restype = c_sz
+        L.lo_convol_run.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p, c_sz, C.POINTER(c_sz)]
+        h = L.lo_convol_new(rate, bps)
+        assert h
+        out = np.empty(len(data) * 16 + 64, np.uint8)
+        c = c_sz()
+        n = L.lo_convol_run(h, _p(data), len(data), _p(out), len(out), C.byref(c))
+        L.lo_convol_free(h)
+        return out[:n].copy(), c.value
+
+    def cstln_transmitter(self, sym, cstln=1, rate=0):
+        sym = np.ascontiguousarray(sym, np.uint8)
+        c = CstlnLut()
+        assert self.lib.lo_make_dvbs2_constellation(C.byref(c), cstln, rate) > 0
+        out = np.empty(len(sym), np.complex64)
+        self.lib.lo_cstln_transmitter.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p]
+        self.lib.lo_cstln_transmitter(C.byref(c), _p(sym), len(sym), _p(out))
+        return out
+
+    def tx_chain(self, ts, interp=2, decim=1, amp=1.0, rolloff=0.35, rrc_rej=10.0, agc=False, cstln=1, rate=0):
+        """leandvbtx (leandvbtx.cc:79-175): TS packets → cf32 baseband."""
+        r = self.randomizer(ts)
+        pk = self.rs_encoder(r)
+        il = self.interleaver(pk)
+        sym, _ = self.dvb_convol(il, rate, {0: 1, 1: 2, 2: 3}.get(cstln, 2))
+        iq = self.cstln_transmitter(sym, cstln, rate)
+        order = int(interp * rrc_rej)
+        co = self.rrc(order, float(np.float32(1.0) / np.float32(interp)), rolloff)
+        co = self.normalize_power(co, float(np.float32(amp) / np.float32(75.0)))
+        y, _ = self.fir_resampler(co, interp, iq)
+        y = self.decimator(decim, y)
+        if agc:
+            y, _ = self.simple_agc(y, float(np.float32(amp) / np.sqrt(np.float32(np.float32(interp) / decim))), float(np.float32(0.001 * decim / interp)))
+        return y
+
+    def simple_agc(self, x, out_rms=1.0, bw=0.001, estimated=0.0):
+        x = cf32(x)
+        out = np.empty_like(x)
+        est = c_f(estimated)
+        self.lib.lo_simple_agc.restype = c_sz
+        self.lib.lo_simple_agc.argtypes = [C.POINTER(c_f), c_f, c_f, C.c_void_p, c_sz, C.c_void_p]
+        n = self.lib.lo_simple_agc(C.byref(est), out_rms, bw, _p(x), len(x), _p(out))
+        return out[:n].copy(), est.value
 
     def hs_chain(self, iq_u8, omega, fastlock=0):
         """leandvb --hs (leandvb.cc:727-969): fast_qpsk_receiver → dvb_deconvol_sync_hard → mpeg_sync(fastlock, resync) →
@@ -719,6 +807,55 @@ class Ref:
         if return_tables:
             res.update(polar_a=pa, polar_r=pr, rect=re, sincos=sc)
         return res
+
+    def randomizer(self, ts):
+        ts = np.ascontiguousarray(ts, np.uint8).reshape(-1, 188)
+        out = np.empty_like(ts)
+        self.lib.ref_randomizer.restype = C.c_long
+        self.lib.ref_randomizer.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        n = self.lib.ref_randomizer(_p(ts), len(ts), _p(out))
+        return out[:n]
+
+    def rs_encoder(self, ts):
+        ts = np.ascontiguousarray(ts, np.uint8).reshape(-1, 188)
+        out = np.empty((len(ts), 204), np.uint8)
+        self.lib.ref_rs_encoder.restype = C.c_long
+        self.lib.ref_rs_encoder.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        n = self.lib.ref_rs_encoder(_p(ts), len(ts), _p(out))
+        return out[:n]
+
+    def interleaver(self, packets):
+        pk = np.ascontiguousarray(packets, np.uint8).reshape(-1, 204)
+        out = np.empty(len(pk) * 204, np.uint8)
+        self.lib.ref_interleaver.restype = C.c_long
+        self.lib.ref_interleaver.argtypes = [C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        n = self.lib.ref_interleaver(_p(pk), len(pk), _p(out), len(out))
+        return out[:n].copy()
+
+    def dvb_convol(self, data, rate=0, bps=2):
+        data = np.ascontiguousarray(data, np.uint8)
+        out = np.empty(len(data) * 16 + 64, np.uint8)
+        self.lib.ref_dvb_convol.restype = C.c_long
+        self.lib.ref_dvb_convol.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p, C.c_long]
+        n = self.lib.ref_dvb_convol(rate, bps, _p(data), len(data), _p(out), len(out))
+        return out[:n].copy()
+
+    def cstln_transmitter(self, sym, cstln=1, rate=0):
+        sym = np.ascontiguousarray(sym, np.uint8)
+        out = np.empty(len(sym), np.complex64)
+        self.lib.ref_cstln_transmitter.restype = C.c_long
+        self.lib.ref_cstln_transmitter.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]
+        n = self.lib.ref_cstln_transmitter(cstln, rate, _p(sym), len(sym), _p(out))
+        return out[:n]
+
+    def simple_agc(self, x, out_rms=1.0, bw=0.001):
+        x = cf32(x)
+        out = np.empty_like(x)
+        est = c_f()
+        self.lib.ref_simple_agc.restype = C.c_long
+        self.lib.ref_simple_agc.argtypes = [c_f, c_f, C.c_void_p, C.c_long, C.c_void_p, C.POINTER(c_f)]
+        n = self.lib.ref_simple_agc(out_rms, bw, _p(x), len(x), _p(out), C.byref(est))
+        return out[:n].copy(), est.value
 
     def hs_deconvol(self, symbols, resync_period=32):
         sym = np.ascontiguousarray(symbols, np.uint8)

@@ -546,6 +546,69 @@ void ref_rs_encode(uint8_t *msg204) {
   rs->encode(msg204);
 }
 
+// ---- transmit chain (leandvbtx.cc:79-175)
+long ref_randomizer(const uint8_t *in, long npackets, uint8_t *out) {           // dvb.h:1063-1102
+  scheduler sch;
+  pipebuf<tspacket> p_in(&sch, "in", BUF_PACKETS), p_out(&sch, "out", BUF_PACKETS);
+  buffer_reader<tspacket> r(&sch, (tspacket *)in, npackets, p_in);
+  randomizer d(&sch, p_in, p_out);
+  buffer_writer<tspacket> w(&sch, p_out, (tspacket *)out, npackets);
+  sch.run();
+  return w.pos;
+}
+long ref_rs_encoder(const uint8_t *in, long npackets, uint8_t *out) {           // dvb.h:957-980
+  scheduler sch;
+  pipebuf<tspacket> p_in(&sch, "in", BUF_PACKETS);
+  pipebuf<rspacket<u8> > p_out(&sch, "out", BUF_PACKETS);
+  buffer_reader<tspacket> r(&sch, (tspacket *)in, npackets, p_in);
+  rs_encoder *d = new (zmem<rs_encoder>()) rs_encoder(&sch, p_in, p_out);
+  (void)d;
+  buffer_writer<rspacket<u8> > w(&sch, p_out, (rspacket<u8> *)out, npackets);
+  sch.run();
+  return w.pos;
+}
+long ref_interleaver(const uint8_t *in, long npackets, uint8_t *out, long cap) {   // dvb.h:899-921
+  scheduler sch;
+  pipebuf<rspacket<u8> > p_in(&sch, "in", 24);          // leandvbtx: BUF_PACKETS = 12*buf_factor (leandvbtx.cc:85)
+  pipebuf<u8> p_out(&sch, "out", BUF_MPEGBYTES);
+  buffer_reader<rspacket<u8> > r(&sch, (rspacket<u8> *)in, npackets, p_in);
+  interleaver d(&sch, p_in, p_out);
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  sch.run();
+  return w.pos;
+}
+long ref_dvb_convol(int rate, int bps, const uint8_t *in, long n, uint8_t *out, long cap) {   // dvb.h:567-604
+  scheduler sch;
+  pipebuf<u8> p_in(&sch, "in", BUF_BYTES), p_out(&sch, "out", BUF_SYMBOLS * 16);
+  buffer_reader<u8> r(&sch, (u8 *)in, n, p_in);
+  dvb_convol d(&sch, p_in, p_out, (code_rate)rate, bps);
+  buffer_writer<u8> w(&sch, p_out, out, cap);
+  sch.run();
+  return w.pos;
+}
+long ref_cstln_transmitter(int cstln, int rate, const uint8_t *sym, long n, float *out) {   // sdr.h:1196-1222
+  scheduler sch;
+  pipebuf<u8> p_in(&sch, "in", BUF_SYMBOLS);
+  pipebuf<cf32> p_out(&sch, "out", BUF_SYMBOLS);
+  buffer_reader<u8> r(&sch, (u8 *)sym, n, p_in);
+  cstln_transmitter<f32, 0> d(&sch, p_in, p_out);
+  d.cstln = make_dvbs2_constellation((cstln_lut<256>::predef)cstln, (code_rate)rate);
+  buffer_writer<cf32> w(&sch, p_out, (cf32 *)out, n);
+  sch.run();
+  return w.pos;
+}
+long ref_simple_agc(float out_rms, float bw, const float *in, long n, float *out, float *estimated) {   // sdr.h:238-274
+  scheduler sch;
+  pipebuf<cf32> p_in(&sch, "in", BUF_BASEBAND), p_out(&sch, "out", BUF_BASEBAND);
+  buffer_reader<cf32> r(&sch, (cf32 *)in, n, p_in);
+  simple_agc<f32> d(&sch, p_in, p_out);
+  d.out_rms = out_rms; d.bw = bw;
+  buffer_writer<cf32> w(&sch, p_out, (cf32 *)out, n);
+  sch.run();
+  if (estimated) *estimated = d.estimated;
+  return w.pos;
+}
+
 // dvb.h:1107-1163
 long ref_derandomizer(const uint8_t *in, long npackets, uint8_t *out, uint8_t *pattern1504) {
   scheduler sch;
