@@ -130,5 +130,48 @@ struct decimator<complex<float> > : runnable {
   pipewriter<complex<float> > out;
 };
 
+// fir_resampler<cf32,float> (dsp.h:290-364): polyphase interpolator on device pipebufs (decim must be 1, as in the reference).
+template <typename T, typename Tc>
+struct fir_resampler;
+
+template <>
+struct fir_resampler<complex<float>, float> : runnable {
+  float *freq_tap;
+  float tap_multiplier;
+  float freq_tol;
+  fir_resampler(scheduler *sch, int ncoeffs, float *coeffs, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o, int interp_ = 1,
+                int decim_ = 1)
+      : runnable(sch, "fir_resampler"), freq_tap(NULL), tap_multiplier(1), freq_tol(0.1),
+        ctx(pipe_ctx(i.dev, o.dev, "fir_resampler: pipebufs must be device pipebufs of one ctx")), n(ncoeffs), interp(interp_), in(i),
+        out(o, interp_), current_freq(0) {
+    if (decim_ != 1) fail("fir_resampler: decim not implemented");
+    lsdr_check(lsdr_fir_resampler_create(ctx, ncoeffs, coeffs, interp_, &h), name);
+  }
+  void run() {
+    if (in.readable() < n) return;
+    if (freq_tap) {   // dsp.h:309-316
+      float new_freq = *freq_tap * tap_multiplier;
+      if (fabs(current_freq - new_freq) > freq_tol) {
+        lsdr_check(lsdr_fir_resampler_set_freq(h, new_freq), name);
+        current_freq = new_freq;
+      }
+    }
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_fir_resampler_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  unsigned n;
+  int interp;
+  pipereader<complex<float> > in;
+  pipewriter<complex<float> > out;
+  lsdr_fir_resampler *h;
+  float current_freq;
+};
+
 }  // namespace leansdr
 #endif

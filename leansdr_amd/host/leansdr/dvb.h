@@ -250,5 +250,84 @@ struct derandomizer : runnable {
   lsdr_derandomizer *h;
 };
 
+// ---- transmit chain (leandvbtx.cc:79-175): same constructor signatures as the reference blocks, device pipebufs.
+struct randomizer : runnable {   // dvb.h:1063-1102
+  randomizer(scheduler *sch, pipebuf<tspacket> &i, pipebuf<tspacket> &o)
+      : runnable(sch, "derandomizer"), ctx(pipe_ctx(i.dev, o.dev, "randomizer: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {
+    lsdr_check(lsdr_randomizer_create(ctx, &h), name);
+  }
+  void run() {
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_randomizer_run(h, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<tspacket> in;
+  pipewriter<tspacket> out;
+  lsdr_randomizer *h;
+};
+
+struct rs_encoder : runnable {   // dvb.h:957-980
+  rs_encoder(scheduler *sch, pipebuf<tspacket> &i, pipebuf<rspacket<u8> > &o)
+      : runnable(sch, "RS encoder"), ctx(pipe_ctx(i.dev, o.dev, "rs_encoder: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {}
+  void run() {
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_rs_encoder_run(ctx, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<tspacket> in;
+  pipewriter<rspacket<u8> > out;
+};
+
+struct interleaver : runnable {   // dvb.h:899-921
+  interleaver(scheduler *sch, pipebuf<rspacket<u8> > &i, pipebuf<u8> &o)
+      : runnable(sch, "interleaver"), ctx(pipe_ctx(i.dev, o.dev, "interleaver: pipebufs must be device pipebufs of one ctx")), in(i),
+        out(o, SIZE_RSPACKET) {}
+  void run() {
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_interleaver_run(ctx, (const uint8_t *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<rspacket<u8> > in;
+  pipewriter<u8> out;
+};
+
+struct dvb_convol : runnable {   // dvb.h:567-604
+  typedef u8 uncoded_byte;
+  typedef u8 hardsymbol;
+  dvb_convol(scheduler *sch, pipebuf<uncoded_byte> &i, pipebuf<hardsymbol> &o, code_rate fec, int bits_per_symbol)
+      : runnable(sch, "dvb_convol"), ctx(pipe_ctx(i.dev, o.dev, "dvb_convol: pipebufs must be device pipebufs of one ctx")), in(i),
+        out(o, 64) {
+    lsdr_check(lsdr_convol_create(ctx, (int)fec, bits_per_symbol, &h), name);
+  }
+  void run() {
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_convol_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<uncoded_byte> in;
+  pipewriter<hardsymbol> out;
+  lsdr_convol *h;
+};
+
 }  // namespace leansdr
 #endif

@@ -451,5 +451,57 @@ struct cstln_receiver<f32> : runnable {
   float *scratch[3] = {NULL, NULL, NULL};
 };
 
+// cstln_transmitter<f32,0> (sdr.h:1196-1222) and simple_agc<f32> (sdr.h:238-274) on device pipebufs.
+template <typename Tout, int Zout>
+struct cstln_transmitter;
+
+template <>
+struct cstln_transmitter<f32, 0> : runnable {
+  cstln_lut<256> *cstln;
+  cstln_transmitter(scheduler *sch, pipebuf<u8> &i, pipebuf<cf32> &o)
+      : runnable(sch, "cstln_transmitter"), cstln(NULL),
+        ctx(pipe_ctx(i.dev, o.dev, "cstln_transmitter: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {}
+  void run() {
+    if (!cstln) fail("constellation not set");
+    unsigned long room = out.writable();
+    unsigned long count = min(in.readable(), room);
+    if (!count) return;
+    lsdr_check(lsdr_cstln_transmitter_run(ctx, (int)cstln->type, cstln->fec, in.rd(), count, (lsdr_cf32 *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<u8> in;
+  pipewriter<cf32> out;
+};
+
+template <typename T>
+struct simple_agc;
+
+template <>
+struct simple_agc<f32> : runnable {
+  float out_rms, bw;
+  simple_agc(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o)
+      : runnable(sch, "AGC"), out_rms(1), bw(0.001), ctx(pipe_ctx(i.dev, o.dev, "simple_agc: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o), h(NULL) {}
+  void run() {
+    if (!h) lsdr_check(lsdr_simple_agc_create(ctx, out_rms, bw, &h), name);
+    lsdr_check(lsdr_simple_agc_set(h, out_rms, bw), name);
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_simple_agc_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
+    in.read(consumed);
+    out.written(produced);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<cf32> in;
+  pipewriter<cf32> out;
+  lsdr_simple_agc *h;
+};
+
 }  // namespace leansdr
 #endif

@@ -1,6 +1,8 @@
 """Transmit chain on the GPU (leansdr_amd/csrc/tx.hip) through the C ABI: == the real `leandvbtx` output (tests/golden/
 tx.npz) and == the pinned oracle with the stream cut into several calls."""
 import hashlib
+import os
+import subprocess
 import numpy as np
 import pytest
 from conftest import gold, bits_equal
@@ -58,3 +60,20 @@ def test_tx_rx_loopback(capi, ctx):
     sent = {bytes(t) for t in ts}
     good = sum(bytes(t) in sent for t in got)
     assert len(got) > 100 and good >= len(got) - 12, (len(got), good)   # the first packets after acquisition are false locks
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TXAPP = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvbtx_amd")
+
+
+@pytest.mark.parametrize("name,args", [("f2", ["-f", "2"]), ("f65_agc", ["-f", "6/5", "--power", "37.5", "--agc"]),
+                                       ("f4_cr34", ["-f", "4", "--cr", "3/4"])])
+def test_leandvbtx_amd_is_leandvbtx(name, args):
+    """The drop-in TX app reproduces the bytes of the reference `leandvbtx` binary (tests/golden/tx.npz)."""
+    g = gold("tx.npz")
+    p = subprocess.run([TXAPP] + args, input=g["ts"].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    y = np.frombuffer(p.stdout, np.complex64)
+    assert len(y) == int(g[name + "_n"])
+    assert bits_equal(y[:256], g[name + "_head"]) and bits_equal(y[-256:], g[name + "_tail"])
+    assert hashlib.sha256(y.tobytes()).digest() == bytes(g[name + "_sha"])
