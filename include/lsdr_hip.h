@@ -366,6 +366,30 @@ int lsdr_simple_agc_set(lsdr_simple_agc *a, float out_rms, float bw);
 int lsdr_simple_agc_run(lsdr_simple_agc *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed,
                         size_t *produced);
 
+/* ---- channel simulator of leanchansim (leanchansim.cc:34-190): noise, adder, LO drift, f32 → u8 ------------------ */
+typedef struct lsdr_wgn lsdr_wgn;                          /* wgn_c<f32>, dsp.h:164-190, on glibc's drand48()/logf() */
+/* seeded = 0: the drand48 state of a process that never seeds (leanchansim --deterministic); else srand48(seed)
+ * (leanchansim.cc:146-147 seeds with the pid). */
+int lsdr_wgn_create(lsdr_ctx *ctx, int seeded, long seed, lsdr_wgn **w);
+void lsdr_wgn_destroy(lsdr_wgn *w);
+int lsdr_wgn_get_state(lsdr_wgn *w, unsigned long long *x48);
+int lsdr_wgn_set_state(lsdr_wgn *w, unsigned long long x48);
+/* the next n samples of wgn_c::run (stddev is its public member); add != NULL: out = add + noise (adder fused) */
+int lsdr_wgn_run(lsdr_wgn *w, float stddev, const lsdr_cf32 *add, lsdr_cf32 *out, size_t n);
+/* adder<cf32>::run, dsp.h:125-134 */
+int lsdr_adder_run(lsdr_ctx *ctx, const lsdr_cf32 *a, const lsdr_cf32 *b, size_t n, lsdr_cf32 *out);
+/* cconverter<f32,0,u8,128,1,1>::run, dsp.h:40-50 (x86 float → int32 → u8 truncation) */
+int lsdr_cconverter_f32_u8_run(lsdr_ctx *ctx, const lsdr_cf32 *in, size_t n, lsdr_cu8 *out);
+typedef struct lsdr_drifter lsdr_drifter;                  /* drifter<float>, leanchansim.cc:34-88 */
+int lsdr_drifter_create(lsdr_ctx *ctx, lsdr_drifter **d);
+void lsdr_drifter_destroy(lsdr_drifter *d);
+int lsdr_drifter_set_component(lsdr_drifter *d, int i, float amp, float freq);   /* public member drifts[i] */
+int lsdr_drifter_get_phases(lsdr_drifter *d, long long a[3]);
+int lsdr_drifter_set_phases(lsdr_drifter *d, const long long a[3]);
+/* n samples as consecutive run() calls of `chunk` samples (0: one call).  run() restarts its phase accumulator at 0, so
+ * the reference's output depends on how its 4096-sample pipes cut the stream; pass 4096 to reproduce leanchansim. */
+int lsdr_drifter_run(lsdr_drifter *d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out, size_t chunk);
+
 #ifdef __cplusplus
 }
 #endif

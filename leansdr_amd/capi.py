@@ -131,6 +131,19 @@ _sig("lsdr_simple_agc_create", C.c_int, [vp, c_f, c_f, C.POINTER(vp)])
 _sig("lsdr_simple_agc_destroy", None, [vp])
 _sig("lsdr_simple_agc_set", C.c_int, [vp, c_f, c_f])
 _sig("lsdr_simple_agc_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_wgn_create", C.c_int, [vp, C.c_int, C.c_long, C.POINTER(vp)])
+_sig("lsdr_wgn_destroy", None, [vp])
+_sig("lsdr_wgn_get_state", C.c_int, [vp, C.POINTER(C.c_ulonglong)])
+_sig("lsdr_wgn_set_state", C.c_int, [vp, C.c_ulonglong])
+_sig("lsdr_wgn_run", C.c_int, [vp, c_f, vp, vp, c_sz])
+_sig("lsdr_adder_run", C.c_int, [vp, vp, vp, c_sz, vp])
+_sig("lsdr_cconverter_f32_u8_run", C.c_int, [vp, vp, c_sz, vp])
+_sig("lsdr_drifter_create", C.c_int, [vp, C.POINTER(vp)])
+_sig("lsdr_drifter_destroy", None, [vp])
+_sig("lsdr_drifter_set_component", C.c_int, [vp, C.c_int, c_f, c_f])
+_sig("lsdr_drifter_get_phases", C.c_int, [vp, C.c_longlong * 3])
+_sig("lsdr_drifter_set_phases", C.c_int, [vp, C.c_longlong * 3])
+_sig("lsdr_drifter_run", C.c_int, [vp, vp, c_sz, vp, c_sz])
 _sig("lsdr_rotator_create", C.c_int, [vp, c_f, C.POINTER(vp)])
 _sig("lsdr_rotator_destroy", None, [vp])
 _sig("lsdr_rotator_run", C.c_int, [vp, vp, c_sz, vp])
@@ -878,6 +891,92 @@ class CnrFft:
         check(lib.lsdr_cnr_fft_run(self.h, freq_tap, tap_multiplier, din.ptr, len(x), _np(out), len(out), C.byref(cons), C.byref(prod)))
         din.free()
         return out[:prod.value].copy(), cons.value
+
+
+# ---- channel simulator (leanchansim.cc:34-190) -------------------------------------------
+class Wgn:
+    """wgn_c<f32> (dsp.h:164-190) on glibc's drand48/logf; seed=None: the state of a process that never seeds."""
+
+    def __init__(self, ctx, seed=None):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_wgn_create(ctx.h, 0 if seed is None else 1, seed or 0, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_wgn_destroy(self.h)
+            self.h = None
+
+    @property
+    def state(self):
+        x = C.c_ulonglong()
+        check(lib.lsdr_wgn_get_state(self.h, C.byref(x)))
+        return x.value
+
+    def run(self, n, stddev=1.0, add=None):
+        dout = self.ctx.alloc(max(8, n * 8))
+        dadd = self.ctx.upload(np.ascontiguousarray(add, np.complex64)) if add is not None else None
+        check(lib.lsdr_wgn_run(self.h, stddev, dadd.ptr if dadd else None, dout.ptr, n))
+        out = self.ctx.download(dout, np.complex64, n)
+        dout.free()
+        if dadd:
+            dadd.free()
+        return out
+
+
+def adder(ctx, a, b):
+    a = np.ascontiguousarray(a, np.complex64); b = np.ascontiguousarray(b, np.complex64)
+    n = min(len(a), len(b))
+    da, db, dout = ctx.upload(a), ctx.upload(b), ctx.alloc(max(8, n * 8))
+    check(lib.lsdr_adder_run(ctx.h, da.ptr, db.ptr, n, dout.ptr))
+    out = ctx.download(dout, np.complex64, n)
+    da.free(); db.free(); dout.free()
+    return out
+
+
+def cconv_f32_u8(ctx, x):
+    x = np.ascontiguousarray(x, np.complex64)
+    din, dout = ctx.upload(x), ctx.alloc(max(8, len(x) * 2))
+    check(lib.lsdr_cconverter_f32_u8_run(ctx.h, din.ptr, len(x), dout.ptr))
+    out = ctx.download(dout, np.uint8, len(x) * 2).reshape(-1, 2)
+    din.free(); dout.free()
+    return out
+
+
+class Drifter:
+    """drifter<float> (leanchansim.cc:34-88)."""
+
+    def __init__(self, ctx, amp=(0, 0, 0), freq=(0, 0, 0)):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_drifter_create(ctx.h, C.byref(h)))
+        self.h = h
+        for i in range(3):
+            check(lib.lsdr_drifter_set_component(h, i, amp[i], freq[i]))
+
+    def close(self):
+        if self.h:
+            lib.lsdr_drifter_destroy(self.h)
+            self.h = None
+
+    @property
+    def phases(self):
+        a = (C.c_longlong * 3)()
+        check(lib.lsdr_drifter_get_phases(self.h, a))
+        return tuple(a)
+
+    @phases.setter
+    def phases(self, v):
+        check(lib.lsdr_drifter_set_phases(self.h, (C.c_longlong * 3)(*v)))
+
+    def run(self, x, chunk=4096):
+        x = np.ascontiguousarray(x, np.complex64)
+        din, dout = self.ctx.upload(x), self.ctx.alloc(max(8, len(x) * 8))
+        check(lib.lsdr_drifter_run(self.h, din.ptr, len(x), dout.ptr, chunk))
+        out = self.ctx.download(dout, np.complex64, len(x))
+        din.free(); dout.free()
+        return out
 
 
 # ---- transmit chain (leandvbtx.cc:79-175) ------------------------------------------------

@@ -173,5 +173,81 @@ struct fir_resampler<complex<float>, float> : runnable {
   float current_freq;
 };
 
+// ---- channel-simulator blocks of leanchansim (dsp.h:33-54, 118-138, 164-190) on device pipebufs.
+template <>
+struct cconverter<float, 0, u8, 128, 1, 1> : runnable {
+  cconverter(scheduler *sch, pipebuf<complex<float> > &i, pipebuf<complex<u8> > &o)
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i.dev, o.dev, "cconverter: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {}
+  void run() {
+    unsigned long count = min(in.readable(), out.writable());
+    if (!count) return;
+    lsdr_check(lsdr_cconverter_f32_u8_run(ctx, (const lsdr_cf32 *)in.rd(), count, (lsdr_cu8 *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<complex<float> > in;
+  pipewriter<complex<u8> > out;
+};
+
+template <typename T>
+struct adder;
+
+template <>
+struct adder<complex<float> > : runnable {
+  adder(scheduler *sch, pipebuf<complex<float> > &i1, pipebuf<complex<float> > &i2, pipebuf<complex<float> > &o)
+      : runnable(sch, "adder"), ctx(pipe_ctx(i1.dev, o.dev, "adder: pipebufs must be device pipebufs of one ctx")), in1(i1), in2(i2),
+        out(o) {
+    pipe_ctx(i2.dev, o.dev, "adder: pipebufs must be device pipebufs of one ctx");
+  }
+  void run() {
+    unsigned long n = out.writable();
+    if (in1.readable() < n) n = in1.readable();
+    if (in2.readable() < n) n = in2.readable();
+    if (!n) return;
+    lsdr_check(lsdr_adder_run(ctx, (const lsdr_cf32 *)in1.rd(), (const lsdr_cf32 *)in2.rd(), n, (lsdr_cf32 *)out.wr()), name);
+    in1.read(n);
+    in2.read(n);
+    out.written(n);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<complex<float> > in1, in2;
+  pipewriter<complex<float> > out;
+};
+
+// wgn_c<float>: glibc's drand48 stream, continued on the device.  `seed()` stands for the srand48() call the reference's
+// main() makes before sch.run() (leanchansim.cc:146-147); without it the stream is that of a process that never seeds.
+template <typename T>
+struct wgn_c;
+
+template <>
+struct wgn_c<float> : runnable {
+  float stddev;
+  wgn_c(scheduler *sch, pipebuf<complex<float> > &o)
+      : runnable(sch, "awgn"), stddev(1.0), ctx(o.dev), out(o), h(NULL), seeded(false), seedval(0) {
+    if (!ctx) fail("wgn_c: pipebuf must be a device pipebuf");
+  }
+  void seed(long s) { seeded = true; seedval = s; }
+  void run() {
+    if (!h) lsdr_check(lsdr_wgn_create(ctx, seeded, seedval, &h), name);
+    unsigned long n = out.writable();
+    if (!n) return;
+    lsdr_check(lsdr_wgn_run(h, stddev, NULL, (lsdr_cf32 *)out.wr(), n), name);
+    out.written(n);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipewriter<complex<float> > out;
+  lsdr_wgn *h;
+  bool seeded;
+  long seedval;
+};
+
 }  // namespace leansdr
 #endif

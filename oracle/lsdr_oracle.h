@@ -197,6 +197,20 @@ size_t lo_convol_run(lo_convol *c, const uint8_t *in, size_t n_in, uint8_t *out,
 void lo_cstln_transmitter(const lo_cstln_lut *c, const uint8_t *sym, size_t n, lo_cf32 *out);          /* sdr.h:1196-1222 */
 size_t lo_simple_agc(float *estimated, float out_rms, float bw, const lo_cf32 *in, size_t n, lo_cf32 *out); /* sdr.h:238-274 */
 
+/* ---- channel simulator of leanchansim (lsdr_oracle_chan.c) --------------------------------- */
+uint64_t lo_drand48_default(void);                        /* glibc's initial drand48 state */
+uint64_t lo_srand48(long seed);
+double lo_drand48(uint64_t *x);
+float lo_logf(float x);                                   /* glibc 2.35 logf restated (positive normal x) */
+void lo_logf_table(double *tab32, double *ln2, double *poly3);
+void lo_wgn(uint64_t *state, float stddev, lo_cf32 *out, size_t n);                                  /* dsp.h:164-190 */
+float lo_db_to_amp(double db);
+void lo_adder(const lo_cf32 *a, const lo_cf32 *b, size_t n, lo_cf32 *out);                           /* dsp.h:118-138 */
+void lo_cconv_f32_u8(const lo_cf32 *in, size_t n, lo_cu8 *out);                                      /* dsp.h:33-54 */
+void lo_drifter_trig(lo_cf32 *lut65536);                                                             /* leanchansim.cc:42-46 */
+void lo_drifter_run(const lo_cf32 *lut, const float amp[3], const float freq[3], long a[3], const lo_cf32 *in, size_t n,
+                    lo_cf32 *out);                                                                   /* leanchansim.cc:57-80 */
+
 /* ---- `--hs` path (lsdr_oracle_hs.c) ------------------------------------------------------ */
 typedef struct lo_fastqpsk lo_fastqpsk;                   /* fast_qpsk_receiver<u8>, sdr.h:946-1189 */
 lo_fastqpsk *lo_fastqpsk_new(float omega, float freq, float pll_adjustment, int allow_drift, unsigned long meas_decimation);

@@ -82,6 +82,39 @@ class CstlnLut(C.Structure):
                 ("phase_error", C.c_int16 * 65536)]
 
 
+def chan_test_input(n=50000):
+    """Deterministic cf32 test signal for the channel-simulator fixtures (exact small integers/halves, plus the float → u8
+    corner cases of cconverter<f32,0,u8,128,1,1> in its first samples)."""
+    i = np.arange(n, dtype=np.int64)
+    x = (((i * 37) % 251 - 125) * 0.5 + 1j * (((i * 91) % 241 - 120) * 0.5)).astype(np.complex64)
+    x[:8] = np.array([1e10, -1e10, 3e9 + 3e9j, np.nan, np.inf, -129.5, 127.9, -0.0], np.complex64)
+    return x
+
+
+CHAN_CASES = [("awgn", "--awgn -3 --deterministic", dict(awgn_db=-3.0)),
+              ("drift_u8", "--awgn 2.5 --deterministic -f 2e6 --lo 10e9 --ppm 3 --drift-period 0.01 --drift2-amp 500 --drift2-freq 70 --ou8 --scale 0.5",
+               dict(awgn_db=2.5, Fs=2e6, lo=10e9, ppm=3, drift_period=0.01, drift2_amp=500, drift2_freq=70, ou8=True, scale=0.5)),
+              ("driftrate", "--deterministic -f 2e6 --lo 10e9 --ppm -3 --drift-rate 40000", dict(Fs=2e6, lo=10e9, ppm=-3, drift_rate=40000))]
+
+
+def chansim_drifts(Fs=0.0, lo=0.0, ppm=-1.0, drift_period=0.0, drift_rate=0.0, drift2_amp=0.0, drift2_freq=0.0):
+    """The drifter components leanchansim derives from its options (leanchansim.cc:155-170; config fields are floats, the
+    expressions mix in double constants)."""
+    f32, f64 = np.float32, np.float64
+    Fs, lo, ppm, drift_period, drift_rate, drift2_amp, drift2_freq = (f32(v) for v in (Fs, lo, ppm, drift_period, drift_rate, drift2_amp, drift2_freq))
+    with np.errstate(all="ignore"):
+        maxoffs = f32(f64(lo * ppm) * 1e-6)
+        amp = [float(maxoffs / Fs), 0.0, 0.0]
+        freq = [0.0, 0.0, 0.0]
+        if drift_period:
+            freq[0] = float(f32((1.0 / f64(drift_period)) / f64(Fs)))
+        if drift_rate:
+            freq[0] = float(f32((f64(drift_rate) / (2 * np.pi * f64(ppm))) / f64(Fs)))
+        if drift2_amp and drift2_freq:
+            amp[1] = float(drift2_amp / Fs); freq[1] = float(drift2_freq / Fs)
+    return amp, freq
+
+
 class Oracle:
     def __init__(self, path=ORACLE_SO):
         if not os.path.exists(path):
@@ -399,6 +432,86 @@ class Oracle:
         self.lib.lo_simple_agc.argtypes = [C.POINTER(c_f), c_f, c_f, C.c_void_p, c_sz, C.c_void_p]
         n = self.lib.lo_simple_agc(C.byref(est), out_rms, bw, _p(x), len(x), _p(out))
         return out[:n].copy(), est.value
+
+    # ---- channel simulator (lsdr_oracle_chan.c) ----
+    def drand48(self, n, seed=None):
+        """n consecutive drand48() results and the final 48-bit state."""
+        L = self.lib
+        L.lo_drand48_default.restype = C.c_uint64
+        L.lo_srand48.restype = C.c_uint64
+        L.lo_srand48.argtypes = [C.c_long]
+        L.lo_drand48.restype = C.c_double
+        L.lo_drand48.argtypes = [C.POINTER(C.c_uint64)]
+        x = C.c_uint64(L.lo_drand48_default() if seed is None else L.lo_srand48(seed))
+        out = np.array([L.lo_drand48(C.byref(x)) for _ in range(n)], np.float64)
+        return out, x.value
+
+    def logf(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        self.lib.lo_logf.restype = c_f
+        self.lib.lo_logf.argtypes = [c_f]
+        return np.array([self.lib.lo_logf(float(v)) for v in x], np.float32)
+
+    def wgn(self, n, stddev=1.0, seed=None, state=None):
+        """wgn_c<f32>: n samples.  Returns (samples, drand48 state after)."""
+        L = self.lib
+        L.lo_drand48_default.restype = C.c_uint64
+        L.lo_srand48.restype = C.c_uint64
+        L.lo_srand48.argtypes = [C.c_long]
+        x = C.c_uint64(state if state is not None else (L.lo_drand48_default() if seed is None else L.lo_srand48(seed)))
+        out = np.empty(n, np.complex64)
+        L.lo_wgn.argtypes = [C.POINTER(C.c_uint64), c_f, C.c_void_p, c_sz]
+        L.lo_wgn(C.byref(x), stddev, _p(out), n)
+        return out, x.value
+
+    def adder(self, a, b):
+        a = cf32(a); b = cf32(b)
+        n = min(len(a), len(b))
+        out = np.empty(n, np.complex64)
+        self.lib.lo_adder.argtypes = [C.c_void_p, C.c_void_p, c_sz, C.c_void_p]
+        self.lib.lo_adder(_p(a), _p(b), n, _p(out))
+        return out
+
+    def cconv_f32_u8(self, x):
+        x = cf32(x)
+        out = np.empty((len(x), 2), np.uint8)
+        self.lib.lo_cconv_f32_u8.argtypes = [C.c_void_p, c_sz, C.c_void_p]
+        self.lib.lo_cconv_f32_u8(_p(x), len(x), _p(out))
+        return out
+
+    def drifter_trig(self):
+        lut = np.empty(65536, np.complex64)
+        self.lib.lo_drifter_trig.argtypes = [C.c_void_p]
+        self.lib.lo_drifter_trig(_p(lut))
+        return lut
+
+    def drifter(self, x, amp, freq, a=(0, 0, 0), chunk=4096):
+        """drifter<float> over x cut into run() calls of `chunk` samples (leanchansim's pipes hold 4096).
+        Returns (out, a after)."""
+        x = cf32(x)
+        lut = self.drifter_trig()
+        out = np.empty_like(x)
+        amp = (c_f * 3)(*amp); freq = (c_f * 3)(*freq); aa = (C.c_long * 3)(*a)
+        self.lib.lo_drifter_run.argtypes = [C.c_void_p, c_f * 3, c_f * 3, C.c_long * 3, C.c_void_p, c_sz, C.c_void_p]
+        chunk = chunk or max(len(x), 1)
+        for p in range(0, len(x), chunk):
+            m = min(chunk, len(x) - p)
+            self.lib.lo_drifter_run(_p(lut), amp, freq, aa, x[p:].ctypes.data, m, out[p:].ctypes.data)
+        return out, tuple(aa)
+
+    def chansim(self, x, awgn_db=None, scale=1.0, Fs=0.0, lo=0.0, ppm=-1.0, drift_period=0.0, drift_rate=0.0, drift2_amp=0.0,
+                drift2_freq=0.0, ou8=False, seed=None, chunk=4096):
+        """leanchansim (leanchansim.cc:120-176) on cf32 input: scaler → + wgn_c → drifter → [cconverter to u8]."""
+        x = cf32(x)
+        y = self.scaler(scale, x)
+        self.lib.lo_db_to_amp.restype = c_f
+        self.lib.lo_db_to_amp.argtypes = [C.c_double]
+        stddev = self.lib.lo_db_to_amp(awgn_db) if awgn_db is not None else 0.0
+        noise, _ = self.wgn(len(y), stddev, seed)
+        y = self.adder(y, noise)
+        amp, freq = chansim_drifts(Fs, lo, ppm, drift_period, drift_rate, drift2_amp, drift2_freq)
+        y, _ = self.drifter(y, amp, freq, chunk=chunk)
+        return self.cconv_f32_u8(y) if ou8 else y
 
     def hs_chain(self, iq_u8, omega, fastlock=0):
         """leandvb --hs (leandvb.cc:727-969): fast_qpsk_receiver → dvb_deconvol_sync_hard → mpeg_sync(fastlock, resync) →
@@ -856,6 +969,50 @@ class Ref:
         self.lib.ref_simple_agc.argtypes = [c_f, c_f, C.c_void_p, C.c_long, C.c_void_p, C.POINTER(c_f)]
         n = self.lib.ref_simple_agc(out_rms, bw, _p(x), len(x), _p(out), C.byref(est))
         return out[:n].copy(), est.value
+
+    def wgn(self, n, stddev=1.0, seed=None):
+        out = np.empty(n, np.complex64)
+        self.lib.ref_wgn.restype = C.c_long
+        self.lib.ref_wgn.argtypes = [C.c_int, C.c_long, c_f, C.c_void_p, C.c_long]
+        k = self.lib.ref_wgn(0 if seed is None else 1, seed or 0, stddev, _p(out), n)
+        return out[:k]
+
+    def drand48_after(self, skip, seed=None):
+        self.lib.ref_drand48_after.restype = C.c_double
+        self.lib.ref_drand48_after.argtypes = [C.c_int, C.c_long, C.c_long]
+        return self.lib.ref_drand48_after(0 if seed is None else 1, seed or 0, skip)
+
+    def logf(self, x):
+        x = np.ascontiguousarray(x, np.float32)
+        y = np.empty_like(x)
+        self.lib.ref_logf.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        self.lib.ref_logf(_p(x), len(x), _p(y))
+        return y
+
+    def logf_mismatches(self, oracle, lo, hi):
+        """Scan every float with bits in [lo, hi): count of inputs where libm's logf and the oracle's restatement differ."""
+        first = C.c_uint32()
+        fn = C.cast(oracle.lib.lo_logf, C.c_void_p)
+        self.lib.ref_logf_mismatches.restype = C.c_long
+        self.lib.ref_logf_mismatches.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
+        return self.lib.ref_logf_mismatches(fn, lo, hi, C.byref(first)), first.value
+
+    def adder(self, a, b):
+        a = cf32(a); b = cf32(b)
+        n = min(len(a), len(b))
+        out = np.empty(n, np.complex64)
+        self.lib.ref_adder.restype = C.c_long
+        self.lib.ref_adder.argtypes = [C.c_void_p, C.c_void_p, C.c_long, C.c_void_p]
+        k = self.lib.ref_adder(_p(a), _p(b), n, _p(out))
+        return out[:k]
+
+    def cconv_f32_u8(self, x):
+        x = cf32(x)
+        out = np.empty((len(x), 2), np.uint8)
+        self.lib.ref_cconv_f32_u8.restype = C.c_long
+        self.lib.ref_cconv_f32_u8.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        k = self.lib.ref_cconv_f32_u8(_p(x), len(x), _p(out))
+        return out[:k]
 
     def hs_deconvol(self, symbols, resync_period=32):
         sym = np.ascontiguousarray(symbols, np.uint8)

@@ -609,6 +609,57 @@ long ref_simple_agc(float out_rms, float bw, const float *in, long n, float *out
   return w.pos;
 }
 
+// ---- channel simulator blocks (leanchansim.cc:120-176) -----------------------------------------------
+// wgn_c<f32> (dsp.h:164-190) on glibc's drand48: seeded = 0 restarts from glibc's initial (all-zero) state (leanchansim --deterministic),
+// else srand48(seed) as leanchansim.cc:146-147 does with the pid.
+long ref_wgn(int seeded, long seed, float stddev, float *out, long n) {
+  if (seeded) srand48(seed);
+  else { unsigned short x0[3] = {0, 0, 0}; seed48(x0); }   // glibc's state in a process that never seeds
+  scheduler sch;
+  pipebuf<cf32> p_out(&sch, "noise", 4096);
+  wgn_c<f32> g(&sch, p_out);
+  g.stddev = stddev;
+  buffer_writer<cf32> w(&sch, p_out, (cf32 *)out, n);
+  sch.run();
+  return w.pos;
+}
+double ref_drand48_after(int seeded, long seed, long skip) {   // (skip+1)-th draw
+  if (seeded) srand48(seed);
+  else { unsigned short x0[3] = {0, 0, 0}; seed48(x0); }   // glibc's state in a process that never seeds
+  for (long i = 0; i < skip; ++i) drand48();
+  return drand48();
+}
+void ref_logf(const float *x, long n, float *y) { for (long i = 0; i < n; ++i) y[i] = logf(x[i]); }
+long ref_logf_mismatches(float (*mine)(float), uint32_t lo, uint32_t hi, uint32_t *first) {   // exhaustive scan helper
+  long bad = 0;
+  for (uint32_t u = lo; u < hi; ++u) {
+    float x, a, b;
+    memcpy(&x, &u, 4);
+    a = logf(x); b = mine(x);
+    if (memcmp(&a, &b, 4)) { if (!bad) *first = u; ++bad; }
+  }
+  return bad;
+}
+long ref_adder(const float *a, const float *b, long n, float *out) {   // dsp.h:118-138
+  scheduler sch;
+  pipebuf<cf32> p_a(&sch, "a", 4096), p_b(&sch, "b", 4096), p_out(&sch, "out", 4096);
+  buffer_reader<cf32> ra(&sch, (cf32 *)a, n, p_a), rb(&sch, (cf32 *)b, n, p_b);
+  adder<cf32> add(&sch, p_a, p_b, p_out);
+  buffer_writer<cf32> w(&sch, p_out, (cf32 *)out, n);
+  sch.run();
+  return w.pos;
+}
+long ref_cconv_f32_u8(const float *in, long n, uint8_t *out) {   // cconverter<f32,0,u8,128,1,1>, dsp.h:33-54
+  scheduler sch;
+  pipebuf<cf32> p_in(&sch, "in", 4096);
+  pipebuf<cu8> p_out(&sch, "out", 4096);
+  buffer_reader<cf32> r(&sch, (cf32 *)in, n, p_in);
+  cconverter<f32, 0, u8, 128, 1, 1> c(&sch, p_in, p_out);
+  buffer_writer<cu8> w(&sch, p_out, (cu8 *)out, n);
+  sch.run();
+  return w.pos;
+}
+
 // dvb.h:1107-1163
 long ref_derandomizer(const uint8_t *in, long npackets, uint8_t *out, uint8_t *pattern1504) {
   scheduler sch;

@@ -22,7 +22,8 @@ def test_two_ranks_gloo(tmp_path):
         secs = 0.5 if s.rank == 0 else 2.0     # the slow rank sets the clock
         total, dt, rate = s.aggregate(units, secs)
         s.barrier()
-        print(json.dumps(dict(rank=s.rank, seed=s.capture_seed(), total=total, dt=dt, rate=rate)), flush=True)
+        # one file per rank: two processes printing to one pipe can interleave their lines
+        open({str(tmp_path)!r} + "/rank%d.json" % s.rank, "w").write(json.dumps(dict(rank=s.rank, seed=s.capture_seed(), total=total, dt=dt, rate=rate)))
         s.close()
     """))
     import socket
@@ -35,7 +36,7 @@ def test_two_ranks_gloo(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=280)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     import json
-    rows = [json.loads(l) for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    rows = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in (0, 1)]
     assert sorted(r["rank"] for r in rows) == [0, 1]
     assert sorted(r["seed"] for r in rows) == [1, 2]          # one capture per rank
     for r in rows:
