@@ -202,7 +202,7 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
         vit_state *st = a.chunk_states + (size_t)job.slot * a.totals_stride + ci;
         st->cost[lane] = cost; st->path[lane] = path;
       }
-      if (ci == 0) { a.first_chunk_states[job.slot].cost[lane] = cost; a.first_chunk_states[job.slot].path[lane] = path; }
+      if (ci == 0 && a.first_chunk_states) { a.first_chunk_states[job.slot].cost[lane] = cost; a.first_chunk_states[job.slot].path[lane] = path; }
     }
   }
   a.end_states[job.slot].cost[lane] = cost;
@@ -226,6 +226,7 @@ struct lsdr_viterbi {
   lsdr_ctx *ctx;
   vit_code C;
   int cstln, rate, bits_per_symbol, nshifts, nsyncs;
+  size_t dbg_chunks = 0;   // chunks consumed so far (LSDR_VIT_DEBUG only)
   int current_sync, resync_phase, resync_period;
   std::vector<unsigned char> maps;   // [nsyncs][256]
   std::vector<int> shifts;
@@ -237,7 +238,7 @@ struct lsdr_viterbi {
   // scratch
   vit_job *d_jobs; vit_state *d_begin, *d_end, *d_first, *d_chunk; int *d_totals, *d_bad;
   vit_state *d_fix;                   // explicit start states of fix-up jobs
-  size_t jobs_cap, totals_cap, chunk_cap, fix_cap;
+  size_t jobs_cap, totals_cap, chunk_cap, fix_cap, first_cap;
   unsigned last_tiles, last_bad;
   size_t budget_chunks;               // chunks attempted per call: shrinks after an alignment switch, regrows
 };
@@ -265,7 +266,8 @@ static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
 
 static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
                       unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr,
-                      const vit_state *dev_start_states = nullptr, bool keep_slots = false, size_t n_slots = 0) {
+                      const vit_state *dev_start_states = nullptr, bool keep_slots = false, size_t n_slots = 0,
+                      bool write_first = true) {
   lsdr_ctx *c = v->ctx;
   const size_t nj = keep_slots ? (n_slots > jobs.size() ? n_slots : jobs.size()) : jobs.size();   // capacity of the slot arrays
   if (start_states && v->fix_cap < start_states->size()) {
@@ -274,13 +276,19 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
     v->fix_cap = start_states->size();
   }
   if (v->jobs_cap < nj) {
-    (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_first); (void)hipFree(v->d_bad);
+    (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_bad);
     LSDR_HIP(hipMalloc((void **)&v->d_jobs, nj * sizeof(vit_job)));
     LSDR_HIP(hipMalloc((void **)&v->d_begin, nj * sizeof(vit_state)));
     LSDR_HIP(hipMalloc((void **)&v->d_end, nj * sizeof(vit_state)));
-    LSDR_HIP(hipMalloc((void **)&v->d_first, nj * sizeof(vit_state)));
     LSDR_HIP(hipMalloc((void **)&v->d_bad, nj * sizeof(int)));
     v->jobs_cap = nj;
+  }
+  // d_first belongs to the current alignment's tiles: it is read lazily after the other alignments have been launched,
+  // so their launches neither write nor reallocate it.
+  if (write_first && v->first_cap < nj) {
+    (void)hipFree(v->d_first);
+    LSDR_HIP(hipMalloc((void **)&v->d_first, nj * sizeof(vit_state)));
+    v->first_cap = nj;
   }
   if (v->totals_cap < nj * stride) {
     (void)hipFree(v->d_totals);
@@ -304,7 +312,7 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.resync_phase0 = phase0; a.resync_period = v->resync_period;
   a.maps = v->d_maps; a.shifts = v->d_shifts;
   a.jobs = v->d_jobs; a.states_in = dev_start_states ? dev_start_states : (start_states ? v->d_fix : v->d_states);
-  a.begin_states = v->d_begin; a.end_states = v->d_end; a.first_chunk_states = v->d_first;
+  a.begin_states = v->d_begin; a.end_states = v->d_end; a.first_chunk_states = write_first ? v->d_first : nullptr;
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
   a.njobs = (unsigned)up.size();
@@ -393,7 +401,7 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
   LSDR_HIP(hipMalloc((void **)&v->d_states, v->nsyncs * sizeof(vit_state)));
   v->d_jobs = nullptr; v->d_begin = v->d_end = v->d_first = v->d_chunk = nullptr; v->d_totals = nullptr; v->d_bad = nullptr;
   v->d_fix = nullptr; v->fix_cap = 0;
-  v->jobs_cap = v->totals_cap = v->chunk_cap = 0;
+  v->jobs_cap = v->totals_cap = v->chunk_cap = v->first_cap = 0;
   v->last_tiles = v->last_bad = 0;
   v->budget_chunks = (size_t)1 << 40;
   *out = v;
@@ -580,7 +588,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       }
       unsigned ostride = 1;
       for (auto &j : oj) if (j.n_chunks > ostride) ostride = j.n_chunks;
-      int rc2 = vit_launch(v, in, out, oj, ostride, sequential, phase0);
+      int rc2 = vit_launch(v, in, out, oj, ostride, sequential, phase0, nullptr, nullptr, false, 0, false);
       if (rc2) return rc2;
       std::vector<int> tot(oj.size() * ostride);
       std::vector<vit_state> hb(oj.size()), he(oj.size()), cst;
@@ -619,7 +627,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
             fj.push_back(j);
             if (j.n_chunks > fstride) fstride = j.n_chunks;
           }
-          rc2 = vit_launch(v, in, out, fj, fstride, false, phase0, &starts);
+          rc2 = vit_launch(v, in, out, fj, fstride, false, phase0, &starts, nullptr, false, 0, false);
           if (rc2) return rc2;
           std::vector<int> ftot(fj.size() * fstride);
           std::vector<vit_state> fe(fj.size());
@@ -657,6 +665,11 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
         const int ts = s == cur ? tcur : other_totals[s][r];
         if (ts > bt) { best = s; bt = ts; }
       }
+      if (getenv("LSDR_VIT_DEBUG")) {
+        fprintf(stderr, "VIT out=%zu cur=%d best=%d :", (size_t)(v->dbg_chunks + rs[r] + 1) * bytes_per_chunk, cur, best);
+        for (int s = 0; s < v->nsyncs; ++s) fprintf(stderr, " %d", s == cur ? tcur : other_totals[s][r]);
+        fprintf(stderr, "\n");
+      }
       if (best != cur) {
         // switch: everything after this chunk must be decoded with the new alignment → stop here
         used_chunks = rs[r] + 1;
@@ -680,7 +693,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
           j.first_chunk = 0; j.n_chunks = (unsigned)(rs[r] + 1);
           j.warm = 0; j.sync = cur; j.from_state = cur; j.emit = 1; j.chunk_step = 1;
           std::vector<vit_job> one(1, j);
-          rc = vit_launch(v, in, out, one, j.n_chunks, false, phase0);
+          rc = vit_launch(v, in, out, one, j.n_chunks, false, phase0, nullptr, nullptr, false, 0, false);
           if (rc) return rc;
           LSDR_HIP(hipMemcpy(&old_cur, v->d_end, sizeof(vit_state), hipMemcpyDeviceToHost));
         }
@@ -699,6 +712,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   else if (v->budget_chunks < ((size_t)1 << 40)) v->budget_chunks *= 2;
   v->current_sync = new_sync;
   v->resync_phase = (int)(((unsigned long long)phase0 + used_chunks) % (unsigned)P);
+  v->dbg_chunks += used_chunks;
   *consumed = used_chunks * sym_per_chunk;
   *produced = used_chunks * bytes_per_chunk;
   return LSDR_OK;

@@ -365,6 +365,11 @@ size_t lo_viterbi_run(lo_viterbi *s, const lo_softsymbol *in, size_t n_in, uint8
     if (!s->resync_phase) {
       int best = s->current_sync;
       for (int k = 0; k < s->nsyncs; ++k) if (total[k] > total[best]) best = k;
+      if (getenv("LO_VIT_DEBUG")) {
+        fprintf(stderr, "VIT out=%zu cur=%d best=%d :", nout_bytes, s->current_sync, best);
+        for (int k = 0; k < s->nsyncs; ++k) fprintf(stderr, " %d", total[k]);
+        fprintf(stderr, "\n");
+      }
       s->current_sync = best;
     }
     if (++s->resync_phase >= s->resync_period) s->resync_phase = 0;

@@ -230,12 +230,18 @@ def test_viterbi_alignment_search(capi, ctx, oracle):
         assert cons == wcons and bits_equal(got, want)
 
 
-@pytest.mark.parametrize("cstln,rate", [(1, 2), (1, 3), (1, 4), (1, 5), (2, 1), (0, 0)])
+# (constellation, code rate): every trellis of dvb.h:1179-1212 and every constellation of sdr.h:340-452 at least once
+VITERBI_MODES = [(1, 2), (1, 3), (1, 4), (1, 5), (2, 1), (0, 0),                   # QPSK 4/6 3/4 5/6 7/8, 8PSK 2/3, BPSK 1/2
+                 (2, 2), (3, 3), (4, 6), (5, 2), (5, 4), (6, 3), (7, 2), (7, 4),   # 8PSK 4/6, 16APSK 3/4, 32APSK 4/5, 64APSK 4/6 5/6, 16QAM 3/4, 64QAM 4/6 5/6
+                 (8, 5), (0, 3), (0, 5)]                                           # 256QAM 7/8, BPSK 3/4 7/8
+
+
+@pytest.mark.parametrize("cstln,rate", VITERBI_MODES)
 def test_viterbi_other_rates_vs_oracle(capi, ctx, oracle, cstln, rate):
     rng = np.random.default_rng(4)
     n = 50000
     sym = np.zeros(n, capi.SOFTSYM)
-    nsym = {0: 2, 1: 4, 2: 8}[cstln]
+    nsym = {0: 2, 1: 4, 2: 8, 3: 16, 4: 32, 5: 64, 6: 16, 7: 64, 8: 256}[cstln]
     sym["symbol"] = rng.integers(0, nsym, n)
     sym["cost"] = -rng.integers(0, 9000, n)
     v = capi.Viterbi(ctx, cstln, rate)

@@ -129,6 +129,20 @@ def test_8psk_viterbi_vs_reference(oracle, ref):
     assert bits_equal(a, b) and cur == rcur
 
 
+@pytest.mark.parametrize("cstln,rate,nsym", [(2, 2, 8), (3, 3, 16), (4, 6, 32), (5, 2, 64), (5, 4, 64), (6, 3, 16), (7, 2, 64), (7, 4, 64),
+                                             (8, 5, 256), (0, 3, 2), (0, 5, 2)])
+def test_viterbi_every_constellation_vs_reference(oracle, ref, cstln, rate, nsym):
+    """the remaining trellises (4/6, 3/4, 4/5, 5/6, 7/8) under the higher-order constellations
+    (8PSK … 256QAM label maps, conjugate/rotation alignments of dvb.h:1246-1296)."""
+    rng = np.random.default_rng(4)
+    sym = np.zeros(30000, po.SOFTSYM)
+    sym["symbol"] = rng.integers(0, nsym, len(sym))
+    sym["cost"] = -rng.integers(0, 9000, len(sym))
+    a, _, cur = oracle.viterbi_sync(sym, cstln, rate)
+    b, rcur = ref.viterbi_sync(sym, cstln, rate)
+    assert bits_equal(a, b) and cur == rcur
+
+
 def test_end_to_end_vs_leandvb_binary(oracle, ref):
     """The real `leandvb` (oracle/_ref) on a reference-generated capture == oracle front end + tail."""
     refdir = po.REF_DIR
