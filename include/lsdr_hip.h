@@ -380,6 +380,8 @@ int lsdr_wgn_run(lsdr_wgn *w, float stddev, const lsdr_cf32 *add, lsdr_cf32 *out
 int lsdr_adder_run(lsdr_ctx *ctx, const lsdr_cf32 *a, const lsdr_cf32 *b, size_t n, lsdr_cf32 *out);
 /* cconverter<f32,0,u8,128,1,1>::run, dsp.h:40-50 (x86 float → int32 → u8 truncation) */
 int lsdr_cconverter_f32_u8_run(lsdr_ctx *ctx, const lsdr_cf32 *in, size_t n, lsdr_cu8 *out);
+/* cconverter<f32,0,int16_t,0,32768,1>::run (leandvbtx --s16, leandvbtx.cc:179): out = interleaved (re, im) int16 */
+int lsdr_cconverter_f32_s16_run(lsdr_ctx *ctx, const lsdr_cf32 *in, size_t n, int16_t *out);
 typedef struct lsdr_drifter lsdr_drifter;                  /* drifter<float>, leanchansim.cc:34-88 */
 int lsdr_drifter_create(lsdr_ctx *ctx, lsdr_drifter **d);
 void lsdr_drifter_destroy(lsdr_drifter *d);

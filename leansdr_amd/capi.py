@@ -19,6 +19,7 @@ psz = C.POINTER(c_sz)
 SOFTSYM = np.dtype([("cost", "<i2"), ("symbol", "u1"), ("pad", "u1")])
 
 (BPSK, QPSK, PSK8, APSK16, APSK32, APSK64E, QAM16, QAM64, QAM256) = range(9)
+CSTLN_BITS = {BPSK: 1, QPSK: 2, PSK8: 3, APSK16: 4, APSK32: 5, APSK64E: 6, QAM16: 4, QAM64: 6, QAM256: 8}
 (FEC12, FEC23, FEC46, FEC34, FEC56, FEC78, FEC45, FEC89, FEC910) = range(9)
 IN_CF32, IN_CU8 = 0, 1
 FIR_EXACT, FIR_FMA = 0, 1
@@ -138,6 +139,7 @@ _sig("lsdr_wgn_set_state", C.c_int, [vp, C.c_ulonglong])
 _sig("lsdr_wgn_run", C.c_int, [vp, c_f, vp, vp, c_sz])
 _sig("lsdr_adder_run", C.c_int, [vp, vp, vp, c_sz, vp])
 _sig("lsdr_cconverter_f32_u8_run", C.c_int, [vp, vp, c_sz, vp])
+_sig("lsdr_cconverter_f32_s16_run", C.c_int, [vp, vp, c_sz, vp])
 _sig("lsdr_drifter_create", C.c_int, [vp, C.POINTER(vp)])
 _sig("lsdr_drifter_destroy", None, [vp])
 _sig("lsdr_drifter_set_component", C.c_int, [vp, C.c_int, c_f, c_f])
@@ -944,6 +946,15 @@ def cconv_f32_u8(ctx, x):
     return out
 
 
+def cconv_f32_s16(ctx, x):
+    x = np.ascontiguousarray(x, np.complex64)
+    din, dout = ctx.upload(x), ctx.alloc(max(8, len(x) * 4))
+    check(lib.lsdr_cconverter_f32_s16_run(ctx.h, din.ptr, len(x), dout.ptr))
+    out = ctx.download(dout, np.int16, len(x) * 2).reshape(-1, 2)
+    din.free(); dout.free()
+    return out
+
+
 class Drifter:
     """drifter<float> (leanchansim.cc:34-88)."""
 
@@ -988,8 +999,9 @@ class TxChain:
     def __init__(self, ctx, interp=2, decim=1, amp=1.0, rolloff=0.35, rrc_rej=10.0, agc=False, cstln=QPSK, rate=FEC12):
         self.ctx, self.interp, self.decim, self.cstln, self.rate = ctx, interp, decim, cstln, rate
         self.rand = vp(); check(lib.lsdr_randomizer_create(ctx.h, C.byref(self.rand)))
-        bps = {BPSK: 1, QPSK: 2, PSK8: 3}.get(cstln, 2)
-        self.conv = vp(); check(lib.lsdr_convol_create(ctx.h, rate, bps, C.byref(self.conv)))
+        bps = CSTLN_BITS[cstln]
+        conv_rate = FEC46 if (rate == FEC23 and bps in (2, 6)) else rate      # leandvbtx.cc:117-121
+        self.conv = vp(); check(lib.lsdr_convol_create(ctx.h, conv_rate, bps, C.byref(self.conv)))
         order = int(interp * rrc_rej)
         co = root_raised_cosine(order, float(np.float32(1.0) / np.float32(interp)), rolloff)
         co = normalize_power(co, float(np.float32(amp) / np.float32(75.0)))
@@ -1001,6 +1013,7 @@ class TxChain:
             check(lib.lsdr_simple_agc_create(ctx.h, float(np.float32(amp) / np.sqrt(np.float32(np.float32(interp) / decim))),
                                              float(np.float32(0.001 * decim / interp)), C.byref(self.agc)))
         self.pk_hold = np.zeros((0, 204), np.uint8)      # interleaver window (host-side carry of unconsumed packets)
+        self.il_hold = np.zeros(0, np.uint8)              # interleaved bytes short of a convolutional group
         self.iq_hold = np.zeros(0, np.complex64)          # resampler input not yet consumed
         self.dec_hold = np.zeros(0, np.complex64)         # decimator / AGC remainders
         self.agc_hold = np.zeros(0, np.complex64)
@@ -1037,9 +1050,10 @@ class TxChain:
         d = ctx.upload(pk)
         il, cons = self._run2(lib.lsdr_interleaver_run, None, d, len(pk), len(pk) * 204, np.uint8); d.free()
         self.pk_hold = pk[cons:]
+        il = np.concatenate([self.il_hold, il])                 # dvb_convol consumes whole groups of bits_in bytes
         d = ctx.upload(il)
         sym, cons = self._run2(lib.lsdr_convol_run, self.conv, d, len(il), len(il) * 16 + 64, np.uint8); d.free()
-        assert cons == len(il)
+        self.il_hold = il[cons:]
         d = ctx.upload(sym)
         dq = ctx.alloc(max(16, len(sym) * 8))
         check(lib.lsdr_cstln_transmitter_run(ctx.h, self.cstln, self.rate, d.ptr, len(sym), dq.ptr)); d.free()

@@ -171,6 +171,14 @@ __global__ __launch_bounds__(256) void k_cconv_f32_u8(const float2 *in, unsigned
   }
 }
 
+__global__ __launch_bounds__(256) void k_cconv_f32_s16(const float2 *in, unsigned long long n, short2 *out) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const float2 v = in[i];
+    out[i] = make_short2((short)x86_f2i(0 + (v.x - 0.f) * 32768 / 1), (short)x86_f2i(0 + (v.y - 0.f) * 32768 / 1));
+  }
+}
+
 struct drift_comp { float amp, freq; long long a; int active; };
 struct drift_args { drift_comp c[3]; long long step[3]; };   // step: per-sample increment where the closed form is valid
 
@@ -350,6 +358,14 @@ int lsdr_cconverter_f32_u8_run(lsdr_ctx *c, const lsdr_cf32 *in, size_t n, lsdr_
   LSDR_ARG(c && (n == 0 || (in && out)));
   if (!n) return LSDR_OK;
   hipLaunchKernelGGL(k_cconv_f32_u8, dim3(grid_for(c, n)), dim3(256), 0, c->stream, (const float2 *)in, (unsigned long long)n, (uchar2 *)out);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+int lsdr_cconverter_f32_s16_run(lsdr_ctx *c, const lsdr_cf32 *in, size_t n, int16_t *out) {
+  LSDR_ARG(c && (n == 0 || (in && out)));
+  if (!n) return LSDR_OK;
+  hipLaunchKernelGGL(k_cconv_f32_s16, dim3(grid_for(c, n)), dim3(256), 0, c->stream, (const float2 *)in, (unsigned long long)n, (short2 *)out);
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }

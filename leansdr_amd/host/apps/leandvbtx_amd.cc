@@ -1,6 +1,6 @@
 // leansdr_amd/host/apps/leandvbtx_amd.cc — the graph of leandvbtx (src/apps/leandvbtx.cc:79-197 of the reference) built
 // against the MI355X host framework: TS packets on stdin → cf32 (or s16) baseband on stdout, every block on the GPU.
-// Same options: --cr N/D, -f INTERP[/DECIM], --roll-off R, --rrc-rej, --power DB, --agc, --f32 | --s16, -v, -d.
+// Same options: --cr N/D, --const NAME, -f INTERP[/DECIM], --roll-off R, --rrc-rej, --power DB, --agc, --f32 | --s16, --fill, -v, -d.
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,10 +22,12 @@ struct config {
   bool agc;
   int interp, decim;
   float rolloff, rrc_rej;
+  enum { OUTPUT_F32, OUTPUT_S16 } output_format;
+  bool fill;
   bool verbose, debug;
   int device;
   config() : constellation(cstln_lut<256>::QPSK), fec(FEC12), amp(1.0), agc(false), interp(2), decim(1), rolloff(0.35), rrc_rej(10),
-             verbose(false), debug(false), device(0) {}
+             output_format(OUTPUT_F32), fill(false), verbose(false), debug(false), device(0) {}
 };
 
 static int log2i(int x) { int n = -1; for (; x; ++n, x >>= 1); return n; }
@@ -78,9 +80,25 @@ static void run(config &cfg) {
     r_agc->bw = 0.001 * cfg.decim / cfg.interp;
     tail = p_agc;
   }
-  pipebuf<cf32> p_host(&sch, "baseband(host)", BUF_SYMBOLS * cfg.interp);
-  d2h_copier<cf32> r_d2h(&sch, ctx, *tail, p_host);
-  file_writer<cf32> r_stdout(&sch, p_host, 1);
+  if (cfg.output_format == config::OUTPUT_F32) {
+    pipebuf<cf32> *p_host = new pipebuf<cf32>(&sch, "baseband(host)", BUF_SYMBOLS * cfg.interp);
+    new d2h_copier<cf32>(&sch, ctx, *tail, *p_host);
+    new file_writer<cf32>(&sch, *p_host, 1);
+  } else {   // leandvbtx.cc:176-182
+    typedef complex<int16_t> cs16;
+    pipebuf<cs16> *p_s16 = new pipebuf<cs16>(&sch, "stdout(dev)", BUF_SYMBOLS * cfg.interp, ctx);
+    new cconverter<f32, 0, int16_t, 0, 32768, 1>(&sch, *tail, *p_s16);
+    pipebuf<cs16> *p_host = new pipebuf<cs16>(&sch, "stdout", BUF_SYMBOLS * cfg.interp);
+    new d2h_copier<cs16>(&sch, ctx, *p_s16, *p_host);
+    new file_writer<cs16>(&sch, *p_host, 1);
+  }
+  if (cfg.fill) {   // leandvbtx.cc:187-193
+    if (cfg.verbose) fprintf(stderr, "Realtime mode\n");
+    tspacket blank;
+    memset(blank.data, 0, 188);
+    blank.data[0] = 0x47;
+    r_stdin.set_realtime(blank);
+  }
 
   sch.run();
   sch.shutdown();
@@ -91,7 +109,8 @@ static void run(config &cfg) {
 static void usage(const char *name, FILE *f, int c) {
   fprintf(f, "Usage: %s [options]  < TS  > IQ\n", name);
   fprintf(f, "Modulate MPEG packets into a DVB-S baseband signal on the GPU (leandvbtx on MI355X)\n"
-             "  --cr N/D | -f INTERP[/DECIM] | --roll-off R | --rrc-rej N | --power DB | --agc | --device N | -v | -d\n");
+             "  --cr N/D | --const NAME | -f INTERP[/DECIM] | --roll-off R | --rrc-rej N | --power DB | --agc\n"
+             "  --f32 | --s16 | --fill | --device N | -v | -d\n");
   exit(c);
 }
 
@@ -108,7 +127,19 @@ int main(int argc, char *argv[]) {
       else if (!strcmp(argv[i], "3/4")) cfg.fec = FEC34;
       else if (!strcmp(argv[i], "5/6")) cfg.fec = FEC56;
       else if (!strcmp(argv[i], "7/8")) cfg.fec = FEC78;
+      else if (!strcmp(argv[i], "4/5")) cfg.fec = FEC45;
+      else if (!strcmp(argv[i], "8/9")) cfg.fec = FEC89;
+      else if (!strcmp(argv[i], "9/10")) cfg.fec = FEC910;
       else usage(argv[0], stderr, 1);
+    } else if (!strcmp(argv[i], "--const") && i + 1 < argc) {
+      ++i;
+      static const struct { const char *n; cstln_lut<256>::predef v; } tab[] = {
+          {"BPSK", cstln_lut<256>::BPSK}, {"QPSK", cstln_lut<256>::QPSK}, {"8PSK", cstln_lut<256>::PSK8},
+          {"16APSK", cstln_lut<256>::APSK16}, {"32APSK", cstln_lut<256>::APSK32}, {"64APSKe", cstln_lut<256>::APSK64E},
+          {"16QAM", cstln_lut<256>::QAM16}, {"64QAM", cstln_lut<256>::QAM64}, {"256QAM", cstln_lut<256>::QAM256}};
+      bool ok = false;
+      for (auto &t : tab) if (!strcmp(argv[i], t.n)) { cfg.constellation = t.v; ok = true; }
+      if (!ok) usage(argv[0], stderr, 1);
     } else if (!strcmp(argv[i], "-f") && i + 1 < argc) {
       ++i;
       cfg.decim = 1;
@@ -117,7 +148,10 @@ int main(int argc, char *argv[]) {
     else if (!strcmp(argv[i], "--rrc-rej") && i + 1 < argc) cfg.rrc_rej = atof(argv[++i]);
     else if (!strcmp(argv[i], "--power") && i + 1 < argc) cfg.amp = expf(logf(10) * atof(argv[++i]) / 20);
     else if (!strcmp(argv[i], "--agc")) cfg.agc = true;
-    else if (!strcmp(argv[i], "--f32")) {}
+    else if (!strcmp(argv[i], "--f32")) cfg.output_format = config::OUTPUT_F32;
+    else if (!strcmp(argv[i], "--s16")) cfg.output_format = config::OUTPUT_S16;
+    else if (!strcmp(argv[i], "--fill")) cfg.fill = true;
+    else if (!strcmp(argv[i], "--version")) { printf("leansdr_amd\n"); exit(0); }
     else if (!strcmp(argv[i], "--device") && i + 1 < argc) cfg.device = atoi(argv[++i]);
     else usage(argv[0], stderr, 1);
   }

@@ -193,6 +193,25 @@ struct cconverter<float, 0, u8, 128, 1, 1> : runnable {
   pipewriter<complex<u8> > out;
 };
 
+template <>
+struct cconverter<float, 0, int16_t, 0, 32768, 1> : runnable {   // leandvbtx --s16 (leandvbtx.cc:179)
+  cconverter(scheduler *sch, pipebuf<complex<float> > &i, pipebuf<complex<int16_t> > &o)
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i.dev, o.dev, "cconverter: pipebufs must be device pipebufs of one ctx")),
+        in(i), out(o) {}
+  void run() {
+    unsigned long count = min(in.readable(), out.writable());
+    if (!count) return;
+    lsdr_check(lsdr_cconverter_f32_s16_run(ctx, (const lsdr_cf32 *)in.rd(), count, (int16_t *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  pipereader<complex<float> > in;
+  pipewriter<complex<int16_t> > out;
+};
+
 template <typename T>
 struct adder;
 

@@ -207,6 +207,7 @@ void lo_wgn(uint64_t *state, float stddev, lo_cf32 *out, size_t n);             
 float lo_db_to_amp(double db);
 void lo_adder(const lo_cf32 *a, const lo_cf32 *b, size_t n, lo_cf32 *out);                           /* dsp.h:118-138 */
 void lo_cconv_f32_u8(const lo_cf32 *in, size_t n, lo_cu8 *out);                                      /* dsp.h:33-54 */
+void lo_cconv_f32_s16(const lo_cf32 *in, size_t n, int16_t *out);                                   /* leandvbtx.cc:179 */
 void lo_drifter_trig(lo_cf32 *lut65536);                                                             /* leanchansim.cc:42-46 */
 void lo_drifter_run(const lo_cf32 *lut, const float amp[3], const float freq[3], long a[3], const lo_cf32 *in, size_t n,
                     lo_cf32 *out);                                                                   /* leanchansim.cc:57-80 */

@@ -88,6 +88,13 @@ void lo_cconv_f32_u8(const lo_cf32 *in, size_t n, lo_cu8 *out) {   /* dsp.h:44-4
   }
 }
 
+void lo_cconv_f32_s16(const lo_cf32 *in, size_t n, int16_t *out /* [n][2] */) {   /* cconverter<f32,0,int16_t,0,32768,1> (leandvbtx.cc:179), dsp.h:44-47 */
+  for (size_t i = 0; i < n; ++i) {
+    out[2 * i] = (int16_t)x86_f2i(0 + (in[i].re - (float)0) * 32768 / 1);
+    out[2 * i + 1] = (int16_t)x86_f2i(0 + (in[i].im - (float)0) * 32768 / 1);
+  }
+}
+
 /* drifter<float> (leanchansim.cc:34-88).  One call = one run(): `phase` restarts at 0 (it is a local of run()). */
 void lo_drifter_trig(lo_cf32 *lut65536) {   /* leanchansim.cc:42-46 */
   for (int i = 0; i < 65536; ++i) {

@@ -413,7 +413,9 @@ class Oracle:
         r = self.randomizer(ts)
         pk = self.rs_encoder(r)
         il = self.interleaver(pk)
-        sym, _ = self.dvb_convol(il, rate, {0: 1, 1: 2, 2: 3}.get(cstln, 2))
+        bps = {0: 1, 1: 2, 2: 3, 3: 4, 4: 5, 5: 6, 6: 4, 7: 6, 8: 8}[cstln]
+        conv_rate = 2 if (rate == 1 and bps in (2, 6)) else rate   # 2/3 on QPSK / 64-ary runs as 4/6 (leandvbtx.cc:117-121)
+        sym, _ = self.dvb_convol(il, conv_rate, bps)
         iq = self.cstln_transmitter(sym, cstln, rate)
         order = int(interp * rrc_rej)
         co = self.rrc(order, float(np.float32(1.0) / np.float32(interp)), rolloff)
@@ -477,6 +479,13 @@ class Oracle:
         out = np.empty((len(x), 2), np.uint8)
         self.lib.lo_cconv_f32_u8.argtypes = [C.c_void_p, c_sz, C.c_void_p]
         self.lib.lo_cconv_f32_u8(_p(x), len(x), _p(out))
+        return out
+
+    def cconv_f32_s16(self, x):
+        x = cf32(x)
+        out = np.empty((len(x), 2), np.int16)
+        self.lib.lo_cconv_f32_s16.argtypes = [C.c_void_p, c_sz, C.c_void_p]
+        self.lib.lo_cconv_f32_s16(_p(x), len(x), _p(out))
         return out
 
     def drifter_trig(self):
@@ -1012,6 +1021,14 @@ class Ref:
         self.lib.ref_cconv_f32_u8.restype = C.c_long
         self.lib.ref_cconv_f32_u8.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
         k = self.lib.ref_cconv_f32_u8(_p(x), len(x), _p(out))
+        return out[:k]
+
+    def cconv_f32_s16(self, x):
+        x = cf32(x)
+        out = np.empty((len(x), 2), np.int16)
+        self.lib.ref_cconv_f32_s16.restype = C.c_long
+        self.lib.ref_cconv_f32_s16.argtypes = [C.c_void_p, C.c_long, C.c_void_p]
+        k = self.lib.ref_cconv_f32_s16(_p(x), len(x), _p(out))
         return out[:k]
 
     def hs_deconvol(self, symbols, resync_period=32):

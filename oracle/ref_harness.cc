@@ -660,6 +660,17 @@ long ref_cconv_f32_u8(const float *in, long n, uint8_t *out) {   // cconverter<f
   return w.pos;
 }
 
+long ref_cconv_f32_s16(const float *in, long n, int16_t *out) {   // cconverter<f32,0,int16_t,0,32768,1>, leandvbtx.cc:179
+  scheduler sch;
+  pipebuf<cf32> p_in(&sch, "in", 4096);
+  pipebuf<complex<int16_t> > p_out(&sch, "out", 4096);
+  buffer_reader<cf32> rd(&sch, (cf32 *)in, n, p_in);
+  cconverter<f32, 0, int16_t, 0, 32768, 1> c(&sch, p_in, p_out);
+  buffer_writer<complex<int16_t> > w(&sch, p_out, (complex<int16_t> *)out, n);
+  sch.run();
+  return w.pos;
+}
+
 // dvb.h:1107-1163
 long ref_derandomizer(const uint8_t *in, long npackets, uint8_t *out, uint8_t *pattern1504) {
   scheduler sch;

@@ -3,10 +3,12 @@ binary (tests/golden/tx.npz) and, where the reference build is present, block by
 import hashlib
 import numpy as np
 import pytest
+import pyoracle as po
 from conftest import gold, bits_equal
 
 CASES = [("f2", dict(interp=2)), ("f65_agc", dict(interp=6, decim=5, amp=float(np.float32(10) ** (np.float32(37.5) / 20)), agc=True)),
-         ("f4_cr34", dict(interp=4, rate=3))]
+         ("f4_cr34", dict(interp=4, rate=3)), ("psk8_23", dict(interp=2, cstln=2, rate=1)), ("apsk16_34", dict(interp=3, cstln=3, rate=3)),
+         ("qpsk_23", dict(interp=2, rate=1))]   # rate: FEC12 0, FEC23 1, FEC46 2, FEC34 3 (dvb.h:38); cstln: sdr.h:340 predef order
 
 
 @pytest.mark.parametrize("name,kw", CASES)
@@ -16,6 +18,16 @@ def test_tx_chain_is_leandvbtx(oracle, name, kw):
     assert len(y) == int(g[name + "_n"])
     assert hashlib.sha256(y.tobytes()).digest() == bytes(g[name + "_sha"])
     assert bits_equal(y[:256], g[name + "_head"]) and bits_equal(y[-256:], g[name + "_tail"])
+
+
+def test_tx_s16_is_leandvbtx(oracle):
+    """leandvbtx --s16: cconverter<f32,0,int16_t,0,32768,1> after the chain (leandvbtx.cc:176-182)."""
+    g = gold("tx.npz")
+    amp = oracle.lib.lo_db_to_amp
+    amp.restype = po.c_f; amp.argtypes = [po.C.c_double]
+    y = oracle.cconv_f32_s16(oracle.tx_chain(g["ts"], interp=2, amp=amp(-30.0))).reshape(-1)
+    assert len(y) == int(g["s16_n"]) and hashlib.sha256(y.tobytes()).digest() == bytes(g["s16_sha"])
+    assert np.array_equal(y[:256], g["s16_head"])
 
 
 def test_tx_blocks_vs_ref(oracle, ref):
@@ -37,3 +49,6 @@ def test_tx_blocks_vs_ref(oracle, ref):
     ya, ea = oracle.simple_agc(x, 0.7, 0.01)
     yb, eb = ref.simple_agc(x, 0.7, 0.01)
     assert bits_equal(ya, yb) and ea == eb
+    with np.errstate(all="ignore"):
+        xs = po.chan_test_input(20000) * 0.01
+    assert np.array_equal(oracle.cconv_f32_s16(xs), ref.cconv_f32_s16(xs))
