@@ -15,7 +15,7 @@ typedef unsigned v2u __attribute__((ext_vector_type(2)));
 // VAR 5: coefficients staged in LDS, read with uniform-address ds_read_b128
 // VAR 6: coefficients held in 6 VGPRs (lane i%64 of register i/64), fetched with v_readlane
 template <int VAR, int PF>
-__global__ __launch_bounds__(256) void k(const float *rc, float2 *out, unsigned long long *cyc, float kc, const float2 *big, size_t nbig) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k(const float *rc, float2 *out, unsigned long long *cyc, float kc, const float2 *big, size_t nbig) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float2 *lds = reinterpret_cast<float2 *>(smem);
   const unsigned l = threadIdx.x;
@@ -37,6 +37,21 @@ __global__ __launch_bounds__(256) void k(const float *rc, float2 *out, unsigned 
       __builtin_amdgcn_sched_barrier(0);
     }
     cptr1 prc = (cptr1)rc;
+    if (VAR == 7) {   // two taps per ds_read_b128: rows interleaved in 16-byte units
+      for (int col = NCOL - 1; col >= 0; --col, prc += D) {
+        const float4 *px4 = reinterpret_cast<const float4 *>(lds) + l + (D / 2 - 1) * S + (unsigned)col;
+        float4 v[D / 2];
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) v[k] = px4[-k * S];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < D / 2; ++k) {
+          const float c0 = prc[2 * k], c1 = prc[2 * k + 1];
+          acc.x = acc.x + c0 * v[k].z; acc.y = acc.y + c0 * v[k].w;
+          acc.x = acc.x + c1 * v[k].x; acc.y = acc.y + c1 * v[k].y;
+        }
+      }
+    } else
     for (int col = NCOL - 1; col >= 0; --col, prc += D) {
       const float2 *px = lds + l + (D - 1) * S + (unsigned)col;
 #pragma unroll
@@ -91,6 +106,8 @@ int main() {
     run<5, 1>("coeffs in LDS + 32 loads in flight", grid, rc, out, cyc);
     run<6>("coeffs via v_readlane", grid, rc, out, cyc);
     run<6, 1>("coeffs via v_readlane + 32 loads in flight", grid, rc, out, cyc);
+    run<7>("s_load coeffs + ds_read_b128 (2 taps)", grid, rc, out, cyc);
+    run<7, 1>("ds_read_b128 (2 taps) + 32 loads in flight", grid, rc, out, cyc);
   }
   return 0;
 }
