@@ -423,15 +423,20 @@ int lsdr_drifter_run(lsdr_drifter *d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *
     g.step[i] = 0;
     if (!g.c[i].active) continue;
     any = true;
-    // closed form a_s = a_0 + s·⌊δ⌋ holds while a ≥ 0, δ ≥ 0 and every (double)a + δ is exact
+    // closed form a_s = a_0 + s·⌊δ⌋: the reference computes (long)((double)a + δ) per sample; with a ≥ 0, δ ≥ 0 and all sums
+    // below 2^52 the double sum is a + ⌊δ⌋ + frac(δ) rounded to a multiple of ulp ≤ 1/2, which truncates back to a + ⌊δ⌋
+    // unless frac(δ) is within ulp/2 of 1
     const double delta = d->c[i].freq * 4294967296.0;
-    bool ok = d->c[i].a >= 0 && delta >= 0 && delta < 0x1p52;
+    bool ok = d->c[i].a >= 0 && delta >= 0 && delta < 0x1p51;
     if (ok) {
-      int frac_bits = 0;
-      double t = delta;
-      while (t != floor(t) && frac_bits < 64) { t *= 2; ++frac_bits; }
-      const double fl = floor(delta), end = (double)d->c[i].a + ((double)n + 1) * (fl + 1);
-      ok = frac_bits < 52 && end < ldexp(1.0, 52 - frac_bits);
+      const double fl = floor(delta), frac = delta - fl, end = (double)d->c[i].a + ((double)n + 1) * (fl + 1);
+      ok = end < 0x1p52;
+      if (ok) {
+        int e = 0;
+        (void)frexp(end, &e);                                   // end < 2^e
+        const double ulp = ldexp(1.0, (e < 1 ? 1 : e) - 53);    // ulp of the largest sum of this call
+        ok = frac + ulp < 1.0;
+      }
       if (ok) g.step[i] = (long long)fl;
     }
     if (!ok) walk = true;

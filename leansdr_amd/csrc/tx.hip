@@ -130,16 +130,39 @@ __global__ __launch_bounds__(64) void k_agc_power(const float2 *in, unsigned lon
   for (int i = 0; i < 128; ++i) a += p[i].x * p[i].x + p[i].y * p[i].y;
   amp2[c] = a / 128;
 }
-// (2) the EMA over the chunks (one lane) → gain per chunk;
-__global__ void k_agc_gains(float *amp2_gain, unsigned long long nchunks, float *estimated, float out_rms, float bw) {
+// (2) the EMA over the chunks → gain per chunk.  The recurrence est ← est·(1−bw) + amp2·bw is a sequential float chain (its
+// rounding sequence is the reference's), so one wave walks it: 64 chunk powers are loaded at once (one per lane), the chain
+// runs on wave-uniform values fed by v_readlane (≈ 4 dependent VALU ops per chunk instead of a global-load round trip), every
+// lane keeps the estimate of its own chunk, and the 64 gains (sqrt, divide) are computed and stored in parallel.
+__global__ __launch_bounds__(64) void k_agc_gains(float *amp2_gain, unsigned long long nchunks, float *estimated, float out_rms, float bw) {
+  const unsigned lane = threadIdx.x;
   float est = *estimated;
-  for (unsigned long long c = 0; c < nchunks; ++c) {
-    const float a = amp2_gain[c];
-    if (!est) est = a;
-    est = est * (1 - bw) + a * bw;
-    amp2_gain[c] = est ? out_rms / __builtin_sqrtf(est) : 0.f;
+  const float keep = 1 - bw;
+  float nxt = lane < nchunks ? amp2_gain[lane] : 0.f;
+  for (unsigned long long c0 = 0; c0 < nchunks; c0 += 64) {
+    const float cur = nxt;
+    const unsigned long long cn = c0 + 64 + lane;
+    nxt = cn < nchunks ? amp2_gain[cn] : 0.f;          // next block's powers are in flight during this block's chain
+    const unsigned m = (unsigned)(nchunks - c0 < 64 ? nchunks - c0 : 64);
+    float mine = 0.f;
+    const float curbw = cur * bw;                      // the second product of every step, all 64 at once
+    if (est != 0.f) {
+      // est·keep + a·bw with est > 0 and a ≥ 0 cannot become 0 again: no "first chunk" test inside the chain
+      for (unsigned i = 0; i < m; ++i) {
+        est = est * keep + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(curbw), i));
+        if (lane == i) mine = est;
+      }
+    } else {
+      for (unsigned i = 0; i < m; ++i) {
+        const float a = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cur), i));
+        if (!est) est = a;
+        est = est * keep + a * bw;
+        if (lane == i) mine = est;
+      }
+    }
+    if (lane < m) amp2_gain[c0 + lane] = mine ? out_rms / __builtin_sqrtf(mine) : 0.f;
   }
-  *estimated = est;
+  if (lane == 0) *estimated = est;
 }
 // (3) out = in · gain[chunk]
 __global__ __launch_bounds__(256) void k_agc_apply(const float2 *in, unsigned long long n, const float *gain, float2 *out) {
@@ -389,7 +412,7 @@ int lsdr_simple_agc_run(lsdr_simple_agc *a, const lsdr_cf32 *in, size_t n_in, ls
     a->gain_cap = chunks;
   }
   hipLaunchKernelGGL(k_agc_power, dim3((unsigned)((chunks + 63) / 64)), dim3(64), 0, c->stream, (const float2 *)in, (unsigned long long)chunks, a->d_gain);
-  hipLaunchKernelGGL(k_agc_gains, dim3(1), dim3(1), 0, c->stream, a->d_gain, (unsigned long long)chunks, a->d_est, a->out_rms, a->bw);
+  hipLaunchKernelGGL(k_agc_gains, dim3(1), dim3(64), 0, c->stream, a->d_gain, (unsigned long long)chunks, a->d_est, a->out_rms, a->bw);
   hipLaunchKernelGGL(k_agc_apply, dim3(grid_for(c, chunks * 128)), dim3(256), 0, c->stream, (const float2 *)in, (unsigned long long)chunks * 128,
                      (const float *)a->d_gain, (float2 *)out);
   LSDR_HIP(hipGetLastError());

@@ -133,3 +133,18 @@ def test_generator_pipeline_on_gpu():
     sent = {bytes(r) for r in ts}
     bad = [i for i, r in enumerate(out) if bytes(r) not in sent]
     assert all(i < 8 for i in bad), bad[:20]       # only the packets before the derandomizer's first group start (the reference too)
+
+
+@pytest.mark.parametrize("freq,a0", [(1e-7, 2**40 + 12345), (1e-7, 2**50 + 7), (3.3e-5, 2**51 - 10**7), (1.0 - 2.0**-24, 2**49),
+                                     (3.3e-5, -5000000), (1e-7, 2**62)])
+def test_drifter_large_phase_words(capi, ctx, oracle, freq, a0):
+    """Component phase words far from zero: the closed-form advance (exact double sums, or rounding that cannot reach the
+    next integer), and the sequential pre-pass where it cannot be proved (negative, ≥ 2^52, fraction next to 1)."""
+    x = po.chan_test_input(30000)[8:]
+    amp, fr = (0.01, 0.0, 0.0), (float(np.float32(freq)), 0.0, 0.0)
+    d = capi.Drifter(ctx, amp, fr)
+    d.phases = (a0, 0, 0)
+    y = d.run(x, 4096)
+    ref, a = oracle.drifter(x, amp, fr, (a0, 0, 0), 4096)
+    assert bits_equal(y, ref) and d.phases == tuple(a)
+    d.close()
