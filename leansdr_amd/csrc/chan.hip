@@ -426,10 +426,13 @@ int lsdr_drifter_run(lsdr_drifter *d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *
     // closed form a_s = a_0 + s·⌊δ⌋: the reference computes (long)((double)a + δ) per sample; with a ≥ 0, δ ≥ 0 and all sums
     // below 2^52 the double sum is a + ⌊δ⌋ + frac(δ) rounded to a multiple of ulp ≤ 1/2, which truncates back to a + ⌊δ⌋
     // unless frac(δ) is within ulp/2 of 1
+    // (the conversion truncates toward zero, so a ≤ 0 with δ ≤ 0 is the mirror image: a_s = a_0 − s·⌊|δ|⌋)
     const double delta = d->c[i].freq * 4294967296.0;
-    bool ok = d->c[i].a >= 0 && delta >= 0 && delta < 0x1p51;
+    const bool neg = delta < 0 || (delta == 0 && d->c[i].a < 0);
+    const double ad = fabs(delta), aa = fabs((double)d->c[i].a);
+    bool ok = (neg ? d->c[i].a <= 0 : d->c[i].a >= 0) && ad < 0x1p51 && ad == ad;
     if (ok) {
-      const double fl = floor(delta), frac = delta - fl, end = (double)d->c[i].a + ((double)n + 1) * (fl + 1);
+      const double fl = floor(ad), frac = ad - fl, end = aa + ((double)n + 1) * (fl + 1);
       ok = end < 0x1p52;
       if (ok) {
         int e = 0;
@@ -437,7 +440,7 @@ int lsdr_drifter_run(lsdr_drifter *d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *
         const double ulp = ldexp(1.0, (e < 1 ? 1 : e) - 53);    // ulp of the largest sum of this call
         ok = frac + ulp < 1.0;
       }
-      if (ok) g.step[i] = (long long)fl;
+      if (ok) g.step[i] = neg ? -(long long)fl : (long long)fl;
     }
     if (!ok) walk = true;
   }

@@ -136,7 +136,7 @@ def test_generator_pipeline_on_gpu():
 
 
 @pytest.mark.parametrize("freq,a0", [(1e-7, 2**40 + 12345), (1e-7, 2**50 + 7), (3.3e-5, 2**51 - 10**7), (1.0 - 2.0**-24, 2**49),
-                                     (3.3e-5, -5000000), (1e-7, 2**62)])
+                                     (3.3e-5, -5000000), (1e-7, 2**62), (-1e-7, 0), (-3.3e-5, -2**45 - 3), (-1e-7, 77)])
 def test_drifter_large_phase_words(capi, ctx, oracle, freq, a0):
     """Component phase words far from zero: the closed-form advance (exact double sums, or rounding that cannot reach the
     next integer), and the sequential pre-pass where it cannot be proved (negative, ≥ 2^52, fraction next to 1)."""
