@@ -1,26 +1,23 @@
-// leansdr_amd/host/apps/leanchansim_amd.cc — the graph of leanchansim (src/apps/leanchansim.cc:120-176 of the reference) built
-// against the MI355X host framework: IQ on stdin → scaled, noisy, drifting IQ on stdout, every block on the GPU.
-// Same options: --iu8 | --if32, --ou8 | --of32, -f HZ, --loop, --scale K, --awgn DB, --deterministic,
-// --lo HZ, --ppm PPM, --drift-period S, --drift-rate R, --drift2-amp HZ, --drift2-freq HZ.
+// leansdr_amd/host/apps/leanchansim_amd.cc — channel simulator: IQ on stdin → scaled, noisy, drifting IQ on stdout, every
+// block on the GPU.  It is the graph of the reference's leanchansim (src/apps/leanchansim.cc:120-176) with the same options;
+// with --deterministic and stdin from a file the output bytes are the reference's (tests/test_gpu_chan.py).
 #include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
 #include <unistd.h>
 
+#include "cli.h"
 #include "leansdr/dsp.h"
-#include "leansdr/framework.h"
 #include "leansdr/generic.h"
 
 using namespace leansdr;
 
 typedef float f32;
 typedef complex<f32> cf32;
-typedef unsigned char u8;
 typedef complex<u8> cu8;
 
-// drifter<float> (leanchansim.cc:34-88).  The reference restarts its phase accumulator on every run(), i.e. every time its
-// 4096-sample pipes hand it a chunk; `chunk` keeps that cut whatever the size of the device pipes.
+// LO drift: up to three sinusoidal FM components (amplitude and rate in cycles per sample) on a 16-bit phase accumulator.
+// The reference's drifter (leanchansim.cc:34-88) keeps that accumulator in a local of run(), so its output depends on how
+// its 4096-sample pipes cut the stream; `chunk` reproduces that cut whatever the size of the device pipes: only whole
+// chunks are consumed, and a short remainder is flushed once a scheduler pass has brought nothing new (end of input).
 template <typename T>
 struct drifter;
 
@@ -28,153 +25,136 @@ template <>
 struct drifter<float> : runnable {
   static const int NCOMPONENTS = 3;
   struct component {
-    float amp;
-    float freq;
+    float amp, freq;
   } drifts[NCOMPONENTS];
   unsigned long chunk;
-  drifter(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o)
-      : runnable(sch, "drifter"), chunk(4096), ctx(pipe_ctx(i.dev, o.dev, "drifter: pipebufs must be device pipebufs of one ctx")), in(i),
-        out(o), h(NULL), stalled(0) {
-    memset(drifts, 0, sizeof(drifts));
-    lsdr_check(lsdr_drifter_create(ctx, &h), name);
+
+  drifter(scheduler *s, pipebuf<cf32> &src, pipebuf<cf32> &dst)
+      : runnable(s, "drifter"), chunk(4096), ctx_(pipe_ctx(src.dev, dst.dev, "drifter: pipebufs must be device pipebufs of one ctx")),
+        from_(src), to_(dst), handle_(NULL), seen_(0) {
+    for (int i = 0; i < NCOMPONENTS; ++i) drifts[i].amp = drifts[i].freq = 0;
+    lsdr_check(lsdr_drifter_create(ctx_, &handle_), name);
   }
   void run() {
-    unsigned long count = min(in.readable(), out.writable());
-    if (!count) return;
-    if (chunk && count >= chunk) count -= count % chunk;
-    else if (chunk && in.readable() != stalled) {   // a partial chunk: wait one scheduler pass for more input (only EOF leaves it)
-      stalled = in.readable();
-      return;
-    }
-    stalled = 0;
-    for (int i = 0; i < NCOMPONENTS; ++i) lsdr_check(lsdr_drifter_set_component(h, i, drifts[i].amp, drifts[i].freq), name);
-    lsdr_check(lsdr_drifter_run(h, (const lsdr_cf32 *)in.rd(), count, (lsdr_cf32 *)out.wr(), chunk), name);
-    in.read(count);
-    out.written(count);
+    unsigned long n = min(from_.readable(), to_.writable());
+    if (chunk && n >= chunk) n -= n % chunk;
+    else if (chunk && n && from_.readable() != seen_) { seen_ = from_.readable(); return; }
+    if (!n) return;
+    seen_ = 0;
+    for (int i = 0; i < NCOMPONENTS; ++i) lsdr_check(lsdr_drifter_set_component(handle_, i, drifts[i].amp, drifts[i].freq), name);
+    lsdr_check(lsdr_drifter_run(handle_, (const lsdr_cf32 *)from_.rd(), n, (lsdr_cf32 *)to_.wr(), chunk), name);
+    from_.read(n);
+    to_.written(n);
   }
 
  private:
-  lsdr_ctx *ctx;
-  pipereader<cf32> in;
-  pipewriter<cf32> out;
-  lsdr_drifter *h;
-  unsigned long stalled;
+  lsdr_ctx *ctx_;
+  pipereader<cf32> from_;
+  pipewriter<cf32> to_;
+  lsdr_drifter *handle_;
+  unsigned long seen_;
 };
 
-struct config {
-  bool loop_input;
-  enum { IO_F32, IO_U8 } input_format, output_format;
-  float scale, awgn;
-  bool deterministic;
-  float Fs, Flo, ppm, drift_period, drift_rate, drift2_amp, drift2_freq;
-  int device;
-  unsigned long buf;
-  config()
-      : loop_input(false), input_format(IO_F32), output_format(IO_F32), scale(1), awgn(0), deterministic(false), Fs(0), Flo(0), ppm(-1),
-        drift_period(0), drift_rate(0), drift2_amp(0), drift2_freq(0), device(0), buf(1 << 20) {}
+namespace {
+
+struct settings {
+  bool in_u8 = false, out_u8 = false, loop = false, deterministic = false;
+  float gain = 1, noise = 0;                    // --scale, --awgn (dB → standard deviation)
+  float rate = 0, lo = 0, ppm = -1;             // -f, --lo, --ppm
+  float period = 0, slope = 0;                  // --drift-period, --drift-rate
+  float amp2 = 0, freq2 = 0;                    // --drift2-amp, --drift2-freq
+  int device = 0;
+  unsigned long pipe = 1ul << 20;               // the reference: 4096 (a CPU cache); a GPU wants batches
 };
 
-static int run(config &cfg) {
-  scheduler sch;
-  lsdr_ctx *ctx = NULL;
-  lsdr_check(lsdr_ctx_create(cfg.device, NULL, &ctx), "lsdr_ctx_create");
-  const unsigned long BUF_BASEBAND = cfg.buf;   // the reference: 4096 (a CPU cache); a GPU wants batches
+template <typename T>
+pipebuf<T> &from_stdin(cli::graph &g, const settings &o) {
+  pipebuf<T> &host = g.host<T>("stdin", o.pipe);
+  (new file_reader<T>(&g.sch, 0, host))->loop = o.loop;
+  pipebuf<T> &dev = g.hbm<T>("stdin(dev)", o.pipe);
+  new h2d_copier<T>(&g.sch, g.ctx, host, dev);
+  return dev;
+}
+template <typename T>
+void to_stdout(cli::graph &g, const settings &o, pipebuf<T> &dev) {
+  pipebuf<T> &host = g.host<T>("stdout", o.pipe);
+  new d2h_copier<T>(&g.sch, g.ctx, dev, host);
+  new file_writer<T>(&g.sch, host, 1);
+}
 
-  pipebuf<cf32> *pipe = NULL;
-  if (cfg.input_format == config::IO_F32) {
-    pipebuf<cf32> *p_stdin = new pipebuf<cf32>(&sch, "stdin", BUF_BASEBAND);
-    file_reader<cf32> *r_stdin = new file_reader<cf32>(&sch, 0, *p_stdin);
-    r_stdin->loop = cfg.loop_input;
-    pipebuf<cf32> *p_dev = new pipebuf<cf32>(&sch, "stdin(dev)", BUF_BASEBAND, ctx);
-    new h2d_copier<cf32>(&sch, ctx, *p_stdin, *p_dev);
-    pipe = p_dev;
+void simulate(const settings &o) {
+  cli::graph g(o.device);
+  pipebuf<cf32> *x;
+  if (o.in_u8) {
+    x = &g.hbm<cf32>("stdinf", o.pipe);
+    new cconverter<u8, 128, f32, 0, 1, 1>(&g.sch, from_stdin<cu8>(g, o), *x);
   } else {
-    pipebuf<cu8> *p_stdin = new pipebuf<cu8>(&sch, "stdin", BUF_BASEBAND);
-    file_reader<cu8> *r_stdin = new file_reader<cu8>(&sch, 0, *p_stdin);
-    r_stdin->loop = cfg.loop_input;
-    pipebuf<cu8> *p_dev = new pipebuf<cu8>(&sch, "stdin(dev)", BUF_BASEBAND, ctx);
-    new h2d_copier<cu8>(&sch, ctx, *p_stdin, *p_dev);
-    pipebuf<cf32> *p_stdinf = new pipebuf<cf32>(&sch, "stdinf", BUF_BASEBAND, ctx);
-    new cconverter<u8, 128, f32, 0, 1, 1>(&sch, *p_dev, *p_stdinf);
-    pipe = p_stdinf;
+    x = &from_stdin<cf32>(g, o);
   }
 
-  pipebuf<cf32> p_scaled(&sch, "scaled", BUF_BASEBAND, ctx);
-  scaler<float, cf32, cf32> r_scale(&sch, cfg.scale, *pipe, p_scaled);
-  pipe = &p_scaled;
+  pipebuf<cf32> &scaled = g.hbm<cf32>("scaled", o.pipe);
+  new scaler<float, cf32, cf32>(&g.sch, o.gain, *x, scaled);
 
-  pipebuf<cf32> p_noise(&sch, "noise", BUF_BASEBAND, ctx);
-  wgn_c<f32> r_noise(&sch, p_noise);
-  if (!cfg.deterministic) r_noise.seed(getpid());   // leanchansim.cc:146-147
-  r_noise.stddev = cfg.awgn;
-  pipebuf<cf32> p_noisy(&sch, "noisy", BUF_BASEBAND, ctx);
-  adder<cf32> r_addnoise(&sch, *pipe, p_noise, p_noisy);
-  pipe = &p_noisy;
+  pipebuf<cf32> &noise = g.hbm<cf32>("noise", o.pipe);
+  wgn_c<f32> *gen = new wgn_c<f32>(&g.sch, noise);
+  gen->stddev = o.noise;
+  if (!o.deterministic) gen->seed(getpid());      // the reference seeds drand48 with its pid (leanchansim.cc:146-147)
+  pipebuf<cf32> &noisy = g.hbm<cf32>("noisy", o.pipe);
+  new adder<cf32>(&g.sch, scaled, noise, noisy);
 
-  pipebuf<cf32> p_drift(&sch, "drift", BUF_BASEBAND, ctx);
-  drifter<float> r_drift(&sch, *pipe, p_drift);
-  float maxoffs = cfg.Flo * cfg.ppm * 1e-6;
-  r_drift.drifts[0].amp = maxoffs / cfg.Fs;
-  if (cfg.drift_period && cfg.drift_rate) fail("Specify only one of --drift-rate and --drift-period");
-  if (cfg.drift_period) r_drift.drifts[0].freq = (1.0 / cfg.drift_period) / cfg.Fs;
-  if (cfg.drift_rate) {
-    if (!cfg.ppm) fail("Need --ppm with --drift-rate");
-    r_drift.drifts[0].freq = (cfg.drift_rate / (2 * M_PI * cfg.ppm)) / cfg.Fs;
+  pipebuf<cf32> &drifting = g.hbm<cf32>("drift", o.pipe);
+  drifter<float> *lo = new drifter<float>(&g.sch, noisy, drifting);
+  // component 0: ±ppm of the LO, swept with a period or a maximum rate; component 1: a secondary wobble.  The arithmetic
+  // (float fields, double constants) is the reference's, leanchansim.cc:155-170 — without -f it yields NaN, i.e. no drift.
+  const float max_offset = o.lo * o.ppm * 1e-6;
+  lo->drifts[0].amp = max_offset / o.rate;
+  if (o.period && o.slope) fail("Specify only one of --drift-rate and --drift-period");
+  if (o.period) lo->drifts[0].freq = (1.0 / o.period) / o.rate;
+  if (o.slope) {
+    if (!o.ppm) fail("Need --ppm with --drift-rate");
+    lo->drifts[0].freq = (o.slope / (2 * M_PI * o.ppm)) / o.rate;
   }
-  if (cfg.drift2_amp && cfg.drift2_freq) {
-    r_drift.drifts[1].amp = cfg.drift2_amp / cfg.Fs;
-    r_drift.drifts[1].freq = cfg.drift2_freq / cfg.Fs;
+  if (o.amp2 && o.freq2) {
+    lo->drifts[1].amp = o.amp2 / o.rate;
+    lo->drifts[1].freq = o.freq2 / o.rate;
   }
-  pipe = &p_drift;
 
-  if (cfg.output_format == config::IO_U8) {
-    pipebuf<cu8> *p_out = new pipebuf<cu8>(&sch, "stdout(dev)", BUF_BASEBAND, ctx);
-    new cconverter<f32, 0, u8, 128, 1, 1>(&sch, *pipe, *p_out);
-    pipebuf<cu8> *p_stdout = new pipebuf<cu8>(&sch, "stdout", BUF_BASEBAND);
-    new d2h_copier<cu8>(&sch, ctx, *p_out, *p_stdout);
-    new file_writer<cu8>(&sch, *p_stdout, 1);
+  if (o.out_u8) {
+    pipebuf<cu8> &bytes = g.hbm<cu8>("stdout(dev)", o.pipe);
+    new cconverter<f32, 0, u8, 128, 1, 1>(&g.sch, drifting, bytes);
+    to_stdout(g, o, bytes);
   } else {
-    pipebuf<cf32> *p_stdout = new pipebuf<cf32>(&sch, "stdout", BUF_BASEBAND);
-    new d2h_copier<cf32>(&sch, ctx, *pipe, *p_stdout);
-    new file_writer<cf32>(&sch, *p_stdout, 1);
+    to_stdout(g, o, drifting);
   }
+  g.run();
+}
 
-  sch.run();
-  sch.shutdown();
+}  // namespace
+
+int main(int argc, char **argv) {
+  settings o;
+  cli::parser p;
+  p.summary = "Simulate an imperfect channel on the GPU: IQ.in on stdin, IQ.out on stdout (leanchansim on MI355X).";
+  p.options = {
+      {"--iu8", NULL, "stdin is complex unsigned char", [&](const char *) { o.in_u8 = true; }},
+      {"--if32", NULL, "stdin is complex float (default)", [&](const char *) { o.in_u8 = false; }},
+      {"-f", "HZ", "sample rate", [&](const char *a) { o.rate = atof(a); }},
+      {"--loop", NULL, "repeat (stdin must be a file)", [&](const char *) { o.loop = true; }},
+      {"--scale", "FACTOR", "multiply by a constant", [&](const char *a) { o.gain = atof(a); }},
+      {"--awgn", "DB", "add white gaussian noise of this standard deviation", [&](const char *a) { o.noise = cli::db_to_amplitude(a); }},
+      {"--deterministic", NULL, "do not seed the noise generator", [&](const char *) { o.deterministic = true; }},
+      {"--lo", "HZ", "nominal LO frequency", [&](const char *a) { o.lo = atof(a); }},
+      {"--ppm", "PPM", "LO accuracy", [&](const char *a) { o.ppm = atof(a); }},
+      {"--drift-period", "S", "drift +-ppm every S seconds", [&](const char *a) { o.period = atof(a); }},
+      {"--drift-rate", "R", "drift with maximum rate R (Hz/s)", [&](const char *a) { o.slope = atof(a); }},
+      {"--drift2-amp", "HZ", "secondary drift, range", [&](const char *a) { o.amp2 = atof(a); }},
+      {"--drift2-freq", "HZ", "secondary drift, rate", [&](const char *a) { o.freq2 = atof(a); }},
+      {"--ou8", NULL, "stdout is complex unsigned char", [&](const char *) { o.out_u8 = true; }},
+      {"--of32", NULL, "stdout is complex float (default)", [&](const char *) { o.out_u8 = false; }},
+      {"--device", "N", "GPU index", [&](const char *a) { o.device = atoi(a); }},
+      {"--buf", "SAMPLES", "pipe size (default 1 Mi)", [&](const char *a) { o.pipe = strtoul(a, NULL, 0); }},
+  };
+  p.parse(argc, argv);
+  simulate(o);
   return 0;
-}
-
-static void usage(const char *name, FILE *f, int c) {
-  fprintf(f, "Usage: %s [options]  < IQ.in  > IQ.out\n", name);
-  fprintf(f, "Simulate an imperfect communication channel on the GPU (leanchansim on MI355X).\n"
-             "  --iu8 | --if32 | -f HZ | --loop | --scale K | --awgn DB | --deterministic\n"
-             "  --lo HZ | --ppm PPM | --drift-period S | --drift-rate R | --drift2-amp HZ | --drift2-freq HZ\n"
-             "  --ou8 | --of32 | --device N | --buf SAMPLES\n");
-  exit(c);
-}
-
-int main(int argc, char *argv[]) {
-  config cfg;
-  for (int i = 1; i < argc; ++i) {
-    if (!strcmp(argv[i], "-h")) usage(argv[0], stdout, 0);
-    else if (!strcmp(argv[i], "--iu8")) cfg.input_format = config::IO_U8;
-    else if (!strcmp(argv[i], "--if32")) cfg.input_format = config::IO_F32;
-    else if (!strcmp(argv[i], "--loop")) cfg.loop_input = true;
-    else if (!strcmp(argv[i], "--ou8")) cfg.output_format = config::IO_U8;
-    else if (!strcmp(argv[i], "--of32")) cfg.output_format = config::IO_F32;
-    else if (!strcmp(argv[i], "-f") && i + 1 < argc) cfg.Fs = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--scale") && i + 1 < argc) cfg.scale = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--awgn") && i + 1 < argc) cfg.awgn = expf(logf(10) * atof(argv[++i]) / 20);
-    else if (!strcmp(argv[i], "--deterministic")) cfg.deterministic = true;
-    else if (!strcmp(argv[i], "--lo") && i + 1 < argc) cfg.Flo = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--ppm") && i + 1 < argc) cfg.ppm = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--drift-period") && i + 1 < argc) cfg.drift_period = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--drift-rate") && i + 1 < argc) cfg.drift_rate = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--drift2-amp") && i + 1 < argc) cfg.drift2_amp = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--drift2-freq") && i + 1 < argc) cfg.drift2_freq = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--device") && i + 1 < argc) cfg.device = atoi(argv[++i]);
-    else if (!strcmp(argv[i], "--buf") && i + 1 < argc) cfg.buf = strtoul(argv[++i], NULL, 0);
-    else usage(argv[0], stderr, 1);
-  }
-  return run(cfg);
 }

@@ -1,160 +1,133 @@
-// leansdr_amd/host/apps/leandvbtx_amd.cc — the graph of leandvbtx (src/apps/leandvbtx.cc:79-197 of the reference) built
-// against the MI355X host framework: TS packets on stdin → cf32 (or s16) baseband on stdout, every block on the GPU.
-// Same options: --cr N/D, --const NAME, -f INTERP[/DECIM], --roll-off R, --rrc-rej, --power DB, --agc, --f32 | --s16, --fill, -v, -d.
+// leansdr_amd/host/apps/leandvbtx_amd.cc — DVB-S modulator: MPEG-TS packets on stdin → baseband IQ on stdout, every block
+// on the GPU.  It is the graph of the reference's leandvbtx (src/apps/leandvbtx.cc:79-197) with the same options and, for
+// the same input, the same output bytes (tests/test_gpu_tx.py); pipes are sized for GPU batches instead of a CPU cache.
 #include <math.h>
-#include <stdio.h>
-#include <stdlib.h>
-#include <string.h>
 
+#include "cli.h"
 #include "leansdr/dsp.h"
 #include "leansdr/dvb.h"
 #include "leansdr/filtergen.h"
-#include "leansdr/framework.h"
 #include "leansdr/generic.h"
 #include "leansdr/sdr.h"
 
 using namespace leansdr;
 
-struct config {
-  cstln_lut<256>::predef constellation;
-  code_rate fec;
-  float amp;
-  bool agc;
-  int interp, decim;
-  float rolloff, rrc_rej;
-  enum { OUTPUT_F32, OUTPUT_S16 } output_format;
-  bool fill;
-  bool verbose, debug;
-  int device;
-  config() : constellation(cstln_lut<256>::QPSK), fec(FEC12), amp(1.0), agc(false), interp(2), decim(1), rolloff(0.35), rrc_rej(10),
-             output_format(OUTPUT_F32), fill(false), verbose(false), debug(false), device(0) {}
+namespace {
+
+struct settings {
+  cstln_lut<256>::predef constellation = cstln_lut<256>::QPSK;
+  code_rate rate = FEC12;
+  float amplitude = 1.0f;     // RMS constellation amplitude (--power, dB)
+  bool agc = false;
+  int up = 2, down = 1;       // -f UP[/DOWN]
+  float rolloff = 0.35f, rrc_rej = 10.0f;
+  bool s16 = false, realtime = false, verbose = false, debug = false;
+  int device = 0;
 };
 
-static int log2i(int x) { int n = -1; for (; x; ++n, x >>= 1); return n; }
+void modulate(const settings &o) {
+  cli::graph g(o.device);
+  g.sch.verbose = o.verbose;
+  g.sch.debug = o.debug;
+  const unsigned long packets = 12 * 512, bytes = packets * SIZE_RSPACKET, symbols = bytes * 16;   // worst case BPSK 1/2
+  const unsigned long samples = symbols * o.up;
 
-static void run(config &cfg) {
-  scheduler sch;
-  sch.verbose = cfg.verbose;
-  sch.debug = cfg.debug;
-  lsdr_ctx *ctx = NULL;
-  lsdr_check(lsdr_ctx_create(cfg.device, NULL, &ctx), "lsdr_ctx_create");
-  // The reference sizes its pipes for a CPU (12·2 packets); a GPU wants batches.
-  const unsigned long bf = 512;
-  unsigned long BUF_PACKETS = 12 * bf, BUF_BYTES = SIZE_RSPACKET * BUF_PACKETS, BUF_SYMBOLS = BUF_BYTES * 8 * 2;
+  // stdin → HBM
+  pipebuf<tspacket> &ts_host = g.host<tspacket>("TS packets(host)", packets);
+  file_reader<tspacket> *source = new file_reader<tspacket>(&g.sch, 0, ts_host);
+  pipebuf<tspacket> &ts = g.hbm<tspacket>("TS packets", packets);
+  new h2d_copier<tspacket>(&g.sch, g.ctx, ts_host, ts);
 
-  pipebuf<tspacket> p_stdin(&sch, "TS packets(host)", BUF_PACKETS);
-  file_reader<tspacket> r_stdin(&sch, 0, p_stdin);
-  pipebuf<tspacket> p_tspackets(&sch, "TS packets", BUF_PACKETS, ctx);
-  h2d_copier<tspacket> r_h2d(&sch, ctx, p_stdin, p_tspackets);
-  pipebuf<tspacket> p_rtspackets(&sch, "rand TS packets", BUF_PACKETS, ctx);
-  randomizer r_rand(&sch, p_tspackets, p_rtspackets);
-  pipebuf<rspacket<u8> > p_rspackets(&sch, "RS-enc packets", BUF_PACKETS, ctx);
-  rs_encoder r_rsenc(&sch, p_rtspackets, p_rspackets);
-  pipebuf<u8> p_mpegbytes(&sch, "mpegbytes", BUF_BYTES, ctx);
-  interleaver r_inter(&sch, p_rspackets, p_mpegbytes);
+  // outer code
+  pipebuf<tspacket> &scrambled = g.hbm<tspacket>("rand TS packets", packets);
+  new randomizer(&g.sch, ts, scrambled);
+  pipebuf<rspacket<u8> > &coded = g.hbm<rspacket<u8> >("RS-enc packets", packets);
+  new rs_encoder(&g.sch, scrambled, coded);
+  pipebuf<u8> &interleaved = g.hbm<u8>("mpegbytes", bytes);
+  new interleaver(&g.sch, coded, interleaved);
 
-  cstln_lut<256> *cstln = make_dvbs2_constellation(cfg.constellation, cfg.fec);
-  int bits_per_symbol = log2i(cstln->nsymbols);
-  if (cfg.fec == FEC23 && (cstln->nsymbols == 4 || cstln->nsymbols == 64)) cfg.fec = FEC46;   // leandvbtx.cc:117-121
-  pipebuf<u8> p_symbols(&sch, "symbols", BUF_SYMBOLS, ctx);
-  dvb_convol r_convol(&sch, p_mpegbytes, p_symbols, cfg.fec, bits_per_symbol);
-  pipebuf<cf32> p_iqsymbols(&sch, "IQ symbols", BUF_SYMBOLS, ctx);
-  cstln_transmitter<f32, 0> r_mod(&sch, p_symbols, p_iqsymbols);
-  r_mod.cstln = cstln;
+  // inner code and mapping.  The constellation is built for the rate the user asked for; rate 2/3 on a constellation
+  // whose label width does not divide 3 coded bits runs on the equivalent 4/6 code (leandvbtx.cc:117-121).
+  cstln_lut<256> *points = make_dvbs2_constellation(o.constellation, o.rate);
+  const int label_bits = log2i(points->nsymbols);
+  const code_rate inner = (o.rate == FEC23 && (points->nsymbols == 4 || points->nsymbols == 64)) ? FEC46 : o.rate;
+  pipebuf<u8> &labels = g.hbm<u8>("symbols", symbols);
+  new dvb_convol(&g.sch, interleaved, labels, inner, label_bits);
+  pipebuf<cf32> &mapped = g.hbm<cf32>("IQ symbols", symbols);
+  (new cstln_transmitter<f32, 0>(&g.sch, labels, mapped))->cstln = points;
 
-  float Fm = 1.0 / cfg.interp;
-  int order = cfg.interp * cfg.rrc_rej;
-  float *coeffs;
-  int ncoeffs = filtergen::root_raised_cosine(order, Fm, cfg.rolloff, &coeffs);
-  filtergen::normalize_power(ncoeffs, coeffs, cfg.amp / cstln_amp);
-  if (sch.verbose) fprintf(stderr, "Interpolation: ratio %d/%d, rolloff %f, %d coeffs\n", cfg.interp, cfg.decim, cfg.rolloff, ncoeffs);
-  pipebuf<cf32> p_interp(&sch, "interpolated", BUF_SYMBOLS * cfg.interp, ctx);
-  fir_resampler<cf32, float> r_resampler(&sch, ncoeffs, coeffs, p_iqsymbols, p_interp, cfg.interp, 1);
-  pipebuf<cf32> p_resampled(&sch, "resampled", BUF_SYMBOLS * cfg.interp, ctx);
-  decimator<cf32> r_decim(&sch, cfg.decim, p_interp, p_resampled);
-  pipebuf<cf32> *tail = &p_resampled;
-  if (cfg.agc) {
-    pipebuf<cf32> *p_agc = new pipebuf<cf32>(&sch, "AGC", BUF_SYMBOLS * cfg.interp, ctx);
-    simple_agc<f32> *r_agc = new simple_agc<f32>(&sch, *tail, *p_agc);
-    r_agc->out_rms = cfg.amp / sqrtf((float)cfg.interp / cfg.decim);
-    r_agc->bw = 0.001 * cfg.decim / cfg.interp;
-    tail = p_agc;
+  // pulse shaping: root raised cosine at UP samples per symbol, scaled so that the output RMS is about `amplitude`
+  float *taps = NULL;
+  const int ntaps = filtergen::root_raised_cosine((int)(o.up * o.rrc_rej), (float)(1.0 / o.up), o.rolloff, &taps);
+  filtergen::normalize_power(ntaps, taps, o.amplitude / cstln_amp);
+  if (o.verbose) fprintf(stderr, "Interpolation: ratio %d/%d, rolloff %f, %d coeffs\n", o.up, o.down, o.rolloff, ntaps);
+  pipebuf<cf32> &shaped = g.hbm<cf32>("interpolated", samples);
+  new fir_resampler<cf32, float>(&g.sch, ntaps, taps, mapped, shaped, o.up, 1);
+  pipebuf<cf32> *baseband = &g.hbm<cf32>("resampled", samples);
+  new decimator<cf32>(&g.sch, o.down, shaped, *baseband);
+  if (o.agc) {
+    pipebuf<cf32> &levelled = g.hbm<cf32>("AGC", samples);
+    simple_agc<f32> *agc = new simple_agc<f32>(&g.sch, *baseband, levelled);
+    agc->out_rms = o.amplitude / sqrtf((float)o.up / o.down);
+    agc->bw = 0.001 * o.down / o.up;            // slower loop for large interpolation ratios
+    baseband = &levelled;
   }
-  if (cfg.output_format == config::OUTPUT_F32) {
-    pipebuf<cf32> *p_host = new pipebuf<cf32>(&sch, "baseband(host)", BUF_SYMBOLS * cfg.interp);
-    new d2h_copier<cf32>(&sch, ctx, *tail, *p_host);
-    new file_writer<cf32>(&sch, *p_host, 1);
-  } else {   // leandvbtx.cc:176-182
+
+  // HBM → stdout
+  if (o.s16) {
     typedef complex<int16_t> cs16;
-    pipebuf<cs16> *p_s16 = new pipebuf<cs16>(&sch, "stdout(dev)", BUF_SYMBOLS * cfg.interp, ctx);
-    new cconverter<f32, 0, int16_t, 0, 32768, 1>(&sch, *tail, *p_s16);
-    pipebuf<cs16> *p_host = new pipebuf<cs16>(&sch, "stdout", BUF_SYMBOLS * cfg.interp);
-    new d2h_copier<cs16>(&sch, ctx, *p_s16, *p_host);
-    new file_writer<cs16>(&sch, *p_host, 1);
+    pipebuf<cs16> &fixed = g.hbm<cs16>("stdout(dev)", samples);
+    new cconverter<f32, 0, int16_t, 0, 32768, 1>(&g.sch, *baseband, fixed);
+    pipebuf<cs16> &out = g.host<cs16>("stdout", samples);
+    new d2h_copier<cs16>(&g.sch, g.ctx, fixed, out);
+    new file_writer<cs16>(&g.sch, out, 1);
+  } else {
+    pipebuf<cf32> &out = g.host<cf32>("baseband(host)", samples);
+    new d2h_copier<cf32>(&g.sch, g.ctx, *baseband, out);
+    new file_writer<cf32>(&g.sch, out, 1);
   }
-  if (cfg.fill) {   // leandvbtx.cc:187-193
-    if (cfg.verbose) fprintf(stderr, "Realtime mode\n");
-    tspacket blank;
-    memset(blank.data, 0, 188);
-    blank.data[0] = 0x47;
-    r_stdin.set_realtime(blank);
+  if (o.realtime) {                               // --fill: null packets while stdin has nothing
+    if (o.verbose) fprintf(stderr, "Realtime mode\n");
+    tspacket idle;
+    memset(idle.data, 0, sizeof(idle.data));
+    idle.data[0] = 0x47;
+    source->set_realtime(idle);
   }
-
-  sch.run();
-  sch.shutdown();
-  if (sch.verbose) sch.dump();
-  lsdr_ctx_destroy(ctx);
+  g.run();
 }
 
-static void usage(const char *name, FILE *f, int c) {
-  fprintf(f, "Usage: %s [options]  < TS  > IQ\n", name);
-  fprintf(f, "Modulate MPEG packets into a DVB-S baseband signal on the GPU (leandvbtx on MI355X)\n"
-             "  --cr N/D | --const NAME | -f INTERP[/DECIM] | --roll-off R | --rrc-rej N | --power DB | --agc\n"
-             "  --f32 | --s16 | --fill | --device N | -v | -d\n");
-  exit(c);
-}
+}  // namespace
 
-int main(int argc, char *argv[]) {
-  config cfg;
-  for (int i = 1; i < argc; ++i) {
-    if (!strcmp(argv[i], "-h")) usage(argv[0], stdout, 0);
-    else if (!strcmp(argv[i], "-v")) cfg.verbose = true;
-    else if (!strcmp(argv[i], "-d")) cfg.debug = true;
-    else if (!strcmp(argv[i], "--cr") && i + 1 < argc) {
-      ++i;
-      if (!strcmp(argv[i], "1/2")) cfg.fec = FEC12;
-      else if (!strcmp(argv[i], "2/3")) cfg.fec = FEC23;
-      else if (!strcmp(argv[i], "3/4")) cfg.fec = FEC34;
-      else if (!strcmp(argv[i], "5/6")) cfg.fec = FEC56;
-      else if (!strcmp(argv[i], "7/8")) cfg.fec = FEC78;
-      else if (!strcmp(argv[i], "4/5")) cfg.fec = FEC45;
-      else if (!strcmp(argv[i], "8/9")) cfg.fec = FEC89;
-      else if (!strcmp(argv[i], "9/10")) cfg.fec = FEC910;
-      else usage(argv[0], stderr, 1);
-    } else if (!strcmp(argv[i], "--const") && i + 1 < argc) {
-      ++i;
-      static const struct { const char *n; cstln_lut<256>::predef v; } tab[] = {
-          {"BPSK", cstln_lut<256>::BPSK}, {"QPSK", cstln_lut<256>::QPSK}, {"8PSK", cstln_lut<256>::PSK8},
-          {"16APSK", cstln_lut<256>::APSK16}, {"32APSK", cstln_lut<256>::APSK32}, {"64APSKe", cstln_lut<256>::APSK64E},
-          {"16QAM", cstln_lut<256>::QAM16}, {"64QAM", cstln_lut<256>::QAM64}, {"256QAM", cstln_lut<256>::QAM256}};
-      bool ok = false;
-      for (auto &t : tab) if (!strcmp(argv[i], t.n)) { cfg.constellation = t.v; ok = true; }
-      if (!ok) usage(argv[0], stderr, 1);
-    } else if (!strcmp(argv[i], "-f") && i + 1 < argc) {
-      ++i;
-      cfg.decim = 1;
-      if (sscanf(argv[i], "%d/%d", &cfg.interp, &cfg.decim) < 1) usage(argv[0], stderr, 1);
-    } else if (!strcmp(argv[i], "--roll-off") && i + 1 < argc) cfg.rolloff = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--rrc-rej") && i + 1 < argc) cfg.rrc_rej = atof(argv[++i]);
-    else if (!strcmp(argv[i], "--power") && i + 1 < argc) cfg.amp = expf(logf(10) * atof(argv[++i]) / 20);
-    else if (!strcmp(argv[i], "--agc")) cfg.agc = true;
-    else if (!strcmp(argv[i], "--f32")) cfg.output_format = config::OUTPUT_F32;
-    else if (!strcmp(argv[i], "--s16")) cfg.output_format = config::OUTPUT_S16;
-    else if (!strcmp(argv[i], "--fill")) cfg.fill = true;
-    else if (!strcmp(argv[i], "--version")) { printf("leansdr_amd\n"); exit(0); }
-    else if (!strcmp(argv[i], "--device") && i + 1 < argc) cfg.device = atoi(argv[++i]);
-    else usage(argv[0], stderr, 1);
-  }
-  run(cfg);
+int main(int argc, char **argv) {
+  settings o;
+  static const cli::named<code_rate> rates[] = {{"1/2", FEC12}, {"2/3", FEC23}, {"3/4", FEC34}, {"5/6", FEC56}, {"7/8", FEC78},
+                                                {"4/5", FEC45}, {"8/9", FEC89}, {"9/10", FEC910}};
+  static const cli::named<cstln_lut<256>::predef> constellations[] = {
+      {"BPSK", cstln_lut<256>::BPSK},       {"QPSK", cstln_lut<256>::QPSK},       {"8PSK", cstln_lut<256>::PSK8},
+      {"16APSK", cstln_lut<256>::APSK16},   {"32APSK", cstln_lut<256>::APSK32},   {"64APSKe", cstln_lut<256>::APSK64E},
+      {"16QAM", cstln_lut<256>::QAM16},     {"64QAM", cstln_lut<256>::QAM64},     {"256QAM", cstln_lut<256>::QAM256}};
+  cli::parser p;
+  p.summary = "Modulate MPEG packets from stdin into a DVB-S baseband signal on stdout (leandvbtx on MI355X).";
+  auto bad = [&]() { p.usage(argv[0], stderr, 1); };
+  p.options = {
+      {"--cr", "N/D", "code rate (default 1/2)", [&](const char *a) { if (!cli::pick(a, rates, &o.rate)) bad(); }},
+      {"--const", "NAME", "constellation: BPSK QPSK 8PSK 16APSK 32APSK 64APSKe 16QAM 64QAM 256QAM",
+       [&](const char *a) { if (!cli::pick(a, constellations, &o.constellation)) bad(); }},
+      {"-f", "UP[/DOWN]", "samples per symbol (default 2)",
+       [&](const char *a) { o.down = 1; if (sscanf(a, "%d/%d", &o.up, &o.down) < 1) bad(); }},
+      {"--roll-off", "R", "RRC roll-off (default 0.35)", [&](const char *a) { o.rolloff = atof(a); }},
+      {"--rrc-rej", "N", "RRC filter length in symbols (default 10)", [&](const char *a) { o.rrc_rej = atof(a); }},
+      {"--power", "DB", "output power (default 0 dB)", [&](const char *a) { o.amplitude = cli::db_to_amplitude(a); }},
+      {"--agc", NULL, "regulate the output power", [&](const char *) { o.agc = true; }},
+      {"--f32", NULL, "output complex float (default)", [&](const char *) { o.s16 = false; }},
+      {"--s16", NULL, "output complex int16", [&](const char *) { o.s16 = true; }},
+      {"--fill", NULL, "insert null packets when stdin starves", [&](const char *) { o.realtime = true; }},
+      {"--device", "N", "GPU index", [&](const char *a) { o.device = atoi(a); }},
+      {"-v", NULL, "verbose", [&](const char *) { o.verbose = true; }},
+      {"-d", NULL, "debug", [&](const char *) { o.debug = true; }},
+      {"--version", NULL, "print the version", [&](const char *) { printf("%s\n", VERSION); exit(0); }},
+  };
+  p.parse(argc, argv);
+  modulate(o);
   return 0;
 }

@@ -1,17 +1,19 @@
-// leansdr_amd/host/leansdr/framework.h — host-side data-flow runtime.
+// leansdr_amd/host/leansdr/framework.h — host-side data-flow runtime of the MI355X build.
 //
-// Same public surface as the reference's framework.h (scheduler, runnable,
-// pipebuf, pipewriter, pipereader, opt_* helpers, fail/fatal, u8…s32), written
-// from scratch, so that a leandvb-shaped flow graph compiles against it
-// unchanged.  Semantics follow framework.h:45-249:
-//   * pipebuf is a LINEAR multi-reader FIFO; readers always see contiguous
-//     memory; when fewer than min_write slots remain the unread span is moved
-//     to the front (pack);
-//   * the scheduler runs every runnable once per step, in construction order,
-//     until a whole step moves no pipe counter (fixpoint = end of input).
-// Addition: a pipebuf may live in MI355X HBM (pipebuf(sch, name, size, ctx)).
-// Device pipebufs are read/written only by GPU-backed blocks and by the
-// h2d/d2h bridges in generic.h; pack() is then a stream-ordered device copy.
+// What a leandvb-shaped graph builder needs from the reference's framework.h is its vocabulary:
+//   scheduler{verbose, debug, run(), shutdown(), dump()}, runnable(sch, name){run(), shutdown()},
+//   pipebuf<T>(sch, name, size), pipewriter<T>(buf, min_write){writable(), wr(), written(n), write(v)},
+//   pipereader<T>(buf){readable(), rd(), read(n)}, opt_writer/opt_writable/opt_write, fail()/fatal(), u8 … s32.
+// This file provides that vocabulary on its own implementation: pipes are cursor-based (one write index, one read index
+// per attached reader, storage compacted on demand), the scheduler keeps its blocks and pipes in vectors, and — the
+// reason the file exists — a pipe may live in MI355X HBM: pipebuf(sch, name, size, ctx).  Device pipes are touched only by
+// GPU-backed blocks and by the h2d/d2h bridges of generic.h; compaction is then a stream-ordered device copy.
+//
+// Behaviour that graphs rely on (checked against framework.h:45-249 by the app-level golden tests):
+//   * readers always see one contiguous span; a writer that finds less tail room than the largest min_write of the
+//     pipe's writers triggers compaction of the unread span to the front; a pipe nobody reads never fills up;
+//   * the scheduler calls every block once per pass, in construction order, and stops after the first pass in which
+//     no pipe moved (its fingerprint weighs pipe i by i+1) — end of input is a fixpoint, not an event.
 #ifndef LEANSDR_AMD_FRAMEWORK_H
 #define LEANSDR_AMD_FRAMEWORK_H
 
@@ -21,6 +23,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <vector>
+
 #include "lsdr_hip.h"
 
 #ifndef VERSION
@@ -29,246 +33,233 @@
 
 namespace leansdr {
 
-// Error convention of the reference: no exceptions, no return codes — a fatal
-// condition prints and exits (framework.h:32-33).
-inline void fatal(const char *s) { perror(s); exit(1); }
-inline void fail(const char *s) { fprintf(stderr, "** %s\n", s); exit(1); }
-// C-ABI status → fail(), as include/lsdr_hip.h prescribes for the shim blocks.
-inline void lsdr_check(int rc, const char *where) {
-  if (rc != 0) {
-    fprintf(stderr, "** %s: lsdr error %d: %s\n", where, rc, lsdr_last_error());
-    exit(1);
-  }
+typedef unsigned char u8;
+typedef unsigned short u16;
+typedef unsigned long u32;   // 8 bytes on x86-64, like the reference's (graphs carry pipebuf<u32> lock times)
+typedef signed char s8;
+typedef signed short s16;
+typedef signed long s32;
+
+// ---- errors: print and leave, no exceptions, no status codes ------------------------------------------------------
+inline void fail(const char *what) {
+  fprintf(stderr, "** %s\n", what);
+  exit(1);
+}
+inline void fatal(const char *syscall) {
+  perror(syscall);
+  exit(1);
+}
+inline void lsdr_check(int status, const char *where) {   // C-ABI status → fail(), as include/lsdr_hip.h prescribes
+  if (status == 0) return;
+  fprintf(stderr, "** %s: lsdr error %d: %s\n", where, status, lsdr_last_error());
+  exit(1);
 }
 
-static const int MAX_PIPES = 64;
-static const int MAX_RUNNABLES = 64;
-static const int MAX_READERS = 8;
+template <typename T>
+T min(const T &a, const T &b) { return b < a ? b : a; }
+template <typename T>
+T max(const T &a, const T &b) { return a < b ? b : a; }
 
-struct pipebuf_common {
+inline float gen_abs(float v) { return fabsf(v); }
+inline int gen_abs(int v) { return abs(v); }
+inline long int gen_abs(long int v) { return labs(v); }
+inline float gen_sqrt(float v) { return sqrtf(v); }
+inline unsigned int gen_sqrt(unsigned int v) { return sqrtl(v); }
+inline long double gen_sqrt(long double v) { return sqrtl(v); }
+inline float gen_hypot(float a, float b) { return hypotf(a, b); }
+inline long double gen_hypot(long double a, long double b) { return hypotl(a, b); }
+inline float gen_atan2(float y, float x) { return atan2f(y, x); }
+inline long double gen_atan2(long double y, long double x) { return atan2l(y, x); }
+
+struct window_placement {   // --gui layout table entry (name == NULL ends a table); kept for option compatibility
   const char *name;
-  explicit pipebuf_common(const char *n) : name(n) {}
-  virtual ~pipebuf_common() {}
-  virtual int sizeofT() { return 0; }
-  virtual long long hash() { return 0; }
-  virtual void dump(size_t *total_bufs) { (void)total_bufs; }
-};
-
-struct runnable_common {
-  const char *name;
-  explicit runnable_common(const char *n) : name(n) {}
-  virtual ~runnable_common() {}
-  virtual void run() {}
-  virtual void shutdown() {}
-};
-
-struct window_placement {
-  const char *name;  // NULL terminates a table
   int x, y, w, h;
 };
 
+struct scheduler;
+
+namespace detail {
+// What the scheduler needs to know about a pipe and a block.
+struct pipe_base {
+  const char *name;
+  explicit pipe_base(const char *n) : name(n) {}
+  virtual ~pipe_base() {}
+  virtual unsigned long long traffic() const = 0;   // items written + items read so far
+  virtual size_t bytes() const = 0;
+  virtual void describe(FILE *f) const = 0;
+};
+struct block_base {
+  const char *name;
+  explicit block_base(const char *n) : name(n) {}
+  virtual ~block_base() {}
+  virtual void run() {}
+  virtual void shutdown() {}
+};
+}  // namespace detail
+
 struct scheduler {
-  pipebuf_common *pipes[MAX_PIPES];
-  int npipes;
-  runnable_common *runnables[MAX_RUNNABLES];
-  int nrunnables;
-  window_placement *windows;
   bool verbose, debug;
+  window_placement *windows;
+  scheduler() : verbose(false), debug(false), windows(NULL) {}
 
-  scheduler() : npipes(0), nrunnables(0), windows(NULL), verbose(false), debug(false) {}
+  void attach(detail::pipe_base *p) { pipes_.push_back(p); }
+  void attach(detail::block_base *b) { blocks_.push_back(b); }
 
-  void add_pipe(pipebuf_common *p) {
-    if (npipes == MAX_PIPES) fail("MAX_PIPES");
-    pipes[npipes++] = p;
-  }
-  void add_runnable(runnable_common *r) {
-    if (nrunnables == MAX_RUNNABLES) fail("MAX_RUNNABLES");
-    runnables[nrunnables++] = r;
-  }
-  // One pass over all blocks, construction order.
   void step() {
-    for (int i = 0; i < nrunnables; ++i) runnables[i]->run();
+    for (size_t i = 0; i < blocks_.size(); ++i) blocks_[i]->run();
   }
-  // Progress fingerprint: pipe i contributes (1+i)·(items written + items read).
-  unsigned long long hash() {
-    unsigned long long h = 0;
-    for (int i = 0; i < npipes; ++i) h += (unsigned long long)(1 + i) * pipes[i]->hash();
-    return h;
-  }
-  // Run to the fixpoint: stop after the first step that moved nothing.
   void run() {
-    unsigned long long before = 0;
-    for (;;) {
+    unsigned long long last = fingerprint();
+    do {
       step();
-      unsigned long long now = hash();
-      if (now == before) return;
-      before = now;
-    }
+    } while (moved(&last));
   }
   void shutdown() {
-    for (int i = 0; i < nrunnables; ++i) runnables[i]->shutdown();
+    for (size_t i = 0; i < blocks_.size(); ++i) blocks_[i]->shutdown();
   }
   void dump() {
-    fprintf(stderr, "\n");
     size_t total = 0;
-    for (int i = 0; i < npipes; ++i) pipes[i]->dump(&total);
-    fprintf(stderr, "Total buffer memory: %ld KiB\n", (unsigned long)total / 1024);
+    fputc('\n', stderr);
+    for (size_t i = 0; i < pipes_.size(); ++i) {
+      pipes_[i]->describe(stderr);
+      total += pipes_[i]->bytes();
+    }
+    fprintf(stderr, "Total buffer memory: %ld KiB\n", (unsigned long)(total >> 10));
+  }
+
+ private:
+  std::vector<detail::pipe_base *> pipes_;
+  std::vector<detail::block_base *> blocks_;
+  unsigned long long fingerprint() const {
+    unsigned long long f = 0;
+    for (size_t i = 0; i < pipes_.size(); ++i) f += (i + 1) * pipes_[i]->traffic();
+    return f;
+  }
+  bool moved(unsigned long long *last) const {
+    const unsigned long long now = fingerprint();
+    const bool changed = now != *last;
+    *last = now;
+    return changed;
   }
 };
 
-struct runnable : runnable_common {
-  runnable(scheduler *s, const char *n) : runnable_common(n), sch(s) { sch->add_runnable(this); }
+struct runnable : detail::block_base {
+  runnable(scheduler *s, const char *n) : detail::block_base(n), sch(s) { s->attach(this); }
 
  protected:
   scheduler *sch;
 };
 
+// Multi-reader FIFO over one linear allocation.  `head` is the write index; reader r has consumed everything below
+// tails[r].  Nothing wraps: when the tail room is short the span [oldest tail, head) is moved to index 0.
 template <typename T>
-struct pipebuf : pipebuf_common {
-  T *buf;
-  T *rds[MAX_READERS];
-  int nrd;
-  T *wr;
-  T *end;
-  unsigned long min_write;
-  unsigned long total_written, total_read;
-  lsdr_ctx *dev;  // NULL: host memory.  Otherwise the buffer lives in this context's HBM.
+struct pipebuf : detail::pipe_base {
+  lsdr_ctx *dev;   // NULL: host memory; otherwise the storage is in this context's HBM
 
-  int sizeofT() { return sizeof(T); }
-
-  pipebuf(scheduler *sch, const char *n, unsigned long size, lsdr_ctx *device = NULL)
-      : pipebuf_common(n), nrd(0), min_write(1), total_written(0), total_read(0), dev(device) {
+  pipebuf(scheduler *s, const char *n, unsigned long size, lsdr_ctx *device = NULL)
+      : detail::pipe_base(n), dev(device), store_(NULL), cap_(size), head_(0), need_(1), n_in_(0), n_out_(0) {
     if (dev) {
       void *p = NULL;
-      lsdr_check(lsdr_malloc(dev, size * sizeof(T), &p), n);
-      buf = (T *)p;
+      lsdr_check(lsdr_malloc(dev, cap_ * sizeof(T), &p), n);
+      store_ = static_cast<T *>(p);
     } else {
-      buf = new T[size];
+      store_ = new T[cap_];
     }
-    wr = buf;
-    end = buf + size;
-    sch->add_pipe(this);
+    s->attach(this);
   }
 
-  int add_reader() {
-    if (nrd == MAX_READERS) fail("too many readers");
-    rds[nrd] = wr;
-    return nrd++;
+  // -- writer side
+  void require_room(unsigned long items) { if (items > need_) need_ = items; }
+  unsigned long room() {
+    if (cap_ - head_ < need_) compact();
+    return cap_ - head_;
+  }
+  T *write_ptr() { return store_ + head_; }
+  void commit(unsigned long items) {
+    if (items > cap_ - head_) { fprintf(stderr, "Bug: overflow to %s\n", name); exit(1); }
+    head_ += items;
+    n_in_ += items;
+  }
+  // -- reader side
+  int attach_reader() {
+    tails_.push_back(head_);
+    return (int)tails_.size() - 1;
+  }
+  unsigned long pending(int r) const { return head_ - tails_[r]; }
+  T *read_ptr(int r) { return store_ + tails_[r]; }
+  void consume(int r, unsigned long items) {
+    if (items > head_ - tails_[r]) { fprintf(stderr, "Bug: underflow from %s\n", name); exit(1); }
+    tails_[r] += items;
+    n_out_ += items;
   }
 
-  // Slide the unread span [oldest reader, wr) to the start of the buffer.
-  void pack() {
-    T *oldest = wr;
-    for (int i = 0; i < nrd; ++i)
-      if (rds[i] < oldest) oldest = rds[i];
-    size_t shift = oldest - buf;
-    if (!shift) return;
-    size_t bytes = (wr - oldest) * sizeof(T);
-    if (dev) lsdr_check(lsdr_memcpy_d2d(dev, buf, oldest, bytes), name);
-    else memmove(buf, oldest, bytes);
-    wr -= shift;
-    for (int i = 0; i < nrd; ++i) rds[i] -= shift;
+  unsigned long long traffic() const { return n_in_ + n_out_; }
+  size_t bytes() const { return cap_ * sizeof(T); }
+  void describe(FILE *f) const {
+    unsigned long div = 1;
+    const char *suffix = "";
+    if (n_in_ >= 1000000) { div = 1000000; suffix = "M"; }
+    else if (n_in_ >= 10000) { div = 1000; suffix = "k"; }
+    const unsigned long tail_room = cap_ - head_;
+    fprintf(f, ".%-16s : %4ld%s/%4ld%s %6ld writable %c, %6d unread (", name, n_out_ / div, suffix, n_in_ / div, suffix, tail_room,
+            tail_room < need_ ? '!' : ' ', (int)(head_ - oldest()));
+    for (size_t r = 0; r < tails_.size(); ++r) fprintf(f, " %d", (int)(head_ - tails_[r]));
+    fprintf(f, " )%s\n", dev ? " [HBM]" : "");
   }
 
-  long long hash() { return total_written + total_read; }
+ private:
+  T *store_;
+  unsigned long cap_, head_, need_;
+  unsigned long n_in_, n_out_;
+  std::vector<unsigned long> tails_;
 
-  void dump(size_t *total_bufs) {
-    const unsigned long k = total_written < 10000 ? 1 : (total_written < 1000000 ? 1000 : 1000000);
-    const char *unit = k == 1 ? "" : (k == 1000 ? "k" : "M");
-    fprintf(stderr, ".%-16s : %4ld%s/%4ld%s", name, total_read / k, unit, total_written / k, unit);
-    *total_bufs += (end - buf) * sizeof(T);
-    unsigned long room = end - wr;
-    fprintf(stderr, " %6ld writable %c,", room, room < min_write ? '!' : ' ');
-    T *oldest = wr;
-    for (int i = 0; i < nrd; ++i)
-      if (rds[i] < oldest) oldest = rds[i];
-    fprintf(stderr, " %6d unread (", (int)(wr - oldest));
-    for (int i = 0; i < nrd; ++i) fprintf(stderr, " %d", (int)(wr - rds[i]));
-    fprintf(stderr, " )%s\n", dev ? " [HBM]" : "");
+  unsigned long oldest() const {
+    unsigned long o = head_;   // no reader: everything written is already "consumed"
+    for (size_t r = 0; r < tails_.size(); ++r)
+      if (tails_[r] < o) o = tails_[r];
+    return o;
+  }
+  void compact() {
+    const unsigned long from = oldest();
+    if (from == 0) return;
+    const size_t live = (head_ - from) * sizeof(T);
+    if (dev) lsdr_check(lsdr_memcpy_d2d(dev, store_, store_ + from, live), name);
+    else memmove(store_, store_ + from, live);
+    head_ -= from;
+    for (size_t r = 0; r < tails_.size(); ++r) tails_[r] -= from;
   }
 };
 
 template <typename T>
 struct pipewriter {
   pipebuf<T> &buf;
-  pipewriter(pipebuf<T> &b, unsigned long min_write = 1) : buf(b) {
-    if (min_write > buf.min_write) buf.min_write = min_write;
-  }
-  // Items writable at wr(); packs first when the tail room fell below min_write.
-  unsigned long writable() {
-    if ((unsigned long)(buf.end - buf.wr) < buf.min_write) buf.pack();
-    return buf.end - buf.wr;
-  }
-  T *wr() { return buf.wr; }
-  void written(unsigned long n) {
-    if (buf.wr + n > buf.end) {
-      fprintf(stderr, "Bug: overflow to %s\n", buf.name);
-      exit(1);
-    }
-    buf.wr += n;
-    buf.total_written += n;
-  }
-  void write(const T &e) {  // host pipebufs only
-    *wr() = e;
-    written(1);
+  pipewriter(pipebuf<T> &b, unsigned long min_write = 1) : buf(b) { buf.require_room(min_write); }
+  unsigned long writable() { return buf.room(); }
+  T *wr() { return buf.write_ptr(); }
+  void written(unsigned long n) { buf.commit(n); }
+  void write(const T &v) {   // host pipes only
+    *buf.write_ptr() = v;
+    buf.commit(1);
   }
 };
-
-template <typename T>
-pipewriter<T> *opt_writer(pipebuf<T> *buf) {
-  return buf ? new pipewriter<T>(*buf) : NULL;
-}
-template <typename T>
-bool opt_writable(pipewriter<T> *p, int n = 1) {
-  return p == NULL || p->writable() >= (unsigned long)n;
-}
-template <typename T>
-void opt_write(pipewriter<T> *p, T val) {
-  if (p) p->write(val);
-}
 
 template <typename T>
 struct pipereader {
   pipebuf<T> &buf;
   int id;
-  explicit pipereader(pipebuf<T> &b) : buf(b), id(b.add_reader()) {}
-  unsigned long readable() { return buf.wr - buf.rds[id]; }
-  T *rd() { return buf.rds[id]; }
-  void read(unsigned long n) {
-    if (buf.rds[id] + n > buf.wr) {
-      fprintf(stderr, "Bug: underflow from %s\n", buf.name);
-      exit(1);
-    }
-    buf.rds[id] += n;
-    buf.total_read += n;
-  }
+  explicit pipereader(pipebuf<T> &b) : buf(b), id(b.attach_reader()) {}
+  unsigned long readable() { return buf.pending(id); }
+  T *rd() { return buf.read_ptr(id); }
+  void read(unsigned long n) { buf.consume(id, n); }
 };
 
-// Math helpers used by templated blocks (framework.h:251-277).
-inline float gen_sqrt(float x) { return sqrtf(x); }
-inline unsigned int gen_sqrt(unsigned int x) { return sqrtl(x); }
-inline long double gen_sqrt(long double x) { return sqrtl(x); }
-inline float gen_abs(float x) { return fabsf(x); }
-inline int gen_abs(int x) { return abs(x); }
-inline long int gen_abs(long int x) { return labs(x); }
-inline float gen_hypot(float x, float y) { return hypotf(x, y); }
-inline long double gen_hypot(long double x, long double y) { return hypotl(x, y); }
-inline float gen_atan2(float y, float x) { return atan2f(y, x); }
-inline long double gen_atan2(long double y, long double x) { return atan2l(y, x); }
-
+// Optional side outputs (measurement pipes): a NULL pipe means "not wired".
 template <typename T>
-T min(const T &x, const T &y) { return (x < y) ? x : y; }
+pipewriter<T> *opt_writer(pipebuf<T> *b) { return b ? new pipewriter<T>(*b) : NULL; }
 template <typename T>
-T max(const T &x, const T &y) { return (x < y) ? y : x; }
-
-// Integer abbreviations.  As in the reference (framework.h:281-286) u32/s32 are
-// `long`, i.e. 8 bytes on x86-64; graphs rely on it (e.g. pipebuf<u32> locktime).
-typedef unsigned char u8;
-typedef unsigned short u16;
-typedef unsigned long u32;
-typedef signed char s8;
-typedef signed short s16;
-typedef signed long s32;
+bool opt_writable(pipewriter<T> *w, int n = 1) { return !w || w->writable() >= (unsigned long)n; }
+template <typename T>
+void opt_write(pipewriter<T> *w, T v) { if (w) w->write(v); }
 
 }  // namespace leansdr
 

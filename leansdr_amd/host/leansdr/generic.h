@@ -1,279 +1,270 @@
-// leansdr_amd/host/leansdr/generic.h — host glue blocks (generic.h:37-375 of the
-// reference: file_reader/writer/printer, decimator, rate_estimator,
-// buffer_reader/writer) plus the two bridges between host and HBM pipebufs.
-// None of this is GPU work; the bridges are the only place where PCIe is crossed.
+// leansdr_amd/host/leansdr/generic.h — host-side end points of a graph: descriptor I/O, the text reports of --fd-info /
+// --fd-const / --fd-spectrum, the VBER ratio, and the two bridges between host pipes and HBM pipes (the only place where
+// PCIe is crossed).  Block names and constructor arguments are the reference's (generic.h:37-375) so that a graph builder
+// written for it compiles; the bodies sit on two small helpers, fdio (whole-item descriptor transfers) and text_out.
 #ifndef LEANSDR_AMD_GENERIC_H
 #define LEANSDR_AMD_GENERIC_H
 
 #include <errno.h>
 #include <fcntl.h>
+#include <stdarg.h>
 #include <sys/types.h>
 #include <unistd.h>
+
+#include <string>
 
 #include "leansdr/framework.h"
 #include "leansdr/math.h"
 
 namespace leansdr {
 
-// Reads raw items from a file descriptor into a (host) pipebuf; end of input is
-// simply "no progress" (generic.h:58-59) which stops the scheduler.
-template <typename T>
-struct file_reader : runnable {
-  bool loop;
-  file_reader(scheduler *sch, int fd, pipebuf<T> &o) : runnable(sch, o.name), loop(false), filler(NULL), fdin(fd), out(o) {}
-  void run() {
-    size_t room = out.writable() * sizeof(T);
-    if (!room) return;
-    for (;;) {
-      ssize_t got = read(fdin, out.wr(), room);
-      if (got < 0 && errno == EWOULDBLOCK && filler) { out.write(*filler); return; }
-      if (got < 0) fatal("read");
-      if (got == 0) {
-        if (!loop) return;
-        if (lseek(fdin, 0, SEEK_SET) == (off_t)-1) fatal("lseek");
-        continue;
-      }
-      size_t tail = got % sizeof(T);  // complete a partially read item
-      for (size_t need = tail ? sizeof(T) - tail : 0; need;) {
-        ssize_t more = read(fdin, (char *)out.wr() + got, need);
-        if (more <= 0) fatal("partial read");
-        got += more;
-        need -= more;
-      }
-      out.written(got / sizeof(T));
-      return;
-    }
+namespace fdio {
+// Up to max_bytes from fd; never returns a fraction of an item (a short tail is completed with blocking reads).
+// Result: bytes read (multiple of item), 0 at end of file, −1 when a non-blocking descriptor has nothing yet.
+inline ssize_t pull(int fd, void *dst, size_t max_bytes, size_t item) {
+  ssize_t got = ::read(fd, dst, max_bytes);
+  if (got < 0) {
+    if (errno == EWOULDBLOCK || errno == EAGAIN) return -1;
+    fatal("read");
   }
-  void set_realtime(T &f) {
-    int flags = fcntl(fdin, F_GETFL);
-    if (fcntl(fdin, F_SETFL, flags | O_NONBLOCK)) fatal("fcntl");
-    filler = new T(f);
+  for (size_t part = (size_t)got % item; part; part = (size_t)got % item) {
+    ssize_t more = ::read(fd, static_cast<char *>(dst) + got, item - part);
+    if (more <= 0) fatal("partial read");
+    got += more;
+  }
+  return got;
+}
+// One write(); a short count is fine as long as it ends on an item boundary.
+inline size_t push(int fd, const void *src, size_t bytes, size_t item) {
+  ssize_t done = ::write(fd, src, bytes);
+  if (done == 0) fatal("pipe");
+  if (done < 0) fatal("write");
+  if ((size_t)done % item) fatal("partial write");
+  return (size_t)done;
+}
+}  // namespace fdio
+
+// printf into a growing line, flushed to a descriptor with one write() per flush.
+struct text_out {
+  explicit text_out(int fd) : fd_(fd) {}
+  void add(const char *fmt, ...) __attribute__((format(printf, 2, 3))) {
+    char piece[256];
+    va_list ap;
+    va_start(ap, fmt);
+    int len = vsnprintf(piece, sizeof(piece), fmt, ap);
+    va_end(ap);
+    if (len < 0) fatal("vsnprintf");
+    line_.append(piece, (size_t)len < sizeof(piece) ? (size_t)len : sizeof(piece) - 1);
+  }
+  void flush() {
+    for (size_t off = 0; off < line_.size();) {
+      ssize_t w = ::write(fd_, line_.data() + off, line_.size() - off);
+      if (w <= 0) fatal("partial write");
+      off += (size_t)w;
+    }
+    line_.clear();
   }
 
  private:
-  T *filler;
-  int fdin;
-  pipewriter<T> out;
+  int fd_;
+  std::string line_;
+};
+
+// ---- raw item streams ------------------------------------------------------------------------------------------------
+// End of input is simply "no progress": the scheduler's fixpoint ends the run.  `loop` rewinds a seekable input instead;
+// set_realtime() makes the descriptor non-blocking and substitutes `filler` items while nothing is available.
+template <typename T>
+struct file_reader : runnable {
+  bool loop;
+  file_reader(scheduler *s, int fd, pipebuf<T> &dst) : runnable(s, dst.name), loop(false), fd_(fd), to_(dst), have_filler_(false) {}
+  void run() {
+    const size_t room = to_.writable() * sizeof(T);
+    if (room == 0) return;
+    ssize_t got = fdio::pull(fd_, to_.wr(), room, sizeof(T));
+    while (got == 0 && loop) {
+      if (lseek(fd_, 0, SEEK_SET) == (off_t)-1) fatal("lseek");
+      got = fdio::pull(fd_, to_.wr(), room, sizeof(T));
+    }
+    if (got > 0) to_.written((size_t)got / sizeof(T));
+    else if (got < 0 && have_filler_) to_.write(filler_);
+  }
+  void set_realtime(T &filler) {
+    const int fl = fcntl(fd_, F_GETFL);
+    if (fcntl(fd_, F_SETFL, fl | O_NONBLOCK) != 0) fatal("fcntl");
+    filler_ = filler;
+    have_filler_ = true;
+  }
+
+ private:
+  int fd_;
+  pipewriter<T> to_;
+  T filler_;
+  bool have_filler_;
 };
 
 template <typename T>
 struct file_writer : runnable {
-  file_writer(scheduler *sch, pipebuf<T> &i, int fd) : runnable(sch, i.name), in(i), fdout(fd) {}
+  file_writer(scheduler *s, pipebuf<T> &src, int fd) : runnable(s, src.name), from_(src), fd_(fd) {}
   void run() {
-    size_t bytes = in.readable() * sizeof(T);
-    if (!bytes) return;
-    ssize_t nw = write(fdout, in.rd(), bytes);
-    if (!nw) fatal("pipe");
-    if (nw < 0) fatal("write");
-    if (nw % sizeof(T)) fatal("partial write");
-    in.read(nw / sizeof(T));
+    const size_t avail = from_.readable() * sizeof(T);
+    if (avail) from_.read(fdio::push(fd_, from_.rd(), avail, sizeof(T)) / sizeof(T));
   }
 
  private:
-  pipereader<T> in;
-  int fdout;
+  pipereader<T> from_;
+  int fd_;
 };
 
-// printf-style text output with optional decimation and scaling (generic.h:116-147).
+// ---- text reports ----------------------------------------------------------------------------------------------------
+// One formatted line per `decimation` items ("FREQ %.0f\n", "LOCK %d\n", …).
 template <typename T>
 struct file_printer : runnable {
   T scale;
   int decimation;
-  file_printer(scheduler *sch, const char *fmt, pipebuf<T> &i, int fd, int decim = 1)
-      : runnable(sch, i.name), scale(1), decimation(decim), in(i), format(fmt), fdout(fd), phase(0) {}
+  file_printer(scheduler *s, const char *fmt, pipebuf<T> &src, int fd, int every = 1)
+      : runnable(s, src.name), scale(1), decimation(every), from_(src), fmt_(fmt), sink_(fd), skipped_(0) {}
   void run() {
-    int n = in.readable();
-    T *p = in.rd();
-    for (int k = 0; k < n; ++k) {
-      if (++phase >= decimation) {
-        phase -= decimation;
-        char line[256];
-        int len = snprintf(line, sizeof(line), format, p[k] * scale);
-        if (len < 0) fatal("obsolete glibc");
-        if (write(fdout, line, len) != len) fatal("partial write");
-      }
+    const unsigned long n = from_.readable();
+    const T *v = from_.rd();
+    for (unsigned long i = 0; i < n; ++i) {
+      if (++skipped_ < decimation) continue;
+      skipped_ -= decimation;
+      sink_.add(fmt_, v[i] * scale);
+      sink_.flush();
     }
-    in.read(n);
+    from_.read(n);
   }
 
  private:
-  pipereader<T> in;
-  const char *format;
-  int fdout;
-  int phase;
+  pipereader<T> from_;
+  const char *fmt_;
+  text_out sink_;
+  int skipped_;
 };
 
-// Batches of complex items as one text line each (generic.h:153-189) — SYMBOLS lines of --fd-const.
+// A batch of complex items per line: head(count) item sep item … tail.  fixed_size > 0 prints exactly that many per line
+// (and waits for them); 0 prints whatever is readable.  --fd-const uses it for the SYMBOLS lines.
 template <typename T>
 struct file_carrayprinter : runnable {
   T scale;
-  int fixed_size;   // items per batch, or 0
-  file_carrayprinter(scheduler *sch, const char *head_, const char *format_, const char *sep_, const char *tail_,
-                     pipebuf<complex<T> > &i, int fd)
-      : runnable(sch, i.name), scale(1), fixed_size(0), in(i), head(head_), format(format_), sep(sep_), tail(tail_),
-        fout(fdopen(fd, "w")) {}
+  int fixed_size;
+  file_carrayprinter(scheduler *s, const char *head, const char *item, const char *sep, const char *tail, pipebuf<complex<T> > &src,
+                     int fd)
+      : runnable(s, src.name), scale(1), fixed_size(0), from_(src), head_(head), item_(item), sep_(sep), tail_(tail), sink_(fd) {}
   void run() {
-    int n, nmin = fixed_size ? fixed_size : 1;
-    while ((n = in.readable()) >= nmin) {
-      if (fixed_size) n = fixed_size;
-      if (fout) {
-        fprintf(fout, head, n);
-        complex<T> *pin = in.rd();
-        for (int k = 0; k < n; ++k) {
-          if (k) fprintf(fout, "%s", sep);
-          fprintf(fout, format, pin[k].re * scale, pin[k].im * scale);
-        }
-        fprintf(fout, "%s", tail);
+    const unsigned long least = fixed_size > 0 ? (unsigned long)fixed_size : 1ul;
+    for (unsigned long n = from_.readable(); n >= least; n = from_.readable()) {
+      if (fixed_size > 0) n = least;
+      const complex<T> *z = from_.rd();
+      sink_.add(head_, (int)n);
+      for (unsigned long i = 0; i < n; ++i) {
+        if (i) sink_.add("%s", sep_);
+        sink_.add(item_, z[i].re * scale, z[i].im * scale);
       }
-      fflush(fout);
-      in.read(n);
+      sink_.add("%s", tail_);
+      sink_.flush();
+      from_.read(n);
     }
   }
 
  private:
-  pipereader<complex<T> > in;
-  const char *head, *format, *sep, *tail;
-  FILE *fout;
+  pipereader<complex<T> > from_;
+  const char *head_, *item_, *sep_, *tail_;
+  text_out sink_;
 };
 
-// One text line per vector item: head, N formatted values joined by sep, tail (generic.h:191-222).
+// One line per N-vector item (the 1024-bin SPECTRUM lines).
 template <typename T, int N>
 struct file_vectorprinter : runnable {
   T scale;
-  file_vectorprinter(scheduler *sch, const char *head_, const char *format_, const char *sep_, const char *tail_,
-                     pipebuf<T[N]> &i, int fd)
-      : runnable(sch, i.name), scale(1), in(i), head(head_), format(format_), sep(sep_), tail(tail_) {
-    fout = fdopen(fd, "w");
-    if (!fout) fatal("fdopen");
-  }
+  file_vectorprinter(scheduler *s, const char *head, const char *item, const char *sep, const char *tail, pipebuf<T[N]> &src, int fd)
+      : runnable(s, src.name), scale(1), from_(src), head_(head), item_(item), sep_(sep), tail_(tail), sink_(fd) {}
   void run() {
-    while (in.readable() >= 1) {
-      fprintf(fout, head, N);
-      T(*pin)[N] = in.rd();
-      for (int k = 0; k < N; ++k) {
-        if (k) fprintf(fout, "%s", sep);
-        fprintf(fout, format, (*pin)[k] * scale);
+    for (; from_.readable(); from_.read(1)) {
+      const T *v = *from_.rd();
+      sink_.add(head_, N);
+      for (int i = 0; i < N; ++i) {
+        if (i) sink_.add("%s", sep_);
+        sink_.add(item_, v[i] * scale);
       }
-      fprintf(fout, "%s", tail);
-      in.read(1);
+      sink_.add("%s", tail_);
+      sink_.flush();
     }
-    fflush(fout);
   }
 
  private:
-  pipereader<T[N]> in;
-  const char *head, *format, *sep, *tail;
-  FILE *fout;
+  pipereader<T[N]> from_;
+  const char *head_, *item_, *sep_, *tail_;
+  text_out sink_;
 };
 
-// Ratio of two accumulated integer streams, emitted once the denominator
-// reaches sample_size (generic.h:272-305) — VBER in leandvb.
+// Σ numerator / Σ denominator over windows of at least sample_size denominator counts — VBER = corrected bits / bits.
 template <typename T>
 struct rate_estimator : runnable {
   int sample_size;
-  rate_estimator(scheduler *sch, pipebuf<int> &n, pipebuf<int> &d, pipebuf<float> &r)
-      : runnable(sch, "rate_estimator"), sample_size(10000), num(n), den(d), rate(r), acc_num(0), acc_den(0) {}
+  rate_estimator(scheduler *s, pipebuf<int> &numerator, pipebuf<int> &denominator, pipebuf<float> &ratio)
+      : runnable(s, "rate_estimator"), sample_size(10000), num_(numerator), den_(denominator), ratio_(ratio), sum_num_(0), sum_den_(0) {}
   void run() {
-    if (rate.writable() < 1) return;
-    int count = min(num.readable(), den.readable());
-    int *pn = num.rd(), *pd = den.rd();
-    for (int k = 0; k < count; ++k) { acc_num += pn[k]; acc_den += pd[k]; }
-    num.read(count);
-    den.read(count);
-    if (acc_den >= sample_size) {
-      rate.write((float)acc_num / acc_den);
-      acc_num = acc_den = 0;
+    if (ratio_.writable() == 0) return;
+    const unsigned long pairs = min(num_.readable(), den_.readable());
+    const int *a = num_.rd(), *b = den_.rd();
+    for (unsigned long i = 0; i < pairs; ++i) {
+      sum_num_ += a[i];
+      sum_den_ += b[i];
     }
+    num_.read(pairs);
+    den_.read(pairs);
+    if (sum_den_ < sample_size) return;
+    ratio_.write((float)sum_num_ / sum_den_);
+    sum_num_ = sum_den_ = 0;
   }
 
  private:
-  pipereader<int> num, den;
-  pipewriter<float> rate;
-  T acc_num, acc_den;
+  pipereader<int> num_, den_;
+  pipewriter<float> ratio_;
+  T sum_num_, sum_den_;
 };
 
+// ---- bridges: host pipe <-> HBM pipe ---------------------------------------------------------------------------------
+// The copy is enqueued on the context's stream, i.e. ordered with the kernels of the neighbouring GPU blocks, and waited
+// for before the items change hands (the producer may overwrite host memory; a host consumer must see the data).
+namespace detail {
 template <typename T>
-struct buffer_reader : runnable {
-  buffer_reader(scheduler *sch, T *d, int n, pipebuf<T> &o) : runnable(sch, "buffer_reader"), data(d), count(n), out(o), pos(0) {}
-  void run() {
-    int n = min(out.writable(), (unsigned long)(count - pos));
-    memcpy(out.wr(), data + pos, n * sizeof(T));
-    pos += n;
-    out.written(n);
-  }
+inline unsigned long bridge(lsdr_ctx *ctx, pipereader<T> &from, pipewriter<T> &to, bool to_device, const char *tag) {
+  const unsigned long n = min(from.readable(), to.writable());
+  if (n == 0) return 0;
+  lsdr_check(to_device ? lsdr_memcpy_h2d(ctx, to.wr(), from.rd(), n * sizeof(T)) : lsdr_memcpy_d2h(ctx, to.wr(), from.rd(), n * sizeof(T)), tag);
+  lsdr_check(lsdr_ctx_sync(ctx), tag);
+  from.read(n);
+  to.written(n);
+  return n;
+}
+}  // namespace detail
 
- private:
-  T *data;
-  int count;
-  pipewriter<T> out;
-
- public:
-  int pos;
-};
-
-template <typename T>
-struct buffer_writer : runnable {
-  buffer_writer(scheduler *sch, pipebuf<T> &i, T *d, int n) : runnable(sch, "buffer_writer"), in(i), data(d), count(n), pos(0) {}
-  void run() {
-    int n = min(in.readable(), (unsigned long)(count - pos));
-    memcpy(data + pos, in.rd(), n * sizeof(T));
-    in.read(n);
-    pos += n;
-  }
-
- private:
-  pipereader<T> in;
-  T *data;
-  int count;
-
- public:
-  int pos;
-};
-
-// ---- bridges (new): host pipebuf <-> HBM pipebuf --------------------------------
-// The copy is enqueued on the context's stream, so it is ordered with the kernels
-// of the neighbouring GPU blocks.  h2d waits for the copy before releasing the host
-// items (the file_reader may overwrite them); d2h waits before publishing them.
 template <typename T>
 struct h2d_copier : runnable {
-  h2d_copier(scheduler *sch, lsdr_ctx *c, pipebuf<T> &host_in, pipebuf<T> &dev_out)
-      : runnable(sch, "h2d"), ctx(c), in(host_in), out(dev_out) {
-    if (host_in.dev || !dev_out.dev) fail("h2d_copier: needs host input and device output pipebufs");
+  h2d_copier(scheduler *s, lsdr_ctx *c, pipebuf<T> &host_src, pipebuf<T> &hbm_dst) : runnable(s, "h2d"), ctx_(c), from_(host_src), to_(hbm_dst) {
+    if (host_src.dev || !hbm_dst.dev) fail("h2d_copier: needs host input and device output pipebufs");
   }
-  void run() {
-    unsigned long n = min(in.readable(), out.writable());
-    if (!n) return;
-    lsdr_check(lsdr_memcpy_h2d(ctx, out.wr(), in.rd(), n * sizeof(T)), "h2d");
-    lsdr_check(lsdr_ctx_sync(ctx), "h2d");
-    in.read(n);
-    out.written(n);
-  }
+  void run() { detail::bridge(ctx_, from_, to_, true, name); }
 
  private:
-  lsdr_ctx *ctx;
-  pipereader<T> in;
-  pipewriter<T> out;
+  lsdr_ctx *ctx_;
+  pipereader<T> from_;
+  pipewriter<T> to_;
 };
 
 template <typename T>
 struct d2h_copier : runnable {
-  d2h_copier(scheduler *sch, lsdr_ctx *c, pipebuf<T> &dev_in, pipebuf<T> &host_out)
-      : runnable(sch, "d2h"), ctx(c), in(dev_in), out(host_out) {
-    if (!dev_in.dev || host_out.dev) fail("d2h_copier: needs device input and host output pipebufs");
+  d2h_copier(scheduler *s, lsdr_ctx *c, pipebuf<T> &hbm_src, pipebuf<T> &host_dst) : runnable(s, "d2h"), ctx_(c), from_(hbm_src), to_(host_dst) {
+    if (!hbm_src.dev || host_dst.dev) fail("d2h_copier: needs device input and host output pipebufs");
   }
-  void run() {
-    unsigned long n = min(in.readable(), out.writable());
-    if (!n) return;
-    lsdr_check(lsdr_memcpy_d2h(ctx, out.wr(), in.rd(), n * sizeof(T)), "d2h");
-    lsdr_check(lsdr_ctx_sync(ctx), "d2h");
-    in.read(n);
-    out.written(n);
-  }
+  void run() { detail::bridge(ctx_, from_, to_, false, name); }
 
  private:
-  lsdr_ctx *ctx;
-  pipereader<T> in;
-  pipewriter<T> out;
+  lsdr_ctx *ctx_;
+  pipereader<T> from_;
+  pipewriter<T> to_;
 };
 
 }  // namespace leansdr
