@@ -61,6 +61,22 @@ struct config {
         buf_factor(4096), fd_info(-1), Finfo(5), out_symbols(false), tiled(false), tile_len(0), tile_warmup(0), device(0) {}
 };
 
+// The constants leandvb prints first on --fd-info (leandvb.cc:143-155).
+static void output_initial_info(int fd, const config &cfg) {
+  static const char *const cstln_name[] = {"BPSK", "QPSK", "8PSK", "16APSK", "32APSK", "64APSKe", "16QAM", "64QAM", "256QAM"};
+  static const int rate_in[] = {1, 2, 4, 3, 5, 7, 4, 8, 9}, rate_out[] = {2, 3, 6, 4, 6, 8, 5, 9, 10};   // code_rate order, dvb.h:38-39
+  const char *q = cfg.json ? "\"" : "";
+  char text[256];
+  int n = snprintf(text, sizeof(text), "STANDARD %sDVB-S%s\nCONSTELLATION %s%s%s\nCR %s%d/%d%s\nSR %f\n", q, q, q,
+                   cstln_name[cfg.constellation], q, q, rate_in[cfg.fec], rate_out[cfg.fec], q, cfg.Fm);
+  if (n > 0 && write(fd, text, n) != n) fatal("write(fd_info)");
+}
+// VBER window: about twice per second, and fine enough to resolve 2e-5 (leandvb.cc:585-587)
+static int vber_window(const config &cfg) {
+  int w = cfg.Fm / 2;
+  return w < 50000 ? 50000 : w;
+}
+
 static int decimation(float Fin, float Fout) {
   int d = Fin / Fout;
   return max(d, 1);
@@ -111,17 +127,19 @@ static int run_highspeed(config &cfg) {
   rs_decoder<u8, 0> r_rsdec(&sch, p_rspackets, p_rtspackets, &p_vbitcount, &p_verrcount);
   pipebuf<float> p_vber(&sch, "VBER", BUF_SLOW);
   rate_estimator<float> r_vber(&sch, p_verrcount, p_vbitcount, p_vber);
+  r_vber.sample_size = vber_window(cfg);
   pipebuf<tspacket> p_tspackets(&sch, "TS packets", BUF_PACKETS, ctx);
   derandomizer r_derand(&sch, p_rtspackets, p_tspackets);
   pipebuf<tspacket> p_ts_host(&sch, "TS packets(host)", BUF_PACKETS);
   d2h_copier<tspacket> r_d2h(&sch, ctx, p_tspackets, p_ts_host);
   file_writer<tspacket> r_stdout(&sch, p_ts_host, 1);
 
-  if (cfg.fd_info >= 0) {
-    new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info);
+  if (cfg.fd_info >= 0) {   // leandvb.cc:897-910
+    (new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info))->scale = cfg.Fs;
     new file_printer<int>(&sch, "LOCK %d\n", p_lock, cfg.fd_info);
-    new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, 10);
+    new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, decimation(cfg.Fm / 8 / 204, cfg.Finfo));
     new file_printer<float>(&sch, "VBER %.6f\n", p_vber, cfg.fd_info);
+    output_initial_info(cfg.fd_info, cfg);
   }
   sch.run();
   sch.shutdown();
@@ -200,7 +218,7 @@ static int run(config &cfg) {
   cnr_fft<f32> *r_cnr = NULL;
   if (cfg.cnr) {
     r_cnr = new cnr_fft<f32>(&sch, *p_preprocessed, p_cnr, cfg.Fm / cfg.Fs);
-    r_cnr->decimation = decimation(cfg.Fs, cfg.Finfo);
+    r_cnr->decimation = decimation(cfg.Fs, 1);  // 1 Hz
   }
 
   // SPECTRUM (leandvb.cc:331-343)
@@ -318,7 +336,7 @@ static int run(config &cfg) {
     new deinterleaver<u8>(&sch, *p_mpegbytes, *p_rspackets);
     pipebuf<tspacket> *p_rtspackets = new pipebuf<tspacket>(&sch, "rand TS packets", BUF_PACKETS, ctx);
     new rs_decoder<u8, 0>(&sch, *p_rspackets, *p_rtspackets, &p_vbitcount, &p_verrcount);
-    new rate_estimator<float>(&sch, p_verrcount, p_vbitcount, p_vber);
+    (new rate_estimator<float>(&sch, p_verrcount, p_vbitcount, p_vber))->sample_size = vber_window(cfg);
     pipebuf<tspacket> *p_tspackets = new pipebuf<tspacket>(&sch, "TS packets", BUF_PACKETS, ctx);
     new derandomizer(&sch, *p_rtspackets, *p_tspackets);
     pipebuf<tspacket> *p_ts_host = new pipebuf<tspacket>(&sch, "TS packets(host)", BUF_PACKETS);
@@ -326,14 +344,15 @@ static int run(config &cfg) {
     new file_writer<tspacket>(&sch, *p_ts_host, 1);
   }
 
-  if (cfg.fd_info >= 0) {
-    new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info);
+  if (cfg.fd_info >= 0) {   // same printers, same order (= order of the lines within a scheduler pass) as leandvb.cc:600-616
+    (new file_printer<f32>(&sch, "FREQ %.0f\n", p_freq, cfg.fd_info))->scale = cfg.Fs;
     new file_printer<f32>(&sch, "SS %f\n", p_ss, cfg.fd_info);
     new file_printer<f32>(&sch, "MER %.1f\n", p_mer, cfg.fd_info);
-    if (cfg.cnr) new file_printer<f32>(&sch, "CNR %.1f\n", p_cnr, cfg.fd_info);
     new file_printer<int>(&sch, "LOCK %d\n", p_lock, cfg.fd_info);
-    new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, 10);
+    new file_printer<u32>(&sch, "LOCKTIME %lu\n", p_locktime, cfg.fd_info, decimation(cfg.Fm / 8 / 204, cfg.Finfo));
+    new file_printer<f32>(&sch, "CNR %.1f\n", p_cnr, cfg.fd_info);
     new file_printer<f32>(&sch, "VBER %.6f\n", p_vber, cfg.fd_info);
+    output_initial_info(cfg.fd_info, cfg);
   } else {
     // unread measurement pipes never block their writer (pipebuf with zero readers packs to empty)
   }

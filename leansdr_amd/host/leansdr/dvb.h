@@ -38,11 +38,14 @@ struct deconvol_sync<u8, 0> : runnable {
         out(o, SIZE_RSPACKET), rate_(rate), h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_deconv_create(ctx, (int)rate_, fastlock, &h), name);
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_deconv_run(h, (const lsdr_softsymbol *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_deconv_run(h, (const lsdr_softsymbol *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
   void next_sync() {
     if (fastlock) fail("Bug: next_sync() called with fastlock");
@@ -74,11 +77,18 @@ struct viterbi_sync : runnable {
   }
   void run() {
     lsdr_check(lsdr_viterbi_set_resync_period(h, resync_period), name);
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_viterbi_run(h, (const lsdr_softsymbol *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    // The reference's run() decodes chunks while input and room last (dvb.h:1371-1412).  lsdr_viterbi_run may stop earlier
+    // (after an alignment switch it only looks one resync period ahead), so it is called until it makes no progress: one
+    // scheduler pass then moves the same amount of data as the reference's, which is what the cadence of the --fd-info
+    // reports downstream depends on.
+    for (;;) {
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_viterbi_run(h, (const lsdr_softsymbol *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -106,11 +116,14 @@ struct dvb_deconvol_sync<u8> : runnable {
         h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_hsdeconv_create(ctx, resync_period, &h), name);
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_hsdeconv_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress, like the while loop of dvb.h:634-637
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_hsdeconv_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -185,11 +198,14 @@ struct deinterleaver<u8> : runnable {
       : runnable(sch, "deinterleaver"), ctx(pipe_ctx(i.dev, o.dev, "deinterleaver: pipebufs must be device pipebufs of one ctx")),
         in(i), out(o) {}
   void run() {
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_deinterleaver_run(ctx, in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_deinterleaver_run(ctx, in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -236,11 +252,14 @@ struct derandomizer : runnable {
         in(i), out(o), h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_derandomizer_create(ctx, &h), name);
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_derandomizer_run(h, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_derandomizer_run(h, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -257,11 +276,14 @@ struct randomizer : runnable {   // dvb.h:1063-1102
     lsdr_check(lsdr_randomizer_create(ctx, &h), name);
   }
   void run() {
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_randomizer_run(h, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_randomizer_run(h, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -275,11 +297,14 @@ struct rs_encoder : runnable {   // dvb.h:957-980
   rs_encoder(scheduler *sch, pipebuf<tspacket> &i, pipebuf<rspacket<u8> > &o)
       : runnable(sch, "RS encoder"), ctx(pipe_ctx(i.dev, o.dev, "rs_encoder: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {}
   void run() {
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_rs_encoder_run(ctx, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_rs_encoder_run(ctx, (const uint8_t *)in.rd(), in.readable(), (uint8_t *)out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -293,11 +318,14 @@ struct interleaver : runnable {   // dvb.h:899-921
       : runnable(sch, "interleaver"), ctx(pipe_ctx(i.dev, o.dev, "interleaver: pipebufs must be device pipebufs of one ctx")), in(i),
         out(o, SIZE_RSPACKET) {}
   void run() {
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_interleaver_run(ctx, (const uint8_t *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_interleaver_run(ctx, (const uint8_t *)in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
@@ -315,11 +343,14 @@ struct dvb_convol : runnable {   // dvb.h:567-604
     lsdr_check(lsdr_convol_create(ctx, (int)fec, bits_per_symbol, &h), name);
   }
   void run() {
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_convol_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_convol_run(h, in.rd(), in.readable(), out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:

@@ -489,11 +489,14 @@ struct simple_agc<f32> : runnable {
   void run() {
     if (!h) lsdr_check(lsdr_simple_agc_create(ctx, out_rms, bw, &h), name);
     lsdr_check(lsdr_simple_agc_set(h, out_rms, bw), name);
-    unsigned long room = out.writable();
-    size_t consumed = 0, produced = 0;
-    lsdr_check(lsdr_simple_agc_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
-    in.read(consumed);
-    out.written(produced);
+    for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
+      unsigned long room = out.writable();
+      size_t consumed = 0, produced = 0;
+      lsdr_check(lsdr_simple_agc_run(h, (const lsdr_cf32 *)in.rd(), in.readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
+      if (!consumed && !produced) break;
+      in.read(consumed);
+      out.written(produced);
+    }
   }
 
  private:
