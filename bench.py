@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per step per GPU")
     ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, tiled)")
     ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "tiled"))
-    ap.add_argument("--tile-len", type=int, default=256)
+    ap.add_argument("--tile-len", type=int, default=128)
     ap.add_argument("--tile-warmup", type=int, default=256)
     ap.add_argument("--no-overlap", action="store_true",
                     help="run fir_filter and cstln_receiver back to back on one stream (default: two HIP streams, "
