@@ -248,6 +248,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
 // ±0 to an accumulator that is never −0, i.e. changes no bit, as long as the
 // sample it multiplies is finite; samples past the end of the input are replaced
 // by the last valid sample for that reason.
+// parts in which the next tile's loads are issued during the tap phase (1 = all before the taps)
+#ifndef LSDR_FIR_SPLIT
+#define LSDR_FIR_SPLIT 4
+#endif
+
 template <int IN_FMT, int R, int MODE, int DT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_fir_persist(fir_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
   // per load, and hardware bounds checking — reads past the end of the input return
   // 0.0, which is exactly the "finite filler" the zero-padded taps need.
   constexpr unsigned ES = IN_FMT == LSDR_IN_CU8 ? 2u : 8u;
-  auto issue = [&](unsigned tile) {
+  auto issue = [&](unsigned tile, int k_lo, int k_hi) {
     const unsigned long long j0 = (unsigned long long)tile * M * D;
     const unsigned long long bytes = (a.n_in - j0) * ES;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -277,6 +282,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
     const unsigned voff = l * ES;
 #pragma unroll
     for (int k = 0; k < NL; ++k) {
+      if (k < k_lo || k >= k_hi) continue;
       if (IN_FMT == LSDR_IN_CU8) {
         unsigned short r = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff, k * kThreads * ES, LSDR_FIR_LOAD_AUX);
         v[k] = make_float2(__uint_as_float((unsigned)r), 0.f);
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
 #else
 #define LSDR_TR(i)
 #endif
-  issue(tile_of(ti));
+  issue(tile_of(ti), 0, NL);
   LSDR_TR(0)
   while (true) {
     const unsigned tile = tile_of(ti);
@@ -310,19 +316,28 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
     LSDR_TR(2)
     const unsigned tn = ti + slots;
     const bool more = valid(tn);
-    if (more) issue(tile_of(tn));          // in flight during the tap phase
-    __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the taps
-    LSDR_TR(3)
-
+    // The next tile's loads are issued in LSDR_FIR_SPLIT parts, one before each group of polyphase columns: the vector-memory
+    // queue takes them only as fast as HBM returns data, and a wave that is stuck issuing all 32 at once (≈ 3.3 K cycles per
+    // tile) does no arithmetic meanwhile.
     float accr[R], acci[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) { accr[r] = 0.f; acci[r] = 0.f; }
     cptr2 psc = (cptr2)a.scp;
     cptr1 prc = (cptr1)a.rcp;
-    for (int col = (int)a.ncols - 1; col >= 0; --col, psc += D, prc += D) {
-      const float2 *px = lds + l + (D - 1) * S + (unsigned)col;
+    constexpr int P = LSDR_FIR_SPLIT;
+    int col = (int)a.ncols - 1;
 #pragma unroll
-      for (int k = 0; k < (int)D; ++k) fir_tap<R, MODE>(psc + k, prc + k, px - k * (int)S, accr, acci);
+    for (int part = 0; part < P; ++part) {
+      if (more) issue(tile_of(tn), NL * part / P, NL * (part + 1) / P);   // in flight during the tap phase
+      __builtin_amdgcn_sched_barrier(0);     // keep the loads ahead of the taps
+      if (part == 0) { LSDR_TR(3) }
+      const int col_end = (int)a.ncols * (P - 1 - part) / P;              // this part runs columns col … col_end
+      for (; col >= col_end; --col, psc += D, prc += D) {
+        const float2 *px = lds + l + (D - 1) * S + (unsigned)col;
+#pragma unroll
+        for (int k = 0; k < (int)D; ++k) fir_tap<R, MODE>(psc + k, prc + k, px - k * (int)S, accr, acci);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     LSDR_TR(4)
