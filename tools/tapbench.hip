@@ -3,10 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>
+#include <cstring>
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) float *cptr1;
 constexpr int D = 30, S = 269, NCOL = 11, REP = 16;
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#include "tapbench_asm.inc"
 
 // VAR 0: s_load coeffs + ds_read (as shipped)   1: coeffs from kernel-arg constants (no s_load in loop)
 // VAR 2: s_load coeffs, no LDS (register sample) 3: ds_read only, coefficient = 1 literal
@@ -37,7 +39,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
       __builtin_amdgcn_sched_barrier(0);
     }
     cptr1 prc = (cptr1)rc;
-    if (VAR == 7) {   // two taps per ds_read_b128: rows interleaved in 16-byte units
+    if (VAR == 8) {   // hand-scheduled 16 + 14 tap blocks, coefficients of the next block prefetched inside the block
+      typedef const __attribute__((address_space(4))) v2f *cpair;
+      cpair pcp = (cpair)rc;
+      v2f a0 = pcp[0], a1 = pcp[1], a2 = pcp[2], a3 = pcp[3], a4 = pcp[4], a5 = pcp[5], a6 = pcp[6], a7 = pcp[7];
+      v2f b0, b1, b2, b3, b4, b5, b6;
+      v2f ac = {acc.x, acc.y};
+      for (int col = NCOL - 1; col >= 0; --col) {
+        const int ci = NCOL - 1 - col;
+        const unsigned addr = (l + (unsigned)col) * 8u;
+        taps_a16<D, S>(ac, addr, (const void __attribute__((address_space(4))) *)(pcp + ci * 15 + 8), a0, a1, a2, a3, a4, a5, a6, a7, b0, b1, b2, b3,
+                       b4, b5, b6);
+        taps_b14<D, S>(ac, addr, (const void __attribute__((address_space(4))) *)(pcp + (ci + 1) * 15), b0, b1, b2, b3, b4, b5, b6, a0, a1, a2, a3, a4,
+                       a5, a6, a7);
+      }
+      acc.x = ac.x; acc.y = ac.y;
+    } else if (VAR == 7) {   // two taps per ds_read_b128: rows interleaved in 16-byte units
       for (int col = NCOL - 1; col >= 0; --col, prc += D) {
         const float4 *px4 = reinterpret_cast<const float4 *>(lds) + l + (D / 2 - 1) * S + (unsigned)col;
         float4 v[D / 2];
@@ -108,6 +125,15 @@ int main() {
     run<6, 1>("coeffs via v_readlane + 32 loads in flight", grid, rc, out, cyc);
     run<7>("s_load coeffs + ds_read_b128 (2 taps)", grid, rc, out, cyc);
     run<7, 1>("ds_read_b128 (2 taps) + 32 loads in flight", grid, rc, out, cyc);
+    {   // same taps, same order: the asm blocks must reproduce the compiler's result bit for bit
+      std::vector<float2> ra(grid * 256), rb(grid * 256);
+      run<0>("(again) shipped", grid, rc, out, cyc);
+      hipMemcpy(ra.data(), out, ra.size() * 8, hipMemcpyDeviceToHost);
+      run<8>("asm 16+14 blocks, coeff prefetch", grid, rc, out, cyc);
+      hipMemcpy(rb.data(), out, rb.size() * 8, hipMemcpyDeviceToHost);
+      printf("asm blocks vs compiler: %s\n", memcmp(ra.data(), rb.data(), ra.size() * 8) ? "DIFFERENT" : "bit-identical");
+    }
+    run<8, 1>("asm 16+14 blocks + 32 loads in flight", grid, rc, out, cyc);
   }
   return 0;
 }
