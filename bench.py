@@ -96,6 +96,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run fir_filter and cstln_receiver back to back on one stream (default: two HIP streams, "
                          "fir_filter of batch k+1 overlaps cstln_receiver of batch k)")
+    ap.add_argument("--captures", type=int, default=3,
+                    help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles; "
+                         "tiled receiver with overlapped streams only); a step is then one batch of every capture")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -159,6 +162,72 @@ def main():
     fir_ms = []
     nsym = [0]
 
+    class Lane:
+        """One capture: input in HBM, fir_filter on its own stream, cstln_receiver on another, double-buffered decimated
+        stream.  Lane 0 wraps the objects created above; further lanes (--captures) get their own of everything."""
+
+        def __init__(self, idx):
+            self.idx = idx
+            if idx == 0:
+                self.ctx, self.ctx_rx, self.d_in, self.dec, self.d_sym, self.fir, self.rx = ctx, ctx_rx, d_in, dec, d_sym, fir, rx
+                self.ev_fir, self.ev_rx = ev_fir, ev_rx
+            else:
+                # fir_filter of every capture goes through ONE stream (two persistent fir kernels side by side only fight for the
+                # LDS of the same CUs); every capture's receiver has its own stream
+                self.ctx, self.ctx_rx = ctx, capi.Ctx(local_rank)
+                xs, _ = synth.qpsk_baseband(period, sps, seed=shard.capture_seed() + 1000 * idx, rms=1.0, snr_db=20.0)
+                self.d_in = self.ctx.alloc(B * 8)
+                dp = self.ctx.upload(xs)
+                for r in range(reps):
+                    capi.check(capi.lib.lsdr_memcpy_d2d(self.ctx.h, self.d_in.at(r * period * 8), dp.ptr, period * 8))
+                self.ctx.sync()
+                dp.free()
+                self.dec = [self.ctx.alloc(n_out_max * 8), self.ctx.alloc(n_out_max * 8)]
+                self.d_sym = self.ctx.alloc((n_out_max + 256) * 4)
+                self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0)
+                self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=args.tile_warmup, **rx_kw)
+                a = capi.CstlnReceiver(self.ctx, mode=capi.RX_SERIAL, **rx_kw)     # acquisition on the head of this capture
+                _, p0 = self.fir.run_dev(self.d_in.ptr, min(B, 1 << 22), self.dec[0].ptr, n_out_max)
+                self.ctx.sync()
+                a.run_dev(self.dec[0].ptr, p0, self.d_sym.ptr, n_out_max + 256, meas=False)
+                self.rx.set_state(a.state())
+                a.close()
+                self.ev_fir = [self.ctx.event(), self.ctx.event()]
+                self.ev_rx = [self.ctx_rx.event(), self.ctx_rx.event()]
+            self.pool, self.queued = [], []
+
+        def enqueue(self, k):
+            i = k & 1
+            while len(self.pool) < 2 * (k + 1):
+                self.pool.append(self.ctx.event())
+            if k >= 2:
+                self.ctx.wait_event(self.ev_rx[i])                 # dec[i] is free once receiver run k-2 has read it
+            self.ctx.event_record(self.pool[2 * k])
+            cons, prod = self.fir.run_dev(self.d_in.ptr, B, self.dec[i].ptr, n_out_max)
+            self.ctx.event_record(self.pool[2 * k + 1])
+            self.ctx.event_record(self.ev_fir[i])
+            self.rx.ctx.wait_event(self.ev_fir[i])
+            self.rx.run_async(self.dec[i].ptr, prod, self.d_sym.ptr, n_out_max + 256)
+            self.rx.ctx.event_record(self.ev_rx[i])
+            self.queued.append(i)
+            return cons
+
+        def retire(self, timed, keep=2):
+            while len(self.queued) > keep:
+                self.queued.pop(0)
+                nprod = self.rx.wait()
+                if timed:
+                    nsym[0] += nprod
+
+        def close(self):
+            if self.idx:
+                self.fir.close(); self.rx.close()
+                self.d_in.free(); self.dec[0].free(); self.dec[1].free(); self.d_sym.free()
+                self.ctx_rx.close()
+
+    n_captures = args.captures if (overlap and args.rx_mode == "tiled") else 1
+    lanes = [Lane(c) for c in range(n_captures)]
+
     def run_steps(k_steps, timed):
         consumed = 0
         if not overlap:
@@ -178,36 +247,18 @@ def main():
             # Queued receiver runs (lsdr_rx_run_async): the host only enqueues.  Per step: fir_filter(k) on the fir
             # stream (after the receiver has released that decimated buffer), cstln_receiver(k) on the rx stream
             # (after fir_filter(k)); results are retired two steps later, so the GPU never waits for the host.
-            queued = []
-            while len(ev_pool) < 2 * k_steps:
-                ev_pool.append(ctx.event())
             for k in range(k_steps):
-                i = k & 1
-                if k >= 2:
-                    ctx.wait_event(ev_rx[i])                 # dec[i] is free once receiver run k-2 has read it
-                ctx.event_record(ev_pool[2 * k])
-                cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)
-                ctx.event_record(ev_pool[2 * k + 1])
-                ctx.event_record(ev_fir[i])
-                consumed += cons
-                rx.ctx.wait_event(ev_fir[i])
-                rx.run_async(dec[i].ptr, prod, d_sym.ptr, n_out_max + 256)
-                rx.ctx.event_record(ev_rx[i])
-                queued.append(i)
-                if len(queued) > 2:
-                    j = queued.pop(0)
-                    nprod = rx.wait()
-                    if timed:
-                        nsym[0] += nprod
-            while queued:
-                queued.pop(0)
-                nprod = rx.wait()
-                if timed:
-                    nsym[0] += nprod
+                for ln in lanes:
+                    consumed += ln.enqueue(k)
+                for ln in lanes:
+                    ln.retire(timed)
+            for ln in lanes:
+                ln.retire(timed, keep=0)
             if timed:
                 ctx.sync()
-                for k in range(k_steps):   # HIP events around every fir_filter launch, on its own stream
-                    fir_ms.append(ctx.event_elapsed_ms(ev_pool[2 * k], ev_pool[2 * k + 1]))
+                for ln in lanes:
+                    for k in range(k_steps):   # HIP events around every fir_filter launch, on its own stream
+                        fir_ms.append(ln.ctx.event_elapsed_ms(ln.pool[2 * k], ln.pool[2 * k + 1]))
             return consumed
         pending = None                      # (buffer index, produced) of the batch waiting for the receiver
         for k in range(k_steps + 1):
@@ -230,12 +281,16 @@ def main():
             pending = cur
         return consumed
 
+    def sync_all():
+        for ln in lanes:
+            ln.ctx.sync(); ln.rx.ctx.sync()
+
     run_steps(args.warmup, False)
-    ctx.sync(); rx.ctx.sync()
+    sync_all()
     barrier()
     t0 = time.perf_counter()
     consumed = run_steps(args.steps, True)
-    ctx.sync(); rx.ctx.sync()
+    sync_all()
     barrier()
     dt = time.perf_counter() - t0
 
@@ -261,11 +316,11 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident; "
                                    "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
-                       "batch_samples_per_gpu": B, "rx_mode": args.rx_mode,
+                       "batch_samples_per_gpu": B * n_captures, "captures_per_gpu": n_captures, "rx_mode": args.rx_mode,
                        "streams": "fir_filter(k+1) || cstln_receiver(k) on two HIP streams, receiver runs queued (lsdr_rx_run_async)" if overlap else "single stream",
                        "rx_tile": {"tile_len": args.tile_len, "warmup": args.tile_warmup},
                        "rx_tiles": rx.tiled_stats() if args.rx_mode == "tiled" else None,
-                       "parallelism": f"{world} independent capture(s), one per GPU, no collectives",
+                       "parallelism": f"{world * n_captures} independent capture(s), {n_captures} per GPU, no collectives",
                        "symbols_per_step": nsym[0] // max(1, args.steps)},
             "roofline": {"kernel": "k_fir (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
@@ -276,6 +331,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(x, coeffs, decim, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
+    for ln in lanes:
+        ln.close()
     fir.close(); rx.close(); ctx_rx.close()
     d_in.free(); d_dec.free(); d_sym.free()
     if d_dec2 is not None:

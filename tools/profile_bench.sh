@@ -1,6 +1,7 @@
 #!/bin/bash
 # tools/profile_bench.sh — the measurement set behind bench.py's `roofline` object, run on the GPU box:
-#   gpurun_out/prof/bench.json, bench_no_overlap.json         the bench line (streams overlapped / fir_filter alone)
+#   gpurun_out/prof/bench.json, bench_one_capture.json, bench_no_overlap.json   the bench line (default: 3 captures per GPU /
+#                                                              one capture / one capture, fir_filter and receiver back to back)
 #   gpurun_out/prof/kernel_stats.csv                           rocprofv3 --kernel-trace --stats of the same command
 #   gpurun_out/prof/pmc_fetch_size.csv, pmc_write_size.csv     one PMC counter per pass (rows of the fir kernel only)
 # Copy what is to be judged into profiles/ afterwards (gpurun_out/ is scratch).
@@ -10,6 +11,7 @@ OUT=$REPO/gpurun_out/prof
 mkdir -p "$OUT"
 cd "$REPO"
 timeout 300 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
+timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu --captures 1 > "$OUT/bench_one_capture.json" 2>> "$OUT/bench.err"
 timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu --no-overlap > "$OUT/bench_no_overlap.json" 2>> "$OUT/bench.err"
 export TMPDIR=/tmp
 cd /tmp
