@@ -184,7 +184,7 @@ def main():
                 dp.free()
                 self.dec = [self.ctx.alloc(n_out_max * 8), self.ctx.alloc(n_out_max * 8)]
                 self.d_sym = self.ctx.alloc((n_out_max + 256) * 4)
-                self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0)
+                self.fir = fir                                          # one filter object: every capture goes through the same launch
                 self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=args.tile_warmup, **rx_kw)
                 a = capi.CstlnReceiver(self.ctx, mode=capi.RX_SERIAL, **rx_kw)     # acquisition on the head of this capture
                 _, p0 = self.fir.run_dev(self.d_in.ptr, min(B, 1 << 22), self.dec[0].ptr, n_out_max)
@@ -194,23 +194,7 @@ def main():
                 a.close()
                 self.ev_fir = [self.ctx.event(), self.ctx.event()]
                 self.ev_rx = [self.ctx_rx.event(), self.ctx_rx.event()]
-            self.pool, self.queued = [], []
-
-        def enqueue(self, k):
-            i = k & 1
-            while len(self.pool) < 2 * (k + 1):
-                self.pool.append(self.ctx.event())
-            if k >= 2:
-                self.ctx.wait_event(self.ev_rx[i])                 # dec[i] is free once receiver run k-2 has read it
-            self.ctx.event_record(self.pool[2 * k])
-            cons, prod = self.fir.run_dev(self.d_in.ptr, B, self.dec[i].ptr, n_out_max)
-            self.ctx.event_record(self.pool[2 * k + 1])
-            self.ctx.event_record(self.ev_fir[i])
-            self.rx.ctx.wait_event(self.ev_fir[i])
-            self.rx.run_async(self.dec[i].ptr, prod, self.d_sym.ptr, n_out_max + 256)
-            self.rx.ctx.event_record(self.ev_rx[i])
-            self.queued.append(i)
-            return cons
+            self.queued = []
 
         def retire(self, timed, keep=2):
             while len(self.queued) > keep:
@@ -221,7 +205,7 @@ def main():
 
         def close(self):
             if self.idx:
-                self.fir.close(); self.rx.close()
+                self.rx.close()
                 self.d_in.free(); self.dec[0].free(); self.dec[1].free(); self.d_sym.free()
                 self.ctx_rx.close()
 
@@ -247,18 +231,34 @@ def main():
             # Queued receiver runs (lsdr_rx_run_async): the host only enqueues.  Per step: fir_filter(k) on the fir
             # stream (after the receiver has released that decimated buffer), cstln_receiver(k) on the rx stream
             # (after fir_filter(k)); results are retired two steps later, so the GPU never waits for the host.
+            while len(ev_pool) < 2 * k_steps:
+                ev_pool.append(ctx.event())
             for k in range(k_steps):
+                i = k & 1
+                if k >= 2:
+                    for ln in lanes:
+                        ctx.wait_event(ln.ev_rx[i])              # dec[i] of every capture is free once its receiver run k-2 has read it
+                ctx.event_record(ev_pool[2 * k])
+                if len(lanes) == 1:
+                    cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)
+                else:                                            # one launch filters batch k of every capture
+                    cons, prod = fir.run_multi_dev([ln.d_in.ptr for ln in lanes], B, [ln.dec[i].ptr for ln in lanes], n_out_max)
+                ctx.event_record(ev_pool[2 * k + 1])
+                ctx.event_record(ev_fir[i])
+                consumed += cons * len(lanes)
                 for ln in lanes:
-                    consumed += ln.enqueue(k)
+                    ln.rx.ctx.wait_event(ev_fir[i])
+                    ln.rx.run_async(ln.dec[i].ptr, prod, ln.d_sym.ptr, n_out_max + 256)
+                    ln.rx.ctx.event_record(ln.ev_rx[i])
+                    ln.queued.append(i)
                 for ln in lanes:
                     ln.retire(timed)
             for ln in lanes:
                 ln.retire(timed, keep=0)
             if timed:
                 ctx.sync()
-                for ln in lanes:
-                    for k in range(k_steps):   # HIP events around every fir_filter launch, on its own stream
-                        fir_ms.append(ln.ctx.event_elapsed_ms(ln.pool[2 * k], ln.pool[2 * k + 1]))
+                for k in range(k_steps):       # HIP events around every fir_filter launch, on its own stream
+                    fir_ms.append(ctx.event_elapsed_ms(ev_pool[2 * k], ev_pool[2 * k + 1]))
             return consumed
         pending = None                      # (buffer index, produced) of the batch waiting for the receiver
         for k in range(k_steps + 1):
@@ -297,8 +297,8 @@ def main():
     total, dt, _ = shard.aggregate(consumed, dt)   # all ranks' samples ÷ the slowest rank's time
 
     if rank == 0:
-        per_launch_samples = (n_out_max * decim)           # input samples one fir launch processes
-        alg_bytes = per_launch_samples * 8 + n_out_max * 8  # cf32 in + cf32 out
+        per_launch_samples = (n_out_max * decim) * n_captures           # input samples one fir launch processes (all captures)
+        alg_bytes = per_launch_samples * 8 + n_out_max * n_captures * 8  # cf32 in + cf32 out
         fir_avg_ms = float(np.mean(fir_ms))
         achieved = alg_bytes / (fir_avg_ms * 1e-3) / 1e9
         out = {
@@ -317,14 +317,15 @@ def main():
             "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident; "
                                    "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
                        "batch_samples_per_gpu": B * n_captures, "captures_per_gpu": n_captures, "rx_mode": args.rx_mode,
-                       "streams": "fir_filter(k+1) || cstln_receiver(k) on two HIP streams, receiver runs queued (lsdr_rx_run_async)" if overlap else "single stream",
+                       "streams": ("fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k), one HIP stream per capture, "
+                                   "receiver runs queued (lsdr_rx_run_async)") if overlap else "single stream",
                        "rx_tile": {"tile_len": args.tile_len, "warmup": args.tile_warmup},
                        "rx_tiles": rx.tiled_stats() if args.rx_mode == "tiled" else None,
                        "parallelism": f"{world * n_captures} independent capture(s), {n_captures} per GPU, no collectives",
                        "symbols_per_step": nsym[0] // max(1, args.steps)},
             "roofline": {"kernel": "k_fir (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(B), "avg_launch_ms": round(fir_avg_ms, 4),
+                         "traffic": pmc_traffic(B * n_captures), "avg_launch_ms": round(fir_avg_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if not args.no_cpu and world == 1:   # reported at N=1 only

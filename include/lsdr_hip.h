@@ -184,6 +184,11 @@ int lsdr_fir_filter_get_shifted_coeffs(const lsdr_fir_filter *f, lsdr_cf32 *shif
  * Output m = Σ_i sc[i]·in[ncoeffs + m·decim − i].  Asynchronous on the ctx stream. */
 int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
                         size_t *consumed, size_t *produced);
+/* The same filter over n_streams (≤ 8) equal-length, independent buffers in ONE launch (no reference counterpart: the
+ * reference has one fir_filter object per stream; this is the batched form of n_streams identical run() calls — same
+ * consumed/produced for each, one prologue and one tail of the persistent kernel instead of n_streams). */
+int lsdr_fir_filter_run_multi(lsdr_fir_filter *f, unsigned n_streams, const void *const *ins, size_t n_in,
+                              lsdr_cf32 *const *outs, size_t cap_out, size_t *consumed, size_t *produced);
 
 /* ---------------------------------------------------------- cstln_receiver
  * cstln_receiver<f32> + sampler_interface<f32>, sdr.h:589-938. */

@@ -160,6 +160,7 @@ _sig("lsdr_fir_filter_track", C.c_int, [vp, c_f, c_f, c_f, C.POINTER(C.c_int)])
 _sig("lsdr_fir_filter_current_freq", c_f, [vp])
 _sig("lsdr_fir_filter_get_shifted_coeffs", C.c_int, [vp, vp])
 _sig("lsdr_fir_filter_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_fir_filter_run_multi", C.c_int, [vp, C.c_uint, C.POINTER(vp), c_sz, C.POINTER(vp), c_sz, psz, psz])
 _sig("lsdr_rx_create", C.c_int, [vp, C.POINTER(RxCfg), C.POINTER(vp)])
 _sig("lsdr_rx_destroy", None, [vp])
 _sig("lsdr_rx_readahead", C.c_int, [vp])
@@ -388,6 +389,15 @@ class FirFilter:
     def run_dev(self, in_ptr, n_in, out_ptr, cap_out):
         cons, prod = c_sz(), c_sz()
         check(lib.lsdr_fir_filter_run(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run_multi_dev(self, in_ptrs, n_in, out_ptrs, cap_out):
+        """The same filter over several equal-length device buffers in one launch; returns (consumed, produced) per buffer."""
+        n = len(in_ptrs)
+        ins = (vp * n)(*[vp(p) if not isinstance(p, vp) else p for p in in_ptrs])
+        outs = (vp * n)(*[vp(p) if not isinstance(p, vp) else p for p in out_ptrs])
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_fir_filter_run_multi(self.h, n, ins, n_in, outs, cap_out, C.byref(cons), C.byref(prod)))
         return cons.value, prod.value
 
     def run(self, x):

@@ -56,6 +56,11 @@ struct fir_args {
   unsigned long long count;      // outputs to produce
   unsigned long long n_in;       // input samples available
   unsigned n_tiles, tiles_per_xcd;
+  // lsdr_fir_filter_run_multi (persistent kernels): the same filter over n_streams equal-length buffers in one launch;
+  // global tile g = stream·tiles_per_stream + local tile.  n_streams = 1: in/out above.
+  unsigned n_streams, tiles_per_stream;
+  const void *ins[8];
+  float2 *outs[8];
   float in_scale;        // 1.0f → none
   unsigned long long *trace;   // LSDR_FIR_TRACE builds: per-wave phase cycle sums
 };
@@ -274,10 +279,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
   // 0.0, which is exactly the "finite filler" the zero-padded taps need.
   constexpr unsigned ES = IN_FMT == LSDR_IN_CU8 ? 2u : 8u;
   auto issue = [&](unsigned tile, int k_lo, int k_hi) {
-    const unsigned long long j0 = (unsigned long long)tile * M * D;
+    const unsigned st = tile / a.tiles_per_stream, lt = tile - st * a.tiles_per_stream;
+    const unsigned long long j0 = (unsigned long long)lt * M * D;
     const unsigned long long bytes = (a.n_in - j0) * ES;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char *>(reinterpret_cast<const char *>(a.in)) + j0 * ES, 0,
+        const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + j0 * ES, 0,
         (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
     const unsigned voff = l * ES;
 #pragma unroll
@@ -341,13 +347,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
     }
 
     LSDR_TR(4)
-    const unsigned long long m0 = (unsigned long long)tile * M;
+    const unsigned st = tile / a.tiles_per_stream;
+    const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * M;
     const unsigned long long rem = a.count - m0;
     const unsigned mv = rem < M ? (unsigned)rem : M;
+    float2 *const po = a.outs[st];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       unsigned lm = l + r * kThreads;
-      if (lm < mv) a.out[m0 + lm] = make_float2(accr[r], acci[r]);
+      if (lm < mv) po[m0 + lm] = make_float2(accr[r], acci[r]);
     }
     LSDR_TR(5)
     if (!more) break;
@@ -565,9 +573,9 @@ int lsdr_fir_filter_get_shifted_coeffs(const lsdr_fir_filter *f, lsdr_cf32 *out)
   return LSDR_OK;
 }
 
-int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
-                        size_t *consumed, size_t *produced) {
-  LSDR_ARG(f && consumed && produced);
+static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *const *ins, size_t n_in, lsdr_cf32 *const *outs,
+                           size_t cap_out, size_t *consumed, size_t *produced) {
+  LSDR_ARG(f && consumed && produced && n_streams >= 1 && n_streams <= 8);
   *consumed = 0;
   *produced = 0;
   const unsigned N = f->cfg.ncoeffs, D = f->cfg.decim;
@@ -575,11 +583,23 @@ int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf
   size_t count = (n_in - N) / D;
   if (count > cap_out) count = cap_out;
   if (!count) return LSDR_OK;
-  LSDR_ARG(in && out);
+  LSDR_ARG(ins && outs);
+  for (unsigned i = 0; i < n_streams; ++i) LSDR_ARG(ins[i] && outs[i]);
+  if (n_streams > 1 && !(f->spec && f->persist)) {   // only the persistent kernels take several buffers per launch
+    for (unsigned i = 0; i < n_streams; ++i) {
+      int rc = fir_run_streams(f, 1, ins + i, n_in, outs + i, cap_out, consumed, produced);
+      if (rc) return rc;
+    }
+    return LSDR_OK;
+  }
+  const void *in = ins[0];
+  lsdr_cf32 *out = outs[0];
 
   fir_args a;
   a.in = in;
   a.out = (float2 *)out;
+  a.n_streams = n_streams;
+  for (unsigned i = 0; i < 8; ++i) { a.ins[i] = i < n_streams ? ins[i] : nullptr; a.outs[i] = i < n_streams ? (float2 *)outs[i] : nullptr; }
   a.sc = f->d_sc;
   a.rc = f->d_rc;
   a.scp = f->d_scp;
@@ -590,7 +610,9 @@ int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf
   a.n_in = n_in;
   const unsigned M = kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
-  LSDR_ARG(n_tiles < (1ull << 31));
+  LSDR_ARG(n_tiles * n_streams < (1ull << 31));
+  a.tiles_per_stream = (unsigned)n_tiles;
+  n_tiles *= n_streams;
   a.n_tiles = (unsigned)n_tiles;
   a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
   a.in_scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
@@ -622,6 +644,16 @@ int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf
   *produced = count;
   *consumed = count * D;
   return LSDR_OK;
+}
+
+int lsdr_fir_filter_run(lsdr_fir_filter *f, const void *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
+                        size_t *consumed, size_t *produced) {
+  return fir_run_streams(f, 1, &in, n_in, &out, cap_out, consumed, produced);
+}
+
+int lsdr_fir_filter_run_multi(lsdr_fir_filter *f, unsigned n_streams, const void *const *ins, size_t n_in, lsdr_cf32 *const *outs,
+                              size_t cap_out, size_t *consumed, size_t *produced) {
+  return fir_run_streams(f, n_streams, ins, n_in, outs, cap_out, consumed, produced);
 }
 
 }  // extern "C"
