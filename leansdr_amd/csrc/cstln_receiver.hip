@@ -665,7 +665,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   }
   if (r->tiles_cap < n_tiles) {
     (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part);
-    LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + 1023) / 1024) * sizeof(rx_seam_part)));
+    LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + kSeamBlock - 1) / kSeamBlock) * sizeof(rx_seam_part)));
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
     r->tiles_cap = n_tiles;
@@ -731,7 +731,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  hipLaunchKernelGGL((k_rx_seam<rx_tile_info, lsdr_softsymbol>), dim3((n_tiles + 1023) / 1024), dim3(1024), 0, c->stream,
+  hipLaunchKernelGGL((k_rx_seam<rx_tile_info, lsdr_softsymbol>), dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
                      (const rx_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, R, quad, r->d_part,
                      (const lsdr_softsymbol *)r->d_stage, stage_stride, (const lsdr_softsymbol *)r->d_wstage, sym_per_chunk,
                      (const uint8_t *)r->d_relabel);

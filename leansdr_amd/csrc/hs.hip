@@ -489,7 +489,7 @@ static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8
     (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part);
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(fq_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
-    LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + 1023) / 1024) * sizeof(rx_seam_part)));
+    LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + kSeamBlock - 1) / kSeamBlock) * sizeof(rx_seam_part)));
     r->tiles_cap = n_tiles;
   }
   if (r->stage_cap < (size_t)n_tiles * stage_stride) {
@@ -513,7 +513,7 @@ static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8
   if (a.freq_window < 8) a.freq_window = 8;
   const unsigned blocks = 1 + (n_tiles - 1 + kFqLanes - 1) / kFqLanes;
   hipLaunchKernelGGL(k_fastqpsk_tiles, dim3(blocks), dim3(64), 0, c->stream, a);
-  hipLaunchKernelGGL((k_rx_seam<fq_tile_info, unsigned char>), dim3((n_tiles + 1023) / 1024), dim3(1024), 0, c->stream,
+  hipLaunchKernelGGL((k_rx_seam<fq_tile_info, unsigned char>), dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
                      (const fq_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, 4, 16384.0f, r->d_part,
                      (const unsigned char *)r->d_stage, stage_stride, (const unsigned char *)r->d_wstage, sym_per_chunk,
                      (const uint8_t *)r->d_relabel);

@@ -78,23 +78,25 @@ __device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur
 }
 
 // Seam pass, two kernels, no single-workgroup scan:
-//  k_rx_seam     one block per 1024 consecutive tiles: evaluates the seams, block-local exclusive scan of
+//  k_rx_seam     one block per kSeamBlock consecutive tiles (256: four wavefronts, one per SIMD — a 1024-thread block needs
+//                16 free wave slots on ONE CU at once and was seen waiting 0.3 ms for them next to the persistent fir kernel): evaluates the seams, block-local exclusive scan of
 //                (symbol count, quadrant step) → fix[] holds block-local offsets, part[] the block totals;
 //  k_rx_compact  one wavefront per tile: adds the (≤ a few dozen) preceding block totals, applies the seam
 //                fix-ups and the quadrant relabelling while copying the tile's symbols to their final place.
 //                Block 0 also leaves the run's totals in *res and rotates the carried carrier phase back into
 //                the frame of tile 0, so the next queued run continues with the same symbol labelling.
+constexpr unsigned kSeamBlock = 256, kSeamWaves = kSeamBlock / 64;
 struct rx_seam_part { unsigned long long cnt; unsigned rot, ndup, nmiss, nbad; };
 
 template <typename INFO, typename SYM>
-__global__ __launch_bounds__(1024) void k_rx_seam(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
                                                   int R, float quad, rx_seam_part *part, const SYM *stage, unsigned stage_stride,
                                                   const SYM *wstage, unsigned wstride, const uint8_t *relabel) {
   const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
-  __shared__ unsigned long long s_cnt[16];
-  __shared__ unsigned s_rot[16], s_d[16], s_m[16], s_b[16];
+  __shared__ unsigned long long s_cnt[kSeamWaves];
+  __shared__ unsigned s_rot[kSeamWaves], s_d[kSeamWaves], s_m[kSeamWaves], s_b[kSeamWaves];
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const unsigned j = blockIdx.x * 1024 + tid;
+  const unsigned j = blockIdx.x * kSeamBlock + tid;
   long long add = 0;
   unsigned k = 0, ins = 0, drp = 0, bad = 0;
   if (j < n_tiles) {
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(1024) void k_rx_seam(const INFO *info, rx_tile_fix 
   }
   if (tid == 0) {
     rx_seam_part p; p.cnt = 0; p.rot = 0; p.ndup = 0; p.nmiss = 0; p.nbad = 0;
-    for (int i = 0; i < 16; ++i) { p.cnt += s_cnt[i]; p.rot = (p.rot + s_rot[i]) & rmask; p.ndup += s_d[i]; p.nmiss += s_m[i]; p.nbad += s_b[i]; }
+    for (unsigned i = 0; i < kSeamWaves; ++i) { p.cnt += s_cnt[i]; p.rot = (p.rot + s_rot[i]) & rmask; p.ndup += s_d[i]; p.nmiss += s_m[i]; p.nbad += s_b[i]; }
     part[blockIdx.x] = p;
   }
 }
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(64) void k_rx_compact(const SYM *stage, unsigned st
   const unsigned j = blockIdx.x;
   if (j >= n_tiles) return;
   const unsigned rmask = (unsigned)R - 1;
-  const unsigned nparts = (n_tiles + 1023) / 1024, mypart = j / 1024;
+  const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock, mypart = j / kSeamBlock;
   // preceding block totals (lane-parallel, then wave-reduced; nparts is tiny)
   unsigned long long base = 0;
   unsigned brot = 0;
