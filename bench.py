@@ -153,11 +153,13 @@ def main():
     # blocks inside the timed region; the pipeline is drained before the clock stops.
     overlap = not args.no_overlap
     d_dec2 = ctx.alloc(n_out_max * 8) if overlap else None
-    dec = [d_dec, d_dec2]
-    ev_fir = [ctx.event(), ctx.event()]
+    NBUF = 3 if (overlap and args.rx_mode == "tiled") else 2   # decimated-stream buffers per capture (queued receiver: three)
+    d_dec3 = ctx.alloc(n_out_max * 8) if NBUF == 3 else None
+    dec = [d_dec, d_dec2] + ([d_dec3] if NBUF == 3 else [])
+    ev_fir = [ctx.event() for _ in range(3)]
     e0 = [ctx.event(), ctx.event()]
     e1 = [ctx.event(), ctx.event()]
-    ev_rx = [ctx_rx.event(), ctx_rx.event()]
+    ev_rx = [ctx_rx.event() for _ in range(3)]
     ev_pool = []
     fir_ms = []
     nsym = [0]
@@ -182,7 +184,7 @@ def main():
                     capi.check(capi.lib.lsdr_memcpy_d2d(self.ctx.h, self.d_in.at(r * period * 8), dp.ptr, period * 8))
                 self.ctx.sync()
                 dp.free()
-                self.dec = [self.ctx.alloc(n_out_max * 8), self.ctx.alloc(n_out_max * 8)]
+                self.dec = [self.ctx.alloc(n_out_max * 8) for _ in range(NBUF)]
                 self.d_sym = self.ctx.alloc((n_out_max + 256) * 4)
                 self.fir = fir                                          # one filter object: every capture goes through the same launch
                 self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=args.tile_warmup, **rx_kw)
@@ -192,8 +194,8 @@ def main():
                 a.run_dev(self.dec[0].ptr, p0, self.d_sym.ptr, n_out_max + 256, meas=False)
                 self.rx.set_state(a.state())
                 a.close()
-                self.ev_fir = [self.ctx.event(), self.ctx.event()]
-                self.ev_rx = [self.ctx_rx.event(), self.ctx_rx.event()]
+                self.ev_fir = [self.ctx.event() for _ in range(3)]
+                self.ev_rx = [self.ctx_rx.event() for _ in range(3)]
             self.queued = []
 
         def retire(self, timed, keep=2):
@@ -206,7 +208,9 @@ def main():
         def close(self):
             if self.idx:
                 self.rx.close()
-                self.d_in.free(); self.dec[0].free(); self.dec[1].free(); self.d_sym.free()
+                self.d_in.free(); self.d_sym.free()
+                for d in self.dec:
+                    d.free()
                 self.ctx_rx.close()
 
     n_captures = args.captures if (overlap and args.rx_mode == "tiled") else 1
@@ -234,10 +238,10 @@ def main():
             while len(ev_pool) < 2 * k_steps:
                 ev_pool.append(ctx.event())
             for k in range(k_steps):
-                i = k & 1
-                if k >= 2:
+                i = k % NBUF
+                if k >= NBUF:
                     for ln in lanes:
-                        ctx.wait_event(ln.ev_rx[i])              # dec[i] of every capture is free once its receiver run k-2 has read it
+                        ctx.wait_event(ln.ev_rx[i])              # dec[i] of every capture is free once its receiver run k-NBUF has read it
                 ctx.event_record(ev_pool[2 * k])
                 if len(lanes) == 1:
                     cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)
@@ -338,6 +342,8 @@ def main():
     d_in.free(); d_dec.free(); d_sym.free()
     if d_dec2 is not None:
         d_dec2.free()
+    if d_dec3 is not None:
+        d_dec3.free()
     ctx.close()
     shard.close()
 
