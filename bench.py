@@ -163,6 +163,7 @@ def main():
     ev_pool = []
     fir_ms = []
     nsym = [0]
+    dbg = []
 
     class Lane:
         """One capture: input in HBM, fir_filter on its own stream, cstln_receiver on another, double-buffered decimated
@@ -238,10 +239,14 @@ def main():
             while len(ev_pool) < 2 * k_steps:
                 ev_pool.append(ctx.event())
             for k in range(k_steps):
+                _t_step = time.perf_counter()
                 i = k % NBUF
-                if k >= NBUF:
+                # dec[i] of every capture is free once its receiver run k-NBUF has read it.  With three buffers that run has
+                # already been retired on the host (at most two runs stay queued), so no GPU-side wait is needed — and none is
+                # wanted: an event recorded on a receiver stream sits behind whatever else shares its hardware queue.
+                if k >= NBUF and NBUF < 3:
                     for ln in lanes:
-                        ctx.wait_event(ln.ev_rx[i])              # dec[i] of every capture is free once its receiver run k-NBUF has read it
+                        ctx.wait_event(ln.ev_rx[i])
                 ctx.event_record(ev_pool[2 * k])
                 if len(lanes) == 1:
                     cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)
@@ -255,8 +260,12 @@ def main():
                     ln.rx.run_async(ln.dec[i].ptr, prod, ln.d_sym.ptr, n_out_max + 256)
                     ln.rx.ctx.event_record(ln.ev_rx[i])
                     ln.queued.append(i)
+                _t_enq = time.perf_counter()
                 for ln in lanes:
                     ln.retire(timed)
+                if timed and os.environ.get("LSDR_BENCH_DEBUG"):
+                    _t_ret = time.perf_counter()
+                    dbg.append((_t_enq - _t_step, _t_ret - _t_enq))
             for ln in lanes:
                 ln.retire(timed, keep=0)
             if timed:
@@ -298,6 +307,8 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
 
+    if dbg:
+        print("host per step: enqueue %.1f us, blocked in retire %.1f us" % (1e6 * np.mean([d[0] for d in dbg]), 1e6 * np.mean([d[1] for d in dbg])), file=sys.stderr)
     total, dt, _ = shard.aggregate(consumed, dt)   # all ranks' samples ÷ the slowest rank's time
 
     if rank == 0:
