@@ -163,7 +163,13 @@ int lsdr_event_create(lsdr_ctx *c, lsdr_event **ev) {
   LSDR_ARG(c && ev);
   lsdr_event *e = new lsdr_event();
   e->ctx = c;
-  LSDR_HIP(hipEventCreate(&e->ev));
+  // Timing stays enabled (bench.py measures launches with these); the release at the event is agent-scope — every consumer is a
+  // kernel on the same device — unless LSDR_EVENT_SYSTEM_FENCE asks for the default system-scope fence.
+  {
+    const char *sf = getenv("LSDR_EVENT_SYSTEM_FENCE");
+    if (sf && atoi(sf)) LSDR_HIP(hipEventCreate(&e->ev));
+    else LSDR_HIP(hipEventCreateWithFlags(&e->ev, hipEventDisableSystemFence));
+  }
   *ev = e;
   return LSDR_OK;
 }
