@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="run fir_filter and cstln_receiver back to back on one stream (default: two HIP streams, "
                          "fir_filter of batch k+1 overlaps cstln_receiver of batch k)")
-    ap.add_argument("--captures", type=int, default=3,
+    ap.add_argument("--captures", type=int, default=6,
                     help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles; "
                          "tiled receiver with overlapped streams only); a step is then one batch of every capture")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
