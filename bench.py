@@ -4,24 +4,38 @@
 Workload at N=1 ("configs[1]"): leandvb DVB-S QPSK 1/2, Fs = 240 MS/s cf32 input at
 120 samples/symbol, device-resident synthetic signal:
     scaler(x75, fused) -> fir_filter(N=313, D=30) -> cstln_receiver(omega=4, linear sampler)
-One step = one pass of that hot path over one batch of `--batch-msamples` Mi input samples
-(the receiver's loop state is carried from step to step, as on an endless stream).
-`value` = input IQ samples consumed per second over all ranks (inputs already in HBM).
+
+The input of every capture is ONE ENDLESS STREAM: the synthetic signal is circular with period B (one batch), every
+batch consumes exactly B samples (fir_filter keeps its N-sample history by reading N + 128·D samples past the batch end,
+the receiver consumes exactly B/D decimated samples and carries its loop state on the device), so batch k+1 continues
+where batch k stopped — no restart, no dropped samples, no timing jump at batch boundaries.
+
+A *step* is `--batches-per-step` batches (default 48 ≈ 50 ms of GPU work) of every capture, so that the driver's
+`--steps 20` times ≈ 1 s and the clocks settle.  `value` = input IQ samples consumed per second over all ranks (inputs
+already in HBM).
+
+After the clock stops the LAST batch of the timed region is verified against the CPU oracle (`verified` in the JSON
+line): the fir_filter output bit for bit, the soft symbols against the oracle's serial receiver started from the very
+loop state the device used for that batch (snapshot taken in stream order), under the tolerance of the tiled mode
+(tests/test_gpu_rx_tiled.py).
 
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+`--gpus N` without a launcher starts the N ranks itself.  N>1: independent captures, one process per GPU, no data-path
+collective, no RCCL (gloo carries the barrier and three scalars) -> weak scaling.
 
-N>1: independent captures, one per GPU, no data-path collective -> weak scaling.
-
-Extra JSON objects: `roofline` for the dominant kernel (fir_filter; algorithmic bytes =
-8 B read per input sample + 8/30 B written) timed with HIP events on the
-kernel's own stream, and `cpu_baseline` = the oracle (plain-C port of the reference)
-timed on this host's cores on a bounded sample of the same workload.
+Extra JSON objects: `roofline` for the dominant kernel (fir_filter; algorithmic bytes = 8 B read per input sample +
+8/30 B written) timed with HIP events on the kernel's own stream, `cpu_baseline` = the reference's blocks
+(oracle/_ref, or the plain-C oracle) timed on this host's cores on a bounded sample of the same workload, and `more` =
+the other configurations (single stream, carrier offset, full chain ...), each measured after the headline region.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -31,6 +45,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 FS, FM, ROLLOFF, REJ = 240e6, 2e6, 0.35, 10.0
+EXTRA = 128                # decimated samples fir_filter produces past the batch end (receiver read-ahead)
+
+# tolerance of the tiled receiver against the exact serial loop started from the same state
+TOL = dict(min_equal_decisions=0.999, max_mean_abs_dcost=0.05 * 11236)
 
 
 def c2_filter(capi):
@@ -43,279 +61,332 @@ def c2_filter(capi):
     return capi.lowpass(order, fcut), decim
 
 
-def cpu_baseline(x, coeffs, decim, budget_s):
-    """CPU baseline over a bounded sample, single thread: scaler -> fir_filter -> cstln_receiver.  When the real reference
-    was built (oracle/_ref/libleansdr_ref.so: the reference's own headers behind oracle/ref_harness.cc) it is what gets
-    timed (kind "reference"); otherwise the plain-C oracle (kind "port").  Test infrastructure used as a yardstick only."""
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as po
+    return po
+
+
+def cpu_baseline(x, coeffs, decim, budget_s):
+    """CPU baseline over a bounded sample: scaler -> fir_filter -> cstln_receiver on independent streams, one per thread
+    (the reference is single-threaded by design; `nproc` processes is how it scales).  When the real reference was built
+    (oracle/_ref/libleansdr_ref.so: the reference's own headers behind oracle/ref_harness.cc) it is what gets timed (kind
+    "reference"); otherwise the plain-C oracle (kind "port").  Test infrastructure used as a yardstick only."""
+    po = _oracle()
     use_ref = po.have_ref()
-    O = po.Ref() if use_ref else po.Oracle()
     p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=1 << 20)
-    n_done, t0 = 0, time.perf_counter()
-    passes = 0
-    while True:
-        xs = O.scaler(75.0, x)
-        y = O.fir_filter(coeffs, decim, xs)
-        y = y[0] if isinstance(y, tuple) else y
-        O.rx(p, y)
-        n_done += len(x)
-        passes += 1
-        if time.perf_counter() - t0 >= budget_s:
-            break
-    dt = time.perf_counter() - t0
+
+    def worker(seconds, out, idx):
+        O = po.Ref() if use_ref else po.Oracle()
+        n_done, t0 = 0, time.perf_counter()
+        while True:
+            xs = O.scaler(75.0, x)
+            y = O.fir_filter(coeffs, decim, xs)
+            y = y[0] if isinstance(y, tuple) else y
+            O.rx(p, y)
+            n_done += len(x)
+            if time.perf_counter() - t0 >= seconds:
+                break
+        out[idx] = (n_done, time.perf_counter() - t0)
+
+    def run(nthreads, seconds):
+        res = [None] * nthreads
+        th = [threading.Thread(target=worker, args=(seconds, res, i)) for i in range(nthreads)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        wall = time.perf_counter() - t0
+        return sum(r[0] for r in res) / wall / 1e6, wall
+
+    one, w1 = run(1, budget_s * 0.4)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    allc, wn = run(cores, budget_s * 0.6) if cores > 1 else (one, 0.0)
     lib = "oracle/_ref/libleansdr_ref.so (pabr/leansdr blocks, g++ -O3)" if use_ref else "oracle/liblsdr_oracle.so"
-    return dict(value=round(n_done / dt / 1e6, 3), unit="MS/s", cores=1, kind="reference" if use_ref else "port",
-                sample=f"{passes} pass(es) over {len(x)} samples of the same workload, {dt:.1f} s, "
-                       f"{lib} (scaler+fir_filter+cstln_receiver), 1 thread")
+    return dict(value=round(allc, 3), unit="MS/s", cores=cores, kind="reference" if use_ref else "port",
+                one_core=round(one, 3),
+                sample=f"{lib}: scaler+fir_filter+cstln_receiver over {len(x)}-sample passes of the same workload; "
+                       f"1 thread for {w1:.1f} s, then {cores} independent streams (one thread each) for {wn:.1f} s")
 
 
 def pmc_traffic(batch_samples):
-    """HBM bytes per fir_filter launch from the committed rocprofv3 PMC passes (profiles/r01_bench/pmc_traffic.json:
-    FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE corrected ×2 for gfx950 as the microarch guide
-    prescribes).  Counters cannot be read from inside a normal run, so this is the recorded per-launch figure for the
-    same workload; None when the batch size differs from the profiled one."""
-    try:
-        with open(os.path.join(ROOT, "profiles", "r01_bench", "pmc_traffic.json")) as f:
-            d = json.load(f)
-        return d["traffic_bytes_per_launch"] if d["batch_samples"] == batch_samples else None
-    except (OSError, KeyError, ValueError):
-        return None
+    """HBM bytes per fir_filter launch, RECORDED (not measured in this run): the committed rocprofv3 PMC passes under
+    profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE corrected ×2 for gfx950 as the
+    microarch guide prescribes).  Counters cannot be read from inside a normal run; None when the launch size differs
+    from the profiled one."""
+    for d in ("r02_bench", "r01_bench"):
+        try:
+            with open(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")) as f:
+                j = json.load(f)
+            if j["batch_samples"] == batch_samples:
+                return j["traffic_bytes_per_launch"], f"profiles/{d}/pmc_traffic.json"
+        except (OSError, KeyError, ValueError):
+            pass
+    return None, None
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks (torch.distributed.run, rendezvous on 127.0.0.1)."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    return subprocess.call(cmd, env=env)
+
+
+class Capture:
+    """One capture: its endless input in HBM, the decimated-stream buffers, the symbol buffer, its receiver (own HIP
+    stream).  fir_filter of all captures of a GPU goes through ONE launch on the fir stream."""
+
+    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, notch=None):
+        self.capi, self.idx, self.geo = capi, idx, geo
+        period, reps, B, n_out, N, decim = geo["period"], geo["reps"], geo["B"], geo["n_out"], geo["N"], geo["decim"]
+        self.x, _ = synth.qpsk_baseband(period, geo["sps"], seed=seed, rms=1.0, snr_db=20.0, freq=freq)
+        self.ctx = fir_ctx
+        self.ctx_rx = capi.Ctx(device)
+        self.d_in = self.ctx.alloc((B + period) * 8)
+        dp = self.ctx.upload(self.x)
+        for r in range(reps + 1):
+            capi.check(capi.lib.lsdr_memcpy_d2d(self.ctx.h, self.d_in.at(r * period * 8), dp.ptr, period * 8))
+        self.ctx.sync()
+        dp.free()
+        self.dec = [self.ctx.alloc((n_out + EXTRA) * 8) for _ in range(geo["nbuf"])]
+        self.d_sym = self.ctx.alloc((n_out + EXTRA + 256) * 4)
+        self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1], **rx_kw)
+        self.ev_rx = [self.ctx_rx.event() for _ in range(geo["nbuf"])]
+        self.queued = 0
+        self.nsym = 0
+        self.last_produced = 0
+
+    def acquire(self, fir, rx_kw):
+        """The exact serial loop locks on the head of the stream; the tiled (tracking) receiver takes over from that
+        state.  Not timed."""
+        capi, g = self.capi, self.geo
+        acq = capi.CstlnReceiver(self.ctx, mode=capi.RX_SERIAL, **rx_kw)
+        _, p0 = fir.run_dev(self.d_in.ptr, min(g["B"], 1 << 22), self.dec[0].ptr, g["n_out"])
+        self.ctx.sync()
+        acq.run_dev(self.dec[0].ptr, p0, self.d_sym.ptr, g["n_out"] + 256, meas=False)
+        self.rx.set_state(acq.state())
+        acq.close()
+
+    def retire(self, timed, keep):
+        while self.queued > keep:
+            self.queued -= 1
+            self.last_produced = self.rx.wait()
+            if timed:
+                self.nsym += self.last_produced
+
+    def close(self):
+        self.rx.close()
+        self.d_in.free(); self.d_sym.free()
+        for d in self.dec:
+            d.free()
+        self.ctx_rx.close()
+
+
+class C2Pipeline:
+    """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
+
+    def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0):
+        self.capi = capi
+        self.ctx = capi.Ctx(device)
+        coeffs, decim = c2_filter(capi)
+        self.coeffs, self.decim = coeffs, decim
+        N, sps = len(coeffs), int(FS / FM)
+        unit = int(128 * decim * sps // np.gcd(128 * decim, sps))     # batch = whole symbols and whole receiver chunks
+        period = max(1, (period_msamples << 20) // unit) * unit
+        reps = max(1, (batch_msamples << 20) // period)
+        B = period * reps
+        self.geo = dict(period=period, reps=reps, B=B, n_out=B // decim, N=N, decim=decim, sps=sps, nbuf=3)
+        assert B % decim == 0 and (B // decim) % 128 == 0 and EXTRA * decim + N <= period
+        self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0)
+        if freq:
+            self.fir.set_freq(freq)
+        self.rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
+        self.tile = tile
+        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=0.0)
+                     for c in range(n_captures)]
+        for cp in self.caps:
+            cp.acquire(self.fir, self.rx_kw)
+        self.ev_fir = [self.ctx.event() for _ in range(self.geo["nbuf"])]
+        self.ev_pool = []
+        self.fir_ms = []
+        self.batch_no = 0
+        self.snap = None            # (capture, dec buffer index) of the batch whose loop state was snapshotted
+
+    def run(self, n_batches, timed, snapshot_last=False):
+        """Queue n_batches batches of every capture.  Per batch: fir_filter(k) of all captures in one launch on the fir
+        stream, cstln_receiver(k) of each capture on its own stream (after fir_filter(k)); results are retired two
+        batches later, so the GPU never waits for the host; the pipeline is drained before returning."""
+        capi, g, caps = self.capi, self.geo, self.caps
+        B, n_out, N, decim, NBUF = g["B"], g["n_out"], g["N"], g["decim"], g["nbuf"]
+        n_in_fir = B + EXTRA * decim + N
+        while timed and len(self.ev_pool) < 2 * n_batches:
+            self.ev_pool.append(self.ctx.event())
+        consumed = 0
+        for k in range(n_batches):
+            i = self.batch_no % NBUF
+            # dec[i] of every capture is free: its receiver run (batch_no − NBUF) was retired on the host (≤ 2 stay queued)
+            if timed:
+                self.ctx.event_record(self.ev_pool[2 * k])
+            if len(caps) == 1:
+                cons, prod = self.fir.run_dev(caps[0].d_in.ptr, n_in_fir, caps[0].dec[i].ptr, n_out + EXTRA)
+            else:
+                cons, prod = self.fir.run_multi_dev([c.d_in.ptr for c in caps], n_in_fir, [c.dec[i].ptr for c in caps], n_out + EXTRA)
+            if timed:
+                self.ctx.event_record(self.ev_pool[2 * k + 1])
+            self.ctx.event_record(self.ev_fir[i])
+            assert prod == n_out + EXTRA, (prod, n_out)
+            for c in caps:
+                c.ctx_rx.wait_event(self.ev_fir[i])
+                if snapshot_last and k == n_batches - 1 and c.idx == 0:
+                    c.rx.snapshot_async()
+                    self.snap = (0, i)
+                used = c.rx.run_async(c.dec[i].ptr, prod, c.d_sym.ptr, n_out + EXTRA + 256)
+                assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
+                c.queued += 1
+            consumed += B * len(caps)
+            for c in caps:
+                c.retire(timed, keep=2)
+            self.batch_no += 1
+        for c in caps:
+            c.retire(timed, keep=0)
+        if timed:
+            self.ctx.sync()
+            for k in range(n_batches):       # HIP events around every fir_filter launch, on its own stream
+                self.fir_ms.append(self.ctx.event_elapsed_ms(self.ev_pool[2 * k], self.ev_pool[2 * k + 1]))
+        return consumed
+
+    def sync(self):
+        self.ctx.sync()
+        for c in self.caps:
+            c.ctx_rx.sync()
+
+    def verify_last_batch(self):
+        """The last queued batch of capture 0 against the CPU oracle (test infrastructure, used as the checker only):
+        fir_filter output bit for bit; soft symbols vs the oracle's exact serial receiver started from the loop state the
+        device used for this batch."""
+        po = _oracle()
+        O = po.Oracle()
+        capi, g = self.capi, self.geo
+        cp = self.caps[self.snap[0]]
+        B, n_out, N, decim = g["B"], g["n_out"], g["N"], g["decim"]
+        st_dev = cp.rx.snapshot()
+        y = self.ctx.download(cp.dec[self.snap[1]], np.complex64, n_out + EXTRA)
+        sym = self.ctx.download(cp.d_sym, capi.SOFTSYM, cp.last_produced)
+        t0 = time.perf_counter()
+        x_full = np.concatenate([np.tile(cp.x, g["reps"]), cp.x[:EXTRA * decim + N]])
+        if self.fir.current_freq:
+            y_ref = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full), freq=self.fir.current_freq)
+        else:
+            y_ref = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full))
+        y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
+        fir_ok = len(y_ref) == len(y) and y_ref.tobytes() == y.tobytes()
+        st = po.RxState()
+        for k, _ in st._fields_:
+            setattr(st, k, getattr(st_dev, k))
+        p = po.rx_params(sampler=1, cstln=1, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
+        ref = O.rx(p, y_ref, state_in=st)
+        out = dict(capture=0, batch="last batch of the timed region", fir_outputs=int(len(y)), fir_bit_exact=bool(fir_ok),
+                   symbols=int(len(sym)), symbols_oracle=int(len(ref["sym"])), count_equal=bool(len(sym) == len(ref["sym"])),
+                   consumed_equal=bool(ref["consumed"] == n_out))
+        if out["count_equal"]:
+            same = float((sym["symbol"] == ref["sym"]["symbol"]).mean())
+            dcost = float(np.abs(sym["cost"].astype(int) - ref["sym"]["cost"].astype(int)).mean())
+            n0 = max(self.tile) // 4 - 8
+            first = sym["cost"][:n0].tobytes() == ref["sym"]["cost"][:n0].tobytes()
+            out.update(equal_decisions=round(same, 6), mean_abs_dcost=round(dcost, 2), first_tile_bit_exact=bool(first),
+                       tolerance=TOL, checker="oracle/liblsdr_oracle.so (serial receiver from the device's loop state)",
+                       checker_seconds=round(time.perf_counter() - t0, 2))
+            ok = fir_ok and out["consumed_equal"] and first and same >= TOL["min_equal_decisions"] and dcost <= TOL["max_mean_abs_dcost"]
+        else:
+            ok = False
+        out["pass"] = bool(ok)
+        return out
+
+    def roofline(self):
+        g = self.geo
+        n_launch_out = (g["n_out"] + EXTRA) * len(self.caps)
+        alg_bytes = n_launch_out * g["decim"] * 8 + n_launch_out * 8          # cf32 in + cf32 out
+        ms = float(np.mean(self.fir_ms))
+        achieved = alg_bytes / (ms * 1e-3) / 1e9
+        traffic, src = pmc_traffic(g["B"] * len(self.caps))
+        return {"kernel": "k_fir_persist (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "traffic_source": (f"recorded, not measured in this run: {src}" if src else None),
+                "avg_launch_ms": round(ms, 4), "launches_timed": len(self.fir_ms), "algorithmic_bytes_per_launch": alg_bytes}
+
+    def close(self):
+        for c in self.caps:
+            c.close()
+        self.fir.close()
+        self.ctx.close()
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per step per GPU")
-    ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, tiled)")
-    ap.add_argument("--rx-mode", choices=["serial", "tiled"], default=os.environ.get("LSDR_BENCH_RX", "tiled"))
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batches-per-step", type=int, default=48, help="batches of every capture in one step")
+    ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per batch per capture")
+    ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, circular)")
     ap.add_argument("--tile-len", type=int, default=128)
     ap.add_argument("--tile-warmup", type=int, default=256)
-    ap.add_argument("--no-overlap", action="store_true",
-                    help="run fir_filter and cstln_receiver back to back on one stream (default: two HIP streams, "
-                         "fir_filter of batch k+1 overlaps cstln_receiver of batch k)")
     ap.add_argument("--captures", type=int, default=6,
-                    help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles; "
-                         "tiled receiver with overlapped streams only); a step is then one batch of every capture")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+                    help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-more", action="store_true", help="skip the secondary configurations (`more` in the JSON line)")
+    ap.add_argument("--dry-run", action="store_true", help="launch/aggregation plumbing only: no GPU work")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+
     from leansdr_amd.shard import Shard
-    shard = Shard()                       # one process per GPU; torch.distributed (RCCL) only when WORLD_SIZE > 1
+    shard = Shard()                       # one process per GPU; gloo (no RCCL) only when WORLD_SIZE > 1
     rank, local_rank, world = shard.rank, shard.local_rank, shard.world
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+
+    if args.dry_run:
+        shard.barrier()
+        total, dt, _ = shard.aggregate(1000.0 * (rank + 1), 1.0 + rank)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "units": total, "seconds": dt}), flush=True)
+        shard.close()
+        return
 
     import leansdr_amd.capi as capi
     from leansdr_amd import synth
 
-    barrier = shard.barrier
+    if capi.lib.lsdr_device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {capi.lib.lsdr_device_count()} visible")
+    tile = (args.tile_len, args.tile_warmup)
+    pipe = C2Pipeline(capi, synth, local_rank, args.captures, args.batch_msamples, args.period_msamples, tile,
+                      seed0=shard.capture_seed())
+    bps = args.batches_per_step
 
-    ctx = capi.Ctx(local_rank)
-    coeffs, decim = c2_filter(capi)
-    N = len(coeffs)
-
-    # ---- synthetic input, resident in HBM ----------------------------------
-    sps = int(FS / FM)
-    period = (args.period_msamples << 20) // sps * sps
-    reps = max(1, (args.batch_msamples << 20) // period)
-    B = period * reps
-    x, _ = synth.qpsk_baseband(period, sps, seed=shard.capture_seed(), rms=1.0, snr_db=20.0)
-    d_in = ctx.alloc(B * 8)
-    d_per = ctx.upload(x)
-    for r in range(reps):
-        capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * period * 8), d_per.ptr, period * 8))
-    ctx.sync()
-    d_per.free()
-    n_out_max = (B - N) // decim
-    d_dec = ctx.alloc(n_out_max * 8)
-    d_sym = ctx.alloc((n_out_max + 256) * 4)
-
-    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
-    rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
-    ctx_rx = capi.Ctx(local_rank)          # second HIP stream on the same device
-    rx = capi.CstlnReceiver(ctx_rx, mode=capi.RX_TILED if args.rx_mode == "tiled" else capi.RX_SERIAL,
-                            tile_len=args.tile_len, tile_warmup=args.tile_warmup, **rx_kw)
-    if args.rx_mode == "tiled":
-        # Acquisition: the exact serial loop locks on the head of the stream, then the tiled
-        # (tracking) receiver takes over from that state.  Not timed (warm-up happens after it).
-        acq = capi.CstlnReceiver(ctx, mode=capi.RX_SERIAL, **rx_kw)
-        cons0, prod0 = fir.run_dev(d_in.ptr, min(B, 1 << 22), d_dec.ptr, n_out_max)
-        ctx.sync()
-        acq.run_dev(d_dec.ptr, prod0, d_sym.ptr, n_out_max + 256, meas=False)
-        rx.set_state(acq.state())
-        acq.close()
-
-    # Two HIP streams: ctx carries fir_filter, ctx_rx carries cstln_receiver.  The decimated
-    # stream is double-buffered so that fir_filter(batch k+1) runs while cstln_receiver(batch k)
-    # (latency-bound, few wavefronts) is still tracking.  Every batch still goes through both
-    # blocks inside the timed region; the pipeline is drained before the clock stops.
-    overlap = not args.no_overlap
-    d_dec2 = ctx.alloc(n_out_max * 8) if overlap else None
-    NBUF = 3 if (overlap and args.rx_mode == "tiled") else 2   # decimated-stream buffers per capture (queued receiver: three)
-    d_dec3 = ctx.alloc(n_out_max * 8) if NBUF == 3 else None
-    dec = [d_dec, d_dec2] + ([d_dec3] if NBUF == 3 else [])
-    ev_fir = [ctx.event() for _ in range(3)]
-    e0 = [ctx.event(), ctx.event()]
-    e1 = [ctx.event(), ctx.event()]
-    ev_rx = [ctx_rx.event() for _ in range(3)]
-    ev_pool = []
-    fir_ms = []
-    nsym = [0]
-    dbg = []
-
-    class Lane:
-        """One capture: input in HBM, fir_filter on its own stream, cstln_receiver on another, double-buffered decimated
-        stream.  Lane 0 wraps the objects created above; further lanes (--captures) get their own of everything."""
-
-        def __init__(self, idx):
-            self.idx = idx
-            if idx == 0:
-                self.ctx, self.ctx_rx, self.d_in, self.dec, self.d_sym, self.fir, self.rx = ctx, ctx_rx, d_in, dec, d_sym, fir, rx
-                self.ev_fir, self.ev_rx = ev_fir, ev_rx
-            else:
-                # fir_filter of every capture goes through ONE stream (two persistent fir kernels side by side only fight for the
-                # LDS of the same CUs); every capture's receiver has its own stream
-                self.ctx, self.ctx_rx = ctx, capi.Ctx(local_rank)
-                xs, _ = synth.qpsk_baseband(period, sps, seed=shard.capture_seed() + 1000 * idx, rms=1.0, snr_db=20.0)
-                self.d_in = self.ctx.alloc(B * 8)
-                dp = self.ctx.upload(xs)
-                for r in range(reps):
-                    capi.check(capi.lib.lsdr_memcpy_d2d(self.ctx.h, self.d_in.at(r * period * 8), dp.ptr, period * 8))
-                self.ctx.sync()
-                dp.free()
-                self.dec = [self.ctx.alloc(n_out_max * 8) for _ in range(NBUF)]
-                self.d_sym = self.ctx.alloc((n_out_max + 256) * 4)
-                self.fir = fir                                          # one filter object: every capture goes through the same launch
-                self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=args.tile_warmup, **rx_kw)
-                a = capi.CstlnReceiver(self.ctx, mode=capi.RX_SERIAL, **rx_kw)     # acquisition on the head of this capture
-                _, p0 = self.fir.run_dev(self.d_in.ptr, min(B, 1 << 22), self.dec[0].ptr, n_out_max)
-                self.ctx.sync()
-                a.run_dev(self.dec[0].ptr, p0, self.d_sym.ptr, n_out_max + 256, meas=False)
-                self.rx.set_state(a.state())
-                a.close()
-                self.ev_fir = [self.ctx.event() for _ in range(3)]
-                self.ev_rx = [self.ctx_rx.event() for _ in range(3)]
-            self.queued = []
-
-        def retire(self, timed, keep=2):
-            while len(self.queued) > keep:
-                self.queued.pop(0)
-                nprod = self.rx.wait()
-                if timed:
-                    nsym[0] += nprod
-
-        def close(self):
-            if self.idx:
-                self.rx.close()
-                self.d_in.free(); self.d_sym.free()
-                for d in self.dec:
-                    d.free()
-                self.ctx_rx.close()
-
-    n_captures = args.captures if (overlap and args.rx_mode == "tiled") else 1
-    lanes = [Lane(c) for c in range(n_captures)]
-
-    def run_steps(k_steps, timed):
-        consumed = 0
-        if not overlap:
-            for _ in range(k_steps):
-                ctx.event_record(e0[0])
-                cons, prod = fir.run_dev(d_in.ptr, B, d_dec.ptr, n_out_max)
-                ctx.event_record(e1[0])
-                ctx.event_record(ev_fir[0])
-                rx.ctx.wait_event(ev_fir[0])
-                o = rx.run_dev(d_dec.ptr, prod, d_sym.ptr, n_out_max + 256, meas=False)
-                if timed:
-                    fir_ms.append(ctx.event_elapsed_ms(e0[0], e1[0]))
-                    nsym[0] += o["produced"]
-                consumed += cons
-            return consumed
-        if args.rx_mode == "tiled":
-            # Queued receiver runs (lsdr_rx_run_async): the host only enqueues.  Per step: fir_filter(k) on the fir
-            # stream (after the receiver has released that decimated buffer), cstln_receiver(k) on the rx stream
-            # (after fir_filter(k)); results are retired two steps later, so the GPU never waits for the host.
-            while len(ev_pool) < 2 * k_steps:
-                ev_pool.append(ctx.event())
-            for k in range(k_steps):
-                _t_step = time.perf_counter()
-                i = k % NBUF
-                # dec[i] of every capture is free once its receiver run k-NBUF has read it.  With three buffers that run has
-                # already been retired on the host (at most two runs stay queued), so no GPU-side wait is needed — and none is
-                # wanted: an event recorded on a receiver stream sits behind whatever else shares its hardware queue.
-                if k >= NBUF and NBUF < 3:
-                    for ln in lanes:
-                        ctx.wait_event(ln.ev_rx[i])
-                ctx.event_record(ev_pool[2 * k])
-                if len(lanes) == 1:
-                    cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)
-                else:                                            # one launch filters batch k of every capture
-                    cons, prod = fir.run_multi_dev([ln.d_in.ptr for ln in lanes], B, [ln.dec[i].ptr for ln in lanes], n_out_max)
-                ctx.event_record(ev_pool[2 * k + 1])
-                ctx.event_record(ev_fir[i])
-                consumed += cons * len(lanes)
-                for ln in lanes:
-                    ln.rx.ctx.wait_event(ev_fir[i])
-                    ln.rx.run_async(ln.dec[i].ptr, prod, ln.d_sym.ptr, n_out_max + 256)
-                    ln.rx.ctx.event_record(ln.ev_rx[i])
-                    ln.queued.append(i)
-                _t_enq = time.perf_counter()
-                for ln in lanes:
-                    ln.retire(timed)
-                if timed and os.environ.get("LSDR_BENCH_DEBUG"):
-                    _t_ret = time.perf_counter()
-                    dbg.append((_t_enq - _t_step, _t_ret - _t_enq))
-            for ln in lanes:
-                ln.retire(timed, keep=0)
-            if timed:
-                ctx.sync()
-                for k in range(k_steps):       # HIP events around every fir_filter launch, on its own stream
-                    fir_ms.append(ctx.event_elapsed_ms(ev_pool[2 * k], ev_pool[2 * k + 1]))
-            return consumed
-        pending = None                      # (buffer index, produced) of the batch waiting for the receiver
-        for k in range(k_steps + 1):
-            cur = None
-            if k < k_steps:
-                i = k & 1
-                ctx.event_record(e0[i])
-                cons, prod = fir.run_dev(d_in.ptr, B, dec[i].ptr, n_out_max)   # async on the fir stream
-                ctx.event_record(e1[i])
-                ctx.event_record(ev_fir[i])
-                consumed += cons
-                cur = (i, prod)
-            if pending is not None:
-                i, prod = pending
-                rx.ctx.wait_event(ev_fir[i])
-                o = rx.run_dev(dec[i].ptr, prod, d_sym.ptr, n_out_max + 256, meas=False)   # syncs the rx stream
-                if timed:
-                    fir_ms.append(ctx.event_elapsed_ms(e0[i], e1[i]))
-                    nsym[0] += o["produced"]
-            pending = cur
-        return consumed
-
-    def sync_all():
-        for ln in lanes:
-            ln.ctx.sync(); ln.rx.ctx.sync()
-
-    run_steps(args.warmup, False)
-    sync_all()
-    barrier()
+    pipe.run(args.warmup * bps, False)
+    pipe.sync()
+    shard.barrier()
     t0 = time.perf_counter()
-    consumed = run_steps(args.steps, True)
-    sync_all()
-    barrier()
+    consumed = pipe.run(args.steps * bps, True, snapshot_last=(rank == 0 and not args.no_verify))
+    pipe.sync()
+    shard.barrier()
     dt = time.perf_counter() - t0
 
-    if dbg:
-        print("host per step: enqueue %.1f us, blocked in retire %.1f us" % (1e6 * np.mean([d[0] for d in dbg]), 1e6 * np.mean([d[1] for d in dbg])), file=sys.stderr)
     total, dt, _ = shard.aggregate(consumed, dt)   # all ranks' samples ÷ the slowest rank's time
 
+    rc = 0
     if rank == 0:
-        per_launch_samples = (n_out_max * decim) * n_captures           # input samples one fir launch processes (all captures)
-        alg_bytes = per_launch_samples * 8 + n_out_max * n_captures * 8  # cf32 in + cf32 out
-        fir_avg_ms = float(np.mean(fir_ms))
-        achieved = alg_bytes / (fir_avg_ms * 1e-3) / 1e9
+        g = pipe.geo
+        nsym = sum(c.nsym for c in pipe.caps)
         out = {
             "metric": "IQ MSamples/s demodulated (leandvb QPSK 1/2)",
             "value": round(total / dt / 1e6, 3),
@@ -329,34 +400,36 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident; "
+            "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident endless stream; "
                                    "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
-                       "batch_samples_per_gpu": B * n_captures, "captures_per_gpu": n_captures, "rx_mode": args.rx_mode,
-                       "streams": ("fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k), one HIP stream per capture, "
-                                   "receiver runs queued (lsdr_rx_run_async)") if overlap else "single stream",
-                       "rx_tile": {"tile_len": args.tile_len, "warmup": args.tile_warmup},
-                       "rx_tiles": rx.tiled_stats() if args.rx_mode == "tiled" else None,
-                       "parallelism": f"{world * n_captures} independent capture(s), {n_captures} per GPU, no collectives",
-                       "symbols_per_step": nsym[0] // max(1, args.steps)},
-            "roofline": {"kernel": "k_fir (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": pmc_traffic(B * n_captures), "avg_launch_ms": round(fir_avg_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                       "batches_per_step": bps, "batch_samples_per_capture": g["B"], "captures_per_gpu": len(pipe.caps),
+                       "samples_per_step_per_gpu": g["B"] * len(pipe.caps) * bps,
+                       "rx_mode": "tiled", "rx_tile": {"tile_len": tile[0], "warmup": tile[1]},
+                       "rx_tiles_last_run": pipe.caps[0].rx.tiled_stats(),
+                       "streams": "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k), "
+                                  "one HIP stream per capture, receiver runs queued (lsdr_rx_run_async)",
+                       "parallelism": f"{world * len(pipe.caps)} independent capture(s), {len(pipe.caps)} per GPU, no collectives, no RCCL",
+                       "symbols_per_step": nsym // max(1, args.steps)},
+            "roofline": pipe.roofline(),
         }
-        if not args.no_cpu and world == 1:   # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(x, coeffs, decim, args.cpu_seconds)
-        print(json.dumps(out), flush=True)
+        if not args.no_verify:
+            out["verified"] = pipe.verify_last_batch()
+            if not out["verified"]["pass"]:
+                print("bench.py: VERIFICATION FAILED: " + json.dumps(out["verified"]), file=sys.stderr)
+                rc = 3
+        x0 = pipe.caps[0].x
+    coeffs, decim = pipe.coeffs, pipe.decim
+    pipe.close()
 
-    for ln in lanes:
-        ln.close()
-    fir.close(); rx.close(); ctx_rx.close()
-    d_in.free(); d_dec.free(); d_sym.free()
-    if d_dec2 is not None:
-        d_dec2.free()
-    if d_dec3 is not None:
-        d_dec3.free()
-    ctx.close()
+    if rank == 0:
+        if world == 1 and not args.no_more:
+            import bench_more
+            out["more"] = bench_more.run_all(capi, synth, local_rank, args)
+        if not args.no_cpu and world == 1:   # reported at N=1 only
+            out["cpu_baseline"] = cpu_baseline(x0, coeffs, decim, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
     shard.close()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

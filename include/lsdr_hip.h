@@ -63,6 +63,20 @@ int lsdr_memcpy_h2d(lsdr_ctx *ctx, void *dst_dev, const void *src_host, size_t b
 int lsdr_memcpy_d2h(lsdr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* async on ctx stream */
 int lsdr_memcpy_d2d(lsdr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* pipebuf::pack() memmove, framework.h:153-159 (overlap-safe) */
 int lsdr_memset(lsdr_ctx *ctx, void *dst_dev, int value, size_t bytes);
+/* Copy engine of a context — what a pipebuf with ends on both sides of PCIe uses (host framework.h; replaces the plain
+ * `new T[size]` + in-place access of framework.h:133-183 for the file_reader → first GPU block and last GPU block →
+ * file_writer edges of leandvb.cc:205-256,593).  Two side streams, one per direction; `src_host`/`dst_host` should be
+ * pinned (lsdr_malloc_host).
+ *   lsdr_copy_h2d_async  upload on the upload stream; returns at once.
+ *   lsdr_copy_fence      later work on the compute stream waits (on the GPU) for every upload enqueued so far.
+ *   lsdr_copy_d2h_async  download on the download stream, ordered after everything already on the compute stream.
+ *   lsdr_copy_sync_d2h   the host waits for the downloads.
+ *   lsdr_copy_sync_all   the host waits for uploads, compute stream and downloads (pipe compaction). */
+int lsdr_copy_h2d_async(lsdr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int lsdr_copy_d2h_async(lsdr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int lsdr_copy_fence(lsdr_ctx *ctx);
+int lsdr_copy_sync_d2h(lsdr_ctx *ctx);
+int lsdr_copy_sync_all(lsdr_ctx *ctx);
 /* Stream timing for bench.py (HIP events recorded on the ctx stream). */
 int lsdr_timer_start(lsdr_ctx *ctx);
 int lsdr_timer_stop_ms(lsdr_ctx *ctx, float *ms); /* synchronises on the stop event */
@@ -97,6 +111,10 @@ int lsdr_cstln_lut_build(int predef, int fec, int16_t *cost_host, uint8_t *symbo
 /* ------------------------------------------------------ elementwise blocks */
 /* cconverter<u8,128,f32,0,1,1>::run, dsp.h:40-50 */
 int lsdr_cconverter_u8_run(lsdr_ctx *ctx, const lsdr_cu8 *in, size_t n, lsdr_cf32 *out);
+/* cconverter<s8,0,f32,0,1,1>, <u16,32768,f32,0,1,1>, <s16,0,f32,0,1,1>::run (dsp.h:40-50; leandvb --s8 / --u16 / --s16,
+ * leandvb.cc:218-248): `in` is n complex items of the given integer format. */
+enum { LSDR_IN_CS8 = 2, LSDR_IN_CU16 = 3, LSDR_IN_CS16 = 4 };   /* (LSDR_IN_CF32 = 0, LSDR_IN_CU8 = 1: fir_filter's fused formats) */
+int lsdr_cconverter_int_run(lsdr_ctx *ctx, int in_format, const void *in, size_t n, lsdr_cf32 *out);
 /* scaler<float,cf32,cf32>::run, dsp.h:149-156 */
 int lsdr_scaler_run(lsdr_ctx *ctx, float scale, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out);
 /* decimator<cf32>::run, generic.h:256-262; *produced = min(n/d, cap), consumes produced*d */
@@ -244,6 +262,12 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
  * the host never sits between two runs.  lsdr_rx_run / _set_state refuse to mix with outstanding queued runs. */
 int lsdr_rx_run_async(lsdr_rx *rx, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
 int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
+/* Loop-state snapshot between queued runs: lsdr_rx_snapshot_async() puts a copy of the device-side loop state (the fields
+ * of cstln_receiver<f32>, sdr.h:923-935) into a pinned slot in stream order, i.e. the state the NEXT queued run starts
+ * from; lsdr_rx_get_snapshot() waits for the stream and returns it.  Lets a caller (bench.py's verification) replay one
+ * queued run on a checker from exactly the state the device used, without putting the host between two runs. */
+int lsdr_rx_snapshot_async(lsdr_rx *rx);
+int lsdr_rx_get_snapshot(lsdr_rx *rx, lsdr_rx_state *st);
 
 /* ================================================================== DVB-S FEC tail
  * Item layouts: bytes are u8; RS packets 204 B (rspacket<u8>), TS packets 188 B (tspacket). */
@@ -352,6 +376,8 @@ int lsdr_rs_encoder_run(lsdr_ctx *ctx, const uint8_t *in_packets, size_t n_packe
 /* interleaver, dvb.h:899-921: needs 12 packets, consumes n−11 */
 int lsdr_interleaver_run(lsdr_ctx *ctx, const uint8_t *in_packets, size_t n_packets, uint8_t *out_bytes, size_t cap_bytes,
                          size_t *consumed_packets, size_t *produced_bytes);
+/* fec_specs[rate] (dvb.h:553-565): bits entering / leaving the convolutional coder and its generator polynomials. */
+int lsdr_fec_spec(int rate, int *bits_in, int *bits_out, uint16_t polys_host[8]);
 typedef struct lsdr_convol lsdr_convol;                  /* dvb_convol, dvb.h:567-604 (16-bit history carried) */
 int lsdr_convol_create(lsdr_ctx *ctx, int rate, int bits_per_symbol, lsdr_convol **v);
 void lsdr_convol_destroy(lsdr_convol *v);

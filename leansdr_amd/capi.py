@@ -191,6 +191,8 @@ _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
 _sig("lsdr_rx_wait", C.c_int, [vp, psz])
+_sig("lsdr_rx_snapshot_async", C.c_int, [vp])
+_sig("lsdr_rx_get_snapshot", C.c_int, [vp, C.POINTER(RxState)])
 
 #: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [n for n in dir(lib) if n.startswith("lsdr_")]
@@ -455,6 +457,15 @@ class CstlnReceiver:
 
     def set_state(self, st):
         check(lib.lsdr_rx_set_state(self.h, C.byref(st)))
+
+    def snapshot_async(self):
+        """Copy the device-side loop state into the receiver's pinned slot, in stream order (between queued runs)."""
+        check(lib.lsdr_rx_snapshot_async(self.h))
+
+    def snapshot(self):
+        st = RxState()
+        check(lib.lsdr_rx_get_snapshot(self.h, C.byref(st)))
+        return st
 
     def tiled_stats(self):
         v = [C.c_uint() for _ in range(4)]

@@ -63,7 +63,20 @@ struct rx_state_dev {            // sdr.h:923-935 + sampler state
   float hist[12];
 };
 
-struct rx_meas { float freqw, est_insp, est_sp, est_ep; };
+// One measurement instant (sdr.h:905-913).  Serial mode: the estimator values themselves.  Tiled mode: a tile only knows
+// the affine map from "estimators at the start of the tile" to "estimators here" (est ↦ a·est + b, b in the est_* fields);
+// k_rx_ema turns it into values once the maps of the preceding tiles have been composed.
+struct rx_meas { float freqw, est_insp, est_sp, est_ep, a; unsigned tile; };
+
+// The per-chunk estimators est_insp / est_sp / est_ep (sdr.h:867-889) are first-order EMAs with a constant pole: every
+// chunk that produced a symbol applies est ↦ (1−kest)·est + kest·x.  A run of chunks is therefore an affine map, and maps
+// compose associatively — the tiled receiver records one per tile and scans them (k_rx_ema) instead of letting every
+// tile restart its own EMA from the carried value.
+struct rx_ema_map { float a, bi, bs, be; };
+__device__ __forceinline__ rx_ema_map ema_then(rx_ema_map f, rx_ema_map g) {   // g ∘ f (f first)
+  rx_ema_map r; r.a = g.a * f.a; r.bi = g.a * f.bi + g.bi; r.bs = g.a * f.bs + g.bs; r.be = g.a * f.be + g.be;
+  return r;
+}
 
 struct rx_consts {
   float omega, freq_alpha, freq_beta, gain_mu, kest;
@@ -71,6 +84,9 @@ struct rx_consts {
   unsigned long long meas_decimation;
   // fir sampler
   int ncoeffs, subsampling;
+  // tolerance tiles: the first acq_syms symbols of a warm-up run the loops in an acquisition gear
+  int acq_syms;
+  float acq_alpha, acq_gain_mu;
 };
 
 struct rx_tables {
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
       st.meas_count += kChunk;
       while (st.meas_count >= a.C.meas_decimation) {
         st.meas_count -= a.C.meas_decimation;
-        rx_meas m; m.freqw = st.freqw; m.est_insp = st.est_insp; m.est_sp = st.est_sp; m.est_ep = st.est_ep;
+        rx_meas m; m.freqw = st.freqw; m.est_insp = st.est_insp; m.est_sp = st.est_sp; m.est_ep = st.est_ep; m.a = 0.f; m.tile = 0u;
         a.meas[sh_nm++] = m;
       }
     }
@@ -442,81 +458,275 @@ struct rx_tiled_args {
   lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
   unsigned wstride;
   rx_tile_info *info;
-  rx_state_dev *state;                 // in: carried state; out: end state of the last tile
+  rx_ema_map *ema;                     // [n_tiles]: estimator map of each tile's body (k_rx_ema scans them)
+  const rx_state_dev *state;           // carried state at the start of the run (read-only while tiles are running)
+  rx_state_dev *state_next;            // end state of the last tile (k_rx_ema moves it into `state`)
   rx_meas *meas;                       // [n_meas] measurement slots (may be null)
   unsigned long long meas_base;        // meas_count at the start of the run
   rx_consts C;
   rx_tables T;
 };
 
-// One lane per tile.  Tile 0 continues exactly from the carried state (block 0, alone, exact table
-// look-ups); tile j ≥ 1 starts `warm_chunks` early from the carried tracking state with mu = phase = 0
-// and uses the hardware-trig policy.  NT tiles share a wavefront.  The samples are read straight from
-// global memory (two adjacent cf32 per symbol): staging them through LDS was measured to help this kernel
-// alone by ~5 % but its LDS footprint (1 KB per tile) evicts one of fir_filter's two workgroups per CU when
-// the two kernels overlap, which costs far more (fir 0.15 → 0.25 ms per batch).
-template <int SAMP, int NT, typename LD>
-__device__ __forceinline__ void rx_tiles_body(const rx_tiled_args &a, unsigned j0, int lane) {
-  const unsigned long long first = a.first_chunks, Lc = a.tile_chunks, Wc = a.warm_chunks, total = a.total_chunks;
-  if (lane >= NT || j0 + (unsigned)lane >= a.n_tiles) return;
-  const unsigned j = j0 + (unsigned)lane;
-  // chunk range of tile j: warm-up [cb, c0), body [c0, c1)
-  unsigned long long cb, c0, c1;
-  if (j == 0) { cb = 0; c0 = 0; c1 = first; }
-  else { c0 = first + (unsigned long long)(j - 1) * Lc; c1 = c0 + Lc; cb = c0 - Wc; }
-  if (c1 > total) c1 = total;
+// measurement instants that fall into chunk c of the run (sdr.h:905-913: one per meas_decimation samples of the stream)
+__device__ __forceinline__ void rx_tile_meas(const rx_tiled_args &a, unsigned long long c, unsigned tile, float freqw,
+                                             const rx_ema_map &m) {
+  const unsigned long long md = a.C.meas_decimation;
+  const unsigned long long before = (a.meas_base + c * kChunk) / md, after = (a.meas_base + (c + 1) * kChunk) / md;
+  const unsigned long long first_m = a.meas_base / md;
+  for (unsigned long long q = before; q < after; ++q) {
+    rx_meas mm; mm.freqw = freqw; mm.a = m.a; mm.est_insp = m.bi; mm.est_sp = m.bs; mm.est_ep = m.be; mm.tile = tile;
+    a.meas[q - first_m] = mm;
+  }
+}
+
+// Tile 0: continues exactly from the carried state (one lane, the reference's arithmetic, exact table look-ups).
+template <int SAMP>
+__device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
+  unsigned long long c1 = a.first_chunks;
+  if (c1 > a.total_chunks) c1 = a.total_chunks;
   rx_state_dev s = *a.state;
   rx_tile_info ti;
   ti.has_pre = 0; ti.pre.cost = 0; ti.pre.symbol = 0; ti.pre.pad = 0; ti.n_warm = 0;
-  ti.mu_begin = ti.phase_begin = 0.f;
-  lsdr_softsymbol *pw = a.wstage + (unsigned long long)j * a.wstride;
-  if (j > 0) {
-    s.mu = 0.f; s.phase = 0.f;
-    for (int k = 0; k < 12; ++k) s.hist[k] = 0.f;
-  }
-  float fwin = 65536.0f / a.C.omega / 2048.0f;
-  if (fwin < 8.f) fwin = 8.f;
-  const float f_lo = s.freqw - fwin, f_hi = s.freqw + fwin;
-  lsdr_softsymbol last; last.cost = 0; last.symbol = 0; last.pad = 0;
-  lsdr_softsymbol *po = a.stage + (unsigned long long)j * a.stage_stride;
-  unsigned cnt = 0, got = 0;
-  for (unsigned long long c = cb; c < c1; ++c) {
-    const bool body = c >= c0;
-    if (c == c0) {
-      ti.mu_begin = s.mu; ti.phase_begin = s.phase;
-      ti.pre = last; ti.has_pre = got ? 1u : 0u;
-    }
+  ti.mu_begin = s.mu; ti.phase_begin = s.phase;
+  lsdr_softsymbol *po = a.stage;
+  unsigned cnt = 0;
+  rx_ema_map m; m.a = 0.f; m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;   // constant map: the values are exact here
+  for (unsigned long long c = 0; c < c1; ++c) {
     if (SAMP == 1) s.samp_freqw = s.freqw;
     bool wrote;
-    const bool lastwarm = c + 1 == c0;
-    unsigned nw = 0;
-    auto emit = [&](lsdr_softsymbol ss) { if (body) po[cnt++] = ss; else { last = ss; if (lastwarm) pw[nw++] = ss; } };
-    const int n = j == 0 ? rx_chunk<SAMP, LD>(a.T, a.C, s, a.in + c * kChunk, emit, nullptr, &wrote)
-                         : rx_chunk<SAMP, LD, true>(a.T, a.C, s, a.in + c * kChunk, emit, nullptr, &wrote, f_lo, f_hi);
-    if (!body) got += (unsigned)n;
-    if (lastwarm) ti.n_warm = nw;
-    if (body && a.meas) {     // measurements, sdr.h:905-913: one per meas_decimation samples of the stream
-      unsigned long long before = (a.meas_base + c * kChunk) / a.C.meas_decimation;
-      unsigned long long after = (a.meas_base + (c + 1) * kChunk) / a.C.meas_decimation;
-      unsigned long long first_m = a.meas_base / a.C.meas_decimation;
-      for (unsigned long long m = before; m < after; ++m) {
-        rx_meas mm; mm.freqw = s.freqw; mm.est_insp = s.est_insp; mm.est_sp = s.est_sp; mm.est_ep = s.est_ep;
-        a.meas[m - first_m] = mm;
-      }
-    }
+    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, nullptr, &wrote);
+    m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;
+    if (a.meas) rx_tile_meas(a, c, 0u, s.freqw, m);
   }
   ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
-  a.info[j] = ti;
-  if (j == a.n_tiles - 1) {
+  a.info[0] = ti;
+  a.ema[0] = m;
+  if (a.n_tiles == 1) {
     s.meas_count = (a.meas_base + a.total_chunks * kChunk) % a.C.meas_decimation;
-    *a.state = s;
+    *a.state_next = s;
+  }
+}
+
+// Tiles j ≥ 1 (tolerance mode): one lane per tile.  The lane starts `warm_chunks` early from the carried tracking state
+// (freqw, AGC, estimators) with mu = phase = 0, lets the loops converge, then emits its tile.  Same chunk structure and
+// operation order as rx_chunk, with three liberties that the tolerance contract pays for:
+//   * expi() of the 16-bit quantised angle comes from v_cos/v_sin_f32 instead of the 512 KiB table;
+//   * the sample-skipping steps advance the phase by k·freqw in one multiply-add instead of k additions;
+//   * freqw is held inside a small window around the carried value (see rx_chunk's WIN).
+// The per-symbol dependency chain is what bounds this kernel (a tile is 96 dependent symbol steps at the C2 geometry), so
+// it is kept to ONE memory round trip: the constellation gather.  The two samples of the NEXT symbol are requested
+// together with it, as a 3-sample window — the next symbol instant is n + ⌊mu + omega + mucorr⌋ with |mucorr| ≤ 0.1,
+// i.e. one of two adjacent positions — and the soft symbol is stored fire-and-forget (the following wait is for the
+// next iteration's loads, one full symbol step later).  No LDS (fir_filter's two workgroups per CU need it), no scratch.
+template <int SAMP, int NT>
+__device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane) {
+  if (lane >= NT || j0 + (unsigned)lane >= a.n_tiles) return;
+  const unsigned j = j0 + (unsigned)lane;
+  const rx_consts &C = a.C;
+  const unsigned long long c0 = a.first_chunks + (unsigned long long)(j - 1) * a.tile_chunks;
+  unsigned long long c1 = c0 + a.tile_chunks;
+  if (c1 > a.total_chunks) c1 = a.total_chunks;
+  const unsigned long long cb = c0 - a.warm_chunks;
+  const int nwarm = (int)a.warm_chunks, nchunks = (int)(c1 - cb);
+  const int ra = SAMP == 1 ? 1 : 0;
+  const int n_last = nchunks * kChunk - 1 + ra;          // last readable sample of this tile's span
+  const float2 *base = a.in + cb * kChunk;
+
+  const rx_state_dev *S = a.state;                        // carried tracking state (wave-uniform)
+  float freqw = S->freqw, agc = S->agc_gain, est_insp = S->est_insp, est_sp = S->est_sp, est_ep = S->est_ep;
+  const float min_f = S->min_freqw, max_f = S->max_freqw;
+  float fwin = 65536.0f / C.omega / 2048.0f;
+  if (fwin < 8.f) fwin = 8.f;
+  const float f_lo = freqw - fwin, f_hi = freqw + fwin;
+  float mu = 0.f, phase = 0.f;
+  float h0pr = 0.f, h0pi = 0.f, h0cr = 0.f, h0ci = 0.f, h1pr = 0.f, h1pi = 0.f, h1cr = 0.f, h1ci = 0.f;
+  float h2pr = 0.f, h2pi = 0.f, h2cr = 0.f, h2ci = 0.f;
+  const float kk = C.kest, k1 = 1 - C.kest;
+  rx_ema_map m; m.a = 1.f; m.bi = 0.f; m.bs = 0.f; m.be = 0.f;
+
+  rx_tile_info ti;
+  ti.has_pre = 0; ti.pre.cost = 0; ti.pre.symbol = 0; ti.pre.pad = 0; ti.n_warm = 0;
+  ti.mu_begin = ti.phase_begin = 0.f;
+  // a soft symbol is the low dword of its table entry {cost, symbol, 0}: one 4-byte store, always issued (a warm-up
+  // symbol that nobody needs lands in the tile's seam row, which the last warm-up chunk rewrites) so that the number of
+  // stores in flight is the same on every path and the wait for the next symbol's samples need not drain them
+  unsigned last = 0;
+  unsigned *const po = reinterpret_cast<unsigned *>(a.stage + (unsigned long long)j * a.stage_stride);
+  unsigned *const pw = reinterpret_cast<unsigned *>(a.wstage + (unsigned long long)j * a.wstride);
+  unsigned cnt = 0, got = 0;
+
+  int n = 0, wn = 0;                                      // current sample, first sample of the window
+  float2 w0 = base[0], w1 = base[1 < n_last ? 1 : n_last], w2 = base[2 < n_last ? 2 : n_last];
+  *pw = 0u;   // (puts the loop entry in the same "three loads, then one store" state as the loop's back edge: see `*dp = raw.x`)
+  for (int ci = 0; ci < nchunks; ++ci) {
+    const bool body = ci >= nwarm, lastwarm = ci + 1 == nwarm;
+    const int cend = (ci + 1) * kChunk;
+    if (ci == nwarm) {
+      ti.mu_begin = mu; ti.phase_begin = phase;
+      ti.pre.cost = (int16_t)(last & 0xffffu); ti.pre.symbol = (uint8_t)(last >> 16); ti.has_pre = got ? 1u : 0u;
+    }
+    const float samp_freqw = freqw;                       // sampler->update_freq(freqw), sdr.h:790
+    unsigned *dp = body ? po + cnt : pw;
+    const unsigned keep = (body || lastwarm) ? 1u : 0u;
+    bool had = false;
+    float2 sg = make_float2(0.f, 0.f), sv = make_float2(0.f, 0.f);
+    int pt_re = 0, pt_im = 0;
+    unsigned nsym = 0;
+    auto skip = [&]() {
+      if (!(mu < 1.f)) {
+        const int rem = cend - n;
+        int k = (int)mu;
+        if (k < 1 || k > rem) k = rem;                    // (k < 1: NaN — the reference then just walks to the chunk end)
+        mu -= (float)k; n += k; phase += (float)k * freqw;
+      }
+    };
+    skip();
+    while (n < cend) {
+      if ((unsigned)(n - wn) > 1u) {                      // window missed (rare: rounding at the ±0.1 edge): plain loads
+        w0 = base[n]; w1 = base[n + ra]; wn = n;
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0) HERE, so that the common path only waits for its window
+      }
+      const bool second = n != wn;
+      const float2 p0 = second ? w1 : w0, p1 = second ? w2 : w1;
+      const float2 s0 = cmul(p0, ld_hwtrig::expi(a.T, trig_index(-phase)));
+      if (SAMP == 1) {
+        const float2 s1 = cmul(p1, ld_hwtrig::expi(a.T, trig_index(-(phase + samp_freqw))));
+        const float k0 = 1 - mu;
+        sg = make_float2(s0.x * k0 + s1.x * mu, s0.y * k0 + s1.y * mu);
+      } else {
+        sg = s0;
+      }
+      sv = make_float2(sg.x * agc, sg.y * agc);
+      const uint2 raw = *reinterpret_cast<const uint2 *>(a.T.lut + lut_index(sv.x, sv.y));
+      // window for the next symbol: ⌊mu + omega − 0.1⌋ samples ahead (at least one)
+      int lo = (int)(mu + C.omega - 0.1f);
+      lo = lo < 1 ? 1 : lo;
+      const int wn2 = n + lo;
+      const float2 v0 = base[wn2 < n_last ? wn2 : n_last];
+      const float2 v1 = base[wn2 + 1 < n_last ? wn2 + 1 : n_last];
+      const float2 v2 = base[wn2 + 2 < n_last ? wn2 + 2 : n_last];
+      const lut_entry e = lut_unpack(raw.x, raw.y);
+      *dp = raw.x; dp += keep;
+      last = raw.x;
+      ++nsym;
+      const bool acq = (int)(got + nsym) <= C.acq_syms && !body;
+      phase += e.phase_error * (acq ? C.acq_alpha : C.freq_alpha);   // sdr.h:814-815
+      freqw += e.phase_error * C.freq_beta;
+      freqw = freqw < f_lo ? f_lo : freqw; freqw = freqw > f_hi ? f_hi : freqw;
+      h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;  // sdr.h:822-840
+      h1pr = h0pr; h1pi = h0pi; h1cr = h0cr; h1ci = h0ci;
+      h0pr = sv.x; h0pi = sv.y;
+      pt_re = e.pt_re; pt_im = e.pt_im;
+      had = true;
+      h0cr = (float)pt_re; h0ci = (float)pt_im;
+      const float muerr = ((h0pr - h2pr) * h1cr + (h0pi - h2pi) * h1ci) - ((h0cr - h2cr) * h1pr + (h0ci - h2ci) * h1pi);
+      float mucorr = muerr * (acq ? C.acq_gain_mu : C.gain_mu);
+      mucorr = mucorr < -0.1f ? -0.1f : mucorr; mucorr = mucorr > 0.1f ? 0.1f : mucorr;
+      mu += mucorr;
+      mu += C.omega;
+      mu -= 1.f; phase += freqw; ++n;                     // the symbol's own sample step
+      w0 = v0; w1 = v1; w2 = v2; wn = wn2;
+      skip();
+    }
+    phase = fmod65536(phase);                             // sdr.h:855
+    if (had) {
+      const float insp = sg.x * sg.x + sg.y * sg.y;       // sdr.h:867-870
+      est_insp = insp * kk + est_insp * k1;
+      if (est_insp) agc = kCstlnAmp / __builtin_sqrtf(est_insp);
+      const float evr = sv.x - pt_re, evi = sv.y - pt_im; // sdr.h:873-889
+      float sig_power, ev_power;
+      if (C.nsymbols == 2) {
+        const float sig_real = (float)((double)(pt_re + pt_im) * 0.707);
+        const float ev_real = (float)((double)(evr + evi) * 0.707);
+        sig_power = sig_real * sig_real; ev_power = ev_real * ev_real;
+      } else {
+        sig_power = (float)(pt_re * pt_re + pt_im * pt_im);
+        ev_power = evr * evr + evi * evi;
+      }
+      est_sp = sig_power * kk + est_sp * k1;
+      est_ep = ev_power * kk + est_ep * k1;
+      if (body) {
+        m.a *= k1;
+        m.bi = insp * kk + m.bi * k1; m.bs = sig_power * kk + m.bs * k1; m.be = ev_power * kk + m.be * k1;
+      }
+    }
+    if (!C.allow_drift) {                                 // sdr.h:895-898
+      if (freqw < min_f || freqw > max_f) freqw = (max_f + min_f) / 2;
+    }
+    if (body) cnt += nsym; else got += nsym;
+    if (lastwarm) ti.n_warm = nsym;
+    if (body && a.meas) rx_tile_meas(a, cb + (unsigned long long)ci, j, freqw, m);
+  }
+  ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
+  a.info[j] = ti;
+  a.ema[j] = m;
+  if (j == a.n_tiles - 1) {
+    rx_state_dev *o = a.state_next;
+    o->mu = mu; o->phase = phase; o->freqw = freqw; o->agc_gain = agc;
+    o->est_insp = est_insp; o->est_sp = est_sp; o->est_ep = est_ep;
+    o->min_freqw = min_f; o->max_freqw = max_f; o->samp_freqw = freqw; o->update_freq_phase = S->update_freq_phase;
+    o->meas_count = (a.meas_base + a.total_chunks * kChunk) % C.meas_decimation;
+    o->hist[0] = h0pr; o->hist[1] = h0pi; o->hist[2] = h0cr; o->hist[3] = h0ci;
+    o->hist[4] = h1pr; o->hist[5] = h1pi; o->hist[6] = h1cr; o->hist[7] = h1ci;
+    o->hist[8] = h2pr; o->hist[9] = h2pi; o->hist[10] = h2cr; o->hist[11] = h2ci;
   }
 }
 
 template <int SAMP, int NT>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
-  if (blockIdx.x == 0) rx_tiles_body<SAMP, 1, ld_uniform>(a, 0u, (int)threadIdx.x);
-  else rx_tiles_body<SAMP, NT, ld_hwtrig>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
+  if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP>(a); }
+  else rx_tile_tol<SAMP, NT>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
+}
+
+// Scan of the tiles' estimator maps (one workgroup): final estimators/AGC of the run and the measurement slots.
+//  * state ← state_next (end state of the last tile; tiles read `state` while they run, so it is only replaced here),
+//    with est_insp/est_sp/est_ep = (all maps composed)(carried values) and agc_gain = 75/sqrt(est_insp) (sdr.h:870);
+//  * slot q of `meas` holds the partial map of its tile up to the measurement instant: composed with the maps of the
+//    preceding tiles it becomes the estimator values there.
+constexpr unsigned kEmaThreads = 256;
+__global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *tile, unsigned n_tiles, const rx_state_dev *next,
+                                                        rx_state_dev *state, rx_meas *meas, unsigned nm) {
+  __shared__ rx_ema_map s_pre[kEmaThreads];     // composition of everything before thread t's tiles
+  __shared__ rx_ema_map s_wave[kEmaThreads / 64];
+  const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const unsigned per = (n_tiles + kEmaThreads - 1) / kEmaThreads;
+  const unsigned lo = t * per < n_tiles ? t * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  const float e_insp = state->est_insp, e_sp = state->est_sp, e_ep = state->est_ep;   // carried values
+  rx_ema_map m; m.a = 1.f; m.bi = m.bs = m.be = 0.f;
+  for (unsigned i = lo; i < hi; ++i) m = ema_then(m, tile[i]);
+  rx_ema_map inc = m;                            // inclusive scan over the lanes of a wave
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    rx_ema_map o;
+    o.a = __shfl_up(inc.a, d, 64); o.bi = __shfl_up(inc.bi, d, 64); o.bs = __shfl_up(inc.bs, d, 64); o.be = __shfl_up(inc.be, d, 64);
+    if (lane >= (unsigned)d) inc = ema_then(o, inc);
+  }
+  if (lane == 63) s_wave[wv] = inc;
+  __syncthreads();
+  rx_ema_map before; before.a = 1.f; before.bi = before.bs = before.be = 0.f;
+  for (unsigned i = 0; i < wv; ++i) before = ema_then(before, s_wave[i]);
+  rx_ema_map exl;                                // exclusive: lanes before this one in the wave
+  exl.a = __shfl_up(inc.a, 1, 64); exl.bi = __shfl_up(inc.bi, 1, 64); exl.bs = __shfl_up(inc.bs, 1, 64); exl.be = __shfl_up(inc.be, 1, 64);
+  if (lane == 0) { exl.a = 1.f; exl.bi = exl.bs = exl.be = 0.f; }
+  s_pre[t] = ema_then(before, exl);
+  __syncthreads();
+  if (t == kEmaThreads - 1) {
+    const rx_ema_map all = ema_then(s_pre[t], m);
+    rx_state_dev s = *next;
+    s.est_insp = all.a * e_insp + all.bi; s.est_sp = all.a * e_sp + all.bs; s.est_ep = all.a * e_ep + all.be;
+    if (s.est_insp) s.agc_gain = kCstlnAmp / __builtin_sqrtf(s.est_insp);
+    *state = s;
+  }
+  for (unsigned q = t; q < nm; q += kEmaThreads) {
+    rx_meas mm = meas[q];
+    const unsigned j = mm.tile < n_tiles ? mm.tile : 0u, owner = j / per;
+    rx_ema_map pm = s_pre[owner];
+    for (unsigned i = owner * per; i < j; ++i) pm = ema_then(pm, tile[i]);
+    rx_ema_map part; part.a = mm.a; part.bi = mm.est_insp; part.bs = mm.est_sp; part.be = mm.est_ep;
+    const rx_ema_map f = ema_then(pm, part);
+    mm.est_insp = f.a * e_insp + f.bi; mm.est_sp = f.a * e_sp + f.bs; mm.est_ep = f.a * e_ep + f.be;
+    meas[q] = mm;
+  }
 }
 
 }  // namespace
@@ -543,6 +753,9 @@ struct lsdr_rx {
   lsdr_softsymbol *d_stage; size_t stage_cap;
   lsdr_softsymbol *d_wstage; size_t wstage_cap;
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
+  rx_ema_map *d_ema;              // [tiles_cap] per-tile estimator maps
+  rx_state_dev *d_state_next;     // end state of a tiled run before k_rx_ema installs it
+  rx_state_dev *h_snap;           // pinned: lsdr_rx_snapshot_async target
   uint8_t *d_relabel;
   struct rx_seam_result *d_seam;
   struct rx_seam_part *d_part;
@@ -557,6 +770,15 @@ struct lsdr_rx {
   int ring_head, ring_count;           // oldest outstanding slot, number outstanding
   bool st_stale_host;                  // device state newer than the host mirror `st`
 };
+
+static void rx_state_export(const rx_state_dev &s, lsdr_rx_state *st) {
+  st->mu = s.mu; st->phase = s.phase; st->freqw = s.freqw; st->agc_gain = s.agc_gain;
+  st->est_insp = s.est_insp; st->est_sp = s.est_sp; st->est_ep = s.est_ep;
+  st->freq_tap = s.freqw / 65536;  // refresh_freq_tap, sdr.h:919-921
+  st->min_freqw = s.min_freqw; st->max_freqw = s.max_freqw;
+  st->meas_count = s.meas_count;
+  memcpy(st->hist, s.hist, sizeof(st->hist));
+}
 
 // sdr.h:755-770
 static void rx_update_freq_limits(lsdr_rx *r, bool have_cstln) {
@@ -607,6 +829,13 @@ static void rx_fill_consts(const lsdr_rx *r, rx_consts &C, rx_tables &T) {
   C.meas_decimation = r->cfg.meas_decimation;
   C.ncoeffs = r->cfg.ncoeffs;
   C.subsampling = r->cfg.subsampling;
+  {
+    // Acquisition gear of the tolerance tiles' warm-up (tuning hooks; defaults chosen from tools/rx_tol_report.py sweeps)
+    const char *e;
+    C.acq_syms = (e = getenv("LSDR_RX_ACQ_SYMS")) ? atoi(e) : 0;
+    C.acq_alpha = C.freq_alpha * ((e = getenv("LSDR_RX_ACQ_ALPHA")) ? (float)atof(e) : 1.f);
+    C.acq_gain_mu = C.gain_mu * ((e = getenv("LSDR_RX_ACQ_MU")) ? (float)atof(e) : 1.f);
+  }
   T.trig = r->d_trig; T.lut = r->d_lut; T.coeffs = r->d_coeffs; T.shifted = r->d_shifted;
 }
 
@@ -664,7 +893,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
     LSDR_HIP(hipStreamSynchronize(c->stream));
   }
   if (r->tiles_cap < n_tiles) {
-    (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part);
+    (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part); (void)hipFree(r->d_ema);
+    LSDR_HIP(hipMalloc((void **)&r->d_ema, n_tiles * sizeof(rx_ema_map)));
     LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + kSeamBlock - 1) / kSeamBlock) * sizeof(rx_seam_part)));
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
@@ -702,7 +932,9 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   a.stage = r->d_stage;
   a.wstage = r->d_wstage; a.wstride = sym_per_chunk;
   a.info = r->d_info;
+  a.ema = r->d_ema;
   a.state = r->d_state;
+  a.state_next = r->d_state_next;
   a.meas = want_meas ? r->d_meas : nullptr;
   a.meas_base = meas_base;
   rx_fill_consts(r, a.C, a.T);
@@ -727,6 +959,9 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
 #undef LSDR_RX_LAUNCH_S
 #undef LSDR_RX_LAUNCH
   LSDR_HIP(hipGetLastError());
+  // estimators (AGC, MER) of the run: scan of the tiles' maps; installs the end state
+  hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema, n_tiles,
+                     (const rx_state_dev *)r->d_state_next, r->d_state, want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
 
   // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
@@ -866,6 +1101,9 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_cstln = nullptr; r->cstln_cap = 0;
   r->d_stage = nullptr; r->stage_cap = 0;
   r->d_info = nullptr; r->d_fix = nullptr; r->d_part = nullptr; r->tiles_cap = 0;
+  r->d_ema = nullptr; r->h_snap = nullptr;
+  LSDR_HIP(hipMalloc((void **)&r->d_state_next, sizeof(rx_state_dev)));
+  LSDR_HIP(hipHostMalloc((void **)&r->h_snap, sizeof(rx_state_dev), hipHostMallocDefault));
   r->d_wstage = nullptr; r->wstage_cap = 0;
   r->h_res = nullptr; r->ring_head = 0; r->ring_count = 0; r->st_stale_host = false;
   for (int i = 0; i < lsdr_rx::kRing; ++i) r->ev[i] = nullptr;
@@ -908,6 +1146,8 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
   (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part); (void)hipFree(r->d_wstage);
+  (void)hipFree(r->d_ema); (void)hipFree(r->d_state_next);
+  if (r->h_snap) (void)hipHostFree(r->h_snap);
   if (r->h_res) (void)hipHostFree(r->h_res);
   for (int i = 0; i < lsdr_rx::kRing; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
   delete r;
@@ -925,13 +1165,22 @@ int lsdr_rx_readahead(const lsdr_rx *r) {
 int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st) {
   LSDR_ARG(r && st);
   { int rc = rx_pull_state(r); if (rc) return rc; }
-  const rx_state_dev &s = r->st;  // host mirror is refreshed after every run
-  st->mu = s.mu; st->phase = s.phase; st->freqw = s.freqw; st->agc_gain = s.agc_gain;
-  st->est_insp = s.est_insp; st->est_sp = s.est_sp; st->est_ep = s.est_ep;
-  st->freq_tap = s.freqw / 65536;  // refresh_freq_tap, sdr.h:919-921
-  st->min_freqw = s.min_freqw; st->max_freqw = s.max_freqw;
-  st->meas_count = s.meas_count;
-  memcpy(st->hist, s.hist, sizeof(st->hist));
+  rx_state_export(r->st, st);  // host mirror is refreshed after every run
+  return LSDR_OK;
+}
+
+int lsdr_rx_snapshot_async(lsdr_rx *r) {
+  LSDR_ARG(r);
+  LSDR_HIP(hipSetDevice(r->ctx->device));
+  if (r->st_dirty_host) { int rc = rx_push_state(r); if (rc) return rc; }
+  LSDR_HIP(hipMemcpyAsync(r->h_snap, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, r->ctx->stream));
+  return LSDR_OK;
+}
+
+int lsdr_rx_get_snapshot(lsdr_rx *r, lsdr_rx_state *st) {
+  LSDR_ARG(r && st);
+  LSDR_HIP(hipStreamSynchronize(r->ctx->stream));
+  rx_state_export(*r->h_snap, st);
   return LSDR_OK;
 }
 

@@ -52,6 +52,7 @@ int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) {
   hipDeviceProp_t prop;
   LSDR_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount;
+  c->copy_ready = false;
   *out = c;
   return LSDR_OK;
 }
@@ -63,6 +64,11 @@ void lsdr_ctx_destroy(lsdr_ctx *c) {
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipFree(c->bounce);
+  if (c->copy_ready) {
+    (void)hipStreamSynchronize(c->up); (void)hipStreamSynchronize(c->down);
+    (void)hipStreamDestroy(c->up); (void)hipStreamDestroy(c->down);
+    (void)hipEventDestroy(c->ev_up); (void)hipEventDestroy(c->ev_compute);
+  }
   if (c->own_stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -142,6 +148,56 @@ int lsdr_memcpy_d2d(lsdr_ctx *c, void *dst, const void *src, size_t bytes) {
   }
   LSDR_HIP(hipMemcpyAsync(c->bounce, s, bytes, hipMemcpyDeviceToDevice, c->stream));
   LSDR_HIP(hipMemcpyAsync(d, c->bounce, bytes, hipMemcpyDeviceToDevice, c->stream));
+  return LSDR_OK;
+}
+
+// ---- copy engine: host<->device transfers on side streams (north_star: "host<->device double-buffered hipMemcpyAsync on
+// a side stream").  Uploads and downloads have a stream each (PCIe is full duplex); ordering against the compute stream is
+// by events, never by blocking the host, except where a host reader needs the bytes (lsdr_copy_sync_d2h).
+static int copy_engine(lsdr_ctx *c) {
+  if (c->copy_ready) return LSDR_OK;
+  LSDR_HIP(hipSetDevice(c->device));
+  LSDR_HIP(hipStreamCreateWithFlags(&c->up, hipStreamNonBlocking));
+  LSDR_HIP(hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking));
+  LSDR_HIP(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+  LSDR_HIP(hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
+  c->copy_ready = true;
+  return LSDR_OK;
+}
+int lsdr_copy_h2d_async(lsdr_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  { int rc = copy_engine(c); if (rc) return rc; }
+  LSDR_HIP(hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->up));
+  return LSDR_OK;
+}
+int lsdr_copy_d2h_async(lsdr_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  { int rc = copy_engine(c); if (rc) return rc; }
+  LSDR_HIP(hipEventRecord(c->ev_compute, c->stream));          // after the kernels that produce the bytes
+  LSDR_HIP(hipStreamWaitEvent(c->down, c->ev_compute, 0));
+  LSDR_HIP(hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->down));
+  return LSDR_OK;
+}
+int lsdr_copy_fence(lsdr_ctx *c) {
+  LSDR_ARG(c);
+  if (!c->copy_ready) return LSDR_OK;
+  LSDR_HIP(hipEventRecord(c->ev_up, c->up));
+  LSDR_HIP(hipStreamWaitEvent(c->stream, c->ev_up, 0));
+  return LSDR_OK;
+}
+int lsdr_copy_sync_d2h(lsdr_ctx *c) {
+  LSDR_ARG(c);
+  if (!c->copy_ready) return LSDR_OK;
+  LSDR_HIP(hipStreamSynchronize(c->down));
+  return LSDR_OK;
+}
+int lsdr_copy_sync_all(lsdr_ctx *c) {
+  LSDR_ARG(c);
+  if (c->copy_ready) { LSDR_HIP(hipStreamSynchronize(c->up)); }
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  if (c->copy_ready) { LSDR_HIP(hipStreamSynchronize(c->down)); }
   return LSDR_OK;
 }
 

@@ -88,6 +88,27 @@ __global__ __launch_bounds__(kBlock) void k_rotate(const float2 *__restrict__ in
 
 }  // namespace
 
+// cconverter<s8,0,f32,0,1,1>, <u16,32768,f32,0,1,1>, <s16,0,f32,0,1,1> (leandvb --s8/--u16/--s16, leandvb.cc:218-248):
+// out = 0 + (in − Zin)·1/1 in int arithmetic, then int → float (dsp.h:46-47).  One scalar component per lane-step,
+// 4 components (two complex samples) per lane: coalesced 4/8-byte loads, 16-byte stores.
+template <typename Tin, int Zin>
+__global__ __launch_bounds__(kBlock) void k_cconv_int(const Tin *__restrict__ in, size_t ncomp, float *__restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  const size_t nvec = ncomp / 4;
+  for (size_t v = (size_t)blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+    Tin r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = in[v * 4 + k];
+    float4 o;
+    o.x = (float)((int)r[0] - (int)(Tin)Zin); o.y = (float)((int)r[1] - (int)(Tin)Zin);
+    o.z = (float)((int)r[2] - (int)(Tin)Zin); o.w = (float)((int)r[3] - (int)(Tin)Zin);
+    if ((((uintptr_t)out) & 15) == 0) *reinterpret_cast<float4 *>(out + v * 4) = o;
+    else { out[v * 4] = o.x; out[v * 4 + 1] = o.y; out[v * 4 + 2] = o.z; out[v * 4 + 3] = o.w; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < ncomp - nvec * 4)
+    out[nvec * 4 + threadIdx.x] = (float)((int)in[nvec * 4 + threadIdx.x] - (int)(Tin)Zin);
+}
+
 extern "C" {
 
 int lsdr_cconverter_u8_run(lsdr_ctx *c, const lsdr_cu8 *in, size_t n, lsdr_cf32 *out) {
@@ -95,6 +116,20 @@ int lsdr_cconverter_u8_run(lsdr_ctx *c, const lsdr_cu8 *in, size_t n, lsdr_cf32 
   if (!n) return LSDR_OK;
   hipLaunchKernelGGL(k_cconv_u8, dim3(grid_for(c, n / 4 + 1)), dim3(kBlock), 0, c->stream,
                      (const uint8_t *)in, n, (float *)out);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
+
+int lsdr_cconverter_int_run(lsdr_ctx *c, int in_format, const void *in, size_t n, lsdr_cf32 *out) {
+  LSDR_ARG(c && (n == 0 || (in && out)));
+  if (!n) return LSDR_OK;
+  const dim3 g(grid_for(c, n / 2 + 1)), b(kBlock);
+  switch (in_format) {
+    case LSDR_IN_CS8: hipLaunchKernelGGL((k_cconv_int<int8_t, 0>), g, b, 0, c->stream, (const int8_t *)in, 2 * n, (float *)out); break;
+    case LSDR_IN_CU16: hipLaunchKernelGGL((k_cconv_int<uint16_t, 32768>), g, b, 0, c->stream, (const uint16_t *)in, 2 * n, (float *)out); break;
+    case LSDR_IN_CS16: hipLaunchKernelGGL((k_cconv_int<int16_t, 0>), g, b, 0, c->stream, (const int16_t *)in, 2 * n, (float *)out); break;
+    default: lsdr_set_error("cconverter: unsupported input format %d", in_format); return LSDR_E_ARG;
+  }
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }

@@ -15,6 +15,10 @@ struct lsdr_ctx {
   int num_cu;
   void *bounce;          // scratch of lsdr_memcpy_d2d for overlapping ranges (pipebuf::pack)
   size_t bounce_cap;
+  // copy engine (lsdr_copy_*): one upload and one download stream next to the compute stream, created on first use
+  hipStream_t up, down;
+  hipEvent_t ev_up, ev_compute;
+  bool copy_ready;
 };
 
 struct lsdr_event {

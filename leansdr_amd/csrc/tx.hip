@@ -256,12 +256,9 @@ int lsdr_interleaver_run(lsdr_ctx *c, const uint8_t *in_packets, size_t n_packet
   return LSDR_OK;
 }
 
-int lsdr_convol_create(lsdr_ctx *c, int rate, int bits_per_symbol, lsdr_convol **out) {
-  LSDR_ARG(c && out && bits_per_symbol >= 1 && bits_per_symbol <= 8);
+int lsdr_fec_spec(int rate, int *bits_in, int *bits_out, uint16_t polys_host[8]) {   // fec_specs, dvb.h:553-565
   static const unsigned short G1 = 0171, G2 = 0133;
-  lsdr_convol *v = new lsdr_convol();
-  v->ctx = c; v->bps = bits_per_symbol; v->hist = 0;
-  const unsigned short p12[] = {G1, G2}, p23[] = {G1, G2, (unsigned short)(G2 << 1)},
+  static const unsigned short p12[] = {G1, G2}, p23[] = {G1, G2, (unsigned short)(G2 << 1)},
                        p46[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2), (unsigned short)(G2 << 2), (unsigned short)(G2 << 3)},
                        p34[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2)},
                        p45[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G1 << 2), (unsigned short)(G1 << 3)},
@@ -269,18 +266,31 @@ int lsdr_convol_create(lsdr_ctx *c, int rate, int bits_per_symbol, lsdr_convol *
                        p78[] = {G1, G2, (unsigned short)(G2 << 1), (unsigned short)(G2 << 2), (unsigned short)(G2 << 3), (unsigned short)(G1 << 4),
                                 (unsigned short)(G2 << 5), (unsigned short)(G1 << 6)};
   const unsigned short *p = nullptr;
-  switch (rate) {   // fec_specs, dvb.h:556-566
-    case LSDR_FEC12: v->bits_in = 1; v->bits_out = 2; p = p12; break;
-    case LSDR_FEC23: v->bits_in = 2; v->bits_out = 3; p = p23; break;
-    case LSDR_FEC46: v->bits_in = 4; v->bits_out = 6; p = p46; break;
-    case LSDR_FEC34: v->bits_in = 3; v->bits_out = 4; p = p34; break;
-    case LSDR_FEC56: v->bits_in = 5; v->bits_out = 6; p = p56; break;
-    case LSDR_FEC78: v->bits_in = 7; v->bits_out = 8; p = p78; break;
-    case LSDR_FEC45: v->bits_in = 4; v->bits_out = 5; p = p45; break;
-    default: delete v; lsdr_set_error("dvb_convol: Unexpected FEC"); return LSDR_E_ARG;
+  int bi = 0, bo = 0;
+  switch (rate) {
+    case LSDR_FEC12: bi = 1; bo = 2; p = p12; break;
+    case LSDR_FEC23: bi = 2; bo = 3; p = p23; break;
+    case LSDR_FEC46: bi = 4; bo = 6; p = p46; break;
+    case LSDR_FEC34: bi = 3; bo = 4; p = p34; break;
+    case LSDR_FEC56: bi = 5; bo = 6; p = p56; break;
+    case LSDR_FEC78: bi = 7; bo = 8; p = p78; break;
+    case LSDR_FEC45: bi = 4; bo = 5; p = p45; break;
+    default: lsdr_set_error("fec_spec: Unexpected FEC"); return LSDR_E_ARG;
   }
+  if (bits_in) *bits_in = bi;
+  if (bits_out) *bits_out = bo;
+  if (polys_host) for (int i = 0; i < 8; ++i) polys_host[i] = i < bo ? p[i] : 0;
+  return LSDR_OK;
+}
+
+int lsdr_convol_create(lsdr_ctx *c, int rate, int bits_per_symbol, lsdr_convol **out) {
+  LSDR_ARG(c && out && bits_per_symbol >= 1 && bits_per_symbol <= 8);
+  lsdr_convol *v = new lsdr_convol();
+  v->ctx = c; v->bps = bits_per_symbol; v->hist = 0;
+  uint16_t p[8];
+  if (lsdr_fec_spec(rate, &v->bits_in, &v->bits_out, p) != LSDR_OK) { delete v; lsdr_set_error("dvb_convol: Unexpected FEC"); return LSDR_E_ARG; }
   if (v->bits_out % v->bps) { delete v; lsdr_set_error("dvb_convol: Code rate not suitable for this constellation"); return LSDR_E_ARG; }
-  for (int i = 0; i < 8; ++i) v->polys[i] = i < v->bits_out ? p[i] : 0;
+  for (int i = 0; i < 8; ++i) v->polys[i] = p[i];
   *out = v;
   return LSDR_OK;
 }

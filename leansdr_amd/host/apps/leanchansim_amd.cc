@@ -30,7 +30,7 @@ struct drifter<float> : runnable {
   unsigned long chunk;
 
   drifter(scheduler *s, pipebuf<cf32> &src, pipebuf<cf32> &dst)
-      : runnable(s, "drifter"), chunk(4096), ctx_(pipe_ctx(src.dev, dst.dev, "drifter: pipebufs must be device pipebufs of one ctx")),
+      : runnable(s, "drifter"), chunk(4096), ctx_(pipe_ctx(src, dst, "drifter: pipebufs must be device pipebufs of one ctx")),
         from_(src), to_(dst), handle_(NULL), seen_(0) {
     for (int i = 0; i < NCOMPONENTS; ++i) drifts[i].amp = drifts[i].freq = 0;
     lsdr_check(lsdr_drifter_create(ctx_, &handle_), name);
@@ -49,8 +49,8 @@ struct drifter<float> : runnable {
 
  private:
   lsdr_ctx *ctx_;
-  pipereader<cf32> from_;
-  pipewriter<cf32> to_;
+  dev_reader<cf32> from_;
+  dev_writer<cf32> to_;
   lsdr_drifter *handle_;
   unsigned long seen_;
 };

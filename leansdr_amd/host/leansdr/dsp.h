@@ -1,7 +1,7 @@
 // leansdr_amd/host/leansdr/dsp.h — DSP blocks with the reference's class surface
 // (dsp.h:33-54 cconverter, :140-160 scaler, :219-285 fir_filter) whose run() is one
-// call through the C ABI into the HIP kernels.  All pipebufs of these blocks live
-// in HBM (constructed with the lsdr_ctx).  There is no CPU implementation here.
+// call through the C ABI into the HIP kernels.  These blocks attach to the DEVICE side
+// of their pipebufs (dev_reader / dev_writer).  There is no CPU implementation here.
 #ifndef LEANSDR_AMD_DSP_H
 #define LEANSDR_AMD_DSP_H
 
@@ -10,11 +10,6 @@
 
 namespace leansdr {
 
-inline lsdr_ctx *pipe_ctx(lsdr_ctx *a, lsdr_ctx *b, const char *who) {
-  if (!a || a != b) fail(who);
-  return a;
-}
-
 // cconverter<u8,128,f32,0,1,1>: the only instantiation leandvb uses (leandvb.cc:215).
 template <typename Tin, int Zin, typename Tout, int Zout, int Gn, int Gd>
 struct cconverter;
@@ -22,7 +17,7 @@ struct cconverter;
 template <>
 struct cconverter<u8, 128, float, 0, 1, 1> : runnable {
   cconverter(scheduler *sch, pipebuf<complex<u8> > &i, pipebuf<complex<float> > &o)
-      : runnable(sch, "cconverter"), ctx(pipe_ctx(i.dev, o.dev, "cconverter: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i, o, "cconverter: pipebufs of two device contexts")),
         in(i), out(o) {}
   void run() {
     unsigned long count = min(in.readable(), out.writable());
@@ -34,8 +29,41 @@ struct cconverter<u8, 128, float, 0, 1, 1> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<complex<u8> > in;
-  pipewriter<complex<float> > out;
+  dev_reader<complex<u8> > in;
+  dev_writer<complex<float> > out;
+};
+
+// cconverter<s8,0,…>, <u16,32768,…>, <s16,0,…> → f32: the other input formats of leandvb (leandvb.cc:218-248).
+namespace detail {
+template <typename Tin, int FMT>
+struct int_cconverter : runnable {
+  int_cconverter(scheduler *sch, pipebuf<complex<Tin> > &i, pipebuf<complex<float> > &o)
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i, o, "cconverter: pipebufs of two device contexts")), in(i), out(o) {}
+  void run() {
+    unsigned long count = min(in.readable(), out.writable());
+    if (!count) return;
+    lsdr_check(lsdr_cconverter_int_run(ctx, FMT, in.rd(), count, (lsdr_cf32 *)out.wr()), name);
+    in.read(count);
+    out.written(count);
+  }
+
+ private:
+  lsdr_ctx *ctx;
+  dev_reader<complex<Tin> > in;
+  dev_writer<complex<float> > out;
+};
+}  // namespace detail
+template <>
+struct cconverter<s8, 0, float, 0, 1, 1> : detail::int_cconverter<s8, LSDR_IN_CS8> {
+  cconverter(scheduler *sch, pipebuf<complex<s8> > &i, pipebuf<complex<float> > &o) : detail::int_cconverter<s8, LSDR_IN_CS8>(sch, i, o) {}
+};
+template <>
+struct cconverter<u16, 32768, float, 0, 1, 1> : detail::int_cconverter<u16, LSDR_IN_CU16> {
+  cconverter(scheduler *sch, pipebuf<complex<u16> > &i, pipebuf<complex<float> > &o) : detail::int_cconverter<u16, LSDR_IN_CU16>(sch, i, o) {}
+};
+template <>
+struct cconverter<s16, 0, float, 0, 1, 1> : detail::int_cconverter<s16, LSDR_IN_CS16> {
+  cconverter(scheduler *sch, pipebuf<complex<s16> > &i, pipebuf<complex<float> > &o) : detail::int_cconverter<s16, LSDR_IN_CS16>(sch, i, o) {}
 };
 
 template <typename Tscale, typename Tin, typename Tout>
@@ -45,7 +73,7 @@ template <>
 struct scaler<float, complex<float>, complex<float> > : runnable {
   float scale;
   scaler(scheduler *sch, float s, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o)
-      : runnable(sch, "scaler"), scale(s), ctx(pipe_ctx(i.dev, o.dev, "scaler: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "scaler"), scale(s), ctx(pipe_ctx(i, o, "scaler: pipebufs of two device contexts")),
         in(i), out(o) {}
   void run() {
     unsigned long count = min(in.readable(), out.writable());
@@ -57,8 +85,8 @@ struct scaler<float, complex<float>, complex<float> > : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<complex<float> > in;
-  pipewriter<complex<float> > out;
+  dev_reader<complex<float> > in;
+  dev_writer<complex<float> > out;
 };
 
 // fir_filter<cf32,float> — same constructor and public tracking members as dsp.h:219-285.
@@ -76,7 +104,7 @@ struct fir_filter<complex<float>, float> : runnable {
   fir_filter(scheduler *sch, int ncoeffs, float *coeffs, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o,
              unsigned int decim = 1, float fuse_scale = 0)
       : runnable(sch, "fir_filter"), freq_tap(NULL), tap_multiplier(1), freq_tol(0.1),
-        ctx(pipe_ctx(i.dev, o.dev, "fir_filter: pipebufs must be device pipebufs of one ctx")), n(ncoeffs), d(decim), in(i), out(o) {
+        ctx(pipe_ctx(i, o, "fir_filter: pipebufs of two device contexts")), n(ncoeffs), d(decim), in(i), out(o) {
     lsdr_fir_filter_cfg cfg;
     cfg.ncoeffs = ncoeffs; cfg.coeffs_host = coeffs; cfg.decim = decim;
     cfg.in_format = LSDR_IN_CF32; cfg.in_scale = fuse_scale; cfg.arith = LSDR_FIR_EXACT;
@@ -101,8 +129,8 @@ struct fir_filter<complex<float>, float> : runnable {
  private:
   lsdr_ctx *ctx;
   unsigned n, d;
-  pipereader<complex<float> > in;
-  pipewriter<complex<float> > out;
+  dev_reader<complex<float> > in;
+  dev_writer<complex<float> > out;
   lsdr_fir_filter *h;
 };
 
@@ -114,7 +142,7 @@ template <>
 struct decimator<complex<float> > : runnable {
   unsigned int d;
   decimator(scheduler *sch, int _d, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o)
-      : runnable(sch, "decimator"), d(_d), ctx(pipe_ctx(i.dev, o.dev, "decimator: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "decimator"), d(_d), ctx(pipe_ctx(i, o, "decimator: pipebufs of two device contexts")),
         in(i), out(o) {}
   void run() {
     unsigned long room = out.writable();
@@ -126,8 +154,8 @@ struct decimator<complex<float> > : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<complex<float> > in;
-  pipewriter<complex<float> > out;
+  dev_reader<complex<float> > in;
+  dev_writer<complex<float> > out;
 };
 
 // fir_resampler<cf32,float> (dsp.h:290-364): polyphase interpolator on device pipebufs (decim must be 1, as in the reference).
@@ -142,7 +170,7 @@ struct fir_resampler<complex<float>, float> : runnable {
   fir_resampler(scheduler *sch, int ncoeffs, float *coeffs, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o, int interp_ = 1,
                 int decim_ = 1)
       : runnable(sch, "fir_resampler"), freq_tap(NULL), tap_multiplier(1), freq_tol(0.1),
-        ctx(pipe_ctx(i.dev, o.dev, "fir_resampler: pipebufs must be device pipebufs of one ctx")), n(ncoeffs), interp(interp_), in(i),
+        ctx(pipe_ctx(i, o, "fir_resampler: pipebufs of two device contexts")), n(ncoeffs), interp(interp_), in(i),
         out(o, interp_), current_freq(0) {
     if (decim_ != 1) fail("fir_resampler: decim not implemented");
     lsdr_check(lsdr_fir_resampler_create(ctx, ncoeffs, coeffs, interp_, &h), name);
@@ -167,8 +195,8 @@ struct fir_resampler<complex<float>, float> : runnable {
   lsdr_ctx *ctx;
   unsigned n;
   int interp;
-  pipereader<complex<float> > in;
-  pipewriter<complex<float> > out;
+  dev_reader<complex<float> > in;
+  dev_writer<complex<float> > out;
   lsdr_fir_resampler *h;
   float current_freq;
 };
@@ -177,7 +205,7 @@ struct fir_resampler<complex<float>, float> : runnable {
 template <>
 struct cconverter<float, 0, u8, 128, 1, 1> : runnable {
   cconverter(scheduler *sch, pipebuf<complex<float> > &i, pipebuf<complex<u8> > &o)
-      : runnable(sch, "cconverter"), ctx(pipe_ctx(i.dev, o.dev, "cconverter: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i, o, "cconverter: pipebufs of two device contexts")),
         in(i), out(o) {}
   void run() {
     unsigned long count = min(in.readable(), out.writable());
@@ -189,14 +217,14 @@ struct cconverter<float, 0, u8, 128, 1, 1> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<complex<float> > in;
-  pipewriter<complex<u8> > out;
+  dev_reader<complex<float> > in;
+  dev_writer<complex<u8> > out;
 };
 
 template <>
 struct cconverter<float, 0, int16_t, 0, 32768, 1> : runnable {   // leandvbtx --s16 (leandvbtx.cc:179)
   cconverter(scheduler *sch, pipebuf<complex<float> > &i, pipebuf<complex<int16_t> > &o)
-      : runnable(sch, "cconverter"), ctx(pipe_ctx(i.dev, o.dev, "cconverter: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "cconverter"), ctx(pipe_ctx(i, o, "cconverter: pipebufs of two device contexts")),
         in(i), out(o) {}
   void run() {
     unsigned long count = min(in.readable(), out.writable());
@@ -208,8 +236,8 @@ struct cconverter<float, 0, int16_t, 0, 32768, 1> : runnable {   // leandvbtx --
 
  private:
   lsdr_ctx *ctx;
-  pipereader<complex<float> > in;
-  pipewriter<complex<int16_t> > out;
+  dev_reader<complex<float> > in;
+  dev_writer<complex<int16_t> > out;
 };
 
 template <typename T>
@@ -218,9 +246,9 @@ struct adder;
 template <>
 struct adder<complex<float> > : runnable {
   adder(scheduler *sch, pipebuf<complex<float> > &i1, pipebuf<complex<float> > &i2, pipebuf<complex<float> > &o)
-      : runnable(sch, "adder"), ctx(pipe_ctx(i1.dev, o.dev, "adder: pipebufs must be device pipebufs of one ctx")), in1(i1), in2(i2),
+      : runnable(sch, "adder"), ctx(pipe_ctx(i1, o, "adder: pipebufs of two device contexts")), in1(i1), in2(i2),
         out(o) {
-    pipe_ctx(i2.dev, o.dev, "adder: pipebufs must be device pipebufs of one ctx");
+    pipe_ctx(i2, o, "adder: pipebufs of two device contexts");
   }
   void run() {
     unsigned long n = out.writable();
@@ -235,8 +263,8 @@ struct adder<complex<float> > : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<complex<float> > in1, in2;
-  pipewriter<complex<float> > out;
+  dev_reader<complex<float> > in1, in2;
+  dev_writer<complex<float> > out;
 };
 
 // wgn_c<float>: glibc's drand48 stream, continued on the device.  `seed()` stands for the srand48() call the reference's
@@ -248,9 +276,7 @@ template <>
 struct wgn_c<float> : runnable {
   float stddev;
   wgn_c(scheduler *sch, pipebuf<complex<float> > &o)
-      : runnable(sch, "awgn"), stddev(1.0), ctx(o.dev), out(o), h(NULL), seeded(false), seedval(0) {
-    if (!ctx) fail("wgn_c: pipebuf must be a device pipebuf");
-  }
+      : runnable(sch, "awgn"), stddev(1.0), ctx(pipe_ctx(o, "wgn_c")), out(o), h(NULL), seeded(false), seedval(0) {}
   void seed(long s) { seeded = true; seedval = s; }
   void run() {
     if (!h) lsdr_check(lsdr_wgn_create(ctx, seeded, seedval, &h), name);
@@ -262,7 +288,7 @@ struct wgn_c<float> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipewriter<complex<float> > out;
+  dev_writer<complex<float> > out;
   lsdr_wgn *h;
   bool seeded;
   long seedval;

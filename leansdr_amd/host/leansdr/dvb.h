@@ -22,6 +22,32 @@ inline cstln_lut<256> *make_dvbs2_constellation(cstln_lut<256>::predef c, code_r
   return new cstln_lut<256>(c, (int)r);   // radii per code rate are applied by the table builder (dvb.h:45-81)
 }
 
+// fec_specs[code_rate] (dvb.h:553-565): parameters of the convolutional coder, filled from the C ABI's table
+// (leandvb prints bits_in/bits_out as the "CR" line of --fd-info).  Rates the coder does not have read 0/0, as in the reference.
+struct fec_spec {
+  int bits_in, bits_out;
+  const uint16_t *polys;
+};
+namespace detail {
+struct fec_spec_table {
+  fec_spec spec[FEC_MAX];
+  uint16_t polys[FEC_MAX][8];
+  fec_spec_table() {
+    for (int r = 0; r < FEC_MAX; ++r) {
+      spec[r].bits_in = spec[r].bits_out = 0;
+      spec[r].polys = polys[r];
+      memset(polys[r], 0, sizeof(polys[r]));
+      (void)lsdr_fec_spec(r, &spec[r].bits_in, &spec[r].bits_out, polys[r]);
+    }
+  }
+};
+inline fec_spec *fec_spec_array() {
+  static fec_spec_table t;
+  return t.spec;
+}
+}  // namespace detail
+static fec_spec *const fec_specs = detail::fec_spec_array();
+
 template <typename Tbyte>
 struct rspacket { Tbyte data[SIZE_RSPACKET]; };
 struct tspacket { u8 data[SIZE_TSPACKET]; };
@@ -34,7 +60,7 @@ struct deconvol_sync<u8, 0> : runnable {
   bool fastlock;
   deconvol_sync(scheduler *sch, pipebuf<softsymbol> &i, pipebuf<u8> &o, code_rate rate)
       : runnable(sch, "deconvol_sync"), fastlock(false),
-        ctx(pipe_ctx(i.dev, o.dev, "deconvol_sync: pipebufs must be device pipebufs of one ctx")), in(i),
+        ctx(pipe_ctx(i, o, "deconvol_sync: pipebufs of two device contexts")), in(i),
         out(o, SIZE_RSPACKET), rate_(rate), h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_deconv_create(ctx, (int)rate_, fastlock, &h), name);
@@ -55,8 +81,8 @@ struct deconvol_sync<u8, 0> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<softsymbol> in;
-  pipewriter<u8> out;
+  dev_reader<softsymbol> in;
+  dev_writer<u8> out;
   code_rate rate_;
   lsdr_deconv *h;
 };
@@ -72,7 +98,7 @@ struct viterbi_sync : runnable {
   int resync_period;
   viterbi_sync(scheduler *sch, pipebuf<softsymbol> &i, pipebuf<unsigned char> &o, cstln_lut<256> *cstln, code_rate cr)
       : runnable(sch, "viterbi_sync"), resync_period(32),
-        ctx(pipe_ctx(i.dev, o.dev, "viterbi_sync: pipebufs must be device pipebufs of one ctx")), in(i), out(o, 128), h(NULL) {
+        ctx(pipe_ctx(i, o, "viterbi_sync: pipebufs of two device contexts")), in(i), out(o, 128), h(NULL) {
     lsdr_check(lsdr_viterbi_create(ctx, (int)cstln->type, (int)cr, &h), name);
   }
   void run() {
@@ -93,8 +119,8 @@ struct viterbi_sync : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<softsymbol> in;
-  pipewriter<unsigned char> out;
+  dev_reader<softsymbol> in;
+  dev_writer<unsigned char> out;
   lsdr_viterbi *h;
 };
 
@@ -112,7 +138,7 @@ struct dvb_deconvol_sync<u8> : runnable {
   static const int chunk_size = 64;
   dvb_deconvol_sync(scheduler *sch, pipebuf<u8> &i, pipebuf<decoded_byte> &o)
       : runnable(sch, "deconvol_sync_multipoly"), resync_period(32),
-        ctx(pipe_ctx(i.dev, o.dev, "dvb_deconvol_sync: pipebufs must be device pipebufs of one ctx")), in(i), out(o, chunk_size),
+        ctx(pipe_ctx(i, o, "dvb_deconvol_sync: pipebufs of two device contexts")), in(i), out(o, chunk_size),
         h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_hsdeconv_create(ctx, resync_period, &h), name);
@@ -128,8 +154,8 @@ struct dvb_deconvol_sync<u8> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<u8> in;
-  pipewriter<decoded_byte> out;
+  dev_reader<u8> in;
+  dev_writer<decoded_byte> out;
   lsdr_hsdeconv *h;
 };
 typedef dvb_deconvol_sync<u8> dvb_deconvol_sync_hard;
@@ -144,7 +170,7 @@ struct mpeg_sync<u8, 0> : runnable {
   mpeg_sync(scheduler *sch, pipebuf<u8> &i, pipebuf<u8> &o, deconvol_sync<u8, 0> *dc, pipebuf<int> *state_o = NULL,
             pipebuf<unsigned long> *locktime_o = NULL)
       : runnable(sch, "sync_detect"), scan_syncs(8), want_syncs(4), lock_timeout(4), fastlock(false), resync_period(1),
-        ctx(pipe_ctx(i.dev, o.dev, "mpeg_sync: pipebufs must be device pipebufs of one ctx")), in(i),
+        ctx(pipe_ctx(i, o, "mpeg_sync: pipebufs of two device contexts")), in(i),
         out(o, SIZE_RSPACKET * (scan_syncs + 1)), deconv(dc), h(NULL), last_locktime(0), first_run(true) {
     state_out = opt_writer(state_o);
     locktime_out = opt_writer(locktime_o);
@@ -179,8 +205,8 @@ struct mpeg_sync<u8, 0> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<u8> in;
-  pipewriter<u8> out;
+  dev_reader<u8> in;
+  dev_writer<u8> out;
   deconvol_sync<u8, 0> *deconv;
   lsdr_mpeg_sync *h;
   unsigned long last_locktime;
@@ -195,7 +221,7 @@ struct deinterleaver;
 template <>
 struct deinterleaver<u8> : runnable {
   deinterleaver(scheduler *sch, pipebuf<u8> &i, pipebuf<rspacket<u8> > &o)
-      : runnable(sch, "deinterleaver"), ctx(pipe_ctx(i.dev, o.dev, "deinterleaver: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "deinterleaver"), ctx(pipe_ctx(i, o, "deinterleaver: pipebufs of two device contexts")),
         in(i), out(o) {}
   void run() {
     for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
@@ -210,8 +236,8 @@ struct deinterleaver<u8> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<u8> in;
-  pipewriter<rspacket<u8> > out;
+  dev_reader<u8> in;
+  dev_writer<rspacket<u8> > out;
 };
 
 template <typename Tbyte, int BYTE_ERASED>
@@ -221,7 +247,7 @@ template <>
 struct rs_decoder<u8, 0> : runnable {
   rs_decoder(scheduler *sch, pipebuf<rspacket<u8> > &i, pipebuf<tspacket> &o, pipebuf<int> *bitcount_o = NULL,
              pipebuf<int> *errcount_o = NULL)
-      : runnable(sch, "RS decoder"), ctx(pipe_ctx(i.dev, o.dev, "rs_decoder: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "RS decoder"), ctx(pipe_ctx(i, o, "rs_decoder: pipebufs of two device contexts")),
         in(i), out(o) {
     bitcount = opt_writer(bitcount_o);
     errcount = opt_writer(errcount_o);
@@ -241,14 +267,14 @@ struct rs_decoder<u8, 0> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<rspacket<u8> > in;
-  pipewriter<tspacket> out;
+  dev_reader<rspacket<u8> > in;
+  dev_writer<tspacket> out;
   pipewriter<int> *bitcount, *errcount;
 };
 
 struct derandomizer : runnable {
   derandomizer(scheduler *sch, pipebuf<tspacket> &i, pipebuf<tspacket> &o)
-      : runnable(sch, "derandomizer"), ctx(pipe_ctx(i.dev, o.dev, "derandomizer: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "derandomizer"), ctx(pipe_ctx(i, o, "derandomizer: pipebufs of two device contexts")),
         in(i), out(o), h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_derandomizer_create(ctx, &h), name);
@@ -264,15 +290,15 @@ struct derandomizer : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<tspacket> in;
-  pipewriter<tspacket> out;
+  dev_reader<tspacket> in;
+  dev_writer<tspacket> out;
   lsdr_derandomizer *h;
 };
 
 // ---- transmit chain (leandvbtx.cc:79-175): same constructor signatures as the reference blocks, device pipebufs.
 struct randomizer : runnable {   // dvb.h:1063-1102
   randomizer(scheduler *sch, pipebuf<tspacket> &i, pipebuf<tspacket> &o)
-      : runnable(sch, "derandomizer"), ctx(pipe_ctx(i.dev, o.dev, "randomizer: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {
+      : runnable(sch, "derandomizer"), ctx(pipe_ctx(i, o, "randomizer: pipebufs of two device contexts")), in(i), out(o) {
     lsdr_check(lsdr_randomizer_create(ctx, &h), name);
   }
   void run() {
@@ -288,14 +314,14 @@ struct randomizer : runnable {   // dvb.h:1063-1102
 
  private:
   lsdr_ctx *ctx;
-  pipereader<tspacket> in;
-  pipewriter<tspacket> out;
+  dev_reader<tspacket> in;
+  dev_writer<tspacket> out;
   lsdr_randomizer *h;
 };
 
 struct rs_encoder : runnable {   // dvb.h:957-980
   rs_encoder(scheduler *sch, pipebuf<tspacket> &i, pipebuf<rspacket<u8> > &o)
-      : runnable(sch, "RS encoder"), ctx(pipe_ctx(i.dev, o.dev, "rs_encoder: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {}
+      : runnable(sch, "RS encoder"), ctx(pipe_ctx(i, o, "rs_encoder: pipebufs of two device contexts")), in(i), out(o) {}
   void run() {
     for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
       unsigned long room = out.writable();
@@ -309,13 +335,13 @@ struct rs_encoder : runnable {   // dvb.h:957-980
 
  private:
   lsdr_ctx *ctx;
-  pipereader<tspacket> in;
-  pipewriter<rspacket<u8> > out;
+  dev_reader<tspacket> in;
+  dev_writer<rspacket<u8> > out;
 };
 
 struct interleaver : runnable {   // dvb.h:899-921
   interleaver(scheduler *sch, pipebuf<rspacket<u8> > &i, pipebuf<u8> &o)
-      : runnable(sch, "interleaver"), ctx(pipe_ctx(i.dev, o.dev, "interleaver: pipebufs must be device pipebufs of one ctx")), in(i),
+      : runnable(sch, "interleaver"), ctx(pipe_ctx(i, o, "interleaver: pipebufs of two device contexts")), in(i),
         out(o, SIZE_RSPACKET) {}
   void run() {
     for (;;) {   // until no progress: the reference's run() is a while loop that re-evaluates writable() (which may pack)
@@ -330,15 +356,15 @@ struct interleaver : runnable {   // dvb.h:899-921
 
  private:
   lsdr_ctx *ctx;
-  pipereader<rspacket<u8> > in;
-  pipewriter<u8> out;
+  dev_reader<rspacket<u8> > in;
+  dev_writer<u8> out;
 };
 
 struct dvb_convol : runnable {   // dvb.h:567-604
   typedef u8 uncoded_byte;
   typedef u8 hardsymbol;
   dvb_convol(scheduler *sch, pipebuf<uncoded_byte> &i, pipebuf<hardsymbol> &o, code_rate fec, int bits_per_symbol)
-      : runnable(sch, "dvb_convol"), ctx(pipe_ctx(i.dev, o.dev, "dvb_convol: pipebufs must be device pipebufs of one ctx")), in(i),
+      : runnable(sch, "dvb_convol"), ctx(pipe_ctx(i, o, "dvb_convol: pipebufs of two device contexts")), in(i),
         out(o, 64) {
     lsdr_check(lsdr_convol_create(ctx, (int)fec, bits_per_symbol, &h), name);
   }
@@ -355,8 +381,8 @@ struct dvb_convol : runnable {   // dvb.h:567-604
 
  private:
   lsdr_ctx *ctx;
-  pipereader<uncoded_byte> in;
-  pipewriter<hardsymbol> out;
+  dev_reader<uncoded_byte> in;
+  dev_writer<hardsymbol> out;
   lsdr_convol *h;
 };
 

@@ -6,8 +6,9 @@
 //   pipereader<T>(buf){readable(), rd(), read(n)}, opt_writer/opt_writable/opt_write, fail()/fatal(), u8 … s32.
 // This file provides that vocabulary on its own implementation: pipes are cursor-based (one write index, one read index
 // per attached reader, storage compacted on demand), the scheduler keeps its blocks and pipes in vectors, and — the
-// reason the file exists — a pipe may live in MI355X HBM: pipebuf(sch, name, size, ctx).  Device pipes are touched only by
-// GPU-backed blocks and by the h2d/d2h bridges of generic.h; compaction is then a stream-ordered device copy.
+// reason the file exists — a pipe has a host side and an MI355X-HBM side (see pipebuf below): blocks written like the
+// reference's attach on the host side, GPU-backed blocks on the device side, and the pipe carries the items across PCIe
+// on side streams where the two meet.
 //
 // Behaviour that graphs rely on (checked against framework.h:45-249 by the app-level golden tests):
 //   * readers always see one contiguous span; a writer that finds less tail room than the largest min_write of the
@@ -150,43 +151,79 @@ struct runnable : detail::block_base {
   scheduler *sch;
 };
 
-// Multi-reader FIFO over one linear allocation.  `head` is the write index; reader r has consumed everything below
-// tails[r].  Nothing wraps: when the tail room is short the span [oldest tail, head) is moved to index 0.
+// The process-default device context: what a pipebuf constructed the reference's way — pipebuf(sch, name, size) — uses
+// as soon as a GPU-backed block attaches to it.  LSDR_DEVICE selects the GPU (default 0).
+inline lsdr_ctx *default_ctx() {
+  static lsdr_ctx *c = NULL;
+  if (!c) {
+    const char *e = getenv("LSDR_DEVICE");
+    lsdr_check(lsdr_ctx_create(e ? atoi(e) : 0, NULL, &c), "default device context");
+  }
+  return c;
+}
+
+enum pipe_side { HOST_SIDE = 0, DEVICE_SIDE = 1 };
+
+// Multi-reader FIFO over one linear index space with TWO address spaces.  `head` is the write index; reader r has
+// consumed everything below tails[r].  Nothing wraps: when the tail room is short the span [oldest tail, head) is moved
+// to index 0.
+//
+// Every end (writer or reader) lives on one side: HOST_SIDE — pipewriter/pipereader, i.e. any block that dereferences
+// wr()/rd() on the CPU, exactly like a block written for the reference — or DEVICE_SIDE — dev_writer/dev_reader, the
+// GPU-backed blocks, whose wr()/rd() are HBM pointers handed to the C ABI.  A side's storage exists only if an end lives
+// there (host storage is pinned when the other side exists too).  Items committed on the writer's side are mirrored to
+// the other side when — and only when — a reader lives there:
+//   host writer → device readers   hipMemcpyAsync on the context's upload stream, enqueued at commit time; the compute
+//                                  stream waits for it (an event, not the host) the next time a device reader looks;
+//                                  the host goes on filling the next stretch of the pipe meanwhile (north_star's
+//                                  double-buffered side-stream transfer: the pipe itself is the multi-buffer);
+//   device writer → host readers   hipMemcpyAsync on the download stream after the producing kernels; a host reader's
+//                                  readable() waits for it, so what it sees is what has arrived (the scheduler's
+//                                  "no progress" test stays exact).
+// So the graph of the reference's leandvb.cc — host file_reader, GPU blocks, host file_writer/printers on plain
+// three-argument pipebufs — runs unchanged, and PCIe is crossed exactly where a pipe has ends on both sides.
 template <typename T>
 struct pipebuf : detail::pipe_base {
-  lsdr_ctx *dev;   // NULL: host memory; otherwise the storage is in this context's HBM
+  lsdr_ctx *dev;   // device context: explicit (fourth constructor argument) or the process default once needed
 
   pipebuf(scheduler *s, const char *n, unsigned long size, lsdr_ctx *device = NULL)
-      : detail::pipe_base(n), dev(device), store_(NULL), cap_(size), head_(0), need_(1), n_in_(0), n_out_(0) {
-    if (dev) {
-      void *p = NULL;
-      lsdr_check(lsdr_malloc(dev, cap_ * sizeof(T), &p), n);
-      store_ = static_cast<T *>(p);
-    } else {
-      store_ = new T[cap_];
-    }
+      : detail::pipe_base(n), dev(device), host_(NULL), devp_(NULL), host_pinned_(false), wside_(-1), cap_(size), head_(0), need_(1),
+        n_in_(0), n_out_(0), mirrored_(0), h2d_unfenced_(false), d2h_inflight_(false) {
+    used_[0] = used_[1] = false;
     s->attach(this);
   }
 
+  // -- ends
+  void attach_writer(pipe_side side, unsigned long min_write) {
+    if (wside_ >= 0 && wside_ != (int)side) { fprintf(stderr, "** %s: writers on both the host and the device side\n", name); exit(1); }
+    wside_ = side;
+    used_[side] = true;
+    if (min_write > need_) need_ = min_write;
+  }
+  int attach_reader(pipe_side side) {
+    used_[side] = true;
+    tails_.push_back(head_);
+    rside_.push_back((char)side);
+    return (int)tails_.size() - 1;
+  }
   // -- writer side
-  void require_room(unsigned long items) { if (items > need_) need_ = items; }
   unsigned long room() {
     if (cap_ - head_ < need_) compact();
     return cap_ - head_;
   }
-  T *write_ptr() { return store_ + head_; }
+  T *write_ptr() { return store(wside_ < 0 ? HOST_SIDE : (pipe_side)wside_) + head_; }
   void commit(unsigned long items) {
     if (items > cap_ - head_) { fprintf(stderr, "Bug: overflow to %s\n", name); exit(1); }
     head_ += items;
     n_in_ += items;
+    if (items) mirror();
   }
   // -- reader side
-  int attach_reader() {
-    tails_.push_back(head_);
-    return (int)tails_.size() - 1;
+  unsigned long pending(int r) {
+    arrive((pipe_side)rside_[r]);
+    return head_ - tails_[r];
   }
-  unsigned long pending(int r) const { return head_ - tails_[r]; }
-  T *read_ptr(int r) { return store_ + tails_[r]; }
+  T *read_ptr(int r) { return store((pipe_side)rside_[r]) + tails_[r]; }
   void consume(int r, unsigned long items) {
     if (items > head_ - tails_[r]) { fprintf(stderr, "Bug: underflow from %s\n", name); exit(1); }
     tails_[r] += items;
@@ -204,15 +241,76 @@ struct pipebuf : detail::pipe_base {
     fprintf(f, ".%-16s : %4ld%s/%4ld%s %6ld writable %c, %6d unread (", name, n_out_ / div, suffix, n_in_ / div, suffix, tail_room,
             tail_room < need_ ? '!' : ' ', (int)(head_ - oldest()));
     for (size_t r = 0; r < tails_.size(); ++r) fprintf(f, " %d", (int)(head_ - tails_[r]));
-    fprintf(f, " )%s\n", dev ? " [HBM]" : "");
+    fprintf(f, " )%s%s\n", used_[DEVICE_SIDE] ? " [HBM]" : "", used_[DEVICE_SIDE] && used_[HOST_SIDE] ? " [PCIe]" : "");
   }
 
  private:
-  T *store_;
+  T *host_, *devp_;
+  bool host_pinned_;
+  bool used_[2];
+  int wside_;
   unsigned long cap_, head_, need_;
   unsigned long n_in_, n_out_;
+  unsigned long mirrored_;            // items below this index have been sent to the non-writer side
+  bool h2d_unfenced_, d2h_inflight_;
   std::vector<unsigned long> tails_;
+  std::vector<char> rside_;
 
+  lsdr_ctx *ctx() {
+    if (!dev) dev = default_ctx();
+    return dev;
+  }
+  T *store(pipe_side side) {
+    if (side == DEVICE_SIDE) {
+      if (!devp_) {
+        void *p = NULL;
+        lsdr_check(lsdr_malloc(ctx(), cap_ * sizeof(T), &p), name);
+        devp_ = static_cast<T *>(p);
+      }
+      return devp_;
+    }
+    if (!host_) {
+      if (used_[DEVICE_SIDE]) {          // staging for PCIe transfers: pinned
+        void *p = NULL;
+        lsdr_check(lsdr_malloc_host(cap_ * sizeof(T), &p), name);
+        host_ = static_cast<T *>(p);
+        host_pinned_ = true;
+      } else {
+        host_ = reinterpret_cast<T *>(new char[cap_ * sizeof(T)]);
+      }
+    }
+    return host_;
+  }
+  // send what the writer has committed to the other side, if somebody reads there
+  void mirror() {
+    if (wside_ < 0 || mirrored_ >= head_) return;
+    const pipe_side other = wside_ == HOST_SIDE ? DEVICE_SIDE : HOST_SIDE;
+    bool wanted = false;
+    for (size_t r = 0; r < rside_.size(); ++r) wanted = wanted || rside_[r] == (char)other;
+    if (!wanted) return;
+    const size_t bytes = (head_ - mirrored_) * sizeof(T);
+    if (wside_ == HOST_SIDE) {
+      lsdr_check(lsdr_copy_h2d_async(ctx(), store(DEVICE_SIDE) + mirrored_, store(HOST_SIDE) + mirrored_, bytes), name);
+      h2d_unfenced_ = true;
+    } else {
+      lsdr_check(lsdr_copy_d2h_async(ctx(), store(HOST_SIDE) + mirrored_, store(DEVICE_SIDE) + mirrored_, bytes), name);
+      d2h_inflight_ = true;
+    }
+    mirrored_ = head_;
+  }
+  // make committed items visible to a reader on `side`
+  void arrive(pipe_side side) {
+    if (wside_ < 0 || (int)side == wside_) return;
+    mirror();
+    if (side == DEVICE_SIDE && h2d_unfenced_) {
+      lsdr_check(lsdr_copy_fence(ctx()), name);       // GPU-side wait: the host does not block
+      h2d_unfenced_ = false;
+    }
+    if (side == HOST_SIDE && d2h_inflight_) {
+      lsdr_check(lsdr_copy_sync_d2h(ctx()), name);
+      d2h_inflight_ = false;
+    }
+  }
   unsigned long oldest() const {
     unsigned long o = head_;   // no reader: everything written is already "consumed"
     for (size_t r = 0; r < tails_.size(); ++r)
@@ -223,21 +321,31 @@ struct pipebuf : detail::pipe_base {
     const unsigned long from = oldest();
     if (from == 0) return;
     const size_t live = (head_ - from) * sizeof(T);
-    if (dev) lsdr_check(lsdr_memcpy_d2d(dev, store_, store_ + from, live), name);
-    else memmove(store_, store_ + from, live);
+    if (devp_) {
+      // transfers in flight use the old layout; kernels may still read it: drain, move, drain
+      lsdr_check(lsdr_copy_sync_all(ctx()), name);
+      h2d_unfenced_ = d2h_inflight_ = false;
+      if (live) {
+        lsdr_check(lsdr_memcpy_d2d(ctx(), devp_, devp_ + from, live), name);
+        lsdr_check(lsdr_ctx_sync(ctx()), name);
+      }
+    }
+    if (host_ && live) memmove(host_, host_ + from, live);
     head_ -= from;
+    mirrored_ = mirrored_ > from ? mirrored_ - from : 0;
     for (size_t r = 0; r < tails_.size(); ++r) tails_[r] -= from;
   }
 };
 
+// Host-side ends: the reference's pipewriter / pipereader (framework.h:185-249).
 template <typename T>
 struct pipewriter {
   pipebuf<T> &buf;
-  pipewriter(pipebuf<T> &b, unsigned long min_write = 1) : buf(b) { buf.require_room(min_write); }
+  pipewriter(pipebuf<T> &b, unsigned long min_write = 1) : buf(b) { buf.attach_writer(HOST_SIDE, min_write); }
   unsigned long writable() { return buf.room(); }
   T *wr() { return buf.write_ptr(); }
   void written(unsigned long n) { buf.commit(n); }
-  void write(const T &v) {   // host pipes only
+  void write(const T &v) {
     *buf.write_ptr() = v;
     buf.commit(1);
   }
@@ -247,11 +355,46 @@ template <typename T>
 struct pipereader {
   pipebuf<T> &buf;
   int id;
-  explicit pipereader(pipebuf<T> &b) : buf(b), id(b.attach_reader()) {}
+  explicit pipereader(pipebuf<T> &b) : buf(b), id(b.attach_reader(HOST_SIDE)) {}
   unsigned long readable() { return buf.pending(id); }
   T *rd() { return buf.read_ptr(id); }
   void read(unsigned long n) { buf.consume(id, n); }
 };
+
+// Device-side ends, used by the GPU-backed blocks: wr()/rd() are HBM pointers for the C ABI.
+template <typename T>
+struct dev_writer {
+  pipebuf<T> &buf;
+  dev_writer(pipebuf<T> &b, unsigned long min_write = 1) : buf(b) { buf.attach_writer(DEVICE_SIDE, min_write); }
+  unsigned long writable() { return buf.room(); }
+  T *wr() { return buf.write_ptr(); }
+  void written(unsigned long n) { buf.commit(n); }
+};
+
+template <typename T>
+struct dev_reader {
+  pipebuf<T> &buf;
+  int id;
+  explicit dev_reader(pipebuf<T> &b) : buf(b), id(b.attach_reader(DEVICE_SIDE)) {}
+  unsigned long readable() { return buf.pending(id); }
+  T *rd() { return buf.read_ptr(id); }
+  void read(unsigned long n) { buf.consume(id, n); }
+};
+
+// The context a GPU-backed block works in: the explicit context of its pipes if any (all the same), else the default.
+template <typename A>
+lsdr_ctx *pipe_ctx(pipebuf<A> &a, const char *who) {
+  if (!a.dev) a.dev = default_ctx();
+  return a.dev;
+}
+template <typename A, typename B>
+lsdr_ctx *pipe_ctx(pipebuf<A> &a, pipebuf<B> &b, const char *who) {
+  lsdr_ctx *c = a.dev ? a.dev : b.dev;
+  if (!c) c = default_ctx();
+  if ((a.dev && a.dev != c) || (b.dev && b.dev != c)) fail(who);
+  a.dev = b.dev = c;
+  return c;
+}
 
 // Optional side outputs (measurement pipes): a NULL pipe means "not wired".
 template <typename T>

@@ -1,6 +1,6 @@
 // leansdr_amd/host/leansdr/generic.h — host-side end points of a graph: descriptor I/O, the text reports of --fd-info /
-// --fd-const / --fd-spectrum, the VBER ratio, and the two bridges between host pipes and HBM pipes (the only place where
-// PCIe is crossed).  Block names and constructor arguments are the reference's (generic.h:37-375) so that a graph builder
+// --fd-const / --fd-spectrum, the VBER ratio — all host-side ends: their pipes carry the items over PCIe when the other
+// end is a GPU block (framework.h) — and two explicit host↔HBM bridge blocks.  Block names and constructor arguments are the reference's (generic.h:37-375) so that a graph builder
 // written for it compiles; the bodies sit on two small helpers, fdio (whole-item descriptor transfers) and text_out.
 #ifndef LEANSDR_AMD_GENERIC_H
 #define LEANSDR_AMD_GENERIC_H
@@ -225,45 +225,42 @@ struct rate_estimator : runnable {
   T sum_num_, sum_den_;
 };
 
-// ---- bridges: host pipe <-> HBM pipe ---------------------------------------------------------------------------------
-// The copy is enqueued on the context's stream, i.e. ordered with the kernels of the neighbouring GPU blocks, and waited
-// for before the items change hands (the producer may overwrite host memory; a host consumer must see the data).
-namespace detail {
-template <typename T>
-inline unsigned long bridge(lsdr_ctx *ctx, pipereader<T> &from, pipewriter<T> &to, bool to_device, const char *tag) {
-  const unsigned long n = min(from.readable(), to.writable());
-  if (n == 0) return 0;
-  lsdr_check(to_device ? lsdr_memcpy_h2d(ctx, to.wr(), from.rd(), n * sizeof(T)) : lsdr_memcpy_d2h(ctx, to.wr(), from.rd(), n * sizeof(T)), tag);
-  lsdr_check(lsdr_ctx_sync(ctx), tag);
-  from.read(n);
-  to.written(n);
-  return n;
-}
-}  // namespace detail
-
+// ---- explicit bridges between two pipes -----------------------------------------------------------------------------
+// A pipebuf carries its items across PCIe by itself wherever it has ends on both sides (framework.h); these two blocks
+// remain for graphs that want the crossing as a block of its own (a host-side pipe copied into a separate HBM pipe).
 template <typename T>
 struct h2d_copier : runnable {
-  h2d_copier(scheduler *s, lsdr_ctx *c, pipebuf<T> &host_src, pipebuf<T> &hbm_dst) : runnable(s, "h2d"), ctx_(c), from_(host_src), to_(hbm_dst) {
-    if (host_src.dev || !hbm_dst.dev) fail("h2d_copier: needs host input and device output pipebufs");
+  h2d_copier(scheduler *s, lsdr_ctx *c, pipebuf<T> &host_src, pipebuf<T> &hbm_dst) : runnable(s, "h2d"), ctx_(c), from_(host_src), to_(hbm_dst) {}
+  void run() {
+    const unsigned long n = min(from_.readable(), to_.writable());
+    if (n == 0) return;
+    lsdr_check(lsdr_memcpy_h2d(ctx_, to_.wr(), from_.rd(), n * sizeof(T)), name);
+    lsdr_check(lsdr_ctx_sync(ctx_), name);      // the producer may overwrite the host items once they are read()
+    from_.read(n);
+    to_.written(n);
   }
-  void run() { detail::bridge(ctx_, from_, to_, true, name); }
 
  private:
   lsdr_ctx *ctx_;
   pipereader<T> from_;
-  pipewriter<T> to_;
+  dev_writer<T> to_;
 };
 
 template <typename T>
 struct d2h_copier : runnable {
-  d2h_copier(scheduler *s, lsdr_ctx *c, pipebuf<T> &hbm_src, pipebuf<T> &host_dst) : runnable(s, "d2h"), ctx_(c), from_(hbm_src), to_(host_dst) {
-    if (!hbm_src.dev || host_dst.dev) fail("d2h_copier: needs device input and host output pipebufs");
+  d2h_copier(scheduler *s, lsdr_ctx *c, pipebuf<T> &hbm_src, pipebuf<T> &host_dst) : runnable(s, "d2h"), ctx_(c), from_(hbm_src), to_(host_dst) {}
+  void run() {
+    const unsigned long n = min(from_.readable(), to_.writable());
+    if (n == 0) return;
+    lsdr_check(lsdr_memcpy_d2h(ctx_, to_.wr(), from_.rd(), n * sizeof(T)), name);
+    lsdr_check(lsdr_ctx_sync(ctx_), name);      // a host consumer must see the data
+    from_.read(n);
+    to_.written(n);
   }
-  void run() { detail::bridge(ctx_, from_, to_, false, name); }
 
  private:
   lsdr_ctx *ctx_;
-  pipereader<T> from_;
+  dev_reader<T> from_;
   pipewriter<T> to_;
 };
 

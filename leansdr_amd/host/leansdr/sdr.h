@@ -80,6 +80,20 @@ struct cstln_lut {
   result *lut;
 };
 
+// Options a graph builder written for the reference has no members for come from the environment: LSDR_TILED=1 selects
+// the throughput (time-tiled, tolerance-tested) mode of the receivers, LSDR_TILE_LEN / LSDR_TILE_WARMUP its geometry.
+inline bool env_flag(const char *name) {
+  const char *e = getenv(name);
+  return e && atoi(e) != 0;
+}
+inline unsigned env_uint(const char *name) {
+  const char *e = getenv(name);
+  return e ? (unsigned)strtoul(e, NULL, 10) : 0u;
+}
+
+// constellation names by cstln_lut<256>::predef (sdr.h:575-585), printed by --fd-info
+static const char *const cstln_names[] = {"BPSK", "QPSK", "8PSK", "16APSK", "32APSK", "64APSKe", "16QAM", "64QAM", "256QAM"};
+
 // auto_notch<f32> (sdr.h:46-154): same constructor and public tunables (decimation, k).
 template <typename T>
 struct auto_notch;
@@ -90,7 +104,7 @@ struct auto_notch<f32> : runnable {
   float k;
   auto_notch(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o, int nslots, f32 agc_rms_setpoint)
       : runnable(sch, "auto_notch"), decimation(1024 * 4096), k(0.002),
-        ctx(pipe_ctx(i.dev, o.dev, "auto_notch: pipebufs must be device pipebufs of one ctx")), in(i), out(o, 4096), h(NULL) {
+        ctx(pipe_ctx(i, o, "auto_notch: pipebufs of two device contexts")), in(i), out(o, 4096), h(NULL) {
     lsdr_check(lsdr_auto_notch_create(ctx, nslots, agc_rms_setpoint, &h), name);
   }
   void run() {
@@ -104,8 +118,8 @@ struct auto_notch<f32> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<cf32> in;
-  pipewriter<cf32> out;
+  dev_reader<cf32> in;
+  dev_writer<cf32> out;
   lsdr_auto_notch *h;
 };
 
@@ -121,8 +135,7 @@ struct cnr_fft<f32> : runnable {
   float kavg;
   cnr_fft(scheduler *sch, pipebuf<cf32> &i, pipebuf<float> &o, float bw, int nfft = 4096)
       : runnable(sch, "cnr_fft"), bandwidth(bw), freq_tap(NULL), tap_multiplier(1), decimation(1048576), kavg(0.1),
-        ctx(i.dev), in(i), out(o), h(NULL) {
-    if (!ctx || o.dev) fail("cnr_fft: needs a device input pipebuf and a host output pipebuf");
+        ctx(pipe_ctx(i, "cnr_fft")), in(i), out(o), h(NULL) {
     lsdr_check(lsdr_cnr_fft_create(ctx, bw, nfft, &h), name);
   }
   void run() {
@@ -137,7 +150,7 @@ struct cnr_fft<f32> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<cf32> in;
+  dev_reader<cf32> in;
   pipewriter<float> out;
   lsdr_cnr_fft *h;
 };
@@ -162,8 +175,8 @@ struct fast_qpsk_receiver<u8> : runnable {
   fast_qpsk_receiver(scheduler *sch, pipebuf<cu8> &i, pipebuf<hardsymbol> &o, pipebuf<float> *freq_o = NULL,
                      pipebuf<cu8> *cstln_o = NULL)
       : runnable(sch, "Fast QPSK receiver"), meas_decimation(1048576), pll_adjustment(1.0), allow_drift(false),
-        tiled(false), tile_len(0), tile_warmup(0),
-        ctx(pipe_ctx(i.dev, o.dev, "fast_qpsk_receiver: in/out must be device pipebufs of one ctx")), in(i), out(o, chunk_size),
+        tiled(env_flag("LSDR_TILED")), tile_len(env_uint("LSDR_TILE_LEN")), tile_warmup(env_uint("LSDR_TILE_WARMUP")),
+        ctx(pipe_ctx(i, o, "fast_qpsk_receiver: in/out of two device contexts")), in(i), out(o, chunk_size),
         h(NULL), freq0(0) {
     set_omega(1);
     set_freq(0);
@@ -216,8 +229,8 @@ struct fast_qpsk_receiver<u8> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<cu8> in;
-  pipewriter<hardsymbol> out;
+  dev_reader<cu8> in;
+  dev_writer<hardsymbol> out;
   pipewriter<float> *freq_out;
   pipewriter<cu8> *cstln_out;
   lsdr_fastqpsk *h;
@@ -232,7 +245,7 @@ struct rotator;
 template <>
 struct rotator<f32> : runnable {
   rotator(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o, float freq)
-      : runnable(sch, "rotator"), ctx(pipe_ctx(i.dev, o.dev, "rotator: in/out must be device pipebufs of one ctx")), in(i), out(o),
+      : runnable(sch, "rotator"), ctx(pipe_ctx(i, o, "rotator: in/out of two device contexts")), in(i), out(o),
         h(NULL) {
     lsdr_check(lsdr_rotator_create(ctx, freq, &h), name);
   }
@@ -247,8 +260,8 @@ struct rotator<f32> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<cf32> in;
-  pipewriter<cf32> out;
+  dev_reader<cf32> in;
+  dev_writer<cf32> out;
   lsdr_rotator *h;
 };
 
@@ -262,8 +275,7 @@ struct spectrum<f32> : runnable {
   int decimation;
   float kavg;
   spectrum(scheduler *sch, pipebuf<cf32> &i, pipebuf<float[nfft]> &o)
-      : runnable(sch, "spectrum"), decimation(1048576), kavg(0.1), ctx(i.dev), in(i), out(o), h(NULL) {
-    if (!ctx || o.dev) fail("spectrum: needs a device input pipebuf and a host output pipebuf");
+      : runnable(sch, "spectrum"), decimation(1048576), kavg(0.1), ctx(pipe_ctx(i, "spectrum")), in(i), out(o), h(NULL) {
     lsdr_check(lsdr_spectrum_create(ctx, &h), name);
   }
   void run() {
@@ -277,7 +289,7 @@ struct spectrum<f32> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<cf32> in;
+  dev_reader<cf32> in;
   pipewriter<float[nfft]> out;
   lsdr_spectrum *h;
 };
@@ -342,8 +354,9 @@ struct cstln_receiver<f32> : runnable {
                  pipebuf<float> *freq_o = NULL, pipebuf<float> *ss_o = NULL, pipebuf<float> *mer_o = NULL,
                  pipebuf<cf32> *cstln_o = NULL)
       : runnable(sch, "Constellation receiver"), sampler(s), cstln(NULL), meas_decimation(1048576), pll_adjustment(1.0),
-        allow_drift(false), kest(0.01), freq_tap(0), mode(LSDR_RX_SERIAL), tile_len(0), tile_warmup(0),
-        ctx(pipe_ctx(i.dev, o.dev, "cstln_receiver: in/out must be device pipebufs of one ctx")), in(i),
+        allow_drift(false), kest(0.01), freq_tap(0), mode(env_flag("LSDR_TILED") ? LSDR_RX_TILED : LSDR_RX_SERIAL),
+        tile_len(env_uint("LSDR_TILE_LEN")), tile_warmup(env_uint("LSDR_TILE_WARMUP")),
+        ctx(pipe_ctx(i, o, "cstln_receiver: in/out of two device contexts")), in(i),
         out(o, chunk_size), h(NULL), freq0(0) {
     set_omega(1);
     set_freq(0);
@@ -442,8 +455,8 @@ struct cstln_receiver<f32> : runnable {
     return scratch[which];
   }
   lsdr_ctx *ctx;
-  pipereader<cf32> in;
-  pipewriter<softsymbol> out;
+  dev_reader<cf32> in;
+  dev_writer<softsymbol> out;
   pipewriter<float> *freq_out, *ss_out, *mer_out;
   pipewriter<cf32> *cstln_out;
   lsdr_rx *h;
@@ -460,7 +473,7 @@ struct cstln_transmitter<f32, 0> : runnable {
   cstln_lut<256> *cstln;
   cstln_transmitter(scheduler *sch, pipebuf<u8> &i, pipebuf<cf32> &o)
       : runnable(sch, "cstln_transmitter"), cstln(NULL),
-        ctx(pipe_ctx(i.dev, o.dev, "cstln_transmitter: pipebufs must be device pipebufs of one ctx")), in(i), out(o) {}
+        ctx(pipe_ctx(i, o, "cstln_transmitter: pipebufs of two device contexts")), in(i), out(o) {}
   void run() {
     if (!cstln) fail("constellation not set");
     unsigned long room = out.writable();
@@ -473,8 +486,8 @@ struct cstln_transmitter<f32, 0> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<u8> in;
-  pipewriter<cf32> out;
+  dev_reader<u8> in;
+  dev_writer<cf32> out;
 };
 
 template <typename T>
@@ -484,7 +497,7 @@ template <>
 struct simple_agc<f32> : runnable {
   float out_rms, bw;
   simple_agc(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o)
-      : runnable(sch, "AGC"), out_rms(1), bw(0.001), ctx(pipe_ctx(i.dev, o.dev, "simple_agc: pipebufs must be device pipebufs of one ctx")),
+      : runnable(sch, "AGC"), out_rms(1), bw(0.001), ctx(pipe_ctx(i, o, "simple_agc: pipebufs of two device contexts")),
         in(i), out(o), h(NULL) {}
   void run() {
     if (!h) lsdr_check(lsdr_simple_agc_create(ctx, out_rms, bw, &h), name);
@@ -501,8 +514,8 @@ struct simple_agc<f32> : runnable {
 
  private:
   lsdr_ctx *ctx;
-  pipereader<cf32> in;
-  pipewriter<cf32> out;
+  dev_reader<cf32> in;
+  dev_writer<cf32> out;
   lsdr_simple_agc *h;
 };
 

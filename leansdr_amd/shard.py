@@ -3,8 +3,8 @@
 The leandvb path shards by capture: every rank owns one GPU and one independent stream, there
 is NO data-path collective.  torch.distributed is used only for (1) a barrier before/after the
 timed region, (2) the max-over-ranks step time and (3) the sum of samples processed — three scalar
-all-reduces per benchmark run.  Works with backend "nccl" (= RCCL over xGMI on the MI355X node) and
-with "gloo" (CPU, used by tests/test_shard_gloo.py).
+all-reduces per benchmark run, over **gloo** (CPU tensors, TCP on 127.0.0.1): the path has no exchange
+step, so RCCL/xGMI is not initialised at all (north_star: "no RCCL").
 """
 import os
 
@@ -19,14 +19,11 @@ class Shard:
         if self.world > 1:
             import torch
             import torch.distributed as dist
-            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
-            if backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
-                self.device = torch.device("cuda", self.local_rank)
-                dist.init_process_group("nccl", device_id=self.device)
-            else:
-                self.device = torch.device("cpu")
-                dist.init_process_group("gloo")
+            if backend not in (None, "gloo"):
+                raise ValueError("leansdr_amd.shard: captures share nothing; only the gloo control plane is supported")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            self.device = torch.device("cpu")
+            dist.init_process_group("gloo")
             self.dist = dist
 
     def capture_seed(self, base=1):
@@ -39,8 +36,6 @@ class Shard:
         import torch
         t = torch.zeros(1, device=self.device)
         self.dist.all_reduce(t)
-        if self.device.type == "cuda":
-            torch.cuda.synchronize()
 
     def max_over_ranks(self, x):
         if self.dist is None:

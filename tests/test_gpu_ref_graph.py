@@ -1,0 +1,78 @@
+"""The drop-in boundary, tried for real (north_star: "the existing leandvb graph drops in unchanged").
+
+leansdr_amd/host/ref_graph/{leandvb,leandvbtx,leanchansim,leantsgen} are the REFERENCE'S OWN app sources
+(/root/reference/src/apps/*.cc, compiled where they lie, unmodified, by leansdr_amd/host/Makefile) built against this repo's
+host headers instead of the reference's: the same graph-building code, the same three-argument pipebufs, host file_reader /
+file_writer / printers — and every DSP/FEC block a GPU block behind the C ABI.  Pipes with a host end and a device end carry
+their items over PCIe by themselves (framework.h).  The binaries travel to the GPU box like oracle/_ref (built artefacts,
+git-ignored); where they are missing the tests are skipped, not faked."""
+import hashlib
+import os
+import subprocess
+import sys
+import numpy as np
+import pytest
+from conftest import gold, bits_equal, ROOT
+
+pytestmark = pytest.mark.gpu
+RG = os.path.join(ROOT, "leansdr_amd", "host", "ref_graph")
+need_graph = pytest.mark.skipif(not os.path.exists(os.path.join(RG, "leandvb")), reason="ref_graph binaries not built (no /root/reference on the build machine)")
+
+BENCH_CASES = [("sps12", "6/5", 18, "", 700), ("sps4_viterbi_rrc", "4", 5.5, "--viterbi --sampler rrc", 500),
+               ("sps12_hs", "6/5", 15, "--u8 --hs", 700)]
+
+
+@need_graph
+@pytest.mark.parametrize("name,ratio,snr,flags,npk", BENCH_CASES)
+def test_reference_apps_on_gpu_blocks_reproduce_the_reference(name, ratio, snr, flags, npk):
+    """test/leandvb_bench.sh's pipeline — leandvbtx | leanchansim --deterministic > file; leandvb --fd-info 2 < file — run
+    with the three reference programs compiled against the GPU headers: report text and transport stream are those of the
+    reference binaries (tests/golden/bench_sh.npz), digit for digit."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import leandvb_bench as lb
+    lb.RX_EXTRA = ""
+    g = gold("bench_sh.npz")
+    text, ts = lb.run_pipeline(ratio, snr, flags, npk, ref="graph")
+    assert len(ts) // 188 == int(g[name + "_ts_n"]) and hashlib.sha256(ts).digest() == bytes(g[name + "_ts_sha"])
+    assert text == bytes(g[name + "_info"]).decode()
+
+
+@need_graph
+def test_reference_leandvb_big_pipes_and_throughput_mode(oracle):
+    """The same unmodified program with the reference's own --buf-factor option raised (pipes of 16 Mi samples instead of
+    16 Ki: what a GPU wants) and, through the environment, the throughput receiver: the transport stream is the exact
+    chain's in both cases."""
+    import pyoracle as po
+    from leansdr_amd import synth_dvbs
+    iq, ts_in = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=5)
+    x = oracle.cconverter_u8(iq)
+    p = po.rx_params(sampler=1, cstln=1, omega=float(np.float32(2400e3 / 2000e3)), meas_decimation=int(2400e3 / 5))
+    want = oracle.fec_chain(oracle.rx(p, x)["sym"], 1, 0, 0)[0]
+    cmd = [os.path.join(RG, "leandvb"), "--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0", "--buf-factor", "4096"]
+    r = subprocess.run(cmd, input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    assert r.returncode == 0, r.stderr.decode()
+    ts = np.frombuffer(r.stdout, np.uint8).reshape(-1, 188)
+    assert len(want) > 900 and bits_equal(ts, want)
+    r = subprocess.run(cmd, input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, env=dict(os.environ, LSDR_TILED="1"))
+    assert r.returncode == 0, r.stderr.decode()
+    got = [bytes(t) for t in np.frombuffer(r.stdout, np.uint8).reshape(-1, 188)]
+    tail = [bytes(t) for t in want[16:]]
+    assert tail[0] in got
+    i0 = got.index(tail[0])
+    assert got[i0:i0 + len(tail)] == tail
+
+
+@need_graph
+@pytest.mark.parametrize("fmt,dtype,zero", [("--s8", np.int8, 0), ("--u16", np.uint16, 32768), ("--s16", np.int16, 0)])
+def test_reference_leandvb_other_input_formats(oracle, fmt, dtype, zero):
+    """--s8 / --u16 / --s16 (cconverter<s8|u16|s16,…>, leandvb.cc:218-248): the same capture re-expressed in each integer
+    format decodes to the transport stream of the u8 run."""
+    from leansdr_amd import synth_dvbs
+    iq, _ = synth_dvbs.capture_u8(n_packets=300, sps_num=6, sps_den=5, seed=8)
+    base = [os.path.join(RG, "leandvb"), "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0"]
+    r0 = subprocess.run(base + ["--u8"], input=iq.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    assert r0.returncode == 0 and len(r0.stdout) > 200 * 188, r0.stderr.decode()
+    x = (iq.astype(np.int32) - 128 + zero).astype(dtype)          # same sample values around the format's zero
+    r1 = subprocess.run(base + [fmt], input=x.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+    assert r1.returncode == 0, r1.stderr.decode()
+    assert r1.stdout == r0.stdout

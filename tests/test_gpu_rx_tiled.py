@@ -17,6 +17,9 @@ from leansdr_amd import synth
 
 pytestmark = pytest.mark.gpu
 
+SS_RTOL = 0.02        # signal-strength report and carried AGC state vs the serial receiver
+MER_ATOL_DB = 0.5     # MER report vs the serial receiver
+
 
 @pytest.fixture(scope="module")
 def stream():
@@ -24,7 +27,7 @@ def stream():
     return x
 
 
-@pytest.mark.parametrize("tile_len,warm", [(512, 1024), (1024, 1024), (256, 1024), (128, 512), (256, 256), (0, 0)])
+@pytest.mark.parametrize("tile_len,warm", [(512, 1024), (1024, 1024), (256, 1024), (128, 512), (256, 256), (128, 256), (0, 0)])
 def test_tiled_vs_serial(capi, ctx, oracle, stream, tile_len, warm):
     p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=4096)
     acq = 40960
@@ -52,8 +55,13 @@ def test_tiled_vs_serial(capi, ctx, oracle, stream, tile_len, warm):
     n0 = (max(tile_len, warm) or 256) // 4 - 8      # (0, 0) = library defaults: 256-sample warm-up at omega 4
     assert bits_equal(out["sym"]["cost"][:n0], ref["sym"]["cost"][:n0])
     # measurement stream has the reference's cadence
-    assert len(out["freq"]) == len(ref["freq"])
-    assert np.allclose(out["ss"], ref["ss"], rtol=0.05)
+    assert len(out["freq"]) == len(ref["freq"]) and len(ref["freq"]) > 50
+    # the estimators behind SS and MER (sdr.h:905-913) are EMAs over ALL chunks: the tiles' per-chunk contributions are
+    # scanned (k_rx_ema), so the reports follow the serial receiver's, not a per-tile restart
+    assert np.allclose(out["ss"], ref["ss"], rtol=SS_RTOL), np.max(np.abs(out["ss"] / ref["ss"] - 1))
+    assert np.max(np.abs(out["mer"] - ref["mer"])) <= MER_ATOL_DB, np.max(np.abs(out["mer"] - ref["mer"]))
+    s0, s1 = out["state"], ref["state"]
+    assert abs(s0.est_insp / s1.est_insp - 1) <= SS_RTOL and abs(s0.agc_gain / s1.agc_gain - 1) <= SS_RTOL
 
 
 def test_tiled_short_input_is_exact(capi, ctx, oracle, stream):
@@ -117,3 +125,38 @@ def test_queued_runs_equal_synchronous_runs(capi, ctx, oracle, stream):
     assert sa.as_dict() == sb.as_dict()
     with pytest.raises(capi.LsdrError):
         b.wait()                      # nothing queued
+
+
+def test_bench_geometry_on_the_c2_chain(capi, ctx, oracle):
+    """The configuration bench.py times: Fs 240 MS/s cf32 at 120 samples/symbol → scaler(×75) + fir_filter(313, /30) on
+    the GPU (bit-exact vs the oracle) → tiled receiver, tiles of 128 samples after a 256-sample warm-up, against the
+    oracle's fir_filter → exact serial receiver from the same acquisition state."""
+    import bench
+    coeffs, decim = bench.c2_filter(capi)
+    x, _ = synth.qpsk_baseband(120 * 65536, 120, seed=11, rms=1.0, snr_db=20.0)
+    y_ref, _ = oracle.fir_filter(coeffs, decim, oracle.scaler(75.0, x))
+    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
+    y, _ = fir.run(x)
+    fir.close()
+    assert bits_equal(y, y_ref)
+    omega = 240e6 / decim / 2e6
+    p = po.rx_params(sampler=1, cstln=1, omega=omega, meas_decimation=8192)
+    acq = 32768
+    a = oracle.rx(p, y_ref[:acq + 1])
+    ref = oracle.rx(p, y_ref[acq:], state_in=a["state"])
+    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=omega, meas_decimation=8192, mode=capi.RX_TILED,
+                           tile_len=128, tile_warmup=256)
+    st = capi.RxState()
+    for k, _ in st._fields_:
+        setattr(st, k, getattr(a["state"], k))
+    r.set_state(st)
+    out = r.run(y[acq:])
+    stats = r.tiled_stats()
+    r.close()
+    assert out["consumed"] == ref["consumed"] and len(out["sym"]) == len(ref["sym"]) > 50000, stats
+    same = (out["sym"]["symbol"] == ref["sym"]["symbol"]).mean()
+    dcost = np.abs(out["sym"]["cost"].astype(int) - ref["sym"]["cost"].astype(int)).mean()
+    assert same >= bench.TOL["min_equal_decisions"] and dcost <= bench.TOL["max_mean_abs_dcost"], (same, dcost, stats)
+    assert stats["bad_seams"] == 0
+    assert bits_equal(out["sym"]["cost"][:56], ref["sym"]["cost"][:56])
+    assert np.allclose(out["ss"], ref["ss"], rtol=SS_RTOL) and np.max(np.abs(out["mer"] - ref["mer"])) <= MER_ATOL_DB

@@ -43,6 +43,33 @@ def test_two_ranks_gloo(tmp_path):
         assert r["total"] == 3000.0 and r["dt"] == 2.0 and r["rate"] == 1500.0
 
 
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` with no launcher starts two ranks itself (torch.distributed.run on 127.0.0.1, gloo) and
+    rank 0 prints ONE line for the whole job; --dry-run exercises exactly that plumbing without a GPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=280)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["units"] == 3000.0 and j["seconds"] == 2.0
+
+
+def test_bench_rejects_mismatched_launcher():
+    """--gpus must equal the number of ranks the launcher started (n_gpus stays honest)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=120)
+    assert p.returncode != 0 and b"--gpus 4" in p.stderr
+
+
+def test_no_rccl_in_the_control_plane():
+    src = open(os.path.join(ROOT, "leansdr_amd", "shard.py")).read()
+    assert 'init_process_group("gloo")' in src and 'init_process_group("nccl"' not in src
+
+
 def test_single_rank_needs_no_torch():
     from leansdr_amd.shard import Shard
     s = Shard()

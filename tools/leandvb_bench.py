@@ -27,7 +27,9 @@ RX_EXTRA = ""   # extra leandvb_amd options (--rx-extra "--buf-factor 4": the re
 
 
 def commands(ratio, snr, flags, ref=False):
-    """The three command lines of one run (leandvb_bench.sh:20-56)."""
+    """The three command lines of one run (leandvb_bench.sh:20-56).  ref: False = this repo's apps, True = the reference
+    binaries (oracle/_ref), "graph" = the reference's own app SOURCES compiled unchanged against this repo's host headers
+    (leansdr_amd/host/ref_graph: every block a GPU block)."""
     num, _, den = ratio.partition("/")
     r = float(num) / float(den or 1)
     symbrate = 1000000
@@ -37,7 +39,10 @@ def commands(ratio, snr, flags, ref=False):
         sigpow, noisepow, scale = 37.5, 37.5 - snr, None
     else:       # fixed noise floor, display scale adjusted
         sigpow, noisepow, scale = snr, 0, 10 * math.sqrt(r)
-    if ref:
+    if ref == "graph":
+        d = os.path.join(ROOT, "leansdr_amd", "host", "ref_graph")
+        tx, ch, rx = f"{d}/leandvbtx", f"{d}/leanchansim", f"{d}/leandvb"
+    elif ref:
         d = os.path.join(ROOT, "oracle", "_ref")
         tx, ch, rx = f"{d}/leandvbtx", f"{d}/leanchansim", f"{d}/leandvb"
     else:
@@ -46,7 +51,7 @@ def commands(ratio, snr, flags, ref=False):
     cnr = "--cnr" if samprate > 3 * symbrate else ""
     c_tx = f"{tx} -f {ratio} --power {sigpow:g} --agc"
     c_ch = f"{ch} --awgn {noisepow:g} --deterministic {'--ou8' if hs else ''}"
-    c_rx = (f"{rx} {'' if hs else f'--f32 --float-scale {scale:.10f}'} -f {samprate} --sr {symbrate} --anf 0 {cnr} --fd-info 2 {flags} {'' if ref else RX_EXTRA}")
+    c_rx = (f"{rx} {'' if hs else f'--f32 --float-scale {scale:.10f}'} -f {samprate} --sr {symbrate} --anf 0 {cnr} --fd-info 2 {flags} {'' if ref is True else RX_EXTRA}")
     return c_tx, c_ch, c_rx, sigpow - noisepow
 
 

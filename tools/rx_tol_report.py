@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""tools/rx_tol_report.py — what the tiled receiver actually achieves against the exact serial loop started from the same
+state, per tile geometry and SNR (feeds the tolerance numbers stated in DESIGN.md §4.2 and asserted in tests/).
+Streams: (a) the 4-sample/symbol test stream of tests/test_gpu_rx_tiled.py, (b) the real C2 chain: 120 sps cf32 →
+fir_filter(313, /30) on the GPU → receiver.   GPU box only."""
+import os, sys, json
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import leansdr_amd.capi as capi
+from leansdr_amd import synth
+import pyoracle as po
+import bench
+
+O = po.Oracle()
+ctx = capi.Ctx(0)
+rows = []
+
+
+def compare(y, tile_len, warm, tag, acq=40960, md=4096):
+    p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=md)
+    a = O.rx(p, y[:acq + 1])
+    ref = O.rx(p, y[acq:], state_in=a["state"])
+    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=4.0, meas_decimation=md, mode=capi.RX_TILED, tile_len=tile_len, tile_warmup=warm)
+    st = capi.RxState()
+    for k, _ in st._fields_:
+        setattr(st, k, getattr(a["state"], k))
+    r.set_state(st)
+    out = r.run(y[acq:])
+    stats = r.tiled_stats()
+    r.close()
+    row = dict(tag=tag, tile=tile_len, warm=warm, n=len(ref["sym"]), count_equal=len(out["sym"]) == len(ref["sym"]), **stats)
+    if row["count_equal"]:
+        row["equal"] = float((out["sym"]["symbol"] == ref["sym"]["symbol"]).mean())
+        dc = np.abs(out["sym"]["cost"].astype(int) - ref["sym"]["cost"].astype(int))
+        row["dcost_mean"] = float(dc.mean()); row["dcost_p99"] = float(np.percentile(dc, 99)); row["dcost_max"] = int(dc.max())
+    nm = min(len(out["ss"]), len(ref["ss"]))
+    if nm:
+        row["n_meas"] = nm
+        row["ss_rel_max"] = float(np.max(np.abs(out["ss"][:nm] / ref["ss"][:nm] - 1)))
+        row["mer_abs_max_db"] = float(np.max(np.abs(out["mer"][:nm] - ref["mer"][:nm])))
+        row["mer_ref_mean"] = float(ref["mer"][:nm].mean()); row["mer_out_mean"] = float(out["mer"][:nm].mean())
+        row["freq_abs_max"] = float(np.max(np.abs(out["freq"][:nm] - ref["freq"][:nm])))
+    s0, s1 = out["state"], ref["state"]
+    row["state_est_insp_rel"] = abs(s0.est_insp / s1.est_insp - 1); row["state_agc_rel"] = abs(s0.agc_gain / s1.agc_gain - 1)
+    row["state_est_ep_rel"] = abs(s0.est_ep / s1.est_ep - 1)
+    rows.append(row)
+    print(json.dumps(row), flush=True)
+
+
+GEOS = [(128, 256), (128, 512), (256, 256), (256, 512), (512, 1024), (0, 0)]
+for snr in (20.0, 12.0, 8.0):
+    x, _ = synth.qpsk_baseband(4 * 100000, 4, seed=5, rms=50.0, snr_db=snr)
+    for g in GEOS:
+        compare(x, g[0], g[1], f"4sps snr{snr:g}")
+
+coeffs, decim = bench.c2_filter(capi)
+for snr in (20.0, 10.0):
+    x, _ = synth.qpsk_baseband(120 * 65536, 120, seed=11, rms=1.0, snr_db=snr)
+    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
+    y, _ = fir.run(x)
+    fir.close()
+    for g in GEOS[:3]:
+        compare(y, g[0], g[1], f"c2chain snr{snr:g}", acq=32768, md=8192)
+# acquisition gear of the warm-up: (symbols, alpha multiplier, gain_mu multiplier)
+x4, _ = synth.qpsk_baseband(4 * 100000, 4, seed=5, rms=50.0, snr_db=12.0)
+x20, _ = synth.qpsk_baseband(120 * 65536, 120, seed=11, rms=1.0, snr_db=20.0)
+fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
+y20, _ = fir.run(x20)
+fir.close()
+for acq in [(0, 1, 1), (16, 4, 4), (24, 4, 4), (32, 4, 4), (32, 2, 4), (32, 4, 2), (32, 8, 8), (48, 4, 4), (24, 6, 2), (40, 3, 3)]:
+    os.environ["LSDR_RX_ACQ_SYMS"], os.environ["LSDR_RX_ACQ_ALPHA"], os.environ["LSDR_RX_ACQ_MU"] = (str(v) for v in acq)
+    compare(y20, 128, 256, f"acq{acq} c2 snr20", acq=32768, md=8192)
+    compare(x4, 128, 256, f"acq{acq} 4sps snr12")
+json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "rx_tol_report.json"), "w"), indent=1)
