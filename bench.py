@@ -51,14 +51,30 @@ EXTRA = 128                # decimated samples fir_filter produces past the batc
 TOL = dict(min_equal_decisions=0.999, max_mean_abs_dcost=0.05 * 11236)
 
 
-def c2_filter(capi):
-    """Filter design of leandvb.cc:353-378 for Fs=240e6, Fm=2e6 -> order 312, decim 30."""
+def c2_design():
+    """Filter design of leandvb.cc:353-378 for Fs=240e6, Fm=2e6 -> order 312, cut-off, decimation 30."""
     decim = int(FS / (FM * 4))
     transition = (FM / 2) * ROLLOFF
     order = int(REJ * FS / (22 * transition))
     order = ((order + 1) // 2) * 2
     fcut = np.float32((FM / 2) * (1 + ROLLOFF / 2) / FS)
+    return order, fcut, decim
+
+
+def c2_filter(capi):
+    order, fcut, decim = c2_design()
     return capi.lowpass(order, fcut), decim
+
+
+def c2_geometry(batch_msamples, period_msamples, ncoeffs, decim):
+    """A batch = whole symbols and whole receiver chunks (so that every batch consumes exactly B samples)."""
+    sps = int(FS / FM)
+    unit = int(128 * decim * sps // np.gcd(128 * decim, sps))
+    period = max(1, (period_msamples << 20) // unit) * unit
+    reps = max(1, (batch_msamples << 20) // period)
+    B = period * reps
+    assert B % decim == 0 and (B // decim) % 128 == 0 and EXTRA * decim + ncoeffs <= period
+    return dict(period=period, reps=reps, B=B, n_out=B // decim, N=ncoeffs, decim=decim, sps=sps, nbuf=3)
 
 
 def _oracle():
@@ -67,47 +83,50 @@ def _oracle():
     return po
 
 
+def _cpu_worker(args):
+    x, coeffs, decim, seconds, use_ref = args
+    po = _oracle()
+    O = po.Ref() if use_ref else po.Oracle()
+    p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=1 << 20)
+    n_done, t0 = 0, time.perf_counter()
+    while True:
+        xs = O.scaler(75.0, x)
+        y = O.fir_filter(coeffs, decim, xs)
+        y = y[0] if isinstance(y, tuple) else y
+        O.rx(p, y)
+        n_done += len(x)
+        if time.perf_counter() - t0 >= seconds:
+            break
+    return n_done, time.perf_counter() - t0
+
+
 def cpu_baseline(x, coeffs, decim, budget_s):
-    """CPU baseline over a bounded sample: scaler -> fir_filter -> cstln_receiver on independent streams, one per thread
-    (the reference is single-threaded by design; `nproc` processes is how it scales).  When the real reference was built
-    (oracle/_ref/libleansdr_ref.so: the reference's own headers behind oracle/ref_harness.cc) it is what gets timed (kind
-    "reference"); otherwise the plain-C oracle (kind "port").  Test infrastructure used as a yardstick only."""
+    """CPU baseline over a bounded sample: scaler -> fir_filter -> cstln_receiver on independent streams, one PROCESS per
+    host core (the reference is single-threaded by design; `nproc` processes is how it scales).  When the real reference
+    was built (oracle/_ref/libleansdr_ref.so: the reference's own headers behind oracle/ref_harness.cc) it is what gets
+    timed (kind "reference"); otherwise the plain-C oracle (kind "port").  Test infrastructure used as a yardstick only.
+    Runs BEFORE the process touches the GPU (the workers are forked)."""
+    import multiprocessing as mp
     po = _oracle()
     use_ref = po.have_ref()
-    p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=1 << 20)
-
-    def worker(seconds, out, idx):
-        O = po.Ref() if use_ref else po.Oracle()
-        n_done, t0 = 0, time.perf_counter()
-        while True:
-            xs = O.scaler(75.0, x)
-            y = O.fir_filter(coeffs, decim, xs)
-            y = y[0] if isinstance(y, tuple) else y
-            O.rx(p, y)
-            n_done += len(x)
-            if time.perf_counter() - t0 >= seconds:
-                break
-        out[idx] = (n_done, time.perf_counter() - t0)
-
-    def run(nthreads, seconds):
-        res = [None] * nthreads
-        th = [threading.Thread(target=worker, args=(seconds, res, i)) for i in range(nthreads)]
-        t0 = time.perf_counter()
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        wall = time.perf_counter() - t0
-        return sum(r[0] for r in res) / wall / 1e6, wall
-
-    one, w1 = run(1, budget_s * 0.4)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    allc, wn = run(cores, budget_s * 0.6) if cores > 1 else (one, 0.0)
+    ctx = mp.get_context("fork")
+    one_n, one_t = _cpu_worker((x, coeffs, decim, budget_s * 0.3, use_ref))
+    one = one_n / one_t / 1e6
+    if cores > 1:
+        t0 = time.perf_counter()
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(x, coeffs, decim, budget_s * 0.7, use_ref)] * cores, chunksize=1)
+        wall = time.perf_counter() - t0
+        allc = sum(r[0] for r in res) / max(r[1] for r in res) / 1e6
+    else:
+        allc, wall = one, 0.0
     lib = "oracle/_ref/libleansdr_ref.so (pabr/leansdr blocks, g++ -O3)" if use_ref else "oracle/liblsdr_oracle.so"
     return dict(value=round(allc, 3), unit="MS/s", cores=cores, kind="reference" if use_ref else "port",
                 one_core=round(one, 3),
                 sample=f"{lib}: scaler+fir_filter+cstln_receiver over {len(x)}-sample passes of the same workload; "
-                       f"1 thread for {w1:.1f} s, then {cores} independent streams (one thread each) for {wn:.1f} s")
+                       f"1 process for {one_t:.1f} s, then {cores} independent streams (one process per core) for "
+                       f"{budget_s * 0.7:.1f} s ({wall:.1f} s incl. start-up)")
 
 
 def pmc_traffic(batch_samples):
@@ -141,12 +160,12 @@ class Capture:
     """One capture: its endless input in HBM, the decimated-stream buffers, the symbol buffer, its receiver (own HIP
     stream).  fir_filter of all captures of a GPU goes through ONE launch on the fir stream."""
 
-    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, notch=None):
+    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None):
         self.capi, self.idx, self.geo = capi, idx, geo
         period, reps, B, n_out, N, decim = geo["period"], geo["reps"], geo["B"], geo["n_out"], geo["N"], geo["decim"]
         self.x, _ = synth.qpsk_baseband(period, geo["sps"], seed=seed, rms=1.0, snr_db=20.0, freq=freq)
         self.ctx = fir_ctx
-        self.ctx_rx = capi.Ctx(device)
+        self.ctx_rx = capi.Ctx(device, cu_mask=rx_cus)
         self.d_in = self.ctx.alloc((B + period) * 8)
         dp = self.ctx.upload(self.x)
         for r in range(reps + 1):
@@ -190,24 +209,30 @@ class Capture:
 class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
-    def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0):
+    def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
+                 cu_pattern="xcd_major"):
         self.capi = capi
-        self.ctx = capi.Ctx(device)
+        # CU partition: the latency-bound receiver tiles get rx_cus compute units of their own (the same number from every
+        # XCD), the HBM-streaming fir_filter the rest, so that neither disturbs the other's issue slots / L1
+        fir_mask = rx_mask = None
+        if rx_cus:
+            total, per_xcd = 256, max(1, rx_cus // 8)
+            if cu_pattern == "xcd_major":        # mask bit i = CU i%32 of XCD i/32
+                rx_mask = [x * 32 + k for x in range(8) for k in range(per_xcd)]
+            else:                                # mask bit i = CU i/8 of XCD i%8
+                rx_mask = list(range(8 * per_xcd))
+            fir_mask = [i for i in range(total) if i not in set(rx_mask)]
+        self.rx_cus = len(rx_mask) if rx_mask else 0
+        self.ctx = capi.Ctx(device, cu_mask=fir_mask)
         coeffs, decim = c2_filter(capi)
         self.coeffs, self.decim = coeffs, decim
-        N, sps = len(coeffs), int(FS / FM)
-        unit = int(128 * decim * sps // np.gcd(128 * decim, sps))     # batch = whole symbols and whole receiver chunks
-        period = max(1, (period_msamples << 20) // unit) * unit
-        reps = max(1, (batch_msamples << 20) // period)
-        B = period * reps
-        self.geo = dict(period=period, reps=reps, B=B, n_out=B // decim, N=N, decim=decim, sps=sps, nbuf=3)
-        assert B % decim == 0 and (B // decim) % 128 == 0 and EXTRA * decim + N <= period
+        self.geo = c2_geometry(batch_msamples, period_msamples, len(coeffs), decim)
         self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0)
         if freq:
             self.fir.set_freq(freq)
         self.rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
         self.tile = tile
-        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=0.0)
+        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=0.0, rx_cus=rx_mask)
                      for c in range(n_captures)]
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)
@@ -338,6 +363,8 @@ def main():
     ap.add_argument("--tile-warmup", type=int, default=256)
     ap.add_argument("--captures", type=int, default=6,
                     help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles)")
+    ap.add_argument("--rx-cus", type=int, default=0, help="compute units reserved for the receiver streams (0: no partition)")
+    ap.add_argument("--cu-pattern", choices=["xcd_major", "interleaved"], default="xcd_major")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -362,14 +389,23 @@ def main():
         shard.close()
         return
 
-    import leansdr_amd.capi as capi
     from leansdr_amd import synth
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:     # before the GPU is touched: the CPU workers are forked
+        order, fcut, decim0 = c2_design()
+        c0 = _oracle().Oracle().lowpass(order, fcut)
+        g0 = c2_geometry(args.batch_msamples, args.period_msamples, len(c0), decim0)
+        x_cpu, _ = synth.qpsk_baseband(g0["period"], g0["sps"], seed=shard.capture_seed(), rms=1.0, snr_db=20.0)
+        cpu = cpu_baseline(x_cpu, c0, decim0, args.cpu_seconds)
+        del x_cpu
+
+    import leansdr_amd.capi as capi
 
     if capi.lib.lsdr_device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {capi.lib.lsdr_device_count()} visible")
     tile = (args.tile_len, args.tile_warmup)
     pipe = C2Pipeline(capi, synth, local_rank, args.captures, args.batch_msamples, args.period_msamples, tile,
-                      seed0=shard.capture_seed())
+                      seed0=shard.capture_seed(), rx_cus=args.rx_cus, cu_pattern=args.cu_pattern)
     bps = args.batches_per_step
 
     pipe.run(args.warmup * bps, False)
@@ -405,7 +441,8 @@ def main():
                        "batches_per_step": bps, "batch_samples_per_capture": g["B"], "captures_per_gpu": len(pipe.caps),
                        "samples_per_step_per_gpu": g["B"] * len(pipe.caps) * bps,
                        "rx_mode": "tiled", "rx_tile": {"tile_len": tile[0], "warmup": tile[1]},
-                       "rx_tiles_last_run": pipe.caps[0].rx.tiled_stats(),
+                       "cu_partition": {"receiver_cus": pipe.rx_cus, "fir_filter_cus": 256 - pipe.rx_cus} if pipe.rx_cus else None,
+                       "rx_tiles_last_run": pipe.caps[0].rx.tiled_stats(), "rx_decisions": pipe.caps[0].rx.decision_mode(),
                        "streams": "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k), "
                                   "one HIP stream per capture, receiver runs queued (lsdr_rx_run_async)",
                        "parallelism": f"{world * len(pipe.caps)} independent capture(s), {len(pipe.caps)} per GPU, no collectives, no RCCL",
@@ -425,8 +462,9 @@ def main():
         if world == 1 and not args.no_more:
             import bench_more
             out["more"] = bench_more.run_all(capi, synth, local_rank, args)
-        if not args.no_cpu and world == 1:   # reported at N=1 only
-            out["cpu_baseline"] = cpu_baseline(x0, coeffs, decim, args.cpu_seconds)
+        if cpu is not None:   # reported at N=1 only
+            assert np.array_equal(c0, coeffs), "cpu_baseline used other filter coefficients than the GPU path"
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     shard.close()
     sys.exit(rc)

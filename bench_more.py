@@ -14,7 +14,8 @@ sys.path.insert(0, ROOT)
 def single_stream(capi, synth, device, args):
     """north_star's N=1 case: ONE capture on the GPU (fir_filter(k+1) ‖ cstln_receiver(k) on two HIP streams)."""
     import bench
-    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=77)
+    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=77,
+                            rx_cus=args.rx_cus, cu_pattern=args.cu_pattern)
     bps = args.batches_per_step
     pipe.run(bps, False)
     pipe.sync()

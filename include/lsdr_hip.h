@@ -50,6 +50,10 @@ int lsdr_abi_version(void);
 const char *lsdr_last_error(void);
 /* stream == NULL: the ctx creates (and owns) a non-blocking HIP stream. */
 int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **ctx);
+/* A context whose stream may only use the compute units set in cu_mask (bit i of word i/32 = CU i): lets two blocks
+ * that would disturb each other (the HBM-streaming fir_filter and the latency-bound receiver tiles) own disjoint parts of
+ * the chip.  Kernels size their grids for the masked CU count. */
+int lsdr_ctx_create_masked(int device, const uint32_t *cu_mask, unsigned mask_words, lsdr_ctx **ctx);
 void lsdr_ctx_destroy(lsdr_ctx *ctx);
 int lsdr_ctx_sync(lsdr_ctx *ctx);
 void *lsdr_ctx_stream(lsdr_ctx *ctx);
@@ -266,6 +270,10 @@ int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
  * of cstln_receiver<f32>, sdr.h:923-935) into a pinned slot in stream order, i.e. the state the NEXT queued run starts
  * from; lsdr_rx_get_snapshot() waits for the stream and returns it.  Lets a caller (bench.py's verification) replay one
  * queued run on a checker from exactly the state the device used, without putting the host between two runs. */
+/* LSDR_RX_TILED, QPSK: whether the tolerance tiles take their decisions by arithmetic instead of the constellation-table
+ * gather (only when lsdr_rx_create verified the arithmetic against all 65536 table entries: symbol/cost/point identical,
+ * |phase_error difference| ≤ 2 table units — reported in *max_phase_error_delta). */
+int lsdr_rx_decision_mode(const lsdr_rx *rx, int *arithmetic, unsigned *max_phase_error_delta);
 int lsdr_rx_snapshot_async(lsdr_rx *rx);
 int lsdr_rx_get_snapshot(lsdr_rx *rx, lsdr_rx_state *st);
 

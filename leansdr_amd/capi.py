@@ -65,6 +65,7 @@ _sig("lsdr_abi_version", C.c_int, [])
 _sig("lsdr_last_error", C.c_char_p, [])
 _sig("lsdr_device_count", C.c_int, [])
 _sig("lsdr_ctx_create", C.c_int, [C.c_int, vp, C.POINTER(vp)])
+_sig("lsdr_ctx_create_masked", C.c_int, [C.c_int, vp, C.c_uint, C.POINTER(vp)])
 _sig("lsdr_ctx_destroy", None, [vp])
 _sig("lsdr_ctx_sync", C.c_int, [vp])
 _sig("lsdr_ctx_stream", vp, [vp])
@@ -191,6 +192,7 @@ _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
 _sig("lsdr_rx_wait", C.c_int, [vp, psz])
+_sig("lsdr_rx_decision_mode", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint)])
 _sig("lsdr_rx_snapshot_async", C.c_int, [vp])
 _sig("lsdr_rx_get_snapshot", C.c_int, [vp, C.POINTER(RxState)])
 
@@ -268,9 +270,18 @@ class DevBuf:
 
 
 class Ctx:
-    def __init__(self, device=0, stream=None):
+    def __init__(self, device=0, stream=None, cu_mask=None):
+        """cu_mask: iterable of CU indices this context's stream may use (None: the whole GPU)."""
         h = vp()
-        check(lib.lsdr_ctx_create(device, stream, C.byref(h)))
+        if cu_mask is None:
+            check(lib.lsdr_ctx_create(device, stream, C.byref(h)))
+        else:
+            cus = sorted(set(int(c) for c in cu_mask))
+            words = (max(cus) // 32 + 1) if cus else 1
+            m = (C.c_uint32 * words)()
+            for c in cus:
+                m[c // 32] |= 1 << (c % 32)
+            check(lib.lsdr_ctx_create_masked(device, m, words, C.byref(h)))
         self.h = h
 
     def close(self):
@@ -457,6 +468,11 @@ class CstlnReceiver:
 
     def set_state(self, st):
         check(lib.lsdr_rx_set_state(self.h, C.byref(st)))
+
+    def decision_mode(self):
+        a, d = C.c_int(), C.c_uint()
+        check(lib.lsdr_rx_decision_mode(self.h, C.byref(a), C.byref(d)))
+        return dict(arithmetic=bool(a.value), max_phase_error_delta=d.value)
 
     def snapshot_async(self):
         """Copy the device-side loop state into the receiver's pinned slot, in stream order (between queued runs)."""

@@ -104,6 +104,12 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {  // math.h:40-43
 }
 
 // cstln_lut<256>::lookup(float,float), sdr.h:470-482
+__device__ __forceinline__ void lut_halve(float &I, float &Q) {   // the range-folding loop of sdr.h:470-476 alone
+  while (__builtin_fmaxf(__builtin_fabsf(I + 0.5f), __builtin_fabsf(Q + 0.5f)) > 127.5f) {
+    I *= 0.5f;
+    Q *= 0.5f;
+  }
+}
 __device__ __forceinline__ unsigned lut_index(float I, float Q) {
   // `I < -128 || I > 127` ⟺ `|I + 0.5| > 127.5`: the addition is exact wherever the comparison could be
   // affected (|I| in [64, 256): 0.5 is a multiple of ulp(I) and the sum does not leave that grid), and
@@ -120,6 +126,48 @@ __device__ __forceinline__ unsigned lut_index(float I, float Q) {
 __device__ __forceinline__ float fmod65536(float x) {
   float q = __builtin_truncf(x * (1.0f / 65536.0f));
   return x - q * 65536.0f;
+}
+
+// ---- QPSK decisions by arithmetic (tolerance tiles only) ------------------------------------------------------------
+// What the 512 KiB constellation table holds for QPSK (sdr.h:334-337 points (±53,±53); sdr.h:529-560 table), computed
+// from the truncated coordinates instead of gathered: the gather is the only memory access on the per-symbol dependency
+// chain of a tile, and an L2 round trip under fir_filter's streaming costs more than these ≈ 35 ALU operations.
+//   symbol / cost: EXACT (integer arithmetic: nearest point by signs — ties go to '+' like the table's lowest-index rule —
+//     second nearest = flip the coordinate of smaller magnitude, d2 = d1 + 4·53·min(|I|,|Q|), both clamped to 32767);
+//   phase_error: atan2 by a degree-11 odd polynomial, within ±2 units of the table's (s32)((atan2f(Q,I) − atan2f(sym))·65536/2π)
+//     (the table's unit is 2π/65536 rad; the loops multiply it by 0.04 and 0.0003).
+// lsdr_rx_create checks both claims against the real table over all 65536 entries and keeps the gather if they fail.
+struct qpsk_decision { int cost; unsigned symbol; int phase_error, pt_re, pt_im; };
+__host__ __device__ __forceinline__ qpsk_decision qpsk_decide(int Ii, int Qi) {
+  qpsk_decision d;
+  const int a = Ii < 0 ? -Ii : Ii, b = Qi < 0 ? -Qi : Qi;
+  const bool ni = Ii < 0, nq = Qi < 0;
+  d.symbol = (ni ? 2u : 0u) | (nq ? 1u : 0u);
+  d.pt_re = ni ? -53 : 53; d.pt_im = nq ? -53 : 53;
+  const int da = a - 53, db = b - 53, d1 = da * da + db * db;
+  int d2 = d1 + 212 * (a < b ? a : b);
+  d2 = d2 > 32767 ? 32767 : d2;
+  d.cost = d1 - d2;                                    // d1 ≤ 2·75² < 32767
+  const float fa = (float)a, fb = (float)b;
+  const float mx = fa > fb ? fa : fb, mn = fa > fb ? fb : fa;
+#ifdef __HIP_DEVICE_COMPILE__
+  const float t = mx > 0.f ? mn * __builtin_amdgcn_rcpf(mx) : 0.f;
+#else
+  const float t = mx > 0.f ? mn / mx : 0.f;
+#endif
+  const float t2 = t * t;
+  // atan(t), 0 ≤ t ≤ 1 (max error 2e-6 rad)
+  float p = -0.0117212f;
+  p = p * t2 + 0.05265332f;
+  p = p * t2 - 0.11643287f;
+  p = p * t2 + 0.19354346f;
+  p = p * t2 - 0.33262347f;
+  p = p * t2 + 0.99997726f;
+  const float at = p * t;
+  const float ang = fb > fa ? 1.57079633f - at : at;  // atan2(b, a), first quadrant
+  const int pe = (int)((ang - 0.785398163f) * 10430.3784f);   // truncation toward zero, like the table's (s32) cast
+  d.phase_error = ni != nq ? -pe : pe;
+  return d;
 }
 
 // ---- table access policies -------------------------------------------------------------------------
@@ -458,7 +506,8 @@ struct rx_tiled_args {
   lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
   unsigned wstride;
   rx_tile_info *info;
-  rx_ema_map *ema;                     // [n_tiles]: estimator map of each tile's body (k_rx_ema scans them)
+  rx_ema_map *ema;                     // [n_tiles]: composition of the maps of the tiles BEFORE this one in its wavefront
+  rx_ema_map *ema_wave;                // [n_waves]: composition of all tiles of a wavefront (k_rx_ema scans these)
   const rx_state_dev *state;           // carried state at the start of the run (read-only while tiles are running)
   rx_state_dev *state_next;            // end state of the last tile (k_rx_ema moves it into `state`)
   rx_meas *meas;                       // [n_meas] measurement slots (may be null)
@@ -500,7 +549,8 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   }
   ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
   a.info[0] = ti;
-  a.ema[0] = m;
+  { rx_ema_map id; id.a = 1.f; id.bi = id.bs = id.be = 0.f; a.ema[0] = id; }
+  a.ema_wave[0] = m;
   if (a.n_tiles == 1) {
     s.meas_count = (a.meas_base + a.total_chunks * kChunk) % a.C.meas_decimation;
     *a.state_next = s;
@@ -518,7 +568,7 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
 // together with it, as a 3-sample window — the next symbol instant is n + ⌊mu + omega + mucorr⌋ with |mucorr| ≤ 0.1,
 // i.e. one of two adjacent positions — and the soft symbol is stored fire-and-forget (the following wait is for the
 // next iteration's loads, one full symbol step later).  No LDS (fir_filter's two workgroups per CU need it), no scratch.
-template <int SAMP, int NT>
+template <int SAMP, int NT, bool ARITH>
 __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane) {
   if (lane >= NT || j0 + (unsigned)lane >= a.n_tiles) return;
   const unsigned j = j0 + (unsigned)lane;
@@ -597,7 +647,8 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         sg = s0;
       }
       sv = make_float2(sg.x * agc, sg.y * agc);
-      const uint2 raw = *reinterpret_cast<const uint2 *>(a.T.lut + lut_index(sv.x, sv.y));
+      uint2 raw;
+      if (!ARITH) raw = *reinterpret_cast<const uint2 *>(a.T.lut + lut_index(sv.x, sv.y));
       // window for the next symbol: ⌊mu + omega − 0.1⌋ samples ahead (at least one)
       int lo = (int)(mu + C.omega - 0.1f);
       lo = lo < 1 ? 1 : lo;
@@ -605,7 +656,17 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
       const float2 v0 = base[wn2 < n_last ? wn2 : n_last];
       const float2 v1 = base[wn2 + 1 < n_last ? wn2 + 1 : n_last];
       const float2 v2 = base[wn2 + 2 < n_last ? wn2 + 2 : n_last];
-      const lut_entry e = lut_unpack(raw.x, raw.y);
+      lut_entry e;
+      if (ARITH) {
+        float hi = sv.x, hq = sv.y;
+        lut_halve(hi, hq);
+        const qpsk_decision qd = qpsk_decide((int)hi, (int)hq);
+        e.cost = (int16_t)qd.cost; e.symbol = (uint8_t)qd.symbol; e.zero = 0;
+        e.phase_error = (int16_t)qd.phase_error; e.pt_re = (int8_t)qd.pt_re; e.pt_im = (int8_t)qd.pt_im;
+        raw.x = ((unsigned)qd.cost & 0xffffu) | (qd.symbol << 16);
+      } else {
+        e = lut_unpack(raw.x, raw.y);
+      }
       *dp = raw.x; dp += keep;
       last = raw.x;
       ++nsym;
@@ -659,7 +720,22 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   }
   ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
   a.info[j] = ti;
-  a.ema[j] = m;
+  {
+    // inclusive composition over the tiles of this wavefront (lane order = stream order; the lanes that left early are
+    // the highest ones and are never read): lane L ends with maps[first] … maps[L] composed
+    rx_ema_map inc = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      rx_ema_map o;
+      o.a = __shfl_up(inc.a, d, 64); o.bi = __shfl_up(inc.bi, d, 64); o.bs = __shfl_up(inc.bs, d, 64); o.be = __shfl_up(inc.be, d, 64);
+      if (lane >= d) inc = ema_then(o, inc);
+    }
+    rx_ema_map ex;
+    ex.a = __shfl_up(inc.a, 1, 64); ex.bi = __shfl_up(inc.bi, 1, 64); ex.bs = __shfl_up(inc.bs, 1, 64); ex.be = __shfl_up(inc.be, 1, 64);
+    if (lane == 0) { ex.a = 1.f; ex.bi = ex.bs = ex.be = 0.f; }
+    a.ema[j] = ex;
+    if (lane == NT - 1 || j == a.n_tiles - 1) a.ema_wave[blockIdx.x] = inc;
+  }
   if (j == a.n_tiles - 1) {
     rx_state_dev *o = a.state_next;
     o->mu = mu; o->phase = phase; o->freqw = freqw; o->agc_gain = agc;
@@ -672,28 +748,30 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   }
 }
 
-template <int SAMP, int NT>
+template <int SAMP, int NT, bool ARITH>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
   if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP>(a); }
-  else rx_tile_tol<SAMP, NT>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
+  else rx_tile_tol<SAMP, NT, ARITH>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
 }
 
-// Scan of the tiles' estimator maps (one workgroup): final estimators/AGC of the run and the measurement slots.
+// Scan of the wavefronts' estimator maps (one workgroup; a run has a few hundred wavefronts): final estimators / AGC of
+// the run and the measurement slots.
 //  * state ← state_next (end state of the last tile; tiles read `state` while they run, so it is only replaced here),
 //    with est_insp/est_sp/est_ep = (all maps composed)(carried values) and agc_gain = 75/sqrt(est_insp) (sdr.h:870);
 //  * slot q of `meas` holds the partial map of its tile up to the measurement instant: composed with the maps of the
-//    preceding tiles it becomes the estimator values there.
+//    preceding wavefronts and of the preceding tiles of its own wavefront (ex[]) it becomes the estimator values there.
 constexpr unsigned kEmaThreads = 256;
-__global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *tile, unsigned n_tiles, const rx_state_dev *next,
-                                                        rx_state_dev *state, rx_meas *meas, unsigned nm) {
-  __shared__ rx_ema_map s_pre[kEmaThreads];     // composition of everything before thread t's tiles
+__global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *wave, unsigned n_waves, const rx_ema_map *ex, unsigned n_tiles,
+                                                        unsigned lanes_per_wave, const rx_state_dev *next, rx_state_dev *state,
+                                                        rx_meas *meas, unsigned nm) {
+  __shared__ rx_ema_map s_pre[kEmaThreads];     // composition of everything before thread t's wavefronts
   __shared__ rx_ema_map s_wave[kEmaThreads / 64];
   const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const unsigned per = (n_tiles + kEmaThreads - 1) / kEmaThreads;
-  const unsigned lo = t * per < n_tiles ? t * per : n_tiles, hi = lo + per < n_tiles ? lo + per : n_tiles;
+  const unsigned per = (n_waves + kEmaThreads - 1) / kEmaThreads;
+  const unsigned lo = t * per < n_waves ? t * per : n_waves, hi = lo + per < n_waves ? lo + per : n_waves;
   const float e_insp = state->est_insp, e_sp = state->est_sp, e_ep = state->est_ep;   // carried values
   rx_ema_map m; m.a = 1.f; m.bi = m.bs = m.be = 0.f;
-  for (unsigned i = lo; i < hi; ++i) m = ema_then(m, tile[i]);
+  for (unsigned i = lo; i < hi; ++i) m = ema_then(m, wave[i]);
   rx_ema_map inc = m;                            // inclusive scan over the lanes of a wave
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
@@ -719,9 +797,11 @@ __global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *tile, 
   }
   for (unsigned q = t; q < nm; q += kEmaThreads) {
     rx_meas mm = meas[q];
-    const unsigned j = mm.tile < n_tiles ? mm.tile : 0u, owner = j / per;
+    const unsigned j = mm.tile < n_tiles ? mm.tile : 0u;
+    const unsigned w = j == 0 ? 0u : 1u + (j - 1u) / lanes_per_wave, owner = w / per;
     rx_ema_map pm = s_pre[owner];
-    for (unsigned i = owner * per; i < j; ++i) pm = ema_then(pm, tile[i]);
+    for (unsigned i = owner * per; i < w; ++i) pm = ema_then(pm, wave[i]);
+    pm = ema_then(pm, ex[j]);
     rx_ema_map part; part.a = mm.a; part.bi = mm.est_insp; part.bs = mm.est_sp; part.be = mm.est_ep;
     const rx_ema_map f = ema_then(pm, part);
     mm.est_insp = f.a * e_insp + f.bi; mm.est_sp = f.a * e_sp + f.bs; mm.est_ep = f.a * e_ep + f.be;
@@ -753,7 +833,8 @@ struct lsdr_rx {
   lsdr_softsymbol *d_stage; size_t stage_cap;
   lsdr_softsymbol *d_wstage; size_t wstage_cap;
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
-  rx_ema_map *d_ema;              // [tiles_cap] per-tile estimator maps
+  rx_ema_map *d_ema;              // [tiles_cap] per-tile exclusive prefix inside its wavefront
+  rx_ema_map *d_ema_wave;         // [tiles_cap + 1] per-wavefront estimator maps
   rx_state_dev *d_state_next;     // end state of a tiled run before k_rx_ema installs it
   rx_state_dev *h_snap;           // pinned: lsdr_rx_snapshot_async target
   uint8_t *d_relabel;
@@ -769,6 +850,8 @@ struct lsdr_rx {
   unsigned ring_tiles[kRing];
   int ring_head, ring_count;           // oldest outstanding slot, number outstanding
   bool st_stale_host;                  // device state newer than the host mirror `st`
+  bool qpsk_arith;                     // tolerance tiles decide by arithmetic (QPSK, verified against the table at create time)
+  unsigned arith_max_dpe;              // largest |phase_error − table| seen by that verification
 };
 
 static void rx_state_export(const rx_state_dev &s, lsdr_rx_state *st) {
@@ -895,6 +978,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   if (r->tiles_cap < n_tiles) {
     (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_part); (void)hipFree(r->d_ema);
     LSDR_HIP(hipMalloc((void **)&r->d_ema, n_tiles * sizeof(rx_ema_map)));
+    (void)hipFree(r->d_ema_wave);
+    LSDR_HIP(hipMalloc((void **)&r->d_ema_wave, ((size_t)n_tiles + 1) * sizeof(rx_ema_map)));
     LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + kSeamBlock - 1) / kSeamBlock) * sizeof(rx_seam_part)));
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
@@ -933,6 +1018,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   a.wstage = r->d_wstage; a.wstride = sym_per_chunk;
   a.info = r->d_info;
   a.ema = r->d_ema;
+  a.ema_wave = r->d_ema_wave;
   a.state = r->d_state;
   a.state_next = r->d_state_next;
   a.meas = want_meas ? r->d_meas : nullptr;
@@ -951,7 +1037,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
     a.lanes_per_wave = (unsigned)lpw;
   }
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
-#define LSDR_RX_LAUNCH(S, N) hipLaunchKernelGGL((k_rx_tiles<S, N>), dim3(blocks), dim3(64), 0, c->stream, a)
+#define LSDR_RX_LAUNCH(S, N) do { if (r->qpsk_arith) hipLaunchKernelGGL((k_rx_tiles<S, N, true>), dim3(blocks), dim3(64), 0, c->stream, a); \
+                                  else hipLaunchKernelGGL((k_rx_tiles<S, N, false>), dim3(blocks), dim3(64), 0, c->stream, a); } while (0)
 #define LSDR_RX_LAUNCH_S(S) \
   do { if (lpw == 2) LSDR_RX_LAUNCH(S, 2); else if (lpw == 8) LSDR_RX_LAUNCH(S, 8); else if (lpw == 4) LSDR_RX_LAUNCH(S, 4); else if (lpw == 16) LSDR_RX_LAUNCH(S, 16); else if (lpw == 64) LSDR_RX_LAUNCH(S, 64); else LSDR_RX_LAUNCH(S, 32); } while (0)
   if (r->cfg.sampler == LSDR_SAMP_NEAREST) LSDR_RX_LAUNCH_S(0);
@@ -960,8 +1047,9 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
 #undef LSDR_RX_LAUNCH
   LSDR_HIP(hipGetLastError());
   // estimators (AGC, MER) of the run: scan of the tiles' maps; installs the end state
-  hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema, n_tiles,
-                     (const rx_state_dev *)r->d_state_next, r->d_state, want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
+  hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema_wave, blocks,
+                     (const rx_ema_map *)r->d_ema, n_tiles, (unsigned)lpw, (const rx_state_dev *)r->d_state_next, r->d_state,
+                     want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
 
   // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
@@ -1069,6 +1157,25 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   if (cfg->freq) rx_set_freq(r, cfg->freq, true);
   r->st_dirty_host = true;
 
+  // Tolerance tiles may decide QPSK symbols by arithmetic instead of the table gather — only if the arithmetic IS the
+  // table: symbol, cost and constellation point identical for all 65536 entries, phase_error within ±2 table units.
+  r->qpsk_arith = false; r->arith_max_dpe = 0;
+  if (cfg->cstln == LSDR_QPSK && !cfg->harden && !getenv("LSDR_RX_NO_ARITH")) {
+    bool ok = r->tabs.nsymbols == 4;
+    unsigned worst = 0;
+    for (int i = 0; ok && i < 65536; ++i) {
+      const int I = (int8_t)(i >> 8), Q = (int8_t)(i & 255);
+      const qpsk_decision d = qpsk_decide(I, Q);
+      ok = d.cost == r->tabs.cost[i] && d.symbol == r->tabs.symbol[i] && d.pt_re == r->tabs.symbols[d.symbol][0] &&
+           d.pt_im == r->tabs.symbols[d.symbol][1];
+      int dpe = (int)(int16_t)d.phase_error - (int)r->tabs.phase_error[i];
+      if (dpe < 0) dpe = -dpe;
+      if ((unsigned)dpe > worst) worst = (unsigned)dpe;
+    }
+    r->qpsk_arith = ok && worst <= 2;
+    r->arith_max_dpe = worst;
+  }
+
   // Tables → HBM.
   std::vector<lsdr_cf32> trig(65536);
   lsdr_trig16_table(trig.data());
@@ -1101,7 +1208,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_cstln = nullptr; r->cstln_cap = 0;
   r->d_stage = nullptr; r->stage_cap = 0;
   r->d_info = nullptr; r->d_fix = nullptr; r->d_part = nullptr; r->tiles_cap = 0;
-  r->d_ema = nullptr; r->h_snap = nullptr;
+  r->d_ema = nullptr; r->d_ema_wave = nullptr; r->h_snap = nullptr;
   LSDR_HIP(hipMalloc((void **)&r->d_state_next, sizeof(rx_state_dev)));
   LSDR_HIP(hipHostMalloc((void **)&r->h_snap, sizeof(rx_state_dev), hipHostMallocDefault));
   r->d_wstage = nullptr; r->wstage_cap = 0;
@@ -1146,7 +1253,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
   (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part); (void)hipFree(r->d_wstage);
-  (void)hipFree(r->d_ema); (void)hipFree(r->d_state_next);
+  (void)hipFree(r->d_ema); (void)hipFree(r->d_ema_wave); (void)hipFree(r->d_state_next);
   if (r->h_snap) (void)hipHostFree(r->h_snap);
   if (r->h_res) (void)hipHostFree(r->h_res);
   for (int i = 0; i < lsdr_rx::kRing; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
@@ -1166,6 +1273,13 @@ int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st) {
   LSDR_ARG(r && st);
   { int rc = rx_pull_state(r); if (rc) return rc; }
   rx_state_export(r->st, st);  // host mirror is refreshed after every run
+  return LSDR_OK;
+}
+
+int lsdr_rx_decision_mode(const lsdr_rx *r, int *arithmetic, unsigned *max_phase_error_delta) {
+  LSDR_ARG(r);
+  if (arithmetic) *arithmetic = r->qpsk_arith ? 1 : 0;
+  if (max_phase_error_delta) *max_phase_error_delta = r->arith_max_dpe;
   return LSDR_OK;
 }
 

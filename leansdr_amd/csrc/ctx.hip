@@ -26,7 +26,16 @@ int lsdr_device_count(void) {
   return n;
 }
 
-int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) {
+static int ctx_create(int device, void *hip_stream, const uint32_t *cu_mask, unsigned mask_words, lsdr_ctx **out);
+
+int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) { return ctx_create(device, hip_stream, nullptr, 0, out); }
+
+int lsdr_ctx_create_masked(int device, const uint32_t *cu_mask, unsigned mask_words, lsdr_ctx **out) {
+  LSDR_ARG(cu_mask && mask_words);
+  return ctx_create(device, nullptr, cu_mask, mask_words, out);
+}
+
+static int ctx_create(int device, void *hip_stream, const uint32_t *cu_mask, unsigned mask_words, lsdr_ctx **out) {
   LSDR_ARG(out != nullptr);
   int ndev = 0;
   LSDR_HIP(hipGetDeviceCount(&ndev));
@@ -38,7 +47,9 @@ int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) {
   lsdr_ctx *c = new lsdr_ctx();
   c->device = device;
   c->own_stream = (hip_stream == nullptr);
-  if (c->own_stream) {
+  if (cu_mask) {
+    LSDR_HIP(hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask));
+  } else if (c->own_stream) {
     const char *pe = getenv("LSDR_STREAM_PRIORITY");   // tuning hook: "high" → highest stream priority
     if (pe && !strcmp(pe, "high")) {
       int lo = 0, hi = 0;
@@ -52,6 +63,11 @@ int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) {
   hipDeviceProp_t prop;
   LSDR_HIP(hipGetDeviceProperties(&prop, device));
   c->num_cu = prop.multiProcessorCount;
+  if (cu_mask) {   // the kernels size their grids for the compute units this stream may use
+    int n = 0;
+    for (unsigned w = 0; w < mask_words; ++w) n += __builtin_popcount(cu_mask[w]);
+    if (n > 0 && n < c->num_cu) c->num_cu = n;
+  }
   c->copy_ready = false;
   *out = c;
   return LSDR_OK;

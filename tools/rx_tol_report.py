@@ -48,7 +48,7 @@ def compare(y, tile_len, warm, tag, acq=40960, md=4096):
     print(json.dumps(row), flush=True)
 
 
-GEOS = [(128, 256), (128, 512), (256, 256), (256, 512), (512, 1024), (0, 0)]
+GEOS = [(128, 256), (128, 512), (256, 256), (512, 1024), (0, 0)]
 for snr in (20.0, 12.0, 8.0):
     x, _ = synth.qpsk_baseband(4 * 100000, 4, seed=5, rms=50.0, snr_db=snr)
     for g in GEOS:
@@ -62,14 +62,4 @@ for snr in (20.0, 10.0):
     fir.close()
     for g in GEOS[:3]:
         compare(y, g[0], g[1], f"c2chain snr{snr:g}", acq=32768, md=8192)
-# acquisition gear of the warm-up: (symbols, alpha multiplier, gain_mu multiplier)
-x4, _ = synth.qpsk_baseband(4 * 100000, 4, seed=5, rms=50.0, snr_db=12.0)
-x20, _ = synth.qpsk_baseband(120 * 65536, 120, seed=11, rms=1.0, snr_db=20.0)
-fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
-y20, _ = fir.run(x20)
-fir.close()
-for acq in [(0, 1, 1), (16, 4, 4), (24, 4, 4), (32, 4, 4), (32, 2, 4), (32, 4, 2), (32, 8, 8), (48, 4, 4), (24, 6, 2), (40, 3, 3)]:
-    os.environ["LSDR_RX_ACQ_SYMS"], os.environ["LSDR_RX_ACQ_ALPHA"], os.environ["LSDR_RX_ACQ_MU"] = (str(v) for v in acq)
-    compare(y20, 128, 256, f"acq{acq} c2 snr20", acq=32768, md=8192)
-    compare(x4, 128, 256, f"acq{acq} 4sps snr12")
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "rx_tol_report.json"), "w"), indent=1)

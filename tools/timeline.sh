@@ -9,6 +9,6 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 with open(sys.argv[2], "w") as o:
     for r in rows:
-        o.write(f"{r['Kernel_Name'][:40].replace(',', ';')},{r['Start_Timestamp']},{r['End_Timestamp']},{r.get('Queue_Id','')}\n")
+        o.write(f"{r['Kernel_Name'][:60].replace(',', ';')},{r['Start_Timestamp']},{r['End_Timestamp']},{r.get('Queue_Id','')}\n")
 print(len(rows), "kernels")
 PY
