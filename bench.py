@@ -83,8 +83,11 @@ def _oracle():
     return po
 
 
-def _cpu_worker(args):
-    x, coeffs, decim, seconds, use_ref = args
+_CPU_JOB = {}     # inherited by the forked workers (no 32 MB pickle per worker)
+
+
+def _cpu_worker(seconds):
+    x, coeffs, decim, use_ref = _CPU_JOB["x"], _CPU_JOB["coeffs"], _CPU_JOB["decim"], _CPU_JOB["use_ref"]
     po = _oracle()
     O = po.Ref() if use_ref else po.Oracle()
     p = po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=1 << 20)
@@ -111,12 +114,13 @@ def cpu_baseline(x, coeffs, decim, budget_s):
     use_ref = po.have_ref()
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     ctx = mp.get_context("fork")
-    one_n, one_t = _cpu_worker((x, coeffs, decim, budget_s * 0.3, use_ref))
+    _CPU_JOB.update(x=x, coeffs=coeffs, decim=decim, use_ref=use_ref)
+    one_n, one_t = _cpu_worker(budget_s * 0.3)
     one = one_n / one_t / 1e6
     if cores > 1:
         t0 = time.perf_counter()
         with ctx.Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(x, coeffs, decim, budget_s * 0.7, use_ref)] * cores, chunksize=1)
+            res = pool.map(_cpu_worker, [budget_s * 0.7] * cores, chunksize=1)
         wall = time.perf_counter() - t0
         allc = sum(r[0] for r in res) / max(r[1] for r in res) / 1e6
     else:
@@ -160,10 +164,13 @@ class Capture:
     """One capture: its endless input in HBM, the decimated-stream buffers, the symbol buffer, its receiver (own HIP
     stream).  fir_filter of all captures of a GPU goes through ONE launch on the fir stream."""
 
-    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None):
+    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None, cw=None):
         self.capi, self.idx, self.geo = capi, idx, geo
         period, reps, B, n_out, N, decim = geo["period"], geo["reps"], geo["B"], geo["n_out"], geo["N"], geo["decim"]
         self.x, _ = synth.qpsk_baseband(period, geo["sps"], seed=seed, rms=1.0, snr_db=20.0, freq=freq)
+        if cw:          # a CW interferer (cycles/sample rounded to a whole number of cycles per period, amplitude): auto_notch's job
+            f = round(cw[0] * period) / period
+            self.x = (self.x + np.float32(cw[1]) * np.exp(2j * np.pi * f * np.arange(period))).astype(np.complex64)
         self.ctx = fir_ctx
         self.ctx_rx = capi.Ctx(device, cu_mask=rx_cus)
         self.d_in = self.ctx.alloc((B + period) * 8)
@@ -210,7 +217,7 @@ class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major"):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None):
         self.capi = capi
         # CU partition: the latency-bound receiver tiles get rx_cus compute units of their own (the same number from every
         # XCD), the HBM-streaming fir_filter the rest, so that neither disturbs the other's issue slots / L1
@@ -227,12 +234,13 @@ class C2Pipeline:
         coeffs, decim = c2_filter(capi)
         self.coeffs, self.decim = coeffs, decim
         self.geo = c2_geometry(batch_msamples, period_msamples, len(coeffs), decim)
-        self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0)
-        if freq:
-            self.fir.set_freq(freq)
-        self.rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
+        self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0, arith=capi.FIR_EXACT if fir_arith is None else fir_arith)
+        self.rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim),
+                          freq=float(rx_freq))
+        if rx_freq:   # what fir_filter::run does on its first call: the receiver's initial freq_tap moves the filter (dsp.h:236-244)
+            self.fir.track(float(np.float32(rx_freq)), 1.0 / decim, float(np.float32(FM / FS * 0.1)))
         self.tile = tile
-        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=0.0, rx_cus=rx_mask)
+        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw)
                      for c in range(n_captures)]
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)

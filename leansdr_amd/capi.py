@@ -25,6 +25,7 @@ IN_CF32, IN_CU8 = 0, 1
 FIR_EXACT, FIR_FMA = 0, 1
 SAMP_NEAREST, SAMP_LINEAR, SAMP_FIR = 0, 1, 2
 RX_SERIAL, RX_TILED = 0, 1
+NOTCH_EXACT, NOTCH_SCAN = 0, 1
 
 
 class LsdrError(RuntimeError):
@@ -97,6 +98,7 @@ _sig("lsdr_auto_notch_create", C.c_int, [vp, C.c_int, c_f, C.POINTER(vp)])
 _sig("lsdr_auto_notch_destroy", None, [vp])
 _sig("lsdr_auto_notch_set", C.c_int, [vp, C.c_int, c_f])
 _sig("lsdr_auto_notch_slot_bin", C.c_int, [vp, C.c_int])
+_sig("lsdr_auto_notch_set_mode", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])
@@ -192,6 +194,13 @@ _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
 _sig("lsdr_rx_wait", C.c_int, [vp, psz])
+_sig("lsdr_fec_spec", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp])
+_sig("lsdr_cconverter_int_run", C.c_int, [vp, C.c_int, vp, c_sz, vp])
+_sig("lsdr_copy_h2d_async", C.c_int, [vp, vp, vp, c_sz])
+_sig("lsdr_copy_d2h_async", C.c_int, [vp, vp, vp, c_sz])
+_sig("lsdr_copy_fence", C.c_int, [vp])
+_sig("lsdr_copy_sync_d2h", C.c_int, [vp])
+_sig("lsdr_copy_sync_all", C.c_int, [vp])
 _sig("lsdr_rx_decision_mode", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint)])
 _sig("lsdr_rx_snapshot_async", C.c_int, [vp])
 _sig("lsdr_rx_get_snapshot", C.c_int, [vp, C.POINTER(RxState)])
@@ -740,12 +749,15 @@ def cfft_host(x, reverse=False):
 class AutoNotch:
     """auto_notch<f32> (sdr.h:46-154) on the GPU."""
 
-    def __init__(self, ctx, nslots=1, setpoint=0.0, decimation=1024 * 4096, k=0.002):
+    def __init__(self, ctx, nslots=1, setpoint=0.0, decimation=1024 * 4096, k=0.002, mode=0):
+        """mode: NOTCH_EXACT (0, bit-exact verified tiles) or NOTCH_SCAN (1, single-pass scan, device-side detect; tolerance)."""
         self.ctx, self.nslots = ctx, nslots
         h = vp()
         check(lib.lsdr_auto_notch_create(ctx.h, nslots, setpoint, C.byref(h)))
         self.h = h
         check(lib.lsdr_auto_notch_set(h, decimation, k))
+        if mode:
+            check(lib.lsdr_auto_notch_set_mode(h, mode))
 
     def close(self):
         if self.h:

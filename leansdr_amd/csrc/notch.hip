@@ -187,10 +187,12 @@ void cfft_host(int n, lsdr_cf32 *data, bool reverse) {
 // cfft_engine<float>::inplace on the GPU: one workgroup, the whole transform in LDS, one barrier per radix-2 stage.
 // Every butterfly is the reference's expression (dsp.h:96-104) evaluated once, so the result is bit-identical to
 // cfft_host(); the twiddles om[] are the host-built cosf/sinf table of the engine's constructor (dsp.h:62-70).
-__global__ __launch_bounds__(1024) void k_cfft(const float2 *in, const float2 *om, float2 *out, int logn, int reverse, float invn) {
+__global__ __launch_bounds__(1024) void k_cfft(const float2 *in, const float2 *om, float2 *out, int logn, int reverse, float invn,
+                                                const unsigned long long *in_offsets = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char cfft_smem[];
   float2 *d = reinterpret_cast<float2 *>(cfft_smem);
   const int n = 1 << logn, tid = threadIdx.x;
+  if (in_offsets) { in += in_offsets[blockIdx.x]; out += (size_t)blockIdx.x * n; }   // batched: one transform per workgroup
   for (int i = tid; i < n; i += 1024) d[__brev((unsigned)i) >> (32 - logn)] = in[i];   // bit-reversal permutation (dsp.h:84-92)
   __syncthreads();
   for (int st = 0; st < logn; ++st) {
@@ -248,6 +250,227 @@ static int cfft_dev_run(lsdr_ctx *c, cfft_dev *f, const lsdr_cf32 *d_in, lsdr_cf
   return LSDR_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------- throughput mode (LSDR_NOTCH_SCAN)
+// The per-slot recurrence  estim ← k·bb + (1−k)·estim  is a first-order linear recurrence with a CONSTANT pole a = 1−k,
+// i.e. a scan:  estim_i = L_i + a^(i+1)·carry,  L = the same recurrence started from zero.  One workgroup per 4096-sample
+// block (the block in which the slot phasors e_i restart, sdr.h:121): 16 consecutive samples per lane — a full 128-byte line
+// in, a full line out — local recurrence in registers with the reference's two roundings per step, then a wave scan with the
+// powers of a, the four wave totals through LDS, and the block's carry-in by decoupled look-back over the THREE preceding
+// blocks' zero-carry totals (a^4096 = 2.7e-4: the fourth is below float resolution), published through run-stamped flags
+// so that nothing has to be cleared between runs.  With several slots the passes repeat per slot on the residual of the
+// previous one, like sdr.h:124-134.  detect() (every `decimation` samples, sdr.h:66-70,76-118) stays on the device too:
+// all detect points of a run depend on the INPUT only, so their FFTs run batched up front (k_cfft), k_notch_peaks does the
+// hypotf peak search, k_notch_plan walks the detect points in order (bin changes reset the slot's estimator and select a new
+// phasor table), k_notch_tables builds the per-interval phasor tables with the reference's expression
+// (float)(2π·bin·i/4096) → cosf/sinf on the device (≤ 1 ulp from libm's).  Single pass: 8 B in + 8 B out per sample.
+// NOT bit-exact (the carry terms are re-associated; device cosf/sinf/hypotf): tolerance-tested against k_notch / the oracle.
+constexpr int kScanPer = 16;                 // samples per lane
+constexpr int kScanThreads = kN / kScanPer;  // 256
+
+struct notch_scan_consts {
+  float k, omk, gain;
+  float apow[kScanPer + 1];        // a^j, j = 0 … 16
+  float apow16[7];                 // a^(16·2^m), m = 0 … 6   (wave scan; [6] = a^1024)
+  float a1024, a2048, a3072, a4096, a8192, a12288;
+};
+
+struct notch_scan_args {
+  const float2 *in;
+  float2 *out;
+  const float2 *tables;            // [n_intervals][nslots][4096]
+  const int *interval_first;       // [n_intervals] first block of each interval (interval 0 starts at block 0)
+  const unsigned char *reset;      // [n_intervals][kMaxSlots]: the slot's estimator restarts from 0 at the interval's first block
+  int n_intervals, nslots;
+  unsigned long long n_blocks;
+  const notch_est *carry;          // estimators before block 0
+  notch_est *carry_out;            // (last block) estimators after the last block → the next run's `carry`
+  float2 *totals;                  // [kMaxSlots][n_blocks] zero-carry block totals
+  unsigned *flags;                 // [kMaxSlots][n_blocks] run stamps
+  unsigned stamp;
+  notch_scan_consts C;
+};
+
+__device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+// Cross-workgroup hand-off of a block total: relaxed AGENT-scope atomics only (write-through store / L2-bypassing load on
+// the multi-XCD part) with an explicit vmcnt(0) between the value and its stamp.  A release FENCE here would write back the
+// whole L2 of the XCD — which this kernel keeps full of dirty output lines — once per block (measured: 16 K blocks in 2.9 ms
+// with fences, i.e. serialised on the fence).
+__device__ __forceinline__ void scan_publish(float2 *tot_slot, unsigned *flag_slot, float2 tot, unsigned stamp) {
+  unsigned long long bits;
+  __builtin_memcpy(&bits, &tot, 8);
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(tot_slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the value is out before the stamp
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  __hip_atomic_store(flag_slot, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float2 scan_wait(const float2 *tot_slot, const unsigned *flag_slot, unsigned stamp) {
+  while (__hip_atomic_load(flag_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) __builtin_amdgcn_s_sleep(1);
+  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(tot_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float2 v;
+  __builtin_memcpy(&v, &bits, 8);
+  return v;
+}
+
+template <int NS>
+__global__ __launch_bounds__(kScanThreads) void k_notch_scan(notch_scan_args a) {
+  __shared__ float2 s_wave[NS][4];
+  __shared__ float2 s_carry[NS];
+  const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const unsigned long long b = blockIdx.x;
+  // interval of this block (few intervals: linear search, wave-uniform)
+  int q = 0;
+  while (q + 1 < a.n_intervals && (unsigned long long)a.interval_first[q + 1] <= b) ++q;
+  const bool first_of_interval = (unsigned long long)a.interval_first[q] == b;
+  const float2 *pin = a.in + b * kN + (size_t)t * kScanPer;
+  float2 x[kScanPer], o[kScanPer];
+#pragma unroll
+  for (int j = 0; j < kScanPer; ++j) { x[j] = pin[j]; o[j] = x[j]; }
+  const notch_scan_consts &C = a.C;
+  // every slot filters the RAW input (sdr.h:126-128: bb from *pin); the slots' corrections are subtracted in slot order
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    const float2 *pe = a.tables + ((size_t)q * a.nslots + s) * kN + (size_t)t * kScanPer;
+    float2 e[kScanPer], L[kScanPer];
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) e[j] = pe[j];
+    float2 run = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+      const float2 bb = make_float2(x[j].x * e[j].x + x[j].y * e[j].y, -x[j].x * e[j].y + x[j].y * e[j].x);   // x·conj(e)
+      run = make_float2(bb.x * C.k + run.x * C.omk, bb.y * C.k + run.y * C.omk);
+      L[j] = run;
+    }
+    // inclusive scan of the lane totals across the wave: P_lane = Σ_{u ≤ lane} a^(16(lane−u))·T_u
+    float2 P = run;
+#pragma unroll
+    for (int m = 0; m < 6; ++m) {
+      const int d = 1 << m;
+      const float ox = __shfl_up(P.x, d, 64), oy = __shfl_up(P.y, d, 64);
+      if (lane >= (unsigned)d) { P.x += C.apow16[m] * ox; P.y += C.apow16[m] * oy; }
+    }
+    if (lane == 63) s_wave[s][wv] = P;
+    __syncthreads();
+    // carry into this wave from the waves before it (zero block carry-in)
+    float2 cw = make_float2(0.f, 0.f);
+    for (unsigned v = 0; v < wv; ++v) cw = make_float2(cw.x * C.a1024 + s_wave[s][v].x, cw.y * C.a1024 + s_wave[s][v].y);
+    if (t == kScanThreads - 1) {
+      // zero-carry total of the block: publish, then look back
+      const float2 tot = make_float2(P.x + C.a1024 * cw.x, P.y + C.a1024 * cw.y);
+      scan_publish(a.totals + (size_t)s * a.n_blocks + b, a.flags + (size_t)s * a.n_blocks + b, tot, a.stamp);
+      float2 ein = make_float2(0.f, 0.f);
+      if (!(first_of_interval && a.reset[q * kMaxSlots + s])) {
+        // E_b = Tot_{b−1} + a^4096·(Tot_{b−2} + a^4096·Tot_{b−3}) … cut where an interval reset or the run's start intervenes
+        const float w[3] = {1.f, C.a4096, C.a8192};
+        bool open = true;
+        for (int back = 1; back <= 3 && open; ++back) {
+          if (b < (unsigned long long)back) {                  // before block 0: the carried estimators
+            ein.x += w[back - 1] * a.carry->re[s]; ein.y += w[back - 1] * a.carry->im[s];
+            break;
+          }
+          const unsigned long long pb = b - back;
+          const float2 pt = scan_wait(a.totals + (size_t)s * a.n_blocks + pb, a.flags + (size_t)s * a.n_blocks + pb, a.stamp);
+          ein.x += w[back - 1] * pt.x; ein.y += w[back - 1] * pt.y;
+          // a reset at block pb means nothing older reaches us
+          int qp = 0;
+          while (qp + 1 < a.n_intervals && (unsigned long long)a.interval_first[qp + 1] <= pb) ++qp;
+          if ((unsigned long long)a.interval_first[qp] == pb && a.reset[qp * kMaxSlots + s]) open = false;
+        }
+      }
+      s_carry[s] = ein;
+      if (b == a.n_blocks - 1) {       // estimators after the last block → next run (a separate buffer: blocks 0..2 read `carry`)
+        const float2 eo = make_float2(tot.x + C.a4096 * ein.x, tot.y + C.a4096 * ein.y);
+        a.carry_out->re[s] = eo.x; a.carry_out->im[s] = eo.y;
+      }
+    }
+    __syncthreads();
+    // carry into this lane: lanes before it in the wave, waves before it, block carry-in
+    float2 cl;
+    {
+      const float ox = __shfl_up(P.x, 1, 64), oy = __shfl_up(P.y, 1, 64);
+      cl = lane ? make_float2(ox, oy) : make_float2(0.f, 0.f);
+    }
+    float pl = 1.f;                    // a^(16·lane) from the binary powers
+#pragma unroll
+    for (int m = 0; m < 6; ++m) if (lane & (1u << m)) pl *= C.apow16[m];
+    const float pw = wv == 0 ? 1.f : (wv == 1 ? C.a1024 : (wv == 2 ? C.a2048 : C.a3072));
+    const float2 eb = s_carry[s];
+    const float2 cin = make_float2(cl.x + pl * cw.x + pl * pw * eb.x, cl.y + pl * cw.y + pl * pw * eb.y);
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) {
+      const float2 est = make_float2(L[j].x + C.apow[j + 1] * cin.x, L[j].y + C.apow[j + 1] * cin.y);
+      const float2 sub = cmulf(est, e[j]);
+      o[j] = make_float2(o[j].x - sub.x, o[j].y - sub.y);
+    }
+  }
+  float2 *pout = a.out + b * kN + (size_t)t * kScanPer;
+#pragma unroll
+  for (int j = 0; j < kScanPer; ++j) pout[j] = make_float2(C.gain * o[j].x, C.gain * o[j].y);
+}
+
+// peak search of detect() (sdr.h:94-117) on one spectrum per workgroup: amplitudes by hypotf, nslots rounds of
+// "first maximum wins, zero it and its two neighbours"
+__global__ __launch_bounds__(256) void k_notch_peaks(const float2 *spec, int nslots, int *cand /*[ndet][kMaxSlots]*/) {
+  __shared__ float amp[kN];
+  __shared__ float s_v[256];
+  __shared__ int s_i[256];
+  const float2 *sp = spec + (size_t)blockIdx.x * kN;
+  for (int i = threadIdx.x; i < kN; i += 256) amp[i] = hypotf(sp[i].x, sp[i].y);
+  __syncthreads();
+  for (int s = 0; s < nslots; ++s) {
+    float bv = -1.f; int bi = 0;
+    for (int i = threadIdx.x; i < kN; i += 256) if (amp[i] > bv) { bv = amp[i]; bi = i; }     // ascending i per lane: first max kept
+    s_v[threadIdx.x] = bv; s_i[threadIdx.x] = bi;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+      if ((int)threadIdx.x < d) {
+        const float ov = s_v[threadIdx.x + d]; const int oi = s_i[threadIdx.x + d];
+        if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) { s_v[threadIdx.x] = ov; s_i[threadIdx.x] = oi; }
+      }
+      __syncthreads();
+    }
+    const int im = s_i[0];
+    if (threadIdx.x == 0) {
+      cand[blockIdx.x * kMaxSlots + s] = im;
+      amp[im] = 0;
+      if (im - 1 >= 0) amp[im - 1] = 0;
+      if (im + 1 < kN) amp[im + 1] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+// walks the detect points of a run in order: interval q+1 starts at detect point q with the slots' new bins
+__global__ void k_notch_plan(const int *cand, int ndet, int nslots, int *bins /*[kMaxSlots] carried*/, int *interval_bins /*[ndet+1][kMaxSlots]*/,
+                             unsigned char *reset /*[ndet+1][kMaxSlots]*/) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (int s = 0; s < kMaxSlots; ++s) { interval_bins[s] = bins[s]; reset[s] = 0; }
+  for (int q = 0; q < ndet; ++q)
+    for (int s = 0; s < kMaxSlots; ++s) {
+      int cur = interval_bins[q * kMaxSlots + s];
+      unsigned char rs = 0;
+      if (s < nslots && cand[q * kMaxSlots + s] != cur) { cur = cand[q * kMaxSlots + s]; rs = 1; }
+      interval_bins[(q + 1) * kMaxSlots + s] = cur;
+      reset[(q + 1) * kMaxSlots + s] = rs;
+    }
+  for (int s = 0; s < kMaxSlots; ++s) bins[s] = interval_bins[ndet * kMaxSlots + s];
+}
+
+// phasor tables per interval and slot: expj[i] = (cosf(a), sinf(a)), a = (float)(2π·bin·i/4096) (sdr.h:107-111); bin < 0
+// (nothing detected yet): zeros, like the reference's untouched slots
+__global__ __launch_bounds__(256) void k_notch_tables(const int *interval_bins, int nslots, float2 *tables) {
+  const int q = blockIdx.x / nslots, s = blockIdx.x % nslots;
+  const int bin = interval_bins[q * kMaxSlots + s];
+  float2 *tb = tables + ((size_t)q * nslots + s) * kN;
+  for (int i = threadIdx.x; i < kN; i += 256) {
+    if (bin < 0) { tb[i] = make_float2(0.f, 0.f); continue; }
+    const float ang = (float)(2 * M_PI * bin * i / kN);
+    tb[i] = make_float2(cosf(ang), sinf(ang));
+  }
+}
+
 }  // namespace
 
 struct lsdr_auto_notch {
@@ -263,6 +486,19 @@ struct lsdr_auto_notch {
   size_t tiles_cap;
   unsigned last_tiles, last_bad;
   cfft_dev fft;
+  // throughput mode (LSDR_NOTCH_SCAN): everything below lives on the device between runs
+  int mode;
+  bool scan_started;
+  notch_est *d_scarry[2]; int scarry_cur;     // estimators, ping-pong (a run reads one and writes the other)
+  int *d_bins;                                // [kMaxSlots] carried bins
+  unsigned long long *d_offsets; float2 *d_spec; int *d_cand; int *d_ibins; unsigned char *d_reset; int *d_ifirst;
+  size_t det_cap;                             // detect points the scratch above is sized for
+  float2 *d_tables; size_t tables_cap;        // [(ndet+1)·nslots·4096]
+  float2 *d_totals; unsigned *d_flags; size_t blocks_cap;
+  unsigned stamp;
+  // per-run argument arrays (interval starts, detect offsets) cross over from two pinned slots used alternately: the copy of
+  // run k-2 has long executed when its slot is rewritten, so the host never waits for the GPU in steady state
+  int *h_ifirst[2]; unsigned long long *h_offsets[2]; size_t h_cap[2]; hipEvent_t h_ev[2]; int h_slot;
 };
 
 struct lsdr_spectrum {
@@ -422,6 +658,128 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
   return LSDR_OK;
 }
 
+// LSDR_NOTCH_SCAN: one run = [batched detect FFTs → peaks → plan → tables] → one k_notch_scan launch, all enqueued, no
+// host synchronisation (the caller's consumed/produced are pure functions of the sizes).
+template <int NS>
+static void notch_scan_launch(hipStream_t st, unsigned grid, const notch_scan_args &a) {
+  hipLaunchKernelGGL(k_notch_scan<NS>, dim3(grid), dim3(kScanThreads), 0, st, a);
+}
+static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out, size_t nb) {
+  lsdr_ctx *c = a->ctx;
+  if (!a->scan_started) {
+    for (int i = 0; i < 2; ++i) {
+      LSDR_HIP(hipMalloc((void **)&a->d_scarry[i], sizeof(notch_est)));
+      LSDR_HIP(hipMemcpyAsync(a->d_scarry[i], &a->est, sizeof(notch_est), hipMemcpyHostToDevice, c->stream));
+    }
+    LSDR_HIP(hipMalloc((void **)&a->d_bins, kMaxSlots * sizeof(int)));
+    LSDR_HIP(hipMemcpyAsync(a->d_bins, a->bins, kMaxSlots * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    a->scarry_cur = 0; a->stamp = 0; a->scan_started = true;
+  }
+  // detect points of this run: `phase += 4096; if (phase >= decimation) { phase -= decimation; detect(); }` per block
+  std::vector<int> ifirst(1, 0);
+  std::vector<unsigned long long> offs;
+  int phase = a->phase;
+  for (size_t b = 0; b < nb; ++b) {
+    phase += kN;
+    if (phase >= a->decimation) { phase -= a->decimation; ifirst.push_back((int)b); offs.push_back((unsigned long long)b * kN); }
+  }
+  a->phase = phase;
+  const size_t ndet = offs.size();
+  const int ns = a->nslots;
+  if (a->det_cap < ndet + 1) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(a->d_offsets); (void)hipFree(a->d_spec); (void)hipFree(a->d_cand); (void)hipFree(a->d_ibins); (void)hipFree(a->d_reset); (void)hipFree(a->d_ifirst);
+    const size_t cap = ndet + 8;
+    LSDR_HIP(hipMalloc((void **)&a->d_offsets, cap * sizeof(unsigned long long)));
+    LSDR_HIP(hipMalloc((void **)&a->d_spec, cap * kN * sizeof(float2)));
+    LSDR_HIP(hipMalloc((void **)&a->d_cand, cap * kMaxSlots * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&a->d_ibins, (cap + 1) * kMaxSlots * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&a->d_reset, (cap + 1) * kMaxSlots));
+    LSDR_HIP(hipMalloc((void **)&a->d_ifirst, (cap + 1) * sizeof(int)));
+    a->det_cap = cap;
+  }
+  if (a->tables_cap < (ndet + 1) * (size_t)ns * kN) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(a->d_tables);
+    a->tables_cap = (ndet + 8) * (size_t)ns * kN;
+    LSDR_HIP(hipMalloc((void **)&a->d_tables, a->tables_cap * sizeof(float2)));
+  }
+  if (a->blocks_cap < nb) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
+    LSDR_HIP(hipMalloc((void **)&a->d_totals, (size_t)kMaxSlots * nb * sizeof(float2)));
+    LSDR_HIP(hipMalloc((void **)&a->d_flags, (size_t)kMaxSlots * nb * sizeof(unsigned)));
+    LSDR_HIP(hipMemsetAsync(a->d_flags, 0, (size_t)kMaxSlots * nb * sizeof(unsigned), c->stream));
+    a->blocks_cap = nb;
+    a->stamp = 0;
+  }
+  // per-run argument arrays: pinned slot → device, in stream order
+  const int hs = a->h_slot;
+  a->h_slot ^= 1;
+  if (a->h_ev[hs]) LSDR_HIP(hipEventSynchronize(a->h_ev[hs]));
+  else LSDR_HIP(hipEventCreateWithFlags(&a->h_ev[hs], hipEventDisableTiming));
+  if (a->h_cap[hs] < ndet + 1) {
+    if (a->h_ifirst[hs]) (void)hipHostFree(a->h_ifirst[hs]);
+    if (a->h_offsets[hs]) (void)hipHostFree(a->h_offsets[hs]);
+    a->h_cap[hs] = ndet + 8;
+    LSDR_HIP(hipHostMalloc((void **)&a->h_ifirst[hs], (a->h_cap[hs] + 1) * sizeof(int), hipHostMallocDefault));
+    LSDR_HIP(hipHostMalloc((void **)&a->h_offsets[hs], a->h_cap[hs] * sizeof(unsigned long long), hipHostMallocDefault));
+  }
+  memcpy(a->h_ifirst[hs], ifirst.data(), ifirst.size() * sizeof(int));
+  if (ndet) memcpy(a->h_offsets[hs], offs.data(), ndet * sizeof(unsigned long long));
+  LSDR_HIP(hipMemcpyAsync(a->d_ifirst, a->h_ifirst[hs], ifirst.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+  if (ndet) LSDR_HIP(hipMemcpyAsync(a->d_offsets, a->h_offsets[hs], ndet * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+  LSDR_HIP(hipEventRecord(a->h_ev[hs], c->stream));
+  if (ndet) {
+    int rc = cfft_dev_init(&a->fft, kN, true);
+    if (rc) return rc;
+    const size_t lds = (size_t)kN * sizeof(float2);
+    hipLaunchKernelGGL(k_cfft, dim3((unsigned)ndet), dim3(1024), lds, c->stream, (const float2 *)in, (const float2 *)a->fft.d_om, a->d_spec,
+                       a->fft.logn, 1, (float)(1.0 / kN), (const unsigned long long *)a->d_offsets);
+    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)ndet), dim3(256), 0, c->stream, (const float2 *)a->d_spec, ns, a->d_cand);
+  }
+  hipLaunchKernelGGL(k_notch_plan, dim3(1), dim3(1), 0, c->stream, (const int *)a->d_cand, (int)ndet, ns, a->d_bins, a->d_ibins, a->d_reset);
+  hipLaunchKernelGGL(k_notch_tables, dim3((unsigned)((ndet + 1) * ns)), dim3(256), 0, c->stream, (const int *)a->d_ibins, ns, a->d_tables);
+  LSDR_HIP(hipGetLastError());
+  // estimators: the run reads d_scarry[cur] and writes the end state there too — through a copy, so that blocks 0..2 (which
+  // read the start state in their look-back) never see the last block's update
+  const int cur = a->scarry_cur, nxt = cur ^ 1;
+  LSDR_HIP(hipMemcpyAsync(a->d_scarry[nxt], a->d_scarry[cur], sizeof(notch_est), hipMemcpyDeviceToDevice, c->stream));
+  notch_scan_args sa;
+  sa.in = (const float2 *)in; sa.out = (float2 *)out; sa.tables = a->d_tables; sa.interval_first = a->d_ifirst; sa.reset = a->d_reset;
+  sa.n_intervals = (int)ifirst.size(); sa.nslots = ns; sa.n_blocks = nb;
+  sa.carry = a->d_scarry[cur];       // read by every block's look-back …
+  sa.totals = a->d_totals; sa.flags = a->d_flags; sa.stamp = ++a->stamp;
+  {
+    const double av = 1.0 - (double)a->k;
+    sa.C.k = a->k; sa.C.omk = 1 - a->k; sa.C.gain = a->gain;
+    for (int j = 0; j <= kScanPer; ++j) sa.C.apow[j] = (float)pow(av, j);
+    for (int m = 0; m < 7; ++m) sa.C.apow16[m] = (float)pow(av, 16.0 * (1 << m));
+    sa.C.a1024 = (float)pow(av, 1024); sa.C.a2048 = (float)pow(av, 2048); sa.C.a3072 = (float)pow(av, 3072);
+    sa.C.a4096 = (float)pow(av, 4096); sa.C.a8192 = (float)pow(av, 8192); sa.C.a12288 = (float)pow(av, 12288);
+  }
+  sa.carry_out = a->d_scarry[nxt];   // … written by the last block
+  switch (ns) {
+    case 1: notch_scan_launch<1>(c->stream, (unsigned)nb, sa); break;
+    case 2: notch_scan_launch<2>(c->stream, (unsigned)nb, sa); break;
+    case 3: notch_scan_launch<3>(c->stream, (unsigned)nb, sa); break;
+    case 4: notch_scan_launch<4>(c->stream, (unsigned)nb, sa); break;
+    default: lsdr_set_error("auto_notch: LSDR_NOTCH_SCAN supports 1 to 4 slots"); return LSDR_E_UNSUPPORTED;
+  }
+  LSDR_HIP(hipGetLastError());
+  a->scarry_cur = nxt;
+  return LSDR_OK;
+}
+
+// refresh the host mirrors (bins, estimators) of a scan-mode notch
+static int notch_scan_pull(lsdr_auto_notch *a) {
+  if (!a->scan_started) return LSDR_OK;
+  LSDR_HIP(hipMemcpyAsync(a->bins, a->d_bins, kMaxSlots * sizeof(int), hipMemcpyDeviceToHost, a->ctx->stream));
+  LSDR_HIP(hipMemcpyAsync(&a->est, a->d_scarry[a->scarry_cur], sizeof(notch_est), hipMemcpyDeviceToHost, a->ctx->stream));
+  LSDR_HIP(hipStreamSynchronize(a->ctx->stream));
+  return LSDR_OK;
+}
+
 extern "C" {
 
 int lsdr_cfft_run(lsdr_ctx *c, int n, int reverse, const lsdr_cf32 *in_dev, lsdr_cf32 *out_host) {
@@ -455,12 +813,37 @@ int lsdr_auto_notch_create(lsdr_ctx *c, int nslots, float setpoint, lsdr_auto_no
   LSDR_HIP(hipMalloc((void **)&a->d_carry, sizeof(notch_est)));
   a->d_begin = a->d_end = nullptr; a->tiles_cap = 0;
   a->last_tiles = a->last_bad = 0;
+  a->mode = LSDR_NOTCH_EXACT; a->scan_started = false;
+  a->d_scarry[0] = a->d_scarry[1] = nullptr; a->scarry_cur = 0; a->d_bins = nullptr;
+  a->d_offsets = nullptr; a->d_spec = nullptr; a->d_cand = nullptr; a->d_ibins = nullptr; a->d_reset = nullptr; a->d_ifirst = nullptr;
+  for (int i = 0; i < 2; ++i) { a->h_ifirst[i] = nullptr; a->h_offsets[i] = nullptr; a->h_cap[i] = 0; a->h_ev[i] = nullptr; }
+  a->h_slot = 0;
+  a->det_cap = 0; a->d_tables = nullptr; a->tables_cap = 0; a->d_totals = nullptr; a->d_flags = nullptr; a->blocks_cap = 0; a->stamp = 0;
   *out = a;
+  return LSDR_OK;
+}
+int lsdr_auto_notch_set_mode(lsdr_auto_notch *a, int mode) {
+  LSDR_ARG(a && (mode == LSDR_NOTCH_EXACT || mode == LSDR_NOTCH_SCAN));
+  if (mode == a->mode) return LSDR_OK;
+  if (a->scan_started) { lsdr_set_error("auto_notch: the mode cannot change once the scan mode has processed data"); return LSDR_E_ARG; }
+  if (mode == LSDR_NOTCH_SCAN && (a->agc_rms_setpoint != 0 || a->nslots < 1 || a->nslots > 4)) {
+    lsdr_set_error("auto_notch: LSDR_NOTCH_SCAN needs 1 to 4 slots and no AGC set point (leandvb's configuration)");
+    return LSDR_E_UNSUPPORTED;
+  }
+  a->mode = mode;
   return LSDR_OK;
 }
 void lsdr_auto_notch_destroy(lsdr_auto_notch *a) {
   if (!a) return;
   (void)hipStreamSynchronize(a->ctx->stream);
+  (void)hipFree(a->d_scarry[0]); (void)hipFree(a->d_scarry[1]); (void)hipFree(a->d_bins); (void)hipFree(a->d_offsets); (void)hipFree(a->d_spec);
+  (void)hipFree(a->d_cand); (void)hipFree(a->d_ibins); (void)hipFree(a->d_reset); (void)hipFree(a->d_ifirst); (void)hipFree(a->d_tables);
+  (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
+  for (int i = 0; i < 2; ++i) {
+    if (a->h_ifirst[i]) (void)hipHostFree(a->h_ifirst[i]);
+    if (a->h_offsets[i]) (void)hipHostFree(a->h_offsets[i]);
+    if (a->h_ev[i]) (void)hipEventDestroy(a->h_ev[i]);
+  }
   (void)hipFree(a->d_expj); (void)hipFree(a->d_carry); (void)hipFree(a->d_begin); (void)hipFree(a->d_end);
   cfft_dev_free(&a->fft);
   delete a;
@@ -470,7 +853,11 @@ int lsdr_auto_notch_set(lsdr_auto_notch *a, int decimation, float k) {
   a->decimation = decimation; a->k = k;
   return LSDR_OK;
 }
-int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot) { return (a && slot >= 0 && slot < a->nslots) ? a->bins[slot] : -1; }
+int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot) {
+  if (!a || slot < 0 || slot >= a->nslots) return -1;
+  if (a->mode == LSDR_NOTCH_SCAN) (void)notch_scan_pull(const_cast<lsdr_auto_notch *>(a));
+  return a->bins[slot];
+}
 int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *bad) {
   LSDR_ARG(a);
   if (tiles) *tiles = a->last_tiles;
@@ -488,6 +875,13 @@ int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, ls
   lsdr_ctx *c = a->ctx;
   LSDR_HIP(hipSetDevice(c->device));
   a->last_tiles = a->last_bad = 0;
+  if (a->mode == LSDR_NOTCH_SCAN) {
+    int rc = notch_run_scan(a, in, out, nb);
+    if (rc) return rc;
+    *consumed = nb * kN;
+    *produced = nb * kN;
+    return LSDR_OK;
+  }
   // Split at the blocks where detect() fires (phase += 4096; if phase >= decimation …, sdr.h:66-70).
   size_t b = 0;
   while (b < nb) {

@@ -195,7 +195,8 @@ static int run(config &cfg) {
       fuse_scale = 0;
     }
     pipebuf<cf32> *p_autonotched = new pipebuf<cf32>(&sch, "autonotched", BUF_BASEBAND, ctx);
-    new auto_notch<f32>(&sch, *p_preprocessed, *p_autonotched, cfg.anf, 0);
+    auto_notch<f32> *r_anf = new auto_notch<f32>(&sch, *p_preprocessed, *p_autonotched, cfg.anf, 0);
+    if (cfg.tiled && cfg.anf <= 4) r_anf->set_throughput_mode();
     p_preprocessed = p_autonotched;
   } else if (cfg.verbose) fprintf(stderr, "ANF is disabled (requires a clean signal).\n");
 

@@ -106,7 +106,10 @@ struct auto_notch<f32> : runnable {
       : runnable(sch, "auto_notch"), decimation(1024 * 4096), k(0.002),
         ctx(pipe_ctx(i, o, "auto_notch: pipebufs of two device contexts")), in(i), out(o, 4096), h(NULL) {
     lsdr_check(lsdr_auto_notch_create(ctx, nslots, agc_rms_setpoint, &h), name);
+    // throughput mode (single-pass scan, detect() on the device) where it applies: leandvb's configuration (no AGC set point)
+    if (env_flag("LSDR_TILED") && agc_rms_setpoint == 0 && nslots >= 1 && nslots <= 4) lsdr_check(lsdr_auto_notch_set_mode(h, LSDR_NOTCH_SCAN), name);
   }
+  void set_throughput_mode() { lsdr_check(lsdr_auto_notch_set_mode(h, LSDR_NOTCH_SCAN), name); }
   void run() {
     lsdr_check(lsdr_auto_notch_set(h, decimation, k), name);
     unsigned long room = out.writable();

@@ -123,3 +123,70 @@ def test_cfft_on_device_is_the_reference_fft(capi, ctx, oracle, n):
         assert bits_equal(capi.cfft_dev(ctx, x, rev), oracle.cfft(x, rev))
     if n == 4096:
         assert bits_equal(capi.cfft_dev(ctx, x, True), g["fft4096_rev"])
+
+
+# ---- throughput mode (LSDR_NOTCH_SCAN): the recurrence as a single-pass scan, detect() on the device --------------------
+NOTCH_RTOL = 2e-5     # max |out − oracle| relative to the largest |oracle| sample (re-associated carries, device libm)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nslots", [1, 2, 3])
+def test_scan_mode_vs_oracle(capi, ctx, oracle, nslots):
+    """Strong CW interferers on noise: same detected bins as the reference, output within NOTCH_RTOL of the exact result,
+    for any cut of the stream into calls (state, bins and block phase are carried on the device)."""
+    rng = np.random.default_rng(11)
+    n = 4096 * 300
+    t = np.arange(n)
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 12 + 70 * np.exp(2j * np.pi * 0.0713 * t)
+         + 40 * np.exp(-2j * np.pi * 0.27 * t) + 25 * np.exp(2j * np.pi * 0.4 * t)).astype(np.complex64)
+    want, wbins = oracle.auto_notch(x, nslots, 4096 * 100)
+    a = capi.AutoNotch(ctx, nslots, 0.0, 4096 * 100, mode=capi.NOTCH_SCAN)
+    parts, pos = [], 0
+    for cut in (4096 * 130 + 17, 4096 * 3, 4096 * 1 + 5, n):
+        y = a.run(x[pos:cut if cut > pos else n])
+        parts.append(y)
+        pos += len(y)
+        if pos >= n // 4096 * 4096:
+            break
+    assert a.bins() == wbins
+    a.close()
+    got = np.concatenate(parts)
+    assert len(got) == len(want)
+    err = np.max(np.abs(got - want)) / np.max(np.abs(want))
+    assert err <= NOTCH_RTOL, err
+    # the interferers are gone: what is left is the noise (power 2·12²), as in the exact result
+    tail = slice(4096 * 120, None)
+    assert abs(np.mean(np.abs(got[tail]) ** 2) / np.mean(np.abs(want[tail]) ** 2) - 1) < 1e-4
+
+
+@pytest.mark.gpu
+def test_scan_mode_is_a_passthrough_before_the_first_detect(capi, ctx, oracle):
+    g = gold("auto_notch.npz")
+    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq"]))
+    a = capi.AutoNotch(ctx, 1, 0.0, mode=capi.NOTCH_SCAN)            # default decimation: no detect within this input
+    y = a.run(x[:4096 * 5 + 100])
+    a.close()
+    assert len(y) == 4096 * 5 and bits_equal(y, x[:4096 * 5])
+
+
+@pytest.mark.gpu
+def test_scan_mode_golden_bins_and_tolerance(capi, ctx, oracle):
+    """The reference's own fixture (tests/golden/auto_notch.npz): same bins; output within tolerance of the golden tail."""
+    g = gold("auto_notch.npz")
+    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq"]))
+    for ns in (1, 2):
+        want, _ = oracle.auto_notch(x, ns, 4096 * 3)
+        a = capi.AutoNotch(ctx, ns, 0.0, 4096 * 3, mode=capi.NOTCH_SCAN)
+        y = a.run(x)
+        assert a.bins() == g[f"anf{ns}_bins"].tolist()
+        a.close()
+        assert np.max(np.abs(y - want)) / np.max(np.abs(want)) <= NOTCH_RTOL
+        assert np.max(np.abs(y[-512:] - g[f"anf{ns}_tail"])) / np.max(np.abs(want)) <= NOTCH_RTOL
+
+
+@pytest.mark.gpu
+def test_scan_mode_refuses_what_it_does_not_implement(capi, ctx):
+    with pytest.raises(capi.LsdrError):
+        capi.AutoNotch(ctx, 1, 30.0, mode=capi.NOTCH_SCAN)      # AGC set point: exact mode only
+    with pytest.raises(capi.LsdrError):
+        capi.AutoNotch(ctx, 6, 0.0, mode=capi.NOTCH_SCAN)
