@@ -512,6 +512,7 @@ struct rx_tiled_args {
   rx_state_dev *state_next;            // end state of the last tile (k_rx_ema moves it into `state`)
   rx_meas *meas;                       // [n_meas] measurement slots (may be null)
   unsigned long long meas_base;        // meas_count at the start of the run
+  float2 *cstln;                       // [total_chunks] last sampled point of every chunk (NaN: the chunk had no symbol); may be null
   rx_consts C;
   rx_tables T;
 };
@@ -543,7 +544,8 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   for (unsigned long long c = 0; c < c1; ++c) {
     if (SAMP == 1) s.samp_freqw = s.freqw;
     bool wrote;
-    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, nullptr, &wrote);
+    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, a.cstln ? a.cstln + c : nullptr, &wrote);
+    if (a.cstln && !wrote) a.cstln[c] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
     m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;
     if (a.meas) rx_tile_meas(a, c, 0u, s.freqw, m);
   }
@@ -717,6 +719,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     if (body) cnt += nsym; else got += nsym;
     if (lastwarm) ti.n_warm = nsym;
     if (body && a.meas) rx_tile_meas(a, cb + (unsigned long long)ci, j, freqw, m);
+    if (body && a.cstln) a.cstln[cb + (unsigned long long)ci] = had ? sv : make_float2(__builtin_nanf(""), __builtin_nanf(""));   // sdr.h:861-864
   }
   ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
   a.info[j] = ti;
@@ -935,7 +938,8 @@ static int rx_pull_state(lsdr_rx *r) {   // refresh the host mirror after queued
 // rx_tiled_enqueue puts one run on the stream (tiles → seam → compaction → results into a pinned ring
 // slot) without waiting; rx_tiled_wait retires the oldest queued run.
 static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
-                            size_t *consumed, bool want_meas, size_t meas_cap, size_t *nm_out) {
+                            size_t *consumed, bool want_meas, size_t meas_cap, size_t *nm_out, size_t cstln_cap = 0,
+                            size_t *chunks_out = nullptr) {
   lsdr_ctx *c = r->ctx;
   LSDR_HIP(hipSetDevice(c->device));
   *consumed = 0;
@@ -958,6 +962,9 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   size_t chunks = n_in >= (size_t)(kChunk + ra) ? (n_in - ra) / kChunk : 0;
   // (+1 symbol per seam: a repaired seam may re-insert a warm-up symbol)
   if ((size_t)(sym_per_chunk + 1) * chunks > cap_out) chunks = cap_out / (sym_per_chunk + 1);
+  const bool want_cstln = cstln_cap > 0;
+  if (want_cstln && chunks > cstln_cap) chunks = cstln_cap;     // one sampled point per chunk at most (sdr.h:785-788 gate)
+  if (chunks_out) *chunks_out = chunks;
   const int slot = (r->ring_head + r->ring_count) % lsdr_rx::kRing;
   if (!chunks) {   // nothing to do: still occupies a slot so that wait() pairs with run_async()
     r->h_res[slot].total = 0; r->h_res[slot].rot_final = 0; r->h_res[slot].ndup = r->h_res[slot].nmiss = r->h_res[slot].nbad = 0;
@@ -1005,6 +1012,12 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
     LSDR_HIP(hipMalloc((void **)&r->d_meas, (nm + 1) * sizeof(rx_meas)));
     r->meas_cap = nm + 1;
   }
+  if (want_cstln && r->cstln_cap < chunks) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(r->d_cstln);
+    LSDR_HIP(hipMalloc((void **)&r->d_cstln, chunks * sizeof(float2)));
+    r->cstln_cap = chunks;
+  }
   int rc = rx_push_state(r);
   if (rc) return rc;
 
@@ -1023,6 +1036,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   a.state_next = r->d_state_next;
   a.meas = want_meas ? r->d_meas : nullptr;
   a.meas_base = meas_base;
+  a.cstln = want_cstln ? r->d_cstln : nullptr;
   rx_fill_consts(r, a.C, a.T);
   // 32 tiles per wavefront: few enough wavefronts that the whole batch is resident in one round even while
   // fir_filter's persistent workgroups hold most of the register file (C2 bench, streams overlapped: 8 → 292,
@@ -1087,11 +1101,11 @@ static int rx_tiled_wait(lsdr_rx *r, size_t *produced) {
 
 static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                         size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
-                        size_t meas_cap, size_t *n_meas) {
+                        size_t meas_cap, size_t *n_meas, lsdr_cf32 *cstln_out, size_t cstln_cap, size_t *n_cstln) {
   if (r->ring_count) { lsdr_set_error("cstln_receiver: queued runs outstanding (lsdr_rx_wait first)"); return LSDR_E_ARG; }
   const bool want_meas = freq_out || ss_out || mer_out;
-  size_t nm = 0;
-  int rc = rx_tiled_enqueue(r, in, n_in, out, cap_out, consumed, want_meas, meas_cap, &nm);
+  size_t nm = 0, chunks = 0;
+  int rc = rx_tiled_enqueue(r, in, n_in, out, cap_out, consumed, want_meas, meas_cap, &nm, cstln_out ? cstln_cap : 0, &chunks);
   if (rc) return rc;
   rc = rx_tiled_wait(r, produced);
   if (rc) return rc;
@@ -1107,6 +1121,14 @@ static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softs
     }
   }
   if (n_meas) *n_meas = want_meas ? nm : 0;
+  if (cstln_out && cstln_cap && chunks) {     // one point per chunk that produced a symbol, in stream order
+    std::vector<float2> pts(chunks);
+    LSDR_HIP(hipMemcpy(pts.data(), r->d_cstln, chunks * sizeof(float2), hipMemcpyDeviceToHost));
+    size_t k = 0;
+    for (size_t i = 0; i < chunks && k < cstln_cap; ++i)
+      if (pts[i].x == pts[i].x) { cstln_out[k].re = pts[i].x; cstln_out[k].im = pts[i].y; ++k; }
+    if (n_cstln) *n_cstln = k;
+  }
   return LSDR_OK;
 }
 
@@ -1343,7 +1365,7 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
   if (n_in < (size_t)(kChunk + ra) || cap_out < (size_t)kChunk) return LSDR_OK;
   LSDR_ARG(in && out);
   if (r->cfg.mode == LSDR_RX_TILED)
-    return rx_run_tiled(r, in, n_in, out, cap_out, consumed, produced, freq_out, ss_out, mer_out, meas_cap, n_meas);
+    return rx_run_tiled(r, in, n_in, out, cap_out, consumed, produced, freq_out, ss_out, mer_out, meas_cap, n_meas, cstln_out, cstln_cap, n_cstln);
   lsdr_ctx *c = r->ctx;
   LSDR_HIP(hipSetDevice(c->device));
 

@@ -80,6 +80,7 @@ void lsdr_ctx_destroy(lsdr_ctx *c) {
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipFree(c->bounce);
+  (void)hipFree(c->rs_tables); (void)hipFree(c->rs_counter);
   if (c->copy_ready) {
     (void)hipStreamSynchronize(c->up); (void)hipStreamSynchronize(c->down);
     (void)hipStreamDestroy(c->up); (void)hipStreamDestroy(c->down);

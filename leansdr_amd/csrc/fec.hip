@@ -393,14 +393,18 @@ __device__ void rs_correct(const gf_tables &g, const unsigned char *synd, unsign
       if (i + j < 16) omega[i + j] ^= gmul(g, synd[i], C[j]);
   unsigned char Cprime[15];
   for (int i = 0; i < 15; ++i) Cprime[i] = (i & 1) ? 0 : C[i + 1];
+  // Berlekamp-Massey can end with L = 16 (more errors than the code corrects); C[] and omega[] have 16 coefficients —
+  // the reference evaluates degree L regardless and reads one byte past them (rs.h:247,258) — such packets stay
+  // uncorrectable either way, so the evaluation is capped at the arrays' degree.
+  const int deg = L > 15 ? 15 : L;
   int roots = 0;
   for (int i = 0; i < 255; ++i) {
     const unsigned char r = g.exp[i];
-    if (!eval_poly(g, C, L, r)) {
+    if (!eval_poly(g, C, deg, r)) {
       const unsigned char xk = ginv(g, r);
       const int loc = (255 - i) % 255;
       if (loc < 204) {
-        const unsigned char num = gmul(g, xk, eval_poly(g, omega, L, r));
+        const unsigned char num = gmul(g, xk, eval_poly(g, omega, deg, r));
         const unsigned char den = eval_poly(g, Cprime, 14, r);
         const unsigned char e = gdiv(g, num, den);
         *nerrs += __popc((unsigned)e);
@@ -672,16 +676,14 @@ static void gf_build(gf_tables &g) {   // gf2x_p<u8,u16,0x11d,8,2>, rs.h:47-63
   }
 }
 
-static gf_tables *rs_device_tables(lsdr_ctx *c) {   // one copy per device, created on first use
-  static gf_tables *d_tab[64] = {nullptr};
-  if (c->device < 0 || c->device >= 64) return nullptr;
-  if (!d_tab[c->device]) {
+static gf_tables *rs_device_tables(lsdr_ctx *c) {   // one copy per context, created on first use, freed with the context
+  if (!c->rs_tables) {
     gf_tables g;
     gf_build(g);
-    if (hipMalloc((void **)&d_tab[c->device], sizeof(gf_tables)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d_tab[c->device], &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (hipMalloc(&c->rs_tables, sizeof(gf_tables)) != hipSuccess) { c->rs_tables = nullptr; return nullptr; }
+    if (hipMemcpy(c->rs_tables, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
   }
-  return d_tab[c->device];
+  return static_cast<gf_tables *>(c->rs_tables);
 }
 
 extern "C" {
@@ -964,14 +966,13 @@ int lsdr_rs_decoder_run(lsdr_ctx *c, uint8_t *in, size_t n, uint8_t *out, long *
   LSDR_HIP(hipSetDevice(c->device));
   gf_tables *tab = rs_device_tables(c);
   if (!tab) { lsdr_set_error("rs_decoder: cannot allocate GF tables"); return LSDR_E_NOMEM; }
-  static unsigned long long *d_cnt[64] = {nullptr};
-  if (!d_cnt[c->device]) LSDR_HIP(hipMalloc((void **)&d_cnt[c->device], sizeof(unsigned long long)));
-  LSDR_HIP(hipMemsetAsync(d_cnt[c->device], 0, sizeof(unsigned long long), c->stream));
+  if (!c->rs_counter) LSDR_HIP(hipMalloc((void **)&c->rs_counter, sizeof(unsigned long long)));
+  LSDR_HIP(hipMemsetAsync(c->rs_counter, 0, sizeof(unsigned long long), c->stream));
   hipLaunchKernelGGL(k_rs_decode, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, in, (unsigned long long)n, out,
-                     (const gf_tables *)tab, d_cnt[c->device]);
+                     (const gf_tables *)tab, c->rs_counter);
   LSDR_HIP(hipGetLastError());
   unsigned long long e = 0;
-  LSDR_HIP(hipMemcpyAsync(&e, d_cnt[c->device], sizeof(e), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipMemcpyAsync(&e, c->rs_counter, sizeof(e), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));
   if (bits) *bits = (long)(n * kRS * 8);   // nbits += SIZE_RSPACKET*8 per packet, dvb.h:1007
   if (errs) *errs = (long)e;

@@ -19,6 +19,10 @@ struct lsdr_ctx {
   hipStream_t up, down;
   hipEvent_t ev_up, ev_compute;
   bool copy_ready;
+  // rs_decoder (fec.hip): GF(256) tables and the corrected-bits counter of THIS context (two contexts on one device decode
+  // concurrently on their own streams)
+  void *rs_tables;
+  unsigned long long *rs_counter;
 };
 
 struct lsdr_event {

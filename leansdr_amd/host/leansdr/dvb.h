@@ -176,6 +176,8 @@ struct mpeg_sync<u8, 0> : runnable {
     locktime_out = opt_writer(locktime_o);
   }
   void run() {
+    if (scan_syncs != 8 || want_syncs != 4 || lock_timeout != 4)   // dvb.h:727-729 defaults: what the device state machine implements
+      fail("mpeg_sync: scan_syncs / want_syncs / lock_timeout other than the reference's defaults (8 / 4 / 4) are not implemented");
     if (!h) lsdr_check(lsdr_mpeg_sync_create(ctx, fastlock, &h), name);
     lsdr_check(lsdr_mpeg_sync_set_resync_period(h, resync_period), name);
     // one run() writes at most: the initial "unlocked" report plus one lock/unlock event (dvb.h:744-754)

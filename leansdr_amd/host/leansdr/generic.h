@@ -86,7 +86,10 @@ struct file_reader : runnable {
       got = fdio::pull(fd_, to_.wr(), room, sizeof(T));
     }
     if (got > 0) to_.written((size_t)got / sizeof(T));
-    else if (got < 0 && have_filler_) to_.write(filler_);
+    else if (got < 0) {
+      if (!have_filler_) fatal("read");        // EAGAIN on a descriptor nobody made non-blocking on purpose: an error, like the reference
+      to_.write(filler_);
+    }
   }
   void set_realtime(T &filler) {
     const int fl = fcntl(fd_, F_GETFL);

@@ -62,6 +62,9 @@ def test_tiled_vs_serial(capi, ctx, oracle, stream, tile_len, warm):
     assert np.max(np.abs(out["mer"] - ref["mer"])) <= MER_ATOL_DB, np.max(np.abs(out["mer"] - ref["mer"]))
     s0, s1 = out["state"], ref["state"]
     assert abs(s0.est_insp / s1.est_insp - 1) <= SS_RTOL and abs(s0.agc_gain / s1.agc_gain - 1) <= SS_RTOL
+    # --fd-const: one sampled constellation point per chunk (sdr.h:861-864), also in the tiled mode
+    assert len(out["cstln"]) == len(ref["cstln"]) > 100
+    assert np.mean(np.abs(out["cstln"] - ref["cstln"])) < 0.05 * 75
 
 
 def test_tiled_short_input_is_exact(capi, ctx, oracle, stream):
