@@ -318,6 +318,11 @@ class C2Pipeline:
             y_ref = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full))
         y_ref = y_ref[0] if isinstance(y_ref, tuple) else y_ref
         fir_ok = len(y_ref) == len(y) and y_ref.tobytes() == y.tobytes()
+        fir_diff = None
+        if not fir_ok and len(y_ref) == len(y):
+            bad = np.flatnonzero(y_ref.view(np.uint64) != y.view(np.uint64))
+            fir_diff = dict(outputs_different=int(len(bad)), first=int(bad[0]), last=int(bad[-1]),
+                            max_abs=float(np.max(np.abs(y_ref[bad] - y[bad]))), ref_abs_max=float(np.max(np.abs(y_ref))))
         st = po.RxState()
         for k, _ in st._fields_:
             setattr(st, k, getattr(st_dev, k))
@@ -326,6 +331,8 @@ class C2Pipeline:
         out = dict(capture=0, batch="last batch of the timed region", fir_outputs=int(len(y)), fir_bit_exact=bool(fir_ok),
                    symbols=int(len(sym)), symbols_oracle=int(len(ref["sym"])), count_equal=bool(len(sym) == len(ref["sym"])),
                    consumed_equal=bool(ref["consumed"] == n_out))
+        if fir_diff:
+            out["fir_diff"] = fir_diff
         if out["count_equal"]:
             same = float((sym["symbol"] == ref["sym"]["symbol"]).mean())
             dcost = float(np.abs(sym["cost"].astype(int) - ref["sym"]["cost"].astype(int)).mean())

@@ -276,6 +276,16 @@ int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
  * of cstln_receiver<f32>, sdr.h:923-935) into a pinned slot in stream order, i.e. the state the NEXT queued run starts
  * from; lsdr_rx_get_snapshot() waits for the stream and returns it.  Lets a caller (bench.py's verification) replay one
  * queued run on a checker from exactly the state the device used, without putting the host between two runs. */
+/* Exact receiver, one GPU LANE per independent capture: n_streams captures with the same parameters (BASELINE config 4's
+ * shape), each with its own loop state, every lane running cstln_receiver<f32>::run's exact arithmetic (sdr.h:772-916) →
+ * bit-exact soft symbols and state per capture, 64 captures per wavefront.  `in_dev` / `out_dev` are HOST arrays of
+ * n_streams DEVICE pointers; every capture gets n_in samples and cap_out symbol slots; all consume the same *consumed. */
+typedef struct lsdr_rx_batch lsdr_rx_batch;
+int lsdr_rx_batch_create(lsdr_ctx *ctx, const lsdr_rx_cfg *cfg, unsigned n_streams, lsdr_rx_batch **b);
+void lsdr_rx_batch_destroy(lsdr_rx_batch *b);
+int lsdr_rx_batch_run(lsdr_rx_batch *b, const lsdr_cf32 *const *in_dev, size_t n_in, lsdr_softsymbol *const *out_dev, size_t cap_out,
+                      size_t *consumed, size_t *produced /*[n_streams]*/);
+int lsdr_rx_batch_get_state(lsdr_rx_batch *b, unsigned stream, lsdr_rx_state *st);
 /* LSDR_RX_TILED, QPSK: whether the tolerance tiles take their decisions by arithmetic instead of the constellation-table
  * gather (only when lsdr_rx_create verified the arithmetic against all 65536 table entries: symbol/cost/point identical,
  * |phase_error difference| ≤ 2 table units — reported in *max_phase_error_delta). */

@@ -201,6 +201,10 @@ _sig("lsdr_copy_d2h_async", C.c_int, [vp, vp, vp, c_sz])
 _sig("lsdr_copy_fence", C.c_int, [vp])
 _sig("lsdr_copy_sync_d2h", C.c_int, [vp])
 _sig("lsdr_copy_sync_all", C.c_int, [vp])
+_sig("lsdr_rx_batch_create", C.c_int, [vp, C.POINTER(RxCfg), C.c_uint, C.POINTER(vp)])
+_sig("lsdr_rx_batch_destroy", None, [vp])
+_sig("lsdr_rx_batch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_rx_batch_get_state", C.c_int, [vp, C.c_uint, C.POINTER(RxState)])
 _sig("lsdr_rx_decision_mode", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint)])
 _sig("lsdr_rx_snapshot_async", C.c_int, [vp])
 _sig("lsdr_rx_get_snapshot", C.c_int, [vp, C.POINTER(RxState)])
@@ -534,6 +538,40 @@ class CstlnReceiver:
         r["state"] = self.state()
         din.free(); dout.free()
         return r
+
+
+class RxBatch:
+    """Exact cstln_receiver<f32>, one GPU lane per independent capture (lsdr_rx_batch_*)."""
+
+    def __init__(self, ctx, n_streams, sampler=SAMP_LINEAR, cstln=QPSK, fec=FEC12, omega=4.0, freq=0.0, pll_adjustment=1.0,
+                 allow_drift=0, meas_decimation=1048576, kest=0.01):
+        self.ctx, self.n = ctx, n_streams
+        cfg = RxCfg()
+        cfg.sampler, cfg.cstln, cfg.fec = sampler, cstln, fec
+        cfg.omega, cfg.freq, cfg.pll_adjustment = omega, freq, pll_adjustment
+        cfg.allow_drift, cfg.meas_decimation, cfg.kest = allow_drift, meas_decimation, kest
+        cfg.subsampling = 1
+        h = vp()
+        check(lib.lsdr_rx_batch_create(ctx.h, C.byref(cfg), n_streams, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_rx_batch_destroy(self.h)
+            self.h = None
+
+    def run_dev(self, in_ptrs, n_in, out_ptrs, cap_out):
+        ins = (vp * self.n)(*[p if isinstance(p, vp) else vp(p) for p in in_ptrs])
+        outs = (vp * self.n)(*[p if isinstance(p, vp) else vp(p) for p in out_ptrs])
+        cons = c_sz()
+        prod = (c_sz * self.n)()
+        check(lib.lsdr_rx_batch_run(self.h, ins, n_in, outs, cap_out, C.byref(cons), prod))
+        return cons.value, list(prod)
+
+    def state(self, stream):
+        st = RxState()
+        check(lib.lsdr_rx_batch_get_state(self.h, stream, C.byref(st)))
+        return st
 
 
 # ---- FEC tail -----------------------------------------------------------------------

@@ -94,6 +94,8 @@ struct rx_tables {
   const lut_entry *lut;          // [65536]
   const float *coeffs;           // fir sampler prototype
   float2 *shifted;               // fir sampler shifted coefficients
+  const float2 *shifted_tol;     // tiled mode: the same table rebuilt from the carried freqw at the start of every run, for the
+                                 // tolerance tiles (`shifted` follows the reference's refresh throttle and belongs to tile 0)
 };
 
 // trig16::expi(float), math.h:108-110
@@ -543,6 +545,20 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   rx_ema_map m; m.a = 0.f; m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;   // constant map: the values are exact here
   for (unsigned long long c = 0; c < c1; ++c) {
     if (SAMP == 1) s.samp_freqw = s.freqw;
+    if (SAMP == 2) {    // fir_sampler::update_freq (sdr.h:667-680): refresh the shifted taps once per N·16 samples
+      int ph = s.update_freq_phase - 128;
+      if (ph <= 0) {
+        const float f = s.freqw / a.C.subsampling;
+        const int N = a.C.ncoeffs;
+        for (int i = 0; i < N; ++i) {
+          const float2 e = ld_uniform::expi(a.T, trig_index(-f * (i - N / 2)));
+          const float cc = a.T.coeffs[i];
+          a.T.shifted[i] = make_float2(e.x * cc, e.y * cc);
+        }
+        ph = N * 16;
+      }
+      s.update_freq_phase = ph;
+    }
     bool wrote;
     rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, a.cstln ? a.cstln + c : nullptr, &wrote);
     if (a.cstln && !wrote) a.cstln[c] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
@@ -580,7 +596,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   if (c1 > a.total_chunks) c1 = a.total_chunks;
   const unsigned long long cb = c0 - a.warm_chunks;
   const int nwarm = (int)a.warm_chunks, nchunks = (int)(c1 - cb);
-  const int ra = SAMP == 1 ? 1 : 0;
+  const int ra = SAMP == 1 ? 1 : (SAMP == 2 ? C.ncoeffs - 1 : 0);
   const int n_last = nchunks * kChunk - 1 + ra;          // last readable sample of this tile's span
   const float2 *base = a.in + cb * kChunk;
 
@@ -634,14 +650,25 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     };
     skip();
     while (n < cend) {
-      if ((unsigned)(n - wn) > 1u) {                      // window missed (rare: rounding at the ±0.1 edge): plain loads
-        w0 = base[n]; w1 = base[n + ra]; wn = n;
+      if (SAMP != 2 && (unsigned)(n - wn) > 1u) {         // window missed (rare: rounding at the ±0.1 edge): plain loads
+        w0 = base[n]; w1 = base[n + (SAMP == 1 ? 1 : 0)]; wn = n;
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0) HERE, so that the common path only waits for its window
       }
       const bool second = n != wn;
       const float2 p0 = second ? w1 : w0, p1 = second ? w2 : w1;
       const float2 s0 = cmul(p0, ld_hwtrig::expi(a.T, trig_index(-phase)));
-      if (SAMP == 1) {
+      if (SAMP == 2) {
+        // fir_sampler::interp (sdr.h:646-665): polyphase branch (1−mu)·S of the matched filter over the next ⌈N/S⌉ samples;
+        // plain loads (an ⌈N/S⌉-sample window does not pay), taps from the per-run table
+        float2 acc = make_float2(0.f, 0.f);
+        const int S = C.subsampling, N = C.ncoeffs;
+        const float2 *px = base + n;
+        for (int pc = (int)((1 - mu) * S); pc < N; pc += S, ++px) {
+          const float2 tt = cmul(a.T.shifted_tol[pc], *px);
+          acc.x += tt.x; acc.y += tt.y;
+        }
+        sg = cmul(ld_hwtrig::expi(a.T, trig_index(-phase)), acc);
+      } else if (SAMP == 1) {
         const float2 s1 = cmul(p1, ld_hwtrig::expi(a.T, trig_index(-(phase + samp_freqw))));
         const float k0 = 1 - mu;
         sg = make_float2(s0.x * k0 + s1.x * mu, s0.y * k0 + s1.y * mu);
@@ -757,6 +784,18 @@ __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
   else rx_tile_tol<SAMP, NT, ARITH>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
 }
 
+// fir_sampler in the tiled mode: the tolerance tiles' shifted taps, rebuilt from the carried freqw before every run
+// (do_update_freq, sdr.h:676-680: sc[i] = expi(−(freqw/S)(i − N/2))·c[i])
+__global__ __launch_bounds__(256) void k_rx_fir_refresh(const rx_state_dev *state, const float2 *trig, const float *coeffs, int N, int S,
+                                                        float2 *shifted_tol) {
+  const float f = state->freqw / S;
+  for (int i = threadIdx.x; i < N; i += 256) {
+    const float2 e = trig[trig_index(-f * (i - N / 2))];
+    const float cc = coeffs[i];
+    shifted_tol[i] = make_float2(e.x * cc, e.y * cc);
+  }
+}
+
 // Scan of the wavefronts' estimator maps (one workgroup; a run has a few hundred wavefronts): final estimators / AGC of
 // the run and the measurement slots.
 //  * state ← state_next (end state of the last tile; tiles read `state` while they run, so it is only replaced here),
@@ -812,6 +851,43 @@ __global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *wave, 
   }
 }
 
+// ---------------------------------------------------------------- exact receiver, one LANE per independent capture
+// The recurrence cannot be parallelised inside a stream without giving up bit-exactness — across streams it can: lane l of
+// a wavefront runs capture l with the reference's exact arithmetic (rx_chunk, the routine of the serial kernel; table
+// look-ups as vector gathers from the same tables), 64 captures per wavefront, as many wavefronts as there are captures
+// (BASELINE config 4's shape: many independent 2 MS/s captures).  Bit-exact soft symbols and loop state per capture.
+struct rx_batch_args {
+  const float2 *const *in;             // [n_streams] device pointers
+  lsdr_softsymbol *const *out;         // [n_streams]
+  unsigned long long chunks;           // the same number of 128-sample chunks for every capture
+  rx_state_dev *states;                // [n_streams]
+  unsigned long long *produced;        // [n_streams]
+  unsigned n_streams;
+  rx_consts C;
+  rx_tables T;
+};
+
+template <int SAMP>
+__global__ __launch_bounds__(64) void k_rx_batch(rx_batch_args a) {
+  const unsigned sidx = blockIdx.x * 64u + threadIdx.x;
+  if (sidx >= a.n_streams) return;
+  rx_state_dev s = a.states[sidx];
+  const float2 *pin = a.in[sidx];
+  lsdr_softsymbol *po = a.out[sidx];
+  unsigned long long nout = 0;
+  for (unsigned long long c = 0; c < a.chunks; ++c) {
+    if (SAMP == 1) s.samp_freqw = s.freqw;     // sampler->update_freq(freqw), sdr.h:790
+    bool wrote;
+    unsigned cnt = 0;
+    rx_chunk<SAMP, ld_vec>(a.T, a.C, s, pin + c * kChunk, [&](lsdr_softsymbol ss) { po[nout + cnt++] = ss; }, nullptr, &wrote);
+    nout += cnt;
+    s.meas_count += kChunk;                    // sdr.h:905-913 (the measurement pipes are not wired in the batch form)
+    while (s.meas_count >= a.C.meas_decimation) s.meas_count -= a.C.meas_decimation;
+  }
+  a.states[sidx] = s;
+  a.produced[sidx] = nout;
+}
+
 }  // namespace
 
 struct lsdr_rx {
@@ -827,7 +903,7 @@ struct lsdr_rx {
   float2 *d_trig;
   lut_entry *d_lut;
   float *d_coeffs;
-  float2 *d_shifted;
+  float2 *d_shifted, *d_shifted_tol;
   rx_state_dev *d_state;
   unsigned long long *d_counters;
   rx_meas *d_meas; size_t meas_cap;
@@ -922,7 +998,7 @@ static void rx_fill_consts(const lsdr_rx *r, rx_consts &C, rx_tables &T) {
     C.acq_alpha = C.freq_alpha * ((e = getenv("LSDR_RX_ACQ_ALPHA")) ? (float)atof(e) : 1.f);
     C.acq_gain_mu = C.gain_mu * ((e = getenv("LSDR_RX_ACQ_MU")) ? (float)atof(e) : 1.f);
   }
-  T.trig = r->d_trig; T.lut = r->d_lut; T.coeffs = r->d_coeffs; T.shifted = r->d_shifted;
+  T.trig = r->d_trig; T.lut = r->d_lut; T.coeffs = r->d_coeffs; T.shifted = r->d_shifted; T.shifted_tol = r->d_shifted_tol;
 }
 
 static int rx_pull_state(lsdr_rx *r) {   // refresh the host mirror after queued runs
@@ -944,10 +1020,6 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   LSDR_HIP(hipSetDevice(c->device));
   *consumed = 0;
   if (nm_out) *nm_out = 0;
-  if (r->cfg.sampler == LSDR_SAMP_FIR) {
-    lsdr_set_error("cstln_receiver: LSDR_RX_TILED supports the nearest and linear samplers");
-    return LSDR_E_UNSUPPORTED;
-  }
   if (r->ring_count == lsdr_rx::kRing) { lsdr_set_error("cstln_receiver: too many queued runs (lsdr_rx_wait first)"); return LSDR_E_ARG; }
   const int ra = lsdr_rx_readahead(r);
   // Defaults: a warm-up of ≈ 64 symbols (whole chunks) — the TS-level yield is flat from 32 to 256 symbols of
@@ -1055,8 +1127,12 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
                                   else hipLaunchKernelGGL((k_rx_tiles<S, N, false>), dim3(blocks), dim3(64), 0, c->stream, a); } while (0)
 #define LSDR_RX_LAUNCH_S(S) \
   do { if (lpw == 2) LSDR_RX_LAUNCH(S, 2); else if (lpw == 8) LSDR_RX_LAUNCH(S, 8); else if (lpw == 4) LSDR_RX_LAUNCH(S, 4); else if (lpw == 16) LSDR_RX_LAUNCH(S, 16); else if (lpw == 64) LSDR_RX_LAUNCH(S, 64); else LSDR_RX_LAUNCH(S, 32); } while (0)
+  if (r->cfg.sampler == LSDR_SAMP_FIR)
+    hipLaunchKernelGGL(k_rx_fir_refresh, dim3(1), dim3(256), 0, c->stream, (const rx_state_dev *)r->d_state, (const float2 *)r->d_trig,
+                       (const float *)r->d_coeffs, r->cfg.ncoeffs, r->cfg.subsampling, r->d_shifted_tol);
   if (r->cfg.sampler == LSDR_SAMP_NEAREST) LSDR_RX_LAUNCH_S(0);
-  else LSDR_RX_LAUNCH_S(1);
+  else if (r->cfg.sampler == LSDR_SAMP_LINEAR) LSDR_RX_LAUNCH_S(1);
+  else LSDR_RX_LAUNCH_S(2);
 #undef LSDR_RX_LAUNCH_S
 #undef LSDR_RX_LAUNCH
   LSDR_HIP(hipGetLastError());
@@ -1217,12 +1293,14 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_HIP(hipMemcpy(r->d_trig, trig.data(), 65536 * sizeof(float2), hipMemcpyHostToDevice));
   LSDR_HIP(hipMemcpy(r->d_lut, lut.data(), 65536 * sizeof(lut_entry), hipMemcpyHostToDevice));
   r->d_coeffs = nullptr;
-  r->d_shifted = nullptr;
+  r->d_shifted = nullptr; r->d_shifted_tol = nullptr;
   if (cfg->sampler == LSDR_SAMP_FIR) {
     LSDR_HIP(hipMalloc((void **)&r->d_coeffs, cfg->ncoeffs * sizeof(float)));
     LSDR_HIP(hipMalloc((void **)&r->d_shifted, cfg->ncoeffs * sizeof(float2)));
     LSDR_HIP(hipMemcpy(r->d_coeffs, r->coeffs.data(), cfg->ncoeffs * sizeof(float), hipMemcpyHostToDevice));
     LSDR_HIP(hipMemset(r->d_shifted, 0, cfg->ncoeffs * sizeof(float2)));
+    LSDR_HIP(hipMalloc((void **)&r->d_shifted_tol, cfg->ncoeffs * sizeof(float2)));
+    LSDR_HIP(hipMemset(r->d_shifted_tol, 0, cfg->ncoeffs * sizeof(float2)));
   }
   LSDR_HIP(hipMalloc((void **)&r->d_state, sizeof(rx_state_dev)));
   LSDR_HIP(hipMalloc((void **)&r->d_counters, 8 * sizeof(unsigned long long)));
@@ -1271,7 +1349,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   if (!r) return;
   (void)hipStreamSynchronize(r->ctx->stream);
   (void)hipFree(r->d_trig); (void)hipFree(r->d_lut);
-  (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted);
+  (void)hipFree(r->d_coeffs); (void)hipFree(r->d_shifted); (void)hipFree(r->d_shifted_tol);
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
   (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part); (void)hipFree(r->d_wstage);
@@ -1427,6 +1505,82 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
   if (n_meas) *n_meas = want_meas ? cnt[2] : 0;
   if (cstln_out && cnt[3]) LSDR_HIP(hipMemcpy(cstln_out, r->d_cstln, cnt[3] * sizeof(float2), hipMemcpyDeviceToHost));
   if (n_cstln) *n_cstln = cstln_out ? cnt[3] : 0;
+  return LSDR_OK;
+}
+
+// ---- lane-per-capture exact receiver -----------------------------------------------------------------------------------
+struct lsdr_rx_batch {
+  lsdr_rx *proto;                 // tables, constants and the initial loop state of one capture
+  unsigned n;
+  rx_state_dev *d_states;
+  const float2 **d_in; lsdr_softsymbol **d_out; unsigned long long *d_prod;
+  std::vector<unsigned long long> h_prod;
+};
+
+int lsdr_rx_batch_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, unsigned n_streams, lsdr_rx_batch **out) {
+  LSDR_ARG(c && cfg && out && n_streams >= 1);
+  if (cfg->sampler == LSDR_SAMP_FIR) { lsdr_set_error("rx_batch: nearest and linear samplers only"); return LSDR_E_UNSUPPORTED; }
+  lsdr_rx_cfg pc = *cfg;
+  pc.mode = LSDR_RX_SERIAL;
+  lsdr_rx *proto = nullptr;
+  int rc = lsdr_rx_create(c, &pc, &proto);
+  if (rc) return rc;
+  lsdr_rx_batch *b = new lsdr_rx_batch();
+  b->proto = proto; b->n = n_streams;
+  std::vector<rx_state_dev> init(n_streams, proto->st);
+  LSDR_HIP(hipMalloc((void **)&b->d_states, n_streams * sizeof(rx_state_dev)));
+  LSDR_HIP(hipMemcpy(b->d_states, init.data(), n_streams * sizeof(rx_state_dev), hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&b->d_in, n_streams * sizeof(void *)));
+  LSDR_HIP(hipMalloc((void **)&b->d_out, n_streams * sizeof(void *)));
+  LSDR_HIP(hipMalloc((void **)&b->d_prod, n_streams * sizeof(unsigned long long)));
+  b->h_prod.resize(n_streams);
+  *out = b;
+  return LSDR_OK;
+}
+
+void lsdr_rx_batch_destroy(lsdr_rx_batch *b) {
+  if (!b) return;
+  (void)hipStreamSynchronize(b->proto->ctx->stream);
+  (void)hipFree(b->d_states); (void)hipFree((void *)b->d_in); (void)hipFree((void *)b->d_out); (void)hipFree(b->d_prod);
+  lsdr_rx_destroy(b->proto);
+  delete b;
+}
+
+int lsdr_rx_batch_run(lsdr_rx_batch *b, const lsdr_cf32 *const *in_dev, size_t n_in, lsdr_softsymbol *const *out_dev, size_t cap_out,
+                      size_t *consumed, size_t *produced) {
+  LSDR_ARG(b && in_dev && out_dev && consumed);
+  *consumed = 0;
+  lsdr_rx *r = b->proto;
+  lsdr_ctx *c = r->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  const int ra = lsdr_rx_readahead(r);
+  size_t chunks = n_in >= (size_t)(kChunk + ra) ? (n_in - ra) / kChunk : 0;
+  const unsigned sym_per_chunk = (unsigned)(kChunk / (r->omega - 0.1f)) + 2;
+  if ((size_t)sym_per_chunk * chunks > cap_out) chunks = cap_out / sym_per_chunk;       // every capture runs the same chunks
+  if (produced) for (unsigned i = 0; i < b->n; ++i) produced[i] = 0;
+  if (!chunks) return LSDR_OK;
+  LSDR_HIP(hipMemcpyAsync((void *)b->d_in, in_dev, b->n * sizeof(void *), hipMemcpyHostToDevice, c->stream));
+  LSDR_HIP(hipMemcpyAsync((void *)b->d_out, out_dev, b->n * sizeof(void *), hipMemcpyHostToDevice, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));                                                 // (the pointer arrays are the caller's)
+  rx_batch_args a;
+  a.in = b->d_in; a.out = b->d_out; a.chunks = chunks; a.states = b->d_states; a.produced = b->d_prod; a.n_streams = b->n;
+  rx_fill_consts(r, a.C, a.T);
+  const unsigned blocks = (b->n + 63) / 64;
+  if (r->cfg.sampler == LSDR_SAMP_NEAREST) hipLaunchKernelGGL(k_rx_batch<0>, dim3(blocks), dim3(64), 0, c->stream, a);
+  else hipLaunchKernelGGL(k_rx_batch<1>, dim3(blocks), dim3(64), 0, c->stream, a);
+  LSDR_HIP(hipGetLastError());
+  LSDR_HIP(hipMemcpyAsync(b->h_prod.data(), b->d_prod, b->n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipStreamSynchronize(c->stream));
+  if (produced) for (unsigned i = 0; i < b->n; ++i) produced[i] = (size_t)b->h_prod[i];
+  *consumed = chunks * kChunk;
+  return LSDR_OK;
+}
+
+int lsdr_rx_batch_get_state(lsdr_rx_batch *b, unsigned stream, lsdr_rx_state *st) {
+  LSDR_ARG(b && st && stream < b->n);
+  rx_state_dev s;
+  LSDR_HIP(hipMemcpy(&s, b->d_states + stream, sizeof(s), hipMemcpyDeviceToHost));
+  rx_state_export(s, st);
   return LSDR_OK;
 }
 

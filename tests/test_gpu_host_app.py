@@ -149,6 +149,21 @@ def test_tiled_receiver_ts_matches_exact_chain(oracle, viterbi):
     assert got[i0:i0 + len(tail)] == tail
 
 
+def test_tiled_rrc_sampler_ts_matches_exact_chain():
+    """--sampler rrc --tiled: the transport stream of the exact chain with the same sampler, once locked."""
+    from leansdr_amd import synth_dvbs
+    iq, _ = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=5)
+    flags = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0", "--sampler", "rrc"]
+    want, _ = run_ts(flags, iq)
+    ts, _ = run_ts(flags + ["--tiled"], iq)
+    assert len(want) > 300          # (the matched filter's 1/S gain makes the AGC — hence the lock — slow: SURVEY A5)
+    got = [bytes(t) for t in ts]
+    tail = [bytes(t) for t in want[len(want) // 2:]]
+    assert tail[0] in got
+    i0 = got.index(tail[0])
+    assert got[i0:i0 + len(tail)] == tail
+
+
 @pytest.mark.parametrize("extra", [[], ["--viterbi"]])
 def test_full_chain_fastlock(oracle, extra):
     """--fastlock (deconvol_sync scoring all alignments per call, mpeg_sync run_searching_fast, viterbi resync every

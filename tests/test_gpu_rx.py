@@ -64,3 +64,35 @@ def test_too_little_input_is_no_progress(capi, ctx):
     o = r.run(np.zeros(128, np.complex64), meas=False)   # needs 128 + readahead(1)
     assert o["consumed"] == 0 and o["produced"] == 0
     r.close()
+
+
+@pytest.mark.parametrize("sampler", [0, 1])
+def test_batch_exact_lane_per_capture(capi, ctx, oracle, sampler):
+    """lsdr_rx_batch: 67 independent captures (two wavefronts, one lane each), different signals, two consecutive runs:
+    every capture's soft symbols and final loop state are those of the oracle's serial receiver, bit for bit."""
+    from leansdr_amd import synth
+    n_streams, n = 67, 128 * 70 + 1
+    xs = [synth.qpsk_baseband(4 * 5000, 4, seed=100 + i, rms=40.0 + i % 7, snr_db=12.0 + (i % 5) * 3, circular=False)[0][:2 * n] for i in range(n_streams)]
+    p = po.rx_params(sampler=sampler, cstln=1, omega=4.0, meas_decimation=4096)
+    b = capi.RxBatch(ctx, n_streams, sampler=sampler, cstln=capi.QPSK, omega=4.0, meas_decimation=4096)
+    d_in = [ctx.upload(x) for x in xs]
+    d_out = [ctx.alloc(2 * n * 4) for _ in range(n_streams)]
+    got = [[] for _ in range(n_streams)]
+    pos = 0
+    for _ in range(2):
+        cons, prod = b.run_dev([d.at(pos * 8) for d in d_in], n, [d.ptr for d in d_out], 2 * n)
+        assert cons == (n - (1 if sampler else 0)) // 128 * 128
+        for i in range(n_streams):
+            got[i].append(ctx.download(d_out[i], capi.SOFTSYM, prod[i]).copy())
+        pos += cons
+    for i in range(n_streams):
+        ref = oracle.rx(p, xs[i][:pos + (1 if sampler else 0)])
+        g = np.concatenate(got[i])
+        assert ref["consumed"] == pos and len(g) == len(ref["sym"]), i
+        assert bits_equal(g["cost"], ref["sym"]["cost"]) and bits_equal(g["symbol"], ref["sym"]["symbol"]), i
+        st = b.state(i)
+        for k in ("mu", "phase", "freqw", "agc_gain", "est_insp", "est_sp", "est_ep"):
+            assert np.float32(getattr(st, k)).tobytes() == np.float32(getattr(ref["state"], k)).tobytes(), (i, k)
+    b.close()
+    for d in d_in + d_out:
+        d.free()

@@ -163,3 +163,32 @@ def test_bench_geometry_on_the_c2_chain(capi, ctx, oracle):
     assert stats["bad_seams"] == 0
     assert bits_equal(out["sym"]["cost"][:56], ref["sym"]["cost"][:56])
     assert np.allclose(out["ss"], ref["ss"], rtol=SS_RTOL) and np.max(np.abs(out["mer"] - ref["mer"])) <= MER_ATOL_DB
+
+
+def test_tiled_fir_sampler_vs_serial(capi, ctx, oracle):
+    """--sampler rrc (fir_sampler: polyphase matched filter, sdr.h:635-689) in the tiled mode: the tolerance tiles take
+    their shifted taps from a table rebuilt from the carried frequency at the start of every run."""
+    from conftest import gold
+    g = gold("cstln_receiver.npz")
+    rrc = g["rrc_rx"]
+    x, _ = synth.qpsk_baseband(4 * 200000, 4, seed=7, rms=50.0, snr_db=20.0)
+    p = po.rx_params(sampler=2, coeffs=rrc, subsampling=16, cstln=1, omega=4.0, meas_decimation=4096)
+    # The matched filter's gain is 1/S: est_insp has to come down from 75² to ≈ 8 at 1 % per chunk (SURVEY A5) — the serial
+    # loop needs ≈ 2000 chunks before its AGC stands still, and a tiled run keeps the AGC of its first chunk for all tiles.
+    acq = 128 * 2400
+    a = oracle.rx(p, x[:acq + len(rrc) - 1])
+    assert a["consumed"] == acq
+    ref = oracle.rx(p, x[acq:], state_in=a["state"])
+    r = capi.CstlnReceiver(ctx, sampler=2, coeffs=rrc, subsampling=16, cstln=1, omega=4.0, meas_decimation=4096,
+                           mode=capi.RX_TILED, tile_len=256, tile_warmup=1024)
+    st = capi.RxState()
+    for k, _ in st._fields_:
+        setattr(st, k, getattr(a["state"], k))
+    r.set_state(st)
+    out = r.run(x[acq:])
+    stats = r.tiled_stats()
+    r.close()
+    assert out["consumed"] == ref["consumed"] and len(out["sym"]) == len(ref["sym"]), (len(out["sym"]), len(ref["sym"]), stats)
+    same = (out["sym"]["symbol"] == ref["sym"]["symbol"]).mean()
+    dcost = np.abs(out["sym"]["cost"].astype(int) - ref["sym"]["cost"].astype(int)).mean()
+    assert same >= 0.999 and dcost <= 0.05 * 11236 and stats["bad_seams"] == 0, (same, dcost, stats)
