@@ -36,7 +36,7 @@ def single_stream(capi, synth, device, args):
     pipe.run(bps, False)
     pipe.sync()
     t0 = time.perf_counter()
-    consumed = pipe.run(max(1, args.steps // 2) * bps, True, snapshot_last=not args.no_verify)
+    consumed = pipe.run(max(1, args.steps // 4) * bps, True, snapshot_last=not args.no_verify)
     pipe.sync()
     dt = time.perf_counter() - t0
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=1,
@@ -55,7 +55,7 @@ def c2_fma(capi, synth, device, args):
     pipe.run(bps, False)
     pipe.sync()
     t0 = time.perf_counter()
-    consumed = pipe.run(max(1, args.steps // 2) * bps, True)
+    consumed = pipe.run(max(1, args.steps // 4) * bps, True)
     pipe.sync()
     dt = time.perf_counter() - t0
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=len(pipe.caps),
@@ -113,7 +113,7 @@ def anf1(capi, synth, device, args):
         pipe.sync(); ctx_n.sync()
 
     run(6, False)
-    nb = max(8, args.batches_per_step)
+    nb = max(48, args.batches_per_step)
     t0 = time.perf_counter()
     run(nb, True)
     dt = time.perf_counter() - t0
@@ -163,7 +163,7 @@ def c2_offset(capi, synth, device, args):
 
     for _ in range(8):
         batch(False)
-    nb = max(8, args.batches_per_step)
+    nb = max(48, args.batches_per_step)
     t0 = time.perf_counter()
     nsym = sum(batch(True) for _ in range(nb))
     pipe.sync()
@@ -338,7 +338,7 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     acq.close()
     for _ in range(3):
         front(False); tail(False)
-    nb = 10
+    nb = 40
     t0 = time.perf_counter()
     npk = 0
     for _ in range(nb):
@@ -396,7 +396,7 @@ def exact_batch(capi, synth, device, args):
     import bench
     po = bench._oracle()
     ctx = capi.Ctx(device)
-    n_streams, n = 8192, 128 * 512 + 1
+    n_streams, n = 8192, 128 * 2048 + 1
     pool_n = 32 << 20
     x, _ = synth.qpsk_baseband(4 * (1 << 20), 4, seed=21, rms=50.0, snr_db=15.0)
     d_pool = ctx.alloc((pool_n + n) * 8)

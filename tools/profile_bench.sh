@@ -1,26 +1,54 @@
 #!/bin/bash
-# tools/profile_bench.sh — the measurement set behind bench.py's `roofline` object, run on the GPU box:
-#   gpurun_out/prof/bench.json, bench_one_capture.json, bench_no_overlap.json   the bench line (default: 3 captures per GPU /
-#                                                              one capture / one capture, fir_filter and receiver back to back)
-#   gpurun_out/prof/kernel_stats.csv                           rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/prof/pmc_fetch_size.csv, pmc_write_size.csv     one PMC counter per pass (rows of the fir kernel only)
+# tools/profile_bench.sh [outdir-name] — the measurement set behind bench.py's `roofline` object, run on the GPU box:
+#   bench.json                      the driver's command (python bench.py --gpus 1 --steps 20 --warmup 5), full line incl. `more`
+#   kernel_stats.csv                rocprofv3 --kernel-trace --stats of the headline region (--no-more)
+#   pmc_fetch_size.csv, pmc_write_size.csv   one PMC counter per pass (rows of the fir kernel only) -> pmc_traffic.json
+#   timeline.csv, overlap.txt       kernel trace of a short run: fir stream occupancy, gaps, receiver kernels inside fir launches
 # Copy what is to be judged into profiles/ afterwards (gpurun_out/ is scratch).
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$REPO/gpurun_out/prof
+OUT=$REPO/gpurun_out/${1:-prof}
 mkdir -p "$OUT"
 cd "$REPO"
-timeout 300 python bench.py --steps 20 --warmup 3 > "$OUT/bench.json" 2> "$OUT/bench.err"
-timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu --captures 1 > "$OUT/bench_one_capture.json" 2>> "$OUT/bench.err"
-timeout 200 python bench.py --steps 20 --warmup 3 --no-cpu --no-overlap > "$OUT/bench_no_overlap.json" 2>> "$OUT/bench.err"
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
 export TMPDIR=/tmp
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$REPO/bench.py" --steps 20 --warmup 3 --no-cpu > /tmp/prof_stats.log 2>&1
+rm -rf /tmp/prof_stats
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python "$REPO/bench.py" --steps 20 --warmup 5 --no-cpu --no-more --no-verify > /tmp/prof_stats.log 2>&1
 f=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$c -- python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu > /tmp/prof_$c.log 2>&1
+  rm -rf /tmp/prof_$c
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$c -- python "$REPO/bench.py" --steps 1 --warmup 1 --batches-per-step 6 --no-cpu --no-more --no-verify > /tmp/prof_$c.log 2>&1
   f=$(find /tmp/prof_$c -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then (head -1 "$f"; grep "k_fir" "$f") > "$OUT/pmc_$(echo $c | tr A-Z a-z).csv"; fi
 done
+cd "$REPO"
+python - "$OUT" <<'PY'
+import csv, json, sys, os
+out = sys.argv[1]
+def avg(name):
+    rows = [r for r in csv.DictReader(open(os.path.join(out, name))) if float(r["Counter_Value"]) > 0]
+    vals = sorted(float(r["Counter_Value"]) for r in rows)
+    big = [v for v in vals if v > 0.5 * vals[-1]]          # the full-size launches (not the acquisition ones)
+    return sum(big) / len(big), len(big)
+try:
+    f, nf = avg("pmc_fetch_size.csv"); w, nw = avg("pmc_write_size.csv")
+    j = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
+    caps = j["config"]["captures_per_gpu"]
+    d = {"_comment": "HBM traffic of the dominant kernel from rocprofv3 PMC passes (one counter per pass: --pmc FETCH_SIZE, --pmc WRITE_SIZE) of "
+                     "`bench.py --steps 1 --warmup 1 --batches-per-step 6 --no-cpu --no-more --no-verify`; FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md "
+                     "(gfx950 tallies 128-B requests at 64 B; calibrated in round 1 on tools/membench), WRITE_SIZE (KiB) uncorrected. The receiver kernels run "
+                     "concurrently on other streams: their counters fall into whichever fir dispatch window they overlap. Averages over the full-size launches.",
+         "kernel": "k_fir_persist<0,1,1,30> (one launch over the batches of all captures, lsdr_fir_filter_run_multi)",
+         "batch_samples": j["config"]["batch_samples_per_capture"] * caps,
+         "fetch_size_kib_per_launch": f, "fetch_correction": 2.0, "write_size_kib_per_launch": w, "launches_averaged": [nf, nw],
+         "traffic_bytes_per_launch": int(f * 1024 * 2 + w * 1024)}
+    json.dump(d, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    print("traffic", d["traffic_bytes_per_launch"], "algorithmic", j["roofline"]["algorithmic_bytes_per_launch"])
+except Exception as e:
+    print("pmc summary failed:", e)
+PY
+bash tools/timeline.sh --no-more --no-verify --batches-per-step 8 > "$OUT/timeline.log" 2>&1
+cp gpurun_out/timeline.csv "$OUT/timeline.csv"; python tools/overlap.py "$OUT/timeline.csv" > "$OUT/overlap.txt" 2>&1; cat "$OUT/overlap.txt"
 ls -la "$OUT"
-tail -c 600 "$OUT/bench.json"
+python tools/bench_brief.py < "$OUT/bench.json"
