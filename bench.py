@@ -324,6 +324,9 @@ class C2Pipeline:
         fir_diff = None
         if not fir_ok and len(y_ref) == len(y):
             bad = np.flatnonzero(y_ref.view(np.uint64) != y.view(np.uint64))
+            if len(bad) == 0:
+                fir_diff = dict(outputs_different=0, note="the last batch's buffer is right; an earlier batch's buffer differs")
+        if fir_diff is None and not fir_ok and len(y_ref) == len(y):
             fir_diff = dict(outputs_different=int(len(bad)), first=int(bad[0]), last=int(bad[-1]),
                             max_abs=float(np.max(np.abs(y_ref[bad] - y[bad]))), ref_abs_max=float(np.max(np.abs(y_ref))))
         st = po.RxState()
@@ -335,7 +338,7 @@ class C2Pipeline:
                    fir_buffers_checked=len(cp.dec),
                    symbols=int(len(sym)), symbols_oracle=int(len(ref["sym"])), count_equal=bool(len(sym) == len(ref["sym"])),
                    consumed_equal=bool(ref["consumed"] == n_out))
-        if fir_diff:     # diagnose: the same filter call again, alone and synchronously
+        if fir_diff and fir_diff.get("outputs_different"):     # diagnose: the same filter call again, alone and synchronously
             scratch = self.ctx.alloc((n_out + EXTRA) * 8)
             self.fir.run_dev(cp.d_in.ptr, B + EXTRA * decim + N, scratch.ptr, n_out + EXTRA)
             self.ctx.sync()
@@ -343,6 +346,7 @@ class C2Pipeline:
             scratch.free()
             fir_diff["rerun_equals_oracle"] = bool(y2.tobytes() == y_ref.tobytes())
             fir_diff["rerun_equals_first_result"] = bool(y2.tobytes() == y.tobytes())
+        if fir_diff:
             out["fir_diff"] = fir_diff
         if out["count_equal"]:
             same = float((sym["symbol"] == ref["sym"]["symbol"]).mean())

@@ -76,3 +76,55 @@ def test_reference_leandvb_other_input_formats(oracle, fmt, dtype, zero):
     r1 = subprocess.run(base + [fmt], input=x.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
     assert r1.returncode == 0, r1.stderr.decode()
     assert r1.stdout == r0.stdout
+
+
+# ---- same command line, same bytes: the reference's leandvb binary vs its source on the GPU headers ----------------------
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "leandvb")
+need_both = pytest.mark.skipif(not (os.path.exists(os.path.join(RG, "leandvb")) and os.path.exists(REFBIN)),
+                               reason="needs leansdr_amd/host/ref_graph/leandvb and oracle/_ref/leandvb (built where /root/reference exists)")
+C1 = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"]
+
+
+def _run_both(flags, data, tmp_path, extra_fd=False):
+    outs = []
+    for exe in (REFBIN, os.path.join(RG, "leandvb")):
+        pp = tmp_path / ("pp_" + os.path.basename(os.path.dirname(exe)))
+        cmd = " ".join([exe] + flags) + (f" 3>{pp}" if extra_fd else "")
+        r = subprocess.run(cmd, shell=True, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert r.returncode == 0, (cmd, r.stderr.decode()[-1500:])
+        outs.append((r.stdout, pp.read_bytes() if extra_fd else b"", r.stderr.decode()))
+    return outs
+
+
+@need_both
+@pytest.mark.parametrize("extra", [[], ["--viterbi"], ["--viterbi", "--hard-metric"], ["--sampler", "nearest"], ["--sampler", "rrc"],
+                                   ["--fastlock"], ["--derotate", "3000"], ["--decim", "1", "--anf", "2"], ["--tune", "2000"],
+                                   ["--hs"], ["--anf", "0", "--fd-info", "2", "--fd-const", "2", "--fd-spectrum", "2"]],
+                         ids=lambda e: "_".join(x.strip("-") for x in e) or "default")
+def test_same_command_line_same_bytes_u8(extra, tmp_path):
+    """Every hot-path variant of the leandvb command line (leandvb.cc:1100-1250) on a C1-shaped capture: the reference binary
+    and the reference SOURCE compiled against the GPU headers write the same transport stream (and the same report text)."""
+    from leansdr_amd import synth_dvbs
+    iq, _ = synth_dvbs.capture_u8(n_packets=500, sps_num=6, sps_den=5, seed=12)
+    (ts_ref, _, err_ref), (ts_gpu, _, err_gpu) = _run_both(C1 + extra, iq.tobytes(), tmp_path)
+    if "nearest" not in extra:          # (nearest-sample "interpolation" cannot lock at 1.2 samples/symbol: the reference writes nothing either)
+        assert len(ts_ref) > 150 * 188
+    assert ts_gpu == ts_ref
+    if "--fd-info" in extra:
+        assert err_gpu == err_ref
+
+
+@need_both
+def test_same_command_line_same_bytes_f32_resample_fd_pp(tmp_path):
+    """Config-2-shaped input (cf32, 120 samples/symbol) with the reference's DEFAULT front end — `--anf 1` and `--resample`
+    (auto_notch → fir_filter(313, /30)) — and `--fd-pp 3` (leandvb.cc:418-423): the preprocessed stream the receiver sees is
+    byte-identical to the reference's, and so is the transport stream (the a4+a6 end-to-end pin)."""
+    from leansdr_amd import synth
+    x, _ = synth.qpsk_baseband(120 * 40000, 120, seed=4, rms=1.0, snr_db=15.0, circular=False)
+    t = np.arange(len(x))
+    x = (x + 2.0 * np.exp(2j * np.pi * 0.0031 * t)).astype(np.complex64)         # a CW interferer inside the filter's passband edge
+    flags = ["--f32", "--float-scale", "75", "-f", "240e6", "--sr", "2000e3", "--cr", "1/2", "--resample", "--fd-pp", "3"]
+    (ts_ref, pp_ref, _), (ts_gpu, pp_gpu, _) = _run_both(flags, x.tobytes(), tmp_path, extra_fd=True)
+    assert len(pp_ref) > 100000 * 8
+    assert pp_gpu == pp_ref
+    assert ts_gpu == ts_ref
