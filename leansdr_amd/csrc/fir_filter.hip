@@ -41,7 +41,10 @@
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef LSDR_FIR_THREADS
+#define LSDR_FIR_THREADS 256
+#endif
+constexpr int kThreads = LSDR_FIR_THREADS;   // lanes (= outputs, R = 1) per workgroup tile
 
 struct fir_args {
   const void *in;        // cf32 or cu8 samples

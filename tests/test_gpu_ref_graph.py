@@ -128,3 +128,26 @@ def test_same_command_line_same_bytes_f32_resample_fd_pp(tmp_path):
     assert len(pp_ref) > 100000 * 8
     assert pp_gpu == pp_ref
     assert ts_gpu == ts_ref
+
+
+@pytest.mark.parametrize("size", [1024, 4099, 1 << 18])
+def test_pipes_with_ends_on_both_sides(tmp_path, size):
+    """tests/host/pipe_sides_test.cc: one host-written pipe read by a GPU block AND a host block, one device-written pipe read
+    by a GPU block AND a host block, small pipes (constant compaction with uploads/downloads in flight): every reader sees
+    every item exactly once, in order."""
+    exe = tmp_path / "pipe_sides"
+    host = os.path.join(ROOT, "leansdr_amd", "host")
+    lib = os.path.join(ROOT, "leansdr_amd")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", "-w", "-I", host, "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "host", "pipe_sides_test.cc"), "-o", str(exe), "-L", lib, "-llsdr_hip", f"-Wl,-rpath,{lib}"])
+    rng = np.random.default_rng(3)
+    n = 300000 + 17
+    x = (rng.integers(-1000, 1000, n) + 1j * rng.integers(-1000, 1000, n)).astype(np.complex64)
+    f3, f4 = tmp_path / "raw.bin", tmp_path / "x2.bin"
+    r = subprocess.run(f"{exe} {size} 3>{f3} 4>{f4}", shell=True, input=x.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-1500:]
+    half = np.frombuffer(r.stdout, np.complex64)
+    raw = np.frombuffer(f3.read_bytes(), np.complex64)
+    x2 = np.frombuffer(f4.read_bytes(), np.complex64)
+    assert len(raw) == len(x2) == len(half) == n
+    assert np.array_equal(raw, x) and np.array_equal(x2, x * 2) and np.array_equal(half, x * np.float32(0.5))

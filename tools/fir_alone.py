@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""tools/fir_alone.py — the C2 fir_filter launch alone (no receiver): ms per 64 Mi-sample batch, bit-exactness vs the oracle on a slice."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import leansdr_amd.capi as capi
+import bench
+import pyoracle as po
+ctx = capi.Ctx(0)
+coeffs, decim = bench.c2_filter(capi)
+n = 64 << 20
+rng = np.random.default_rng(0)
+blk = ((rng.standard_normal(1 << 22) + 1j * rng.standard_normal(1 << 22)) * 0.7).astype(np.complex64)
+d_in = ctx.alloc(n * 8); d_blk = ctx.upload(blk)
+for r in range(n // len(blk)):
+    capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * blk.nbytes), d_blk.ptr, blk.nbytes))
+ctx.sync()
+d_out = ctx.alloc(n // decim * 8 + 1024)
+f = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
+for _ in range(3):
+    cons, prod = f.run_dev(d_in.ptr, n, d_out.ptr, n // decim)
+ctx.sync()
+e0, e1 = ctx.event(), ctx.event()
+ctx.event_record(e0)
+for _ in range(20):
+    f.run_dev(d_in.ptr, n, d_out.ptr, n // decim)
+ctx.event_record(e1)
+ms = ctx.event_elapsed_ms(e0, e1) / 20
+y = ctx.download(d_out, np.complex64, 100000)
+O = po.Oracle()
+yr = O.fir_filter(coeffs, decim, O.scaler(75.0, np.tile(blk, 1)[:100000 * decim + len(coeffs)]))[0][:100000]
+print(f"LSDR_FIR_PERSIST={os.environ.get('LSDR_FIR_PERSIST','2')} lib={os.path.basename(capi.LIB_PATH)}: {ms:.4f} ms per 64 Mi samples = {(cons*8+prod*8)/ms/1e9:.2f} TB/s; bit-exact {y.tobytes()==yr.tobytes()}")
