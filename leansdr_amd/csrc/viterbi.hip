@@ -87,6 +87,12 @@ __device__ __forceinline__ int wave_min(int v) {
 
 constexpr int kVitWaves = 4;
 // One wavefront = one job.  Lane = trellis state.
+// TWO = the code has two branches per state (rate 1/2: the headline mode): the lane's two predecessors, their input bits and
+// the branch-by-label map live in registers, the two predecessors' metrics AND path registers are fetched together (six
+// independent ds_bpermute) and the survivor is a select — one LDS round trip per trellis step instead of the generic
+// path's chain of table read → shuffle → compare → table read → shuffle (≈ 900 cycles per step).  Same candidates, same
+// order, same `<=` tie rule as the generic path: bit-identical.
+template <bool TWO>
 __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   __shared__ vit_tables T;
   const int lane = threadIdx.x & 63;
@@ -111,6 +117,11 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   unsigned long long path;
   if (job.from_state >= 0) { cost = a.states_in[job.from_state].cost[lane]; path = a.states_in[job.from_state].path[lane]; }
   else { cost = 0; path = 0; }
+  // TWO: per-lane constants of the trellis
+  const int pred0 = T.pred[0][lane], pred1 = T.pred[1][lane];
+  const unsigned us0 = T.us[0][lane], us1 = T.us[1][lane];
+  const unsigned bl4 = (unsigned)T.by_label[0][lane] | ((unsigned)T.by_label[1][lane] << 8) | ((unsigned)T.by_label[2][lane] << 16) |
+                       ((unsigned)T.by_label[3][lane] << 24);
 
   for (long long q = -(long long)job.warm; q < (long long)job.n_chunks; ++q) {
     const unsigned long long c = (unsigned long long)((long long)job.first_chunk + q * (long long)job.chunk_step);
@@ -148,26 +159,39 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
       const int cost1 = __builtin_amdgcn_readlane(b < 64 ? my_cost[0] : my_cost[1], b & 63);
       // viterbi_dec::update(nm = 1), viterbi.h:202-260
       int best_m = 0x7fffffff, bk = 0;
-      {
-        const unsigned k1 = T.by_label[cs1][lane];
-        const unsigned kk = k1 == 255 ? 0u : k1;
-        const int pc = __shfl(cost, (int)T.pred[kk][lane], 64);
-        if (k1 != 255) { const int m = pc + cost1; if (m <= best_m) { best_m = m; bk = (int)k1; } }
+      if (TWO) {
+        const int c0 = __shfl(cost, pred0, 64), c1 = __shfl(cost, pred1, 64);
+        const unsigned lo0 = __shfl((unsigned)path, pred0, 64), hi0 = __shfl((unsigned)(path >> 32), pred0, 64);
+        const unsigned lo1 = __shfl((unsigned)path, pred1, 64), hi1 = __shfl((unsigned)(path >> 32), pred1, 64);
+        const unsigned k1 = (bl4 >> (8u * (cs1 & 3u))) & 255u;          // branch carrying the received label, 255 = none
+        if (k1 != 255u) { best_m = (k1 ? c1 : c0) + cost1; bk = (int)k1; }   // first candidate: always ≤ the initial maximum
+        if (c0 <= best_m) { best_m = c0; bk = 0; }
+        if (c1 <= best_m) { best_m = c1; bk = 1; }
+        const unsigned long long ps = bk ? ((unsigned long long)hi1 << 32 | lo1) : ((unsigned long long)hi0 << 32 | lo0);
+        path = ((ps << C.nbits) | (bk ? us1 : us0)) & pmask;
+        cost = best_m;
+      } else {
+        {
+          const unsigned k1 = T.by_label[cs1][lane];
+          const unsigned kk = k1 == 255 ? 0u : k1;
+          const int pc = __shfl(cost, (int)T.pred[kk][lane], 64);
+          if (k1 != 255) { const int m = pc + cost1; if (m <= best_m) { best_m = m; bk = (int)k1; } }
+        }
+        for (int k = 0; k < C.nus; ++k) {
+          const int m = __shfl(cost, (int)T.pred[k][lane], 64);
+          if (m <= best_m) { best_m = m; bk = k; }
+        }
+        const int bp = T.pred[bk][lane];
+        const unsigned lo = __shfl((unsigned)path, bp, 64), hi = __shfl((unsigned)(path >> 32), bp, 64);
+        path = ((((unsigned long long)hi << 32 | lo) << C.nbits) | T.us[bk][lane]) & pmask;
+        cost = best_m;
       }
-      for (int k = 0; k < C.nus; ++k) {
-        const int m = __shfl(cost, (int)T.pred[k][lane], 64);
-        if (m <= best_m) { best_m = m; bk = k; }
-      }
-      const int bp = T.pred[bk][lane];
-      const unsigned lo = __shfl((unsigned)path, bp, 64), hi = __shfl((unsigned)(path >> 32), bp, 64);
-      path = ((((unsigned long long)hi << 32 | lo) << C.nbits) | T.us[bk][lane]) & pmask;
-      cost = best_m;
       // output symbol of the best state (lowest index among the minima); skip the search when all agree
       unsigned sym_out = (unsigned)(path >> out_shift) & us_mask;
       int best_tpm = 0;
       bool have_best = false;
       if (emitting || want_q) {
-        const unsigned s0 = __shfl(sym_out, 0, 64);
+        const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sym_out);   // lane 0 is active: every lane of a job is
         const bool all_same = __all(sym_out == s0);
         if (!all_same || (want_q && b >= discr_delay)) {
           best_tpm = wave_min(cost);
@@ -316,7 +340,10 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
   a.njobs = (unsigned)up.size();
-  hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
+  if (a.C.nus == 2 && a.C.bits_out == 2 && !getenv("LSDR_VIT_GENERIC"))
+    hipLaunchKernelGGL(k_viterbi<true>, dim3((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
+  else
+    hipLaunchKernelGGL(k_viterbi<false>, dim3((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }
