@@ -298,19 +298,25 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
         if timed and use_fir:
             fir_ms.append(ctx.event_elapsed_ms(e0, e1))
 
+    stage_s = {"front": 0.0, "viterbi": 0.0, "mpeg_sync": 0.0, "rest": 0.0}
+
     def tail(keep):
+        t0 = time.perf_counter()
         while True:
             p_bytes.room(p_sym.n // 4 + 256)
             c, p = vit.run_dev(p_sym.rp(), p_sym.n, p_bytes.wr(), p_bytes.room(0))
             if not c and not p:
                 break
             p_sym.pop(c); p_bytes.push(p)
+        t1 = time.perf_counter()
         while True:
             p_mpeg.room(p_bytes.n + 4096)
             c, p, _, _, _ = msync.run_dev(p_bytes.rp(), p_bytes.n, p_mpeg.wr(), p_mpeg.room(0))
             if not c and not p:
                 break
             p_bytes.pop(c); p_mpeg.push(p)
+        t2 = time.perf_counter()
+        stage_s["viterbi"] += t1 - t0; stage_s["mpeg_sync"] += t2 - t1
         cons, prod = C.c_size_t(), C.c_size_t()
         capi.check(lib.lsdr_deinterleaver_run(ctx.h, p_mpeg.rp(), p_mpeg.n, d_rs.ptr, pk_cap, C.byref(cons), C.byref(prod)))
         p_mpeg.pop(cons.value)
@@ -341,11 +347,16 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     nb = 40
     t0 = time.perf_counter()
     npk = 0
+    for k in stage_s:
+        stage_s[k] = 0.0
     for _ in range(nb):
+        tf = time.perf_counter()
         front(True)
+        stage_s["front"] += time.perf_counter() - tf
         npk += tail(True)
     ctx.sync()
     dt = time.perf_counter() - t0
+    stage_s["rest"] = dt - stage_s["front"] - stage_s["viterbi"] - stage_s["mpeg_sync"]
     got = np.concatenate(ts_out) if ts_out else np.zeros((0, 188), np.uint8)
     # every packet must be the next one of the transmitted 8-packet cycle
     ok = bad = 0
@@ -361,6 +372,7 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
                symbols_per_s=round(nb * B / sps / dt / 1e6, 3), ts_packets=int(len(got)), ts_packets_per_s=round(len(got) / dt, 1),
                ts_check={"packets_equal_to_the_transmitted_sequence": ok, "different": bad, "pass": bool(bad == 0 and ok > 8)},
                vber=(errs[0] / bits[0] if bits[0] else None), viterbi=vit.stats(), rx_tiles=rx.tiled_stats(),
+               host_seconds_per_stage={k: round(v, 4) for k, v in stage_s.items()},
                mode="synchronous per batch (every FEC block returns data-dependent counts)")
     if use_fir and fir_ms:
         n_launch_out = n_out + bench.EXTRA

@@ -1,4 +1,5 @@
 // leansdr_amd/csrc/ctx.hip — context, device memory and stream timing of the C ABI.
+#include <cstring>
 #include "lsdr_internal.h"
 
 static thread_local char g_err[512] = "";
@@ -81,6 +82,8 @@ void lsdr_ctx_destroy(lsdr_ctx *c) {
   (void)hipEventDestroy(c->ev1);
   (void)hipFree(c->bounce);
   (void)hipFree(c->rs_tables); (void)hipFree(c->rs_counter);
+  if (c->stage_base) (void)hipHostFree(c->stage_base);
+  for (char *r : c->stage_retired) (void)hipHostFree(r);
   if (c->copy_ready) {
     (void)hipStreamSynchronize(c->up); (void)hipStreamSynchronize(c->down);
     (void)hipStreamDestroy(c->up); (void)hipStreamDestroy(c->down);
@@ -97,6 +100,57 @@ int lsdr_ctx_sync(lsdr_ctx *c) {
 }
 
 void *lsdr_ctx_stream(lsdr_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+}   // extern "C"
+
+// ---- pinned bounce arena (lsdr_internal.h)
+static int stage_reserve(lsdr_ctx *c, size_t bytes, char **slot) {
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (c->stage_used + need > c->stage_cap) {
+    // outgrown: copies in flight keep using the old arena (freed at the next sync); the new one is twice as large
+    size_t cap = c->stage_cap ? c->stage_cap * 2 : ((size_t)1 << 20);
+    while (cap < need) cap *= 2;
+    char *nb = nullptr;
+    LSDR_HIP(hipHostMalloc((void **)&nb, cap, hipHostMallocDefault));
+    if (c->stage_base) c->stage_retired.push_back(c->stage_base);
+    c->stage_base = nb; c->stage_cap = cap; c->stage_used = 0;
+  }
+  *slot = c->stage_base + c->stage_used;
+  c->stage_used += need;
+  return LSDR_OK;
+}
+int lsdr_stage_h2d(lsdr_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  char *slot;
+  { int rc = stage_reserve(c, bytes, &slot); if (rc) return rc; }
+  memcpy(slot, src_host, bytes);
+  LSDR_HIP(hipMemcpyAsync(dst_dev, slot, bytes, hipMemcpyHostToDevice, c->stream));
+  return LSDR_OK;
+}
+int lsdr_stage_d2h(lsdr_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
+  LSDR_ARG(c);
+  if (!bytes) return LSDR_OK;
+  char *slot;
+  { int rc = stage_reserve(c, bytes, &slot); if (rc) return rc; }
+  LSDR_HIP(hipMemcpyAsync(slot, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  c->stage_pending.push_back({dst_host, slot, bytes});
+  return LSDR_OK;
+}
+int lsdr_stage_sync(lsdr_ctx *c) {
+  LSDR_ARG(c);
+  const hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess)
+    for (const auto &p : c->stage_pending) memcpy(p.dst, p.src, p.bytes);
+  c->stage_pending.clear();
+  c->stage_used = 0;
+  for (char *r : c->stage_retired) (void)hipHostFree(r);
+  c->stage_retired.clear();
+  LSDR_HIP(e);
+  return LSDR_OK;
+}
+
+extern "C" {
 
 int lsdr_malloc(lsdr_ctx *c, size_t bytes, void **p) {
   LSDR_ARG(c && p);

@@ -18,6 +18,7 @@
 namespace {
 
 constexpr int kRS = 204, kTS = 188;
+constexpr size_t kMsyncSplitPackets = 128;   // locked runs at least this long take the chip-wide realign + bookkeeping split
 constexpr int kSync = 0x47, kSyncInv = 0xb8, kCorrupt = 0x55;
 
 __device__ __forceinline__ int par64(unsigned long long x) { return __popcll(x) & 1; }
@@ -332,6 +333,70 @@ __global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsign
   if (tid == 0) { R.consumed = pos; R.produced = nout; *gS = S; *gR = R; }
 }
 
+// Locked path for long inputs (dvb.h:842-875), split so that the byte work runs on the whole chip: while locked, bit phase
+// and polarity are constants, so every packet of the run can be realigned independently (k_msync_realign, also records
+// whether each packet's sync byte is the one the 8-packet phase counter predicts); k_msync_book then replays the
+// per-packet bookkeeping (locktime, lock_timeleft, phase8) over the flags and cuts the run where the reference would
+// have dropped the lock.  Bytes realigned past the cut are not part of the output (produced stops there).
+__global__ __launch_bounds__(256) void k_msync_realign(const msync_state *gS, const unsigned char *__restrict__ in,
+                                                       unsigned long long P, unsigned char *__restrict__ out,
+                                                       unsigned char *__restrict__ okflag) {
+  const int bitphase = gS->bitphase, phase8 = gS->phase8;
+  const unsigned polarity = gS->polarity;
+  const unsigned long long nbytes = P * kRS, nthreads = (unsigned long long)gridDim.x * 256;
+  const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  for (unsigned long long i = gid; i < nbytes; i += nthreads) out[i] = (unsigned char)(shift_byte(in + i, bitphase) ^ polarity);
+  for (unsigned long long p = gid; p < P; p += nthreads) {
+    const unsigned char b = (unsigned char)(shift_byte(in + p * kRS, bitphase) ^ polarity);
+    const unsigned char expected = ((phase8 + (int)(p & 7)) & 7) ? kSync : kSyncInv;
+    okflag[p] = b == expected;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_msync_book(msync_state *gS, const unsigned char *okflag, unsigned long long P,
+                                                   msync_result *gR) {
+  msync_state S = *gS;
+  msync_result R;
+  R.consumed = R.produced = 0; R.n_events = 0; R.call_next_sync = 0;
+  for (int k = 0; k < 4; ++k) R.events[k] = 0;
+  const int lane = threadIdx.x;
+  unsigned long long done = 0;
+  bool stop = false;
+  for (unsigned long long base = 0; base < P && !stop; base += 64) {
+    const unsigned long long left = P - base;
+    const unsigned n = left < 64 ? (unsigned)left : 64u;
+    const unsigned long long okmask = __ballot((unsigned)lane < n && okflag[base + lane]);
+    const unsigned long long full = n == 64 ? ~0ull : ((1ull << n) - 1);
+    if (okmask == full && S.lock_timeout > 1) {   // every sync byte as predicted: n packets counted, no lock decision
+      S.locktime += n;
+      S.phase8 = (S.phase8 + (int)n) & 7;
+      S.lock_timeleft = S.lock_timeout - 1;
+      done += n;
+      continue;
+    }
+    unsigned p = 0;
+    for (; p < n; ++p) {
+      ++S.locktime;
+      if ((okmask >> p) & 1ull) S.lock_timeleft = S.lock_timeout;
+      S.phase8 = (S.phase8 + 1) & 7;
+      --S.lock_timeleft;
+      if (!S.lock_timeleft) {
+        S.synchronized = 0;
+        S.next_sync_count = 0;
+        R.events[R.n_events++] = 0;
+        stop = true;
+        ++p;
+        break;
+      }
+    }
+    done += p;
+  }
+  if (lane == 0) {
+    R.consumed = R.produced = done * kRS;
+    *gS = S; *gR = R;
+  }
+}
+
 // ======================================================================== deinterleaver
 // out[p][j] = in[p*204 + 2244 + j − 12·17·((11 − j) mod 12)]   (dvb.h:935-940)
 __global__ __launch_bounds__(256) void k_deinterleave(const unsigned char *in, unsigned long long n_packets,
@@ -638,6 +703,8 @@ struct lsdr_mpeg_sync {
   msync_state st;             // host mirror (refreshed after every run)
   msync_state *d_state;
   msync_result *d_res;
+  unsigned char *d_ok;        // per-packet sync flags of the split locked path
+  size_t ok_cap;
   bool report_state;
 };
 
@@ -887,7 +954,7 @@ int lsdr_mpeg_sync_create(lsdr_ctx *c, int fastlock, lsdr_mpeg_sync **out) {
 void lsdr_mpeg_sync_destroy(lsdr_mpeg_sync *m) {
   if (!m) return;
   (void)hipStreamSynchronize(m->ctx->stream);
-  (void)hipFree(m->d_state); (void)hipFree(m->d_res);
+  (void)hipFree(m->d_state); (void)hipFree(m->d_res); if (m->d_ok) (void)hipFree(m->d_ok);
   delete m;
 }
 int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m) { return m ? m->st.synchronized : 0; }
@@ -918,8 +985,24 @@ int lsdr_mpeg_sync_run(lsdr_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_
   if (n_in >= need_in && cap_out >= need_out) {
     LSDR_ARG(in && out);
     lsdr_ctx *c = m->ctx;
-    hipLaunchKernelGGL(k_mpeg_sync, dim3(1), dim3(256), 0, c->stream, m->d_state, in, (unsigned long long)n_in, out,
-                       (unsigned long long)cap_out, m->d_res);
+    size_t P = (n_in - 1) / kRS;
+    if (P > cap_out / kRS) P = cap_out / kRS;
+    if (m->st.synchronized && P >= kMsyncSplitPackets) {
+      if (P > m->ok_cap) {
+        if (m->d_ok) LSDR_HIP(hipFree(m->d_ok));
+        m->d_ok = nullptr; m->ok_cap = 0;
+        LSDR_HIP(hipMalloc((void **)&m->d_ok, P + P / 2));
+        m->ok_cap = P + P / 2;
+      }
+      size_t blocks = (P * kRS + 256 * 16 - 1) / (256 * 16);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(k_msync_realign, dim3((unsigned)blocks), dim3(256), 0, c->stream, m->d_state, in,
+                         (unsigned long long)P, out, m->d_ok);
+      hipLaunchKernelGGL(k_msync_book, dim3(1), dim3(64), 0, c->stream, m->d_state, m->d_ok, (unsigned long long)P, m->d_res);
+    } else {
+      hipLaunchKernelGGL(k_mpeg_sync, dim3(1), dim3(256), 0, c->stream, m->d_state, in, (unsigned long long)n_in, out,
+                         (unsigned long long)cap_out, m->d_res);
+    }
     LSDR_HIP(hipGetLastError());
     msync_result r;
     LSDR_HIP(hipMemcpyAsync(&r, m->d_res, sizeof(r), hipMemcpyDeviceToHost, c->stream));

@@ -648,8 +648,8 @@ int lsdr_hsdeconv_run(lsdr_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t 
     hipLaunchKernelGGL(k_hsd_errors, dim3((unsigned)((n_resync * 32 + 255) / 256)), dim3(256), 0, c->stream, a,
                        (unsigned long long)n_resync);
     LSDR_HIP(hipGetLastError());
-    LSDR_HIP(hipMemcpyAsync(err.data(), d->d_err, err.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    LSDR_HIP(hipStreamSynchronize(c->stream));
+    LSDR_TRY(lsdr_stage_d2h(c, err.data(), d->d_err, err.size() * sizeof(int)));
+    LSDR_TRY(lsdr_stage_sync(c));
   }
   // alignment in force per chunk: `locked` changes after a resync chunk to the first arg-min of its error counts
   std::vector<unsigned char> lock_of(chunks);
@@ -664,7 +664,7 @@ int lsdr_hsdeconv_run(lsdr_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t 
       ++r;
     }
   }
-  LSDR_HIP(hipMemcpyAsync(d->d_lock, lock_of.data(), chunks, hipMemcpyHostToDevice, c->stream));
+  LSDR_TRY(lsdr_stage_h2d(c, d->d_lock, lock_of.data(), chunks));
   hipLaunchKernelGGL(k_hsd_decode, dim3((unsigned)((chunks * 16 + 255) / 256)), dim3(256), 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
   // carried deconv state (inI/inQ) of every alignment = remapped last 32 symbols of the last chunk IT processed:
@@ -688,7 +688,7 @@ int lsdr_hsdeconv_run(lsdr_hsdeconv *d, const uint8_t *in, size_t n_in, uint8_t 
     }
     if (last >= 0) { int rc = hist_of((size_t)last, s); if (rc) return rc; }
   }
-  LSDR_HIP(hipStreamSynchronize(c->stream));
+  LSDR_TRY(lsdr_stage_sync(c));
   d->locked = locked;
   d->resync_phase = (int)(((size_t)ph0 + chunks) % (size_t)P);
   *consumed = chunks * kDcSyms;

@@ -23,6 +23,12 @@ struct lsdr_ctx {
   // concurrently on their own streams)
   void *rs_tables;
   unsigned long long *rs_counter;
+  // Pinned bounce arena for per-call bookkeeping transfers (lsdr_stage_*): see below.
+  char *stage_base;
+  size_t stage_cap, stage_used;
+  struct stage_pend { void *dst; const char *src; size_t bytes; };
+  std::vector<stage_pend> stage_pending;   // D2H results to hand to their host destinations at the next lsdr_stage_sync
+  std::vector<char *> stage_retired;       // outgrown arenas, still referenced by copies in flight
 };
 
 struct lsdr_event {
@@ -39,6 +45,12 @@ int lsdr_hip_fail(hipError_t e, const char *what, const char *file, int line);
     if (e__ != hipSuccess) return lsdr_hip_fail(e__, #call, __FILE__, __LINE__); \
   } while (0)
 
+#define LSDR_TRY(call)                                                  \
+  do {                                                                  \
+    const int rc__ = (call);                                            \
+    if (rc__) return rc__;                                              \
+  } while (0)
+
 #define LSDR_ARG(cond)                                                  \
   do {                                                                  \
     if (!(cond)) {                                                      \
@@ -46,6 +58,18 @@ int lsdr_hip_fail(hipError_t e, const char *what, const char *file, int line);
       return LSDR_E_ARG;                                                \
     }                                                                   \
   } while (0)
+
+// Bookkeeping transfers between the compute stream and ordinary (pageable) host memory — job lists, per-tile states, totals.
+// hipMemcpyAsync on a pageable buffer of 128 KiB or more makes the runtime pin the caller's pages for the transfer; when that
+// buffer (a std::vector) is freed afterwards, the unmap invalidates the pinned range and the driver suspends and restores
+// every queue of the process: the next submission waits ~25 ms (measured: the 8PSK 2/3 chain ran 8x slower for it).  These
+// go through one pinned arena per context instead:
+//   lsdr_stage_h2d: the bytes are copied into the arena first, so `src_host` may be freed as soon as the call returns;
+//   lsdr_stage_d2h: lands in the arena; `dst_host` holds the bytes after the next lsdr_stage_sync;
+//   lsdr_stage_sync: hipStreamSynchronize(c->stream), then delivers every pending D2H and empties the arena.
+int lsdr_stage_h2d(lsdr_ctx *c, void *dst_dev, const void *src_host, size_t bytes);
+int lsdr_stage_d2h(lsdr_ctx *c, void *dst_host, const void *src_dev, size_t bytes);
+int lsdr_stage_sync(lsdr_ctx *c);
 
 // Host-side table builders (host_tables.cpp)
 namespace lsdr {

@@ -601,9 +601,9 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
   notch_launch(a->nslots, c->stream, (n_tiles + kNotchLanes - 1) / kNotchLanes, na);
   LSDR_HIP(hipGetLastError());
   std::vector<notch_est> hb(n_tiles), he(n_tiles);
-  LSDR_HIP(hipMemcpyAsync(hb.data(), a->d_begin, n_tiles * sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipMemcpyAsync(he.data(), a->d_end, n_tiles * sizeof(notch_est), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipStreamSynchronize(c->stream));
+  LSDR_TRY(lsdr_stage_d2h(c, hb.data(), a->d_begin, n_tiles * sizeof(notch_est)));
+  LSDR_TRY(lsdr_stage_d2h(c, he.data(), a->d_end, n_tiles * sizeof(notch_est)));
+  LSDR_TRY(lsdr_stage_sync(c));
   a->last_tiles += n_tiles;
   // seam verification
   unsigned first_bad = n_tiles;

@@ -79,10 +79,19 @@ struct vit_args {
   vit_state *chunk_states;           // optional [njobs][totals_stride]: state after every chunk (sparse decoders)
 };
 
+// Minimum over the 64 lanes, returned wave-uniform: DPP steps inside the rows of 16 (quad swaps, half mirror, mirror), two
+// row broadcasts, one v_readlane — all on the vector ALU.  (The xor-butterfly of six dependent ds_bpermute it replaces cost
+// ≈ 600 cycles; the best-state search runs whenever the survivors' oldest symbols disagree.)
 __device__ __forceinline__ int wave_min(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
-  return v;
+#define LSDR_DPP_MIN(ctrl, row_mask) { const int o__ = __builtin_amdgcn_update_dpp(v, v, ctrl, row_mask, 0xf, false); v = o__ < v ? o__ : v; }
+  LSDR_DPP_MIN(0xB1, 0xf)    // quad_perm [1,0,3,2]
+  LSDR_DPP_MIN(0x4E, 0xf)    // quad_perm [2,3,0,1]
+  LSDR_DPP_MIN(0x141, 0xf)   // row_half_mirror
+  LSDR_DPP_MIN(0x140, 0xf)   // row_mirror: every lane of a row holds the row's minimum
+  LSDR_DPP_MIN(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+  LSDR_DPP_MIN(0x143, 0xc)   // row_bcast:31 into rows 2 and 3: lane 63 holds the minimum of all
+#undef LSDR_DPP_MIN
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
 constexpr int kVitWaves = 4;
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
           have_best = true;
           const unsigned long long mask = __ballot(cost == best_tpm);
           const int best_state = __ffsll((long long)mask) - 1;
-          sym_out = __shfl(sym_out, best_state, 64);
+          sym_out = (unsigned)__builtin_amdgcn_readlane((int)sym_out, best_state);
           if (want_q && b >= discr_delay) {
             // second-best in the reference's scan = 2nd smallest with multiplicity (viterbi.h:246-251)
             const int second = __popcll(mask) > 1 ? best_tpm : wave_min(cost == best_tpm ? 0x7fffffff : cost);
@@ -326,10 +335,10 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   }
   std::vector<vit_job> up(jobs);
   if (!keep_slots) for (size_t i = 0; i < up.size(); ++i) up[i].slot = (unsigned)i;
-  LSDR_HIP(hipMemcpyAsync(v->d_jobs, up.data(), up.size() * sizeof(vit_job), hipMemcpyHostToDevice, c->stream));
-  LSDR_HIP(hipMemcpyAsync(v->d_states, v->states.data(), v->nsyncs * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
+  LSDR_TRY(lsdr_stage_h2d(c, v->d_jobs, up.data(), up.size() * sizeof(vit_job)));
+  LSDR_TRY(lsdr_stage_h2d(c, v->d_states, v->states.data(), v->nsyncs * sizeof(vit_state)));
   if (start_states)
-    LSDR_HIP(hipMemcpyAsync(v->d_fix, start_states->data(), start_states->size() * sizeof(vit_state), hipMemcpyHostToDevice, c->stream));
+    LSDR_TRY(lsdr_stage_h2d(c, v->d_fix, start_states->data(), start_states->size() * sizeof(vit_state)));
   vit_args a;
   a.in = in; a.out = out; a.T = v->d_T; a.C = v->C;
   a.bits_per_symbol = v->bits_per_symbol; a.nshifts = v->nshifts;
@@ -484,10 +493,11 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   const int cur = v->current_sync;
   {
     unsigned long long cstart = 0;
+    size_t ri = 0;                          // first resync chunk beyond cstart (both ascend)
     // first tile ends at the first resync chunk (or after TL chunks)
     while (cstart < chunks) {
-      unsigned long long next_rs = chunks;
-      for (unsigned long long r : rs) if (r > cstart) { next_rs = r; break; }
+      while (ri < rs.size() && rs[ri] <= cstart) ++ri;
+      const unsigned long long next_rs = ri < rs.size() ? rs[ri] : chunks;
       unsigned long long cend = cstart + TL;
       if (cend > next_rs) cend = next_rs;
       if (cend > chunks) cend = chunks;
@@ -511,9 +521,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   if (n_main > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream,
                                      (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
   std::vector<int> bad(n_main, 0), totals_main(n_main * stride);
-  LSDR_HIP(hipMemcpyAsync(bad.data(), v->d_bad, n_main * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipMemcpyAsync(totals_main.data(), v->d_totals, n_main * stride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-  LSDR_HIP(hipStreamSynchronize(c->stream));
+  LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_main * sizeof(int)));
+  LSDR_TRY(lsdr_stage_d2h(c, totals_main.data(), v->d_totals, n_main * stride * sizeof(int)));
+  LSDR_TRY(lsdr_stage_sync(c));
   v->last_tiles = (unsigned)n_main; v->last_bad = 0;
   // ---- fix-up rounds: a tile whose speculative start state differs from its predecessor's end state is decoded
   // again from that end state (read on the device from the slot array; results land in the tile's own slots); a changed
@@ -534,9 +544,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream, (const vit_state *)v->d_begin,
                        (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
-    LSDR_HIP(hipMemcpyAsync(bad.data(), v->d_bad, n_main * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    LSDR_HIP(hipMemcpyAsync(totals_main.data(), v->d_totals, n_main * stride * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    LSDR_HIP(hipStreamSynchronize(c->stream));
+    LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_main * sizeof(int)));
+    LSDR_TRY(lsdr_stage_d2h(c, totals_main.data(), v->d_totals, n_main * stride * sizeof(int)));
+    LSDR_TRY(lsdr_stage_sync(c));
   }
   // ---- last resort (seams that keep failing): everything from the first bad seam on, sequentially, from the previous
   // tile's end state (exact by construction).
@@ -549,8 +559,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     for (size_t j = first_bad; j < n_main; ++j) v->last_bad += bad[j] ? 1u : 0u;
     // keep results of tiles < first_bad; redo the rest as ONE sequential job starting from end_states[first_bad-1]
     std::vector<vit_state> ends(n_main);
-    LSDR_HIP(hipMemcpy(ends.data(), v->d_end, n_main * sizeof(vit_state), hipMemcpyDeviceToHost));
-    LSDR_HIP(hipMemcpy(main_first.data(), v->d_first, n_main * sizeof(vit_state), hipMemcpyDeviceToHost));
+    LSDR_TRY(lsdr_stage_d2h(c, ends.data(), v->d_end, n_main * sizeof(vit_state)));
+    LSDR_TRY(lsdr_stage_d2h(c, main_first.data(), v->d_first, n_main * sizeof(vit_state)));
+    LSDR_TRY(lsdr_stage_sync(c));
     std::vector<vit_state> keep = v->states;
     v->states[cur] = ends[first_bad - 1];
     vit_job j;
@@ -561,10 +572,10 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     if (rc) return rc;
     std::vector<int> tot(j.n_chunks);
     std::vector<vit_state> cst(j.n_chunks);
-    LSDR_HIP(hipMemcpyAsync(tot.data(), v->d_totals, j.n_chunks * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    LSDR_HIP(hipMemcpyAsync(cst.data(), v->d_chunk, j.n_chunks * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
-    LSDR_HIP(hipMemcpyAsync(&main_end, v->d_end, sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
-    LSDR_HIP(hipStreamSynchronize(c->stream));
+    LSDR_TRY(lsdr_stage_d2h(c, tot.data(), v->d_totals, j.n_chunks * sizeof(int)));
+    LSDR_TRY(lsdr_stage_d2h(c, cst.data(), v->d_chunk, j.n_chunks * sizeof(vit_state)));
+    LSDR_TRY(lsdr_stage_d2h(c, &main_end, v->d_end, sizeof(vit_state)));
+    LSDR_TRY(lsdr_stage_sync(c));
     v->states = keep;
     // splice the sequential results back into the per-tile bookkeeping
     for (size_t t = first_bad; t < n_main; ++t) {
@@ -619,14 +630,14 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       if (rc2) return rc2;
       std::vector<int> tot(oj.size() * ostride);
       std::vector<vit_state> hb(oj.size()), he(oj.size()), cst;
-      LSDR_HIP(hipMemcpyAsync(tot.data(), v->d_totals, tot.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-      LSDR_HIP(hipMemcpyAsync(hb.data(), v->d_begin, oj.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
-      LSDR_HIP(hipMemcpyAsync(he.data(), v->d_end, oj.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+      LSDR_TRY(lsdr_stage_d2h(c, tot.data(), v->d_totals, tot.size() * sizeof(int)));
+      LSDR_TRY(lsdr_stage_d2h(c, hb.data(), v->d_begin, oj.size() * sizeof(vit_state)));
+      LSDR_TRY(lsdr_stage_d2h(c, he.data(), v->d_end, oj.size() * sizeof(vit_state)));
       if (sequential) {
         cst.resize(oj.size() * ostride);
-        LSDR_HIP(hipMemcpyAsync(cst.data(), v->d_chunk, cst.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
+        LSDR_TRY(lsdr_stage_d2h(c, cst.data(), v->d_chunk, cst.size() * sizeof(vit_state)));
       }
-      LSDR_HIP(hipStreamSynchronize(c->stream));
+      LSDR_TRY(lsdr_stage_sync(c));
       for (size_t k = 0; k < oj.size(); ++k) {
         const int s = which[k];
         if (tile_first[k] == 0) { other_totals[s].assign(nrs, 0); other_states[s].clear(); other_ok[s] = 1; }
@@ -658,9 +669,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
           if (rc2) return rc2;
           std::vector<int> ftot(fj.size() * fstride);
           std::vector<vit_state> fe(fj.size());
-          LSDR_HIP(hipMemcpyAsync(ftot.data(), v->d_totals, ftot.size() * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-          LSDR_HIP(hipMemcpyAsync(fe.data(), v->d_end, fj.size() * sizeof(vit_state), hipMemcpyDeviceToHost, c->stream));
-          LSDR_HIP(hipStreamSynchronize(c->stream));
+          LSDR_TRY(lsdr_stage_d2h(c, ftot.data(), v->d_totals, ftot.size() * sizeof(int)));
+          LSDR_TRY(lsdr_stage_d2h(c, fe.data(), v->d_end, fj.size() * sizeof(vit_state)));
+          LSDR_TRY(lsdr_stage_sync(c));
           for (size_t i = 0; i < bad.size(); ++i) {
             const size_t k = bad[i];
             start_used[k] = starts[i];
@@ -682,10 +693,10 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       if (!redo.empty()) { rc = run_others(true, redo); if (rc) return rc; }
     }
     std::vector<vit_state> st = v->states;
+    size_t tj = 0;                          // tile holding resync chunk r: tiles and resync chunks both ascend
     for (size_t r = 0; r < rs.size(); ++r) {
       // alignment decision after this resync chunk (dvb.h:1401-1410): s ascending from best = current, strict '>'
-      size_t tj = 0;
-      for (size_t t = 0; t < n_main; ++t) if (jobs[t].first_chunk <= rs[r] && rs[r] < jobs[t].first_chunk + jobs[t].n_chunks) tj = t;
+      while (tj + 1 < n_main && jobs[tj + 1].first_chunk <= rs[r]) ++tj;
       const int tcur = totals_main[tj * stride + (unsigned)(rs[r] - jobs[tj].first_chunk)];
       int best = cur, bt = tcur;
       for (int s = 0; s < v->nsyncs; ++s) {

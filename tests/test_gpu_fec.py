@@ -134,6 +134,63 @@ def test_mpeg_sync_fastlock_and_garbage_vs_oracle(capi, ctx, oracle):
             assert bits_equal(got, want) and ev == st.tolist()
 
 
+def framed_bytes(rng, n_packets, phase8=0):
+    """n_packets RS-sized packets with the DVB sync pattern (0xB8 on every 8th, 0x47 otherwise) and random payload."""
+    pk = rng.integers(0, 256, (n_packets, 204)).astype(np.uint8)
+    pk[:, 0] = 0x47
+    pk[(8 - phase8) % 8::8, 0] = 0xB8
+    return pk
+
+
+def shift_bits(data, k):
+    """The byte stream delayed by k bits (what a hard-decision front end hands mpeg_sync when it starts mid-byte)."""
+    bits = np.unpackbits(data)
+    return np.packbits(np.concatenate([np.zeros(k, np.uint8), bits]))
+
+
+@pytest.mark.parametrize("bitshift,invert", [(0, False), (3, False), (5, True), (7, False)])
+def test_mpeg_sync_long_locked_runs_vs_oracle(capi, ctx, oracle, bitshift, invert):
+    """Locked runs far longer than one workgroup batch (the chip-wide realign + bookkeeping split): isolated sync misses,
+    three in a row (lock kept), four and more in a row (lock dropped mid-run, at offsets that are not multiples of 64),
+    a drop in the last packets of a call, then re-acquisition — bytes and lock events equal to the reference's."""
+    rng = np.random.default_rng(100 + bitshift)
+    pk = framed_bytes(rng, 6000)
+    for i in (70, 333, 2049):
+        pk[i, 0] ^= 0x10                              # isolated
+    pk[1000:1003, 0] ^= 0xff                          # three in a row
+    pk[2501:2505, 0] = 0                              # four: lock lost at 2504
+    pk[4000:4009, 0] = 0x11                           # nine
+    pk[5993:5999, 0] = 0x22                           # near the end of the stream
+    s = shift_bits(np.concatenate([rng.integers(0, 256, 777).astype(np.uint8), pk.reshape(-1)]), bitshift)
+    if invert:
+        s = s ^ np.uint8(0xff)
+    for fl in (0, 1):
+        want, st, _ = oracle.mpeg_sync(s, fl)
+        ms = capi.MpegSync(ctx, fl)
+        got, ev = ms.run_stream(s)
+        ms.close()
+        assert len(want) > 5000 * 204 and bits_equal(got, want) and ev == st.tolist()
+        # the same stream handed over in uneven pieces (each call sees what the previous ones left plus a new piece)
+        ms = capi.MpegSync(ctx, fl)
+        din = ctx.upload(s)
+        dout = ctx.alloc(len(s) + 4096)
+        pos = nout = avail = 0
+        ev2 = []
+        pieces = [100_000, 37, 204 * 129 + 1, 500_000, 204 * 128, 13, len(s)]
+        for piece in pieces:
+            avail = min(len(s), avail + piece)
+            while True:
+                c, p, e, _, _ = ms.run_dev(din.at(pos), avail - pos, dout.at(nout), len(s) + 4096 - nout)
+                ev2 += e
+                if not c and not p:
+                    break
+                pos += c; nout += p
+        got2 = ctx.download(dout, np.uint8, nout)
+        ms.close(); din.free(); dout.free()
+        # how the input is cut into calls changes nothing: a search waits until it has its scan window
+        assert bits_equal(got2, want) and ev2 == st.tolist()
+
+
 def test_rs_error_patterns(capi, ctx, oracle):
     g = gold("fec.npz")
     ts, bits, errs = capi.rs_decoder(ctx, g["rs_bad_in"])
