@@ -253,11 +253,11 @@ static int cfft_dev_run(lsdr_ctx *c, cfft_dev *f, const lsdr_cf32 *d_in, lsdr_cf
 
 // ---------------------------------------------------------------------------------------- throughput mode (LSDR_NOTCH_SCAN)
 // The per-slot recurrence  estim ← k·bb + (1−k)·estim  is a first-order linear recurrence with a CONSTANT pole a = 1−k,
-// i.e. a scan:  estim_i = L_i + a^(i+1)·carry,  L = the same recurrence started from zero.  One workgroup per 4096-sample
-// block (the block in which the slot phasors e_i restart, sdr.h:121): 16 consecutive samples per lane — a full 128-byte line
-// in, a full line out — local recurrence in registers with the reference's two roundings per step, then a wave scan with the
-// powers of a, the four wave totals through LDS, and the block's carry-in by decoupled look-back over the THREE preceding
-// blocks' zero-carry totals (a^4096 = 2.7e-4: the fourth is below float resolution), published through run-stamped flags
+// i.e. a scan:  estim_i = L_i + a^(i+1)·carry,  L = the same recurrence started from zero.  One wavefront per 1024-sample
+// wave-block, 16 consecutive samples per lane: the recurrence in registers with the reference's two roundings per step, a
+// wave scan with the powers of a, and the wave-block's carry-in by decoupled look-back over the TWELVE preceding
+// wave-blocks' zero-carry totals (a^4096 = 2.7e-4, a^12288 = 2e-11: older ones are below float resolution — the mode is
+// refused for a k that does not make it so), published through run-stamped flags
 // so that nothing has to be cleared between runs.  With several slots the passes repeat per slot on the residual of the
 // previous one, like sdr.h:124-134.  detect() (every `decimation` samples, sdr.h:66-70,76-118) stays on the device too:
 // all detect points of a run depend on the INPUT only, so their FFTs run batched up front (k_cfft), k_notch_peaks does the
@@ -266,7 +266,6 @@ static int cfft_dev_run(lsdr_ctx *c, cfft_dev *f, const lsdr_cf32 *d_in, lsdr_cf
 // (float)(2π·bin·i/4096) → cosf/sinf on the device (≤ 1 ulp from libm's).  Single pass: 8 B in + 8 B out per sample.
 // NOT bit-exact (the carry terms are re-associated; device cosf/sinf/hypotf): tolerance-tested against k_notch / the oracle.
 constexpr int kScanPer = 16;                 // samples per lane
-constexpr int kScanThreads = kN / kScanPer;  // 256
 
 struct notch_scan_consts {
   float k, omk, gain;
@@ -285,8 +284,8 @@ struct notch_scan_args {
   unsigned long long n_blocks;
   const notch_est *carry;          // estimators before block 0
   notch_est *carry_out;            // (last block) estimators after the last block → the next run's `carry`
-  float2 *totals;                  // [kMaxSlots][n_blocks] zero-carry block totals
-  unsigned *flags;                 // [kMaxSlots][n_blocks] run stamps
+  float2 *totals;                  // [kMaxSlots][4·n_blocks] zero-carry wave-block totals
+  unsigned *flags;                 // [kMaxSlots][4·n_blocks] run stamps
   unsigned stamp;
   notch_scan_consts C;
 };
@@ -314,34 +313,71 @@ __device__ __forceinline__ float2 scan_wait(const float2 *tot_slot, const unsign
   return v;
 }
 
+// One wavefront per 1024-sample wave-block (a 64-thread workgroup: nothing couples two wave-blocks but the look-back).
+//  - global traffic is coalesced (each instruction moves 1 KiB of consecutive samples) and turned into the lane-blocked
+//    register layout (16 consecutive samples per lane) through a padded LDS tile, both ways;
+//  - pass 1 runs the recurrence with zero carry to get the lane totals, a weighted wave scan gives the wave-block total,
+//    which is published; lanes 0..11 then each fetch one of the TWELVE preceding wave-block totals (a^12288 is below float
+//    resolution for the reference's k) and a butterfly sum gives the carry-in;
+//  - pass 2 re-runs the recurrence from the lane's carry-in — the reference's own sequential formula per lane — and
+//    subtracts est·e.  (Keeping pass 1's partial sums instead costs 32 VGPRs and an occupancy step.)
+constexpr int kWaveSamples = 64 * kScanPer;            // 1024
+constexpr int kWavesPerBlock = kN / kWaveSamples;      // 4 wave-blocks per 4096-sample FFT block
+constexpr int kLaneStride = kScanPer * 8 + 16;         // bytes between two lanes' chunks in the LDS tile (bank spread)
+constexpr int kLookBack = 12;
+
+__device__ __forceinline__ unsigned lds_off(unsigned n) { return n * 8u + (n >> 4) * 16u; }   // sample n of the wave-block
+
+__device__ __forceinline__ void wave_load_blocked(const float2 *__restrict__ g, float2 (&r)[kScanPer], char *lds, unsigned lane) {
+#pragma unroll
+  for (int i = 0; i < kScanPer / 2; ++i) {
+    const unsigned n = (unsigned)i * 128u + lane * 2u;
+    *reinterpret_cast<float4 *>(lds + lds_off(n)) = *reinterpret_cast<const float4 *>(g + n);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < kScanPer / 2; ++k) {
+    const float4 v = *reinterpret_cast<const float4 *>(lds + lane * kLaneStride + k * 16);
+    r[2 * k] = make_float2(v.x, v.y); r[2 * k + 1] = make_float2(v.z, v.w);
+  }
+  __syncthreads();
+}
+
 template <int NS>
-__global__ __launch_bounds__(kScanThreads) void k_notch_scan(notch_scan_args a) {
-  __shared__ float2 s_wave[NS][4];
-  __shared__ float2 s_carry[NS];
-  const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const unsigned long long b = blockIdx.x;
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 4 : 2))) void k_notch_scan(notch_scan_args a) {
+  __shared__ __attribute__((aligned(16))) char lds[64 * kLaneStride];
+  const unsigned lane = threadIdx.x;
+  const unsigned long long wb = blockIdx.x, n_wb = a.n_blocks * kWavesPerBlock;
+  const unsigned long long b = wb / kWavesPerBlock;
+  const unsigned part = (unsigned)(wb % kWavesPerBlock);
   // interval of this block (few intervals: linear search, wave-uniform)
   int q = 0;
   while (q + 1 < a.n_intervals && (unsigned long long)a.interval_first[q + 1] <= b) ++q;
-  const bool first_of_interval = (unsigned long long)a.interval_first[q] == b;
-  const float2 *pin = a.in + b * kN + (size_t)t * kScanPer;
-  float2 x[kScanPer], o[kScanPer];
-#pragma unroll
-  for (int j = 0; j < kScanPer; ++j) { x[j] = pin[j]; o[j] = x[j]; }
   const notch_scan_consts &C = a.C;
+  float2 x[kScanPer], o[NS > 1 ? kScanPer : 1];
+  wave_load_blocked(a.in + wb * kWaveSamples, x, lds, lane);
+  if (NS > 1) {
+#pragma unroll
+    for (int j = 0; j < kScanPer; ++j) o[NS > 1 ? j : 0] = x[j];
+  }
+  float pl = 1.f;                      // a^(16·lane) from the binary powers
+#pragma unroll
+  for (int m = 0; m < 6; ++m) if (lane & (1u << m)) pl *= C.apow16[m];
+  float wl = 1.f;                      // a^(1024·lane), lanes 0..11: the weight of the (lane+1)-th wave-block back
+  if (lane & 1u) wl *= C.a1024;
+  if (lane & 2u) wl *= C.a2048;
+  if (lane & 4u) wl *= C.a4096;
+  if (lane & 8u) wl *= C.a8192;
   // every slot filters the RAW input (sdr.h:126-128: bb from *pin); the slots' corrections are subtracted in slot order
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
-    const float2 *pe = a.tables + ((size_t)q * a.nslots + s) * kN + (size_t)t * kScanPer;
-    float2 e[kScanPer], L[kScanPer];
-#pragma unroll
-    for (int j = 0; j < kScanPer; ++j) e[j] = pe[j];
+    float2 e[kScanPer];
+    wave_load_blocked(a.tables + ((size_t)q * a.nslots + s) * kN + part * kWaveSamples, e, lds, lane);
     float2 run = make_float2(0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
       const float2 bb = make_float2(x[j].x * e[j].x + x[j].y * e[j].y, -x[j].x * e[j].y + x[j].y * e[j].x);   // x·conj(e)
       run = make_float2(bb.x * C.k + run.x * C.omk, bb.y * C.k + run.y * C.omk);
-      L[j] = run;
     }
     // inclusive scan of the lane totals across the wave: P_lane = Σ_{u ≤ lane} a^(16(lane−u))·T_u
     float2 P = run;
@@ -351,63 +387,56 @@ __global__ __launch_bounds__(kScanThreads) void k_notch_scan(notch_scan_args a) 
       const float ox = __shfl_up(P.x, d, 64), oy = __shfl_up(P.y, d, 64);
       if (lane >= (unsigned)d) { P.x += C.apow16[m] * ox; P.y += C.apow16[m] * oy; }
     }
-    if (lane == 63) s_wave[s][wv] = P;
-    __syncthreads();
-    // carry into this wave from the waves before it (zero block carry-in)
-    float2 cw = make_float2(0.f, 0.f);
-    for (unsigned v = 0; v < wv; ++v) cw = make_float2(cw.x * C.a1024 + s_wave[s][v].x, cw.y * C.a1024 + s_wave[s][v].y);
-    if (t == kScanThreads - 1) {
-      // zero-carry total of the block: publish, then look back
-      const float2 tot = make_float2(P.x + C.a1024 * cw.x, P.y + C.a1024 * cw.y);
-      scan_publish(a.totals + (size_t)s * a.n_blocks + b, a.flags + (size_t)s * a.n_blocks + b, tot, a.stamp);
-      float2 ein = make_float2(0.f, 0.f);
-      if (!(first_of_interval && a.reset[q * kMaxSlots + s])) {
-        // E_b = Tot_{b−1} + a^4096·(Tot_{b−2} + a^4096·Tot_{b−3}) … cut where an interval reset or the run's start intervenes
-        const float w[3] = {1.f, C.a4096, C.a8192};
-        bool open = true;
-        for (int back = 1; back <= 3 && open; ++back) {
-          if (b < (unsigned long long)back) {                  // before block 0: the carried estimators
-            ein.x += w[back - 1] * a.carry->re[s]; ein.y += w[back - 1] * a.carry->im[s];
-            break;
-          }
-          const unsigned long long pb = b - back;
-          const float2 pt = scan_wait(a.totals + (size_t)s * a.n_blocks + pb, a.flags + (size_t)s * a.n_blocks + pb, a.stamp);
-          ein.x += w[back - 1] * pt.x; ein.y += w[back - 1] * pt.y;
-          // a reset at block pb means nothing older reaches us
-          int qp = 0;
-          while (qp + 1 < a.n_intervals && (unsigned long long)a.interval_first[qp + 1] <= pb) ++qp;
-          if ((unsigned long long)a.interval_first[qp] == pb && a.reset[qp * kMaxSlots + s]) open = false;
-        }
-      }
-      s_carry[s] = ein;
-      if (b == a.n_blocks - 1) {       // estimators after the last block → next run (a separate buffer: blocks 0..2 read `carry`)
-        const float2 eo = make_float2(tot.x + C.a4096 * ein.x, tot.y + C.a4096 * ein.y);
-        a.carry_out->re[s] = eo.x; a.carry_out->im[s] = eo.y;
+    const float2 tot = make_float2(__shfl(P.x, 63, 64), __shfl(P.y, 63, 64));   // zero-carry total of the wave-block
+    float2 *tslot = a.totals + (size_t)s * n_wb;
+    unsigned *fslot = a.flags + (size_t)s * n_wb;
+    if (lane == 0) scan_publish(tslot + wb, fslot + wb, tot, a.stamp);
+    // Nothing older than the slot's latest restart (the first wave-block of an interval whose plan resets the slot) reaches
+    // this wave-block; before wave-block 0 stand the carried estimators.
+    long long restart = -2;
+    for (int qq = 0; qq <= q; ++qq)
+      if (a.reset[qq * kMaxSlots + s]) restart = (long long)a.interval_first[qq] * kWavesPerBlock;
+    float2 v = make_float2(0.f, 0.f);
+    if (lane < (unsigned)kLookBack) {
+      const long long pb = (long long)wb - 1 - (long long)lane;
+      if (pb >= 0 && pb >= restart) {
+        const float2 pt = scan_wait(tslot + pb, fslot + pb, a.stamp);
+        v = make_float2(wl * pt.x, wl * pt.y);
+      } else if (pb == -1 && restart < 0) {
+        v = make_float2(wl * a.carry->re[s], wl * a.carry->im[s]);
       }
     }
-    __syncthreads();
-    // carry into this lane: lanes before it in the wave, waves before it, block carry-in
-    float2 cl;
-    {
-      const float ox = __shfl_up(P.x, 1, 64), oy = __shfl_up(P.y, 1, 64);
-      cl = lane ? make_float2(ox, oy) : make_float2(0.f, 0.f);
-    }
-    float pl = 1.f;                    // a^(16·lane) from the binary powers
 #pragma unroll
-    for (int m = 0; m < 6; ++m) if (lane & (1u << m)) pl *= C.apow16[m];
-    const float pw = wv == 0 ? 1.f : (wv == 1 ? C.a1024 : (wv == 2 ? C.a2048 : C.a3072));
-    const float2 eb = s_carry[s];
-    const float2 cin = make_float2(cl.x + pl * cw.x + pl * pw * eb.x, cl.y + pl * cw.y + pl * pw * eb.y);
+    for (int d = 8; d >= 1; d >>= 1) { v.x += __shfl_xor(v.x, d, 64); v.y += __shfl_xor(v.y, d, 64); }
+    const float2 ein = make_float2(__shfl(v.x, 0, 64), __shfl(v.y, 0, 64));
+    if (wb == n_wb - 1 && lane == 0) {   // estimators after the last wave-block → next run (a separate buffer: the first ones read `carry`)
+      a.carry_out->re[s] = tot.x + C.a1024 * ein.x; a.carry_out->im[s] = tot.y + C.a1024 * ein.y;
+    }
+    // carry into this lane: the lanes before it, then the wave-block's carry-in
+    const float ox = __shfl_up(P.x, 1, 64), oy = __shfl_up(P.y, 1, 64);
+    run = lane ? make_float2(ox + pl * ein.x, oy + pl * ein.y) : ein;
 #pragma unroll
     for (int j = 0; j < kScanPer; ++j) {
-      const float2 est = make_float2(L[j].x + C.apow[j + 1] * cin.x, L[j].y + C.apow[j + 1] * cin.y);
-      const float2 sub = cmulf(est, e[j]);
-      o[j] = make_float2(o[j].x - sub.x, o[j].y - sub.y);
+      const float2 bb = make_float2(x[j].x * e[j].x + x[j].y * e[j].y, -x[j].x * e[j].y + x[j].y * e[j].x);
+      run = make_float2(bb.x * C.k + run.x * C.omk, bb.y * C.k + run.y * C.omk);
+      const float2 sub = cmulf(run, e[j]);
+      if (NS > 1) o[NS > 1 ? j : 0] = make_float2(o[NS > 1 ? j : 0].x - sub.x, o[NS > 1 ? j : 0].y - sub.y);
+      else x[j] = make_float2(x[j].x - sub.x, x[j].y - sub.y);
     }
   }
-  float2 *pout = a.out + b * kN + (size_t)t * kScanPer;
+  // lane-blocked registers → LDS → coalesced stores
 #pragma unroll
-  for (int j = 0; j < kScanPer; ++j) pout[j] = make_float2(C.gain * o[j].x, C.gain * o[j].y);
+  for (int k = 0; k < kScanPer / 2; ++k) {
+    const float2 p0 = NS > 1 ? o[NS > 1 ? 2 * k : 0] : x[2 * k], p1 = NS > 1 ? o[NS > 1 ? 2 * k + 1 : 0] : x[2 * k + 1];
+    *reinterpret_cast<float4 *>(lds + lane * kLaneStride + k * 16) = make_float4(C.gain * p0.x, C.gain * p0.y, C.gain * p1.x, C.gain * p1.y);
+  }
+  __syncthreads();
+  float2 *pout = a.out + wb * kWaveSamples;
+#pragma unroll
+  for (int i = 0; i < kScanPer / 2; ++i) {
+    const unsigned n = (unsigned)i * 128u + lane * 2u;
+    *reinterpret_cast<float4 *>(pout + n) = *reinterpret_cast<const float4 *>(lds + lds_off(n));
+  }
 }
 
 // peak search of detect() (sdr.h:94-117) on one spectrum per workgroup: amplitudes by hypotf, nslots rounds of
@@ -662,7 +691,7 @@ static int notch_process(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out
 // host synchronisation (the caller's consumed/produced are pure functions of the sizes).
 template <int NS>
 static void notch_scan_launch(hipStream_t st, unsigned grid, const notch_scan_args &a) {
-  hipLaunchKernelGGL(k_notch_scan<NS>, dim3(grid), dim3(kScanThreads), 0, st, a);
+  hipLaunchKernelGGL(k_notch_scan<NS>, dim3(grid * kWavesPerBlock), dim3(64), 0, st, a);
 }
 static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out, size_t nb) {
   lsdr_ctx *c = a->ctx;
@@ -707,9 +736,9 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
   if (a->blocks_cap < nb) {
     LSDR_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
-    LSDR_HIP(hipMalloc((void **)&a->d_totals, (size_t)kMaxSlots * nb * sizeof(float2)));
-    LSDR_HIP(hipMalloc((void **)&a->d_flags, (size_t)kMaxSlots * nb * sizeof(unsigned)));
-    LSDR_HIP(hipMemsetAsync(a->d_flags, 0, (size_t)kMaxSlots * nb * sizeof(unsigned), c->stream));
+    LSDR_HIP(hipMalloc((void **)&a->d_totals, (size_t)kMaxSlots * nb * kWavesPerBlock * sizeof(float2)));
+    LSDR_HIP(hipMalloc((void **)&a->d_flags, (size_t)kMaxSlots * nb * kWavesPerBlock * sizeof(unsigned)));
+    LSDR_HIP(hipMemsetAsync(a->d_flags, 0, (size_t)kMaxSlots * nb * kWavesPerBlock * sizeof(unsigned), c->stream));
     a->blocks_cap = nb;
     a->stamp = 0;
   }
@@ -757,6 +786,10 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     for (int m = 0; m < 7; ++m) sa.C.apow16[m] = (float)pow(av, 16.0 * (1 << m));
     sa.C.a1024 = (float)pow(av, 1024); sa.C.a2048 = (float)pow(av, 2048); sa.C.a3072 = (float)pow(av, 3072);
     sa.C.a4096 = (float)pow(av, 4096); sa.C.a8192 = (float)pow(av, 8192); sa.C.a12288 = (float)pow(av, 12288);
+    if (!(sa.C.a12288 < 1e-8f)) {
+      lsdr_set_error("auto_notch: LSDR_NOTCH_SCAN looks 12288 samples back; k=%g leaves (1-k)^12288=%g of older input (use LSDR_NOTCH_EXACT)", (double)a->k, (double)sa.C.a12288);
+      return LSDR_E_UNSUPPORTED;
+    }
   }
   sa.carry_out = a->d_scarry[nxt];   // … written by the last block
   switch (ns) {

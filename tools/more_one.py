@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""tools/more_one.py NAME [NAME...] — run single secondary configurations of bench_more (anf1, c3, c5_rescoped, ...) with
+bench.py's default geometry and print each result as JSON."""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import leansdr_amd.capi as capi
+from leansdr_amd import synth
+import bench_more
+a = argparse.Namespace(batch_msamples=64, period_msamples=4, tile_len=256, tile_warmup=256, batches_per_step=96, steps=20, no_verify=True,
+                       rx_cus=0, cu_pattern="xcd_major", captures=4)
+for name in sys.argv[1:]:
+    r = getattr(bench_more, name)(capi, synth, 0, a)
+    r.pop("trace", None)
+    print(name, json.dumps(r), flush=True)
