@@ -216,27 +216,29 @@ class DevPipe:
         self.buf.free()
 
 
-def framed_period(capi, ctx, cstln, rate, sps, snr_db, seed):
-    """One period (8 TS packets: the energy-dispersal cycle) of circular DVB-S baseband at `sps` samples/symbol, unit RMS,
-    from this repo's GPU transmit chain (randomizer → RS → interleaver → convolutional coder → mapper → RRC interpolator);
-    the stream is run until the interleaver and the filters are in steady state and one period is cut out."""
+def framed_period(capi, ctx, cstln, rate, sps, snr_db, seed, decim=1, groups=1):
+    """One period (8·groups TS packets: whole energy-dispersal cycles) of circular DVB-S baseband at `sps`/`decim` samples per
+    symbol, unit RMS, from this repo's GPU transmit chain (randomizer → RS → interleaver → convolutional coder → mapper → RRC
+    interpolator → decimator); the stream is run until the interleaver and the filters are in steady state and one period is
+    cut out.  `groups` makes the period a whole number of samples when `decim` > 1."""
     from leansdr_amd import synth_dvbs
-    ts8 = synth_dvbs.ts_packets(8)
+    ts8 = synth_dvbs.ts_packets(8 * groups)
     periods = 10
-    tx = capi.TxChain(ctx, interp=sps, amp=1.0, cstln=cstln, rate=rate)
+    tx = capi.TxChain(ctx, interp=sps, decim=decim, amp=1.0, cstln=cstln, rate=rate)
     y = tx.run(np.tile(ts8, (periods, 1)))
     tx.close()
     bits_in, bits_out = C.c_int(), C.c_int()
     capi.check(capi.lib.lsdr_fec_spec(capi.FEC46 if (rate == capi.FEC23 and capi.CSTLN_BITS[cstln] in (2, 6)) else rate,
                                       C.byref(bits_in), C.byref(bits_out), None))
-    nsym = 8 * 204 * 8 * bits_out.value // bits_in.value // capi.CSTLN_BITS[cstln]
-    P = nsym * sps
+    nsym = 8 * groups * 204 * 8 * bits_out.value // bits_in.value // capi.CSTLN_BITS[cstln]
+    assert (nsym * sps) % decim == 0
+    P = nsym * sps // decim
     assert len(y) >= 7 * P, (len(y), P)
     a, b = y[5 * P:6 * P], y[6 * P:7 * P]
     assert np.allclose(a, b, atol=1e-4 * np.abs(a).max()), "transmit chain not periodic"
     x = a / np.sqrt(np.mean(np.abs(a) ** 2))
     rng = np.random.default_rng(seed)
-    nstd = np.sqrt(0.5 * sps / (10 ** (snr_db / 10)))
+    nstd = np.sqrt(0.5 * (sps / decim) / (10 ** (snr_db / 10)))
     x = x + (rng.standard_normal(P) + 1j * rng.standard_normal(P)) * nstd
     x = x / np.sqrt(1 + 2 * nstd ** 2)
     return x.astype(np.complex64), ts8
@@ -404,6 +406,114 @@ def c5_rescoped(capi, synth, device, args):
                       "8PSK 2/3 @ 4 sps cf32 (30 MS/s symbols = 120 MS/s input): cstln_receiver(PSK8, tiled) -> viterbi_sync(2/3) -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer")
 
 
+def c1_hs(capi, synth, device, args):
+    """BASELINE config 1's shape, device-resident, on the reference's own "maximum throughput" receiver:
+    cu8 IQ at 1.2 samples/symbol (2 B/sample) → fast_qpsk_receiver<u8> (tiled) → dvb_deconvol_sync<u8> → mpeg_sync →
+    deinterleaver → rs_decoder → derandomizer, TS checked against the transmitted packet sequence."""
+    lib = capi.lib
+    ctx = capi.Ctx(device)
+    groups = 5
+    x, ts = framed_period(capi, ctx, capi.QPSK, capi.FEC12, 6, 20.0, seed=5, decim=5, groups=groups)
+    P = len(x)
+    u8 = capi.cconv_f32_u8(ctx, x * np.float32(75.0)).reshape(-1)          # leanchansim --ou8: amplitude 75 around 128
+    reps = max(1, (64 << 20) // P)
+    B = P * reps
+    extra = 8192
+    d_in = ctx.alloc((B + 2 * P + extra) * 2)
+    dp = ctx.upload(u8)
+    for r in range(reps + 2):
+        capi.check(lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * P * 2), dp.ptr, P * 2))
+    capi.check(lib.lsdr_memcpy_d2d(ctx.h, d_in.at((reps + 2) * P * 2), dp.ptr, extra * 2))
+    ctx.sync(); dp.free()
+    rx = capi.FastQpsk(ctx, 1.2)
+    dec = capi.HsDeconv(ctx)
+    msync = capi.MpegSync(ctx)
+    derand = capi.Derandomizer(ctx)
+    sym_cap = int(B / 1.2 * 1.05) + 65536
+    p_sym = DevPipe(capi, ctx, 1, 2 * sym_cap)
+    p_bytes = DevPipe(capi, ctx, 1, sym_cap // 4)
+    p_mpeg = DevPipe(capi, ctx, 1, sym_cap // 4)
+    pk_cap = sym_cap // 8 // 204 + 64
+    d_rs, d_rts, d_ts = ctx.alloc(pk_cap * 204), ctx.alloc(pk_cap * 188), ctx.alloc(pk_cap * 188)
+    ts_out, bits, errs = [], [0], [0]
+    pos = [0]
+    stage_s = {"receiver": 0.0, "deconvol": 0.0, "mpeg_sync": 0.0, "rest": 0.0}
+
+    def batch(keep, n=None):
+        t0 = time.perf_counter()
+        p_sym.room(sym_cap)
+        c, p = rx.run_dev(d_in.at(pos[0] * 2), (n or B) + extra, p_sym.wr(), p_sym.room(0))
+        assert c > 0
+        pos[0] = (pos[0] + c) % P
+        p_sym.push(p)
+        t1 = time.perf_counter()
+        while True:
+            p_bytes.room(p_sym.n // 8 + 256)
+            c2, p2 = dec.run_dev(p_sym.rp(), p_sym.n, p_bytes.wr(), p_bytes.room(0))
+            if not p2:
+                break
+            p_sym.pop(c2); p_bytes.push(p2)
+        t2 = time.perf_counter()
+        while True:
+            p_mpeg.room(p_bytes.n + 4096)
+            c3_, p3, _, _, _ = msync.run_dev(p_bytes.rp(), p_bytes.n, p_mpeg.wr(), p_mpeg.room(0))
+            if not c3_ and not p3:
+                break
+            p_bytes.pop(c3_); p_mpeg.push(p3)
+        t3 = time.perf_counter()
+        stage_s["receiver"] += t1 - t0; stage_s["deconvol"] += t2 - t1; stage_s["mpeg_sync"] += t3 - t2
+        cons, prod = C.c_size_t(), C.c_size_t()
+        capi.check(lib.lsdr_deinterleaver_run(ctx.h, p_mpeg.rp(), p_mpeg.n, d_rs.ptr, pk_cap, C.byref(cons), C.byref(prod)))
+        p_mpeg.pop(cons.value)
+        npk = prod.value
+        if npk:
+            b, e = C.c_long(), C.c_long()
+            capi.check(lib.lsdr_rs_decoder_run(ctx.h, d_rs.ptr, npk, d_rts.ptr, C.byref(b), C.byref(e)))
+            bits[0] += b.value; errs[0] += e.value
+            cc, pp = C.c_size_t(), C.c_size_t()
+            capi.check(lib.lsdr_derandomizer_run(derand.h, d_rts.ptr, npk, d_ts.ptr, pk_cap, C.byref(cc), C.byref(pp)))
+            if keep and pp.value:
+                ts_out.append(ctx.download(d_ts, np.uint8, pp.value * 188).reshape(-1, 188).copy())
+        return c
+
+    batch(False, n=1 << 20)            # acquisition: the exact serial loop on the head of the stream
+    rx.set_tiled(1, 0, 0)
+    for _ in range(2):
+        batch(False)
+    nb = 12
+    for k in stage_s:
+        stage_s[k] = 0.0
+    t0 = time.perf_counter()
+    consumed = 0
+    for _ in range(nb):
+        consumed += batch(True)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    stage_s["rest"] = dt - sum(stage_s.values())
+    got = np.concatenate(ts_out) if ts_out else np.zeros((0, 188), np.uint8)
+    ok = bad = 0
+    if len(got):
+        first = [k for k in range(len(ts)) if bytes(ts[k]) == bytes(got[0])]
+        ph = first[0] if first else 0
+        for i, t in enumerate(got):
+            if bytes(t) == bytes(ts[(ph + i) % len(ts)]):
+                ok += 1
+            else:
+                bad += 1
+    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3),
+               chain="QPSK 1/2 @ 1.2 sps cu8 (2 B/sample): fast_qpsk_receiver<u8>(tiled) -> dvb_deconvol_sync<u8> -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
+               symbols_per_s=round(consumed / 1.2 / dt / 1e6, 3), ts_packets=int(len(got)), ts_packets_per_s=round(len(got) / dt, 1),
+               ts_check={"packets_equal_to_the_transmitted_sequence": ok, "different": bad, "pass": bool(bad == 0 and ok > 8)},
+               rs_byte_errors_corrected=errs[0], rx_tiles=rx.tiled_stats(), host_seconds_per_stage={k: round(v, 4) for k, v in stage_s.items()},
+               cpu_reference_one_core_MSps=29.7, mode="synchronous per batch (every block returns data-dependent counts)")
+    for p_ in (p_sym, p_bytes, p_mpeg):
+        p_.free()
+    for d in (d_in, d_rs, d_rts, d_ts):
+        d.free()
+    rx.close(); dec.close(); msync.close(); derand.close(); ctx.close()
+    return out
+
+
 def exact_batch(capi, synth, device, args):
     import bench
     po = bench._oracle()
@@ -509,7 +619,7 @@ def end_to_end(capi, synth, device, args):
 def run_all(capi, synth, device, args):
     more = {}
     for name, fn in (("single_stream", single_stream), ("anf1", anf1), ("c2_offset", c2_offset), ("c2_fma", c2_fma), ("c3", c3),
-                     ("c5_rescoped", c5_rescoped), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
+                     ("c5_rescoped", c5_rescoped), ("c1_hs", c1_hs), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
         t0 = time.perf_counter()
         try:
             more[name] = fn(capi, synth, device, args)

@@ -855,6 +855,13 @@ class FastQpsk:
         check(lib.lsdr_fastqpsk_get_state(self.h, C.byref(mu), C.byref(ph), C.byref(fw), C.byref(mn), C.byref(mx)))
         return dict(mu=mu.value, phase=ph.value, freqw=fw.value, min_freqw=mn.value, max_freqw=mx.value)
 
+    def run_dev(self, in_ptr, n_in, out_ptr, cap):
+        """Device pointers (cu8 in, one hard symbol per byte out); no FREQ/constellation reports.  → (consumed, produced)."""
+        cons, prod, nf, nc = c_sz(), c_sz(), c_sz(), c_sz()
+        check(lib.lsdr_fastqpsk_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod), None, 0, C.byref(nf), None, 0,
+                                    C.byref(nc)))
+        return cons.value, prod.value
+
     def run(self, iq_u8, meas=True):
         """Upload interleaved u8 I/Q, run once, download.  Returns dict(sym, consumed, freq, cstln)."""
         iq = np.ascontiguousarray(iq_u8, np.uint8)
@@ -888,6 +895,11 @@ class HsDeconv:
     @property
     def locked(self):
         return lib.lsdr_hsdeconv_locked(self.h)
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap):
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_hsdeconv_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
 
     def run_stream(self, symbols, pipe=None, room=None):
         sym = np.ascontiguousarray(symbols, np.uint8)
