@@ -488,7 +488,15 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
 
   // ---- jobs.  Current alignment: tiles of TL chunks (each starting kWarm chunks early) so that every
   // resync chunk is the FIRST chunk of a tile; other alignments: one sequential job each over the resync chunks.
-  const unsigned TL = P >= 8 ? 8u : (unsigned)P;   // tile length divides the resync period when P ≥ 8
+  unsigned TL = P >= 8 ? 8u : (unsigned)P;   // tile length divides the resync period when P ≥ 8
+  // Short inputs: shorter tiles put more wavefronts on an otherwise idle chip (a tile is one wavefront walking
+  // (kWarm + TL)·128 trellis steps; the output does not depend on the tiling).  Aim at two wavefronts per SIMD.
+  {
+    static const int forced = getenv("LSDR_VIT_TL") ? atoi(getenv("LSDR_VIT_TL")) : 0;   // tuning hook
+    const size_t want = (size_t)c->num_cu * 4 * 2;
+    if (forced > 0) TL = (unsigned)forced;
+    else while (TL > 1 && TL % 2 == 0 && chunks / TL < want) TL /= 2;
+  }
   std::vector<vit_job> jobs;
   const int cur = v->current_sync;
   {
@@ -513,16 +521,63 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     }
   }
   const size_t n_main = jobs.size();
+  // The other alignments decode only the resync chunks (stride P), each from its own carried state.  Their "virtual
+  // stream" is tiled and verified like the main one; their tiles ride in the SAME launch as the main tiles (nothing in
+  // them depends on the main alignment's results), after the main slots.
+  const bool have_others = !rs.empty() && v->nsyncs > 1;
+  const unsigned TLo = 4;
+  const unsigned Wo = getenv("LSDR_VIT_WO") ? (unsigned)atoi(getenv("LSDR_VIT_WO")) : (unsigned)kWarm;   // tuning hook
+  const unsigned nrs = (unsigned)rs.size();
+  struct other_jobs { std::vector<vit_job> oj; std::vector<int> which, tile_first; unsigned ostride; };   // tile_first: index into rs
+  auto build_others = [&](bool sequential, const std::vector<int> &only) {
+    other_jobs J;
+    for (int s : only) {
+      if (sequential) {
+        vit_job j;
+        j.first_chunk = rs[0]; j.n_chunks = nrs; j.warm = 0; j.sync = s; j.from_state = s; j.emit = 0; j.chunk_step = (unsigned)P;
+        J.oj.push_back(j); J.which.push_back(s); J.tile_first.push_back(0);
+      } else {
+        unsigned r0 = 0;
+        while (r0 < nrs) {
+          unsigned r1 = r0 + TLo;
+          if (r0 == 0 && r1 < Wo + TLo) r1 = Wo + TLo;   // tile 0 is long enough for tile 1 to warm up fully
+          if (r1 > nrs) r1 = nrs;
+          vit_job j;
+          j.first_chunk = rs[r0]; j.n_chunks = r1 - r0; j.warm = r0 == 0 ? 0u : Wo; j.sync = s;
+          j.from_state = r0 == 0 ? s : -1; j.emit = 0; j.chunk_step = (unsigned)P;
+          J.oj.push_back(j); J.which.push_back(s); J.tile_first.push_back((int)r0);
+          r0 = r1;
+        }
+      }
+    }
+    J.ostride = 1;
+    for (auto &j : J.oj) if (j.n_chunks > J.ostride) J.ostride = j.n_chunks;
+    return J;
+  };
+  std::vector<int> all_others;
+  if (have_others) for (int s = 0; s < v->nsyncs; ++s) if (s != cur) all_others.push_back(s);
+  other_jobs first_others = build_others(false, all_others);
+  const size_t n_first = first_others.oj.size();
   unsigned stride = 1;
   for (auto &j : jobs) if (j.n_chunks > stride) stride = j.n_chunks;
-  int rc = vit_launch(v, in, out, jobs, stride, false, phase0);
+  if (n_first && first_others.ostride > stride) stride = first_others.ostride;
+  std::vector<vit_job> launch_jobs(jobs);
+  launch_jobs.insert(launch_jobs.end(), first_others.oj.begin(), first_others.oj.end());
+  int rc = vit_launch(v, in, out, launch_jobs, stride, false, phase0);
   if (rc) return rc;
   LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
   if (n_main > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream,
                                      (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
   std::vector<int> bad(n_main, 0), totals_main(n_main * stride);
+  std::vector<int> first_tot(n_first * stride);
+  std::vector<vit_state> first_hb(n_first), first_he(n_first);
   LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_main * sizeof(int)));
   LSDR_TRY(lsdr_stage_d2h(c, totals_main.data(), v->d_totals, n_main * stride * sizeof(int)));
+  if (n_first) {
+    LSDR_TRY(lsdr_stage_d2h(c, first_tot.data(), v->d_totals + n_main * stride, n_first * stride * sizeof(int)));
+    LSDR_TRY(lsdr_stage_d2h(c, first_hb.data(), v->d_begin + n_main, n_first * sizeof(vit_state)));
+    LSDR_TRY(lsdr_stage_d2h(c, first_he.data(), v->d_end + n_main, n_first * sizeof(vit_state)));
+  }
   LSDR_TRY(lsdr_stage_sync(c));
   v->last_tiles = (unsigned)n_main; v->last_bad = 0;
   // ---- fix-up rounds: a tile whose speculative start state differs from its predecessor's end state is decoded
@@ -539,7 +594,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       }
     if (fj.empty()) break;
     v->last_bad += (unsigned)fj.size();
-    rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_main);
+    rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_main + n_first);
     if (rc) return rc;
     LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
     hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream, (const vit_state *)v->d_begin,
@@ -595,85 +650,50 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   std::vector<std::vector<int> > other_totals(v->nsyncs);
   std::vector<vit_state> other_end(v->nsyncs);
   std::vector<int> other_ok(v->nsyncs, 1);
-  if (!rs.empty() && v->nsyncs > 1) {
-    // The other alignments decode only the resync chunks (stride P), each from its own carried state.  Their
-    // "virtual stream" is tiled and verified exactly like the main one; a decoder whose seams do not verify
-    // (wrong alignments see noise-like input, survivors may merge slowly) is redone sequentially.
-    const unsigned TLo = 4;
-    const unsigned Wo = getenv("LSDR_VIT_WO") ? (unsigned)atoi(getenv("LSDR_VIT_WO")) : (unsigned)kWarm;   // tuning hook
-    const unsigned nrs = (unsigned)rs.size();
-    auto run_others = [&](bool sequential, std::vector<int> only) -> int {
-      std::vector<vit_job> oj;
-      std::vector<int> which, tile_first;   // tile_first: index into rs of the tile's first chunk
-      for (int s : only) {
-        if (sequential) {
-          vit_job j;
-          j.first_chunk = rs[0]; j.n_chunks = nrs; j.warm = 0; j.sync = s; j.from_state = s; j.emit = 0; j.chunk_step = (unsigned)P;
-          oj.push_back(j); which.push_back(s); tile_first.push_back(0);
-        } else {
-          unsigned r0 = 0;
-          while (r0 < nrs) {
-            unsigned r1 = r0 + TLo;
-            if (r0 == 0 && r1 < Wo + TLo) r1 = Wo + TLo;   // tile 0 is long enough for tile 1 to warm up fully
-            if (r1 > nrs) r1 = nrs;
-            vit_job j;
-            j.first_chunk = rs[r0]; j.n_chunks = r1 - r0; j.warm = r0 == 0 ? 0u : Wo; j.sync = s;
-            j.from_state = r0 == 0 ? s : -1; j.emit = 0; j.chunk_step = (unsigned)P;
-            oj.push_back(j); which.push_back(s); tile_first.push_back((int)r0);
-            r0 = r1;
-          }
-        }
-      }
-      unsigned ostride = 1;
-      for (auto &j : oj) if (j.n_chunks > ostride) ostride = j.n_chunks;
-      int rc2 = vit_launch(v, in, out, oj, ostride, sequential, phase0, nullptr, nullptr, false, 0, false);
-      if (rc2) return rc2;
-      std::vector<int> tot(oj.size() * ostride);
-      std::vector<vit_state> hb(oj.size()), he(oj.size()), cst;
-      LSDR_TRY(lsdr_stage_d2h(c, tot.data(), v->d_totals, tot.size() * sizeof(int)));
-      LSDR_TRY(lsdr_stage_d2h(c, hb.data(), v->d_begin, oj.size() * sizeof(vit_state)));
-      LSDR_TRY(lsdr_stage_d2h(c, he.data(), v->d_end, oj.size() * sizeof(vit_state)));
-      if (sequential) {
-        cst.resize(oj.size() * ostride);
-        LSDR_TRY(lsdr_stage_d2h(c, cst.data(), v->d_chunk, cst.size() * sizeof(vit_state)));
-      }
-      LSDR_TRY(lsdr_stage_sync(c));
+  if (have_others) {
+    // A decoder whose seams do not verify (wrong alignments see noise-like input, survivors may merge slowly) is redone
+    // sequentially.  `finish_others` takes the downloaded results of a launch of J's jobs (per-chunk totals with row
+    // stride `tstride`, begin/end states per job, per-chunk states of a sequential launch).
+    auto finish_others = [&](bool sequential, const other_jobs &J, const std::vector<int> &tot, unsigned tstride,
+                             const std::vector<vit_state> &hb, std::vector<vit_state> he, const std::vector<vit_state> &cst) -> int {
+      const std::vector<vit_job> &oj = J.oj;
+      const std::vector<int> &which = J.which, &tile_first = J.tile_first;
       for (size_t k = 0; k < oj.size(); ++k) {
         const int s = which[k];
         if (tile_first[k] == 0) { other_totals[s].assign(nrs, 0); other_states[s].clear(); other_ok[s] = 1; }
-        for (unsigned q = 0; q < oj[k].n_chunks; ++q) other_totals[s][tile_first[k] + q] = tot[k * ostride + q];
-        if (sequential) other_states[s].assign(cst.begin() + k * ostride, cst.begin() + k * ostride + nrs);
+        for (unsigned q = 0; q < oj[k].n_chunks; ++q) other_totals[s][tile_first[k] + q] = tot[k * tstride + q];
+        if (sequential) other_states[s].assign(cst.begin() + k * tstride, cst.begin() + k * tstride + nrs);
       }
       if (!sequential) {
         // fix-up rounds: a tile whose speculative start state differs from its predecessor's true end state is
         // re-decoded from that end state; a changed end state propagates to the next seam in the next round.
         std::vector<vit_state> start_used = hb;
         for (int round = 0;; ++round) {
-          std::vector<size_t> bad;
+          std::vector<size_t> badk;
           for (size_t k = 0; k < oj.size(); ++k)
-            if (tile_first[k] != 0 && memcmp(&start_used[k], &he[k - 1], sizeof(vit_state)) != 0) bad.push_back(k);
-          if (bad.empty()) break;
-          v->last_bad += (unsigned)bad.size();
-          if (round >= 6) { for (size_t k : bad) other_ok[which[k]] = 0; break; }   // pathological: sequential fallback
+            if (tile_first[k] != 0 && memcmp(&start_used[k], &he[k - 1], sizeof(vit_state)) != 0) badk.push_back(k);
+          if (badk.empty()) break;
+          v->last_bad += (unsigned)badk.size();
+          if (round >= 6) { for (size_t k : badk) other_ok[which[k]] = 0; break; }   // pathological: sequential fallback
           std::vector<vit_job> fj;
           std::vector<vit_state> starts;
           unsigned fstride = 1;
-          for (size_t k : bad) {
+          for (size_t k : badk) {
             vit_job j = oj[k];
             j.warm = 0; j.from_state = (int)starts.size();
             starts.push_back(he[k - 1]);
             fj.push_back(j);
             if (j.n_chunks > fstride) fstride = j.n_chunks;
           }
-          rc2 = vit_launch(v, in, out, fj, fstride, false, phase0, &starts, nullptr, false, 0, false);
+          int rc2 = vit_launch(v, in, out, fj, fstride, false, phase0, &starts, nullptr, false, 0, false);
           if (rc2) return rc2;
           std::vector<int> ftot(fj.size() * fstride);
           std::vector<vit_state> fe(fj.size());
           LSDR_TRY(lsdr_stage_d2h(c, ftot.data(), v->d_totals, ftot.size() * sizeof(int)));
           LSDR_TRY(lsdr_stage_d2h(c, fe.data(), v->d_end, fj.size() * sizeof(vit_state)));
           LSDR_TRY(lsdr_stage_sync(c));
-          for (size_t i = 0; i < bad.size(); ++i) {
-            const size_t k = bad[i];
+          for (size_t i = 0; i < badk.size(); ++i) {
+            const size_t k = badk[i];
             start_used[k] = starts[i];
             he[k] = fe[i];
             for (unsigned q = 0; q < oj[k].n_chunks; ++q) other_totals[which[k]][tile_first[k] + q] = ftot[i * fstride + q];
@@ -683,9 +703,23 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       for (size_t k = 0; k < oj.size(); ++k) other_end[which[k]] = he[k];
       return LSDR_OK;
     };
-    std::vector<int> all_others;
-    for (int s = 0; s < v->nsyncs; ++s) if (s != cur) all_others.push_back(s);
-    rc = run_others(false, all_others);
+    auto run_others = [&](bool sequential, const std::vector<int> &only) -> int {
+      const other_jobs J = build_others(sequential, only);
+      int rc2 = vit_launch(v, in, out, J.oj, J.ostride, sequential, phase0, nullptr, nullptr, false, 0, false);
+      if (rc2) return rc2;
+      std::vector<int> tot(J.oj.size() * J.ostride);
+      std::vector<vit_state> hb(J.oj.size()), he(J.oj.size()), cst;
+      LSDR_TRY(lsdr_stage_d2h(c, tot.data(), v->d_totals, tot.size() * sizeof(int)));
+      LSDR_TRY(lsdr_stage_d2h(c, hb.data(), v->d_begin, J.oj.size() * sizeof(vit_state)));
+      LSDR_TRY(lsdr_stage_d2h(c, he.data(), v->d_end, J.oj.size() * sizeof(vit_state)));
+      if (sequential) {
+        cst.resize(J.oj.size() * J.ostride);
+        LSDR_TRY(lsdr_stage_d2h(c, cst.data(), v->d_chunk, cst.size() * sizeof(vit_state)));
+      }
+      LSDR_TRY(lsdr_stage_sync(c));
+      return finish_others(sequential, J, tot, J.ostride, hb, he, cst);
+    };
+    rc = finish_others(false, first_others, first_tot, stride, first_hb, first_he, std::vector<vit_state>());
     if (rc) return rc;
     {
       std::vector<int> redo;
