@@ -271,21 +271,27 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0) if use_fir else None
     d_dec = ctx.alloc((n_out + bench.EXTRA) * 8) if use_fir else None
     rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=max(args.tile_warmup, 512), **rx_kw)
-    vit = capi.Viterbi(ctx, cstln, rate)
-    msync = capi.MpegSync(ctx)
-    derand = capi.Derandomizer(ctx)
+    # The FEC tail lives on its own context (stream) and its own host thread: every block of it returns data-dependent counts
+    # (a host synchronisation per call), so the only way to keep the front end busy meanwhile is a second thread — the
+    # C ABI is thread-safe per context and ctypes releases the GIL.  Two symbol buffers go back and forth between the threads.
+    ctx_t = capi.Ctx(device)
+    vit = capi.Viterbi(ctx_t, cstln, rate)
+    msync = capi.MpegSync(ctx_t)
+    derand = capi.Derandomizer(ctx_t)
     sym_cap = int(n_out / omega * 1.1) + 4096
-    p_sym = DevPipe(capi, ctx, 4, 2 * sym_cap)
-    p_bytes = DevPipe(capi, ctx, 1, sym_cap)
-    p_mpeg = DevPipe(capi, ctx, 1, sym_cap)
+    d_stage = [ctx.alloc(sym_cap * 4) for _ in range(2)]
+    p_sym = DevPipe(capi, ctx_t, 4, 2 * sym_cap)
+    p_bytes = DevPipe(capi, ctx_t, 1, sym_cap)
+    p_mpeg = DevPipe(capi, ctx_t, 1, sym_cap)
     pk_cap = sym_cap // 204 + 64
-    d_rs = ctx.alloc(pk_cap * 204)
-    d_rts = ctx.alloc(pk_cap * 188)
-    d_ts = ctx.alloc(pk_cap * 188)
+    d_rs = ctx_t.alloc(pk_cap * 204)
+    d_rts = ctx_t.alloc(pk_cap * 188)
+    d_ts = ctx_t.alloc(pk_cap * 188)
     e0, e1 = ctx.event(), ctx.event()
     fir_ms, ts_out, bits, errs = [], [], [0], [0]
 
-    def front(timed):
+    def front(timed, dst):
+        """fir_filter + receiver of one batch into the staging buffer `dst`; returns the symbol count."""
         if use_fir:
             ctx.event_record(e0)
             _, prod = fir.run_dev(d_in.ptr, B + bench.EXTRA * decim + N, d_dec.ptr, n_out + bench.EXTRA)
@@ -293,17 +299,19 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
             src, n_src = d_dec.ptr, prod
         else:
             src, n_src = d_in.ptr, n_out + bench.EXTRA
-        p_sym.room(sym_cap)
-        o = rx.run_dev(src, n_src, p_sym.wr(), p_sym.room(0), meas=False)
+        o = rx.run_dev(src, n_src, dst.ptr, sym_cap, meas=False)
         assert o["consumed"] == n_out, (o["consumed"], n_out)
-        p_sym.push(o["produced"])
         if timed and use_fir:
             fir_ms.append(ctx.event_elapsed_ms(e0, e1))
+        return o["produced"]
 
     stage_s = {"front": 0.0, "viterbi": 0.0, "mpeg_sync": 0.0, "rest": 0.0}
 
-    def tail(keep):
+    def tail(keep, src, n_sym):
         t0 = time.perf_counter()
+        p_sym.room(n_sym)
+        capi.check(lib.lsdr_memcpy_d2d(ctx_t.h, p_sym.wr(), src.ptr, n_sym * 4))
+        p_sym.push(n_sym)
         while True:
             p_bytes.room(p_sym.n // 4 + 256)
             c, p = vit.run_dev(p_sym.rp(), p_sym.n, p_bytes.wr(), p_bytes.room(0))
@@ -319,46 +327,83 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
             p_bytes.pop(c); p_mpeg.push(p)
         t2 = time.perf_counter()
         stage_s["viterbi"] += t1 - t0; stage_s["mpeg_sync"] += t2 - t1
+        t3 = time.perf_counter()
         cons, prod = C.c_size_t(), C.c_size_t()
-        capi.check(lib.lsdr_deinterleaver_run(ctx.h, p_mpeg.rp(), p_mpeg.n, d_rs.ptr, pk_cap, C.byref(cons), C.byref(prod)))
+        capi.check(lib.lsdr_deinterleaver_run(ctx_t.h, p_mpeg.rp(), p_mpeg.n, d_rs.ptr, pk_cap, C.byref(cons), C.byref(prod)))
         p_mpeg.pop(cons.value)
         npk = prod.value
+        n_ts = 0
         if npk:
             b, e = C.c_long(), C.c_long()
-            capi.check(lib.lsdr_rs_decoder_run(ctx.h, d_rs.ptr, npk, d_rts.ptr, C.byref(b), C.byref(e)))
+            capi.check(lib.lsdr_rs_decoder_run(ctx_t.h, d_rs.ptr, npk, d_rts.ptr, C.byref(b), C.byref(e)))
             bits[0] += b.value; errs[0] += e.value
             c2, p2 = C.c_size_t(), C.c_size_t()
             capi.check(lib.lsdr_derandomizer_run(derand.h, d_rts.ptr, npk, d_ts.ptr, pk_cap, C.byref(c2), C.byref(p2)))
             if keep and p2.value:
-                ts_out.append(ctx.download(d_ts, np.uint8, p2.value * 188).reshape(-1, 188).copy())
-            return p2.value
-        return 0
+                ts_out.append(ctx_t.download(d_ts, np.uint8, p2.value * 188).reshape(-1, 188).copy())
+            n_ts = p2.value
+        stage_s["rest"] += time.perf_counter() - t3
+        return n_ts
 
     # acquisition (exact serial loop on the head of the stream), then tracking
     acq = capi.CstlnReceiver(ctx, mode=capi.RX_SERIAL, **rx_kw)
     if use_fir:
         _, p0 = fir.run_dev(d_in.ptr, min(B, 1 << 22), d_dec.ptr, n_out)
         ctx.sync()
-        acq.run_dev(d_dec.ptr, p0, p_sym.wr(), p_sym.room(0), meas=False)
+        acq.run_dev(d_dec.ptr, p0, d_stage[0].ptr, sym_cap, meas=False)
     else:
-        acq.run_dev(d_in.ptr, min(n_out, 1 << 18), p_sym.wr(), p_sym.room(0), meas=False)
+        acq.run_dev(d_in.ptr, min(n_out, 1 << 18), d_stage[0].ptr, sym_cap, meas=False)
     rx.set_state(acq.state())
     acq.close()
-    for _ in range(3):
-        front(False); tail(False)
+
+    import queue, threading
+
+    def pipeline(n_batches, timed):
+        """front end on this thread, FEC tail on a second one; the two staging buffers circulate through two queues."""
+        free_q, full_q = queue.Queue(), queue.Queue()
+        for i in range(2):
+            free_q.put(i)
+        failure = []
+
+        def tail_thread():
+            try:
+                while True:
+                    item = full_q.get()
+                    if item is None:
+                        return
+                    i, n_sym = item
+                    tail(timed, d_stage[i], n_sym)
+                    ctx_t.sync()
+                    free_q.put(i)
+            except BaseException as e:      # surfaces in the main thread
+                failure.append(e)
+                free_q.put(0); free_q.put(1)
+
+        th = threading.Thread(target=tail_thread)
+        th.start()
+        try:
+            for _ in range(n_batches):
+                i = free_q.get()
+                if failure:
+                    break
+                tf = time.perf_counter()
+                n_sym = front(timed, d_stage[i])
+                stage_s["front"] += time.perf_counter() - tf
+                full_q.put((i, n_sym))
+        finally:
+            full_q.put(None)
+            th.join()
+        if failure:
+            raise failure[0]
+
+    pipeline(3, False)
     nb = 40
-    t0 = time.perf_counter()
-    npk = 0
     for k in stage_s:
         stage_s[k] = 0.0
-    for _ in range(nb):
-        tf = time.perf_counter()
-        front(True)
-        stage_s["front"] += time.perf_counter() - tf
-        npk += tail(True)
-    ctx.sync()
+    t0 = time.perf_counter()
+    pipeline(nb, True)
+    ctx.sync(); ctx_t.sync()
     dt = time.perf_counter() - t0
-    stage_s["rest"] = dt - stage_s["front"] - stage_s["viterbi"] - stage_s["mpeg_sync"]
     got = np.concatenate(ts_out) if ts_out else np.zeros((0, 188), np.uint8)
     # every packet must be the next one of the transmitted 8-packet cycle
     ok = bad = 0
@@ -375,7 +420,8 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
                ts_check={"packets_equal_to_the_transmitted_sequence": ok, "different": bad, "pass": bool(bad == 0 and ok > 8)},
                vber=(errs[0] / bits[0] if bits[0] else None), viterbi=vit.stats(), rx_tiles=rx.tiled_stats(),
                host_seconds_per_stage={k: round(v, 4) for k, v in stage_s.items()},
-               mode="synchronous per batch (every FEC block returns data-dependent counts)")
+               mode="front end (fir_filter + receiver) and FEC tail on two host threads / two streams, two symbol buffers in "
+                    "flight; host_seconds_per_stage are busy times per thread (front | viterbi+mpeg_sync+rest)")
     if use_fir and fir_ms:
         n_launch_out = n_out + bench.EXTRA
         alg = n_launch_out * decim * 8 + n_launch_out * 8
@@ -385,14 +431,14 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
                            "algorithmic_bytes_per_launch": alg, "traffic": None}
     for p in (p_sym, p_bytes, p_mpeg):
         p.free()
-    for d in (d_in, d_rs, d_rts, d_ts):
+    for d in (d_in, d_rs, d_rts, d_ts, d_stage[0], d_stage[1]):
         d.free()
     if d_dec:
         d_dec.free()
     vit.close(); msync.close(); derand.close(); rx.close()
     if fir:
         fir.close()
-    ctx.close()
+    ctx_t.close(); ctx.close()
     return out
 
 

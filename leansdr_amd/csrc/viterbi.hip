@@ -12,7 +12,11 @@
 // which metrics (relative to the best) and path registers no longer depend on the starting point:
 // the tile then reproduces the sequential decoder bit for bit.  This is CHECKED, not assumed: the
 // state of tile j after its warm-up is compared (64 normalised metrics + 64 path registers) with the
-// end state of tile j−1; a mismatch makes the host re-decode from there sequentially.
+// end state of tile j−1 on the device; mismatching tiles are decoded again from their predecessor's end state (rounds,
+// all in parallel), and a seam that still fails after six rounds makes the host re-decode from there sequentially.
+// The decoders of the alignments not in force (they see the resync chunks only, dvb.h:1386-1410) are tiled and checked
+// the same way and ride in the same launches as the main alignment's tiles.  Tiles get shorter when the input is short
+// (more wavefronts on an otherwise idle chip).  Host↔device bookkeeping goes through the context's pinned arena.
 //
 // Work is skipped only where the reference's result cannot depend on it: the per-step "quality"
 // (second-best − best) is needed on resync chunks only (dvb.h:1386-1394), metrics are renormalised
@@ -565,51 +569,53 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   launch_jobs.insert(launch_jobs.end(), first_others.oj.begin(), first_others.oj.end());
   int rc = vit_launch(v, in, out, launch_jobs, stride, false, phase0);
   if (rc) return rc;
-  LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
-  if (n_main > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream,
-                                     (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
-  std::vector<int> bad(n_main, 0), totals_main(n_main * stride);
-  std::vector<int> first_tot(n_first * stride);
-  std::vector<vit_state> first_hb(n_first), first_he(n_first);
-  LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_main * sizeof(int)));
-  LSDR_TRY(lsdr_stage_d2h(c, totals_main.data(), v->d_totals, n_main * stride * sizeof(int)));
-  if (n_first) {
-    LSDR_TRY(lsdr_stage_d2h(c, first_tot.data(), v->d_totals + n_main * stride, n_first * stride * sizeof(int)));
-    LSDR_TRY(lsdr_stage_d2h(c, first_hb.data(), v->d_begin + n_main, n_first * sizeof(vit_state)));
-    LSDR_TRY(lsdr_stage_d2h(c, first_he.data(), v->d_end + n_main, n_first * sizeof(vit_state)));
-  }
-  LSDR_TRY(lsdr_stage_sync(c));
+  // ---- seam check and fix-up rounds, main and other alignments together.  A tile whose speculative start state differs
+  // from its predecessor's end state is decoded again from that end state (read on the device from the slot array; results
+  // land in the tile's own slots); a changed end state shows up at the next seam in the next round.  The seam check is
+  // redone over all tiles after every round, and it compares the state each job actually started from, so the result is
+  // exact whatever the interleaving.  Only the flags and the per-chunk totals come back to the host.
+  const size_t n_total = n_main + n_first;
+  std::vector<unsigned char> seam(n_total, 0);          // slot k continues slot k−1
+  for (size_t k = 1; k < n_main; ++k) seam[k] = 1;
+  for (size_t k = 0; k < n_first; ++k) seam[n_main + k] = first_others.tile_first[k] != 0;
+  std::vector<int> bad(n_total, 0), totals_all(n_total * stride);
+  vit_state main_end;
+  std::vector<vit_state> first_end(v->nsyncs);
   v->last_tiles = (unsigned)n_main; v->last_bad = 0;
-  // ---- fix-up rounds: a tile whose speculative start state differs from its predecessor's end state is decoded
-  // again from that end state (read on the device from the slot array; results land in the tile's own slots); a changed
-  // end state shows up at the next seam in the next round.  The seam check is redone over all tiles after every round,
-  // and it compares the state each job actually started from, so the result is exact whatever the interleaving.
-  for (int round = 0; round < 6; ++round) {
+  for (int round = 0;; ++round) {
+    LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_total * sizeof(int), c->stream));
+    if (n_total > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_total - 1)), dim3(64), 0, c->stream,
+                                        (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_total, v->d_bad);
+    LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_total * sizeof(int)));
+    LSDR_TRY(lsdr_stage_d2h(c, totals_all.data(), v->d_totals, n_total * stride * sizeof(int)));
+    // end states the host needs if this round turns out to be the last (later launches reuse the slots): the main
+    // alignment's last tile, each other alignment's last tile
+    LSDR_TRY(lsdr_stage_d2h(c, &main_end, v->d_end + (n_main - 1), sizeof(vit_state)));
+    for (size_t k = 0; k < n_first; ++k)
+      if (k + 1 == n_first || first_others.which[k + 1] != first_others.which[k])
+        LSDR_TRY(lsdr_stage_d2h(c, &first_end[first_others.which[k]], v->d_end + (n_main + k), sizeof(vit_state)));
+    LSDR_TRY(lsdr_stage_sync(c));
+    for (size_t k = 0; k < n_total; ++k) if (!seam[k]) bad[k] = 0;
+    if (round >= 6) break;
     std::vector<vit_job> fj;
-    for (size_t k = 1; k < n_main; ++k)
+    for (size_t k = 1; k < n_total; ++k)
       if (bad[k]) {
-        vit_job j = jobs[k];
+        vit_job j = launch_jobs[k];
         j.warm = 0; j.from_state = (int)(k - 1); j.slot = (unsigned)k;
         fj.push_back(j);
       }
     if (fj.empty()) break;
     v->last_bad += (unsigned)fj.size();
-    rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_main + n_first);
+    rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_total);
     if (rc) return rc;
-    LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_main * sizeof(int), c->stream));
-    hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_main - 1)), dim3(64), 0, c->stream, (const vit_state *)v->d_begin,
-                       (const vit_state *)v->d_end, (unsigned)n_main, v->d_bad);
-    LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_main * sizeof(int)));
-    LSDR_TRY(lsdr_stage_d2h(c, totals_main.data(), v->d_totals, n_main * stride * sizeof(int)));
-    LSDR_TRY(lsdr_stage_sync(c));
   }
+  std::vector<int> totals_main(totals_all.begin(), totals_all.begin() + n_main * stride);
   // ---- last resort (seams that keep failing): everything from the first bad seam on, sequentially, from the previous
   // tile's end state (exact by construction).
   size_t first_bad = n_main;
   for (size_t j = 1; j < n_main; ++j) if (bad[j]) { first_bad = j; break; }
   std::vector<vit_state> main_first(n_main);   // state after the first chunk of each tile (alignment switches)
   bool main_first_on_device = false;
-  vit_state main_end;
   if (first_bad < n_main) {
     for (size_t j = first_bad; j < n_main; ++j) v->last_bad += bad[j] ? 1u : 0u;
     // keep results of tiles < first_bad; redo the rest as ONE sequential job starting from end_states[first_bad-1]
@@ -640,7 +646,6 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     }
   } else {
     main_first_on_device = true;   // fetched per tile only if an alignment switch needs it (2.8 MB per call otherwise)
-    LSDR_HIP(hipMemcpy(&main_end, v->d_end + (n_main - 1), sizeof(vit_state), hipMemcpyDeviceToHost));
   }
 
   // ---- other alignments: sequential over the resync chunks, exact carried state
@@ -719,8 +724,14 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       LSDR_TRY(lsdr_stage_sync(c));
       return finish_others(sequential, J, tot, J.ostride, hb, he, cst);
     };
-    rc = finish_others(false, first_others, first_tot, stride, first_hb, first_he, std::vector<vit_state>());
-    if (rc) return rc;
+    // the tiles that rode in the main launch are verified already; an alignment with a seam that never settled goes sequential
+    for (int sidx : all_others) { other_totals[sidx].assign(nrs, 0); other_states[sidx].clear(); other_ok[sidx] = 1; other_end[sidx] = first_end[sidx]; }
+    for (size_t k = 0; k < n_first; ++k) {
+      const int sidx = first_others.which[k];
+      for (unsigned q = 0; q < first_others.oj[k].n_chunks; ++q)
+        other_totals[sidx][first_others.tile_first[k] + q] = totals_all[(n_main + k) * stride + q];
+      if (bad[n_main + k]) other_ok[sidx] = 0;
+    }
     {
       std::vector<int> redo;
       for (int s : all_others) if (!other_ok[s]) redo.push_back(s);
