@@ -17,8 +17,12 @@
  *    reference's fail() (framework.h:33).  "Not enough input / no room" is not
  *    an error: *produced == 0, exactly like a reference run() that returns
  *    without progress (SURVEY §8b "Error convention").
- *  - One lsdr_ctx = one device + one HIP stream; all calls on a ctx must come
- *    from one thread (the scheduler thread, README.coding.md:29).
+ *  - One lsdr_ctx = one device + one HIP stream; all calls on a ctx (and on the
+ *    blocks created on it) must come from one thread at a time (the scheduler
+ *    thread, README.coding.md:29).  Different contexts may be driven from
+ *    different threads concurrently (per-context tables, counters and staging;
+ *    lsdr_last_error() is per thread): bench_more.py runs the front end and the
+ *    FEC tail of one capture that way.
  *  - Work is enqueued on the ctx stream.  Functions whose outputs have a
  *    data-dependent size (cstln_receiver, the FEC tail) synchronise before
  *    returning so that the scheduler's progress hash (framework.h:96-113)
