@@ -132,8 +132,11 @@ int lsdr_stage_d2h(lsdr_ctx *c, void *dst_host, const void *src_dev, size_t byte
   LSDR_ARG(c);
   if (!bytes) return LSDR_OK;
   char *slot;
-  { int rc = stage_reserve(c, bytes, &slot); if (rc) return rc; }
-  LSDR_HIP(hipMemcpyAsync(slot, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+  // A failure makes the caller return before its lsdr_stage_sync: the destinations queued so far (its locals) must not be
+  // written by somebody else's next sync.
+  { int rc = stage_reserve(c, bytes, &slot); if (rc) { c->stage_pending.clear(); return rc; } }
+  const hipError_t e = hipMemcpyAsync(slot, src_dev, bytes, hipMemcpyDeviceToHost, c->stream);
+  if (e != hipSuccess) { c->stage_pending.clear(); LSDR_HIP(e); }
   c->stage_pending.push_back({dst_host, slot, bytes});
   return LSDR_OK;
 }

@@ -316,3 +316,47 @@ def test_viterbi_resync_period_1(capi, ctx, oracle):
     v.close()
     want, wcons, _ = oracle.viterbi_sync(sym, 1, 0, 1)
     assert cons == wcons and bits_equal(got, want)
+
+
+def test_two_contexts_on_two_threads(capi, oracle):
+    """Different contexts may be driven from different host threads at once (include/lsdr_hip.h, conventions): the FEC blocks
+    of two contexts running concurrently give the bytes each gives alone (per-context RS tables/counters and staging arenas)."""
+    import threading
+    sym = fec_input(hard_symbols(), 40)
+    data = oracle.deconvol_sync(sym, 0, 0, 0)
+    want_m, want_ev, _ = oracle.mpeg_sync(data, 0)
+    pk = oracle.deinterleaver(want_m)
+    want_ts = oracle.rs_decoder(pk)
+    ctxs = [capi.Ctx(0), capi.Ctx(0)]
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            out = []
+            for _ in range(6):
+                v = capi.Viterbi(ctxs[i], capi.QPSK, capi.FEC12)
+                vb, _ = v.run_stream(sym)
+                v.close()
+                ms = capi.MpegSync(ctxs[i])
+                m, ev = ms.run_stream(data)
+                ms.close()
+                p2, _ = capi.deinterleaver(ctxs[i], m)
+                out.append((sha(vb), sha(m), ev, capi.rs_decoder(ctxs[i], p2)))
+            results[i] = out
+        except BaseException as e:
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for c in ctxs:
+        c.close()
+    assert not errors, errors
+    first = results[0][0]
+    assert first[1] == sha(want_m) and first[2] == want_ev.tolist()
+    assert bits_equal(first[3][0], want_ts[0]) and list(first[3][1:]) == list(want_ts[1:])
+    for r in results[0] + results[1]:
+        assert r[0] == first[0] and r[1] == first[1] and r[2] == first[2]
+        assert bits_equal(r[3][0], first[3][0]) and r[3][1:] == first[3][1:]
