@@ -443,7 +443,10 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
 
 
 def c3(capi, synth, device, args):
-    return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, args.batch_msamples,
+    # The FEC tail's cost per batch is mostly latency (a few launch → readback rounds of viterbi_sync, each a fraction of a
+    # millisecond whatever the size, until the tiles fill the chip): batches eight times the headline's keep it off the
+    # critical path.  4 GB of input per batch, resident (64 → 128 → 256 → 512 Mi samples: 51 → 93 → 150 → 190 GS/s).
+    return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, int(os.environ.get("LSDR_C3_BATCH_MSAMPLES", 8 * args.batch_msamples)),
                       "QPSK 1/2 @ 120 sps cf32: scaler+fir_filter(313,/30) -> cstln_receiver(tiled) -> viterbi_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer")
 
 

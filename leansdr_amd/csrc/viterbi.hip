@@ -530,7 +530,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   // them depends on the main alignment's results), after the main slots.
   const bool have_others = !rs.empty() && v->nsyncs > 1;
   const unsigned TLo = 4;
-  const unsigned Wo = getenv("LSDR_VIT_WO") ? (unsigned)atoi(getenv("LSDR_VIT_WO")) : (unsigned)kWarm;   // tuning hook
+  // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
+  // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in forty
+  const unsigned Wo = getenv("LSDR_VIT_WO") ? (unsigned)atoi(getenv("LSDR_VIT_WO")) : (unsigned)(kWarm < 8 ? 8 : kWarm);   // tuning hook
   const unsigned nrs = (unsigned)rs.size();
   struct other_jobs { std::vector<vit_job> oj; std::vector<int> which, tile_first; unsigned ostride; };   // tile_first: index into rs
   auto build_others = [&](bool sequential, const std::vector<int> &only) {
