@@ -105,8 +105,10 @@ constexpr int kVitWaves = 4;
 // independent ds_bpermute) and the survivor is a select — one LDS round trip per trellis step instead of the generic
 // path's chain of table read → shuffle → compare → table read → shuffle (≈ 900 cycles per step).  Same candidates, same
 // order, same `<=` tie rule as the generic path: bit-identical.
-template <bool TWO>
+// NUS = 2 / 4: that fast path (4: 8PSK 2/3 — four predecessors, eight labels, twelve independent ds_bpermute); 0 = generic.
+template <int NUS>
 __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
+  constexpr bool TWO = NUS == 2;
   __shared__ vit_tables T;
   const int lane = threadIdx.x & 63;
   const unsigned jid = blockIdx.x * kVitWaves + (threadIdx.x >> 6);   // one wavefront = one job; kVitWaves jobs share the LDS tables
@@ -135,6 +137,11 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   const unsigned us0 = T.us[0][lane], us1 = T.us[1][lane];
   const unsigned bl4 = (unsigned)T.by_label[0][lane] | ((unsigned)T.by_label[1][lane] << 8) | ((unsigned)T.by_label[2][lane] << 16) |
                        ((unsigned)T.by_label[3][lane] << 24);
+  // NUS == 4: predecessors 2, 3 and the labels 4..7
+  const int pred2 = T.pred[2][lane], pred3 = T.pred[3][lane];
+  const unsigned us2 = T.us[2][lane], us3 = T.us[3][lane];
+  const unsigned bl4h = (unsigned)T.by_label[4][lane] | ((unsigned)T.by_label[5][lane] << 8) | ((unsigned)T.by_label[6][lane] << 16) |
+                        ((unsigned)T.by_label[7][lane] << 24);
 
   for (long long q = -(long long)job.warm; q < (long long)job.n_chunks; ++q) {
     const unsigned long long c = (unsigned long long)((long long)job.first_chunk + q * (long long)job.chunk_step);
@@ -182,6 +189,21 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
         if (c1 <= best_m) { best_m = c1; bk = 1; }
         const unsigned long long ps = bk ? ((unsigned long long)hi1 << 32 | lo1) : ((unsigned long long)hi0 << 32 | lo0);
         path = ((ps << C.nbits) | (bk ? us1 : us0)) & pmask;
+        cost = best_m;
+      } else if (NUS == 4) {
+        const unsigned plo = (unsigned)path, phi = (unsigned)(path >> 32);
+        const int c0 = __shfl(cost, pred0, 64), c1 = __shfl(cost, pred1, 64), c2 = __shfl(cost, pred2, 64), c3 = __shfl(cost, pred3, 64);
+        const unsigned lo0 = __shfl(plo, pred0, 64), hi0 = __shfl(phi, pred0, 64), lo1 = __shfl(plo, pred1, 64), hi1 = __shfl(phi, pred1, 64);
+        const unsigned lo2 = __shfl(plo, pred2, 64), hi2 = __shfl(phi, pred2, 64), lo3 = __shfl(plo, pred3, 64), hi3 = __shfl(phi, pred3, 64);
+        const unsigned k1 = ((cs1 & 4u ? bl4h : bl4) >> (8u * (cs1 & 3u))) & 255u;   // branch carrying the received label, 255 = none
+        if (k1 != 255u) { best_m = (k1 == 0 ? c0 : k1 == 1 ? c1 : k1 == 2 ? c2 : c3) + cost1; bk = (int)k1; }
+        if (c0 <= best_m) { best_m = c0; bk = 0; }
+        if (c1 <= best_m) { best_m = c1; bk = 1; }
+        if (c2 <= best_m) { best_m = c2; bk = 2; }
+        if (c3 <= best_m) { best_m = c3; bk = 3; }
+        const unsigned slo = bk == 0 ? lo0 : bk == 1 ? lo1 : bk == 2 ? lo2 : lo3, shi = bk == 0 ? hi0 : bk == 1 ? hi1 : bk == 2 ? hi2 : hi3;
+        const unsigned usel = bk == 0 ? us0 : bk == 1 ? us1 : bk == 2 ? us2 : us3;
+        path = ((((unsigned long long)shi << 32 | slo) << C.nbits) | usel) & pmask;
         cost = best_m;
       } else {
         {
@@ -353,10 +375,11 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
   a.njobs = (unsigned)up.size();
-  if (a.C.nus == 2 && a.C.bits_out == 2 && !getenv("LSDR_VIT_GENERIC"))
-    hipLaunchKernelGGL(k_viterbi<true>, dim3((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
-  else
-    hipLaunchKernelGGL(k_viterbi<false>, dim3((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), dim3(kVitWaves * 64), 0, c->stream, a);
+  const dim3 grid((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), block(kVitWaves * 64);
+  static const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;   // test hook: every mode through the generic path
+  if (a.C.nus == 2 && a.C.bits_out == 2 && !generic_only) hipLaunchKernelGGL(k_viterbi<2>, grid, block, 0, c->stream, a);
+  else if (a.C.nus == 4 && a.C.bits_out == 3 && !generic_only) hipLaunchKernelGGL(k_viterbi<4>, grid, block, 0, c->stream, a);
+  else hipLaunchKernelGGL(k_viterbi<0>, grid, block, 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }
