@@ -1117,7 +1117,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   // least (128-sample tiles, 17.5 K of them: 32 → fir 0.160 ms per launch, 64 → 0.149 ms, same whole-job rate).
   int lpw = n_tiles > 12288u ? 64 : 32;
   {
-    const char *e = getenv("LSDR_RX_LANES");   // tuning hook: tiles per wavefront
+    static const char *const e = getenv("LSDR_RX_LANES");   // tuning hook: tiles per wavefront
     if (e) lpw = atoi(e);
     if (lpw != 2 && lpw != 4 && lpw != 8 && lpw != 16 && lpw != 32 && lpw != 64) lpw = n_tiles > 12288u ? 64 : 32;
     a.lanes_per_wave = (unsigned)lpw;

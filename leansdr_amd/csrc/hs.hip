@@ -524,7 +524,8 @@ static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8
   LSDR_HIP(hipGetLastError());
   LSDR_HIP(hipMemcpyAsync(&r->st, r->d_state, sizeof(fq_state), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));
-  if (const char *e = getenv("LSDR_FQ_DEBUG")) {
+  static const char *const fq_debug = getenv("LSDR_FQ_DEBUG");
+  if (const char *e = fq_debug) {
     const unsigned t0 = (unsigned)atoi(e);
     std::vector<fq_tile_info> hi(n_tiles); std::vector<rx_tile_fix> hf(n_tiles);
     LSDR_HIP(hipMemcpy(hi.data(), r->d_info, n_tiles * sizeof(fq_tile_info), hipMemcpyDeviceToHost));

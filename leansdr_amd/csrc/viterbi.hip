@@ -555,7 +555,8 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   const unsigned TLo = 4;
   // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
   // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in forty
-  const unsigned Wo = getenv("LSDR_VIT_WO") ? (unsigned)atoi(getenv("LSDR_VIT_WO")) : (unsigned)(kWarm < 8 ? 8 : kWarm);   // tuning hook
+  static const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook
+  const unsigned Wo = wo_env > 0 ? (unsigned)wo_env : (unsigned)(kWarm < 8 ? 8 : kWarm);
   const unsigned nrs = (unsigned)rs.size();
   struct other_jobs { std::vector<vit_job> oj; std::vector<int> which, tile_first; unsigned ostride; };   // tile_first: index into rs
   auto build_others = [&](bool sequential, const std::vector<int> &only) {
@@ -773,7 +774,8 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
         const int ts = s == cur ? tcur : other_totals[s][r];
         if (ts > bt) { best = s; bt = ts; }
       }
-      if (getenv("LSDR_VIT_DEBUG")) {
+      static const bool vit_debug = getenv("LSDR_VIT_DEBUG") != nullptr;
+      if (vit_debug) {
         fprintf(stderr, "VIT out=%zu cur=%d best=%d :", (size_t)(v->dbg_chunks + rs[r] + 1) * bytes_per_chunk, cur, best);
         for (int s = 0; s < v->nsyncs; ++s) fprintf(stderr, " %d", s == cur ? tcur : other_totals[s][r]);
         fprintf(stderr, "\n");
