@@ -30,9 +30,11 @@ sys.path.insert(0, ROOT)
 
 def single_stream(capi, synth, device, args):
     import bench
-    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=77,
+    # one capture, batches as large as the headline's four together (256 Mi samples: 64 → 441, 128 → 486, 256 → 505 GS/s — the
+    # hand-over between two filter launches costs the same whatever the launch size)
+    pipe = bench.C2Pipeline(capi, synth, device, 1, 4 * args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=77,
                             rx_cus=args.rx_cus, cu_pattern=args.cu_pattern)
-    bps = args.batches_per_step
+    bps = max(1, args.batches_per_step // 4)
     pipe.run(bps, False)
     pipe.sync()
     t0 = time.perf_counter()
