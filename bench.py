@@ -184,6 +184,7 @@ class Capture:
         self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1], **rx_kw)
         self.ev_rx = [self.ctx_rx.event() for _ in range(geo["nbuf"])]
         self.queued = 0
+        self.retired = 0
         self.nsym = 0
         self.last_produced = 0
 
@@ -202,6 +203,7 @@ class Capture:
         while self.queued > keep:
             self.queued -= 1
             self.last_produced = self.rx.wait()
+            self.retired += 1
             if timed:
                 self.nsym += self.last_produced
 
@@ -248,9 +250,10 @@ class C2Pipeline:
         self.ev_pool = []
         self.fir_ms = []
         self.batch_no = 0
+        self.reshifts = 0
         self.snap = None            # (capture, dec buffer index) of the batch whose loop state was snapshotted
 
-    def run(self, n_batches, timed, snapshot_last=False):
+    def run(self, n_batches, timed, snapshot_last=False, track_tol=None):
         """Queue n_batches batches of every capture.  Per batch: fir_filter(k) of all captures in one launch on the fir
         stream, cstln_receiver(k) of each capture on its own stream (after fir_filter(k)); results are retired two
         batches later, so the GPU never waits for the host; the pipeline is drained before returning."""
@@ -283,6 +286,10 @@ class C2Pipeline:
             consumed += B * len(caps)
             for c in caps:
                 c.retire(timed, keep=2)
+            if track_tol is not None and caps[0].retired:
+                # fir_filter follows the receiver's carrier estimate (dsp.h:236-244) from the newest run that has COMPLETED:
+                # the feedback of leandvb.cc:506-510 with the queue depth as latency, no host wait between two batches
+                self.reshifts += int(self.fir.track(caps[0].rx.retired_freq_tap, 1.0 / decim, track_tol))
             self.batch_no += 1
         for c in caps:
             c.retire(timed, keep=0)

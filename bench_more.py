@@ -137,48 +137,29 @@ def anf1(capi, synth, device, args):
 
 
 def c2_offset(capi, synth, device, args):
-    """Synchronous per batch on purpose: the receiver's freq_tap is read back and handed to fir_filter::track() before the
-    next batch, like the scheduler does between run() calls (leandvb.cc:506-510)."""
+    """Carrier 1 MHz off: fir_filter runs with complex (frequency-shifted) taps and keeps following the receiver's carrier
+    estimate (fir_filter::track, dsp.h:236-244; the scheduler's feedback of leandvb.cc:506-510).  The estimate comes from the
+    newest receiver run that has COMPLETED (lsdr_rx_retired_freq_tap) while later ones are still queued: same queued pipeline as
+    the headline, feedback latency = queue depth (two batches) instead of a host wait after every batch."""
     import bench
     f0 = 1.0e6 / bench.FS                 # cycles per input sample
     pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup),
                             seed0=55, freq=f0, rx_freq=f0 * 30)
-    g, cp = pipe.geo, pipe.caps[0]
-    n_in = g["B"] + bench.EXTRA * g["decim"] + g["N"]
+    g = pipe.geo
     tol = float(np.float32(bench.FM / bench.FS * 0.1))
-    shifts, fir_ms = 0, []
-    e0, e1 = pipe.ctx.event(), pipe.ctx.event()
-
-    def batch(timed):
-        nonlocal shifts
-        pipe.ctx.event_record(e0)
-        _, prod = pipe.fir.run_dev(cp.d_in.ptr, n_in, cp.dec[0].ptr, g["n_out"] + bench.EXTRA)
-        pipe.ctx.event_record(e1)
-        pipe.ctx.event_record(pipe.ev_fir[0])
-        cp.ctx_rx.wait_event(pipe.ev_fir[0])
-        o = cp.rx.run_dev(cp.dec[0].ptr, prod, cp.d_sym.ptr, g["n_out"] + bench.EXTRA + 256, meas=False)
-        assert o["consumed"] == g["n_out"]
-        if timed:
-            fir_ms.append(pipe.ctx.event_elapsed_ms(e0, e1))
-        shifts += pipe.fir.track(cp.rx.state().freq_tap, 1.0 / g["decim"], tol)
-        return o["produced"]
-
-    for _ in range(8):
-        batch(False)
+    pipe.run(8, False, track_tol=tol)
+    pipe.sync()
     nb = max(48, args.batches_per_step)
     t0 = time.perf_counter()
-    nsym = sum(batch(True) for _ in range(nb))
+    consumed = pipe.run(nb, True, track_tol=tol)
     pipe.sync()
     dt = time.perf_counter() - t0
-    n_launch_out = g["n_out"] + bench.EXTRA
-    alg = n_launch_out * g["decim"] * 8 + n_launch_out * 8
-    ms = float(np.mean(fir_ms))
-    out = dict(value=round(nb * g["B"] / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), carrier_offset_hz=1.0e6,
-               filter_freq=pipe.fir.current_freq, filter_reshifts=int(shifts), receiver_freq_tap=cp.rx.state().freq_tap,
-               symbols_per_batch=nsym // nb, mode="synchronous per batch (freq_tap -> track() feedback on the host)",
-               roofline={"kernel": "k_fir_persist, complex taps", "bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 2),
-                         "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4),
-                         "avg_launch_ms": round(ms, 4), "algorithmic_bytes_per_launch": alg, "traffic": None})
+    cp = pipe.caps[0]
+    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), carrier_offset_hz=1.0e6,
+               filter_freq=pipe.fir.current_freq, filter_reshifts=int(pipe.reshifts), receiver_freq_tap=cp.rx.state().freq_tap,
+               symbols_per_batch=cp.nsym // nb,
+               mode="queued like the headline; freq_tap of the newest completed receiver run -> fir_filter::track() on the host",
+               roofline=dict(pipe.roofline(), kernel="k_fir_persist, complex taps", traffic=None, traffic_source=None))
     assert abs(pipe.fir.current_freq - f0) < tol, "the filter did not follow the carrier"
     pipe.close()
     return out

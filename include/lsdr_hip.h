@@ -276,6 +276,10 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
  * the host never sits between two runs.  lsdr_rx_run / _set_state refuse to mix with outstanding queued runs. */
 int lsdr_rx_run_async(lsdr_rx *rx, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
 int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
+/* freq_tap (sdr.h:919-921, cycles per sample) as of the end of the most recently retired queued run: lets the caller keep
+ * fir_filter tracking the carrier (lsdr_fir_filter_track, dsp.h:236-244) from runs that have already completed while later
+ * ones are still queued — the feedback of leandvb.cc:506-510 with a latency of the queue depth instead of a host wait. */
+float lsdr_rx_retired_freq_tap(const lsdr_rx *rx);
 /* Loop-state snapshot between queued runs: lsdr_rx_snapshot_async() puts a copy of the device-side loop state (the fields
  * of cstln_receiver<f32>, sdr.h:923-935) into a pinned slot in stream order, i.e. the state the NEXT queued run starts
  * from; lsdr_rx_get_snapshot() waits for the stream and returns it.  Lets a caller (bench.py's verification) replay one

@@ -194,6 +194,7 @@ _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
 _sig("lsdr_rx_wait", C.c_int, [vp, psz])
+_sig("lsdr_rx_retired_freq_tap", C.c_float, [vp])
 _sig("lsdr_fec_spec", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp])
 _sig("lsdr_cconverter_int_run", C.c_int, [vp, C.c_int, vp, c_sz, vp])
 _sig("lsdr_copy_h2d_async", C.c_int, [vp, vp, vp, c_sz])
@@ -512,6 +513,11 @@ class CstlnReceiver:
         prod = c_sz()
         check(lib.lsdr_rx_wait(self.h, C.byref(prod)))
         return prod.value
+
+    @property
+    def retired_freq_tap(self):
+        """freq_tap after the most recently retired queued run (cycles per sample)."""
+        return lib.lsdr_rx_retired_freq_tap(self.h)
 
     def run_dev(self, in_ptr, n_in, out_ptr, cap_out, meas=True):
         cons, prod, nm, nc = c_sz(), c_sz(), c_sz(), c_sz()

@@ -490,6 +490,7 @@ __device__ __forceinline__ lsdr_softsymbol rx_relabel(lsdr_softsymbol v, const u
 __device__ __forceinline__ unsigned rx_symbol_of(lsdr_softsymbol v) { return v.symbol; }
 __device__ __forceinline__ float fmod65536(float x);
 __device__ __forceinline__ void rx_rotate_back(rx_state_dev *st, unsigned rot, float quad);
+__device__ __forceinline__ float rx_freq_tap(const rx_state_dev *st) { return st->freqw / 65536; }   // refresh_freq_tap, sdr.h:919-921
 #include "rx_tiling.h"
 typedef rx_tile_info_t<lsdr_softsymbol> rx_tile_info;
 
@@ -928,6 +929,7 @@ struct lsdr_rx {
   hipEvent_t ev[kRing];
   unsigned ring_tiles[kRing];
   int ring_head, ring_count;           // oldest outstanding slot, number outstanding
+  float retired_freq_tap;              // freq_tap after the most recently retired queued run
   bool st_stale_host;                  // device state newer than the host mirror `st`
   bool qpsk_arith;                     // tolerance tiles decide by arithmetic (QPSK, verified against the table at create time)
   unsigned arith_max_dpe;              // largest |phase_error − table| seen by that verification
@@ -1171,6 +1173,7 @@ static int rx_tiled_wait(lsdr_rx *r, size_t *produced) {
   r->ring_head = (r->ring_head + 1) % lsdr_rx::kRing;
   --r->ring_count;
   r->last_tiles = r->ring_tiles[slot]; r->last_dup = sr.ndup; r->last_miss = sr.nmiss; r->last_badseam = sr.nbad;
+  r->retired_freq_tap = sr.freq_tap;
   *produced = (size_t)sr.total;
   return LSDR_OK;
 }
@@ -1431,6 +1434,7 @@ int lsdr_rx_wait(lsdr_rx *r, size_t *produced) {
   LSDR_ARG(r && produced);
   return rx_tiled_wait(r, produced);
 }
+float lsdr_rx_retired_freq_tap(const lsdr_rx *r) { return r ? r->retired_freq_tap : 0.f; }
 
 int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                 size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(64) void k_fastqpsk_serial(fq_args a) {
 // transport stream behind it is what the tests compare.
 __device__ __forceinline__ unsigned char rx_relabel(unsigned char v, const uint8_t *map) { return map[v]; }
 __device__ __forceinline__ unsigned rx_symbol_of(unsigned char v) { return v; }
+__device__ __forceinline__ float rx_freq_tap(const fq_state *st) { return (float)st->freqw / 65536.0f / 65536.0f; }   // (not consumed: --hs has no freq_tap user)
 __device__ __forceinline__ void rx_rotate_back(fq_state *st, unsigned rot, float quad) {
   st->phase = (st->phase - rot * (unsigned)quad) & 0xffffu;
 }

@@ -1,7 +1,8 @@
 // leansdr_amd/csrc/rx_tiling.h — device-side seam reconciliation shared by the time-tiled (throughput-mode)
 // receivers: cstln_receiver (cstln_receiver.hip) and fast_qpsk_receiver (hs.hip).  Included inside each file's
 // anonymous namespace.  SYM = the symbol record type, STATE = the carried loop state (its phase is rotated back into
-// tile 0's frame at the end of a run through rx_rotate_back(), specialised by each includer).
+// tile 0's frame at the end of a run through rx_rotate_back(), specialised by each includer, as is rx_freq_tap():
+// the receiver's freq_tap in cycles per sample, which rides home with the run's totals).
 #ifndef LSDR_RX_TILING_H
 #define LSDR_RX_TILING_H
 
@@ -34,7 +35,7 @@ struct rx_tile_fix {          // per tile, produced by the seam pass
 //    when the two tiles disagree on which side of the boundary one symbol instant falls →
 //    drop the duplicate / insert the lost symbol (the warm-up's last symbol);
 //  * output offsets: exclusive prefix sum of the adjusted counts.
-struct rx_seam_result { unsigned long long total; unsigned rot_final, ndup, nmiss, nbad; };
+struct rx_seam_result { unsigned long long total; unsigned rot_final, ndup, nmiss, nbad; float freq_tap; };   // freq_tap: rx_freq_tap(state) after the run
 
 struct seam_step { unsigned insert, drop, k, bad; };
 
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(64) void k_rx_compact(const SYM *stage, unsigned st
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
   if (j == 0 && threadIdx.x == 0) {
-    rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0;
+    rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0; sr.freq_tap = rx_freq_tap(state);
     for (unsigned i = 0; i < nparts; ++i) {
       sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
       sr.ndup += part[i].ndup; sr.nmiss += part[i].nmiss; sr.nbad += part[i].nbad;
