@@ -116,19 +116,25 @@ def anf1(capi, synth, device, args):
 
     run(6, False)
     nb = max(48, args.batches_per_step)
+    notch.scan_time(True)                 # HIP events around the k_notch_scan launches (the last 16 are kept)
     t0 = time.perf_counter()
     run(nb, True)
     dt = time.perf_counter() - t0
+    kms, klaunches = notch.scan_time(False)
     for e in pool:
         notch_ms.append(ctx_n.event_elapsed_ms(e[0], e[1])); fir_ms.append(pipe.ctx.event_elapsed_ms(e[2], e[3]))
     nms = float(np.mean(notch_ms))
     alg = nblk * 4096 * 16
     out = dict(value=round(nb * g["B"] / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), notch_bin=notch.bins(),
                interferer="CW at 0.0137 cycles/sample, 3x the signal amplitude", fir_filter_avg_launch_ms=round(float(np.mean(fir_ms)), 4),
-               roofline={"kernel": "k_notch_scan (auto_notch, 1 slot)", "bound": "hbm", "achieved": round(alg / (nms * 1e-3) / 1e9, 2),
-                         "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (nms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4),
-                         "avg_launch_ms": round(nms, 4), "algorithmic_bytes_per_launch": alg, "traffic": None,
-                         "note": "the launch time includes the batched detect FFTs / peak search / table build of the run"})
+               auto_notch_run_avg_ms=round(nms, 4),
+               pipeline_hbm_bytes_per_sample=24, pipeline_hbm_frac=round(nb * g["B"] * 24 / dt / 1e9 / bench.HBM_PEAK_GBS, 4),
+               roofline={"kernel": "k_notch_scan (auto_notch, 1 slot)", "bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 2),
+                         "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (kms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4),
+                         "avg_launch_ms": round(kms, 4), "launches_timed": klaunches, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                         "note": "HIP events around the k_notch_scan launch on its stream (lsdr_auto_notch_scan_time), fir_filter and the "
+                                 "receiver running next to it; auto_notch_run_avg_ms is the whole run incl. the batched detect FFTs / "
+                                 "peak search / table build"})
     notch.close(); ctx_n.close()
     for d in d_notched:
         d.free()

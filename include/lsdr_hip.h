@@ -148,12 +148,16 @@ void lsdr_auto_notch_destroy(lsdr_auto_notch *a);
 int lsdr_auto_notch_set(lsdr_auto_notch *a, int decimation, float k);      /* public members, sdr.h:49-50 */
 int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot);
 /* LSDR_NOTCH_EXACT (default): the reference's sequential arithmetic in verified time tiles — bit-exact.
- * LSDR_NOTCH_SCAN: throughput mode — the estimator recurrence as a single-pass scan (one workgroup per 4096-sample block,
+ * LSDR_NOTCH_SCAN: throughput mode — the estimator recurrence as a single-pass scan (one wavefront per 1024 samples,
  * decoupled look-back for the carry), detect() entirely on the device, no host synchronisation per run; tolerance-tested
  * (tests/test_gpu_notch.py), needs 1-4 slots and agc_rms_setpoint == 0 (leandvb's configuration, leandvb.cc:300-301). */
 enum { LSDR_NOTCH_EXACT = 0, LSDR_NOTCH_SCAN = 1 };
 int lsdr_auto_notch_set_mode(lsdr_auto_notch *a, int mode);
 int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *bad_seams);
+/* Measurement hook (bench_more.py's roofline of the scan kernel): HIP events on the block's stream around the k_notch_scan
+ * launch of every LSDR_NOTCH_SCAN run while enabled.  Each call returns the mean over the (up to 16 most recent) launches
+ * recorded since the previous call — after waiting for the stream — and then sets the switch. */
+int lsdr_auto_notch_scan_time(lsdr_auto_notch *a, int enable, float *avg_ms, unsigned *launches);
 /* run(), sdr.h:64-75: whole 4096-sample blocks; *consumed == *produced.  Synchronous. */
 int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
                         size_t *consumed, size_t *produced);

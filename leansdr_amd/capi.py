@@ -100,6 +100,7 @@ _sig("lsdr_auto_notch_set", C.c_int, [vp, C.c_int, c_f])
 _sig("lsdr_auto_notch_slot_bin", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_set_mode", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
+_sig("lsdr_auto_notch_scan_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])
 _sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
@@ -810,6 +811,12 @@ class AutoNotch:
 
     def bins(self):
         return [lib.lsdr_auto_notch_slot_bin(self.h, s) for s in range(self.nslots)]
+
+    def scan_time(self, enable=True):
+        """(mean ms, launches) of the k_notch_scan launches recorded since the previous call; then switches recording."""
+        ms, n = c_f(), C.c_uint()
+        check(lib.lsdr_auto_notch_scan_time(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def stats(self):
         t, b = C.c_uint(), C.c_uint()

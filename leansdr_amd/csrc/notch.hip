@@ -524,6 +524,11 @@ struct lsdr_auto_notch {
   size_t det_cap;                             // detect points the scratch above is sized for
   float2 *d_tables; size_t tables_cap;        // [(ndet+1)·nslots·4096]
   float2 *d_totals; unsigned *d_flags; size_t blocks_cap;
+  // optional timing of the scan kernel alone (lsdr_auto_notch_scan_time): a ring of event pairs around its launches
+  static const int kTimed = 16;
+  bool timing;
+  hipEvent_t tev[kTimed][2];
+  unsigned timed_runs;
   unsigned stamp;
   // per-run argument arrays (interval starts, detect offsets) cross over from two pinned slots used alternately: the copy of
   // run k-2 has long executed when its slot is rewritten, so the host never waits for the GPU in steady state
@@ -792,6 +797,12 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     }
   }
   sa.carry_out = a->d_scarry[nxt];   // … written by the last block
+  hipEvent_t *tp = nullptr;
+  if (a->timing) {
+    tp = a->tev[a->timed_runs % lsdr_auto_notch::kTimed];
+    if (!tp[0]) { LSDR_HIP(hipEventCreate(&tp[0])); LSDR_HIP(hipEventCreate(&tp[1])); }
+    LSDR_HIP(hipEventRecord(tp[0], c->stream));
+  }
   switch (ns) {
     case 1: notch_scan_launch<1>(c->stream, (unsigned)nb, sa); break;
     case 2: notch_scan_launch<2>(c->stream, (unsigned)nb, sa); break;
@@ -800,6 +811,7 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     default: lsdr_set_error("auto_notch: LSDR_NOTCH_SCAN supports 1 to 4 slots"); return LSDR_E_UNSUPPORTED;
   }
   LSDR_HIP(hipGetLastError());
+  if (tp) { LSDR_HIP(hipEventRecord(tp[1], c->stream)); ++a->timed_runs; }
   a->scarry_cur = nxt;
   return LSDR_OK;
 }
@@ -851,6 +863,7 @@ int lsdr_auto_notch_create(lsdr_ctx *c, int nslots, float setpoint, lsdr_auto_no
   a->d_offsets = nullptr; a->d_spec = nullptr; a->d_cand = nullptr; a->d_ibins = nullptr; a->d_reset = nullptr; a->d_ifirst = nullptr;
   for (int i = 0; i < 2; ++i) { a->h_ifirst[i] = nullptr; a->h_offsets[i] = nullptr; a->h_cap[i] = 0; a->h_ev[i] = nullptr; }
   a->h_slot = 0;
+  a->timing = false; a->timed_runs = 0; for (auto &pr : a->tev) pr[0] = pr[1] = nullptr;
   a->det_cap = 0; a->d_tables = nullptr; a->tables_cap = 0; a->d_totals = nullptr; a->d_flags = nullptr; a->blocks_cap = 0; a->stamp = 0;
   *out = a;
   return LSDR_OK;
@@ -872,6 +885,7 @@ void lsdr_auto_notch_destroy(lsdr_auto_notch *a) {
   (void)hipFree(a->d_scarry[0]); (void)hipFree(a->d_scarry[1]); (void)hipFree(a->d_bins); (void)hipFree(a->d_offsets); (void)hipFree(a->d_spec);
   (void)hipFree(a->d_cand); (void)hipFree(a->d_ibins); (void)hipFree(a->d_reset); (void)hipFree(a->d_ifirst); (void)hipFree(a->d_tables);
   (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
+  for (auto &pr : a->tev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
   for (int i = 0; i < 2; ++i) {
     if (a->h_ifirst[i]) (void)hipHostFree(a->h_ifirst[i]);
     if (a->h_offsets[i]) (void)hipHostFree(a->h_offsets[i]);
@@ -891,6 +905,23 @@ int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot) {
   if (a->mode == LSDR_NOTCH_SCAN) (void)notch_scan_pull(const_cast<lsdr_auto_notch *>(a));
   return a->bins[slot];
 }
+int lsdr_auto_notch_scan_time(lsdr_auto_notch *a, int enable, float *avg_ms, unsigned *launches) {
+  LSDR_ARG(a);
+  if (avg_ms) *avg_ms = 0.f;
+  if (launches) *launches = 0;
+  if (a->timing && a->timed_runs && (avg_ms || launches)) {
+    LSDR_HIP(hipStreamSynchronize(a->ctx->stream));
+    const unsigned n = a->timed_runs < (unsigned)lsdr_auto_notch::kTimed ? a->timed_runs : (unsigned)lsdr_auto_notch::kTimed;
+    double sum = 0;
+    for (unsigned i = 0; i < n; ++i) { float ms = 0; LSDR_HIP(hipEventElapsedTime(&ms, a->tev[i][0], a->tev[i][1])); sum += ms; }
+    if (avg_ms) *avg_ms = (float)(sum / n);
+    if (launches) *launches = n;
+  }
+  a->timing = enable != 0;
+  a->timed_runs = 0;
+  return LSDR_OK;
+}
+
 int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *bad) {
   LSDR_ARG(a);
   if (tiles) *tiles = a->last_tiles;
