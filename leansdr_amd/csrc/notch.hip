@@ -191,16 +191,20 @@ __global__ __launch_bounds__(1024) void k_cfft(const float2 *in, const float2 *o
                                                 const unsigned long long *in_offsets = nullptr) {
   extern __shared__ __attribute__((aligned(16))) char cfft_smem[];
   float2 *d = reinterpret_cast<float2 *>(cfft_smem);
-  const int n = 1 << logn, tid = threadIdx.x;
+  const int n = 1 << logn, tid = threadIdx.x, nt = blockDim.x;   // any workgroup size up to 1024
+  float2 *w_lds = d + n;                                           // the n/2 twiddles the butterflies use (om[0 .. n/2))
   if (in_offsets) { in += in_offsets[blockIdx.x]; out += (size_t)blockIdx.x * n; }   // batched: one transform per workgroup
-  for (int i = tid; i < n; i += 1024) d[__brev((unsigned)i) >> (32 - logn)] = in[i];   // bit-reversal permutation (dsp.h:84-92)
+  for (int i = tid; i < n; i += nt) d[__brev((unsigned)i) >> (32 - logn)] = in[i];   // bit-reversal permutation (dsp.h:84-92)
+  // Twiddles into LDS up front: a global load per butterfly inside the stage loop pays the memory latency logn times, and next
+  // to kernels that saturate HBM that latency is microseconds (the batched detect FFTs took 88-91 us there, 15 alone).
+  for (int i = tid; i < n / 2; i += nt) w_lds[i] = om[i];
   __syncthreads();
   for (int st = 0; st < logn; ++st) {
     const int hbs = 1 << st, dom = 1 << (logn - 1 - st);
-    for (int b = tid; b < n / 2; b += 1024) {
+    for (int b = tid; b < n / 2; b += nt) {
       const int j = b >> st, k = b & (hbs - 1);
       const int p = j * hbs * 2 + k, q = p + hbs;
-      const float2 w = om[k * dom], dd = d[q], dp = d[p];
+      const float2 w = w_lds[k * dom], dd = d[q], dp = d[p];
       const float xr = w.x * dd.x - w.y * dd.y;
       const float xi = w.x * dd.y + w.y * dd.x;
       d[q] = make_float2(dp.x - xr, dp.y - xi);
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(1024) void k_cfft(const float2 *in, const float2 *o
     }
     __syncthreads();
   }
-  for (int i = tid; i < n; i += 1024) {
+  for (int i = tid; i < n; i += nt) {
     float2 v = d[i];
     if (reverse) { v.x *= invn; v.y *= invn; }
     out[i] = v;
@@ -240,7 +244,7 @@ static int cfft_dev_init(cfft_dev *f, int n, bool reverse) {
 static void cfft_dev_free(cfft_dev *f) { (void)hipFree(f->d_om); (void)hipFree(f->d_out); f->d_om = f->d_out = nullptr; }
 // FFT of the device block `d_in` → host `spectrum` (n complex values).
 static int cfft_dev_run(lsdr_ctx *c, cfft_dev *f, const lsdr_cf32 *d_in, lsdr_cf32 *spectrum) {
-  const size_t lds = (size_t)f->n * sizeof(float2);
+  const size_t lds = (size_t)(f->n + f->n / 2) * sizeof(float2);   // data + the n/2 twiddles
   if (lds > 64 * 1024) LSDR_HIP(hipFuncSetAttribute((const void *)k_cfft, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(k_cfft, dim3(1), dim3(1024), lds, c->stream, (const float2 *)d_in, (const float2 *)f->d_om, f->d_out, f->logn,
                      f->reverse, (float)(1.0 / f->n));
@@ -439,14 +443,62 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 4 
   }
 }
 
+// Per-run argument arrays (interval starts, detect offsets) from the kernel-argument segment, and the estimators' hand-over
+// copy: one tiny launch instead of two pinned-memory uploads, an event and a device-to-device copy in front of the FFTs.
+constexpr int kArgMax = 64;
+struct notch_run_args { int n_ifirst, ndet; int ifirst[kArgMax + 1]; unsigned long long offs[kArgMax]; };
+__global__ __launch_bounds__(64) void k_notch_args(notch_run_args r, int *d_ifirst, unsigned long long *d_offsets, const notch_est *carry_cur,
+                                                   notch_est *carry_next) {
+  const int t = threadIdx.x;
+  for (int i = t; i < r.n_ifirst; i += 64) d_ifirst[i] = r.ifirst[i];
+  for (int i = t; i < r.ndet; i += 64) d_offsets[i] = r.offs[i];
+  if (t == 0) *carry_next = *carry_cur;
+}
+
 // peak search of detect() (sdr.h:94-117) on one spectrum per workgroup: amplitudes by hypotf, nslots rounds of
 // "first maximum wins, zero it and its two neighbours"
-__global__ __launch_bounds__(256) void k_notch_peaks(const float2 *spec, int nslots, int *cand /*[ndet][kMaxSlots]*/) {
+// The detect transforms of the scan mode, small enough to run NEXT TO two fir_filter workgroups on a CU (those hold 126 of the
+// 160 KB of LDS and two thirds of the registers; a 4096-point transform in one workgroup — 32 KB of LDS — was seen in the kernel
+// trace starting with a fir_filter launch and ending with it, 90-110 us for 15 us of work).  Stages 0..10 of cfft_engine's loop
+// (dsp.h:84-104) touch the two halves of the bit-reversed array independently: one 256-lane workgroup with 16 KB of LDS per
+// half; the last stage (position p with p + 2048, twiddle om[p]) is done by k_notch_peaks on the fly.  Same butterflies, each
+// evaluated once with the same expression: bit-identical to k_cfft.
+__global__ __launch_bounds__(256) void k_cfft_half(const float2 *in, const float2 *om, float2 *halves /*[ndet][2][2048]*/,
+                                                   const unsigned long long *in_offsets) {
+  __shared__ float2 d[kN / 2];
+  const int det = blockIdx.x >> 1, h = blockIdx.x & 1, tid = threadIdx.x;
+  const float2 *src = in + in_offsets[det];
+  for (int p = tid; p < kN / 2; p += 256) d[p] = src[__brev((unsigned)(h * (kN / 2) + p)) >> 20];   // position P holds in[brev12(P)]
+  __syncthreads();
+  for (int st = 0; st < 11; ++st) {
+    const int hbs = 1 << st, dom = 1 << (11 - st);
+    for (int b = tid; b < kN / 4; b += 256) {
+      const int j = b >> st, k = b & (hbs - 1);
+      const int p = j * hbs * 2 + k, q = p + hbs;
+      const float2 w = om[k * dom], dd = d[q], dp = d[p];
+      const float xr = w.x * dd.x - w.y * dd.y;
+      const float xi = w.x * dd.y + w.y * dd.x;
+      d[q] = make_float2(dp.x - xr, dp.y - xi);
+      d[p] = make_float2(dp.x + xr, dp.y + xi);
+    }
+    __syncthreads();
+  }
+  for (int p = tid; p < kN / 2; p += 256) halves[(size_t)blockIdx.x * (kN / 2) + p] = d[p];
+}
+
+__global__ __launch_bounds__(256) void k_notch_peaks(const float2 *halves, const float2 *om, float invn, int nslots,
+                                                     int *cand /*[ndet][kMaxSlots]*/) {
   __shared__ float amp[kN];
   __shared__ float s_v[256];
   __shared__ int s_i[256];
-  const float2 *sp = spec + (size_t)blockIdx.x * kN;
-  for (int i = threadIdx.x; i < kN; i += 256) amp[i] = hypotf(sp[i].x, sp[i].y);
+  const float2 *he = halves + (size_t)blockIdx.x * kN, *ho = he + kN / 2;
+  for (int k = threadIdx.x; k < kN / 2; k += 256) {   // last radix-2 stage + the reverse transform's 1/n + |.|
+    const float2 w = om[k], dd = ho[k], dp = he[k];
+    const float xr = w.x * dd.x - w.y * dd.y;
+    const float xi = w.x * dd.y + w.y * dd.x;
+    amp[k + kN / 2] = hypotf((dp.x - xr) * invn, (dp.y - xi) * invn);
+    amp[k] = hypotf((dp.x + xr) * invn, (dp.y + xi) * invn);
+  }
   __syncthreads();
   for (int s = 0; s < nslots; ++s) {
     float bv = -1.f; int bi = 0;
@@ -471,27 +523,26 @@ __global__ __launch_bounds__(256) void k_notch_peaks(const float2 *spec, int nsl
   }
 }
 
-// walks the detect points of a run in order: interval q+1 starts at detect point q with the slots' new bins
-__global__ void k_notch_plan(const int *cand, int ndet, int nslots, int *bins /*[kMaxSlots] carried*/, int *interval_bins /*[ndet+1][kMaxSlots]*/,
-                             unsigned char *reset /*[ndet+1][kMaxSlots]*/) {
-  if (threadIdx.x || blockIdx.x) return;
-  for (int s = 0; s < kMaxSlots; ++s) { interval_bins[s] = bins[s]; reset[s] = 0; }
-  for (int q = 0; q < ndet; ++q)
-    for (int s = 0; s < kMaxSlots; ++s) {
-      int cur = interval_bins[q * kMaxSlots + s];
-      unsigned char rs = 0;
-      if (s < nslots && cand[q * kMaxSlots + s] != cur) { cur = cand[q * kMaxSlots + s]; rs = 1; }
-      interval_bins[(q + 1) * kMaxSlots + s] = cur;
-      reset[(q + 1) * kMaxSlots + s] = rs;
-    }
-  for (int s = 0; s < kMaxSlots; ++s) bins[s] = interval_bins[ndet * kMaxSlots + s];
-}
-
-// phasor tables per interval and slot: expj[i] = (cosf(a), sinf(a)), a = (float)(2π·bin·i/4096) (sdr.h:107-111); bin < 0
-// (nothing detected yet): zeros, like the reference's untouched slots
-__global__ __launch_bounds__(256) void k_notch_tables(const int *interval_bins, int nslots, float2 *tables) {
+// Interval q+1 of a run starts at detect point q with the slots' new bins (sdr.h:94-118): slot s of interval q uses
+// cand[q−1][s] (interval 0: the carried bin), and its estimator restarts where that differs from the interval before.  Every
+// (interval, slot) is independent, so the workgroup that builds the (q, s) phasor table works its own bin out — a separate
+// single-thread planning kernel walked the detect points through dependent global loads and took 20 µs alone, 50 µs next to
+// fir_filter.  The carried bins ping-pong (bins_cur is read by several workgroups, bins_next written by the last interval's).
+// Phasor table: expj[i] = (cosf(a), sinf(a)), a = (float)(2π·bin·i/4096) (sdr.h:107-111); bin < 0 (nothing detected yet): zeros,
+// like the reference's untouched slots.
+__global__ __launch_bounds__(256) void k_notch_tables(const int *cand /*[ndet][kMaxSlots]*/, int ndet, int nslots, const int *bins_cur,
+                                                      int *bins_next, unsigned char *reset /*[ndet+1][kMaxSlots]*/, float2 *tables) {
   const int q = blockIdx.x / nslots, s = blockIdx.x % nslots;
-  const int bin = interval_bins[q * kMaxSlots + s];
+  const int bin = q == 0 ? bins_cur[s] : cand[(q - 1) * kMaxSlots + s];
+  if (threadIdx.x == 0) {
+    const int prev = q == 0 ? bin : (q == 1 ? bins_cur[s] : cand[(q - 2) * kMaxSlots + s]);
+    reset[q * kMaxSlots + s] = (unsigned char)(bin != prev);
+    if (q == ndet) bins_next[s] = bin;
+  }
+  if (s == 0 && (int)threadIdx.x >= nslots && (int)threadIdx.x < kMaxSlots) {   // unused slots: carried through, never reset
+    reset[q * kMaxSlots + threadIdx.x] = 0;
+    if (q == ndet) bins_next[threadIdx.x] = bins_cur[threadIdx.x];
+  }
   float2 *tb = tables + ((size_t)q * nslots + s) * kN;
   for (int i = threadIdx.x; i < kN; i += 256) {
     if (bin < 0) { tb[i] = make_float2(0.f, 0.f); continue; }
@@ -519,7 +570,7 @@ struct lsdr_auto_notch {
   int mode;
   bool scan_started;
   notch_est *d_scarry[2]; int scarry_cur;     // estimators, ping-pong (a run reads one and writes the other)
-  int *d_bins;                                // [kMaxSlots] carried bins
+  int *d_bins;                                // [2][kMaxSlots] carried bins, ping-pong with d_scarry
   unsigned long long *d_offsets; float2 *d_spec; int *d_cand; int *d_ibins; unsigned char *d_reset; int *d_ifirst;
   size_t det_cap;                             // detect points the scratch above is sized for
   float2 *d_tables; size_t tables_cap;        // [(ndet+1)·nslots·4096]
@@ -705,8 +756,8 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
       LSDR_HIP(hipMalloc((void **)&a->d_scarry[i], sizeof(notch_est)));
       LSDR_HIP(hipMemcpyAsync(a->d_scarry[i], &a->est, sizeof(notch_est), hipMemcpyHostToDevice, c->stream));
     }
-    LSDR_HIP(hipMalloc((void **)&a->d_bins, kMaxSlots * sizeof(int)));
-    LSDR_HIP(hipMemcpyAsync(a->d_bins, a->bins, kMaxSlots * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    LSDR_HIP(hipMalloc((void **)&a->d_bins, 2 * kMaxSlots * sizeof(int)));   // ping-pong like d_scarry (same index)
+    for (int i = 0; i < 2; ++i) LSDR_HIP(hipMemcpyAsync(a->d_bins + i * kMaxSlots, a->bins, kMaxSlots * sizeof(int), hipMemcpyHostToDevice, c->stream));
     a->scarry_cur = 0; a->stamp = 0; a->scan_started = true;
   }
   // detect points of this run: `phase += 4096; if (phase >= decimation) { phase -= decimation; detect(); }` per block
@@ -747,38 +798,47 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     a->blocks_cap = nb;
     a->stamp = 0;
   }
-  // per-run argument arrays: pinned slot → device, in stream order
-  const int hs = a->h_slot;
-  a->h_slot ^= 1;
-  if (a->h_ev[hs]) LSDR_HIP(hipEventSynchronize(a->h_ev[hs]));
-  else LSDR_HIP(hipEventCreateWithFlags(&a->h_ev[hs], hipEventDisableTiming));
-  if (a->h_cap[hs] < ndet + 1) {
-    if (a->h_ifirst[hs]) (void)hipHostFree(a->h_ifirst[hs]);
-    if (a->h_offsets[hs]) (void)hipHostFree(a->h_offsets[hs]);
-    a->h_cap[hs] = ndet + 8;
-    LSDR_HIP(hipHostMalloc((void **)&a->h_ifirst[hs], (a->h_cap[hs] + 1) * sizeof(int), hipHostMallocDefault));
-    LSDR_HIP(hipHostMalloc((void **)&a->h_offsets[hs], a->h_cap[hs] * sizeof(unsigned long long), hipHostMallocDefault));
+  // estimators: the run reads d_scarry[cur] and writes the end state to d_scarry[nxt] — a copy made up front, so that the
+  // first wave-blocks (which read the start state in their look-back) never see the last one's update
+  const int cur = a->scarry_cur, nxt = cur ^ 1;
+  if (ndet <= (size_t)kArgMax) {
+    notch_run_args ra;
+    ra.n_ifirst = (int)ifirst.size(); ra.ndet = (int)ndet;
+    for (size_t i = 0; i < ifirst.size(); ++i) ra.ifirst[i] = ifirst[i];
+    for (size_t i = 0; i < ndet; ++i) ra.offs[i] = offs[i];
+    hipLaunchKernelGGL(k_notch_args, dim3(1), dim3(64), 0, c->stream, ra, a->d_ifirst, a->d_offsets, (const notch_est *)a->d_scarry[cur],
+                       a->d_scarry[nxt]);
+  } else {
+    // (a run with more detect points than fit the argument segment: pinned slot → device, in stream order)
+    const int hs = a->h_slot;
+    a->h_slot ^= 1;
+    if (a->h_ev[hs]) LSDR_HIP(hipEventSynchronize(a->h_ev[hs]));
+    else LSDR_HIP(hipEventCreateWithFlags(&a->h_ev[hs], hipEventDisableTiming));
+    if (a->h_cap[hs] < ndet + 1) {
+      if (a->h_ifirst[hs]) (void)hipHostFree(a->h_ifirst[hs]);
+      if (a->h_offsets[hs]) (void)hipHostFree(a->h_offsets[hs]);
+      a->h_cap[hs] = ndet + 8;
+      LSDR_HIP(hipHostMalloc((void **)&a->h_ifirst[hs], (a->h_cap[hs] + 1) * sizeof(int), hipHostMallocDefault));
+      LSDR_HIP(hipHostMalloc((void **)&a->h_offsets[hs], a->h_cap[hs] * sizeof(unsigned long long), hipHostMallocDefault));
+    }
+    memcpy(a->h_ifirst[hs], ifirst.data(), ifirst.size() * sizeof(int));
+    memcpy(a->h_offsets[hs], offs.data(), ndet * sizeof(unsigned long long));
+    LSDR_HIP(hipMemcpyAsync(a->d_ifirst, a->h_ifirst[hs], ifirst.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    LSDR_HIP(hipMemcpyAsync(a->d_offsets, a->h_offsets[hs], ndet * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    LSDR_HIP(hipEventRecord(a->h_ev[hs], c->stream));
+    LSDR_HIP(hipMemcpyAsync(a->d_scarry[nxt], a->d_scarry[cur], sizeof(notch_est), hipMemcpyDeviceToDevice, c->stream));
   }
-  memcpy(a->h_ifirst[hs], ifirst.data(), ifirst.size() * sizeof(int));
-  if (ndet) memcpy(a->h_offsets[hs], offs.data(), ndet * sizeof(unsigned long long));
-  LSDR_HIP(hipMemcpyAsync(a->d_ifirst, a->h_ifirst[hs], ifirst.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-  if (ndet) LSDR_HIP(hipMemcpyAsync(a->d_offsets, a->h_offsets[hs], ndet * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-  LSDR_HIP(hipEventRecord(a->h_ev[hs], c->stream));
   if (ndet) {
     int rc = cfft_dev_init(&a->fft, kN, true);
     if (rc) return rc;
-    const size_t lds = (size_t)kN * sizeof(float2);
-    hipLaunchKernelGGL(k_cfft, dim3((unsigned)ndet), dim3(1024), lds, c->stream, (const float2 *)in, (const float2 *)a->fft.d_om, a->d_spec,
-                       a->fft.logn, 1, (float)(1.0 / kN), (const unsigned long long *)a->d_offsets);
-    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)ndet), dim3(256), 0, c->stream, (const float2 *)a->d_spec, ns, a->d_cand);
+    hipLaunchKernelGGL(k_cfft_half, dim3((unsigned)(2 * ndet)), dim3(256), 0, c->stream, (const float2 *)in, (const float2 *)a->fft.d_om, a->d_spec,
+                       (const unsigned long long *)a->d_offsets);
+    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)ndet), dim3(256), 0, c->stream, (const float2 *)a->d_spec, (const float2 *)a->fft.d_om,
+                       (float)(1.0 / kN), ns, a->d_cand);
   }
-  hipLaunchKernelGGL(k_notch_plan, dim3(1), dim3(1), 0, c->stream, (const int *)a->d_cand, (int)ndet, ns, a->d_bins, a->d_ibins, a->d_reset);
-  hipLaunchKernelGGL(k_notch_tables, dim3((unsigned)((ndet + 1) * ns)), dim3(256), 0, c->stream, (const int *)a->d_ibins, ns, a->d_tables);
+  hipLaunchKernelGGL(k_notch_tables, dim3((unsigned)((ndet + 1) * ns)), dim3(256), 0, c->stream, (const int *)a->d_cand, (int)ndet, ns,
+                     (const int *)(a->d_bins + cur * kMaxSlots), a->d_bins + nxt * kMaxSlots, a->d_reset, a->d_tables);
   LSDR_HIP(hipGetLastError());
-  // estimators: the run reads d_scarry[cur] and writes the end state there too — through a copy, so that blocks 0..2 (which
-  // read the start state in their look-back) never see the last block's update
-  const int cur = a->scarry_cur, nxt = cur ^ 1;
-  LSDR_HIP(hipMemcpyAsync(a->d_scarry[nxt], a->d_scarry[cur], sizeof(notch_est), hipMemcpyDeviceToDevice, c->stream));
   notch_scan_args sa;
   sa.in = (const float2 *)in; sa.out = (float2 *)out; sa.tables = a->d_tables; sa.interval_first = a->d_ifirst; sa.reset = a->d_reset;
   sa.n_intervals = (int)ifirst.size(); sa.nslots = ns; sa.n_blocks = nb;
@@ -819,7 +879,7 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
 // refresh the host mirrors (bins, estimators) of a scan-mode notch
 static int notch_scan_pull(lsdr_auto_notch *a) {
   if (!a->scan_started) return LSDR_OK;
-  LSDR_HIP(hipMemcpyAsync(a->bins, a->d_bins, kMaxSlots * sizeof(int), hipMemcpyDeviceToHost, a->ctx->stream));
+  LSDR_HIP(hipMemcpyAsync(a->bins, a->d_bins + a->scarry_cur * kMaxSlots, kMaxSlots * sizeof(int), hipMemcpyDeviceToHost, a->ctx->stream));
   LSDR_HIP(hipMemcpyAsync(&a->est, a->d_scarry[a->scarry_cur], sizeof(notch_est), hipMemcpyDeviceToHost, a->ctx->stream));
   LSDR_HIP(hipStreamSynchronize(a->ctx->stream));
   return LSDR_OK;
