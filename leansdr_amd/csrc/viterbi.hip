@@ -24,8 +24,19 @@
 // 128 steps), and the best-state reduction is skipped when all 64 path registers already agree on
 // the output symbol.
 #include "lsdr_internal.h"
+#include <chrono>
 
 namespace {
+
+// LSDR_VIT_TIMING (debug hook): one stderr line per lsdr_viterbi_run call — wall time, number of launch → readback rounds and
+// the time spent waiting in them.
+struct vit_timing {
+  bool on; double t0, wait_ms; int rounds; unsigned tiles, fixups;
+  static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+  vit_timing() : wait_ms(0), rounds(0), tiles(0), fixups(0) { static const bool e = getenv("LSDR_VIT_TIMING") != nullptr; on = e; t0 = on ? now() : 0; }
+  ~vit_timing() { if (on && rounds) fprintf(stderr, "viterbi_run %.3f ms: %d rounds waited %.3f ms, %u tiles, %u fix-ups\n", now() - t0, rounds, wait_ms, tiles, fixups); }
+};
+#define VIT_SYNC(c, T) do { const double t__ = (T).on ? vit_timing::now() : 0; LSDR_TRY(lsdr_stage_sync(c)); if ((T).on) { (T).wait_ms += vit_timing::now() - t__; ++(T).rounds; } } while (0)
 
 constexpr int kChunkBlocks = 128;   // viterbi_sync::chunk_size, dvb.h:1229
 constexpr int kStates = 64;
@@ -493,6 +504,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
                      size_t *consumed, size_t *produced) {
   LSDR_ARG(v && consumed && produced);
   *consumed = 0; *produced = 0;
+  vit_timing vt;
   const vit_code &C = v->C;
   const size_t sym_per_chunk = (size_t)v->nshifts * kChunkBlocks;
   const size_t bytes_per_chunk = (size_t)C.bits_in * kChunkBlocks / 8;
@@ -515,12 +527,15 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
 
   // ---- jobs.  Current alignment: tiles of TL chunks (each starting kWarm chunks early) so that every
   // resync chunk is the FIRST chunk of a tile; other alignments: one sequential job each over the resync chunks.
-  unsigned TL = P >= 8 ? 8u : (unsigned)P;   // tile length divides the resync period when P ≥ 8
-  // Short inputs: shorter tiles put more wavefronts on an otherwise idle chip (a tile is one wavefront walking
-  // (kWarm + TL)·128 trellis steps; the output does not depend on the tiling).  Aim at two wavefronts per SIMD.
+  // Tile length (chunks): a tile is one wavefront walking (kWarm + TL)·128 trellis steps, kWarm of them thrown away, and the
+  // output does not depend on the tiling.  Long inputs take the longest tile that divides the resync period (≤ 32: a fifth
+  // of the work is warm-up at 16, a third at 8); short inputs take shorter tiles, which put more wavefronts on an otherwise
+  // idle chip.
+  unsigned TL = (unsigned)P;
+  if (P >= 8) { TL = 8; while (TL < 32 && P % (int)(TL * 2) == 0) TL *= 2; }
   {
     static const int forced = getenv("LSDR_VIT_TL") ? atoi(getenv("LSDR_VIT_TL")) : 0;   // tuning hook
-    const size_t want = (size_t)c->num_cu * 4 * 2;
+    const size_t want = (size_t)c->num_cu * 4 * 3 / 2;   // 1.5 wavefronts per SIMD keep the chip busy
     if (forced > 0) TL = (unsigned)forced;
     else while (TL > 1 && TL % 2 == 0 && chunks / TL < want) TL /= 2;
   }
@@ -552,7 +567,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   // stream" is tiled and verified like the main one; their tiles ride in the SAME launch as the main tiles (nothing in
   // them depends on the main alignment's results), after the main slots.
   const bool have_others = !rs.empty() && v->nsyncs > 1;
-  const unsigned TLo = 4;
+  // tile length of the other alignments (in resync chunks): 8 when that still leaves a thousand tiles (half the work is
+  // warm-up then, two thirds at 4)
+  const unsigned TLo = (size_t)(v->nsyncs - 1) * ((rs.size() + 7) / 8) >= 1024 ? 8u : 4u;
   // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
   // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in forty
   static const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook
@@ -608,6 +625,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   vit_state main_end;
   std::vector<vit_state> first_end(v->nsyncs);
   v->last_tiles = (unsigned)n_main; v->last_bad = 0;
+  vt.tiles = (unsigned)n_total;
   for (int round = 0;; ++round) {
     LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_total * sizeof(int), c->stream));
     if (n_total > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_total - 1)), dim3(64), 0, c->stream,
@@ -620,7 +638,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     for (size_t k = 0; k < n_first; ++k)
       if (k + 1 == n_first || first_others.which[k + 1] != first_others.which[k])
         LSDR_TRY(lsdr_stage_d2h(c, &first_end[first_others.which[k]], v->d_end + (n_main + k), sizeof(vit_state)));
-    LSDR_TRY(lsdr_stage_sync(c));
+    VIT_SYNC(c, vt);
     for (size_t k = 0; k < n_total; ++k) if (!seam[k]) bad[k] = 0;
     if (round >= 6) break;
     std::vector<vit_job> fj;
@@ -632,6 +650,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
       }
     if (fj.empty()) break;
     v->last_bad += (unsigned)fj.size();
+    vt.fixups += (unsigned)fj.size();
     rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_total);
     if (rc) return rc;
   }
@@ -648,7 +667,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     std::vector<vit_state> ends(n_main);
     LSDR_TRY(lsdr_stage_d2h(c, ends.data(), v->d_end, n_main * sizeof(vit_state)));
     LSDR_TRY(lsdr_stage_d2h(c, main_first.data(), v->d_first, n_main * sizeof(vit_state)));
-    LSDR_TRY(lsdr_stage_sync(c));
+    VIT_SYNC(c, vt);
     std::vector<vit_state> keep = v->states;
     v->states[cur] = ends[first_bad - 1];
     vit_job j;
@@ -662,7 +681,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     LSDR_TRY(lsdr_stage_d2h(c, tot.data(), v->d_totals, j.n_chunks * sizeof(int)));
     LSDR_TRY(lsdr_stage_d2h(c, cst.data(), v->d_chunk, j.n_chunks * sizeof(vit_state)));
     LSDR_TRY(lsdr_stage_d2h(c, &main_end, v->d_end, sizeof(vit_state)));
-    LSDR_TRY(lsdr_stage_sync(c));
+    VIT_SYNC(c, vt);
     v->states = keep;
     // splice the sequential results back into the per-tile bookkeeping
     for (size_t t = first_bad; t < n_main; ++t) {
@@ -722,7 +741,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
           std::vector<vit_state> fe(fj.size());
           LSDR_TRY(lsdr_stage_d2h(c, ftot.data(), v->d_totals, ftot.size() * sizeof(int)));
           LSDR_TRY(lsdr_stage_d2h(c, fe.data(), v->d_end, fj.size() * sizeof(vit_state)));
-          LSDR_TRY(lsdr_stage_sync(c));
+          VIT_SYNC(c, vt);
           for (size_t i = 0; i < badk.size(); ++i) {
             const size_t k = badk[i];
             start_used[k] = starts[i];
@@ -747,7 +766,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
         cst.resize(J.oj.size() * J.ostride);
         LSDR_TRY(lsdr_stage_d2h(c, cst.data(), v->d_chunk, cst.size() * sizeof(vit_state)));
       }
-      LSDR_TRY(lsdr_stage_sync(c));
+      VIT_SYNC(c, vt);
       return finish_others(sequential, J, tot, J.ostride, hb, he, cst);
     };
     // the tiles that rode in the main launch are verified already; an alignment with a seam that never settled goes sequential
