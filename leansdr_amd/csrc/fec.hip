@@ -253,7 +253,6 @@ __global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsign
     // then thread 0 replays the per-packet bookkeeping (sync byte test, lock_timeleft, phase8) over the batch and cuts
     // it where the reference would have dropped the lock.  Same bytes, same events; two barriers per batch, not per packet.
     constexpr unsigned kBatch = 64;
-    __shared__ unsigned s_valid;
     while (!s_stop) {
       if (n_in - pos < (unsigned long long)kRS + 1 || cap - nout < (unsigned long long)kRS) break;
       unsigned long long P = (n_in - pos - 1) / kRS;
@@ -290,7 +289,6 @@ __global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsign
             break;
           }
         }
-        s_valid = p;
         pos += (unsigned long long)p * kRS; nout += (unsigned long long)p * kRS;
       }
       __syncthreads();
@@ -546,7 +544,6 @@ __global__ __launch_bounds__(1024) void k_derand_scan(const unsigned char *in, u
   __shared__ unsigned s_cnt[16];
   __shared__ int carry_last, carry_pos;   // last reset before this segment (absolute index) or -1 with pos0 at index 0
   __shared__ unsigned long long carry_cnt;
-  __shared__ int s_last_seg[SEG / PER];
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (tid == 0) { carry_last = -1; carry_pos = pos0; carry_cnt = 0; }
   for (unsigned base = 0; base < n_packets; base += SEG) {
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(256) void k_derand_apply(const unsigned char *in, u
 
 // ============================================================================ host side
 namespace {
-int log2u(unsigned long long x) { int n = -1; for (; x; ++n, x >>= 1); return n; }
+int log2u(unsigned long long x) { int n = -1; while (x) { ++n; x >>= 1; } return n; }
 int hpar(unsigned long long x) { return __builtin_parityll(x); }
 
 struct deconv_host {

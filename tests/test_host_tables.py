@@ -30,3 +30,17 @@ def test_filtergen(capi, oracle):
     for order, fs, ro in [(41, 0.25, 0.35), (64, 0.25, 0.25), (100, 0.5, 0.2), (33, 1 / 3.0, 0.35)]:
         assert bits_equal(capi.root_raised_cosine(order, np.float32(fs), np.float32(ro)),
                           oracle.rrc(order, np.float32(fs), np.float32(ro)))
+
+
+def test_bench_more_lists_every_secondary_configuration():
+    """(CPU) bench.py's `more` object is built from bench_more.run_all's list: every entry must be a function of the module
+    (a typo would only show up on the GPU box, after the headline has been measured)."""
+    import ast, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tree = ast.parse(open(os.path.join(root, "bench_more.py")).read())
+    funcs = {n.name for n in tree.body if isinstance(n, ast.FunctionDef)}
+    run_all = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "run_all")
+    names = [(e.elts[0].value, e.elts[1].id) for n in ast.walk(run_all) if isinstance(n, ast.Tuple) for e in [n]
+             if len(n.elts) == 2 and isinstance(n.elts[0], ast.Constant) and isinstance(n.elts[1], ast.Name)]
+    assert len(names) >= 9 and all(f in funcs for _, f in names)
+    assert {"single_stream", "anf1", "c2_offset", "c3", "c5_rescoped", "c1_hs", "exact_batch", "end_to_end"} <= {k for k, _ in names}
