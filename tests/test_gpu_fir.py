@@ -175,3 +175,18 @@ def test_run_multi_equals_separate_runs(capi, ctx, oracle):
     for d in dins + douts:
         d.free()
     f.close()
+
+
+@pytest.mark.parametrize("d,nt", [(1, 9), (2, 23), (4, 40), (5, 61), (8, 65), (10, 101), (16, 161), (30, 313)])
+def test_long_inputs_all_specialised_decimations(capi, ctx, oracle, d, nt):
+    """A million samples through every compile-time-D kernel (R = 4 / 2 / 1 outputs per lane): many tiles per persistent
+    workgroup, prefetch running ahead across tiles, the tail tile — bit for bit the oracle's output."""
+    rng = np.random.default_rng(5)
+    n = 4096 * 260
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 12).astype(np.complex64)
+    co = capi.lowpass(nt - 1, 0.4 / d)
+    f = capi.FirFilter(ctx, co, d)
+    y, cons = f.run(x)
+    f.close()
+    ref, rcons = oracle.fir_filter(co, d, x)
+    assert cons == rcons and bits_equal(y, ref)
