@@ -28,13 +28,27 @@ if repeat > 1:
                 f.write(data)
     path = rpath
 n = os.path.getsize(path) // 2
-app = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
+which = "own"
+for w in ("--ref-graph", "--ref-cpu"):      # the reference's leandvb.cc on this repo's headers (GPU blocks) / the reference's CPU binary
+    if w in flags:
+        flags.remove(w); which = w
+env = dict(os.environ)
+if which == "--ref-graph":
+    app = os.path.join(ROOT, "leansdr_amd", "host", "ref_graph", "leandvb")
+    if "--tiled" in flags:
+        flags.remove("--tiled"); env["LSDR_TILED"] = "1"
+    flags += ["--buf-factor", "4096"]
+elif which == "--ref-cpu":
+    app = os.path.join(ROOT, "oracle", "_ref", "leandvb")
+    flags = [f for f in flags if f != "--tiled"]
+else:
+    app = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
 cmd = [app, "--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"] + flags
 t0 = time.perf_counter()
 with open(path, "rb") as f:
-    p = subprocess.run(cmd, stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.run(cmd, stdin=f, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
 dt = time.perf_counter() - t0
 ts = np.frombuffer(p.stdout, np.uint8).reshape(-1, 188)
 cnt = ts[:, 1].astype(int) * 65536 + ts[:, 2].astype(int) * 256 + ts[:, 3] if len(ts) else np.array([])
-print(f"{' '.join(flags) or '(default)'}: {n} samples in {dt:.3f} s = {n/dt/1e6:.1f} MS/s wall (incl. process start, file read, H2D/D2H); "
+print(f"[{which}] {' '.join(flags) or '(default)'}: {n} samples in {dt:.3f} s = {n/dt/1e6:.1f} MS/s wall (incl. process start, file read, H2D/D2H); "
       f"{len(ts)} TS packets, {int((np.diff(cnt)==1).sum()) if len(cnt)>1 else 0} consecutive; rc={p.returncode} {p.stderr.decode()[-200:]}")
