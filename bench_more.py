@@ -18,6 +18,7 @@ own roofline.  N=1 only.
                  side stream, double-buffered), C2 (cf32, 8 B/sample) and a C1-shaped cu8 stream (2 B/sample).
 """
 import ctypes as C
+import json
 import os
 import sys
 import time
@@ -125,13 +126,21 @@ def anf1(capi, synth, device, args):
         notch_ms.append(ctx_n.event_elapsed_ms(e[0], e[1])); fir_ms.append(pipe.ctx.event_elapsed_ms(e[2], e[3]))
     nms = float(np.mean(notch_ms))
     alg = nblk * 4096 * 16
+    n_traffic = n_traffic_src = None
+    try:      # recorded, not measured in this run (separate rocprofv3 --pmc passes of the kernel alone, per sample)
+        rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_bench", "notch_scan_pmc_traffic.json")))
+        n_traffic = int(rec["traffic_bytes_per_sample"] * nblk * 4096)
+        n_traffic_src = "recorded, not measured in this run: profiles/r02_bench/notch_scan_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE of the kernel alone, scaled per sample)"
+    except Exception:
+        pass
     out = dict(value=round(nb * g["B"] / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), notch_bin=notch.bins(),
                interferer="CW at 0.0137 cycles/sample, 3x the signal amplitude", fir_filter_avg_launch_ms=round(float(np.mean(fir_ms)), 4),
                auto_notch_run_avg_ms=round(nms, 4),
                pipeline_hbm_bytes_per_sample=24, pipeline_hbm_frac=round(nb * g["B"] * 24 / dt / 1e9 / bench.HBM_PEAK_GBS, 4),
                roofline={"kernel": "k_notch_scan (auto_notch, 1 slot)", "bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 2),
                          "peak": bench.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / (kms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4),
-                         "avg_launch_ms": round(kms, 4), "launches_timed": klaunches, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                         "avg_launch_ms": round(kms, 4), "launches_timed": klaunches, "algorithmic_bytes_per_launch": alg,
+                         "traffic": n_traffic, "traffic_source": n_traffic_src,
                          "note": "HIP events around the k_notch_scan launch on its stream (lsdr_auto_notch_scan_time), fir_filter and the "
                                  "receiver running next to it; auto_notch_run_avg_ms is the whole run incl. the batched detect FFTs / "
                                  "peak search / table build"})
