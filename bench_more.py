@@ -453,10 +453,11 @@ def c5_rescoped(capi, synth, device, args):
                       "8PSK 2/3 @ 4 sps cf32 (30 MS/s symbols = 120 MS/s input): cstln_receiver(PSK8, tiled) -> viterbi_sync(2/3) -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer")
 
 
-def c1_hs(capi, synth, device, args):
-    """BASELINE config 1's shape, device-resident, on the reference's own "maximum throughput" receiver:
-    cu8 IQ at 1.2 samples/symbol (2 B/sample) → fast_qpsk_receiver<u8> (tiled) → dvb_deconvol_sync<u8> → mpeg_sync →
-    deinterleaver → rs_decoder → derandomizer, TS checked against the transmitted packet sequence."""
+def c1(capi, synth, device, args, hs=False):
+    """BASELINE config 1's shape (QPSK 1/2, cu8 IQ at 1.2 samples/symbol, 2 B/sample), device-resident, TS checked against the
+    transmitted packet sequence.  Default chain (leandvb.cc:205-600 without options): cconverter<u8> → cstln_receiver (linear
+    sampler, tiled) → deconvol_sync → mpeg_sync → deinterleaver → rs_decoder → derandomizer; hs: the reference's "maximum
+    throughput" receiver (SURVEY §8(f) rank 1): fast_qpsk_receiver<u8> (tiled) → dvb_deconvol_sync<u8> → the same tail."""
     lib = capi.lib
     ctx = capi.Ctx(device)
     groups = 5
@@ -472,12 +473,18 @@ def c1_hs(capi, synth, device, args):
         capi.check(lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * P * 2), dp.ptr, P * 2))
     capi.check(lib.lsdr_memcpy_d2d(ctx.h, d_in.at((reps + 2) * P * 2), dp.ptr, extra * 2))
     ctx.sync(); dp.free()
-    rx = capi.FastQpsk(ctx, 1.2)
-    dec = capi.HsDeconv(ctx)
+    if hs:
+        rx = capi.FastQpsk(ctx, 1.2)
+        dec = capi.HsDeconv(ctx)
+    else:
+        rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, fec=capi.FEC12, omega=1.2, meas_decimation=1 << 22)
+        rx = capi.CstlnReceiver(ctx, mode=capi.RX_SERIAL, **rx_kw)
+        dec = capi.Deconv(ctx, capi.FEC12)
+        d_cf = ctx.alloc((B + extra) * 8)
     msync = capi.MpegSync(ctx)
     derand = capi.Derandomizer(ctx)
     sym_cap = int(B / 1.2 * 1.05) + 65536
-    p_sym = DevPipe(capi, ctx, 1, 2 * sym_cap)
+    p_sym = DevPipe(capi, ctx, 1 if hs else 4, 2 * sym_cap)
     p_bytes = DevPipe(capi, ctx, 1, sym_cap // 4)
     p_mpeg = DevPipe(capi, ctx, 1, sym_cap // 4)
     pk_cap = sym_cap // 8 // 204 + 64
@@ -489,7 +496,12 @@ def c1_hs(capi, synth, device, args):
     def batch(keep, n=None):
         t0 = time.perf_counter()
         p_sym.room(sym_cap)
-        c, p = rx.run_dev(d_in.at(pos[0] * 2), (n or B) + extra, p_sym.wr(), p_sym.room(0))
+        if hs:
+            c, p = rx.run_dev(d_in.at(pos[0] * 2), (n or B) + extra, p_sym.wr(), p_sym.room(0))
+        else:
+            capi.check(lib.lsdr_cconverter_u8_run(ctx.h, d_in.at(pos[0] * 2), (n or B) + extra, d_cf.ptr))
+            o = rx.run_dev(d_cf.ptr, (n or B) + extra, p_sym.wr(), p_sym.room(0), meas=False)
+            c, p = o["consumed"], o["produced"]
         assert c > 0
         pos[0] = (pos[0] + c) % P
         p_sym.push(p)
@@ -524,7 +536,13 @@ def c1_hs(capi, synth, device, args):
         return c
 
     batch(False, n=1 << 20)            # acquisition: the exact serial loop on the head of the stream
-    rx.set_tiled(1, 0, 0)
+    if hs:
+        rx.set_tiled(1, 0, 0)
+    else:
+        st = rx.state()
+        rx.close()
+        rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=max(args.tile_warmup, 512), **rx_kw)
+        rx.set_state(st)
     for _ in range(2):
         batch(False)
     nb = 12
@@ -548,17 +566,24 @@ def c1_hs(capi, synth, device, args):
             else:
                 bad += 1
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3),
-               chain="QPSK 1/2 @ 1.2 sps cu8 (2 B/sample): fast_qpsk_receiver<u8>(tiled) -> dvb_deconvol_sync<u8> -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
+               chain="QPSK 1/2 @ 1.2 sps cu8 (2 B/sample): " + ("fast_qpsk_receiver<u8>(tiled) -> dvb_deconvol_sync<u8>" if hs else
+                                                                "cconverter<u8> -> cstln_receiver(tiled) -> deconvol_sync")
+                     + " -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                symbols_per_s=round(consumed / 1.2 / dt / 1e6, 3), ts_packets=int(len(got)), ts_packets_per_s=round(len(got) / dt, 1),
                ts_check={"packets_equal_to_the_transmitted_sequence": ok, "different": bad, "pass": bool(bad == 0 and ok > 8)},
                rs_byte_errors_corrected=errs[0], rx_tiles=rx.tiled_stats(), host_seconds_per_stage={k: round(v, 4) for k, v in stage_s.items()},
-               cpu_reference_one_core_MSps=29.7, mode="synchronous per batch (every block returns data-dependent counts)")
+               cpu_reference_one_core_MSps=29.7 if hs else 17.6, mode="synchronous per batch (every block returns data-dependent counts)")
     for p_ in (p_sym, p_bytes, p_mpeg):
         p_.free()
-    for d in (d_in, d_rs, d_rts, d_ts):
+    for d in (d_in, d_rs, d_rts, d_ts) + (() if hs else (d_cf,)):
         d.free()
     rx.close(); dec.close(); msync.close(); derand.close(); ctx.close()
     return out
+
+
+
+def c1_hs(capi, synth, device, args):
+    return c1(capi, synth, device, args, hs=True)
 
 
 def exact_batch(capi, synth, device, args):
@@ -666,7 +691,7 @@ def end_to_end(capi, synth, device, args):
 def run_all(capi, synth, device, args):
     more = {}
     for name, fn in (("single_stream", single_stream), ("anf1", anf1), ("c2_offset", c2_offset), ("c2_fma", c2_fma), ("c3", c3),
-                     ("c5_rescoped", c5_rescoped), ("c1_hs", c1_hs), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
+                     ("c5_rescoped", c5_rescoped), ("c1", c1), ("c1_hs", c1_hs), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
         t0 = time.perf_counter()
         try:
             more[name] = fn(capi, synth, device, args)
