@@ -541,7 +541,8 @@ def c1(capi, synth, device, args, hs=False):
     else:
         st = rx.state()
         rx.close()
-        rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=max(args.tile_warmup, 512), **rx_kw)
+        rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_C1_TILE", 4 * args.tile_len)),
+                                tile_warmup=max(args.tile_warmup, 512), **rx_kw)
         rx.set_state(st)
     for _ in range(2):
         batch(False)
