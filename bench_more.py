@@ -268,7 +268,8 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=cstln, fec=rate, omega=omega, meas_decimation=1 << 22, pll_adjustment=1 / 6.0)
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0) if use_fir else None
     d_dec = ctx.alloc((n_out + bench.EXTRA) * 8) if use_fir else None
-    rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=args.tile_len, tile_warmup=max(args.tile_warmup, 512), **rx_kw)
+    rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_CHAIN_TILE", 4 * args.tile_len)),
+                            tile_warmup=max(args.tile_warmup, 512), **rx_kw)
     # The FEC tail lives on its own context (stream) and its own host thread: every block of it returns data-dependent counts
     # (a host synchronisation per call), so the only way to keep the front end busy meanwhile is a second thread — the
     # C ABI is thread-safe per context and ctypes releases the GIL.  Two symbol buffers go back and forth between the threads.
