@@ -592,7 +592,7 @@ def exact_batch(capi, synth, device, args):
     import bench
     po = bench._oracle()
     ctx = capi.Ctx(device)
-    n_streams, n = 8192, 128 * 2048 + 1
+    n_streams, n = int(os.environ.get("LSDR_EXACT_STREAMS", 65536)), 128 * 2048 + 1
     pool_n = 32 << 20
     x, _ = synth.qpsk_baseband(4 * (1 << 20), 4, seed=21, rms=50.0, snr_db=15.0)
     d_pool = ctx.alloc((pool_n + n) * 8)
@@ -620,7 +620,9 @@ def exact_batch(capi, synth, device, args):
     ok = bool(cons == n - 1 and ref["consumed"] == cons and len(g) == len(ref["sym"]) and g["cost"].tobytes() == ref["sym"]["cost"].tobytes() and g["symbol"].tobytes() == ref["sym"]["symbol"].tobytes())
     out = dict(value=round(n_streams * cons / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures=n_streams, samples_per_capture=cons,
                per_capture_MSps=round(cons / dt / 1e6, 3), symbols=int(sum(prod)), capture0_bit_exact_vs_oracle=ok,
-               note="decimated-domain captures (4 samples/symbol cf32), exact arithmetic per lane; 64 captures per wavefront")
+               note="decimated-domain captures (4 samples/symbol cf32), exact arithmetic per lane; 64 captures per wavefront, i.e. one "
+                    "wavefront per SIMD at 65 536 captures (8 192: 32 GS/s, 32 768: 120, 65 536: 179, 131 072: 128 — the 36 GB of "
+                    "symbol output no longer stay cached)")
     b.close(); d_pool.free(); d_out.free(); ctx.close()
     return out
 
