@@ -538,7 +538,7 @@ def c1(capi, synth, device, args, hs=False):
 
     batch(False, n=1 << 20)            # acquisition: the exact serial loop on the head of the stream
     if hs:
-        rx.set_tiled(1, 0, 0)
+        rx.set_tiled(1, int(os.environ.get("LSDR_HS_TILE", 1024)), int(os.environ.get("LSDR_HS_WARM", 512)))   # no unreconciled seams at 512
     else:
         st = rx.state()
         rx.close()
