@@ -384,7 +384,7 @@ void lsdr_fastqpsk_destroy(lsdr_fastqpsk *r);
 int lsdr_fastqpsk_get_state(const lsdr_fastqpsk *r, float *mu, unsigned *phase, long long *freqw, long long *min_freqw,
                             long long *max_freqw);
 /* throughput mode (time-tiled like LSDR_RX_TILED; not bit-exact at the symbol level, no FREQ/constellation reports);
- * tile_len / tile_warmup in samples (multiples of 128), 0 = defaults (≈ 192 symbols of warm-up, tiles twice that) */
+ * tile_len / tile_warmup in samples (multiples of 128), 0 = defaults (≈ 400 symbols of warm-up, tiles twice that) */
 int lsdr_fastqpsk_set_tiled(lsdr_fastqpsk *r, int enable, unsigned tile_len, unsigned tile_warmup);
 int lsdr_fastqpsk_tiled_stats(const lsdr_fastqpsk *r, unsigned *tiles, unsigned *dup, unsigned *miss, unsigned *bad_seams);
 int lsdr_fastqpsk_run(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,

@@ -462,9 +462,12 @@ int lsdr_fastqpsk_tiled_stats(const lsdr_fastqpsk *r, unsigned *tiles, unsigned 
 static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8_t *out, size_t cap_out, size_t *consumed,
                         size_t *produced, const fq_args &sa) {
   lsdr_ctx *c = r->ctx;
-  // default warm-up ≈ 192 symbols: the integer loops of this receiver settle more slowly than cstln_receiver's (TS yield
-  // of the 8000-packet chain: 107 symbols → 36 re-syncs, 213 and more → none; tools/chain_bench.py --hs --tiled)
-  unsigned Wc = r->tile_warmup ? r->tile_warmup / kChunk : (unsigned)((192.0f * r->omega + kChunk - 1) / kChunk);
+  // default warm-up ≈ 400 symbols: the integer loops of this receiver settle more slowly than cstln_receiver's.  TS yield of
+  // the 8000-packet chain: 107 symbols → 36 re-syncs, 213 and more → none (tools/chain_bench.py --hs --tiled); but at 213
+  // (256 samples at 1.2 samples/symbol) 0.65 % of the seams still lose a symbol that the RS decoder then repairs, at 427
+  // (512 samples) none does (bench_more.py c1_hs: 64 698 tiles, no RS correction) — and the longer tiles that go with it
+  // are faster (17.4 against 16.0 GS/s).
+  unsigned Wc = r->tile_warmup ? r->tile_warmup / kChunk : (unsigned)((400.0f * r->omega + kChunk - 1) / kChunk);
   if (Wc < 1) Wc = 1;
   const unsigned Lc = r->tile_len ? r->tile_len / kChunk : 2 * Wc;
   const unsigned sym_per_chunk = (unsigned)(kChunk / (r->omega - 0.1f)) + 2;   // mu advances by ≥ omega − 0.1 per symbol
