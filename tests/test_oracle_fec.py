@@ -158,3 +158,33 @@ def test_end_to_end_vs_leandvb_binary(oracle, ref):
                          pll_adjustment=(1 / 6.0 if vit else 1.0))
         got = oracle.fec_chain(oracle.rx(p, x)["sym"], 1, 0, vit)[0]
         assert len(want) > 50 and bits_equal(got, want)
+
+
+def _framed_stream(bitshift, invert):
+    """The stream of tests/test_gpu_fec.py::test_mpeg_sync_long_locked_runs_vs_oracle: 6000 framed packets with isolated sync
+    misses, three in a row (lock kept), four / nine / six in a row (lock lost, re-acquired), behind 777 random bytes, delayed by
+    `bitshift` bits, optionally inverted."""
+    rng = np.random.default_rng(100 + bitshift)
+    pk = rng.integers(0, 256, (6000, 204)).astype(np.uint8)
+    pk[:, 0] = 0x47
+    pk[0::8, 0] = 0xB8
+    for i in (70, 333, 2049):
+        pk[i, 0] ^= 0x10
+    pk[1000:1003, 0] ^= 0xff
+    pk[2501:2505, 0] = 0
+    pk[4000:4009, 0] = 0x11
+    pk[5993:5999, 0] = 0x22
+    s = np.concatenate([rng.integers(0, 256, 777).astype(np.uint8), pk.reshape(-1)])
+    s = np.packbits(np.concatenate([np.zeros(bitshift, np.uint8), np.unpackbits(s)]))
+    return s ^ np.uint8(0xff) if invert else s
+
+
+@pytest.mark.parametrize("bitshift,invert", [(0, False), (3, False), (5, True), (7, False)])
+def test_mpeg_sync_long_locked_runs_pinned_to_the_reference(oracle, ref, bitshift, invert):
+    """(CPU) the oracle's mpeg_sync on long locked runs with lock losses in the middle is the compiled reference's, byte for byte,
+    lock events and lock times included — the GPU's chip-wide locked path is tested against exactly this oracle output."""
+    s = _framed_stream(bitshift, invert)
+    for fl in (0, 1):
+        x, y = oracle.mpeg_sync(s, fl), ref.mpeg_sync(s, fl)
+        assert len(x[0]) > 5000 * 204
+        assert bits_equal(x[0], y[0]) and x[1].tolist() == y[1].tolist() and x[2].tolist() == y[2].tolist()
