@@ -120,3 +120,17 @@ def test_cstln_receiver_fir_sampler(oracle, ref, sig):
 def test_rotator(oracle, ref, sig):
     for f in (0.01, -0.123, 0.4999, 1e-5):
         assert bits_equal(oracle.rotator(sig, f, splits=(7, 3000)), ref.rotator(sig, f))
+
+
+@pytest.mark.parametrize("nslots", [1, 2, 3])
+def test_auto_notch_long_interferer_stream_pinned(oracle, ref, nslots):
+    """(CPU) the stream the GPU's scan-mode notch is held against (tests/test_gpu_notch.py::test_scan_mode_vs_oracle: three CW
+    interferers on noise, 300 blocks, detect every 100): the oracle's output and bins are the compiled reference's, bit for bit."""
+    rng = np.random.default_rng(11)
+    n = 4096 * 300
+    t = np.arange(n)
+    x = ((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 12 + 70 * np.exp(2j * np.pi * 0.0713 * t)
+         + 40 * np.exp(-2j * np.pi * 0.27 * t) + 25 * np.exp(2j * np.pi * 0.4 * t)).astype(np.complex64)
+    a, ba = oracle.auto_notch(x, nslots, 4096 * 100)
+    b, bb = ref.auto_notch(x, nslots, 4096 * 100)
+    assert ba == [int(v) for v in bb] and bits_equal(a, b)
