@@ -47,3 +47,13 @@ def test_product_does_not_touch_oracle():
                 if re.search(r"pyoracle|lsdr_oracle|oracle/|liblsdr_oracle|_ref/", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/lsdr_hip.h is the C-ABI boundary: it must compile as C (gcc, no C++/HIP types) on its own."""
+    import subprocess
+    src = tmp_path / "h.c"
+    src.write_text('#include "lsdr_hip.h"\nint main(void) { return LSDR_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
