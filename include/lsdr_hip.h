@@ -249,6 +249,10 @@ typedef struct {
   int mode;                  /* LSDR_RX_* */
   unsigned tile_len;         /* LSDR_RX_TILED: samples per tile (multiple of 128); 0 = default (twice the warm-up) */
   unsigned tile_warmup;      /* LSDR_RX_TILED: warm-up samples before each tile (multiple of 128); 0 = default (≈ 64 symbols) */
+  int in_format;             /* LSDR_IN_CF32 (0, the reference's block) or LSDR_IN_CU8: the cconverter<u8,128,f32,0,1,1> in front
+                              * of the receiver in the `leandvb --u8` graph (leandvb.cc:211-217, dsp.h:40-50) fused into the
+                              * receiver's loads — `in` then points to lsdr_cu8 items and the converted cf32 stream never exists
+                              * in HBM; results are bit-identical to running the two blocks separately */
 } lsdr_rx_cfg;
 typedef struct {             /* the receiver's loop state, sdr.h:923-935 */
   float mu, phase, freqw, agc_gain, est_insp, est_sp, est_ep, freq_tap;
@@ -270,7 +274,7 @@ int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsign
  * outputs have room).  freq/ss/mer (meas_cap floats each, HOST pointers, may be
  * NULL) receive one value per meas_decimation samples; cstln_out_host (may be
  * NULL) one cf32 per chunk that produced a symbol.  Synchronous. */
-int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+int lsdr_rx_run(lsdr_rx *r, const void *in /* n_in items of cfg.in_format */, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                 size_t *consumed, size_t *produced,
                 float *freq_out_host, float *ss_out_host, float *mer_out_host, size_t meas_cap, size_t *n_meas,
                 lsdr_cf32 *cstln_out_host, size_t cstln_cap, size_t *n_cstln);
@@ -278,7 +282,7 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
  * returns at once with `consumed` (a pure function of the sizes); lsdr_rx_wait() retires the oldest queued run and
  * yields its symbol count.  Up to 8 runs may be queued; the loop state is carried on the device from run to run, so
  * the host never sits between two runs.  lsdr_rx_run / _set_state refuse to mix with outstanding queued runs. */
-int lsdr_rx_run_async(lsdr_rx *rx, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
+int lsdr_rx_run_async(lsdr_rx *rx, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
 int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
 /* freq_tap (sdr.h:919-921, cycles per sample) as of the end of the most recently retired queued run: lets the caller keep
  * fir_filter tracking the carrier (lsdr_fir_filter_track, dsp.h:236-244) from runs that have already completed while later
@@ -295,7 +299,7 @@ float lsdr_rx_retired_freq_tap(const lsdr_rx *rx);
 typedef struct lsdr_rx_batch lsdr_rx_batch;
 int lsdr_rx_batch_create(lsdr_ctx *ctx, const lsdr_rx_cfg *cfg, unsigned n_streams, lsdr_rx_batch **b);
 void lsdr_rx_batch_destroy(lsdr_rx_batch *b);
-int lsdr_rx_batch_run(lsdr_rx_batch *b, const lsdr_cf32 *const *in_dev, size_t n_in, lsdr_softsymbol *const *out_dev, size_t cap_out,
+int lsdr_rx_batch_run(lsdr_rx_batch *b, const void *const *in_dev, size_t n_in, lsdr_softsymbol *const *out_dev, size_t cap_out,
                       size_t *consumed, size_t *produced /*[n_streams]*/);
 int lsdr_rx_batch_get_state(lsdr_rx_batch *b, unsigned stream, lsdr_rx_state *st);
 /* LSDR_RX_TILED, QPSK: whether the tolerance tiles take their decisions by arithmetic instead of the constellation-table

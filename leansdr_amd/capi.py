@@ -41,7 +41,7 @@ class RxCfg(C.Structure):
     _fields_ = [("sampler", C.c_int), ("ncoeffs", C.c_int), ("coeffs_host", vp), ("subsampling", C.c_int),
                 ("cstln", C.c_int), ("fec", C.c_int), ("harden", C.c_int), ("omega", c_f), ("freq", c_f),
                 ("pll_adjustment", c_f), ("allow_drift", C.c_int), ("meas_decimation", C.c_ulong),
-                ("kest", c_f), ("mode", C.c_int), ("tile_len", C.c_uint), ("tile_warmup", C.c_uint)]
+                ("kest", c_f), ("mode", C.c_int), ("tile_len", C.c_uint), ("tile_warmup", C.c_uint), ("in_format", C.c_int)]
 
 
 class RxState(C.Structure):
@@ -449,9 +449,11 @@ class CstlnReceiver:
 
     def __init__(self, ctx, sampler=SAMP_LINEAR, coeffs=None, subsampling=1, cstln=QPSK, fec=FEC12, harden=0,
                  omega=4.0, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=1048576, kest=0.01,
-                 mode=RX_SERIAL, tile_len=0, tile_warmup=0):
+                 mode=RX_SERIAL, tile_len=0, tile_warmup=0, in_format=0):
+        """in_format = IN_CU8: cconverter<u8,128,f32,0,1,1> fused into the receiver's loads (input = cu8 items)."""
         self.ctx = ctx
         cfg = RxCfg()
+        cfg.in_format = in_format
         cfg.sampler = sampler
         if coeffs is not None:
             self.coeffs = np.ascontiguousarray(coeffs, np.float32)
@@ -536,7 +538,11 @@ class CstlnReceiver:
         return dict(consumed=cons.value, produced=prod.value)
 
     def run(self, x, meas=True):
-        x = np.ascontiguousarray(x, np.complex64)
+        """x: complex64 samples, or (in_format = IN_CU8) a uint8 array of interleaved re, im."""
+        if self.cfg.in_format == IN_CU8:
+            x = np.ascontiguousarray(x, np.uint8).reshape(-1, 2)
+        else:
+            x = np.ascontiguousarray(x, np.complex64)
         cap = len(x) + 256
         din = self.ctx.upload(x)
         dout = self.ctx.alloc(cap * 4)
@@ -551,9 +557,10 @@ class RxBatch:
     """Exact cstln_receiver<f32>, one GPU lane per independent capture (lsdr_rx_batch_*)."""
 
     def __init__(self, ctx, n_streams, sampler=SAMP_LINEAR, cstln=QPSK, fec=FEC12, omega=4.0, freq=0.0, pll_adjustment=1.0,
-                 allow_drift=0, meas_decimation=1048576, kest=0.01):
+                 allow_drift=0, meas_decimation=1048576, kest=0.01, in_format=0):
         self.ctx, self.n = ctx, n_streams
         cfg = RxCfg()
+        cfg.in_format = in_format
         cfg.sampler, cfg.cstln, cfg.fec = sampler, cstln, fec
         cfg.omega, cfg.freq, cfg.pll_adjustment = omega, freq, pll_adjustment
         cfg.allow_drift, cfg.meas_decimation, cfg.kest = allow_drift, meas_decimation, kest

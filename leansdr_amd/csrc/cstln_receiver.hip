@@ -105,6 +105,64 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {  // math.h:40-43
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// ---- input sample streams --------------------------------------------------------------------------------------------
+// The receiver reads either the reference's cf32 items or — LSDR_IN_CU8, the leandvb --u8 graph (leandvb.cc:211-217) with
+// cconverter<u8,128,f32,0,1,1> fused into the load — cu8 items converted exactly as dsp.h:40-50 does it:
+// out = 0 + ((int)in − 128)·1/1 in int, then → float (exact).  The converted cf32 stream never exists in HBM.
+__device__ __forceinline__ float2 cu8_to_cf32(unsigned re, unsigned im) {
+  return make_float2((float)((int)re - 128), (float)((int)im - 128));
+}
+struct in_cf32 {
+  const float2 *p;
+  __device__ __forceinline__ float2 operator[](long long i) const { return p[i]; }
+  __device__ __forceinline__ in_cf32 operator+(long long k) const { in_cf32 r; r.p = p + k; return r; }
+};
+struct in_cu8 {
+  const uchar2 *p;
+  __device__ __forceinline__ float2 operator[](long long i) const { const uchar2 v = p[i]; return cu8_to_cf32(v.x, v.y); }
+  __device__ __forceinline__ in_cu8 operator+(long long k) const { in_cu8 r; r.p = p + k; return r; }
+};
+template <int FMT> struct in_stream { typedef in_cf32 type; };
+template <> struct in_stream<LSDR_IN_CU8> { typedef in_cu8 type; };
+template <int FMT> __device__ __forceinline__ typename in_stream<FMT>::type in_make(const void *p) {
+  typename in_stream<FMT>::type r; r.p = reinterpret_cast<decltype(r.p)>(p); return r;
+}
+
+// The tolerance tiles' look-ahead window: the samples the NEXT symbol can need (instant n' = n + ⌊mu + omega + mucorr⌋ is one
+// of two adjacent positions, the linear sampler reads n' and n'+1), requested one symbol step ahead.
+//   cf32: three 8-byte loads, positions wn … wn+2 (each clamped to the tile's last readable sample);
+//   cu8:  ONE 8-byte load = four samples wn … wn+3 (unaligned dwordx2; the window start is clamped so that it never reaches
+//         past the last readable sample), the pair is picked with a 64-bit shift and converted with v_cvt_f32_ubyte*.
+template <int FMT> struct rx_window;
+template <> struct rx_window<LSDR_IN_CF32> {
+  float2 w0, w1, w2; int wn;
+  __device__ __forceinline__ void load(const in_cf32 &b, int i, int n_last) {
+    w0 = b.p[i < n_last ? i : n_last]; w1 = b.p[i + 1 < n_last ? i + 1 : n_last]; w2 = b.p[i + 2 < n_last ? i + 2 : n_last]; wn = i;
+  }
+  __device__ __forceinline__ bool covers(int n) const { return (unsigned)(n - wn) <= 1u; }
+  __device__ __forceinline__ void get(int n, float2 &p0, float2 &p1) const {
+    const bool second = n != wn;
+    p0 = second ? w1 : w0; p1 = second ? w2 : w1;
+  }
+};
+template <> struct rx_window<LSDR_IN_CU8> {
+  unsigned long long w; int wn;
+  __device__ __forceinline__ void load(const in_cu8 &b, int i, int n_last) {
+    const int lim = n_last - 3;                            // (a tile span is ≥ 128 samples)
+    wn = i < lim ? i : lim;
+    __builtin_memcpy(&w, reinterpret_cast<const unsigned char *>(b.p) + 2 * (long long)wn, 8);
+  }
+  __device__ __forceinline__ bool covers(int n) const { return (unsigned)(n - wn) <= 2u; }
+  __device__ __forceinline__ void get(int n, float2 &p0, float2 &p1) const {
+    const unsigned v = (unsigned)(w >> (16 * (n - wn)));   // {re0, im0, re1, im1}
+    p0 = cu8_to_cf32(v & 255u, (v >> 8) & 255u);
+    p1 = cu8_to_cf32((v >> 16) & 255u, v >> 24);
+  }
+};
+
+__device__ __forceinline__ void rx_window_set(rx_window<LSDR_IN_CU8> &wd, unsigned long long w, int wn) { wd.w = w; wd.wn = wn; }
+__device__ __forceinline__ void rx_window_set(rx_window<LSDR_IN_CF32> &, unsigned long long, int) {}   // (no LDS staging for cf32)
+
 // cstln_lut<256>::lookup(float,float), sdr.h:470-482
 __device__ __forceinline__ void lut_halve(float &I, float &Q) {   // the range-folding loop of sdr.h:470-476 alone
   while (__builtin_fmaxf(__builtin_fabsf(I + 0.5f), __builtin_fabsf(Q + 0.5f)) > 127.5f) {
@@ -379,7 +437,7 @@ __device__ __forceinline__ int rx_chunk(const rx_tables &T, const rx_consts &C, 
 }
 
 struct rx_serial_args {
-  const float2 *in;
+  const void *in;                  // cf32 or cu8 items (FMT)
   unsigned long long n_in;
   lsdr_softsymbol *out;
   unsigned long long cap_out;
@@ -393,8 +451,9 @@ struct rx_serial_args {
 };
 
 // One wavefront.  Lane 0 = the recurrence; all lanes = staging + coefficient refresh.
-template <int SAMP>
+template <int SAMP, int FMT>
 __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
+  const typename in_stream<FMT>::type src = in_make<FMT>(a.in);
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float2 *buf = reinterpret_cast<float2 *>(smem_raw);     // [kChunk + readahead]
   __shared__ rx_state_dev st;
@@ -408,7 +467,7 @@ __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
   unsigned long long pos = 0;
   auto available = [&](unsigned long long p) { return a.n_in >= p && a.n_in - p >= (unsigned long long)span; };
   if (available(0))
-    for (int k = lane; k < span; k += 64) buf[k] = a.in[k];
+    for (int k = lane; k < span; k += 64) buf[k] = src[k];
   __syncthreads();
   while (true) {
     // loop condition of sdr.h:783-788 (uniform: shared counters)
@@ -423,7 +482,7 @@ __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
     if (have_next) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
-        if (lane + 64 * q < span) pre[q] = a.in[pos + kChunk + lane + 64 * q];
+        if (lane + 64 * q < span) pre[q] = src[pos + kChunk + lane + 64 * q];
     }
 
     // sampler->update_freq(freqw), sdr.h:790
@@ -472,7 +531,7 @@ __global__ __launch_bounds__(64) void k_rx_serial(rx_serial_args a) {
 #pragma unroll
       for (int q = 0; q < 3; ++q)
         if (lane + 64 * q < span) buf[lane + 64 * q] = pre[q];
-      for (int k = lane + 192; k < span; k += 64) buf[k] = a.in[pos + k];
+      for (int k = lane + 192; k < span; k += 64) buf[k] = src[pos + k];
     }
     __syncthreads();
   }
@@ -499,7 +558,7 @@ __device__ __forceinline__ void rx_rotate_back(rx_state_dev *st, unsigned rot, f
 }
 
 struct rx_tiled_args {
-  const float2 *in;
+  const void *in;                      // cf32 or cu8 items (FMT)
   unsigned long long total_chunks;     // chunks processed by this run
   unsigned first_chunks, tile_chunks, warm_chunks;
   unsigned n_tiles;
@@ -533,8 +592,9 @@ __device__ __forceinline__ void rx_tile_meas(const rx_tiled_args &a, unsigned lo
 }
 
 // Tile 0: continues exactly from the carried state (one lane, the reference's arithmetic, exact table look-ups).
-template <int SAMP>
+template <int SAMP, int FMT>
 __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
+  const typename in_stream<FMT>::type src = in_make<FMT>(a.in);
   unsigned long long c1 = a.first_chunks;
   if (c1 > a.total_chunks) c1 = a.total_chunks;
   rx_state_dev s = *a.state;
@@ -561,7 +621,7 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
       s.update_freq_phase = ph;
     }
     bool wrote;
-    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, a.in + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, a.cstln ? a.cstln + c : nullptr, &wrote);
+    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, src + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, a.cstln ? a.cstln + c : nullptr, &wrote);
     if (a.cstln && !wrote) a.cstln[c] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
     m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;
     if (a.meas) rx_tile_meas(a, c, 0u, s.freqw, m);
@@ -587,19 +647,61 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
 // together with it, as a 3-sample window — the next symbol instant is n + ⌊mu + omega + mucorr⌋ with |mucorr| ≤ 0.1,
 // i.e. one of two adjacent positions — and the soft symbol is stored fire-and-forget (the following wait is for the
 // next iteration's loads, one full symbol step later).  No LDS (fir_filter's two workgroups per CU need it), no scratch.
-template <int SAMP, int NT, bool ARITH>
-__device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane) {
-  if (lane >= NT || j0 + (unsigned)lane >= a.n_tiles) return;
-  const unsigned j = j0 + (unsigned)lane;
+// LDS staging of the tolerance tiles' samples (cu8 input only: LSDR_IN_CU8, nearest / linear sampler).  Every lane of a
+// wavefront walks its own tile, so a per-symbol global load touches 64 different cache lines; with more than one wavefront
+// per SIMD the lines of a CU's lanes no longer fit its L1 (nor, chip-wide, the L2s) and every 8-byte window costs a 128-byte
+// line from memory (measured: 4 wavefronts per SIMD ran 6× slower per wavefront than one).  Instead the wavefront fetches,
+// for all of its 64 tiles at once, the next kStage samples (+ look-ahead margin) with kStageLoads buffer→LDS loads of 1 KiB —
+// every 128-byte line crosses once — and the per-symbol windows come out of LDS.  One row of kRowBytes per lane; the rows are
+// filled in flat order (LDS-DMA writes lane·16 contiguous bytes), the global side of each 16-byte piece is per lane.  The
+// buffer resource starts at the 16-byte boundary below the stream's first byte (a pipebuf<cu8> read pointer is only 2-byte
+// aligned) and ends with the readable samples: pieces past the end come back as zeros and are never used.
+constexpr int kStage = 64;                                   // samples per stage (two stages per chunk)
+constexpr int kStageMargin = 16;                             // look-ahead kept behind a stage (covers omega ≤ ≈ 10)
+constexpr int kRowBytes = 2 * (kStage + kStageMargin) + 16;  // + alignment slack
+constexpr int kStageLoads = kRowBytes / 16;
+static_assert(kRowBytes % 16 == 0 && kChunk % kStage == 0, "stage geometry");
+typedef __attribute__((address_space(3))) void *rx_lds_ptr;
+
+template <int SAMP, bool ARITH, int FMT, bool LDS>
+__device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane, char *lds) {
+  const bool valid = lane < (int)a.lanes_per_wave && j0 + (unsigned)lane < a.n_tiles;
+  if (!LDS && !valid) return;                            // (LDS: every lane takes part in the stage loads)
+  const unsigned j = valid ? j0 + (unsigned)lane : j0;
   const rx_consts &C = a.C;
   const unsigned long long c0 = a.first_chunks + (unsigned long long)(j - 1) * a.tile_chunks;
   unsigned long long c1 = c0 + a.tile_chunks;
   if (c1 > a.total_chunks) c1 = a.total_chunks;
   const unsigned long long cb = c0 - a.warm_chunks;
-  const int nwarm = (int)a.warm_chunks, nchunks = (int)(c1 - cb);
+  const int nwarm = (int)a.warm_chunks, nchunks = valid ? (int)(c1 - cb) : 0;
+  const int wave_chunks = LDS ? nwarm + (int)a.tile_chunks : nchunks;       // wave-uniform trip count of the chunk loop
   const int ra = SAMP == 1 ? 1 : (SAMP == 2 ? C.ncoeffs - 1 : 0);
   const int n_last = nchunks * kChunk - 1 + ra;          // last readable sample of this tile's span
-  const float2 *base = a.in + cb * kChunk;
+  const typename in_stream<FMT>::type base = in_make<FMT>(a.in) + cb * kChunk;
+
+  // LDS staging: this lane's row, the wave's buffer resource, the per-lane part of the source offsets
+  const unsigned *row32 = nullptr;
+  int delta = 0;
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned src_off[LDS ? kStageLoads : 1];
+  if (LDS) {
+    const unsigned long long addr = (unsigned long long)a.in;
+    delta = (int)(addr & 15ull);
+    // extent: up to the end of the 16-byte granule that holds the last readable sample (range checks are per dword, and a
+    // granule never crosses a page), zeros beyond
+    const unsigned long long bytes = ((a.total_chunks * kChunk + (unsigned)ra) * 2ull + (unsigned)delta + 15ull) & ~15ull;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.in)) - delta, 0,
+                                             (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
+    row32 = reinterpret_cast<const unsigned *>(lds + lane * kRowBytes);
+    const unsigned long long cb0 = a.first_chunks + (unsigned long long)(j0 - 1) * a.tile_chunks - a.warm_chunks;   // first tile of the wave
+#pragma unroll
+    for (int q = 0; q < kStageLoads; ++q) {
+      const unsigned f = (unsigned)q * 1024u + (unsigned)lane * 16u, r = f / (unsigned)kRowBytes, col = f - r * (unsigned)kRowBytes;
+      const unsigned long long tile_byte = (cb0 + (unsigned long long)r * a.tile_chunks) * (kChunk * 2ull);
+      // rows of tiles that do not exist, or offsets beyond 4 GiB, point past the end of the resource: zeros
+      src_off[q] = (j0 + r < a.n_tiles && tile_byte + col < 0xfff00000ull) ? (unsigned)(tile_byte + col) : 0xfffffff0u;
+    }
+  }
 
   const rx_state_dev *S = a.state;                        // carried tracking state (wave-uniform)
   float freqw = S->freqw, agc = S->agc_gain, est_insp = S->est_insp, est_sp = S->est_sp, est_ep = S->est_ep;
@@ -624,13 +726,19 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   unsigned *const pw = reinterpret_cast<unsigned *>(a.wstage + (unsigned long long)j * a.wstride);
   unsigned cnt = 0, got = 0;
 
-  int n = 0, wn = 0;                                      // current sample, first sample of the window
-  float2 w0 = base[0], w1 = base[1 < n_last ? 1 : n_last], w2 = base[2 < n_last ? 2 : n_last];
-  *pw = 0u;   // (puts the loop entry in the same "three loads, then one store" state as the loop's back edge: see `*dp = raw.x`)
-  for (int ci = 0; ci < nchunks; ++ci) {
+  int n = 0;                                              // current sample
+  rx_window<FMT> win;
+  if (!LDS) {
+    win.load(base, 0, n_last);
+    *pw = 0u;   // (puts the loop entry in the same "three loads, then one store" state as the loop's back edge: see `*dp = raw.x`)
+  } else {
+    rx_window_set(win, 0ull, -16);
+  }
+  for (int ci = 0; ci < wave_chunks; ++ci) {
+    const bool active = !LDS || ci < nchunks;
     const bool body = ci >= nwarm, lastwarm = ci + 1 == nwarm;
     const int cend = (ci + 1) * kChunk;
-    if (ci == nwarm) {
+    if (active && ci == nwarm) {
       ti.mu_begin = mu; ti.phase_begin = phase;
       ti.pre.cost = (int16_t)(last & 0xffffu); ti.pre.symbol = (uint8_t)(last >> 16); ti.has_pre = got ? 1u : 0u;
     }
@@ -649,111 +757,137 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         mu -= (float)k; n += k; phase += (float)k * freqw;
       }
     };
-    skip();
-    while (n < cend) {
-      if (SAMP != 2 && (unsigned)(n - wn) > 1u) {         // window missed (rare: rounding at the ±0.1 edge): plain loads
-        w0 = base[n]; w1 = base[n + (SAMP == 1 ? 1 : 0)]; wn = n;
-        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0) HERE, so that the common path only waits for its window
+    if (active) skip();
+#pragma unroll 1
+    for (int sb = 0; sb < (LDS ? kChunk / kStage : 1); ++sb) {
+      const int s0 = ci * kChunk + sb * kStage;           // first sample of the stage (tile-relative)
+      const int send = LDS ? s0 + kStage : cend;
+      // window of sample i out of this lane's LDS row (two dwords starting at the dword that holds sample i)
+      auto lds_window = [&](rx_window<FMT> &wd, int i) {
+        int bo = 2 * (i - s0) + delta;
+        bo = bo < 0 ? 0 : (bo > kRowBytes - 8 ? kRowBytes - 8 : bo);
+        const int d = bo >> 2;
+        const unsigned lo32 = row32[d], hi32 = row32[d + 1];
+        rx_window_set(wd, ((unsigned long long)hi32 << 32) | lo32, s0 + ((4 * d - delta) >> 1));
+      };
+      if (LDS) {
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s0 * 2);   // (wave-uniform; says so to the compiler: no waterfall loop)
+#pragma unroll
+        for (int q = 0; q < kStageLoads; ++q)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (rx_lds_ptr)(size_t)(unsigned)(unsigned long long)(lds + q * 1024), 16, src_off[q], soff, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the stage has landed (single-wave workgroup: no barrier)
+        asm volatile("" ::: "memory");
+        if (active && n < send && !win.covers(n)) lds_window(win, n);
       }
-      const bool second = n != wn;
-      const float2 p0 = second ? w1 : w0, p1 = second ? w2 : w1;
-      const float2 s0 = cmul(p0, ld_hwtrig::expi(a.T, trig_index(-phase)));
-      if (SAMP == 2) {
-        // fir_sampler::interp (sdr.h:646-665): polyphase branch (1−mu)·S of the matched filter over the next ⌈N/S⌉ samples;
-        // plain loads (an ⌈N/S⌉-sample window does not pay), taps from the per-run table
-        float2 acc = make_float2(0.f, 0.f);
-        const int S = C.subsampling, N = C.ncoeffs;
-        const float2 *px = base + n;
-        for (int pc = (int)((1 - mu) * S); pc < N; pc += S, ++px) {
-          const float2 tt = cmul(a.T.shifted_tol[pc], *px);
-          acc.x += tt.x; acc.y += tt.y;
+      while (active && n < send) {
+        if (SAMP != 2 && !win.covers(n)) {                // window missed (rare: rounding at the ±0.1 edge): plain reload
+          if (LDS) lds_window(win, n);
+          else {
+            win.load(base, n, n_last);
+            __builtin_amdgcn_s_waitcnt(0x0F70);           // vmcnt(0) HERE, so that the common path only waits for its window
+          }
         }
-        sg = cmul(ld_hwtrig::expi(a.T, trig_index(-phase)), acc);
-      } else if (SAMP == 1) {
-        const float2 s1 = cmul(p1, ld_hwtrig::expi(a.T, trig_index(-(phase + samp_freqw))));
-        const float k0 = 1 - mu;
-        sg = make_float2(s0.x * k0 + s1.x * mu, s0.y * k0 + s1.y * mu);
-      } else {
-        sg = s0;
-      }
-      sv = make_float2(sg.x * agc, sg.y * agc);
-      uint2 raw;
-      if (!ARITH) raw = *reinterpret_cast<const uint2 *>(a.T.lut + lut_index(sv.x, sv.y));
-      // window for the next symbol: ⌊mu + omega − 0.1⌋ samples ahead (at least one)
-      int lo = (int)(mu + C.omega - 0.1f);
-      lo = lo < 1 ? 1 : lo;
-      const int wn2 = n + lo;
-      const float2 v0 = base[wn2 < n_last ? wn2 : n_last];
-      const float2 v1 = base[wn2 + 1 < n_last ? wn2 + 1 : n_last];
-      const float2 v2 = base[wn2 + 2 < n_last ? wn2 + 2 : n_last];
-      lut_entry e;
-      if (ARITH) {
-        float hi = sv.x, hq = sv.y;
-        lut_halve(hi, hq);
-        const qpsk_decision qd = qpsk_decide((int)hi, (int)hq);
-        e.cost = (int16_t)qd.cost; e.symbol = (uint8_t)qd.symbol; e.zero = 0;
-        e.phase_error = (int16_t)qd.phase_error; e.pt_re = (int8_t)qd.pt_re; e.pt_im = (int8_t)qd.pt_im;
-        raw.x = ((unsigned)qd.cost & 0xffffu) | (qd.symbol << 16);
-      } else {
-        e = lut_unpack(raw.x, raw.y);
-      }
-      *dp = raw.x; dp += keep;
-      last = raw.x;
-      ++nsym;
-      const bool acq = (int)(got + nsym) <= C.acq_syms && !body;
-      phase += e.phase_error * (acq ? C.acq_alpha : C.freq_alpha);   // sdr.h:814-815
-      freqw += e.phase_error * C.freq_beta;
-      freqw = freqw < f_lo ? f_lo : freqw; freqw = freqw > f_hi ? f_hi : freqw;
-      h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;  // sdr.h:822-840
-      h1pr = h0pr; h1pi = h0pi; h1cr = h0cr; h1ci = h0ci;
-      h0pr = sv.x; h0pi = sv.y;
-      pt_re = e.pt_re; pt_im = e.pt_im;
-      had = true;
-      h0cr = (float)pt_re; h0ci = (float)pt_im;
-      const float muerr = ((h0pr - h2pr) * h1cr + (h0pi - h2pi) * h1ci) - ((h0cr - h2cr) * h1pr + (h0ci - h2ci) * h1pi);
-      float mucorr = muerr * (acq ? C.acq_gain_mu : C.gain_mu);
-      mucorr = mucorr < -0.1f ? -0.1f : mucorr; mucorr = mucorr > 0.1f ? 0.1f : mucorr;
-      mu += mucorr;
-      mu += C.omega;
-      mu -= 1.f; phase += freqw; ++n;                     // the symbol's own sample step
-      w0 = v0; w1 = v1; w2 = v2; wn = wn2;
-      skip();
-    }
-    phase = fmod65536(phase);                             // sdr.h:855
-    if (had) {
-      const float insp = sg.x * sg.x + sg.y * sg.y;       // sdr.h:867-870
-      est_insp = insp * kk + est_insp * k1;
-      if (est_insp) agc = kCstlnAmp / __builtin_sqrtf(est_insp);
-      const float evr = sv.x - pt_re, evi = sv.y - pt_im; // sdr.h:873-889
-      float sig_power, ev_power;
-      if (C.nsymbols == 2) {
-        const float sig_real = (float)((double)(pt_re + pt_im) * 0.707);
-        const float ev_real = (float)((double)(evr + evi) * 0.707);
-        sig_power = sig_real * sig_real; ev_power = ev_real * ev_real;
-      } else {
-        sig_power = (float)(pt_re * pt_re + pt_im * pt_im);
-        ev_power = evr * evr + evi * evi;
-      }
-      est_sp = sig_power * kk + est_sp * k1;
-      est_ep = ev_power * kk + est_ep * k1;
-      if (body) {
-        m.a *= k1;
-        m.bi = insp * kk + m.bi * k1; m.bs = sig_power * kk + m.bs * k1; m.be = ev_power * kk + m.be * k1;
+        float2 p0, p1;
+        win.get(n, p0, p1);
+        const float2 sx0 = cmul(p0, ld_hwtrig::expi(a.T, trig_index(-phase)));
+        if (SAMP == 2) {
+          // fir_sampler::interp (sdr.h:646-665): polyphase branch (1−mu)·S of the matched filter over the next ⌈N/S⌉ samples;
+          // plain loads (an ⌈N/S⌉-sample window does not pay), taps from the per-run table
+          float2 acc = make_float2(0.f, 0.f);
+          const int SS = C.subsampling, N = C.ncoeffs;
+          int px = n;
+          for (int pc = (int)((1 - mu) * SS); pc < N; pc += SS, ++px) {
+            const float2 tt = cmul(a.T.shifted_tol[pc], base[px]);
+            acc.x += tt.x; acc.y += tt.y;
+          }
+          sg = cmul(ld_hwtrig::expi(a.T, trig_index(-phase)), acc);
+        } else if (SAMP == 1) {
+          const float2 sx1 = cmul(p1, ld_hwtrig::expi(a.T, trig_index(-(phase + samp_freqw))));
+          const float k0 = 1 - mu;
+          sg = make_float2(sx0.x * k0 + sx1.x * mu, sx0.y * k0 + sx1.y * mu);
+        } else {
+          sg = sx0;
+        }
+        sv = make_float2(sg.x * agc, sg.y * agc);
+        uint2 raw;
+        if (!ARITH) raw = *reinterpret_cast<const uint2 *>(a.T.lut + lut_index(sv.x, sv.y));
+        // window for the next symbol: ⌊mu + omega − 0.1⌋ samples ahead (at least one)
+        int lo = (int)(mu + C.omega - 0.1f);
+        lo = lo < 1 ? 1 : lo;
+        rx_window<FMT> nxt;
+        if (LDS) lds_window(nxt, n + lo);
+        else nxt.load(base, n + lo, n_last);
+        lut_entry e;
+        if (ARITH) {
+          float hi = sv.x, hq = sv.y;
+          lut_halve(hi, hq);
+          const qpsk_decision qd = qpsk_decide((int)hi, (int)hq);
+          e.cost = (int16_t)qd.cost; e.symbol = (uint8_t)qd.symbol; e.zero = 0;
+          e.phase_error = (int16_t)qd.phase_error; e.pt_re = (int8_t)qd.pt_re; e.pt_im = (int8_t)qd.pt_im;
+          raw.x = ((unsigned)qd.cost & 0xffffu) | (qd.symbol << 16);
+        } else {
+          e = lut_unpack(raw.x, raw.y);
+        }
+        *dp = raw.x; dp += keep;
+        last = raw.x;
+        ++nsym;
+        const bool acq = (int)(got + nsym) <= C.acq_syms && !body;
+        phase += e.phase_error * (acq ? C.acq_alpha : C.freq_alpha);   // sdr.h:814-815
+        freqw += e.phase_error * C.freq_beta;
+        freqw = freqw < f_lo ? f_lo : freqw; freqw = freqw > f_hi ? f_hi : freqw;
+        h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;  // sdr.h:822-840
+        h1pr = h0pr; h1pi = h0pi; h1cr = h0cr; h1ci = h0ci;
+        h0pr = sv.x; h0pi = sv.y;
+        pt_re = e.pt_re; pt_im = e.pt_im;
+        had = true;
+        h0cr = (float)pt_re; h0ci = (float)pt_im;
+        const float muerr = ((h0pr - h2pr) * h1cr + (h0pi - h2pi) * h1ci) - ((h0cr - h2cr) * h1pr + (h0ci - h2ci) * h1pi);
+        float mucorr = muerr * (acq ? C.acq_gain_mu : C.gain_mu);
+        mucorr = mucorr < -0.1f ? -0.1f : mucorr; mucorr = mucorr > 0.1f ? 0.1f : mucorr;
+        mu += mucorr;
+        mu += C.omega;
+        mu -= 1.f; phase += freqw; ++n;                   // the symbol's own sample step
+        win = nxt;
+        skip();
       }
     }
-    if (!C.allow_drift) {                                 // sdr.h:895-898
-      if (freqw < min_f || freqw > max_f) freqw = (max_f + min_f) / 2;
+    if (active) {
+      phase = fmod65536(phase);                           // sdr.h:855
+      if (had) {
+        const float insp = sg.x * sg.x + sg.y * sg.y;     // sdr.h:867-870
+        est_insp = insp * kk + est_insp * k1;
+        if (est_insp) agc = kCstlnAmp / __builtin_sqrtf(est_insp);
+        const float evr = sv.x - pt_re, evi = sv.y - pt_im; // sdr.h:873-889
+        float sig_power, ev_power;
+        if (C.nsymbols == 2) {
+          const float sig_real = (float)((double)(pt_re + pt_im) * 0.707);
+          const float ev_real = (float)((double)(evr + evi) * 0.707);
+          sig_power = sig_real * sig_real; ev_power = ev_real * ev_real;
+        } else {
+          sig_power = (float)(pt_re * pt_re + pt_im * pt_im);
+          ev_power = evr * evr + evi * evi;
+        }
+        est_sp = sig_power * kk + est_sp * k1;
+        est_ep = ev_power * kk + est_ep * k1;
+        if (body) {
+          m.a *= k1;
+          m.bi = insp * kk + m.bi * k1; m.bs = sig_power * kk + m.bs * k1; m.be = ev_power * kk + m.be * k1;
+        }
+      }
+      if (!C.allow_drift) {                               // sdr.h:895-898
+        if (freqw < min_f || freqw > max_f) freqw = (max_f + min_f) / 2;
+      }
+      if (body) cnt += nsym; else got += nsym;
+      if (lastwarm) ti.n_warm = nsym;
+      if (body && a.meas) rx_tile_meas(a, cb + (unsigned long long)ci, j, freqw, m);
+      if (body && a.cstln) a.cstln[cb + (unsigned long long)ci] = had ? sv : make_float2(__builtin_nanf(""), __builtin_nanf(""));   // sdr.h:861-864
     }
-    if (body) cnt += nsym; else got += nsym;
-    if (lastwarm) ti.n_warm = nsym;
-    if (body && a.meas) rx_tile_meas(a, cb + (unsigned long long)ci, j, freqw, m);
-    if (body && a.cstln) a.cstln[cb + (unsigned long long)ci] = had ? sv : make_float2(__builtin_nanf(""), __builtin_nanf(""));   // sdr.h:861-864
   }
   ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
-  a.info[j] = ti;
+  if (valid) a.info[j] = ti;
   {
-    // inclusive composition over the tiles of this wavefront (lane order = stream order; the lanes that left early are
-    // the highest ones and are never read): lane L ends with maps[first] … maps[L] composed
+    // inclusive composition over the tiles of this wavefront (lane order = stream order; lanes without a tile — the
+    // highest ones — hold the identity and are never read): lane L ends with maps[first] … maps[L] composed
     rx_ema_map inc = m;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -764,10 +898,12 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     rx_ema_map ex;
     ex.a = __shfl_up(inc.a, 1, 64); ex.bi = __shfl_up(inc.bi, 1, 64); ex.bs = __shfl_up(inc.bs, 1, 64); ex.be = __shfl_up(inc.be, 1, 64);
     if (lane == 0) { ex.a = 1.f; ex.bi = ex.bs = ex.be = 0.f; }
-    a.ema[j] = ex;
-    if (lane == NT - 1 || j == a.n_tiles - 1) a.ema_wave[blockIdx.x] = inc;
+    if (valid) {
+      a.ema[j] = ex;
+      if (lane == (int)a.lanes_per_wave - 1 || j == a.n_tiles - 1) a.ema_wave[blockIdx.x] = inc;
+    }
   }
-  if (j == a.n_tiles - 1) {
+  if (valid && j == a.n_tiles - 1) {
     rx_state_dev *o = a.state_next;
     o->mu = mu; o->phase = phase; o->freqw = freqw; o->agc_gain = agc;
     o->est_insp = est_insp; o->est_sp = est_sp; o->est_ep = est_ep;
@@ -779,10 +915,11 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   }
 }
 
-template <int SAMP, int NT, bool ARITH>
+template <int SAMP, bool ARITH, int FMT, bool LDS>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
-  if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP>(a); }
-  else rx_tile_tol<SAMP, NT, ARITH>(a, 1u + (blockIdx.x - 1u) * NT, (int)threadIdx.x);
+  __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * kRowBytes : 16];
+  if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP, FMT>(a); }
+  else rx_tile_tol<SAMP, ARITH, FMT, LDS>(a, 1u + (blockIdx.x - 1u) * a.lanes_per_wave, (int)threadIdx.x, lds);
 }
 
 // fir_sampler in the tiled mode: the tolerance tiles' shifted taps, rebuilt from the carried freqw before every run
@@ -858,7 +995,7 @@ __global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *wave, 
 // look-ups as vector gathers from the same tables), 64 captures per wavefront, as many wavefronts as there are captures
 // (BASELINE config 4's shape: many independent 2 MS/s captures).  Bit-exact soft symbols and loop state per capture.
 struct rx_batch_args {
-  const float2 *const *in;             // [n_streams] device pointers
+  const void *const *in;               // [n_streams] device pointers (cf32 or cu8 items, FMT)
   lsdr_softsymbol *const *out;         // [n_streams]
   unsigned long long chunks;           // the same number of 128-sample chunks for every capture
   rx_state_dev *states;                // [n_streams]
@@ -868,12 +1005,12 @@ struct rx_batch_args {
   rx_tables T;
 };
 
-template <int SAMP>
+template <int SAMP, int FMT>
 __global__ __launch_bounds__(64) void k_rx_batch(rx_batch_args a) {
   const unsigned sidx = blockIdx.x * 64u + threadIdx.x;
   if (sidx >= a.n_streams) return;
   rx_state_dev s = a.states[sidx];
-  const float2 *pin = a.in[sidx];
+  const typename in_stream<FMT>::type pin = in_make<FMT>(a.in[sidx]);
   lsdr_softsymbol *po = a.out[sidx];
   unsigned long long nout = 0;
   for (unsigned long long c = 0; c < a.chunks; ++c) {
@@ -1015,7 +1152,7 @@ static int rx_pull_state(lsdr_rx *r) {   // refresh the host mirror after queued
 // re-acquires timing/phase during its warm-up; seams are reconciled on the device.
 // rx_tiled_enqueue puts one run on the stream (tiles → seam → compaction → results into a pinned ring
 // slot) without waiting; rx_tiled_wait retires the oldest queued run.
-static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                             size_t *consumed, bool want_meas, size_t meas_cap, size_t *nm_out, size_t cstln_cap = 0,
                             size_t *chunks_out = nullptr) {
   lsdr_ctx *c = r->ctx;
@@ -1047,7 +1184,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
     ++r->ring_count;
     return LSDR_OK;
   }
-  const unsigned first = Lc > Wc ? Lc : Wc;
+  // tile 0 (one lane, the exact recurrence) only has to reach the point where tile 1's warm-up can start
+  const unsigned first = Wc;
   unsigned n_tiles = 1;
   if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
   const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
@@ -1096,7 +1234,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   if (rc) return rc;
 
   rx_tiled_args a;
-  a.in = (const float2 *)in;
+  a.in = in;
   a.total_chunks = chunks;
   a.first_chunks = first; a.tile_chunks = Lc; a.warm_chunks = Wc;
   a.n_tiles = n_tiles;
@@ -1121,14 +1259,19 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   {
     static const char *const e = getenv("LSDR_RX_LANES");   // tuning hook: tiles per wavefront
     if (e) lpw = atoi(e);
-    if (lpw != 2 && lpw != 4 && lpw != 8 && lpw != 16 && lpw != 32 && lpw != 64) lpw = n_tiles > 12288u ? 64 : 32;
+    if (lpw < 1 || lpw > 64) lpw = n_tiles > 12288u ? 64 : 32;
     a.lanes_per_wave = (unsigned)lpw;
   }
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
-#define LSDR_RX_LAUNCH(S, N) do { if (r->qpsk_arith) hipLaunchKernelGGL((k_rx_tiles<S, N, true>), dim3(blocks), dim3(64), 0, c->stream, a); \
-                                  else hipLaunchKernelGGL((k_rx_tiles<S, N, false>), dim3(blocks), dim3(64), 0, c->stream, a); } while (0)
-#define LSDR_RX_LAUNCH_S(S) \
-  do { if (lpw == 2) LSDR_RX_LAUNCH(S, 2); else if (lpw == 8) LSDR_RX_LAUNCH(S, 8); else if (lpw == 4) LSDR_RX_LAUNCH(S, 4); else if (lpw == 16) LSDR_RX_LAUNCH(S, 16); else if (lpw == 64) LSDR_RX_LAUNCH(S, 64); else LSDR_RX_LAUNCH(S, 32); } while (0)
+  // cu8 input, nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol); LSDR_RX_NO_LDS=1 keeps
+  // the direct loads (A/B measurements)
+  static const bool no_lds = getenv("LSDR_RX_NO_LDS") != nullptr;
+  const bool use_lds = r->cfg.in_format == LSDR_IN_CU8 && r->cfg.sampler != LSDR_SAMP_FIR && !no_lds && r->omega <= 8.f;
+#define LSDR_RX_LAUNCH_F(S, A, F, L) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L>), dim3(blocks), dim3(64), 0, c->stream, a)
+#define LSDR_RX_LAUNCH(S, A) do { if (use_lds) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2)); \
+                                  else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, false); \
+                                  else LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CF32, false); } while (0)
+#define LSDR_RX_LAUNCH_S(S) do { if (r->qpsk_arith) LSDR_RX_LAUNCH(S, true); else LSDR_RX_LAUNCH(S, false); } while (0)
   if (r->cfg.sampler == LSDR_SAMP_FIR)
     hipLaunchKernelGGL(k_rx_fir_refresh, dim3(1), dim3(256), 0, c->stream, (const rx_state_dev *)r->d_state, (const float2 *)r->d_trig,
                        (const float *)r->d_coeffs, r->cfg.ncoeffs, r->cfg.subsampling, r->d_shifted_tol);
@@ -1137,6 +1280,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_s
   else LSDR_RX_LAUNCH_S(2);
 #undef LSDR_RX_LAUNCH_S
 #undef LSDR_RX_LAUNCH
+#undef LSDR_RX_LAUNCH_F
   LSDR_HIP(hipGetLastError());
   // estimators (AGC, MER) of the run: scan of the tiles' maps; installs the end state
   hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema_wave, blocks,
@@ -1178,7 +1322,7 @@ static int rx_tiled_wait(lsdr_rx *r, size_t *produced) {
   return LSDR_OK;
 }
 
-static int rx_run_tiled(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+static int rx_run_tiled(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                         size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
                         size_t meas_cap, size_t *n_meas, lsdr_cf32 *cstln_out, size_t cstln_cap, size_t *n_cstln) {
   if (r->ring_count) { lsdr_set_error("cstln_receiver: queued runs outstanding (lsdr_rx_wait first)"); return LSDR_E_ARG; }
@@ -1229,6 +1373,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_ARG(cfg->sampler != LSDR_SAMP_FIR || (cfg->ncoeffs > 0 && cfg->coeffs_host && cfg->subsampling >= 1));
   LSDR_ARG(cfg->omega > 0 && cfg->meas_decimation >= 1);
   LSDR_ARG(cfg->mode == LSDR_RX_SERIAL || cfg->mode == LSDR_RX_TILED);
+  LSDR_ARG(cfg->in_format == LSDR_IN_CF32 || cfg->in_format == LSDR_IN_CU8);
   LSDR_HIP(hipSetDevice(c->device));
   lsdr_rx *r = new lsdr_rx();
   r->ctx = c;
@@ -1424,7 +1569,7 @@ int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st) {
   return LSDR_OK;
 }
 
-int lsdr_rx_run_async(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed) {
+int lsdr_rx_run_async(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed) {
   LSDR_ARG(r && consumed && (in || !n_in) && out);
   if (r->cfg.mode != LSDR_RX_TILED) { lsdr_set_error("cstln_receiver: lsdr_rx_run_async needs LSDR_RX_TILED"); return LSDR_E_UNSUPPORTED; }
   return rx_tiled_enqueue(r, in, n_in, out, cap_out, consumed, false, 0, nullptr);
@@ -1436,7 +1581,7 @@ int lsdr_rx_wait(lsdr_rx *r, size_t *produced) {
 }
 float lsdr_rx_retired_freq_tap(const lsdr_rx *r) { return r ? r->retired_freq_tap : 0.f; }
 
-int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+int lsdr_rx_run(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                 size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,
                 size_t meas_cap, size_t *n_meas, lsdr_cf32 *cstln_out, size_t cstln_cap, size_t *n_cstln) {
   LSDR_ARG(r && consumed && produced);
@@ -1473,7 +1618,7 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
   if (rc) return rc;
 
   rx_serial_args a;
-  a.in = (const float2 *)in;
+  a.in = in;
   a.n_in = n_in;
   a.out = out;
   a.cap_out = cap_out;
@@ -1484,11 +1629,14 @@ int lsdr_rx_run(lsdr_rx *r, const lsdr_cf32 *in, size_t n_in, lsdr_softsymbol *o
   rx_fill_consts(r, a.C, a.T);
   a.readahead = ra;
   size_t shmem = (size_t)(kChunk + ra) * sizeof(float2);
+#define LSDR_RX_SERIAL(S) do { if (r->cfg.in_format == LSDR_IN_CU8) hipLaunchKernelGGL((k_rx_serial<S, LSDR_IN_CU8>), dim3(1), dim3(64), shmem, c->stream, a); \
+                               else hipLaunchKernelGGL((k_rx_serial<S, LSDR_IN_CF32>), dim3(1), dim3(64), shmem, c->stream, a); } while (0)
   switch (r->cfg.sampler) {
-    case LSDR_SAMP_NEAREST: hipLaunchKernelGGL(k_rx_serial<0>, dim3(1), dim3(64), shmem, c->stream, a); break;
-    case LSDR_SAMP_LINEAR: hipLaunchKernelGGL(k_rx_serial<1>, dim3(1), dim3(64), shmem, c->stream, a); break;
-    default: hipLaunchKernelGGL(k_rx_serial<2>, dim3(1), dim3(64), shmem, c->stream, a); break;
+    case LSDR_SAMP_NEAREST: LSDR_RX_SERIAL(0); break;
+    case LSDR_SAMP_LINEAR: LSDR_RX_SERIAL(1); break;
+    default: LSDR_RX_SERIAL(2); break;
   }
+#undef LSDR_RX_SERIAL
   LSDR_HIP(hipGetLastError());
 
   unsigned long long cnt[4];
@@ -1517,7 +1665,7 @@ struct lsdr_rx_batch {
   lsdr_rx *proto;                 // tables, constants and the initial loop state of one capture
   unsigned n;
   rx_state_dev *d_states;
-  const float2 **d_in; lsdr_softsymbol **d_out; unsigned long long *d_prod;
+  const void **d_in; lsdr_softsymbol **d_out; unsigned long long *d_prod;
   std::vector<unsigned long long> h_prod;
 };
 
@@ -1550,7 +1698,7 @@ void lsdr_rx_batch_destroy(lsdr_rx_batch *b) {
   delete b;
 }
 
-int lsdr_rx_batch_run(lsdr_rx_batch *b, const lsdr_cf32 *const *in_dev, size_t n_in, lsdr_softsymbol *const *out_dev, size_t cap_out,
+int lsdr_rx_batch_run(lsdr_rx_batch *b, const void *const *in_dev, size_t n_in, lsdr_softsymbol *const *out_dev, size_t cap_out,
                       size_t *consumed, size_t *produced) {
   LSDR_ARG(b && in_dev && out_dev && consumed);
   *consumed = 0;
@@ -1570,8 +1718,11 @@ int lsdr_rx_batch_run(lsdr_rx_batch *b, const lsdr_cf32 *const *in_dev, size_t n
   a.in = b->d_in; a.out = b->d_out; a.chunks = chunks; a.states = b->d_states; a.produced = b->d_prod; a.n_streams = b->n;
   rx_fill_consts(r, a.C, a.T);
   const unsigned blocks = (b->n + 63) / 64;
-  if (r->cfg.sampler == LSDR_SAMP_NEAREST) hipLaunchKernelGGL(k_rx_batch<0>, dim3(blocks), dim3(64), 0, c->stream, a);
-  else hipLaunchKernelGGL(k_rx_batch<1>, dim3(blocks), dim3(64), 0, c->stream, a);
+#define LSDR_RX_BATCH(S) do { if (r->cfg.in_format == LSDR_IN_CU8) hipLaunchKernelGGL((k_rx_batch<S, LSDR_IN_CU8>), dim3(blocks), dim3(64), 0, c->stream, a); \
+                              else hipLaunchKernelGGL((k_rx_batch<S, LSDR_IN_CF32>), dim3(blocks), dim3(64), 0, c->stream, a); } while (0)
+  if (r->cfg.sampler == LSDR_SAMP_NEAREST) LSDR_RX_BATCH(0);
+  else LSDR_RX_BATCH(1);
+#undef LSDR_RX_BATCH
   LSDR_HIP(hipGetLastError());
   LSDR_HIP(hipMemcpyAsync(b->h_prod.data(), b->d_prod, b->n * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
   LSDR_HIP(hipStreamSynchronize(c->stream));

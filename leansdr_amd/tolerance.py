@@ -1,0 +1,71 @@
+"""leansdr_amd/tolerance.py — THE tolerance of the time-tiled (throughput) receiver, stated once.
+
+LSDR_RX_TILED (cstln_receiver.hip) is not bit-exact: every tile but the first re-acquires symbol timing and carrier phase
+during its warm-up, so its loop state differs from the reference's serial trajectory (sdr.h:772-916) by loop noise.  What is
+promised — and asserted with these numbers by tests/test_gpu_rx_tiled.py, tests/test_gpu_rx_u8.py, bench.py's `verified`
+objects and tools/rx_tol_report.py — against the oracle's exact serial receiver started from the same loop state, on a locked
+QPSK stream at the bench condition (Es/N0 = 20 dB in leansdr_amd.synth's definition):
+
+  count            exactly the same number of soft symbols for the same consumed input
+  first tile       bit-exact (it continues from the carried state with the reference's arithmetic)
+  decisions        >= min_equal_decisions identical `symbol` fields
+  cost, mean       mean |Δcost| <= max_mean_abs_dcost        (cost = the soft symbol's int16 confidence, |cost| <= COST_MAX)
+  cost, p99        99th percentile of |Δcost| <= max_p99_abs_dcost
+  cost, max        no single symbol further than max_abs_dcost from the serial receiver's
+  seams            no seam left unreconciled (bad_seams == 0)
+  reports          signal-strength report and carried AGC within ss_rtol, MER report within mer_atol_db
+
+LOW_SNR holds the same bounds for the 10–12 dB checks (the loops' own noise is larger there; a few seams may stay
+unrepaired — they cost a handful of symbols that the FEC corrects, and are counted).
+"""
+import numpy as np
+
+COST_MAX = 11236          # largest |cost| of the QPSK table (cstln_lut<256>, sdr.h:529-560)
+
+TOL = dict(
+    min_equal_decisions=0.999,
+    max_mean_abs_dcost=0.05 * COST_MAX,       # 562
+    max_p99_abs_dcost=0.20 * COST_MAX,        # 2247
+    max_abs_dcost=COST_MAX,                   # one symbol may at worst move from "certain" to "undecided", never flip with confidence
+    max_bad_seams=0,
+    ss_rtol=0.02,
+    mer_atol_db=1.0,
+)
+
+LOW_SNR = dict(
+    min_equal_decisions=0.99,
+    max_mean_abs_dcost=0.10 * COST_MAX,
+    max_p99_abs_dcost=0.50 * COST_MAX,
+    max_abs_dcost=2 * COST_MAX,
+    max_bad_seams_per_1000_tiles=20,
+    ss_rtol=0.05,
+    mer_atol_db=1.0,
+)
+
+
+def check_tiled(sym, ref_sym, stats=None, first_exact=0, tol=None):
+    """Compare a tiled run's soft symbols with the serial reference's under `tol` (default TOL).  Returns a report dict with
+    every measured figure and `pass`.  first_exact: number of leading symbols that must be bit-identical (inside tile 0)."""
+    tol = TOL if tol is None else tol
+    rep = dict(symbols=int(len(sym)), symbols_ref=int(len(ref_sym)), count_equal=bool(len(sym) == len(ref_sym)))
+    ok = rep["count_equal"]
+    if ok:
+        same = float((sym["symbol"] == ref_sym["symbol"]).mean()) if len(sym) else 1.0
+        dc = np.abs(sym["cost"].astype(np.int64) - ref_sym["cost"].astype(np.int64))
+        rep.update(equal_decisions=round(same, 6), mean_abs_dcost=round(float(dc.mean()), 2) if len(dc) else 0.0,
+                   p99_abs_dcost=float(np.percentile(dc, 99)) if len(dc) else 0.0, max_abs_dcost=int(dc.max()) if len(dc) else 0)
+        ok = (same >= tol["min_equal_decisions"] and rep["mean_abs_dcost"] <= tol["max_mean_abs_dcost"]
+              and rep["p99_abs_dcost"] <= tol["max_p99_abs_dcost"] and rep["max_abs_dcost"] <= tol["max_abs_dcost"])
+        if first_exact:
+            rep["first_tile_bit_exact"] = bool(sym["cost"][:first_exact].tobytes() == ref_sym["cost"][:first_exact].tobytes()
+                                               and sym["symbol"][:first_exact].tobytes() == ref_sym["symbol"][:first_exact].tobytes())
+            ok = ok and rep["first_tile_bit_exact"]
+    if stats is not None:
+        rep["tiles"] = int(stats["tiles"]); rep["bad_seams"] = int(stats["bad_seams"])
+        rep["seams_repaired"] = int(stats["dup"]) + int(stats["miss"])
+        if "max_bad_seams" in tol:
+            ok = ok and rep["bad_seams"] <= tol["max_bad_seams"]
+        else:
+            ok = ok and rep["bad_seams"] * 1000 <= tol["max_bad_seams_per_1000_tiles"] * max(1, rep["tiles"])
+    rep["pass"] = bool(ok)
+    return rep

@@ -22,11 +22,14 @@ for _ in range(3):
     cons, prod = f.run_dev(d_in.ptr, n, d_out.ptr, n // decim)
 ctx.sync()
 e0, e1 = ctx.event(), ctx.event()
-ctx.event_record(e0)
-for _ in range(20):
-    f.run_dev(d_in.ptr, n, d_out.ptr, n // decim)
-ctx.event_record(e1)
-ms = ctx.event_elapsed_ms(e0, e1) / 20
+for reps in [int(v) for v in os.environ.get("FIR_ALONE_REPS", "20").split(",")]:      # e.g. 1,20,400,4000: burst vs sustained
+    ctx.sync()
+    ctx.event_record(e0)
+    for _ in range(reps):
+        f.run_dev(d_in.ptr, n, d_out.ptr, n // decim)
+    ctx.event_record(e1)
+    ms = ctx.event_elapsed_ms(e0, e1) / reps
+    print(f"  {reps} launches back to back: {ms:.4f} ms each = {(cons*8+prod*8)/ms/1e9:.2f} TB/s", flush=True)
 y = ctx.download(d_out, np.complex64, 100000)
 O = po.Oracle()
 yr = O.fir_filter(coeffs, decim, O.scaler(75.0, np.tile(blk, 1)[:100000 * decim + len(coeffs)]))[0][:100000]
