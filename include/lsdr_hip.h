@@ -229,6 +229,7 @@ int lsdr_fir_filter_run_multi(lsdr_fir_filter *f, unsigned n_streams, const void
 /* ---------------------------------------------------------- cstln_receiver
  * cstln_receiver<f32> + sampler_interface<f32>, sdr.h:589-938. */
 enum { LSDR_SAMP_NEAREST = 0, LSDR_SAMP_LINEAR = 1, LSDR_SAMP_FIR = 2 }; /* sdr.h:600-689 */
+enum { LSDR_SYM_SOFT = 0, LSDR_SYM_HARD2 = 1 };
 enum {
   LSDR_RX_SERIAL = 0, /* one sequential pass, the reference's exact arithmetic → bit-exact soft symbols */
   LSDR_RX_TILED = 1   /* time-tiled with warm-up overlap (throughput mode; tolerance-tested) */
@@ -253,6 +254,11 @@ typedef struct {
                               * of the receiver in the `leandvb --u8` graph (leandvb.cc:211-217, dsp.h:40-50) fused into the
                               * receiver's loads — `in` then points to lsdr_cu8 items and the converted cf32 stream never exists
                               * in HBM; results are bit-identical to running the two blocks separately */
+  int out_format;            /* LSDR_SYM_SOFT (0): lsdr_softsymbol items.  LSDR_SYM_HARD2: LSDR_RX_TILED on QPSK only — the decisions
+                              * alone, packed 16 per uint32 word, MSB first (symbol k of a run in word k/16, bits 31-2(k%16)..30-2(k%16)):
+                              * what deconvol_sync, the next block of the default leandvb chain, reads of a softsymbol (`symbol & 3`,
+                              * dvb.h:369-417); `out` then points to uint32 words and counts stay in symbols.  Needs cu8 input and the
+                              * nearest or linear sampler. */
 } lsdr_rx_cfg;
 typedef struct {             /* the receiver's loop state, sdr.h:923-935 */
   float mu, phase, freqw, agc_gain, est_insp, est_sp, est_ep, freq_tap;
@@ -284,6 +290,11 @@ int lsdr_rx_run(lsdr_rx *r, const void *in /* n_in items of cfg.in_format */, si
  * the host never sits between two runs.  lsdr_rx_run / _set_state refuse to mix with outstanding queued runs. */
 int lsdr_rx_run_async(lsdr_rx *rx, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
 int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
+/* The queued run of a LSDR_SYM_HARD2 receiver, writing its packed symbols from symbol position out_sym_offset of the stream
+ * that starts at out_words[0] (symbols before it — a caller's unconsumed remainder of the previous run — are preserved, so
+ * consecutive runs form one packed stream without a bit-shifting copy).  cap_out counts symbols after the offset. */
+int lsdr_rx_run_async_hs2(lsdr_rx *rx, const void *in, size_t n_in, uint32_t *out_words, size_t out_sym_offset, size_t cap_out,
+                          size_t *consumed);
 /* freq_tap (sdr.h:919-921, cycles per sample) as of the end of the most recently retired queued run: lets the caller keep
  * fir_filter tracking the carrier (lsdr_fir_filter_track, dsp.h:236-244) from runs that have already completed while later
  * ones are still queued — the feedback of leandvb.cc:506-510 with a latency of the queue depth instead of a host wait. */
@@ -323,6 +334,12 @@ int lsdr_deconv_next_sync(lsdr_deconv *d);                       /* deconvol_syn
  * produces n = min(maxrd, cap_out) bytes when n >= 32.  Asynchronous (sizes are data-independent). */
 int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
                     size_t *consumed, size_t *produced);
+
+/* The same block on the packed hard symbols of a LSDR_SYM_HARD2 receiver (deconvol_sync reads `symbol & 3` only, dvb.h:373,396):
+ * symbols [sym_offset, sym_offset + n_in) of the packed stream that starts at in_words[0]; same arithmetic, same outputs as
+ * lsdr_deconv_run on the unpacked symbols.  No fastlock. */
+int lsdr_deconv_run_hs2(lsdr_deconv *d, const uint32_t *in_words, size_t sym_offset, size_t n_in, uint8_t *out, size_t cap_out,
+                        size_t *consumed, size_t *produced);
 
 /* ---- viterbi_sync, dvb.h:1173-1416 (+ viterbi_dec / trellis / bitpath, viterbi.h).  Soft-decision Viterbi
  * with the reference's partial-metric update and its alignment search (conjugation x rotation x shift).

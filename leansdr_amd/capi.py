@@ -22,6 +22,7 @@ SOFTSYM = np.dtype([("cost", "<i2"), ("symbol", "u1"), ("pad", "u1")])
 CSTLN_BITS = {BPSK: 1, QPSK: 2, PSK8: 3, APSK16: 4, APSK32: 5, APSK64E: 6, QAM16: 4, QAM64: 6, QAM256: 8}
 (FEC12, FEC23, FEC46, FEC34, FEC56, FEC78, FEC45, FEC89, FEC910) = range(9)
 IN_CF32, IN_CU8 = 0, 1
+SYM_SOFT, SYM_HARD2 = 0, 1
 FIR_EXACT, FIR_FMA = 0, 1
 SAMP_NEAREST, SAMP_LINEAR, SAMP_FIR = 0, 1, 2
 RX_SERIAL, RX_TILED = 0, 1
@@ -41,7 +42,7 @@ class RxCfg(C.Structure):
     _fields_ = [("sampler", C.c_int), ("ncoeffs", C.c_int), ("coeffs_host", vp), ("subsampling", C.c_int),
                 ("cstln", C.c_int), ("fec", C.c_int), ("harden", C.c_int), ("omega", c_f), ("freq", c_f),
                 ("pll_adjustment", c_f), ("allow_drift", C.c_int), ("meas_decimation", C.c_ulong),
-                ("kest", c_f), ("mode", C.c_int), ("tile_len", C.c_uint), ("tile_warmup", C.c_uint), ("in_format", C.c_int)]
+                ("kest", c_f), ("mode", C.c_int), ("tile_len", C.c_uint), ("tile_warmup", C.c_uint), ("in_format", C.c_int), ("out_format", C.c_int)]
 
 
 class RxState(C.Structure):
@@ -175,6 +176,7 @@ _sig("lsdr_deconv_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
 _sig("lsdr_deconv_destroy", None, [vp])
 _sig("lsdr_deconv_next_sync", C.c_int, [vp])
 _sig("lsdr_deconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_deconv_run_hs2", C.c_int, [vp, vp, c_sz, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_viterbi_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
 _sig("lsdr_viterbi_destroy", None, [vp])
 _sig("lsdr_viterbi_set_resync_period", C.c_int, [vp, C.c_int])
@@ -194,6 +196,7 @@ _sig("lsdr_derandomizer_pattern", None, [vp])
 _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
+_sig("lsdr_rx_run_async_hs2", C.c_int, [vp, vp, c_sz, vp, c_sz, c_sz, psz])
 _sig("lsdr_rx_wait", C.c_int, [vp, psz])
 _sig("lsdr_rx_retired_freq_tap", C.c_float, [vp])
 _sig("lsdr_fec_spec", C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), vp])
@@ -449,11 +452,12 @@ class CstlnReceiver:
 
     def __init__(self, ctx, sampler=SAMP_LINEAR, coeffs=None, subsampling=1, cstln=QPSK, fec=FEC12, harden=0,
                  omega=4.0, freq=0.0, pll_adjustment=1.0, allow_drift=0, meas_decimation=1048576, kest=0.01,
-                 mode=RX_SERIAL, tile_len=0, tile_warmup=0, in_format=0):
-        """in_format = IN_CU8: cconverter<u8,128,f32,0,1,1> fused into the receiver's loads (input = cu8 items)."""
+                 mode=RX_SERIAL, tile_len=0, tile_warmup=0, in_format=0, out_format=0):
+        """in_format = IN_CU8: cconverter<u8,128,f32,0,1,1> fused into the receiver's loads (input = cu8 items).
+        out_format = SYM_HARD2 (tiled QPSK on cu8 only): packed 2-bit decisions instead of soft symbols."""
         self.ctx = ctx
         cfg = RxCfg()
-        cfg.in_format = in_format
+        cfg.in_format, cfg.out_format = in_format, out_format
         cfg.sampler = sampler
         if coeffs is not None:
             self.coeffs = np.ascontiguousarray(coeffs, np.float32)
@@ -509,6 +513,12 @@ class CstlnReceiver:
         """Queue one tiled run on the receiver's stream; returns the samples it will consume."""
         cons = c_sz()
         check(lib.lsdr_rx_run_async(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons)))
+        return cons.value
+
+    def run_async_hs2(self, in_ptr, n_in, out_ptr, out_sym_offset, cap_out):
+        """Queue one tiled run of a SYM_HARD2 receiver writing its packed symbols from symbol out_sym_offset of `out_ptr`."""
+        cons = c_sz()
+        check(lib.lsdr_rx_run_async_hs2(self.h, in_ptr, n_in, out_ptr, out_sym_offset, cap_out, C.byref(cons)))
         return cons.value
 
     def wait(self):
@@ -588,6 +598,20 @@ class RxBatch:
         return st
 
 
+def hs2_pack(symbols, offset=0):
+    """Hard symbols (0..3) → the packed "hs2" stream (16 per uint32, MSB first), starting at symbol `offset` of word 0."""
+    s = np.concatenate([np.zeros(offset, np.uint8), np.asarray(symbols, np.uint8) & 3])
+    s = np.concatenate([s, np.zeros((-len(s)) % 16, np.uint8)]).reshape(-1, 16).astype(np.uint32)
+    sh = (30 - 2 * np.arange(16)).astype(np.uint32)
+    return np.bitwise_or.reduce(s << sh, axis=1).astype(np.uint32)
+
+
+def hs2_unpack(words, n, offset=0):
+    w = np.asarray(words, np.uint32)
+    sh = (30 - 2 * np.arange(16)).astype(np.uint32)
+    return ((w[:, None] >> sh) & 3).astype(np.uint8).reshape(-1)[offset:offset + n]
+
+
 # ---- FEC tail -----------------------------------------------------------------------
 def derandomizer_pattern():
     out = np.empty(1504, np.uint8)
@@ -621,6 +645,12 @@ class Deconv:
     def run_dev(self, in_ptr, n_in, out_ptr, cap):
         cons, prod = c_sz(), c_sz()
         check(lib.lsdr_deconv_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run_dev_hs2(self, words_ptr, sym_offset, n_in, out_ptr, cap):
+        """The same on packed hard symbols (SYM_HARD2): symbols [sym_offset, sym_offset + n_in) of the stream at words_ptr."""
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_deconv_run_hs2(self.h, words_ptr, sym_offset, n_in, out_ptr, cap, C.byref(cons), C.byref(prod)))
         return cons.value, prod.value
 
     def run_stream(self, sym, pipe=4096, room=8192):

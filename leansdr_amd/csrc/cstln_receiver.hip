@@ -568,6 +568,9 @@ struct rx_tiled_args {
   lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
   unsigned wstride;
   rx_tile_info *info;
+  unsigned *hstage;                    // LSDR_SYM_HARD2: [n_tiles][hstride] packed body symbols (rx_tiling.h "hs2")
+  unsigned hstride;
+  rx_tile_info_h *hinfo;
   rx_ema_map *ema;                     // [n_tiles]: composition of the maps of the tiles BEFORE this one in its wavefront
   rx_ema_map *ema_wave;                // [n_waves]: composition of all tiles of a wavefront (k_rx_ema scans these)
   const rx_state_dev *state;           // carried state at the start of the run (read-only while tiles are running)
@@ -592,7 +595,7 @@ __device__ __forceinline__ void rx_tile_meas(const rx_tiled_args &a, unsigned lo
 }
 
 // Tile 0: continues exactly from the carried state (one lane, the reference's arithmetic, exact table look-ups).
-template <int SAMP, int FMT>
+template <int SAMP, int FMT, bool HARD>
 __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   const typename in_stream<FMT>::type src = in_make<FMT>(a.in);
   unsigned long long c1 = a.first_chunks;
@@ -603,6 +606,15 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   ti.mu_begin = s.mu; ti.phase_begin = s.phase;
   lsdr_softsymbol *po = a.stage;
   unsigned cnt = 0;
+  unsigned hacc = 0, htail = 0;          // HARD: word being filled, last 16 symbols
+  auto emit = [&](lsdr_softsymbol ss) {
+    if (HARD) {
+      hacc = (hacc << 2) | (ss.symbol & 3u); htail = (htail << 2) | (ss.symbol & 3u);
+      if ((++cnt & 15u) == 0) a.hstage[(cnt >> 4) - 1] = hacc;
+    } else {
+      po[cnt++] = ss;
+    }
+  };
   rx_ema_map m; m.a = 0.f; m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;   // constant map: the values are exact here
   for (unsigned long long c = 0; c < c1; ++c) {
     if (SAMP == 1) s.samp_freqw = s.freqw;
@@ -621,13 +633,21 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
       s.update_freq_phase = ph;
     }
     bool wrote;
-    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, src + c * kChunk, [&](lsdr_softsymbol ss) { po[cnt++] = ss; }, a.cstln ? a.cstln + c : nullptr, &wrote);
+    rx_chunk<SAMP, ld_uniform>(a.T, a.C, s, src + c * kChunk, emit, a.cstln ? a.cstln + c : nullptr, &wrote);
     if (a.cstln && !wrote) a.cstln[c] = make_float2(__builtin_nanf(""), __builtin_nanf(""));
     m.bi = s.est_insp; m.bs = s.est_sp; m.be = s.est_ep;
     if (a.meas) rx_tile_meas(a, c, 0u, s.freqw, m);
   }
   ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
-  a.info[0] = ti;
+  if (HARD) {
+    if (cnt & 15u) a.hstage[cnt >> 4] = hacc << (2 * (16 - (cnt & 15u)));
+    rx_tile_info_h th;
+    th.mu_begin = ti.mu_begin; th.phase_begin = ti.phase_begin; th.mu_end = ti.mu_end; th.phase_end = ti.phase_end;
+    th.count = cnt; th.has_pre = 0; th.n_warm = 0; th.warm_tail = 0; th.body_tail = htail;
+    a.hinfo[0] = th;
+  } else {
+    a.info[0] = ti;
+  }
   { rx_ema_map id; id.a = 1.f; id.bi = id.bs = id.be = 0.f; a.ema[0] = id; }
   a.ema_wave[0] = m;
   if (a.n_tiles == 1) {
@@ -663,7 +683,7 @@ constexpr int kStageLoads = kRowBytes / 16;
 static_assert(kRowBytes % 16 == 0 && kChunk % kStage == 0, "stage geometry");
 typedef __attribute__((address_space(3))) void *rx_lds_ptr;
 
-template <int SAMP, bool ARITH, int FMT, bool LDS>
+template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane, char *lds) {
   const bool valid = lane < (int)a.lanes_per_wave && j0 + (unsigned)lane < a.n_tiles;
   if (!LDS && !valid) return;                            // (LDS: every lane takes part in the stage loads)
@@ -725,12 +745,16 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   unsigned *const po = reinterpret_cast<unsigned *>(a.stage + (unsigned long long)j * a.stage_stride);
   unsigned *const pw = reinterpret_cast<unsigned *>(a.wstage + (unsigned long long)j * a.wstride);
   unsigned cnt = 0, got = 0;
+  // LSDR_SYM_HARD2: the decisions only, packed (rx_tiling.h): the word being filled, the last 16 symbols, the row, the snapshot
+  // of the tail at the end of the warm-up
+  unsigned hacc = 0, htail = 0, hwarm = 0, hnwarm = 0, hcnt = 0;
+  unsigned *const hrow = HARD ? a.hstage + (unsigned long long)j * a.hstride : nullptr;
 
   int n = 0;                                              // current sample
   rx_window<FMT> win;
   if (!LDS) {
     win.load(base, 0, n_last);
-    *pw = 0u;   // (puts the loop entry in the same "three loads, then one store" state as the loop's back edge: see `*dp = raw.x`)
+    if (!HARD) *pw = 0u;   // (puts the loop entry in the same "three loads, then one store" state as the loop's back edge: see `*dp = raw.x`)
   } else {
     rx_window_set(win, 0ull, -16);
   }
@@ -741,6 +765,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     if (active && ci == nwarm) {
       ti.mu_begin = mu; ti.phase_begin = phase;
       ti.pre.cost = (int16_t)(last & 0xffffu); ti.pre.symbol = (uint8_t)(last >> 16); ti.has_pre = got ? 1u : 0u;
+      hwarm = htail; hnwarm = got < 16u ? got : 16u;
     }
     const float samp_freqw = freqw;                       // sampler->update_freq(freqw), sdr.h:790
     unsigned *dp = body ? po + cnt : pw;
@@ -828,7 +853,16 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         } else {
           e = lut_unpack(raw.x, raw.y);
         }
-        *dp = raw.x; dp += keep;
+        if (HARD) {
+          const unsigned hs = (raw.x >> 16) & 3u;
+          htail = (htail << 2) | hs;
+          if (body) {
+            hacc = (hacc << 2) | hs;
+            if ((++hcnt & 15u) == 0) hrow[(hcnt >> 4) - 1] = hacc;
+          }
+        } else {
+          *dp = raw.x; dp += keep;
+        }
         last = raw.x;
         ++nsym;
         const bool acq = (int)(got + nsym) <= C.acq_syms && !body;
@@ -884,7 +918,17 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     }
   }
   ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
-  if (valid) a.info[j] = ti;
+  if (valid) {
+    if (HARD) {
+      if (hcnt & 15u) hrow[hcnt >> 4] = hacc << (2 * (16 - (hcnt & 15u)));
+      rx_tile_info_h th;
+      th.mu_begin = ti.mu_begin; th.phase_begin = ti.phase_begin; th.mu_end = mu; th.phase_end = phase;
+      th.count = cnt; th.has_pre = ti.has_pre; th.n_warm = hnwarm; th.warm_tail = hwarm; th.body_tail = htail;
+      a.hinfo[j] = th;
+    } else {
+      a.info[j] = ti;
+    }
+  }
   {
     // inclusive composition over the tiles of this wavefront (lane order = stream order; lanes without a tile — the
     // highest ones — hold the identity and are never read): lane L ends with maps[first] … maps[L] composed
@@ -915,11 +959,11 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   }
 }
 
-template <int SAMP, bool ARITH, int FMT, bool LDS>
+template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
   __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * kRowBytes : 16];
-  if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP, FMT>(a); }
-  else rx_tile_tol<SAMP, ARITH, FMT, LDS>(a, 1u + (blockIdx.x - 1u) * a.lanes_per_wave, (int)threadIdx.x, lds);
+  if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP, FMT, HARD>(a); }
+  else rx_tile_tol<SAMP, ARITH, FMT, LDS, HARD>(a, 1u + (blockIdx.x - 1u) * a.lanes_per_wave, (int)threadIdx.x, lds);
 }
 
 // fir_sampler in the tiled mode: the tolerance tiles' shifted taps, rebuilt from the carried freqw before every run
@@ -1049,6 +1093,9 @@ struct lsdr_rx {
   // tiled mode
   lsdr_softsymbol *d_stage; size_t stage_cap;
   lsdr_softsymbol *d_wstage; size_t wstage_cap;
+  unsigned *d_hstage; size_t hstage_cap;      // LSDR_SYM_HARD2: packed rows, [tiles_cap] info records
+  rx_tile_info_h *d_hinfo;
+  size_t out_sym_offset;                     // LSDR_SYM_HARD2: where the next run starts writing in `out` (symbols)
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
   rx_ema_map *d_ema;              // [tiles_cap] per-tile exclusive prefix inside its wavefront
   rx_ema_map *d_ema_wave;         // [tiles_cap + 1] per-wavefront estimator maps
@@ -1190,7 +1237,10 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
   const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
 
-  if (r->tiles_cap < n_tiles || r->stage_cap < (size_t)n_tiles * stage_stride || r->wstage_cap < (size_t)n_tiles * sym_per_chunk) {
+  const bool hard = r->cfg.out_format == LSDR_SYM_HARD2;
+  const unsigned hstride = stage_stride / 16 + 2;          // words per packed row
+  if (r->tiles_cap < n_tiles || (!hard && (r->stage_cap < (size_t)n_tiles * stage_stride || r->wstage_cap < (size_t)n_tiles * sym_per_chunk)) ||
+      (hard && r->hstage_cap < (size_t)n_tiles * hstride)) {
     // scratch grows: queued runs may still be using the old buffers
     LSDR_HIP(hipStreamSynchronize(c->stream));
   }
@@ -1202,14 +1252,21 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
     LSDR_HIP(hipMalloc((void **)&r->d_part, ((n_tiles + kSeamBlock - 1) / kSeamBlock) * sizeof(rx_seam_part)));
     LSDR_HIP(hipMalloc((void **)&r->d_info, n_tiles * sizeof(rx_tile_info)));
     LSDR_HIP(hipMalloc((void **)&r->d_fix, n_tiles * sizeof(rx_tile_fix)));
+    (void)hipFree(r->d_hinfo); r->d_hinfo = nullptr;
+    if (hard) LSDR_HIP(hipMalloc((void **)&r->d_hinfo, n_tiles * sizeof(rx_tile_info_h)));
     r->tiles_cap = n_tiles;
   }
-  if (r->stage_cap < (size_t)n_tiles * stage_stride) {
+  if (hard && r->hstage_cap < (size_t)n_tiles * hstride) {
+    (void)hipFree(r->d_hstage);
+    LSDR_HIP(hipMalloc((void **)&r->d_hstage, (size_t)n_tiles * hstride * sizeof(unsigned)));
+    r->hstage_cap = (size_t)n_tiles * hstride;
+  }
+  if (!hard && r->stage_cap < (size_t)n_tiles * stage_stride) {
     (void)hipFree(r->d_stage);
     LSDR_HIP(hipMalloc((void **)&r->d_stage, (size_t)n_tiles * stage_stride * sizeof(lsdr_softsymbol)));
     r->stage_cap = (size_t)n_tiles * stage_stride;
   }
-  if (r->wstage_cap < (size_t)n_tiles * sym_per_chunk) {
+  if (!hard && r->wstage_cap < (size_t)n_tiles * sym_per_chunk) {
     (void)hipFree(r->d_wstage);
     LSDR_HIP(hipMalloc((void **)&r->d_wstage, (size_t)n_tiles * sym_per_chunk * sizeof(lsdr_softsymbol)));
     r->wstage_cap = (size_t)n_tiles * sym_per_chunk;
@@ -1241,6 +1298,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   a.stage_stride = stage_stride;
   a.stage = r->d_stage;
   a.wstage = r->d_wstage; a.wstride = sym_per_chunk;
+  a.hstage = r->d_hstage; a.hstride = hstride; a.hinfo = r->d_hinfo;
   a.info = r->d_info;
   a.ema = r->d_ema;
   a.ema_wave = r->d_ema_wave;
@@ -1267,10 +1325,12 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   // the direct loads (A/B measurements)
   static const bool no_lds = getenv("LSDR_RX_NO_LDS") != nullptr;
   const bool use_lds = r->cfg.in_format == LSDR_IN_CU8 && r->cfg.sampler != LSDR_SAMP_FIR && !no_lds && r->omega <= 8.f;
-#define LSDR_RX_LAUNCH_F(S, A, F, L) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L>), dim3(blocks), dim3(64), 0, c->stream, a)
-#define LSDR_RX_LAUNCH(S, A) do { if (use_lds) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2)); \
-                                  else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, false); \
-                                  else LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CF32, false); } while (0)
+  if (hard && !use_lds) { lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 needs cu8 input with the nearest or linear sampler"); return LSDR_E_UNSUPPORTED; }
+#define LSDR_RX_LAUNCH_F(S, A, F, L, H) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L, H>), dim3(blocks), dim3(64), 0, c->stream, a)
+#define LSDR_RX_LAUNCH(S, A) do { if (hard) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), (S != 2)); \
+                                  else if (use_lds) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), false); \
+                                  else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, false, false); \
+                                  else LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CF32, false, false); } while (0)
 #define LSDR_RX_LAUNCH_S(S) do { if (r->qpsk_arith) LSDR_RX_LAUNCH(S, true); else LSDR_RX_LAUNCH(S, false); } while (0)
   if (r->cfg.sampler == LSDR_SAMP_FIR)
     hipLaunchKernelGGL(k_rx_fir_refresh, dim3(1), dim3(256), 0, c->stream, (const rx_state_dev *)r->d_state, (const float2 *)r->d_trig,
@@ -1290,6 +1350,14 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   // ---- seam pass + compaction, all on the stream
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
+  if (hard) {
+    hipLaunchKernelGGL(k_rx_seam_h, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
+                       (const rx_tile_info_h *)r->d_hinfo, r->d_fix, n_tiles, r->omega, R, quad, r->d_part, (const uint8_t *)r->d_relabel);
+    hipLaunchKernelGGL((k_rx_compact_h<rx_state_dev>), dim3(n_tiles), dim3(64), 0, c->stream, (const unsigned *)r->d_hstage, hstride,
+                       (const rx_tile_info_h *)r->d_hinfo, (const rx_tile_fix *)r->d_fix, (const rx_seam_part *)r->d_part,
+                       (const uint8_t *)r->d_relabel, n_tiles, R, quad, reinterpret_cast<unsigned *>(out),
+                       (unsigned long long)r->out_sym_offset, r->d_state, r->h_res_dev + slot);
+  } else {
   hipLaunchKernelGGL((k_rx_seam<rx_tile_info, lsdr_softsymbol>), dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
                      (const rx_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, R, quad, r->d_part,
                      (const lsdr_softsymbol *)r->d_stage, stage_stride, (const lsdr_softsymbol *)r->d_wstage, sym_per_chunk,
@@ -1298,6 +1366,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
                      stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
                      (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, R, quad, out, r->d_state,
                      r->h_res_dev + slot);   // totals go straight into the pinned ring slot (no copy command)
+  }
   LSDR_HIP(hipGetLastError());
   LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
   r->ring_tiles[slot] = n_tiles;
@@ -1374,6 +1443,12 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_ARG(cfg->omega > 0 && cfg->meas_decimation >= 1);
   LSDR_ARG(cfg->mode == LSDR_RX_SERIAL || cfg->mode == LSDR_RX_TILED);
   LSDR_ARG(cfg->in_format == LSDR_IN_CF32 || cfg->in_format == LSDR_IN_CU8);
+  LSDR_ARG(cfg->out_format == LSDR_SYM_SOFT || cfg->out_format == LSDR_SYM_HARD2);
+  if (cfg->out_format == LSDR_SYM_HARD2 && (cfg->mode != LSDR_RX_TILED || cfg->cstln != LSDR_QPSK || cfg->in_format != LSDR_IN_CU8 ||
+                                            cfg->sampler == LSDR_SAMP_FIR)) {
+    lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 is the tiled QPSK receiver on cu8 input (nearest / linear sampler)");
+    return LSDR_E_UNSUPPORTED;
+  }
   LSDR_HIP(hipSetDevice(c->device));
   lsdr_rx *r = new lsdr_rx();
   r->ctx = c;
@@ -1460,6 +1535,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_HIP(hipMalloc((void **)&r->d_state_next, sizeof(rx_state_dev)));
   LSDR_HIP(hipHostMalloc((void **)&r->h_snap, sizeof(rx_state_dev), hipHostMallocDefault));
   r->d_wstage = nullptr; r->wstage_cap = 0;
+  r->d_hstage = nullptr; r->hstage_cap = 0; r->d_hinfo = nullptr; r->out_sym_offset = 0;
   r->h_res = nullptr; r->ring_head = 0; r->ring_count = 0; r->st_stale_host = false;
   for (int i = 0; i < lsdr_rx::kRing; ++i) r->ev[i] = nullptr;
   r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
@@ -1501,6 +1577,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   (void)hipFree(r->d_state); (void)hipFree(r->d_counters);
   (void)hipFree(r->d_meas); (void)hipFree(r->d_cstln);
   (void)hipFree(r->d_stage); (void)hipFree(r->d_info); (void)hipFree(r->d_fix); (void)hipFree(r->d_relabel); (void)hipFree(r->d_seam); (void)hipFree(r->d_part); (void)hipFree(r->d_wstage);
+  (void)hipFree(r->d_hstage); (void)hipFree(r->d_hinfo);
   (void)hipFree(r->d_ema); (void)hipFree(r->d_ema_wave); (void)hipFree(r->d_state_next);
   if (r->h_snap) (void)hipHostFree(r->h_snap);
   if (r->h_res) (void)hipHostFree(r->h_res);
@@ -1573,6 +1650,19 @@ int lsdr_rx_run_async(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *
   LSDR_ARG(r && consumed && (in || !n_in) && out);
   if (r->cfg.mode != LSDR_RX_TILED) { lsdr_set_error("cstln_receiver: lsdr_rx_run_async needs LSDR_RX_TILED"); return LSDR_E_UNSUPPORTED; }
   return rx_tiled_enqueue(r, in, n_in, out, cap_out, consumed, false, 0, nullptr);
+}
+
+int lsdr_rx_run_async_hs2(lsdr_rx *r, const void *in, size_t n_in, uint32_t *out_words, size_t out_sym_offset, size_t cap_out,
+                          size_t *consumed) {
+  LSDR_ARG(r && consumed && (in || !n_in) && out_words);
+  if (r->cfg.mode != LSDR_RX_TILED || r->cfg.out_format != LSDR_SYM_HARD2) {
+    lsdr_set_error("cstln_receiver: lsdr_rx_run_async_hs2 needs LSDR_RX_TILED with LSDR_SYM_HARD2");
+    return LSDR_E_UNSUPPORTED;
+  }
+  r->out_sym_offset = out_sym_offset;
+  const int rc = rx_tiled_enqueue(r, in, n_in, reinterpret_cast<lsdr_softsymbol *>(out_words), cap_out, consumed, false, 0, nullptr);
+  r->out_sym_offset = 0;
+  return rc;
 }
 
 int lsdr_rx_wait(lsdr_rx *r, size_t *produced) {

@@ -38,7 +38,9 @@ struct deconv_carry {      // sync_t fields that cross run() calls (dvb.h:297-30
 //   refill q (q = 0…R-1) shifts in m(q) symbols and emits pp bits; m(0) = m0, m(q>0) = pw/2.
 //   output bit stream = n_out0 carried bits ++ refill bits; byte k = bits [8k, 8k+8).
 struct deconv_plan {
-  const lsdr_softsymbol *in;
+  const lsdr_softsymbol *in;       // soft symbols, or (PACKED) null
+  const unsigned *in_words;        // PACKED: "hs2" hard symbols, 16 per word MSB first (rx_tiling.h); symbol i of this call is
+  unsigned long long in_off;       //         symbol in_off + i of that stream
   unsigned char *out;
   unsigned long long n_bytes;
   unsigned long long refills;      // R
@@ -49,18 +51,54 @@ struct deconv_plan {
   int n_out_end;
 };
 
+template <bool PACKED>
+__device__ __forceinline__ unsigned deconv_sym(const deconv_plan &P, unsigned long long i) {   // hard symbol i of this call
+  if (PACKED) {
+    const unsigned long long k = P.in_off + i;
+    return (P.in_words[k >> 4] >> (30 - 2 * (int)(k & 15))) & 3u;
+  }
+  return P.in[i].symbol & 3u;
+}
 // I/Q window after refill q: the 64 newest I/Q bits, newest symbol in the low bits (dvb.h:378-384).
+template <bool PACKED>
 __device__ __forceinline__ unsigned long long deconv_window(const deconv_dev &D, const deconv_plan &P,
                                                             unsigned long long in0, unsigned long long q) {
   const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);   // symbols shifted in so far
   unsigned long long w = 0;
   const unsigned take = nsym < 32 ? (unsigned)nsym : 32u;
+  if (PACKED && take == 32) {
+    // the 32 symbols [nsym−32, nsym) are 64 consecutive bits of the packed stream, oldest first — already the window's
+    // order; the symbol → I/Q map of the locked alignment is applied to all of them at once
+    const unsigned long long o = P.in_off + nsym - 32;
+    const unsigned long long wi = o >> 4;
+    const int sh = 2 * (int)(o & 15);
+    const unsigned a = P.in_words[wi], b = P.in_words[wi + 1], c = sh ? P.in_words[wi + 2] : 0u;
+    const unsigned hi = sh ? (a << sh) | (b >> (32 - sh)) : a, lo = sh ? (b << sh) | (c >> (32 - sh)) : b;
+    const unsigned map4 = (unsigned)D.lut[0] | ((unsigned)D.lut[1] << 2) | ((unsigned)D.lut[2] << 4) | ((unsigned)D.lut[3] << 6);
+    const unsigned M = 0x55555555u;
+    unsigned res[2];
+    const unsigned xs[2] = {hi, lo};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const unsigned x = xs[h], b1 = (x >> 1) & M, b0 = x & M;
+      const unsigned sel[4] = {~b1 & ~b0 & M, ~b1 & b0, b1 & ~b0, b1 & b0};
+      unsigned o2 = 0;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        const unsigned m = (map4 >> (2 * v)) & 3u;
+        o2 |= (m & 1u ? sel[v] : 0u) | (m & 2u ? sel[v] << 1 : 0u);
+      }
+      res[h] = o2;
+    }
+    return ((unsigned long long)res[0] << 32) | res[1];
+  }
   for (unsigned k = 0; k < take; ++k)   // oldest of the `take` first
-    w = (w << 2) | D.lut[P.in[nsym - take + k].symbol & 3];
+    w = (w << 2) | D.lut[deconv_sym<PACKED>(P, nsym - take + k)];
   if (take < 32) w |= in0 << (2 * take);
   return w;
 }
 
+template <bool PACKED>
 __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
   const unsigned long long in0 = P.carry->in, out0 = P.carry->out;
   const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
@@ -77,8 +115,8 @@ __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
         if (q != q_cached) {
           if (q_cached != ~0ull && q == q_cached + 1) {   // slide by one refill
             const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);
-            for (int s = D.pw / 2; s > 0; --s) w = (w << 2) | D.lut[P.in[nsym - s].symbol & 3];
-          } else w = deconv_window(D, P, in0, q);
+            for (int s = D.pw / 2; s > 0; --s) w = (w << 2) | D.lut[deconv_sym<PACKED>(P, nsym - s)];
+          } else w = deconv_window<PACKED>(D, P, in0, q);
           q_cached = q;
         }
         bit = (unsigned)par64(w & D.deconv[bi]);
@@ -90,7 +128,7 @@ __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
   if (k == 0) {   // state for the next call
     deconv_carry c;
     if (P.refills) {
-      c.in = deconv_window(D, P, in0, P.refills - 1);
+      c.in = deconv_window<PACKED>(D, P, in0, P.refills - 1);
       unsigned long long o = out0;   // only the low n_out_end bits matter afterwards
       const unsigned long long w = c.in;
       // bits still pending come from the tail of the last refill(s); n_out_end < pp + 8
@@ -103,7 +141,7 @@ __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
         else {
           const unsigned long long q = (unsigned long long)g / (unsigned)D.pp;
           const int bi = D.pp - 1 - (int)((unsigned long long)g % (unsigned)D.pp);
-          const unsigned long long wq = q == P.refills - 1 ? w : deconv_window(D, P, in0, q);
+          const unsigned long long wq = q == P.refills - 1 ? w : deconv_window<PACKED>(D, P, in0, q);
           bit = (unsigned)par64(wq & D.deconv[bi]);
         }
         o = (o << 1) | bit;
@@ -849,9 +887,10 @@ int lsdr_deconv_next_sync(lsdr_deconv *d) {   // dvb.h:185-193
   return LSDR_OK;
 }
 
-int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
-                    size_t *consumed, size_t *produced) {
+static int deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, const uint32_t *in_words, size_t in_off, size_t n_in, uint8_t *out,
+                      size_t cap_out, size_t *consumed, size_t *produced) {
   LSDR_ARG(d && consumed && produced);
+  if (in_words && d->fastlock) { lsdr_set_error("deconvol_sync: fastlock is not available on packed symbols"); return LSDR_E_UNSUPPORTED; }
   const deconv_host &H = d->H;
   size_t pos = (size_t)d->skip;   // in.read(skip), dvb.h:420-421
   d->skip = 0;
@@ -863,7 +902,7 @@ int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint
   const long long maxrd = (long long)((readable - 64) / (size_t)(H.pw / 2) * (size_t)H.pp / 8);
   long long n = maxrd < (long long)cap_out ? maxrd : (long long)cap_out;
   if (n < 32) return LSDR_OK;   // also covers n == 0
-  LSDR_ARG(in && out);
+  LSDR_ARG((in || in_words) && out);
   if (d->fastlock) {   // dvb.h:428-452
     deconv_err_args A;
     for (int b = 0; b < 8; ++b) { A.deconv[b] = b < H.pp ? H.deconv[b] : 0; A.deconv2[b] = b < H.pp ? d->deconv2[b] : 0; }
@@ -912,7 +951,8 @@ int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint
   for (int sidx = 0; sidx < 4; ++sidx) D.lut[sidx] = d->luts[a][sidx];
   D.pp = H.pp; D.pw = H.pw;
   deconv_plan P;
-  P.in = in + pos;
+  P.in = in_words ? nullptr : in + pos;
+  P.in_words = in_words; P.in_off = (unsigned long long)(in_off + pos);
   P.out = out;
   P.n_bytes = (unsigned long long)n;
   P.refills = R;
@@ -921,7 +961,8 @@ int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint
   P.carry = d->d_carry[d->cur[a]] + a;
   P.carry_next = d->d_carry[d->cur[a] ^ 1] + a;
   P.n_out_end = (int)(n_out0 + (long long)R * H.pp - 8 * n);
-  hipLaunchKernelGGL(k_deconv, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->ctx->stream, D, P);
+  if (in_words) hipLaunchKernelGGL(k_deconv<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->ctx->stream, D, P);
+  else hipLaunchKernelGGL(k_deconv<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->ctx->stream, D, P);
   LSDR_HIP(hipGetLastError());
   d->cur[a] ^= 1;
   if (R) d->n_in[a] = 64 - H.pw;
@@ -929,6 +970,17 @@ int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint
   *consumed = pos + (size_t)used;
   *produced = (size_t)n;
   return LSDR_OK;
+}
+
+int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                    size_t *consumed, size_t *produced) {
+  return deconv_run(d, in, nullptr, 0, n_in, out, cap_out, consumed, produced);
+}
+
+int lsdr_deconv_run_hs2(lsdr_deconv *d, const uint32_t *in_words, size_t sym_offset, size_t n_in, uint8_t *out, size_t cap_out,
+                        size_t *consumed, size_t *produced) {
+  LSDR_ARG(in_words || !n_in);
+  return deconv_run(d, nullptr, in_words, sym_offset, n_in, out, cap_out, consumed, produced);
 }
 
 // ------------------------------------------------------------------ mpeg_sync

@@ -39,9 +39,11 @@ struct rx_seam_result { unsigned long long total; unsigned rot_final, ndup, nmis
 
 struct seam_step { unsigned insert, drop, k, bad; };
 
-template <typename INFO, typename SYM>
-__device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur, float omega, int R, float quad,
-                                               const SYM *prev_body, const SYM *cur_warm, const uint8_t *relabel) {
+// gw(i): i-th symbol from the END of the current tile's (last) warm-up chunk, gp(i): i-th from the end of the previous
+// tile's body; n_warm / n_prev: how many of each can be asked for.
+template <typename INFO, typename GW, typename GP>
+__device__ __forceinline__ seam_step seam_eval_core(const INFO &prev, const INFO &cur, float omega, int R, float quad,
+                                                    int n_warm, int n_prev, GW gw, GP gp, const uint8_t *relabel) {
   seam_step r; r.insert = 0; r.drop = 0; r.bad = 0;
   const float d = cur.mu_begin - prev.mu_end;
   if (d > omega / 2 && cur.has_pre) r.insert = 1;
@@ -57,16 +59,12 @@ __device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur
   // vote on the overlapping decisions: warm-up symbol w[i] (i = 0: last) ↔ body symbol p[i] of the previous tile,
   // shifted by one when the two tiles disagree on the boundary symbol (insert: w[0] is new; drop: body[0] repeats p[0])
   const int wo = r.insert ? 1 : 0, po = r.drop ? 1 : 0;
-  const int have = min((int)cur.n_warm - wo, (int)prev.count - po);
+  const int have = min(n_warm - wo, n_prev - po);
   if (have >= kSeamVote) {
     int best = -1, best_k = 0;
     for (int kk = 0; kk < R; ++kk) {
       int hits = 0;
-      for (int i = 0; i < kSeamVote; ++i) {
-        const unsigned ws = rx_symbol_of(cur_warm[(int)cur.n_warm - 1 - wo - i]);
-        const unsigned ps = rx_symbol_of(prev_body[(int)prev.count - 1 - po - i]);
-        hits += relabel[kk * 256 + ws] == ps;
-      }
+      for (int i = 0; i < kSeamVote; ++i) hits += relabel[kk * 256 + gw(wo + i)] == gp(po + i);
       if (hits > best) { best = hits; best_k = kk; }
     }
     if (best >= kSeamVote - 2) {                // clear majority: trust the decisions
@@ -76,6 +74,14 @@ __device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur
     }
   }
   return r;
+}
+
+template <typename INFO, typename SYM>
+__device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur, float omega, int R, float quad,
+                                               const SYM *prev_body, const SYM *cur_warm, const uint8_t *relabel) {
+  return seam_eval_core(prev, cur, omega, R, quad, (int)cur.n_warm, (int)prev.count,
+                        [&](int i) { return rx_symbol_of(cur_warm[(int)cur.n_warm - 1 - i]); },
+                        [&](int i) { return rx_symbol_of(prev_body[(int)prev.count - 1 - i]); }, relabel);
 }
 
 // Seam pass, two kernels, no single-workgroup scan:
@@ -89,27 +95,12 @@ __device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur
 constexpr unsigned kSeamBlock = 256, kSeamWaves = kSeamBlock / 64;
 struct rx_seam_part { unsigned long long cnt; unsigned rot, ndup, nmiss, nbad; };
 
-template <typename INFO, typename SYM>
-__global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
-                                                  int R, float quad, rx_seam_part *part, const SYM *stage, unsigned stage_stride,
-                                                  const SYM *wstage, unsigned wstride, const uint8_t *relabel) {
-  const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
+// block-local exclusive scan of (symbol count, quadrant step) over the kSeamBlock tiles of a workgroup → fix[], part[]
+__device__ __forceinline__ void seam_block_scan(long long add, unsigned k, unsigned ins, unsigned drp, unsigned bad, unsigned j,
+                                                unsigned n_tiles, unsigned rmask, rx_tile_fix *fix, rx_seam_part *part) {
   __shared__ unsigned long long s_cnt[kSeamWaves];
   __shared__ unsigned s_rot[kSeamWaves], s_d[kSeamWaves], s_m[kSeamWaves], s_b[kSeamWaves];
   const unsigned tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const unsigned j = blockIdx.x * kSeamBlock + tid;
-  long long add = 0;
-  unsigned k = 0, ins = 0, drp = 0, bad = 0;
-  if (j < n_tiles) {
-    const INFO cur = info[j];
-    add = (long long)cur.count;
-    if (j > 0) {
-      const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad, stage + (unsigned long long)(j - 1) * stage_stride,
-                                     wstage + (unsigned long long)j * wstride, relabel);
-      add += (long long)st.insert - (long long)st.drop;
-      k = st.k; ins = st.insert; drp = st.drop; bad = st.bad;
-    }
-  }
   long long icnt = add;
   unsigned irot = k, nd = drp, nm = ins, nb = bad;
 #pragma unroll
@@ -138,6 +129,27 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_til
     for (unsigned i = 0; i < kSeamWaves; ++i) { p.cnt += s_cnt[i]; p.rot = (p.rot + s_rot[i]) & rmask; p.ndup += s_d[i]; p.nmiss += s_m[i]; p.nbad += s_b[i]; }
     part[blockIdx.x] = p;
   }
+}
+
+template <typename INFO, typename SYM>
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                                  int R, float quad, rx_seam_part *part, const SYM *stage, unsigned stage_stride,
+                                                  const SYM *wstage, unsigned wstride, const uint8_t *relabel) {
+  const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
+  const unsigned j = blockIdx.x * kSeamBlock + threadIdx.x;
+  long long add = 0;
+  unsigned k = 0, ins = 0, drp = 0, bad = 0;
+  if (j < n_tiles) {
+    const INFO cur = info[j];
+    add = (long long)cur.count;
+    if (j > 0) {
+      const seam_step st = seam_eval(info[j - 1], cur, omega, R, quad, stage + (unsigned long long)(j - 1) * stage_stride,
+                                     wstage + (unsigned long long)j * wstride, relabel);
+      add += (long long)st.insert - (long long)st.drop;
+      k = st.k; ins = st.insert; drp = st.drop; bad = st.bad;
+    }
+  }
+  seam_block_scan(add, k, ins, drp, bad, j, n_tiles, rmask, fix, part);
 }
 
 // relabel: [nrot][256] symbol relabelling per accumulated quadrant step; rx_relabel(sym, map) applies it to a record.
@@ -181,5 +193,150 @@ __global__ __launch_bounds__(64) void k_rx_compact(const SYM *stage, unsigned st
   }
 }
 
+
+// ---- packed hard symbols ("hs2": QPSK decisions, 2 bits each) -------------------------------------------------------------
+// The default leandvb chain feeds cstln_receiver's soft symbols to deconvol_sync, which reads nothing but `symbol & 3`
+// (dvb.h:369-417).  In that chain the tiles keep only those two bits: 16 symbols per 32-bit word, MSB first (symbol k of a
+// stream sits in word k/16 at bits 31−2(k%16) … 30−2(k%16)) — the order in which a tile shifts them in and in which the
+// deconvolver's 64-bit window wants them (older symbols in higher bits).  Per tile: a row of packed body symbols (the last
+// word left-aligned) and, in its info record, the last ≤ 16 warm-up and body symbols for the seam vote.
+struct rx_tile_info_h {
+  float mu_begin, phase_begin, mu_end, phase_end;
+  unsigned count;                // body symbols
+  unsigned has_pre;              // a warm-up symbol exists (pre = warm_tail & 3)
+  unsigned n_warm;               // warm-up symbols held in warm_tail (≤ 16)
+  unsigned warm_tail, body_tail; // newest symbol in bits 1:0
+};
+
+__device__ __forceinline__ unsigned hs2_get(const unsigned *words, long long k) {   // symbol k of a packed stream
+  return (words[k >> 4] >> (30 - 2 * (int)(k & 15))) & 3u;
+}
+// apply a 4-entry symbol map (map4: new label of v in bits 2v+1:2v) to all 16 symbols of a word
+__device__ __forceinline__ unsigned hs2_map_word(unsigned x, unsigned map4) {
+  const unsigned M = 0x55555555u, b1 = (x >> 1) & M, b0 = x & M;
+  const unsigned sel[4] = {~b1 & ~b0 & M, ~b1 & b0, b1 & ~b0, b1 & b0};
+  unsigned out = 0;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const unsigned m = (map4 >> (2 * v)) & 3u;
+    out |= (m & 1u ? sel[v] : 0u) | (m & 2u ? sel[v] << 1 : 0u);
+  }
+  return out;
+}
+__device__ __forceinline__ unsigned hs2_map4(const uint8_t *map) {   // [256]-entry relabel row → packed 4-entry map
+  return (unsigned)(map[0] & 3) | ((unsigned)(map[1] & 3) << 2) | ((unsigned)(map[2] & 3) << 4) | ((unsigned)(map[3] & 3) << 6);
+}
+// 16 symbols starting at symbol offset o (may be negative or reach past the row: zeros there) of a packed row of nw words
+__device__ __forceinline__ unsigned hs2_fetch16(const unsigned *row, long long nw, long long o) {
+  const long long wi = o >> 4;                 // floor
+  const int sh = 2 * (int)(o & 15);
+  const unsigned a = (wi >= 0 && wi < nw) ? row[wi] : 0u, b = (wi + 1 >= 0 && wi + 1 < nw) ? row[wi + 1] : 0u;
+  return sh ? (a << sh) | (b >> (32 - sh)) : a;
+}
+
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                                          int R, float quad, rx_seam_part *part, const uint8_t *relabel) {
+  const unsigned rmask = (unsigned)R - 1;
+  const unsigned j = blockIdx.x * kSeamBlock + threadIdx.x;
+  long long add = 0;
+  unsigned k = 0, ins = 0, drp = 0, bad = 0;
+  if (j < n_tiles) {
+    const rx_tile_info_h cur = info[j];
+    add = (long long)cur.count;
+    if (j > 0) {
+      const rx_tile_info_h prev = info[j - 1];
+      const seam_step st = seam_eval_core(prev, cur, omega, R, quad, (int)cur.n_warm, (int)(prev.count < 16u ? prev.count : 16u),
+                                          [&](int i) { return (cur.warm_tail >> (2 * i)) & 3u; },
+                                          [&](int i) { return (prev.body_tail >> (2 * i)) & 3u; }, relabel);
+      add += (long long)st.insert - (long long)st.drop;
+      k = st.k; ins = st.insert; drp = st.drop; bad = st.bad;
+    }
+  }
+  seam_block_scan(add, k, ins, drp, bad, j, n_tiles, rmask, fix, part);
+}
+
+// Compaction of the packed rows: one wavefront per tile writes the output words that START inside the tile's symbol range
+// [D, D + len) — plus, for tile 0, the word that holds out_sym_offset; a word that two tiles share is written by the later
+// one, which takes the earlier tile's last symbols from that tile's row (no atomics, no pre-zeroing).  The symbols before
+// out_sym_offset in the first word (a caller's leftover symbols) are preserved.
+template <typename STATE>
+__global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, unsigned hstride, const rx_tile_info_h *info,
+                                                     const rx_tile_fix *fix, const rx_seam_part *part, const uint8_t *relabel,
+                                                     unsigned n_tiles, int R, float quad, unsigned *out, unsigned long long out_sym_offset,
+                                                     STATE *state, rx_seam_result *res) {
+  const unsigned j = blockIdx.x;
+  if (j >= n_tiles) return;
+  const unsigned rmask = (unsigned)R - 1;
+  const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock;
+  // totals of the seam blocks before tile j's and before tile j−1's
+  auto block_base = [&](unsigned tile, unsigned long long &base, unsigned &brot) {
+    const unsigned mypart = tile / kSeamBlock;
+    base = 0; brot = 0;
+    for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
+  };
+  unsigned long long base, pbase = 0;
+  unsigned brot, pbrot = 0;
+  block_base(j, base, brot);
+  if (j > 0) block_base(j - 1, pbase, pbrot);
+  if (j == 0 && threadIdx.x == 0) {
+    rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0; sr.freq_tap = rx_freq_tap(state);
+    for (unsigned i = 0; i < nparts; ++i) {
+      sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
+      sr.ndup += part[i].ndup; sr.nmiss += part[i].nmiss; sr.nbad += part[i].nbad;
+    }
+    *res = sr;                 // host-pinned ring slot
+    __threadfence_system();
+    if (sr.rot_final) rx_rotate_back(state, sr.rot_final, quad);
+  }
+  // this tile's sequence T = [pre]? ++ body[skip …): destination symbols [D, D + len); body symbol b sits at D' = b + Q
+  const rx_tile_fix f = fix[j];
+  const rx_tile_info_h ti = info[j];
+  const long long skip = f.drop_first ? 1 : 0, ins = f.insert_pre ? 1 : 0;
+  const long long D = (long long)(out_sym_offset + base + f.out_offset), len = ins + (long long)ti.count - skip;
+  const long long Q = D + ins - skip;
+  const unsigned map4 = hs2_map4(relabel + ((f.rot + brot) & rmask) * 256);
+  const unsigned *row = hstage + (unsigned long long)j * hstride;
+  const long long nw = ((long long)ti.count + 15) >> 4;
+  // previous tile (for the shared first word)
+  long long pQ = 0, pnw = 0, pD = 0, pins = 0;
+  unsigned pmap4 = 0, ppre = 0;
+  const unsigned *prow = nullptr;
+  if (j > 0) {
+    const rx_tile_fix pf = fix[j - 1];
+    const rx_tile_info_h pti = info[j - 1];
+    pins = pf.insert_pre ? 1 : 0;
+    pD = (long long)(out_sym_offset + pbase + pf.out_offset);
+    pQ = pD + pins - (pf.drop_first ? 1 : 0);
+    pmap4 = hs2_map4(relabel + ((pf.rot + pbrot) & rmask) * 256);
+    prow = hstage + (unsigned long long)(j - 1) * hstride;
+    pnw = ((long long)pti.count + 15) >> 4;
+    ppre = pti.warm_tail & 3u;
+  }
+  const long long w_own0 = D >> 4;                                         // first word this tile writes (a shared one included)
+  const long long end = D + len;
+  const long long w_last = j == n_tiles - 1 ? (end + 15) >> 4 : end >> 4;  // exclusive; a partial last word belongs to the next tile
+  for (long long m = w_own0 + threadIdx.x; m < w_last; m += 64) {
+    const long long s0 = m << 4;                                            // first symbol of the word
+    // part from this tile: symbols u with D ≤ s0+u < end
+    unsigned cur = hs2_fetch16(row, nw, s0 - Q);
+    if (ins && D >= s0 && D < s0 + 16) cur = (cur & ~(3u << (30 - 2 * (int)(D - s0)))) | ((ti.warm_tail & 3u) << (30 - 2 * (int)(D - s0)));
+    const long long lo = D > s0 ? D - s0 : 0, hi = end < s0 + 16 ? end - s0 : 16;       // valid symbol slots [lo, hi)
+    unsigned mask = hi > lo ? (hi - lo >= 16 ? 0xffffffffu : ((1u << (2 * (int)(hi - lo))) - 1u) << (32 - 2 * (int)hi)) : 0u;
+    unsigned word = hs2_map_word(cur, map4) & mask;
+    if (lo > 0) {
+      if (j > 0) {       // symbols [s0, D) are the previous tile's last ones
+        unsigned pv = hs2_fetch16(prow, pnw, s0 - pQ);
+        if (pins && pD >= s0 && pD < s0 + 16) pv = (pv & ~(3u << (30 - 2 * (int)(pD - s0)))) | (ppre << (30 - 2 * (int)(pD - s0)));
+        const unsigned pmask = ~0u << (32 - 2 * (int)lo);
+        word |= hs2_map_word(pv, pmap4) & pmask;
+      } else {           // tile 0: the caller's symbols before out_sym_offset stay
+        word |= out[m] & (~0u << (32 - 2 * (int)lo));
+      }
+    }
+    out[m] = word;
+  }
+}
 
 #endif  // LSDR_RX_TILING_H

@@ -119,3 +119,70 @@ def test_tiled_cu8_tracks_the_serial_receiver(capi, ctx, oracle, capture):
     assert out["consumed"] == ref["consumed"]
     rep = check_tiled(out["sym"], ref["sym"], stats, first_exact=512 // 2)
     assert rep["pass"], (rep, TOL)
+
+
+# ---- LSDR_SYM_HARD2: the decisions only, packed (what deconvol_sync reads of a soft symbol) -----------------------------------
+@pytest.mark.parametrize("sampler", [0, 1])
+@pytest.mark.parametrize("tile_len,warm,offset", [(1024, 512, 0), (4096, 512, 37), (256, 256, 16), (2048, 1024, 5)])
+def test_packed_hard_output_is_the_soft_output_s_symbol_field(capi, ctx, capture, sampler, tile_len, warm, offset):
+    """Same tiles, same arithmetic: the packed stream of a SYM_HARD2 run is symbol & 3 of the soft run's symbols, the symbols
+    already in front of out_sym_offset stay untouched, count / seam statistics / carried state are the same; two consecutive
+    runs continue one stream."""
+    kw = dict(sampler=sampler, cstln=1, omega=OMEGA, meas_decimation=4096, mode=capi.RX_TILED, tile_len=tile_len, tile_warmup=warm,
+              in_format=capi.IN_CU8)
+    soft = capi.CstlnReceiver(ctx, **kw)
+    hard = capi.CstlnReceiver(ctx, out_format=capi.SYM_HARD2, **kw)
+    n = len(capture) // 2
+    d = ctx.upload(capture)
+    cap = n + 4096
+    o_soft, o_hard = ctx.alloc(cap * 4), ctx.alloc((cap // 16 + 8) * 4)
+    rng = np.random.default_rng(7)
+    front = rng.integers(0, 4, offset).astype(np.uint8)
+    pos = 0
+    for part in (n // 3, n - n // 3):
+        # soft run
+        c1 = soft.run_async(d.at(2 * pos), min(part, n - pos), o_soft.ptr, cap)
+        n1 = soft.wait()
+        want = ctx.download(o_soft, capi.SOFTSYM, n1)["symbol"] & 3
+        # packed run behind `offset` symbols that are already there
+        pre = capi.hs2_pack(front)
+        capi.check(capi.lib.lsdr_memset(ctx.h, o_hard.ptr, 0xA5, (cap // 16 + 8) * 4))
+        if offset:
+            capi.check(capi.lib.lsdr_memcpy_h2d(ctx.h, o_hard.ptr, pre.ctypes.data, pre.nbytes))
+        ctx.sync()
+        c2 = hard.run_async_hs2(d.at(2 * pos), min(part, n - pos), o_hard.ptr, offset, cap)
+        n2 = hard.wait()
+        assert c1 == c2 > 50000 and n1 == n2 and soft.tiled_stats() == hard.tiled_stats()
+        words = ctx.download(o_hard, np.uint32, (offset + n2 + 15) // 16)
+        got = capi.hs2_unpack(words, offset + n2)
+        assert np.array_equal(got[:offset], front)
+        bad = np.flatnonzero(got[offset:] != want)
+        assert len(bad) == 0, (len(bad), bad[:10], n2)
+        assert soft.state().as_dict() == hard.state().as_dict()
+        pos += c1
+    soft.close(); hard.close(); d.free(); o_soft.free(); o_hard.free()
+
+
+@pytest.mark.parametrize("rate", [0, 3])
+@pytest.mark.parametrize("offset", [0, 9])
+def test_deconv_on_packed_symbols(capi, ctx, rate, offset):
+    """lsdr_deconv_run_hs2 == lsdr_deconv_run on the same hard symbols, call by call (carried shift registers, next_sync())."""
+    rng = np.random.default_rng(11 + rate)
+    n = 300000
+    hs = rng.integers(0, 4, n).astype(np.uint8)
+    sym = np.zeros(n, capi.SOFTSYM); sym["symbol"] = hs; sym["cost"] = rng.integers(-500, 500, n)
+    d_soft, d_words = ctx.upload(sym), ctx.upload(capi.hs2_pack(hs, offset))
+    a, b = capi.Deconv(ctx, rate), capi.Deconv(ctx, rate)
+    oa, ob = ctx.alloc(n), ctx.alloc(n)
+    pos = 0
+    for k, piece in enumerate((70000, 63, 5000, 100001, 1 << 30)):
+        m = min(piece, n - pos)
+        ca, pa = a.run_dev(d_soft.at(4 * pos), m, oa.ptr, n)
+        cb, pb = b.run_dev_hs2(d_words.ptr, offset + pos, m, ob.ptr, n)
+        assert (ca, pa) == (cb, pb)
+        assert bits_equal(ctx.download(oa, np.uint8, pa), ctx.download(ob, np.uint8, pb)), k
+        pos += ca
+        if k == 1:
+            a.next_sync(); b.next_sync()
+    assert pos > n - 200
+    a.close(); b.close(); d_soft.free(); d_words.free(); oa.free(); ob.free()

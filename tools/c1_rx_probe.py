@@ -46,15 +46,18 @@ for ms in sizes:
                 ctxs = [capi.Ctx(0) for _ in range(ncap)]
                 rxs, outs = [], []
                 for c in ctxs:
-                    r = capi.CstlnReceiver(c, mode=capi.RX_TILED, tile_len=tl, tile_warmup=tw, in_format=capi.IN_CU8 if fmt == "u8" else capi.IN_CF32, **rx_kw)
+                    r = capi.CstlnReceiver(c, mode=capi.RX_TILED, tile_len=tl, tile_warmup=tw, in_format=capi.IN_CF32 if fmt == "f32" else capi.IN_CU8,
+                                           out_format=capi.SYM_HARD2 if fmt == "u8h" else capi.SYM_SOFT, **rx_kw)
                     r.set_state(st)
-                    rxs.append(r); outs.append(c.alloc(sym_cap * 4))
+                    rxs.append(r); outs.append(c.alloc(sym_cap * 4 if fmt != "u8h" else sym_cap // 4 + 64))
 
                 def once():
                     for c, r, o in zip(ctxs, rxs, outs):
                         if fmt == "f32":
                             capi.check(lib.lsdr_cconverter_u8_run(c.h, d_in.ptr, B + extra, d_cf.ptr))
                             r.run_async(d_cf.ptr, B + extra, o.ptr, sym_cap)
+                        elif fmt == "u8h":
+                            r.run_async_hs2(d_in.ptr, B + extra, o.ptr, 0, sym_cap)
                         else:
                             r.run_async(d_in.ptr, B + extra, o.ptr, sym_cap)
                     return [r.wait() for r in rxs]
