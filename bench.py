@@ -407,6 +407,14 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-more", action="store_true", help="skip the secondary configurations (`more` in the JSON line)")
     ap.add_argument("--dry-run", action="store_true", help="launch/aggregation plumbing only: no GPU work")
+    ap.add_argument("--workload", choices=["c2", "c1"], default="c2",
+                    help="c2: BASELINE config 2 (the headline: cf32 at 120 sps, fir_filter + receiver); c1: BASELINE config 1 / 4 — independent "
+                         "cu8 captures at 1.2 sps decoded to TS (bench_c1.py); with --gpus N that is config 4 (captures sharded over the GPUs)")
+    ap.add_argument("--c1-captures", type=int, default=8, help="c1: independent captures resident per GPU (each decoded once per step)")
+    ap.add_argument("--c1-msamples", type=int, default=128, help="c1: Mi samples per capture")
+    ap.add_argument("--c1-workers", type=int, default=8, help="c1: host threads / HIP streams decoding captures concurrently per GPU")
+    ap.add_argument("--c1-tile", type=int, default=2048)
+    ap.add_argument("--c1-warmup", type=int, default=512)
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -422,9 +430,20 @@ def main():
         shard.barrier()
         total, dt, _ = shard.aggregate(1000.0 * (rank + 1), 1.0 + rank)
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": world, "units": total, "seconds": dt}), flush=True)
+            print(json.dumps({"dry_run": True, "workload": args.workload, "n_gpus": world, "ranks": world, "units": total, "seconds": dt}), flush=True)
         shard.close()
         return
+
+    if args.workload == "c1":
+        import leansdr_amd.capi as capi
+        import bench_c1
+        if capi.lib.lsdr_device_count() <= local_rank:
+            raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {capi.lib.lsdr_device_count()} visible")
+        out, rc = bench_c1.run_workload(capi, local_rank, args, shard)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        shard.close()
+        sys.exit(rc)
 
     from leansdr_amd import synth
     cpu = None

@@ -1,0 +1,403 @@
+"""bench_c1.py — BASELINE config 1 / config 4: independent 2 MS/s-class QPSK 1/2 captures (cu8 IQ at 1.2 samples/symbol, the
+README's `leandvb --u8 -f 2400e3 --sr 2000e3 --cr 1/2` case) decoded from the first sample to transport-stream packets:
+
+    cconverter<u8> (fused) + cstln_receiver (linear sampler, tiled, packed hard decisions) → deconvol_sync → mpeg_sync →
+    deinterleaver → rs_decoder → derandomizer → TS packets in host memory
+
+Unit of work = one CAPTURE = one scheduler instance of the reference (leandvb.cc:163, 205-600): every decode starts from freshly
+reset blocks (acquisition included) and ends with the capture's TS in pinned host memory.  `captures` captures live in HBM per GPU;
+a step decodes each of them once.  Decodes are handed to `workers` host threads, each with its own context (HIP stream) and
+block handles — captures share nothing, so the chains of different captures overlap on the GPU; inside a chain the FEC tail's
+data-dependent calls wait for the host, which is what the other workers' kernels hide.  Multi-GPU = the same on every rank
+(bench.py --workload c1 --gpus N: one process per GPU, no collective).
+
+Verification after the clock stops (`verified`): the IQ of EVERY capture goes through the reference's own binary
+(oracle/_ref/leandvb --u8 … --anf 0, built from /root/reference by oracle/Makefile; it travels with the repo) on the host cores,
+and every packet the reference wrote after acquisition must be in this path's TS, byte for byte and in order; without the binary
+the check falls back to the transmitted packet sequence (and says so).
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FS, FM = 2400e3, 2000e3
+OMEGA = float(np.float32(FS / FM))
+ALG_BYTES_PER_SAMPLE = 2.0 + 188.0 / (204 * 8 * 1.2)       # cu8 in + TS out = 2.096
+REFBIN = os.path.join(ROOT, "oracle", "_ref", "leandvb")
+REF_ARGS = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0"]
+SKIP_ACQ = 16            # packets of the reference's output skipped before the comparison (lock instants may differ by a few packets)
+
+
+def ts_packets(n, start=0):
+    from leansdr_amd import synth_dvbs
+    return synth_dvbs.ts_packets(n, start)
+
+
+class Generator:
+    """leantsgen | leandvbtx -f 6/5 --power 37.5 --agc | leanchansim --awgn 17.5 --ou8 with this repo's GPU blocks (tx.hip,
+    chan.hip: each bit-exact against the reference class, tests/test_gpu_tx.py, test_gpu_chan.py), device-resident.  The clean
+    baseband is modulated once; a capture is a stretch of it (its own start packet) plus its own noise (srand48 seed)."""
+
+    def __init__(self, capi, ctx, n_samples, n_captures):
+        self.capi, self.ctx, self.n = capi, ctx, n_samples
+        lib = capi.lib
+        sps_num, sps_den = 6, 5
+        self.shift_packets = 3                                       # capture k starts 3k packets (5875.2 samples) later
+        n_pk = int((n_samples + 64) * sps_den / (204 * 8 * sps_num)) + self.shift_packets * n_captures + 128
+        n_pk = (n_pk + 7) // 8 * 8
+        self.n_packets = n_pk
+        ts = ts_packets(n_pk)
+        cons, prod = C.c_size_t(), C.c_size_t()
+
+        def call(fn, *a):
+            capi.check(fn(*a, C.byref(cons), C.byref(prod)))
+            return prod.value
+        d_ts = ctx.upload(ts)
+        rand = C.c_void_p(); capi.check(lib.lsdr_randomizer_create(ctx.h, C.byref(rand)))
+        d_a = ctx.alloc(n_pk * 188)
+        call(lib.lsdr_randomizer_run, rand, d_ts.ptr, n_pk, d_a.ptr, n_pk)
+        d_b = ctx.alloc(n_pk * 204)
+        call(lib.lsdr_rs_encoder_run, ctx.h, d_a.ptr, n_pk, d_b.ptr, n_pk)
+        d_il = ctx.alloc(n_pk * 204)
+        n_il = call(lib.lsdr_interleaver_run, ctx.h, d_b.ptr, n_pk, d_il.ptr, n_pk * 204)
+        conv = C.c_void_p(); capi.check(lib.lsdr_convol_create(ctx.h, capi.FEC12, 2, C.byref(conv)))
+        d_sym = ctx.alloc(n_il * 8 + 64)
+        n_sym = call(lib.lsdr_convol_run, conv, d_il.ptr, n_il, d_sym.ptr, n_il * 8 + 64)
+        d_iq = ctx.alloc(n_sym * 8)
+        capi.check(lib.lsdr_cstln_transmitter_run(ctx.h, capi.QPSK, capi.FEC12, d_sym.ptr, n_sym, d_iq.ptr))
+        amp = float(np.float32(10 ** (37.5 / 20)))                   # leandvbtx --power 37.5
+        co = capi.root_raised_cosine(int(sps_num * 10.0), float(np.float32(1.0) / np.float32(sps_num)), 0.35)
+        co = capi.normalize_power(co, float(np.float32(amp) / np.float32(75.0)))
+        res = C.c_void_p(); capi.check(lib.lsdr_fir_resampler_create(ctx.h, len(co), capi._np(co), sps_num, C.byref(res)))
+        d_up = ctx.alloc(n_sym * sps_num * 8)
+        n_up = call(lib.lsdr_fir_resampler_run, res, d_iq.ptr, n_sym, d_up.ptr, n_sym * sps_num)
+        d_dec = ctx.alloc((n_up // sps_den + 8) * 8)
+        pr = C.c_size_t()
+        capi.check(lib.lsdr_decimator_run(ctx.h, sps_den, d_up.ptr, n_up, d_dec.ptr, n_up // sps_den + 8, C.byref(pr)))
+        n_dec = pr.value
+        agc = C.c_void_p()
+        capi.check(lib.lsdr_simple_agc_create(ctx.h, float(np.float32(amp) / np.sqrt(np.float32(np.float32(sps_num) / sps_den))),
+                                              float(np.float32(0.001 * sps_den / sps_num)), C.byref(agc)))
+        self.d_base = ctx.alloc(n_dec * 8)
+        self.n_base = call(lib.lsdr_simple_agc_run, agc, d_dec.ptr, n_dec, self.d_base.ptr, n_dec)
+        ctx.sync()
+        for d in (d_ts, d_a, d_b, d_il, d_sym, d_iq, d_up, d_dec):
+            d.free()
+        lib.lsdr_randomizer_destroy(rand); lib.lsdr_convol_destroy(conv); lib.lsdr_fir_resampler_destroy(res); lib.lsdr_simple_agc_destroy(agc)
+        self.ts = ts
+        self.spp5 = 204 * 8 * sps_num                                 # samples per 5 packets (9792)
+        self.d_noisy = ctx.alloc(n_samples * 8)
+
+    def capture(self, k, seed):
+        """cu8 capture k in a new device buffer; returns (buffer, first packet index of the stretch)."""
+        capi, ctx, lib = self.capi, self.ctx, self.capi.lib
+        # start on a whole number of samples: 5 packets = 9792 samples; the AGC / filter transients of the modulator are skipped
+        first_pk = 40 + 5 * ((self.shift_packets * k + 4) // 5)
+        start = first_pk // 5 * self.spp5
+        assert start + self.n <= self.n_base, (start, self.n, self.n_base)
+        w = C.c_void_p()
+        capi.check(lib.lsdr_wgn_create(ctx.h, 1, int(seed), C.byref(w)))
+        stddev = float(np.float32(10 ** (17.5 / 20)))                 # leanchansim --awgn 17.5
+        capi.check(lib.lsdr_wgn_run(w, stddev, self.d_base.at(start * 8), self.d_noisy.ptr, self.n))
+        d_u8 = ctx.alloc(self.n * 2 + 64)
+        capi.check(lib.lsdr_cconverter_f32_u8_run(ctx.h, self.d_noisy.ptr, self.n, d_u8.ptr))
+        ctx.sync()
+        lib.lsdr_wgn_destroy(w)
+        return d_u8, first_pk
+
+    def close(self):
+        self.d_base.free(); self.d_noisy.free()
+
+
+class Worker:
+    """One context (HIP stream) with the block handles and buffers of one capture's chain."""
+
+    def __init__(self, capi, device, n_samples, tile, warm):
+        self.capi, self.n = capi, n_samples
+        ctx = self.ctx = capi.Ctx(device)
+        self.rx = capi.CstlnReceiver(ctx, sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, fec=capi.FEC12, omega=OMEGA, meas_decimation=int(FS / 5),
+                                     mode=capi.RX_TILED, tile_len=tile, tile_warmup=warm, in_format=capi.IN_CU8, out_format=capi.SYM_HARD2)
+        self.dec = capi.Deconv(ctx, capi.FEC12)
+        self.msync = capi.MpegSync(ctx)
+        self.derand = capi.Derandomizer(ctx)
+        self.sym_cap = int(n_samples * 0.94) + 65536          # the tiled run reserves ⌈128/(omega−0.1)⌉+3 symbol slots per chunk
+        self.byte_cap = self.sym_cap // 8 + 65536
+        self.pk_cap = self.byte_cap // 204 + 64
+        self.d_words = ctx.alloc(self.sym_cap // 4 + 256)
+        self.d_bytes = ctx.alloc(self.byte_cap)
+        self.d_mpeg = ctx.alloc(self.byte_cap)
+        self.d_rs = ctx.alloc(self.pk_cap * 204)
+        self.d_rts = ctx.alloc(self.pk_cap * 188)
+        self.d_ts = ctx.alloc(self.pk_cap * 188)
+        self.stats = dict(bits=0, errs=0, next_sync=0, jobs=0)
+        self.t_stage = dict(receiver=0.0, deconv_sync=0.0, rs_derand=0.0)
+
+    def decode(self, d_iq, h_ts_ptr, h_ts_cap):
+        """One capture, first sample to TS in host memory.  Returns (TS packets, samples consumed by the receiver)."""
+        capi, lib, ctx = self.capi, self.capi.lib, self.ctx
+        t0 = time.perf_counter()
+        self.rx.reset(); self.dec.reset(); self.msync.reset()
+        capi.check(lib.lsdr_derandomizer_reset(self.derand.h))
+        consumed = self.rx.run_async_hs2(d_iq.ptr, self.n, self.d_words.ptr, 0, self.sym_cap)
+        nsym = self.rx.wait()
+        t1 = time.perf_counter()
+        # deconvol_sync ↔ mpeg_sync: until mpeg_sync has locked the deconvolver is given small windows (the reference's pipe
+        # sizes bound how far it runs ahead of a next_sync(), leandvb.cc:185-202); once locked, the rest of the capture in one call
+        pos = bw = br = mw = 0
+        while True:
+            cap = self.byte_cap - bw if self.msync.locked else min(65536, self.byte_cap - bw)
+            c, p = self.dec.run_dev_hs2(self.d_words.ptr, pos, nsym - pos, self.d_bytes.at(bw), cap)
+            if not p:
+                break
+            pos += c; bw += p
+            while True:
+                c3, p3, _, _, cns = self.msync.run_dev(self.d_bytes.at(br), bw - br, self.d_mpeg.at(mw), self.byte_cap - mw)
+                if cns:
+                    self.dec.next_sync(); self.stats["next_sync"] += 1
+                if not c3 and not p3:
+                    break
+                br += c3; mw += p3
+        t2 = time.perf_counter()
+        cons, prod = C.c_size_t(), C.c_size_t()
+        capi.check(lib.lsdr_deinterleaver_run(ctx.h, self.d_mpeg.ptr, mw, self.d_rs.ptr, self.pk_cap, C.byref(cons), C.byref(prod)))
+        npk, n_ts = prod.value, 0
+        if npk:
+            b, e = C.c_long(), C.c_long()
+            capi.check(lib.lsdr_rs_decoder_run(ctx.h, self.d_rs.ptr, npk, self.d_rts.ptr, C.byref(b), C.byref(e)))
+            self.stats["bits"] += b.value; self.stats["errs"] += e.value
+            c2, p2 = C.c_size_t(), C.c_size_t()
+            capi.check(lib.lsdr_derandomizer_run(self.derand.h, self.d_rts.ptr, npk, self.d_ts.ptr, self.pk_cap, C.byref(c2), C.byref(p2)))
+            n_ts = p2.value
+            assert n_ts * 188 <= h_ts_cap
+            capi.check(lib.lsdr_memcpy_d2h(ctx.h, h_ts_ptr, self.d_ts.ptr, n_ts * 188))     # pinned destination: asynchronous
+        t3 = time.perf_counter()
+        self.t_stage["receiver"] += t1 - t0; self.t_stage["deconv_sync"] += t2 - t1; self.t_stage["rs_derand"] += t3 - t2
+        self.stats["jobs"] += 1
+        return n_ts, consumed
+
+    def close(self):
+        self.ctx.sync()
+        self.rx.close(); self.dec.close(); self.msync.close(); self.derand.close()
+        for d in (self.d_words, self.d_bytes, self.d_mpeg, self.d_rs, self.d_rts, self.d_ts):
+            d.free()
+        self.ctx.close()
+
+
+class C1Job:
+    def __init__(self, capi, device, n_captures, msamples, workers, tile, warm, seed0):
+        self.capi, self.device = capi, device
+        self.n = (msamples << 20) // 128 * 128 + 1
+        ctx = self.ctx = capi.Ctx(device)
+        gen = Generator(capi, ctx, self.n, n_captures)
+        self.ts_sent = gen.ts
+        self.caps, self.first_pk, self.seeds = [], [], []
+        for k in range(n_captures):
+            d, fp = gen.capture(k, seed0 + k)
+            self.caps.append(d); self.first_pk.append(fp); self.seeds.append(seed0 + k)
+        gen.close()
+        self.workers = [Worker(capi, device, self.n, tile, warm) for _ in range(max(1, workers))]
+        self.ts_cap = self.workers[0].pk_cap * 188
+        self.h_ts = []
+        for _ in range(n_captures):
+            p = C.c_void_p()
+            capi.check(capi.lib.lsdr_malloc_host(self.ts_cap, C.byref(p)))
+            self.h_ts.append(p)
+        self.n_ts = [0] * n_captures
+        self.counts = [[] for _ in range(n_captures)]
+        self.tile = (tile, warm)
+
+    def run(self, steps, timed=False):
+        """`steps` decodes of every capture, spread over the workers.  Returns the samples consumed."""
+        jobs = [(s, k) for s in range(steps) for k in range(len(self.caps))]
+        lock, nxt, total, failure = threading.Lock(), [0], [0], []
+
+        def work(w):
+            try:
+                while True:
+                    with lock:
+                        i = nxt[0]; nxt[0] += 1
+                    if i >= len(jobs) or failure:
+                        return
+                    _, k = jobs[i]
+                    n_ts, cons = w.decode(self.caps[k], self.h_ts[k], self.ts_cap)
+                    self.n_ts[k] = n_ts
+                    if timed:
+                        self.counts[k].append(n_ts)
+                    with lock:
+                        total[0] += cons
+            except BaseException as e:
+                failure.append(e)
+        if timed:
+            for w in self.workers:
+                w.rx.tile_time(True)
+        ths = [threading.Thread(target=work, args=(w,)) for w in self.workers]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        for w in self.workers:
+            w.ctx.sync()
+        if failure:
+            raise failure[0]
+        return total[0]
+
+    def tile_kernel_ms(self):
+        ms, n = 0.0, 0
+        for w in self.workers:
+            a, b = w.rx.tile_time(False)
+            ms += a * b; n += b
+        return (ms / n if n else 0.0), n
+
+    def ts_of(self, k):
+        return bytes(C.string_at(self.h_ts[k], self.n_ts[k] * 188))
+
+    def iq_of(self, k):
+        return self.ctx.download(self.caps[k], np.uint8, self.n * 2)
+
+    def verify(self, max_ref_workers=None):
+        """Every capture: this path's TS of the last decode against the reference binary's TS for the same IQ."""
+        out = dict(captures=len(self.caps), checker=None, per_capture=[])
+        have_ref = os.path.exists(REFBIN) and os.access(REFBIN, os.X_OK)
+        t0 = time.perf_counter()
+        refs = [None] * len(self.caps)
+        if have_ref:
+            out["checker"] = "oracle/_ref/leandvb " + " ".join(REF_ARGS) + " (the reference binary, one process per capture on the host cores)"
+            tmp = tempfile.mkdtemp(prefix="lsdr_c1_")
+            procs = []
+            for k in range(len(self.caps)):
+                f = os.path.join(tmp, f"cap{k}.u8")
+                self.iq_of(k).tofile(f)
+                procs.append((k, f, subprocess.Popen([REFBIN] + REF_ARGS, stdin=open(f, "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)))
+            for k, f, p in procs:
+                refs[k] = p.communicate()[0]
+                os.unlink(f)
+            os.rmdir(tmp)
+        else:
+            out["checker"] = "transmitted packet sequence (oracle/_ref/leandvb not present on this machine)"
+        ok_all = True
+        for k in range(len(self.caps)):
+            got = self.ts_of(k)
+            pk = [got[i:i + 188] for i in range(0, len(got), 188)]
+            rep = dict(capture=k, seed=self.seeds[k], ts_packets=len(pk), sha256=hashlib.sha256(got).hexdigest()[:16],
+                       same_count_every_step=bool(len(set(self.counts[k])) <= 1))
+            if refs[k] is not None:
+                ref = refs[k]
+                rpk = [ref[i:i + 188] for i in range(0, len(ref), 188)]
+                tail = rpk[SKIP_ACQ:]
+                rep["ref_packets"] = len(rpk)
+                ok = len(tail) > 100 and tail[0] in pk
+                if ok:
+                    i0 = pk.index(tail[0])
+                    # the reference stops where its input ends; this path's last partial window may end a few packets earlier
+                    m = min(len(tail), len(pk) - i0)
+                    ok = pk[i0:i0 + m] == tail[:m] and len(tail) - m <= 16
+                    rep["compared"] = m; rep["ref_tail_not_reached"] = len(tail) - m
+                rep["equal_to_reference_after_acquisition"] = bool(ok)
+            else:
+                sent = self.ts_sent
+                first = [i for i in range(max(0, self.first_pk[k] - 64), min(len(sent), self.first_pk[k] + 4096)) if bytes(sent[i]) == pk[SKIP_ACQ]] if len(pk) > SKIP_ACQ else []
+                ok = bool(first) and len(pk) > 100 and b"".join(pk[SKIP_ACQ:]) == sent[first[0]:first[0] + len(pk) - SKIP_ACQ].tobytes()
+                rep["equal_to_transmitted_after_acquisition"] = bool(ok)
+            rep["pass"] = bool(ok and rep["same_count_every_step"])
+            ok_all = ok_all and rep["pass"]
+            out["per_capture"].append(rep)
+        out["checker_seconds"] = round(time.perf_counter() - t0, 2)
+        out["pass"] = bool(ok_all)
+        return out
+
+    def close(self):
+        for w in self.workers:
+            w.close()
+        for p in self.h_ts:
+            self.capi.lib.lsdr_free_host(p)
+        for d in self.caps:
+            d.free()
+        self.ctx.close()
+
+
+def cpu_reference(job, budget_s=20.0):
+    """The reference binary on the host cores: one process on a bounded head of capture 0, then one process per core on it
+    (the reference is single-threaded; processes are how it scales), median of three passes."""
+    if not os.path.exists(REFBIN):
+        return None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = min(job.n, 16 << 20)
+    iq = job.iq_of(0)[: 2 * n]
+    f = tempfile.NamedTemporaryFile(prefix="lsdr_c1_cpu_", suffix=".u8", delete=False)
+    iq.tofile(f); f.close()
+
+    def run(np_):
+        t0 = time.perf_counter()
+        ps = [subprocess.Popen([REFBIN] + REF_ARGS, stdin=open(f.name, "rb"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(np_)]
+        for p in ps:
+            p.wait()
+        return np_ * n / (time.perf_counter() - t0) / 1e6
+    one = sorted(run(1) for _ in range(3))[1]
+    allc = sorted(run(cores) for _ in range(3))[1] if cores > 1 else one
+    os.unlink(f.name)
+    return dict(value=round(allc, 3), unit="MS/s", cores=cores, kind="reference", one_core=round(one, 3),
+                sample=f"oracle/_ref/leandvb {' '.join(REF_ARGS)} on the first {n} samples of capture 0 (whole chain to TS): 1 process, then "
+                       f"{cores} processes (one per core); median of 3 passes each")
+
+
+def run_workload(capi, device, args, shard):
+    """bench.py --workload c1.  Returns the JSON object of rank 0 (None on the other ranks)."""
+    rank, world = shard.rank, shard.world
+    job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile, args.c1_warmup, seed0=1000 * (rank + 1))
+    job.run(max(1, args.warmup))
+    shard.barrier()
+    t0 = time.perf_counter()
+    consumed = job.run(args.steps, timed=True)
+    shard.barrier()
+    dt = time.perf_counter() - t0
+    total, dt, _ = shard.aggregate(consumed, dt)
+    if rank != 0:
+        job.close()
+        return None, 0
+    kms, klaunch = job.tile_kernel_ms()
+    alg = job.n * ALG_BYTES_PER_SAMPLE
+    W = len(job.workers)
+    stage = {k: round(sum(w.t_stage[k] for w in job.workers), 3) for k in job.workers[0].t_stage}
+    out = {
+        "metric": "IQ MSamples/s demodulated (leandvb QPSK 1/2)", "value": round(total / dt / 1e6, 3), "unit": "MS/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE config 1 / config 4: independent QPSK 1/2 captures, cu8 IQ at 1.2 samples/symbol (leandvb --u8 -f 2400e3 "
+                               "--sr 2000e3 --cr 1/2 --anf 0), each decoded from its first sample to TS packets in host memory: cconverter<u8> (fused) + "
+                               "cstln_receiver(linear, tiled, packed decisions) -> deconvol_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
+                   "captures_per_gpu": len(job.caps), "samples_per_capture": job.n, "samples_per_step_per_gpu": job.n * len(job.caps),
+                   "workers_per_gpu": W, "rx_tile": {"tile_len": job.tile[0], "warmup": job.tile[1]},
+                   "parallelism": f"{world * len(job.caps)} independent capture(s), {len(job.caps)} per GPU, no collectives, no RCCL",
+                   "ts_packets_per_capture": job.n_ts[0], "rs_byte_errors_corrected": sum(w.stats["errs"] for w in job.workers),
+                   "deconv_next_sync_calls": sum(w.stats["next_sync"] for w in job.workers),
+                   "host_seconds_per_stage_summed_over_workers": stage},
+        "roofline": {"kernel": "k_rx_tiles<linear, arithmetic QPSK, cu8, LDS-staged, packed> (cstln_receiver tolerance tiles)", "bound": "hbm",
+                     "achieved": round(alg / (kms * 1e-3) / 1e9, 2) if kms else None, "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(alg / (kms * 1e-3) / 1e9 / 8000.0, 5) if kms else None, "avg_launch_ms": round(kms, 4), "launches_timed": klaunch,
+                     "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4), "traffic": None,
+                     "concurrent_launches": f"up to {W} (one per worker stream): a launch shares the chip, its duration is not the chip's rate",
+                     "whole_job_frac": round(total / dt * ALG_BYTES_PER_SAMPLE / 1e9 / 8000.0 / world, 5),
+                     "note": "latency/issue-bound decision-feedback recurrence (DESIGN §4.2): the HBM roofline is reported because SURVEY §8(d) asks for it"},
+    }
+    rc = 0
+    if not args.no_verify:
+        out["verified"] = job.verify()
+        if not out["verified"]["pass"]:
+            print("bench.py: C1 VERIFICATION FAILED: " + str(out["verified"])[:3000], file=sys.stderr)
+            rc = 3
+    if world == 1 and not args.no_cpu:
+        cpu = cpu_reference(job, args.cpu_seconds)
+        if cpu:
+            out["cpu_baseline"] = cpu
+    job.close()
+    return out, rc

@@ -272,6 +272,9 @@ void lsdr_rx_destroy(lsdr_rx *r);
 int lsdr_rx_readahead(const lsdr_rx *r);                 /* sampler->readahead() */
 int lsdr_rx_get_state(lsdr_rx *r, lsdr_rx_state *st);    /* includes freq_tap (sdr.h:918-921) */
 int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st);
+/* Back to the loop state lsdr_rx_create left (= a freshly constructed cstln_receiver, sdr.h:709-736 + leandvb.cc:476-487): the next
+ * run starts a new capture.  Stream-ordered, no host wait; no queued runs may be outstanding. */
+int lsdr_rx_reset(lsdr_rx *r);
 /* LSDR_RX_TILED diagnostics of the last run: tiles, seams where a duplicated / lost symbol was
  * repaired, seams whose timing or carrier-phase mismatch exceeded the lock criterion. */
 int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsigned *miss, unsigned *bad_seams);
@@ -299,6 +302,9 @@ int lsdr_rx_run_async_hs2(lsdr_rx *rx, const void *in, size_t n_in, uint32_t *ou
  * fir_filter tracking the carrier (lsdr_fir_filter_track, dsp.h:236-244) from runs that have already completed while later
  * ones are still queued — the feedback of leandvb.cc:506-510 with a latency of the queue depth instead of a host wait. */
 float lsdr_rx_retired_freq_tap(const lsdr_rx *rx);
+/* Measurement hook (bench.py's roofline of the tile kernel): HIP events on the receiver's stream around the k_rx_tiles launch of
+ * every queued run while enabled; each call returns the mean over the runs retired since the previous call, then sets the switch. */
+int lsdr_rx_tile_time(lsdr_rx *rx, int enable, float *avg_ms, unsigned *launches);
 /* Loop-state snapshot between queued runs: lsdr_rx_snapshot_async() puts a copy of the device-side loop state (the fields
  * of cstln_receiver<f32>, sdr.h:923-935) into a pinned slot in stream order, i.e. the state the NEXT queued run starts
  * from; lsdr_rx_get_snapshot() waits for the stream and returns it.  Lets a caller (bench.py's verification) replay one
@@ -330,6 +336,7 @@ typedef struct lsdr_deconv lsdr_deconv;
 int lsdr_deconv_create(lsdr_ctx *ctx, int rate, int fastlock, lsdr_deconv **d);
 void lsdr_deconv_destroy(lsdr_deconv *d);
 int lsdr_deconv_next_sync(lsdr_deconv *d);                       /* deconvol_sync::next_sync, dvb.h:185-193 */
+int lsdr_deconv_reset(lsdr_deconv *d);                           /* the state of a freshly constructed block (a new stream begins); stream-ordered */
 /* One run() call (run_decoding, dvb.h:419-470): skips `skip` symbols, needs >= 64 symbols of margin,
  * produces n = min(maxrd, cap_out) bytes when n >= 32.  Asynchronous (sizes are data-independent). */
 int lsdr_deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
@@ -369,6 +376,7 @@ int lsdr_mpeg_sync_run(lsdr_mpeg_sync *m, const uint8_t *in, size_t n_in, uint8_
                        size_t *consumed, size_t *produced, int *state_events_host, int *n_state_events,
                        unsigned long *locktime, int *call_next_sync);
 int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m);
+int lsdr_mpeg_sync_reset(lsdr_mpeg_sync *m);                     /* a freshly constructed block (options kept); stream-ordered */
 int lsdr_mpeg_sync_set_resync_period(lsdr_mpeg_sync *m, int period);   /* public member resync_period (dvb.h:717), used by --hs */
 
 /* ---- deinterleaver<u8>::run, dvb.h:932-944 (Forney I=12, M=17 as a gather).  Needs 2448 bytes per
@@ -387,6 +395,7 @@ int lsdr_rs_decoder_run(lsdr_ctx *ctx, uint8_t *in_packets, size_t n_packets, ui
 typedef struct lsdr_derandomizer lsdr_derandomizer;
 int lsdr_derandomizer_create(lsdr_ctx *ctx, lsdr_derandomizer **d);
 void lsdr_derandomizer_destroy(lsdr_derandomizer *d);
+int lsdr_derandomizer_reset(lsdr_derandomizer *d);               /* a new stream begins (PRBS position 0) */
 int lsdr_derandomizer_run(lsdr_derandomizer *d, const uint8_t *in_packets, size_t n_packets, uint8_t *out_packets,
                           size_t cap_packets, size_t *consumed, size_t *produced);
 /* host-side tables for tests: PRBS pattern (dvb.h:1116-1129), GF(256) exp/log and RS generator (rs.h:47-105) */

@@ -175,6 +175,11 @@ _sig("lsdr_rx_tiled_stats", C.c_int, [vp] + [C.POINTER(C.c_uint)] * 4)
 _sig("lsdr_deconv_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
 _sig("lsdr_deconv_destroy", None, [vp])
 _sig("lsdr_deconv_next_sync", C.c_int, [vp])
+_sig("lsdr_deconv_reset", C.c_int, [vp])
+_sig("lsdr_mpeg_sync_reset", C.c_int, [vp])
+_sig("lsdr_derandomizer_reset", C.c_int, [vp])
+_sig("lsdr_rx_reset", C.c_int, [vp])
+_sig("lsdr_rx_tile_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
 _sig("lsdr_deconv_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_deconv_run_hs2", C.c_int, [vp, vp, c_sz, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_viterbi_create", C.c_int, [vp, C.c_int, C.c_int, C.POINTER(vp)])
@@ -490,6 +495,16 @@ class CstlnReceiver:
     def set_state(self, st):
         check(lib.lsdr_rx_set_state(self.h, C.byref(st)))
 
+    def reset(self):
+        """The loop state right after construction: the next run starts a new capture."""
+        check(lib.lsdr_rx_reset(self.h))
+
+    def tile_time(self, enable):
+        """(mean ms, launches) of the k_rx_tiles launches of the runs retired since the last call; then set the switch."""
+        ms, n = c_f(), C.c_uint()
+        check(lib.lsdr_rx_tile_time(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
     def decision_mode(self):
         a, d = C.c_int(), C.c_uint()
         check(lib.lsdr_rx_decision_mode(self.h, C.byref(a), C.byref(d)))
@@ -642,6 +657,9 @@ class Deconv:
     def next_sync(self):
         check(lib.lsdr_deconv_next_sync(self.h))
 
+    def reset(self):
+        check(lib.lsdr_deconv_reset(self.h))
+
     def run_dev(self, in_ptr, n_in, out_ptr, cap):
         cons, prod = c_sz(), c_sz()
         check(lib.lsdr_deconv_run(self.h, in_ptr, n_in, out_ptr, cap, C.byref(cons), C.byref(prod)))
@@ -739,6 +757,9 @@ class MpegSync:
 
     def set_resync_period(self, period):
         check(lib.lsdr_mpeg_sync_set_resync_period(self.h, period))
+
+    def reset(self):
+        check(lib.lsdr_mpeg_sync_reset(self.h))
 
     def run_dev(self, in_ptr, n_in, out_ptr, cap):
         cons, prod = c_sz(), c_sz()

@@ -1080,6 +1080,7 @@ struct lsdr_rx {
   // receiver parameters kept on the host exactly like the reference's members
   float omega, min_omega, max_omega;
   rx_state_dev st;          // host mirror of the device state
+  rx_state_dev st_initial;  // the state lsdr_rx_create left (lsdr_rx_reset)
   bool st_dirty_host;       // host copy newer than device
   // device
   float2 *d_trig;
@@ -1096,6 +1097,8 @@ struct lsdr_rx {
   unsigned *d_hstage; size_t hstage_cap;      // LSDR_SYM_HARD2: packed rows, [tiles_cap] info records
   rx_tile_info_h *d_hinfo;
   size_t out_sym_offset;                     // LSDR_SYM_HARD2: where the next run starts writing in `out` (symbols)
+  // measurement hook (lsdr_rx_tile_time): HIP events around the k_rx_tiles launch of every queued run while enabled
+  bool time_on; hipEvent_t tev0[8], tev1[8]; bool tev_set[8]; double time_ms; unsigned time_n;
   rx_tile_info *d_info; rx_tile_fix *d_fix; size_t tiles_cap;
   rx_ema_map *d_ema;              // [tiles_cap] per-tile exclusive prefix inside its wavefront
   rx_ema_map *d_ema_wave;         // [tiles_cap + 1] per-wavefront estimator maps
@@ -1226,7 +1229,8 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   const int slot = (r->ring_head + r->ring_count) % lsdr_rx::kRing;
   if (!chunks) {   // nothing to do: still occupies a slot so that wait() pairs with run_async()
     r->h_res[slot].total = 0; r->h_res[slot].rot_final = 0; r->h_res[slot].ndup = r->h_res[slot].nmiss = r->h_res[slot].nbad = 0;
-    r->ring_tiles[slot] = 0;
+    r->h_res[slot].freq_tap = r->retired_freq_tap;
+    r->ring_tiles[slot] = 0; r->tev_set[slot] = false;
     LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
     ++r->ring_count;
     return LSDR_OK;
@@ -1335,9 +1339,12 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   if (r->cfg.sampler == LSDR_SAMP_FIR)
     hipLaunchKernelGGL(k_rx_fir_refresh, dim3(1), dim3(256), 0, c->stream, (const rx_state_dev *)r->d_state, (const float2 *)r->d_trig,
                        (const float *)r->d_coeffs, r->cfg.ncoeffs, r->cfg.subsampling, r->d_shifted_tol);
+  if (r->time_on) { LSDR_HIP(hipEventRecord(r->tev0[slot], c->stream)); }
   if (r->cfg.sampler == LSDR_SAMP_NEAREST) LSDR_RX_LAUNCH_S(0);
   else if (r->cfg.sampler == LSDR_SAMP_LINEAR) LSDR_RX_LAUNCH_S(1);
   else LSDR_RX_LAUNCH_S(2);
+  r->tev_set[slot] = r->time_on;
+  if (r->time_on) { LSDR_HIP(hipEventRecord(r->tev1[slot], c->stream)); }
 #undef LSDR_RX_LAUNCH_S
 #undef LSDR_RX_LAUNCH
 #undef LSDR_RX_LAUNCH_F
@@ -1382,6 +1389,11 @@ static int rx_tiled_wait(lsdr_rx *r, size_t *produced) {
   if (!r->ring_count) { lsdr_set_error("cstln_receiver: no queued run"); return LSDR_E_ARG; }
   const int slot = r->ring_head;
   LSDR_HIP(hipEventSynchronize(r->ev[slot]));
+  if (r->tev_set[slot]) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r->tev0[slot], r->tev1[slot]) == hipSuccess) { r->time_ms += ms; ++r->time_n; }
+    r->tev_set[slot] = false;
+  }
   const rx_seam_result sr = r->h_res[slot];
   r->ring_head = (r->ring_head + 1) % lsdr_rx::kRing;
   --r->ring_count;
@@ -1477,6 +1489,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   rx_set_omega(r, cfg->omega, true);
   if (cfg->freq) rx_set_freq(r, cfg->freq, true);
   r->st_dirty_host = true;
+  r->st_initial = r->st;
 
   // Tolerance tiles may decide QPSK symbols by arithmetic instead of the table gather — only if the arithmetic IS the
   // table: symbol, cost and constellation point identical for all 65536 entries, phase_error within ±2 table units.
@@ -1536,6 +1549,9 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   LSDR_HIP(hipHostMalloc((void **)&r->h_snap, sizeof(rx_state_dev), hipHostMallocDefault));
   r->d_wstage = nullptr; r->wstage_cap = 0;
   r->d_hstage = nullptr; r->hstage_cap = 0; r->d_hinfo = nullptr; r->out_sym_offset = 0;
+  r->time_on = false; r->time_ms = 0; r->time_n = 0;
+  for (int i = 0; i < lsdr_rx::kRing; ++i) { r->tev0[i] = r->tev1[i] = nullptr; r->tev_set[i] = false; }
+  r->retired_freq_tap = r->st.freqw / 65536;
   r->h_res = nullptr; r->ring_head = 0; r->ring_count = 0; r->st_stale_host = false;
   for (int i = 0; i < lsdr_rx::kRing; ++i) r->ev[i] = nullptr;
   r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
@@ -1582,6 +1598,7 @@ void lsdr_rx_destroy(lsdr_rx *r) {
   if (r->h_snap) (void)hipHostFree(r->h_snap);
   if (r->h_res) (void)hipHostFree(r->h_res);
   for (int i = 0; i < lsdr_rx::kRing; ++i) if (r->ev[i]) (void)hipEventDestroy(r->ev[i]);
+  for (int i = 0; i < lsdr_rx::kRing; ++i) { if (r->tev0[i]) (void)hipEventDestroy(r->tev0[i]); if (r->tev1[i]) (void)hipEventDestroy(r->tev1[i]); }
   delete r;
 }
 
@@ -1632,6 +1649,15 @@ int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsign
   return LSDR_OK;
 }
 
+int lsdr_rx_reset(lsdr_rx *r) {   // the loop state right after lsdr_rx_create (a new capture begins); no host wait
+  LSDR_ARG(r);
+  if (r->ring_count) { lsdr_set_error("cstln_receiver: queued runs outstanding (lsdr_rx_wait first)"); return LSDR_E_ARG; }
+  r->st = r->st_initial;
+  r->st_stale_host = false;
+  r->st_dirty_host = false;
+  return lsdr_stage_h2d(r->ctx, r->d_state, &r->st, sizeof(rx_state_dev));
+}
+
 int lsdr_rx_set_state(lsdr_rx *r, const lsdr_rx_state *st) {
   LSDR_ARG(r && st);
   if (r->ring_count) { lsdr_set_error("cstln_receiver: queued runs outstanding (lsdr_rx_wait first)"); return LSDR_E_ARG; }
@@ -1670,6 +1696,17 @@ int lsdr_rx_wait(lsdr_rx *r, size_t *produced) {
   return rx_tiled_wait(r, produced);
 }
 float lsdr_rx_retired_freq_tap(const lsdr_rx *r) { return r ? r->retired_freq_tap : 0.f; }
+
+int lsdr_rx_tile_time(lsdr_rx *r, int enable, float *avg_ms, unsigned *launches) {
+  LSDR_ARG(r);
+  if (enable && !r->tev0[0])
+    for (int i = 0; i < lsdr_rx::kRing; ++i) { LSDR_HIP(hipEventCreate(&r->tev0[i])); LSDR_HIP(hipEventCreate(&r->tev1[i])); }
+  if (avg_ms) *avg_ms = r->time_n ? (float)(r->time_ms / r->time_n) : 0.f;
+  if (launches) *launches = r->time_n;
+  r->time_ms = 0; r->time_n = 0;
+  r->time_on = enable != 0;
+  return LSDR_OK;
+}
 
 int lsdr_rx_run(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                 size_t *consumed, size_t *produced, float *freq_out, float *ss_out, float *mer_out,

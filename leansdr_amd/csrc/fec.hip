@@ -880,6 +880,17 @@ void lsdr_deconv_destroy(lsdr_deconv *d) {
   delete d;
 }
 
+int lsdr_deconv_reset(lsdr_deconv *d) {   // back to the state after construction (a new stream begins); stream-ordered
+  LSDR_ARG(d);
+  d->locked = 0; d->skip = 0;
+  for (int i = 0; i < 4; ++i) { d->n_in[i] = 0; d->n_out[i] = 0; d->cur[i] = 0; d->n_in2[i] = 0; d->n_out2[i] = 0; d->cur2[i] = 0; }
+  for (int i = 0; i < 2; ++i) {
+    LSDR_HIP(hipMemsetAsync(d->d_carry[i], 0, 4 * sizeof(deconv_carry), d->ctx->stream));
+    LSDR_HIP(hipMemsetAsync(d->d_carry2[i], 0, 4 * sizeof(deconv_carry), d->ctx->stream));
+  }
+  return LSDR_OK;
+}
+
 int lsdr_deconv_next_sync(lsdr_deconv *d) {   // dvb.h:185-193
   LSDR_ARG(d);
   ++d->locked;
@@ -1005,6 +1016,15 @@ void lsdr_mpeg_sync_destroy(lsdr_mpeg_sync *m) {
   (void)hipStreamSynchronize(m->ctx->stream);
   (void)hipFree(m->d_state); (void)hipFree(m->d_res); if (m->d_ok) (void)hipFree(m->d_ok);
   delete m;
+}
+int lsdr_mpeg_sync_reset(lsdr_mpeg_sync *m) {   // back to the state after construction (options kept); stream-ordered
+  LSDR_ARG(m);
+  const int fastlock = m->st.fastlock, resync_period = m->st.resync_period;
+  memset(&m->st, 0, sizeof(m->st));
+  m->st.scan_syncs = 8; m->st.want_syncs = 4; m->st.lock_timeout = 4;   // dvb.h:727-731
+  m->st.fastlock = fastlock; m->st.resync_period = resync_period;
+  m->report_state = true;
+  return lsdr_stage_h2d(m->ctx, m->d_state, &m->st, sizeof(msync_state));
 }
 int lsdr_mpeg_sync_locked(const lsdr_mpeg_sync *m) { return m ? m->st.synchronized : 0; }
 int lsdr_mpeg_sync_set_resync_period(lsdr_mpeg_sync *m, int period) {
@@ -1143,6 +1163,11 @@ int lsdr_derandomizer_create(lsdr_ctx *c, lsdr_derandomizer **out) {
   LSDR_HIP(hipMemcpy(d->d_pattern + 1504, d->pattern, 188, hipMemcpyHostToDevice));
   LSDR_HIP(hipMalloc((void **)&d->d_res, sizeof(derand_result)));
   *out = d;
+  return LSDR_OK;
+}
+int lsdr_derandomizer_reset(lsdr_derandomizer *d) {   // a new stream begins
+  LSDR_ARG(d);
+  d->pos = 0;
   return LSDR_OK;
 }
 void lsdr_derandomizer_destroy(lsdr_derandomizer *d) {
