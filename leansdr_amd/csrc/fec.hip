@@ -106,12 +106,15 @@ __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
     unsigned v = 0;
     long long g = (long long)(8 * k) - P.n_out0;   // index into the refill bit stream (negative: carried bits)
     unsigned long long q_cached = ~0ull, w = 0;
+    // refill index and bit position of the first refill bit of this byte: ONE division per thread, then counted along
+    const long long g0 = g < 0 ? 0 : g;
+    unsigned long long q = (unsigned long long)g0 / (unsigned)D.pp;
+    int r = (int)((unsigned long long)g0 - q * (unsigned)D.pp);
     for (int b = 0; b < 8; ++b, ++g) {
       unsigned bit;
       if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;   // carried bits, MSB first
       else {
-        const unsigned long long q = (unsigned long long)g / (unsigned)D.pp;
-        const int bi = D.pp - 1 - (int)((unsigned long long)g % (unsigned)D.pp);
+        const int bi = D.pp - 1 - r;
         if (q != q_cached) {
           if (q_cached != ~0ull && q == q_cached + 1) {   // slide by one refill
             const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);
@@ -120,6 +123,7 @@ __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
           q_cached = q;
         }
         bit = (unsigned)par64(w & D.deconv[bi]);
+        if (++r == D.pp) { r = 0; ++q; }
       }
       v = (v << 1) | bit;
     }
@@ -463,9 +467,39 @@ __device__ unsigned char eval_poly(const gf_tables &g, const unsigned char *p, i
   return a;
 }
 
-// rs_engine::correct, rs.h:173-270, run by one lane on the packet copy in LDS.
-__device__ void rs_correct(const gf_tables &g, const unsigned char *synd, unsigned char *pk /*204, in place*/,
-                           unsigned char *pout /*188*/, int *nerrs) {
+// Syndromes of one 204-byte packet by one wavefront (rs.h:116-129: synd[j] = P(α^j), P(x) = Σ_i pk[i]·x^(203−i), which the
+// reference evaluates by Horner's rule — 204 dependent multiplications per syndrome).  Field arithmetic is exact, so the sum
+// may be taken in any order: lane l owns bytes l, l+64, l+128, l+192 and adds pk[i]·α^(j·(203−i)) to all 16 syndromes (one
+// log look-up per byte, one exp look-up per term, all independent), then the lanes' partial sums are XORed together.  The
+// 16 syndromes come back packed four per word, identical on every lane.
+__device__ __forceinline__ void rs_syndromes(const gf_tables &g, const unsigned char *pk, int lane, unsigned s[4]) {
+  s[0] = s[1] = s[2] = s[3] = 0u;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = lane + 64 * k;
+    const unsigned r = i < kRS ? pk[i] : 0u;
+    if (r) {
+      const int lr = g.log[r], e = kRS - 1 - i;     // e < 255
+      int m = 0;                                    // (j·e) mod 255
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        s[j >> 2] ^= (unsigned)g.exp[lr + m] << (8 * (j & 3));
+        m += e;
+        m = m >= 255 ? m - 255 : m;
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[q] ^= __shfl_xor(s[q], d, 64);
+  }
+}
+
+// Key equation of rs_engine::correct (rs.h:173-243) by one lane: Berlekamp-Massey → error locator C (degree L), evaluator
+// omega, formal derivative C'.  Results go to LDS for the wavefront's Chien search.
+struct rs_key { unsigned char C[16], omega[16], Cprime[16]; int L; };
+__device__ void rs_solve_key(const gf_tables &g, const unsigned char *synd, rs_key *K) {
   unsigned char C[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned char B[16] = {1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   int L = 0, m = 1;
@@ -492,37 +526,27 @@ __device__ void rs_correct(const gf_tables &g, const unsigned char *synd, unsign
   for (int i = 0; i < 16; ++i)
     for (int j = 0; j < 16; ++j)
       if (i + j < 16) omega[i + j] ^= gmul(g, synd[i], C[j]);
-  unsigned char Cprime[15];
-  for (int i = 0; i < 15; ++i) Cprime[i] = (i & 1) ? 0 : C[i + 1];
-  // Berlekamp-Massey can end with L = 16 (more errors than the code corrects); C[] and omega[] have 16 coefficients —
-  // the reference evaluates degree L regardless and reads one byte past them (rs.h:247,258) — such packets stay
-  // uncorrectable either way, so the evaluation is capped at the arrays' degree.
-  const int deg = L > 15 ? 15 : L;
-  int roots = 0;
-  for (int i = 0; i < 255; ++i) {
-    const unsigned char r = g.exp[i];
-    if (!eval_poly(g, C, deg, r)) {
-      const unsigned char xk = ginv(g, r);
-      const int loc = (255 - i) % 255;
-      if (loc < 204) {
-        const unsigned char num = gmul(g, xk, eval_poly(g, omega, deg, r));
-        const unsigned char den = eval_poly(g, Cprime, 14, r);
-        const unsigned char e = gdiv(g, num, den);
-        *nerrs += __popc((unsigned)e);
-        if (loc >= 16) pout[203 - loc] ^= e;
-        pk[203 - loc] ^= e;
-      }
-      if (++roots == L) break;
-    }
-  }
+  for (int i = 0; i < 16; ++i) { K->C[i] = C[i]; K->omega[i] = omega[i]; }
+  for (int i = 0; i < 15; ++i) K->Cprime[i] = (i & 1) ? 0 : C[i + 1];
+  K->Cprime[15] = 0;
+  K->L = L;
 }
 
-// One wavefront per packet, 4 packets per workgroup.
+// p(x) for x = α^lx (x ≠ 0), Horner from the highest coefficient like rs.h's eval_poly
+__device__ __forceinline__ unsigned char rs_eval(const gf_tables &g, const unsigned char *p, int deg, int lx) {
+  unsigned char a = 0;
+  for (; deg >= 0; --deg) a = (unsigned char)((a ? g.exp[g.log[a] + lx] : 0) ^ p[deg]);
+  return a;
+}
+
+// One wavefront per packet, 4 packets per workgroup.  Clean packets (all syndromes zero) cost the parallel syndrome pass only;
+// corrupted ones: key equation on lane 0, Chien search + Forney (rs.h:245-264) spread over the lanes (root α^i ↔ lane i mod 64:
+// every root touches its own byte, so the corrections commute), then the syndromes of the corrected packet (rs.h:266-269).
 __global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned long long n_packets, unsigned char *out,
                                                    const gf_tables *gtab, unsigned long long *counters /*[0] errs*/) {
   __shared__ gf_tables g;
   __shared__ unsigned char pk[4][kRS + 4], po[4][kTS + 4], synd[4][16];
-  __shared__ int corrupted[4];
+  __shared__ rs_key key[4];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   for (int i = tid; i < 512; i += 256) g.exp[i] = gtab->exp[i];
   g.log[tid] = gtab->log[tid];
@@ -530,43 +554,50 @@ __global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned l
   const bool live = p < n_packets;
   if (live)
     for (int i = lane; i < kRS; i += 64) pk[wv][i] = in[p * kRS + i];
-  if (lane == 0) corrupted[wv] = 0;
   __syncthreads();
-  if (live) {
+  if (!live) return;                                   // (no workgroup barrier below: the rest is per wavefront)
+  unsigned s[4];
+  rs_syndromes(g, pk[wv], lane, s);
+  const bool corrupted = (s[0] | s[1] | s[2] | s[3]) != 0u;      // wave-uniform
+  bool still_bad = false;
+  if (corrupted) {
     for (int i = lane; i < kTS; i += 64) po[wv][i] = pk[wv][i];   // the message is the first 188 bytes
-    if (lane < 16) {   // synd[i] = P(alpha^i), Horner over the 204 bytes (rs.h:116-129)
-      const unsigned char x = g.exp[lane];
-      unsigned char acc = 0;
-      for (int i = 0; i < kRS; ++i) acc = gmul(g, acc, x) ^ pk[wv][i];
-      synd[wv][lane] = acc;
-      if (acc) corrupted[wv] = 1;
+    if (lane < 16) synd[wv][lane] = (unsigned char)(s[lane >> 2] >> (8 * (lane & 3)));
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) rs_solve_key(g, synd[wv], &key[wv]);
+    __builtin_amdgcn_wave_barrier();
+    const rs_key &K = key[wv];
+    // Berlekamp-Massey can end with L = 16 (more errors than the code corrects); C[] and omega[] have 16 coefficients —
+    // the reference evaluates degree L regardless and reads one byte past them (rs.h:247,258) — such packets stay
+    // uncorrectable either way, so the evaluation is capped at the arrays' degree.
+    const int deg = K.L > 15 ? 15 : K.L;
+    int nerrs = 0;
+    for (int i = lane; i < 255; i += 64) {             // candidate root r = α^i
+      if (!rs_eval(g, K.C, deg, i)) {
+        const unsigned char xk = g.exp[255 - i];       // 1/r
+        const int loc = (255 - i) % 255;
+        if (loc < kRS) {
+          const unsigned char num = gmul(g, xk, rs_eval(g, K.omega, deg, i));
+          const unsigned char den = rs_eval(g, K.Cprime, 14, i);
+          const unsigned char e = gdiv(g, num, den);
+          nerrs += __popc((unsigned)e);
+          if (loc >= 16) po[wv][kRS - 1 - loc] ^= e;
+          pk[wv][kRS - 1 - loc] ^= e;
+        }
+      }
     }
-  }
-  __syncthreads();
-  if (live && corrupted[wv]) {
-    if (lane == 0) {
-      int nerrs = 0;
-      rs_correct(g, synd[wv], pk[wv], po[wv], &nerrs);
-      if (nerrs) atomicAdd(&counters[0], (unsigned long long)nerrs);
-      corrupted[wv] = 0;
-    }
-  }
-  __syncthreads();
-  if (live) {   // re-check the corrected packet (correct() returns syndromes(pin), rs.h:266-269)
-    // (cheap to run unconditionally; only meaningful for packets that went through correct())
-    if (lane < 16) {
-      const unsigned char x = g.exp[lane];
-      unsigned char acc = 0;
-      for (int i = 0; i < kRS; ++i) acc = gmul(g, acc, x) ^ pk[wv][i];
-      if (acc) corrupted[wv] = 1;
-    }
-  }
-  __syncthreads();
-  if (live) {
-    if (lane == 0 && corrupted[wv]) po[wv][0] ^= kCorrupt;   // dvb.h:1045
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nerrs += __shfl_xor(nerrs, d, 64);
+    if (lane == 0 && nerrs) atomicAdd(&counters[0], (unsigned long long)nerrs);
+    __builtin_amdgcn_wave_barrier();
+    rs_syndromes(g, pk[wv], lane, s);                  // correct() returns syndromes(pin), rs.h:266-269
+    still_bad = (s[0] | s[1] | s[2] | s[3]) != 0u;
+    if (lane == 0 && still_bad) po[wv][0] ^= kCorrupt;   // dvb.h:1045
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = po[wv][i];
     for (int i = lane; i < kRS; i += 64) in[p * kRS + i] = pk[wv][i];   // in-place correction like the reference
+  } else {
+    for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = pk[wv][i];
   }
 }
 
@@ -783,7 +814,11 @@ static gf_tables *rs_device_tables(lsdr_ctx *c) {   // one copy per context, cre
     gf_tables g;
     gf_build(g);
     if (hipMalloc(&c->rs_tables, sizeof(gf_tables)) != hipSuccess) { c->rs_tables = nullptr; return nullptr; }
-    if (hipMemcpy(c->rs_tables, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    if (hipMemcpy(c->rs_tables, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(c->rs_tables);      // never leave a non-null pointer to uninitialised tables behind
+      c->rs_tables = nullptr;
+      return nullptr;
+    }
   }
   return static_cast<gf_tables *>(c->rs_tables);
 }
