@@ -568,8 +568,8 @@ struct rx_tiled_args {
   lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
   unsigned wstride;
   rx_tile_info *info;
-  unsigned *hstage;                    // LSDR_SYM_HARD2: [n_tiles][hstride] packed body symbols (rx_tiling.h "hs2")
-  unsigned hstride;
+  unsigned *hstage;                    // LSDR_SYM_HARD2: packed body symbols (rx_tiling.h "hs2"), transposed: word w of tile j at
+  unsigned long long hpitch;           //                 hstage[w·hpitch + j]
   rx_tile_info_h *hinfo;
   rx_ema_map *ema;                     // [n_tiles]: composition of the maps of the tiles BEFORE this one in its wavefront
   rx_ema_map *ema_wave;                // [n_waves]: composition of all tiles of a wavefront (k_rx_ema scans these)
@@ -610,7 +610,7 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   auto emit = [&](lsdr_softsymbol ss) {
     if (HARD) {
       hacc = (hacc << 2) | (ss.symbol & 3u); htail = (htail << 2) | (ss.symbol & 3u);
-      if ((++cnt & 15u) == 0) a.hstage[(cnt >> 4) - 1] = hacc;
+      if ((++cnt & 15u) == 0) a.hstage[(unsigned long long)((cnt >> 4) - 1) * a.hpitch] = hacc;
     } else {
       po[cnt++] = ss;
     }
@@ -640,7 +640,7 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
   }
   ti.mu_end = s.mu; ti.phase_end = s.phase; ti.count = cnt;
   if (HARD) {
-    if (cnt & 15u) a.hstage[cnt >> 4] = hacc << (2 * (16 - (cnt & 15u)));
+    if (cnt & 15u) a.hstage[(unsigned long long)(cnt >> 4) * a.hpitch] = hacc << (2 * (16 - (cnt & 15u)));
     rx_tile_info_h th;
     th.mu_begin = ti.mu_begin; th.phase_begin = ti.phase_begin; th.mu_end = ti.mu_end; th.phase_end = ti.phase_end;
     th.count = cnt; th.has_pre = 0; th.n_warm = 0; th.warm_tail = 0; th.body_tail = htail;
@@ -748,7 +748,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   // LSDR_SYM_HARD2: the decisions only, packed (rx_tiling.h): the word being filled, the last 16 symbols, the row, the snapshot
   // of the tail at the end of the warm-up
   unsigned hacc = 0, htail = 0, hwarm = 0, hnwarm = 0, hcnt = 0;
-  unsigned *const hrow = HARD ? a.hstage + (unsigned long long)j * a.hstride : nullptr;
+  unsigned *const hcol = HARD ? a.hstage + j : nullptr;      // this tile's column of the transposed staging
 
   int n = 0;                                              // current sample
   rx_window<FMT> win;
@@ -858,7 +858,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
           htail = (htail << 2) | hs;
           if (body) {
             hacc = (hacc << 2) | hs;
-            if ((++hcnt & 15u) == 0) hrow[(hcnt >> 4) - 1] = hacc;
+            if ((++hcnt & 15u) == 0) hcol[(unsigned long long)((hcnt >> 4) - 1) * a.hpitch] = hacc;
           }
         } else {
           *dp = raw.x; dp += keep;
@@ -920,7 +920,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
   if (valid) {
     if (HARD) {
-      if (hcnt & 15u) hrow[hcnt >> 4] = hacc << (2 * (16 - (hcnt & 15u)));
+      if (hcnt & 15u) hcol[(unsigned long long)(hcnt >> 4) * a.hpitch] = hacc << (2 * (16 - (hcnt & 15u)));
       rx_tile_info_h th;
       th.mu_begin = ti.mu_begin; th.phase_begin = ti.phase_begin; th.mu_end = mu; th.phase_end = phase;
       th.count = cnt; th.has_pre = ti.has_pre; th.n_warm = hnwarm; th.warm_tail = hwarm; th.body_tail = htail;
@@ -1242,9 +1242,10 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
 
   const bool hard = r->cfg.out_format == LSDR_SYM_HARD2;
-  const unsigned hstride = stage_stride / 16 + 2;          // words per packed row
+  const unsigned hstride = stage_stride / 16 + 2;          // words per tile
+  const unsigned long long hpitch = ((unsigned long long)n_tiles + 63) & ~63ull;   // transposed staging: word w of tile j at [w·hpitch + j]
   if (r->tiles_cap < n_tiles || (!hard && (r->stage_cap < (size_t)n_tiles * stage_stride || r->wstage_cap < (size_t)n_tiles * sym_per_chunk)) ||
-      (hard && r->hstage_cap < (size_t)n_tiles * hstride)) {
+      (hard && r->hstage_cap < (size_t)hpitch * hstride)) {
     // scratch grows: queued runs may still be using the old buffers
     LSDR_HIP(hipStreamSynchronize(c->stream));
   }
@@ -1260,10 +1261,10 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
     if (hard) LSDR_HIP(hipMalloc((void **)&r->d_hinfo, n_tiles * sizeof(rx_tile_info_h)));
     r->tiles_cap = n_tiles;
   }
-  if (hard && r->hstage_cap < (size_t)n_tiles * hstride) {
+  if (hard && r->hstage_cap < (size_t)hpitch * hstride) {
     (void)hipFree(r->d_hstage);
-    LSDR_HIP(hipMalloc((void **)&r->d_hstage, (size_t)n_tiles * hstride * sizeof(unsigned)));
-    r->hstage_cap = (size_t)n_tiles * hstride;
+    LSDR_HIP(hipMalloc((void **)&r->d_hstage, (size_t)hpitch * hstride * sizeof(unsigned)));
+    r->hstage_cap = (size_t)hpitch * hstride;
   }
   if (!hard && r->stage_cap < (size_t)n_tiles * stage_stride) {
     (void)hipFree(r->d_stage);
@@ -1302,7 +1303,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   a.stage_stride = stage_stride;
   a.stage = r->d_stage;
   a.wstage = r->d_wstage; a.wstride = sym_per_chunk;
-  a.hstage = r->d_hstage; a.hstride = hstride; a.hinfo = r->d_hinfo;
+  a.hstage = r->d_hstage; a.hpitch = hpitch; a.hinfo = r->d_hinfo;
   a.info = r->d_info;
   a.ema = r->d_ema;
   a.ema_wave = r->d_ema_wave;
@@ -1360,7 +1361,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   if (hard) {
     hipLaunchKernelGGL(k_rx_seam_h, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
                        (const rx_tile_info_h *)r->d_hinfo, r->d_fix, n_tiles, r->omega, R, quad, r->d_part, (const uint8_t *)r->d_relabel);
-    hipLaunchKernelGGL((k_rx_compact_h<rx_state_dev>), dim3(n_tiles), dim3(64), 0, c->stream, (const unsigned *)r->d_hstage, hstride,
+    hipLaunchKernelGGL((k_rx_compact_h<rx_state_dev>), dim3((n_tiles + 63) / 64), dim3(64), 0, c->stream, (const unsigned *)r->d_hstage, hpitch,
                        (const rx_tile_info_h *)r->d_hinfo, (const rx_tile_fix *)r->d_fix, (const rx_seam_part *)r->d_part,
                        (const uint8_t *)r->d_relabel, n_tiles, R, quad, reinterpret_cast<unsigned *>(out),
                        (unsigned long long)r->out_sym_offset, r->d_state, r->h_res_dev + slot);

@@ -226,11 +226,16 @@ __device__ __forceinline__ unsigned hs2_map_word(unsigned x, unsigned map4) {
 __device__ __forceinline__ unsigned hs2_map4(const uint8_t *map) {   // [256]-entry relabel row → packed 4-entry map
   return (unsigned)(map[0] & 3) | ((unsigned)(map[1] & 3) << 2) | ((unsigned)(map[2] & 3) << 4) | ((unsigned)(map[3] & 3) << 6);
 }
-// 16 symbols starting at symbol offset o (may be negative or reach past the row: zeros there) of a packed row of nw words
-__device__ __forceinline__ unsigned hs2_fetch16(const unsigned *row, long long nw, long long o) {
+// The tiles' packed rows are stored TRANSPOSED: word w of tile j at hstage[w·pitch + j] (pitch = tiles, padded).  A wavefront
+// of the tile kernel holds 64 consecutive tiles, its lanes reach "16 more symbols" within a few iterations of each other, so
+// their 4-byte stores fall into the same 256 bytes and leave L2 as whole lines (row-major rows cost 5.7 bytes written per
+// byte of payload: every lane dirtied its own line 4 bytes at a time).
+// 16 symbols starting at symbol offset o (may be negative or reach past the row: zeros there) of tile column `col` (nw words)
+__device__ __forceinline__ unsigned hs2_fetch16(const unsigned *col, unsigned long long pitch, long long nw, long long o) {
   const long long wi = o >> 4;                 // floor
   const int sh = 2 * (int)(o & 15);
-  const unsigned a = (wi >= 0 && wi < nw) ? row[wi] : 0u, b = (wi + 1 >= 0 && wi + 1 < nw) ? row[wi + 1] : 0u;
+  const unsigned a = (wi >= 0 && wi < nw) ? col[(unsigned long long)wi * pitch] : 0u;
+  const unsigned b = (wi + 1 >= 0 && wi + 1 < nw) ? col[(unsigned long long)(wi + 1) * pitch] : 0u;
   return sh ? (a << sh) | (b >> (32 - sh)) : a;
 }
 
@@ -255,32 +260,20 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *
   seam_block_scan(add, k, ins, drp, bad, j, n_tiles, rmask, fix, part);
 }
 
-// Compaction of the packed rows: one wavefront per tile writes the output words that START inside the tile's symbol range
-// [D, D + len) — plus, for tile 0, the word that holds out_sym_offset; a word that two tiles share is written by the later
-// one, which takes the earlier tile's last symbols from that tile's row (no atomics, no pre-zeroing).  The symbols before
-// out_sym_offset in the first word (a caller's leftover symbols) are preserved.
+// Compaction of the packed tile columns: one LANE per tile (64 consecutive tiles per wavefront: the transposed staging is
+// read coalesced) walks the output words that START inside its tile's symbol range [D, D + len) — word by word, so the lines
+// of its stretch of the output fill up within a few loop trips and leave L2 whole.  A word that two tiles share is written by
+// the later one, which takes the earlier tile's last symbols from that tile's column (no atomics, no pre-zeroing); the symbols
+// before out_sym_offset in the first word (a caller's leftover symbols) are preserved.
 template <typename STATE>
-__global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, unsigned hstride, const rx_tile_info_h *info,
+__global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, unsigned long long pitch, const rx_tile_info_h *info,
                                                      const rx_tile_fix *fix, const rx_seam_part *part, const uint8_t *relabel,
                                                      unsigned n_tiles, int R, float quad, unsigned *out, unsigned long long out_sym_offset,
                                                      STATE *state, rx_seam_result *res) {
-  const unsigned j = blockIdx.x;
-  if (j >= n_tiles) return;
+  const unsigned j = blockIdx.x * 64u + threadIdx.x;
   const unsigned rmask = (unsigned)R - 1;
   const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock;
-  // totals of the seam blocks before tile j's and before tile j−1's
-  auto block_base = [&](unsigned tile, unsigned long long &base, unsigned &brot) {
-    const unsigned mypart = tile / kSeamBlock;
-    base = 0; brot = 0;
-    for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
-  };
-  unsigned long long base, pbase = 0;
-  unsigned brot, pbrot = 0;
-  block_base(j, base, brot);
-  if (j > 0) block_base(j - 1, pbase, pbrot);
-  if (j == 0 && threadIdx.x == 0) {
+  if (j == 0) {
     rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0; sr.freq_tap = rx_freq_tap(state);
     for (unsigned i = 0; i < nparts; ++i) {
       sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
@@ -290,19 +283,30 @@ __global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, uns
     __threadfence_system();
     if (sr.rot_final) rx_rotate_back(state, sr.rot_final, quad);
   }
-  // this tile's sequence T = [pre]? ++ body[skip …): destination symbols [D, D + len); body symbol b sits at D' = b + Q
+  // totals of the seam blocks before this wavefront's (kSeamBlock is a multiple of 64: one seam block per wavefront; only
+  // lane 0's predecessor can sit in the block before)
+  const unsigned mypart = (blockIdx.x * 64u) / kSeamBlock;
+  unsigned long long base = 0;
+  unsigned brot = 0;
+  for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
+  if (j >= n_tiles) return;
+  unsigned long long pbase = base;
+  unsigned pbrot = brot;
+  if (j > 0 && (j % kSeamBlock) == 0) { pbase = base - part[mypart - 1].cnt; pbrot = brot - part[mypart - 1].rot; }   // (mod R below)
+  // this tile's sequence T = [pre]? ++ body[skip …): destination symbols [D, D + len); body symbol b sits at b + Q
   const rx_tile_fix f = fix[j];
   const rx_tile_info_h ti = info[j];
   const long long skip = f.drop_first ? 1 : 0, ins = f.insert_pre ? 1 : 0;
   const long long D = (long long)(out_sym_offset + base + f.out_offset), len = ins + (long long)ti.count - skip;
   const long long Q = D + ins - skip;
   const unsigned map4 = hs2_map4(relabel + ((f.rot + brot) & rmask) * 256);
-  const unsigned *row = hstage + (unsigned long long)j * hstride;
+  const unsigned *col = hstage + j;
   const long long nw = ((long long)ti.count + 15) >> 4;
   // previous tile (for the shared first word)
   long long pQ = 0, pnw = 0, pD = 0, pins = 0;
   unsigned pmap4 = 0, ppre = 0;
-  const unsigned *prow = nullptr;
   if (j > 0) {
     const rx_tile_fix pf = fix[j - 1];
     const rx_tile_info_h pti = info[j - 1];
@@ -310,27 +314,24 @@ __global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, uns
     pD = (long long)(out_sym_offset + pbase + pf.out_offset);
     pQ = pD + pins - (pf.drop_first ? 1 : 0);
     pmap4 = hs2_map4(relabel + ((pf.rot + pbrot) & rmask) * 256);
-    prow = hstage + (unsigned long long)(j - 1) * hstride;
     pnw = ((long long)pti.count + 15) >> 4;
     ppre = pti.warm_tail & 3u;
   }
-  const long long w_own0 = D >> 4;                                         // first word this tile writes (a shared one included)
   const long long end = D + len;
   const long long w_last = j == n_tiles - 1 ? (end + 15) >> 4 : end >> 4;  // exclusive; a partial last word belongs to the next tile
-  for (long long m = w_own0 + threadIdx.x; m < w_last; m += 64) {
+  for (long long m = D >> 4; m < w_last; ++m) {
     const long long s0 = m << 4;                                            // first symbol of the word
     // part from this tile: symbols u with D ≤ s0+u < end
-    unsigned cur = hs2_fetch16(row, nw, s0 - Q);
+    unsigned cur = hs2_fetch16(col, pitch, nw, s0 - Q);
     if (ins && D >= s0 && D < s0 + 16) cur = (cur & ~(3u << (30 - 2 * (int)(D - s0)))) | ((ti.warm_tail & 3u) << (30 - 2 * (int)(D - s0)));
     const long long lo = D > s0 ? D - s0 : 0, hi = end < s0 + 16 ? end - s0 : 16;       // valid symbol slots [lo, hi)
-    unsigned mask = hi > lo ? (hi - lo >= 16 ? 0xffffffffu : ((1u << (2 * (int)(hi - lo))) - 1u) << (32 - 2 * (int)hi)) : 0u;
+    const unsigned mask = hi > lo ? (hi - lo >= 16 ? 0xffffffffu : ((1u << (2 * (int)(hi - lo))) - 1u) << (32 - 2 * (int)hi)) : 0u;
     unsigned word = hs2_map_word(cur, map4) & mask;
     if (lo > 0) {
       if (j > 0) {       // symbols [s0, D) are the previous tile's last ones
-        unsigned pv = hs2_fetch16(prow, pnw, s0 - pQ);
+        unsigned pv = hs2_fetch16(col - 1, pitch, pnw, s0 - pQ);
         if (pins && pD >= s0 && pD < s0 + 16) pv = (pv & ~(3u << (30 - 2 * (int)(pD - s0)))) | (ppre << (30 - 2 * (int)(pD - s0)));
-        const unsigned pmask = ~0u << (32 - 2 * (int)lo);
-        word |= hs2_map_word(pv, pmap4) & pmask;
+        word |= hs2_map_word(pv, pmap4) & (~0u << (32 - 2 * (int)lo));
       } else {           // tile 0: the caller's symbols before out_sym_offset stay
         word |= out[m] & (~0u << (32 - 2 * (int)lo));
       }
