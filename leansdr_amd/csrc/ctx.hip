@@ -48,21 +48,27 @@ static int ctx_create(int device, void *hip_stream, const uint32_t *cu_mask, uns
   lsdr_ctx *c = new lsdr_ctx();
   c->device = device;
   c->own_stream = (hip_stream == nullptr);
+  // any HIP failure below: release what exists so far (the context is not handed out)
+#define CTX_HIP(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { \
+    if (c->ev0) (void)hipEventDestroy(c->ev0); if (c->ev1) (void)hipEventDestroy(c->ev1); \
+    if (c->stream && (c->own_stream || cu_mask)) (void)hipStreamDestroy(c->stream); \
+    delete c; return lsdr_hip_fail(e__, #call, __FILE__, __LINE__); } } while (0)
   if (cu_mask) {
-    LSDR_HIP(hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask));
+    CTX_HIP(hipExtStreamCreateWithCUMask(&c->stream, mask_words, cu_mask));
   } else if (c->own_stream) {
     const char *pe = getenv("LSDR_STREAM_PRIORITY");   // tuning hook: "high" → highest stream priority
     if (pe && !strcmp(pe, "high")) {
       int lo = 0, hi = 0;
-      LSDR_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      LSDR_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
-    } else LSDR_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      CTX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      CTX_HIP(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi));
+    } else CTX_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   }
   else c->stream = (hipStream_t)hip_stream;
-  LSDR_HIP(hipEventCreate(&c->ev0));
-  LSDR_HIP(hipEventCreate(&c->ev1));
+  CTX_HIP(hipEventCreate(&c->ev0));
+  CTX_HIP(hipEventCreate(&c->ev1));
   hipDeviceProp_t prop;
-  LSDR_HIP(hipGetDeviceProperties(&prop, device));
+  CTX_HIP(hipGetDeviceProperties(&prop, device));
+#undef CTX_HIP
   c->num_cu = prop.multiProcessorCount;
   if (cu_mask) {   // the kernels size their grids for the compute units this stream may use
     int n = 0;

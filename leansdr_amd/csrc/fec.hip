@@ -439,11 +439,18 @@ __global__ __launch_bounds__(64) void k_msync_book(msync_state *gS, const unsign
 
 // ======================================================================== deinterleaver
 // out[p][j] = in[p*204 + 2244 + j − 12·17·((11 − j) mod 12)]   (dvb.h:935-940)
+// A byte of the output comes from up to 2244 bytes further back, so neighbouring 256-byte chunks of the output gather from
+// the same input lines: every XCD (block b runs on XCD b mod 8, each with its own L2) walks ONE contiguous eighth of the
+// stream, so that an input line is fetched by one L2 instead of by all of them (measured with a round-robin walk: 4 bytes
+// fetched per input byte).
 __global__ __launch_bounds__(256) void k_deinterleave(const unsigned char *in, unsigned long long n_packets,
                                                       unsigned char *out) {
   const unsigned long long total = n_packets * kRS;
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
-  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < total; i += stride) {
+  const unsigned long long chunks = (total + 255) / 256, per_xcd = (chunks + 7) / 8;
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;      // (the grid is a multiple of 8)
+  for (unsigned long long c = slot; c < per_xcd; c += slots) {
+    const unsigned long long i = (xcd * per_xcd + c) * 256 + threadIdx.x;
+    if (i >= total) continue;
     const unsigned long long p = i / kRS;
     const unsigned j = (unsigned)(i % kRS);
     const unsigned delay = 17u * ((11u + 12u * 17u - j) % 12u);
@@ -1136,6 +1143,7 @@ int lsdr_deinterleaver_run(lsdr_ctx *c, const uint8_t *in, size_t n_in, uint8_t 
   size_t blocks = (n * kRS + 255) / 256;
   const size_t capb = (size_t)c->num_cu * 8;
   if (blocks > capb) blocks = capb;
+  blocks = (blocks + 7) / 8 * 8;
   hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)blocks), dim3(256), 0, c->stream, in, (unsigned long long)n, out);
   LSDR_HIP(hipGetLastError());
   *produced = n;

@@ -303,9 +303,12 @@ __device__ __forceinline__ float2 cmulf(float2 a, float2 b) { return make_float2
 __device__ __forceinline__ void scan_publish(float2 *tot_slot, unsigned *flag_slot, float2 tot, unsigned stamp) {
   unsigned long long bits;
   __builtin_memcpy(&bits, &tot, 8);
+  // Hand-off form "8-byte agent-scope atomics on both sides" (MI355X_MICROARCH.md, inter-workgroup visibility): the value and
+  // the stamp are written through to L2 (sc1), the reader's loads bypass its L1 (sc1); the value has LEFT this CU before the
+  // stamp is issued — the wait is inline asm so that no compiler pass can drop or move it.  gfx942/gfx950 semantics, not the
+  // portable HIP memory model (a release fence per wave-block would flush the XCD's dirty L2: measured 12× slower).
   __hip_atomic_store(reinterpret_cast<unsigned long long *>(tot_slot), bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the value is out before the stamp
-  __atomic_signal_fence(__ATOMIC_SEQ_CST);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __hip_atomic_store(flag_slot, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ float2 scan_wait(const float2 *tot_slot, const unsigned *flag_slot, unsigned stamp) {
@@ -751,6 +754,13 @@ static void notch_scan_launch(hipStream_t st, unsigned grid, const notch_scan_ar
 }
 static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *out, size_t nb) {
   lsdr_ctx *c = a->ctx;
+  {   // refused BEFORE anything of the block's state is touched
+    const float a12288 = (float)pow(1.0 - (double)a->k, 12288);
+    if (!(a12288 < 1e-8f)) {
+      lsdr_set_error("auto_notch: LSDR_NOTCH_SCAN looks 12288 samples back; k=%g leaves (1-k)^12288=%g of older input (use LSDR_NOTCH_EXACT)", (double)a->k, (double)a12288);
+      return LSDR_E_UNSUPPORTED;
+    }
+  }
   if (!a->scan_started) {
     for (int i = 0; i < 2; ++i) {
       LSDR_HIP(hipMalloc((void **)&a->d_scarry[i], sizeof(notch_est)));
@@ -851,10 +861,6 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     for (int m = 0; m < 7; ++m) sa.C.apow16[m] = (float)pow(av, 16.0 * (1 << m));
     sa.C.a1024 = (float)pow(av, 1024); sa.C.a2048 = (float)pow(av, 2048); sa.C.a3072 = (float)pow(av, 3072);
     sa.C.a4096 = (float)pow(av, 4096); sa.C.a8192 = (float)pow(av, 8192); sa.C.a12288 = (float)pow(av, 12288);
-    if (!(sa.C.a12288 < 1e-8f)) {
-      lsdr_set_error("auto_notch: LSDR_NOTCH_SCAN looks 12288 samples back; k=%g leaves (1-k)^12288=%g of older input (use LSDR_NOTCH_EXACT)", (double)a->k, (double)sa.C.a12288);
-      return LSDR_E_UNSUPPORTED;
-    }
   }
   sa.carry_out = a->d_scarry[nxt];   // … written by the last block
   hipEvent_t *tp = nullptr;

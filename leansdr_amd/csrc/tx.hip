@@ -12,6 +12,7 @@
 // All integer/byte blocks are data-parallel given a few carried bytes; the AGC's per-chunk sums and its EMA are
 // sequential float recurrences and are evaluated in exactly the reference's order (a lane per chunk, then one lane
 // over the chunks).  Bit-exact against the oracle, which is pinned to the reference blocks and to `leandvbtx` itself.
+#include <mutex>
 #include "lsdr_internal.h"
 
 namespace {
@@ -184,14 +185,20 @@ struct lsdr_randomizer { lsdr_ctx *ctx; unsigned pos; unsigned char *d_pattern; 
 struct lsdr_convol { lsdr_ctx *ctx; int bits_in, bits_out, bps; unsigned short polys[8]; unsigned short hist; };
 struct lsdr_fir_resampler { lsdr_ctx *ctx; unsigned ncoeffs, interp; std::vector<float> coeffs; float2 *d_sc; float current_freq; };
 struct lsdr_simple_agc { lsdr_ctx *ctx; float out_rms, bw; float *d_est, *d_gain; size_t gain_cap; };
+// Read-only tables shared by every context of a device, created on first use.  Contexts may be driven from different threads
+// (include/lsdr_hip.h): creation is serialised, and a table pointer is published only after its (synchronous) upload.
+static std::mutex g_tx_tables_mutex;
 static gf_tab *tx_gf_tables(lsdr_ctx *c) {
   static gf_tab *d_tab[64] = {nullptr};
   if (c->device < 0 || c->device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_tx_tables_mutex);
   if (!d_tab[c->device]) {
     gf_tab g;
     lsdr_rs_tables(g.exp, g.log, g.G);
-    if (hipMalloc((void **)&d_tab[c->device], sizeof(gf_tab)) != hipSuccess) return nullptr;
-    if (hipMemcpy(d_tab[c->device], &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    gf_tab *d = nullptr;
+    if (hipMalloc((void **)&d, sizeof(gf_tab)) != hipSuccess) return nullptr;
+    if (hipMemcpy(d, &g, sizeof(g), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    d_tab[c->device] = d;
   }
   return d_tab[c->device];
 }
@@ -337,14 +344,21 @@ int lsdr_cstln_transmitter_run(lsdr_ctx *c, int cstln, int rate, const uint8_t *
   LSDR_HIP(hipSetDevice(c->device));
   static float2 *d_pts[64][16][16] = {};   // [device][constellation][code rate], created on first use
   LSDR_ARG(c->device >= 0 && c->device < 64 && cstln >= 0 && cstln < 16 && rate >= 0 && rate < 16);
-  float2 *&d = d_pts[c->device][cstln][rate];
-  if (!d) {
-    lsdr::cstln_tables tab;
-    if (lsdr::build_cstln(cstln, rate, tab) < 0) { lsdr_set_error("cstln_transmitter: constellation/code rate not supported"); return LSDR_E_ARG; }
-    std::vector<float2> pts(256, make_float2(0.f, 0.f));
-    for (int s = 0; s < tab.nsymbols; ++s) pts[s] = make_float2((float)(0 + tab.symbols[s][0]), (float)(0 + tab.symbols[s][1]));   // Zout + cp (sdr.h:1213-1214)
-    LSDR_HIP(hipMalloc((void **)&d, 256 * sizeof(float2)));
-    LSDR_HIP(hipMemcpy(d, pts.data(), 256 * sizeof(float2), hipMemcpyHostToDevice));
+  float2 *d = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_tx_tables_mutex);
+    float2 *&slot = d_pts[c->device][cstln][rate];
+    if (!slot) {
+      lsdr::cstln_tables tab;
+      if (lsdr::build_cstln(cstln, rate, tab) < 0) { lsdr_set_error("cstln_transmitter: constellation/code rate not supported"); return LSDR_E_ARG; }
+      std::vector<float2> pts(256, make_float2(0.f, 0.f));
+      for (int s = 0; s < tab.nsymbols; ++s) pts[s] = make_float2((float)(0 + tab.symbols[s][0]), (float)(0 + tab.symbols[s][1]));   // Zout + cp (sdr.h:1213-1214)
+      float2 *nd = nullptr;
+      LSDR_HIP(hipMalloc((void **)&nd, 256 * sizeof(float2)));
+      if (hipMemcpy(nd, pts.data(), 256 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(nd); LSDR_HIP(hipErrorUnknown); }
+      slot = nd;
+    }
+    d = slot;
   }
   hipLaunchKernelGGL(k_cstln_map, dim3(grid_for(c, n)), dim3(256), 0, c->stream, sym, (unsigned long long)n, (const float2 *)d, (float2 *)out);
   LSDR_HIP(hipGetLastError());

@@ -322,12 +322,15 @@ struct pipebuf : detail::pipe_base {
     if (from == 0) return;
     const size_t live = (head_ - from) * sizeof(T);
     if (devp_) {
-      // transfers in flight use the old layout; kernels may still read it: drain, move, drain
-      lsdr_check(lsdr_copy_sync_all(ctx()), name);
+      // A pipe that also has a host side may have uploads / downloads in flight that use the old layout (they run on the
+      // side streams): drain, move, drain.  A device-only pipe needs no host wait at all: the move is stream-ordered behind
+      // the kernels that still read the old layout and ahead of the ones that will use the new one.
+      const bool two_sided = host_ != NULL || h2d_unfenced_ || d2h_inflight_;
+      if (two_sided) lsdr_check(lsdr_copy_sync_all(ctx()), name);
       h2d_unfenced_ = d2h_inflight_ = false;
       if (live) {
         lsdr_check(lsdr_memcpy_d2d(ctx(), devp_, devp_ + from, live), name);
-        lsdr_check(lsdr_ctx_sync(ctx()), name);
+        if (two_sided) lsdr_check(lsdr_ctx_sync(ctx()), name);
       }
     }
     if (host_ && live) memmove(host_, host_ + from, live);

@@ -26,7 +26,7 @@ TOL = dict(
     min_equal_decisions=0.999,
     max_mean_abs_dcost=0.05 * COST_MAX,       # 562
     max_p99_abs_dcost=0.20 * COST_MAX,        # 2247
-    max_abs_dcost=COST_MAX,                   # one symbol may at worst move from "certain" to "undecided", never flip with confidence
+    max_abs_dcost=0.5 * COST_MAX,             # 5618: no single symbol moves by more than half the confidence scale (measured <= 2544)
     max_bad_seams=0,
     ss_rtol=0.02,
     mer_atol_db=1.0,

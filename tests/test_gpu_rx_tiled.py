@@ -1,24 +1,20 @@
 """LSDR_RX_TILED (throughput mode of cstln_receiver) against the exact serial oracle.
 
-Tolerance (stated): every tile but the first re-acquires
-timing and carrier phase during its warm-up, so the loop state differs from the serial
-trajectory by loop noise.  On a locked QPSK stream (Es/N0 = 20 dB in the synth's
-definition, the bench condition) we require
-  * exactly the same number of soft symbols for the same consumed input,
-  * >= 99.9 % identical symbol decisions,
-  * mean |Δcost| <= 3 % of the constellation's largest |cost| (11236 for QPSK),
-and the first tile (which continues from the carried state) must be bit-exact.
+The tolerance is stated ONCE, in leansdr_amd/tolerance.py (TOL at the bench condition, LOW_SNR at 10-12 dB): same symbol count,
+first tile bit-exact, >= 99.9 % identical decisions, mean / 99th percentile / maximum of |Δcost| bounded, no unreconciled seam,
+reports within ss_rtol / mer_atol_db.  bench.py's `verified` objects use the same module.
 """
 import numpy as np
 import pytest
 from conftest import bits_equal
 import pyoracle as po
 from leansdr_amd import synth
+from leansdr_amd.tolerance import TOL, LOW_SNR, check_tiled
 
 pytestmark = pytest.mark.gpu
 
-SS_RTOL = 0.02        # signal-strength report and carried AGC state vs the serial receiver
-MER_ATOL_DB = 1.0     # MER report vs the serial receiver (the tiles' residual timing/AGC settling shows at ≈ 20 dB MER)
+SS_RTOL = TOL["ss_rtol"]          # signal-strength report and carried AGC state vs the serial receiver
+MER_ATOL_DB = TOL["mer_atol_db"]  # MER report vs the serial receiver (the tiles' residual timing/AGC settling shows at ≈ 20 dB MER)
 
 
 @pytest.fixture(scope="module")
@@ -45,15 +41,9 @@ def test_tiled_vs_serial(capi, ctx, oracle, stream, tile_len, warm):
     stats = r.tiled_stats()
     r.close()
     assert out["consumed"] == ref["consumed"]
-    assert len(out["sym"]) == len(ref["sym"]), (len(out["sym"]), len(ref["sym"]), stats)
-    same = (out["sym"]["symbol"] == ref["sym"]["symbol"]).mean()
-    dcost = np.abs(out["sym"]["cost"].astype(int) - ref["sym"]["cost"].astype(int))
-    assert same >= 0.999, (same, stats)
-    assert dcost.mean() <= 0.03 * 11236, (dcost.mean(), stats)
-    assert stats["bad_seams"] == 0 and stats["tiles"] > 10
-    # first tile: exact continuation of the carried state
-    n0 = (warm or 256) // 4 - 8      # tile 0 is one warm-up long; (0, 0) = library defaults: 256-sample warm-up at omega 4
-    assert bits_equal(out["sym"]["cost"][:n0], ref["sym"]["cost"][:n0])
+    # first tile: exact continuation of the carried state (tile 0 is one warm-up long; (0, 0) = library defaults: 256 samples)
+    rep = check_tiled(out["sym"], ref["sym"], stats, first_exact=(warm or 256) // 4 - 8)
+    assert rep["pass"] and stats["tiles"] > 10, (rep, TOL)
     # measurement stream has the reference's cadence
     assert len(out["freq"]) == len(ref["freq"]) and len(ref["freq"]) > 50
     # the estimators behind SS and MER (sdr.h:905-913) are EMAs over ALL chunks: the tiles' per-chunk contributions are
@@ -130,25 +120,24 @@ def test_queued_runs_equal_synchronous_runs(capi, ctx, oracle, stream):
         b.wait()                      # nothing queued
 
 
-def test_bench_geometry_on_the_c2_chain(capi, ctx, oracle):
-    """The configuration bench.py times: Fs 240 MS/s cf32 at 120 samples/symbol → scaler(×75) + fir_filter(313, /30) on
-    the GPU (bit-exact vs the oracle) → tiled receiver, tiles of 128 samples after a 256-sample warm-up, against the
-    oracle's fir_filter → exact serial receiver from the same acquisition state."""
+def _c2_chain(capi, ctx, oracle, snr_db, n_sym=65536, seed=11):
+    """Fs 240 MS/s cf32 at 120 samples/symbol → scaler(×75) + fir_filter(313, /30) on the GPU (bit-exact vs the oracle)."""
     import bench
     coeffs, decim = bench.c2_filter(capi)
-    x, _ = synth.qpsk_baseband(120 * 65536, 120, seed=11, rms=1.0, snr_db=20.0)
+    x, _ = synth.qpsk_baseband(120 * n_sym, 120, seed=seed, rms=1.0, snr_db=snr_db)
     y_ref, _ = oracle.fir_filter(coeffs, decim, oracle.scaler(75.0, x))
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
     y, _ = fir.run(x)
     fir.close()
     assert bits_equal(y, y_ref)
-    omega = 240e6 / decim / 2e6
+    return y, 240e6 / decim / 2e6
+
+
+def _tiled_vs_serial(capi, ctx, oracle, y, omega, acq, tile):
     p = po.rx_params(sampler=1, cstln=1, omega=omega, meas_decimation=8192)
-    acq = 32768
-    a = oracle.rx(p, y_ref[:acq + 1])
-    ref = oracle.rx(p, y_ref[acq:], state_in=a["state"])
-    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=omega, meas_decimation=8192, mode=capi.RX_TILED,
-                           tile_len=128, tile_warmup=256)
+    a = oracle.rx(p, y[:acq + 1])
+    ref = oracle.rx(p, y[acq:], state_in=a["state"])
+    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=omega, meas_decimation=8192, mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1])
     st = capi.RxState()
     for k, _ in st._fields_:
         setattr(st, k, getattr(a["state"], k))
@@ -156,13 +145,33 @@ def test_bench_geometry_on_the_c2_chain(capi, ctx, oracle):
     out = r.run(y[acq:])
     stats = r.tiled_stats()
     r.close()
-    assert out["consumed"] == ref["consumed"] and len(out["sym"]) == len(ref["sym"]) > 50000, stats
-    same = (out["sym"]["symbol"] == ref["sym"]["symbol"]).mean()
-    dcost = np.abs(out["sym"]["cost"].astype(int) - ref["sym"]["cost"].astype(int)).mean()
-    assert same >= bench.TOL["min_equal_decisions"] and dcost <= bench.TOL["max_mean_abs_dcost"], (same, dcost, stats)
-    assert stats["bad_seams"] == 0
-    assert bits_equal(out["sym"]["cost"][:56], ref["sym"]["cost"][:56])
+    assert out["consumed"] == ref["consumed"]
+    return out, ref, stats
+
+
+def test_bench_geometry_on_the_c2_chain(capi, ctx, oracle):
+    """The configuration bench.py times (its DEFAULT_TILE, imported): the C2 chain → tiled receiver against the oracle's
+    fir_filter → exact serial receiver from the same acquisition state, under TOL."""
+    import bench
+    y, omega = _c2_chain(capi, ctx, oracle, 20.0)
+    out, ref, stats = _tiled_vs_serial(capi, ctx, oracle, y, omega, 32768, bench.DEFAULT_TILE)
+    rep = check_tiled(out["sym"], ref["sym"], stats, first_exact=bench.DEFAULT_TILE[1] // 4 - 8)
+    assert rep["pass"] and len(out["sym"]) > 50000, (rep, TOL)
     assert np.allclose(out["ss"], ref["ss"], rtol=SS_RTOL) and np.max(np.abs(out["mer"] - ref["mer"])) <= MER_ATOL_DB
+
+
+@pytest.mark.parametrize("snr_db", [12.0, 10.0])
+def test_c2_chain_at_low_snr(capi, ctx, oracle, snr_db):
+    """10-12 dB on the C2 chain, bench geometry, under LOW_SNR.  The serial loop is given 1000 chunks to acquire: the AGC
+    estimator has a 100-chunk time constant (sdr.h:867-870) and a tiled run keeps the gain it starts with, so a run that begins
+    before the AGC has settled carries that error through all of its tiles (2.5 time constants gave -1.5 dB of MER here)."""
+    import bench
+    y, omega = _c2_chain(capi, ctx, oracle, snr_db, n_sym=98304)
+    out, ref, stats = _tiled_vs_serial(capi, ctx, oracle, y, omega, 128 * 1000, bench.DEFAULT_TILE)
+    rep = check_tiled(out["sym"], ref["sym"], stats, first_exact=bench.DEFAULT_TILE[1] // 4 - 8, tol=LOW_SNR)
+    assert rep["pass"], (rep, LOW_SNR)
+    assert np.allclose(out["ss"], ref["ss"], rtol=LOW_SNR["ss_rtol"]), np.max(np.abs(out["ss"] / ref["ss"] - 1))
+    assert np.max(np.abs(out["mer"] - ref["mer"])) <= LOW_SNR["mer_atol_db"], (out["mer"] - ref["mer"])
 
 
 def test_tiled_fir_sampler_vs_serial(capi, ctx, oracle):
@@ -189,6 +198,5 @@ def test_tiled_fir_sampler_vs_serial(capi, ctx, oracle):
     stats = r.tiled_stats()
     r.close()
     assert out["consumed"] == ref["consumed"] and len(out["sym"]) == len(ref["sym"]), (len(out["sym"]), len(ref["sym"]), stats)
-    same = (out["sym"]["symbol"] == ref["sym"]["symbol"]).mean()
-    dcost = np.abs(out["sym"]["cost"].astype(int) - ref["sym"]["cost"].astype(int)).mean()
-    assert same >= 0.999 and dcost <= 0.05 * 11236 and stats["bad_seams"] == 0, (same, dcost, stats)
+    rep = check_tiled(out["sym"], ref["sym"], stats)
+    assert rep["pass"], (rep, TOL)

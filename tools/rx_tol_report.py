@@ -55,11 +55,14 @@ for snr in (20.0, 12.0, 8.0):
         compare(x, g[0], g[1], f"4sps snr{snr:g}")
 
 coeffs, decim = bench.c2_filter(capi)
-for snr in (20.0, 10.0):
-    x, _ = synth.qpsk_baseband(120 * 65536, 120, seed=11, rms=1.0, snr_db=snr)
+for snr in (20.0, 12.0, 10.0):
+    x, _ = synth.qpsk_baseband(120 * 98304, 120, seed=11, rms=1.0, snr_db=snr)
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0)
     y, _ = fir.run(x)
     fir.close()
     for g in GEOS[:3]:
-        compare(y, g[0], g[1], f"c2chain snr{snr:g}", acq=32768, md=8192)
+        # 1000 chunks of serial acquisition: the AGC estimator (100-chunk time constant) has settled; `acq256` shows what a run
+        # started after 2.5 time constants carries through its tiles
+        compare(y, g[0], g[1], f"c2chain snr{snr:g}", acq=128 * 1000, md=8192)
+    compare(y, 256, 256, f"c2chain snr{snr:g} acq256", acq=32768, md=8192)
 json.dump(rows, open(os.path.join(ROOT, "gpurun_out", "rx_tol_report.json"), "w"), indent=1)
