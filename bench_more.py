@@ -48,6 +48,18 @@ def batches_for(seconds_per_batch, lo=8):
     return max(lo, int(np.ceil(MIN_SECONDS / max(seconds_per_batch, 1e-6))))
 
 
+def timed_at_least(run_once, sync):
+    """Repeat run_once() (returns the units it processed) until MIN_SECONDS of wall time have been timed.  Returns (units, seconds, calls)."""
+    units, calls, t0 = 0, 0, time.perf_counter()
+    while True:
+        units += run_once()
+        sync()
+        calls += 1
+        dt = time.perf_counter() - t0
+        if dt >= MIN_SECONDS:
+            return units, dt, calls
+
+
 def reference_ts(iq, flags, timeout=600):
     """TS bytes the reference binary writes for `iq` (None where oracle/_ref was not built)."""
     if not (os.path.exists(REFBIN) and os.access(REFBIN, os.X_OK)):
@@ -82,10 +94,8 @@ def single_stream(capi, synth, device, args):
     pipe.run(8, False)
     pipe.sync()
     nb = batches_for((time.perf_counter() - t0) / 8)
-    t0 = time.perf_counter()
-    consumed = pipe.run(nb, True, snapshot_last=not args.no_verify)
-    pipe.sync()
-    dt = time.perf_counter() - t0
+    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True, snapshot_last=not args.no_verify), pipe.sync)
+    nb *= calls
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=1, batches=nb,
                roofline=pipe.roofline())
     if not args.no_verify:
@@ -103,10 +113,8 @@ def c2_fma(capi, synth, device, args):
     pipe.run(16, False)
     pipe.sync()
     nb = batches_for((time.perf_counter() - t0) / 16)
-    t0 = time.perf_counter()
-    consumed = pipe.run(nb, True)
-    pipe.sync()
-    dt = time.perf_counter() - t0
+    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True), pipe.sync)
+    nb *= calls
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=len(pipe.caps), batches=nb,
                arithmetic="v_pk_fma_f32 (one rounding per tap instead of two; tolerance-tested in tests/test_gpu_fir.py, not the default)",
                roofline=pipe.roofline(), **{"pass": None})
@@ -165,9 +173,11 @@ def anf1(capi, synth, device, args):
     run(12, False)
     nb = batches_for((time.perf_counter() - t0) / 12)
     notch.scan_time(True)                 # HIP events around the k_notch_scan launches (the last 16 are kept)
-    t0 = time.perf_counter()
-    run(nb, True)
-    dt = time.perf_counter() - t0
+    def once():
+        run(nb, True)
+        return nb
+    nb_total, dt, _ = timed_at_least(once, lambda: None)
+    nb = nb_total
     kms, klaunches = notch.scan_time(False)
     for e in pool:
         notch_ms.append(ctx_n.event_elapsed_ms(e[0], e[1])); fir_ms.append(pipe.ctx.event_elapsed_ms(e[2], e[3]))
@@ -220,10 +230,8 @@ def c2_offset(capi, synth, device, args):
     # first track() inside the timed region moves it (dsp.h:236-244)
     pipe.fir.set_freq(float(np.float32(f0 + 1.2 * tol)))
     pipe.reshifts = 0
-    t0 = time.perf_counter()
-    consumed = pipe.run(nb, True, track_tol=tol)
-    pipe.sync()
-    dt = time.perf_counter() - t0
+    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True, track_tol=tol), pipe.sync)
+    nb *= calls
     cp = pipe.caps[0]
     followed = abs(pipe.fir.current_freq - f0) < tol
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), batches=nb, carrier_offset_hz=1.0e6,
@@ -322,8 +330,12 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     omega = float(sps / decim)
     rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=cstln, fec=rate, omega=omega, meas_decimation=1 << 22, pll_adjustment=1 / 6.0)
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0) if use_fir else None
-    d_dec = ctx.alloc((n_out + bench.EXTRA) * 8) if use_fir else None
-    rx = capi.CstlnReceiver(ctx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_CHAIN_TILE", 4 * args.tile_len)),
+    d_decs = [ctx.alloc((n_out + bench.EXTRA) * 8) for _ in range(2)] if use_fir else None
+    d_dec = d_decs[0] if use_fir else None
+    # the receiver has its own stream: fir_filter(k+1) runs while cstln_receiver(k) (queued) works on the other decimated buffer
+    ctx_rx = capi.Ctx(device)
+    ev_fir = [ctx.event() for _ in range(2)]
+    rx = capi.CstlnReceiver(ctx_rx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_CHAIN_TILE", 4 * args.tile_len)),
                             tile_warmup=max(args.tile_warmup, 512), **rx_kw)
     # The FEC tail lives on its own context (stream) and its own host thread: every block of it returns data-dependent counts
     # (a host synchronisation per call), so the only way to keep the front end busy meanwhile is a second thread — the
@@ -344,20 +356,28 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     e0, e1 = ctx.event(), ctx.event()
     fir_ms, ts_out, bits, errs = [], [], [0], [0]
 
-    def front(timed, dst):
-        """fir_filter + receiver of one batch into the staging buffer `dst`; returns the symbol count."""
+    fir_ev = []
+
+    def front_enqueue(timed, dst, k):
+        """fir_filter + (queued) receiver of batch k into the staging buffer `dst`; front_wait() yields the symbol count."""
         if use_fir:
-            ctx.event_record(e0)
-            _, prod = fir.run_dev(d_in.ptr, B + bench.EXTRA * decim + N, d_dec.ptr, n_out + bench.EXTRA)
-            ctx.event_record(e1)
-            src, n_src = d_dec.ptr, prod
+            probe = timed and len(fir_ev) < 64          # HIP events around the first 64 timed filter launches
+            if probe:
+                fir_ev.append((ctx.event(), ctx.event()))
+                ctx.event_record(fir_ev[-1][0])
+            _, prod = fir.run_dev(d_in.ptr, B + bench.EXTRA * decim + N, d_decs[k & 1].ptr, n_out + bench.EXTRA)
+            if probe:
+                ctx.event_record(fir_ev[-1][1])
+            ctx.event_record(ev_fir[k & 1])
+            ctx_rx.wait_event(ev_fir[k & 1])
+            src, n_src = d_decs[k & 1].ptr, prod
         else:
             src, n_src = d_in.ptr, n_out + bench.EXTRA
-        o = rx.run_dev(src, n_src, dst.ptr, sym_cap, meas=False)
-        assert o["consumed"] == n_out, (o["consumed"], n_out)
-        if timed and use_fir:
-            fir_ms.append(ctx.event_elapsed_ms(e0, e1))
-        return o["produced"]
+        used = rx.run_async(src, n_src, dst.ptr, sym_cap)
+        assert used == n_out, (used, n_out)
+
+    def front_wait():
+        return rx.wait()
 
     stage_s = {"front": 0.0, "viterbi": 0.0, "mpeg_sync": 0.0, "rest": 0.0}
 
@@ -436,14 +456,20 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
         th = threading.Thread(target=tail_thread)
         th.start()
         try:
-            for _ in range(n_batches):
+            pending = None
+            for k in range(n_batches):
                 i = free_q.get()
                 if failure:
                     break
                 tf = time.perf_counter()
-                n_sym = front(timed, d_stage[i])
+                front_enqueue(timed, d_stage[i], k)
+                if pending is not None:
+                    n_sym = front_wait()
+                    full_q.put((pending, n_sym))
+                pending = i
                 stage_s["front"] += time.perf_counter() - tf
-                full_q.put((i, n_sym))
+            if pending is not None and not failure:
+                full_q.put((pending, front_wait()))
         finally:
             full_q.put(None)
             th.join()
@@ -455,10 +481,11 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     nb = batches_for((time.perf_counter() - t0) / 4)
     for k in stage_s:
         stage_s[k] = 0.0
-    t0 = time.perf_counter()
-    pipeline(nb, True)
-    ctx.sync(); ctx_t.sync()
-    dt = time.perf_counter() - t0
+    def once():
+        pipeline(nb, True)
+        return nb
+    nb, dt, _ = timed_at_least(once, lambda: (ctx.sync(), ctx_rx.sync(), ctx_t.sync()))
+    fir_ms = [ctx.event_elapsed_ms(a, b) for a, b in fir_ev]
     got = np.concatenate(ts_out) if ts_out else np.zeros((0, 188), np.uint8)
     # every packet must be the next one of the transmitted 8-packet cycle
     ok = bad = 0
@@ -511,21 +538,24 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     vit.close(); msync.close(); derand.close(); rx.close()
     if fir:
         fir.close()
-    ctx_t.close(); ctx.close()
+    if use_fir:
+        d_decs[1].free()
+    ctx_t.close(); ctx_rx.close(); ctx.close()
     return out
 
 
 def c3(capi, synth, device, args):
-    # The FEC tail's cost per batch is mostly latency (a few launch → readback rounds of viterbi_sync, each a fraction of a
-    # millisecond whatever the size, until the tiles fill the chip): batches eight times the headline's keep it off the
-    # critical path.  4 GB of input per batch, resident (64 → 128 → 256 → 512 Mi samples: 51 → 93 → 150 → 190 GS/s).
-    return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, int(os.environ.get("LSDR_C3_BATCH_MSAMPLES", 8 * args.batch_msamples)),
+    # viterbi_sync's tiles are long dependent chains (one wavefront walks thousands of trellis steps): a call costs a tile's
+    # latency however few tiles there are, and next to fir_filter's persistent workgroups its wavefronts get few slots.  Large
+    # batches give a call enough tiles to fill what is left of the chip: 512 Mi samples per batch 227 GS/s, 1 Gi 247, 2 Gi 277,
+    # 4 Gi 307 (32 GB of input per batch, resident; 288 GB of HBM is what makes this the natural batch).
+    return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, int(os.environ.get("LSDR_C3_BATCH_MSAMPLES", 64 * args.batch_msamples)),
                       "QPSK 1/2 @ 120 sps cf32: scaler+fir_filter(313,/30) -> cstln_receiver(tiled) -> viterbi_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                       ["--f32", "--float-scale", "75", "-f", "240e6", "--sr", "2000e3", "--cr", "1/2", "--resample", "--anf", "0", "--viterbi"])
 
 
 def c5_rescoped(capi, synth, device, args):
-    return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, 16,
+    return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, int(os.environ.get("LSDR_C5_BATCH_MSAMPLES", 16)),
                       "8PSK 2/3 @ 4 sps cf32 (30 MS/s symbols = 120 MS/s input): cstln_receiver(PSK8, tiled) -> viterbi_sync(2/3) -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                       ["--f32", "--float-scale", "1", "-f", "120e6", "--sr", "30000e3", "--const", "8PSK", "--cr", "2/3", "--anf", "0", "--viterbi"])
 
@@ -538,9 +568,8 @@ def c1(capi, synth, device, args):
     t0 = time.perf_counter()
     job.run(1)
     steps = batches_for(time.perf_counter() - t0, lo=3)
-    t0 = time.perf_counter()
-    consumed = job.run(steps, timed=True)
-    dt = time.perf_counter() - t0
+    consumed, dt, calls = timed_at_least(lambda: job.run(steps, timed=True), lambda: None)
+    steps *= calls
     kms, klaunch = job.tile_kernel_ms()
     alg = bench_c1.ALG_BYTES_PER_SAMPLE
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), steps=steps, captures=len(job.caps), workers=len(job.workers),
@@ -662,12 +691,8 @@ def c1_hs(capi, synth, device, args, hs=True):
     ts_out.clear()
     for k in stage_s:
         stage_s[k] = 0.0
-    t0 = time.perf_counter()
-    consumed = 0
-    for _ in range(nb):
-        consumed += batch(True)
-    ctx.sync()
-    dt = time.perf_counter() - t0
+    consumed, dt, calls = timed_at_least(lambda: sum(batch(True) for _ in range(nb)), ctx.sync)
+    nb *= calls
     stage_s["rest"] = dt - sum(stage_s.values())
     got = np.concatenate(ts_out) if ts_out else np.zeros((0, 188), np.uint8)
     ok = bad = 0
@@ -834,10 +859,10 @@ def end_to_end(capi, synth, device, args):
         run(6)
         ctx.sync()
         nb = batches_for((time.perf_counter() - t0) / 6)
-        t0 = time.perf_counter()
-        run(nb)
-        ctx.sync()
-        dt = time.perf_counter() - t0
+        def once():
+            run(nb)
+            return nb
+        nb, dt, _ = timed_at_least(once, ctx.sync)
         out[fmt] = dict(value=round(nb * chunk / dt / 1e6, 3), unit="MS/s", bytes_per_sample=item, seconds=round(dt, 3), chunks=nb,
                         roofline={"bound": "pcie", "peak": 63.0, "unit": "GB/s", "achieved": round(nb * chunk * item / dt / 1e9, 2),
                                   "frac": round(nb * chunk * item / dt / 1e9 / 63.0, 4), "hbm_frac": hbm_frac(nb * chunk / dt, item + 4.0 / 120),

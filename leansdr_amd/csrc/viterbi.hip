@@ -120,15 +120,19 @@ constexpr int kVitWaves = 4;
 template <int NUS>
 __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   constexpr bool TWO = NUS == 2;
-  __shared__ vit_tables T;
+  // The generic path walks the trellis tables in its inner loop: they live in LDS (≈ 41 KB per workgroup — three workgroups,
+  // twelve wavefronts per CU).  The fast paths (NUS = 2, 4) only read their lane's constants once, straight from HBM: no LDS,
+  // so the registers alone bound the occupancy (five wavefronts per SIMD) and tiles can be shorter for the same chip fill.
+  __shared__ __attribute__((aligned(16))) char t_raw[NUS == 0 ? sizeof(vit_tables) : 16];
   const int lane = threadIdx.x & 63;
   const unsigned jid = blockIdx.x * kVitWaves + (threadIdx.x >> 6);   // one wavefront = one job; kVitWaves jobs share the LDS tables
-  {   // tables → LDS (≈41 KB)
+  if (NUS == 0) {   // tables → LDS
     const unsigned *src = reinterpret_cast<const unsigned *>(a.T);
-    unsigned *dst = reinterpret_cast<unsigned *>(&T);
+    unsigned *dst = reinterpret_cast<unsigned *>(t_raw);
     for (unsigned i = threadIdx.x; i < sizeof(vit_tables) / 4; i += kVitWaves * 64) dst[i] = src[i];
+    __syncthreads();
   }
-  __syncthreads();
+  const vit_tables &T = NUS == 0 ? *reinterpret_cast<const vit_tables *>(t_raw) : *a.T;
   if (jid >= a.njobs) return;
   const vit_job job = a.jobs[jid];
   const unsigned char *map = a.maps + job.sync * 256;
@@ -191,28 +195,28 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
       // viterbi_dec::update(nm = 1), viterbi.h:202-260
       int best_m = 0x7fffffff, bk = 0;
       if (TWO) {
+        // rate 1/2: 32-symbol paths of one bit each (the 64-bit register's upper half stays 0).  The two predecessors' metrics
+        // come first; the survivor's path is then fetched from the ONE lane that won (three ds_bpermute per step instead of
+        // six; the path exchange is off the metric recurrence's critical chain).
         const int c0 = __shfl(cost, pred0, 64), c1 = __shfl(cost, pred1, 64);
-        const unsigned lo0 = __shfl((unsigned)path, pred0, 64), hi0 = __shfl((unsigned)(path >> 32), pred0, 64);
-        const unsigned lo1 = __shfl((unsigned)path, pred1, 64), hi1 = __shfl((unsigned)(path >> 32), pred1, 64);
         const unsigned k1 = (bl4 >> (8u * (cs1 & 3u))) & 255u;          // branch carrying the received label, 255 = none
         if (k1 != 255u) { best_m = (k1 ? c1 : c0) + cost1; bk = (int)k1; }   // first candidate: always ≤ the initial maximum
         if (c0 <= best_m) { best_m = c0; bk = 0; }
         if (c1 <= best_m) { best_m = c1; bk = 1; }
-        const unsigned long long ps = bk ? ((unsigned long long)hi1 << 32 | lo1) : ((unsigned long long)hi0 << 32 | lo0);
-        path = ((ps << C.nbits) | (bk ? us1 : us0)) & pmask;
+        const unsigned ps = __shfl((unsigned)path, bk ? pred1 : pred0, 64);
+        path = (unsigned long long)((ps << 1) | (bk ? us1 : us0));       // nbits = 1, pathbits = 32
         cost = best_m;
       } else if (NUS == 4) {
-        const unsigned plo = (unsigned)path, phi = (unsigned)(path >> 32);
+        // four predecessors: their metrics first, then the path register of the ONE that won (six ds_bpermute, not twelve)
         const int c0 = __shfl(cost, pred0, 64), c1 = __shfl(cost, pred1, 64), c2 = __shfl(cost, pred2, 64), c3 = __shfl(cost, pred3, 64);
-        const unsigned lo0 = __shfl(plo, pred0, 64), hi0 = __shfl(phi, pred0, 64), lo1 = __shfl(plo, pred1, 64), hi1 = __shfl(phi, pred1, 64);
-        const unsigned lo2 = __shfl(plo, pred2, 64), hi2 = __shfl(phi, pred2, 64), lo3 = __shfl(plo, pred3, 64), hi3 = __shfl(phi, pred3, 64);
         const unsigned k1 = ((cs1 & 4u ? bl4h : bl4) >> (8u * (cs1 & 3u))) & 255u;   // branch carrying the received label, 255 = none
         if (k1 != 255u) { best_m = (k1 == 0 ? c0 : k1 == 1 ? c1 : k1 == 2 ? c2 : c3) + cost1; bk = (int)k1; }
         if (c0 <= best_m) { best_m = c0; bk = 0; }
         if (c1 <= best_m) { best_m = c1; bk = 1; }
         if (c2 <= best_m) { best_m = c2; bk = 2; }
         if (c3 <= best_m) { best_m = c3; bk = 3; }
-        const unsigned slo = bk == 0 ? lo0 : bk == 1 ? lo1 : bk == 2 ? lo2 : lo3, shi = bk == 0 ? hi0 : bk == 1 ? hi1 : bk == 2 ? hi2 : hi3;
+        const int bp = bk == 0 ? pred0 : bk == 1 ? pred1 : bk == 2 ? pred2 : pred3;
+        const unsigned slo = __shfl((unsigned)path, bp, 64), shi = __shfl((unsigned)(path >> 32), bp, 64);
         const unsigned usel = bk == 0 ? us0 : bk == 1 ? us1 : bk == 2 ? us2 : us3;
         path = ((((unsigned long long)shi << 32 | slo) << C.nbits) | usel) & pmask;
         cost = best_m;
@@ -232,34 +236,35 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
         path = ((((unsigned long long)hi << 32 | lo) << C.nbits) | T.us[bk][lane]) & pmask;
         cost = best_m;
       }
-      // output symbol of the best state (lowest index among the minima); skip the search when all agree
-      unsigned sym_out = (unsigned)(path >> out_shift) & us_mask;
-      int best_tpm = 0;
-      bool have_best = false;
+      // output symbol of the best state (lowest index among the minima); skip the search when all agree.  Everything from
+      // here to the store is wave-uniform (scalar registers): sym_u, the bit accumulator, the counters.
+      const unsigned sym_out = (unsigned)(path >> out_shift) & us_mask;
+      unsigned sym_u = 0;
       if (emitting || want_q) {
         const unsigned s0 = (unsigned)__builtin_amdgcn_readfirstlane((int)sym_out);   // lane 0 is active: every lane of a job is
         const bool all_same = __all(sym_out == s0);
+        sym_u = s0;
         if (!all_same || (want_q && b >= discr_delay)) {
-          best_tpm = wave_min(cost);
-          have_best = true;
+          const int best_tpm = wave_min(cost);
           const unsigned long long mask = __ballot(cost == best_tpm);
           const int best_state = __ffsll((long long)mask) - 1;
-          sym_out = (unsigned)__builtin_amdgcn_readlane((int)sym_out, best_state);
+          sym_u = (unsigned)__builtin_amdgcn_readlane((int)sym_out, best_state);
           if (want_q && b >= discr_delay) {
             // second-best in the reference's scan = 2nd smallest with multiplicity (viterbi.h:246-251)
             const int second = __popcll(mask) > 1 ? best_tpm : wave_min(cost == best_tpm ? 0x7fffffff : cost);
             total += second - best_tpm;
           }
-        } else sym_out = s0;
+        }
       }
-      (void)have_best;
       if (emitting && job.emit) {
-        outstream = (outstream << C.bits_in) | sym_out;
+        // a chunk emits 128·bits_in bits = a whole number of 32-bit words, and its output starts 16·bits_in bytes into the
+        // stream: whole aligned words, first decoded bit in the first byte's MSB
+        outstream = (outstream << C.bits_in) | sym_u;
         nout += C.bits_in;
-        while (nout >= 8) {
-          if (lane == 0) *pout = (unsigned char)(outstream >> (nout - 8));
-          ++pout;
-          nout -= 8;
+        if (nout >= 32) {
+          if (lane == 0) *reinterpret_cast<unsigned *>(pout) = __builtin_bswap32((unsigned)(outstream >> (nout - 32)));
+          pout += 4;
+          nout -= 32;
         }
       }
     }
@@ -535,7 +540,8 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   if (P >= 8) { TL = 8; while (TL < 32 && P % (int)(TL * 2) == 0) TL *= 2; }
   {
     static const int forced = getenv("LSDR_VIT_TL") ? atoi(getenv("LSDR_VIT_TL")) : 0;   // tuning hook
-    const size_t want = (size_t)c->num_cu * 4 * 3 / 2;   // 1.5 wavefronts per SIMD keep the chip busy
+    static const int want_x2 = getenv("LSDR_VIT_WANT") ? atoi(getenv("LSDR_VIT_WANT")) : 3;   // tuning hook: wavefronts per SIMD, in halves
+    const size_t want = (size_t)c->num_cu * 4 * (size_t)want_x2 / 2;   // 1.5 wavefronts per SIMD keep the chip busy
     if (forced > 0) TL = (unsigned)forced;
     else while (TL > 1 && TL % 2 == 0 && chunks / TL < want) TL /= 2;
   }
@@ -651,6 +657,11 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
     if (fj.empty()) break;
     v->last_bad += (unsigned)fj.size();
     vt.fixups += (unsigned)fj.size();
+    if (vt.on && round == 0) {       // LSDR_VIT_TIMING: which seams failed (slot, alignment, first chunk, chunks)
+      fprintf(stderr, "viterbi fix-ups (n_main %zu, n_total %zu):", n_main, n_total);
+      for (size_t q = 0; q < fj.size() && q < 12; ++q) fprintf(stderr, " [slot %u sync %d first %llu n %u]", fj[q].slot, fj[q].sync, (unsigned long long)fj[q].first_chunk, fj[q].n_chunks);
+      fprintf(stderr, "\n");
+    }
     rc = vit_launch(v, in, out, fj, stride, false, phase0, nullptr, v->d_end, true, n_total);
     if (rc) return rc;
   }
