@@ -1212,7 +1212,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   if (r->ring_count == lsdr_rx::kRing) { lsdr_set_error("cstln_receiver: too many queued runs (lsdr_rx_wait first)"); return LSDR_E_ARG; }
   const int ra = lsdr_rx_readahead(r);
   // Defaults: a warm-up of ≈ 64 symbols (whole chunks) — the TS-level yield is flat from 32 to 256 symbols of
-  // warm-up down to loss of lock (tools/snr_sweep.py) — and tiles twice as long as the warm-up.
+  // warm-up down to loss of lock (profiles/r02_sensitivity/) — and tiles twice as long as the warm-up.
   unsigned Wc = r->cfg.tile_warmup ? r->cfg.tile_warmup / kChunk : (unsigned)((64.0f * r->omega + kChunk - 1) / kChunk);
   if (!r->cfg.tile_warmup && Wc < 1) Wc = 1;
   unsigned Lc = r->cfg.tile_len ? r->cfg.tile_len / kChunk : 2 * Wc;

@@ -100,6 +100,7 @@ import os
 import subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 APPS = os.path.join(ROOT, "leansdr_amd", "host", "apps")
+RG = os.path.join(ROOT, "leansdr_amd", "host", "ref_graph")
 
 
 @pytest.mark.parametrize("name,args,kw", po.CHAN_CASES)
@@ -116,16 +117,17 @@ def test_leanchansim_amd_is_leanchansim(name, args, kw, buf):
     assert hashlib.sha256(y.tobytes()).digest() == bytes(g[name + "_sha"])
 
 
+@pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "leansdr_amd", "host", "ref_graph", "leandvb")), reason="ref_graph/leandvb not built")
 def test_generator_pipeline_on_gpu():
     """test/leandvb_bench.sh:52-56 with every stage on the GPU: TS → leandvbtx_amd → leanchansim_amd (noise + LO drift) →
-    leandvb_amd returns the transmitted packets."""
+    leandvb (the reference's source on the GPU headers, throughput receiver) returns the transmitted packets."""
     ts = gold("tx.npz")["ts"]
     ts = np.tile(ts, (60, 1))                      # 2400 packets
     ts[:, 3] = (np.arange(len(ts)) & 15) | 0x10    # distinct continuity counters
     ts[:, 4:8] = np.arange(len(ts), dtype=">u4").view(np.uint8).reshape(-1, 4)
     cmd = (f"{APPS}/leandvbtx_amd -f 6/5 --power 37.5 --agc | "
            f"{APPS}/leanchansim_amd --awgn 24 --deterministic -f 2.4e6 --lo 10e9 --ppm 0.0005 --drift-period 0.5 | "
-           f"{APPS}/leandvb_amd --f32 --float-scale 1 -f 2.4e6 --sr 2e6 --anf 0 --tiled")
+           f"LSDR_TILED=1 {RG}/leandvb --f32 --float-scale 1 -f 2.4e6 --sr 2e6 --anf 0 --buf-factor 4096")
     p = subprocess.run(cmd, shell=True, input=ts.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     out = np.frombuffer(p.stdout, np.uint8).reshape(-1, 188)

@@ -1,89 +1,48 @@
-"""The C++ host framework (leansdr_amd/host: scheduler / pipebuf / shim blocks with the
-reference's class surface) driving the HIP kernels through the C ABI, end to end through
-the `leandvb_amd` graph builder, against the reference's golden vectors and the oracle."""
+"""The C++ host framework (leansdr_amd/host: scheduler / pipebuf / shim blocks with the reference's class surface) driving the
+HIP kernels through the C ABI, end to end through the REFERENCE'S OWN graph builder: leansdr_amd/host/ref_graph/leandvb is
+/root/reference/src/apps/leandvb.cc compiled unchanged against this repo's host headers (tests/test_gpu_ref_graph.py checks it
+byte for byte against the reference binary; here the transport stream is checked against the oracle chain, for several pipe
+sizes and for the throughput modes, which the reference's command line has no option for: they come from the environment,
+LSDR_TILED=1).  Symbol-level parity of the same blocks is tests/test_gpu_rx.py / test_gpu_fir.py (goldens of the reference)."""
 import os
 import sys
 import subprocess
 import numpy as np
 import pytest
-from conftest import gold, bits_equal, iq16_to_cf32, ROOT
+from conftest import gold, bits_equal, ROOT
 import pyoracle as po
 
-pytestmark = pytest.mark.gpu
-APP = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
-SOFTSYM = np.dtype([("cost", "<i2"), ("symbol", "u1"), ("pad", "u1")])
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(not os.path.exists(os.path.join(ROOT, "leansdr_amd", "host", "ref_graph", "leandvb")),
+                                 reason="ref_graph binaries not built (no /root/reference on the build machine)")]
+APP = os.path.join(ROOT, "leansdr_amd", "host", "ref_graph", "leandvb")
+C1 = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"]
 
 
-def run_app(args, data):
-    if not os.path.exists(APP):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "leansdr_amd", "host")])
-    p = subprocess.run([APP, "--out-symbols", "--anf", "0"] + args, input=data.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
-    assert p.returncode == 0, p.stderr.decode()
-    return np.frombuffer(p.stdout, SOFTSYM), p.stderr.decode()
-
-
-@pytest.mark.parametrize("buf_factor", [4, 64, 4096])
-def test_f32_linear_golden(buf_factor):
-    g = gold("cstln_receiver.npz")
-    x = iq16_to_cf32(g["iq4"])
-    sym, _ = run_app(["--f32", "--float-scale", "0.009375", "-f", "8e6", "--sr", "2e6", "--sampler", "linear",
-                      "--buf-factor", str(buf_factor)], x)
-    # the scheduler stops when the reader runs dry: everything the reference emits, it emits
-    n = len(g["lin4_cost"])
-    assert len(sym) == n
-    assert bits_equal(sym["cost"], g["lin4_cost"]) and bits_equal(sym["symbol"], g["lin4_symbol"])
-
-
-def test_u8_golden():
-    g = gold("cstln_receiver.npz")
-    sym, _ = run_app(["--u8", "-f", "2400e3", "--sr", "2000e3", "--buf-factor", "16"], g["u8"])
-    assert bits_equal(sym["cost"], g["lin1p2_u8_cost"]) and bits_equal(sym["symbol"], g["lin1p2_u8_symbol"])
-
-
-def test_rrc_sampler_golden():
-    g = gold("cstln_receiver.npz")
-    x = iq16_to_cf32(g["iq4"])
-    sym, _ = run_app(["--f32", "--float-scale", "0.009375", "-f", "8e6", "--sr", "2e6", "--sampler", "rrc", "--viterbi",
-                      "--buf-factor", "64"], x)
-    assert bits_equal(sym["cost"], g["rrc4_cost"]) and bits_equal(sym["symbol"], g["rrc4_symbol"])
-
-
-def test_resample_chain_vs_oracle(oracle):
-    """C2 geometry: scaler(fused) → fir_filter(313 taps, /30) → receiver, host graph vs oracle chain."""
-    g, tab = gold("fir_filter.npz"), gold("tables.npz")
-    x = iq16_to_cf32(g["iq120"])
-    sym, err = run_app(["--f32", "--float-scale", "0.009375", "-f", "240e6", "--sr", "2e6", "--resample", "-v",
-                        "--buf-factor", "64"], x)
-    assert "order 312, decimation 30" in err
-    y, _ = oracle.fir_filter(tab["lowpass_c2"], 30, oracle.scaler(float(g["scale"]), x))
-    ref = oracle.rx(po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=int(8e6 / 5)), y)
-    assert len(sym) == len(ref["sym"]) and len(sym) > 100
-    assert bits_equal(sym["cost"], ref["sym"]["cost"]) and bits_equal(sym["symbol"], ref["sym"]["symbol"])
-
-
-def test_info_lines():
-    g = gold("cstln_receiver.npz")
-    x = iq16_to_cf32(g["iq4"])
-    p = subprocess.run([APP, "--f32", "--float-scale", "0.009375", "-f", "8e6", "--sr", "2e6", "--fd-info", "2", "--cnr",
-                        "--buf-factor", "16"], input=np.tile(x, 50).tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
-    assert p.returncode == 0
-    lines = p.stderr.decode().split("\n")
-    assert any(l.startswith("FREQ ") for l in lines) and any(l.startswith("SS ") for l in lines) and any(l.startswith("MER ") for l in lines)
-
-
-def run_ts(args, data):
-    p = subprocess.run([APP] + args, input=data.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180)
+def run_ts(args, data, tiled=False):
+    env = dict(os.environ, LSDR_TILED="1") if tiled else None
+    p = subprocess.run([APP] + args, input=data.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=180, env=env)
     assert p.returncode == 0, p.stderr.decode()
     return np.frombuffer(p.stdout, np.uint8).reshape(-1, 188), p.stderr.decode()
 
 
+def after_acquisition(ts, want, skip=16):
+    """Every packet of `want` after its first `skip` is in `ts`, byte for byte and in order (lock instants may differ by a few
+    packets between the exact and the throughput receivers)."""
+    got = [bytes(t) for t in ts]
+    tail = [bytes(t) for t in want[skip:]]
+    assert tail and tail[0] in got
+    i0 = got.index(tail[0])
+    return got[i0:i0 + len(tail)] == tail
+
+
 @pytest.mark.parametrize("buf_factor", [4, 64, 4096])
 def test_full_chain_ts_vs_oracle(oracle, buf_factor):
-    """u8 capture → TS packets through the whole GPU graph == oracle front end + FEC tail
-    (which tests/test_oracle_fec.py pins to the real `leandvb` binary, default algebraic deconvolution)."""
+    """u8 capture → TS packets through the whole GPU graph == oracle front end + FEC tail (which tests/test_oracle_fec.py pins
+    to the real `leandvb` binary, default algebraic deconvolution), for the reference's pipe sizes and for GPU-sized ones."""
     from leansdr_amd import synth_dvbs
     iq, ts_in = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=3)
-    ts, err = run_ts(["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--buf-factor", str(buf_factor), "--fd-info", "2"], iq)
+    ts, err = run_ts(C1 + ["--buf-factor", str(buf_factor), "--fd-info", "2"], iq)
     # default --anf 1 like leandvb: a bit-exact pass-through here (no detect within 4 Mi samples) that only
     # withholds the last partial 4096-sample block
     x = oracle.cconverter_u8(iq)
@@ -92,7 +51,6 @@ def test_full_chain_ts_vs_oracle(oracle, buf_factor):
     want = oracle.fec_chain(oracle.rx(p, x)["sym"], 1, 0, 0)[0]
     assert len(want) > 60
     assert bits_equal(ts, want)
-    # and the payload is what was transmitted
     sent = {bytes(t) for t in ts_in}
     assert sum(bytes(t) in sent for t in ts) >= len(ts) - 10   # a few packets around acquisition are false locks, as in the reference
     assert "LOCK 1" in err
@@ -104,8 +62,7 @@ def test_full_chain_viterbi_ts_vs_oracle(oracle, buf_factor):
     == the oracle chain that tests/test_oracle_fec.py pins to `leandvb --viterbi`."""
     from leansdr_amd import synth_dvbs
     iq, ts_in = synth_dvbs.capture_u8(n_packets=300, sps_num=6, sps_den=5, seed=4)
-    ts, _ = run_ts(["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--viterbi", "--anf", "0",
-                    "--buf-factor", str(buf_factor)], iq)
+    ts, _ = run_ts(C1 + ["--viterbi", "--anf", "0", "--buf-factor", str(buf_factor)], iq)
     x = oracle.cconverter_u8(iq)
     p = po.rx_params(sampler=1, cstln=1, omega=float(np.float32(2400e3 / 2000e3)), meas_decimation=int(2400e3 / 5),
                      pll_adjustment=1 / 6.0)
@@ -120,7 +77,7 @@ def test_full_chain_viterbi_noisy_is_exact(oracle):
     verified fix-up rounds); the TS output must still be bit-identical to the oracle chain."""
     from leansdr_amd import synth_dvbs
     iq, _ = synth_dvbs.capture_u8(n_packets=300, sps_num=6, sps_den=5, seed=9, noise_std=25.0)
-    ts, _ = run_ts(["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--viterbi", "--anf", "0"], iq)
+    ts, _ = run_ts(C1 + ["--viterbi", "--anf", "0"], iq)
     x = oracle.cconverter_u8(iq)
     p = po.rx_params(sampler=1, cstln=1, omega=float(np.float32(2400e3 / 2000e3)), meas_decimation=int(2400e3 / 5),
                      pll_adjustment=1 / 6.0)
@@ -130,38 +87,27 @@ def test_full_chain_viterbi_noisy_is_exact(oracle):
 
 @pytest.mark.parametrize("viterbi", [0, 1])
 def test_tiled_receiver_ts_matches_exact_chain(oracle, viterbi):
-    """--tiled (the throughput receiver, not bit-exact at the soft-symbol level) must deliver the same transport
-    stream as the exact chain once locked: every packet the oracle chain outputs after acquisition is in the tiled
-    output, byte for byte and in order."""
+    """LSDR_TILED=1 (the throughput receiver, not bit-exact at the soft-symbol level) must deliver the same transport
+    stream as the exact chain once locked."""
     from leansdr_amd import synth_dvbs
     iq, ts_in = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=5)
-    flags = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0", "--tiled"] + (["--viterbi"] if viterbi else [])
-    ts, _ = run_ts(flags, iq)
+    ts, _ = run_ts(C1 + ["--anf", "0", "--buf-factor", "4096"] + (["--viterbi"] if viterbi else []), iq, tiled=True)
     x = oracle.cconverter_u8(iq)
     p = po.rx_params(sampler=1, cstln=1, omega=float(np.float32(2400e3 / 2000e3)), meas_decimation=int(2400e3 / 5),
                      pll_adjustment=1 / 6.0 if viterbi else 1.0)
     want = oracle.fec_chain(oracle.rx(p, x)["sym"], 1, 0, viterbi)[0]
-    assert len(want) > 900
-    got = [bytes(t) for t in ts]
-    tail = [bytes(t) for t in want[16:]]          # skip acquisition (lock instants may differ by a few packets)
-    assert tail[0] in got
-    i0 = got.index(tail[0])
-    assert got[i0:i0 + len(tail)] == tail
+    assert len(want) > 900 and after_acquisition(ts, want)
 
 
 def test_tiled_rrc_sampler_ts_matches_exact_chain():
-    """--sampler rrc --tiled: the transport stream of the exact chain with the same sampler, once locked."""
+    """--sampler rrc in the throughput mode: the transport stream of the exact chain with the same sampler, once locked."""
     from leansdr_amd import synth_dvbs
     iq, _ = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=5)
-    flags = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0", "--sampler", "rrc"]
+    flags = C1 + ["--anf", "0", "--sampler", "rrc", "--buf-factor", "4096"]
     want, _ = run_ts(flags, iq)
-    ts, _ = run_ts(flags + ["--tiled"], iq)
+    ts, _ = run_ts(flags, iq, tiled=True)
     assert len(want) > 300          # (the matched filter's 1/S gain makes the AGC — hence the lock — slow: SURVEY A5)
-    got = [bytes(t) for t in ts]
-    tail = [bytes(t) for t in want[len(want) // 2:]]
-    assert tail[0] in got
-    i0 = got.index(tail[0])
-    assert got[i0:i0 + len(tail)] == tail
+    assert after_acquisition(ts, want, skip=len(want) // 2)
 
 
 @pytest.mark.parametrize("extra", [[], ["--viterbi"]])
@@ -171,7 +117,7 @@ def test_full_chain_fastlock(oracle, extra):
     after acquisition is one of the transmitted packets, and at least as many come out as from the oracle chain."""
     from leansdr_amd import synth_dvbs
     iq, ts_in = synth_dvbs.capture_u8(n_packets=600, sps_num=6, sps_den=5, seed=6)
-    ts, _ = run_ts(["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0", "--fastlock", "--buf-factor", "4"] + extra, iq)
+    ts, _ = run_ts(C1 + ["--anf", "0", "--fastlock", "--buf-factor", "4"] + extra, iq)
     x = oracle.cconverter_u8(iq)
     vit = 1 if extra else 0
     p = po.rx_params(sampler=1, cstln=1, omega=float(np.float32(2400e3 / 2000e3)), meas_decimation=int(2400e3 / 5),
@@ -180,74 +126,23 @@ def test_full_chain_fastlock(oracle, extra):
     sent = {bytes(t) for t in ts_in}
     good = sum(bytes(t) in sent for t in ts)
     assert good >= len(ts) - 10 and len(ts) >= len(want) - 8 and len(ts) > 500
-    if bits_equal(ts, want):
-        return   # same call pattern as the reference's pipes: identical stream
 
 
 @pytest.mark.parametrize("extra,key", [([], "ts"), (["--fastlock"], "ts_fastlock")])
 @pytest.mark.parametrize("buf_factor", [4, 64, 4096])
 def test_hs_app_equals_leandvb_hs(extra, key, buf_factor):
-    """leandvb_amd --hs (host framework + fast_qpsk_receiver / dvb_deconvol_sync / mpeg_sync(fastlock) / … on the GPU) ==
-    the TS the real `leandvb --hs` wrote for the same capture (tests/golden/hs.npz), for any pipe size."""
+    """leandvb --hs on the GPU headers (fast_qpsk_receiver / dvb_deconvol_sync / mpeg_sync(fastlock) / …) == the TS the real
+    `leandvb --hs` wrote for the same capture (tests/golden/hs.npz), for any pipe size."""
     g = gold("hs.npz")
-    ts, err = run_ts(["--u8", "--hs", "-f", "2400e3", "--sr", "2000e3", "--buf-factor", str(buf_factor), "--fd-info", "2"] + extra,
-                     g["iq"])
+    ts, err = run_ts(["--u8", "--hs", "-f", "2400e3", "--sr", "2000e3", "--buf-factor", str(buf_factor), "--fd-info", "2"] + extra, g["iq"])
     assert bits_equal(ts, g[key]) and len(ts) > 20
     assert "LOCK 1" in err   # (no VBER line: the window is max(Fm/2, 50000) bits like the reference's, longer than this capture)
 
 
 def test_hs_tiled_app_ts_matches_exact_chain(oracle):
-    """leandvb_amd --hs --tiled: same transport stream as the exact --hs chain once locked."""
+    """--hs in the throughput mode: same transport stream as the exact --hs chain once locked."""
     from leansdr_amd import synth_dvbs
     iq, ts_in = synth_dvbs.capture_u8(n_packets=1000, sps_num=6, sps_den=5, seed=5)
-    ts, _ = run_ts(["--u8", "--hs", "-f", "2400e3", "--sr", "2000e3", "--tiled"], iq)
+    ts, _ = run_ts(["--u8", "--hs", "-f", "2400e3", "--sr", "2000e3", "--buf-factor", "4096"], iq, tiled=True)
     want = oracle.hs_chain(iq, float(np.float32(2400e3 / 2000e3)))
-    assert len(want) > 900
-    got = [bytes(t) for t in ts]
-    tail = [bytes(t) for t in want[16:]]
-    assert tail[0] in got
-    i0 = got.index(tail[0])
-    assert got[i0:i0 + len(tail)] == tail
-
-
-def test_derotate_and_fd_const(oracle):
-    """--derotate (rotator<f32> in front of the receiver) and --fd-const (CONST line + SYMBOLS batches of 128 sampled
-    points): symbols == oracle rotator → receiver; the SYMBOLS lines carry the receiver's constellation output."""
-    g = gold("cstln_receiver.npz")
-    x = oracle.scaler(float(g["scale"]), iq16_to_cf32(g["iq4"]))
-    p = subprocess.run([APP, "--out-symbols", "--anf", "0", "--f32", "--float-scale", str(float(g["scale"])), "-f", "8e6", "--sr", "2e6",
-                        "--derotate", "16000", "--fd-const", "2"], input=iq16_to_cf32(g["iq4"]).tobytes(), stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=120)
-    assert p.returncode == 0, p.stderr.decode()
-    sym = np.frombuffer(p.stdout, SOFTSYM)
-    xr = oracle.rotator(x, float(np.float32(-16000.0) / np.float32(8e6)))
-    want = oracle.rx(po.rx_params(sampler=1, cstln=1, omega=4.0, meas_decimation=int(8e6 / 5)), xr)
-    assert bits_equal(sym["cost"], want["sym"]["cost"]) and bits_equal(sym["symbol"], want["sym"]["symbol"])
-    lines = p.stderr.decode().split("\n")
-    assert lines[0] == "CONST 4 53,53 53,-53 -53,53 -53,-53"
-    batches = [l for l in lines if l.startswith("SYMBOLS 128 ")]
-    assert len(batches) == len(want["cstln"]) // 128
-    first = [tuple(int(v) for v in t.split(",")) for t in batches[0].split()[2:]]
-    ref_pts = [(int(float("%.0f" % c.real)), int(float("%.0f" % c.imag))) for c in want["cstln"][:128]]
-    assert first == ref_pts
-
-
-# ---- the reference's own system test, test/leandvb_bench.sh, with every stage on the GPU ----------------------------
-BENCH_CASES = [("sps12", "6/5", 18, "", 700), ("sps4_viterbi_rrc", "4", 5.5, "--viterbi --sampler rrc", 500),
-               ("sps12_hs", "6/5", 15, "--u8 --hs", 700)]
-
-
-@pytest.mark.parametrize("name,ratio,snr,flags,npk", BENCH_CASES)
-def test_leandvb_bench_pipeline_is_the_reference(name, ratio, snr, flags, npk):
-    """TS counter pattern | leandvbtx_amd | leanchansim_amd --deterministic > file; leandvb_amd --fd-info 2 < file:
-    the report text (LOCK / FREQ / SS / MER / LOCKTIME / VBER lines, their order and values) and the TS are those of the
-    reference binaries (tests/golden/bench_sh.npz).  --buf-factor 4 gives the receiver the reference's pipe sizes: the
-    report cadence (not the decoded stream) depends on them."""
-    import hashlib
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import leandvb_bench as lb
-    lb.RX_EXTRA = "--buf-factor 4"
-    g = gold("bench_sh.npz")
-    text, ts = lb.run_pipeline(ratio, snr, flags, npk)
-    assert len(ts) // 188 == int(g[name + "_ts_n"]) and hashlib.sha256(ts).digest() == bytes(g[name + "_ts_sha"])
-    assert text == bytes(g[name + "_info"]).decode()
+    assert len(want) > 900 and after_acquisition(ts, want)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/chain_bench.py — end-to-end leandvb_amd (host framework + all GPU blocks) on a synthetic DVB-S capture.
+"""tools/chain_bench.py — end-to-end leandvb (the reference's source on this repo's host framework + all GPU blocks) on a synthetic DVB-S capture.
 Writes the capture to /tmp, runs the app (optionally under rocprofv3), reports MS/s and checks the TS payload."""
 import os, subprocess, sys, time
 import numpy as np
@@ -28,7 +28,7 @@ if repeat > 1:
                 f.write(data)
     path = rpath
 n = os.path.getsize(path) // 2
-which = "own"
+which = "--ref-graph"      # default: the reference's leandvb.cc on this repo's headers (GPU blocks)
 for w in ("--ref-graph", "--ref-cpu"):      # the reference's leandvb.cc on this repo's headers (GPU blocks) / the reference's CPU binary
     if w in flags:
         flags.remove(w); which = w
@@ -41,8 +41,6 @@ if which == "--ref-graph":
 elif which == "--ref-cpu":
     app = os.path.join(ROOT, "oracle", "_ref", "leandvb")
     flags = [f for f in flags if f != "--tiled"]
-else:
-    app = os.path.join(ROOT, "leansdr_amd", "host", "apps", "leandvb_amd")
 cmd = [app, "--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"] + flags
 t0 = time.perf_counter()
 with open(path, "rb") as f:

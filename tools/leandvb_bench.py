@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/leandvb_bench.py — the sensitivity benchmark of the reference (test/leandvb_bench.sh) with every stage on the GPU:
     TS counter pattern | leandvbtx_amd -f RATIO --power P --agc | leanchansim_amd --awgn N --deterministic [--ou8]
-                       | leandvb_amd --f32 --float-scale S -f FS --sr 1e6 --anf 0 --fd-info 2 FLAGS
+                       | ref_graph/leandvb --f32 --float-scale S -f FS --sr 1e6 --anf 0 --fd-info 2 FLAGS
 It parses the LOCK / VBER / CNR / SS / MER / LOCKTIME lines the same way (min/max VBER from the last lock until LOCKTIME
 reaches MINPACKETS) and prints one row per SNR: ratio rxsnr cnr ss mer vbermin vbermax.
     python tools/leandvb_bench.py [--ref] [--packets N] [--min-packets M] [series ...]
@@ -23,7 +23,7 @@ SERIES = {   # name: (ratio, SNRs, receiver flags) — test/leandvb_bench.sh:119
 }
 
 
-RX_EXTRA = ""   # extra leandvb_amd options (--rx-extra "--buf-factor 4": the reference's pipe sizes, hence its report cadence)
+RX_EXTRA = ""   # extra leandvb options (--rx-extra "--buf-factor 4": the reference's pipe sizes, hence its report cadence)
 
 
 def commands(ratio, snr, flags, ref=False):
@@ -46,8 +46,8 @@ def commands(ratio, snr, flags, ref=False):
         d = os.path.join(ROOT, "oracle", "_ref")
         tx, ch, rx = f"{d}/leandvbtx", f"{d}/leanchansim", f"{d}/leandvb"
     else:
-        d = os.path.join(ROOT, "leansdr_amd", "host", "apps")
-        tx, ch, rx = f"{d}/leandvbtx_amd", f"{d}/leanchansim_amd", f"{d}/leandvb_amd"
+        d = os.path.join(ROOT, "leansdr_amd", "host", "apps")      # this repo's own generator-side builders; the receiver is always the
+        tx, ch, rx = f"{d}/leandvbtx_amd", f"{d}/leanchansim_amd", os.path.join(ROOT, "leansdr_amd", "host", "ref_graph", "leandvb")   # reference's source
     cnr = "--cnr" if samprate > 3 * symbrate else ""
     c_tx = f"{tx} -f {ratio} --power {sigpow:g} --agc"
     c_ch = f"{ch} --awgn {noisepow:g} --deterministic {'--ou8' if hs else ''}"
