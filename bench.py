@@ -430,9 +430,9 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c1"], default="c2",
                     help="c2: BASELINE config 2 (the headline: cf32 at 120 sps, fir_filter + receiver); c1: BASELINE config 1 / 4 — independent "
                          "cu8 captures at 1.2 sps decoded to TS (bench_c1.py); with --gpus N that is config 4 (captures sharded over the GPUs)")
-    ap.add_argument("--c1-captures", type=int, default=8, help="c1: independent captures resident per GPU (each decoded once per step)")
+    ap.add_argument("--c1-captures", type=int, default=16, help="c1: independent captures resident per GPU (each decoded once per step)")
     ap.add_argument("--c1-msamples", type=int, default=128, help="c1: Mi samples per capture")
-    ap.add_argument("--c1-workers", type=int, default=8, help="c1: host threads / HIP streams decoding captures concurrently per GPU")
+    ap.add_argument("--c1-workers", type=int, default=16, help="c1: host threads / HIP streams decoding captures concurrently per GPU")
     ap.add_argument("--c1-tile", type=int, default=2048)
     ap.add_argument("--c1-warmup", type=int, default=512)
     args = ap.parse_args()

@@ -36,6 +36,16 @@ ALG_BYTES_PER_SAMPLE = 2.0 + 188.0 / (204 * 8 * 1.2)       # cu8 
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "leandvb")
 REF_ARGS = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0"]
 SKIP_ACQ = 16            # packets of the reference's output skipped before the comparison (lock instants may differ by a few packets)
+GOLDEN = os.path.join(ROOT, "tests", "golden", "c1_ts.json")   # recorded on an MI355X box with the reference binary next to it
+
+
+def recorded_hashes():
+    try:
+        import json
+        with open(GOLDEN) as f:
+            return {(e["samples"], e["seed"], e["first_packet"]): e for e in json.load(f)["captures"]}
+    except (OSError, ValueError, KeyError):
+        return {}
 
 
 def ts_packets(n, start=0):
@@ -267,6 +277,7 @@ class C1Job:
     def verify(self, max_ref_workers=None):
         """Every capture: this path's TS of the last decode against the reference binary's TS for the same IQ."""
         out = dict(captures=len(self.caps), checker=None, per_capture=[])
+        rec = recorded_hashes()
         have_ref = os.path.exists(REFBIN) and os.access(REFBIN, os.X_OK)
         t0 = time.perf_counter()
         refs = [None] * len(self.caps)
@@ -274,27 +285,39 @@ class C1Job:
             out["checker"] = "oracle/_ref/leandvb " + " ".join(REF_ARGS) + " (the reference binary, one process per capture on the host cores)"
             tmp = tempfile.mkdtemp(prefix="lsdr_c1_")
             procs = []
+            self.iq_sha = {}
             for k in range(len(self.caps)):
                 f = os.path.join(tmp, f"cap{k}.u8")
-                self.iq_of(k).tofile(f)
+                iq = self.iq_of(k)
+                self.iq_sha[k] = hashlib.sha256(iq.tobytes()).hexdigest()
+                iq.tofile(f)
+                del iq
                 procs.append((k, f, subprocess.Popen([REFBIN] + REF_ARGS, stdin=open(f, "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)))
             for k, f, p in procs:
                 refs[k] = p.communicate()[0]
                 os.unlink(f)
             os.rmdir(tmp)
         else:
-            out["checker"] = "transmitted packet sequence (oracle/_ref/leandvb not present on this machine)"
+            out["checker"] = ("tests/golden/c1_ts.json (TS hashes recorded where the reference binary decoded the same IQ), else the transmitted packet "
+                              "sequence (oracle/_ref/leandvb not present on this machine)")
         ok_all = True
         for k in range(len(self.caps)):
             got = self.ts_of(k)
             pk = [got[i:i + 188] for i in range(0, len(got), 188)]
-            rep = dict(capture=k, seed=self.seeds[k], ts_packets=len(pk), sha256=hashlib.sha256(got).hexdigest()[:16],
-                       same_count_every_step=bool(len(set(self.counts[k])) <= 1))
+            rep = dict(capture=k, seed=self.seeds[k], first_packet=self.first_pk[k], samples=self.n, ts_packets=len(pk),
+                       ts_sha256=hashlib.sha256(got).hexdigest(), same_count_every_step=bool(len(set(self.counts[k])) <= 1))
+            r0 = rec.get((self.n, self.seeds[k], self.first_pk[k]))
+            if r0:      # this capture was decoded by the reference binary when tests/golden/c1_ts.json was recorded
+                rep["recorded"] = dict(ts_sha256_equal=bool(r0["ts_sha256"] == rep["ts_sha256"]), ref_ts_sha256=r0["ref_ts_sha256"][:16],
+                                       was_equal_to_reference_after_acquisition=bool(r0["equal_to_reference_after_acquisition"]))
             if refs[k] is not None:
                 ref = refs[k]
                 rpk = [ref[i:i + 188] for i in range(0, len(ref), 188)]
                 tail = rpk[SKIP_ACQ:]
                 rep["ref_packets"] = len(rpk)
+                rep["ref_ts_sha256"] = hashlib.sha256(ref).hexdigest()
+                rep["iq_sha256"] = self.iq_sha.get(k)
+                rep["whole_ts_identical"] = bool(ref == got)
                 ok = len(tail) > 100 and tail[0] in pk
                 if ok:
                     i0 = pk.index(tail[0])
@@ -303,6 +326,9 @@ class C1Job:
                     ok = pk[i0:i0 + m] == tail[:m] and len(tail) - m <= 16
                     rep["compared"] = m; rep["ref_tail_not_reached"] = len(tail) - m
                 rep["equal_to_reference_after_acquisition"] = bool(ok)
+            elif r0:
+                ok = rep["recorded"]["ts_sha256_equal"] and rep["recorded"]["was_equal_to_reference_after_acquisition"]
+                rep["equal_to_recorded_reference_checked_ts"] = bool(ok)
             else:
                 sent = self.ts_sent
                 first = [i for i in range(max(0, self.first_pk[k] - 64), min(len(sent), self.first_pk[k] + 4096)) if bytes(sent[i]) == pk[SKIP_ACQ]] if len(pk) > SKIP_ACQ else []

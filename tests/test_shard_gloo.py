@@ -57,6 +57,26 @@ def test_bench_self_launches_ranks():
     assert j["n_gpus"] == 2 and j["ranks"] == 2 and j["units"] == 3000.0 and j["seconds"] == 2.0
 
 
+def test_bench_c1_workload_self_launches_ranks():
+    """BASELINE config 4's launch path: `python bench.py --workload c1 --gpus 2` (one rank per GPU, every rank its own captures,
+    gloo for the barrier and the totals) — plumbing only (--dry-run), on CPU."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c1", "--gpus", "2", "--dry-run"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=280)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    assert j["workload"] == "c1" and j["n_gpus"] == 2 and j["ranks"] == 2 and j["units"] == 3000.0
+
+
+def test_c1_job_gives_every_rank_its_own_captures():
+    """bench_c1.run_workload seeds rank r's captures with 1000·(r+1)+k: no two captures of a job share a noise seed."""
+    src = open(os.path.join(ROOT, "bench_c1.py")).read()
+    assert "seed0=1000 * (rank + 1)" in src and "seed0 + k" in src
+
+
 def test_bench_rejects_mismatched_launcher():
     """--gpus must equal the number of ranks the launcher started (n_gpus stays honest)."""
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
