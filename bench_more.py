@@ -555,7 +555,7 @@ def c3(capi, synth, device, args):
 
 
 def c5_rescoped(capi, synth, device, args):
-    return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, int(os.environ.get("LSDR_C5_BATCH_MSAMPLES", 16)),
+    return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, int(os.environ.get("LSDR_C5_BATCH_MSAMPLES", 64)),
                       "8PSK 2/3 @ 4 sps cf32 (30 MS/s symbols = 120 MS/s input): cstln_receiver(PSK8, tiled) -> viterbi_sync(2/3) -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                       ["--f32", "--float-scale", "1", "-f", "120e6", "--sr", "30000e3", "--const", "8PSK", "--cr", "2/3", "--anf", "0", "--viterbi"])
 

@@ -48,6 +48,32 @@ try:
 except Exception as e:
     print("pmc summary failed:", e)
 PY
+# ---- BASELINE config 1 / 4 (bench.py --workload c1): its own line, kernel statistics, HBM-side traffic of the whole chain
+timeout 900 python bench.py --workload c1 --steps 20 --warmup 2 > "$OUT/c1.json" 2> "$OUT/c1.err"
+cd /tmp; rm -rf /tmp/prof_c1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c1 -- python "$REPO/bench.py" --workload c1 --steps 5 --warmup 1 --no-cpu --no-verify > /tmp/prof_c1.log 2>&1
+f=$(find /tmp/prof_c1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/c1_kernel_stats.csv"
+cd "$REPO"
+timeout 900 python tools/pmc_traffic.py "$OUT/c1_pmc_traffic.json" -- python "$REPO/bench.py" --workload c1 --steps 1 --warmup 1 --no-cpu --no-verify --c1-captures 2 --c1-workers 1 > "$OUT/c1_pmc_traffic.txt" 2>&1
+# ---- effective shader clock of fir_filter launches (GRBM_GUI_ACTIVE / duration: MI355X_MICROARCH.md "DVFS give-back"): a lone launch,
+#      a burst of 20 after idle, 400 and 4000 back to back
+cd /tmp; rm -rf /tmp/prof_clk
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d /tmp/prof_clk -- env FIR_ALONE_REPS=1,20,400,20 python "$REPO/tools/fir_alone.py" > "$OUT/fir_alone_pmc.log" 2>&1
+f=$(find /tmp/prof_clk -name "*counter_collection.csv" | head -1)
+[ -n "$f" ] && python - "$f" > "$OUT/fir_clock.txt" <<'PY'
+import csv, sys, statistics
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_fir" in r["Kernel_Name"] and r["Counter_Name"] == "GRBM_GUI_ACTIVE"]
+d = [(float(r["Counter_Value"]) / 8 / ((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3) for r in rows]
+print("# fir_filter (k_fir_persist, 64 Mi samples per launch) under rocprofv3 --pmc GRBM_GUI_ACTIVE: effective clock = counter / 8 XCDs / duration")
+print("# launch  clock_MHz  duration_us")
+for i, (c, t) in enumerate(d):
+    if i < 30 or i % 20 == 0:
+        print(f"{i:6d} {c:9.0f} {t:10.1f}")
+print(f"# median clock {statistics.median(c for c, _ in d):.0f} MHz, median duration {statistics.median(t for _, t in d):.1f} us over {len(d)} launches")
+PY
+cd "$REPO"
+env FIR_ALONE_REPS=1,20,400,4000,20 python tools/fir_alone.py > "$OUT/fir_alone.txt" 2>&1
+timeout 900 python tools/rx_tol_report.py > "$OUT/rx_tol_report.jsonl" 2>&1
 bash tools/timeline.sh --no-more --no-verify --batches-per-step 8 > "$OUT/timeline.log" 2>&1
 cp gpurun_out/timeline.csv "$OUT/timeline.csv"; python tools/overlap.py "$OUT/timeline.csv" > "$OUT/overlap.txt" 2>&1; cat "$OUT/overlap.txt"
 ls -la "$OUT"
