@@ -109,6 +109,22 @@ __device__ __forceinline__ int wave_min(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// AND / OR over the 64 lanes (same DPP ladder as wave_min), returned wave-uniform
+__device__ __forceinline__ void wave_and_or(unsigned v, unsigned &all_and, unsigned &all_or) {
+  unsigned a = v, o = v;
+#define LSDR_DPP_AO(ctrl, row_mask) { const unsigned xa__ = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)a, ctrl, row_mask, 0xf, false); \
+                                       const unsigned xo__ = (unsigned)__builtin_amdgcn_update_dpp((int)o, (int)o, ctrl, row_mask, 0xf, false); a &= xa__; o |= xo__; }
+  LSDR_DPP_AO(0xB1, 0xf)
+  LSDR_DPP_AO(0x4E, 0xf)
+  LSDR_DPP_AO(0x141, 0xf)
+  LSDR_DPP_AO(0x140, 0xf)
+  LSDR_DPP_AO(0x142, 0xa)
+  LSDR_DPP_AO(0x143, 0xc)
+#undef LSDR_DPP_AO
+  all_and = (unsigned)__builtin_amdgcn_readlane((int)a, 63);
+  all_or = (unsigned)__builtin_amdgcn_readlane((int)o, 63);
+}
+
 constexpr int kVitWaves = 4;
 // One wavefront = one job.  Lane = trellis state.
 // TWO = the code has two branches per state (rate 1/2: the headline mode): the lane's two predecessors, their input bits and
@@ -189,6 +205,7 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
       }
       my_cs[h] = cs; my_cost[h] = cst;
     }
+    bool bulk = false;     // TWO: the outputs of the current group of 16 steps have been emitted at its first step
     for (int b = 0; b < kChunkBlocks; ++b) {
       const unsigned cs1 = (unsigned)__builtin_amdgcn_readlane((int)(b < 64 ? my_cs[0] : my_cs[1]), b & 63);
       const int cost1 = __builtin_amdgcn_readlane(b < 64 ? my_cost[0] : my_cost[1], b & 63);
@@ -238,6 +255,28 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
       }
       // output symbol of the best state (lowest index among the minima); skip the search when all agree.  Everything from
       // here to the store is wave-uniform (scalar registers): sym_u, the bit accumulator, the counters.
+      if (TWO && !want_q) {
+        // Rate 1/2, no quality wanted on this chunk: the symbol the reference returns at step t+j is bit 31 of the best path
+        // at t+j, i.e. the decision of step t+j−31 — bit 31−j of the time-t path of that survivor's ancestor.  Where ALL 64
+        // survivors of time t agree on bits 31…16, the outputs of steps t … t+15 are those bits whichever state is best then:
+        // one AND/OR reduction per 16 steps instead of an agreement test (and a possible best-state search) per step.
+        if (!(emitting && job.emit)) continue;            // nothing leaves this job on this chunk
+        if ((b & 15) == 0) {
+          unsigned all_and, all_or;
+          wave_and_or((unsigned)path, all_and, all_or);
+          bulk = ((all_and ^ all_or) >> 16) == 0u;
+          if (bulk) {
+            outstream = (outstream << 16) | (all_and >> 16);
+            nout += 16;
+            if (nout >= 32) {
+              if (lane == 0) *reinterpret_cast<unsigned *>(pout) = __builtin_bswap32((unsigned)(outstream >> (nout - 32)));
+              pout += 4;
+              nout -= 32;
+            }
+          }
+        }
+        if (bulk) continue;
+      }
       const unsigned sym_out = (unsigned)(path >> out_shift) & us_mask;
       unsigned sym_u = 0;
       if (emitting || want_q) {
