@@ -92,6 +92,7 @@ struct vit_args {
   int *totals;                       // [njobs][n_chunks_max] totaldiscr per chunk (valid on resync chunks)
   unsigned totals_stride;
   vit_state *chunk_states;           // optional [njobs][totals_stride]: state after every chunk (sparse decoders)
+  unsigned q4_n_main, q4_main_waves; // k_viterbi_q4: jobs [0, q4_n_main) fill the first q4_main_waves wavefronts, the rest the others
 };
 
 // Minimum over the 64 lanes, returned wave-uniform: DPP steps inside the rows of 16 (quad swaps, half mirror, mirror), two
@@ -323,6 +324,241 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   a.end_states[job.slot].path[lane] = path;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Rate 1/2 (K = 7, 171/133), QPSK: FOUR lanes per tile, sixteen tiles per wavefront.
+//
+// Lane q of a quad holds the sixteen states 16q … 16q+15 of its tile in registers (metric + 32-bit path each).  State
+// s' = 16q + r is entered from 2(s' & 31) and 2(s' & 31) + 1 with input bit s' >> 5 (viterbi.h:59-92): registers 2(r & 7)
+// and 2(r & 7) + 1 of lane 2(q & 1) + (r >> 3) of the same quad — two fixed quad permutes (DPP operands of the adds and
+// selects: no LDS, no shuffle latency), register indices known at compile time.  One wavefront instruction advances sixteen
+// tiles, where the lane = state kernel above advances one and waits for two LDS round trips per step.
+//
+// Same arithmetic as viterbi_dec::update (viterbi.h:202-260), restated so that it needs no branch per state:
+//   * candidates in the reference's order are [labelled branch + cost, branch 0, branch 1] with `<=` (the last one wins a
+//     tie); branches are ordered by coded symbol.  The labelled branch reappears with cost 0, so a POSITIVE cost can never
+//     win: cost' = min(cost, 0) gives the same survivor and metric.  With cost' < 0 the plain copy of the labelled branch
+//     never wins either, and on a tie between (labelled + cost') and the other branch the other one is taken (it comes
+//     later); with cost' = 0 or no labelled branch into the state, branch 1 wins a tie.
+//   * metrics are kept × 16.  The four low bits carry the tie rule: +1 on the branch with the lower coded symbol, +2 on the
+//     labelled branch when cost' < 0; after the minimum they are cleared.  A strict compare of the two sums then IS the
+//     reference's choice.  Range: |cost| ≤ 32768 per step, renormalised every 128 steps, spread ≤ 6·32768: × 16 stays
+//     inside ± 2^27.
+//   * the coded symbol of the branch from the even predecessor into state 16q + r is Lr(r) ^ Lq(q) (the code is linear),
+//     that of the odd predecessor its complement (both polynomials tap the oldest bit).  The received symbol is XORed with
+//     Lq once per step; Lr(r) then picks one of four per-step addends by a compile-time register index.
+// lsdr_viterbi_create checks these properties on the trellis tables it built before this kernel is ever chosen.
+namespace q4 {
+constexpr unsigned kG1 = 0171, kG2 = 0133;
+constexpr unsigned parity7(unsigned x) { return (x ^ (x >> 1) ^ (x >> 2) ^ (x >> 3) ^ (x >> 4) ^ (x >> 5) ^ (x >> 6)) & 1u; }
+// coded symbol of the branch into state s from its even predecessor (shift register = 2(s & 31) | input bit << 6)
+constexpr unsigned lab_even(unsigned s) { return (parity7((((s & 31u) << 1) | ((s >> 5) << 6)) & kG1) << 1) | parity7((((s & 31u) << 1) | ((s >> 5) << 6)) & kG2); }
+
+struct regs { int c[16]; unsigned p[16]; };
+
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+template <int CTRL> __device__ __forceinline__ unsigned dppu(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int quad_min(int v) { int o = dpp<0xB1>(v); v = o < v ? o : v; o = dpp<0x4E>(v); return o < v ? o : v; }
+
+// add-compare-select for the eight states r = 8·HI + j
+template <int HI>
+__device__ __forceinline__ void acs_half(const regs &R, regs &N, const int (&A)[4], unsigned us31) {
+  constexpr int CTRL = HI ? 0xDD : 0x88;   // quad_perm [1,3,1,3] / [0,2,0,2]
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int r = 8 * HI + j;
+    const unsigned le = lab_even((unsigned)r);
+    const int me = dpp<CTRL>(R.c[2 * j]) + A[le];
+    const int mo = dpp<CTRL>(R.c[2 * j + 1]) + A[le ^ 3u];
+    const bool odd = mo < me;
+    N.c[r] = (odd ? mo : me) & ~15;
+    const unsigned pe = dppu<CTRL>(R.p[2 * j]), po = dppu<CTRL>(R.p[2 * j + 1]);
+    N.p[r] = __builtin_amdgcn_alignbit(odd ? po : pe, us31, 31);   // (survivor's path << 1) | input bit of the state
+  }
+}
+
+// one trellis step of every tile of the wavefront.  d: this lane's decoded symbol register holding the step's symbol in
+// lane SRC of the quad; lq2 = Lq(q) << 2; sb[l]: 1 where l ^ Lq(q) is the lower coded symbol of its pair.
+template <int SRC>
+__device__ __forceinline__ void step(regs &R, int d, unsigned lq2, const int (&sb)[4], unsigned us31) {
+  const int S = dpp<SRC * 0x55>(d);                 // quad_perm [SRC,SRC,SRC,SRC]
+  const unsigned csx = (((unsigned)S ^ lq2) >> 2) & 3u;
+  const int hotv = S & ~12;                         // 16·cost' + 2, or 0
+  int A[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) A[l] = csx == (unsigned)l ? hotv + sb[l] : sb[l];
+  regs N;
+  acs_half<0>(R, N, A, us31);
+  acs_half<1>(R, N, A, us31);
+  R = N;
+}
+
+// best metric of the tile (× 16), in every lane of the quad
+__device__ __forceinline__ int tile_min(const regs &R) {
+  int m = R.c[0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) m = R.c[r] < m ? R.c[r] : m;
+  return quad_min(m);
+}
+
+// oldest path bit of the best state, lowest state index among equal metrics (viterbi.h:232-260)
+__device__ __forceinline__ unsigned best_symbol(const regs &R, int q) {
+  int k = 0x7fffffff;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = (int)__builtin_amdgcn_alignbit((unsigned)(R.c[r] | r), R.p[r], 31);   // metric·32 | r·2 | path bit 31
+    k = key < k ? key : k;
+  }
+  k = (int)((((unsigned)k & ~31u) << 2) | ((unsigned)q << 5) | ((unsigned)k & 31u));         // metric·128 | state·2 | bit
+  return (unsigned)quad_min(k) & 1u;
+}
+
+// second smallest − smallest metric of the tile, equal minima counted separately (viterbi.h:246-251)
+__device__ __forceinline__ int quality(const regs &R) {
+  int m1 = R.c[0] < R.c[1] ? R.c[0] : R.c[1], m2 = R.c[0] < R.c[1] ? R.c[1] : R.c[0];
+#pragma unroll
+  for (int r = 2; r < 16; ++r) {
+    const int x = R.c[r];
+    const int lo = m1 < x ? m1 : x, hi = m1 < x ? x : m1;
+    m2 = hi < m2 ? hi : m2;
+    m1 = lo;
+  }
+  {
+    const int o1 = dpp<0xB1>(m1), o2 = dpp<0xB1>(m2);
+    const int hi = m1 < o1 ? o1 : m1, lo2 = m2 < o2 ? m2 : o2;
+    m1 = m1 < o1 ? m1 : o1; m2 = hi < lo2 ? hi : lo2;
+  }
+  {
+    const int o1 = dpp<0x4E>(m1), o2 = dpp<0x4E>(m2);
+    const int hi = m1 < o1 ? o1 : m1, lo2 = m2 < o2 ? m2 : o2;
+    m1 = m1 < o1 ? m1 : o1; m2 = hi < lo2 ? hi : lo2;
+  }
+  return (m2 - m1) >> 4;
+}
+
+__device__ __forceinline__ void load_state(regs &R, const vit_state &st, int q) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { R.c[r] = st.cost[16 * q + r] << 4; R.p[r] = (unsigned)st.path[16 * q + r]; }
+}
+__device__ __forceinline__ void store_state(const regs &R, vit_state &st, int q) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { st.cost[16 * q + r] = R.c[r] >> 4; st.path[16 * q + r] = (unsigned long long)R.p[r]; }
+}
+
+struct sym4 { unsigned v[4]; };
+}  // namespace q4
+
+__global__ __launch_bounds__(64) void k_viterbi_q4(vit_args a) {
+  using namespace q4;
+  const int lane = threadIdx.x, q = lane & 3;
+  const unsigned quad = (unsigned)lane >> 2;
+  // jobs [0, q4_n_main) are the current alignment's tiles, the rest the other alignments' (they want the quality of every
+  // step and emit nothing): the two kinds never share a wavefront
+  unsigned jid;
+  bool valid;
+  if (blockIdx.x < a.q4_main_waves) { jid = blockIdx.x * 16u + quad; valid = jid < a.q4_n_main; }
+  else { jid = a.q4_n_main + (blockIdx.x - a.q4_main_waves) * 16u + quad; valid = jid < a.njobs; }
+  vit_job job;
+  if (valid) job = a.jobs[jid];
+  else { job.first_chunk = 0; job.n_chunks = 0; job.warm = 0; job.sync = 0; job.from_state = -1; job.emit = 0; job.chunk_step = 1; job.slot = 0; }
+  const int wmax = -wave_min(-(int)job.warm), nmax = -wave_min(-(int)job.n_chunks);
+  const unsigned char *map = a.maps + job.sync * 256;
+  const unsigned map4 = (unsigned)map[0] | ((unsigned)map[1] << 8) | ((unsigned)map[2] << 16) | ((unsigned)map[3] << 24);
+  const unsigned lq = lab_even(16u * (unsigned)q), lq2 = lq << 2, us = ((unsigned)q >> 1) << 31;   // us: the states' input bit (s >> 5), in bit 31
+  int sb[4];
+#pragma unroll
+  for (int l = 0; l < 4; ++l) sb[l] = (((unsigned)l ^ lq) >> 1) ? 0 : 1;
+
+  regs R;
+  if (valid && job.from_state >= 0) load_state(R, a.states_in[job.from_state], q);
+  else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { R.c[r] = 0; R.p[r] = 0; }
+  }
+  // the lane's four symbols of a group of sixteen steps: symbols 16g + 4i + q of the chunk (step 16g + 4i + k reads register
+  // i of lane k of the quad)
+  auto load_group = [&](long long qq, int g, sym4 &o) {
+    const unsigned long long c = (unsigned long long)((long long)job.first_chunk + qq * (long long)job.chunk_step);
+    const unsigned *p = reinterpret_cast<const unsigned *>(a.in + c * (unsigned)kChunkBlocks + (unsigned)(16 * g + q));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) o.v[i] = p[4 * i];
+  };
+  sym4 nxt = {{0, 0, 0, 0}};
+  if (valid && job.n_chunks) load_group(-(long long)job.warm, 0, nxt);
+
+  for (int qq = -wmax; qq < nmax; ++qq) {
+    const bool act = valid && qq >= -(int)job.warm && qq < (int)job.n_chunks;
+    if (!act) continue;
+    const unsigned long long c = (unsigned long long)((long long)job.first_chunk + (long long)qq * (long long)job.chunk_step);
+    const bool emitting = qq >= 0;
+    if (qq == 0) store_state(R, a.begin_states[job.slot], q);
+    const bool resync = ((c + (unsigned long long)a.resync_phase0) % (unsigned)a.resync_period) == 0;
+    const bool want_q = resync && emitting, do_emit = emitting && job.emit;
+    int total = 0;
+    unsigned outw = 0;
+    unsigned *pout = reinterpret_cast<unsigned *>(a.out + c * (unsigned)(kChunkBlocks / 8));
+#pragma unroll 1
+    for (int g = 0; g < 8; ++g) {
+      // decode this group's symbols (update_sync, dvb.h:1353-1364, nshifts = 1), fetch the next group's
+      int d[4];
+      const sym4 cur = nxt;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const unsigned raw = cur.v[i];
+        const unsigned sym = (raw >> 16) & 255u;
+        const unsigned cs = sym < 4u ? (map4 >> (8u * sym)) & 255u : (unsigned)map[sym];
+        const int cost = (int)(short)(raw & 0xffffu);
+        // 16·cost' + 2 with the coded symbol in bits 3:2; 0 where nothing is added to any branch (cost ≥ 0, or a coded
+        // symbol no branch carries)
+        d[i] = (cs < 4u && cost < 0) ? ((cost * 16 + 2) | (int)(cs << 2)) : 0;
+      }
+      {
+        const bool last = g == 7;
+        long long nq = last ? (long long)qq + 1 : (long long)qq;
+        if (nq >= (long long)job.n_chunks) nq = (long long)job.n_chunks - 1;
+        load_group(nq, last ? 0 : g + 1, nxt);
+      }
+      bool bulk = false;
+#pragma unroll 1
+      for (int jj = 0; jj < 4; ++jj) {
+        const int dj = d[0];
+        d[0] = d[1]; d[1] = d[2]; d[2] = d[3];
+#define LSDR_Q4_AFTER(first)                                                                               \
+        if (do_emit) {                                                                                     \
+          if (first) {                                                                                     \
+            unsigned aa = R.p[0], oo = R.p[0];                                                             \
+            _Pragma("unroll") for (int r = 1; r < 16; ++r) { aa &= R.p[r]; oo |= R.p[r]; }                 \
+            aa &= dppu<0xB1>(aa); oo |= dppu<0xB1>(oo);                                                    \
+            aa &= dppu<0x4E>(aa); oo |= dppu<0x4E>(oo);                                                    \
+            bulk = ((aa ^ oo) >> 16) == 0u;                                                                \
+            if (bulk) outw = (outw << 16) | (aa >> 16);                                                    \
+          }                                                                                                \
+          if (!bulk) outw = (outw << 1) | best_symbol(R, q);                                               \
+        }                                                                                                  \
+        if (want_q && g >= 4) total += quality(R);
+        step<0>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(jj == 0)
+        step<1>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(false)
+        step<2>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(false)
+        step<3>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(false)
+#undef LSDR_Q4_AFTER
+      }
+      if (do_emit && (g & 1)) { if (q == 0) pout[g >> 1] = __builtin_bswap32(outw); }
+    }
+    // renormalise once per chunk (the reference subtracts the best metric after every step)
+    {
+      const int m = tile_min(R);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) R.c[r] -= m;
+    }
+    if (emitting) {
+      const unsigned ci = (unsigned)qq;
+      if (q == 0) a.totals[(size_t)job.slot * a.totals_stride + ci] = total;
+      if (a.chunk_states) store_state(R, a.chunk_states[(size_t)job.slot * a.totals_stride + ci], q);
+      if (ci == 0 && a.first_chunk_states) store_state(R, a.first_chunk_states[job.slot], q);
+    }
+  }
+  if (valid) store_state(R, a.end_states[job.slot], q);
+}
+
 // seam check: begin state of job j (j ≥ 1) == end state of job j−1
 __global__ __launch_bounds__(64) void k_vit_verify(const vit_state *begin_states, const vit_state *end_states, unsigned njobs,
                                                    int *bad) {
@@ -355,6 +591,7 @@ struct lsdr_viterbi {
   size_t jobs_cap, totals_cap, chunk_cap, fix_cap, first_cap;
   unsigned last_tiles, last_bad;
   size_t budget_chunks;               // chunks attempted per call: shrinks after an alignment switch, regrows
+  bool q4;                            // rate 1/2 QPSK on the four-lanes-per-tile kernel (trellis structure checked at create)
 };
 
 static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
@@ -381,7 +618,7 @@ static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
 static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
                       unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr,
                       const vit_state *dev_start_states = nullptr, bool keep_slots = false, size_t n_slots = 0,
-                      bool write_first = true) {
+                      bool write_first = true, size_t n_main = (size_t)-1) {
   lsdr_ctx *c = v->ctx;
   const size_t nj = keep_slots ? (n_slots > jobs.size() ? n_slots : jobs.size()) : jobs.size();   // capacity of the slot arrays
   if (start_states && v->fix_cap < start_states->size()) {
@@ -430,9 +667,16 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.totals = v->d_totals; a.totals_stride = stride;
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
   a.njobs = (unsigned)up.size();
+  a.q4_n_main = a.njobs; a.q4_main_waves = 0;
   const dim3 grid((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), block(kVitWaves * 64);
   static const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;   // test hook: every mode through the generic path
-  if (a.C.nus == 2 && a.C.bits_out == 2 && !generic_only) hipLaunchKernelGGL(k_viterbi<2>, grid, block, 0, c->stream, a);
+  static const bool lane_only = getenv("LSDR_VIT_LANE") != nullptr;         // test hook: rate 1/2 on the lane = state kernel
+  if (v->q4 && !generic_only && !lane_only) {
+    a.q4_n_main = (unsigned)(n_main < up.size() ? n_main : up.size());
+    a.q4_main_waves = (a.q4_n_main + 15u) / 16u;
+    const unsigned other_waves = (a.njobs - a.q4_n_main + 15u) / 16u;
+    hipLaunchKernelGGL(k_viterbi_q4, dim3(a.q4_main_waves + other_waves), dim3(64), 0, c->stream, a);
+  } else if (a.C.nus == 2 && a.C.bits_out == 2 && !generic_only) hipLaunchKernelGGL(k_viterbi<2>, grid, block, 0, c->stream, a);
   else if (a.C.nus == 4 && a.C.bits_out == 3 && !generic_only) hipLaunchKernelGGL(k_viterbi<4>, grid, block, 0, c->stream, a);
   else hipLaunchKernelGGL(k_viterbi<0>, grid, block, 0, c->stream, a);
   LSDR_HIP(hipGetLastError());
@@ -507,6 +751,17 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
     nbr[s] = C.nus;
   }
   (void)nbr;
+  // k_viterbi_q4's assumptions, checked on the tables just built: state s is entered from 2(s & 31) and 2(s & 31) + 1 with
+  // input bit s >> 5, the even predecessor's branch carries q4::lab_even(s), the odd one's its complement
+  v->q4 = C.nus == 2 && C.bits_out == 2 && v->nshifts == 1 && C.nbits == 1 && C.depth == 32;
+  for (int s = 0; v->q4 && s < kStates; ++s) {
+    const int ke = (T->pred[0][s] & 1) ? 1 : 0, ko = 1 - ke;
+    v->q4 = T->pred[ke][s] == 2 * (s & 31) && T->pred[ko][s] == 2 * (s & 31) + 1 && T->us[0][s] == (s >> 5) && T->us[1][s] == (s >> 5) &&
+            T->lab[ke][s] == q4::lab_even((unsigned)s) && T->lab[ko][s] == (q4::lab_even((unsigned)s) ^ 3u) &&
+            q4::lab_even((unsigned)s) == (q4::lab_even((unsigned)s & 15u) ^ q4::lab_even((unsigned)s & 48u));
+    for (int cs = 0; v->q4 && cs < 256; ++cs)
+      v->q4 = T->by_label[cs][s] == (cs == T->lab[0][s] ? 0 : cs == T->lab[1][s] ? 1 : 255);
+  }
   LSDR_HIP(hipMalloc((void **)&v->d_T, sizeof(vit_tables)));
   LSDR_HIP(hipMemcpy(v->d_T, T, sizeof(vit_tables), hipMemcpyHostToDevice));
   delete T;
@@ -579,10 +834,16 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   if (P >= 8) { TL = 8; while (TL < 32 && P % (int)(TL * 2) == 0) TL *= 2; }
   {
     static const int forced = getenv("LSDR_VIT_TL") ? atoi(getenv("LSDR_VIT_TL")) : 0;   // tuning hook
-    static const int want_x2 = getenv("LSDR_VIT_WANT") ? atoi(getenv("LSDR_VIT_WANT")) : 3;   // tuning hook: wavefronts per SIMD, in halves
-    const size_t want = (size_t)c->num_cu * 4 * (size_t)want_x2 / 2;   // 1.5 wavefronts per SIMD keep the chip busy
+    static const int want_x2 = getenv("LSDR_VIT_WANT") ? atoi(getenv("LSDR_VIT_WANT")) : 0;   // tuning hook: wavefronts per SIMD, in halves
+    static const bool lane_kernel = getenv("LSDR_VIT_LANE") != nullptr || getenv("LSDR_VIT_GENERIC") != nullptr;
+    const bool q4 = v->q4 && !lane_kernel;
+    // 1.5 wavefronts per SIMD keep the chip busy with one tile per wavefront.  k_viterbi_q4 carries sixteen tiles per
+    // wavefront and is bound by instruction issue, not latency: what counts is the total number of trellis steps, so it
+    // keeps the long tiles (an eighth of the work is warm-up) down to one wavefront on every other SIMD
+    const size_t want = (size_t)c->num_cu * 4 * (size_t)(want_x2 > 0 ? want_x2 : q4 ? 1 : 3) / 2 * (q4 ? 12 : 1);
+    const unsigned tl_min = q4 ? 4u : 1u;
     if (forced > 0) TL = (unsigned)forced;
-    else while (TL > 1 && TL % 2 == 0 && chunks / TL < want) TL /= 2;
+    else while (TL > tl_min && TL % 2 == 0 && chunks / TL < want) TL /= 2;
   }
   std::vector<vit_job> jobs;
   const int cur = v->current_sync;
@@ -612,9 +873,11 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   // stream" is tiled and verified like the main one; their tiles ride in the SAME launch as the main tiles (nothing in
   // them depends on the main alignment's results), after the main slots.
   const bool have_others = !rs.empty() && v->nsyncs > 1;
-  // tile length of the other alignments (in resync chunks): 8 when that still leaves a thousand tiles (half the work is
-  // warm-up then, two thirds at 4)
-  const unsigned TLo = (size_t)(v->nsyncs - 1) * ((rs.size() + 7) / 8) >= 1024 ? 8u : 4u;
+  // tile length of the other alignments (in resync chunks): the longest of 32, 16, 8 that still leaves a thousand tiles (a
+  // fifth of the work is warm-up at 32, half at 8, two thirds at 4)
+  unsigned TLo = 4;
+  for (unsigned t = 32; t >= 8; t /= 2)
+    if ((size_t)(v->nsyncs - 1) * ((rs.size() + t - 1) / t) >= 1024) { TLo = t; break; }
   // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
   // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in forty
   static const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook
@@ -655,7 +918,7 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   if (n_first && first_others.ostride > stride) stride = first_others.ostride;
   std::vector<vit_job> launch_jobs(jobs);
   launch_jobs.insert(launch_jobs.end(), first_others.oj.begin(), first_others.oj.end());
-  int rc = vit_launch(v, in, out, launch_jobs, stride, false, phase0);
+  int rc = vit_launch(v, in, out, launch_jobs, stride, false, phase0, nullptr, nullptr, false, 0, true, n_main);
   if (rc) return rc;
   // ---- seam check and fix-up rounds, main and other alignments together.  A tile whose speculative start state differs
   // from its predecessor's end state is decoded again from that end state (read on the device from the slot array; results
