@@ -524,8 +524,20 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
                            "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample)}
     else:
         st = vit.stats()
-        out["roofline"] = {"kernel": "k_viterbi (viterbi_sync, lane = trellis state)", "bound": "valu (64-state add-compare-select per symbol; not an HBM stream)",
-                           "trellis_steps_per_s": round(nb * B / sps / dt, 1), "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample),
+        # viterbi_sync bounds this chain.  k_viterbi_q4 is bound by vector-instruction issue (one wave64 VALU instruction per
+        # 4 cycles and SIMD, measured: SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction): `valu_issue` prices the trellis
+        # steps of the CURRENT alignment alone against 1024 SIMDs x 2.4 GHz / (instructions per tile step x 4 cycles); the
+        # other alignments' resync chunks (15 of them for 8PSK) and the tiles' warm-up are on top of that.
+        instr_per_tile_step = {capi.FEC12: 190 / 16.0, capi.FEC23: 590 / 16.0}.get(rate)
+        steps_per_s = nb * B / sps / dt
+        valu = None
+        if instr_per_tile_step:
+            peak_steps = 1024 * 2.4e9 / (instr_per_tile_step * 4.0)
+            valu = {"instructions_per_tile_step": round(instr_per_tile_step, 2), "peak_trellis_steps_per_s": round(peak_steps, 1),
+                    "achieved_trellis_steps_per_s": round(steps_per_s, 1), "frac": round(steps_per_s / peak_steps, 4)}
+        out["roofline"] = {"kernel": "k_viterbi_q4 (viterbi_sync, four lanes per tile, sixteen tiles per wavefront)",
+                           "bound": "valu issue (64-state add-compare-select per symbol; not an HBM stream)",
+                           "trellis_steps_per_s": round(steps_per_s, 1), "valu_issue": valu, "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample),
                            "frac": hbm_frac(nb * B / dt, alg_per_sample), "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
                            "achieved": round(nb * B / dt * alg_per_sample / 1e9, 2), "algorithmic_bytes_per_sample": round(alg_per_sample, 3),
                            "viterbi_stats": st}
@@ -555,7 +567,9 @@ def c3(capi, synth, device, args):
 
 
 def c5_rescoped(capi, synth, device, args):
-    return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, int(os.environ.get("LSDR_C5_BATCH_MSAMPLES", 64)),
+    # batch: 128 Mi symbols per viterbi_sync call let k_viterbi_q4 keep 32-chunk tiles on every SIMD (64 Mi samples per batch
+    # 9.7 GS/s — the lane = state kernel does 11.2 there —, 256 Mi 15.1, 512 Mi 18–19, 1 Gi 14.8)
+    return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, int(os.environ.get("LSDR_C5_BATCH_MSAMPLES", 512)),
                       "8PSK 2/3 @ 4 sps cf32 (30 MS/s symbols = 120 MS/s input): cstln_receiver(PSK8, tiled) -> viterbi_sync(2/3) -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                       ["--f32", "--float-scale", "1", "-f", "120e6", "--sr", "30000e3", "--const", "8PSK", "--cr", "2/3", "--anf", "0", "--viterbi"])
 

@@ -325,95 +325,129 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Rate 1/2 (K = 7, 171/133), QPSK: FOUR lanes per tile, sixteen tiles per wavefront.
+// Rates 1/2 (QPSK) and 2/3 (8PSK) of the K = 7, 171/133 code: FOUR lanes per tile, sixteen tiles per wavefront.
 //
-// Lane q of a quad holds the sixteen states 16q … 16q+15 of its tile in registers (metric + 32-bit path each).  State
-// s' = 16q + r is entered from 2(s' & 31) and 2(s' & 31) + 1 with input bit s' >> 5 (viterbi.h:59-92): registers 2(r & 7)
-// and 2(r & 7) + 1 of lane 2(q & 1) + (r >> 3) of the same quad — two fixed quad permutes (DPP operands of the adds and
-// selects: no LDS, no shuffle latency), register indices known at compile time.  One wavefront instruction advances sixteen
-// tiles, where the lane = state kernel above advances one and waits for two LDS round trips per step.
+// Lane q of a quad holds the sixteen states 16q … 16q+15 of its tile in registers (metric + path each).  The predecessors of
+// state s' = 16q + r (viterbi.h:59-92) sit in fixed registers of a fixed lane of the same quad:
+//   rate 1/2: 2(s' & 31) + e, e = 0, 1, input bit s' >> 5: registers 2(r & 7) + e of lane 2(q & 1) + (r >> 3);
+//   rate 2/3: 4(s' & 15) + e, e = 0 … 3, input bits s' >> 4 (reversed): registers 4(r & 3) + e of lane r >> 2;
+// i.e. quad permutes with compile-time register indices (DPP operands of the adds and moves: no LDS, no shuffle latency).
+// One wavefront instruction advances sixteen tiles, where the lane = state kernel above advances one and waits for two LDS
+// round trips per step.
 //
 // Same arithmetic as viterbi_dec::update (viterbi.h:202-260), restated so that it needs no branch per state:
-//   * candidates in the reference's order are [labelled branch + cost, branch 0, branch 1] with `<=` (the last one wins a
-//     tie); branches are ordered by coded symbol.  The labelled branch reappears with cost 0, so a POSITIVE cost can never
+//   * candidates in the reference's order are [labelled branch + cost, then every branch by ascending coded symbol] with
+//     `<=`, so the last of equal candidates wins.  The labelled branch reappears with cost 0, so a POSITIVE cost can never
 //     win: cost' = min(cost, 0) gives the same survivor and metric.  With cost' < 0 the plain copy of the labelled branch
-//     never wins either, and on a tie between (labelled + cost') and the other branch the other one is taken (it comes
-//     later); with cost' = 0 or no labelled branch into the state, branch 1 wins a tie.
-//   * metrics are kept × 16.  The four low bits carry the tie rule: +1 on the branch with the lower coded symbol, +2 on the
-//     labelled branch when cost' < 0; after the minimum they are cleared.  A strict compare of the two sums then IS the
-//     reference's choice.  Range: |cost| ≤ 32768 per step, renormalised every 128 steps, spread ≤ 6·32768: × 16 stays
-//     inside ± 2^27.
-//   * the coded symbol of the branch from the even predecessor into state 16q + r is Lr(r) ^ Lq(q) (the code is linear),
-//     that of the odd predecessor its complement (both polynomials tap the oldest bit).  The received symbol is XORed with
-//     Lq once per step; Lr(r) then picks one of four per-step addends by a compile-time register index.
+//     never wins either, and (labelled + cost') loses a tie against any other branch (they all come later); among plain
+//     branches the one with the highest coded symbol wins a tie.
+//   * metrics are kept × 16.  The four low bits carry the tie rule: the number of branches into the state with a higher
+//     coded symbol (0 … 3), or 4 on the labelled branch when cost' < 0; after the minimum they are cleared.  No two
+//     candidates of a state are equal then, and a strict compare of the sums IS the reference's choice.  Range: |cost| ≤ 32768
+//     per step, renormalised every 128 steps, spread ≤ 6·32768: × 16 stays inside ± 2^27.
+//   * the code is linear: the coded symbol of branch e into state 16q + r is Lr(r) ^ Le(e) ^ Lq(q), and the coded symbols of
+//     the branches into one state form a coset of {Le(e)}, so the tie rank of a branch depends on its coded symbol alone.
+//     The received symbol is XORed with Lq once per step; Lr(r) ^ Le(e) then picks one of NCS per-step addends by a
+//     compile-time register index.
 // lsdr_viterbi_create checks these properties on the trellis tables it built before this kernel is ever chosen.
 namespace q4 {
 constexpr unsigned kG1 = 0171, kG2 = 0133;
-constexpr unsigned parity7(unsigned x) { return (x ^ (x >> 1) ^ (x >> 2) ^ (x >> 3) ^ (x >> 4) ^ (x >> 5) ^ (x >> 6)) & 1u; }
-// coded symbol of the branch into state s from its even predecessor (shift register = 2(s & 31) | input bit << 6)
-constexpr unsigned lab_even(unsigned s) { return (parity7((((s & 31u) << 1) | ((s >> 5) << 6)) & kG1) << 1) | parity7((((s & 31u) << 1) | ((s >> 5) << 6)) & kG2); }
+constexpr unsigned par8(unsigned x) { return (x ^ (x >> 1) ^ (x >> 2) ^ (x >> 3) ^ (x >> 4) ^ (x >> 5) ^ (x >> 6) ^ (x >> 7)) & 1u; }
+// coded symbol of the branch into state s from its predecessor number e (shift register = predecessor | input bits << 6)
+template <int NUS> constexpr unsigned branch_label(unsigned s, unsigned e) {
+  if (NUS == 2) { const unsigned reg = ((s & 31u) << 1) | e | ((s >> 5) << 6); return (par8(reg & kG1) << 1) | par8(reg & kG2); }
+  const unsigned reg = ((s & 15u) << 2) | e | ((s >> 4) << 6);
+  return (par8(reg & kG1) << 2) | (par8(reg & kG2) << 1) | par8(reg & (kG2 << 1));
+}
+// the input symbol stored in the path register of state s (trellis::us: the reversed bits are the state's top bits)
+template <int NUS> constexpr unsigned state_us(unsigned s) { return NUS == 2 ? s >> 5 : (((s >> 4) & 1u) << 1) | (s >> 5); }
 
-struct regs { int c[16]; unsigned p[16]; };
+template <int NUS> struct regs { int c[16]; unsigned p[16]; unsigned ph[NUS == 4 ? 16 : 1]; };
 
 template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL> __device__ __forceinline__ unsigned dppu(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ int quad_min(int v) { int o = dpp<0xB1>(v); v = o < v ? o : v; o = dpp<0x4E>(v); return o < v ? o : v; }
 
-// add-compare-select for the eight states r = 8·HI + j
+// rate 1/2: add-compare-select for the eight states r = 8·HI + j
 template <int HI>
-__device__ __forceinline__ void acs_half(const regs &R, regs &N, const int (&A)[4], unsigned us31) {
+__device__ __forceinline__ void acs2_half(const regs<2> &R, regs<2> &N, const int (&A)[4], unsigned us31) {
   constexpr int CTRL = HI ? 0xDD : 0x88;   // quad_perm [1,3,1,3] / [0,2,0,2]
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int r = 8 * HI + j;
-    const unsigned le = lab_even((unsigned)r);
-    const int me = dpp<CTRL>(R.c[2 * j]) + A[le];
-    const int mo = dpp<CTRL>(R.c[2 * j + 1]) + A[le ^ 3u];
+    const int me = dpp<CTRL>(R.c[2 * j]) + A[branch_label<2>((unsigned)r, 0)];
+    const int mo = dpp<CTRL>(R.c[2 * j + 1]) + A[branch_label<2>((unsigned)r, 1)];
     const bool odd = mo < me;
     N.c[r] = (odd ? mo : me) & ~15;
     const unsigned pe = dppu<CTRL>(R.p[2 * j]), po = dppu<CTRL>(R.p[2 * j + 1]);
     N.p[r] = __builtin_amdgcn_alignbit(odd ? po : pe, us31, 31);   // (survivor's path << 1) | input bit of the state
   }
 }
+// rate 2/3: the four states r = 4·K + j, predecessors in lane K
+template <int K>
+__device__ __forceinline__ void acs4_quarter(const regs<4> &R, regs<4> &N, const int (&A)[8], unsigned us) {
+  constexpr int CTRL = K * 0x55;           // quad_perm [K,K,K,K]
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 4 * K + j;
+    const int m0 = dpp<CTRL>(R.c[4 * j]) + A[branch_label<4>((unsigned)r, 0)], m1 = dpp<CTRL>(R.c[4 * j + 1]) + A[branch_label<4>((unsigned)r, 1)];
+    const int m2 = dpp<CTRL>(R.c[4 * j + 2]) + A[branch_label<4>((unsigned)r, 2)], m3 = dpp<CTRL>(R.c[4 * j + 3]) + A[branch_label<4>((unsigned)r, 3)];
+    const bool o01 = m1 < m0, o23 = m3 < m2;
+    const int l01 = o01 ? m1 : m0, l23 = o23 ? m3 : m2;
+    const bool hi = l23 < l01;
+    N.c[r] = (hi ? l23 : l01) & ~15;
+    const unsigned a0 = dppu<CTRL>(R.p[4 * j]), a1 = dppu<CTRL>(R.p[4 * j + 1]), a2 = dppu<CTRL>(R.p[4 * j + 2]), a3 = dppu<CTRL>(R.p[4 * j + 3]);
+    const unsigned b0 = dppu<CTRL>(R.ph[4 * j]), b1 = dppu<CTRL>(R.ph[4 * j + 1]), b2 = dppu<CTRL>(R.ph[4 * j + 2]), b3 = dppu<CTRL>(R.ph[4 * j + 3]);
+    const unsigned a01 = o01 ? a1 : a0, a23 = o23 ? a3 : a2, b01 = o01 ? b1 : b0, b23 = o23 ? b3 : b2;
+    const unsigned lo = hi ? a23 : a01, hw = hi ? b23 : b01;
+    N.ph[r] = __builtin_amdgcn_alignbit(hw, lo, 29);               // 64-bit (path << 3) | input symbol of the state
+    N.p[r] = (lo << 3) | us;
+  }
+}
 
 // one trellis step of every tile of the wavefront.  d: this lane's decoded symbol register holding the step's symbol in
-// lane SRC of the quad; lq2 = Lq(q) << 2; sb[l]: 1 where l ^ Lq(q) is the lower coded symbol of its pair.
-template <int SRC>
-__device__ __forceinline__ void step(regs &R, int d, unsigned lq2, const int (&sb)[4], unsigned us31) {
+// lane SRC of the quad (16·cost' | coded symbol, or 8: nothing to add); lq = Lq(q); tl[l]: tie rank of coded symbol l ^ Lq(q).
+template <int NUS, int SRC>
+__device__ __forceinline__ void step(regs<NUS> &R, int d, unsigned lq, const int (&tl)[2 * NUS], unsigned us) {
   const int S = dpp<SRC * 0x55>(d);                 // quad_perm [SRC,SRC,SRC,SRC]
-  const unsigned csx = (((unsigned)S ^ lq2) >> 2) & 3u;
-  const int hotv = S & ~12;                         // 16·cost' + 2, or 0
-  int A[4];
+  const unsigned csx = ((unsigned)S ^ lq) & 15u;
+  const int hotv = (S & ~15) | NUS;
+  int A[2 * NUS];
 #pragma unroll
-  for (int l = 0; l < 4; ++l) A[l] = csx == (unsigned)l ? hotv + sb[l] : sb[l];
-  regs N;
-  acs_half<0>(R, N, A, us31);
-  acs_half<1>(R, N, A, us31);
+  for (int l = 0; l < 2 * NUS; ++l) A[l] = csx == (unsigned)l ? hotv : tl[l];
+  regs<NUS> N;
+  if constexpr (NUS == 2) { acs2_half<0>(R, N, A, us); acs2_half<1>(R, N, A, us); }
+  else { acs4_quarter<0>(R, N, A, us); acs4_quarter<1>(R, N, A, us); acs4_quarter<2>(R, N, A, us); acs4_quarter<3>(R, N, A, us); }
   R = N;
 }
 
 // best metric of the tile (× 16), in every lane of the quad
-__device__ __forceinline__ int tile_min(const regs &R) {
+template <int NUS> __device__ __forceinline__ int tile_min(const regs<NUS> &R) {
   int m = R.c[0];
 #pragma unroll
   for (int r = 1; r < 16; ++r) m = R.c[r] < m ? R.c[r] : m;
   return quad_min(m);
 }
 
-// oldest path bit of the best state, lowest state index among equal metrics (viterbi.h:232-260)
-__device__ __forceinline__ unsigned best_symbol(const regs &R, int q) {
+// oldest path symbol of the best state, lowest state index among equal metrics (viterbi.h:232-260).  The key is
+// metric·2^(5+B) | state·2^B | symbol (B = 1, 3): 16·metric ≥ −2^26 (128 steps of −32768 after a renormalisation) keeps
+// metric·512 ≥ −2^31.
+template <int NUS> __device__ __forceinline__ unsigned best_symbol(const regs<NUS> &R, int q) {
+  constexpr int B = NUS == 2 ? 1 : 3;
   int k = 0x7fffffff;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int key = (int)__builtin_amdgcn_alignbit((unsigned)(R.c[r] | r), R.p[r], 31);   // metric·32 | r·2 | path bit 31
+    const unsigned old = NUS == 2 ? R.p[r] : R.ph[r] << 1;     // oldest symbol in the top B bits
+    const int key = (int)__builtin_amdgcn_alignbit((unsigned)(R.c[r] | r), old, 32 - B);
     k = key < k ? key : k;
   }
-  k = (int)((((unsigned)k & ~31u) << 2) | ((unsigned)q << 5) | ((unsigned)k & 31u));         // metric·128 | state·2 | bit
-  return (unsigned)quad_min(k) & 1u;
+  constexpr unsigned low = (16u << B) - 1u;
+  k = (int)((((unsigned)k & ~low) << 2) | ((unsigned)q << (4 + B)) | ((unsigned)k & low));
+  return (unsigned)quad_min(k) & (NUS == 2 ? 1u : 3u);
 }
 
 // second smallest − smallest metric of the tile, equal minima counted separately (viterbi.h:246-251)
-__device__ __forceinline__ int quality(const regs &R) {
+template <int NUS> __device__ __forceinline__ int quality(const regs<NUS> &R) {
   int m1 = R.c[0] < R.c[1] ? R.c[0] : R.c[1], m2 = R.c[0] < R.c[1] ? R.c[1] : R.c[0];
 #pragma unroll
   for (int r = 2; r < 16; ++r) {
@@ -435,20 +469,50 @@ __device__ __forceinline__ int quality(const regs &R) {
   return (m2 - m1) >> 4;
 }
 
-__device__ __forceinline__ void load_state(regs &R, const vit_state &st, int q) {
+// Where ALL 64 survivors of a tile agree on their oldest symbols, those are the decoder's next outputs whichever state is
+// best then: the output of step t + j is the oldest symbol of the best path at t + j, i.e. symbol number depth − 1 − j of
+// its ancestor's path at t.  Rate 1/2: 16 one-bit symbols (path bits 31…16); rate 2/3: 8 symbols of the 21 (path bits
+// 62…39), two bits each.  Returns agreement; `bits` = the 16 output bits, first one in bit 15.
+template <int NUS> __device__ __forceinline__ bool agreed_outputs(const regs<NUS> &R, unsigned &bits) {
+  unsigned aa, oo;
+  if constexpr (NUS == 2) { aa = R.p[0]; oo = R.p[0]; } else { aa = R.ph[0]; oo = R.ph[0]; }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { R.c[r] = st.cost[16 * q + r] << 4; R.p[r] = (unsigned)st.path[16 * q + r]; }
+  for (int r = 1; r < 16; ++r) { const unsigned x = NUS == 2 ? R.p[r] : R.ph[r]; aa &= x; oo |= x; }
+  aa &= dppu<0xB1>(aa); oo |= dppu<0xB1>(oo);
+  aa &= dppu<0x4E>(aa); oo |= dppu<0x4E>(oo);
+  if constexpr (NUS == 2) { bits = aa >> 16; return ((aa ^ oo) >> 16) == 0u; }
+  else {
+    unsigned b = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b = (b << 2) | ((aa >> (28 - 3 * j)) & 3u);   // path bits 62−3j … 60−3j live in ph bits 30−3j … 28−3j
+    bits = b;
+    return ((aa ^ oo) & 0x7fffff80u) == 0u;
+  }
 }
-__device__ __forceinline__ void store_state(const regs &R, vit_state &st, int q) {
+
+template <int NUS> __device__ __forceinline__ void load_state(regs<NUS> &R, const vit_state &st, int q) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { st.cost[16 * q + r] = R.c[r] >> 4; st.path[16 * q + r] = (unsigned long long)R.p[r]; }
+  for (int r = 0; r < 16; ++r) {
+    R.c[r] = st.cost[16 * q + r] << 4; R.p[r] = (unsigned)st.path[16 * q + r];
+    if constexpr (NUS == 4) R.ph[r] = (unsigned)(st.path[16 * q + r] >> 32);
+  }
+}
+template <int NUS> __device__ __forceinline__ void store_state(const regs<NUS> &R, vit_state &st, int q) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    st.cost[16 * q + r] = R.c[r] >> 4;
+    st.path[16 * q + r] = NUS == 4 ? ((unsigned long long)R.ph[r] << 32) | R.p[r] : (unsigned long long)R.p[r];
+  }
 }
 
 struct sym4 { unsigned v[4]; };
 }  // namespace q4
 
+template <int NUS>
 __global__ __launch_bounds__(64) void k_viterbi_q4(vit_args a) {
   using namespace q4;
+  constexpr int BITS_IN = NUS == 2 ? 1 : 2;          // decoded bits per step
+  constexpr int NCS = 2 * NUS;
   const int lane = threadIdx.x, q = lane & 3;
   const unsigned quad = (unsigned)lane >> 2;
   // jobs [0, q4_n_main) are the current alignment's tiles, the rest the other alignments' (they want the quality of every
@@ -462,17 +526,26 @@ __global__ __launch_bounds__(64) void k_viterbi_q4(vit_args a) {
   else { job.first_chunk = 0; job.n_chunks = 0; job.warm = 0; job.sync = 0; job.from_state = -1; job.emit = 0; job.chunk_step = 1; job.slot = 0; }
   const int wmax = -wave_min(-(int)job.warm), nmax = -wave_min(-(int)job.n_chunks);
   const unsigned char *map = a.maps + job.sync * 256;
-  const unsigned map4 = (unsigned)map[0] | ((unsigned)map[1] << 8) | ((unsigned)map[2] << 16) | ((unsigned)map[3] << 24);
-  const unsigned lq = lab_even(16u * (unsigned)q), lq2 = lq << 2, us = ((unsigned)q >> 1) << 31;   // us: the states' input bit (s >> 5), in bit 31
-  int sb[4];
+  const unsigned map_lo = (unsigned)map[0] | ((unsigned)map[1] << 8) | ((unsigned)map[2] << 16) | ((unsigned)map[3] << 24);
+  const unsigned map_hi = (unsigned)map[4] | ((unsigned)map[5] << 8) | ((unsigned)map[6] << 16) | ((unsigned)map[7] << 24);
+  const unsigned lq = branch_label<NUS>(16u * (unsigned)q, 0);
+  // the states' input symbol (trellis::us) as the step functions want it: rate 1/2 in bit 31, rate 2/3 as the low bits
+  const unsigned us = NUS == 2 ? state_us<2>(16u * (unsigned)q) << 31 : state_us<4>(16u * (unsigned)q);
+  int tl[NCS];   // tie rank of the branch whose coded symbol is l ^ Lq(q): the number of higher coded symbols in its coset
 #pragma unroll
-  for (int l = 0; l < 4; ++l) sb[l] = (((unsigned)l ^ lq) >> 1) ? 0 : 1;
+  for (int l = 0; l < NCS; ++l) {
+    const unsigned y = (unsigned)l ^ lq;
+    int n = 0;
+#pragma unroll
+    for (int e = 1; e < NUS; ++e) n += (y ^ branch_label<NUS>(0, (unsigned)e)) > y ? 1 : 0;
+    tl[l] = n;
+  }
 
-  regs R;
-  if (valid && job.from_state >= 0) load_state(R, a.states_in[job.from_state], q);
+  regs<NUS> R;
+  if (valid && job.from_state >= 0) load_state<NUS>(R, a.states_in[job.from_state], q);
   else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { R.c[r] = 0; R.p[r] = 0; }
+    for (int r = 0; r < 16; ++r) { R.c[r] = 0; R.p[r] = 0; if constexpr (NUS == 4) R.ph[r] = 0; }
   }
   // the lane's four symbols of a group of sixteen steps: symbols 16g + 4i + q of the chunk (step 16g + 4i + k reads register
   // i of lane k of the quad)
@@ -490,12 +563,12 @@ __global__ __launch_bounds__(64) void k_viterbi_q4(vit_args a) {
     if (!act) continue;
     const unsigned long long c = (unsigned long long)((long long)job.first_chunk + (long long)qq * (long long)job.chunk_step);
     const bool emitting = qq >= 0;
-    if (qq == 0) store_state(R, a.begin_states[job.slot], q);
+    if (qq == 0) store_state<NUS>(R, a.begin_states[job.slot], q);
     const bool resync = ((c + (unsigned long long)a.resync_phase0) % (unsigned)a.resync_period) == 0;
     const bool want_q = resync && emitting, do_emit = emitting && job.emit;
     int total = 0;
     unsigned outw = 0;
-    unsigned *pout = reinterpret_cast<unsigned *>(a.out + c * (unsigned)(kChunkBlocks / 8));
+    unsigned *pout = reinterpret_cast<unsigned *>(a.out + c * (unsigned)(kChunkBlocks * BITS_IN / 8));
 #pragma unroll 1
     for (int g = 0; g < 8; ++g) {
       // decode this group's symbols (update_sync, dvb.h:1353-1364, nshifts = 1), fetch the next group's
@@ -505,11 +578,11 @@ __global__ __launch_bounds__(64) void k_viterbi_q4(vit_args a) {
       for (int i = 0; i < 4; ++i) {
         const unsigned raw = cur.v[i];
         const unsigned sym = (raw >> 16) & 255u;
-        const unsigned cs = sym < 4u ? (map4 >> (8u * sym)) & 255u : (unsigned)map[sym];
+        const unsigned cs = sym < 4u ? (map_lo >> (8u * sym)) & 255u : sym < 8u ? (map_hi >> (8u * (sym - 4u))) & 255u : (unsigned)map[sym];
         const int cost = (int)(short)(raw & 0xffffu);
-        // 16·cost' + 2 with the coded symbol in bits 3:2; 0 where nothing is added to any branch (cost ≥ 0, or a coded
+        // 16·cost' with the coded symbol in the low bits; 8 where nothing is added to any branch (cost ≥ 0, or a coded
         // symbol no branch carries)
-        d[i] = (cs < 4u && cost < 0) ? ((cost * 16 + 2) | (int)(cs << 2)) : 0;
+        d[i] = (cs < (unsigned)NCS && cost < 0) ? (cost * 16) | (int)cs : 8;
       }
       {
         const bool last = g == 7;
@@ -522,41 +595,41 @@ __global__ __launch_bounds__(64) void k_viterbi_q4(vit_args a) {
       for (int jj = 0; jj < 4; ++jj) {
         const int dj = d[0];
         d[0] = d[1]; d[1] = d[2]; d[2] = d[3];
+        // a check covers the outputs of the next 16 (rate 1/2) / 8 (rate 2/3) steps
+        const bool check = NUS == 2 ? jj == 0 : (jj & 1) == 0;
 #define LSDR_Q4_AFTER(first)                                                                               \
         if (do_emit) {                                                                                     \
           if (first) {                                                                                     \
-            unsigned aa = R.p[0], oo = R.p[0];                                                             \
-            _Pragma("unroll") for (int r = 1; r < 16; ++r) { aa &= R.p[r]; oo |= R.p[r]; }                 \
-            aa &= dppu<0xB1>(aa); oo |= dppu<0xB1>(oo);                                                    \
-            aa &= dppu<0x4E>(aa); oo |= dppu<0x4E>(oo);                                                    \
-            bulk = ((aa ^ oo) >> 16) == 0u;                                                                \
-            if (bulk) outw = (outw << 16) | (aa >> 16);                                                    \
+            unsigned bits;                                                                                 \
+            bulk = agreed_outputs<NUS>(R, bits);                                                           \
+            if (bulk) outw = (outw << 16) | bits;                                                          \
           }                                                                                                \
-          if (!bulk) outw = (outw << 1) | best_symbol(R, q);                                               \
+          if (!bulk) outw = (outw << BITS_IN) | best_symbol<NUS>(R, q);                                    \
         }                                                                                                  \
-        if (want_q && g >= 4) total += quality(R);
-        step<0>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(jj == 0)
-        step<1>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(false)
-        step<2>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(false)
-        step<3>(R, dj, lq2, sb, us); LSDR_Q4_AFTER(false)
+        if (want_q && g >= 4 / BITS_IN) total += quality<NUS>(R);
+        step<NUS, 0>(R, dj, lq, tl, us); LSDR_Q4_AFTER(check)
+        step<NUS, 1>(R, dj, lq, tl, us); LSDR_Q4_AFTER(false)
+        step<NUS, 2>(R, dj, lq, tl, us); LSDR_Q4_AFTER(false)
+        step<NUS, 3>(R, dj, lq, tl, us); LSDR_Q4_AFTER(false)
 #undef LSDR_Q4_AFTER
       }
-      if (do_emit && (g & 1)) { if (q == 0) pout[g >> 1] = __builtin_bswap32(outw); }
+      // sixteen steps make 16·BITS_IN bits: a word every other group (rate 1/2) / every group (rate 2/3)
+      if (do_emit && (NUS == 4 || (g & 1))) { if (q == 0) pout[NUS == 4 ? g : g >> 1] = __builtin_bswap32(outw); }
     }
     // renormalise once per chunk (the reference subtracts the best metric after every step)
     {
-      const int m = tile_min(R);
+      const int m = tile_min<NUS>(R);
 #pragma unroll
       for (int r = 0; r < 16; ++r) R.c[r] -= m;
     }
     if (emitting) {
       const unsigned ci = (unsigned)qq;
       if (q == 0) a.totals[(size_t)job.slot * a.totals_stride + ci] = total;
-      if (a.chunk_states) store_state(R, a.chunk_states[(size_t)job.slot * a.totals_stride + ci], q);
-      if (ci == 0 && a.first_chunk_states) store_state(R, a.first_chunk_states[job.slot], q);
+      if (a.chunk_states) store_state<NUS>(R, a.chunk_states[(size_t)job.slot * a.totals_stride + ci], q);
+      if (ci == 0 && a.first_chunk_states) store_state<NUS>(R, a.first_chunk_states[job.slot], q);
     }
   }
-  if (valid) store_state(R, a.end_states[job.slot], q);
+  if (valid) store_state<NUS>(R, a.end_states[job.slot], q);
 }
 
 // seam check: begin state of job j (j ≥ 1) == end state of job j−1
@@ -591,7 +664,8 @@ struct lsdr_viterbi {
   size_t jobs_cap, totals_cap, chunk_cap, fix_cap, first_cap;
   unsigned last_tiles, last_bad;
   size_t budget_chunks;               // chunks attempted per call: shrinks after an alignment switch, regrows
-  bool q4;                            // rate 1/2 QPSK on the four-lanes-per-tile kernel (trellis structure checked at create)
+  bool q4;                            // rate 1/2 QPSK / 2/3 8PSK may use the four-lanes-per-tile kernel (trellis structure checked at create)
+  bool q4_call;                       // ... and the current lsdr_viterbi_run call does
 };
 
 static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
@@ -669,13 +743,15 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.njobs = (unsigned)up.size();
   a.q4_n_main = a.njobs; a.q4_main_waves = 0;
   const dim3 grid((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), block(kVitWaves * 64);
-  static const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;   // test hook: every mode through the generic path
-  static const bool lane_only = getenv("LSDR_VIT_LANE") != nullptr;         // test hook: rate 1/2 on the lane = state kernel
-  if (v->q4 && !generic_only && !lane_only) {
+  // (test hooks, read at every call so that one process can exercise every kernel)
+  const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;   // test hook: every mode through the generic path
+  const bool lane_only = getenv("LSDR_VIT_LANE") != nullptr;         // test hook: rates 1/2 and 2/3 on the lane = state kernel
+  if (v->q4_call && !generic_only && !lane_only) {
     a.q4_n_main = (unsigned)(n_main < up.size() ? n_main : up.size());
     a.q4_main_waves = (a.q4_n_main + 15u) / 16u;
     const unsigned other_waves = (a.njobs - a.q4_n_main + 15u) / 16u;
-    hipLaunchKernelGGL(k_viterbi_q4, dim3(a.q4_main_waves + other_waves), dim3(64), 0, c->stream, a);
+    if (a.C.nus == 2) hipLaunchKernelGGL(k_viterbi_q4<2>, dim3(a.q4_main_waves + other_waves), dim3(64), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_viterbi_q4<4>, dim3(a.q4_main_waves + other_waves), dim3(64), 0, c->stream, a);
   } else if (a.C.nus == 2 && a.C.bits_out == 2 && !generic_only) hipLaunchKernelGGL(k_viterbi<2>, grid, block, 0, c->stream, a);
   else if (a.C.nus == 4 && a.C.bits_out == 3 && !generic_only) hipLaunchKernelGGL(k_viterbi<4>, grid, block, 0, c->stream, a);
   else hipLaunchKernelGGL(k_viterbi<0>, grid, block, 0, c->stream, a);
@@ -751,16 +827,26 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
     nbr[s] = C.nus;
   }
   (void)nbr;
-  // k_viterbi_q4's assumptions, checked on the tables just built: state s is entered from 2(s & 31) and 2(s & 31) + 1 with
-  // input bit s >> 5, the even predecessor's branch carries q4::lab_even(s), the odd one's its complement
-  v->q4 = C.nus == 2 && C.bits_out == 2 && v->nshifts == 1 && C.nbits == 1 && C.depth == 32;
+  // k_viterbi_q4's assumptions, checked on the tables just built: the predecessors of state s are NUS·(s mod 64/NUS) + e, all
+  // its branches store the same input symbol, branch e carries q4::branch_label(s, e), coded symbols are linear in (s & 15),
+  // (s & 48) and e, and the branches are ordered by coded symbol
+  v->q4 = ((C.nus == 2 && C.bits_out == 2 && C.nbits == 1 && C.depth == 32) || (C.nus == 4 && C.bits_out == 3 && C.nbits == 3 && C.depth == 21)) &&
+          v->nshifts == 1;
   for (int s = 0; v->q4 && s < kStates; ++s) {
-    const int ke = (T->pred[0][s] & 1) ? 1 : 0, ko = 1 - ke;
-    v->q4 = T->pred[ke][s] == 2 * (s & 31) && T->pred[ko][s] == 2 * (s & 31) + 1 && T->us[0][s] == (s >> 5) && T->us[1][s] == (s >> 5) &&
-            T->lab[ke][s] == q4::lab_even((unsigned)s) && T->lab[ko][s] == (q4::lab_even((unsigned)s) ^ 3u) &&
-            q4::lab_even((unsigned)s) == (q4::lab_even((unsigned)s & 15u) ^ q4::lab_even((unsigned)s & 48u));
-    for (int cs = 0; v->q4 && cs < 256; ++cs)
-      v->q4 = T->by_label[cs][s] == (cs == T->lab[0][s] ? 0 : cs == T->lab[1][s] ? 1 : 255);
+    for (int k = 0; v->q4 && k < C.nus; ++k) {
+      const unsigned e = (unsigned)T->pred[k][s] % (unsigned)C.nus;
+      const unsigned lab = C.nus == 2 ? q4::branch_label<2>((unsigned)s, e) : q4::branch_label<4>((unsigned)s, e);
+      const unsigned lin = C.nus == 2 ? q4::branch_label<2>((unsigned)s & 15u, e) ^ q4::branch_label<2>((unsigned)s & 48u, 0)
+                                      : q4::branch_label<4>((unsigned)s & 15u, e) ^ q4::branch_label<4>((unsigned)s & 48u, 0);
+      const unsigned us = C.nus == 2 ? q4::state_us<2>((unsigned)s) : q4::state_us<4>((unsigned)s);
+      v->q4 = T->pred[k][s] == (unsigned)C.nus * ((unsigned)s % (unsigned)(kStates / C.nus)) + e && T->us[k][s] == us && T->lab[k][s] == lab &&
+              lab == lin && (k == 0 || T->lab[k][s] > T->lab[k - 1][s]);
+    }
+    for (int cs = 0; v->q4 && cs < 256; ++cs) {
+      int want = 255;
+      for (int k = 0; k < C.nus; ++k) if (T->lab[k][s] == cs) want = k;
+      v->q4 = T->by_label[cs][s] == want;
+    }
   }
   LSDR_HIP(hipMalloc((void **)&v->d_T, sizeof(vit_tables)));
   LSDR_HIP(hipMemcpy(v->d_T, T, sizeof(vit_tables), hipMemcpyHostToDevice));
@@ -777,6 +863,7 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
   v->jobs_cap = v->totals_cap = v->chunk_cap = v->first_cap = 0;
   v->last_tiles = v->last_bad = 0;
   v->budget_chunks = (size_t)1 << 40;
+  v->q4_call = false;
   *out = v;
   return LSDR_OK;
 }
@@ -832,15 +919,23 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   // idle chip.
   unsigned TL = (unsigned)P;
   if (P >= 8) { TL = 8; while (TL < 32 && P % (int)(TL * 2) == 0) TL *= 2; }
+  bool q4_kernel = false;
   {
     static const int forced = getenv("LSDR_VIT_TL") ? atoi(getenv("LSDR_VIT_TL")) : 0;   // tuning hook
     static const int want_x2 = getenv("LSDR_VIT_WANT") ? atoi(getenv("LSDR_VIT_WANT")) : 0;   // tuning hook: wavefronts per SIMD, in halves
-    static const bool lane_kernel = getenv("LSDR_VIT_LANE") != nullptr || getenv("LSDR_VIT_GENERIC") != nullptr;
-    const bool q4 = v->q4 && !lane_kernel;
-    // 1.5 wavefronts per SIMD keep the chip busy with one tile per wavefront.  k_viterbi_q4 carries sixteen tiles per
-    // wavefront and is bound by instruction issue, not latency: what counts is the total number of trellis steps, so it
-    // keeps the long tiles (an eighth of the work is warm-up) down to one wavefront on every other SIMD
-    const size_t want = (size_t)c->num_cu * 4 * (size_t)(want_x2 > 0 ? want_x2 : q4 ? 1 : 3) / 2 * (q4 ? 12 : 1);
+    const bool lane_kernel = getenv("LSDR_VIT_LANE") != nullptr || getenv("LSDR_VIT_GENERIC") != nullptr;
+    const bool q4_always = getenv("LSDR_VIT_Q4") != nullptr;            // test hook: k_viterbi_q4 whatever the input length
+    // Which kernel.  k_viterbi_q4 carries sixteen tiles per wavefront and is bound by instruction issue (a wavefront alone on
+    // its SIMD already issues back to back; more wavefronts add nothing): what counts is the number of trellis steps and an
+    // even spread over the SIMDs, so it wants long tiles (an eighth of the work is warm-up at 32 chunks) and about one
+    // wavefront on every other SIMD (6144 tiles on 256 CUs) before it shortens them.  A call too short for that — fewer
+    // than 8 chunks per such tile — is a latency problem instead: the lane = state kernel, one tile per wavefront and 1.5
+    // wavefronts per SIMD, finishes it sooner (4 Mi symbols: 0.77 ms against 1.2; 32 Mi: 2.8 against 1.95).
+    const size_t want_q4 = (size_t)c->num_cu * 4 * (size_t)(want_x2 > 0 ? want_x2 : 1) / 2 * 12;
+    const bool q4 = v->q4 && !lane_kernel && (q4_always || chunks >= want_q4 * 8);
+    q4_kernel = q4;
+    v->q4_call = q4;
+    const size_t want = q4 ? want_q4 : (size_t)c->num_cu * 4 * (size_t)(want_x2 > 0 ? want_x2 : 3) / 2;
     const unsigned tl_min = q4 ? 4u : 1u;
     if (forced > 0) TL = (unsigned)forced;
     else while (TL > tl_min && TL % 2 == 0 && chunks / TL < want) TL /= 2;
@@ -878,6 +973,9 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   unsigned TLo = 4;
   for (unsigned t = 32; t >= 8; t /= 2)
     if ((size_t)(v->nsyncs - 1) * ((rs.size() + t - 1) / t) >= 1024) { TLo = t; break; }
+  // k_viterbi_q4 runs about one wavefront per SIMD and all of them at once: a call takes as long as its longest wavefront,
+  // so the other alignments' tiles (8 chunks of warm-up, the quality of every step on top) are kept no longer than the main ones
+  if (q4_kernel) while (TLo > 4 && (TLo + 8) * 23 > (TL + (unsigned)kWarm) * 22) TLo /= 2;
   // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
   // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in forty
   static const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook

@@ -225,8 +225,19 @@ def test_derandomizer_resync_and_drops(capi, ctx, oracle):
 
 
 # ------------------------------------------------------------------ viterbi_sync
+@pytest.fixture(params=["auto", "q4", "lane", "generic"])
+def vit_kernel(request, monkeypatch):
+    """viterbi.hip picks a kernel per call: the four-lanes-per-tile kernel (rates 1/2 and 2/3, long inputs), the lane = state
+    kernel, the generic table-driven one (every other rate).  The hooks force each of them on the same inputs."""
+    for k in ("LSDR_VIT_Q4", "LSDR_VIT_LANE", "LSDR_VIT_GENERIC"):
+        monkeypatch.delenv(k, raising=False)
+    if request.param != "auto":
+        monkeypatch.setenv({"q4": "LSDR_VIT_Q4", "lane": "LSDR_VIT_LANE", "generic": "LSDR_VIT_GENERIC"}[request.param], "1")
+    return request.param
+
+
 @pytest.mark.parametrize("tag,errp", CASES)
-def test_viterbi_golden(capi, ctx, tag, errp):
+def test_viterbi_golden(capi, ctx, tag, errp, vit_kernel):
     g = gold("fec.npz")
     sym = fec_input(hard_symbols(), errp)
     v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
@@ -241,7 +252,7 @@ def test_viterbi_golden(capi, ctx, tag, errp):
 
 @pytest.mark.parametrize("errp", [0, 40, 120, 300])
 @pytest.mark.parametrize("pipe", [None, 4096, 40000])
-def test_viterbi_vs_oracle_qpsk12(capi, ctx, oracle, errp, pipe):
+def test_viterbi_vs_oracle_qpsk12(capi, ctx, oracle, errp, pipe, vit_kernel):
     """Clean to hopeless inputs, several call patterns (the pipe size changes where calls start):
     the tiled decoder with seam verification reproduces the sequential reference exactly."""
     sym = fec_input(hard_symbols(), errp)
@@ -271,7 +282,7 @@ def test_viterbi_vs_oracle_qpsk12(capi, ctx, oracle, errp, pipe):
     assert bits_equal(got, want)
 
 
-def test_viterbi_alignment_search(capi, ctx, oracle):
+def test_viterbi_alignment_search(capi, ctx, oracle, vit_kernel):
     """Rotated / conjugated symbol streams make the decoder switch alignment (dvb.h:1401-1410)."""
     hard = hard_symbols()
     rot = np.array([2, 0, 3, 1], np.uint8)       # +90° relabelling
@@ -309,7 +320,42 @@ def test_viterbi_other_rates_vs_oracle(capi, ctx, oracle, cstln, rate):
     assert cons == wcons and cur == wcur and bits_equal(got, want)
 
 
-def test_viterbi_resync_period_1(capi, ctx, oracle):
+@pytest.mark.parametrize("seed,maxcost", [(5, 9000), (6, 3), (7, 32768)])
+def test_viterbi_8psk23_kernels_vs_oracle(capi, ctx, oracle, vit_kernel, seed, maxcost):
+    """8PSK 2/3 (config 5's code) on every kernel: random symbols, costs from near-ties (0…2) to the int16 extreme."""
+    rng = np.random.default_rng(seed)
+    n = 120000
+    sym = np.zeros(n, capi.SOFTSYM)
+    sym["symbol"] = rng.integers(0, 8, n)
+    sym["cost"] = np.maximum(-rng.integers(0, maxcost + 1, n), -32768)
+    v = capi.Viterbi(ctx, capi.PSK8, capi.FEC23)
+    got, cons = v.run_stream(sym)
+    cur = v.current_sync
+    v.close()
+    want, wcons, wcur = oracle.viterbi_sync(sym, 2, 1)
+    assert cons == wcons and cur == wcur and bits_equal(got, want)
+
+
+@pytest.mark.parametrize("maxcost", [1, 32768])
+def test_viterbi_qpsk12_extreme_costs(capi, ctx, oracle, vit_kernel, maxcost):
+    """Rate 1/2 with costs of 0/−1 only (ties on most states, the tie rule decides the survivors) and with the int16 extreme
+    (the scaled metrics of k_viterbi_q4 stay in range), positive costs included (they can never win, viterbi.h:222-231)."""
+    rng = np.random.default_rng(11)
+    n = 150000
+    sym = np.zeros(n, capi.SOFTSYM)
+    sym["symbol"] = rng.integers(0, 4, n)
+    c = -rng.integers(0, maxcost + 1, n)
+    c[::97] = 5                                   # a few positive costs
+    sym["cost"] = np.maximum(c, -32768)
+    v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
+    got, cons = v.run_stream(sym)
+    cur = v.current_sync
+    v.close()
+    want, wcons, wcur = oracle.viterbi_sync(sym, 1, 0)
+    assert cons == wcons and cur == wcur and bits_equal(got, want)
+
+
+def test_viterbi_resync_period_1(capi, ctx, oracle, vit_kernel):
     sym = fec_input(hard_symbols()[:80000], 40)
     v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12, resync_period=1)
     got, cons = v.run_stream(sym)
