@@ -135,15 +135,18 @@ template <int FMT> __device__ __forceinline__ typename in_stream<FMT>::type in_m
 //         past the last readable sample), the pair is picked with a 64-bit shift and converted with v_cvt_f32_ubyte*.
 template <int FMT> struct rx_window;
 template <> struct rx_window<LSDR_IN_CF32> {
-  float2 w0, w1, w2; int wn;
+  // samples wn and wn + 1 (what one linear interpolation reads), fetched by ONE 16-byte load: a tile walks its own part of
+  // the stream, so every load instruction of a wavefront touches 64 different cache lines — the texture-address unit's time,
+  // which fir_filter's streaming loads share, goes with the number of load instructions, not with their width
+  struct __attribute__((aligned(8))) pair { float ar, ai, br, bi; };
+  float2 w0, w1; int wn;
   __device__ __forceinline__ void load(const in_cf32 &b, int i, int n_last) {
-    w0 = b.p[i < n_last ? i : n_last]; w1 = b.p[i + 1 < n_last ? i + 1 : n_last]; w2 = b.p[i + 2 < n_last ? i + 2 : n_last]; wn = i;
+    const int k = i < n_last ? i : n_last - 1;           // (a tile span is ≥ 128 samples)
+    const pair v = *reinterpret_cast<const pair *>(b.p + k);
+    w1 = make_float2(v.br, v.bi); w0 = i < n_last ? make_float2(v.ar, v.ai) : w1; wn = i;   // beyond the span the last sample repeats
   }
-  __device__ __forceinline__ bool covers(int n) const { return (unsigned)(n - wn) <= 1u; }
-  __device__ __forceinline__ void get(int n, float2 &p0, float2 &p1) const {
-    const bool second = n != wn;
-    p0 = second ? w1 : w0; p1 = second ? w2 : w1;
-  }
+  __device__ __forceinline__ bool covers(int n) const { return n == wn; }
+  __device__ __forceinline__ void get(int, float2 &p0, float2 &p1) const { p0 = w0; p1 = w1; }
 };
 template <> struct rx_window<LSDR_IN_CU8> {
   unsigned long long w; int wn;
@@ -744,6 +747,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   unsigned last = 0;
   unsigned *const po = reinterpret_cast<unsigned *>(a.stage + (unsigned long long)j * a.stage_stride);
   unsigned *const pw = reinterpret_cast<unsigned *>(a.wstage + (unsigned long long)j * a.wstride);
+  unsigned *const pw0 = reinterpret_cast<unsigned *>(a.wstage + (unsigned long long)j0 * a.wstride);
   unsigned cnt = 0, got = 0;
   // LSDR_SYM_HARD2: the decisions only, packed (rx_tiling.h): the word being filled, the last 16 symbols, the row, the snapshot
   // of the tail at the end of the warm-up
@@ -768,7 +772,10 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
       hwarm = htail; hnwarm = got < 16u ? got : 16u;
     }
     const float samp_freqw = freqw;                       // sampler->update_freq(freqw), sdr.h:790
-    unsigned *dp = body ? po + cnt : pw;
+    // (the symbols of the earlier warm-up chunks are needed by nobody: every lane parks them on ONE word — the first one of the
+    // wavefront's first seam row, which that tile's last warm-up chunk rewrites — so that their stores cost the texture-address unit
+    // one cache line instead of 64)
+    unsigned *dp = body ? po + cnt : (lastwarm ? pw : pw0);
     const unsigned keep = (body || lastwarm) ? 1u : 0u;
     bool had = false;
     float2 sg = make_float2(0.f, 0.f), sv = make_float2(0.f, 0.f);
