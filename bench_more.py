@@ -514,6 +514,17 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
                     "flight; host_seconds_per_stage are busy times per thread (front | viterbi+mpeg_sync+rest)")
     out["pass"] = bool(out["ts_check"]["pass"] and (ref_check is None or ref_check["equal"]))
     alg_per_sample = 8.0 + 188.0 / (204 * 8 * sps * {capi.QPSK: 1.0, capi.PSK8: 0.5}.get(cstln, 1.0))     # cf32 in + TS out
+    # viterbi_sync's kernel (k_viterbi_q4 at these batch sizes) is bound by vector-instruction issue — one wave64 VALU instruction
+    # per 4 cycles and SIMD (SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction, profiles/r03_viterbi_q4.txt): `valu_issue`
+    # prices the trellis steps of the CURRENT alignment alone against 1024 SIMDs x 2.4 GHz / (instructions per tile step x 4
+    # cycles); the other alignments' resync chunks (3 of them for QPSK, 15 for 8PSK) and the tiles' warm-up come on top.
+    instr_per_tile_step = {capi.FEC12: 190 / 16.0, capi.FEC23: 590 / 16.0}.get(rate)
+    steps_per_s = nb * B / sps / dt
+    valu = None
+    if instr_per_tile_step:
+        peak_steps = 1024 * 2.4e9 / (instr_per_tile_step * 4.0)
+        valu = {"kernel": "k_viterbi_q4 (viterbi_sync, four lanes per tile, sixteen tiles per wavefront)", "instructions_per_tile_step": round(instr_per_tile_step, 2),
+                "peak_trellis_steps_per_s": round(peak_steps, 1), "achieved_trellis_steps_per_s": round(steps_per_s, 1), "frac": round(steps_per_s / peak_steps, 4)}
     if use_fir and fir_ms:
         n_launch_out = n_out + bench.EXTRA
         kb = n_launch_out * decim * 8 + n_launch_out * 8
@@ -521,20 +532,9 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
         out["roofline"] = {"kernel": "k_fir_persist (fir_filter)", "bound": "hbm", "achieved": round(B * alg_per_sample / (ms * 1e-3) / 1e9, 2), "peak": bench.HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(B * alg_per_sample / (ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
                            "algorithmic_bytes_per_launch": int(B * alg_per_sample), "kernel_bytes": kb, "traffic": None,
-                           "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample)}
+                           "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample), "viterbi_valu_issue": valu}
     else:
         st = vit.stats()
-        # viterbi_sync bounds this chain.  k_viterbi_q4 is bound by vector-instruction issue (one wave64 VALU instruction per
-        # 4 cycles and SIMD, measured: SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction): `valu_issue` prices the trellis
-        # steps of the CURRENT alignment alone against 1024 SIMDs x 2.4 GHz / (instructions per tile step x 4 cycles); the
-        # other alignments' resync chunks (15 of them for 8PSK) and the tiles' warm-up are on top of that.
-        instr_per_tile_step = {capi.FEC12: 190 / 16.0, capi.FEC23: 590 / 16.0}.get(rate)
-        steps_per_s = nb * B / sps / dt
-        valu = None
-        if instr_per_tile_step:
-            peak_steps = 1024 * 2.4e9 / (instr_per_tile_step * 4.0)
-            valu = {"instructions_per_tile_step": round(instr_per_tile_step, 2), "peak_trellis_steps_per_s": round(peak_steps, 1),
-                    "achieved_trellis_steps_per_s": round(steps_per_s, 1), "frac": round(steps_per_s / peak_steps, 4)}
         out["roofline"] = {"kernel": "k_viterbi_q4 (viterbi_sync, four lanes per tile, sixteen tiles per wavefront)",
                            "bound": "valu issue (64-state add-compare-select per symbol; not an HBM stream)",
                            "trellis_steps_per_s": round(steps_per_s, 1), "valu_issue": valu, "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample),

@@ -746,7 +746,9 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   // (test hooks, read at every call so that one process can exercise every kernel)
   const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;   // test hook: every mode through the generic path
   const bool lane_only = getenv("LSDR_VIT_LANE") != nullptr;         // test hook: rates 1/2 and 2/3 on the lane = state kernel
-  if (v->q4_call && !generic_only && !lane_only) {
+  // k_viterbi_q4 takes as long as its longest wavefront however few tiles there are; a launch of a few tiles (a fix-up round,
+  // a sequential re-run) is a latency problem and goes to the lane = state kernel, which walks one tile five times faster
+  if (v->q4_call && !generic_only && !lane_only && (up.size() >= 1024 || getenv("LSDR_VIT_Q4") != nullptr)) {
     a.q4_n_main = (unsigned)(n_main < up.size() ? n_main : up.size());
     a.q4_main_waves = (a.q4_n_main + 15u) / 16u;
     const unsigned other_waves = (a.njobs - a.q4_n_main + 15u) / 16u;
@@ -973,13 +975,15 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   unsigned TLo = 4;
   for (unsigned t = 32; t >= 8; t /= 2)
     if ((size_t)(v->nsyncs - 1) * ((rs.size() + t - 1) / t) >= 1024) { TLo = t; break; }
-  // k_viterbi_q4 runs about one wavefront per SIMD and all of them at once: a call takes as long as its longest wavefront,
-  // so the other alignments' tiles (8 chunks of warm-up, the quality of every step on top) are kept no longer than the main ones
-  if (q4_kernel) while (TLo > 4 && (TLo + 8) * 23 > (TL + (unsigned)kWarm) * 22) TLo /= 2;
   // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
-  // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in forty
-  static const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook
-  const unsigned Wo = wo_env > 0 ? (unsigned)wo_env : (unsigned)(kWarm < 8 ? 8 : kWarm);
+  // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in thirty, with 12
+  // none in the bench's streams.  A fix-up round is a second launch → readback on the critical path of the call whatever
+  // the number of tiles in it (c3: 9.0 ms per call with it, 7.6 without), so the long calls take 12.
+  const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook
+  const unsigned Wo = wo_env > 0 ? (unsigned)wo_env : q4_kernel ? 12u : (unsigned)(kWarm < 8 ? 8 : kWarm);
+  // k_viterbi_q4 runs about one wavefront per SIMD and all of them at once: a call takes as long as its longest wavefront,
+  // so the other alignments' tiles (their longer warm-up, the quality of every step on top) are kept no longer than the main ones
+  if (q4_kernel) while (TLo > 4 && (TLo + Wo) * 23 > (TL + (unsigned)kWarm) * 22) TLo /= 2;
   const unsigned nrs = (unsigned)rs.size();
   struct other_jobs { std::vector<vit_job> oj; std::vector<int> which, tile_first; unsigned ostride; };   // tile_first: index into rs
   auto build_others = [&](bool sequential, const std::vector<int> &only) {
@@ -1070,13 +1074,14 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   // tile's end state (exact by construction).
   size_t first_bad = n_main;
   for (size_t j = 1; j < n_main; ++j) if (bad[j]) { first_bad = j; break; }
-  std::vector<vit_state> main_first(n_main);   // state after the first chunk of each tile (alignment switches)
+  std::vector<vit_state> main_first;           // state after the first chunk of each tile (alignment switches); sized only on the sequential path
   bool main_first_on_device = false;
   if (first_bad < n_main) {
     for (size_t j = first_bad; j < n_main; ++j) v->last_bad += bad[j] ? 1u : 0u;
     // keep results of tiles < first_bad; redo the rest as ONE sequential job starting from end_states[first_bad-1]
     std::vector<vit_state> ends(n_main);
     LSDR_TRY(lsdr_stage_d2h(c, ends.data(), v->d_end, n_main * sizeof(vit_state)));
+    main_first.resize(n_main);
     LSDR_TRY(lsdr_stage_d2h(c, main_first.data(), v->d_first, n_main * sizeof(vit_state)));
     VIT_SYNC(c, vt);
     std::vector<vit_state> keep = v->states;
