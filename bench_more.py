@@ -515,7 +515,7 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     out["pass"] = bool(out["ts_check"]["pass"] and (ref_check is None or ref_check["equal"]))
     alg_per_sample = 8.0 + 188.0 / (204 * 8 * sps * {capi.QPSK: 1.0, capi.PSK8: 0.5}.get(cstln, 1.0))     # cf32 in + TS out
     # viterbi_sync's kernel (k_viterbi_q4 at these batch sizes) is bound by vector-instruction issue — one wave64 VALU instruction
-    # per 4 cycles and SIMD (SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction, profiles/r03_viterbi_q4.txt): `valu_issue`
+    # per 4 cycles and SIMD (SQ_ACTIVE_INST_VALU = 1 quad-cycle per instruction, profiles/r03_bench/viterbi_q4.txt): `valu_issue`
     # prices the trellis steps of the CURRENT alignment alone against 1024 SIMDs x 2.4 GHz / (instructions per tile step x 4
     # cycles); the other alignments' resync chunks (3 of them for QPSK, 15 for 8PSK) and the tiles' warm-up come on top.
     instr_per_tile_step = {capi.FEC12: 190 / 16.0, capi.FEC23: 590 / 16.0}.get(rate)

@@ -4,6 +4,7 @@
 #   kernel_stats.csv                rocprofv3 --kernel-trace --stats of the headline region (--no-more)
 #   pmc_fetch_size.csv, pmc_write_size.csv   one PMC counter per pass (rows of the fir kernel only) -> pmc_traffic.json
 #   timeline.csv, overlap.txt       kernel trace of a short run: fir stream occupancy, gaps, receiver kernels inside fir launches
+#   viterbi_q4.txt                  viterbi_sync alone: lane = state kernel against k_viterbi_q4, SQ counters of the latter
 # Copy what is to be judged into profiles/ afterwards (gpurun_out/ is scratch).
 set -u
 REPO=$(cd "$(dirname "$0")/.." && pwd)
@@ -74,6 +75,7 @@ PY
 cd "$REPO"
 env FIR_ALONE_REPS=1,20,400,4000,20 python tools/fir_alone.py > "$OUT/fir_alone.txt" 2>&1
 timeout 900 python tools/rx_tol_report.py > "$OUT/rx_tol_report.jsonl" 2>&1
+timeout 600 bash tools/vit_q4_report.sh "$OUT/viterbi_q4.txt" > /dev/null 2>&1   # viterbi_sync alone, both kernels + SQ counters
 bash tools/timeline.sh --no-more --no-verify --batches-per-step 8 > "$OUT/timeline.log" 2>&1
 cp gpurun_out/timeline.csv "$OUT/timeline.csv"; python tools/overlap.py "$OUT/timeline.csv" > "$OUT/overlap.txt" 2>&1; cat "$OUT/overlap.txt"
 ls -la "$OUT"
