@@ -666,6 +666,7 @@ struct lsdr_viterbi {
   size_t budget_chunks;               // chunks attempted per call: shrinks after an alignment switch, regrows
   bool q4;                            // rate 1/2 QPSK / 2/3 8PSK may use the four-lanes-per-tile kernel (trellis structure checked at create)
   bool q4_call;                       // ... and the current lsdr_viterbi_run call does
+  unsigned warm_others;               // warm-up chunks of the other alignments' tiles (grows when their seams fail)
 };
 
 static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
@@ -866,6 +867,7 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
   v->last_tiles = v->last_bad = 0;
   v->budget_chunks = (size_t)1 << 40;
   v->q4_call = false;
+  v->warm_others = 8;
   *out = v;
   return LSDR_OK;
 }
@@ -976,11 +978,13 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   for (unsigned t = 32; t >= 8; t /= 2)
     if ((size_t)(v->nsyncs - 1) * ((rs.size() + t - 1) / t) >= 1024) { TLo = t; break; }
   // warm-up of the other alignments' tiles: they decode a wrong alignment (noise-like input), whose survivors merge more
-  // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in thirty, with 12
-  // none in the bench's streams.  A fix-up round is a second launch → readback on the critical path of the call whatever
-  // the number of tiles in it (c3: 9.0 ms per call with it, 7.6 without), so the long calls take 12.
+  // slowly — with the main tiles' 4 chunks a third of their seams needed a fix-up round, with 8 about one in thirty on QPSK
+  // (none on 8PSK), with 12 none in the bench's streams.  A fix-up round is a second launch → readback on the critical path
+  // of the call whatever the number of tiles in it (c3: 9.0 ms per call with it, 5.5–6 without), a longer warm-up is a few per
+  // cent more trellis steps: the decoder starts at 8 and adds 4 (up to 16) whenever a call had to fix up seams of the other
+  // alignments.  (The output never depends on it.)
   const int wo_env = getenv("LSDR_VIT_WO") ? atoi(getenv("LSDR_VIT_WO")) : 0;   // tuning hook
-  const unsigned Wo = wo_env > 0 ? (unsigned)wo_env : q4_kernel ? 12u : (unsigned)(kWarm < 8 ? 8 : kWarm);
+  const unsigned Wo = wo_env > 0 ? (unsigned)wo_env : v->warm_others < (unsigned)kWarm ? (unsigned)kWarm : v->warm_others;
   // k_viterbi_q4 runs about one wavefront per SIMD and all of them at once: a call takes as long as its longest wavefront,
   // so the other alignments' tiles (their longer warm-up, the quality of every step on top) are kept no longer than the main ones
   if (q4_kernel) while (TLo > 4 && (TLo + Wo) * 23 > (TL + (unsigned)kWarm) * 22) TLo /= 2;
@@ -1059,6 +1063,8 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
         fj.push_back(j);
       }
     if (fj.empty()) break;
+    if (round == 0 && v->warm_others < 16)
+      for (const vit_job &j : fj) if (j.sync != cur) { v->warm_others += 4; break; }
     v->last_bad += (unsigned)fj.size();
     vt.fixups += (unsigned)fj.size();
     if (vt.on && round == 0) {       // LSDR_VIT_TIMING: which seams failed (slot, alignment, first chunk, chunks)
