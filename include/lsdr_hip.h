@@ -361,6 +361,10 @@ int lsdr_viterbi_set_resync_period(lsdr_viterbi *v, int period);   /* public mem
 int lsdr_viterbi_current_sync(const lsdr_viterbi *v);
 /* diagnostics of the last run: tiles decoded, seams that failed verification (re-decoded serially) */
 int lsdr_viterbi_stats(const lsdr_viterbi *v, unsigned *tiles, unsigned *bad_seams);
+/* host only (no GPU, no context): 1 if the trellis of (constellation, code rate) — built as trellis::init_convolutional does,
+ * viterbi.h:59-92 — has the structure the four-lanes-per-tile kernel relies on (long inputs of QPSK 1/2 and 8PSK 2/3 then
+ * use it; same bytes as every other kernel), 0 if not, -1 if viterbi_sync does not support the combination (dvb.h:1234-1331). */
+int lsdr_viterbi_q4_supported(int cstln, int rate);
 int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
                      size_t *consumed, size_t *produced);
 

@@ -187,6 +187,7 @@ _sig("lsdr_viterbi_destroy", None, [vp])
 _sig("lsdr_viterbi_set_resync_period", C.c_int, [vp, C.c_int])
 _sig("lsdr_viterbi_current_sync", C.c_int, [vp])
 _sig("lsdr_viterbi_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
+_sig("lsdr_viterbi_q4_supported", C.c_int, [C.c_int, C.c_int])
 _sig("lsdr_viterbi_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_mpeg_sync_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
 _sig("lsdr_mpeg_sync_destroy", None, [vp])

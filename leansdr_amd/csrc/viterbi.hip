@@ -690,6 +690,62 @@ static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
   return -1;
 }
 
+// trellis::init_convolutional (viterbi.h:59-92), branches of each state ordered by coded symbol.  Host only.
+static int vit_build_trellis(const vit_code &C, const unsigned short *polys, vit_tables *T) {
+  memset(T, 0, sizeof(*T));
+  memset(T->by_label, 255, sizeof(T->by_label));
+  int nG = 0;
+  while ((1 << nG) < C.ncs) ++nG;
+  struct br { int cs, pred, us; };
+  std::vector<br> all[kStates];
+  for (int s = 0; s < kStates; ++s)
+    for (int us = 0; us < C.nus; ++us) {
+      unsigned long long reg = (unsigned long long)s;
+      int us_rev = 0;
+      for (int b = 1; b < C.nus; b *= 2) if (us & b) us_rev |= (C.nus / 2 / b);
+      reg |= (unsigned long long)us_rev * kStates;
+      unsigned cs = 0;
+      for (int g = 0; g < nG; ++g) cs = (cs << 1) | (unsigned)__builtin_parityll(reg & polys[g]);
+      reg /= (unsigned)C.nus;
+      all[reg].push_back({(int)cs, s, us});
+    }
+  for (int s = 0; s < kStates; ++s) {
+    std::vector<br> &L = all[s];
+    for (size_t i = 0; i < L.size(); ++i) for (size_t j = i + 1; j < L.size(); ++j) if (L[j].cs < L[i].cs) { br t = L[i]; L[i] = L[j]; L[j] = t; }
+    if ((int)L.size() != C.nus) return -1;
+    for (int k = 0; k < C.nus; ++k) {
+      T->pred[k][s] = (unsigned char)L[k].pred; T->us[k][s] = (unsigned char)L[k].us; T->lab[k][s] = (unsigned char)L[k].cs;
+      T->by_label[L[k].cs][s] = (unsigned char)k;
+    }
+  }
+  return 0;
+}
+
+// k_viterbi_q4's assumptions, checked on the tables of the code at hand: the predecessors of state s are NUS·(s mod 64/NUS) + e,
+// all its branches store the same input symbol, branch e carries q4::branch_label(s, e), coded symbols are linear in (s & 15),
+// (s & 48) and e, and the branches are ordered by coded symbol.  Host only.
+static bool vit_q4_fits(const vit_code &C, int nshifts, const vit_tables *T) {
+  bool ok = ((C.nus == 2 && C.bits_out == 2 && C.nbits == 1 && C.depth == 32) || (C.nus == 4 && C.bits_out == 3 && C.nbits == 3 && C.depth == 21)) &&
+            nshifts == 1;
+  for (int s = 0; ok && s < kStates; ++s) {
+    for (int k = 0; ok && k < C.nus; ++k) {
+      const unsigned e = (unsigned)T->pred[k][s] % (unsigned)C.nus;
+      const unsigned lab = C.nus == 2 ? q4::branch_label<2>((unsigned)s, e) : q4::branch_label<4>((unsigned)s, e);
+      const unsigned lin = C.nus == 2 ? q4::branch_label<2>((unsigned)s & 15u, e) ^ q4::branch_label<2>((unsigned)s & 48u, 0)
+                                      : q4::branch_label<4>((unsigned)s & 15u, e) ^ q4::branch_label<4>((unsigned)s & 48u, 0);
+      const unsigned us = C.nus == 2 ? q4::state_us<2>((unsigned)s) : q4::state_us<4>((unsigned)s);
+      ok = T->pred[k][s] == (unsigned)C.nus * ((unsigned)s % (unsigned)(kStates / C.nus)) + e && T->us[k][s] == us && T->lab[k][s] == lab &&
+           lab == lin && (k == 0 || T->lab[k][s] > T->lab[k - 1][s]);
+    }
+    for (int cs = 0; ok && cs < 256; ++cs) {
+      int want = 255;
+      for (int k = 0; k < C.nus; ++k) if (T->lab[k][s] == cs) want = k;
+      ok = T->by_label[cs][s] == want;
+    }
+  }
+  return ok;
+}
+
 static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
                       unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr,
                       const vit_state *dev_start_states = nullptr, bool keep_slots = false, size_t n_slots = 0,
@@ -799,58 +855,9 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
       v->maps[(size_t)s * 256 + i] = tab.symbol[(size_t)(uint8_t)RI * 256 + (uint8_t)RQ];
     }
   }
-  // trellis (viterbi.h:59-92), branches of each state ordered by coded symbol
   vit_tables *T = new vit_tables();
-  memset(T, 0, sizeof(*T));
-  memset(T->by_label, 255, sizeof(T->by_label));
-  int nbr[kStates] = {0};
-  int nG = 0;
-  while ((1 << nG) < C.ncs) ++nG;
-  struct br { int cs, pred, us; };
-  std::vector<br> all[kStates];
-  for (int s = 0; s < kStates; ++s)
-    for (int us = 0; us < C.nus; ++us) {
-      unsigned long long reg = (unsigned long long)s;
-      int us_rev = 0;
-      for (int b = 1; b < C.nus; b *= 2) if (us & b) us_rev |= (C.nus / 2 / b);
-      reg |= (unsigned long long)us_rev * kStates;
-      unsigned cs = 0;
-      for (int g = 0; g < nG; ++g) cs = (cs << 1) | (unsigned)__builtin_parityll(reg & polys[g]);
-      reg /= (unsigned)C.nus;
-      all[reg].push_back({(int)cs, s, us});
-    }
-  for (int s = 0; s < kStates; ++s) {
-    std::vector<br> &L = all[s];
-    for (size_t i = 0; i < L.size(); ++i) for (size_t j = i + 1; j < L.size(); ++j) if (L[j].cs < L[i].cs) { br t = L[i]; L[i] = L[j]; L[j] = t; }
-    if ((int)L.size() != C.nus) { delete T; delete v; lsdr_set_error("viterbi_sync: invalid convolutional code"); return LSDR_E_ARG; }
-    for (int k = 0; k < C.nus; ++k) {
-      T->pred[k][s] = (unsigned char)L[k].pred; T->us[k][s] = (unsigned char)L[k].us; T->lab[k][s] = (unsigned char)L[k].cs;
-      T->by_label[L[k].cs][s] = (unsigned char)k;
-    }
-    nbr[s] = C.nus;
-  }
-  (void)nbr;
-  // k_viterbi_q4's assumptions, checked on the tables just built: the predecessors of state s are NUS·(s mod 64/NUS) + e, all
-  // its branches store the same input symbol, branch e carries q4::branch_label(s, e), coded symbols are linear in (s & 15),
-  // (s & 48) and e, and the branches are ordered by coded symbol
-  v->q4 = ((C.nus == 2 && C.bits_out == 2 && C.nbits == 1 && C.depth == 32) || (C.nus == 4 && C.bits_out == 3 && C.nbits == 3 && C.depth == 21)) &&
-          v->nshifts == 1;
-  for (int s = 0; v->q4 && s < kStates; ++s) {
-    for (int k = 0; v->q4 && k < C.nus; ++k) {
-      const unsigned e = (unsigned)T->pred[k][s] % (unsigned)C.nus;
-      const unsigned lab = C.nus == 2 ? q4::branch_label<2>((unsigned)s, e) : q4::branch_label<4>((unsigned)s, e);
-      const unsigned lin = C.nus == 2 ? q4::branch_label<2>((unsigned)s & 15u, e) ^ q4::branch_label<2>((unsigned)s & 48u, 0)
-                                      : q4::branch_label<4>((unsigned)s & 15u, e) ^ q4::branch_label<4>((unsigned)s & 48u, 0);
-      const unsigned us = C.nus == 2 ? q4::state_us<2>((unsigned)s) : q4::state_us<4>((unsigned)s);
-      v->q4 = T->pred[k][s] == (unsigned)C.nus * ((unsigned)s % (unsigned)(kStates / C.nus)) + e && T->us[k][s] == us && T->lab[k][s] == lab &&
-              lab == lin && (k == 0 || T->lab[k][s] > T->lab[k - 1][s]);
-    }
-    for (int cs = 0; v->q4 && cs < 256; ++cs) {
-      int want = 255;
-      for (int k = 0; k < C.nus; ++k) if (T->lab[k][s] == cs) want = k;
-      v->q4 = T->by_label[cs][s] == want;
-    }
-  }
+  if (vit_build_trellis(C, polys, T)) { delete T; delete v; lsdr_set_error("viterbi_sync: invalid convolutional code"); return LSDR_E_ARG; }
+  v->q4 = vit_q4_fits(C, v->nshifts, T);
   LSDR_HIP(hipMalloc((void **)&v->d_T, sizeof(vit_tables)));
   LSDR_HIP(hipMemcpy(v->d_T, T, sizeof(vit_tables), hipMemcpyHostToDevice));
   delete T;
@@ -870,6 +877,22 @@ int lsdr_viterbi_create(lsdr_ctx *c, int cstln, int rate, lsdr_viterbi **out) {
   v->warm_others = 8;
   *out = v;
   return LSDR_OK;
+}
+
+int lsdr_viterbi_q4_supported(int cstln, int rate) {
+  vit_code C;
+  const unsigned short *polys = nullptr;
+  if (vit_code_for(rate, &C, &polys)) return -1;
+  lsdr::cstln_tables tab;
+  if (lsdr::build_cstln(cstln, rate, tab) < 0) return -1;
+  int bps = 0;
+  while ((1 << (bps + 1)) <= tab.nsymbols) ++bps;
+  if (bps * (C.bits_out / bps) != C.bits_out) return -1;
+  vit_tables *T = new vit_tables();
+  const int bad = vit_build_trellis(C, polys, T);
+  const bool ok = !bad && vit_q4_fits(C, C.bits_out / bps, T);
+  delete T;
+  return bad ? -1 : ok ? 1 : 0;
 }
 
 void lsdr_viterbi_destroy(lsdr_viterbi *v) {

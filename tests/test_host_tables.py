@@ -19,6 +19,19 @@ def test_unsupported_code_rate_is_an_error(capi):
         capi.cstln_lut(capi.APSK16, capi.FEC12)   # "Code rate not supported with APSK16", dvb.h:60
 
 
+def test_viterbi_quad_kernel_trellis_check(capi):
+    """(CPU) lsdr_viterbi_q4_supported builds the trellis like trellis::init_convolutional (viterbi.h:59-92) and checks the
+    structure k_viterbi_q4 relies on (predecessor registers, input symbols, coded symbols linear in the state bits, branch order):
+    it must hold for the two codes the kernel is instantiated for, fail for every other rate, and report unsupported pairs."""
+    sup = capi.lib.lsdr_viterbi_q4_supported
+    assert sup(capi.QPSK, capi.FEC12) == 1 and sup(capi.PSK8, capi.FEC23) == 1
+    for cstln, rate in [(capi.QPSK, capi.FEC34), (capi.QPSK, capi.FEC56), (capi.QPSK, capi.FEC78), (capi.QPSK, capi.FEC46),
+                        (capi.BPSK, capi.FEC12), (capi.APSK16, capi.FEC34), (capi.QAM64, capi.FEC56)]:
+        assert sup(cstln, rate) == 0, (cstln, rate)
+    assert sup(capi.QPSK, capi.FEC23) == -1      # 3 coded bits do not fill QPSK symbols (dvb.h:1243)
+    assert sup(capi.QPSK, capi.FEC910) == -1     # not a DVB-S code rate
+
+
 def test_filtergen(capi, oracle):
     g = gold("tables.npz")
     assert bits_equal(capi.lowpass(312, float(g["lowpass_c2_fcut"])), g["lowpass_c2"])
