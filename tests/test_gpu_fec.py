@@ -355,6 +355,38 @@ def test_viterbi_qpsk12_extreme_costs(capi, ctx, oracle, vit_kernel, maxcost):
     assert cons == wcons and cur == wcur and bits_equal(got, want)
 
 
+@pytest.mark.parametrize("cstln,rate,errp", [(1, 0, 40), (1, 0, 250), (2, 1, 0)])
+def test_viterbi_long_call_picks_the_quad_kernel(capi, ctx, oracle, cstln, rate, errp, monkeypatch):
+    """A call of 7.3 Mi symbols is long enough for lsdr_viterbi_run to choose k_viterbi_q4 by itself (≥ 48 Ki chunks): 8192+ tiles
+    of the current alignment plus the other alignments' tiles in one launch, the 16-bits-at-a-time output path on the clean
+    stretches and the best-state search on the noisy ones (250 ‰ symbol errors keep the decoder switching alignments, so the
+    look-ahead budget and the lane-kernel fix-up launches run too).  Same bytes as the sequential oracle."""
+    for k in ("LSDR_VIT_Q4", "LSDR_VIT_LANE", "LSDR_VIT_GENERIC"):
+        monkeypatch.delenv(k, raising=False)
+    if cstln == 1:
+        sym = fec_input(np.tile(hard_symbols(), 41), errp)
+    else:
+        # a locked 8PSK 2/3 stream: the GPU transmit chain and receiver make one framed period of soft symbols (as tools/vit_alone.py)
+        import bench_more
+        x, _ = bench_more.framed_period(capi, ctx, capi.PSK8, capi.FEC23, 4, 24.0, seed=3)
+        rx = capi.CstlnReceiver(ctx, sampler=capi.SAMP_LINEAR, cstln=capi.PSK8, fec=capi.FEC23, omega=4.0, pll_adjustment=1 / 6.0)
+        o = rx.run(np.tile(x * np.float32(75.0), 6), meas=False)
+        rx.close()
+        one = o["sym"][len(o["sym"]) // 3:]
+        per = len(x) // 4
+        one = one[: len(one) // per * per]
+        sym = np.tile(one, (49152 * 128 + 200000) // len(one) + 1)
+    assert len(sym) >= 49152 * 128
+    v = capi.Viterbi(ctx, cstln, rate)
+    got, cons = v.run_stream(sym)
+    cur, st = v.current_sync, v.stats()
+    v.close()
+    want, wcons, wcur = oracle.viterbi_sync(sym, cstln, rate)
+    assert cons == wcons and cur == wcur and bits_equal(got, want)
+    if errp < 100:
+        assert st["tiles"] >= 1024          # (a locked stream goes through in one long call)
+
+
 def test_viterbi_resync_period_1(capi, ctx, oracle, vit_kernel):
     sym = fec_input(hard_symbols()[:80000], 40)
     v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12, resync_period=1)
