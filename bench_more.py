@@ -568,7 +568,7 @@ def c3(capi, synth, device, args):
 
 def c5_rescoped(capi, synth, device, args):
     # batch: 128 Mi symbols per viterbi_sync call let k_viterbi_q4 keep 32-chunk tiles on every SIMD (64 Mi samples per batch
-    # 9.7 GS/s — the lane = state kernel does 11.2 there —, 256 Mi 15.1, 512 Mi 18–19, 1 Gi 14.8)
+    # 9.7 GS/s — the lane = state kernel does 11.2 there —, 256 Mi 15.1, 512 Mi 17–20, 1 Gi 14.8)
     return full_chain(capi, synth, device, args, capi.PSK8, capi.FEC23, 4, False, int(os.environ.get("LSDR_C5_BATCH_MSAMPLES", 512)),
                       "8PSK 2/3 @ 4 sps cf32 (30 MS/s symbols = 120 MS/s input): cstln_receiver(PSK8, tiled) -> viterbi_sync(2/3) -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                       ["--f32", "--float-scale", "1", "-f", "120e6", "--sr", "30000e3", "--const", "8PSK", "--cr", "2/3", "--anf", "0", "--viterbi"])
