@@ -455,6 +455,11 @@ def main():
         return
 
     if args.workload == "c1":
+        # 16 worker streams: by default the HIP runtime multiplexes a process's streams onto 4 hardware queues, and two
+        # captures whose kernels share a queue run one after the other.  One queue per worker: 123 -> 139 GS/s.  (The C2 pipeline
+        # is the other way round — 5 streams, and 8 queues let the receivers crowd the filter: 495 -> 436 GS/s — so this is set
+        # for this workload only, before the runtime initialises.)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         import leansdr_amd.capi as capi
         import bench_c1
         if capi.lib.lsdr_device_count() <= local_rank:

@@ -575,33 +575,44 @@ def c5_rescoped(capi, synth, device, args):
 
 
 def c1(capi, synth, device, args):
-    """BASELINE config 1 / 4 on one GPU: bench_c1.py's job (bench.py --workload c1 is the same thing as its own line, and the
-    multi-GPU form of config 4)."""
-    import bench_c1
-    job = bench_c1.C1Job(capi, device, 16, 128, 16, 2048, 512, seed0=1000)
-    t0 = time.perf_counter()
-    job.run(1)
-    steps = batches_for(time.perf_counter() - t0, lo=3)
-    consumed, dt, calls = timed_at_least(lambda: job.run(steps, timed=True), lambda: None)
-    steps *= calls
-    kms, klaunch = job.tile_kernel_ms()
-    alg = bench_c1.ALG_BYTES_PER_SAMPLE
-    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), steps=steps, captures=len(job.caps), workers=len(job.workers),
-               samples_per_capture=job.n, ts_packets_per_capture=job.n_ts[0], rs_byte_errors_corrected=sum(w.stats["errs"] for w in job.workers),
+    """BASELINE config 1 / 4 on one GPU = `bench.py --workload c1` (also its own line, and with --gpus N the multi-GPU form of
+    config 4), run as a process of its own: its 16 worker streams want 16 hardware queues (GPU_MAX_HW_QUEUES, read when the HIP
+    runtime initialises: 123 -> 139 GS/s), which this process — the C2 pipeline, best with the default 4 — cannot switch to."""
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--no-cpu", "--steps", "45", "--warmup", "2"]
+    if args.no_verify:
+        cmd.append("--no-verify")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if not lines:
+        return dict(value=None, unit="MS/s", **{"pass": False}, error=(r.stderr or r.stdout)[-1500:])
+    j = json.loads(lines[-1])
+    out = dict(value=j["value"], unit="MS/s", seconds=round(j["steps"] * j["ms_per_step"] / 1e3, 3), steps=j["steps"], ms_per_step=j["ms_per_step"],
+               captures=j["config"]["captures_per_gpu"], workers=j["config"]["workers_per_gpu"], samples_per_capture=j["config"]["samples_per_capture"],
+               ts_packets_per_capture=j["config"].get("ts_packets_per_capture"), rs_byte_errors_corrected=j["config"].get("rs_byte_errors_corrected"),
                chain="cconverter<u8> (fused) + cstln_receiver(linear, tiled, packed decisions) -> deconvol_sync -> mpeg_sync -> deinterleaver -> rs_decoder "
                      "-> derandomizer -> TS in host memory; every decode starts from reset blocks (acquisition included)",
-               roofline={"kernel": "k_rx_tiles<linear, cu8, LDS-staged, packed> (cstln_receiver tolerance tiles)", "bound": "hbm", "peak": HBM, "unit": "GB/s",
-                         "achieved": round(consumed / dt * alg / 1e9, 2), "frac": hbm_frac(consumed / dt, alg), "hbm_frac": hbm_frac(consumed / dt, alg),
-                         "algorithmic_bytes_per_sample": round(alg, 4), "tile_kernel_avg_launch_ms": round(kms, 4), "launches_timed": klaunch,
-                         "traffic": None, "traffic_source": "profiles/r03_bench/c1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)",
-                         "note": "whole-job rate on the algorithmic bytes (up to 16 tile launches share the chip: a single launch's duration is "
-                                 "not the chip's rate); the receiver is an issue/latency-bound recurrence, not an HBM stream"})
-    if not args.no_verify:
-        out["verified"] = job.verify()
-        out["pass"] = out["verified"]["pass"]
-        out["verified"]["per_capture"] = out["verified"]["per_capture"][:2] + [{"...": f"{len(job.caps) - 2} more, all in `pass`"}]
-    job.close()
+               mode="`bench.py --workload c1 --no-cpu --steps 45` in a process of its own (GPU_MAX_HW_QUEUES=16), exit code %d" % r.returncode)
+    rl = dict(j["roofline"])
+    rl["tile_kernel_avg_launch_ms"] = rl.pop("avg_launch_ms", None)
+    rl["achieved"] = round(j["value"] * 1e6 * bench_alg_c1() / 1e9, 2)
+    rl["frac"] = rl["hbm_frac"] = hbm_frac(j["value"] * 1e6, bench_alg_c1())
+    rl["traffic_source"] = "profiles/r03_bench/c1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    out["roofline"] = rl
+    if "verified" in j:
+        v = j["verified"]
+        out["pass"] = bool(v["pass"]) and r.returncode == 0
+        v["per_capture"] = v["per_capture"][:2] + [{"...": f"{len(v['per_capture']) - 2} more, all in `pass`"}]
+        out["verified"] = v
+    else:
+        out["pass"] = r.returncode == 0
     return out
+
+
+def bench_alg_c1():
+    import bench_c1
+    return bench_c1.ALG_BYTES_PER_SAMPLE
 
 
 def c1_hs(capi, synth, device, args, hs=True):
