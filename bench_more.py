@@ -829,7 +829,7 @@ def exact_batch(capi, synth, device, args):
     po = bench._oracle()
     lib = capi.lib
     ctx = capi.Ctx(device)
-    n_streams, L = int(os.environ.get("LSDR_EXACT_STREAMS", 65536)), 128 * 1024
+    n_streams, L = int(os.environ.get("LSDR_EXACT_STREAMS", 65536)), int(os.environ.get("LSDR_EXACT_KSAMPLES", 128)) * 1024
     period = 32 << 20                                   # clean baseband period (samples) the captures are cut from
     gen = bench_c1.Generator(capi, ctx, period + 2 * L, 1)
     total = n_streams * L + L
