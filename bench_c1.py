@@ -135,15 +135,22 @@ class Worker:
     def __init__(self, capi, device, n_samples, tile, warm):
         self.capi, self.n = capi, n_samples
         ctx = self.ctx = capi.Ctx(device)
-        self.rx = capi.CstlnReceiver(ctx, sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, fec=capi.FEC12, omega=OMEGA, meas_decimation=int(FS / 5),
-                                     mode=capi.RX_TILED, tile_len=tile, tile_warmup=warm, in_format=capi.IN_CU8, out_format=capi.SYM_HARD2)
+        self.sym_cap = int(n_samples * 0.94) + 65536          # the tiled run reserves ⌈128/(omega−0.1)⌉+3 symbol slots per chunk
+        # Two receiver fronts (own stream, own receiver, own packed-symbol buffer each): the receiver of the worker's NEXT capture is
+        # queued before the FEC tail of the current one starts, so the tail's data-dependent host round trips never leave this
+        # worker without a tile kernel on the GPU.  fronts = 1: one capture at a time (LSDR_C1_FRONTS).
+        self.fronts = []
+        for i in range(max(1, int(os.environ.get("LSDR_C1_FRONTS", 2)))):
+            fc = ctx if i == 0 else capi.Ctx(device)
+            rx = capi.CstlnReceiver(fc, sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, fec=capi.FEC12, omega=OMEGA, meas_decimation=int(FS / 5),
+                                    mode=capi.RX_TILED, tile_len=tile, tile_warmup=warm, in_format=capi.IN_CU8, out_format=capi.SYM_HARD2)
+            self.fronts.append(dict(ctx=fc, rx=rx, d_words=fc.alloc(self.sym_cap // 4 + 256), consumed=0, t0=0.0))
+        self.rx = self.fronts[0]["rx"]
         self.dec = capi.Deconv(ctx, capi.FEC12)
         self.msync = capi.MpegSync(ctx)
         self.derand = capi.Derandomizer(ctx)
-        self.sym_cap = int(n_samples * 0.94) + 65536          # the tiled run reserves ⌈128/(omega−0.1)⌉+3 symbol slots per chunk
         self.byte_cap = self.sym_cap // 8 + 65536
         self.pk_cap = self.byte_cap // 204 + 64
-        self.d_words = ctx.alloc(self.sym_cap // 4 + 256)
         self.d_bytes = ctx.alloc(self.byte_cap)
         self.d_mpeg = ctx.alloc(self.byte_cap)
         self.d_rs = ctx.alloc(self.pk_cap * 204)
@@ -152,21 +159,33 @@ class Worker:
         self.stats = dict(bits=0, errs=0, next_sync=0, jobs=0)
         self.t_stage = dict(receiver=0.0, deconv_sync=0.0, rs_derand=0.0)
 
+    def start(self, slot, d_iq):
+        """Queue the receiver of one capture (first sample to packed decisions) on front `slot`."""
+        f = self.fronts[slot]
+        f["t0"] = time.perf_counter()
+        f["rx"].reset()
+        f["consumed"] = f["rx"].run_async_hs2(d_iq.ptr, self.n, f["d_words"].ptr, 0, self.sym_cap)
+
     def decode(self, d_iq, h_ts_ptr, h_ts_cap):
         """One capture, first sample to TS in host memory.  Returns (TS packets, samples consumed by the receiver)."""
+        self.start(0, d_iq)
+        return self.finish(0, h_ts_ptr, h_ts_cap)
+
+    def finish(self, slot, h_ts_ptr, h_ts_cap):
+        """The FEC tail of the capture whose receiver was queued on front `slot`: packed decisions to TS in host memory."""
         capi, lib, ctx = self.capi, self.capi.lib, self.ctx
-        t0 = time.perf_counter()
-        self.rx.reset(); self.dec.reset(); self.msync.reset()
+        f = self.fronts[slot]
+        d_words, consumed, t0 = f["d_words"], f["consumed"], f["t0"]
+        self.dec.reset(); self.msync.reset()
         capi.check(lib.lsdr_derandomizer_reset(self.derand.h))
-        consumed = self.rx.run_async_hs2(d_iq.ptr, self.n, self.d_words.ptr, 0, self.sym_cap)
-        nsym = self.rx.wait()
+        nsym = f["rx"].wait()
         t1 = time.perf_counter()
         # deconvol_sync ↔ mpeg_sync: until mpeg_sync has locked the deconvolver is given small windows (the reference's pipe
         # sizes bound how far it runs ahead of a next_sync(), leandvb.cc:185-202); once locked, the rest of the capture in one call
         pos = bw = br = mw = 0
         while True:
             cap = self.byte_cap - bw if self.msync.locked else min(65536, self.byte_cap - bw)
-            c, p = self.dec.run_dev_hs2(self.d_words.ptr, pos, nsym - pos, self.d_bytes.at(bw), cap)
+            c, p = self.dec.run_dev_hs2(d_words.ptr, pos, nsym - pos, self.d_bytes.at(bw), cap)
             if not p:
                 break
             pos += c; bw += p
@@ -197,9 +216,13 @@ class Worker:
 
     def close(self):
         self.ctx.sync()
-        self.rx.close(); self.dec.close(); self.msync.close(); self.derand.close()
-        for d in (self.d_words, self.d_bytes, self.d_mpeg, self.d_rs, self.d_rts, self.d_ts):
+        for f in self.fronts:
+            f["ctx"].sync(); f["rx"].close(); f["d_words"].free()
+        self.dec.close(); self.msync.close(); self.derand.close()
+        for d in (self.d_bytes, self.d_mpeg, self.d_rs, self.d_rts, self.d_ts):
             d.free()
+        for f in self.fronts[1:]:
+            f["ctx"].close()
         self.ctx.close()
 
 
@@ -233,23 +256,29 @@ class C1Job:
 
         def work(w):
             try:
+                pending, turn = None, 0       # (capture, front) whose receiver is queued and whose tail is still to run
                 while True:
                     with lock:
                         i = nxt[0]; nxt[0] += 1
-                    if i >= len(jobs) or failure:
+                    cur = None
+                    if i < len(jobs) and not failure:
+                        _, k = jobs[i]
+                        slot = turn % len(w.fronts); turn += 1
+                        if pending is not None and pending[1] == slot:      # a single front: finish before it is reused
+                            self._finish(w, pending, timed, lock, total); pending = None
+                        w.start(slot, self.caps[k])
+                        cur = (k, slot)
+                    if pending is not None:
+                        self._finish(w, pending, timed, lock, total)
+                    pending = cur
+                    if cur is None:
                         return
-                    _, k = jobs[i]
-                    n_ts, cons = w.decode(self.caps[k], self.h_ts[k], self.ts_cap)
-                    self.n_ts[k] = n_ts
-                    if timed:
-                        self.counts[k].append(n_ts)
-                    with lock:
-                        total[0] += cons
             except BaseException as e:
                 failure.append(e)
         if timed:
             for w in self.workers:
-                w.rx.tile_time(True)
+                for f in w.fronts:
+                    f["rx"].tile_time(True)
         ths = [threading.Thread(target=work, args=(w,)) for w in self.workers]
         for t in ths:
             t.start()
@@ -261,11 +290,21 @@ class C1Job:
             raise failure[0]
         return total[0]
 
+    def _finish(self, w, pend, timed, lock, total):
+        k, slot = pend
+        n_ts, cons = w.finish(slot, self.h_ts[k], self.ts_cap)
+        self.n_ts[k] = n_ts
+        if timed:
+            self.counts[k].append(n_ts)
+        with lock:
+            total[0] += cons
+
     def tile_kernel_ms(self):
         ms, n = 0.0, 0
         for w in self.workers:
-            a, b = w.rx.tile_time(False)
-            ms += a * b; n += b
+            for f in w.fronts:
+                a, b = f["rx"].tile_time(False)
+                ms += a * b; n += b
         return (ms / n if n else 0.0), n
 
     def ts_of(self, k):
