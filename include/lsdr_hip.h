@@ -195,7 +195,10 @@ int lsdr_spectrum_run(lsdr_spectrum *s, const lsdr_cf32 *in, size_t n_in, float 
 enum { LSDR_IN_CF32 = 0, LSDR_IN_CU8 = 1 };
 enum {
   LSDR_FIR_EXACT = 0, /* reference arithmetic: i-ascending accumulation, no FMA contraction → bit-exact */
-  LSDR_FIR_FMA = 1    /* same order, fused multiply-add (≤ 1 ulp/tap differences; tolerance-tested) */
+  LSDR_FIR_FMA = 1,   /* same order, fused multiply-add (≤ 1 ulp/tap differences; tolerance-tested) */
+  LSDR_FIR_MFMA = 2   /* LSDR_FIR_FMA's arithmetic, bit for bit, on the f32 matrix pipe (v_mfma_f32_16x16x4_f32 is an exact
+                       * k-ordered fmaf chain): the taps as a banded Toeplitz block, sixteen outputs per row group.  cf32 input
+                       * at the decimations with a compile-time kernel; anything else runs LSDR_FIR_FMA's kernels (same bits). */
 };
 typedef struct {
   unsigned ncoeffs;          /* fir_filter ctor _ncoeffs */

@@ -65,6 +65,9 @@ struct fir_args {
   const void *ins[8];
   float2 *outs[8];
   float in_scale;        // 1.0f → none
+  // k_fir_mfma: coefficient operand table (zero-padded, lsdr_fir_filter::d_atab), its length, blocks of four MFMA steps
+  const float *mf_atab;
+  unsigned mf_alen, mf_blocks;
   unsigned long long *trace;   // LSDR_FIR_TRACE builds: per-wave phase cycle sums
 };
 
@@ -379,7 +382,264 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
 #endif
 }
 
+// ---- LSDR_FIR_MFMA: the decimating FIR on the f32 matrix pipe -----------------------
+// The tap phase of k_fir_persist is bound by LDS-read + VALU issue (one ds_read_b64 and two packed operations per tap per
+// lane, profiles/r03); the matrix pipe is idle chip-wide.  v_mfma_f32_16x16x4_f32 is exact f32 — D = fma(a3,b3, fma(a2,b2,
+// fma(a1,b1, fma(a0,b0, C)))) with one rounding per product — so a chain of them over a K axis that walks the taps in the
+// reference's order (i ascending) gives, bit for bit, what LSDR_FIR_FMA's per-lane fmaf chain gives.  The product is shaped as
+// a banded Toeplitz block:
+//     rows    i  = 16 consecutive outputs m = m0 + 16·G + i of "group" G,
+//     columns    = 8 groups × {re, im}  (one wavefront: 128 complex outputs, ONE 16×16 accumulator tile = 4 VGPRs),
+//     K slot t'  = (15 − i)·D + tap index  →  A[i][t'] = c[t' − (15−i)·D] (0 outside the taps), B[t'][G,c] = x_c[top_G − t'],
+// 15·D + N slots (764 at C2: 191 MFMAs per 128 outputs; 41 % of the multiplies hit the zero band — the price of having one
+// filter, not sixteen).  Zero slots are exact no-ops (fma(0, x, acc) = acc for finite x and acc ≠ −0).
+// Per MFMA a lane fetches ONE dword of samples and ONE dword of coefficients from LDS (0.5 B per useful multiply-add where the
+// VALU kernel reads 4), and no VALU instruction at all — the receiver's tile waves get the vector ALUs.
+//
+// LDS holds the tile's samples in "u-space": u = TOP − n counts samples DOWN from the newest sample of the tile (n = tile-local
+// sample index), plain interleaved (re, im), 4 floats of padding after every 16·D samples so that the eight groups of a
+// wavefront (group stride 16·D samples = 32·D floats ≡ 0 mod 32 banks) fall on different banks: conflict-free ds_read_b32.
+// Anchoring at the top makes the walk independent of N: lane (k = l>>4, col = l&15 → g = col>>1, c = col&1) reads float
+// 2·u + 4·⌊u/16D⌋ + c at u = 16·G'·D + 4·s + k (G' counts groups from the top), i.e. base + 32 B per MFMA step, +16 B once per
+// D blocks of four steps.  The coefficient operand comes from a zero-padded linear table cz'[4·s + k + i·D] (LDS, written
+// once per workgroup).
+//
+// CP = 1 (complex shifted taps, current_freq ≠ 0): two K slots per tap — (cr, x_c) then (−ci, x_{1−c}) with the sign of the
+// im column's second sample flipped — the same chain as LSDR_FIR_FMA's complex kernel
+//     re: fma(−ci, xi, fma(cr, xr, acc))     im: fma(ci, xr, fma(cr, xi, acc)) = fma(−ci, −xr, fma(cr, xi, acc)).
+// Staging, prefetch of the next tile into registers during the MFMA phase, persistence and the XCD-aware tile walk are
+// k_fir_persist's.  W = wavefronts per workgroup (tile = 128·W outputs; LDS ≈ 8·D·128·W bytes).
+typedef float lsdr_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned lsdr_v4u __attribute__((ext_vector_type(4)));
+
+#ifndef LSDR_MFMA_PARTS
+#define LSDR_MFMA_PARTS 8
+#endif
+#ifndef LSDR_MFMA_SPAN
+#define LSDR_MFMA_SPAN 8
+#endif
+#ifndef LSDR_MFMA_ASM_STORE
+#define LSDR_MFMA_ASM_STORE 1
+#endif
+
+// NLT > 0: the number of prefetch loads per lane is a compile-time constant and the staged extent is padded to exactly
+// NLT·T granules — every load and every LDS write of the staging is unconditional (a tile past the end loads through an EMPTY
+// buffer resource: zeros, no traffic), so the compiler can count: the LDS-write phase waits vmcnt(NLT−1−k) for load k instead of
+// vmcnt(0) for all of them.  NLT = 0: run-time count (any geometry), conservative waits.
+template <int DT, int W, int CP, int NLT>
+__global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr unsigned T = 64 * W;                 // lanes per workgroup
+  constexpr unsigned M = 128 * W;                // outputs per tile
+  constexpr unsigned D = DT;
+  constexpr unsigned GW = 8 * W;                 // groups of 16 outputs per tile
+  constexpr unsigned PADB = 16;                  // bytes of padding per 16·D samples
+  const unsigned l = threadIdx.x;
+  const unsigned NB = a.mf_blocks;               // blocks of four MFMA steps (16 K slots)
+  const unsigned Uneed = 16 * (GW - 1) * D + ((16 * NB) >> CP);   // staged samples the MFMA phase reads (u-space extent), even
+  const unsigned U = NLT ? 2u * NLT * T : Uneed;
+  const unsigned NG = U / 2;                     // 16-byte granules (two samples)
+  const unsigned NLr = NLT ? (unsigned)NLT : (NG + T - 1) / T;    // loads per lane
+  constexpr int NLmax = NLT ? NLT : 32;          // register budget for the prefetch (checked on the host)
+  const unsigned b_bytes = U * 8 + (U / (16 * D) + 1) * PADB;
+  float *const lds_a = reinterpret_cast<float *>(smem_raw + ((b_bytes + 15) & ~15u));
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  auto tile_of = [&](unsigned ti) { return xcd * a.tiles_per_xcd + ti; };
+  auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
+
+  // coefficient operand table → LDS (constant for the launch)
+  for (unsigned e = l; e < a.mf_alen; e += T) lds_a[e] = a.mf_atab[e];
+
+  // Prefetch: granule p ↔ u ∈ {2p, 2p+1} ↔ tile-local samples n = TOP − 2p − 1 (low half of the 16 bytes), TOP − 2p.
+  // Load k of lane l fetches p = (NLr−1−k)·T + (T−1−l): ascending addresses in k and in l.  The buffer resource starts at the
+  // lowest sample any lane touches (clamped to the start of the stream: what lies before it is multiplied by zero taps and
+  // only has to be finite — the wrapped offset is out of range and reads 0.0, like everything past the end of the input).
+  const int TOP = (int)a.N + (int)(M - 1) * (int)D;
+  const int nb = TOP - 2 * (int)(NLr * T) + 1;   // tile-local sample of (k = 0, l = 0); ≤ 0
+  lsdr_v4u v[NLmax];
+  auto issue = [&](unsigned tile, bool live, int k_lo, int k_hi) {
+    const unsigned st = live ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
+    const long long j0 = (long long)lt * M * D + nb;                 // global sample of (k = 0, l = 0), may be < 0
+    const long long jb = j0 < 0 ? 0 : j0;
+    const unsigned long long bytes = live ? (a.n_in - (unsigned long long)jb) * 8ull : 0ull;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
+        (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
+    const unsigned voff = l * 16u - (unsigned)((jb - j0) * 8);       // wraps (→ out of range → 0.0) before the stream start
+#pragma unroll
+    for (int k = 0; k < NLmax; ++k) {
+      if (k < k_lo || k >= k_hi || (!NLT && k >= (int)NLr)) continue;
+      v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)k * (T * 16u), 0, LSDR_FIR_LOAD_AUX);
+    }
+  };
+
+  unsigned ti = slot;
+  if (!valid(ti)) return;
+#ifdef LSDR_FIR_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_amdgcn_s_memtime();
+#endif
+  issue(tile_of(ti), true, 0, NLmax);
+  LSDR_TR(0)
+
+  // per-lane operand cursors
+  const unsigned kq = l >> 4 & 3u, col = l & 15u, g = col >> 1, c = col & 1u, w = l >> 6;
+  const unsigned Gp = GW - 1 - (8 * w + g);                                        // group index from the top
+  const unsigned sub = CP ? (kq & 1u) : 0u;
+  const unsigned b0 = Gp * (16 * D * 8 + PADB) + ((CP ? (kq >> 1) : kq) * 8) + ((c ^ sub) * 4);   // bytes
+  const unsigned a0 = (kq + col * D * (1 + CP)) * 4;                               // bytes into lds_a
+  const unsigned sgn = (CP && sub && c) ? 0x80000000u : 0u;
+  constexpr unsigned BSTEP = CP ? 16 : 32;       // bytes of samples per MFMA step
+  constexpr unsigned BUMP = CP ? 2 * D : D;      // blocks between two paddings
+
+  while (true) {
+    const unsigned tile = tile_of(ti);
+    // registers → LDS (scaler fused)
+#pragma unroll
+    for (int k = 0; k < NLmax; ++k) {
+      if (!NLT && k >= (int)NLr) continue;
+      const unsigned p = (NLr - 1 - (unsigned)k) * T + (T - 1 - l);
+      if (NLT || p < NG) {
+        const float s = a.in_scale;
+        const lsdr_v4f x = {__uint_as_float(v[k].z) * s, __uint_as_float(v[k].w) * s, __uint_as_float(v[k].x) * s,
+                            __uint_as_float(v[k].y) * s};
+        *reinterpret_cast<lsdr_v4f *>(smem_raw + 16u * p + PADB * (p / (8 * D))) = x;
+      }
+    }
+    LSDR_TR(1)
+    __syncthreads();
+    LSDR_TR(2)
+    const unsigned tn = ti + slots;
+    const bool more = valid(tn);
+
+    lsdr_v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const char *bp = smem_raw + b0;
+    const char *ap = reinterpret_cast<const char *>(lds_a) + a0;
+    unsigned bump = BUMP;
+    auto ldb = [&](const char *p, int i) {
+      const unsigned r = *reinterpret_cast<const unsigned *>(p + i * BSTEP);
+      return __uint_as_float(CP ? (r ^ sgn) : r);
+    };
+    auto lda = [&](const char *p, int i) { return *reinterpret_cast<const float *>(p + i * 16); };
+    // Two operand sets used alternately: the reads of block b+1 are issued BEFORE the four dependent MFMAs of block b
+    // (sched_barrier pins that order), so LDS latency hides behind ≈ 160 cycles of matrix work.
+    float pa[2][4], pb[2][4];
+    auto fetch = [&](int set) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { pa[set][i] = lda(ap, i); pb[set][i] = ldb(bp, i); }
+    };
+    auto advance = [&]() {
+      ap += 64;
+      bp += 4 * BSTEP;
+      if (--bump == 0) { bp += PADB; bump = BUMP; }
+    };
+    auto mac4 = [&](int set) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][i], pb[set][i], acc, 0, 0, 0);
+    };
+    fetch(0);
+    constexpr int P = LSDR_MFMA_PARTS;
+    const unsigned npair = NB / 2;
+    const unsigned nspan = npair * LSDR_MFMA_SPAN / 8;     // the next tile's loads are all issued within the first SPAN/8 of the phase
+    unsigned pair = 0;
+    auto run_pairs = [&](unsigned pair_end) {
+      for (; pair < pair_end; ++pair) {
+        // (the last block reads one block past the slots: inside the staged / table extent, never used)
+        advance(); fetch(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mac4(0);
+        __builtin_amdgcn_sched_barrier(0);
+        advance(); fetch(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mac4(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    };
+#pragma unroll
+    for (int part = 0; part < P; ++part) {
+      if (NLT) issue(more ? tile_of(tn) : 0u, more, NLmax * part / P, NLmax * (part + 1) / P);   // in flight during the MFMA phase
+      else if (more) issue(tile_of(tn), true, NLmax * part / P, NLmax * (part + 1) / P);
+      __builtin_amdgcn_sched_barrier(0);
+      if (part == 0) { LSDR_TR(3) }
+      run_pairs(nspan * (unsigned)(part + 1) / P);
+    }
+    run_pairs(npair);
+    if (NB & 1u) mac4(0);
+    LSDR_TR(4)
+
+    // accumulator tile → out: register r of lane (q = l>>4, col) is row 4q + r, column col.  The stores are hidden from the
+    // compiler's wait-count pass (inline asm): with a store known to be pending behind the prefetch loads it turns every
+    // vmcnt(n) of the LDS-write phase into vmcnt(0) — stores may retire out of order with loads on gfx9, so the count alone does
+    // not tell them apart.  Unaccounted stores only make the hardware counter LARGER than the compiler assumes, i.e. its
+    // vmcnt(n) waits for at least the loads it meant (loads retire in order among themselves), and the phase ends in vmcnt(0).
+    const unsigned st = tile / a.tiles_per_stream;
+    const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * M;
+    float *const po = reinterpret_cast<float *>(a.outs[st]);
+    const unsigned long long mrow = m0 + 16u * (8 * w + g) + 4u * kq;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (mrow + r < a.count) {
+#if LSDR_MFMA_ASM_STORE
+        const float val = acc[r];
+        asm volatile("global_store_dword %0, %1, off" ::"v"(po + 2 * (mrow + r) + c), "v"(val) : "memory");
+#else
+        po[2 * (mrow + r) + c] = acc[r];
+#endif
+      }
+    LSDR_TR(5)
+    if (!more) break;
+    ti = tn;
+    __syncthreads();                       // LDS is rewritten next
+    LSDR_TR(6)
+  }
+#if LSDR_MFMA_ASM_STORE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef LSDR_FIR_TRACE
+  if (a.trace && (l & 63) == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 8; ++i) a.trace[((size_t)blockIdx.x * 4 + (l >> 6)) * 8 + i] = tr[i];
+#endif
+}
+
 typedef void (*fir_kernel_t)(fir_args);
+
+// k_fir_mfma instances: decimations with a compile-time kernel × {2, 4} wavefronts per workgroup × {real, complex} taps; the C2
+// decimation also with the compile-time load counts of its geometry (nl = 32 at W = 2, 31 at W = 4).
+template <int DT>
+fir_kernel_t pick_mfma_d(int W, bool cplx) {
+  if (W == 4) return cplx ? k_fir_mfma<DT, 4, 1, 0> : k_fir_mfma<DT, 4, 0, 0>;
+  return cplx ? k_fir_mfma<DT, 2, 1, 0> : k_fir_mfma<DT, 2, 0, 0>;
+}
+constexpr unsigned mfma_fixed_nl(unsigned D, int W) { return D == 30 ? (W == 4 ? 31u : 32u) : 0u; }
+fir_kernel_t pick_mfma(unsigned D, int W, bool cplx, unsigned nl_fixed) {
+  if (nl_fixed && nl_fixed == mfma_fixed_nl(D, W)) {
+    if (W == 4) return cplx ? k_fir_mfma<30, 4, 1, 31> : k_fir_mfma<30, 4, 0, 31>;
+    return cplx ? k_fir_mfma<30, 2, 1, 32> : k_fir_mfma<30, 2, 0, 32>;
+  }
+  switch (D) {
+    case 4: return pick_mfma_d<4>(W, cplx);
+    case 8: return pick_mfma_d<8>(W, cplx);
+    case 10: return pick_mfma_d<10>(W, cplx);
+    case 16: return pick_mfma_d<16>(W, cplx);
+    case 30: return pick_mfma_d<30>(W, cplx);
+    default: return nullptr;
+  }
+}
+// geometry of a k_fir_mfma launch: K slots, blocks, staged extent, LDS bytes, prefetch loads per lane
+struct mfma_geom { unsigned nb, alen, U, lds, nl, nl_fixed; };
+mfma_geom mfma_geometry(unsigned N, unsigned D, int W, bool cplx) {
+  mfma_geom g;
+  const unsigned cp = cplx ? 1 : 0, slots = (15 * D + N) << cp;
+  g.nb = (slots + 15) / 16;
+  g.alen = 16 * (g.nb + 1) + ((15 * D) << cp) + 4;     // one block of read-ahead past the last slot
+  g.U = 16 * (8 * W - 1) * D + ((16 * g.nb) >> cp);
+  g.nl = (g.U / 2 + 64 * W - 1) / (64 * W);
+  const char *e = getenv("LSDR_MFMA_NLT");             // test hook: 0 forces the run-time-count kernel
+  g.nl_fixed = (g.nl == mfma_fixed_nl(D, W) && !(e && !atoi(e))) ? g.nl : 0;
+  if (g.nl_fixed) g.U = 2 * g.nl * 64 * W;             // staged extent padded to whole loads (k_fir_mfma NLT)
+  const unsigned b_bytes = g.U * 8 + (g.U / (16 * D) + 1) * 16;
+  g.lds = ((b_bytes + 15) & ~15u) + g.alen * 4 + 256;  // + the read-ahead of the top group's last block
+  return g;
+}
 
 template <int IN_FMT, int R, int DT>
 fir_kernel_t pick_mode(int mode, bool persist = false) {
@@ -453,6 +713,12 @@ struct lsdr_fir_filter {
   bool spec;                        // compile-time-D kernel in use
   bool persist;                     // persistent software-pipelined kernel (spec only)
   unsigned persist_grid;            // workgroups launched by the persistent kernel
+  // LSDR_FIR_MFMA (k_fir_mfma): wavefronts per workgroup, workgroups per CU, coefficient operand tables for the real-tap and
+  // the complex-tap form (d_atab[cplx], geometry mf[cplx]); mfma_ok[cplx] = that form exists for this N / D
+  int mf_W, mf_wpc;
+  float *d_atab[2];
+  mfma_geom mf[2];
+  bool mfma_ok[2];
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -475,6 +741,17 @@ static int fir_upload(lsdr_fir_filter *f) {
   for (unsigned i = 0; i < N; ++i) { scp[F + i] = f->shifted[i]; rcp[F + i] = rc[i]; }
   LSDR_HIP(hipMemcpyAsync(f->d_scp, scp.data(), scp.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream));
   LSDR_HIP(hipMemcpyAsync(f->d_rcp, rcp.data(), rcp.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+  // k_fir_mfma's A operand: cz'[e'] = tap (e' − 15·D) of the real kernel; (cr, −ci) pairs of tap (e'/2 − 15·D) of the complex one
+  for (int cp = 0; cp < 2; ++cp) {
+    if (!f->mfma_ok[cp]) continue;
+    std::vector<float> at(f->mf[cp].alen, 0.f);
+    for (unsigned i = 0; i < N; ++i) {
+      if (cp == 0) at[15 * D + i] = rc[i];
+      else { at[2 * (15 * D + i)] = f->shifted[i].re; at[2 * (15 * D + i) + 1] = -f->shifted[i].im; }
+    }
+    LSDR_HIP(hipMemcpyAsync(f->d_atab[cp], at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));   // `at` is pageable and dies here
+  }
   LSDR_HIP(hipStreamSynchronize(c->stream));
   return LSDR_OK;
 }
@@ -485,7 +762,7 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   LSDR_ARG(c && cfg && out);
   LSDR_ARG(cfg->ncoeffs >= 1 && cfg->coeffs_host && cfg->decim >= 1);
   LSDR_ARG(cfg->in_format == LSDR_IN_CF32 || cfg->in_format == LSDR_IN_CU8);
-  LSDR_ARG(cfg->arith == LSDR_FIR_EXACT || cfg->arith == LSDR_FIR_FMA);
+  LSDR_ARG(cfg->arith == LSDR_FIR_EXACT || cfg->arith == LSDR_FIR_FMA || cfg->arith == LSDR_FIR_MFMA);
   LSDR_HIP(hipSetDevice(c->device));
   lsdr_fir_filter *f = new lsdr_fir_filter();
   f->ctx = c;
@@ -540,6 +817,22 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   f->ncols = N / D + 1;
   LSDR_HIP(hipMalloc((void **)&f->d_scp, (size_t)f->ncols * D * sizeof(float2)));
   LSDR_HIP(hipMalloc((void **)&f->d_rcp, (size_t)f->ncols * D * sizeof(float)));
+  // LSDR_FIR_MFMA: available for cf32 input at the decimations k_fir_mfma is instantiated for, while a tile (and its
+  // prefetch: ≤ 32 sixteen-byte loads per lane) fits; everything else runs LSDR_FIR_FMA's kernels — the same bits.
+  f->d_atab[0] = f->d_atab[1] = nullptr;
+  f->mfma_ok[0] = f->mfma_ok[1] = false;
+  {
+    const char *ew = getenv("LSDR_MFMA_W"), *ep = getenv("LSDR_MFMA_WPC");
+    f->mf_W = ew && atoi(ew) == 4 ? 4 : 2;
+    f->mf_wpc = ep && atoi(ep) > 0 ? atoi(ep) : (f->mf_W == 4 ? 1 : 2);
+  }
+  if (cfg->arith == LSDR_FIR_MFMA && cfg->in_format == LSDR_IN_CF32 && pick_mfma(D, f->mf_W, false, 0) != nullptr) {
+    for (int cp = 0; cp < 2; ++cp) {
+      f->mf[cp] = mfma_geometry(N, D, f->mf_W, cp != 0);
+      f->mfma_ok[cp] = f->mf[cp].nl <= 32 && f->mf[cp].lds <= (size_t)160 * 1024 / f->mf_wpc;
+      if (f->mfma_ok[cp]) LSDR_HIP(hipMalloc((void **)&f->d_atab[cp], f->mf[cp].alen * sizeof(float)));
+    }
+  }
   *out = f;
   return lsdr_fir_filter_set_freq(f, 0.0f);  // fir_filter ctor ends with set_freq(0), dsp.h:230
 }
@@ -551,6 +844,8 @@ void lsdr_fir_filter_destroy(lsdr_fir_filter *f) {
   (void)hipFree(f->d_rc);
   (void)hipFree(f->d_scp);
   (void)hipFree(f->d_rcp);
+  (void)hipFree(f->d_atab[0]);
+  (void)hipFree(f->d_atab[1]);
   delete f;
 }
 
@@ -595,7 +890,9 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   if (!count) return LSDR_OK;
   LSDR_ARG(ins && outs);
   for (unsigned i = 0; i < n_streams; ++i) LSDR_ARG(ins[i] && outs[i]);
-  if (n_streams > 1 && !(f->spec && f->persist)) {   // only the persistent kernels take several buffers per launch
+  const bool real_taps = f->all_real && !f->force_complex;
+  const bool mfma = f->cfg.arith == LSDR_FIR_MFMA && f->mfma_ok[real_taps ? 0 : 1];
+  if (n_streams > 1 && !mfma && !(f->spec && f->persist)) {   // only the persistent kernels take several buffers per launch
     for (unsigned i = 0; i < n_streams; ++i) {
       int rc = fir_run_streams(f, 1, ins + i, n_in, outs + i, cap_out, consumed, produced);
       if (rc) return rc;
@@ -618,7 +915,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.N = N; a.D = D; a.S = f->S;
   a.count = count;
   a.n_in = n_in;
-  const unsigned M = kThreads * f->R;
+  const unsigned M = mfma ? 128u * f->mf_W : kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
   a.tiles_per_stream = (unsigned)n_tiles;
@@ -626,6 +923,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.n_tiles = (unsigned)n_tiles;
   a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
   a.in_scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
+  a.mf_atab = nullptr; a.mf_alen = 0; a.mf_blocks = 0;
   a.trace = nullptr;
 #ifdef LSDR_FIR_TRACE
   {
@@ -637,8 +935,25 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   }
 #endif
 
-  const bool real_path = f->all_real && !f->force_complex;
-  int mode = (f->cfg.arith == LSDR_FIR_FMA ? 2 : 0) + (real_path ? 1 : 0);
+  if (mfma) {
+    const int cp = real_taps ? 0 : 1;
+    a.mf_atab = f->d_atab[cp];
+    a.mf_alen = f->mf[cp].alen;
+    a.mf_blocks = f->mf[cp].nb;
+    fir_kernel_t k = pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
+    if (f->mf[cp].lds > 64 * 1024)
+      LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->mf[cp].lds));
+    unsigned grid = a.tiles_per_xcd * 8;
+    const unsigned pg = (unsigned)(f->ctx->num_cu * f->mf_wpc + 7) / 8 * 8;
+    if (grid > pg) grid = pg;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * f->mf_W), f->mf[cp].lds, f->ctx->stream, a);
+    LSDR_HIP(hipGetLastError());
+    *produced = count;
+    *consumed = count * D;
+    return LSDR_OK;
+  }
+  const bool real_path = real_taps;
+  int mode = (f->cfg.arith != LSDR_FIR_EXACT ? 2 : 0) + (real_path ? 1 : 0);
   int Rs = 0;
   fir_kernel_t k;
   if (f->spec)

@@ -70,6 +70,38 @@ size_t lo_fir_filter(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
   return count;
 }
 
+/* The arithmetic of the TOLERANCE modes of the HIP fir_filter (LSDR_FIR_FMA, LSDR_FIR_MFMA), stated once so that the
+ * kernels can be pinned to it bit for bit: the reference's loop (dsp.h:246-262) with each product-and-add fused, i.e. what
+ * the reference itself computes when built for an FMA machine with -ffp-contract=fast.  fmaf() is a correctly rounded fused
+ * multiply-add whatever the host.  Taps with zero imaginary part (current_freq == 0) take the two-chain form (a product
+ * with ±0 would be an exact no-op anyway). */
+size_t lo_fir_filter_fma(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
+                         const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
+                         size_t *consumed) {
+  *consumed = 0;
+  if (n_in < ncoeffs) return 0;
+  size_t count = (n_in - ncoeffs) / decim;
+  if (count > cap) count = cap;
+  int all_real = 1;
+  for (unsigned i = 0; i < ncoeffs; ++i) all_real &= sc[i].im == 0.0f;
+  for (size_t m = 0; m < count; ++m) {
+    const lo_cf32 *pi = in + ncoeffs + m * decim;
+    float xr = 0, xi = 0;
+    for (unsigned i = 0; i < ncoeffs; ++i, --pi) {
+      xr = fmaf(sc[i].re, pi->re, xr);
+      xi = fmaf(sc[i].re, pi->im, xi);
+      if (!all_real) {
+        xr = fmaf(-sc[i].im, pi->im, xr);
+        xi = fmaf(sc[i].im, pi->re, xi);
+      }
+    }
+    out[m].re = xr;
+    out[m].im = xi;
+  }
+  *consumed = count * decim;
+  return count;
+}
+
 /* dsp.h:351-360: a = 2*M_PI*f*i with int i. */
 void lo_fir_resampler_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq, lo_cf32 *shifted) {
   for (int i = 0; i < (int)ncoeffs; ++i) {

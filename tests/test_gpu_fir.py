@@ -190,3 +190,65 @@ def test_long_inputs_all_specialised_decimations(capi, ctx, oracle, d, nt):
     f.close()
     ref, rcons = oracle.fir_filter(co, d, x)
     assert cons == rcons and bits_equal(y, ref)
+
+
+MFMA_GEOMS = [(313, 30), (200, 30), (101, 10), (161, 16), (65, 8), (40, 4), (17, 16), (330, 30)]
+
+
+@pytest.mark.parametrize("w", [2, 4])
+@pytest.mark.parametrize("n,d", MFMA_GEOMS, ids=[f"N{n}_D{d}" for n, d in MFMA_GEOMS])
+def test_mfma_is_the_fma_chain_bit_for_bit(capi, ctx, oracle, w, n, d):
+    """LSDR_FIR_MFMA (k_fir_mfma: the taps as a banded Toeplitz block on v_mfma_f32_16x16x4_f32) computes LSDR_FIR_FMA's
+    arithmetic — the reference's loop with fused multiply-adds, oracle.fir_filter(fma=True) — bit for bit: real taps and
+    shifted (complex) taps, fused scaler, many tiles per persistent workgroup, ragged tail, the stream start."""
+    rng = np.random.default_rng(n * 31 + d)
+    ns = 4096 * 90 + 77
+    x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 12).astype(np.complex64)
+    co = capi.lowpass(n - 1, 0.4 / d)
+    os.environ["LSDR_MFMA_W"] = str(w)
+    try:
+        for freq in (0.0, 0.0123):
+            f = capi.FirFilter(ctx, co, d, in_scale=75.0, arith=capi.FIR_MFMA)
+            g = capi.FirFilter(ctx, co, d, in_scale=75.0, arith=capi.FIR_FMA)
+            if freq:
+                f.set_freq(freq); g.set_freq(freq)
+            y, cons = f.run(x)
+            yg, _ = g.run(x)
+            f.close(); g.close()
+            ref, rcons = oracle.fir_filter(co, d, oracle.scaler(75.0, x), freq, fma=True)
+            assert cons == rcons and len(y) == len(ref)
+            assert np.array_equal(y, ref), (freq, int((y != ref).sum()), float(np.abs(y - ref).max()))
+            assert np.array_equal(yg, ref), ("fma kernel", freq)
+            exact, _ = oracle.fir_filter(co, d, oracle.scaler(75.0, x), freq)
+            bound = 4e-6 * np.abs(co).sum() * np.abs(x).max() * 75 * 2
+            assert np.abs(y - exact).max() <= bound
+    finally:
+        del os.environ["LSDR_MFMA_W"]
+
+
+def test_mfma_run_multi_and_short_inputs(capi, ctx, oracle):
+    """Several buffers per launch, inputs shorter than one tile, cap_out below what the input allows."""
+    rng = np.random.default_rng(12)
+    co = capi.lowpass(312, np.float32(0.0049))
+    f = capi.FirFilter(ctx, co, 30, in_scale=0.5, arith=capi.FIR_MFMA)
+    n = 250000
+    xs = [((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 20).astype(np.complex64) for _ in range(3)]
+    cap = (n - 313) // 30
+    dins = [ctx.upload(x) for x in xs]
+    douts = [ctx.alloc(cap * 8 + 64) for _ in xs]
+    cons, prod = f.run_multi_dev([d.ptr for d in dins], n, [d.ptr for d in douts], cap)
+    assert prod == cap and cons == cap * 30
+    for x, dout in zip(xs, douts):
+        want, _ = oracle.fir_filter(co, 30, oracle.scaler(0.5, x), fma=True)
+        assert np.array_equal(ctx.download(dout, np.complex64, prod), want[:prod])
+    for m in (0, 312, 313, 342, 343, 344, 1000, 4153, 8000):
+        y, cons = f.run(xs[0][:m])
+        want, wcons = oracle.fir_filter(co, 30, oracle.scaler(0.5, xs[0][:m]), fma=True)
+        assert cons == wcons and np.array_equal(y, want), m
+    cons, prod = f.run_dev(dins[0].ptr, n, douts[0].ptr, 1000)
+    assert (cons, prod) == (30000, 1000)
+    want, _ = oracle.fir_filter(co, 30, oracle.scaler(0.5, xs[0]), fma=True)
+    assert np.array_equal(ctx.download(douts[0], np.complex64, 1000), want[:1000])
+    for d in dins + douts:
+        d.free()
+    f.close()

@@ -16,19 +16,26 @@ for r in range(n // len(blk)):
     capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * blk.nbytes), d_blk.ptr, blk.nbytes))
 d_out = ctx.alloc(n // 30 * 8 + 64)
 c = capi.lowpass(312, np.float32((2e6 / 2) * (1 + 0.35 / 2) / 240e6))
-f = capi.FirFilter(ctx, c, 30, in_scale=75.0)
+arith = {"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA}[os.environ.get("FIR_ARITH", "exact")]
+f = capi.FirFilter(ctx, c, 30, in_scale=75.0, arith=arith)
 if freq:
     f.set_freq(freq)
 for _ in range(3):
     f.run_dev(d_in.ptr, n, d_out.ptr, n // 30)
 ctx.sync()
-nwg = int(os.environ.get("LSDR_FIR_PERSIST", "2")) * 256
+mf = arith == capi.FIR_MFMA
+W = int(os.environ.get("LSDR_MFMA_W", "2"))
+nwg = (int(os.environ.get("LSDR_MFMA_WPC", "1" if W == 4 else "2")) if mf else int(os.environ.get("LSDR_FIR_PERSIST", "2"))) * 256
 tr = np.zeros(nwg * 4 * 8, np.uint64)
 capi.lib.lsdr_fir_trace_read.argtypes = [C.c_void_p, C.c_size_t]
 assert capi.lib.lsdr_fir_trace_read(tr.ctypes.data, len(tr)) == 0
 tr = tr.reshape(nwg, 4, 8).astype(np.float64)
-tiles = (n // 30 // 256) / nwg
-names = ["prologue issue", "wait loads + LDS write", "barrier A", "issue next loads", "taps", "store", "barrier B", "-"]
+if mf:
+    tr = tr[:, :W, :]
+tiles = (n // 30 // (128 * W if mf else 256)) / nwg
+names = ["prologue issue", "wait loads + LDS write", "barrier A", "issue next loads (first part)" if mf else "issue next loads",
+         "MFMA phase (+ later parts)" if mf else "taps", "store", "barrier B", "-"]
+print(f"FIR_ARITH={os.environ.get('FIR_ARITH','exact')} W={W} workgroups={nwg}")
 tot = tr.sum(axis=2).mean()
 print(f"tiles/WG {tiles:.1f}; total cycles/wave {tot:.0f} ({tot/tiles:.0f}/tile)  [s_memtime ticks = 100 MHz? see ratio]")
 for i, nm in enumerate(names[:7]):
