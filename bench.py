@@ -349,9 +349,10 @@ class C2Pipeline:
         if self.fir_arith == capi.FIR_EXACT:
             y_want = y_ref
         else:
-            y_want = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full), freq=self.fir.current_freq, fma=True)[0]
+            y_want = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full), freq=self.fir.current_freq,
+                                  fma="blk" if self.fir_arith == capi.FIR_MFMA_BLK else True)[0]
             scale = float(np.abs(y_ref).max())
-            fir_extra = dict(fir_arith={capi.FIR_FMA: "fma", capi.FIR_MFMA: "mfma"}[self.fir_arith],
+            fir_extra = dict(fir_arith={capi.FIR_FMA: "fma", capi.FIR_MFMA: "mfma", capi.FIR_MFMA_BLK: "mfma_blk"}[self.fir_arith],
                              fir_max_abs_err_vs_exact=float(np.abs(y - y_ref).max()) if len(y) == len(y_ref) else None,
                              fir_max_rel_err_vs_exact=float(np.abs(y - y_ref).max() / scale) if len(y) == len(y_ref) else None,
                              fir_rel_err_bound=1e-5)
@@ -389,7 +390,8 @@ class C2Pipeline:
         ms = float(np.mean(self.fir_ms))
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         traffic, src = pmc_traffic(g["B"] * len(self.caps))
-        return {"kernel": ("k_fir_mfma" if self.fir_arith == self.capi.FIR_MFMA else "k_fir_persist") + " (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        kname = {self.capi.FIR_MFMA: "k_fir_mfma", self.capi.FIR_MFMA_BLK: "k_fir_mfma_blk"}.get(self.fir_arith, "k_fir_persist")
+        return {"kernel": kname + " (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": (f"recorded, not measured in this run: {src}" if src else None),
                 "avg_launch_ms": round(ms, 4), "launches_timed": len(self.fir_ms), "algorithmic_bytes_per_launch": alg_bytes,
@@ -437,7 +439,7 @@ def main():
     ap.add_argument("--tile-warmup", type=int, default=DEFAULT_TILE[1])
     ap.add_argument("--captures", type=int, default=4,
                     help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles)")
-    ap.add_argument("--fir-arith", choices=["exact", "fma", "mfma"], default="exact",
+    ap.add_argument("--fir-arith", choices=["exact", "fma", "mfma", "blk"], default="exact",
                     help="fir_filter arithmetic of the headline: exact = the reference's (bit-exact output); fma / mfma = fused multiply-adds "
                          "(VALU / matrix pipe; output bit-identical to the oracle's fmaf restatement, soft symbols under the stated tolerance)")
     ap.add_argument("--rx-cus", type=int, default=0, help="compute units reserved for the receiver streams (0: no partition)")
@@ -507,7 +509,7 @@ def main():
     tile = (args.tile_len, args.tile_warmup)
     pipe = C2Pipeline(capi, synth, local_rank, args.captures, args.batch_msamples, args.period_msamples, tile,
                       seed0=shard.capture_seed(), rx_cus=args.rx_cus, cu_pattern=args.cu_pattern,
-                      fir_arith={"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA}[args.fir_arith])
+                      fir_arith={"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[args.fir_arith])
     bps = args.batches_per_step
 
     pipe.run(args.warmup * bps, False)

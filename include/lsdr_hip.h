@@ -196,9 +196,13 @@ enum { LSDR_IN_CF32 = 0, LSDR_IN_CU8 = 1 };
 enum {
   LSDR_FIR_EXACT = 0, /* reference arithmetic: i-ascending accumulation, no FMA contraction → bit-exact */
   LSDR_FIR_FMA = 1,   /* same order, fused multiply-add (≤ 1 ulp/tap differences; tolerance-tested) */
-  LSDR_FIR_MFMA = 2   /* LSDR_FIR_FMA's arithmetic, bit for bit, on the f32 matrix pipe (v_mfma_f32_16x16x4_f32 is an exact
+  LSDR_FIR_MFMA = 2,  /* LSDR_FIR_FMA's arithmetic, bit for bit, on the f32 matrix pipe (v_mfma_f32_16x16x4_f32 is an exact
                        * k-ordered fmaf chain): the taps as a banded Toeplitz block, sixteen outputs per row group.  cf32 input
                        * at the decimations with a compile-time kernel; anything else runs LSDR_FIR_FMA's kernels (same bits). */
+  LSDR_FIR_MFMA_BLK = 3 /* block-polyphase form on the matrix pipe (a dense product): the taps in blocks of `decim`, each block an
+                       * fmaf chain from zero in tap order, the block sums added in block order — its own stated arithmetic
+                       * (oracle lo_fir_filter_blk), same error bound as LSDR_FIR_FMA.  cf32 input, even decimations with a
+                       * compile-time kernel, ncoeffs ≤ 16·decim; refused (LSDR_E_ARG) otherwise. */
 };
 typedef struct {
   unsigned ncoeffs;          /* fir_filter ctor _ncoeffs */

@@ -23,7 +23,7 @@ CSTLN_BITS = {BPSK: 1, QPSK: 2, PSK8: 3, APSK16: 4, APSK32: 5, APSK64E: 6, QAM16
 (FEC12, FEC23, FEC46, FEC34, FEC56, FEC78, FEC45, FEC89, FEC910) = range(9)
 IN_CF32, IN_CU8 = 0, 1
 SYM_SOFT, SYM_HARD2 = 0, 1
-FIR_EXACT, FIR_FMA, FIR_MFMA = 0, 1, 2
+FIR_EXACT, FIR_FMA, FIR_MFMA, FIR_MFMA_BLK = 0, 1, 2, 3
 SAMP_NEAREST, SAMP_LINEAR, SAMP_FIR = 0, 1, 2
 RX_SERIAL, RX_TILED = 0, 1
 NOTCH_EXACT, NOTCH_SCAN = 0, 1

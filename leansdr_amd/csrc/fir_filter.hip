@@ -457,15 +457,21 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
   const int TOP = (int)a.N + (int)(M - 1) * (int)D;
   const int nb = TOP - 2 * (int)(NLr * T) + 1;   // tile-local sample of (k = 0, l = 0); ≤ 0
   lsdr_v4u v[NLmax];
-  auto issue = [&](unsigned tile, bool live, int k_lo, int k_hi) {
+  // (the buffer resource of the next tile is set up ONCE per tile, before the MFMA phase: its scalar loads and divisions must
+  // not sit between the MFMAs, where an s_waitcnt lgkmcnt(0) for a.ins[st] would also wait for every LDS read in flight)
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff;
+  auto aim = [&](unsigned tile, bool live) {
     const unsigned st = live ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
     const long long j0 = (long long)lt * M * D + nb;                 // global sample of (k = 0, l = 0), may be < 0
     const long long jb = j0 < 0 ? 0 : j0;
     const unsigned long long bytes = live ? (a.n_in - (unsigned long long)jb) * 8ull : 0ull;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
         (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
-    const unsigned voff = l * 16u - (unsigned)((jb - j0) * 8);       // wraps (→ out of range → 0.0) before the stream start
+    voff = l * 16u - (unsigned)((jb - j0) * 8);                      // wraps (→ out of range → 0.0) before the stream start
+  };
+  auto issue = [&](int k_lo, int k_hi) {
 #pragma unroll
     for (int k = 0; k < NLmax; ++k) {
       if (k < k_lo || k >= k_hi || (!NLT && k >= (int)NLr)) continue;
@@ -478,7 +484,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
 #ifdef LSDR_FIR_TRACE
   unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_amdgcn_s_memtime();
 #endif
-  issue(tile_of(ti), true, 0, NLmax);
+  aim(tile_of(ti), true);
+  issue(0, NLmax);
   LSDR_TR(0)
 
   // per-lane operand cursors
@@ -510,6 +517,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
     LSDR_TR(2)
     const unsigned tn = ti + slots;
     const bool more = valid(tn);
+    aim(more ? tile_of(tn) : 0u, more);
 
     lsdr_v4f acc = {0.f, 0.f, 0.f, 0.f};
     const char *bp = smem_raw + b0;
@@ -556,8 +564,7 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
     };
 #pragma unroll
     for (int part = 0; part < P; ++part) {
-      if (NLT) issue(more ? tile_of(tn) : 0u, more, NLmax * part / P, NLmax * (part + 1) / P);   // in flight during the MFMA phase
-      else if (more) issue(tile_of(tn), true, NLmax * part / P, NLmax * (part + 1) / P);
+      if (NLT || more) issue(NLmax * part / P, NLmax * (part + 1) / P);   // in flight during the MFMA phase
       __builtin_amdgcn_sched_barrier(0);
       if (part == 0) { LSDR_TR(3) }
       run_pairs(nspan * (unsigned)(part + 1) / P);
@@ -600,6 +607,232 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
 #endif
 }
 
+// ---- LSDR_FIR_MFMA_BLK: block-polyphase form — a DENSE product on the matrix pipe ----------------------------
+// k_fir_mfma pays for having one filter: 59 % of its multiplies hit the zero band of the Toeplitz block, and its single
+// accumulator chain runs at the 40-cycle dependent-MFMA latency (trace: the MFMA phase IS 192 × 40 cycles).  Cutting the taps
+// into NQ = ⌈N/D⌉ blocks of D makes the product dense.  With x_u[u] = the tile's samples counted DOWN from its newest one,
+//     Z[b][q] = Σ_{r<D} c[D·q + r] · x_u[D·b + r]          rows b = blocks of D samples, columns q = tap blocks,
+//     y[b]    = Σ_{q<NQ} Z[b + q][q]                        output b (counted down from the tile's last output),
+// Z = X·H is one GEMM: rows = 8 sample blocks × {re, im}, K = D (30 → 32), columns = NQ (11 → 16): 61 % useful multiplies,
+// and consecutive row tiles are INDEPENDENT accumulators — two are interleaved, so the pipe issues every 32 cycles.  The
+// coefficient operand is 8 VGPRs for the whole launch (no LDS table); the sample operand is one conflict-free ds_read_b32
+// per MFMA (row stride 2·D + PADF floats ≡ ±4·odd mod 32 banks).  Z tiles go through a 64-row LDS ring per wavefront
+// ([row][q][re,im]); after every four row tiles 32 outputs × {re, im} = 64 lanes add their NQ diagonal terms (q ascending)
+// and store 256 consecutive bytes.  A wavefront owns 128 rows → 128 − (NQ−1) outputs (118 at C2): 128 MFMAs per 118 outputs
+// at 32 cycles where k_fir_mfma needs 192 at 40 per 128.
+// Arithmetic (stated once, oracle lo_fir_filter_blk): the reference's loop with the taps in blocks of D — each block an fmaf
+// chain from zero in tap order, the block sums added in block order.  NOT the single chain of LSDR_FIR_FMA; pinned bit for
+// bit to that restatement, and under the same error bound against the reference's arithmetic.
+constexpr unsigned blk_padf(unsigned D) {          // floats of padding per row of D samples: (2·D + PADF) mod 32 ∈ {4,12,20,28}
+  unsigned p = 0;
+  while (((2 * D + p) % 8) != 4) p += 4;
+  return p;
+}
+
+template <int DT, int W, int CP, int NLT>
+__global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr unsigned T = 64 * W, D = DT, SL = 1 + CP;
+  static_assert(DT % 2 == 0, "a 16-byte granule must not straddle two rows");
+  constexpr unsigned KP = (D * SL + 3) / 4 * 4, KS = KP / 4;      // K slots per row (padded), MFMA steps per row tile
+  constexpr unsigned PADF = blk_padf(D), ROWF = 2 * D + PADF;     // floats per LDS row
+  constexpr unsigned RW = 128;                                    // rows per wavefront (16 row tiles)
+  const unsigned l = threadIdx.x;
+  const unsigned NQ = a.mf_blocks;                                // tap blocks (≤ 16)
+  const unsigned MW = RW - (NQ - 1), M = W * MW;                  // outputs per wavefront / per tile
+  const unsigned R = M + NQ - 1;                                  // rows per tile
+  const unsigned Uneed = (R * D + (KP / SL - D) + 1) & ~1u;       // staged samples incl. the K padding's read-ahead, even
+  const unsigned U = NLT ? 2u * NLT * T : Uneed;
+  const unsigned NG = U / 2;
+  const unsigned NLr = NLT ? (unsigned)NLT : (NG + T - 1) / T;
+  constexpr int NLmax = NLT ? NLT : 32;
+  const unsigned ROWZ = 2 * (NQ | 1u);                            // floats per ring row: [q][re,im], odd pair count
+  const unsigned data_bytes = ((U + D - 1) / D + 1) * ROWF * 4;
+  char *const ring = smem_raw + ((data_bytes + 15) & ~15u) + (l >> 6) * (64 * ROWZ * 4);
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  auto tile_of = [&](unsigned ti) { return xcd * a.tiles_per_xcd + ti; };
+  auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
+
+  // coefficient operand: KS registers for the whole launch (lane (k = l>>4, q = l&15) of step s: slot 4·s + k of tap block q)
+  float bco[KS];
+#pragma unroll
+  for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[s * 64 + (l & 63u)];
+  if (PADF) {   // the K padding reads the row padding: finite filler, written once (staging never touches it)
+    for (unsigned b = l; b < (U + D - 1) / D + 1; b += T)
+      for (unsigned j = 0; j < PADF; ++j) reinterpret_cast<float *>(smem_raw)[b * ROWF + 2 * D + j] = 0.f;
+  }
+
+  const int TOP = (int)a.N + (int)(M - 1) * (int)D;
+  const int nb = TOP - 2 * (int)(NLr * T) + 1;
+  lsdr_v4u v[NLmax];
+  // (the buffer resource of the next tile is set up ONCE per tile, before the MFMA phase: its scalar loads and divisions must
+  // not sit between the MFMAs, where an s_waitcnt lgkmcnt(0) for a.ins[st] would also wait for every LDS read in flight)
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned voff;
+  auto aim = [&](unsigned tile, bool live) {
+    const unsigned st = live ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
+    const long long j0 = (long long)lt * M * D + nb;
+    const long long jb = j0 < 0 ? 0 : j0;
+    const unsigned long long bytes = live ? (a.n_in - (unsigned long long)jb) * 8ull : 0ull;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
+        (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
+    voff = l * 16u - (unsigned)((jb - j0) * 8);                      // wraps (→ out of range → 0.0) before the stream start
+  };
+  auto issue = [&](int k_lo, int k_hi) {
+#pragma unroll
+    for (int k = 0; k < NLmax; ++k) {
+      if (k < k_lo || k >= k_hi || (!NLT && k >= (int)NLr)) continue;
+      v[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (unsigned)k * (T * 16u), 0, LSDR_FIR_LOAD_AUX);
+    }
+  };
+
+  unsigned ti = slot;
+  if (!valid(ti)) return;
+#ifdef LSDR_FIR_TRACE
+  unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tc = __builtin_amdgcn_s_memtime();
+#endif
+  aim(tile_of(ti), true);
+  issue(0, NLmax);
+  LSDR_TR(0)
+
+  // per-lane cursors.  Sample operand: row i = l&15 → sample block β = i>>1, component c = i&1; K slot k = (l>>4)&3.
+  const unsigned kq = l >> 4 & 3u, i16 = l & 15u, beta = i16 >> 1, c = i16 & 1u, w = l >> 6;
+  const unsigned sub = CP ? (kq & 1u) : 0u;
+  const unsigned Bw = MW * w;                                                      // first row of this wavefront
+  const unsigned a0 = ((Bw + beta) * ROWF + 2 * (CP ? (kq >> 1) : kq) + (c ^ sub)) * 4;   // bytes
+  const unsigned sgn = (CP && sub && c) ? 0x80000000u : 0u;
+  constexpr unsigned ASTEP = CP ? 16 : 32, ATILE = 8 * ROWF * 4;
+  // accumulator tile → ring: lane (q = l&15, g4 = (l>>4)&3) holds rows 4·g4 + r = (β = 2·g4 + (r>>1), c = r&1)
+  const unsigned zq = l & 15u, zrow = 2 * kq;
+  // diagonal sum: lane (o = (l&63)>>1, c = l&1)
+  const unsigned ro = (l & 63u) >> 1, rc = l & 1u;
+
+  while (true) {
+    const unsigned tile = tile_of(ti);
+#pragma unroll
+    for (int k = 0; k < NLmax; ++k) {
+      if (!NLT && k >= (int)NLr) continue;
+      const unsigned p = (NLr - 1 - (unsigned)k) * T + (T - 1 - l);
+      if (NLT || p < NG) {
+        const float s = a.in_scale;
+        const lsdr_v4f x = {__uint_as_float(v[k].z) * s, __uint_as_float(v[k].w) * s, __uint_as_float(v[k].x) * s,
+                            __uint_as_float(v[k].y) * s};
+        *reinterpret_cast<lsdr_v4f *>(smem_raw + 16u * p + (PADF ? 4u * PADF * ((2 * p) / D) : 0u)) = x;
+      }
+    }
+    LSDR_TR(1)
+    __syncthreads();
+    LSDR_TR(2)
+    const unsigned tn = ti + slots;
+    const bool more = valid(tn);
+    const unsigned st = tile / a.tiles_per_stream;
+    const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * M;
+    float *const po = reinterpret_cast<float *>(a.outs[st]);
+    aim(more ? tile_of(tn) : 0u, more);
+
+    const char *ap = smem_raw + a0;
+    float pa[2][2][KS];                      // [set][row tile of the pair][step]
+    auto fetch1 = [&](int set, int pair, int h, unsigned s) {
+      const unsigned r = *reinterpret_cast<const unsigned *>(ap + (2 * pair + h) * ATILE + s * ASTEP);
+      pa[set][h][s] = __uint_as_float(CP ? (r ^ sgn) : r);
+    };
+    lsdr_v4f acc[2][2];                      // [pair parity][row tile of the pair]
+    auto to_ring = [&](int set, int pair) {
+      if (zq < NQ) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned row = (16u * pair + 8u * h + zrow) & 63u;
+          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = (lsdr_v2f){acc[set][h][0], acc[set][h][1]};
+          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = (lsdr_v2f){acc[set][h][2], acc[set][h][3]};
+        }
+      }
+    };
+    // diagonal sum of batch B (rows ≤ 32·B + 31 are in the ring): output bm = 32·B − (NQ−1) + o needs Z[bm + q][q], q < NQ.
+    // Split in two so that neither half ever waits between two MFMAs: the reads of term q, and — a pair of row tiles later —
+    // the adds (q ascending) and the store.
+    float zv[16];
+    auto diag_read = [&](int batch, int q) {
+      // (all 16 terms are read, branch-free: a term q ≥ NQ is whatever lies behind the row — never added)
+      const int bm = 32 * batch - (int)(NQ - 1) + (int)ro;
+      zv[q] = *reinterpret_cast<const float *>(ring + ((((unsigned)(bm + q)) & 63u) * ROWZ + 2 * q + rc) * 4);
+    };
+    float ysum = 0.f;
+    auto diag_add = [&](int q) {
+      const float t = ysum + zv[q];
+      ysum = q == 0 ? zv[0] : ((unsigned)q < NQ ? t : ysum);
+    };
+    auto diag_store = [&](int batch) {
+      const int bm = 32 * batch - (int)(NQ - 1) + (int)ro;
+      const unsigned long long m = m0 + (M - 1 - (Bw + (unsigned)bm));
+      if (bm >= 0 && m < a.count) {
+#if LSDR_MFMA_ASM_STORE
+        asm volatile("global_store_dword %0, %1, off" ::"v"(po + 2 * m + rc), "v"(ysum) : "memory");
+#else
+        po[2 * m + rc] = ysum;
+#endif
+      }
+    };
+    // Everything that is not an MFMA is cut into slices and placed BETWEEN the MFMAs of a pair of row tiles (a wavefront
+    // issues in order: whatever follows the 2·KS MFMAs of a pair waits for all of them, and whatever precedes them delays them).
+    // During pair P: step 0 sends pair P−1's tiles to the ring; every step fetches its share of pair P+1's sample operand;
+    // even P ≥ 2 reads the diagonal terms of batch P/2 − 1 (steps ≥ 1: behind the ring writes); odd P ≥ 3 adds them up and stores.
+    auto at_step = [](int i, int n, int lo, int hi) { return hi > lo ? lo + i * (hi - lo) / n : lo; };   // item i of n → a step of [lo, hi)
+#pragma unroll
+    for (unsigned s = 0; s < KS; ++s) { fetch1(0, 0, 0, s); fetch1(0, 0, 1, s); }
+    constexpr int P8 = 8;                    // one part of the next tile's loads at the head of each pair
+#pragma unroll
+    for (int pair = 0; pair < 8; ++pair) {
+      if (NLT || more) issue(NLmax * pair / P8, NLmax * (pair + 1) / P8);
+      __builtin_amdgcn_sched_barrier(0);
+      if (pair == 0) { LSDR_TR(3) }
+      const int set = pair & 1;
+#pragma unroll
+      for (unsigned s = 0; s < KS; ++s) {
+        if (s == 0) {
+          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][0][0], bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][1][0], bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {     // two independent accumulators interleaved: the pipe issues every 32 cycles
+          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][0][s], bco[s], acc[set][0], 0, 0, 0);
+          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][1][s], bco[s], acc[set][1], 0, 0, 0);
+        }
+        if (pair < 7) { fetch1(set ^ 1, pair + 1, 0, s); fetch1(set ^ 1, pair + 1, 1, s); }
+        if (pair >= 1 && s == 0) to_ring(set ^ 1, pair - 1);
+        if (pair >= 2 && !(pair & 1)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (at_step(q, 16, KS > 1 ? 1 : 0, KS) == (int)s) diag_read(pair / 2 - 1, q);
+        }
+        if (pair >= 3 && (pair & 1)) {
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            if (at_step(q, 16, 0, KS) == (int)s) diag_add(q);
+          if (s == KS - 1) diag_store((pair - 3) / 2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    to_ring(1, 7);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) diag_read(3, q);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) diag_add(q);
+    diag_store(3);
+    LSDR_TR(4)
+    if (!more) break;
+    ti = tn;
+    __syncthreads();                         // LDS is rewritten next
+    LSDR_TR(6)
+  }
+#if LSDR_MFMA_ASM_STORE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+#ifdef LSDR_FIR_TRACE
+  if (a.trace && (l & 63) == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < 8; ++i) a.trace[((size_t)blockIdx.x * 4 + (l >> 6)) * 8 + i] = tr[i];
+#endif
+}
+
 typedef void (*fir_kernel_t)(fir_args);
 
 // k_fir_mfma instances: decimations with a compile-time kernel × {2, 4} wavefronts per workgroup × {real, complex} taps; the C2
@@ -624,6 +857,49 @@ fir_kernel_t pick_mfma(unsigned D, int W, bool cplx, unsigned nl_fixed) {
     default: return nullptr;
   }
 }
+template <int DT>
+fir_kernel_t pick_blk_d(int W, bool cplx) {
+  if (W == 4) return cplx ? k_fir_mfma_blk<DT, 4, 1, 0> : k_fir_mfma_blk<DT, 4, 0, 0>;
+  return cplx ? k_fir_mfma_blk<DT, 2, 1, 0> : k_fir_mfma_blk<DT, 2, 0, 0>;
+}
+constexpr unsigned blk_fixed_nl(unsigned D, int W) { return D == 30 ? 29u : 0u; }
+fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed) {
+  if (nl_fixed && nl_fixed == blk_fixed_nl(D, W)) {
+    if (W == 4) return cplx ? k_fir_mfma_blk<30, 4, 1, 29> : k_fir_mfma_blk<30, 4, 0, 29>;
+    return cplx ? k_fir_mfma_blk<30, 2, 1, 29> : k_fir_mfma_blk<30, 2, 0, 29>;
+  }
+  switch (D) {
+    case 4: return pick_blk_d<4>(W, cplx);
+    case 8: return pick_blk_d<8>(W, cplx);
+    case 10: return pick_blk_d<10>(W, cplx);
+    case 16: return pick_blk_d<16>(W, cplx);
+    case 30: return pick_blk_d<30>(W, cplx);
+    default: return nullptr;
+  }
+}
+// geometry of a k_fir_mfma_blk launch (nb = tap blocks NQ, alen = coefficient operand floats, M = outputs per tile)
+struct blk_geom { unsigned nq, alen, U, lds, nl, nl_fixed, M, ks; };
+blk_geom blk_geometry(unsigned N, unsigned D, int W, bool cplx) {
+  blk_geom g;
+  const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4;
+  g.ks = kp / 4;
+  g.nq = (N + D - 1) / D;
+  g.alen = g.ks * 64;
+  if (g.nq > 16 || g.nq < 1) { g.M = 0; g.U = g.lds = g.nl = g.nl_fixed = 0; return g; }
+  const unsigned MW = 128 - (g.nq - 1);
+  g.M = W * MW;
+  const unsigned R = g.M + g.nq - 1;
+  g.U = (R * D + (kp / sl - D) + 1) & ~1u;
+  g.nl = (g.U / 2 + 64 * W - 1) / (64 * W);
+  const char *e = getenv("LSDR_MFMA_NLT");
+  g.nl_fixed = (g.nl == blk_fixed_nl(D, W) && !(e && !atoi(e))) ? g.nl : 0;
+  if (g.nl_fixed) g.U = 2 * g.nl * 64 * W;
+  const unsigned rowf = 2 * D + blk_padf(D);
+  const unsigned data_bytes = ((g.U + D - 1) / D + 1) * rowf * 4;
+  g.lds = ((data_bytes + 15) & ~15u) + W * 64 * 2 * (g.nq | 1u) * 4 + 128;   // + the branch-free diagonal reads' overrun
+  return g;
+}
+
 // geometry of a k_fir_mfma launch: K slots, blocks, staged extent, LDS bytes, prefetch loads per lane
 struct mfma_geom { unsigned nb, alen, U, lds, nl, nl_fixed; };
 mfma_geom mfma_geometry(unsigned N, unsigned D, int W, bool cplx) {
@@ -719,6 +995,10 @@ struct lsdr_fir_filter {
   float *d_atab[2];
   mfma_geom mf[2];
   bool mfma_ok[2];
+  // LSDR_FIR_MFMA_BLK (k_fir_mfma_blk): coefficient operand tables and geometry, real / complex taps
+  float *d_btab[2];
+  blk_geom bk[2];
+  bool blk_ok[2];
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -752,6 +1032,20 @@ static int fir_upload(lsdr_fir_filter *f) {
     LSDR_HIP(hipMemcpyAsync(f->d_atab[cp], at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     LSDR_HIP(hipStreamSynchronize(c->stream));   // `at` is pageable and dies here
   }
+  // k_fir_mfma_blk's coefficient operand: lane (k = l>>4, q = l&15) of step s holds K slot e = 4·s + k of tap block q —
+  // tap D·q + e (real taps), or tap D·q + e/2 as (re, −im) pairs (complex taps); zero outside the block / the filter
+  for (int cp = 0; cp < 2; ++cp) {
+    if (!f->blk_ok[cp]) continue;
+    std::vector<float> bt(f->bk[cp].alen, 0.f);
+    for (unsigned s = 0; s < f->bk[cp].ks; ++s)
+      for (unsigned ln = 0; ln < 64; ++ln) {
+        const unsigned e = 4 * s + (ln >> 4), q = ln & 15, r = cp ? e >> 1 : e;
+        if (q >= f->bk[cp].nq || r >= D || D * q + r >= N) continue;
+        bt[s * 64 + ln] = cp == 0 ? rc[D * q + r] : ((e & 1) ? -f->shifted[D * q + r].im : f->shifted[D * q + r].re);
+      }
+    LSDR_HIP(hipMemcpyAsync(f->d_btab[cp], bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+  }
   LSDR_HIP(hipStreamSynchronize(c->stream));
   return LSDR_OK;
 }
@@ -762,7 +1056,7 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   LSDR_ARG(c && cfg && out);
   LSDR_ARG(cfg->ncoeffs >= 1 && cfg->coeffs_host && cfg->decim >= 1);
   LSDR_ARG(cfg->in_format == LSDR_IN_CF32 || cfg->in_format == LSDR_IN_CU8);
-  LSDR_ARG(cfg->arith == LSDR_FIR_EXACT || cfg->arith == LSDR_FIR_FMA || cfg->arith == LSDR_FIR_MFMA);
+  LSDR_ARG(cfg->arith == LSDR_FIR_EXACT || cfg->arith == LSDR_FIR_FMA || cfg->arith == LSDR_FIR_MFMA || cfg->arith == LSDR_FIR_MFMA_BLK);
   LSDR_HIP(hipSetDevice(c->device));
   lsdr_fir_filter *f = new lsdr_fir_filter();
   f->ctx = c;
@@ -824,12 +1118,25 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   {
     const char *ew = getenv("LSDR_MFMA_W"), *ep = getenv("LSDR_MFMA_WPC");
     f->mf_W = ew && atoi(ew) == 4 ? 4 : 2;
-    f->mf_wpc = ep && atoi(ep) > 0 ? atoi(ep) : (f->mf_W == 4 ? 1 : 2);
+    f->mf_wpc = ep && atoi(ep) > 0 ? atoi(ep) : (f->mf_W == 4 ? 2 : 3);   // more workgroups than fit at once: the resident ones fall out of step (measured: W = 2: 2 → 0.154 ms, 3 → 0.119 ms per 64 Mi)
+  }
+  f->d_btab[0] = f->d_btab[1] = nullptr;
+  f->blk_ok[0] = f->blk_ok[1] = false;
+  if (cfg->arith == LSDR_FIR_MFMA_BLK) {
+    // available for cf32 input, even compile-time decimations, N ≤ 16·D; anything else is refused at create time (the blocked
+    // sum is its own arithmetic: there is no other kernel with the same bits to fall back to)
+    LSDR_ARG(cfg->in_format == LSDR_IN_CF32 && pick_blk(D, f->mf_W, false, 0) != nullptr);
+    for (int cp = 0; cp < 2; ++cp) {
+      f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
+      f->blk_ok[cp] = f->bk[cp].M > 0 && f->bk[cp].nl <= 32 && f->bk[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2);
+      LSDR_ARG(f->blk_ok[cp]);
+      LSDR_HIP(hipMalloc((void **)&f->d_btab[cp], f->bk[cp].alen * sizeof(float)));
+    }
   }
   if (cfg->arith == LSDR_FIR_MFMA && cfg->in_format == LSDR_IN_CF32 && pick_mfma(D, f->mf_W, false, 0) != nullptr) {
     for (int cp = 0; cp < 2; ++cp) {
       f->mf[cp] = mfma_geometry(N, D, f->mf_W, cp != 0);
-      f->mfma_ok[cp] = f->mf[cp].nl <= 32 && f->mf[cp].lds <= (size_t)160 * 1024 / f->mf_wpc;
+      f->mfma_ok[cp] = f->mf[cp].nl <= 32 && f->mf[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2);
       if (f->mfma_ok[cp]) LSDR_HIP(hipMalloc((void **)&f->d_atab[cp], f->mf[cp].alen * sizeof(float)));
     }
   }
@@ -846,6 +1153,8 @@ void lsdr_fir_filter_destroy(lsdr_fir_filter *f) {
   (void)hipFree(f->d_rcp);
   (void)hipFree(f->d_atab[0]);
   (void)hipFree(f->d_atab[1]);
+  (void)hipFree(f->d_btab[0]);
+  (void)hipFree(f->d_btab[1]);
   delete f;
 }
 
@@ -892,7 +1201,8 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   for (unsigned i = 0; i < n_streams; ++i) LSDR_ARG(ins[i] && outs[i]);
   const bool real_taps = f->all_real && !f->force_complex;
   const bool mfma = f->cfg.arith == LSDR_FIR_MFMA && f->mfma_ok[real_taps ? 0 : 1];
-  if (n_streams > 1 && !mfma && !(f->spec && f->persist)) {   // only the persistent kernels take several buffers per launch
+  const bool blk = f->cfg.arith == LSDR_FIR_MFMA_BLK;
+  if (n_streams > 1 && !mfma && !blk && !(f->spec && f->persist)) {   // only the persistent kernels take several buffers per launch
     for (unsigned i = 0; i < n_streams; ++i) {
       int rc = fir_run_streams(f, 1, ins + i, n_in, outs + i, cap_out, consumed, produced);
       if (rc) return rc;
@@ -915,7 +1225,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.N = N; a.D = D; a.S = f->S;
   a.count = count;
   a.n_in = n_in;
-  const unsigned M = mfma ? 128u * f->mf_W : kThreads * f->R;
+  const unsigned M = blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
   a.tiles_per_stream = (unsigned)n_tiles;
@@ -935,18 +1245,19 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   }
 #endif
 
-  if (mfma) {
+  if (mfma || blk) {
     const int cp = real_taps ? 0 : 1;
-    a.mf_atab = f->d_atab[cp];
-    a.mf_alen = f->mf[cp].alen;
-    a.mf_blocks = f->mf[cp].nb;
-    fir_kernel_t k = pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
-    if (f->mf[cp].lds > 64 * 1024)
-      LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)f->mf[cp].lds));
+    a.mf_atab = blk ? f->d_btab[cp] : f->d_atab[cp];
+    a.mf_alen = blk ? f->bk[cp].alen : f->mf[cp].alen;
+    a.mf_blocks = blk ? f->bk[cp].nq : f->mf[cp].nb;
+    fir_kernel_t k = blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
+    const size_t lds_bytes = blk ? f->bk[cp].lds : f->mf[cp].lds;
+    if (lds_bytes > 64 * 1024)
+      LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;
     const unsigned pg = (unsigned)(f->ctx->num_cu * f->mf_wpc + 7) / 8 * 8;
     if (grid > pg) grid = pg;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * f->mf_W), f->mf[cp].lds, f->ctx->stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * f->mf_W), lds_bytes, f->ctx->stream, a);
     LSDR_HIP(hipGetLastError());
     *produced = count;
     *consumed = count * D;

@@ -75,6 +75,10 @@ size_t lo_fir_filter(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
 size_t lo_fir_filter_fma(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
                      const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
                      size_t *consumed);
+/* blocks of `decim` taps: an fmaf chain per block, block sums added in order — the stated arithmetic of LSDR_FIR_MFMA_BLK */
+size_t lo_fir_filter_blk(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
+                     const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
+                     size_t *consumed);
 /* fir_resampler<cf32,float> (interpolator): dsp.h:290-364 */
 void lo_fir_resampler_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq,
                                    lo_cf32 *shifted);      /* dsp.h:351-360 */

@@ -102,6 +102,43 @@ size_t lo_fir_filter_fma(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
   return count;
 }
 
+/* The arithmetic of LSDR_FIR_MFMA_BLK (k_fir_mfma_blk), stated once: the reference's loop (dsp.h:246-262) with the taps cut
+ * into blocks of `decim` consecutive taps — each block an fmaf chain from zero in tap order, the block sums added in block
+ * order with plain float adds.  (What a block-polyphase evaluation on fused hardware computes; same error class as
+ * lo_fir_filter_fma.) */
+size_t lo_fir_filter_blk(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
+                         const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
+                         size_t *consumed) {
+  *consumed = 0;
+  if (n_in < ncoeffs) return 0;
+  size_t count = (n_in - ncoeffs) / decim;
+  if (count > cap) count = cap;
+  int all_real = 1;
+  for (unsigned i = 0; i < ncoeffs; ++i) all_real &= sc[i].im == 0.0f;
+  for (size_t m = 0; m < count; ++m) {
+    const lo_cf32 *p0 = in + ncoeffs + m * decim;
+    float yr = 0, yi = 0;
+    for (unsigned q = 0; q * decim < ncoeffs; ++q) {
+      float zr = 0, zi = 0;
+      for (unsigned i = q * decim; i < (q + 1) * decim && i < ncoeffs; ++i) {
+        const lo_cf32 *pi = p0 - i;
+        zr = fmaf(sc[i].re, pi->re, zr);
+        zi = fmaf(sc[i].re, pi->im, zi);
+        if (!all_real) {
+          zr = fmaf(-sc[i].im, pi->im, zr);
+          zi = fmaf(sc[i].im, pi->re, zi);
+        }
+      }
+      yr = q ? yr + zr : zr;
+      yi = q ? yi + zi : zi;
+    }
+    out[m].re = yr;
+    out[m].im = yi;
+  }
+  *consumed = count * decim;
+  return count;
+}
+
 /* dsp.h:351-360: a = 2*M_PI*f*i with int i. */
 void lo_fir_resampler_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq, lo_cf32 *shifted) {
   for (int i = 0; i < (int)ncoeffs; ++i) {

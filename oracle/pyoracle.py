@@ -140,6 +140,8 @@ class Oracle:
                                     C.c_void_p, c_sz, C.POINTER(c_sz)]
         L.lo_fir_filter_fma.restype = c_sz
         L.lo_fir_filter_fma.argtypes = L.lo_fir_filter.argtypes
+        L.lo_fir_filter_blk.restype = c_sz
+        L.lo_fir_filter_blk.argtypes = L.lo_fir_filter.argtypes
         L.lo_fir_resampler_shift_coeffs.argtypes = [C.c_uint, C.c_void_p, c_f, C.c_void_p]
         L.lo_fir_resampler.restype = c_sz
         L.lo_fir_resampler.argtypes = [C.c_uint, C.c_void_p, C.c_int, C.c_void_p, c_sz,
@@ -251,13 +253,14 @@ class Oracle:
         return out
 
     def fir_filter(self, coeffs, decim, x, freq=0.0, shifted=None, fma=False):
-        """fma=True: the fused-multiply-add restatement (the arithmetic of LSDR_FIR_FMA / LSDR_FIR_MFMA)."""
+        """fma=True: the fused-multiply-add restatement (the arithmetic of LSDR_FIR_FMA / LSDR_FIR_MFMA); fma="blk": the
+        block-polyphase restatement (LSDR_FIR_MFMA_BLK)."""
         x = cf32(x)
         sc = self.fir_shift(coeffs, freq) if shifted is None else cf32(shifted)
         cap = max(0, (len(x) - len(sc)) // decim) + 1
         out = np.empty(cap, np.complex64)
         consumed = c_sz()
-        fn = self.lib.lo_fir_filter_fma if fma else self.lib.lo_fir_filter
+        fn = self.lib.lo_fir_filter_blk if fma == "blk" else self.lib.lo_fir_filter_fma if fma else self.lib.lo_fir_filter
         n = fn(len(sc), _p(sc), decim, _p(x), len(x), _p(out), cap, C.byref(consumed))
         return out[:n], consumed.value
 

@@ -252,3 +252,65 @@ def test_mfma_run_multi_and_short_inputs(capi, ctx, oracle):
     for d in dins + douts:
         d.free()
     f.close()
+
+
+BLK_GEOMS = [(313, 30), (200, 30), (330, 30), (480, 30), (30, 30), (101, 10), (160, 10), (161, 16), (65, 8), (40, 4), (17, 16), (7, 8)]
+
+
+@pytest.mark.parametrize("w", [2, 4])
+@pytest.mark.parametrize("n,d", BLK_GEOMS, ids=[f"N{n}_D{d}" for n, d in BLK_GEOMS])
+def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, w, n, d):
+    """LSDR_FIR_MFMA_BLK (k_fir_mfma_blk: block-polyphase dense product on the matrix pipe) against its stated arithmetic,
+    oracle.fir_filter(fma="blk") — the reference's loop with the taps in blocks of D, an fmaf chain per block, block sums
+    added in order — bit for bit, and against the reference's arithmetic under LSDR_FIR_FMA's error bound."""
+    rng = np.random.default_rng(n * 37 + d)
+    ns = 4096 * 90 + 77
+    x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 12).astype(np.complex64)
+    co = capi.lowpass(n - 1, 0.4 / d) if n > 1 else np.array([0.75], np.float32)
+    os.environ["LSDR_MFMA_W"] = str(w)
+    try:
+        for freq in (0.0, 0.0123):
+            f = capi.FirFilter(ctx, co, d, in_scale=75.0, arith=capi.FIR_MFMA_BLK)
+            if freq:
+                f.set_freq(freq)
+            y, cons = f.run(x)
+            f.close()
+            ref, rcons = oracle.fir_filter(co, d, oracle.scaler(75.0, x), freq, fma="blk")
+            assert cons == rcons and len(y) == len(ref)
+            assert np.array_equal(y, ref), (freq, int((y != ref).sum()), int(np.flatnonzero(y != ref)[0]), float(np.abs(y - ref).max()))
+            exact, _ = oracle.fir_filter(co, d, oracle.scaler(75.0, x), freq)
+            bound = 4e-6 * np.abs(co).sum() * np.abs(x).max() * 75 * 2
+            assert np.abs(y - exact).max() <= bound
+    finally:
+        del os.environ["LSDR_MFMA_W"]
+
+
+def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle):
+    rng = np.random.default_rng(13)
+    co = capi.lowpass(312, np.float32(0.0049))
+    f = capi.FirFilter(ctx, co, 30, in_scale=0.5, arith=capi.FIR_MFMA_BLK)
+    n = 250000
+    xs = [((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 20).astype(np.complex64) for _ in range(3)]
+    cap = (n - 313) // 30
+    dins = [ctx.upload(x) for x in xs]
+    douts = [ctx.alloc(cap * 8 + 64) for _ in xs]
+    cons, prod = f.run_multi_dev([d.ptr for d in dins], n, [d.ptr for d in douts], cap)
+    assert prod == cap and cons == cap * 30
+    for x, dout in zip(xs, douts):
+        want, _ = oracle.fir_filter(co, 30, oracle.scaler(0.5, x), fma="blk")
+        assert np.array_equal(ctx.download(dout, np.complex64, prod), want[:prod])
+    for m in (0, 312, 313, 342, 343, 344, 1000, 4153, 8000):
+        y, cons = f.run(xs[0][:m])
+        want, wcons = oracle.fir_filter(co, 30, oracle.scaler(0.5, xs[0][:m]), fma="blk")
+        assert cons == wcons and np.array_equal(y, want), m
+    cons, prod = f.run_dev(dins[0].ptr, n, douts[0].ptr, 1000)
+    assert (cons, prod) == (30000, 1000)
+    want, _ = oracle.fir_filter(co, 30, oracle.scaler(0.5, xs[0]), fma="blk")
+    assert np.array_equal(ctx.download(douts[0], np.complex64, 1000), want[:1000])
+    for d in dins + douts:
+        d.free()
+    f.close()
+    # its own arithmetic: no other kernel has the same bits, so geometries without a kernel are refused, not re-routed
+    for nn, dd, fmt in ((313, 7, capi.IN_CF32), (600, 30, capi.IN_CF32), (313, 30, capi.IN_CU8)):
+        with pytest.raises(Exception):
+            capi.FirFilter(ctx, capi.lowpass(nn - 1, 0.01), dd, in_format=fmt, arith=capi.FIR_MFMA_BLK)

@@ -16,23 +16,24 @@ for r in range(n // len(blk)):
     capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * blk.nbytes), d_blk.ptr, blk.nbytes))
 d_out = ctx.alloc(n // 30 * 8 + 64)
 c = capi.lowpass(312, np.float32((2e6 / 2) * (1 + 0.35 / 2) / 240e6))
-arith = {"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA}[os.environ.get("FIR_ARITH", "exact")]
+arith = {"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[os.environ.get("FIR_ARITH", "exact")]
 f = capi.FirFilter(ctx, c, 30, in_scale=75.0, arith=arith)
 if freq:
     f.set_freq(freq)
 for _ in range(3):
     f.run_dev(d_in.ptr, n, d_out.ptr, n // 30)
 ctx.sync()
-mf = arith == capi.FIR_MFMA
+mf = arith in (capi.FIR_MFMA, capi.FIR_MFMA_BLK)
+is_blk = arith == capi.FIR_MFMA_BLK
 W = int(os.environ.get("LSDR_MFMA_W", "2"))
-nwg = (int(os.environ.get("LSDR_MFMA_WPC", "1" if W == 4 else "2")) if mf else int(os.environ.get("LSDR_FIR_PERSIST", "2"))) * 256
+nwg = (int(os.environ.get("LSDR_MFMA_WPC", "2" if W == 4 else "3")) if mf else int(os.environ.get("LSDR_FIR_PERSIST", "2"))) * 256
 tr = np.zeros(nwg * 4 * 8, np.uint64)
 capi.lib.lsdr_fir_trace_read.argtypes = [C.c_void_p, C.c_size_t]
 assert capi.lib.lsdr_fir_trace_read(tr.ctypes.data, len(tr)) == 0
 tr = tr.reshape(nwg, 4, 8).astype(np.float64)
 if mf:
     tr = tr[:, :W, :]
-tiles = (n // 30 // (128 * W if mf else 256)) / nwg
+tiles = (n // 30 // ((118 if is_blk else 128) * W if mf else 256)) / nwg
 names = ["prologue issue", "wait loads + LDS write", "barrier A", "issue next loads (first part)" if mf else "issue next loads",
          "MFMA phase (+ later parts)" if mf else "taps", "store", "barrier B", "-"]
 print(f"FIR_ARITH={os.environ.get('FIR_ARITH','exact')} W={W} workgroups={nwg}")
