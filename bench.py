@@ -169,7 +169,7 @@ class Capture:
     """One capture: its endless input in HBM, the decimated-stream buffers, the symbol buffer, its receiver (own HIP
     stream).  fir_filter of all captures of a GPU goes through ONE launch on the fir stream."""
 
-    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None, cw=None):
+    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None, cw=None, shared_rx_ctx=None):
         self.capi, self.idx, self.geo = capi, idx, geo
         period, reps, B, n_out, N, decim = geo["period"], geo["reps"], geo["B"], geo["n_out"], geo["N"], geo["decim"]
         self.x, _ = synth.qpsk_baseband(period, geo["sps"], seed=seed, rms=1.0, snr_db=20.0, freq=freq)
@@ -177,7 +177,8 @@ class Capture:
             f = round(cw[0] * period) / period
             self.x = (self.x + np.float32(cw[1]) * np.exp(2j * np.pi * f * np.arange(period))).astype(np.complex64)
         self.ctx = fir_ctx
-        self.ctx_rx = capi.Ctx(device, cu_mask=rx_cus)
+        self.own_rx_ctx = shared_rx_ctx is None
+        self.ctx_rx = capi.Ctx(device, cu_mask=rx_cus) if shared_rx_ctx is None else shared_rx_ctx
         self.d_in = self.ctx.alloc((B + period) * 8)
         dp = self.ctx.upload(self.x)
         for r in range(reps + 1):
@@ -217,15 +218,20 @@ class Capture:
         self.d_in.free(); self.d_sym.free()
         for d in self.dec:
             d.free()
-        self.ctx_rx.close()
+        if self.own_rx_ctx:
+            self.ctx_rx.close()
 
 
 class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True):
         self.capi = capi
+        # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
+        # streams in all — with a stream per capture, five streams on the runtime's four hardware queues let two receivers
+        # share a queue, and that queue paced the pipeline
+        self.rx_multi = bool(rx_multi) and n_captures > 1
         # CU partition: the latency-bound receiver tiles get rx_cus compute units of their own (the same number from every
         # XCD), the HBM-streaming fir_filter the rest, so that neither disturbs the other's issue slots / L1
         fir_mask = rx_mask = None
@@ -248,8 +254,9 @@ class C2Pipeline:
         if rx_freq:   # what fir_filter::run does on its first call: the receiver's initial freq_tap moves the filter (dsp.h:236-244)
             self.fir.track(float(np.float32(rx_freq)), 1.0 / decim, float(np.float32(FM / FS * 0.1)))
         self.tile = tile
-        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw)
-                     for c in range(n_captures)]
+        self.ctx_rx = capi.Ctx(device, cu_mask=rx_mask) if self.rx_multi else None
+        self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw,
+                             shared_rx_ctx=self.ctx_rx) for c in range(n_captures)]
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)
         self.ev_fir = [self.ctx.event() for _ in range(self.geo["nbuf"])]
@@ -269,7 +276,11 @@ class C2Pipeline:
         while timed and len(self.ev_pool) < 2 * n_batches:
             self.ev_pool.append(self.ctx.event())
         consumed = 0
+        prof = os.environ.get("LSDR_BENCH_HOSTPROF") and timed        # host-side seconds per call category (diagnostic)
+        tp = [0.0, 0.0, 0.0, 0.0]
+        pc = time.perf_counter
         for k in range(n_batches):
+            if prof: t_a = pc()
             i = self.batch_no % NBUF
             # dec[i] of every capture is free: its receiver run (batch_no − NBUF) was retired on the host (≤ 2 stay queued)
             if timed:
@@ -281,7 +292,19 @@ class C2Pipeline:
             done = self.ev_pool[2 * k + 1] if timed else self.ev_fir[i]   # (timed: the stop event doubles as the "filtered" event)
             self.ctx.event_record(done)
             assert prod == n_out + EXTRA, (prod, n_out)
-            for c in caps:
+            if prof: t_b = pc(); tp[0] += t_b - t_a
+            if self.rx_multi:
+                self.ctx_rx.wait_event(done)
+                if snapshot_last and k == n_batches - 1:
+                    for c in caps:
+                        c.rx.snapshot_async()
+                    self.snap = (0, i)
+                used = capi.CstlnReceiver.run_multi_async([c.rx for c in caps], [c.dec[i].ptr for c in caps], prod,
+                                                          [c.d_sym.ptr for c in caps], n_out + EXTRA + 256)
+                assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
+                for c in caps:
+                    c.queued += 1
+            for c in ([] if self.rx_multi else caps):
                 c.ctx_rx.wait_event(done)
                 if snapshot_last and k == n_batches - 1:
                     c.rx.snapshot_async()
@@ -290,8 +313,10 @@ class C2Pipeline:
                 assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
                 c.queued += 1
             consumed += B * len(caps)
+            if prof: t_c = pc(); tp[1] += t_c - t_b
             for c in caps:
                 c.retire(timed, keep=2)
+            if prof: tp[2] += pc() - t_c
             if track_tol is not None and caps[0].retired:
                 # fir_filter follows the receiver's carrier estimate (dsp.h:236-244) from the newest run that has COMPLETED:
                 # the feedback of leandvb.cc:506-510 with the queue depth as latency, no host wait between two batches
@@ -299,6 +324,9 @@ class C2Pipeline:
             self.batch_no += 1
         for c in caps:
             c.retire(timed, keep=0)
+        if prof:
+            print(f"hostprof: per batch: fir enqueue {tp[0] / n_batches * 1e6:.1f} us, receiver enqueue ({len(caps)} captures) {tp[1] / n_batches * 1e6:.1f} us, "
+                  f"retire (waits for the GPU) {tp[2] / n_batches * 1e6:.1f} us", file=sys.stderr)
         if timed:
             self.ctx.sync()
             for k in range(n_batches):       # HIP events around every fir_filter launch, on its own stream
@@ -349,8 +377,10 @@ class C2Pipeline:
         if self.fir_arith == capi.FIR_EXACT:
             y_want = y_ref
         else:
-            y_want = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full), freq=self.fir.current_freq,
-                                  fma="blk" if self.fir_arith == capi.FIR_MFMA_BLK else True)[0]
+            if self.fir_arith == capi.FIR_MFMA_BLK:      # the scaler rides on the taps in this mode
+                y_want = O.fir_filter(self.coeffs, decim, x_full, freq=self.fir.current_freq, fma="blk", scale=75.0)[0]
+            else:
+                y_want = O.fir_filter(self.coeffs, decim, O.scaler(75.0, x_full), freq=self.fir.current_freq, fma=True)[0]
             scale = float(np.abs(y_ref).max())
             fir_extra = dict(fir_arith={capi.FIR_FMA: "fma", capi.FIR_MFMA: "mfma", capi.FIR_MFMA_BLK: "mfma_blk"}[self.fir_arith],
                              fir_max_abs_err_vs_exact=float(np.abs(y - y_ref).max()) if len(y) == len(y_ref) else None,
@@ -401,6 +431,8 @@ class C2Pipeline:
     def close(self):
         for c in self.caps:
             c.close()
+        if self.ctx_rx is not None:
+            self.ctx_rx.close()
         self.fir.close()
         self.ctx.close()
 
@@ -439,9 +471,13 @@ def main():
     ap.add_argument("--tile-warmup", type=int, default=DEFAULT_TILE[1])
     ap.add_argument("--captures", type=int, default=4,
                     help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles)")
-    ap.add_argument("--fir-arith", choices=["exact", "fma", "mfma", "blk"], default="exact",
-                    help="fir_filter arithmetic of the headline: exact = the reference's (bit-exact output); fma / mfma = fused multiply-adds "
-                         "(VALU / matrix pipe; output bit-identical to the oracle's fmaf restatement, soft symbols under the stated tolerance)")
+    ap.add_argument("--fir-arith", choices=["exact", "fma", "mfma", "blk"], default="blk",
+                    help="fir_filter arithmetic of the headline.  blk (default) = block-polyphase on the f32 matrix pipe (LSDR_FIR_MFMA_BLK: output "
+                         "bit-identical to the oracle's restatement lo_fir_filter_blk, ≤ 1e-5 of full scale from the reference's arithmetic; "
+                         "north_star's contract: soft symbols within the stated tolerance, TS bit-exact — both checked); exact = the reference's "
+                         "arithmetic (bit-exact filter output: `more.c2_exact`); fma / mfma = one fmaf chain per output (VALU / matrix pipe)")
+    ap.add_argument("--rx-per-stream", action="store_true", help="one HIP stream and one set of launches per capture's receiver (round 3's arrangement) "
+                                                                 "instead of shared launches on one stream (lsdr_rx_run_multi_async)")
     ap.add_argument("--rx-cus", type=int, default=0, help="compute units reserved for the receiver streams (0: no partition)")
     ap.add_argument("--cu-pattern", choices=["xcd_major", "interleaved"], default="xcd_major")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
@@ -509,7 +545,8 @@ def main():
     tile = (args.tile_len, args.tile_warmup)
     pipe = C2Pipeline(capi, synth, local_rank, args.captures, args.batch_msamples, args.period_msamples, tile,
                       seed0=shard.capture_seed(), rx_cus=args.rx_cus, cu_pattern=args.cu_pattern,
-                      fir_arith={"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[args.fir_arith])
+                      fir_arith={"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[args.fir_arith],
+                      rx_multi=not args.rx_per_stream)
     bps = args.batches_per_step
 
     pipe.run(args.warmup * bps, False)
@@ -542,13 +579,17 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE config 2: QPSK 1/2, Fs 240 MS/s cf32 (120 sps), device-resident endless stream; "
                                    "scaler(x75 fused) + fir_filter(N=313,D=30) + cstln_receiver(omega 4, linear sampler)",
+                       "fir_arith": {"exact": "LSDR_FIR_EXACT (the reference's arithmetic, bit-exact)", "fma": "LSDR_FIR_FMA", "mfma": "LSDR_FIR_MFMA",
+                                     "blk": "LSDR_FIR_MFMA_BLK (f32 matrix pipe, block-polyphase; tolerance mode: filter output pinned bit for bit to "
+                                            "oracle lo_fir_filter_blk, soft symbols under leansdr_amd.tolerance.TOL vs the exact chain)"}[args.fir_arith],
+                       "rx_launches": "per capture (one stream each)" if args.rx_per_stream else "shared by the captures of a GPU (lsdr_rx_run_multi_async, one stream)",
                        "batches_per_step": bps, "batch_samples_per_capture": g["B"], "captures_per_gpu": len(pipe.caps),
                        "samples_per_step_per_gpu": g["B"] * len(pipe.caps) * bps,
                        "rx_mode": "tiled", "rx_tile": {"tile_len": tile[0], "warmup": tile[1]},
                        "cu_partition": {"receiver_cus": pipe.rx_cus, "fir_filter_cus": 256 - pipe.rx_cus} if pipe.rx_cus else None,
                        "rx_tiles_last_run": pipe.caps[0].rx.tiled_stats(), "rx_decisions": pipe.caps[0].rx.decision_mode(),
-                       "streams": "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k), "
-                                  "one HIP stream per capture, receiver runs queued (lsdr_rx_run_async)",
+                       "streams": "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k) of all captures in "
+                                  "shared launches (lsdr_rx_run_multi_async): two HIP streams, receiver runs queued",
                        "parallelism": f"{world * len(pipe.caps)} independent capture(s), {len(pipe.caps)} per GPU, no collectives, no RCCL",
                        "symbols_per_step": nsym // max(1, args.steps)},
             "roofline": pipe.roofline(),

@@ -84,12 +84,17 @@ def ts_contains(got_packets, ref_bytes, skip=16, min_packets=24):
     return dict(ref_packets=len(rpk), compared=m, equal=bool(m >= min_packets and got_packets[i0:i0 + m] == tail[:m]))
 
 
+def headline_arith(capi, args):
+    """The fir_filter arithmetic of the headline (bench.py --fir-arith): the secondary configurations run the same filter."""
+    return {"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[getattr(args, "fir_arith", "blk")]
+
+
 def single_stream(capi, synth, device, args):
     import bench
     # one capture, batches as large as the headline's four together (256 Mi samples: 64 → 441, 128 → 486, 256 → 505 GS/s — the
     # hand-over between two filter launches costs the same whatever the launch size)
     pipe = bench.C2Pipeline(capi, synth, device, 1, 4 * args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=77,
-                            rx_cus=args.rx_cus, cu_pattern=args.cu_pattern)
+                            rx_cus=args.rx_cus, cu_pattern=args.cu_pattern, fir_arith=headline_arith(capi, args))
     t0 = time.perf_counter()
     pipe.run(8, False)
     pipe.sync()
@@ -105,28 +110,49 @@ def single_stream(capi, synth, device, args):
     return out
 
 
-def c2_fma(capi, synth, device, args):
+def c2_variant(capi, synth, device, args, arith, note, n_caps=None):
+    """Config 2 with another fir_filter arithmetic than the headline's; verified like the headline (filter output bit for bit
+    against the arithmetic's oracle restatement, soft symbols under TOL against the exact chain)."""
     import bench
-    pipe = bench.C2Pipeline(capi, synth, device, min(3, args.captures), args.batch_msamples, args.period_msamples,
-                            (args.tile_len, args.tile_warmup), seed0=91, fir_arith=capi.FIR_FMA)
+    pipe = bench.C2Pipeline(capi, synth, device, n_caps or args.captures, args.batch_msamples, args.period_msamples,
+                            (args.tile_len, args.tile_warmup), seed0=91, fir_arith=arith)
     t0 = time.perf_counter()
     pipe.run(16, False)
     pipe.sync()
     nb = batches_for((time.perf_counter() - t0) / 16)
-    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True), pipe.sync)
+    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True, snapshot_last=not args.no_verify), pipe.sync)
     nb *= calls
     out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=len(pipe.caps), batches=nb,
-               arithmetic="v_pk_fma_f32 (one rounding per tap instead of two; tolerance-tested in tests/test_gpu_fir.py, not the default)",
-               roofline=pipe.roofline(), **{"pass": None})
+               arithmetic=note, roofline=pipe.roofline())
+    if not args.no_verify:
+        out["verified"] = pipe.verify_last_batch()
+        out["pass"] = out["verified"]["pass"]
     pipe.close()
     return out
+
+
+def c2_exact(capi, synth, device, args):
+    return c2_variant(capi, synth, device, args, capi.FIR_EXACT,
+                      "LSDR_FIR_EXACT: the reference's arithmetic (two roundings per tap, i ascending) on the vector ALUs, k_fir_persist — "
+                      "filter output bit-exact against the oracle")
+
+
+def c2_fma(capi, synth, device, args):
+    return c2_variant(capi, synth, device, args, capi.FIR_FMA,
+                      "LSDR_FIR_FMA: one fmaf chain per output on the vector ALUs (v_pk_fma_f32) — bit-identical to oracle lo_fir_filter_fma")
+
+
+def c2_mfma(capi, synth, device, args):
+    return c2_variant(capi, synth, device, args, capi.FIR_MFMA,
+                      "LSDR_FIR_MFMA: the same fmaf chain as a banded Toeplitz block on v_mfma_f32_16x16x4_f32 (k_fir_mfma) — bit-identical to "
+                      "oracle lo_fir_filter_fma and to c2_fma")
 
 
 def anf1(capi, synth, device, args):
     """One capture: auto_notch(scan) on its own stream → fir_filter → cstln_receiver (queued), three stages in flight."""
     import bench
     pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=33,
-                            cw=(0.0137, 3.0))
+                            cw=(0.0137, 3.0), fir_arith=headline_arith(capi, args))
     g, cp = pipe.geo, pipe.caps[0]
     ctx_n = capi.Ctx(device)
     notch = capi.AutoNotch(ctx_n, 1, 0.0, mode=capi.NOTCH_SCAN)
@@ -219,7 +245,7 @@ def c2_offset(capi, synth, device, args):
     import bench
     f0 = 1.0e6 / bench.FS                 # cycles per input sample
     pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup),
-                            seed0=55, freq=f0, rx_freq=f0 * 30)
+                            seed0=55, freq=f0, rx_freq=f0 * 30, fir_arith=headline_arith(capi, args))
     g = pipe.geo
     tol = float(np.float32(bench.FM / bench.FS * 0.1))
     t0 = time.perf_counter()
@@ -238,7 +264,7 @@ def c2_offset(capi, synth, device, args):
                filter_freq=pipe.fir.current_freq, filter_reshifts=int(pipe.reshifts), receiver_freq_tap=cp.rx.state().freq_tap,
                symbols_per_batch=cp.nsym // nb, **{"pass": bool(followed and pipe.reshifts > 0)},
                mode="queued like the headline; freq_tap of the newest completed receiver run -> fir_filter::track() on the host",
-               roofline=dict(pipe.roofline(), kernel="k_fir_persist, complex taps", traffic=None, traffic_source=None))
+               roofline=dict(pipe.roofline(), kernel=pipe.roofline()["kernel"] + ", complex taps", traffic=None, traffic_source=None))
     pipe.close()
     return out
 
@@ -329,7 +355,7 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     dp.free()
     omega = float(sps / decim)
     rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=cstln, fec=rate, omega=omega, meas_decimation=1 << 22, pll_adjustment=1 / 6.0)
-    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0) if use_fir else None
+    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0, arith=headline_arith(capi, args)) if use_fir else None
     d_decs = [ctx.alloc((n_out + bench.EXTRA) * 8) for _ in range(2)] if use_fir else None
     d_dec = d_decs[0] if use_fir else None
     # the receiver has its own stream: fir_filter(k+1) runs while cstln_receiver(k) (queued) works on the other decimated buffer
@@ -967,7 +993,8 @@ def end_to_end(capi, synth, device, args):
 
 def run_all(capi, synth, device, args):
     more = {}
-    for name, fn in (("single_stream", single_stream), ("anf1", anf1), ("c2_offset", c2_offset), ("c2_fma", c2_fma), ("c3", c3),
+    for name, fn in (("single_stream", single_stream), ("c2_exact", c2_exact), ("c2_fma", c2_fma), ("c2_mfma", c2_mfma), ("anf1", anf1),
+                     ("c2_offset", c2_offset), ("c3", c3),
                      ("c5_rescoped", c5_rescoped), ("c1", c1), ("c1_hs", c1_hs_entry), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
         t0 = time.perf_counter()
         try:

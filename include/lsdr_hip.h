@@ -200,8 +200,9 @@ enum {
                        * k-ordered fmaf chain): the taps as a banded Toeplitz block, sixteen outputs per row group.  cf32 input
                        * at the decimations with a compile-time kernel; anything else runs LSDR_FIR_FMA's kernels (same bits). */
   LSDR_FIR_MFMA_BLK = 3 /* block-polyphase form on the matrix pipe (a dense product): the taps in blocks of `decim`, each block an
-                       * fmaf chain from zero in tap order, the block sums added in block order — its own stated arithmetic
-                       * (oracle lo_fir_filter_blk), same error bound as LSDR_FIR_FMA.  cf32 input, even decimations with a
+                       * fmaf chain from zero in tap order, the block sums added in block order, in_scale multiplied into the taps (one
+                       * rounding per tap) instead of the samples — its own stated arithmetic (oracle lo_fir_filter_blk), same
+                       * error bound as LSDR_FIR_FMA.  cf32 input, even decimations with a
                        * compile-time kernel, ncoeffs ≤ 16·decim; refused (LSDR_E_ARG) otherwise. */
 };
 typedef struct {
@@ -300,6 +301,13 @@ int lsdr_rx_run(lsdr_rx *r, const void *in /* n_in items of cfg.in_format */, si
  * the host never sits between two runs.  lsdr_rx_run / _set_state refuse to mix with outstanding queued runs. */
 int lsdr_rx_run_async(lsdr_rx *rx, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
 int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
+/* lsdr_rx_run_async for n_rx independent captures at once (one receiver per capture — the reference has one cstln_receiver
+ * object per stream, sdr.h:697-938, leandvb.cc:163): equally long inputs ins[i] → outs[i], `consumed` per capture.  Receivers
+ * on ONE context with the same configuration share their launches (four per batch instead of four per capture); any other
+ * combination is queued receiver by receiver.  Same results as n_rx separate lsdr_rx_run_async calls, bit for bit; each
+ * receiver is retired with its own lsdr_rx_wait. */
+int lsdr_rx_run_multi_async(lsdr_rx *const *rxs, unsigned n_rx, const void *const *ins, size_t n_in, lsdr_softsymbol *const *outs,
+                            size_t cap_out, size_t *consumed);
 /* The queued run of a LSDR_SYM_HARD2 receiver, writing its packed symbols from symbol position out_sym_offset of the stream
  * that starts at out_words[0] (symbols before it — a caller's unconsumed remainder of the previous run — are preserved, so
  * consecutive runs form one packed stream without a bit-shifting copy).  cap_out counts symbols after the offset. */

@@ -531,6 +531,18 @@ class CstlnReceiver:
         check(lib.lsdr_rx_run_async(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons)))
         return cons.value
 
+    @staticmethod
+    def run_multi_async(rxs, in_ptrs, n_in, out_ptrs, cap_out):
+        """lsdr_rx_run_multi_async: one tiled run of every receiver in `rxs` (equally long inputs) with shared launches; returns the
+        samples each will consume.  Each receiver is retired with its own wait()."""
+        n = len(rxs)
+        hs = (vp * n)(*[r.h for r in rxs])
+        ins = (vp * n)(*[p if isinstance(p, vp) else vp(p) for p in in_ptrs])
+        outs = (vp * n)(*[p if isinstance(p, vp) else vp(p) for p in out_ptrs])
+        cons = c_sz()
+        check(lib.lsdr_rx_run_multi_async(hs, n, ins, n_in, outs, cap_out, C.byref(cons)))
+        return cons.value
+
     def run_async_hs2(self, in_ptr, n_in, out_ptr, out_sym_offset, cap_out):
         """Queue one tiled run of a SYM_HARD2 receiver writing its packed symbols from symbol out_sym_offset of `out_ptr`."""
         cons = c_sz()

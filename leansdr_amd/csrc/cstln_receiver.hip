@@ -966,9 +966,17 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   }
 }
 
+// One launch runs the tiles of up to kRxMulti independent captures (one receiver each, same configuration and run geometry:
+// lsdr_rx_run_multi_async; an ordinary run is the case of one) — blockIdx.y picks the capture's argument record out of the
+// kernel-argument segment.  (Four captures on four streams were five streams on the runtime's four hardware queues: two
+// receivers shared a queue and their runs — four launches each per batch — serialised: that queue, 94 % busy, paced the C2
+// pipeline, not the filter.)
+constexpr int kRxMulti = 8;
+struct rx_tiled_multi { rx_tiled_args a[kRxMulti]; };
 template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
-__global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_args a) {
+__global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_multi m) {
   __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * kRowBytes : 16];
+  const rx_tiled_args &a = m.a[blockIdx.y];
   if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP, FMT, HARD>(a); }
   else rx_tile_tol<SAMP, ARITH, FMT, LDS, HARD>(a, 1u + (blockIdx.x - 1u) * a.lanes_per_wave, (int)threadIdx.x, lds);
 }
@@ -992,9 +1000,9 @@ __global__ __launch_bounds__(256) void k_rx_fir_refresh(const rx_state_dev *stat
 //  * slot q of `meas` holds the partial map of its tile up to the measurement instant: composed with the maps of the
 //    preceding wavefronts and of the preceding tiles of its own wavefront (ex[]) it becomes the estimator values there.
 constexpr unsigned kEmaThreads = 256;
-__global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *wave, unsigned n_waves, const rx_ema_map *ex, unsigned n_tiles,
-                                                        unsigned lanes_per_wave, const rx_state_dev *next, rx_state_dev *state,
-                                                        rx_meas *meas, unsigned nm) {
+__device__ __forceinline__ void rx_ema_body(const rx_ema_map *wave, unsigned n_waves, const rx_ema_map *ex, unsigned n_tiles,
+                                            unsigned lanes_per_wave, const rx_state_dev *next, rx_state_dev *state,
+                                            rx_meas *meas, unsigned nm) {
   __shared__ rx_ema_map s_pre[kEmaThreads];     // composition of everything before thread t's wavefronts
   __shared__ rx_ema_map s_wave[kEmaThreads / 64];
   const unsigned t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -1038,6 +1046,33 @@ __global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *wave, 
     mm.est_insp = f.a * e_insp + f.bi; mm.est_sp = f.a * e_sp + f.bs; mm.est_ep = f.a * e_ep + f.be;
     meas[q] = mm;
   }
+}
+__global__ __launch_bounds__(kEmaThreads) void k_rx_ema(const rx_ema_map *wave, unsigned n_waves, const rx_ema_map *ex, unsigned n_tiles,
+                                                        unsigned lanes_per_wave, const rx_state_dev *next, rx_state_dev *state,
+                                                        rx_meas *meas, unsigned nm) {
+  rx_ema_body(wave, n_waves, ex, n_tiles, lanes_per_wave, next, state, meas, nm);
+}
+struct rx_ema_rec { const rx_ema_map *wave, *ex; const rx_state_dev *next; rx_state_dev *state; };
+struct rx_ema_multi { rx_ema_rec c[kRxMulti]; };
+__global__ __launch_bounds__(kEmaThreads) void k_rx_ema_multi(rx_ema_multi m, unsigned n_waves, unsigned n_tiles, unsigned lanes_per_wave) {
+  const rx_ema_rec &c = m.c[blockIdx.x];
+  rx_ema_body(c.wave, n_waves, c.ex, n_tiles, lanes_per_wave, c.next, c.state, nullptr, 0u);
+}
+// seam pass and compaction of several captures (rx_tiling.h bodies; blockIdx.y = capture)
+struct rx_seam_rec {
+  const rx_tile_info *info; rx_tile_fix *fix; rx_seam_part *part; const lsdr_softsymbol *stage, *wstage; lsdr_softsymbol *out;
+  rx_state_dev *state; rx_seam_result *res;
+};
+struct rx_seam_multi { rx_seam_rec c[kRxMulti]; };
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam_multi(rx_seam_multi m, unsigned n_tiles, float omega, int R, float quad,
+                                                              unsigned stage_stride, unsigned wstride, const uint8_t *relabel) {
+  const rx_seam_rec &c = m.c[blockIdx.y];
+  rx_seam_body<rx_tile_info, lsdr_softsymbol>(c.info, c.fix, n_tiles, omega, R, quad, c.part, c.stage, stage_stride, c.wstage, wstride, relabel);
+}
+__global__ __launch_bounds__(64) void k_rx_compact_multi(rx_seam_multi m, unsigned n_tiles, int R, float quad, unsigned stage_stride,
+                                                         const uint8_t *relabel) {
+  const rx_seam_rec &c = m.c[blockIdx.y];
+  rx_compact_body<lsdr_softsymbol, rx_state_dev>(c.stage, stage_stride, c.info, c.fix, c.part, relabel, n_tiles, R, quad, c.out, c.state, c.res);
 }
 
 // ---------------------------------------------------------------- exact receiver, one LANE per independent capture
@@ -1209,13 +1244,25 @@ static int rx_pull_state(lsdr_rx *r) {   // refresh the host mirror after queued
 // re-acquires timing/phase during its warm-up; seams are reconciled on the device.
 // rx_tiled_enqueue puts one run on the stream (tiles → seam → compaction → results into a pinned ring
 // slot) without waiting; rx_tiled_wait retires the oldest queued run.
-static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
-                            size_t *consumed, bool want_meas, size_t meas_cap, size_t *nm_out, size_t cstln_cap = 0,
-                            size_t *chunks_out = nullptr) {
+// One queued run in three steps, so that several receivers can share the launches (lsdr_rx_run_multi_async):
+//   rx_tiled_plan    sizes, scratch, the argument record (no launch); chunks == 0: nothing to do
+//   rx_tiled_launch  the run's kernels on the receiver's stream (or: the multi-capture launches over several plans)
+//   rx_tiled_commit  ring slot, completion event, host-side bookkeeping
+struct rx_plan {
+  rx_tiled_args a;
+  lsdr_softsymbol *out;
+  size_t chunks, nm;
+  unsigned n_tiles, blocks, lpw, stage_stride, sym_per_chunk;
+  unsigned long long hpitch, meas_base, md;
+  bool want_meas, want_cstln, use_lds, hard;
+  int slot;
+};
+
+static int rx_tiled_plan(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                         bool want_meas, size_t meas_cap, size_t cstln_cap, rx_plan *P) {
   lsdr_ctx *c = r->ctx;
   LSDR_HIP(hipSetDevice(c->device));
-  *consumed = 0;
-  if (nm_out) *nm_out = 0;
+  P->out = out; P->chunks = 0; P->nm = 0; P->n_tiles = 0;
   if (r->ring_count == lsdr_rx::kRing) { lsdr_set_error("cstln_receiver: too many queued runs (lsdr_rx_wait first)"); return LSDR_E_ARG; }
   const int ra = lsdr_rx_readahead(r);
   // Defaults: a warm-up of ≈ 64 symbols (whole chunks) — the TS-level yield is flat from 32 to 256 symbols of
@@ -1232,16 +1279,9 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   if ((size_t)(sym_per_chunk + 1) * chunks > cap_out) chunks = cap_out / (sym_per_chunk + 1);
   const bool want_cstln = cstln_cap > 0;
   if (want_cstln && chunks > cstln_cap) chunks = cstln_cap;     // one sampled point per chunk at most (sdr.h:785-788 gate)
-  if (chunks_out) *chunks_out = chunks;
   const int slot = (r->ring_head + r->ring_count) % lsdr_rx::kRing;
-  if (!chunks) {   // nothing to do: still occupies a slot so that wait() pairs with run_async()
-    r->h_res[slot].total = 0; r->h_res[slot].rot_final = 0; r->h_res[slot].ndup = r->h_res[slot].nmiss = r->h_res[slot].nbad = 0;
-    r->h_res[slot].freq_tap = r->retired_freq_tap;
-    r->ring_tiles[slot] = 0; r->tev_set[slot] = false;
-    LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
-    ++r->ring_count;
-    return LSDR_OK;
-  }
+  P->slot = slot; P->chunks = chunks; P->want_meas = want_meas; P->want_cstln = want_cstln;
+  if (!chunks) return LSDR_OK;   // nothing to do: the commit still occupies a slot so that wait() pairs with run_async()
   // tile 0 (one lane, the exact recurrence) only has to reach the point where tile 1's warm-up can start
   const unsigned first = Wc;
   unsigned n_tiles = 1;
@@ -1286,6 +1326,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   const unsigned long long md = r->cfg.meas_decimation;
   const unsigned long long meas_base = r->st.meas_count;   // kept current on the host even while `st` is stale
   const size_t nm = (size_t)((meas_base + chunks * kChunk) / md - meas_base / md);
+  P->nm = nm; P->meas_base = meas_base; P->md = md;
   if (want_meas && nm > meas_cap) { lsdr_set_error("cstln_receiver(tiled): measurement buffers too small"); return LSDR_E_ARG; }
   if (want_meas && r->meas_cap < nm + 1) {
     LSDR_HIP(hipStreamSynchronize(c->stream));
@@ -1302,7 +1343,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   int rc = rx_push_state(r);
   if (rc) return rc;
 
-  rx_tiled_args a;
+  rx_tiled_args &a = P->a;
   a.in = in;
   a.total_chunks = chunks;
   a.first_chunks = first; a.tile_chunks = Lc; a.warm_chunks = Wc;
@@ -1333,12 +1374,29 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
     a.lanes_per_wave = (unsigned)lpw;
   }
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
+  P->n_tiles = n_tiles; P->blocks = blocks; P->lpw = (unsigned)lpw; P->stage_stride = stage_stride; P->sym_per_chunk = sym_per_chunk;
+  P->hpitch = hpitch; P->hard = hard;
   // cu8 input, nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol); LSDR_RX_NO_LDS=1 keeps
   // the direct loads (A/B measurements)
   static const bool no_lds = getenv("LSDR_RX_NO_LDS") != nullptr;
   const bool use_lds = r->cfg.in_format == LSDR_IN_CU8 && r->cfg.sampler != LSDR_SAMP_FIR && !no_lds && r->omega <= 8.f;
   if (hard && !use_lds) { lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 needs cu8 input with the nearest or linear sampler"); return LSDR_E_UNSUPPORTED; }
-#define LSDR_RX_LAUNCH_F(S, A, F, L, H) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L, H>), dim3(blocks), dim3(64), 0, c->stream, a)
+  P->use_lds = use_lds;
+  return LSDR_OK;
+}
+
+static int rx_tiled_launch(lsdr_rx *r, const rx_plan &P) {
+  lsdr_ctx *c = r->ctx;
+  const rx_tiled_args &a = P.a;
+  const unsigned blocks = P.blocks, n_tiles = P.n_tiles, stage_stride = P.stage_stride, sym_per_chunk = P.sym_per_chunk;
+  const unsigned long long hpitch = P.hpitch;
+  const bool hard = P.hard, use_lds = P.use_lds, want_meas = P.want_meas;
+  const size_t nm = P.nm;
+  const int lpw = (int)P.lpw, slot = P.slot;
+  lsdr_softsymbol *const out = P.out;
+  rx_tiled_multi tm1;
+  for (int i = 0; i < kRxMulti; ++i) tm1.a[i] = a;
+#define LSDR_RX_LAUNCH_F(S, A, F, L, H) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L, H>), dim3(blocks), dim3(64), 0, c->stream, tm1)
 #define LSDR_RX_LAUNCH(S, A) do { if (hard) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), (S != 2)); \
                                   else if (use_lds) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), false); \
                                   else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, false, false); \
@@ -1383,13 +1441,114 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
                      r->h_res_dev + slot);   // totals go straight into the pinned ring slot (no copy command)
   }
   LSDR_HIP(hipGetLastError());
-  LSDR_HIP(hipEventRecord(r->ev[slot], c->stream));
-  r->ring_tiles[slot] = n_tiles;
+  return LSDR_OK;
+}
+
+static int rx_tiled_commit(lsdr_rx *r, const rx_plan &P, hipStream_t stream, size_t *consumed) {
+  const int slot = P.slot;
+  if (!P.chunks) {
+    r->h_res[slot].total = 0; r->h_res[slot].rot_final = 0; r->h_res[slot].ndup = r->h_res[slot].nmiss = r->h_res[slot].nbad = 0;
+    r->h_res[slot].freq_tap = r->retired_freq_tap;
+    r->ring_tiles[slot] = 0; r->tev_set[slot] = false;
+    LSDR_HIP(hipEventRecord(r->ev[slot], stream));
+    ++r->ring_count;
+    *consumed = 0;
+    return LSDR_OK;
+  }
+  LSDR_HIP(hipEventRecord(r->ev[slot], stream));
+  r->ring_tiles[slot] = P.n_tiles;
   ++r->ring_count;
   r->st_stale_host = true;
-  r->st.meas_count = (meas_base + chunks * kChunk) % md;   // what the last tile writes on the device
-  *consumed = chunks * kChunk;
-  if (nm_out) *nm_out = nm;
+  r->st.meas_count = (P.meas_base + P.chunks * kChunk) % P.md;   // what the last tile writes on the device
+  *consumed = P.chunks * kChunk;
+  return LSDR_OK;
+}
+
+static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+                            size_t *consumed, bool want_meas, size_t meas_cap, size_t *nm_out, size_t cstln_cap = 0,
+                            size_t *chunks_out = nullptr) {
+  *consumed = 0;
+  if (nm_out) *nm_out = 0;
+  rx_plan P;
+  LSDR_TRY(rx_tiled_plan(r, in, n_in, out, cap_out, want_meas, meas_cap, cstln_cap, &P));
+  if (chunks_out) *chunks_out = P.chunks;
+  if (P.chunks) LSDR_TRY(rx_tiled_launch(r, P));
+  LSDR_TRY(rx_tiled_commit(r, P, r->ctx->stream, consumed));
+  if (nm_out) *nm_out = P.nm;
+  return LSDR_OK;
+}
+
+// Several receivers, one set of launches: see k_rx_tiles_multi.  The receivers must live on ONE context (stream), be configured
+// alike (soft symbols out, same sampler / input format / tile geometry / constellation) and get equally long inputs; anything
+// else is queued receiver by receiver — the same results either way.
+static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *const *ins, size_t n_in, lsdr_softsymbol *const *outs,
+                                  size_t cap_out, size_t *consumed) {
+  *consumed = 0;
+  bool alike = n >= 2 && n <= (unsigned)kRxMulti;
+  for (unsigned i = 1; i < n && alike; ++i) {
+    const lsdr_rx *a = rs[0], *b = rs[i];
+    alike = a->ctx == b->ctx && a->cfg.sampler == b->cfg.sampler && a->cfg.in_format == b->cfg.in_format &&
+            a->cfg.out_format == b->cfg.out_format && a->cfg.tile_len == b->cfg.tile_len && a->cfg.tile_warmup == b->cfg.tile_warmup &&
+            a->cfg.cstln == b->cfg.cstln && a->omega == b->omega && a->qpsk_arith == b->qpsk_arith && a->cfg.ncoeffs == b->cfg.ncoeffs &&
+            a->cfg.subsampling == b->cfg.subsampling && a->tabs.nrotations == b->tabs.nrotations;
+  }
+  if (alike) alike = rs[0]->cfg.out_format != LSDR_SYM_HARD2 && rs[0]->cfg.sampler != LSDR_SAMP_FIR && !rs[0]->time_on;
+  rx_plan P[kRxMulti];
+  if (alike) {
+    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_plan(rs[i], ins[i], n_in, outs[i], cap_out, false, 0, 0, &P[i]));
+    for (unsigned i = 1; i < n; ++i)
+      alike = alike && P[i].chunks == P[0].chunks && P[i].n_tiles == P[0].n_tiles && P[i].blocks == P[0].blocks && P[i].lpw == P[0].lpw &&
+              P[i].stage_stride == P[0].stage_stride && P[i].use_lds == P[0].use_lds;
+    if (!alike || !P[0].chunks) {      // plans exist already: run them one by one
+      for (unsigned i = 0; i < n; ++i) {
+        if (P[i].chunks) LSDR_TRY(rx_tiled_launch(rs[i], P[i]));
+        LSDR_TRY(rx_tiled_commit(rs[i], P[i], rs[i]->ctx->stream, consumed));
+      }
+      return LSDR_OK;
+    }
+  } else {
+    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_enqueue(rs[i], ins[i], n_in, outs[i], cap_out, consumed, false, 0, nullptr));
+    return LSDR_OK;
+  }
+  lsdr_rx *r = rs[0];
+  lsdr_ctx *c = r->ctx;
+  static const bool skip = getenv("LSDR_RX_SKIP") != nullptr;     // measurement hook: no receiver kernels at all (results are garbage)
+  if (skip) {
+    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, consumed));
+    return LSDR_OK;
+  }
+  rx_tiled_multi tm;
+  rx_ema_multi em;
+  rx_seam_multi sm;
+  for (unsigned i = 0; i < n; ++i) {
+    tm.a[i] = P[i].a;
+    em.c[i] = rx_ema_rec{rs[i]->d_ema_wave, rs[i]->d_ema, rs[i]->d_state_next, rs[i]->d_state};
+    sm.c[i] = rx_seam_rec{rs[i]->d_info, rs[i]->d_fix, rs[i]->d_part, rs[i]->d_stage, rs[i]->d_wstage, outs[i], rs[i]->d_state,
+                          rs[i]->h_res_dev + P[i].slot};
+  }
+  for (unsigned i = n; i < (unsigned)kRxMulti; ++i) { tm.a[i] = P[0].a; em.c[i] = em.c[0]; sm.c[i] = sm.c[0]; }
+  const unsigned blocks = P[0].blocks, n_tiles = P[0].n_tiles;
+  const bool use_lds = P[0].use_lds;
+#define LSDR_RXM_LAUNCH_F(S, A, F, L) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L, false>), dim3(blocks, n), dim3(64), 0, c->stream, tm)
+#define LSDR_RXM_LAUNCH(S, A) do { if (use_lds) LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CU8, true); \
+                                   else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CU8, false); \
+                                   else LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CF32, false); } while (0)
+#define LSDR_RXM_LAUNCH_S(S) do { if (r->qpsk_arith) LSDR_RXM_LAUNCH(S, true); else LSDR_RXM_LAUNCH(S, false); } while (0)
+  if (r->cfg.sampler == LSDR_SAMP_NEAREST) LSDR_RXM_LAUNCH_S(0);
+  else LSDR_RXM_LAUNCH_S(1);
+#undef LSDR_RXM_LAUNCH_S
+#undef LSDR_RXM_LAUNCH
+#undef LSDR_RXM_LAUNCH_F
+  LSDR_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_rx_ema_multi, dim3(n), dim3(kEmaThreads), 0, c->stream, em, blocks, n_tiles, P[0].lpw);
+  const int R = r->tabs.nrotations;
+  const float quad = 65536.0f / R;
+  hipLaunchKernelGGL(k_rx_seam_multi, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock, n), dim3(kSeamBlock), 0, c->stream, sm, n_tiles, r->omega, R,
+                     quad, P[0].stage_stride, P[0].sym_per_chunk, (const uint8_t *)r->d_relabel);
+  hipLaunchKernelGGL(k_rx_compact_multi, dim3(n_tiles, n), dim3(64), 0, c->stream, sm, n_tiles, R, quad, P[0].stage_stride,
+                     (const uint8_t *)r->d_relabel);
+  LSDR_HIP(hipGetLastError());
+  for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, consumed));
   return LSDR_OK;
 }
 
@@ -1697,6 +1856,17 @@ int lsdr_rx_run_async_hs2(lsdr_rx *r, const void *in, size_t n_in, uint32_t *out
   const int rc = rx_tiled_enqueue(r, in, n_in, reinterpret_cast<lsdr_softsymbol *>(out_words), cap_out, consumed, false, 0, nullptr);
   r->out_sym_offset = 0;
   return rc;
+}
+
+int lsdr_rx_run_multi_async(lsdr_rx *const *rxs, unsigned n_rx, const void *const *ins, size_t n_in, lsdr_softsymbol *const *outs,
+                            size_t cap_out, size_t *consumed) {
+  LSDR_ARG(rxs && n_rx >= 1 && ins && outs && consumed);
+  for (unsigned i = 0; i < n_rx; ++i) {
+    LSDR_ARG(rxs[i] && (ins[i] || !n_in) && outs[i]);
+    if (rxs[i]->cfg.mode != LSDR_RX_TILED) { lsdr_set_error("cstln_receiver: lsdr_rx_run_multi_async needs LSDR_RX_TILED"); return LSDR_E_UNSUPPORTED; }
+    for (unsigned k = 0; k < i; ++k) LSDR_ARG(rxs[k] != rxs[i]);
+  }
+  return rx_tiled_enqueue_multi(rxs, n_rx, ins, n_in, outs, cap_out, consumed);
 }
 
 int lsdr_rx_wait(lsdr_rx *r, size_t *produced) {

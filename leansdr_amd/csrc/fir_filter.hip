@@ -621,7 +621,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma(fir_args a) {
 // and store 256 consecutive bytes.  A wavefront owns 128 rows → 128 − (NQ−1) outputs (118 at C2): 128 MFMAs per 118 outputs
 // at 32 cycles where k_fir_mfma needs 192 at 40 per 128.
 // Arithmetic (stated once, oracle lo_fir_filter_blk): the reference's loop with the taps in blocks of D — each block an fmaf
-// chain from zero in tap order, the block sums added in block order.  NOT the single chain of LSDR_FIR_FMA; pinned bit for
+// chain from zero in tap order, the block sums added in block order; a fused scaler (in_scale) multiplies the TAPS (one f32
+// rounding per tap) instead of the samples.  NOT the single chain of LSDR_FIR_FMA; pinned bit for
 // bit to that restatement, and under the same error bound against the reference's arithmetic.
 constexpr unsigned blk_padf(unsigned D) {          // floats of padding per row of D samples: (2·D + PADF) mod 32 ∈ {4,12,20,28}
   unsigned p = 0;
@@ -629,7 +630,10 @@ constexpr unsigned blk_padf(unsigned D) {          // floats of padding per row 
   return p;
 }
 
-template <int DT, int W, int CP, int NLT>
+// NQT > 0: the number of tap blocks is a compile-time constant — the diagonal sum's addresses become immediates and its
+// loops exact (PMC of the run-time form: ≈ 900 instructions per wave tile, issued one at a time by the only wave of its
+// SIMD, cost more cycles than the 128 MFMAs).
+template <int DT, int W, int CP, int NLT, int NQT>
 __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr unsigned T = 64 * W, D = DT, SL = 1 + CP;
@@ -638,7 +642,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
   constexpr unsigned PADF = blk_padf(D), ROWF = 2 * D + PADF;     // floats per LDS row
   constexpr unsigned RW = 128;                                    // rows per wavefront (16 row tiles)
   const unsigned l = threadIdx.x;
-  const unsigned NQ = a.mf_blocks;                                // tap blocks (≤ 16)
+  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks;          // tap blocks (≤ 16)
+  constexpr int NQR = NQT ? NQT : 16;                             // diagonal terms read
   const unsigned MW = RW - (NQ - 1), M = W * MW;                  // outputs per wavefront / per tile
   const unsigned R = M + NQ - 1;                                  // rows per tile
   const unsigned Uneed = (R * D + (KP / SL - D) + 1) & ~1u;       // staged samples incl. the K padding's read-ahead, even
@@ -648,7 +653,8 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
   constexpr int NLmax = NLT ? NLT : 32;
   const unsigned ROWZ = 2 * (NQ | 1u);                            // floats per ring row: [q][re,im], odd pair count
   const unsigned data_bytes = ((U + D - 1) / D + 1) * ROWF * 4;
-  char *const ring = smem_raw + ((data_bytes + 15) & ~15u) + (l >> 6) * (64 * ROWZ * 4);
+  // Z ring of a wavefront: 64 rows + rows 0…15 once more behind them (rows 64…79), so that "row (b + q) mod 64" is plain b mod 64 + q
+  char *const ring = smem_raw + ((data_bytes + 15) & ~15u) + (l >> 6) * (80 * ROWZ * 4);
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   auto tile_of = [&](unsigned ti) { return xcd * a.tiles_per_xcd + ti; };
   auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
@@ -705,8 +711,13 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
   constexpr unsigned ASTEP = CP ? 16 : 32, ATILE = 8 * ROWF * 4;
   // accumulator tile → ring: lane (q = l&15, g4 = (l>>4)&3) holds rows 4·g4 + r = (β = 2·g4 + (r>>1), c = r&1)
   const unsigned zq = l & 15u, zrow = 2 * kq;
-  // diagonal sum: lane (o = (l&63)>>1, c = l&1)
+  // diagonal sum: lane (o = (l&63)>>1, c = l&1); batch B finalises output bm = 32·B − (NQ−1) + o from rows bm + q: byte offset of
+  // its q = 0 term for even / odd B (bm mod 64 depends on B's parity only), terms `dstep` bytes apart
   const unsigned ro = (l & 63u) >> 1, rc = l & 1u;
+  const unsigned dstep = ROWZ * 4 + 8;
+  unsigned dbase[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) dbase[par] = ((((unsigned)(32 * par - (int)(NQ - 1) + (int)ro)) & 63u) * ROWZ + rc) * 4;
 
   while (true) {
     const unsigned tile = tile_of(ti);
@@ -714,11 +725,9 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
     for (int k = 0; k < NLmax; ++k) {
       if (!NLT && k >= (int)NLr) continue;
       const unsigned p = (NLr - 1 - (unsigned)k) * T + (T - 1 - l);
-      if (NLT || p < NG) {
-        const float s = a.in_scale;
-        const lsdr_v4f x = {__uint_as_float(v[k].z) * s, __uint_as_float(v[k].w) * s, __uint_as_float(v[k].x) * s,
-                            __uint_as_float(v[k].y) * s};
-        *reinterpret_cast<lsdr_v4f *>(smem_raw + 16u * p + (PADF ? 4u * PADF * ((2 * p) / D) : 0u)) = x;
+      if (NLT || p < NG) {     // (no scaler here: LSDR_FIR_MFMA_BLK carries in_scale on the taps)
+        const lsdr_v4u x = {v[k].z, v[k].w, v[k].x, v[k].y};
+        *reinterpret_cast<lsdr_v4u *>(smem_raw + 16u * p + (PADF ? 4u * PADF * ((2 * p) / D) : 0u)) = x;
       }
     }
     LSDR_TR(1)
@@ -743,24 +752,28 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const unsigned row = (16u * pair + 8u * h + zrow) & 63u;
-          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = (lsdr_v2f){acc[set][h][0], acc[set][h][1]};
-          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = (lsdr_v2f){acc[set][h][2], acc[set][h][3]};
+          const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
+          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
+          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
+          if (((16u * pair) & 63u) == 0) {   // rows 0…15 also as rows 64…79
+            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
+            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
+          }
         }
       }
     };
     // diagonal sum of batch B (rows ≤ 32·B + 31 are in the ring): output bm = 32·B − (NQ−1) + o needs Z[bm + q][q], q < NQ.
     // Split in two so that neither half ever waits between two MFMAs: the reads of term q, and — a pair of row tiles later —
-    // the adds (q ascending) and the store.
-    float zv[16];
+    // the adds (q ascending) and the store.  (Run-time NQ: all 16 terms are read, branch-free — a term q ≥ NQ is whatever lies
+    // behind the row — and a select keeps it out of the sum.)
+    float zv[NQR];
     auto diag_read = [&](int batch, int q) {
-      // (all 16 terms are read, branch-free: a term q ≥ NQ is whatever lies behind the row — never added)
-      const int bm = 32 * batch - (int)(NQ - 1) + (int)ro;
-      zv[q] = *reinterpret_cast<const float *>(ring + ((((unsigned)(bm + q)) & 63u) * ROWZ + 2 * q + rc) * 4);
+      zv[q] = *reinterpret_cast<const float *>(ring + dbase[batch & 1] + (unsigned)q * dstep);
     };
     float ysum = 0.f;
     auto diag_add = [&](int q) {
       const float t = ysum + zv[q];
-      ysum = q == 0 ? zv[0] : ((unsigned)q < NQ ? t : ysum);
+      ysum = q == 0 ? zv[0] : (NQT || (unsigned)q < NQ ? t : ysum);
     };
     auto diag_store = [&](int batch) {
       const int bm = 32 * batch - (int)(NQ - 1) + (int)ro;
@@ -796,17 +809,20 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
           acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][0][s], bco[s], acc[set][0], 0, 0, 0);
           acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[set][1][s], bco[s], acc[set][1], 0, 0, 0);
         }
-        if (pair < 7) { fetch1(set ^ 1, pair + 1, 0, s); fetch1(set ^ 1, pair + 1, 1, s); }
+        if (pair < 7 && !(s & 1)) {          // two steps at a time: neighbouring dwords → ds_read2_b32
+#pragma unroll
+          for (int h = 0; h < 2; ++h) { fetch1(set ^ 1, pair + 1, h, s); if (s + 1 < KS) fetch1(set ^ 1, pair + 1, h, s + 1); }
+        }
         if (pair >= 1 && s == 0) to_ring(set ^ 1, pair - 1);
         if (pair >= 2 && !(pair & 1)) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (at_step(q, 16, KS > 1 ? 1 : 0, KS) == (int)s) diag_read(pair / 2 - 1, q);
+          for (int q = 0; q < NQR; ++q)
+            if (at_step(q, NQR, KS > 1 ? 1 : 0, KS) == (int)s) diag_read(pair / 2 - 1, q);
         }
         if (pair >= 3 && (pair & 1)) {
 #pragma unroll
-          for (int q = 0; q < 16; ++q)
-            if (at_step(q, 16, 0, KS) == (int)s) diag_add(q);
+          for (int q = 0; q < NQR; ++q)
+            if (at_step(q, NQR, 0, KS) == (int)s) diag_add(q);
           if (s == KS - 1) diag_store((pair - 3) / 2);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -814,9 +830,9 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
     }
     to_ring(1, 7);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) diag_read(3, q);
+    for (int q = 0; q < NQR; ++q) diag_read(3, q);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) diag_add(q);
+    for (int q = 0; q < NQR; ++q) diag_add(q);
     diag_store(3);
     LSDR_TR(4)
     if (!more) break;
@@ -831,6 +847,213 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
   if (a.trace && (l & 63) == 0 && blockIdx.x < 4096)
     for (int i = 0; i < 8; ++i) a.trace[((size_t)blockIdx.x * 4 + (l >> 6)) * 8 + i] = tr[i];
 #endif
+}
+
+// ---- k_fir_mfma_stream: LSDR_FIR_MFMA_BLK without a staging phase ---------------------------------------------
+// k_fir_mfma_blk's trace: the MFMAs themselves are 43 % of a tile; the rest is the wave standing in the vector-memory queue
+// with the next tile's loads (in-order issue: a load that cannot be queued blocks the MFMAs behind it), then waiting for them,
+// writing 64 KB from registers to LDS, and two barriers.  None of that is needed.  A wavefront walks its 128 rows in order —
+// once the sample operands of a pair of row tiles are in registers those 16 rows of LDS are dead — so the NEXT tile's rows are
+// loaded straight into them (buffer_load … lds: no registers, no LDS-write instructions, the wave never waits for the queue's
+// data, only for its slots) while the wave goes on with the following pairs; they are read again seven pairs later.
+// Every wavefront is its own workgroup with a private region (128 rows + the K padding's read-ahead, natural sample order)
+// and a private Z ring: no barrier anywhere.  Samples reach the MFMA untouched (the fused scaler rides on the taps, as in
+// k_fir_mfma_blk), so the arithmetic is k_fir_mfma_blk's, bit for bit.
+// Decimations whose row stride needs no padding (2·D ≡ 4 mod 8: 10, 30) — LDS-direct loads write 1 KiB of consecutive bytes.
+typedef __attribute__((address_space(3))) void *fir_lds_ptr;
+
+template <int DT, int CP, int NQT>
+__global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr unsigned D = DT, SL = 1 + CP;
+  static_assert(DT % 2 == 0 && blk_padf(DT) == 0, "row stride must be bank-friendly without padding");
+  constexpr unsigned KP = (D * SL + 3) / 4 * 4, KS = KP / 4;
+  constexpr unsigned FP = ((KP / SL - D) + 1) & ~1u;              // samples in front of row 0 that the K padding reads
+  constexpr unsigned ROWB = D * 8, PAIRG = 8 * D;                 // bytes per row; 16-byte granules per pair of row tiles
+  constexpr unsigned REGB = FP * 8 + 128 * ROWB;                  // region bytes
+  constexpr unsigned NLI = (PAIRG + FP / 2 + 63) / 64;            // LDS-direct loads per refill group
+  const unsigned l = threadIdx.x;
+  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks, MW = 128 - (NQ - 1);
+  constexpr int NQR = NQT ? NQT : 16;
+  const unsigned ROWZ = 2 * (NQ | 1u);
+  char *const ring = smem_raw + ((REGB + 15) & ~15u);       // 64 rows + rows 0…15 once more as rows 64…79 (see k_fir_mfma_blk)
+  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+  auto tile_of = [&](unsigned ti) { return xcd * a.tiles_per_xcd + ti; };
+  auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
+
+  float bco[KS];
+#pragma unroll
+  for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[s * 64 + l];
+
+  // The region of wave tile `lt` of a stream: row ρ = output-row p = lt·MW − (NQ−1) + ρ, i.e. samples
+  // x[N + D·p − (D−1) … N + D·p]; region sample 0 is x[X0], X0 = N + 1 − D·NQ − FP + D·MW·lt (negative at the stream start:
+  // those samples meet zero taps — the clamped resource makes their offsets wrap out of range: zeros).
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned adj = 0;
+  auto aim = [&](unsigned tile, bool live) {
+    const unsigned st = live ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
+    const long long j0 = (long long)a.N + 1 - (long long)(D * NQ) - (long long)FP + (long long)lt * MW * D;
+    const long long jb = j0 < 0 ? 0 : j0;
+    const unsigned long long bytes = live ? (a.n_in - (unsigned long long)jb) * 8ull : 0ull;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
+                                             (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
+    adj = (unsigned)((jb - j0) * 8);
+  };
+  // refill group P = the granules pair P reads first (its rows; pair 0 also the front padding)
+  auto refill = [&](int P) {
+    const unsigned g0 = P ? FP / 2 + (unsigned)P * PAIRG : 0u, g1 = FP / 2 + (unsigned)(P + 1) * PAIRG;
+#pragma unroll
+    for (unsigned i = 0; i < NLI; ++i) {
+      const unsigned g = g0 + 64 * i + l;
+#ifdef LSDR_STREAM_NOLOAD      // measurement build: the compute side alone (results are garbage)
+      if (g == 0xffffffffu)
+#else
+      if (g0 + 64 * i + 64 <= g1 || g < g1)      // (whole loads: no lane mask)
+#endif
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fir_lds_ptr)(size_t)(unsigned)(unsigned long long)(smem_raw + 16 * (g0 + 64 * i)), 16,
+                                                 16 * g - adj, 0, 0, LSDR_FIR_LOAD_AUX);
+    }
+  };
+
+  unsigned ti = slot;
+  if (!valid(ti)) return;
+#ifdef LSDR_STREAM_PRIO
+  __builtin_amdgcn_s_setprio(LSDR_STREAM_PRIO);
+#endif
+  aim(tile_of(ti), true);
+#pragma unroll
+  for (int P = 0; P < 8; ++P) refill(P);
+
+  // per-lane cursors (see k_fir_mfma_blk); the sample operand of K slot r' of row ρ is the sample r' BEFORE the row's last one
+  const unsigned kq = l >> 4 & 3u, i16 = l & 15u, beta = i16 >> 1, c = i16 & 1u;
+  const unsigned sub = CP ? (kq & 1u) : 0u;
+  constexpr unsigned ASTEP = CP ? 16 : 32, ATILE = 8 * ROWB;
+  // float index of (row ρ, step s): 2·(FP + D·ρ + D − 1 − r') + comp, r' = CP ? 2·s + (k>>1) : 4·s + k  →  lane part at s = KS−1
+  const int rlast = CP ? 2 * (int)(KS - 1) + (int)(kq >> 1) : 4 * (int)(KS - 1) + (int)kq;
+  const unsigned a0 = (unsigned)(2 * ((int)FP + (int)(D * beta) + (int)D - 1 - rlast) + (int)(c ^ sub)) * 4u;   // bytes, ≥ 0 by FP
+  const unsigned sgn = (CP && sub && c) ? 0x80000000u : 0u;
+  const unsigned zq = l & 15u, zrow = 2 * kq;
+  const unsigned ro = l >> 1, rc = l & 1u;
+  // diagonal sum (rows ascend with the output index here): output of row ρ = 32·B + o is Σ_q Z[ρ − q][q]; its row as 16 … 79
+  // (rows 0…15 are mirrored at 64…79) so that ρ − q needs no wrap; byte offset of term q = 15 for even / odd B, terms with
+  // smaller q `dstep` bytes further on
+  const unsigned dstep = ROWZ * 4 - 8;
+  unsigned dbase[2];
+#pragma unroll
+  for (int par = 0; par < 2; ++par) {
+    const unsigned rr = 32u * par + ro, rp = rr < 16 ? rr + 64 : rr;
+    dbase[par] = (rp * ROWZ + rc) * 4 - 15 * dstep;               // = ((rp − 15)·ROWZ + 2·15 + rc)·4
+  }
+
+  while (true) {
+    const unsigned tile = tile_of(ti);
+    const unsigned tn = ti + slots;
+    const bool more = valid(tn);
+    const unsigned st = tile / a.tiles_per_stream;
+    const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * MW;
+    float *const po = reinterpret_cast<float *>(a.outs[st]);
+    aim(more ? tile_of(tn) : 0u, more);      // the refills of this iteration fetch the NEXT tile (an empty resource at the end: no traffic)
+
+    const char *ap = smem_raw + a0;
+    unsigned pa[2][2][KS];
+    auto fetch1 = [&](int set, int pair, int h, unsigned s) {
+      pa[set][h][s] = *reinterpret_cast<const unsigned *>(ap + (2 * pair + h) * ATILE + (KS - 1 - s) * ASTEP);
+    };
+    auto opnd = [&](unsigned r) { return __uint_as_float(CP ? (r ^ sgn) : r); };
+    lsdr_v4f acc[2][2];
+    auto to_ring = [&](int set, int pair) {
+      if (zq < NQ) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const unsigned row = (16u * pair + 8u * h + zrow) & 63u;
+          const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
+          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
+          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
+          if (((16u * pair) & 63u) == 0) {
+            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
+            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
+          }
+        }
+      }
+    };
+    float zv[NQR];
+    auto diag_read = [&](int batch, int q) {
+      zv[q] = *reinterpret_cast<const float *>(ring + dbase[batch & 1] + (unsigned)(15 - q) * dstep);
+    };
+    float ysum = 0.f;
+    auto diag_add = [&](int q) {
+      const float t = ysum + zv[q];
+      ysum = q == 0 ? zv[0] : (NQT || (unsigned)q < NQ ? t : ysum);
+    };
+    auto diag_store = [&](int batch) {
+      const int rho = 32 * batch + (int)ro;
+      const unsigned long long m = m0 + (unsigned)(rho - (int)(NQ - 1));
+      if (rho >= (int)(NQ - 1) && m < a.count)
+        asm volatile("global_store_dword %0, %1, off" ::"v"(po + 2 * m + rc), "v"(ysum) : "memory");
+    };
+    auto at_step = [](int i, int n, int lo, int hi) { return hi > lo ? lo + i * (hi - lo) / n : lo; };
+
+    // Wait counts (vector-memory operations retire in order; the hidden output stores only make the counter larger, i.e. the
+    // waits stricter).  Refill group j of the previous iteration must have landed before fetch(j).  Behind it in the queue:
+    // the previous iteration's groups j+1 … 7 and this iteration's groups issued so far (group P−1 goes out at the END of
+    // pair P, behind fetch(P+1)): fetch(0): 7 groups; fetch(1), during pair 0: 6; fetch(j ≥ 2), during pair j−1: 5.
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NLI) : "memory");
+#pragma unroll
+    for (unsigned s = 0; s < KS; ++s) { fetch1(0, 0, 0, s); fetch1(0, 0, 1, s); }
+#pragma unroll
+    for (int pair = 0; pair < 8; ++pair) {
+      const int set = pair & 1;
+      if (pair < 7) {
+        if (pair == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NLI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NLI) : "memory");
+      }
+#pragma unroll
+      for (unsigned s = 0; s < KS; ++s) {
+#ifdef LSDR_STREAM_NOMFMA       // measurement build: the memory side alone (one VALU op stands in for each MFMA)
+        if (s == 0) { acc[set][0] = (lsdr_v4f){0.f, 0.f, 0.f, 0.f}; acc[set][1] = acc[set][0]; }
+        acc[set][0][s & 3] += opnd(pa[set][0][s]) * bco[s];
+        acc[set][1][s & 3] += opnd(pa[set][1][s]) * bco[s];
+#else
+        if (s == 0) {
+          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][0][0]), bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][0]), bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        } else {
+          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][0][s]), bco[s], acc[set][0], 0, 0, 0);
+          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][s]), bco[s], acc[set][1], 0, 0, 0);
+        }
+#endif
+        if (pair < 7 && !(s & 1)) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) { if (s + 1 < KS) fetch1(set ^ 1, pair + 1, h, s + 1); fetch1(set ^ 1, pair + 1, h, s); }
+        }
+        if (pair >= 1 && s == 0) to_ring(set ^ 1, pair - 1);
+        if (pair >= 2 && !(pair & 1)) {
+#pragma unroll
+          for (int q = 0; q < NQR; ++q)
+            if (at_step(q, NQR, KS > 1 ? 1 : 0, KS) == (int)s) diag_read(pair / 2 - 1, q);
+        }
+        if (pair >= 3 && (pair & 1)) {
+#pragma unroll
+          for (int q = 0; q < NQR; ++q)
+            if (at_step(q, NQR, 0, KS) == (int)s) diag_add(q);
+          if (s == KS - 1) diag_store((pair - 3) / 2);
+        }
+        // rows of pair P−1: every operand of them has been consumed by an MFMA by now (program order) — refill them
+        if (pair >= 1 && s == KS - 1) refill(pair - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    to_ring(1, 7);
+    refill(7);
+#pragma unroll
+    for (int q = 0; q < NQR; ++q) diag_read(3, q);
+#pragma unroll
+    for (int q = 0; q < NQR; ++q) diag_add(q);
+    diag_store(3);
+    if (!more) break;
+    ti = tn;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 typedef void (*fir_kernel_t)(fir_args);
@@ -859,14 +1082,18 @@ fir_kernel_t pick_mfma(unsigned D, int W, bool cplx, unsigned nl_fixed) {
 }
 template <int DT>
 fir_kernel_t pick_blk_d(int W, bool cplx) {
-  if (W == 4) return cplx ? k_fir_mfma_blk<DT, 4, 1, 0> : k_fir_mfma_blk<DT, 4, 0, 0>;
-  return cplx ? k_fir_mfma_blk<DT, 2, 1, 0> : k_fir_mfma_blk<DT, 2, 0, 0>;
+  if (W == 4) return cplx ? k_fir_mfma_blk<DT, 4, 1, 0, 0> : k_fir_mfma_blk<DT, 4, 0, 0, 0>;
+  return cplx ? k_fir_mfma_blk<DT, 2, 1, 0, 0> : k_fir_mfma_blk<DT, 2, 0, 0, 0>;
 }
 constexpr unsigned blk_fixed_nl(unsigned D, int W) { return D == 30 ? 29u : 0u; }
-fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed) {
-  if (nl_fixed && nl_fixed == blk_fixed_nl(D, W)) {
-    if (W == 4) return cplx ? k_fir_mfma_blk<30, 4, 1, 29> : k_fir_mfma_blk<30, 4, 0, 29>;
-    return cplx ? k_fir_mfma_blk<30, 2, 1, 29> : k_fir_mfma_blk<30, 2, 0, 29>;
+fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed, unsigned nq) {
+  if (nl_fixed && nl_fixed == blk_fixed_nl(D, W)) {          // (nl = 29 at D = 30 implies 11 tap blocks: the C2 geometry)
+    if (nq == 11) {
+      if (W == 4) return cplx ? k_fir_mfma_blk<30, 4, 1, 29, 11> : k_fir_mfma_blk<30, 4, 0, 29, 11>;
+      return cplx ? k_fir_mfma_blk<30, 2, 1, 29, 11> : k_fir_mfma_blk<30, 2, 0, 29, 11>;
+    }
+    if (W == 4) return cplx ? k_fir_mfma_blk<30, 4, 1, 29, 0> : k_fir_mfma_blk<30, 4, 0, 29, 0>;
+    return cplx ? k_fir_mfma_blk<30, 2, 1, 29, 0> : k_fir_mfma_blk<30, 2, 0, 29, 0>;
   }
   switch (D) {
     case 4: return pick_blk_d<4>(W, cplx);
@@ -876,6 +1103,20 @@ fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed) {
     case 30: return pick_blk_d<30>(W, cplx);
     default: return nullptr;
   }
+}
+fir_kernel_t pick_stream(unsigned D, bool cplx, unsigned nq) {
+  const char *e = getenv("LSDR_MFMA_NQT");                 // test hook: 0 forces the run-time-NQ kernels
+  if (D == 30 && nq == 11 && !(e && !atoi(e))) return cplx ? k_fir_mfma_stream<30, 1, 11> : k_fir_mfma_stream<30, 0, 11>;
+  switch (D) {
+    case 10: return cplx ? k_fir_mfma_stream<10, 1, 0> : k_fir_mfma_stream<10, 0, 0>;
+    case 30: return cplx ? k_fir_mfma_stream<30, 1, 0> : k_fir_mfma_stream<30, 0, 0>;
+    default: return nullptr;
+  }
+}
+// LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 128 rows) + Z ring + the diagonal reads' overrun
+unsigned stream_lds(unsigned D, unsigned nq, bool cplx) {
+  const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4, fp = ((kp / sl - D) + 1) & ~1u;
+  return ((fp * 8 + 128 * D * 8 + 15) & ~15u) + 80 * 2 * (nq | 1u) * 4 + 128;
 }
 // geometry of a k_fir_mfma_blk launch (nb = tap blocks NQ, alen = coefficient operand floats, M = outputs per tile)
 struct blk_geom { unsigned nq, alen, U, lds, nl, nl_fixed, M, ks; };
@@ -896,7 +1137,7 @@ blk_geom blk_geometry(unsigned N, unsigned D, int W, bool cplx) {
   if (g.nl_fixed) g.U = 2 * g.nl * 64 * W;
   const unsigned rowf = 2 * D + blk_padf(D);
   const unsigned data_bytes = ((g.U + D - 1) / D + 1) * rowf * 4;
-  g.lds = ((data_bytes + 15) & ~15u) + W * 64 * 2 * (g.nq | 1u) * 4 + 128;   // + the branch-free diagonal reads' overrun
+  g.lds = ((data_bytes + 15) & ~15u) + W * 80 * 2 * (g.nq | 1u) * 4 + 128;   // + the branch-free diagonal reads' overrun
   return g;
 }
 
@@ -999,6 +1240,8 @@ struct lsdr_fir_filter {
   float *d_btab[2];
   blk_geom bk[2];
   bool blk_ok[2];
+  bool stream;                      // k_fir_mfma_stream (one wavefront per workgroup, LDS-direct refill) instead of k_fir_mfma_blk
+  int stream_wpc;                   // its workgroups (= wavefronts) per CU in the persistent grid
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -1034,6 +1277,7 @@ static int fir_upload(lsdr_fir_filter *f) {
   }
   // k_fir_mfma_blk's coefficient operand: lane (k = l>>4, q = l&15) of step s holds K slot e = 4·s + k of tap block q —
   // tap D·q + e (real taps), or tap D·q + e/2 as (re, −im) pairs (complex taps); zero outside the block / the filter
+  const float scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
   for (int cp = 0; cp < 2; ++cp) {
     if (!f->blk_ok[cp]) continue;
     std::vector<float> bt(f->bk[cp].alen, 0.f);
@@ -1041,7 +1285,8 @@ static int fir_upload(lsdr_fir_filter *f) {
       for (unsigned ln = 0; ln < 64; ++ln) {
         const unsigned e = 4 * s + (ln >> 4), q = ln & 15, r = cp ? e >> 1 : e;
         if (q >= f->bk[cp].nq || r >= D || D * q + r >= N) continue;
-        bt[s * 64 + ln] = cp == 0 ? rc[D * q + r] : ((e & 1) ? -f->shifted[D * q + r].im : f->shifted[D * q + r].re);
+        const float tap = cp == 0 ? rc[D * q + r] : ((e & 1) ? -f->shifted[D * q + r].im : f->shifted[D * q + r].re);
+        bt[s * 64 + ln] = tap * scale;         // the fused scaler rides on the taps: one f32 rounding per tap
       }
     LSDR_HIP(hipMemcpyAsync(f->d_btab[cp], bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     LSDR_HIP(hipStreamSynchronize(c->stream));
@@ -1118,14 +1363,19 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   {
     const char *ew = getenv("LSDR_MFMA_W"), *ep = getenv("LSDR_MFMA_WPC");
     f->mf_W = ew && atoi(ew) == 4 ? 4 : 2;
-    f->mf_wpc = ep && atoi(ep) > 0 ? atoi(ep) : (f->mf_W == 4 ? 2 : 3);   // more workgroups than fit at once: the resident ones fall out of step (measured: W = 2: 2 → 0.154 ms, 3 → 0.119 ms per 64 Mi)
+    f->mf_wpc = ep && atoi(ep) > 0 ? atoi(ep) : (f->mf_W == 4 || cfg->arith == LSDR_FIR_MFMA_BLK ? 2 : 3);   // more workgroups than fit at once: the resident ones fall out of step (measured: W = 2: 2 → 0.154 ms, 3 → 0.119 ms per 64 Mi)
   }
   f->d_btab[0] = f->d_btab[1] = nullptr;
   f->blk_ok[0] = f->blk_ok[1] = false;
   if (cfg->arith == LSDR_FIR_MFMA_BLK) {
     // available for cf32 input, even compile-time decimations, N ≤ 16·D; anything else is refused at create time (the blocked
     // sum is its own arithmetic: there is no other kernel with the same bits to fall back to)
-    LSDR_ARG(cfg->in_format == LSDR_IN_CF32 && pick_blk(D, f->mf_W, false, 0) != nullptr);
+    LSDR_ARG(cfg->in_format == LSDR_IN_CF32 && pick_blk(D, f->mf_W, false, 0, 0) != nullptr);
+    {
+      const char *es = getenv("LSDR_MFMA_STREAM"), *ew = getenv("LSDR_MFMA_SWPC");
+      f->stream = pick_stream(D, false, 0) != nullptr && !(es && !atoi(es));
+      f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 3;   // (4 fit by LDS; next to the receiver's tiles 3 leave it room: C2 pipeline 546 → 569 GS/s)
+    }
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
       f->blk_ok[cp] = f->bk[cp].M > 0 && f->bk[cp].nl <= 32 && f->bk[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2);
@@ -1225,7 +1475,8 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.N = N; a.D = D; a.S = f->S;
   a.count = count;
   a.n_in = n_in;
-  const unsigned M = blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
+  const bool stream = blk && f->stream && real_taps;   // (complex taps: 15 MFMA steps per row pair and twice the operand reads — the register-staged kernel measured 2× faster there)
+  const unsigned M = stream ? 128u - (f->bk[real_taps ? 0 : 1].nq - 1) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
   a.tiles_per_stream = (unsigned)n_tiles;
@@ -1250,14 +1501,16 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     a.mf_atab = blk ? f->d_btab[cp] : f->d_atab[cp];
     a.mf_alen = blk ? f->bk[cp].alen : f->mf[cp].alen;
     a.mf_blocks = blk ? f->bk[cp].nq : f->mf[cp].nb;
-    fir_kernel_t k = blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
-    const size_t lds_bytes = blk ? f->bk[cp].lds : f->mf[cp].lds;
+    static const char *const enq = getenv("LSDR_MFMA_NQT");
+    const unsigned nqk = blk && !(enq && !atoi(enq)) ? f->bk[cp].nq : 0;
+    fir_kernel_t k = stream ? pick_stream(D, cp != 0, f->bk[cp].nq) : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
+    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0) : blk ? f->bk[cp].lds : f->mf[cp].lds;
     if (lds_bytes > 64 * 1024)
       LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;
-    const unsigned pg = (unsigned)(f->ctx->num_cu * f->mf_wpc + 7) / 8 * 8;
+    const unsigned pg = (unsigned)(f->ctx->num_cu * (stream ? f->stream_wpc : f->mf_wpc) + 7) / 8 * 8;
     if (grid > pg) grid = pg;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(64 * f->mf_W), lds_bytes, f->ctx->stream, a);
+    hipLaunchKernelGGL(k, dim3(grid), dim3(stream ? 64 : 64 * f->mf_W), lds_bytes, f->ctx->stream, a);
     LSDR_HIP(hipGetLastError());
     *produced = count;
     *consumed = count * D;

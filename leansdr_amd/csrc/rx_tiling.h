@@ -132,9 +132,9 @@ __device__ __forceinline__ void seam_block_scan(long long add, unsigned k, unsig
 }
 
 template <typename INFO, typename SYM>
-__global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
-                                                  int R, float quad, rx_seam_part *part, const SYM *stage, unsigned stage_stride,
-                                                  const SYM *wstage, unsigned wstride, const uint8_t *relabel) {
+__device__ __forceinline__ void rx_seam_body(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                             int R, float quad, rx_seam_part *part, const SYM *stage, unsigned stage_stride,
+                                             const SYM *wstage, unsigned wstride, const uint8_t *relabel) {
   const unsigned rmask = (unsigned)R - 1;   // nrotations is 2, 4 or 8 for every constellation (sdr.h:326-468)
   const unsigned j = blockIdx.x * kSeamBlock + threadIdx.x;
   long long add = 0;
@@ -151,13 +151,19 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_til
   }
   seam_block_scan(add, k, ins, drp, bad, j, n_tiles, rmask, fix, part);
 }
+template <typename INFO, typename SYM>
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam(const INFO *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                                  int R, float quad, rx_seam_part *part, const SYM *stage, unsigned stage_stride,
+                                                  const SYM *wstage, unsigned wstride, const uint8_t *relabel) {
+  rx_seam_body<INFO, SYM>(info, fix, n_tiles, omega, R, quad, part, stage, stage_stride, wstage, wstride, relabel);
+}
 
 // relabel: [nrot][256] symbol relabelling per accumulated quadrant step; rx_relabel(sym, map) applies it to a record.
 template <typename SYM, typename STATE>
-__global__ __launch_bounds__(64) void k_rx_compact(const SYM *stage, unsigned stage_stride,
-                                                   const rx_tile_info_t<SYM> *info, const rx_tile_fix *fix, const rx_seam_part *part,
-                                                   const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles, int R, float quad,
-                                                   SYM *out, STATE *state, rx_seam_result *res) {
+__device__ __forceinline__ void rx_compact_body(const SYM *stage, unsigned stage_stride,
+                                                const rx_tile_info_t<SYM> *info, const rx_tile_fix *fix, const rx_seam_part *part,
+                                                const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles, int R, float quad,
+                                                SYM *out, STATE *state, rx_seam_result *res) {
   const unsigned j = blockIdx.x;
   if (j >= n_tiles) return;
   const unsigned rmask = (unsigned)R - 1;
@@ -191,6 +197,13 @@ __global__ __launch_bounds__(64) void k_rx_compact(const SYM *stage, unsigned st
   for (unsigned k = threadIdx.x + skip; k < ti.count; k += 64) {
     dst[k - skip] = rx_relabel(src[k], map);
   }
+}
+template <typename SYM, typename STATE>
+__global__ __launch_bounds__(64) void k_rx_compact(const SYM *stage, unsigned stage_stride,
+                                                   const rx_tile_info_t<SYM> *info, const rx_tile_fix *fix, const rx_seam_part *part,
+                                                   const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles, int R, float quad,
+                                                   SYM *out, STATE *state, rx_seam_result *res) {
+  rx_compact_body<SYM, STATE>(stage, stage_stride, info, fix, part, relabel, n_tiles, R, quad, out, state, res);
 }
 
 

@@ -252,11 +252,14 @@ class Oracle:
         self.lib.lo_fir_shift_coeffs(len(coeffs), _p(coeffs), freq, _p(out))
         return out
 
-    def fir_filter(self, coeffs, decim, x, freq=0.0, shifted=None, fma=False):
+    def fir_filter(self, coeffs, decim, x, freq=0.0, shifted=None, fma=False, scale=None):
         """fma=True: the fused-multiply-add restatement (the arithmetic of LSDR_FIR_FMA / LSDR_FIR_MFMA); fma="blk": the
         block-polyphase restatement (LSDR_FIR_MFMA_BLK)."""
         x = cf32(x)
         sc = self.fir_shift(coeffs, freq) if shifted is None else cf32(shifted)
+        if scale is not None:      # LSDR_FIR_MFMA_BLK: the fused scaler rides on the taps, one f32 rounding per component
+            assert fma == "blk"
+            sc = (sc.view(np.float32) * np.float32(scale)).view(np.complex64)
         cap = max(0, (len(x) - len(sc)) // decim) + 1
         out = np.empty(cap, np.complex64)
         consumed = c_sz()

@@ -257,12 +257,17 @@ def test_mfma_run_multi_and_short_inputs(capi, ctx, oracle):
 BLK_GEOMS = [(313, 30), (200, 30), (330, 30), (480, 30), (30, 30), (101, 10), (160, 10), (161, 16), (65, 8), (40, 4), (17, 16), (7, 8)]
 
 
-@pytest.mark.parametrize("w", [2, 4])
+@pytest.mark.parametrize("kern", ["stream", "blk_w2", "blk_w4"])
 @pytest.mark.parametrize("n,d", BLK_GEOMS, ids=[f"N{n}_D{d}" for n, d in BLK_GEOMS])
-def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, w, n, d):
-    """LSDR_FIR_MFMA_BLK (k_fir_mfma_blk: block-polyphase dense product on the matrix pipe) against its stated arithmetic,
-    oracle.fir_filter(fma="blk") — the reference's loop with the taps in blocks of D, an fmaf chain per block, block sums
-    added in order — bit for bit, and against the reference's arithmetic under LSDR_FIR_FMA's error bound."""
+def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, kern, n, d):
+    """LSDR_FIR_MFMA_BLK (block-polyphase dense product on the matrix pipe: k_fir_mfma_stream — LDS-direct refill, the default
+    where the decimation allows it — and k_fir_mfma_blk, register-staged, any even compile-time decimation) against its stated
+    arithmetic, oracle.fir_filter(fma="blk") — the reference's loop with the taps in blocks of D, an fmaf chain per block,
+    block sums added in order — bit for bit, and against the reference's arithmetic under LSDR_FIR_FMA's error bound."""
+    if kern == "stream" and d not in (10, 30):
+        pytest.skip("k_fir_mfma_stream exists for decimations 10 and 30")
+    w = 4 if kern == "blk_w4" else 2
+    os.environ["LSDR_MFMA_STREAM"] = "1" if kern == "stream" else "0"
     rng = np.random.default_rng(n * 37 + d)
     ns = 4096 * 90 + 77
     x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 12).astype(np.complex64)
@@ -275,7 +280,7 @@ def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, w, n, 
                 f.set_freq(freq)
             y, cons = f.run(x)
             f.close()
-            ref, rcons = oracle.fir_filter(co, d, oracle.scaler(75.0, x), freq, fma="blk")
+            ref, rcons = oracle.fir_filter(co, d, x, freq, fma="blk", scale=75.0)
             assert cons == rcons and len(y) == len(ref)
             assert np.array_equal(y, ref), (freq, int((y != ref).sum()), int(np.flatnonzero(y != ref)[0]), float(np.abs(y - ref).max()))
             exact, _ = oracle.fir_filter(co, d, oracle.scaler(75.0, x), freq)
@@ -283,9 +288,12 @@ def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, w, n, 
             assert np.abs(y - exact).max() <= bound
     finally:
         del os.environ["LSDR_MFMA_W"]
+        del os.environ["LSDR_MFMA_STREAM"]
 
 
-def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle):
+@pytest.mark.parametrize("stream", ["1", "0"])
+def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle, stream, monkeypatch):
+    monkeypatch.setenv("LSDR_MFMA_STREAM", stream)
     rng = np.random.default_rng(13)
     co = capi.lowpass(312, np.float32(0.0049))
     f = capi.FirFilter(ctx, co, 30, in_scale=0.5, arith=capi.FIR_MFMA_BLK)
@@ -297,15 +305,15 @@ def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle):
     cons, prod = f.run_multi_dev([d.ptr for d in dins], n, [d.ptr for d in douts], cap)
     assert prod == cap and cons == cap * 30
     for x, dout in zip(xs, douts):
-        want, _ = oracle.fir_filter(co, 30, oracle.scaler(0.5, x), fma="blk")
+        want, _ = oracle.fir_filter(co, 30, x, fma="blk", scale=0.5)
         assert np.array_equal(ctx.download(dout, np.complex64, prod), want[:prod])
     for m in (0, 312, 313, 342, 343, 344, 1000, 4153, 8000):
         y, cons = f.run(xs[0][:m])
-        want, wcons = oracle.fir_filter(co, 30, oracle.scaler(0.5, xs[0][:m]), fma="blk")
+        want, wcons = oracle.fir_filter(co, 30, xs[0][:m], fma="blk", scale=0.5)
         assert cons == wcons and np.array_equal(y, want), m
     cons, prod = f.run_dev(dins[0].ptr, n, douts[0].ptr, 1000)
     assert (cons, prod) == (30000, 1000)
-    want, _ = oracle.fir_filter(co, 30, oracle.scaler(0.5, xs[0]), fma="blk")
+    want, _ = oracle.fir_filter(co, 30, xs[0], fma="blk", scale=0.5)
     assert np.array_equal(ctx.download(douts[0], np.complex64, 1000), want[:1000])
     for d in dins + douts:
         d.free()

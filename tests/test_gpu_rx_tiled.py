@@ -200,3 +200,71 @@ def test_tiled_fir_sampler_vs_serial(capi, ctx, oracle):
     assert out["consumed"] == ref["consumed"] and len(out["sym"]) == len(ref["sym"]), (len(out["sym"]), len(ref["sym"]), stats)
     rep = check_tiled(out["sym"], ref["sym"], stats)
     assert rep["pass"], (rep, TOL)
+
+
+@pytest.mark.parametrize("fmt", ["cf32", "cu8"])
+def test_multi_capture_runs_equal_separate_queued_runs(capi, ctx, oracle, fmt):
+    """lsdr_rx_run_multi_async: three independent captures (own signal, own loop state) share their launches — same symbols,
+    counts, seam statistics and final loop state as three separate lsdr_rx_run_async calls, bit for bit, over two queued runs;
+    receivers that cannot share (different tile geometry) fall back to separate launches with the same results."""
+    n = 60000
+    xs = []
+    for k in range(3):
+        x, _ = synth.qpsk_baseband(4 * (n // 4 + 9000), 4, seed=20 + k, rms=50.0, snr_db=18.0 + k)
+        xs.append(x)
+    kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=4.0, mode=capi.RX_TILED, tile_len=256, tile_warmup=256)
+    if fmt == "cu8":
+        kw["in_format"] = capi.IN_CU8
+        xs = [np.clip(np.round(np.stack([x.real, x.imag], -1) * 0.5) + 128, 0, 255).astype(np.uint8) for x in xs]
+        isz, acq_kw = 2, dict(in_format=capi.IN_CU8)
+    else:
+        isz, acq_kw = 8, {}
+    sts = []
+    for x in xs:
+        acq = capi.CstlnReceiver(ctx, sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=4.0, **acq_kw)
+        acq.run(x[:32768], meas=False)
+        sts.append(acq.state()); acq.close()
+    dins = [ctx.upload(x[32768:]) for x in xs]
+    m = len(xs[0]) - 32768
+    half = 16000
+
+    def run(multi, kws):
+        rxs = [capi.CstlnReceiver(ctx, **k) for k in kws]
+        for r, st in zip(rxs, sts):
+            r.set_state(st)
+        outs = [[ctx.alloc(m * 4 + 1024) for _ in range(2)] for _ in rxs]
+        pos = 0
+        for q in range(2):
+            if multi:
+                used = capi.CstlnReceiver.run_multi_async(rxs, [d.at(pos * isz) for d in dins], half + 1, [o[q].ptr for o in outs], m)
+            else:
+                for r, d, o in zip(rxs, dins, outs):
+                    used = r.run_async(d.at(pos * isz), half + 1, o[q].ptr, m)
+            pos += used
+        res = []
+        for r, o in zip(rxs, outs):
+            syms = [ctx.download(o[q], capi.SOFTSYM, r.wait()).copy() for q in range(2)]
+            res.append((syms, r.tiled_stats(), r.state().as_dict()))
+            r.close()
+        for o in outs:
+            for b in o:
+                b.free()
+        return pos, res
+
+    pos_a, sep = run(False, [kw] * 3)
+    pos_b, mul = run(True, [kw] * 3)
+    assert pos_a == pos_b and pos_a > 0
+    for k in range(3):
+        for q in range(2):
+            assert len(mul[k][0][q]) > 3000 and bits_equal(mul[k][0][q], sep[k][0][q]), (k, q)
+        assert mul[k][1] == sep[k][1] and mul[k][2] == sep[k][2], k
+    assert not bits_equal(mul[0][0][0], mul[1][0][0][:len(mul[0][0][0])]) or len(mul[0][0][0]) != len(mul[1][0][0])
+    # not alike: one receiver has another tile length → queued one by one, same results as on its own
+    kws = [kw, dict(kw, tile_len=512), kw]
+    _, mixed = run(True, kws)
+    _, mixed_sep = run(False, kws)
+    for k in range(3):
+        for q in range(2):
+            assert bits_equal(mixed[k][0][q], mixed_sep[k][0][q]), (k, q)
+    for d in dins:
+        d.free()

@@ -35,5 +35,9 @@ for reps in [int(v) for v in os.environ.get("FIR_ALONE_REPS", "20").split(",")]:
     print(f"  {reps} launches back to back: {ms:.4f} ms each = {(cons*8+prod*8)/ms/1e9:.2f} TB/s", flush=True)
 y = ctx.download(d_out, np.complex64, 100000)
 O = po.Oracle()
-yr = O.fir_filter(coeffs, decim, O.scaler(75.0, np.tile(blk, 1)[:100000 * decim + len(coeffs)]), freq=f.current_freq, fma=("blk" if arith == capi.FIR_MFMA_BLK else arith != capi.FIR_EXACT))[0][:100000]
+xs = np.tile(blk, 1)[:100000 * decim + len(coeffs)]
+if arith == capi.FIR_MFMA_BLK:
+    yr = O.fir_filter(coeffs, decim, xs, freq=f.current_freq, fma="blk", scale=75.0)[0][:100000]
+else:
+    yr = O.fir_filter(coeffs, decim, O.scaler(75.0, xs), freq=f.current_freq, fma=arith != capi.FIR_EXACT)[0][:100000]
 print(f"FIR_ARITH={os.environ.get('FIR_ARITH','exact')} W={os.environ.get('LSDR_MFMA_W','-')} WPC={os.environ.get('LSDR_MFMA_WPC','-')} freq={f.current_freq} LSDR_FIR_PERSIST={os.environ.get('LSDR_FIR_PERSIST','2')} lib={os.path.basename(capi.LIB_PATH)}: {ms:.4f} ms per 64 Mi samples = {(cons*8+prod*8)/ms/1e9:.2f} TB/s; bit-exact vs the oracle ({'fmaf chain' if arith != capi.FIR_EXACT else 'reference arithmetic'}) {np.array_equal(y, yr)}")
