@@ -555,7 +555,9 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
         n_launch_out = n_out + bench.EXTRA
         kb = n_launch_out * decim * 8 + n_launch_out * 8
         ms = float(np.mean(fir_ms))
-        out["roofline"] = {"kernel": "k_fir_persist (fir_filter)", "bound": "hbm", "achieved": round(B * alg_per_sample / (ms * 1e-3) / 1e9, 2), "peak": bench.HBM_PEAK_GBS,
+        kname = {capi.FIR_MFMA: "k_fir_mfma", capi.FIR_MFMA_BLK: "k_fir_mfma_stream"}.get(headline_arith(capi, args), "k_fir_persist")
+        out["fir_arith"] = getattr(args, "fir_arith", "blk")
+        out["roofline"] = {"kernel": kname + " (fir_filter)", "bound": "hbm", "achieved": round(B * alg_per_sample / (ms * 1e-3) / 1e9, 2), "peak": bench.HBM_PEAK_GBS,
                            "unit": "GB/s", "frac": round(B * alg_per_sample / (ms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4), "avg_launch_ms": round(ms, 4),
                            "algorithmic_bytes_per_launch": int(B * alg_per_sample), "kernel_bytes": kb, "traffic": None,
                            "hbm_frac": hbm_frac(nb * B / dt, alg_per_sample), "viterbi_valu_issue": valu}

@@ -1508,7 +1508,11 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     if (lds_bytes > 64 * 1024)
       LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;
-    const unsigned pg = (unsigned)(f->ctx->num_cu * (stream ? f->stream_wpc : f->mf_wpc) + 7) / 8 * 8;
+    // (complex taps on the register-staged kernels: three workgroups per CU queued — two resident ones that start together stay in
+    // step and leave the memory idle while both compute: 0.345 ms per 64 Mi against 0.157)
+    static const bool wpc_env = getenv("LSDR_MFMA_WPC") != nullptr;
+    const int wpc = stream ? f->stream_wpc : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
+    const unsigned pg = (unsigned)(f->ctx->num_cu * wpc + 7) / 8 * 8;
     if (grid > pg) grid = pg;
     hipLaunchKernelGGL(k, dim3(grid), dim3(stream ? 64 : 64 * f->mf_W), lds_bytes, f->ctx->stream, a);
     LSDR_HIP(hipGetLastError());
