@@ -237,7 +237,7 @@ def anf1(capi, synth, device, args):
     return out
 
 
-def c2_offset(capi, synth, device, args):
+def c2_offset(capi, synth, device, args):   # (complex taps under the headline's arithmetic: k_fir_mfma_stream<CP = 1>)
     """Carrier 1 MHz off: fir_filter runs with complex (frequency-shifted) taps and keeps following the receiver's carrier
     estimate (fir_filter::track, dsp.h:236-244; the scheduler's feedback of leandvb.cc:506-510).  The estimate comes from the
     newest receiver run that has COMPLETED (lsdr_rx_retired_freq_tap) while later ones are still queued: same queued pipeline as

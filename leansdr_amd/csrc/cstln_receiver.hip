@@ -1279,6 +1279,18 @@ static int rx_tiled_plan(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbo
   if ((size_t)(sym_per_chunk + 1) * chunks > cap_out) chunks = cap_out / (sym_per_chunk + 1);
   const bool want_cstln = cstln_cap > 0;
   if (want_cstln && chunks > cstln_cap) chunks = cstln_cap;     // one sampled point per chunk at most (sdr.h:785-788 gate)
+  {
+    // LDS-staged cu8 tiles address their samples through a buffer resource with 32-bit byte offsets (rows beyond 0xfff00000 are
+    // pointed past the end and read zeros): a run is cut to what those offsets reach — `consumed` reports the partial run and the
+    // caller comes back with the rest, as with any other limit.  (LSDR_RX_LDS_SPAN: test hook, bytes.)
+    static const bool no_lds0 = getenv("LSDR_RX_NO_LDS") != nullptr;
+    static const unsigned long long span = getenv("LSDR_RX_LDS_SPAN") ? strtoull(getenv("LSDR_RX_LDS_SPAN"), nullptr, 0) : 0xfff00000ull;
+    const bool lds_tiles = r->cfg.in_format == LSDR_IN_CU8 && r->cfg.sampler != LSDR_SAMP_FIR && !no_lds0 && r->omega <= 8.f;
+    if (lds_tiles) {
+      const unsigned long long max_samples = (span - 64) / 2;
+      if ((unsigned long long)chunks * kChunk + (unsigned)ra > max_samples) chunks = (size_t)((max_samples - (unsigned)ra) / kChunk);
+    }
+  }
   const int slot = (r->ring_head + r->ring_count) % lsdr_rx::kRing;
   P->slot = slot; P->chunks = chunks; P->want_meas = want_meas; P->want_cstln = want_cstln;
   if (!chunks) return LSDR_OK;   // nothing to do: the commit still occupies a slot so that wait() pairs with run_async()
@@ -1381,6 +1393,12 @@ static int rx_tiled_plan(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbo
   static const bool no_lds = getenv("LSDR_RX_NO_LDS") != nullptr;
   const bool use_lds = r->cfg.in_format == LSDR_IN_CU8 && r->cfg.sampler != LSDR_SAMP_FIR && !no_lds && r->omega <= 8.f;
   if (hard && !use_lds) { lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 needs cu8 input with the nearest or linear sampler"); return LSDR_E_UNSUPPORTED; }
+  // k_rx_compact_h lets a partial output word be finished by the NEXT tile from the previous tile's column only: every tile must
+  // hold at least two words' worth of symbols (32) after a dropped first one
+  if (hard && (float)Lc * kChunk / (r->omega + 0.1f) < 34.f) {
+    lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 needs tiles of at least 34 symbols (tile_len %u samples at omega %.2f)", Lc * kChunk, (double)r->omega);
+    return LSDR_E_ARG;
+  }
   P->use_lds = use_lds;
   return LSDR_OK;
 }
@@ -1822,6 +1840,8 @@ int lsdr_rx_reset(lsdr_rx *r) {   // the loop state right after lsdr_rx_create (
   r->st = r->st_initial;
   r->st_stale_host = false;
   r->st_dirty_host = false;
+  r->retired_freq_tap = r->st_initial.freqw / 65536;      // what refresh_freq_tap (sdr.h:919-921) shows for the new capture, not the old one's estimate
+  r->last_tiles = r->last_dup = r->last_miss = r->last_badseam = 0;
   return lsdr_stage_h2d(r->ctx, r->d_state, &r->st, sizeof(rx_state_dev));
 }
 

@@ -1475,7 +1475,8 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.N = N; a.D = D; a.S = f->S;
   a.count = count;
   a.n_in = n_in;
-  const bool stream = blk && f->stream && real_taps;   // (complex taps: 15 MFMA steps per row pair and twice the operand reads — the register-staged kernel measured 2× faster there)
+  static const bool stream_cp = !(getenv("LSDR_MFMA_STREAM_CP") && !atoi(getenv("LSDR_MFMA_STREAM_CP")));   // A/B hook
+  const bool stream = blk && f->stream && (real_taps || stream_cp);
   const unsigned M = stream ? 128u - (f->bk[real_taps ? 0 : 1].nq - 1) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
@@ -1514,6 +1515,18 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     const int wpc = stream ? f->stream_wpc : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
     const unsigned pg = (unsigned)(f->ctx->num_cu * wpc + 7) / 8 * 8;
     if (grid > pg) grid = pg;
+    {
+      static const bool dbg = getenv("LSDR_FIR_DEBUG") != nullptr;   // diagnostic: what the runtime will co-schedule
+      if (dbg) {
+        int nb = -1;
+        hipFuncAttributes fa;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)k, stream ? 64 : 64 * f->mf_W, lds_bytes);
+        (void)hipFuncGetAttributes(&fa, (const void *)k);
+        fprintf(stderr, "fir_filter: %s cp=%d grid %u x %d lanes, LDS %zu B, regs %d, scratch %zu B, workgroups per CU (occupancy API) %d\n",
+                stream ? "k_fir_mfma_stream" : blk ? "k_fir_mfma_blk" : "k_fir_mfma", cp, grid, stream ? 64 : 64 * f->mf_W, lds_bytes,
+                fa.numRegs, (size_t)fa.localSizeBytes, nb);
+      }
+    }
     hipLaunchKernelGGL(k, dim3(grid), dim3(stream ? 64 : 64 * f->mf_W), lds_bytes, f->ctx->stream, a);
     LSDR_HIP(hipGetLastError());
     *produced = count;

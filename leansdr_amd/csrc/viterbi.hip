@@ -667,6 +667,8 @@ struct lsdr_viterbi {
   bool q4;                            // rate 1/2 QPSK / 2/3 8PSK may use the four-lanes-per-tile kernel (trellis structure checked at create)
   bool q4_call;                       // ... and the current lsdr_viterbi_run call does
   unsigned warm_others;               // warm-up chunks of the other alignments' tiles (grows when their seams fail)
+  unsigned char *d_bounce = nullptr;  // 4-byte aligned stand-in for a misaligned `out` (lsdr_viterbi_run)
+  size_t bounce_cap = 0;
 };
 
 static int vit_code_for(int rate, vit_code *c, const unsigned short **polys) {
@@ -901,6 +903,7 @@ void lsdr_viterbi_destroy(lsdr_viterbi *v) {
   (void)hipFree(v->d_T); (void)hipFree(v->d_maps); (void)hipFree(v->d_shifts); (void)hipFree(v->d_states);
   (void)hipFree(v->d_jobs); (void)hipFree(v->d_begin); (void)hipFree(v->d_end); (void)hipFree(v->d_first);
   (void)hipFree(v->d_chunk); (void)hipFree(v->d_totals); (void)hipFree(v->d_bad); (void)hipFree(v->d_fix);
+  (void)hipFree(v->d_bounce);
   delete v;
 }
 
@@ -913,8 +916,33 @@ int lsdr_viterbi_stats(const lsdr_viterbi *v, unsigned *tiles, unsigned *bad) {
   return LSDR_OK;
 }
 
+static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                               size_t *consumed, size_t *produced);
+
+// The kernels store decoded bytes four at a time (32-bit words).  A caller's `out` may sit at any byte offset — a pipebuf<u8>
+// write pointer after compaction and mpeg_sync's byte-granular reads — so a pointer that is not 4-byte aligned is served through
+// an aligned bounce buffer and one device copy (same bytes; rare).
 int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
                      size_t *consumed, size_t *produced) {
+  LSDR_ARG(v && consumed && produced);
+  if (((uintptr_t)out & 3u) == 0 || !out || !cap_out) return viterbi_run_aligned(v, in, n_in, out, cap_out, consumed, produced);
+  lsdr_ctx *c = v->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  if (v->bounce_cap < cap_out) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(v->d_bounce);
+    v->d_bounce = nullptr; v->bounce_cap = 0;
+    LSDR_HIP(hipMalloc((void **)&v->d_bounce, cap_out + 64));
+    v->bounce_cap = cap_out;
+  }
+  const int rc = viterbi_run_aligned(v, in, n_in, v->d_bounce, cap_out, consumed, produced);
+  if (rc) return rc;
+  if (*produced) LSDR_HIP(hipMemcpyAsync(out, v->d_bounce, *produced, hipMemcpyDeviceToDevice, c->stream));
+  return LSDR_OK;
+}
+
+static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, uint8_t *out, size_t cap_out,
+                               size_t *consumed, size_t *produced) {
   LSDR_ARG(v && consumed && produced);
   *consumed = 0; *produced = 0;
   vit_timing vt;

@@ -9,7 +9,7 @@ QPSK stream at the bench condition (Es/N0 = 20 dB in leansdr_amd.synth's definit
   count            exactly the same number of soft symbols for the same consumed input
   first tile       bit-exact (it continues from the carried state with the reference's arithmetic)
   decisions        >= min_equal_decisions identical `symbol` fields
-  cost, mean       mean |Δcost| <= max_mean_abs_dcost        (cost = the soft symbol's int16 confidence, |cost| <= COST_MAX)
+  cost, mean       mean |Δcost| <= max_mean_abs_dcost        (cost = the soft symbol's int16 confidence, |cost| <= COST_MAX = 11236)
   cost, p99        99th percentile of |Δcost| <= max_p99_abs_dcost
   cost, max        no single symbol further than max_abs_dcost from the serial receiver's
   seams            no seam left unreconciled (bad_seams == 0)
@@ -18,26 +18,36 @@ QPSK stream at the bench condition (Es/N0 = 20 dB in leansdr_amd.synth's definit
 LOW_SNR holds the same bounds for the 10–12 dB checks (the loops' own noise is larger there; a few seams may stay
 unrepaired — they cost a handful of symbols that the FEC corrects, and are counted).
 """
+import os
+
 import numpy as np
 
 COST_MAX = 11236          # largest |cost| of the QPSK table (cstln_lut<256>, sdr.h:529-560)
 
+# How the bounds were set (round 4): every comparison made by the gpu tests and by bench.py's verification was logged
+# (LSDR_TOL_LOG, below; profiles/r04_tolerance.txt) and each bound is 1.5 × the largest figure seen, rounded up —
+#   TOL      bench geometry (256-sample tiles after 256 of warm-up) on the C2 chain, loops settled: mean |Δcost| 185–219,
+#            p99 848, max 1908–2332; the other tile geometries of tests/test_gpu_rx_tiled.py: 137–155 / 424 / 636–1060; cu8 and
+#            fir_sampler runs: 74–78 / 212 / 636; identical decisions everywhere, no unreconciled seam
+#   LOW_SNR  C2 chain at 12 / 10 dB: mean 248 / 331, p99 1060 / 1696, max 3392 / 7632 (a flipped decision moves a cost by up to
+#            2·COST_MAX; 0.07 % of the decisions differ at 10 dB), 4 unreconciled seams in 1036 tiles at 10 dB
+# so a regression that doubles any error figure fails.
 TOL = dict(
-    min_equal_decisions=0.999,
-    max_mean_abs_dcost=0.05 * COST_MAX,       # 562
-    max_p99_abs_dcost=0.20 * COST_MAX,        # 2247
-    max_abs_dcost=0.5 * COST_MAX,             # 5618: no single symbol moves by more than half the confidence scale (measured <= 2544)
+    min_equal_decisions=0.9995,
+    max_mean_abs_dcost=330,       # 1.5 × 219
+    max_p99_abs_dcost=1300,       # 1.5 × 848
+    max_abs_dcost=3500,           # 1.5 × 2332
     max_bad_seams=0,
     ss_rtol=0.02,
     mer_atol_db=1.0,
 )
 
 LOW_SNR = dict(
-    min_equal_decisions=0.99,
-    max_mean_abs_dcost=0.10 * COST_MAX,
-    max_p99_abs_dcost=0.50 * COST_MAX,
-    max_abs_dcost=2 * COST_MAX,
-    max_bad_seams_per_1000_tiles=20,
+    min_equal_decisions=0.998,    # measured 0.99934 at 10 dB
+    max_mean_abs_dcost=500,       # 1.5 × 331
+    max_p99_abs_dcost=2600,       # 1.5 × 1696
+    max_abs_dcost=11500,          # 1.5 × 7632
+    max_bad_seams_per_1000_tiles=8,   # measured 3.9 at 10 dB, 0 at 12 dB
     ss_rtol=0.05,
     mer_atol_db=1.0,
 )
@@ -68,4 +78,9 @@ def check_tiled(sym, ref_sym, stats=None, first_exact=0, tol=None):
         else:
             ok = ok and rep["bad_seams"] * 1000 <= tol["max_bad_seams_per_1000_tiles"] * max(1, rep["tiles"])
     rep["pass"] = bool(ok)
+    log = os.environ.get("LSDR_TOL_LOG")          # every comparison's measured figures, one JSON line each (how the bounds above were set)
+    if log:
+        import json
+        with open(log, "a") as f:
+            f.write(json.dumps(dict(rep, tol="TOL" if tol is TOL else "LOW_SNR", where=os.environ.get("PYTEST_CURRENT_TEST", ""))) + "\n")
     return rep

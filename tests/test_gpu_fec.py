@@ -438,3 +438,26 @@ def test_two_contexts_on_two_threads(capi, oracle):
     for r in results[0] + results[1]:
         assert r[0] == first[0] and r[1] == first[1] and r[2] == first[2]
         assert bits_equal(r[3][0], first[3][0]) and r[3][1:] == first[3][1:]
+
+
+@pytest.mark.parametrize("off", [1, 2, 3])
+def test_viterbi_misaligned_output_pointer(capi, ctx, oracle, off, vit_kernel):
+    """A pipebuf<u8> write pointer sits at any byte offset: the kernels' 32-bit stores then go through an aligned bounce buffer —
+    same bytes as an aligned call, nothing written outside [out, out + produced)."""
+    sym = fec_input(hard_symbols(), 40)
+    want, wcons, _ = oracle.viterbi_sync(sym, 1, 0)
+    v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
+    d = ctx.upload(sym)
+    cap = len(sym)
+    o = ctx.alloc(cap + 64)
+    capi.check(capi.lib.lsdr_memset(ctx.h, o.ptr, 0xEE, cap + 64))
+    pos = nout = 0
+    while True:
+        cons, prod = v.run_dev(d.at(pos * 4), len(sym) - pos, o.at(off + nout), cap - nout)
+        if not cons and not prod:
+            break
+        pos += cons; nout += prod
+    got = ctx.download(o, np.uint8, off + nout + 16)
+    v.close(); d.free(); o.free()
+    assert pos == wcons and nout == len(want)
+    assert bits_equal(got[off:off + nout], want) and (got[:off] == 0xEE).all() and (got[off + nout:] == 0xEE).all()
