@@ -500,7 +500,8 @@ def main():
 
     from leansdr_amd.shard import Shard
     shard = Shard()                       # one process per GPU; gloo (no RCCL) only when WORLD_SIZE > 1
-    rank, local_rank, world = shard.rank, shard.local_rank, shard.world
+    rank, world = shard.rank, shard.world
+    local_rank = shard.device_index()     # LOCAL_RANK (or the rank → GPU map of LSDR_RANK_DEVICES)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
 
@@ -553,14 +554,22 @@ def main():
     pipe.sync()
     shard.barrier()
     t0 = time.perf_counter()
-    consumed = pipe.run(args.steps * bps, True, snapshot_last=(rank == 0 and not args.no_verify))
+    consumed = pipe.run(args.steps * bps, True, snapshot_last=not args.no_verify)
     pipe.sync()
     shard.barrier()
     dt = time.perf_counter() - t0
 
     total, dt, _ = shard.aggregate(consumed, dt)   # all ranks' samples ÷ the slowest rank's time
 
+    # EVERY rank checks its own captures against the oracle and contributes its verdict (gloo); rank 0 reports the job's
     rc = 0
+    verified = None
+    if not args.no_verify:
+        verified = pipe.verify_last_batch()
+        ranks_ok, ranks = shard.all_ranks_ok(verified["pass"])
+        if not verified["pass"]:
+            print(f"bench.py: rank {rank}: VERIFICATION FAILED: " + json.dumps(verified)[:3000], file=sys.stderr)
+            rc = 3
     if rank == 0:
         g = pipe.geo
         nsym = sum(c.nsym for c in pipe.caps)
@@ -594,12 +603,12 @@ def main():
                        "symbols_per_step": nsym // max(1, args.steps)},
             "roofline": pipe.roofline(),
         }
-        if not args.no_verify:
-            out["verified"] = pipe.verify_last_batch()
+        if verified is not None:
+            out["verified"] = verified                              # rank 0's own captures, in full
+            out["verified"]["ranks_passed"], out["verified"]["ranks"] = ranks_ok, ranks
+            out["verified"]["pass"] = bool(verified["pass"] and ranks_ok == ranks)
             if not out["verified"]["pass"]:
-                print("bench.py: VERIFICATION FAILED: " + json.dumps(out["verified"]), file=sys.stderr)
                 rc = 3
-        x0 = pipe.caps[0].x
     coeffs, decim = pipe.coeffs, pipe.decim
     pipe.close()
 

@@ -426,9 +426,16 @@ def run_workload(capi, device, args, shard):
     shard.barrier()
     dt = time.perf_counter() - t0
     total, dt, _ = shard.aggregate(consumed, dt)
+    # every rank checks the TS of its own captures and contributes its verdict; rank 0 reports
+    ver = None
+    if not args.no_verify:
+        ver = job.verify()
+        ranks_ok, ranks = shard.all_ranks_ok(ver["pass"])
+        if not ver["pass"]:
+            print(f"bench.py: rank {rank}: C1 VERIFICATION FAILED: " + str(ver)[:3000], file=sys.stderr)
     if rank != 0:
         job.close()
-        return None, 0
+        return None, (3 if ver is not None and not ver["pass"] else 0)
     kms, klaunch = job.tile_kernel_ms()
     alg = job.n * ALG_BYTES_PER_SAMPLE
     W = len(job.workers)
@@ -455,11 +462,24 @@ def run_workload(capi, device, args, shard):
                      "note": "latency/issue-bound decision-feedback recurrence (DESIGN §4.2): the HBM roofline is reported because SURVEY §8(d) asks for it"},
     }
     rc = 0
-    if not args.no_verify:
-        out["verified"] = job.verify()
+    if ver is not None:
+        out["verified"] = ver
+        out["verified"]["ranks_passed"], out["verified"]["ranks"] = ranks_ok, ranks
+        out["verified"]["pass"] = bool(ver["pass"] and ranks_ok == ranks)
         if not out["verified"]["pass"]:
-            print("bench.py: C1 VERIFICATION FAILED: " + str(out["verified"])[:3000], file=sys.stderr)
             rc = 3
+    if world == 1 and args.c1_captures > 1 and not getattr(args, "no_single", False):
+        # BASELINE config 4 as written — ONE capture per GPU: nothing hides the chain's data-dependent host waits, so this is a
+        # latency figure (ms from the first sample to the last TS packet of a 128 Mi-sample capture), not the GPU's rate
+        one = C1Job(capi, device, 1, args.c1_msamples, 1, args.c1_tile, args.c1_warmup, seed0=1000 * (rank + 1))
+        one.run(1)
+        t1 = time.perf_counter()
+        reps = 3
+        n1 = one.run(reps, timed=True)
+        d1 = time.perf_counter() - t1
+        out["config4_one_capture_per_gpu"] = {"ms_per_capture": round(d1 / reps * 1e3, 3), "value": round(n1 / d1 / 1e6, 3), "unit": "MS/s",
+                                              "samples_per_capture": one.n, "note": "--c1-captures 1 --c1-workers 1: per-capture latency"}
+        one.close()
     if world == 1 and not args.no_cpu:
         cpu = cpu_reference(job, args.cpu_seconds)
         if cpu:

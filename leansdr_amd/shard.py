@@ -26,6 +26,21 @@ class Shard:
             dist.init_process_group("gloo")
             self.dist = dist
 
+    def device_index(self):
+        """The GPU of this rank: its LOCAL_RANK, or entry LOCAL_RANK of LSDR_RANK_DEVICES ("0,0": two ranks on GPU 0 — how the
+        N > 1 path is exercised, kernels and all, on a one-GPU box: tests/test_gpu_multirank.py)."""
+        m = os.environ.get("LSDR_RANK_DEVICES")
+        if m:
+            ids = [int(v) for v in m.split(",") if v.strip() != ""]
+            if self.local_rank < len(ids):
+                return ids[self.local_rank]
+        return self.local_rank
+
+    def all_ranks_ok(self, ok):
+        """(ranks that passed, ranks): every rank verifies its own captures and contributes its verdict."""
+        failed = self.sum_over_ranks(0.0 if ok else 1.0)
+        return self.world - int(round(failed)), self.world
+
     def capture_seed(self, base=1):
         """Every rank demodulates its own capture."""
         return base + self.rank

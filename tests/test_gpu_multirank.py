@@ -1,0 +1,42 @@
+"""N > 1 on hardware: `bench.py --gpus 2` with BOTH ranks mapped onto GPU 0 (LSDR_RANK_DEVICES=0,0) — the real launcher
+(torch.distributed.run on 127.0.0.1), the real kernels, gloo for the barrier and the totals, and EVERY rank verifying its own
+captures and contributing its verdict.  (The CPU-only plumbing test is tests/test_shard_gloo.py; an 8-GPU node is the driver's.)"""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LSDR_RANK_DEVICES"] = "0,0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-more"] + extra,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_c2_two_ranks_on_one_gpu_every_rank_verifies():
+    j = _run(["--batches-per-step", "4", "--captures", "2", "--batch-msamples", "16"])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["value"] > 0
+    v = j["verified"]
+    assert v["ranks"] == 2 and v["ranks_passed"] == 2 and v["pass"] and v["fir_bit_exact"] and v["captures_checked"] == 2
+    # two ranks' samples, the slower rank's clock
+    assert j["config"]["samples_per_step_per_gpu"] * 2 * j["steps"] == pytest.approx(j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"], rel=1e-3)
+
+
+def test_c1_two_ranks_on_one_gpu_every_rank_verifies():
+    """BASELINE config 4's launch path with real kernels: every rank generates, decodes and checks its own captures' TS against the
+    reference binary's."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "leandvb")):
+        pytest.fail("oracle/_ref/leandvb is missing on the GPU box: the per-rank TS check needs it (make -C oracle where /root/reference is)")
+    j = _run(["--workload", "c1", "--c1-captures", "2", "--c1-msamples", "8", "--c1-workers", "2"])
+    assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["captures_per_gpu"] == 2
+    v = j["verified"]
+    assert v["ranks"] == 2 and v["ranks_passed"] == 2 and v["pass"], v
