@@ -45,7 +45,8 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, MI355X_MICROARCH.md
 FS, FM, ROLLOFF, REJ = 240e6, 2e6, 0.35, 10.0
-EXTRA = 128                # decimated samples fir_filter produces past the batch end (receiver read-ahead)
+EXTRA = 128                # decimated samples fir_filter produces past the batch end (receiver read-ahead + less than a chunk)
+EXTRA_RRC = 384            # ... with the RRC fir_sampler (read-ahead 166): the receiver is handed n_out + 256 of them
 
 from leansdr_amd.tolerance import TOL, check_tiled      # THE tolerance of the tiled receiver (stated once, shared with tests/)
 
@@ -68,14 +69,14 @@ def c2_filter(capi):
     return capi.lowpass(order, fcut), decim
 
 
-def c2_geometry(batch_msamples, period_msamples, ncoeffs, decim):
+def c2_geometry(batch_msamples, period_msamples, ncoeffs, decim, extra=EXTRA):
     """A batch = whole symbols and whole receiver chunks (so that every batch consumes exactly B samples)."""
     sps = int(FS / FM)
     unit = int(128 * decim * sps // np.gcd(128 * decim, sps))
     period = max(1, (period_msamples << 20) // unit) * unit
     reps = max(1, (batch_msamples << 20) // period)
     B = period * reps
-    assert B % decim == 0 and (B // decim) % 128 == 0 and EXTRA * decim + ncoeffs <= period
+    assert B % decim == 0 and (B // decim) % 128 == 0 and extra * decim + ncoeffs <= period
     return dict(period=period, reps=reps, B=B, n_out=B // decim, N=ncoeffs, decim=decim, sps=sps, nbuf=3)
 
 
@@ -169,8 +170,9 @@ class Capture:
     """One capture: its endless input in HBM, the decimated-stream buffers, the symbol buffer, its receiver (own HIP
     stream).  fir_filter of all captures of a GPU goes through ONE launch on the fir stream."""
 
-    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None, cw=None, shared_rx_ctx=None):
+    def __init__(self, capi, synth, device, fir_ctx, idx, seed, geo, rx_kw, tile, freq=0.0, rx_cus=None, cw=None, shared_rx_ctx=None, extra=EXTRA):
         self.capi, self.idx, self.geo = capi, idx, geo
+        EXTRA = extra
         period, reps, B, n_out, N, decim = geo["period"], geo["reps"], geo["B"], geo["n_out"], geo["N"], geo["decim"]
         self.x, _ = synth.qpsk_baseband(period, geo["sps"], seed=seed, rms=1.0, snr_db=20.0, freq=freq)
         if cw:          # a CW interferer (cycles/sample rounded to a whole number of cycles per period, amplitude): auto_notch's job
@@ -226,8 +228,9 @@ class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None):
         self.capi = capi
+        self.batch_hook = batch_hook          # called per batch after fir_filter was queued: hook(pipe, dec buffer index, outputs, done event)
         # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
         # streams in all — with a stream per capture, five streams on the runtime's four hardware queues let two receivers
         # share a queue, and that queue paced the pipeline
@@ -246,17 +249,28 @@ class C2Pipeline:
         self.ctx = capi.Ctx(device, cu_mask=fir_mask)
         coeffs, decim = c2_filter(capi)
         self.coeffs, self.decim = coeffs, decim
-        self.geo = c2_geometry(batch_msamples, period_msamples, len(coeffs), decim)
+        self.geo = c2_geometry(batch_msamples, period_msamples, len(coeffs), decim, extra=EXTRA_RRC if sampler == "rrc" else EXTRA)
         self.fir_arith = capi.FIR_EXACT if fir_arith is None else fir_arith
         self.fir = capi.FirFilter(self.ctx, coeffs, decim, in_scale=75.0, arith=self.fir_arith)
         self.rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=capi.QPSK, omega=float(FS / decim / FM), meas_decimation=int(FS / decim),
                           freq=float(rx_freq))
+        self.oracle_rx_kw = dict(sampler=1)
+        if sampler == "rrc":      # leandvb --sampler rrc (leandvb.cc:440-458): fir_sampler on an RRC of ≥ 64 steps per symbol
+            fs_dec = FS / decim
+            steps = max(1, int(64 * FM / fs_dec))
+            order = int(REJ * fs_dec * steps / (22 * (FM / 2) * ROLLOFF))
+            rrc = capi.root_raised_cosine(order, float(np.float32(FM) / np.float32(fs_dec * steps)), ROLLOFF)
+            self.rx_kw.update(sampler=capi.SAMP_FIR, coeffs=rrc, subsampling=steps)
+            self.oracle_rx_kw = dict(sampler=2, coeffs=rrc, subsampling=steps)
+            self.rrc = dict(ncoeffs=len(rrc), subsampling=steps)
+        self.extra = EXTRA_RRC if sampler == "rrc" else EXTRA
+        self.rx_extra = 256 if sampler == "rrc" else EXTRA     # consumed = ⌊(n_in − read-ahead)/128⌋·128 must be exactly n_out
         if rx_freq:   # what fir_filter::run does on its first call: the receiver's initial freq_tap moves the filter (dsp.h:236-244)
             self.fir.track(float(np.float32(rx_freq)), 1.0 / decim, float(np.float32(FM / FS * 0.1)))
         self.tile = tile
         self.ctx_rx = capi.Ctx(device, cu_mask=rx_mask) if self.rx_multi else None
         self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw,
-                             shared_rx_ctx=self.ctx_rx) for c in range(n_captures)]
+                             shared_rx_ctx=self.ctx_rx, extra=self.extra) for c in range(n_captures)]
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)
         self.ev_fir = [self.ctx.event() for _ in range(self.geo["nbuf"])]
@@ -272,6 +286,7 @@ class C2Pipeline:
         batches later, so the GPU never waits for the host; the pipeline is drained before returning."""
         capi, g, caps = self.capi, self.geo, self.caps
         B, n_out, N, decim, NBUF = g["B"], g["n_out"], g["N"], g["decim"], g["nbuf"]
+        EXTRA, rx_n_in = self.extra, g["n_out"] + self.rx_extra
         n_in_fir = B + EXTRA * decim + N
         while timed and len(self.ev_pool) < 2 * n_batches:
             self.ev_pool.append(self.ctx.event())
@@ -292,6 +307,8 @@ class C2Pipeline:
             done = self.ev_pool[2 * k + 1] if timed else self.ev_fir[i]   # (timed: the stop event doubles as the "filtered" event)
             self.ctx.event_record(done)
             assert prod == n_out + EXTRA, (prod, n_out)
+            if self.batch_hook is not None:
+                self.batch_hook(self, i, prod, done)
             if prof: t_b = pc(); tp[0] += t_b - t_a
             if self.rx_multi:
                 self.ctx_rx.wait_event(done)
@@ -299,7 +316,7 @@ class C2Pipeline:
                     for c in caps:
                         c.rx.snapshot_async()
                     self.snap = (0, i)
-                used = capi.CstlnReceiver.run_multi_async([c.rx for c in caps], [c.dec[i].ptr for c in caps], prod,
+                used = capi.CstlnReceiver.run_multi_async([c.rx for c in caps], [c.dec[i].ptr for c in caps], rx_n_in,
                                                           [c.d_sym.ptr for c in caps], n_out + EXTRA + 256)
                 assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
                 for c in caps:
@@ -309,7 +326,7 @@ class C2Pipeline:
                 if snapshot_last and k == n_batches - 1:
                     c.rx.snapshot_async()
                     self.snap = (0, i)
-                used = c.rx.run_async(c.dec[i].ptr, prod, c.d_sym.ptr, n_out + EXTRA + 256)
+                used = c.rx.run_async(c.dec[i].ptr, rx_n_in, c.d_sym.ptr, n_out + EXTRA + 256)
                 assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
                 c.queued += 1
             consumed += B * len(caps)
@@ -360,6 +377,7 @@ class C2Pipeline:
         capi, g = self.capi, self.geo
         cp = self.caps[ci]
         B, n_out, N, decim = g["B"], g["n_out"], g["N"], g["decim"]
+        EXTRA = self.extra
         st_dev = cp.rx.snapshot()
         y = self.ctx.download(cp.dec[self.snap[1]], np.complex64, n_out + EXTRA)
         sym = self.ctx.download(cp.d_sym, capi.SOFTSYM, cp.last_produced)
@@ -396,8 +414,8 @@ class C2Pipeline:
         st = po.RxState()
         for k, _ in st._fields_:
             setattr(st, k, getattr(st_dev, k))
-        p = po.rx_params(sampler=1, cstln=1, omega=float(FS / decim / FM), meas_decimation=int(FS / decim))
-        ref = O.rx(p, y_ref, state_in=st)
+        p = po.rx_params(cstln=1, omega=float(FS / decim / FM), meas_decimation=int(FS / decim), **self.oracle_rx_kw)
+        ref = O.rx(p, y_ref[:n_out + self.rx_extra], state_in=st)
         rep = check_tiled(sym, ref["sym"], cp.rx.tiled_stats(), first_exact=self.tile[1] // 4 - 8)   # tile 0 (exact) is one warm-up long
         rep.update(fir_extra)
         rep.update(capture=ci, fir_outputs=int(len(y)), fir_bit_exact=bool(fir_ok), fir_buffers_checked=len(cp.dec),
@@ -414,6 +432,7 @@ class C2Pipeline:
         soft symbols out — the decimated stream between the two kernels is not algorithmic traffic) over the mean launch
         duration (HIP events on the filter's stream).  kernel_bytes = what this kernel itself must move (cf32 in + cf32/D out)."""
         g = self.geo
+        EXTRA = self.extra
         n_launch_out = (g["n_out"] + EXTRA) * len(self.caps)
         kernel_bytes = n_launch_out * g["decim"] * 8 + n_launch_out * 8          # cf32 in + cf32 out
         alg_bytes = int(g["B"] * len(self.caps) * ALG_BYTES_PER_SAMPLE_C2)

@@ -131,6 +131,82 @@ def c2_variant(capi, synth, device, args, arith, note, n_caps=None):
     return out
 
 
+def c2_rrc(capi, synth, device, args):
+    """Config 2 with the polyphase fractional resampler north_star names: leandvb --sampler rrc = fir_sampler on a root-raised-cosine
+    of 16 steps per sample and 167 taps (sdr.h:635-689, leandvb.cc:440-458) in place of the linear interpolator; tiled, every capture
+    verified against the oracle's exact fir_filter -> exact serial receiver with the same sampler under TOL."""
+    import bench
+    tile = (int(os.environ.get("LSDR_RRC_TILE", args.tile_len)), int(os.environ.get("LSDR_RRC_WARMUP", max(args.tile_warmup, 512))))
+    pipe = bench.C2Pipeline(capi, synth, device, args.captures, args.batch_msamples, args.period_msamples, tile, seed0=61,
+                            fir_arith=headline_arith(capi, args), sampler="rrc")
+    t0 = time.perf_counter()
+    pipe.run(16, False)
+    pipe.sync()
+    nb = batches_for((time.perf_counter() - t0) / 16)
+    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True, snapshot_last=not args.no_verify), pipe.sync)
+    nb *= calls
+    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=len(pipe.caps), batches=nb,
+               sampler=dict(kind="fir_sampler (RRC)", rx_tile=dict(tile_len=tile[0], warmup=tile[1]), **pipe.rrc), roofline=pipe.roofline())
+    if not args.no_verify:
+        out["verified"] = pipe.verify_last_batch()
+        out["pass"] = out["verified"]["pass"]
+    pipe.close()
+    return out
+
+
+def c2_cnr(capi, synth, device, args):
+    """Config 2 with the two FFT blocks leandvb wires onto the preprocessed stream at a 1 Hz cadence: cnr_fft (carrier-to-noise
+    estimate, sdr.h:1273-1345, leandvb.cc:322-329) and spectrum (always in the graph, sdr.h:1347-1404, leandvb.cc:335-343) on capture
+    0's decimated stream.  Their outputs are compared with the oracle's blocks run over the same decimated stream (the stream is
+    B-periodic, so the last batch's buffer, downloaded, IS every batch) bit for bit."""
+    import bench
+    st = dict(cnr=[], spec=[], fed=0)
+    ctx_m = capi.Ctx(device)
+    fs_dec = bench.FS / 30
+    dec1hz = int(fs_dec)                                          # decimation(Fs, 1), leandvb.cc:138-141 (after the resampler: Fs/decim)
+    cnr = capi.CnrFft(ctx_m, float(np.float32(bench.FM / fs_dec)), 4096, dec1hz, 0.1)
+    spec = capi.Spectrum(ctx_m, dec1hz, 0.5)
+
+    def hook(pipe, i, prod, done):
+        g = pipe.geo
+        ctx_m.wait_event(done)
+        vals, c1 = cnr.run_dev(pipe.caps[0].dec[i].ptr, g["n_out"], 0.0, 1.0 / g["decim"])
+        rows, c2 = spec.run_dev(pipe.caps[0].dec[i].ptr, g["n_out"])
+        assert c1 == g["n_out"] and c2 == g["n_out"]
+        st["cnr"].extend(vals.tolist()); st["spec"].extend(rows); st["fed"] += 1
+
+    pipe = bench.C2Pipeline(capi, synth, device, args.captures, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup),
+                            seed0=71, fir_arith=headline_arith(capi, args), batch_hook=hook)
+    t0 = time.perf_counter()
+    pipe.run(16, False)
+    pipe.sync()
+    nb = batches_for((time.perf_counter() - t0) / 16)
+    consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True, snapshot_last=not args.no_verify), pipe.sync)
+    nb *= calls
+    g = pipe.geo
+    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=len(pipe.caps), batches=nb,
+               blocks="cnr_fft(bandwidth Fm/Fs, 4096 points) + spectrum(1024 points, kavg 0.5) on capture 0, one transform each per second of signal "
+                      f"(every {dec1hz} decimated samples = {dec1hz / g['n_out']:.2f} batches)",
+               cnr_values=len(st["cnr"]), spectrum_rows=len(st["spec"]), cnr_db_last=st["cnr"][-1] if st["cnr"] else None, roofline=pipe.roofline())
+    if not args.no_verify:
+        out["verified"] = pipe.verify_last_batch()
+        po = bench._oracle()
+        O = po.Oracle()
+        y = pipe.ctx.download(pipe.caps[0].dec[pipe.snap[1]], np.complex64, g["n_out"])
+        stream = np.tile(y, st["fed"])
+        want_c = O.cnr_fft(stream, np.float32(bench.FM / fs_dec), 4096, dec1hz, 0.0, 1.0 / g["decim"])
+        want_s = O.spectrum(stream, dec1hz, 0.5)
+        got_c, got_s = np.array(st["cnr"], np.float32), np.array(st["spec"], np.float32).reshape(-1, 1024)
+        ok_c = len(got_c) == len(want_c) and len(got_c) > 0 and got_c.tobytes() == want_c.tobytes()
+        ok_s = got_s.shape == want_s.shape and len(got_s) > 0 and got_s.tobytes() == want_s.tobytes()
+        out["fft_blocks_checked"] = dict(cnr_values=int(len(want_c)), cnr_bit_exact=bool(ok_c), spectrum_rows=int(len(want_s)), spectrum_bit_exact=bool(ok_s),
+                                         checker="oracle lo_cnr_fft / lo_spectrum over the same decimated stream")
+        out["pass"] = bool(out["verified"]["pass"] and ok_c and ok_s)
+    pipe.close()
+    cnr.close(); spec.close(); ctx_m.close()
+    return out
+
+
 def c2_exact(capi, synth, device, args):
     return c2_variant(capi, synth, device, args, capi.FIR_EXACT,
                       "LSDR_FIR_EXACT: the reference's arithmetic (two roundings per tap, i ascending) on the vector ALUs, k_fir_persist — "
@@ -995,7 +1071,8 @@ def end_to_end(capi, synth, device, args):
 
 def run_all(capi, synth, device, args):
     more = {}
-    for name, fn in (("single_stream", single_stream), ("c2_exact", c2_exact), ("c2_fma", c2_fma), ("c2_mfma", c2_mfma), ("anf1", anf1),
+    for name, fn in (("single_stream", single_stream), ("c2_exact", c2_exact), ("c2_fma", c2_fma), ("c2_mfma", c2_mfma), ("c2_rrc", c2_rrc),
+                     ("c2_cnr", c2_cnr), ("anf1", anf1),
                      ("c2_offset", c2_offset), ("c3", c3),
                      ("c5_rescoped", c5_rescoped), ("c1", c1), ("c1_hs", c1_hs_entry), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
         t0 = time.perf_counter()

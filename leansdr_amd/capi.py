@@ -1052,6 +1052,12 @@ class Spectrum:
         din.free()
         return out[:prod.value].copy(), cons.value
 
+    def run_dev(self, in_ptr, n_in):
+        out = np.empty((n_in // 1024 // 64 + 4, 1024), np.float32)
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_spectrum_run(self.h, in_ptr, n_in, _np(out), len(out), C.byref(cons), C.byref(prod)))
+        return out[:prod.value].copy(), cons.value
+
 
 class CnrFft:
     """cnr_fft<f32> (sdr.h:1273-1345)."""
@@ -1075,6 +1081,13 @@ class CnrFft:
         cons, prod = c_sz(), c_sz()
         check(lib.lsdr_cnr_fft_run(self.h, freq_tap, tap_multiplier, din.ptr, len(x), _np(out), len(out), C.byref(cons), C.byref(prod)))
         din.free()
+        return out[:prod.value].copy(), cons.value
+
+    def run_dev(self, in_ptr, n_in, freq_tap=0.0, tap_multiplier=1.0):
+        """One run() over a device buffer: (CNR values appended by this call, samples consumed)."""
+        out = np.empty(n_in // 64 + 8, np.float32)
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_cnr_fft_run(self.h, freq_tap, tap_multiplier, in_ptr, n_in, _np(out), len(out), C.byref(cons), C.byref(prod)))
         return out[:prod.value].copy(), cons.value
 
 
