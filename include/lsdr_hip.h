@@ -157,6 +157,11 @@ int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *b
 /* Measurement hook (bench_more.py's roofline of the scan kernel): HIP events on the block's stream around the k_notch_scan
  * launch of every LSDR_NOTCH_SCAN run while enabled.  Each call returns the mean over the (up to 16 most recent) launches
  * recorded since the previous call — after waiting for the stream — and then sets the switch. */
+/* LSDR_NOTCH_SCAN's cross-workgroup look-back spins are bounded: *aborted_run = 0 while all were served, else the number of the
+ * first run in which one gave up (the next lsdr_auto_notch_run then fails instead of continuing from garbage) */
+int lsdr_auto_notch_check(lsdr_auto_notch *n, unsigned *aborted_run);
+/* test hook: garbage into the scan mode's hand-off buffers (totals and flags); a correct hand-off never reads it */
+int lsdr_auto_notch_debug_poison(lsdr_auto_notch *n);
 int lsdr_auto_notch_scan_time(lsdr_auto_notch *a, int enable, float *avg_ms, unsigned *launches);
 /* run(), sdr.h:64-75: whole 4096-sample blocks; *consumed == *produced.  Synchronous. */
 int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,

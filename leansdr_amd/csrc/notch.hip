@@ -291,6 +291,7 @@ struct notch_scan_args {
   float2 *totals;                  // [kMaxSlots][4·n_blocks] zero-carry wave-block totals
   unsigned *flags;                 // [kMaxSlots][4·n_blocks] run stamps
   unsigned stamp;
+  unsigned *abort_flag;            // pinned host word: set when a look-back wait gave up (see k_notch_scan)
   notch_scan_consts C;
 };
 
@@ -311,8 +312,15 @@ __device__ __forceinline__ void scan_publish(float2 *tot_slot, unsigned *flag_sl
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __hip_atomic_store(flag_slot, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ float2 scan_wait(const float2 *tot_slot, const unsigned *flag_slot, unsigned stamp) {
-  while (__hip_atomic_load(flag_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) __builtin_amdgcn_s_sleep(1);
+__device__ __forceinline__ float2 scan_wait(const float2 *tot_slot, const unsigned *flag_slot, unsigned stamp, unsigned *abort_flag) {
+  unsigned spins = 0;
+  while (__hip_atomic_load(flag_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
+    __builtin_amdgcn_s_sleep(1);
+    if (++spins > (1u << 21)) {      // ≈ 0.1 s: the predecessor is not coming (dispatch order?) — give up loudly
+      __hip_atomic_store(abort_flag, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      break;
+    }
+  }
   __atomic_signal_fence(__ATOMIC_SEQ_CST);
   const unsigned long long bits = __hip_atomic_load(reinterpret_cast<const unsigned long long *>(tot_slot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   float2 v;
@@ -354,7 +362,17 @@ template <int NS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 4 : 2))) void k_notch_scan(notch_scan_args a) {
   __shared__ __attribute__((aligned(16))) char lds[64 * kLaneStride];
   const unsigned lane = threadIdx.x;
+  // Wave-block = blockIdx: a wave-block spins on its twelve predecessors' totals, and those belong to LOWER block indices, which
+  // gfx942 / gfx950 start first (observed; promised nowhere).  Two dispatch-order-independent forms were built and measured on
+  // the anf1 pipeline (k_notch_scan 0.22 ms per 64 Mi samples as written here): a ticket per workgroup — 65 536 agent-scope
+  // atomics on one address per launch — 0.83 ms; persistent workgroups that take one ticket each and walk wave-blocks
+  // t, t + grid, … 0.58 – 1.1 ms (4 – 16 workgroups per CU).  So the order stays an ASSUMPTION, and it is made safe instead of
+  // fast-and-hopeful: every spin is bounded (scan_wait gives up after ≈ 0.1 s), a wave-block that gave up raises the run's abort
+  // word in pinned memory, and the host refuses to go on (lsdr_auto_notch_run returns an error at the next call or at
+  // lsdr_auto_notch_check) — no hang, no silently wrong output.  tests/test_gpu_notch.py poisons the hand-off buffers before each
+  // of 1000 runs and demands bit-identical output.
   const unsigned long long wb = blockIdx.x, n_wb = a.n_blocks * kWavesPerBlock;
+  {
   const unsigned long long b = wb / kWavesPerBlock;
   const unsigned part = (unsigned)(wb % kWavesPerBlock);
   // interval of this block (few intervals: linear search, wave-uniform)
@@ -407,7 +425,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 4 
     if (lane < (unsigned)kLookBack) {
       const long long pb = (long long)wb - 1 - (long long)lane;
       if (pb >= 0 && pb >= restart) {
-        const float2 pt = scan_wait(tslot + pb, fslot + pb, a.stamp);
+        const float2 pt = scan_wait(tslot + pb, fslot + pb, a.stamp, a.abort_flag);
         v = make_float2(wl * pt.x, wl * pt.y);
       } else if (pb == -1 && restart < 0) {
         v = make_float2(wl * a.carry->re[s], wl * a.carry->im[s]);
@@ -443,6 +461,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(NS == 1 ? 4 
   for (int i = 0; i < kScanPer / 2; ++i) {
     const unsigned n = (unsigned)i * 128u + lane * 2u;
     *reinterpret_cast<float4 *>(pout + n) = *reinterpret_cast<const float4 *>(lds + lds_off(n));
+  }
   }
 }
 
@@ -578,6 +597,7 @@ struct lsdr_auto_notch {
   size_t det_cap;                             // detect points the scratch above is sized for
   float2 *d_tables; size_t tables_cap;        // [(ndet+1)·nslots·4096]
   float2 *d_totals; unsigned *d_flags; size_t blocks_cap;
+  unsigned *h_abort, *d_abort;               // pinned word (host / device view): a look-back wait of k_notch_scan gave up
   // optional timing of the scan kernel alone (lsdr_auto_notch_scan_time): a ring of event pairs around its launches
   static const int kTimed = 16;
   bool timing;
@@ -854,6 +874,16 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
   sa.n_intervals = (int)ifirst.size(); sa.nslots = ns; sa.n_blocks = nb;
   sa.carry = a->d_scarry[cur];       // read by every block's look-back …
   sa.totals = a->d_totals; sa.flags = a->d_flags; sa.stamp = ++a->stamp;
+  if (!a->h_abort) {
+    LSDR_HIP(hipHostMalloc((void **)&a->h_abort, sizeof(unsigned), hipHostMallocMapped));
+    *a->h_abort = 0;
+    LSDR_HIP(hipHostGetDevicePointer((void **)&a->d_abort, a->h_abort, 0));
+  }
+  if (*a->h_abort) {     // an earlier run's look-back gave up: its output (and everything after it) is not to be trusted
+    lsdr_set_error("auto_notch(scan): a wave-block's look-back timed out in run %u (workgroups not started in index order?) — use LSDR_NOTCH_EXACT", *a->h_abort);
+    return LSDR_E_UNSUPPORTED;
+  }
+  sa.abort_flag = a->d_abort;
   {
     const double av = 1.0 - (double)a->k;
     sa.C.k = a->k; sa.C.omk = 1 - a->k; sa.C.gain = a->gain;
@@ -930,7 +960,7 @@ int lsdr_auto_notch_create(lsdr_ctx *c, int nslots, float setpoint, lsdr_auto_no
   for (int i = 0; i < 2; ++i) { a->h_ifirst[i] = nullptr; a->h_offsets[i] = nullptr; a->h_cap[i] = 0; a->h_ev[i] = nullptr; }
   a->h_slot = 0;
   a->timing = false; a->timed_runs = 0; for (auto &pr : a->tev) pr[0] = pr[1] = nullptr;
-  a->det_cap = 0; a->d_tables = nullptr; a->tables_cap = 0; a->d_totals = nullptr; a->d_flags = nullptr; a->blocks_cap = 0; a->stamp = 0;
+  a->det_cap = 0; a->d_tables = nullptr; a->tables_cap = 0; a->d_totals = nullptr; a->d_flags = nullptr; a->blocks_cap = 0; a->stamp = 0; a->h_abort = nullptr; a->d_abort = nullptr;
   *out = a;
   return LSDR_OK;
 }
@@ -951,6 +981,7 @@ void lsdr_auto_notch_destroy(lsdr_auto_notch *a) {
   (void)hipFree(a->d_scarry[0]); (void)hipFree(a->d_scarry[1]); (void)hipFree(a->d_bins); (void)hipFree(a->d_offsets); (void)hipFree(a->d_spec);
   (void)hipFree(a->d_cand); (void)hipFree(a->d_ibins); (void)hipFree(a->d_reset); (void)hipFree(a->d_ifirst); (void)hipFree(a->d_tables);
   (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
+  if (a->h_abort) (void)hipHostFree(a->h_abort);
   for (auto &pr : a->tev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
   for (int i = 0; i < 2; ++i) {
     if (a->h_ifirst[i]) (void)hipHostFree(a->h_ifirst[i]);
@@ -971,6 +1002,26 @@ int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot) {
   if (a->mode == LSDR_NOTCH_SCAN) (void)notch_scan_pull(const_cast<lsdr_auto_notch *>(a));
   return a->bins[slot];
 }
+// Test hook (tests/test_gpu_notch.py stress test): fill the scan mode's hand-off buffers — every wave-block total and every flag —
+// with garbage, as a stale or torn hand-off would leave them.  A correct protocol never reads a total whose flag does not carry
+// the CURRENT run's stamp, so the next run's output must not change by a bit.
+int lsdr_auto_notch_debug_poison(lsdr_auto_notch *a) {
+  LSDR_ARG(a);
+  if (!a->d_totals || !a->blocks_cap) return LSDR_OK;
+  const size_t n = (size_t)kMaxSlots * a->blocks_cap * kWavesPerBlock;
+  LSDR_HIP(hipMemsetAsync(a->d_totals, 0x7f, n * sizeof(float2), a->ctx->stream));     // 3.39e38: one of these in a carry-in is no rounding error
+  LSDR_HIP(hipMemsetAsync(a->d_flags, 0xee, n * sizeof(unsigned), a->ctx->stream));     // no stamp this side of 4·10^9 runs
+  return LSDR_OK;
+}
+
+// 0 while every look-back of every queued run so far has been served; the stamp of the first run whose did not otherwise
+// (meaningful after the runs have executed: synchronise the context first)
+int lsdr_auto_notch_check(lsdr_auto_notch *a, unsigned *aborted_run) {
+  LSDR_ARG(a && aborted_run);
+  *aborted_run = a->h_abort ? *a->h_abort : 0u;
+  return LSDR_OK;
+}
+
 int lsdr_auto_notch_scan_time(lsdr_auto_notch *a, int enable, float *avg_ms, unsigned *launches) {
   LSDR_ARG(a);
   if (avg_ms) *avg_ms = 0.f;
