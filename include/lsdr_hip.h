@@ -157,6 +157,10 @@ int lsdr_auto_notch_stats(const lsdr_auto_notch *a, unsigned *tiles, unsigned *b
 /* Measurement hook (bench_more.py's roofline of the scan kernel): HIP events on the block's stream around the k_notch_scan
  * launch of every LSDR_NOTCH_SCAN run while enabled.  Each call returns the mean over the (up to 16 most recent) launches
  * recorded since the previous call — after waiting for the stream — and then sets the switch. */
+/* LSDR_NOTCH_SCAN, opt-in: a run's detect chain (FFTs of the detect points of its INPUT -> peaks -> phasor tables) on a side stream,
+ * overlapping the previous run's scan kernel.  The caller promises that an input buffer is complete when lsdr_auto_notch_run is
+ * called with it (the side stream does not wait for earlier work queued on the context).  Same results. */
+int lsdr_auto_notch_set_overlap(lsdr_auto_notch *n, int on);
 /* LSDR_NOTCH_SCAN's cross-workgroup look-back spins are bounded: *aborted_run = 0 while all were served, else the number of the
  * first run in which one gave up (the next lsdr_auto_notch_run then fails instead of continuing from garbage) */
 int lsdr_auto_notch_check(lsdr_auto_notch *n, unsigned *aborted_run);

@@ -103,6 +103,7 @@ _sig("lsdr_auto_notch_set_mode", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_scan_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_debug_poison", C.c_int, [vp])
+_sig("lsdr_auto_notch_set_overlap", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_check", C.c_int, [vp, C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])

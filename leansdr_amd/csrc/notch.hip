@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64) void k_notch_args(notch_run_args r, int *d_ifir
   const int t = threadIdx.x;
   for (int i = t; i < r.n_ifirst; i += 64) d_ifirst[i] = r.ifirst[i];
   for (int i = t; i < r.ndet; i += 64) d_offsets[i] = r.offs[i];
-  if (t == 0) *carry_next = *carry_cur;
+  if (t == 0 && carry_cur) *carry_next = *carry_cur;
 }
 
 // peak search of detect() (sdr.h:94-117) on one spectrum per workgroup: amplitudes by hypotf, nslots rounds of
@@ -598,6 +598,9 @@ struct lsdr_auto_notch {
   float2 *d_tables; size_t tables_cap;        // [(ndet+1)·nslots·4096]
   float2 *d_totals; unsigned *d_flags; size_t blocks_cap;
   unsigned *h_abort, *d_abort;               // pinned word (host / device view): a look-back wait of k_notch_scan gave up
+  // lsdr_auto_notch_set_overlap: the detect chain of run k+1 (FFTs → peaks → tables: it depends on the INPUT and on the bins of
+  // chain k only) on a side stream, next to k_notch_scan of run k; two sets of the chain's buffers, used alternately
+  bool overlap; hipStream_t side; hipEvent_t ev_chain[2], ev_scan[2]; unsigned run_no;
   // optional timing of the scan kernel alone (lsdr_auto_notch_scan_time): a ring of event pairs around its launches
   static const int kTimed = 16;
   bool timing;
@@ -801,24 +804,46 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
   a->phase = phase;
   const size_t ndet = offs.size();
   const int ns = a->nslots;
-  if (a->det_cap < ndet + 1) {
+  if (a->overlap && !a->side) {
+    LSDR_HIP(hipStreamCreateWithFlags(&a->side, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      LSDR_HIP(hipEventCreateWithFlags(&a->ev_chain[i], hipEventDisableTiming));
+      LSDR_HIP(hipEventCreateWithFlags(&a->ev_scan[i], hipEventDisableTiming));
+    }
+  }
+  auto sync_all = [&]() -> int {
     LSDR_HIP(hipStreamSynchronize(c->stream));
+    if (a->side) LSDR_HIP(hipStreamSynchronize(a->side));
+    return LSDR_OK;
+  };
+  if (a->det_cap < ndet + 1) {     // (two sets of everything the detect chain writes: [set 0 | set 1])
+    LSDR_TRY(sync_all());
     (void)hipFree(a->d_offsets); (void)hipFree(a->d_spec); (void)hipFree(a->d_cand); (void)hipFree(a->d_ibins); (void)hipFree(a->d_reset); (void)hipFree(a->d_ifirst);
     const size_t cap = ndet + 8;
-    LSDR_HIP(hipMalloc((void **)&a->d_offsets, cap * sizeof(unsigned long long)));
-    LSDR_HIP(hipMalloc((void **)&a->d_spec, cap * kN * sizeof(float2)));
-    LSDR_HIP(hipMalloc((void **)&a->d_cand, cap * kMaxSlots * sizeof(int)));
-    LSDR_HIP(hipMalloc((void **)&a->d_ibins, (cap + 1) * kMaxSlots * sizeof(int)));
-    LSDR_HIP(hipMalloc((void **)&a->d_reset, (cap + 1) * kMaxSlots));
-    LSDR_HIP(hipMalloc((void **)&a->d_ifirst, (cap + 1) * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&a->d_offsets, 2 * cap * sizeof(unsigned long long)));
+    LSDR_HIP(hipMalloc((void **)&a->d_spec, 2 * cap * kN * sizeof(float2)));
+    LSDR_HIP(hipMalloc((void **)&a->d_cand, 2 * cap * kMaxSlots * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&a->d_ibins, 2 * (cap + 1) * kMaxSlots * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&a->d_reset, 2 * (cap + 1) * kMaxSlots));
+    LSDR_HIP(hipMalloc((void **)&a->d_ifirst, 2 * (cap + 1) * sizeof(int)));
     a->det_cap = cap;
   }
   if (a->tables_cap < (ndet + 1) * (size_t)ns * kN) {
-    LSDR_HIP(hipStreamSynchronize(c->stream));
+    LSDR_TRY(sync_all());
     (void)hipFree(a->d_tables);
     a->tables_cap = (ndet + 8) * (size_t)ns * kN;
-    LSDR_HIP(hipMalloc((void **)&a->d_tables, a->tables_cap * sizeof(float2)));
+    LSDR_HIP(hipMalloc((void **)&a->d_tables, 2 * a->tables_cap * sizeof(float2)));
   }
+  const unsigned par = a->overlap ? (a->run_no & 1u) : 0u;
+  ++a->run_no;
+  unsigned long long *const p_offsets = a->d_offsets + par * a->det_cap;
+  float2 *const p_spec = a->d_spec + (size_t)par * a->det_cap * kN;
+  int *const p_cand = a->d_cand + (size_t)par * a->det_cap * kMaxSlots;
+  unsigned char *const p_reset = a->d_reset + (size_t)par * (a->det_cap + 1) * kMaxSlots;
+  int *const p_ifirst = a->d_ifirst + (size_t)par * (a->det_cap + 1);
+  float2 *const p_tables = a->d_tables + (size_t)par * a->tables_cap;
+  hipStream_t cs = a->overlap ? a->side : c->stream;                 // the detect chain's stream
+  if (a->overlap && a->run_no > 2) LSDR_HIP(hipStreamWaitEvent(cs, a->ev_scan[par], 0));   // the scan two runs ago read this set
   if (a->blocks_cap < nb) {
     LSDR_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
@@ -836,8 +861,10 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     ra.n_ifirst = (int)ifirst.size(); ra.ndet = (int)ndet;
     for (size_t i = 0; i < ifirst.size(); ++i) ra.ifirst[i] = ifirst[i];
     for (size_t i = 0; i < ndet; ++i) ra.offs[i] = offs[i];
-    hipLaunchKernelGGL(k_notch_args, dim3(1), dim3(64), 0, c->stream, ra, a->d_ifirst, a->d_offsets, (const notch_est *)a->d_scarry[cur],
-                       a->d_scarry[nxt]);
+    hipLaunchKernelGGL(k_notch_args, dim3(1), dim3(64), 0, cs, ra, p_ifirst, p_offsets,
+                       a->overlap ? (const notch_est *)nullptr : (const notch_est *)a->d_scarry[cur], a->d_scarry[nxt]);
+    // (overlapped: the estimators' hand-over copy reads what the PREVIOUS scan's last wave-block writes — main stream, below)
+    if (a->overlap) LSDR_HIP(hipMemcpyAsync(a->d_scarry[nxt], a->d_scarry[cur], sizeof(notch_est), hipMemcpyDeviceToDevice, c->stream));
   } else {
     // (a run with more detect points than fit the argument segment: pinned slot → device, in stream order)
     const int hs = a->h_slot;
@@ -853,24 +880,28 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
     }
     memcpy(a->h_ifirst[hs], ifirst.data(), ifirst.size() * sizeof(int));
     memcpy(a->h_offsets[hs], offs.data(), ndet * sizeof(unsigned long long));
-    LSDR_HIP(hipMemcpyAsync(a->d_ifirst, a->h_ifirst[hs], ifirst.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    LSDR_HIP(hipMemcpyAsync(a->d_offsets, a->h_offsets[hs], ndet * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    LSDR_HIP(hipEventRecord(a->h_ev[hs], c->stream));
+    LSDR_HIP(hipMemcpyAsync(p_ifirst, a->h_ifirst[hs], ifirst.size() * sizeof(int), hipMemcpyHostToDevice, cs));
+    LSDR_HIP(hipMemcpyAsync(p_offsets, a->h_offsets[hs], ndet * sizeof(unsigned long long), hipMemcpyHostToDevice, cs));
+    LSDR_HIP(hipEventRecord(a->h_ev[hs], cs));
     LSDR_HIP(hipMemcpyAsync(a->d_scarry[nxt], a->d_scarry[cur], sizeof(notch_est), hipMemcpyDeviceToDevice, c->stream));
   }
   if (ndet) {
     int rc = cfft_dev_init(&a->fft, kN, true);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_cfft_half, dim3((unsigned)(2 * ndet)), dim3(256), 0, c->stream, (const float2 *)in, (const float2 *)a->fft.d_om, a->d_spec,
-                       (const unsigned long long *)a->d_offsets);
-    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)ndet), dim3(256), 0, c->stream, (const float2 *)a->d_spec, (const float2 *)a->fft.d_om,
-                       (float)(1.0 / kN), ns, a->d_cand);
+    hipLaunchKernelGGL(k_cfft_half, dim3((unsigned)(2 * ndet)), dim3(256), 0, cs, (const float2 *)in, (const float2 *)a->fft.d_om, p_spec,
+                       (const unsigned long long *)p_offsets);
+    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)ndet), dim3(256), 0, cs, (const float2 *)p_spec, (const float2 *)a->fft.d_om,
+                       (float)(1.0 / kN), ns, p_cand);
   }
-  hipLaunchKernelGGL(k_notch_tables, dim3((unsigned)((ndet + 1) * ns)), dim3(256), 0, c->stream, (const int *)a->d_cand, (int)ndet, ns,
-                     (const int *)(a->d_bins + cur * kMaxSlots), a->d_bins + nxt * kMaxSlots, a->d_reset, a->d_tables);
+  hipLaunchKernelGGL(k_notch_tables, dim3((unsigned)((ndet + 1) * ns)), dim3(256), 0, cs, (const int *)p_cand, (int)ndet, ns,
+                     (const int *)(a->d_bins + cur * kMaxSlots), a->d_bins + nxt * kMaxSlots, p_reset, p_tables);
   LSDR_HIP(hipGetLastError());
+  if (a->overlap) {                     // the scan of this run waits for its chain; the chain did not wait for the previous scan
+    LSDR_HIP(hipEventRecord(a->ev_chain[par], cs));
+    LSDR_HIP(hipStreamWaitEvent(c->stream, a->ev_chain[par], 0));
+  }
   notch_scan_args sa;
-  sa.in = (const float2 *)in; sa.out = (float2 *)out; sa.tables = a->d_tables; sa.interval_first = a->d_ifirst; sa.reset = a->d_reset;
+  sa.in = (const float2 *)in; sa.out = (float2 *)out; sa.tables = p_tables; sa.interval_first = p_ifirst; sa.reset = p_reset;
   sa.n_intervals = (int)ifirst.size(); sa.nslots = ns; sa.n_blocks = nb;
   sa.carry = a->d_scarry[cur];       // read by every block's look-back …
   sa.totals = a->d_totals; sa.flags = a->d_flags; sa.stamp = ++a->stamp;
@@ -908,6 +939,7 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
   }
   LSDR_HIP(hipGetLastError());
   if (tp) { LSDR_HIP(hipEventRecord(tp[1], c->stream)); ++a->timed_runs; }
+  if (a->overlap) LSDR_HIP(hipEventRecord(a->ev_scan[par], c->stream));
   a->scarry_cur = nxt;
   return LSDR_OK;
 }
@@ -915,6 +947,7 @@ static int notch_run_scan(lsdr_auto_notch *a, const lsdr_cf32 *in, lsdr_cf32 *ou
 // refresh the host mirrors (bins, estimators) of a scan-mode notch
 static int notch_scan_pull(lsdr_auto_notch *a) {
   if (!a->scan_started) return LSDR_OK;
+  if (a->side) LSDR_HIP(hipStreamSynchronize(a->side));
   LSDR_HIP(hipMemcpyAsync(a->bins, a->d_bins + a->scarry_cur * kMaxSlots, kMaxSlots * sizeof(int), hipMemcpyDeviceToHost, a->ctx->stream));
   LSDR_HIP(hipMemcpyAsync(&a->est, a->d_scarry[a->scarry_cur], sizeof(notch_est), hipMemcpyDeviceToHost, a->ctx->stream));
   LSDR_HIP(hipStreamSynchronize(a->ctx->stream));
@@ -961,6 +994,7 @@ int lsdr_auto_notch_create(lsdr_ctx *c, int nslots, float setpoint, lsdr_auto_no
   a->h_slot = 0;
   a->timing = false; a->timed_runs = 0; for (auto &pr : a->tev) pr[0] = pr[1] = nullptr;
   a->det_cap = 0; a->d_tables = nullptr; a->tables_cap = 0; a->d_totals = nullptr; a->d_flags = nullptr; a->blocks_cap = 0; a->stamp = 0; a->h_abort = nullptr; a->d_abort = nullptr;
+  a->overlap = false; a->side = nullptr; a->ev_chain[0] = a->ev_chain[1] = a->ev_scan[0] = a->ev_scan[1] = nullptr; a->run_no = 0;
   *out = a;
   return LSDR_OK;
 }
@@ -982,6 +1016,11 @@ void lsdr_auto_notch_destroy(lsdr_auto_notch *a) {
   (void)hipFree(a->d_cand); (void)hipFree(a->d_ibins); (void)hipFree(a->d_reset); (void)hipFree(a->d_ifirst); (void)hipFree(a->d_tables);
   (void)hipFree(a->d_totals); (void)hipFree(a->d_flags);
   if (a->h_abort) (void)hipHostFree(a->h_abort);
+  if (a->side) {
+    (void)hipStreamSynchronize(a->side);
+    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(a->ev_chain[i]); (void)hipEventDestroy(a->ev_scan[i]); }
+    (void)hipStreamDestroy(a->side);
+  }
   for (auto &pr : a->tev) { if (pr[0]) (void)hipEventDestroy(pr[0]); if (pr[1]) (void)hipEventDestroy(pr[1]); }
   for (int i = 0; i < 2; ++i) {
     if (a->h_ifirst[i]) (void)hipHostFree(a->h_ifirst[i]);
@@ -1011,6 +1050,20 @@ int lsdr_auto_notch_debug_poison(lsdr_auto_notch *a) {
   const size_t n = (size_t)kMaxSlots * a->blocks_cap * kWavesPerBlock;
   LSDR_HIP(hipMemsetAsync(a->d_totals, 0x7f, n * sizeof(float2), a->ctx->stream));     // 3.39e38: one of these in a carry-in is no rounding error
   LSDR_HIP(hipMemsetAsync(a->d_flags, 0xee, n * sizeof(unsigned), a->ctx->stream));     // no stamp this side of 4·10^9 runs
+  return LSDR_OK;
+}
+
+// Opt-in: the detect chain of a run (it reads the run's INPUT) goes to a side stream, where it overlaps the previous run's
+// k_notch_scan.  The side stream does not wait for earlier work on the context's stream, so the caller promises that an input
+// buffer is complete when lsdr_auto_notch_run is called with it (a resident capture; a buffer whose producer has been waited for).
+int lsdr_auto_notch_set_overlap(lsdr_auto_notch *a, int on) {
+  LSDR_ARG(a);
+  if (a->scan_started) {
+    LSDR_HIP(hipStreamSynchronize(a->ctx->stream));
+    if (a->side) LSDR_HIP(hipStreamSynchronize(a->side));
+  }
+  a->overlap = on != 0;
+  a->run_no = 0;
   return LSDR_OK;
 }
 

@@ -233,3 +233,25 @@ def test_scan_hand_off_never_reads_a_stale_total(capi, ctx, nslots):
         a.close()
     assert runs == 1000
     d_in.free(); d_out.free()
+
+
+@pytest.mark.gpu
+def test_scan_overlapped_detect_chain_gives_the_same_output(capi, ctx):
+    """lsdr_auto_notch_set_overlap: the detect chain of run k+1 on a side stream next to the scan of run k — bit-identical output
+    and bins over eight queued runs with a detect point in each (two buffer sets used alternately, bins carried from chain to chain)."""
+    rng = np.random.default_rng(31)
+    n = 4096 * 40
+    t = np.arange(8 * n)
+    x = ((rng.standard_normal(8 * n) + 1j * rng.standard_normal(8 * n)) * 12 + 70 * np.exp(2j * np.pi * (0.0713 + 1e-8 * t) * t)).astype(np.complex64)
+    d_in = ctx.upload(x)
+    outs = {}
+    for ov in (0, 1):
+        a = capi.AutoNotch(ctx, 2, 0.0, 4096 * 16, mode=capi.NOTCH_SCAN)
+        capi.check(capi.lib.lsdr_auto_notch_set_overlap(a.h, ov))
+        d_out = ctx.alloc(8 * n * 8)
+        for k in range(8):
+            a.run_dev(d_in.at(k * n * 8), n, d_out.at(k * n * 8), n)
+        outs[ov] = (ctx.download(d_out, np.complex64, 8 * n).copy(), a.bins())
+        a.close(); d_out.free()
+    assert outs[0][1] == outs[1][1] and np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64))
+    d_in.free()
