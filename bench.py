@@ -144,7 +144,7 @@ def pmc_traffic(batch_samples):
     profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE corrected ×2 for gfx950 as the
     microarch guide prescribes).  Counters cannot be read from inside a normal run; None when the launch size differs
     from the profiled one."""
-    for d in ("r03_bench", "r02_bench", "r01_bench"):
+    for d in ("r04_bench", "r03_bench", "r02_bench", "r01_bench"):
         try:
             with open(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")) as f:
                 j = json.load(f)
@@ -439,7 +439,7 @@ class C2Pipeline:
         ms = float(np.mean(self.fir_ms))
         achieved = alg_bytes / (ms * 1e-3) / 1e9
         traffic, src = pmc_traffic(g["B"] * len(self.caps))
-        kname = {self.capi.FIR_MFMA: "k_fir_mfma", self.capi.FIR_MFMA_BLK: "k_fir_mfma_blk" if self.fir.current_freq else "k_fir_mfma_stream"}.get(self.fir_arith, "k_fir_persist")
+        kname = {self.capi.FIR_MFMA: "k_fir_mfma", self.capi.FIR_MFMA_BLK: "k_fir_mfma_stream"}.get(self.fir_arith, "k_fir_persist")
         return {"kernel": kname + " (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "traffic_source": (f"recorded, not measured in this run: {src}" if src else None),

@@ -1055,10 +1055,29 @@ def end_to_end(capi, synth, device, args):
             run(nb)
             return nb
         nb, dt, _ = timed_at_least(once, ctx.sync)
-        out[fmt] = dict(value=round(nb * chunk / dt / 1e6, 3), unit="MS/s", bytes_per_sample=item, seconds=round(dt, 3), chunks=nb,
+        # what arrived and what came out of it, after the clock stopped: the last upload's device buffer byte for byte against the host
+        # data, the filter's output of the last chunk bit for bit against the oracle (a 200 000-output head), the receiver's seams
+        ver = None
+        if not args.no_verify:
+            po = bench._oracle()
+            O = po.Oracle()
+            last = (nb - 1) & 1
+            got_in = ctx.download(d_in[last], np.uint8, nbytes)
+            in_ok = bool(got_in.tobytes() == host.view(np.uint8).reshape(-1)[:nbytes].tobytes())
+            nchk = min(200000, n_out)
+            y = ctx.download(d_dec, np.complex64, nchk)
+            head = host[: nchk * decim + N]
+            xin = O.scaler(75.0, head) if fmt == "cf32" else O.cconverter_u8(head.reshape(-1))
+            y_ref = O.fir_filter(coeffs, decim, xin)[0][:nchk]
+            fir_ok = bool(len(y_ref) == nchk and y_ref.tobytes() == y.tobytes())
+            stt = rx.tiled_stats()
+            ver = dict(uploaded_bytes_identical=in_ok, fir_outputs_checked=int(nchk), fir_bit_exact=fir_ok, rx_tiles=stt["tiles"], rx_bad_seams=stt["bad_seams"],
+                       **{"pass": bool(in_ok and fir_ok and stt["tiles"] > 0 and stt["bad_seams"] == 0)})
+        out[fmt] = dict(value=round(nb * chunk / dt / 1e6, 3), unit="MS/s", bytes_per_sample=item, seconds=round(dt, 3), chunks=nb, verified=ver,
                         roofline={"bound": "pcie", "peak": 63.0, "unit": "GB/s", "achieved": round(nb * chunk * item / dt / 1e9, 2),
                                   "frac": round(nb * chunk * item / dt / 1e9 / 63.0, 4), "hbm_frac": hbm_frac(nb * chunk / dt, item + 4.0 / 120),
-                                  "note": "host-resident input: bounded by the PCIe Gen5 x16 link (63 GB/s spec), not by HBM"}, **{"pass": None},
+                                  "note": "host-resident input: bounded by the PCIe Gen5 x16 link (63 GB/s spec), not by HBM"},
+                        **{"pass": None if ver is None else ver["pass"]},
                         pcie_GBps=round(nb * chunk * item / dt / 1e9, 2), chunk_samples=chunk)
         rx.close(); fir.close()
         for p in pin:

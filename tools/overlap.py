@@ -9,7 +9,7 @@ for ln in open(sys.argv[1]):
     p = ln.rstrip("\n").split(",")
     rows.append((p[0], int(p[1]), int(p[2]), p[3] if len(p) > 3 else ""))
 rows.sort(key=lambda r: r[1])
-fir = [(s, e) for n, s, e, q in rows if "k_fir_persis" in n and e - s > 50000]
+fir = [(s, e) for n, s, e, q in rows if "k_fir" in n and e - s > 50000]
 if len(fir) > 40:
     fir = fir[len(fir) // 2:]          # the timed half
 t0, t1 = fir[0][0], fir[-1][1]
@@ -18,7 +18,7 @@ gaps = np.array([fir[i + 1][0] - fir[i][1] for i in range(len(fir) - 1)]) / 1e3
 print(f"fir launches {len(fir)}: mean {busy / len(fir) / 1e3:.1f} us, stream busy {busy / (t1 - t0):.3f}, gap mean {gaps.mean():.1f} us  p50 {np.median(gaps):.1f}  max {gaps.max():.1f}")
 names = {}
 for n, s, e, q in rows:
-    if s < t0 or e > t1 or "k_fir_persis" in n:
+    if s < t0 or e > t1 or "k_fir" in n:
         continue
     m = re.search(r"(k_\w+|__amd\w+)", n)
     key = m.group(1) if m else n[:28]
