@@ -228,7 +228,7 @@ class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1):
         self.capi = capi
         self.batch_hook = batch_hook          # called per batch after fir_filter was queued: hook(pipe, dec buffer index, outputs, done event)
         # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
@@ -268,9 +268,12 @@ class C2Pipeline:
         if rx_freq:   # what fir_filter::run does on its first call: the receiver's initial freq_tap moves the filter (dsp.h:236-244)
             self.fir.track(float(np.float32(rx_freq)), 1.0 / decim, float(np.float32(FM / FS * 0.1)))
         self.tile = tile
-        self.ctx_rx = capi.Ctx(device, cu_mask=rx_mask) if self.rx_multi else None
+        # receiver streams: the captures are dealt to `rx_groups` streams, each with shared launches (1: all on one stream)
+        self.rx_groups = max(1, min(int(os.environ.get("LSDR_BENCH_RX_GROUPS", rx_groups)), n_captures)) if self.rx_multi else 0
+        self.ctx_rxs = [capi.Ctx(device, cu_mask=rx_mask) for _ in range(self.rx_groups)]
+        self.ctx_rx = self.ctx_rxs[0] if self.ctx_rxs else None
         self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw,
-                             shared_rx_ctx=self.ctx_rx, extra=self.extra) for c in range(n_captures)]
+                             shared_rx_ctx=self.ctx_rxs[c % self.rx_groups] if self.rx_multi else None, extra=self.extra) for c in range(n_captures)]
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)
         self.ev_fir = [self.ctx.event() for _ in range(self.geo["nbuf"])]
@@ -311,14 +314,17 @@ class C2Pipeline:
                 self.batch_hook(self, i, prod, done)
             if prof: t_b = pc(); tp[0] += t_b - t_a
             if self.rx_multi:
-                self.ctx_rx.wait_event(done)
                 if snapshot_last and k == n_batches - 1:
-                    for c in caps:
-                        c.rx.snapshot_async()
                     self.snap = (0, i)
-                used = capi.CstlnReceiver.run_multi_async([c.rx for c in caps], [c.dec[i].ptr for c in caps], rx_n_in,
-                                                          [c.d_sym.ptr for c in caps], n_out + EXTRA + 256)
-                assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
+                for gi, cx in enumerate(self.ctx_rxs):
+                    grp = caps[gi::self.rx_groups]
+                    cx.wait_event(done)
+                    if snapshot_last and k == n_batches - 1:
+                        for c in grp:
+                            c.rx.snapshot_async()
+                    used = capi.CstlnReceiver.run_multi_async([c.rx for c in grp], [c.dec[i].ptr for c in grp], rx_n_in,
+                                                              [c.d_sym.ptr for c in grp], n_out + EXTRA + 256)
+                    assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
                 for c in caps:
                     c.queued += 1
             for c in ([] if self.rx_multi else caps):
@@ -450,8 +456,8 @@ class C2Pipeline:
     def close(self):
         for c in self.caps:
             c.close()
-        if self.ctx_rx is not None:
-            self.ctx_rx.close()
+        for cx in self.ctx_rxs:
+            cx.close()
         self.fir.close()
         self.ctx.close()
 

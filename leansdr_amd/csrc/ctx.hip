@@ -1,6 +1,7 @@
 // leansdr_amd/csrc/ctx.hip — context, device memory and stream timing of the C ABI.
 #include <cstring>
 #include "lsdr_internal.h"
+#include <malloc.h>
 
 static thread_local char g_err[512] = "";
 
@@ -45,6 +46,24 @@ static int ctx_create(int device, void *hip_stream, const uint32_t *cu_mask, uns
     return LSDR_E_HIP;
   }
   LSDR_HIP(hipSetDevice(device));
+  {
+    // Host memory must not go back to the kernel while GPU queues are live.  The blocks build per-call job lists and fetch per-call
+    // totals in std::vectors of hundreds of KB to MB; glibc returns such blocks with munmap / a heap trim when they are freed, the
+    // unmap runs the driver's MMU notifier, and the driver suspends and restores every queue of the process: the NEXT submission,
+    // whatever it is, waits ≈ 25 ms (round 2 met this as "mpeg_sync takes 24.7 ms" and moved the transfers into a pinned arena;
+    // round 4 found the same stall behind viterbi_sync's "cliff" — 8PSK 2/3, 32 Mi symbols per call: 25.3 ms per call, 4.0 ms
+    // under rocprofv3, 4.5 ms with MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ raised — although none of those vectors is ever
+    // touched by a transfer).  So the first context of a process tells malloc to keep what it has: blocks up to 32 MB come from the
+    // heap, and the heap is not trimmed.  LSDR_KEEP_MALLOC=1 leaves the allocator alone.
+    static bool once = false;
+    if (!once) {
+      once = true;
+      if (!getenv("LSDR_KEEP_MALLOC")) {
+        (void)mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);
+        (void)mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
+      }
+    }
+  }
   lsdr_ctx *c = new lsdr_ctx();
   c->device = device;
   c->own_stream = (hip_stream == nullptr);

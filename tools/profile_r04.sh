@@ -58,7 +58,8 @@ with open(os.path.join(out, "pmc_sq.txt"), "w") as o:
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             acc = collections.defaultdict(lambda: collections.defaultdict(list))
             for r in csv.DictReader(open(f)):
-                kn = r["Kernel_Name"].split("(")[0].split("::")[-1][:60]
+                import re
+                m = re.search(r"k_\w+(<[^>]*>)?", r["Kernel_Name"]); kn = (m.group(0) if m else r["Kernel_Name"])[:60]
                 acc[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
             for kn, cs in acc.items():
                 if not any(k in kn for k in ("k_fir", "k_rx")): continue
