@@ -163,10 +163,18 @@ template <> struct rx_window<LSDR_IN_CU8> {
   }
 };
 
-__device__ __forceinline__ void rx_window_set(rx_window<LSDR_IN_CU8> &wd, unsigned long long w, int wn) { wd.w = w; wd.wn = wn; }
-__device__ __forceinline__ void rx_window_set(rx_window<LSDR_IN_CF32> &, unsigned long long, int) {}   // (no LDS staging for cf32)
+// window of the sample at byte offset `bo` (clamped to the row by the caller) of a lane's LDS row; `first` = index of the sample there
+__device__ __forceinline__ void rx_window_lds(rx_window<LSDR_IN_CU8> &wd, const char *row, int bo, int delta, int s0) {
+  const int d = bo >> 2;                                  // two dwords starting at the dword that holds the sample
+  const unsigned *r32 = reinterpret_cast<const unsigned *>(row);
+  const unsigned lo32 = r32[d], hi32 = r32[d + 1];
+  wd.w = ((unsigned long long)hi32 << 32) | lo32; wd.wn = s0 + ((4 * d - delta) >> 1);
+}
+__device__ __forceinline__ void rx_window_lds(rx_window<LSDR_IN_CF32> &wd, const char *row, int bo, int delta, int s0) {
+  const float2 *r64 = reinterpret_cast<const float2 *>(row + bo);
+  wd.w0 = r64[0]; wd.w1 = r64[1]; wd.wn = s0 + ((bo - delta) >> 3);
+}
 
-// cstln_lut<256>::lookup(float,float), sdr.h:470-482
 __device__ __forceinline__ void lut_halve(float &I, float &Q) {   // the range-folding loop of sdr.h:470-476 alone
   while (__builtin_fmaxf(__builtin_fabsf(I + 0.5f), __builtin_fabsf(Q + 0.5f)) > 127.5f) {
     I *= 0.5f;
@@ -566,6 +574,7 @@ struct rx_tiled_args {
   unsigned first_chunks, tile_chunks, warm_chunks;
   unsigned n_tiles;
   unsigned lanes_per_wave;             // active lanes (tiles) per wavefront
+  unsigned dbg;                        // measurement hooks (LSDR_RX_DBG; results are garbage): 1 no scattered symbol stores, 2 no window loads
   unsigned stage_stride;               // symbols reserved per tile in `stage`
   lsdr_softsymbol *stage;
   lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
@@ -679,11 +688,26 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
 // filled in flat order (LDS-DMA writes lane·16 contiguous bytes), the global side of each 16-byte piece is per lane.  The
 // buffer resource starts at the 16-byte boundary below the stream's first byte (a pipebuf<cu8> read pointer is only 2-byte
 // aligned) and ends with the readable samples: pieces past the end come back as zeros and are never used.
-constexpr int kStage = 64;                                   // samples per stage (two stages per chunk)
-constexpr int kStageMargin = 16;                             // look-ahead kept behind a stage (covers omega ≤ ≈ 10)
-constexpr int kRowBytes = 2 * (kStage + kStageMargin) + 16;  // + alignment slack
-constexpr int kStageLoads = kRowBytes / 16;
-static_assert(kRowBytes % 16 == 0 && kChunk % kStage == 0, "stage geometry");
+// cf32 input stages the same way with shorter rows (16 samples + the interpolation partner: at 8 bytes per sample a per-symbol
+// window was a 128-byte line per lane per FOUR symbols, half of them from memory, and the wavefront waited for the slowest lane on
+// every step; the stage's last 16-byte piece is also the first piece of the NEXT stage's line, which so is on its way early).
+template <int FMT> struct rx_stage;
+template <> struct rx_stage<LSDR_IN_CU8> {
+  static constexpr int kStage = 64;                                   // samples per stage (two stages per chunk)
+  static constexpr int kStageMargin = 16;                             // look-ahead kept behind a stage (covers omega ≤ ≈ 10)
+  static constexpr int kBps = 2;                                      // bytes per sample
+  static constexpr int kRowBytes = kBps * (kStage + kStageMargin) + 16;   // + alignment slack
+  static constexpr int kWindow = 8;                                   // bytes one window read takes out of a row
+};
+template <> struct rx_stage<LSDR_IN_CF32> {
+  static constexpr int kStage = 16;
+  static constexpr int kStageMargin = 1;                              // the interpolation partner of the stage's last sample
+  static constexpr int kBps = 8;
+  static constexpr int kRowBytes = kBps * (kStage + kStageMargin) + 8;    // (+ 8: the stream may start on an odd sample of a 16-byte piece)
+  static constexpr int kWindow = 16;
+};
+static_assert(rx_stage<LSDR_IN_CU8>::kRowBytes % 16 == 0 && rx_stage<LSDR_IN_CF32>::kRowBytes % 16 == 0, "stage geometry");
+static_assert(kChunk % rx_stage<LSDR_IN_CU8>::kStage == 0 && kChunk % rx_stage<LSDR_IN_CF32>::kStage == 0, "stage geometry");
 typedef __attribute__((address_space(3))) void *rx_lds_ptr;
 
 template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
@@ -703,24 +727,29 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   const typename in_stream<FMT>::type base = in_make<FMT>(a.in) + cb * kChunk;
 
   // LDS staging: this lane's row, the wave's buffer resource, the per-lane part of the source offsets
-  const unsigned *row32 = nullptr;
+  typedef rx_stage<FMT> ST;
+  constexpr int kStage = ST::kStage, kRowBytes = ST::kRowBytes, kStageLoads = ST::kRowBytes / 16;
+  const char *row = nullptr;
   int delta = 0;
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned src_off[LDS ? kStageLoads : 1];
   if (LDS) {
     const unsigned long long addr = (unsigned long long)a.in;
     delta = (int)(addr & 15ull);
+    const unsigned long long cb0 = a.first_chunks + (unsigned long long)(j0 - 1) * a.tile_chunks - a.warm_chunks;   // first tile of the wave
+    // cu8: the resource spans the run (offsets clamp at 4 GiB); cf32: it starts at the wavefront's first tile, so that the
+    // offsets stay small however long the run is
+    const unsigned long long org = FMT == LSDR_IN_CU8 ? 0ull : cb0;
     // extent: up to the end of the 16-byte granule that holds the last readable sample (range checks are per dword, and a
     // granule never crosses a page), zeros beyond
-    const unsigned long long bytes = ((a.total_chunks * kChunk + (unsigned)ra) * 2ull + (unsigned)delta + 15ull) & ~15ull;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.in)) - delta, 0,
+    const unsigned long long bytes = (((a.total_chunks - org) * kChunk + (unsigned)ra) * (unsigned)ST::kBps + (unsigned)delta + 15ull) & ~15ull;
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.in)) + org * (kChunk * ST::kBps) - delta, 0,
                                              (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
-    row32 = reinterpret_cast<const unsigned *>(lds + lane * kRowBytes);
-    const unsigned long long cb0 = a.first_chunks + (unsigned long long)(j0 - 1) * a.tile_chunks - a.warm_chunks;   // first tile of the wave
+    row = lds + lane * kRowBytes;
 #pragma unroll
     for (int q = 0; q < kStageLoads; ++q) {
       const unsigned f = (unsigned)q * 1024u + (unsigned)lane * 16u, r = f / (unsigned)kRowBytes, col = f - r * (unsigned)kRowBytes;
-      const unsigned long long tile_byte = (cb0 + (unsigned long long)r * a.tile_chunks) * (kChunk * 2ull);
+      const unsigned long long tile_byte = (cb0 - org + (unsigned long long)r * a.tile_chunks) * (kChunk * (unsigned long long)ST::kBps);
       // rows of tiles that do not exist, or offsets beyond 4 GiB, point past the end of the resource: zeros
       src_off[q] = (j0 + r < a.n_tiles && tile_byte + col < 0xfff00000ull) ? (unsigned)(tile_byte + col) : 0xfffffff0u;
     }
@@ -736,6 +765,10 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   float h0pr = 0.f, h0pi = 0.f, h0cr = 0.f, h0ci = 0.f, h1pr = 0.f, h1pi = 0.f, h1cr = 0.f, h1ci = 0.f;
   float h2pr = 0.f, h2pi = 0.f, h2cr = 0.f, h2ci = 0.f;
   const float kk = C.kest, k1 = 1 - C.kest;
+  // (loop gains in registers: left in the argument record, a per-lane choice between two of them became a per-lane LOAD from it)
+  const float acq_alpha = C.acq_alpha, freq_alpha = C.freq_alpha, acq_gain_mu = C.acq_gain_mu, gain_mu = C.gain_mu;
+  const float freq_beta = C.freq_beta, omega = C.omega;
+  const int acq_syms = C.acq_syms;
   rx_ema_map m; m.a = 1.f; m.bi = 0.f; m.bs = 0.f; m.be = 0.f;
 
   rx_tile_info ti;
@@ -760,7 +793,7 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     win.load(base, 0, n_last);
     if (!HARD) *pw = 0u;   // (puts the loop entry in the same "three loads, then one store" state as the loop's back edge: see `*dp = raw.x`)
   } else {
-    rx_window_set(win, 0ull, -16);
+    win.wn = -16;
   }
   for (int ci = 0; ci < wave_chunks; ++ci) {
     const bool active = !LDS || ci < nchunks;
@@ -776,7 +809,8 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     // wavefront's first seam row, which that tile's last warm-up chunk rewrites — so that their stores cost the texture-address unit
     // one cache line instead of 64)
     unsigned *dp = body ? po + cnt : (lastwarm ? pw : pw0);
-    const unsigned keep = (body || lastwarm) ? 1u : 0u;
+    unsigned keep = (body || lastwarm) ? 1u : 0u;
+    if (a.dbg & 1u) { dp = pw0; keep = 0u; }
     bool had = false;
     float2 sg = make_float2(0.f, 0.f), sv = make_float2(0.f, 0.f);
     int pt_re = 0, pt_im = 0;
@@ -794,25 +828,24 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     for (int sb = 0; sb < (LDS ? kChunk / kStage : 1); ++sb) {
       const int s0 = ci * kChunk + sb * kStage;           // first sample of the stage (tile-relative)
       const int send = LDS ? s0 + kStage : cend;
-      // window of sample i out of this lane's LDS row (two dwords starting at the dword that holds sample i)
+      // window of sample i out of this lane's LDS row
       auto lds_window = [&](rx_window<FMT> &wd, int i) {
-        int bo = 2 * (i - s0) + delta;
-        bo = bo < 0 ? 0 : (bo > kRowBytes - 8 ? kRowBytes - 8 : bo);
-        const int d = bo >> 2;
-        const unsigned lo32 = row32[d], hi32 = row32[d + 1];
-        rx_window_set(wd, ((unsigned long long)hi32 << 32) | lo32, s0 + ((4 * d - delta) >> 1));
+        int bo = ST::kBps * (i - s0) + delta;
+        bo = bo < 0 ? 0 : (bo > kRowBytes - ST::kWindow ? kRowBytes - ST::kWindow : bo);
+        rx_window_lds(wd, row, bo, delta, s0);
       };
       if (LDS) {
-        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s0 * 2);   // (wave-uniform; says so to the compiler: no waterfall loop)
+        const unsigned soff = (unsigned)__builtin_amdgcn_readfirstlane(s0 * ST::kBps);   // (wave-uniform; says so to the compiler: no waterfall loop)
 #pragma unroll
         for (int q = 0; q < kStageLoads; ++q)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (rx_lds_ptr)(size_t)(unsigned)(unsigned long long)(lds + q * 1024), 16, src_off[q], soff, 0, 0);
         __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the stage has landed (single-wave workgroup: no barrier)
         asm volatile("" ::: "memory");
-        if (active && n < send && !win.covers(n)) lds_window(win, n);
+        // (cf32 rows keep no look-ahead: the window a lane carries over a stage boundary was read out of the OLD stage)
+        if (active && n < send && (FMT == LSDR_IN_CF32 || !win.covers(n))) lds_window(win, n);
       }
       while (active && n < send) {
-        if (SAMP != 2 && !win.covers(n)) {                // window missed (rare: rounding at the ±0.1 edge): plain reload
+        if (SAMP != 2 && !win.covers(n) && !(a.dbg & 2u)) {   // window missed (rare: rounding at the ±0.1 edge): plain reload
           if (LDS) lds_window(win, n);
           else {
             win.load(base, n, n_last);
@@ -844,10 +877,11 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         uint2 raw;
         if (!ARITH) raw = *reinterpret_cast<const uint2 *>(a.T.lut + lut_index(sv.x, sv.y));
         // window for the next symbol: ⌊mu + omega − 0.1⌋ samples ahead (at least one)
-        int lo = (int)(mu + C.omega - 0.1f);
+        int lo = (int)(mu + omega - 0.1f);
         lo = lo < 1 ? 1 : lo;
         rx_window<FMT> nxt;
         if (LDS) lds_window(nxt, n + lo);
+        else if (a.dbg & 2u) { nxt = win; nxt.wn = n + lo; }
         else nxt.load(base, n + lo, n_last);
         lut_entry e;
         if (ARITH) {
@@ -872,9 +906,9 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         }
         last = raw.x;
         ++nsym;
-        const bool acq = (int)(got + nsym) <= C.acq_syms && !body;
-        phase += e.phase_error * (acq ? C.acq_alpha : C.freq_alpha);   // sdr.h:814-815
-        freqw += e.phase_error * C.freq_beta;
+        const bool acq = (int)(got + nsym) <= acq_syms && !body;
+        phase += e.phase_error * (acq ? acq_alpha : freq_alpha);   // sdr.h:814-815
+        freqw += e.phase_error * freq_beta;
         freqw = freqw < f_lo ? f_lo : freqw; freqw = freqw > f_hi ? f_hi : freqw;
         h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;  // sdr.h:822-840
         h1pr = h0pr; h1pi = h0pi; h1cr = h0cr; h1ci = h0ci;
@@ -883,10 +917,10 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         had = true;
         h0cr = (float)pt_re; h0ci = (float)pt_im;
         const float muerr = ((h0pr - h2pr) * h1cr + (h0pi - h2pi) * h1ci) - ((h0cr - h2cr) * h1pr + (h0ci - h2ci) * h1pi);
-        float mucorr = muerr * (acq ? C.acq_gain_mu : C.gain_mu);
+        float mucorr = muerr * (acq ? acq_gain_mu : gain_mu);
         mucorr = mucorr < -0.1f ? -0.1f : mucorr; mucorr = mucorr > 0.1f ? 0.1f : mucorr;
         mu += mucorr;
-        mu += C.omega;
+        mu += omega;
         mu -= 1.f; phase += freqw; ++n;                   // the symbol's own sample step
         win = nxt;
         skip();
@@ -975,8 +1009,11 @@ constexpr int kRxMulti = 8;
 struct rx_tiled_multi { rx_tiled_args a[kRxMulti]; };
 template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_multi m) {
-  __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * kRowBytes : 16];
+  __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * rx_stage<FMT>::kRowBytes : 16];
   const rx_tiled_args &a = m.a[blockIdx.y];
+  // a tile is one long dependent chain with few instructions in flight: next to fir_filter's streaming wavefronts on the same SIMD
+  // it gets the issue slot whenever it is ready (C2 pipeline: tiles 284 -> 201 us per batch, the filter's launch unchanged)
+  __builtin_amdgcn_s_setprio(3);
   if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP, FMT, HARD>(a); }
   else rx_tile_tol<SAMP, ARITH, FMT, LDS, HARD>(a, 1u + (blockIdx.x - 1u) * a.lanes_per_wave, (int)threadIdx.x, lds);
 }
@@ -1373,26 +1410,30 @@ static int rx_tiled_plan(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbo
   a.meas_base = meas_base;
   a.cstln = want_cstln ? r->d_cstln : nullptr;
   rx_fill_consts(r, a.C, a.T);
-  // 32 tiles per wavefront: few enough wavefronts that the whole batch is resident in one round even while
+  // nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol); LSDR_RX_NO_LDS=1 keeps the direct
+  // loads (A/B measurements), LSDR_RX_NO_LDS=2 for cf32 input only
+  static const int no_lds = getenv("LSDR_RX_NO_LDS") ? atoi(getenv("LSDR_RX_NO_LDS")) : 0;
+  const bool lds_fmt = r->cfg.in_format == LSDR_IN_CU8 ? (no_lds != 1 && r->omega <= 8.f) : (no_lds == 0);
+  const bool use_lds = r->cfg.sampler != LSDR_SAMP_FIR && lds_fmt;
+  // Direct loads, 32 tiles per wavefront: few enough wavefronts that the whole batch is resident in one round even while
   // fir_filter's persistent workgroups hold most of the register file (C2 bench, streams overlapped: 8 → 292,
   // 16 → 298, 32 → 310, 64 → 302 GS/s whole-job)
   // With more than ≈ 12 K tiles (short tiles) 64 per wavefront keeps the wavefront count where fir_filter is disturbed
   // least (128-sample tiles, 17.5 K of them: 32 → fir 0.160 ms per launch, 64 → 0.149 ms, same whole-job rate).
-  int lpw = n_tiles > 12288u ? 64 : 32;
+  // Staged samples: a stage is loaded for 64 rows whatever the number of tiles, so all 64 lanes carry one.
+  int lpw = (n_tiles > 12288u || use_lds) ? 64 : 32;
   {
     static const char *const e = getenv("LSDR_RX_LANES");   // tuning hook: tiles per wavefront
     if (e) lpw = atoi(e);
     if (lpw < 1 || lpw > 64) lpw = n_tiles > 12288u ? 64 : 32;
     a.lanes_per_wave = (unsigned)lpw;
+    static const char *const d = getenv("LSDR_RX_DBG");
+    a.dbg = d ? (unsigned)atoi(d) : 0u;
   }
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
   P->n_tiles = n_tiles; P->blocks = blocks; P->lpw = (unsigned)lpw; P->stage_stride = stage_stride; P->sym_per_chunk = sym_per_chunk;
   P->hpitch = hpitch; P->hard = hard;
-  // cu8 input, nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol); LSDR_RX_NO_LDS=1 keeps
-  // the direct loads (A/B measurements)
-  static const bool no_lds = getenv("LSDR_RX_NO_LDS") != nullptr;
-  const bool use_lds = r->cfg.in_format == LSDR_IN_CU8 && r->cfg.sampler != LSDR_SAMP_FIR && !no_lds && r->omega <= 8.f;
-  if (hard && !use_lds) { lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 needs cu8 input with the nearest or linear sampler"); return LSDR_E_UNSUPPORTED; }
+  if (hard && !(use_lds && r->cfg.in_format == LSDR_IN_CU8)) { lsdr_set_error("cstln_receiver: LSDR_SYM_HARD2 needs cu8 input with the nearest or linear sampler"); return LSDR_E_UNSUPPORTED; }
   // k_rx_compact_h lets a partial output word be finished by the NEXT tile from the previous tile's column only: every tile must
   // hold at least two words' worth of symbols (32) after a dropped first one
   if (hard && (float)Lc * kChunk / (r->omega + 0.1f) < 34.f) {
@@ -1416,7 +1457,8 @@ static int rx_tiled_launch(lsdr_rx *r, const rx_plan &P) {
   for (int i = 0; i < kRxMulti; ++i) tm1.a[i] = a;
 #define LSDR_RX_LAUNCH_F(S, A, F, L, H) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L, H>), dim3(blocks), dim3(64), 0, c->stream, tm1)
 #define LSDR_RX_LAUNCH(S, A) do { if (hard) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), (S != 2)); \
-                                  else if (use_lds) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), false); \
+                                  else if (use_lds && r->cfg.in_format == LSDR_IN_CU8) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, (S != 2), false); \
+                                  else if (use_lds) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CF32, (S != 2), false); \
                                   else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CU8, false, false); \
                                   else LSDR_RX_LAUNCH_F(S, A, LSDR_IN_CF32, false, false); } while (0)
 #define LSDR_RX_LAUNCH_S(S) do { if (r->qpsk_arith) LSDR_RX_LAUNCH(S, true); else LSDR_RX_LAUNCH(S, false); } while (0)
@@ -1548,7 +1590,8 @@ static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *co
   const unsigned blocks = P[0].blocks, n_tiles = P[0].n_tiles;
   const bool use_lds = P[0].use_lds;
 #define LSDR_RXM_LAUNCH_F(S, A, F, L) hipLaunchKernelGGL((k_rx_tiles<S, A, F, L, false>), dim3(blocks, n), dim3(64), 0, c->stream, tm)
-#define LSDR_RXM_LAUNCH(S, A) do { if (use_lds) LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CU8, true); \
+#define LSDR_RXM_LAUNCH(S, A) do { if (use_lds && r->cfg.in_format == LSDR_IN_CU8) LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CU8, true); \
+                                   else if (use_lds) LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CF32, true); \
                                    else if (r->cfg.in_format == LSDR_IN_CU8) LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CU8, false); \
                                    else LSDR_RXM_LAUNCH_F(S, A, LSDR_IN_CF32, false); } while (0)
 #define LSDR_RXM_LAUNCH_S(S) do { if (r->qpsk_arith) LSDR_RXM_LAUNCH(S, true); else LSDR_RXM_LAUNCH(S, false); } while (0)

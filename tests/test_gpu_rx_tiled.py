@@ -271,3 +271,48 @@ def test_multi_capture_runs_equal_separate_queued_runs(capi, ctx, oracle, fmt):
             assert bits_equal(mixed[k][0][q], mixed_sep[k][0][q]), (k, q)
     for d in dins:
         d.free()
+
+
+_STAGED_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/oracle")
+import leansdr_amd.capi as capi
+from leansdr_amd import synth
+ctx = capi.Ctx(0)
+x, _ = synth.qpsk_baseband(4 * 60000, 4, seed=11, rms=50.0, snr_db=18.0)
+out = {}
+for sampler in (0, 1):
+    for shift in (0, 1):                        # shift 1: the stream starts on the odd sample of a 16-byte piece
+        r = capi.CstlnReceiver(ctx, sampler=sampler, cstln=1, omega=4.0, meas_decimation=4096, mode=capi.RX_TILED, tile_len=256, tile_warmup=256)
+        n = len(x) - 8
+        d_in = ctx.upload(x); d_out = ctx.alloc(n * 4)
+        used = r.run_async(d_in.at(8 * shift), n, d_out.ptr, n)
+        prod = r.wait()
+        s = ctx.download(d_out, capi.SOFTSYM, prod)
+        out[f"c{sampler}{shift}"] = s["cost"].copy(); out[f"s{sampler}{shift}"] = s["symbol"].copy(); out[f"u{sampler}{shift}"] = np.array([used, prod])
+        st = r.state()
+        out[f"t{sampler}{shift}"] = np.array([st.mu, st.phase, st.freqw, st.agc_gain, st.est_insp], np.float32)
+        r.close(); d_in.free(); d_out.free()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_staged_cf32_tiles_equal_direct_loads(tmp_path):
+    """cf32 input, nearest / linear sampler: the tolerance tiles take their samples out of LDS stages (rx_stage<LSDR_IN_CF32>)
+    instead of per-symbol global loads — the same samples, the same arithmetic, bit for bit the same run, whether the stream
+    starts on a 16-byte boundary or not.  (The loads are chosen once per process: two processes.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "staged.py"
+    script.write_text(_STAGED_SCRIPT)
+    res = []
+    for tag, extra in (("staged", {}), ("direct", {"LSDR_RX_NO_LDS": "2", "LSDR_RX_LANES": "64"})):
+        f = str(tmp_path / f"{tag}.npz")
+        p = subprocess.run([sys.executable, str(script), root, f], env=dict(os.environ, **extra), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        assert p.returncode == 0, p.stderr.decode()[-2000:]
+        res.append(np.load(f))
+    a, b = res
+    assert sorted(a.files) == sorted(b.files) and len(a.files) == 16
+    for k in a.files:
+        assert a[k].tobytes() == b[k].tobytes(), k
+    assert a["u10"][1] > 50000
