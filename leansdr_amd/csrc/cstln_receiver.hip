@@ -574,7 +574,7 @@ struct rx_tiled_args {
   unsigned first_chunks, tile_chunks, warm_chunks;
   unsigned n_tiles;
   unsigned lanes_per_wave;             // active lanes (tiles) per wavefront
-  unsigned dbg;                        // measurement hooks (LSDR_RX_DBG; results are garbage): 1 no scattered symbol stores, 2 no window loads
+  unsigned dbg;                        // measurement hooks (LSDR_RX_DBG; results are garbage): 1 no scattered symbol stores, 2 no window loads; 4: LSDR_RX_PRIO
   unsigned stage_stride;               // symbols reserved per tile in `stage`
   lsdr_softsymbol *stage;
   lsdr_softsymbol *wstage;             // [n_tiles][wstride]: symbols of each tile's last warm-up chunk (seam vote)
@@ -971,21 +971,25 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     }
   }
   {
-    // inclusive composition over the tiles of this wavefront (lane order = stream order; lanes without a tile — the
-    // highest ones — hold the identity and are never read): lane L ends with maps[first] … maps[L] composed
+    // inclusive composition over the tiles of this wavefront in GROUPS of (at most) 32 (lane order = stream order; lanes without
+    // a tile — the highest ones — hold the identity and are never read): lane L ends with maps[first of its group] … maps[L]
+    // composed.  (Groups, not wavefronts: a run's estimators then come out bit for bit the same with 32 and with 64 tiles per
+    // wavefront, i.e. whether or not the captures of a GPU share their launches.)
     rx_ema_map inc = m;
+    const int gl = lane & 31;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < 32; d <<= 1) {
       rx_ema_map o;
-      o.a = __shfl_up(inc.a, d, 64); o.bi = __shfl_up(inc.bi, d, 64); o.bs = __shfl_up(inc.bs, d, 64); o.be = __shfl_up(inc.be, d, 64);
-      if (lane >= d) inc = ema_then(o, inc);
+      o.a = __shfl_up(inc.a, d, 32); o.bi = __shfl_up(inc.bi, d, 32); o.bs = __shfl_up(inc.bs, d, 32); o.be = __shfl_up(inc.be, d, 32);
+      if (gl >= d) inc = ema_then(o, inc);
     }
     rx_ema_map ex;
-    ex.a = __shfl_up(inc.a, 1, 64); ex.bi = __shfl_up(inc.bi, 1, 64); ex.bs = __shfl_up(inc.bs, 1, 64); ex.be = __shfl_up(inc.be, 1, 64);
-    if (lane == 0) { ex.a = 1.f; ex.bi = ex.bs = ex.be = 0.f; }
+    ex.a = __shfl_up(inc.a, 1, 32); ex.bi = __shfl_up(inc.bi, 1, 32); ex.bs = __shfl_up(inc.bs, 1, 32); ex.be = __shfl_up(inc.be, 1, 32);
+    if (gl == 0) { ex.a = 1.f; ex.bi = ex.bs = ex.be = 0.f; }
     if (valid) {
       a.ema[j] = ex;
-      if (lane == (int)a.lanes_per_wave - 1 || j == a.n_tiles - 1) a.ema_wave[blockIdx.x] = inc;
+      const unsigned grp = a.lanes_per_wave > 32u ? 1u + (blockIdx.x - 1u) * 2u + (unsigned)(lane >> 5) : blockIdx.x;
+      if (gl == 31 || lane == (int)a.lanes_per_wave - 1 || j == a.n_tiles - 1) a.ema_wave[grp] = inc;
     }
   }
   if (valid && j == a.n_tiles - 1) {
@@ -1011,9 +1015,10 @@ template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_multi m) {
   __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * rx_stage<FMT>::kRowBytes : 16];
   const rx_tiled_args &a = m.a[blockIdx.y];
-  // a tile is one long dependent chain with few instructions in flight: next to fir_filter's streaming wavefronts on the same SIMD
-  // it gets the issue slot whenever it is ready (C2 pipeline: tiles 284 -> 201 us per batch, the filter's launch unchanged)
-  __builtin_amdgcn_s_setprio(3);
+  // LSDR_RX_PRIO=1 (tuning hook): raised issue priority.  Next to fir_filter's streaming wavefronts the tiles then take 201 instead of
+  // 284 us per C2 batch — and the filter's launch, which paces that pipeline, not a microsecond less; next to viterbi_sync (C3), which
+  // paces THAT chain, they cost it 15 %.  Off.
+  if (a.dbg & 4u) __builtin_amdgcn_s_setprio(3);
   if (blockIdx.x == 0) { if (threadIdx.x == 0) rx_tile_exact<SAMP, FMT, HARD>(a); }
   else rx_tile_tol<SAMP, ARITH, FMT, LDS, HARD>(a, 1u + (blockIdx.x - 1u) * a.lanes_per_wave, (int)threadIdx.x, lds);
 }
@@ -1037,6 +1042,9 @@ __global__ __launch_bounds__(256) void k_rx_fir_refresh(const rx_state_dev *stat
 //  * slot q of `meas` holds the partial map of its tile up to the measurement instant: composed with the maps of the
 //    preceding wavefronts and of the preceding tiles of its own wavefront (ex[]) it becomes the estimator values there.
 constexpr unsigned kEmaThreads = 256;
+// the tiles' estimator maps are composed in groups of min(lanes per wavefront, 32) tiles (rx_tile_tol); group 0 is the exact first tile
+static unsigned rx_ema_group(unsigned lpw) { return lpw > 32u ? 32u : lpw; }
+static unsigned rx_ema_groups(unsigned n_tiles, unsigned lpw) { return 1u + (n_tiles - 1u + rx_ema_group(lpw) - 1u) / rx_ema_group(lpw); }
 __device__ __forceinline__ void rx_ema_body(const rx_ema_map *wave, unsigned n_waves, const rx_ema_map *ex, unsigned n_tiles,
                                             unsigned lanes_per_wave, const rx_state_dev *next, rx_state_dev *state,
                                             rx_meas *meas, unsigned nm) {
@@ -1295,7 +1303,7 @@ struct rx_plan {
   int slot;
 };
 
-static int rx_tiled_plan(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
+static int rx_tiled_plan(lsdr_rx *r, unsigned share, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out,
                          bool want_meas, size_t meas_cap, size_t cstln_cap, rx_plan *P) {
   lsdr_ctx *c = r->ctx;
   LSDR_HIP(hipSetDevice(c->device));
@@ -1410,26 +1418,27 @@ static int rx_tiled_plan(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsymbo
   a.meas_base = meas_base;
   a.cstln = want_cstln ? r->d_cstln : nullptr;
   rx_fill_consts(r, a.C, a.T);
-  // nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol); LSDR_RX_NO_LDS=1 keeps the direct
-  // loads (A/B measurements), LSDR_RX_NO_LDS=2 for cf32 input only
-  static const int no_lds = getenv("LSDR_RX_NO_LDS") ? atoi(getenv("LSDR_RX_NO_LDS")) : 0;
-  const bool lds_fmt = r->cfg.in_format == LSDR_IN_CU8 ? (no_lds != 1 && r->omega <= 8.f) : (no_lds == 0);
-  const bool use_lds = r->cfg.sampler != LSDR_SAMP_FIR && lds_fmt;
-  // Direct loads, 32 tiles per wavefront: few enough wavefronts that the whole batch is resident in one round even while
-  // fir_filter's persistent workgroups hold most of the register file (C2 bench, streams overlapped: 8 → 292,
-  // 16 → 298, 32 → 310, 64 → 302 GS/s whole-job)
-  // With more than ≈ 12 K tiles (short tiles) 64 per wavefront keeps the wavefront count where fir_filter is disturbed
-  // least (128-sample tiles, 17.5 K of them: 32 → fir 0.160 ms per launch, 64 → 0.149 ms, same whole-job rate).
-  // Staged samples: a stage is loaded for 64 rows whatever the number of tiles, so all 64 lanes carry one.
-  int lpw = (n_tiles > 12288u || use_lds) ? 64 : 32;
+  // 32 tiles per wavefront: few enough wavefronts that the whole batch is resident in one round even while fir_filter's
+  // persistent workgroups hold most of the register file (C2 bench, streams overlapped: 8 → 292, 16 → 298, 32 → 310,
+  // 64 → 302 GS/s whole-job).  With more than ≈ 12 K tiles in a launch (short tiles, or the captures of a GPU sharing it: `share`)
+  // 64 per wavefront keeps the wavefront count where fir_filter is disturbed least (128-sample tiles, 17.5 K of them:
+  // 32 → fir 0.160 ms per launch, 64 → 0.149 ms, same whole-job rate).
+  int lpw = (unsigned long long)n_tiles * share > 12288ull ? 64 : 32;
   {
     static const char *const e = getenv("LSDR_RX_LANES");   // tuning hook: tiles per wavefront
     if (e) lpw = atoi(e);
-    if (lpw < 1 || lpw > 64) lpw = n_tiles > 12288u ? 64 : 32;
+    if (lpw < 1 || (lpw > 32 && lpw != 64)) lpw = (unsigned long long)n_tiles * share > 12288ull ? 64 : 32;   // (estimator groups: ≤ 32, or two of 32)
     a.lanes_per_wave = (unsigned)lpw;
     static const char *const d = getenv("LSDR_RX_DBG");
-    a.dbg = d ? (unsigned)atoi(d) : 0u;
+    static const bool prio = getenv("LSDR_RX_PRIO") && atoi(getenv("LSDR_RX_PRIO"));
+    a.dbg = (d ? (unsigned)atoi(d) & 3u : 0u) | (prio ? 4u : 0u);
   }
+  // nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol) — cu8 always, cf32 when all 64 rows of a
+  // stage belong to tiles of the wavefront (a lone 8.7 K-tile capture next to viterbi_sync, C3, is better off with twice the
+  // wavefronts and direct loads).  LSDR_RX_NO_LDS=1 keeps the direct loads (A/B measurements), =2 for cf32 input only
+  static const int no_lds = getenv("LSDR_RX_NO_LDS") ? atoi(getenv("LSDR_RX_NO_LDS")) : 0;
+  const bool lds_fmt = r->cfg.in_format == LSDR_IN_CU8 ? (no_lds != 1 && r->omega <= 8.f) : (no_lds == 0 && lpw == 64);
+  const bool use_lds = r->cfg.sampler != LSDR_SAMP_FIR && lds_fmt;
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
   P->n_tiles = n_tiles; P->blocks = blocks; P->lpw = (unsigned)lpw; P->stage_stride = stage_stride; P->sym_per_chunk = sym_per_chunk;
   P->hpitch = hpitch; P->hard = hard;
@@ -1476,8 +1485,8 @@ static int rx_tiled_launch(lsdr_rx *r, const rx_plan &P) {
 #undef LSDR_RX_LAUNCH_F
   LSDR_HIP(hipGetLastError());
   // estimators (AGC, MER) of the run: scan of the tiles' maps; installs the end state
-  hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema_wave, blocks,
-                     (const rx_ema_map *)r->d_ema, n_tiles, (unsigned)lpw, (const rx_state_dev *)r->d_state_next, r->d_state,
+  hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema_wave, rx_ema_groups(n_tiles, (unsigned)lpw),
+                     (const rx_ema_map *)r->d_ema, n_tiles, rx_ema_group((unsigned)lpw), (const rx_state_dev *)r->d_state_next, r->d_state,
                      want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
 
   // ---- seam pass + compaction, all on the stream
@@ -1530,7 +1539,7 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
   *consumed = 0;
   if (nm_out) *nm_out = 0;
   rx_plan P;
-  LSDR_TRY(rx_tiled_plan(r, in, n_in, out, cap_out, want_meas, meas_cap, cstln_cap, &P));
+  LSDR_TRY(rx_tiled_plan(r, 1u, in, n_in, out, cap_out, want_meas, meas_cap, cstln_cap, &P));
   if (chunks_out) *chunks_out = P.chunks;
   if (P.chunks) LSDR_TRY(rx_tiled_launch(r, P));
   LSDR_TRY(rx_tiled_commit(r, P, r->ctx->stream, consumed));
@@ -1555,7 +1564,7 @@ static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *co
   if (alike) alike = rs[0]->cfg.out_format != LSDR_SYM_HARD2 && rs[0]->cfg.sampler != LSDR_SAMP_FIR && !rs[0]->time_on;
   rx_plan P[kRxMulti];
   if (alike) {
-    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_plan(rs[i], ins[i], n_in, outs[i], cap_out, false, 0, 0, &P[i]));
+    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_plan(rs[i], n, ins[i], n_in, outs[i], cap_out, false, 0, 0, &P[i]));
     for (unsigned i = 1; i < n; ++i)
       alike = alike && P[i].chunks == P[0].chunks && P[i].n_tiles == P[0].n_tiles && P[i].blocks == P[0].blocks && P[i].lpw == P[0].lpw &&
               P[i].stage_stride == P[0].stage_stride && P[i].use_lds == P[0].use_lds;
@@ -1601,7 +1610,7 @@ static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *co
 #undef LSDR_RXM_LAUNCH
 #undef LSDR_RXM_LAUNCH_F
   LSDR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_rx_ema_multi, dim3(n), dim3(kEmaThreads), 0, c->stream, em, blocks, n_tiles, P[0].lpw);
+  hipLaunchKernelGGL(k_rx_ema_multi, dim3(n), dim3(kEmaThreads), 0, c->stream, em, rx_ema_groups(n_tiles, P[0].lpw), n_tiles, rx_ema_group(P[0].lpw));
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
   hipLaunchKernelGGL(k_rx_seam_multi, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock, n), dim3(kSeamBlock), 0, c->stream, sm, n_tiles, r->omega, R,

@@ -6,6 +6,7 @@
 #   pmc_*.csv, pmc_traffic.json   FETCH_SIZE / WRITE_SIZE (one counter per pass, rows of the fir kernel) -> HBM bytes per launch
 #   pmc_sq.txt            SQ counters of the headline's filter kernel (MFMA busy, VALU / LDS / MFMA instructions, wait classes)
 #   overlap.txt           kernel trace of a short run: fir stream occupancy, receiver kernels inside fir launches, per-queue busy
+#   rx_alone.txt          the receiver kernels of the same pipeline with the filter launches skipped
 #   fir_alone.txt         the filter kernels alone (exact / fma / mfma / blk, real and complex taps)
 #   c1.json, c1_kernel_stats.csv   bench.py --workload c1
 set -u
@@ -70,6 +71,21 @@ print(open(os.path.join(out, "pmc_sq.txt")).read()[:3000])
 PY
 bash tools/timeline.sh --no-more --no-verify --batches-per-step 8 > "$OUT/timeline.log" 2>&1
 python tools/overlap.py gpurun_out/timeline.csv > "$OUT/overlap.txt" 2>&1; cat "$OUT/overlap.txt"
+# the receiver chain alone: same pipeline, filter launches skipped after the buffers are filled (LSDR_FIR_SKIP)
+LSDR_FIR_SKIP=1 bash tools/timeline.sh --no-more --no-verify --batches-per-step 8 > /dev/null 2>&1
+python - > "$OUT/rx_alone.txt" <<'PY'
+import re, collections
+d = collections.defaultdict(list)
+for ln in open("gpurun_out/timeline.csv"):
+    p = ln.split(",")
+    m = re.search(r"(k_rx\w+)", p[0])
+    if m: d[m.group(1)].append(int(p[2]) - int(p[1]))
+print("receiver kernels of the C2 pipeline with the filter launches skipped (LSDR_FIR_SKIP=1): per batch of 4 captures")
+for k, v in d.items():
+    v = v[len(v) // 2:]
+    print(f"  {k:28s} n={len(v):4d} mean {sum(v) / len(v) / 1e3:8.1f} us")
+PY
+cat "$OUT/rx_alone.txt"
 {
 for a in exact fma mfma blk; do FIR_ARITH=$a FIR_ALONE_REPS=20,400 timeout 120 python tools/fir_alone.py 2>&1 | tail -3; done
 for a in exact fma mfma blk; do FIR_FREQ=0.0123 FIR_ARITH=$a FIR_ALONE_REPS=400 timeout 120 python tools/fir_alone.py 2>&1 | tail -1; done
