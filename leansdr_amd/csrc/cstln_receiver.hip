@@ -1433,11 +1433,14 @@ static int rx_tiled_plan(lsdr_rx *r, unsigned share, const void *in, size_t n_in
     static const bool prio = getenv("LSDR_RX_PRIO") && atoi(getenv("LSDR_RX_PRIO"));
     a.dbg = (d ? (unsigned)atoi(d) & 3u : 0u) | (prio ? 4u : 0u);
   }
-  // nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol) — cu8 always, cf32 when all 64 rows of a
-  // stage belong to tiles of the wavefront (a lone 8.7 K-tile capture next to viterbi_sync, C3, is better off with twice the
-  // wavefronts and direct loads).  LSDR_RX_NO_LDS=1 keeps the direct loads (A/B measurements), =2 for cf32 input only
+  // nearest / linear sampler: the tiles' samples are staged through LDS (see rx_tile_tol) — cu8 always; cf32 when all 64 rows of a
+  // stage belong to tiles of the wavefront and the launch is small enough (≤ 1024 wavefronts) that its 9 KiB per wavefront do not
+  // decide how many are resident: C3's 4 Gi-sample batches are 8.7 K wavefronts, and next to fir_filter's 114 KiB per CU only
+  // four of them fit a CU — direct loads (no LDS) ran that chain 12 % faster.  LSDR_RX_NO_LDS=1 keeps the direct loads (A/B
+  // measurements), =2 for cf32 input only
   static const int no_lds = getenv("LSDR_RX_NO_LDS") ? atoi(getenv("LSDR_RX_NO_LDS")) : 0;
-  const bool lds_fmt = r->cfg.in_format == LSDR_IN_CU8 ? (no_lds != 1 && r->omega <= 8.f) : (no_lds == 0 && lpw == 64);
+  const bool lds_fmt = r->cfg.in_format == LSDR_IN_CU8 ? (no_lds != 1 && r->omega <= 8.f)
+                                                       : (no_lds == 0 && lpw == 64 && (unsigned long long)n_tiles * share <= 65536ull);
   const bool use_lds = r->cfg.sampler != LSDR_SAMP_FIR && lds_fmt;
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
   P->n_tiles = n_tiles; P->blocks = blocks; P->lpw = (unsigned)lpw; P->stage_stride = stage_stride; P->sym_per_chunk = sym_per_chunk;
