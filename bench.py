@@ -189,6 +189,8 @@ class Capture:
         dp.free()
         self.dec = [self.ctx.alloc((n_out + EXTRA) * 8) for _ in range(geo["nbuf"])]
         self.d_sym = self.ctx.alloc((n_out + EXTRA + 256) * 4)
+        if os.environ.get("LSDR_BENCH_PTRS"):       # diagnostic: where the buffers landed
+            print("ptrs d_in %x dec %s d_sym %x" % (self.d_in.ptr, " ".join("%x" % d.ptr for d in self.dec), self.d_sym.ptr), file=sys.stderr)
         self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1], **rx_kw)
         self.ev_rx = [self.ctx_rx.event() for _ in range(geo["nbuf"])]
         self.queued = 0
@@ -489,13 +491,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batches-per-step", type=int, default=96, help="batches of every capture in one step")
-    ap.add_argument("--batch-msamples", type=int, default=64, help="Mi input samples per batch per capture")
+    ap.add_argument("--batches-per-step", type=int, default=None, help="batches of every capture in one step (default: 24 Gi samples per step and GPU)")
+    ap.add_argument("--batch-msamples", type=int, default=None, help="Mi input samples per batch per capture (default: 256 per GPU, shared by its captures)")
     ap.add_argument("--period-msamples", type=int, default=4, help="unique synthetic period (Mi samples, circular)")
     ap.add_argument("--tile-len", type=int, default=DEFAULT_TILE[0])
     ap.add_argument("--tile-warmup", type=int, default=DEFAULT_TILE[1])
-    ap.add_argument("--captures", type=int, default=4,
-                    help="independent captures demodulated concurrently on each GPU (own streams, buffers and block handles)")
+    ap.add_argument("--captures", type=int, default=1,
+                    help="independent captures demodulated concurrently on each GPU (own buffers and block handles, shared launches); "
+                         "1 = north_star's one capture per GPU (`more.four_captures` is the batched-streams case)")
     ap.add_argument("--fir-arith", choices=["exact", "fma", "mfma", "blk"], default="blk",
                     help="fir_filter arithmetic of the headline.  blk (default) = block-polyphase on the f32 matrix pipe (LSDR_FIR_MFMA_BLK: output "
                          "bit-identical to the oracle's restatement lo_fir_filter_blk, ≤ 1e-5 of full scale from the reference's arithmetic; "
@@ -519,6 +522,11 @@ def main():
     ap.add_argument("--c1-tile", type=int, default=2048)
     ap.add_argument("--c1-warmup", type=int, default=512)
     args = ap.parse_args()
+    if args.batch_msamples is None:
+        args.batch_msamples = max(16, 256 // max(1, args.captures))
+    if args.batches_per_step is None:
+        args.batches_per_step = max(1, 96 * 256 // (args.batch_msamples * max(1, args.captures)))
+    args.more_batch_msamples = 64         # the one-capture secondary configurations keep round 3's batch (comparable numbers)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
@@ -616,14 +624,15 @@ def main():
                        "fir_arith": {"exact": "LSDR_FIR_EXACT (the reference's arithmetic, bit-exact)", "fma": "LSDR_FIR_FMA", "mfma": "LSDR_FIR_MFMA",
                                      "blk": "LSDR_FIR_MFMA_BLK (f32 matrix pipe, block-polyphase; tolerance mode: filter output pinned bit for bit to "
                                             "oracle lo_fir_filter_blk, soft symbols under leansdr_amd.tolerance.TOL vs the exact chain)"}[args.fir_arith],
-                       "rx_launches": "per capture (one stream each)" if args.rx_per_stream else "shared by the captures of a GPU (lsdr_rx_run_multi_async, one stream)",
+                       "rx_launches": "per capture (one stream each)" if args.rx_per_stream or len(pipe.caps) == 1 else "shared by the captures of a GPU (lsdr_rx_run_multi_async, one stream)",
                        "batches_per_step": bps, "batch_samples_per_capture": g["B"], "captures_per_gpu": len(pipe.caps),
                        "samples_per_step_per_gpu": g["B"] * len(pipe.caps) * bps,
                        "rx_mode": "tiled", "rx_tile": {"tile_len": tile[0], "warmup": tile[1]},
                        "cu_partition": {"receiver_cus": pipe.rx_cus, "fir_filter_cus": 256 - pipe.rx_cus} if pipe.rx_cus else None,
                        "rx_tiles_last_run": pipe.caps[0].rx.tiled_stats(), "rx_decisions": pipe.caps[0].rx.decision_mode(),
-                       "streams": "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k) of all captures in "
-                                  "shared launches (lsdr_rx_run_multi_async): two HIP streams, receiver runs queued",
+                       "streams": ("fir_filter(k+1) || cstln_receiver(k): two HIP streams, receiver runs queued" if len(pipe.caps) == 1 else
+                                   "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k) of all captures in "
+                                   "shared launches (lsdr_rx_run_multi_async): two HIP streams, receiver runs queued"),
                        "parallelism": f"{world * len(pipe.caps)} independent capture(s), {len(pipe.caps)} per GPU, no collectives, no RCCL",
                        "symbols_per_step": nsym // max(1, args.steps)},
             "roofline": pipe.roofline(),

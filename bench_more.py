@@ -2,7 +2,8 @@
 measured after the headline's timed region, on the same GPU, each with its own clock and (where a kernel dominates) its
 own roofline.  N=1 only.
 
-  single_stream  north_star's N=1 case: ONE capture, fir_filter(k+1) ‖ cstln_receiver(k) on two HIP streams.
+  four_captures  batched streams: FOUR independent captures on the GPU, 64 Mi samples each per batch (the headline's batch split four
+                 ways), one fir_filter launch and one set of receiver launches for all of them (rounds 2-4's headline arrangement).
   anf1           config 2 with the reference's default `--anf 1` in front: auto_notch (throughput mode: single-pass scan,
                  detect() on the device) → fir_filter → cstln_receiver; the notch is its own HBM pass (8 B in + 8 B out).
   c2_offset      config 2 with the carrier 1 MHz off: the receiver is biased there (leandvb --tune), its freq_tap feeds
@@ -89,19 +90,18 @@ def headline_arith(capi, args):
     return {"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[getattr(args, "fir_arith", "blk")]
 
 
-def single_stream(capi, synth, device, args):
+def four_captures(capi, synth, device, args):
     import bench
-    # one capture, batches as large as the headline's four together (256 Mi samples: 64 → 441, 128 → 486, 256 → 505 GS/s — the
-    # hand-over between two filter launches costs the same whatever the launch size)
-    pipe = bench.C2Pipeline(capi, synth, device, 1, 4 * args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=77,
-                            rx_cus=args.rx_cus, cu_pattern=args.cu_pattern, fir_arith=headline_arith(capi, args))
+    # four captures whose batches together are the headline's one (256 Mi samples per GPU and batch)
+    pipe = bench.C2Pipeline(capi, synth, device, 4, max(16, args.batch_msamples * args.captures // 4), args.period_msamples, (args.tile_len, args.tile_warmup),
+                            seed0=77, rx_cus=args.rx_cus, cu_pattern=args.cu_pattern, fir_arith=headline_arith(capi, args))
     t0 = time.perf_counter()
     pipe.run(8, False)
     pipe.sync()
     nb = batches_for((time.perf_counter() - t0) / 8)
     consumed, dt, calls = timed_at_least(lambda: pipe.run(nb, True, snapshot_last=not args.no_verify), pipe.sync)
     nb *= calls
-    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=1, batches=nb,
+    out = dict(value=round(consumed / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), captures_per_gpu=4, batches=nb,
                roofline=pipe.roofline())
     if not args.no_verify:
         out["verified"] = pipe.verify_last_batch()
@@ -227,7 +227,7 @@ def c2_mfma(capi, synth, device, args):
 def anf1(capi, synth, device, args):
     """One capture: auto_notch(scan) on its own stream → fir_filter → cstln_receiver (queued), three stages in flight."""
     import bench
-    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=33,
+    pipe = bench.C2Pipeline(capi, synth, device, 1, getattr(args, "more_batch_msamples", 64), args.period_msamples, (args.tile_len, args.tile_warmup), seed0=33,
                             cw=(0.0137, 3.0), fir_arith=headline_arith(capi, args))
     g, cp = pipe.geo, pipe.caps[0]
     ctx_n = capi.Ctx(device)
@@ -322,7 +322,7 @@ def c2_offset(capi, synth, device, args):   # (complex taps under the headline's
     the headline, feedback latency = queue depth (two batches) instead of a host wait after every batch."""
     import bench
     f0 = 1.0e6 / bench.FS                 # cycles per input sample
-    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup),
+    pipe = bench.C2Pipeline(capi, synth, device, 1, getattr(args, "more_batch_msamples", 64), args.period_msamples, (args.tile_len, args.tile_warmup),
                             seed0=55, freq=f0, rx_freq=f0 * 30, fir_arith=headline_arith(capi, args))
     g = pipe.geo
     tol = float(np.float32(bench.FM / bench.FS * 0.1))
@@ -667,7 +667,7 @@ def c3(capi, synth, device, args):
     # latency however few tiles there are, and next to fir_filter's persistent workgroups its wavefronts get few slots.  Large
     # batches give a call enough tiles to fill what is left of the chip: 512 Mi samples per batch 227 GS/s, 1 Gi 247, 2 Gi 277,
     # 4 Gi 307 (32 GB of input per batch, resident; 288 GB of HBM is what makes this the natural batch).
-    return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, int(os.environ.get("LSDR_C3_BATCH_MSAMPLES", 64 * args.batch_msamples)),
+    return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, int(os.environ.get("LSDR_C3_BATCH_MSAMPLES", 4096)),
                       "QPSK 1/2 @ 120 sps cf32: scaler+fir_filter(313,/30) -> cstln_receiver(tiled) -> viterbi_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
                       ["--f32", "--float-scale", "75", "-f", "240e6", "--sr", "2000e3", "--cr", "1/2", "--resample", "--anf", "0", "--viterbi"])
 
@@ -1092,7 +1092,7 @@ def end_to_end(capi, synth, device, args):
 
 def run_all(capi, synth, device, args):
     more = {}
-    for name, fn in (("single_stream", single_stream), ("c2_exact", c2_exact), ("c2_fma", c2_fma), ("c2_mfma", c2_mfma), ("c2_rrc", c2_rrc),
+    for name, fn in (("four_captures", four_captures), ("c2_exact", c2_exact), ("c2_fma", c2_fma), ("c2_mfma", c2_mfma), ("c2_rrc", c2_rrc),
                      ("c2_cnr", c2_cnr), ("anf1", anf1),
                      ("c2_offset", c2_offset), ("c3", c3),
                      ("c5_rescoped", c5_rescoped), ("c1", c1), ("c1_hs", c1_hs_entry), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):

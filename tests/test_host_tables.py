@@ -56,4 +56,4 @@ def test_bench_more_lists_every_secondary_configuration():
     names = [(e.elts[0].value, e.elts[1].id) for n in ast.walk(run_all) if isinstance(n, ast.Tuple) for e in [n]
              if len(n.elts) == 2 and isinstance(n.elts[0], ast.Constant) and isinstance(n.elts[1], ast.Name)]
     assert len(names) >= 9 and all(f in funcs for _, f in names)
-    assert {"single_stream", "anf1", "c2_offset", "c3", "c5_rescoped", "c1", "c1_hs", "exact_batch", "end_to_end"} <= {k for k, _ in names}
+    assert {"four_captures", "anf1", "c2_offset", "c3", "c5_rescoped", "c1", "c1_hs", "exact_batch", "end_to_end"} <= {k for k, _ in names}
