@@ -80,7 +80,7 @@ for ln in open("gpurun_out/timeline.csv"):
     p = ln.split(",")
     m = re.search(r"(k_rx\w+)", p[0])
     if m: d[m.group(1)].append(int(p[2]) - int(p[1]))
-print("receiver kernels of the C2 pipeline with the filter launches skipped (LSDR_FIR_SKIP=1): per batch of 4 captures")
+print("receiver kernels of the C2 pipeline with the filter launches skipped (LSDR_FIR_SKIP=1): per batch")
 for k, v in d.items():
     v = v[len(v) // 2:]
     print(f"  {k:28s} n={len(v):4d} mean {sum(v) / len(v) / 1e3:8.1f} us")
