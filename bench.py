@@ -155,6 +155,18 @@ def pmc_traffic(batch_samples):
     return None, None
 
 
+def resolve_defaults(args):
+    """The C2 geometry that was not given: 256 Mi samples per batch and GPU shared by its captures, 24 Gi samples per step and GPU —
+    one capture: 96 batches of 256 Mi; four captures: 96 batches of 4 × 64 Mi."""
+    caps = max(1, args.captures)
+    if args.batch_msamples is None:
+        args.batch_msamples = max(16, 256 // caps)
+    if args.batches_per_step is None:
+        args.batches_per_step = max(1, 96 * 256 // (args.batch_msamples * caps))
+    args.more_batch_msamples = 64         # the one-capture secondary configurations keep round 3's batch (comparable numbers)
+    return args
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher: start the N ranks (torch.distributed.run, rendezvous on 127.0.0.1)."""
     with socket.socket() as sk:
@@ -521,12 +533,7 @@ def main():
     ap.add_argument("--c1-workers", type=int, default=16, help="c1: host threads / HIP streams decoding captures concurrently per GPU")
     ap.add_argument("--c1-tile", type=int, default=2048)
     ap.add_argument("--c1-warmup", type=int, default=512)
-    args = ap.parse_args()
-    if args.batch_msamples is None:
-        args.batch_msamples = max(16, 256 // max(1, args.captures))
-    if args.batches_per_step is None:
-        args.batches_per_step = max(1, 96 * 256 // (args.batch_msamples * max(1, args.captures)))
-    args.more_batch_msamples = 64         # the one-capture secondary configurations keep round 3's batch (comparable numbers)
+    args = resolve_defaults(ap.parse_args())
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))

@@ -95,3 +95,18 @@ def test_single_rank_needs_no_torch():
     s = Shard()
     assert (s.rank, s.world) == (0, 1)
     assert s.aggregate(10.0, 2.0) == (10.0, 2.0, 5.0)
+
+
+def test_bench_default_geometry():
+    """bench.py's C2 defaults: one capture per GPU with 256 Mi-sample batches (north_star's sharding); whatever the number of
+    captures, a GPU's batch is 256 Mi samples and its step 24 Gi."""
+    import argparse
+    sys.path.insert(0, ROOT)
+    import bench
+    for caps, want in ((1, (256, 96)), (2, (128, 96)), (4, (64, 96)), (8, (32, 96))):
+        a = bench.resolve_defaults(argparse.Namespace(captures=caps, batch_msamples=None, batches_per_step=None))
+        assert (a.batch_msamples, a.batches_per_step) == want and a.batch_msamples * caps * a.batches_per_step == 24 * 1024
+    a = bench.resolve_defaults(argparse.Namespace(captures=2, batch_msamples=16, batches_per_step=None))
+    assert (a.batch_msamples, a.batches_per_step) == (16, 768)
+    a = bench.resolve_defaults(argparse.Namespace(captures=1, batch_msamples=256, batches_per_step=6))
+    assert a.batches_per_step == 6 and a.more_batch_msamples == 64
