@@ -163,7 +163,8 @@ template <> struct rx_window<LSDR_IN_CU8> {
   }
 };
 
-// window of the sample at byte offset `bo` (clamped to the row by the caller) of a lane's LDS row; `first` = index of the sample there
+// window starting at byte offset `bo` (clamped to the row by the caller) of a lane's LDS row; s0 = tile-relative index of the row's first
+// sample, delta = byte offset of that sample in the row (the stream's misalignment against the 16-byte pieces)
 __device__ __forceinline__ void rx_window_lds(rx_window<LSDR_IN_CU8> &wd, const char *row, int bo, int delta, int s0) {
   const int d = bo >> 2;                                  // two dwords starting at the dword that holds the sample
   const unsigned *r32 = reinterpret_cast<const unsigned *>(row);
@@ -678,7 +679,7 @@ __device__ __forceinline__ void rx_tile_exact(const rx_tiled_args &a) {
 // it is kept to ONE memory round trip: the constellation gather.  The two samples of the NEXT symbol are requested
 // together with it, as a 3-sample window — the next symbol instant is n + ⌊mu + omega + mucorr⌋ with |mucorr| ≤ 0.1,
 // i.e. one of two adjacent positions — and the soft symbol is stored fire-and-forget (the following wait is for the
-// next iteration's loads, one full symbol step later).  No LDS (fir_filter's two workgroups per CU need it), no scratch.
+// next iteration's loads, one full symbol step later).  No scratch; LDS only in the staged forms below.
 // LDS staging of the tolerance tiles' samples (cu8 input only: LSDR_IN_CU8, nearest / linear sampler).  Every lane of a
 // wavefront walks its own tile, so a per-symbol global load touches 64 different cache lines; with more than one wavefront
 // per SIMD the lines of a CU's lanes no longer fit its L1 (nor, chip-wide, the L2s) and every 8-byte window costs a 128-byte
@@ -1440,7 +1441,8 @@ static int rx_tiled_plan(lsdr_rx *r, unsigned share, const void *in, size_t n_in
   // measurements), =2 for cf32 input only
   static const int no_lds = getenv("LSDR_RX_NO_LDS") ? atoi(getenv("LSDR_RX_NO_LDS")) : 0;
   const bool lds_fmt = r->cfg.in_format == LSDR_IN_CU8 ? (no_lds != 1 && r->omega <= 8.f)
-                                                       : (no_lds == 0 && lpw == 64 && (unsigned long long)n_tiles * share <= 65536ull);
+                                                       : (no_lds == 0 && lpw == 64 && (unsigned long long)n_tiles * share <= 65536ull &&
+                                                          ((unsigned long long)in & 7ull) == 0);
   const bool use_lds = r->cfg.sampler != LSDR_SAMP_FIR && lds_fmt;
   const unsigned blocks = 1 + (n_tiles - 1 + (unsigned)lpw - 1) / (unsigned)lpw;
   P->n_tiles = n_tiles; P->blocks = blocks; P->lpw = (unsigned)lpw; P->stage_stride = stage_stride; P->sym_per_chunk = sym_per_chunk;
