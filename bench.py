@@ -32,6 +32,7 @@ the other configurations (single stream, carrier offset, full chain ...), each m
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -139,20 +140,36 @@ def cpu_baseline(x, coeffs, decim, budget_s):
                        f"{budget_s * 0.7 / 3:.1f} s ({wall:.1f} s incl. start-up)")
 
 
-def pmc_traffic(batch_samples):
-    """HBM bytes per fir_filter launch, RECORDED (not measured in this run): the committed rocprofv3 PMC passes under
+def pmc_traffic(kernel, batch_samples):
+    """HBM bytes per launch of `kernel`, RECORDED (not measured in this run): the committed rocprofv3 PMC passes under
     profiles/ (FETCH_SIZE and WRITE_SIZE collected in separate passes, FETCH_SIZE corrected ×2 for gfx950 as the
-    microarch guide prescribes).  Counters cannot be read from inside a normal run; None when the launch size differs
-    from the profiled one."""
-    for d in ("r04_bench", "r03_bench", "r02_bench", "r01_bench"):
+    microarch guide prescribes).  Counters cannot be read from inside a normal run.  A record counts only when it was taken
+    on the SAME kernel (by name) at the SAME launch size; otherwise None."""
+    for d in ("r05_bench", "r04_bench", "r03_bench", "r02_bench", "r01_bench"):
         try:
             with open(os.path.join(ROOT, "profiles", d, "pmc_traffic.json")) as f:
                 j = json.load(f)
-            if j["batch_samples"] == batch_samples:
+            if j["batch_samples"] == batch_samples and re.search(r"\b%s\b" % re.escape(kernel), j["kernel"]):
                 return j["traffic_bytes_per_launch"], f"profiles/{d}/pmc_traffic.json"
         except (OSError, KeyError, ValueError):
             pass
     return None, None
+
+
+def measured_copy_ceiling():
+    """The practical HBM ceiling SURVEY §8(d) asks for next to the spec peak: a plain streaming-read kernel's rate on this chip (the
+    filter reads 30 bytes for every byte it writes), RECORDED from the newest profiles/**/membench*.txt (tools/membench.hip; not measured in this run)."""
+    best = None
+    for pat in ("profiles/r05_bench/membench.txt", "profiles/membench_r01.txt"):
+        try:
+            txt = open(os.path.join(ROOT, pat)).read()
+        except OSError:
+            continue
+        vals = [float(v) for v in re.findall(r"([0-9]+(?:\.[0-9]+)?)\s*GB/s", txt)]
+        if vals:
+            best = (max(vals), pat)
+            break
+    return best
 
 
 def resolve_defaults(args):
@@ -458,10 +475,13 @@ class C2Pipeline:
         alg_bytes = int(g["B"] * len(self.caps) * ALG_BYTES_PER_SAMPLE_C2)
         ms = float(np.mean(self.fir_ms))
         achieved = alg_bytes / (ms * 1e-3) / 1e9
-        traffic, src = pmc_traffic(g["B"] * len(self.caps))
         kname = {self.capi.FIR_MFMA: "k_fir_mfma", self.capi.FIR_MFMA_BLK: "k_fir_mfma_stream"}.get(self.fir_arith, "k_fir_persist")
+        traffic, src = pmc_traffic(kname, g["B"] * len(self.caps))
+        ceil = measured_copy_ceiling()
         return {"kernel": kname + " (fir_filter)", "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "ceiling": ceil[0] if ceil else None, "ceiling_source": (f"measured streaming-read kernel (tools/membench.hip), recorded: {ceil[1]}" if ceil else None),
+                "frac_of_ceiling": round(achieved / ceil[0], 4) if ceil else None, "traffic": traffic,
                 "traffic_source": (f"recorded, not measured in this run: {src}" if src else None),
                 "avg_launch_ms": round(ms, 4), "launches_timed": len(self.fir_ms), "algorithmic_bytes_per_launch": alg_bytes,
                 "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE_C2, 4), "kernel_bytes": kernel_bytes,
@@ -496,6 +516,67 @@ def summary_of(out):
         sm["cpu_ref_all_cores"] = [round(out["cpu_baseline"]["value"]), None, None]
     sm["_cols"] = "MS/s, frac of 8 TB/s on SURVEY 8(d) bytes, pass"
     return sm
+
+
+
+LINE_LIMIT = 4096     # bytes of the one JSON line on stdout (the driver keeps an 8 KB tail and parses the last line)
+
+
+def _short(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "…"
+
+
+def compact_line(out):
+    """The ONE stdout line: the contract's keys + `roofline` + `cpu_baseline` + the verdict of the in-run verification + the
+    one-row-per-configuration summary, ≤ LINE_LIMIT bytes.  Everything else (`more`, per-capture verification reports, long
+    descriptions) goes to bench_full.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: out[k] for k in keep if k in out}
+    cfg = out.get("config") or {}
+    line["config"] = {k: (_short(v, 200) if k == "workload" else _short(v, 60)) for k, v in cfg.items()
+                      if k in ("workload", "fir_arith", "batches_per_step", "batch_samples_per_capture", "captures_per_gpu", "samples_per_step_per_gpu",
+                               "rx_mode", "rx_tile", "parallelism", "symbols_per_step", "c1_captures", "capture_samples")}
+    r = out.get("roofline")
+    if isinstance(r, dict):
+        line["roofline"] = {k: _short(r[k], 80) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ceiling", "frac_of_ceiling", "traffic",
+                                                          "traffic_source", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
+                                                          "algorithmic_bytes_per_sample") if k in r}
+    c = out.get("cpu_baseline")
+    if isinstance(c, dict):
+        line["cpu_baseline"] = {k: _short(c[k], 230) for k in ("value", "unit", "cores", "kind", "one_core", "sample") if k in c}
+    v = out.get("verified")
+    if isinstance(v, dict):
+        line["verified"] = {k: v[k] for k in ("pass", "batches", "captures_checked", "fir_bit_exact", "count_equal", "first_tile_bit_exact", "equal_decisions",
+                                              "mean_abs_dcost", "p99_abs_dcost", "max_abs_dcost", "bad_seams", "fir_max_rel_err_vs_exact",
+                                              "ts_identical", "ranks_passed", "ranks") if k in v}
+    if "summary" in out:
+        line["summary"] = out["summary"]
+    if "full" in out:
+        line["full"] = out["full"]
+    txt = json.dumps(line, separators=(",", ":"))
+    if len(txt.encode()) > LINE_LIMIT:            # never outgrow the driver's parser again: drop the optional parts, largest first
+        for k in ("summary", "verified", "full"):
+            line.pop(k, None)
+            txt = json.dumps(line, separators=(",", ":"))
+            if len(txt.encode()) <= LINE_LIMIT:
+                break
+    return txt
+
+
+def emit(out):
+    """Full record → bench_full.json (repo root, and gpurun_out/ when that exists: it is what travels back from the GPU box);
+    compact record → the single stdout line."""
+    paths = []
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_full.json"), "w") as f:
+                    json.dump(out, f)
+                paths.append(os.path.relpath(os.path.join(d, "bench_full.json"), ROOT))
+            except OSError:
+                pass
+    out = dict(out, full=paths[-1] if paths else None)
+    print(compact_line(out), flush=True)
 
 
 def main():
@@ -565,7 +646,7 @@ def main():
             raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {capi.lib.lsdr_device_count()} visible")
         out, rc = bench_c1.run_workload(capi, local_rank, args, shard)
         if rank == 0:
-            print(json.dumps(out), flush=True)
+            emit(out)
         shard.close()
         sys.exit(rc)
 
@@ -660,8 +741,8 @@ def main():
         if cpu is not None:   # reported at N=1 only
             assert np.array_equal(c0, coeffs), "cpu_baseline used other filter coefficients than the GPU path"
             out["cpu_baseline"] = cpu
-        out["summary"] = summary_of(out)      # LAST key: a log that keeps only the tail of this line still has every configuration
-        print(json.dumps(out), flush=True)
+        out["summary"] = summary_of(out)
+        emit(out)
     shard.close()
     sys.exit(rc)
 

@@ -110,3 +110,42 @@ def test_bench_default_geometry():
     assert (a.batch_msamples, a.batches_per_step) == (16, 768)
     a = bench.resolve_defaults(argparse.Namespace(captures=1, batch_msamples=256, batches_per_step=6))
     assert a.batches_per_step == 6 and a.more_batch_msamples == 64
+
+
+def test_bench_line_stays_small():
+    """The driver parses the LAST stdout line and keeps an 8 KB tail: round 4's 28.7 KB line came back `parsed: null`.  The
+    line bench.py prints is compact_line() of the full record — under 4 KB whatever the full record holds, with the contract's
+    keys, `roofline` and `cpu_baseline` in it; the full record goes to bench_full.json."""
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    for rec in ("profiles/r04_bench/bench.json", "profiles/r04_bench/c1.json"):
+        full = json.load(open(os.path.join(ROOT, rec)))
+        full["more"] = {f"extra{i}": {"value": 1.0, "note": "x" * 4000} for i in range(40)}       # however much detail there is
+        full.setdefault("verified", {})["per_capture"] = [{"blob": "y" * 3000}] * 16
+        line = bench.compact_line(full)
+        assert len(line.encode()) <= bench.LINE_LIMIT < 8192 and "\n" not in line
+        got = json.loads(line)
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in got, k
+        assert "workload" in got["config"] and "more" not in got
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in got["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in got["cpu_baseline"], k
+    # a summary that outgrew the line is dropped before the contract's keys are
+    full["summary"] = {f"row{i}": [1, 2, True] for i in range(2000)}
+    got = json.loads(bench.compact_line(full))
+    assert "summary" not in got and "roofline" in got and "cpu_baseline" in got
+
+
+def test_recorded_traffic_is_keyed_by_kernel():
+    """roofline.traffic is a RECORDED figure (PMC passes under profiles/): it must come from the same kernel at the same launch
+    size, never from another kernel that happened to run the same batch."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t, src = bench.pmc_traffic("k_fir_mfma_stream", 268369920)
+    assert t and "pmc_traffic.json" in src
+    assert bench.pmc_traffic("k_fir_persist", 268369920) == (None, None) or "k_fir_persist" in open(os.path.join(ROOT, bench.pmc_traffic("k_fir_persist", 268369920)[1])).read()
+    assert bench.pmc_traffic("k_fir_mfma_stream", 12345) == (None, None)
