@@ -222,10 +222,13 @@ class Capture:
             print("ptrs d_in %x dec %s d_sym %x" % (self.d_in.ptr, " ".join("%x" % d.ptr for d in self.dec), self.d_sym.ptr), file=sys.stderr)
         self.rx = capi.CstlnReceiver(self.ctx_rx, mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1], **rx_kw)
         self.ev_rx = [self.ctx_rx.event() for _ in range(geo["nbuf"])]
+        self.d_sym_mid = None       # copy of the symbols of the MIDDLE batch of a verified region (made in stream order)
         self.queued = 0
         self.retired = 0
         self.nsym = 0
         self.last_produced = 0
+        self.mid_run = -1           # retire index of that batch's run; mid_produced = its symbol count
+        self.mid_produced = 0
 
     def acquire(self, fir, rx_kw):
         """The exact serial loop locks on the head of the stream; the tiled (tracking) receiver takes over from that
@@ -242,6 +245,8 @@ class Capture:
         while self.queued > keep:
             self.queued -= 1
             self.last_produced = self.rx.wait()
+            if self.retired == self.mid_run:
+                self.mid_produced = self.last_produced
             self.retired += 1
             if timed:
                 self.nsym += self.last_produced
@@ -249,6 +254,8 @@ class Capture:
     def close(self):
         self.rx.close()
         self.d_in.free(); self.d_sym.free()
+        if self.d_sym_mid is not None:
+            self.d_sym_mid.free()
         for d in self.dec:
             d.free()
         if self.own_rx_ctx:
@@ -313,6 +320,7 @@ class C2Pipeline:
         self.batch_no = 0
         self.reshifts = 0
         self.snap = None            # (capture, dec buffer index) of the batch whose loop state was snapshotted
+        self.snap_mid, self.last_k = None, -1
 
     def run(self, n_batches, timed, snapshot_last=False, track_tol=None):
         """Queue n_batches batches of every capture.  Per batch: fir_filter(k) of all captures in one launch on the fir
@@ -325,6 +333,10 @@ class C2Pipeline:
         while timed and len(self.ev_pool) < 2 * n_batches:
             self.ev_pool.append(self.ctx.event())
         consumed = 0
+        # verified regions keep two batches: the LAST one (loop-state snapshot slot 0, symbols still in d_sym afterwards) and one in
+        # the MIDDLE (slot 1; its symbols are copied aside on the receiver's stream right behind its run — 9 MB, device to device)
+        k_mid = n_batches // 2 - 1 if snapshot_last and n_batches >= 4 else -1
+        self.snap_mid = None
         prof = os.environ.get("LSDR_BENCH_HOSTPROF") and timed        # host-side seconds per call category (diagnostic)
         tp = [0.0, 0.0, 0.0, 0.0]
         pc = time.perf_counter
@@ -347,24 +359,33 @@ class C2Pipeline:
             if self.rx_multi:
                 if snapshot_last and k == n_batches - 1:
                     self.snap = (0, i)
+                    self.last_k = k
                 for gi, cx in enumerate(self.ctx_rxs):
                     grp = caps[gi::self.rx_groups]
                     cx.wait_event(done)
-                    if snapshot_last and k == n_batches - 1:
+                    if (snapshot_last and k == n_batches - 1) or k == k_mid:
                         for c in grp:
-                            c.rx.snapshot_async()
+                            c.rx.snapshot_async(1 if k == k_mid else 0)
                     used = capi.CstlnReceiver.run_multi_async([c.rx for c in grp], [c.dec[i].ptr for c in grp], rx_n_in,
                                                               [c.d_sym.ptr for c in grp], n_out + EXTRA + 256)
-                    assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
+                    assert all(u == n_out for u in used), (used, n_out)          # the stream continues exactly at the next batch
+                    if k == k_mid:
+                        for c in grp:
+                            self._keep_mid(c, k, i)
                 for c in caps:
                     c.queued += 1
             for c in ([] if self.rx_multi else caps):
                 c.ctx_rx.wait_event(done)
                 if snapshot_last and k == n_batches - 1:
-                    c.rx.snapshot_async()
+                    c.rx.snapshot_async(0)
                     self.snap = (0, i)
+                    self.last_k = k
+                if k == k_mid:
+                    c.rx.snapshot_async(1)
                 used = c.rx.run_async(c.dec[i].ptr, rx_n_in, c.d_sym.ptr, n_out + EXTRA + 256)
                 assert used == n_out, (used, n_out)          # the stream continues exactly at the next batch
+                if k == k_mid:
+                    self._keep_mid(c, k, i)
                 c.queued += 1
             consumed += B * len(caps)
             if prof: t_c = pc(); tp[1] += t_c - t_b
@@ -387,17 +408,36 @@ class C2Pipeline:
                 self.fir_ms.append(self.ctx.event_elapsed_ms(self.ev_pool[2 * k], self.ev_pool[2 * k + 1]))
         return consumed
 
+    def _keep_mid(self, c, k, i):
+        """Right behind the middle batch's receiver run, on its stream: its symbols aside (the next run overwrites d_sym)."""
+        g = self.geo
+        nbytes = (g["n_out"] + self.extra + 256) * 4
+        if c.d_sym_mid is None:
+            c.d_sym_mid = c.ctx_rx.alloc(nbytes)
+        self.capi.check(self.capi.lib.lsdr_memcpy_d2d(c.ctx_rx.h, c.d_sym_mid.ptr, c.d_sym.ptr, nbytes))
+        c.mid_run = c.retired + c.queued          # this run's place in the capture's retire order
+        self.snap_mid = (k, i)
+
     def sync(self):
         self.ctx.sync()
         for c in self.caps:
             c.ctx_rx.sync()
 
     def verify_last_batch(self):
-        """The last queued batch of EVERY capture against the CPU oracle (test infrastructure, used as the checker only):
-        fir_filter output bit for bit; soft symbols vs the oracle's exact serial receiver started from the loop state the
-        device used for this batch, under leansdr_amd.tolerance.TOL."""
+        """The LAST queued batch and one from the MIDDLE of the region, of EVERY capture, against the CPU oracle (test
+        infrastructure, used as the checker only): fir_filter output bit for bit; soft symbols vs the oracle's exact serial
+        receiver started from the loop state the device used for that very batch (snapshots taken in stream order), under
+        leansdr_amd.tolerance.TOL.  A drift that built up over the queue would show in the last batch's state-restarted check
+        only if it broke that batch; the middle batch is a second, independent sample of the queue."""
         caps = [self._verify_capture(ci) for ci in range(len(self.caps))]
-        out = dict(batch="last batch of the timed region", captures_checked=len(caps), tolerance=TOL, per_capture=caps,
+        batches = []
+        if self.snap_mid is not None:
+            batches.append(dict(batch_index=self.snap_mid[0], which="middle", pass_=all(c["mid"]["pass"] for c in caps),
+                                max_abs_dcost=max(c["mid"]["max_abs_dcost"] for c in caps), equal_decisions=min(c["mid"]["equal_decisions"] for c in caps)))
+        batches.append(dict(batch_index=self.last_k, which="last", pass_=all(c["last_pass"] for c in caps)))
+        for b in batches:
+            b["pass"] = bool(b.pop("pass_"))
+        out = dict(batch="last batch of the timed region + one middle batch", batches=batches, captures_checked=len(caps), tolerance=TOL, per_capture=caps,
                    checker="oracle/liblsdr_oracle.so (fir_filter; serial receiver from the device's loop state)",
                    checker_seconds=round(sum(c.pop("checker_seconds") for c in caps), 2))
         for k in ("fir_bit_exact", "count_equal", "first_tile_bit_exact"):
@@ -405,6 +445,8 @@ class C2Pipeline:
         out["equal_decisions"] = min(c.get("equal_decisions", 0.0) for c in caps)
         for k in ("mean_abs_dcost", "p99_abs_dcost", "max_abs_dcost", "bad_seams"):
             out[k] = max(c.get(k, 1e9) for c in caps)
+        if any("fir_max_rel_err_vs_exact" in c for c in caps):
+            out["fir_max_rel_err_vs_exact"] = max(c.get("fir_max_rel_err_vs_exact") or 1.0 for c in caps)
         out["pass"] = bool(all(c["pass"] for c in caps))
         return out
 
@@ -461,7 +503,22 @@ class C2Pipeline:
             bad = np.flatnonzero((y_want.real != y.real) | (y_want.imag != y.imag))
             rep["fir_diff"] = dict(outputs_different=int(len(bad)), first=int(bad[0]) if len(bad) else None,
                                    note=None if len(bad) else "the last batch's buffer is right; an earlier batch's buffer differs")
-        rep["pass"] = bool(rep["pass"] and fir_ok and rep["consumed_equal"])
+        rep["last_pass"] = bool(rep["pass"] and fir_ok and rep["consumed_equal"])
+        rep["pass"] = rep["last_pass"]
+        if self.snap_mid is not None and cp.d_sym_mid is not None:
+            # the middle batch: same input bits (the stream is B-periodic; all buffers were just compared), its own loop state, its own symbols
+            st_mid = cp.rx.snapshot(1)
+            sym_mid = cp.ctx_rx.download(cp.d_sym_mid, capi.SOFTSYM, cp.mid_produced)
+            stm = po.RxState()
+            for k, _ in stm._fields_:
+                setattr(stm, k, getattr(st_mid, k))
+            ref_mid = O.rx(p, y_ref[:n_out + self.rx_extra], state_in=stm)
+            mid = check_tiled(sym_mid, ref_mid["sym"], None, first_exact=self.tile[1] // 4 - 8)
+            mid["state_differs_from_last"] = bool(any(getattr(st_mid, k) != getattr(st_dev, k) for k, _ in stm._fields_))
+            rep["mid"] = {k: mid[k] for k in ("pass", "count_equal", "first_tile_bit_exact", "equal_decisions", "mean_abs_dcost", "p99_abs_dcost",
+                                               "max_abs_dcost", "state_differs_from_last") if k in mid}
+            rep["pass"] = bool(rep["pass"] and mid["pass"])
+        rep["checker_seconds"] = time.perf_counter() - t0
         return rep
 
     def roofline(self):
@@ -629,8 +686,14 @@ def main():
     if args.dry_run:
         shard.barrier()
         total, dt, _ = shard.aggregate(1000.0 * (rank + 1), 1.0 + rank)
+        if args.workload == "c1":       # the noise seeds every rank WOULD give its captures (the same functions the real run calls)
+            import bench_c1
+            seeds = shard.gather_ints(bench_c1.capture_seeds(rank, args.c1_captures))
+        else:
+            seeds = shard.gather_ints([shard.capture_seed() + 1000 * c for c in range(args.captures)])
         if rank == 0:
-            print(json.dumps({"dry_run": True, "workload": args.workload, "n_gpus": world, "ranks": world, "units": total, "seconds": dt}), flush=True)
+            print(json.dumps({"dry_run": True, "workload": args.workload, "n_gpus": world, "ranks": world, "units": total, "seconds": dt,
+                              "capture_seeds_by_rank": seeds}), flush=True)
         shard.close()
         return
 

@@ -226,6 +226,11 @@ class Worker:
         self.ctx.close()
 
 
+def capture_seeds(rank, n_captures):
+    """Noise seeds of rank `rank`'s captures: 1000·(rank+1)+k — no two captures of a job share one (bench.py --dry-run prints them)."""
+    return [1000 * (rank + 1) + k for k in range(n_captures)]
+
+
 class C1Job:
     def __init__(self, capi, device, n_captures, msamples, workers, tile, warm, seed0):
         self.capi, self.device = capi, device
@@ -418,7 +423,7 @@ def cpu_reference(job, budget_s=20.0):
 def run_workload(capi, device, args, shard):
     """bench.py --workload c1.  Returns the JSON object of rank 0 (None on the other ranks)."""
     rank, world = shard.rank, shard.world
-    job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile, args.c1_warmup, seed0=1000 * (rank + 1))
+    job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile, args.c1_warmup, seed0=capture_seeds(rank, 1)[0])
     job.run(max(1, args.warmup))
     shard.barrier()
     t0 = time.perf_counter()
@@ -471,7 +476,7 @@ def run_workload(capi, device, args, shard):
     if world == 1 and args.c1_captures > 1 and not getattr(args, "no_single", False):
         # BASELINE config 4 as written — ONE capture per GPU: nothing hides the chain's data-dependent host waits, so this is a
         # latency figure (ms from the first sample to the last TS packet of a 128 Mi-sample capture), not the GPU's rate
-        one = C1Job(capi, device, 1, args.c1_msamples, 1, args.c1_tile, args.c1_warmup, seed0=1000 * (rank + 1))
+        one = C1Job(capi, device, 1, args.c1_msamples, 1, args.c1_tile, args.c1_warmup, seed0=capture_seeds(rank, 1)[0])
         one.run(1)
         t1 = time.perf_counter()
         reps = 3

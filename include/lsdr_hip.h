@@ -52,7 +52,15 @@ typedef struct { int16_t cost; uint8_t symbol; uint8_t pad; } lsdr_softsymbol; /
 typedef struct lsdr_ctx lsdr_ctx;
 int lsdr_abi_version(void);
 const char *lsdr_last_error(void);
-/* stream == NULL: the ctx creates (and owns) a non-blocking HIP stream. */
+/* stream == NULL: the ctx creates (and owns) a non-blocking HIP stream.
+ *
+ * PROCESS-WIDE SIDE EFFECT: the first context created in a process changes the C library's allocator policy for the WHOLE
+ * process — mallopt(M_MMAP_THRESHOLD, 32 MiB) and mallopt(M_TRIM_THRESHOLD, 2 GiB), once, thread-safe (glibc only).  Reason: when
+ * a host block of hundreds of KB is freed, glibc unmaps it; the amdgpu MMU notifier then suspends and restores every GPU queue of
+ * the process, and the next submission waits 20-25 ms (measured: viterbi_sync 25 ms per call instead of 4.5).  Consequence for the
+ * host application: freed host memory up to 32 MiB per block stays in the process heap instead of going back to the OS.  Set
+ * LSDR_KEEP_MALLOC=1 in the environment before the first context to leave the allocator alone (and accept the stalls, or keep
+ * your own large host buffers alive while GPU work is queued). */
 int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **ctx);
 /* A context whose stream may only use the compute units set in cu_mask (bit i of word i/32 = CU i): lets two blocks
  * that would disturb each other (the HBM-streaming fir_filter and the latency-bound receiver tiles) own disjoint parts of
@@ -164,8 +172,11 @@ int lsdr_auto_notch_set_overlap(lsdr_auto_notch *n, int on);
 /* LSDR_NOTCH_SCAN's cross-workgroup look-back spins are bounded: *aborted_run = 0 while all were served, else the number of the
  * first run in which one gave up (the next lsdr_auto_notch_run then fails instead of continuing from garbage) */
 int lsdr_auto_notch_check(lsdr_auto_notch *n, unsigned *aborted_run);
-/* test hook: garbage into the scan mode's hand-off buffers (totals and flags); a correct hand-off never reads it */
+#ifdef LSDR_MEASURE
+/* Measurement build only (make -C leansdr_amd/csrc measure; NOT in liblsdr_hip.so): garbage into the scan mode's hand-off buffers
+ * (totals and flags); a correct hand-off never reads it (tools/notch_poison_stress.py) */
 int lsdr_auto_notch_debug_poison(lsdr_auto_notch *n);
+#endif
 int lsdr_auto_notch_scan_time(lsdr_auto_notch *a, int enable, float *avg_ms, unsigned *launches);
 /* run(), sdr.h:64-75: whole 4096-sample blocks; *consumed == *produced.  Synchronous. */
 int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
@@ -311,7 +322,9 @@ int lsdr_rx_run(lsdr_rx *r, const void *in /* n_in items of cfg.in_format */, si
 int lsdr_rx_run_async(lsdr_rx *rx, const void *in, size_t n_in, lsdr_softsymbol *out, size_t cap_out, size_t *consumed);
 int lsdr_rx_wait(lsdr_rx *rx, size_t *produced);
 /* lsdr_rx_run_async for n_rx independent captures at once (one receiver per capture — the reference has one cstln_receiver
- * object per stream, sdr.h:697-938, leandvb.cc:163): equally long inputs ins[i] → outs[i], `consumed` per capture.  Receivers
+ * object per stream, sdr.h:697-938, leandvb.cc:163): equally long inputs ins[i] → outs[i]; `consumed` is an ARRAY of n_rx
+ * entries, consumed[i] = the samples receiver i takes (they differ only when the receivers are configured differently).  Every
+ * run is planned before anything is queued: on an argument error no receiver has been queued.  Receivers
  * on ONE context with the same configuration share their launches (four per batch instead of four per capture); any other
  * combination is queued receiver by receiver.  Same results as n_rx separate lsdr_rx_run_async calls, bit for bit; each
  * receiver is retired with its own lsdr_rx_wait. */
@@ -332,7 +345,8 @@ int lsdr_rx_tile_time(lsdr_rx *rx, int enable, float *avg_ms, unsigned *launches
 /* Loop-state snapshot between queued runs: lsdr_rx_snapshot_async() puts a copy of the device-side loop state (the fields
  * of cstln_receiver<f32>, sdr.h:923-935) into a pinned slot in stream order, i.e. the state the NEXT queued run starts
  * from; lsdr_rx_get_snapshot() waits for the stream and returns it.  Lets a caller (bench.py's verification) replay one
- * queued run on a checker from exactly the state the device used, without putting the host between two runs. */
+ * queued run on a checker from exactly the state the device used, without putting the host between two runs.  Four slots
+ * (`_slot` forms; the plain forms use slot 0), so that a batch in the middle of a long queue and the last one can both be kept. */
 /* Exact receiver, one GPU LANE per independent capture: n_streams captures with the same parameters (BASELINE config 4's
  * shape), each with its own loop state, every lane running cstln_receiver<f32>::run's exact arithmetic (sdr.h:772-916) →
  * bit-exact soft symbols and state per capture, 64 captures per wavefront.  `in_dev` / `out_dev` are HOST arrays of
@@ -349,6 +363,8 @@ int lsdr_rx_batch_get_state(lsdr_rx_batch *b, unsigned stream, lsdr_rx_state *st
 int lsdr_rx_decision_mode(const lsdr_rx *rx, int *arithmetic, unsigned *max_phase_error_delta);
 int lsdr_rx_snapshot_async(lsdr_rx *rx);
 int lsdr_rx_get_snapshot(lsdr_rx *rx, lsdr_rx_state *st);
+int lsdr_rx_snapshot_async_slot(lsdr_rx *rx, unsigned slot);
+int lsdr_rx_get_snapshot_slot(lsdr_rx *rx, unsigned slot, lsdr_rx_state *st);
 
 /* ================================================================== DVB-S FEC tail
  * Item layouts: bytes are u8; RS packets 204 B (rspacket<u8>), TS packets 188 B (tspacket). */

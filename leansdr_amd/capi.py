@@ -102,7 +102,8 @@ _sig("lsdr_auto_notch_slot_bin", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_set_mode", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_scan_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
-_sig("lsdr_auto_notch_debug_poison", C.c_int, [vp])
+if hasattr(lib, "lsdr_auto_notch_debug_poison"):       # the measure build only (make -C leansdr_amd/csrc measure)
+    _sig("lsdr_auto_notch_debug_poison", C.c_int, [vp])
 _sig("lsdr_auto_notch_set_overlap", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_check", C.c_int, [vp, C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
@@ -205,6 +206,7 @@ _sig("lsdr_derandomizer_pattern", None, [vp])
 _sig("lsdr_rs_tables", None, [vp, vp, vp])
 _sig("lsdr_rx_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz, vp, vp, vp, c_sz, psz, vp, c_sz, psz])
 _sig("lsdr_rx_run_async", C.c_int, [vp, vp, c_sz, vp, c_sz, psz])
+_sig("lsdr_rx_run_multi_async", C.c_int, [C.POINTER(vp), C.c_uint, C.POINTER(vp), c_sz, C.POINTER(vp), c_sz, psz])
 _sig("lsdr_rx_run_async_hs2", C.c_int, [vp, vp, c_sz, vp, c_sz, c_sz, psz])
 _sig("lsdr_rx_wait", C.c_int, [vp, psz])
 _sig("lsdr_rx_retired_freq_tap", C.c_float, [vp])
@@ -222,6 +224,8 @@ _sig("lsdr_rx_batch_get_state", C.c_int, [vp, C.c_uint, C.POINTER(RxState)])
 _sig("lsdr_rx_decision_mode", C.c_int, [vp, C.POINTER(C.c_int), C.POINTER(C.c_uint)])
 _sig("lsdr_rx_snapshot_async", C.c_int, [vp])
 _sig("lsdr_rx_get_snapshot", C.c_int, [vp, C.POINTER(RxState)])
+_sig("lsdr_rx_snapshot_async_slot", C.c_int, [vp, C.c_uint])
+_sig("lsdr_rx_get_snapshot_slot", C.c_int, [vp, C.c_uint, C.POINTER(RxState)])
 
 #: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [n for n in dir(lib) if n.startswith("lsdr_")]
@@ -514,13 +518,13 @@ class CstlnReceiver:
         check(lib.lsdr_rx_decision_mode(self.h, C.byref(a), C.byref(d)))
         return dict(arithmetic=bool(a.value), max_phase_error_delta=d.value)
 
-    def snapshot_async(self):
-        """Copy the device-side loop state into the receiver's pinned slot, in stream order (between queued runs)."""
-        check(lib.lsdr_rx_snapshot_async(self.h))
+    def snapshot_async(self, slot=0):
+        """Copy the device-side loop state into one of the receiver's four pinned slots, in stream order (between queued runs)."""
+        check(lib.lsdr_rx_snapshot_async_slot(self.h, slot))
 
-    def snapshot(self):
+    def snapshot(self, slot=0):
         st = RxState()
-        check(lib.lsdr_rx_get_snapshot(self.h, C.byref(st)))
+        check(lib.lsdr_rx_get_snapshot_slot(self.h, slot, C.byref(st)))
         return st
 
     def tiled_stats(self):
@@ -537,14 +541,14 @@ class CstlnReceiver:
     @staticmethod
     def run_multi_async(rxs, in_ptrs, n_in, out_ptrs, cap_out):
         """lsdr_rx_run_multi_async: one tiled run of every receiver in `rxs` (equally long inputs) with shared launches; returns the
-        samples each will consume.  Each receiver is retired with its own wait()."""
+        LIST of samples each receiver will consume.  Each receiver is retired with its own wait()."""
         n = len(rxs)
         hs = (vp * n)(*[r.h for r in rxs])
         ins = (vp * n)(*[p if isinstance(p, vp) else vp(p) for p in in_ptrs])
         outs = (vp * n)(*[p if isinstance(p, vp) else vp(p) for p in out_ptrs])
-        cons = c_sz()
-        check(lib.lsdr_rx_run_multi_async(hs, n, ins, n_in, outs, cap_out, C.byref(cons)))
-        return cons.value
+        cons = (c_sz * n)()
+        check(lib.lsdr_rx_run_multi_async(hs, n, ins, n_in, outs, cap_out, cons))
+        return [int(v) for v in cons]
 
     def run_async_hs2(self, in_ptr, n_in, out_ptr, out_sym_offset, cap_out):
         """Queue one tiled run of a SYM_HARD2 receiver writing its packed symbols from symbol out_sym_offset of `out_ptr`."""

@@ -1191,7 +1191,8 @@ struct lsdr_rx {
   rx_ema_map *d_ema;              // [tiles_cap] per-tile exclusive prefix inside its wavefront
   rx_ema_map *d_ema_wave;         // [tiles_cap + 1] per-wavefront estimator maps
   rx_state_dev *d_state_next;     // end state of a tiled run before k_rx_ema installs it
-  rx_state_dev *h_snap;           // pinned: lsdr_rx_snapshot_async target
+  rx_state_dev *h_snap;           // pinned: lsdr_rx_snapshot_async targets (kSnapSlots of them)
+  static constexpr unsigned kSnapSlots = 4;
   uint8_t *d_relabel;
   struct rx_seam_result *d_seam;
   struct rx_seam_part *d_part;
@@ -1430,7 +1431,7 @@ static int rx_tiled_plan(lsdr_rx *r, unsigned share, const void *in, size_t n_in
     if (e) lpw = atoi(e);
     if (lpw < 1 || (lpw > 32 && lpw != 64)) lpw = (unsigned long long)n_tiles * share > 12288ull ? 64 : 32;   // (estimator groups: ≤ 32, or two of 32)
     a.lanes_per_wave = (unsigned)lpw;
-    static const char *const d = getenv("LSDR_RX_DBG");
+    static const char *const d = LSDR_MEASURE_ENV("LSDR_RX_DBG");   // measure build only: timing-only tiles
     static const bool prio = getenv("LSDR_RX_PRIO") && atoi(getenv("LSDR_RX_PRIO"));
     a.dbg = (d ? (unsigned)atoi(d) & 3u : 0u) | (prio ? 4u : 0u);
   }
@@ -1554,10 +1555,12 @@ static int rx_tiled_enqueue(lsdr_rx *r, const void *in, size_t n_in, lsdr_softsy
 
 // Several receivers, one set of launches: see k_rx_tiles_multi.  The receivers must live on ONE context (stream), be configured
 // alike (soft symbols out, same sampler / input format / tile geometry / constellation) and get equally long inputs; anything
-// else is queued receiver by receiver — the same results either way.
+// else is queued receiver by receiver — the same results either way.  consumed[i] = what receiver i takes (they can differ on
+// the receiver-by-receiver paths: another omega with cap_out binding, the cu8 LDS-span cut).  EVERY run is planned before
+// anything is launched: an argument error leaves no receiver queued.
 static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *const *ins, size_t n_in, lsdr_softsymbol *const *outs,
                                   size_t cap_out, size_t *consumed) {
-  *consumed = 0;
+  for (unsigned i = 0; i < n; ++i) consumed[i] = 0;
   bool alike = n >= 2 && n <= (unsigned)kRxMulti;
   for (unsigned i = 1; i < n && alike; ++i) {
     const lsdr_rx *a = rs[0], *b = rs[i];
@@ -1567,28 +1570,24 @@ static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *co
             a->cfg.subsampling == b->cfg.subsampling && a->tabs.nrotations == b->tabs.nrotations;
   }
   if (alike) alike = rs[0]->cfg.out_format != LSDR_SYM_HARD2 && rs[0]->cfg.sampler != LSDR_SAMP_FIR && !rs[0]->time_on;
-  rx_plan P[kRxMulti];
-  if (alike) {
-    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_plan(rs[i], n, ins[i], n_in, outs[i], cap_out, false, 0, 0, &P[i]));
-    for (unsigned i = 1; i < n; ++i)
-      alike = alike && P[i].chunks == P[0].chunks && P[i].n_tiles == P[0].n_tiles && P[i].blocks == P[0].blocks && P[i].lpw == P[0].lpw &&
-              P[i].stage_stride == P[0].stage_stride && P[i].use_lds == P[0].use_lds;
-    if (!alike || !P[0].chunks) {      // plans exist already: run them one by one
-      for (unsigned i = 0; i < n; ++i) {
-        if (P[i].chunks) LSDR_TRY(rx_tiled_launch(rs[i], P[i]));
-        LSDR_TRY(rx_tiled_commit(rs[i], P[i], rs[i]->ctx->stream, consumed));
-      }
-      return LSDR_OK;
+  std::vector<rx_plan> Pv(n);
+  rx_plan *P = Pv.data();
+  for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_plan(rs[i], alike ? n : 1u, ins[i], n_in, outs[i], cap_out, false, 0, 0, &P[i]));
+  for (unsigned i = 1; i < n && alike; ++i)
+    alike = P[i].chunks == P[0].chunks && P[i].n_tiles == P[0].n_tiles && P[i].blocks == P[0].blocks && P[i].lpw == P[0].lpw &&
+            P[i].stage_stride == P[0].stage_stride && P[i].use_lds == P[0].use_lds;
+  if (!alike || !P[0].chunks) {      // receiver by receiver, from the plans
+    for (unsigned i = 0; i < n; ++i) {
+      if (P[i].chunks) LSDR_TRY(rx_tiled_launch(rs[i], P[i]));
+      LSDR_TRY(rx_tiled_commit(rs[i], P[i], rs[i]->ctx->stream, &consumed[i]));
     }
-  } else {
-    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_enqueue(rs[i], ins[i], n_in, outs[i], cap_out, consumed, false, 0, nullptr));
     return LSDR_OK;
   }
   lsdr_rx *r = rs[0];
   lsdr_ctx *c = r->ctx;
-  static const bool skip = getenv("LSDR_RX_SKIP") != nullptr;     // measurement hook: no receiver kernels at all (results are garbage)
+  static const bool skip = LSDR_MEASURE_ENV("LSDR_RX_SKIP") != nullptr;     // measure build only: no receiver kernels at all (results are garbage)
   if (skip) {
-    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, consumed));
+    for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, &consumed[i]));
     return LSDR_OK;
   }
   rx_tiled_multi tm;
@@ -1623,7 +1622,7 @@ static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *co
   hipLaunchKernelGGL(k_rx_compact_multi, dim3(n_tiles, n), dim3(64), 0, c->stream, sm, n_tiles, R, quad, P[0].stage_stride,
                      (const uint8_t *)r->d_relabel);
   LSDR_HIP(hipGetLastError());
-  for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, consumed));
+  for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, &consumed[i]));
   return LSDR_OK;
 }
 
@@ -1788,7 +1787,7 @@ int lsdr_rx_create(lsdr_ctx *c, const lsdr_rx_cfg *cfg, lsdr_rx **out) {
   r->d_info = nullptr; r->d_fix = nullptr; r->d_part = nullptr; r->tiles_cap = 0;
   r->d_ema = nullptr; r->d_ema_wave = nullptr; r->h_snap = nullptr;
   LSDR_HIP(hipMalloc((void **)&r->d_state_next, sizeof(rx_state_dev)));
-  LSDR_HIP(hipHostMalloc((void **)&r->h_snap, sizeof(rx_state_dev), hipHostMallocDefault));
+  LSDR_HIP(hipHostMalloc((void **)&r->h_snap, lsdr_rx::kSnapSlots * sizeof(rx_state_dev), hipHostMallocDefault));
   r->d_wstage = nullptr; r->wstage_cap = 0;
   r->d_hstage = nullptr; r->hstage_cap = 0; r->d_hinfo = nullptr; r->out_sym_offset = 0;
   r->time_on = false; r->time_ms = 0; r->time_n = 0;
@@ -1867,20 +1866,22 @@ int lsdr_rx_decision_mode(const lsdr_rx *r, int *arithmetic, unsigned *max_phase
   return LSDR_OK;
 }
 
-int lsdr_rx_snapshot_async(lsdr_rx *r) {
-  LSDR_ARG(r);
+int lsdr_rx_snapshot_async_slot(lsdr_rx *r, unsigned slot) {
+  LSDR_ARG(r && slot < lsdr_rx::kSnapSlots);
   LSDR_HIP(hipSetDevice(r->ctx->device));
   if (r->st_dirty_host) { int rc = rx_push_state(r); if (rc) return rc; }
-  LSDR_HIP(hipMemcpyAsync(r->h_snap, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, r->ctx->stream));
+  LSDR_HIP(hipMemcpyAsync(r->h_snap + slot, r->d_state, sizeof(rx_state_dev), hipMemcpyDeviceToHost, r->ctx->stream));
   return LSDR_OK;
 }
+int lsdr_rx_snapshot_async(lsdr_rx *r) { return lsdr_rx_snapshot_async_slot(r, 0); }
 
-int lsdr_rx_get_snapshot(lsdr_rx *r, lsdr_rx_state *st) {
-  LSDR_ARG(r && st);
+int lsdr_rx_get_snapshot_slot(lsdr_rx *r, unsigned slot, lsdr_rx_state *st) {
+  LSDR_ARG(r && st && slot < lsdr_rx::kSnapSlots);
   LSDR_HIP(hipStreamSynchronize(r->ctx->stream));
-  rx_state_export(*r->h_snap, st);
+  rx_state_export(r->h_snap[slot], st);
   return LSDR_OK;
 }
+int lsdr_rx_get_snapshot(lsdr_rx *r, lsdr_rx_state *st) { return lsdr_rx_get_snapshot_slot(r, 0, st); }
 
 int lsdr_rx_tiled_stats(const lsdr_rx *r, unsigned *tiles, unsigned *dup, unsigned *miss, unsigned *bad_seams) {
   LSDR_ARG(r);

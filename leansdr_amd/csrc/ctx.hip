@@ -2,6 +2,7 @@
 #include <cstring>
 #include "lsdr_internal.h"
 #include <malloc.h>
+#include <mutex>
 
 static thread_local char g_err[512] = "";
 
@@ -55,14 +56,14 @@ static int ctx_create(int device, void *hip_stream, const uint32_t *cu_mask, uns
     // under rocprofv3, 4.5 ms with MALLOC_TRIM_THRESHOLD_ / MALLOC_MMAP_THRESHOLD_ raised — although none of those vectors is ever
     // touched by a transfer).  So the first context of a process tells malloc to keep what it has: blocks up to 32 MB come from the
     // heap, and the heap is not trimmed.  LSDR_KEEP_MALLOC=1 leaves the allocator alone.
-    static bool once = false;
-    if (!once) {
-      once = true;
+    // Contexts are created from many threads (one per capture): once per process, race-free.  Documented in include/lsdr_hip.h.
+    static std::once_flag once;
+    std::call_once(once, [] {
       if (!getenv("LSDR_KEEP_MALLOC")) {
         (void)mallopt(M_MMAP_THRESHOLD, 32 * 1024 * 1024);
         (void)mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
       }
-    }
+    });
   }
   lsdr_ctx *c = new lsdr_ctx();
   c->device = device;

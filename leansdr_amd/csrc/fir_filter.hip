@@ -1527,7 +1527,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
                 fa.numRegs, (size_t)fa.localSizeBytes, nb);
       }
     }
-    static const bool skip = getenv("LSDR_FIR_SKIP") != nullptr;   // measurement hook: after 16 launches, no filter kernel (stale outputs)
+    static const bool skip = LSDR_MEASURE_ENV("LSDR_FIR_SKIP") != nullptr;   // measure build only: after 16 launches, no filter kernel (stale outputs)
     static int launches = 0;
     if (!(skip && ++launches > 16))
       hipLaunchKernelGGL(k, dim3(grid), dim3(stream ? 64 : 64 * f->mf_W), lds_bytes, f->ctx->stream, a);

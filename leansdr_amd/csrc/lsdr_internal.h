@@ -36,6 +36,16 @@ struct lsdr_event {
   hipEvent_t ev;
 };
 
+// Environment hooks come in two kinds.  Tuning / test hooks (plain getenv in the sources; INTEGRATION.md §6 lists them) choose
+// among kernels and launch parameters that ALL give the documented results.  Measurement hooks skip or corrupt work (no filter
+// launch, no receiver kernels, timing-only tiles, poisoned hand-off buffers): they exist only in the `make measure` build
+// (-DLSDR_MEASURE → tools/variants/liblsdr_hip_measure.so); in the shipped library the macro does not even keep the name.
+#ifdef LSDR_MEASURE
+#define LSDR_MEASURE_ENV(name) getenv(name)
+#else
+#define LSDR_MEASURE_ENV(name) ((const char *)nullptr)
+#endif
+
 void lsdr_set_error(const char *fmt, ...);
 int lsdr_hip_fail(hipError_t e, const char *what, const char *file, int line);
 

@@ -1041,7 +1041,8 @@ int lsdr_auto_notch_slot_bin(const lsdr_auto_notch *a, int slot) {
   if (a->mode == LSDR_NOTCH_SCAN) (void)notch_scan_pull(const_cast<lsdr_auto_notch *>(a));
   return a->bins[slot];
 }
-// Test hook (tests/test_gpu_notch.py stress test): fill the scan mode's hand-off buffers — every wave-block total and every flag —
+#ifdef LSDR_MEASURE
+// Test hook of the measure build only (tools/notch_poison_stress.py, run by tests/test_gpu_notch.py): fill the scan mode's hand-off buffers — every wave-block total and every flag —
 // with garbage, as a stale or torn hand-off would leave them.  A correct protocol never reads a total whose flag does not carry
 // the CURRENT run's stamp, so the next run's output must not change by a bit.
 int lsdr_auto_notch_debug_poison(lsdr_auto_notch *a) {
@@ -1052,6 +1053,7 @@ int lsdr_auto_notch_debug_poison(lsdr_auto_notch *a) {
   LSDR_HIP(hipMemsetAsync(a->d_flags, 0xee, n * sizeof(unsigned), a->ctx->stream));     // no stamp this side of 4·10^9 runs
   return LSDR_OK;
 }
+#endif
 
 // Opt-in: the detect chain of a run (it reads the run's INPUT) goes to a side stream, where it overlaps the previous run's
 // k_notch_scan.  The side stream does not wait for earlier work on the context's stream, so the caller promises that an input

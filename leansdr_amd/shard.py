@@ -68,6 +68,16 @@ class Shard:
         self.dist.all_reduce(t)
         return float(t.item())
 
+    def gather_ints(self, values):
+        """Every rank's short list of integers, by rank (control plane only: seeds, counts)."""
+        if self.dist is None:
+            return [list(values)]
+        import torch
+        mine = torch.tensor([int(v) for v in values], device=self.device, dtype=torch.int64)
+        out = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(out, mine)
+        return [[int(v) for v in t.tolist()] for t in out]
+
     def aggregate(self, units_this_rank, seconds_this_rank):
         """Whole-job throughput: units over all ranks ÷ the slowest rank's time."""
         total = self.sum_over_ranks(units_this_rank)

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_symbols():
     src = open(os.path.join(ROOT, "include", "lsdr_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"#ifdef LSDR_MEASURE.*?#endif", "", src, flags=re.S)      # the measure build's extras are not part of the shipped ABI
     return sorted(set(re.findall(r"\b(lsdr_[a-z0-9_]+)\s*\(", src)))
 
 
@@ -57,3 +58,26 @@ def test_header_is_plain_c(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+MEASURE_HOOKS = ("LSDR_FIR_SKIP", "LSDR_RX_SKIP", "LSDR_RX_DBG", "lsdr_auto_notch_debug_poison")
+
+
+def test_no_work_skipping_hook_in_the_shipped_library(capi):
+    """Hooks that skip or corrupt work for measurements (no filter launch, no receiver kernels, timing-only tiles, poisoned hand-off
+    buffers) are compiled only into the measure build (-DLSDR_MEASURE): no environment variable can turn liblsdr_hip.so into a
+    no-op that still reports consumed/produced."""
+    blob = open(capi.LIB_PATH, "rb").read()
+    found = [h for h in MEASURE_HOOKS if h.encode() in blob]
+    assert not found, found
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    assert not hasattr(lib, "lsdr_auto_notch_debug_poison")
+
+
+def test_measure_build_has_them():
+    """... and the measure build (tools/variants/liblsdr_hip_measure.so, built by __graft_entry__.build()) does."""
+    path = os.path.join(ROOT, "tools", "variants", "liblsdr_hip_measure.so")
+    assert os.path.exists(path), "run: make -C leansdr_amd/csrc measure"
+    blob = open(path, "rb").read()
+    missing = [h for h in MEASURE_HOOKS if h.encode() not in blob]
+    assert not missing, missing

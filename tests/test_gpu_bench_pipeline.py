@@ -10,14 +10,24 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def pipe(capi):
+@pytest.fixture(scope="module", params=["exact", "blk"])
+def pipe(capi, request):
+    """Both filter arithmetics: `exact` (the reference's) and `blk` — what bench.py's headline times (--fir-arith blk)."""
     sys.path.insert(0, ROOT)
     import bench
     from leansdr_amd import synth
-    p = bench.C2Pipeline(capi, synth, 0, 3, 8, 4, (256, 256), seed0=5)     # 3 captures, batches of 2 x 4 Mi samples
+    arith = {"exact": capi.FIR_EXACT, "blk": capi.FIR_MFMA_BLK}[request.param]
+    p = bench.C2Pipeline(capi, synth, 0, 3, 8, 4, (256, 256), seed0=5, fir_arith=arith)     # 3 captures, batches of 2 x 4 Mi samples
     yield p
     p.close()
+
+
+def want_filter_output(pipe, oracle, x_full):
+    """What the decimated stream must equal BIT FOR BIT: the reference's arithmetic, or (blk) the oracle's stated blocked sums."""
+    g = pipe.geo
+    if pipe.fir_arith == pipe.capi.FIR_MFMA_BLK:
+        return oracle.fir_filter(pipe.coeffs, g["decim"], x_full, fma="blk", scale=75.0)[0]
+    return oracle.fir_filter(pipe.coeffs, g["decim"], oracle.scaler(75.0, x_full))[0]
 
 
 def test_every_batch_of_the_endless_stream_is_the_oracles_filter_output(pipe, oracle):
@@ -28,7 +38,7 @@ def test_every_batch_of_the_endless_stream_is_the_oracles_filter_output(pipe, or
     refs = []
     for cp in pipe.caps:
         x_full = np.concatenate([np.tile(cp.x, g["reps"]), cp.x[:bench.EXTRA * g["decim"] + g["N"]]])
-        refs.append(oracle.fir_filter(pipe.coeffs, g["decim"], oracle.scaler(75.0, x_full))[0].view(np.uint64))
+        refs.append(want_filter_output(pipe, oracle, x_full).view(np.uint64))
     for burst in (7, 12):
         pipe.run(burst, True)
         pipe.sync()
@@ -47,6 +57,10 @@ def test_bench_self_verification_passes(pipe):
     assert consumed == 9 * pipe.geo["B"] * len(pipe.caps)
     v = pipe.verify_last_batch()
     assert v["pass"], v
+    assert [b["batch_index"] for b in v["batches"]] == [3, 8]          # a MIDDLE batch and the last one, each from its own snapshot
+    assert all(b["pass"] for b in v["batches"])
+    if pipe.fir_arith != pipe.capi.FIR_EXACT:
+        assert v["fir_max_rel_err_vs_exact"] <= 1e-5
     assert v["fir_bit_exact"] and v["count_equal"] and v["first_tile_bit_exact"]
     assert v["equal_decisions"] >= bench.TOL["min_equal_decisions"] and v["mean_abs_dcost"] <= bench.TOL["max_mean_abs_dcost"]
     r = pipe.roofline()

@@ -44,6 +44,29 @@ def test_golden_c2_geometry(capi, ctx):
     f.close()
 
 
+@pytest.mark.parametrize("arith", ["fma", "mfma", "blk"])
+def test_golden_c2_geometry_tolerance_modes(capi, ctx, arith):
+    """The tolerance arithmetics against the REFERENCE-produced fixture (not only against their own restatements): at the C2 geometry,
+    real and shifted taps, every output within the stated bound 4e-6·Σ|c|·max|x| of the reference's — and the headline's
+    kernel (k_fir_mfma_stream for blk at D=30) is what runs."""
+    g, tab = gold("fir_filter.npz"), gold("tables.npz")
+    x = iq16_to_cf32(g["iq120"])
+    scale = float(g["scale"])
+    c = tab["lowpass_c2"]
+    bound = 4e-6 * float(np.abs(c).sum()) * float(np.abs(x).max()) * scale * np.sqrt(2)
+    for tag, freq in [("f0", 0.0), ("fshift", 0.0123), ("fneg", -0.004)]:
+        f = capi.FirFilter(ctx, c, 30, in_scale=scale, arith={"fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[arith])
+        if freq:
+            f.set_freq(freq)
+        y, cons = f.run(x)
+        want = g[f"c2_{tag}_out"]
+        assert len(y) == len(want) and cons == 30 * len(y)
+        err = float(np.abs(y.astype(np.complex128) - want.astype(np.complex128)).max())
+        assert err <= bound, (arith, tag, err, bound)
+        assert err <= 1e-5 * float(np.abs(want).max()), (arith, tag, err)      # bench.py's in-run bound: 1e-5 of full scale
+        f.close()
+
+
 GEOMS = [(313, 30), (313, 1), (21, 1), (21, 7), (2, 3), (64, 64), (1, 1), (1, 5), (40, 4), (100, 10), (33, 16),
          (257, 8), (500, 30), (31, 31), (200, 2), (75, 5), (640, 64), (90, 9)]
 

@@ -240,6 +240,8 @@ def test_multi_capture_runs_equal_separate_queued_runs(capi, ctx, oracle, fmt):
         for q in range(2):
             if multi:
                 used = capi.CstlnReceiver.run_multi_async(rxs, [d.at(pos * isz) for d in dins], half + 1, [o[q].ptr for o in outs], m)
+                assert len(used) == len(rxs) and len(set(used)) == 1       # one entry per capture; alike receivers take the same
+                used = used[0]
             else:
                 for r, d, o in zip(rxs, dins, outs):
                     used = r.run_async(d.at(pos * isz), half + 1, o[q].ptr, m)

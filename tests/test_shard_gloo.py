@@ -69,12 +69,21 @@ def test_bench_c1_workload_self_launches_ranks():
     assert len(lines) == 1, lines
     j = json.loads(lines[0])
     assert j["workload"] == "c1" and j["n_gpus"] == 2 and j["ranks"] == 2 and j["units"] == 3000.0
+    # every rank gives its captures their own noise seeds (gathered from the ranks, computed by the function the real run calls)
+    seeds = j["capture_seeds_by_rank"]
+    assert len(seeds) == 2 and all(len(s) == 16 for s in seeds)
+    flat = [v for s in seeds for v in s]
+    assert len(set(flat)) == len(flat) == 32 and seeds[0][0] == 1000 and seeds[1][0] == 2000
 
 
-def test_c1_job_gives_every_rank_its_own_captures():
-    """bench_c1.run_workload seeds rank r's captures with 1000·(r+1)+k: no two captures of a job share a noise seed."""
-    src = open(os.path.join(ROOT, "bench_c1.py")).read()
-    assert "seed0=1000 * (rank + 1)" in src and "seed0 + k" in src
+def test_c1_job_seeds_come_from_capture_seeds():
+    """C1Job(seed0=capture_seeds(rank, 1)[0]) numbers its captures seed0 + k = capture_seeds(rank, n)[k]."""
+    sys.path.insert(0, ROOT)
+    import bench_c1
+    for rank in (0, 1, 7):
+        s = bench_c1.capture_seeds(rank, 16)
+        assert s == [s[0] + k for k in range(16)] and s[0] == 1000 * (rank + 1)
+    assert not set(bench_c1.capture_seeds(0, 16)) & set(bench_c1.capture_seeds(1, 16))
 
 
 def test_bench_rejects_mismatched_launcher():
