@@ -624,14 +624,14 @@ def emit(out):
     """Full record → bench_full.json (repo root, and gpurun_out/ when that exists: it is what travels back from the GPU box);
     compact record → the single stdout line."""
     paths = []
-    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
-        if os.path.isdir(d):
-            try:
-                with open(os.path.join(d, "bench_full.json"), "w") as f:
-                    json.dump(out, f)
-                paths.append(os.path.relpath(os.path.join(d, "bench_full.json"), ROOT))
-            except OSError:
-                pass
+    override = os.environ.get("LSDR_BENCH_FULL")      # a caller that runs bench.py as a sub-process (bench_more.c1) names its own file
+    for fn in ([override] if override else [os.path.join(d, "bench_full.json") for d in (ROOT, os.path.join(ROOT, "gpurun_out")) if os.path.isdir(d)]):
+        try:
+            with open(fn, "w") as f:
+                json.dump(out, f)
+            paths.append(os.path.relpath(fn, ROOT))
+        except OSError:
+            pass
     out = dict(out, full=paths[-1] if paths else None)
     print(compact_line(out), flush=True)
 

@@ -689,11 +689,13 @@ def c1(capi, synth, device, args):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--no-cpu", "--steps", "45", "--warmup", "2"]
     if args.no_verify:
         cmd.append("--no-verify")
-    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500)
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if not lines:
-        return dict(value=None, unit="MS/s", **{"pass": False}, error=(r.stderr or r.stdout)[-1500:])
-    j = json.loads(lines[-1])
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:       # the child's stdout line is the compact record; its full record goes to a file of ours
+        full = os.path.join(td, "c1_full.json")
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, env=dict(os.environ, LSDR_BENCH_FULL=full))
+        if not os.path.exists(full):
+            return dict(value=None, unit="MS/s", **{"pass": False}, error=(r.stderr or r.stdout)[-1500:])
+        j = json.load(open(full))
     out = dict(value=j["value"], unit="MS/s", seconds=round(j["steps"] * j["ms_per_step"] / 1e3, 3), steps=j["steps"], ms_per_step=j["ms_per_step"],
                captures=j["config"]["captures_per_gpu"], workers=j["config"]["workers_per_gpu"], samples_per_capture=j["config"]["samples_per_capture"],
                ts_packets_per_capture=j["config"].get("ts_packets_per_capture"), rs_byte_errors_corrected=j["config"].get("rs_byte_errors_corrected"),
