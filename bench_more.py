@@ -225,7 +225,112 @@ def c2_mfma(capi, synth, device, args):
 
 
 def anf1(capi, synth, device, args):
-    """One capture: auto_notch(scan) on its own stream → fir_filter → cstln_receiver (queued), three stages in flight."""
+    """The reference's DEFAULT graph (leandvb.cc:103,296-301: auto_notch(1 slot) in front of fir_filter) on the FUSED block
+    lsdr_notch_fir: one complex-tap matrix-pipe filter pass over the raw samples + a recurrence at the decimated rate — the notched
+    stream never exists (8 B per sample instead of the 24 B of `anf1_scan`).  notch_fir(k+1) runs next to cstln_receiver(k−1).
+    Checked: the bin; the filter output from the stream start through the first detect against the oracle's chain
+    scaler → auto_notch → fir_filter in the reference's arithmetic (≤ 2e-5 of full scale); later runs against an earlier one at the same
+    phase of the periodic signal (the block's state carries over consistently)."""
+    import bench
+    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup), seed0=33,
+                            cw=(0.0137, 3.0), fir_arith=headline_arith(capi, args))
+    g, cp = pipe.geo, pipe.caps[0]
+    B, period, n_out, N, D, EXTRA = g["B"], g["period"], g["n_out"], g["N"], g["decim"], bench.EXTRA
+    ctx = pipe.ctx
+    # the endless stream: reps + 2 periods resident, run k reads from stream position F (≡ F mod period) on
+    d_x = ctx.alloc((B + 2 * period) * 8)
+    dp = ctx.upload(cp.x)
+    for r in range(g["reps"] + 2):
+        capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_x.at(r * period * 8), dp.ptr, period * 8))
+    ctx.sync(); dp.free()
+    nf = capi.NotchFir(ctx, pipe.coeffs, D, in_scale=75.0)
+    NB = 4
+    dec = [ctx.alloc((n_out + EXTRA + 64) * 8) for _ in range(NB)]
+    ev_nf = [ctx.event() for _ in range(NB)]
+    ev_rx = [cp.ctx_rx.event() for _ in range(NB)]
+    st = dict(F=0, k=0)
+
+    def nf_run(j):
+        cons, prod = nf.run_dev(d_x.at((st["F"] % period) * 8), B + 400, dec[j].ptr, n_out)
+        st["F"] += cons
+        return prod
+
+    # run 0 (the stream start: pass-through, then the first detect at block 1023): B/D − 11 outputs, kept for the check below
+    prod0 = nf_run(0)
+    assert prod0 == n_out - 11 and st["F"] == B - 330, (prod0, st["F"])
+    ctx.sync()
+    n_chk = min(prod0, (12 << 20) // D)
+    y0 = ctx.download(dec[0], np.complex64, n_chk)
+
+    def run(nb, timed):
+        for _ in range(nb):
+            st["k"] += 1
+            k = st["k"]; j = k % NB; jp = (k - 1) % NB
+            if k > NB:
+                ctx.wait_event(ev_rx[j])                      # the receiver run that read this buffer (batch k − NB) is done
+            prod = nf_run(j)
+            assert prod == n_out and st["F"] == (k + 1) * B - 330, (prod, st["F"])
+            if k >= 2:       # batch k−1 is complete once the head of batch k sits behind it (the receiver's read-ahead)
+                capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, dec[jp].at(n_out * 8), dec[j].ptr, EXTRA * 8))
+                ctx.event_record(ev_nf[jp])
+                cp.ctx_rx.wait_event(ev_nf[jp])
+                used = cp.rx.run_async(dec[jp].ptr, n_out + EXTRA, cp.d_sym.ptr, n_out + EXTRA + 256)
+                assert used == n_out
+                cp.ctx_rx.event_record(ev_rx[jp])
+                cp.queued += 1
+                cp.retire(False, keep=2)
+        cp.retire(False, keep=0)
+        pipe.sync()
+
+    t0 = time.perf_counter()
+    run(12, False)
+    nb = batches_for((time.perf_counter() - t0) / 12)
+    nf.pass_time(True)
+    def once():
+        run(nb, True)
+        return nb
+    nb_total, dt, _ = timed_at_least(once, lambda: None)
+    kms, klaunches = nf.pass_time(False)
+    # checks (after the clock): the bin, the stream start against the oracle chain, two runs one period-multiple apart against each other
+    want_bin = int(round(0.0137 * period) / period * 4096 + 0.5) % 4096
+    got_bin = nf.bin()
+    po = bench._oracle()
+    O = po.Oracle()
+    n_s = N + n_chk * D
+    xs = np.tile(cp.x, -(-n_s // period))[:n_s]
+    xn, _ = O.auto_notch(O.scaler(75.0, xs), 1, 1024 * 4096, 0.002, 0.0)
+    yr = O.fir_filter(pipe.coeffs, D, xn)[0][:n_chk]
+    m = min(len(yr), n_chk)
+    err = float(np.abs(y0[:m].astype(np.complex128) - yr[:m]).max() / np.abs(yr).max()) if m else 1.0
+    ja, jb = st["k"] % NB, (st["k"] - 2) % NB                  # batches k and k − 2: the same phase of the B-periodic signal
+    ya, yb = ctx.download(dec[ja], np.complex64, 1 << 20), ctx.download(dec[jb], np.complex64, 1 << 20)
+    drift = float(np.abs(ya - yb).max() / np.abs(ya).max())
+    ok = bool(got_bin == want_bin and m > (4096 * 1100) // D and err <= 2e-5 and drift <= 1e-5)
+    alg = int(B * bench.ALG_BYTES_PER_SAMPLE_C2)
+    out = dict(value=round(nb_total * B / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), batches=nb_total, notch_bin=got_bin, expected_bin=want_bin,
+               **{"pass": ok}, interferer="CW at 0.0137 cycles/sample, 3x the signal amplitude",
+               block="lsdr_notch_fir (auto_notch(1) fused into fir_filter: k_fir_mfma_stream<30,1,12,IV> + k_nf_scan), then cstln_receiver (tiled)",
+               checked=dict(outputs_vs_oracle_chain=int(m), max_rel_err_vs_reference_arithmetic=err, bound=2e-5,
+                            run_to_run_same_phase_max_rel_diff=drift, bound_run_to_run=1e-5),
+               pipeline_hbm_bytes_per_sample=round(8 + 3 * 8 / D, 3),
+               roofline={"kernel": "k_fir_mfma_stream<30,1,12,IV> (notch_fir filter pass, complex taps per detect interval)", "bound": "hbm",
+                         "achieved": round(alg / (kms * 1e-3) / 1e9, 2) if kms else None, "peak": bench.HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (kms * 1e-3) / 1e9 / bench.HBM_PEAK_GBS, 4) if kms else None,
+                         "hbm_frac": hbm_frac(nb_total * B / dt, bench.ALG_BYTES_PER_SAMPLE_C2),
+                         "avg_launch_ms": round(kms, 4), "launches_timed": klaunches, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                         "note": "HIP events around the filter pass on its stream (lsdr_notch_fir_time), the receiver running next to it; the "
+                                 "decimated-rate kernels (taps, head, scan, state) add 3 x 8/30 B per sample"})
+    nf.close()
+    for d in dec:
+        d.free()
+    d_x.free()
+    pipe.close()
+    return out
+
+
+def anf1_scan(capi, synth, device, args):
+    """One capture: auto_notch(scan) on its own stream → fir_filter → cstln_receiver (queued), three stages in flight (the separate blocks:
+    24 B per sample; ≤ 2e-5 of the reference's arithmetic for every bin)."""
     import bench
     pipe = bench.C2Pipeline(capi, synth, device, 1, getattr(args, "more_batch_msamples", 64), args.period_msamples, (args.tile_len, args.tile_warmup), seed0=33,
                             cw=(0.0137, 3.0), fir_arith=headline_arith(capi, args))
@@ -322,7 +427,7 @@ def c2_offset(capi, synth, device, args):   # (complex taps under the headline's
     the headline, feedback latency = queue depth (two batches) instead of a host wait after every batch."""
     import bench
     f0 = 1.0e6 / bench.FS                 # cycles per input sample
-    pipe = bench.C2Pipeline(capi, synth, device, 1, getattr(args, "more_batch_msamples", 64), args.period_msamples, (args.tile_len, args.tile_warmup),
+    pipe = bench.C2Pipeline(capi, synth, device, 1, args.batch_msamples, args.period_msamples, (args.tile_len, args.tile_warmup),
                             seed0=55, freq=f0, rx_freq=f0 * 30, fir_arith=headline_arith(capi, args))
     g = pipe.geo
     tol = float(np.float32(bench.FM / bench.FS * 0.1))
@@ -1095,7 +1200,7 @@ def end_to_end(capi, synth, device, args):
 def run_all(capi, synth, device, args):
     more = {}
     for name, fn in (("four_captures", four_captures), ("c2_exact", c2_exact), ("c2_fma", c2_fma), ("c2_mfma", c2_mfma), ("c2_rrc", c2_rrc),
-                     ("c2_cnr", c2_cnr), ("anf1", anf1),
+                     ("c2_cnr", c2_cnr), ("anf1", anf1), ("anf1_scan", anf1_scan),
                      ("c2_offset", c2_offset), ("c3", c3),
                      ("c5_rescoped", c5_rescoped), ("c1", c1), ("c1_hs", c1_hs_entry), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
         t0 = time.perf_counter()

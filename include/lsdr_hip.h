@@ -181,6 +181,37 @@ int lsdr_auto_notch_scan_time(lsdr_auto_notch *a, int enable, float *avg_ms, uns
 /* run(), sdr.h:64-75: whole 4096-sample blocks; *consumed == *produced.  Synchronous. */
 int lsdr_auto_notch_run(lsdr_auto_notch *a, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out,
                         size_t *consumed, size_t *produced);
+
+/* ---- notch_fir: auto_notch (one slot) FUSED into fir_filter — leandvb's default graph (`--anf 1`, leandvb.cc:103,296-301:
+ * auto_notch<f32>(…, 1, 0) feeding fir_filter<cf32,float>) without the notched stream ever existing.  The notch of sdr.h:119-138 is, per
+ * detect interval, the LTI filter (1 − k − p·z⁻¹)/(1 − p·z⁻¹), p = (1−k)·exp(j2π·bin/4096); composed with the decimating FIR it is ONE
+ * complex-tap decimating FIR over the raw samples (matrix pipe, 8 B per sample) plus a first-order recurrence at the decimated rate;
+ * detect() (FFT of the detect block, first maximum, sdr.h:76-118) runs on the device; outputs around a bin CHANGE are computed directly.
+ * TOLERANCE MODE (float32 with exact phases, not the reference's rounding sequence): same bins as the reference; every output within
+ * 5e-5 of the stream's full scale of fir_filter(auto_notch(x)) in the reference's arithmetic — 2e-5 for bins below 2048.  (The larger
+ * figure is the reference's own doing: its phasor table is cosf/sinf of an angle ROUNDED TO FLOAT, 2π·bin·i/4096 up to 25 736 rad for
+ * the negative-frequency bins, i.e. ±1e-3 rad of table noise that an exact-phase formulation does not reproduce.)
+ * Exists for nslots == 1, decim == 30, ncoeffs ≤ 330, cf32 input, agc set point 0; anything else: LSDR_E_UNSUPPORTED at create —
+ * use the two blocks.  `in` is the RAW stream at fir_filter's read position (the block keeps the 32 samples in front of it).
+ * One run = auto_notch::run over the whole 4096-sample blocks present, then fir_filter::run over what the notch released:
+ * *produced = (A − F − ncoeffs)/decim with A the notch's frontier (a multiple of 4096 of the stream), *consumed = *produced·decim.
+ * Queued on the context's stream.  cap_out must hold at least 150 outputs for the block to make progress. */
+typedef struct lsdr_notch_fir lsdr_notch_fir;
+typedef struct {
+  unsigned ncoeffs; const float *coeffs_host;   /* fir_filter's prototype taps (dsp.h:221-231) */
+  unsigned decim;
+  float in_scale;                               /* a fused scaler in front (0 or 1: none); rides on the taps */
+  int nslots;                                   /* auto_notch's slots: 1 */
+  int notch_decimation;                         /* auto_notch::decimation (0: 1024·4096, sdr.h:56) */
+  float k;                                      /* auto_notch::k (0: 0.002) */
+} lsdr_notch_fir_cfg;
+int lsdr_notch_fir_create(lsdr_ctx *ctx, const lsdr_notch_fir_cfg *cfg, lsdr_notch_fir **h);
+void lsdr_notch_fir_destroy(lsdr_notch_fir *h);
+int lsdr_notch_fir_set(lsdr_notch_fir *h, int decimation, float k);
+int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed, size_t *produced);
+int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h);   /* waits for the stream; −1: nothing detected yet */
+/* measurement hook: HIP events around the filter pass of every run while enabled (as lsdr_auto_notch_scan_time) */
+int lsdr_notch_fir_time(lsdr_notch_fir *h, int enable, float *avg_ms, unsigned *launches);
 /* cfft_engine<float>::inplace (dsp.h:56-116).  lsdr_cfft_run: the transform of one device block on the GPU (one workgroup,
  * in LDS, bit-identical butterflies) with the spectrum delivered to the host — what auto_notch::detect, cnr_fft and spectrum
  * use.  lsdr_cfft_host: the same arithmetic on host data (utility / cross-check). */

@@ -38,6 +38,11 @@ class FirCfg(C.Structure):
                 ("in_format", C.c_int), ("in_scale", c_f), ("arith", C.c_int)]
 
 
+class NotchFirCfg(C.Structure):
+    _fields_ = [("ncoeffs", C.c_uint), ("coeffs_host", vp), ("decim", C.c_uint), ("in_scale", c_f), ("nslots", C.c_int),
+                ("notch_decimation", C.c_int), ("k", c_f)]
+
+
 class RxCfg(C.Structure):
     _fields_ = [("sampler", C.c_int), ("ncoeffs", C.c_int), ("coeffs_host", vp), ("subsampling", C.c_int),
                 ("cstln", C.c_int), ("fec", C.c_int), ("harden", C.c_int), ("omega", c_f), ("freq", c_f),
@@ -107,6 +112,12 @@ if hasattr(lib, "lsdr_auto_notch_debug_poison"):       # the measure build only 
 _sig("lsdr_auto_notch_set_overlap", C.c_int, [vp, C.c_int])
 _sig("lsdr_auto_notch_check", C.c_int, [vp, C.POINTER(C.c_uint)])
 _sig("lsdr_auto_notch_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_notch_fir_create", C.c_int, [vp, C.POINTER(NotchFirCfg), C.POINTER(vp)])
+_sig("lsdr_notch_fir_destroy", None, [vp])
+_sig("lsdr_notch_fir_set", C.c_int, [vp, C.c_int, c_f])
+_sig("lsdr_notch_fir_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
+_sig("lsdr_notch_fir_slot_bin", C.c_int, [vp])
+_sig("lsdr_notch_fir_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
 _sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])
 _sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
 _sig("lsdr_cnr_fft_destroy", None, [vp])
@@ -914,6 +925,61 @@ class AutoNotch:
         out = self.ctx.download(dout, np.complex64, prod)
         din.free(); dout.free()
         return out
+
+
+class NotchFir:
+    """auto_notch<f32>(1 slot) fused into fir_filter<cf32,float> (leandvb's default graph, leandvb.cc:296-301): lsdr_notch_fir_*.
+    Tolerance mode; LsdrError (LSDR_E_UNSUPPORTED) for geometries without the fused kernel — use AutoNotch + FirFilter then."""
+
+    def __init__(self, ctx, coeffs, decim, in_scale=0.0, nslots=1, decimation=1024 * 4096, k=0.002):
+        self.ctx = ctx
+        self.coeffs = np.ascontiguousarray(coeffs, np.float32)
+        self.decim = decim
+        cfg = NotchFirCfg(len(self.coeffs), self.coeffs.ctypes.data, decim, in_scale, nslots, decimation, k)
+        h = vp()
+        check(lib.lsdr_notch_fir_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib.lsdr_notch_fir_destroy(self.h)
+            self.h = None
+
+    def bin(self):
+        return lib.lsdr_notch_fir_slot_bin(self.h)
+
+    def pass_time(self, enable=True):
+        """(mean ms, launches) of the filter pass (k_fir_mfma_stream, per-interval taps) since the previous call; then switches recording."""
+        ms, n = c_f(), C.c_uint()
+        check(lib.lsdr_notch_fir_time(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def run_dev(self, in_ptr, n_in, out_ptr, cap_out):
+        cons, prod = c_sz(), c_sz()
+        check(lib.lsdr_notch_fir_run(self.h, in_ptr, n_in, out_ptr, cap_out, C.byref(cons), C.byref(prod)))
+        return cons.value, prod.value
+
+    def run(self, x, step=None):
+        """The whole stream `x` through the block in runs of at most `step` samples (None: one run); returns (outputs, consumed)."""
+        x = np.ascontiguousarray(x, np.complex64)
+        din = self.ctx.upload(x) if len(x) else None
+        cap = len(x) // self.decim + 16
+        dout = self.ctx.alloc(cap * 8)
+        pos = nout = 0
+        while din is not None:
+            avail = len(x) - pos if step is None else min(len(x) - pos, step)
+            cons, prod = self.run_dev(din.at(pos * 8), avail, dout.at(nout * 8), cap - nout)
+            if not prod:
+                if step is None or avail == len(x) - pos:
+                    break
+                step *= 2          # a run needs a whole 4096-block beyond the filter's history: offer more
+                continue
+            pos += cons; nout += prod
+        out = self.ctx.download(dout, np.complex64, nout)
+        if din is not None:
+            din.free()
+        dout.free()
+        return out, pos
 
 
 class FastQpsk:

@@ -1115,6 +1115,22 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam_multi(rx_seam_multi m, u
   const rx_seam_rec &c = m.c[blockIdx.y];
   rx_seam_body<rx_tile_info, lsdr_softsymbol>(c.info, c.fix, n_tiles, omega, R, quad, c.part, c.stage, stage_stride, c.wstage, wstride, relabel);
 }
+// Seam pass and estimator scan in ONE launch: the scan (one workgroup per capture) neither reads what the seam pass writes nor the
+// other way round, and as a launch of its own it was 20 µs of a dependent chain next to fir_filter (4.8 µs alone).  blockIdx.x < the
+// seam blocks: seam pass; the block behind them: rx_ema_body.  An ordinary run is the case of one capture (with its measurement slots).
+static_assert(kEmaThreads == kSeamBlock, "one launch geometry for the seam pass and the estimator scan");
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam_ema_multi(rx_seam_multi m, rx_ema_multi em, unsigned n_tiles, float omega, int R, float quad,
+                                                                  unsigned stage_stride, unsigned wstride, const uint8_t *relabel,
+                                                                  unsigned n_groups, unsigned ema_group, rx_meas *meas, unsigned nm) {
+  const unsigned nsb = (n_tiles + kSeamBlock - 1) / kSeamBlock;
+  if (blockIdx.x == nsb) {
+    const rx_ema_rec &c = em.c[blockIdx.y];
+    rx_ema_body(c.wave, n_groups, c.ex, n_tiles, ema_group, c.next, c.state, meas, nm);
+    return;
+  }
+  const rx_seam_rec &c = m.c[blockIdx.y];
+  rx_seam_body<rx_tile_info, lsdr_softsymbol>(c.info, c.fix, n_tiles, omega, R, quad, c.part, c.stage, stage_stride, c.wstage, wstride, relabel);
+}
 __global__ __launch_bounds__(64) void k_rx_compact_multi(rx_seam_multi m, unsigned n_tiles, int R, float quad, unsigned stage_stride,
                                                          const uint8_t *relabel) {
   const rx_seam_rec &c = m.c[blockIdx.y];
@@ -1490,15 +1506,13 @@ static int rx_tiled_launch(lsdr_rx *r, const rx_plan &P) {
 #undef LSDR_RX_LAUNCH
 #undef LSDR_RX_LAUNCH_F
   LSDR_HIP(hipGetLastError());
-  // estimators (AGC, MER) of the run: scan of the tiles' maps; installs the end state
-  hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema_wave, rx_ema_groups(n_tiles, (unsigned)lpw),
-                     (const rx_ema_map *)r->d_ema, n_tiles, rx_ema_group((unsigned)lpw), (const rx_state_dev *)r->d_state_next, r->d_state,
-                     want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
-
-  // ---- seam pass + compaction, all on the stream
+  // ---- estimators (AGC, MER) of the run — scan of the tiles' maps, installs the end state —, seam pass, compaction: all on the stream
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
   if (hard) {
+    hipLaunchKernelGGL(k_rx_ema, dim3(1), dim3(kEmaThreads), 0, c->stream, (const rx_ema_map *)r->d_ema_wave, rx_ema_groups(n_tiles, (unsigned)lpw),
+                       (const rx_ema_map *)r->d_ema, n_tiles, rx_ema_group((unsigned)lpw), (const rx_state_dev *)r->d_state_next, r->d_state,
+                       want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
     hipLaunchKernelGGL(k_rx_seam_h, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
                        (const rx_tile_info_h *)r->d_hinfo, r->d_fix, n_tiles, r->omega, R, quad, r->d_part, (const uint8_t *)r->d_relabel);
     hipLaunchKernelGGL((k_rx_compact_h<rx_state_dev>), dim3((n_tiles + 63) / 64), dim3(64), 0, c->stream, (const unsigned *)r->d_hstage, hpitch,
@@ -1506,14 +1520,17 @@ static int rx_tiled_launch(lsdr_rx *r, const rx_plan &P) {
                        (const uint8_t *)r->d_relabel, n_tiles, R, quad, reinterpret_cast<unsigned *>(out),
                        (unsigned long long)r->out_sym_offset, r->d_state, r->h_res_dev + slot);
   } else {
-  hipLaunchKernelGGL((k_rx_seam<rx_tile_info, lsdr_softsymbol>), dim3((n_tiles + kSeamBlock - 1) / kSeamBlock), dim3(kSeamBlock), 0, c->stream,
-                     (const rx_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, R, quad, r->d_part,
-                     (const lsdr_softsymbol *)r->d_stage, stage_stride, (const lsdr_softsymbol *)r->d_wstage, sym_per_chunk,
-                     (const uint8_t *)r->d_relabel);
-  hipLaunchKernelGGL((k_rx_compact<lsdr_softsymbol, rx_state_dev>), dim3(n_tiles), dim3(64), 0, c->stream, (const lsdr_softsymbol *)r->d_stage,
-                     stage_stride, (const rx_tile_info *)r->d_info, (const rx_tile_fix *)r->d_fix,
-                     (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, R, quad, out, r->d_state,
-                     r->h_res_dev + slot);   // totals go straight into the pinned ring slot (no copy command)
+    rx_seam_multi sm;
+    rx_ema_multi em;
+    for (int i = 0; i < kRxMulti; ++i) {
+      sm.c[i] = rx_seam_rec{r->d_info, r->d_fix, r->d_part, r->d_stage, r->d_wstage, out, r->d_state, r->h_res_dev + slot};   // totals go straight into the pinned ring slot
+      em.c[i] = rx_ema_rec{r->d_ema_wave, r->d_ema, r->d_state_next, r->d_state};
+    }
+    hipLaunchKernelGGL(k_rx_seam_ema_multi, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock + 1, 1), dim3(kSeamBlock), 0, c->stream, sm, em, n_tiles,
+                       r->omega, R, quad, stage_stride, sym_per_chunk, (const uint8_t *)r->d_relabel, rx_ema_groups(n_tiles, (unsigned)lpw),
+                       rx_ema_group((unsigned)lpw), want_meas ? r->d_meas : nullptr, want_meas ? (unsigned)nm : 0u);
+    hipLaunchKernelGGL(k_rx_compact_multi, dim3((n_tiles + kCompactTiles - 1) / kCompactTiles, 1), dim3(64), 0, c->stream, sm, n_tiles, R, quad,
+                       stage_stride, (const uint8_t *)r->d_relabel);
   }
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
@@ -1614,13 +1631,13 @@ static int rx_tiled_enqueue_multi(lsdr_rx *const *rs, unsigned n, const void *co
 #undef LSDR_RXM_LAUNCH
 #undef LSDR_RXM_LAUNCH_F
   LSDR_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_rx_ema_multi, dim3(n), dim3(kEmaThreads), 0, c->stream, em, rx_ema_groups(n_tiles, P[0].lpw), n_tiles, rx_ema_group(P[0].lpw));
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  hipLaunchKernelGGL(k_rx_seam_multi, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock, n), dim3(kSeamBlock), 0, c->stream, sm, n_tiles, r->omega, R,
-                     quad, P[0].stage_stride, P[0].sym_per_chunk, (const uint8_t *)r->d_relabel);
-  hipLaunchKernelGGL(k_rx_compact_multi, dim3(n_tiles, n), dim3(64), 0, c->stream, sm, n_tiles, R, quad, P[0].stage_stride,
-                     (const uint8_t *)r->d_relabel);
+  hipLaunchKernelGGL(k_rx_seam_ema_multi, dim3((n_tiles + kSeamBlock - 1) / kSeamBlock + 1, n), dim3(kSeamBlock), 0, c->stream, sm, em, n_tiles, r->omega,
+                     R, quad, P[0].stage_stride, P[0].sym_per_chunk, (const uint8_t *)r->d_relabel, rx_ema_groups(n_tiles, P[0].lpw),
+                     rx_ema_group(P[0].lpw), (rx_meas *)nullptr, 0u);
+  hipLaunchKernelGGL(k_rx_compact_multi, dim3((n_tiles + kCompactTiles - 1) / kCompactTiles, n), dim3(64), 0, c->stream, sm, n_tiles, R, quad,
+                     P[0].stage_stride, (const uint8_t *)r->d_relabel);
   LSDR_HIP(hipGetLastError());
   for (unsigned i = 0; i < n; ++i) LSDR_TRY(rx_tiled_commit(rs[i], P[i], c->stream, &consumed[i]));
   return LSDR_OK;

@@ -69,6 +69,10 @@ struct fir_args {
   const float *mf_atab;
   unsigned mf_alen, mf_blocks;
   unsigned long long *trace;   // LSDR_FIR_TRACE builds: per-wave phase cycle sums
+  // k_fir_mfma_stream<…, IV = 1> (the fused auto_notch + fir_filter of notch.hip): the coefficient operand changes along the
+  // stream — mf_atab holds n_iv tables of KS·64 floats, table i serves the tiles from iv_tile_first[i] on (ascending, [0] = 0)
+  const unsigned *iv_tile_first;
+  unsigned n_iv;
 };
 
 // Staging is split into the global load (raw bits kept in two VGPRs) and the
@@ -862,7 +866,14 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
 // Decimations whose row stride needs no padding (2·D ≡ 4 mod 8: 10, 30) — LDS-direct loads write 1 KiB of consecutive bytes.
 typedef __attribute__((address_space(3))) void *fir_lds_ptr;
 
-template <int DT, int CP, int NQT>
+// IV = 1: the taps are a function of the position in the stream (fir_args::iv_tile_first): a wavefront walks its tiles in
+// ascending order, so it reloads the coefficient operand the (few) times it crosses into another interval — behind a vmcnt(0),
+// so that the hand-counted waits below never see these loads.  One stream per launch.
+// The IV launch is OVERSUBSCRIBED (32 workgroups per CU queued, each with a short tile list): with four 39 KB workgroups per CU a grid of
+// exactly the resident workgroups is only resident in full while nothing else holds LDS — next to cstln_receiver's staged tiles (9 KB
+// per wavefront) some workgroups started when others ENDED and the launch took 1.19 ms instead of 0.76 (256 Mi samples); with 16–32 per CU
+// the dispatcher deals the work: 0.80 ms.  (Tiles dealt by a per-XCD atomic counter, one returned atomic per tile: 0.96 ms alone — dropped.)
+template <int DT, int CP, int NQT, int IV = 0>
 __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr unsigned D = DT, SL = 1 + CP;
@@ -882,8 +893,11 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
 
   float bco[KS];
+  unsigned iv_cur = 0;
+  if (!IV) {
 #pragma unroll
-  for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[s * 64 + l];
+    for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[s * 64 + l];
+  }
 
   // The region of wave tile `lt` of a stream: row ρ = output-row p = lt·MW − (NQ−1) + ρ, i.e. samples
   // x[N + D·p − (D−1) … N + D·p]; region sample 0 is x[X0], X0 = N + 1 − D·NQ − FP + D·MW·lt (negative at the stream start:
@@ -920,6 +934,13 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
 #ifdef LSDR_STREAM_PRIO
   __builtin_amdgcn_s_setprio(LSDR_STREAM_PRIO);
 #endif
+  if (IV) {      // the interval of the first tile
+    const unsigned t0 = tile_of(ti);
+    while (iv_cur + 1 < a.n_iv && t0 >= a.iv_tile_first[iv_cur + 1]) ++iv_cur;
+#pragma unroll
+    for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (KS * 64) + s * 64 + l];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
   aim(tile_of(ti), true);
 #pragma unroll
   for (int P = 0; P < 8; ++P) refill(P);
@@ -953,6 +974,17 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * MW;
     float *const po = reinterpret_cast<float *>(a.outs[st]);
     aim(more ? tile_of(tn) : 0u, more);      // the refills of this iteration fetch the NEXT tile (an empty resource at the end: no traffic)
+    if (IV) {
+      unsigned iv = iv_cur;
+      while (iv + 1 < a.n_iv && tile >= a.iv_tile_first[iv + 1]) ++iv;
+      if (iv != iv_cur) {                    // (wave-uniform, a handful of times per launch)
+        iv_cur = iv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (KS * 64) + s * 64 + l];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
 
     const char *ap = smem_raw + a0;
     unsigned pa[2][2][KS];
@@ -1202,6 +1234,40 @@ fir_kernel_t pick_generic(int R, int mode) {
 }
 
 }  // namespace
+
+// The fused auto_notch + fir_filter block of notch.hip (lsdr_notch_fir_*): its matrix-pipe pass is k_fir_mfma_stream with complex taps
+// that change along the stream.  `align_n` = the fir_filter's ncoeffs (output m is aligned at sample align_n + m·D of `in`, dsp.h:246-262),
+// nq tap blocks of D = 30 are applied (taps align_n … nq·D − 1 reach back past the aligned window).
+int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf32 *out, size_t count, unsigned align_n, unsigned D, unsigned nq,
+                              const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile) {
+  if (D != 30 || nq != 12) { lsdr_set_error("notch_fir: the fused matrix-pipe pass exists for decimation 30 with 12 tap blocks"); return LSDR_E_UNSUPPORTED; }
+  const unsigned M = 128u - (nq - 1);
+  if (outputs_per_tile) *outputs_per_tile = M;
+  if (!count) return LSDR_OK;
+  fir_args a;
+  memset(&a, 0, sizeof(a));
+  a.in = in; a.out = (float2 *)out;
+  a.n_streams = 1;
+  a.ins[0] = in; a.outs[0] = (float2 *)out;
+  a.N = align_n; a.D = D;
+  a.count = count; a.n_in = n_in;
+  const size_t n_tiles = (count + M - 1) / M;
+  LSDR_ARG(n_tiles < (1ull << 31));
+  a.tiles_per_stream = (unsigned)n_tiles;
+  a.n_tiles = (unsigned)n_tiles;
+  a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
+  a.in_scale = 1.0f;
+  a.mf_atab = iv_tabs; a.mf_alen = 15 * 64; a.mf_blocks = nq;
+  a.iv_tile_first = iv_tile_first; a.n_iv = n_iv;
+  fir_kernel_t k = k_fir_mfma_stream<30, 1, 12, 1>;
+  const size_t lds_bytes = stream_lds(D, nq, true);
+  unsigned grid = a.tiles_per_xcd * 8;
+  const unsigned pg = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 32) + 7) / 8 * 8;
+  if (grid > pg) grid = pg;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds_bytes, c->stream, a);
+  LSDR_HIP(hipGetLastError());
+  return LSDR_OK;
+}
 
 #ifdef LSDR_FIR_TRACE
 static unsigned long long *g_fir_trace = nullptr;
@@ -1512,7 +1578,10 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     // (complex taps on the register-staged kernels: three workgroups per CU queued — two resident ones that start together stay in
     // step and leave the memory idle while both compute: 0.345 ms per 64 Mi against 0.157)
     static const bool wpc_env = getenv("LSDR_MFMA_WPC") != nullptr;
-    const int wpc = stream ? f->stream_wpc : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
+    // (stream kernel, complex taps: twice the matrix-pipe work per sample — the fourth wavefront of a CU pays: 0.190 → 0.151 ms per
+    // 64 Mi alone, 0.195 → 0.156 in the C2 pipeline; with real taps three leave the receiver's tiles room: 546 → 569 GS/s)
+    static const bool swpc_env = getenv("LSDR_MFMA_SWPC") != nullptr;
+    const int wpc = stream ? (cp && !swpc_env ? 4 : f->stream_wpc) : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
     const unsigned pg = (unsigned)(f->ctx->num_cu * wpc + 7) / 8 * 8;
     if (grid > pg) grid = pg;
     {

@@ -521,7 +521,7 @@ static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8
                      (const fq_tile_info *)r->d_info, r->d_fix, n_tiles, r->omega, 4, 16384.0f, r->d_part,
                      (const unsigned char *)r->d_stage, stage_stride, (const unsigned char *)r->d_wstage, sym_per_chunk,
                      (const uint8_t *)r->d_relabel);
-  hipLaunchKernelGGL((k_rx_compact<unsigned char, fq_state>), dim3(n_tiles), dim3(64), 0, c->stream,
+  hipLaunchKernelGGL((k_rx_compact<unsigned char, fq_state>), dim3((n_tiles + kCompactTiles - 1) / kCompactTiles), dim3(64), 0, c->stream,
                      (const unsigned char *)r->d_stage, stage_stride, (const fq_tile_info *)r->d_info,
                      (const rx_tile_fix *)r->d_fix, (const rx_seam_part *)r->d_part, (const uint8_t *)r->d_relabel, n_tiles, 4,
                      16384.0f, out, r->d_state, r->h_res_dev);

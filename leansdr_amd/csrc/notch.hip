@@ -573,6 +573,330 @@ __global__ __launch_bounds__(256) void k_notch_tables(const int *cand /*[ndet][k
   }
 }
 
+
+// ---------------------------------------------------------------- fused auto_notch (one slot) + fir_filter: "notch_fir"
+// leandvb's DEFAULT graph puts auto_notch(1 slot) in front of fir_filter (leandvb.cc:103,296-301).  As separate blocks that is three
+// kernels moving 24 B per input sample (scan 8 + 8, filter 8).  Fused, the notched stream never exists:
+//   auto_notch::process (sdr.h:119-138), one slot, gain 1:  estim[n] = k·x[n]·conj(e[n]) + (1−k)·estim[n−1],  out[n] = x[n] − estim[n]·e[n],
+//   e[n] = exp(jθn), θ = 2π·bin/4096.  With sub[n] = estim[n]·e[n]:  sub[n] = p·sub[n−1] + k·x[n],  p = (1−k)·exp(jθ)  —  the notch is the
+//   LTI filter  H(z) = (1 − k − p·z⁻¹) / (1 − p·z⁻¹)  (zero ON the unit circle at θ, pole at p).
+//   fir_filter (dsp.h:246-262) then takes  y[m] = Σ_i c[i]·out[N + m·D − i].  Since (1 − p^D z^−D) / (1 − p z⁻¹) = Σ_{j<D} p^j z^−j,
+//       y[m] − P·y[m−1] = Σ_t ρ[t]·x[N + m·D − t],     P = p^D,   ρ = c ∗ κ,   κ = [1−k, −k·p, −k·p², …, −k·p^{D−1}, −p^D]   (N + D taps),
+//   i.e. ONE decimating FIR with complex taps over the RAW samples (k_fir_mfma_stream<30, 1, 12, IV>: the matrix pipe, 8 B per sample)
+//   and a first-order recurrence at the DECIMATED rate (k_nf_scan: |P| = 0.94, a 512-output warm-up forgets the start to 4·10⁻¹⁴).
+// detect() (sdr.h:76-118) stays what it is — FFT of the detect block's input, first maximum — on the device (k_cfft_half, k_notch_peaks);
+// the taps of every detect interval of a run are built on the device from its bin (k_nf_taps), the filter pass picks them by tile.
+// Where a detect CHANGES the bin (estim ← 0, new e[]) the recurrence above does not hold for the outputs whose windows straddle the
+// change: those few outputs (and the rest of the tile that still ran with the old taps) are computed directly — notch recurrences over
+// a few thousand samples in one workgroup, then the filter sums (k_nf_fix) — and enter the scan as given values.
+// State between runs: the last output, the last D raw samples before the read pointer (the ρ window reaches D samples further back than
+// fir_filter's), the bin, and sub at the notch's frontier (so that a later bin change can reconstruct the old segment's estimator).
+// Arithmetic: float32 with exact phases — NOT the reference's rounding sequence: a tolerance mode (include/lsdr_hip.h states the bound).
+constexpr int kNfD = 30, kNfNq = 12, kNfKs = 15, kNfTaps = kNfD * kNfNq;   // 360 tap slots, N + D ≤ 360
+constexpr int kNfLook = 12288;            // samples an estimator remembers ((1−k)^12288 < 1e-8 is checked at run time, as in the scan mode)
+constexpr int kNfMaxDet = 64;             // detect points per run (the run is cut there)
+constexpr int kNfFixSpan = 4736;          // samples one fix-up stages (N + a tile and the transition outputs' windows)
+constexpr int kNfChunk = 2048, kNfWarm = 512, kNfPer = (kNfChunk + kNfWarm) / 256;   // k_nf_scan geometry
+
+struct nf_state {
+  float2 y_last;          // output M0−1
+  float2 sub;             // sub[A−1] of the current segment (0 before the first detect)
+  int bin, pad;           // −1: no detect yet
+  float2 carry[32];       // x[F−32 … F): the raw samples before the read pointer
+};
+
+struct nf_run {           // geometry of one run (kernel-argument segment)
+  int ndet;
+  unsigned mw;                                  // outputs per wave tile of the filter pass
+  unsigned long long count;                     // outputs of this run
+  unsigned long long a_prev_rel, a_rel;         // notch frontier before / after the run, relative to `in`
+  unsigned long long s_rel[kNfMaxDet];          // detect point q: first sample of its block, relative to `in`
+  unsigned m_lo[kNfMaxDet], m_hi[kNfMaxDet];    // outputs given directly if the bin changes there (run-relative, inclusive; lo > hi: none)
+  unsigned tile_first[kNfMaxDet + 1];           // interval q serves the filter tiles from tile_first[q] on ([0] = 0)
+};
+
+struct nf_consts { float k, omk, scale; int N; };
+
+__device__ __forceinline__ float2 nf_cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// p^e, p = omk·exp(j·2π·bin/4096): the phase by integer arithmetic (exact), the magnitude in double
+__device__ __forceinline__ float2 nf_ppow(int bin, float omk, long long e) {
+  const double mag = exp((double)e * log((double)omk));
+  const double ang = 2.0 * M_PI * (double)(((long long)bin * e) & 4095) / 4096.0;
+  return make_float2((float)(mag * cos(ang)), (float)(mag * sin(ang)));
+}
+// Σ_{n=lo}^{hi−1} p^{hi−1−n}·x[n] by a 256-thread workgroup (every thread gets the sum); x[n] = 0 for n < 0
+__device__ float2 nf_wsum(const float2 *x, long long lo, long long hi, int bin, float omk, float2 *sh /*[256]*/) {
+  const int t = threadIdx.x;
+  const long long L = hi > lo ? hi - lo : 0, per = (L + 255) / 256;
+  const long long b = lo + t * per, e = b + per < hi ? b + per : hi;
+  float2 acc = make_float2(0.f, 0.f);
+  if (b < e) {
+    const float2 p = nf_ppow(bin, omk, 1);
+    for (long long n = b; n < e; ++n) {
+      const float2 v = n >= 0 ? x[n] : make_float2(0.f, 0.f);
+      acc = nf_cmul(acc, p);
+      acc.x += v.x; acc.y += v.y;
+    }
+    acc = nf_cmul(acc, nf_ppow(bin, omk, hi - e));
+  }
+  __syncthreads();
+  sh[t] = acc;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { sh[t].x += sh[t + d].x; sh[t].y += sh[t + d].y; }
+    __syncthreads();
+  }
+  const float2 r = sh[0];
+  __syncthreads();
+  return r;
+}
+
+// the run's small arrays into device memory (k_cfft_half and the filter pass read them through pointers)
+__global__ __launch_bounds__(64) void k_nf_prep(nf_run r, const float2 *in, unsigned long long *d_offsets, unsigned *d_tile_first) {
+  for (int i = threadIdx.x; i < r.ndet; i += 64) d_offsets[i] = r.s_rel[i];
+  for (int i = threadIdx.x; i <= r.ndet; i += 64) d_tile_first[i] = r.tile_first[i];
+}
+
+// Interval q of a run (q = 0: up to the first detect point of the run, carried bin; q ≥ 1: from detect point q−1 on): its bin, whether
+// it differs from the interval before, P = p^D and the taps ρ = (scale·c) ∗ κ — in natural order (k_nf_head) and as the filter pass's
+// coefficient operand (lane (k = l>>4, q' = l&15) of step s: K slot e = 4·s + k of tap block q': tap D·q' + e/2 as (re, −im)).
+__global__ __launch_bounds__(256) void k_nf_taps(const nf_state *st, const int *cand /*[ndet][kMaxSlots]*/, const float *coeffs, nf_consts C,
+                                                 int *ivbin, unsigned char *changed, float2 *ivP, float2 *ivrho /*[·][kNfTaps]*/,
+                                                 float *ivtab /*[·][kNfKs·64]*/) {
+  __shared__ double kr[kNfD + 1], ki[kNfD + 1];
+  __shared__ double rr[kNfTaps], ri[kNfTaps];
+  const int q = blockIdx.x, t = threadIdx.x;
+  const int bin = q == 0 ? st->bin : cand[(q - 1) * kMaxSlots];
+  const int prev = q == 0 ? bin : (q == 1 ? st->bin : cand[(q - 2) * kMaxSlots]);
+  if (t <= kNfD) {
+    double re = 0, im = 0;
+    if (bin < 0) { re = t == 0 ? 1.0 : 0.0; }
+    else if (t == 0) { re = 1.0 - (double)C.k; }
+    else {
+      const double mag = exp((double)t * log((double)C.omk)), ang = 2.0 * M_PI * (double)((bin * t) & 4095) / 4096.0;
+      const double g = t < kNfD ? -(double)C.k : -1.0;
+      re = g * mag * cos(ang); im = g * mag * sin(ang);
+    }
+    kr[t] = re; ki[t] = im;
+  }
+  __syncthreads();
+  if (t == 0) {
+    ivbin[q] = bin; changed[q] = (unsigned char)(q > 0 && bin != prev);
+    ivP[q] = bin < 0 ? make_float2(0.f, 0.f) : make_float2((float)-kr[kNfD], (float)-ki[kNfD]);
+  }
+  for (int tt = t; tt < kNfTaps; tt += 256) {
+    double re = 0, im = 0;
+    for (int j = 0; j <= kNfD; ++j) {
+      const int i = tt - j;
+      if (i < 0 || i >= C.N) continue;
+      const double cs = (double)(coeffs[i] * C.scale);      // the fused scaler rides on the taps: one f32 rounding per tap (as LSDR_FIR_MFMA_BLK)
+      re += kr[j] * cs; im += ki[j] * cs;
+    }
+    rr[tt] = re; ri[tt] = im;
+    ivrho[(size_t)q * kNfTaps + tt] = make_float2((float)re, (float)im);
+  }
+  __syncthreads();
+  for (int idx = t; idx < kNfKs * 64; idx += 256) {
+    const int s = idx >> 6, ln = idx & 63, e = 4 * s + (ln >> 4), qq = ln & 15, r = e >> 1;
+    float v = 0.f;
+    if (qq < kNfNq && r < kNfD) v = (e & 1) ? (float)-ri[kNfD * qq + r] : (float)rr[kNfD * qq + r];
+    ivtab[(size_t)q * (kNfKs * 64) + idx] = v;
+  }
+}
+
+// r[0] of a run: its window reaches D − 1 samples back past `in` (the carried ones); the filter pass read zeros there
+__global__ __launch_bounds__(256) void k_nf_head(const float2 *in, const nf_state *st, const float2 *ivrho, int N, float2 *r) {
+  __shared__ float2 sh[256];
+  float2 acc = make_float2(0.f, 0.f);
+  for (int t = threadIdx.x; t < N + kNfD; t += 256) {
+    const int i = N - t;
+    const float2 x = i >= 0 ? in[i] : st->carry[32 + i];
+    const float2 v = nf_cmul(ivrho[t], x);
+    acc.x += v.x; acc.y += v.y;
+  }
+  sh[threadIdx.x] = acc;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if ((int)threadIdx.x < d) { sh[threadIdx.x].x += sh[threadIdx.x + d].x; sh[threadIdx.x].y += sh[threadIdx.x + d].y; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) r[0] = sh[0];
+}
+
+// which boundary before `q` (exclusive) last changed the bin in this run: its index, or −1 (the segment came in with the run)
+__device__ __forceinline__ int nf_seg_start(const unsigned char *changed, int q) {
+  for (int i = q - 1; i >= 1; --i) if (changed[i]) return i;
+  return -1;
+}
+
+// Detect point q (interval q+1 begins at sample S) changed the bin: the outputs [m_lo, m_hi] directly.
+__global__ __launch_bounds__(256) void k_nf_fix(nf_run run, const float2 *in, const nf_state *st, const int *ivbin, const unsigned char *changed,
+                                                const float *coeffs, nf_consts C, float2 *r) {
+  __shared__ float2 xs[kNfFixSpan];
+  __shared__ float2 sh[256];
+  const int q = blockIdx.x, t = threadIdx.x;
+  if (!changed[q + 1]) return;
+  const unsigned mlo = run.m_lo[q], mhi = run.m_hi[q];
+  if (mlo > mhi) return;
+  const long long S = (long long)run.s_rel[q];
+  const int N = C.N, bin_old = ivbin[q], bin_new = ivbin[q + 1];
+  const long long n_first = S - N, n_last = (long long)N + (long long)mhi * kNfD;
+  const int span = (int)(n_last - n_first + 1);          // ≤ kNfFixSpan by the run's geometry (host)
+  for (int i = t; i < span; i += 256) {
+    const long long n = n_first + i;
+    xs[i] = n >= 0 ? in[n] : make_float2(0.f, 0.f);
+  }
+  // the old segment's sub[S−1]
+  float2 sub_old = make_float2(0.f, 0.f);
+  if (bin_old >= 0) {
+    const int sg = nf_seg_start(changed, q + 1);
+    const bool carried = sg < 0;
+    const long long start = carried ? (long long)run.a_prev_rel : (long long)run.s_rel[sg - 1];
+    const long long lo = S - kNfLook > start ? S - kNfLook : start;
+    const float2 w = nf_wsum(in, lo, S, bin_old, C.omk, sh);
+    sub_old = make_float2(C.k * w.x, C.k * w.y);
+    if (carried && S - start <= kNfLook) {
+      const float2 c2 = nf_cmul(nf_ppow(bin_old, C.omk, S - start), st->sub);
+      sub_old.x += c2.x; sub_old.y += c2.y;
+    }
+  }
+  __syncthreads();
+  if (t == 0) {            // the two recurrences, sequentially (a few thousand steps, once per bin change)
+    const int iS = (int)(S - n_first);
+    if (bin_old >= 0) {
+      const float2 p = nf_ppow(bin_old, C.omk, 1);
+      const float inv = 1.0f / (p.x * p.x + p.y * p.y);
+      const float2 ip = make_float2(p.x * inv, -p.y * inv);
+      float2 s = sub_old;
+      for (int i = iS - 1; i >= 0; --i) {
+        const float2 x = xs[i];
+        xs[i] = make_float2(x.x - s.x, x.y - s.y);
+        s = nf_cmul(make_float2(s.x - C.k * x.x, s.y - C.k * x.y), ip);
+      }
+    }
+    {
+      const float2 p = nf_ppow(bin_new, C.omk, 1);
+      float2 s = make_float2(0.f, 0.f);
+      for (int i = iS; i < span; ++i) {
+        const float2 x = xs[i];
+        s = nf_cmul(p, s);
+        s.x += C.k * x.x; s.y += C.k * x.y;
+        xs[i] = make_float2(x.x - s.x, x.y - s.y);
+      }
+    }
+  }
+  __syncthreads();
+  for (unsigned m = mlo + t; m <= mhi; m += 256) {
+    const int top = (int)((long long)N + (long long)m * kNfD - n_first);
+    float2 acc = make_float2(0.f, 0.f);
+    for (int i = 0; i < N; ++i) {
+      const float cs = coeffs[i] * C.scale;
+      const float2 v = xs[top - i];
+      acc.x = fmaf(cs, v.x, acc.x); acc.y = fmaf(cs, v.y, acc.y);
+    }
+    r[m] = acc;
+  }
+}
+
+// y[m] = A_m·y[m−1] + r[m] over the run: A_m = P of the interval that served output m's filter tile, 0 where r[m] is a given value.
+// One workgroup per kNfChunk outputs, started kNfWarm outputs early from zero (block 0: from the carried output, exactly).
+struct nf_aff { float2 a, b; };     // y → a·y + b
+__device__ __forceinline__ nf_aff nf_then(const nf_aff &f, const nf_aff &g) {   // f first, then g
+  nf_aff o; o.a = nf_cmul(g.a, f.a); o.b = nf_cmul(g.a, f.b); o.b.x += g.b.x; o.b.y += g.b.y; return o;
+}
+__global__ __launch_bounds__(256) void k_nf_scan(nf_run run, const float2 *r, const nf_state *st, const float2 *ivP, const unsigned char *changed,
+                                                 float2 *out) {
+  __shared__ nf_aff sc[2][256];
+  __shared__ unsigned long long s_mask;
+  const int t = threadIdx.x;
+  const long long c0 = (long long)blockIdx.x * kNfChunk, base = c0 - kNfWarm, cnt = (long long)run.count;
+  const long long hi = c0 + kNfChunk < cnt ? c0 + kNfChunk : cnt;
+  if (t == 0) s_mask = 0ull;
+  __syncthreads();
+  if (t < run.ndet && changed[t + 1] && run.m_lo[t] <= run.m_hi[t] && (long long)run.m_hi[t] >= base && (long long)run.m_lo[t] < hi)
+    atomicOr(&s_mask, 1ull << t);
+  __syncthreads();
+  const unsigned long long mask = s_mask;
+  const long long i0 = base + (long long)t * kNfPer;
+  int iv = 0;
+  {
+    const long long mf = i0 > 0 ? i0 : 0;
+    const unsigned lt = (unsigned)(mf / run.mw);
+    while (iv < run.ndet && lt >= run.tile_first[iv + 1]) ++iv;
+  }
+  float2 A[kNfPer], B[kNfPer];
+  nf_aff loc; loc.a = make_float2(1.f, 0.f); loc.b = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int e = 0; e < kNfPer; ++e) {
+    const long long m = i0 + e;
+    float2 a = make_float2(1.f, 0.f), b = make_float2(0.f, 0.f);
+    if (m >= 0 && m < hi) {
+      const unsigned lt = (unsigned)(m / run.mw);
+      while (iv < run.ndet && lt >= run.tile_first[iv + 1]) ++iv;
+      a = ivP[iv];
+      b = r[m];
+      if (mask) {
+        for (int q = 0; q < run.ndet; ++q)
+          if ((mask >> q & 1ull) && m >= (long long)run.m_lo[q] && m <= (long long)run.m_hi[q]) a = make_float2(0.f, 0.f);
+      }
+    }
+    A[e] = a; B[e] = b;
+    nf_aff g; g.a = a; g.b = b;
+    loc = nf_then(loc, g);
+  }
+  sc[0][t] = loc;
+  __syncthreads();
+  int cur = 0;
+  for (int d = 1; d < 256; d <<= 1) {
+    nf_aff v = sc[cur][t];
+    if (t >= d) v = nf_then(sc[cur][t - d], v);
+    sc[cur ^ 1][t] = v;
+    cur ^= 1;
+    __syncthreads();
+  }
+  float2 y = blockIdx.x == 0 ? st->y_last : make_float2(0.f, 0.f);     // value in front of the block's first element
+  if (t > 0) {
+    const nf_aff ex = sc[cur][t - 1];
+    const float2 ay = nf_cmul(ex.a, y);
+    y = make_float2(ay.x + ex.b.x, ay.y + ex.b.y);
+  }
+#pragma unroll
+  for (int e = 0; e < kNfPer; ++e) {
+    const long long m = i0 + e;
+    const float2 ay = nf_cmul(A[e], y);
+    y = make_float2(ay.x + B[e].x, ay.y + B[e].y);
+    if (m >= c0 && m < hi) out[m] = y;
+  }
+}
+
+// what the next run needs: last output, the raw samples in front of the new read pointer, the bin, sub at the new frontier
+__global__ __launch_bounds__(256) void k_nf_state(nf_run run, const float2 *in, const float2 *out, const int *ivbin, const unsigned char *changed,
+                                                  nf_consts C, nf_state *st) {
+  __shared__ float2 sh[256];
+  const int t = threadIdx.x;
+  const int bin = ivbin[run.ndet];
+  const long long A = (long long)run.a_rel, Ap = (long long)run.a_prev_rel;
+  float2 sub = make_float2(0.f, 0.f);
+  if (bin >= 0) {
+    const int sg = nf_seg_start(changed, run.ndet + 1);
+    const bool carried = sg < 0;
+    const long long start = carried ? Ap : (long long)run.s_rel[sg - 1];
+    const long long lo = A - kNfLook > start ? A - kNfLook : start;
+    const float2 w = nf_wsum(in, lo, A, bin, C.omk, sh);
+    sub = make_float2(C.k * w.x, C.k * w.y);
+    if (carried && A - start <= kNfLook) {
+      const float2 c2 = nf_cmul(nf_ppow(bin, C.omk, A - start), st->sub);
+      sub.x += c2.x; sub.y += c2.y;
+    }
+  }
+  const long long F = (long long)run.count * kNfD;           // the new read pointer, relative to `in`
+  float2 cv = make_float2(0.f, 0.f);
+  if (t < 32) { const long long n = F - 32 + t; cv = n >= 0 ? in[n] : st->carry[32 + n]; }   // (n ≥ −32: the old carry, shifted)
+  __syncthreads();
+  if (t < 32) st->carry[t] = cv;
+  if (t == 0) { st->y_last = out[run.count - 1]; st->sub = sub; st->bin = bin; }
+}
+
 }  // namespace
 
 struct lsdr_auto_notch {
@@ -1271,6 +1595,197 @@ int lsdr_spectrum_run(lsdr_spectrum *f, const lsdr_cf32 *in, size_t n_in, float 
   }
   *consumed = pos;
   *produced = nout;
+  return LSDR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ notch_fir: fused auto_notch (one slot) + fir_filter
+struct lsdr_notch_fir {
+  lsdr_ctx *ctx;
+  int N, D, decimation, phase;
+  float k, scale;
+  int wpc;
+  unsigned long long F, A;          // stream positions: fir_filter's read pointer (= samples consumed), the notch's frontier (multiple of 4096)
+  float *d_coeffs;
+  nf_state *d_state;
+  int *d_cand; float2 *d_spec; unsigned long long *d_offsets; unsigned *d_tile_first;
+  int *d_ivbin; unsigned char *d_changed; float2 *d_ivP, *d_ivrho; float *d_ivtab;
+  float2 *d_r; size_t r_cap;
+  cfft_dev fft;
+  // optional timing of the filter pass alone (lsdr_notch_fir_time): a ring of event pairs
+  static const int kTimed = 16;
+  bool timing; hipEvent_t tev[kTimed][2]; unsigned timed_runs;
+};
+
+extern "C" {
+
+int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch_fir **out) {
+  LSDR_ARG(c && cfg && out && cfg->coeffs_host && cfg->ncoeffs >= 1);
+  if (cfg->nslots != 1 || cfg->decim != (unsigned)kNfD || cfg->ncoeffs + cfg->decim > (unsigned)kNfTaps) {
+    lsdr_set_error("notch_fir: the fused block exists for one notch slot, decimation %d and ncoeffs ≤ %d (got %d slots, decimation %u, %u taps): "
+                   "use auto_notch and fir_filter as separate blocks", kNfD, kNfTaps - kNfD, cfg->nslots, cfg->decim, cfg->ncoeffs);
+    return LSDR_E_UNSUPPORTED;
+  }
+  LSDR_HIP(hipSetDevice(c->device));
+  lsdr_notch_fir *h = new lsdr_notch_fir();
+  h->ctx = c; h->N = (int)cfg->ncoeffs; h->D = (int)cfg->decim;
+  h->decimation = cfg->notch_decimation > 0 ? cfg->notch_decimation : 1024 * 4096;   // sdr.h:56
+  h->k = cfg->k > 0.f ? cfg->k : 0.002f;
+  h->scale = cfg->in_scale != 0.f ? cfg->in_scale : 1.0f;
+  h->phase = 0; h->F = 0; h->A = 0;
+  { const char *e = getenv("LSDR_NF_WPC"); h->wpc = e && atoi(e) > 0 ? atoi(e) : 32; }   // tuning hook: workgroups per CU queued for the filter pass (oversubscribed: see k_fir_mfma_stream)
+  h->d_r = nullptr; h->r_cap = 0; h->timing = false; h->timed_runs = 0;
+  memset(h->tev, 0, sizeof(h->tev));
+  const size_t niv = kNfMaxDet + 1;
+  LSDR_HIP(hipMalloc((void **)&h->d_coeffs, cfg->ncoeffs * sizeof(float)));
+  LSDR_HIP(hipMemcpy(h->d_coeffs, cfg->coeffs_host, cfg->ncoeffs * sizeof(float), hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&h->d_state, sizeof(nf_state)));
+  nf_state s0; memset(&s0, 0, sizeof(s0)); s0.bin = -1;
+  LSDR_HIP(hipMemcpy(h->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&h->d_cand, kNfMaxDet * kMaxSlots * sizeof(int)));
+  LSDR_HIP(hipMalloc((void **)&h->d_spec, (size_t)kNfMaxDet * kN * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&h->d_offsets, kNfMaxDet * sizeof(unsigned long long)));
+  LSDR_HIP(hipMalloc((void **)&h->d_tile_first, niv * sizeof(unsigned)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivbin, niv * sizeof(int)));
+  LSDR_HIP(hipMalloc((void **)&h->d_changed, niv + 1));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivP, niv * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivrho, niv * kNfTaps * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivtab, niv * kNfKs * 64 * sizeof(float)));
+  int rc = cfft_dev_init(&h->fft, kN, true);
+  if (rc) return rc;
+  *out = h;
+  return LSDR_OK;
+}
+
+void lsdr_notch_fir_destroy(lsdr_notch_fir *h) {
+  if (!h) return;
+  (void)hipStreamSynchronize(h->ctx->stream);
+  (void)hipFree(h->d_coeffs); (void)hipFree(h->d_state); (void)hipFree(h->d_cand); (void)hipFree(h->d_spec); (void)hipFree(h->d_offsets);
+  (void)hipFree(h->d_tile_first); (void)hipFree(h->d_ivbin); (void)hipFree(h->d_changed); (void)hipFree(h->d_ivP); (void)hipFree(h->d_ivrho);
+  (void)hipFree(h->d_ivtab); (void)hipFree(h->d_r);
+  for (int i = 0; i < lsdr_notch_fir::kTimed; ++i) for (int j = 0; j < 2; ++j) if (h->tev[i][j]) (void)hipEventDestroy(h->tev[i][j]);
+  cfft_dev_free(&h->fft);
+  delete h;
+}
+
+int lsdr_notch_fir_set(lsdr_notch_fir *h, int decimation, float k) {      // auto_notch's public `decimation` and `k` (sdr.h:48-49); before the first run
+  LSDR_ARG(h && decimation >= 1 && k > 0.f && k < 1.f && h->F == 0 && h->A == 0);
+  h->decimation = decimation; h->k = k;
+  return LSDR_OK;
+}
+
+int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h) {      // auto_notch's slot bin after the runs queued so far (waits for the stream)
+  if (!h) return -1;
+  int bin = -1;
+  if (hipMemcpyAsync(&bin, &h->d_state->bin, sizeof(int), hipMemcpyDeviceToHost, h->ctx->stream) != hipSuccess) return -1;
+  if (hipStreamSynchronize(h->ctx->stream) != hipSuccess) return -1;
+  return bin;
+}
+
+int lsdr_notch_fir_time(lsdr_notch_fir *h, int enable, float *avg_ms, unsigned *launches) {
+  LSDR_ARG(h);
+  LSDR_HIP(hipStreamSynchronize(h->ctx->stream));
+  const unsigned n = h->timed_runs < (unsigned)lsdr_notch_fir::kTimed ? h->timed_runs : (unsigned)lsdr_notch_fir::kTimed;
+  double sum = 0;
+  for (unsigned i = 0; i < n; ++i) { float ms = 0.f; LSDR_HIP(hipEventElapsedTime(&ms, h->tev[i][0], h->tev[i][1])); sum += ms; }
+  if (avg_ms) *avg_ms = n ? (float)(sum / n) : 0.f;
+  if (launches) *launches = n;
+  h->timing = enable != 0; h->timed_runs = 0;
+  return LSDR_OK;
+}
+
+// One run = auto_notch::run over the whole 4096-sample blocks that are there (sdr.h:64-75) followed by fir_filter::run over what the notch
+// has released (dsp.h:233-262): `in` is the RAW stream at fir_filter's read position; *produced = ⌊(A − F − N) / D⌋ outputs where A is the
+// notch's frontier (the largest multiple of 4096 of the stream within in + n_in — fewer blocks when cap_out or the 64 detect points per run
+// bind), *consumed = *produced · D.  Queued on the context's stream; nothing waits for the host.
+int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed, size_t *produced) {
+  LSDR_ARG(h && consumed && produced);
+  *consumed = 0; *produced = 0;
+  lsdr_ctx *c = h->ctx;
+  const unsigned long long N = (unsigned long long)h->N, D = (unsigned long long)h->D;
+  {
+    const double a = pow(1.0 - (double)h->k, (double)kNfLook);
+    if (!(a < 1e-8)) { lsdr_set_error("notch_fir: k=%g leaves (1-k)^%d=%g of older input (use auto_notch + fir_filter)", (double)h->k, kNfLook, a); return LSDR_E_UNSUPPORTED; }
+  }
+  unsigned long long A = ((h->F + n_in) / kN) * kN;
+  auto count_of = [&](unsigned long long a) { return a > h->F + N ? (a - h->F - N) / D : 0ull; };
+  while (A > h->A && count_of(A) > cap_out) A -= kN;
+  // detect points of the blocks [h->A, A): `phase += 4096; if (phase >= decimation) { phase -= decimation; detect(); }` (sdr.h:66-70)
+  nf_run run;
+  memset(&run, 0, sizeof(run));
+  int phase = h->phase;
+  {
+    unsigned long long b = h->A / kN;
+    for (; b < A / kN; ++b) {
+      int ph = phase + kN;
+      if (ph >= h->decimation) {
+        if (run.ndet == kNfMaxDet) break;               // the run is cut in front of this block
+        ph -= h->decimation;
+        run.s_rel[run.ndet++] = b * kN - h->F;
+      }
+      phase = ph;
+    }
+    A = b * kN;
+  }
+  const unsigned long long count = count_of(A);
+  if (A <= h->A || !count) return LSDR_OK;
+  LSDR_ARG(in && out);
+  LSDR_HIP(hipSetDevice(c->device));
+  unsigned MW = 0;
+  LSDR_TRY(lsdr_fir_stream_iv_launch(c, nullptr, 0, nullptr, 0, (unsigned)N, (unsigned)D, kNfNq, nullptr, nullptr, 0, h->wpc, &MW));
+  run.mw = MW; run.count = count; run.a_prev_rel = h->A - h->F; run.a_rel = A - h->F;
+  run.tile_first[0] = 0;
+  for (int q = 0; q < run.ndet; ++q) {
+    const unsigned long long S = run.s_rel[q];
+    const unsigned long long mS = S <= N ? 0ull : (S - N + D - 1) / D;
+    const unsigned long long T = (mS + MW - 1) / MW;
+    unsigned long long mE = (S + D - 2) / D, mhi = T * MW ? T * MW - 1 : 0;
+    if (mE > mhi) mhi = mE;
+    if (mhi > count - 1) mhi = count - 1;
+    run.tile_first[q + 1] = (unsigned)T;
+    run.m_lo[q] = (unsigned)mS; run.m_hi[q] = (unsigned)mhi;
+    if (mS <= mhi && N + mhi * D + N + 1 - S > (unsigned long long)kNfFixSpan) { lsdr_set_error("notch_fir: fix-up span"); return LSDR_E_ARG; }
+  }
+  if (h->r_cap < count) {
+    LSDR_HIP(hipStreamSynchronize(c->stream));
+    (void)hipFree(h->d_r);
+    h->r_cap = count + count / 8 + 1024;
+    LSDR_HIP(hipMalloc((void **)&h->d_r, h->r_cap * sizeof(float2)));
+  }
+  nf_consts C; C.k = h->k; C.omk = 1 - h->k; C.scale = h->scale; C.N = h->N;
+  hipStream_t st = c->stream;
+  hipLaunchKernelGGL(k_nf_prep, dim3(1), dim3(64), 0, st, run, (const float2 *)in, h->d_offsets, h->d_tile_first);
+  if (run.ndet) {
+    hipLaunchKernelGGL(k_cfft_half, dim3(2u * run.ndet), dim3(256), 0, st, (const float2 *)in, (const float2 *)h->fft.d_om, h->d_spec,
+                       (const unsigned long long *)h->d_offsets);
+    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)run.ndet), dim3(256), 0, st, (const float2 *)h->d_spec, (const float2 *)h->fft.d_om,
+                       (float)(1.0 / kN), 1, h->d_cand);
+  }
+  hipLaunchKernelGGL(k_nf_taps, dim3((unsigned)run.ndet + 1), dim3(256), 0, st, (const nf_state *)h->d_state, (const int *)h->d_cand,
+                     (const float *)h->d_coeffs, C, h->d_ivbin, h->d_changed, h->d_ivP, h->d_ivrho, h->d_ivtab);
+  LSDR_HIP(hipGetLastError());
+  hipEvent_t *tp = nullptr;
+  if (h->timing) {
+    tp = h->tev[h->timed_runs % lsdr_notch_fir::kTimed];
+    if (!tp[0]) { LSDR_HIP(hipEventCreate(&tp[0])); LSDR_HIP(hipEventCreate(&tp[1])); }
+    LSDR_HIP(hipEventRecord(tp[0], st));
+  }
+  LSDR_TRY(lsdr_fir_stream_iv_launch(c, in, n_in, (lsdr_cf32 *)h->d_r, (size_t)count, (unsigned)N, (unsigned)D, kNfNq, h->d_ivtab, h->d_tile_first,
+                                     (unsigned)run.ndet + 1, h->wpc, nullptr));
+  if (tp) { LSDR_HIP(hipEventRecord(tp[1], st)); ++h->timed_runs; }
+  hipLaunchKernelGGL(k_nf_head, dim3(1), dim3(256), 0, st, (const float2 *)in, (const nf_state *)h->d_state, (const float2 *)h->d_ivrho, h->N, h->d_r);
+  if (run.ndet)
+    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, (const nf_state *)h->d_state, (const int *)h->d_ivbin,
+                       (const unsigned char *)h->d_changed, (const float *)h->d_coeffs, C, h->d_r);
+  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk)), dim3(256), 0, st, run, (const float2 *)h->d_r,
+                     (const nf_state *)h->d_state, (const float2 *)h->d_ivP, (const unsigned char *)h->d_changed, (float2 *)out);
+  hipLaunchKernelGGL(k_nf_state, dim3(1), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)out, (const int *)h->d_ivbin,
+                     (const unsigned char *)h->d_changed, C, h->d_state);
+  LSDR_HIP(hipGetLastError());
+  h->phase = phase; h->A = A; h->F += count * D;
+  *consumed = (size_t)(count * D);
+  *produced = (size_t)count;
   return LSDR_OK;
 }
 

@@ -88,11 +88,15 @@ __device__ __forceinline__ seam_step seam_eval(const INFO &prev, const INFO &cur
 //  k_rx_seam     one block per kSeamBlock consecutive tiles (256: four wavefronts, one per SIMD — a 1024-thread block needs
 //                16 free wave slots on ONE CU at once and was seen waiting 0.3 ms for them next to the persistent fir kernel): evaluates the seams, block-local exclusive scan of
 //                (symbol count, quadrant step) → fix[] holds block-local offsets, part[] the block totals;
-//  k_rx_compact  one wavefront per tile: adds the (≤ a few dozen) preceding block totals, applies the seam
+//  k_rx_compact  one wavefront per kCompactTiles tiles: adds the (≤ a few dozen) preceding block totals, applies the seam
 //                fix-ups and the quadrant relabelling while copying the tile's symbols to their final place.
 //                Block 0 also leaves the run's totals in *res and rotates the carried carrier phase back into
 //                the frame of tile 0, so the next queued run continues with the same symbol labelling.
 constexpr unsigned kSeamBlock = 256, kSeamWaves = kSeamBlock / 64;
+// k_rx_compact: consecutive tiles per (one-wavefront) workgroup.  One tile per workgroup was 34 944 workgroups to move 9 MB in the C2
+// pipeline — 78 % of their wave cycles waiting, 59 µs next to fir_filter; a seam block (256 tiles) is a whole number of these groups.
+constexpr unsigned kCompactTiles = 16;
+static_assert(kSeamBlock % kCompactTiles == 0, "the tiles of a compaction workgroup share their seam block");
 struct rx_seam_part { unsigned long long cnt; unsigned rot, ndup, nmiss, nbad; };
 
 // block-local exclusive scan of (symbol count, quadrant step) over the kSeamBlock tiles of a workgroup → fix[], part[]
@@ -164,17 +168,17 @@ __device__ __forceinline__ void rx_compact_body(const SYM *stage, unsigned stage
                                                 const rx_tile_info_t<SYM> *info, const rx_tile_fix *fix, const rx_seam_part *part,
                                                 const uint8_t *relabel /*[nrot][256]*/, unsigned n_tiles, int R, float quad,
                                                 SYM *out, STATE *state, rx_seam_result *res) {
-  const unsigned j = blockIdx.x;
-  if (j >= n_tiles) return;
+  const unsigned j0 = blockIdx.x * kCompactTiles;
+  if (j0 >= n_tiles) return;
   const unsigned rmask = (unsigned)R - 1;
-  const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock, mypart = j / kSeamBlock;
-  // preceding block totals (lane-parallel, then wave-reduced; nparts is tiny)
+  const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock, mypart = j0 / kSeamBlock;
+  // preceding block totals (lane-parallel, then wave-reduced; nparts is tiny) — once for the workgroup's tiles
   unsigned long long base = 0;
   unsigned brot = 0;
   for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { base += __shfl_xor(base, d, 64); brot += __shfl_xor(brot, d, 64); }
-  if (j == 0 && threadIdx.x == 0) {
+  if (j0 == 0 && threadIdx.x == 0) {
     rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0; sr.freq_tap = rx_freq_tap(state);
     for (unsigned i = 0; i < nparts; ++i) {
       sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
@@ -184,18 +188,21 @@ __device__ __forceinline__ void rx_compact_body(const SYM *stage, unsigned stage
     __threadfence_system();
     if (sr.rot_final) rx_rotate_back(state, sr.rot_final, quad);
   }
-  const rx_tile_fix f = fix[j];
-  const rx_tile_info_t<SYM> ti = info[j];
-  const uint8_t *map = relabel + ((f.rot + brot) & rmask) * 256;
-  const SYM *src = stage + (unsigned long long)j * stage_stride;
-  SYM *dst = out + base + f.out_offset;
-  if (f.insert_pre) {
-    if (threadIdx.x == 0) dst[0] = rx_relabel(ti.pre, map);
-    dst += 1;
-  }
-  const unsigned skip = f.drop_first ? 1u : 0u;
-  for (unsigned k = threadIdx.x + skip; k < ti.count; k += 64) {
-    dst[k - skip] = rx_relabel(src[k], map);
+  const unsigned j1 = j0 + kCompactTiles < n_tiles ? j0 + kCompactTiles : n_tiles;
+  for (unsigned j = j0; j < j1; ++j) {
+    const rx_tile_fix f = fix[j];
+    const rx_tile_info_t<SYM> ti = info[j];
+    const uint8_t *map = relabel + ((f.rot + brot) & rmask) * 256;
+    const SYM *src = stage + (unsigned long long)j * stage_stride;
+    SYM *dst = out + base + f.out_offset;
+    if (f.insert_pre) {
+      if (threadIdx.x == 0) dst[0] = rx_relabel(ti.pre, map);
+      dst += 1;
+    }
+    const unsigned skip = f.drop_first ? 1u : 0u;
+    for (unsigned k = threadIdx.x + skip; k < ti.count; k += 64) {
+      dst[k - skip] = rx_relabel(src[k], map);
+    }
   }
 }
 template <typename SYM, typename STATE>

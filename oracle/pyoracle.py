@@ -303,6 +303,51 @@ class Oracle:
         self.lib.lo_auto_notch_free(h)
         return out[:n], bins
 
+    def auto_notch_bins(self, x, decimation=1024 * 4096, k=0.002):
+        """The slot's bin after every 4096-sample block of auto_notch (one slot), from the oracle run block by block: [−1, …, bin, …]."""
+        x = cf32(x)
+        h = self.lib.lo_auto_notch_new(1, decimation, k, 0.0)
+        out = np.empty(4096, np.complex64)
+        bins = []
+        for b in range(len(x) // 4096):
+            blk = np.ascontiguousarray(x[b * 4096:(b + 1) * 4096])
+            self.lib.lo_auto_notch_run(h, _p(blk), 4096, _p(out))
+            bins.append(self.lib.lo_auto_notch_slot_bin(h, 0))
+        self.lib.lo_auto_notch_free(h)
+        return bins
+
+    def notch_fir_ideal(self, x, coeffs, decim, decimation=1024 * 4096, k=0.002, scale=None):
+        """The arithmetic lsdr_notch_fir states (leansdr_amd/csrc/notch.hip), in float64: auto_notch's recurrence (sdr.h:119-138) as the
+        LTI filter sub[n] = p·sub[n−1] + k·x[n], out = x − sub, p = (1−k)·exp(j2π·bin/4096) with EXACT phases — not the reference's
+        float-rounded phasor table — restarted from 0 wherever a detect (sdr.h:76-118; bins taken from the oracle's own detect) changes the
+        bin, then fir_filter (dsp.h:246-262) over it.  What the GPU block must equal to float32 accuracy for every bin; its distance
+        from the reference's arithmetic for bins ≥ 2048 is the reference's table noise."""
+        from scipy.signal import lfilter
+        x = cf32(x)
+        kf = np.float32(k)
+        omk = float(np.float32(1) - kf)
+        bins = self.auto_notch_bins(x, decimation, k)
+        n = len(bins) * 4096
+        xs = x[:n].astype(np.complex128) * (float(np.float32(scale)) if scale else 1.0)
+        out = xs.copy()
+        b = 0
+        while b < len(bins):
+            e = b
+            while e < len(bins) and bins[e] == bins[b]:
+                e += 1
+            if bins[b] >= 0:
+                p = omk * np.exp(2j * np.pi * bins[b] / 4096)
+                out[b * 4096:e * 4096] -= lfilter([float(kf)], [1, -p], xs[b * 4096:e * 4096])
+            b = e
+        c = np.ascontiguousarray(coeffs, np.float32).astype(np.float64)
+        N = len(c)
+        count = (n - N) // decim if n >= N else 0
+        idx = N + decim * np.arange(count)
+        y = np.zeros(count, np.complex128)
+        for i in range(N):            # y[m] = Σ_i c[i]·out[N + m·D − i]
+            y += c[i] * out[idx - i]
+        return y, bins
+
     def cnr_fft(self, x, bandwidth, nfft=4096, decimation=1048576, freq_tap=0.0, tap_multiplier=1.0):
         x = cf32(x)
         h = self.lib.lo_cnr_fft_new(bandwidth, nfft, decimation)
