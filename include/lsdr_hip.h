@@ -210,6 +210,11 @@ void lsdr_notch_fir_destroy(lsdr_notch_fir *h);
 int lsdr_notch_fir_set(lsdr_notch_fir *h, int decimation, float k);
 int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed, size_t *produced);
 int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h);   /* waits for the stream; −1: nothing detected yet */
+/* Opt-in: run k+1's detect chain and filter pass on streams of the block's own, next to run k's tail (first output, fix-ups, recurrence,
+ * state) on the context's stream; the output is complete in the order of the context's stream, as always.  The own streams do NOT wait
+ * for earlier work queued on the context: the caller promises that an input buffer is complete when lsdr_notch_fir_run is called with
+ * it and stays untouched until that run has completed on the context's stream.  Same results, bit for bit. */
+int lsdr_notch_fir_set_overlap(lsdr_notch_fir *h, int on);
 /* measurement hook: HIP events around the filter pass of every run while enabled (as lsdr_auto_notch_scan_time) */
 int lsdr_notch_fir_time(lsdr_notch_fir *h, int enable, float *avg_ms, unsigned *launches);
 /* cfft_engine<float>::inplace (dsp.h:56-116).  lsdr_cfft_run: the transform of one device block on the GPU (one workgroup,

@@ -117,6 +117,7 @@ _sig("lsdr_notch_fir_destroy", None, [vp])
 _sig("lsdr_notch_fir_set", C.c_int, [vp, C.c_int, c_f])
 _sig("lsdr_notch_fir_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_notch_fir_slot_bin", C.c_int, [vp])
+_sig("lsdr_notch_fir_set_overlap", C.c_int, [vp, C.c_int])
 _sig("lsdr_notch_fir_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
 _sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])
 _sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
@@ -947,6 +948,10 @@ class NotchFir:
 
     def bin(self):
         return lib.lsdr_notch_fir_slot_bin(self.h)
+
+    def set_overlap(self, on=True):
+        """Detect chain and filter pass of run k+1 on the block's own streams next to run k's tail (inputs must be complete at call time)."""
+        check(lib.lsdr_notch_fir_set_overlap(self.h, int(on)))
 
     def pass_time(self, enable=True):
         """(mean ms, launches) of the filter pass (k_fir_mfma_stream, per-interval taps) since the previous call; then switches recording."""

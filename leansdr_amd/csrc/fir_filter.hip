@@ -1239,7 +1239,7 @@ fir_kernel_t pick_generic(int R, int mode) {
 // that change along the stream.  `align_n` = the fir_filter's ncoeffs (output m is aligned at sample align_n + m·D of `in`, dsp.h:246-262),
 // nq tap blocks of D = 30 are applied (taps align_n … nq·D − 1 reach back past the aligned window).
 int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf32 *out, size_t count, unsigned align_n, unsigned D, unsigned nq,
-                              const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile) {
+                              const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile, hipStream_t stream) {
   if (D != 30 || nq != 12) { lsdr_set_error("notch_fir: the fused matrix-pipe pass exists for decimation 30 with 12 tap blocks"); return LSDR_E_UNSUPPORTED; }
   const unsigned M = 128u - (nq - 1);
   if (outputs_per_tile) *outputs_per_tile = M;
@@ -1264,7 +1264,7 @@ int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf3
   unsigned grid = a.tiles_per_xcd * 8;
   const unsigned pg = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 32) + 7) / 8 * 8;
   if (grid > pg) grid = pg;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds_bytes, c->stream, a);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds_bytes, stream ? stream : c->stream, a);
   LSDR_HIP(hipGetLastError());
   return LSDR_OK;
 }

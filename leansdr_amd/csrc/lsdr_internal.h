@@ -83,7 +83,7 @@ int lsdr_stage_sync(lsdr_ctx *c);
 
 // fir_filter.hip: the matrix-pipe pass of the fused auto_notch + fir_filter block (notch.hip)
 int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf32 *out, size_t count, unsigned align_n, unsigned D, unsigned nq,
-                              const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile);
+                              const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile, hipStream_t stream = nullptr);
 
 // Host-side table builders (host_tables.cpp)
 namespace lsdr {

@@ -660,14 +660,17 @@ __global__ __launch_bounds__(64) void k_nf_prep(nf_run r, const float2 *in, unsi
 // Interval q of a run (q = 0: up to the first detect point of the run, carried bin; q ≥ 1: from detect point q−1 on): its bin, whether
 // it differs from the interval before, P = p^D and the taps ρ = (scale·c) ∗ κ — in natural order (k_nf_head) and as the filter pass's
 // coefficient operand (lane (k = l>>4, q' = l&15) of step s: K slot e = 4·s + k of tap block q': tap D·q' + e/2 as (re, −im)).
-__global__ __launch_bounds__(256) void k_nf_taps(const nf_state *st, const int *cand /*[ndet][kMaxSlots]*/, const float *coeffs, nf_consts C,
-                                                 int *ivbin, unsigned char *changed, float2 *ivP, float2 *ivrho /*[·][kNfTaps]*/,
+// The carried bin travels from one run's launch of this kernel to the next one's through a ping-pong word (bin_in / bin_out), not through
+// nf_state: with lsdr_notch_fir_set_overlap the detect chain of run k+1 runs while run k's tail still owns the state.
+__global__ __launch_bounds__(256) void k_nf_taps(const int *bin_in, int *bin_out, int ndet, const int *cand /*[ndet][kMaxSlots]*/, const float *coeffs,
+                                                 nf_consts C, int *ivbin, unsigned char *changed, float2 *ivP, float2 *ivrho /*[·][kNfTaps]*/,
                                                  float *ivtab /*[·][kNfKs·64]*/) {
   __shared__ double kr[kNfD + 1], ki[kNfD + 1];
   __shared__ double rr[kNfTaps], ri[kNfTaps];
   const int q = blockIdx.x, t = threadIdx.x;
-  const int bin = q == 0 ? st->bin : cand[(q - 1) * kMaxSlots];
-  const int prev = q == 0 ? bin : (q == 1 ? st->bin : cand[(q - 2) * kMaxSlots]);
+  const int bin = q == 0 ? *bin_in : cand[(q - 1) * kMaxSlots];
+  const int prev = q == 0 ? bin : (q == 1 ? *bin_in : cand[(q - 2) * kMaxSlots]);
+  if (t == 0 && q == ndet) *bin_out = bin;
   if (t <= kNfD) {
     double re = 0, im = 0;
     if (bin < 0) { re = t == 0 ? 1.0 : 0.0; }
@@ -1609,9 +1612,16 @@ struct lsdr_notch_fir {
   unsigned long long F, A;          // stream positions: fir_filter's read pointer (= samples consumed), the notch's frontier (multiple of 4096)
   float *d_coeffs;
   nf_state *d_state;
-  int *d_cand; float2 *d_spec; unsigned long long *d_offsets; unsigned *d_tile_first;
-  int *d_ivbin; unsigned char *d_changed; float2 *d_ivP, *d_ivrho; float *d_ivtab;
-  float2 *d_r; size_t r_cap;
+  int *d_cand; float2 *d_spec; unsigned long long *d_offsets;
+  // per-run tables, two sets used alternately (run parity): with lsdr_notch_fir_set_overlap run k+1's detect chain and filter pass are
+  // under way while run k's tail still reads its own
+  unsigned *d_tile_first; int *d_ivbin; unsigned char *d_changed; float2 *d_ivP, *d_ivrho; float *d_ivtab;
+  int *d_bin_carry;                 // [2] the carried bin, ping-pong between consecutive runs' k_nf_taps
+  float2 *d_r[2]; size_t r_cap[2];
+  unsigned run_no;
+  // lsdr_notch_fir_set_overlap: detect chain + taps on s_det, the filter pass on s_pass, the tail (head, fix-ups, scan, state) on the
+  // context's stream; events hand over between them
+  bool overlap; hipStream_t s_det, s_pass; hipEvent_t ev_taps[2], ev_pass[2], ev_tail[2]; bool tail_recorded[2];
   cfft_dev fft;
   // optional timing of the filter pass alone (lsdr_notch_fir_time): a ring of event pairs
   static const int kTimed = 16;
@@ -1635,7 +1645,9 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   h->scale = cfg->in_scale != 0.f ? cfg->in_scale : 1.0f;
   h->phase = 0; h->F = 0; h->A = 0;
   { const char *e = getenv("LSDR_NF_WPC"); h->wpc = e && atoi(e) > 0 ? atoi(e) : 32; }   // tuning hook: workgroups per CU queued for the filter pass (oversubscribed: see k_fir_mfma_stream)
-  h->d_r = nullptr; h->r_cap = 0; h->timing = false; h->timed_runs = 0;
+  h->d_r[0] = h->d_r[1] = nullptr; h->r_cap[0] = h->r_cap[1] = 0; h->timing = false; h->timed_runs = 0;
+  h->run_no = 0; h->overlap = false; h->s_det = h->s_pass = nullptr; h->tail_recorded[0] = h->tail_recorded[1] = false;
+  memset(h->ev_taps, 0, sizeof(h->ev_taps)); memset(h->ev_pass, 0, sizeof(h->ev_pass)); memset(h->ev_tail, 0, sizeof(h->ev_tail));
   memset(h->tev, 0, sizeof(h->tev));
   const size_t niv = kNfMaxDet + 1;
   LSDR_HIP(hipMalloc((void **)&h->d_coeffs, cfg->ncoeffs * sizeof(float)));
@@ -1646,24 +1658,41 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   LSDR_HIP(hipMalloc((void **)&h->d_cand, kNfMaxDet * kMaxSlots * sizeof(int)));
   LSDR_HIP(hipMalloc((void **)&h->d_spec, (size_t)kNfMaxDet * kN * sizeof(float2)));
   LSDR_HIP(hipMalloc((void **)&h->d_offsets, kNfMaxDet * sizeof(unsigned long long)));
-  LSDR_HIP(hipMalloc((void **)&h->d_tile_first, niv * sizeof(unsigned)));
-  LSDR_HIP(hipMalloc((void **)&h->d_ivbin, niv * sizeof(int)));
-  LSDR_HIP(hipMalloc((void **)&h->d_changed, niv + 1));
-  LSDR_HIP(hipMalloc((void **)&h->d_ivP, niv * sizeof(float2)));
-  LSDR_HIP(hipMalloc((void **)&h->d_ivrho, niv * kNfTaps * sizeof(float2)));
-  LSDR_HIP(hipMalloc((void **)&h->d_ivtab, niv * kNfKs * 64 * sizeof(float)));
+  LSDR_HIP(hipMalloc((void **)&h->d_tile_first, 2 * niv * sizeof(unsigned)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivbin, 2 * niv * sizeof(int)));
+  LSDR_HIP(hipMalloc((void **)&h->d_changed, 2 * (niv + 1)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivP, 2 * niv * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivrho, 2 * niv * kNfTaps * sizeof(float2)));
+  LSDR_HIP(hipMalloc((void **)&h->d_ivtab, 2 * niv * kNfKs * 64 * sizeof(float)));
+  LSDR_HIP(hipMalloc((void **)&h->d_bin_carry, 2 * sizeof(int)));
+  { const int none[2] = {-1, -1}; LSDR_HIP(hipMemcpy(h->d_bin_carry, none, sizeof(none), hipMemcpyHostToDevice)); }
   int rc = cfft_dev_init(&h->fft, kN, true);
   if (rc) return rc;
   *out = h;
   return LSDR_OK;
 }
 
+static int nf_sync_all(lsdr_notch_fir *h) {
+  if (h->s_det) LSDR_HIP(hipStreamSynchronize(h->s_det));
+  if (h->s_pass) LSDR_HIP(hipStreamSynchronize(h->s_pass));
+  LSDR_HIP(hipStreamSynchronize(h->ctx->stream));
+  return LSDR_OK;
+}
+
 void lsdr_notch_fir_destroy(lsdr_notch_fir *h) {
   if (!h) return;
-  (void)hipStreamSynchronize(h->ctx->stream);
+  (void)nf_sync_all(h);
+  if (h->s_det) (void)hipStreamDestroy(h->s_det);
+  if (h->s_pass) (void)hipStreamDestroy(h->s_pass);
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_taps[i]) (void)hipEventDestroy(h->ev_taps[i]);
+    if (h->ev_pass[i]) (void)hipEventDestroy(h->ev_pass[i]);
+    if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]);
+  }
+  (void)hipFree(h->d_bin_carry); (void)hipFree(h->d_r[1]);
   (void)hipFree(h->d_coeffs); (void)hipFree(h->d_state); (void)hipFree(h->d_cand); (void)hipFree(h->d_spec); (void)hipFree(h->d_offsets);
   (void)hipFree(h->d_tile_first); (void)hipFree(h->d_ivbin); (void)hipFree(h->d_changed); (void)hipFree(h->d_ivP); (void)hipFree(h->d_ivrho);
-  (void)hipFree(h->d_ivtab); (void)hipFree(h->d_r);
+  (void)hipFree(h->d_ivtab); (void)hipFree(h->d_r[0]);
   for (int i = 0; i < lsdr_notch_fir::kTimed; ++i) for (int j = 0; j < 2; ++j) if (h->tev[i][j]) (void)hipEventDestroy(h->tev[i][j]);
   cfft_dev_free(&h->fft);
   delete h;
@@ -1672,6 +1701,32 @@ void lsdr_notch_fir_destroy(lsdr_notch_fir *h) {
 int lsdr_notch_fir_set(lsdr_notch_fir *h, int decimation, float k) {      // auto_notch's public `decimation` and `k` (sdr.h:48-49); before the first run
   LSDR_ARG(h && decimation >= 1 && k > 0.f && k < 1.f && h->F == 0 && h->A == 0);
   h->decimation = decimation; h->k = k;
+  return LSDR_OK;
+}
+
+// Opt-in: run k+1's detect chain and filter pass on streams of the block's own, next to run k's tail on the context's stream (the
+// output is complete, as always, in the order of the context's stream).  The own streams do not wait for earlier work queued on the
+// context: the caller promises that an input buffer is COMPLETE when lsdr_notch_fir_run is called with it (a resident capture; a buffer
+// whose producer has been waited for) and stays untouched until the run has completed on the context's stream.  Same results.
+int lsdr_notch_fir_set_overlap(lsdr_notch_fir *h, int on) {
+  LSDR_ARG(h);
+  LSDR_HIP(hipSetDevice(h->ctx->device));
+  LSDR_TRY(nf_sync_all(h));
+  if (on && !h->s_det) {
+    // (two plain streams.  Measured, kernel traces of the C2 pipeline with auto_notch: when the runtime puts both on ONE hardware queue the
+    // chain of run k+1 runs between two passes, 306 GS/s against 292 without overlap; on queues of their own — GPU_MAX_HW_QUEUES=8, or the
+    // chain's stream at high priority — the tail's one-workgroup kernels wait 250–340 µs for a slot among the pass's 8192 queued
+    // workgroups: 268–272 GS/s.  Opt-in, and bench_more.anf1 leaves it off.)
+    LSDR_HIP(hipStreamCreateWithFlags(&h->s_det, hipStreamNonBlocking));
+    LSDR_HIP(hipStreamCreateWithFlags(&h->s_pass, hipStreamNonBlocking));
+    for (int i = 0; i < 2; ++i) {
+      LSDR_HIP(hipEventCreateWithFlags(&h->ev_taps[i], hipEventDisableTiming));
+      LSDR_HIP(hipEventCreateWithFlags(&h->ev_pass[i], hipEventDisableTiming));
+      LSDR_HIP(hipEventCreateWithFlags(&h->ev_tail[i], hipEventDisableTiming));
+    }
+  }
+  h->overlap = on != 0;
+  h->tail_recorded[0] = h->tail_recorded[1] = false;          // (everything is idle: no stale event is waited for)
   return LSDR_OK;
 }
 
@@ -1685,7 +1740,7 @@ int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h) {      // auto_notch's slot bin a
 
 int lsdr_notch_fir_time(lsdr_notch_fir *h, int enable, float *avg_ms, unsigned *launches) {
   LSDR_ARG(h);
-  LSDR_HIP(hipStreamSynchronize(h->ctx->stream));
+  LSDR_TRY(nf_sync_all(h));
   const unsigned n = h->timed_runs < (unsigned)lsdr_notch_fir::kTimed ? h->timed_runs : (unsigned)lsdr_notch_fir::kTimed;
   double sum = 0;
   for (unsigned i = 0; i < n; ++i) { float ms = 0.f; LSDR_HIP(hipEventElapsedTime(&ms, h->tev[i][0], h->tev[i][1])); sum += ms; }
@@ -1747,42 +1802,57 @@ int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr
     run.m_lo[q] = (unsigned)mS; run.m_hi[q] = (unsigned)mhi;
     if (mS <= mhi && N + mhi * D + N + 1 - S > (unsigned long long)kNfFixSpan) { lsdr_set_error("notch_fir: fix-up span"); return LSDR_E_ARG; }
   }
-  if (h->r_cap < count) {
-    LSDR_HIP(hipStreamSynchronize(c->stream));
-    (void)hipFree(h->d_r);
-    h->r_cap = count + count / 8 + 1024;
-    LSDR_HIP(hipMalloc((void **)&h->d_r, h->r_cap * sizeof(float2)));
+  const unsigned par = h->run_no & 1u;
+  const size_t niv = kNfMaxDet + 1;
+  if (h->r_cap[par] < count) {
+    LSDR_TRY(nf_sync_all(h));
+    (void)hipFree(h->d_r[par]);
+    h->r_cap[par] = count + count / 8 + 1024;
+    LSDR_HIP(hipMalloc((void **)&h->d_r[par], h->r_cap[par] * sizeof(float2)));
   }
+  unsigned *const p_tile_first = h->d_tile_first + par * niv;
+  int *const p_ivbin = h->d_ivbin + par * niv;
+  unsigned char *const p_changed = h->d_changed + par * (niv + 1);
+  float2 *const p_ivP = h->d_ivP + par * niv, *const p_ivrho = h->d_ivrho + par * niv * kNfTaps, *const p_r = h->d_r[par];
+  float *const p_ivtab = h->d_ivtab + par * niv * kNfKs * 64;
   nf_consts C; C.k = h->k; C.omk = 1 - h->k; C.scale = h->scale; C.N = h->N;
-  hipStream_t st = c->stream;
-  hipLaunchKernelGGL(k_nf_prep, dim3(1), dim3(64), 0, st, run, (const float2 *)in, h->d_offsets, h->d_tile_first);
+  hipStream_t st = c->stream, sd = h->overlap ? h->s_det : st, sp = h->overlap ? h->s_pass : st;
+  // detect chain + taps (sd): the tables of this parity are free once the tail of the run two runs ago is through
+  if (h->overlap && h->tail_recorded[par]) LSDR_HIP(hipStreamWaitEvent(sd, h->ev_tail[par], 0));
+  hipLaunchKernelGGL(k_nf_prep, dim3(1), dim3(64), 0, sd, run, (const float2 *)in, h->d_offsets, p_tile_first);
   if (run.ndet) {
-    hipLaunchKernelGGL(k_cfft_half, dim3(2u * run.ndet), dim3(256), 0, st, (const float2 *)in, (const float2 *)h->fft.d_om, h->d_spec,
+    hipLaunchKernelGGL(k_cfft_half, dim3(2u * run.ndet), dim3(256), 0, sd, (const float2 *)in, (const float2 *)h->fft.d_om, h->d_spec,
                        (const unsigned long long *)h->d_offsets);
-    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)run.ndet), dim3(256), 0, st, (const float2 *)h->d_spec, (const float2 *)h->fft.d_om,
+    hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)run.ndet), dim3(256), 0, sd, (const float2 *)h->d_spec, (const float2 *)h->fft.d_om,
                        (float)(1.0 / kN), 1, h->d_cand);
   }
-  hipLaunchKernelGGL(k_nf_taps, dim3((unsigned)run.ndet + 1), dim3(256), 0, st, (const nf_state *)h->d_state, (const int *)h->d_cand,
-                     (const float *)h->d_coeffs, C, h->d_ivbin, h->d_changed, h->d_ivP, h->d_ivrho, h->d_ivtab);
+  hipLaunchKernelGGL(k_nf_taps, dim3((unsigned)run.ndet + 1), dim3(256), 0, sd, (const int *)(h->d_bin_carry + par), h->d_bin_carry + (par ^ 1u), run.ndet,
+                     (const int *)h->d_cand, (const float *)h->d_coeffs, C, p_ivbin, p_changed, p_ivP, p_ivrho, p_ivtab);
   LSDR_HIP(hipGetLastError());
+  if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_taps[par], sd)); LSDR_HIP(hipStreamWaitEvent(sp, h->ev_taps[par], 0)); }
+  // the filter pass (sp)
   hipEvent_t *tp = nullptr;
   if (h->timing) {
     tp = h->tev[h->timed_runs % lsdr_notch_fir::kTimed];
     if (!tp[0]) { LSDR_HIP(hipEventCreate(&tp[0])); LSDR_HIP(hipEventCreate(&tp[1])); }
-    LSDR_HIP(hipEventRecord(tp[0], st));
+    LSDR_HIP(hipEventRecord(tp[0], sp));
   }
-  LSDR_TRY(lsdr_fir_stream_iv_launch(c, in, n_in, (lsdr_cf32 *)h->d_r, (size_t)count, (unsigned)N, (unsigned)D, kNfNq, h->d_ivtab, h->d_tile_first,
-                                     (unsigned)run.ndet + 1, h->wpc, nullptr));
-  if (tp) { LSDR_HIP(hipEventRecord(tp[1], st)); ++h->timed_runs; }
-  hipLaunchKernelGGL(k_nf_head, dim3(1), dim3(256), 0, st, (const float2 *)in, (const nf_state *)h->d_state, (const float2 *)h->d_ivrho, h->N, h->d_r);
+  LSDR_TRY(lsdr_fir_stream_iv_launch(c, in, n_in, (lsdr_cf32 *)p_r, (size_t)count, (unsigned)N, (unsigned)D, kNfNq, p_ivtab, p_tile_first,
+                                     (unsigned)run.ndet + 1, h->wpc, nullptr, sp));
+  if (tp) { LSDR_HIP(hipEventRecord(tp[1], sp)); ++h->timed_runs; }
+  if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_pass[par], sp)); LSDR_HIP(hipStreamWaitEvent(st, h->ev_pass[par], 0)); }
+  // the tail (the context's stream): r[0], the given outputs, the recurrence, the state for the next run
+  hipLaunchKernelGGL(k_nf_head, dim3(1), dim3(256), 0, st, (const float2 *)in, (const nf_state *)h->d_state, (const float2 *)p_ivrho, h->N, p_r);
   if (run.ndet)
-    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, (const nf_state *)h->d_state, (const int *)h->d_ivbin,
-                       (const unsigned char *)h->d_changed, (const float *)h->d_coeffs, C, h->d_r);
-  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk)), dim3(256), 0, st, run, (const float2 *)h->d_r,
-                     (const nf_state *)h->d_state, (const float2 *)h->d_ivP, (const unsigned char *)h->d_changed, (float2 *)out);
-  hipLaunchKernelGGL(k_nf_state, dim3(1), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)out, (const int *)h->d_ivbin,
-                     (const unsigned char *)h->d_changed, C, h->d_state);
+    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, (const nf_state *)h->d_state, (const int *)p_ivbin,
+                       (const unsigned char *)p_changed, (const float *)h->d_coeffs, C, p_r);
+  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk)), dim3(256), 0, st, run, (const float2 *)p_r,
+                     (const nf_state *)h->d_state, (const float2 *)p_ivP, (const unsigned char *)p_changed, (float2 *)out);
+  hipLaunchKernelGGL(k_nf_state, dim3(1), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)out, (const int *)p_ivbin,
+                     (const unsigned char *)p_changed, C, h->d_state);
   LSDR_HIP(hipGetLastError());
+  if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_tail[par], st)); h->tail_recorded[par] = true; }
+  ++h->run_no;
   h->phase = phase; h->A = A; h->F += count * D;
   *consumed = (size_t)(count * D);
   *produced = (size_t)count;

@@ -104,3 +104,21 @@ def test_unsupported_geometries_are_refused(capi, ctx):
     for kw in (dict(nslots=2), dict(decim=10), dict(coeffs=np.ones(340, np.float32))):
         with pytest.raises(capi.LsdrError):
             capi.NotchFir(ctx, kw.get("coeffs", c), kw.get("decim", DECIM), nslots=kw.get("nslots", 1))
+
+
+def test_overlapped_runs_give_the_same_bits(capi, ctx, oracle):
+    """lsdr_notch_fir_set_overlap: detect chain and filter pass of run k+1 on the block's own streams next to run k's tail — the same
+    output bit for bit, over runs of a few blocks each with bin changes in them."""
+    dec = 4096 * 4
+    x = signal(4096 * 50, 11, [(0, 0.0024, 35.0), (4096 * 17 + 2000, -0.0035, 45.0), (4096 * 34, 0.0024, 35.0)])
+    c = c2_taps(capi)
+    outs = []
+    for ov in (False, True):
+        nf = capi.NotchFir(ctx, c, DECIM, decimation=dec)
+        if ov:
+            nf.set_overlap(True)
+        y, cons = nf.run(x, step=3 * 4096 + 17)
+        outs.append((y, cons, nf.bin()))
+        nf.close()
+    assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
+    assert np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64))
