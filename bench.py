@@ -266,7 +266,7 @@ class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=12):
         self.capi = capi
         self.batch_hook = batch_hook          # called per batch after fir_filter was queued: hook(pipe, dec buffer index, outputs, done event)
         # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
@@ -312,6 +312,7 @@ class C2Pipeline:
         self.ctx_rx = self.ctx_rxs[0] if self.ctx_rxs else None
         self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw,
                              shared_rx_ctx=self.ctx_rxs[c % self.rx_groups] if self.rx_multi else None, extra=self.extra) for c in range(n_captures)]
+        self.placement = self.place_buffers(int(os.environ.get("LSDR_BENCH_PLACEMENT", placement_candidates))) if len(self.caps) == 1 else None
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)
         self.ev_fir = [self.ctx.event() for _ in range(self.geo["nbuf"])]
@@ -321,6 +322,52 @@ class C2Pipeline:
         self.reshifts = 0
         self.snap = None            # (capture, dec buffer index) of the batch whose loop state was snapshotted
         self.snap_mid, self.last_k = None, -1
+
+    def place_buffers(self, candidates):
+        """WHERE a resident buffer lands decides how fast fir_filter streams it: one process, six 2 GiB buffers allocated one after
+        the other — the same launch takes 0.37 ms over some and 0.42 ms over others, reproducibly per buffer (profiles/r05_bench/
+        placement_probe.txt); the C2 headline moved ±8 % from process to process with it.  So the capture's input buffer and its
+        decimated-stream buffers are CHOSEN: `candidates` allocations of each are held at once, the filter launch is timed over every
+        one (HIP events, 3 + 6 launches), the fastest are kept, the rest freed.  Not timed; the data in the buffers is the same."""
+        if candidates <= 1:
+            return None
+        capi, g, cp, ctx = self.capi, self.geo, self.caps[0], self.ctx
+        n_in = g["B"] + self.extra * g["decim"] + g["N"]
+        n_dec = g["n_out"] + self.extra
+        e0, e1 = ctx.event(), ctx.event()
+
+        def launch_ms(d_in, d_dec):
+            for _ in range(3):
+                self.fir.run_dev(d_in.ptr, n_in, d_dec.ptr, n_dec)
+            ctx.sync(); ctx.event_record(e0)
+            for _ in range(6):
+                self.fir.run_dev(d_in.ptr, n_in, d_dec.ptr, n_dec)
+            ctx.event_record(e1); ctx.sync()
+            return ctx.event_elapsed_ms(e0, e1) / 6
+
+        # (candidates are held until the choice is made — a freed buffer would be handed out again; the search stops early once one
+        # candidate is clearly in the fast group: at least four tried, the best 7 % under the slowest)
+        ins, t_in = [cp.d_in], [launch_ms(cp.d_in, cp.dec[0])]
+        while len(ins) < candidates and not (len(ins) >= 4 and min(t_in) < 0.93 * max(t_in)):
+            d = ctx.alloc((g["B"] + g["period"]) * 8)
+            capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.ptr, cp.d_in.ptr, (g["B"] + g["period"]) * 8))
+            ctx.sync()
+            ins.append(d); t_in.append(launch_ms(d, cp.dec[0]))
+        best = int(np.argmin(t_in))
+        cp.d_in = ins[best]
+        for k, d in enumerate(ins):
+            if k != best:
+                d.free()
+        decs = list(cp.dec) + [ctx.alloc((n_dec) * 8) for _ in range(max(0, min(candidates, 6) - len(cp.dec)))]
+        t_dec = [launch_ms(cp.d_in, d) for d in decs]
+        order = list(np.argsort(t_dec))
+        keep = order[:len(cp.dec)]
+        cp.dec = [decs[k] for k in keep]
+        for k, d in enumerate(decs):
+            if k not in keep:
+                d.free()
+        return dict(candidates=candidates, filter_launch_ms_by_input_buffer=[round(float(v), 4) for v in t_in],
+                    filter_launch_ms_by_decimated_buffer=[round(float(v), 4) for v in t_dec])
 
     def run(self, n_batches, timed, snapshot_last=False, track_tol=None):
         """Queue n_batches batches of every capture.  Per batch: fir_filter(k) of all captures in one launch on the fir
@@ -707,6 +754,8 @@ def main():
         import bench_c1
         if capi.lib.lsdr_device_count() <= local_rank:
             raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {capi.lib.lsdr_device_count()} visible")
+        if world > 1:       # the 16 worker threads of a rank inherit its affinity: the CPUs next to its GPU
+            shard.pin_to_gpu_numa(capi.device_pci_bus_id(local_rank))
         out, rc = bench_c1.run_workload(capi, local_rank, args, shard)
         if rank == 0:
             emit(out)
@@ -727,6 +776,7 @@ def main():
 
     if capi.lib.lsdr_device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank}, only {capi.lib.lsdr_device_count()} visible")
+    numa = shard.pin_to_gpu_numa(capi.device_pci_bus_id(local_rank)) if world > 1 else None      # (after the CPU baseline's all-core pass)
     tile = (args.tile_len, args.tile_warmup)
     pipe = C2Pipeline(capi, synth, local_rank, args.captures, args.batch_msamples, args.period_msamples, tile,
                       seed0=shard.capture_seed(), rx_cus=args.rx_cus, cu_pattern=args.cu_pattern,
@@ -785,6 +835,7 @@ def main():
                                    "fir_filter(k+1) of all captures in one launch (lsdr_fir_filter_run_multi) || cstln_receiver(k) of all captures in "
                                    "shared launches (lsdr_rx_run_multi_async): two HIP streams, receiver runs queued"),
                        "parallelism": f"{world * len(pipe.caps)} independent capture(s), {len(pipe.caps)} per GPU, no collectives, no RCCL",
+                       "rank0_numa": numa, "buffer_placement": pipe.placement,
                        "symbols_per_step": nsym // max(1, args.steps)},
             "roofline": pipe.roofline(),
         }

@@ -51,6 +51,8 @@ typedef struct { int16_t cost; uint8_t symbol; uint8_t pad; } lsdr_softsymbol; /
 /* ------------------------------------------------------------------ context */
 typedef struct lsdr_ctx lsdr_ctx;
 int lsdr_abi_version(void);
+/* PCI address of a device ("0000:c1:00.0", at least 16 bytes): lets the host pin a capture's threads to the GPU's NUMA node */
+int lsdr_device_pci_bus_id(int device, char *buf, int len);
 const char *lsdr_last_error(void);
 /* stream == NULL: the ctx creates (and owns) a non-blocking HIP stream.
  *

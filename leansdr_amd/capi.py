@@ -71,6 +71,13 @@ def _sig(name, restype, argtypes):
 _sig("lsdr_abi_version", C.c_int, [])
 _sig("lsdr_last_error", C.c_char_p, [])
 _sig("lsdr_device_count", C.c_int, [])
+_sig("lsdr_device_pci_bus_id", C.c_int, [C.c_int, C.c_char_p, C.c_int])
+
+
+def device_pci_bus_id(device):
+    buf = C.create_string_buffer(32)
+    check(lib.lsdr_device_pci_bus_id(device, buf, 32))
+    return buf.value.decode()
 _sig("lsdr_ctx_create", C.c_int, [C.c_int, vp, C.POINTER(vp)])
 _sig("lsdr_ctx_create_masked", C.c_int, [C.c_int, vp, C.c_uint, C.POINTER(vp)])
 _sig("lsdr_ctx_destroy", None, [vp])

@@ -29,6 +29,13 @@ int lsdr_device_count(void) {
   return n;
 }
 
+// "0000:c1:00.0"-style PCI address of a device (for the host side to find the GPU's NUMA node under /sys/bus/pci/devices/)
+int lsdr_device_pci_bus_id(int device, char *buf, int len) {
+  LSDR_ARG(buf && len >= 16);
+  LSDR_HIP(hipDeviceGetPCIBusId(buf, len, device));
+  return LSDR_OK;
+}
+
 static int ctx_create(int device, void *hip_stream, const uint32_t *cu_mask, unsigned mask_words, lsdr_ctx **out);
 
 int lsdr_ctx_create(int device, void *hip_stream, lsdr_ctx **out) { return ctx_create(device, hip_stream, nullptr, 0, out); }

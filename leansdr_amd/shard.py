@@ -36,6 +36,28 @@ class Shard:
                 return ids[self.local_rank]
         return self.local_rank
 
+    def pin_to_gpu_numa(self, pci_bus_id):
+        """Pin this process (and the worker threads it starts later) to the CPUs of the NUMA node its GPU hangs off: on an 8-GPU node
+        with two sockets a capture's host threads — 16 per GPU in the c1 workload, 128 on the node — otherwise wander across both.
+        Returns {"node": n, "cpus": k} or None when the node cannot be told (single-node boxes report −1) or the affinity cannot be set."""
+        try:
+            with open(f"/sys/bus/pci/devices/{pci_bus_id.lower()}/numa_node") as f:
+                node = int(f.read().strip())
+            if node < 0:
+                return None
+            with open(f"/sys/devices/system/node/node{node}/cpulist") as f:
+                cpus = set()
+                for part in f.read().strip().split(","):
+                    lo, _, hi = part.partition("-")
+                    cpus.update(range(int(lo), int(hi or lo) + 1))
+            allowed = cpus & set(os.sched_getaffinity(0))
+            if not allowed:
+                return None
+            os.sched_setaffinity(0, allowed)
+            return {"node": node, "cpus": len(allowed)}
+        except (OSError, ValueError, AttributeError):
+            return None
+
     def all_ranks_ok(self, ok):
         """(ranks that passed, ranks): every rank verifies its own captures and contributes its verdict."""
         failed = self.sum_over_ranks(0.0 if ok else 1.0)

@@ -11,10 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra):
+def _run(extra, ranks=2):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    env["LSDR_RANK_DEVICES"] = "0,0"
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-more"] + extra,
+    env["LSDR_RANK_DEVICES"] = ",".join(["0"] * ranks)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-more"] + extra,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
     lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
@@ -40,3 +40,21 @@ def test_c1_two_ranks_on_one_gpu_every_rank_verifies():
     assert j["n_gpus"] == 2 and j["value"] > 0 and j["config"]["captures_per_gpu"] == 2
     v = j["verified"]
     assert v["ranks"] == 2 and v["ranks_passed"] == 2 and v["pass"], v
+
+
+def test_c2_four_ranks_on_one_gpu():
+    """Four ranks (four processes, 8+ HIP streams, four gloo peers) on GPU 0: queue and thread oversubscription exercised before the
+    driver's 8-GPU curve is; every rank verifies."""
+    j = _run(["--batches-per-step", "3", "--batch-msamples", "16"], ranks=4)
+    assert j["n_gpus"] == 4 and j["value"] > 0
+    v = j["verified"]
+    assert v["ranks"] == 4 and v["ranks_passed"] == 4 and v["pass"] and v["fir_bit_exact"]
+
+
+def test_c1_four_ranks_on_one_gpu():
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "leandvb")):
+        pytest.fail("oracle/_ref/leandvb is missing on the GPU box")
+    j = _run(["--workload", "c1", "--c1-captures", "2", "--c1-msamples", "8", "--c1-workers", "2"], ranks=4)
+    assert j["n_gpus"] == 4 and j["value"] > 0
+    v = j["verified"]
+    assert v["ranks"] == 4 and v["ranks_passed"] == 4 and v["pass"], v

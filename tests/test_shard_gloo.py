@@ -158,3 +158,11 @@ def test_recorded_traffic_is_keyed_by_kernel():
     assert t and "pmc_traffic.json" in src
     assert bench.pmc_traffic("k_fir_persist", 268369920) == (None, None) or "k_fir_persist" in open(os.path.join(ROOT, bench.pmc_traffic("k_fir_persist", 268369920)[1])).read()
     assert bench.pmc_traffic("k_fir_mfma_stream", 12345) == (None, None)
+
+
+def test_numa_pinning_degrades_gracefully():
+    """pin_to_gpu_numa: None (and no exception, affinity untouched) where the PCI device or its NUMA node cannot be told."""
+    from leansdr_amd.shard import Shard
+    before = os.sched_getaffinity(0)
+    assert Shard().pin_to_gpu_numa("ffff:ff:1f.7") is None
+    assert os.sched_getaffinity(0) == before
