@@ -1440,7 +1440,12 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
     {
       const char *es = getenv("LSDR_MFMA_STREAM"), *ew = getenv("LSDR_MFMA_SWPC");
       f->stream = pick_stream(D, false, 0) != nullptr && !(es && !atoi(es));
-      f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 3;   // (4 fit by LDS; next to the receiver's tiles 3 leave it room: C2 pipeline 546 → 569 GS/s)
+      // OVERSUBSCRIBED: 48 workgroups per CU queued, each with a short tile list (6 tiles at the C2 batch), instead of a grid of exactly
+      // the resident workgroups (3 per CU) that own a 99-tile list each: the dispatcher deals the work, the wavefronts of a CU fall out
+      // of step, a workgroup that could not start next to the receiver's tiles costs 6 tiles, not a second round.  Same box, buffer
+      // placement chosen (bench.py), three processes each: 3 → 602–612 GS/s, 48 → 627–635, 96 → 605–624, 192 → 585–601; 6 (two exact
+      // rounds) → 465.  Complex taps: 4 → 402, 48 → 409.
+      f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 48;
     }
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
@@ -1578,10 +1583,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     // (complex taps on the register-staged kernels: three workgroups per CU queued — two resident ones that start together stay in
     // step and leave the memory idle while both compute: 0.345 ms per 64 Mi against 0.157)
     static const bool wpc_env = getenv("LSDR_MFMA_WPC") != nullptr;
-    // (stream kernel, complex taps: twice the matrix-pipe work per sample — the fourth wavefront of a CU pays: 0.190 → 0.151 ms per
-    // 64 Mi alone, 0.195 → 0.156 in the C2 pipeline; with real taps three leave the receiver's tiles room: 546 → 569 GS/s)
-    static const bool swpc_env = getenv("LSDR_MFMA_SWPC") != nullptr;
-    const int wpc = stream ? (cp && !swpc_env ? 4 : f->stream_wpc) : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
+    const int wpc = stream ? f->stream_wpc : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
     const unsigned pg = (unsigned)(f->ctx->num_cu * wpc + 7) / 8 * 8;
     if (grid > pg) grid = pg;
     {
