@@ -485,11 +485,9 @@ __global__ __launch_bounds__(64) void k_notch_args(notch_run_args r, int *d_ifir
 // (dsp.h:84-104) touch the two halves of the bit-reversed array independently: one 256-lane workgroup with 16 KB of LDS per
 // half; the last stage (position p with p + 2048, twiddle om[p]) is done by k_notch_peaks on the fly.  Same butterflies, each
 // evaluated once with the same expression: bit-identical to k_cfft.
-__global__ __launch_bounds__(256) void k_cfft_half(const float2 *in, const float2 *om, float2 *halves /*[ndet][2][2048]*/,
-                                                   const unsigned long long *in_offsets) {
+__device__ __forceinline__ void cfft_half_body(const float2 *src, const float2 *om, float2 *halves /*[ndet][2][2048]*/) {
   __shared__ float2 d[kN / 2];
-  const int det = blockIdx.x >> 1, h = blockIdx.x & 1, tid = threadIdx.x;
-  const float2 *src = in + in_offsets[det];
+  const int h = blockIdx.x & 1, tid = threadIdx.x;
   for (int p = tid; p < kN / 2; p += 256) d[p] = src[__brev((unsigned)(h * (kN / 2) + p)) >> 20];   // position P holds in[brev12(P)]
   __syncthreads();
   for (int st = 0; st < 11; ++st) {
@@ -506,6 +504,10 @@ __global__ __launch_bounds__(256) void k_cfft_half(const float2 *in, const float
     __syncthreads();
   }
   for (int p = tid; p < kN / 2; p += 256) halves[(size_t)blockIdx.x * (kN / 2) + p] = d[p];
+}
+__global__ __launch_bounds__(256) void k_cfft_half(const float2 *in, const float2 *om, float2 *halves /*[ndet][2][2048]*/,
+                                                   const unsigned long long *in_offsets) {
+  cfft_half_body(in + in_offsets[blockIdx.x >> 1], om, halves);
 }
 
 __global__ __launch_bounds__(256) void k_notch_peaks(const float2 *halves, const float2 *om, float invn, int nslots,
@@ -651,20 +653,21 @@ __device__ float2 nf_wsum(const float2 *x, long long lo, long long hi, int bin, 
   return r;
 }
 
-// the run's small arrays into device memory (k_cfft_half and the filter pass read them through pointers)
-__global__ __launch_bounds__(64) void k_nf_prep(nf_run r, const float2 *in, unsigned long long *d_offsets, unsigned *d_tile_first) {
-  for (int i = threadIdx.x; i < r.ndet; i += 64) d_offsets[i] = r.s_rel[i];
-  for (int i = threadIdx.x; i <= r.ndet; i += 64) d_tile_first[i] = r.tile_first[i];
+// the detect points' half transforms, offsets straight from the run's record
+__global__ __launch_bounds__(256) void k_nf_cfft_half(nf_run r, const float2 *in, const float2 *om, float2 *halves) {
+  cfft_half_body(in + r.s_rel[blockIdx.x >> 1], om, halves);
 }
 
 // Interval q of a run (q = 0: up to the first detect point of the run, carried bin; q ≥ 1: from detect point q−1 on): its bin, whether
-// it differs from the interval before, P = p^D and the taps ρ = (scale·c) ∗ κ — in natural order (k_nf_head) and as the filter pass's
+// it differs from the interval before, P = p^D and the taps ρ = (scale·c) ∗ κ — in natural order (k_nf_scan computes r[0] with them) and as the filter pass's
 // coefficient operand (lane (k = l>>4, q' = l&15) of step s: K slot e = 4·s + k of tap block q': tap D·q' + e/2 as (re, −im)).
 // The carried bin travels from one run's launch of this kernel to the next one's through a ping-pong word (bin_in / bin_out), not through
 // nf_state: with lsdr_notch_fir_set_overlap the detect chain of run k+1 runs while run k's tail still owns the state.
-__global__ __launch_bounds__(256) void k_nf_taps(const int *bin_in, int *bin_out, int ndet, const int *cand /*[ndet][kMaxSlots]*/, const float *coeffs,
+__global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, int *bin_out, const int *cand /*[ndet][kMaxSlots]*/, const float *coeffs,
                                                  nf_consts C, int *ivbin, unsigned char *changed, float2 *ivP, float2 *ivrho /*[·][kNfTaps]*/,
-                                                 float *ivtab /*[·][kNfKs·64]*/) {
+                                                 float *ivtab /*[·][kNfKs·64]*/, unsigned *tile_first) {
+  const int ndet = run.ndet;
+  if (blockIdx.x == 0) for (int i = threadIdx.x; i <= ndet; i += 256) tile_first[i] = run.tile_first[i];     // (the filter pass reads them through a pointer)
   __shared__ double kr[kNfD + 1], ki[kNfD + 1];
   __shared__ double rr[kNfTaps], ri[kNfTaps];
   const int q = blockIdx.x, t = threadIdx.x;
@@ -705,25 +708,6 @@ __global__ __launch_bounds__(256) void k_nf_taps(const int *bin_in, int *bin_out
     if (qq < kNfNq && r < kNfD) v = (e & 1) ? (float)-ri[kNfD * qq + r] : (float)rr[kNfD * qq + r];
     ivtab[(size_t)q * (kNfKs * 64) + idx] = v;
   }
-}
-
-// r[0] of a run: its window reaches D − 1 samples back past `in` (the carried ones); the filter pass read zeros there
-__global__ __launch_bounds__(256) void k_nf_head(const float2 *in, const nf_state *st, const float2 *ivrho, int N, float2 *r) {
-  __shared__ float2 sh[256];
-  float2 acc = make_float2(0.f, 0.f);
-  for (int t = threadIdx.x; t < N + kNfD; t += 256) {
-    const int i = N - t;
-    const float2 x = i >= 0 ? in[i] : st->carry[32 + i];
-    const float2 v = nf_cmul(ivrho[t], x);
-    acc.x += v.x; acc.y += v.y;
-  }
-  sh[threadIdx.x] = acc;
-  __syncthreads();
-  for (int d = 128; d >= 1; d >>= 1) {
-    if ((int)threadIdx.x < d) { sh[threadIdx.x].x += sh[threadIdx.x + d].x; sh[threadIdx.x].y += sh[threadIdx.x + d].y; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) r[0] = sh[0];
 }
 
 // which boundary before `q` (exclusive) last changed the bin in this run: its index, or −1 (the segment came in with the run)
@@ -802,25 +786,63 @@ __global__ __launch_bounds__(256) void k_nf_fix(nf_run run, const float2 *in, co
 }
 
 // y[m] = A_m·y[m−1] + r[m] over the run: A_m = P of the interval that served output m's filter tile, 0 where r[m] is a given value.
-// One workgroup per kNfChunk outputs, started kNfWarm outputs early from zero (block 0: from the carried output, exactly).
+// One workgroup per kNfChunk outputs, started kNfWarm outputs early from zero (block 0: from the carried output, exactly).  The chunk
+// goes through LDS both ways (coalesced 8-byte accesses; a lane's kNfPer consecutive elements sit kNfPer + 1 slots apart: no conflicts
+// worth the name) — with 80-byte strides between lanes the kernel ran at 1.9 TB/s.
+// Block 0 also computes r[0] — its window reaches D − 1 samples back past `in` (the carried ones); the filter pass read zeros there —
+// and the block that holds the run's last output leaves what the next run needs in `so` (the OTHER state record: block 0 of this launch
+// may still be reading `st`): the last output, the raw samples in front of the new read pointer, the bin, sub at the new frontier.
 struct nf_aff { float2 a, b; };     // y → a·y + b
 __device__ __forceinline__ nf_aff nf_then(const nf_aff &f, const nf_aff &g) {   // f first, then g
   nf_aff o; o.a = nf_cmul(g.a, f.a); o.b = nf_cmul(g.a, f.b); o.b.x += g.b.x; o.b.y += g.b.y; return o;
 }
-__global__ __launch_bounds__(256) void k_nf_scan(nf_run run, const float2 *r, const nf_state *st, const float2 *ivP, const unsigned char *changed,
-                                                 float2 *out) {
+__device__ __forceinline__ void nf_state_body(const nf_run &run, const float2 *in, const nf_state *st, nf_state *so, const int *ivbin,
+                                              const unsigned char *changed, const nf_consts &C, float2 *sh);
+constexpr int kNfSlots = (kNfChunk + kNfWarm) + (kNfChunk + kNfWarm) / kNfPer;
+__device__ __forceinline__ int nf_slot(int i) { return i + i / kNfPer; }
+__global__ __launch_bounds__(256) void k_nf_scan(nf_run run, const float2 *in, const float2 *r, const nf_state *st, nf_state *so, const float2 *ivP,
+                                                 const float2 *ivrho, const int *ivbin, const unsigned char *changed, nf_consts C, float2 *out) {
+  __shared__ float2 rs[kNfSlots];
   __shared__ nf_aff sc[2][256];
+  __shared__ float2 sh[256];
   __shared__ unsigned long long s_mask;
   const int t = threadIdx.x;
+  if (blockIdx.x == gridDim.x - 1) { nf_state_body(run, in, st, so, ivbin, changed, C, sh); return; }      // (the grid's extra block)
   const long long c0 = (long long)blockIdx.x * kNfChunk, base = c0 - kNfWarm, cnt = (long long)run.count;
   const long long hi = c0 + kNfChunk < cnt ? c0 + kNfChunk : cnt;
   if (t == 0) s_mask = 0ull;
+  for (int i = t; i < kNfChunk + kNfWarm; i += 256) {
+    const long long m = base + i;
+    rs[nf_slot(i)] = (m >= 0 && m < hi) ? r[m] : make_float2(0.f, 0.f);
+  }
   __syncthreads();
   if (t < run.ndet && changed[t + 1] && run.m_lo[t] <= run.m_hi[t] && (long long)run.m_hi[t] >= base && (long long)run.m_lo[t] < hi)
     atomicOr(&s_mask, 1ull << t);
+  if (blockIdx.x == 0) {          // r[0]
+    float2 acc = make_float2(0.f, 0.f);
+    for (int tt = t; tt < C.N + kNfD; tt += 256) {
+      const int i = C.N - tt;
+      const float2 x = i >= 0 ? in[i] : st->carry[32 + i];
+      const float2 v = nf_cmul(ivrho[tt], x);
+      acc.x += v.x; acc.y += v.y;
+    }
+    sh[t] = acc;
+    __syncthreads();
+    for (int d = 128; d >= 1; d >>= 1) {
+      if (t < d) { sh[t].x += sh[t + d].x; sh[t].y += sh[t + d].y; }
+      __syncthreads();
+    }
+  }
   __syncthreads();
   const unsigned long long mask = s_mask;
-  const long long i0 = base + (long long)t * kNfPer;
+  if (blockIdx.x == 0 && t == 0) {
+    bool given0 = false;
+    for (int q = 0; q < run.ndet; ++q) if ((mask >> q & 1ull) && run.m_lo[q] == 0u) given0 = true;
+    if (!given0) rs[nf_slot(kNfWarm)] = sh[0];
+  }
+  __syncthreads();
+  const int e0 = t * kNfPer;
+  const long long i0 = base + e0;
   int iv = 0;
   {
     const long long mf = i0 > 0 ? i0 : 0;
@@ -837,7 +859,7 @@ __global__ __launch_bounds__(256) void k_nf_scan(nf_run run, const float2 *r, co
       const unsigned lt = (unsigned)(m / run.mw);
       while (iv < run.ndet && lt >= run.tile_first[iv + 1]) ++iv;
       a = ivP[iv];
-      b = r[m];
+      b = rs[e0 + e + t];          // = nf_slot(e0 + e)
       if (mask) {
         for (int q = 0; q < run.ndet; ++q)
           if ((mask >> q & 1ull) && m >= (long long)run.m_lo[q] && m <= (long long)run.m_hi[q]) a = make_float2(0.f, 0.f);
@@ -865,39 +887,43 @@ __global__ __launch_bounds__(256) void k_nf_scan(nf_run run, const float2 *r, co
   }
 #pragma unroll
   for (int e = 0; e < kNfPer; ++e) {
-    const long long m = i0 + e;
     const float2 ay = nf_cmul(A[e], y);
     y = make_float2(ay.x + B[e].x, ay.y + B[e].y);
-    if (m >= c0 && m < hi) out[m] = y;
+    rs[e0 + e + t] = y;
   }
+  __syncthreads();
+  for (int i = kNfWarm + t; i < kNfChunk + kNfWarm; i += 256) {
+    const long long m = base + i;
+    if (m < hi) out[m] = rs[nf_slot(i)];
+  }
+  if (hi == cnt && t == 0) so->y_last = rs[nf_slot((int)(cnt - 1 - base))];
 }
 
-// what the next run needs: last output, the raw samples in front of the new read pointer, the bin, sub at the new frontier
-__global__ __launch_bounds__(256) void k_nf_state(nf_run run, const float2 *in, const float2 *out, const int *ivbin, const unsigned char *changed,
-                                                  nf_consts C, nf_state *st) {
-  __shared__ float2 sh[256];
+// the rest of what the next run needs — the raw samples in front of the new read pointer, the bin, sub at the new frontier — into `so`;
+// launched as one more block of k_nf_scan's grid would have made that launch as long as scan + this (80 µs): its own workgroup in the same
+// launch instead (k_nf_scan_state below)
+__device__ __forceinline__ void nf_state_body(const nf_run &run, const float2 *in, const nf_state *st, nf_state *so, const int *ivbin,
+                                              const unsigned char *changed, const nf_consts &C, float2 *sh) {
   const int t = threadIdx.x;
+  const long long cnt = (long long)run.count;
   const int bin = ivbin[run.ndet];
-  const long long A = (long long)run.a_rel, Ap = (long long)run.a_prev_rel;
+  const long long Af = (long long)run.a_rel, Ap = (long long)run.a_prev_rel;
   float2 sub = make_float2(0.f, 0.f);
   if (bin >= 0) {
     const int sg = nf_seg_start(changed, run.ndet + 1);
     const bool carried = sg < 0;
     const long long start = carried ? Ap : (long long)run.s_rel[sg - 1];
-    const long long lo = A - kNfLook > start ? A - kNfLook : start;
-    const float2 w = nf_wsum(in, lo, A, bin, C.omk, sh);
+    const long long lo = Af - kNfLook > start ? Af - kNfLook : start;
+    const float2 w = nf_wsum(in, lo, Af, bin, C.omk, sh);
     sub = make_float2(C.k * w.x, C.k * w.y);
-    if (carried && A - start <= kNfLook) {
-      const float2 c2 = nf_cmul(nf_ppow(bin, C.omk, A - start), st->sub);
+    if (carried && Af - start <= kNfLook) {
+      const float2 c2 = nf_cmul(nf_ppow(bin, C.omk, Af - start), st->sub);
       sub.x += c2.x; sub.y += c2.y;
     }
   }
-  const long long F = (long long)run.count * kNfD;           // the new read pointer, relative to `in`
-  float2 cv = make_float2(0.f, 0.f);
-  if (t < 32) { const long long n = F - 32 + t; cv = n >= 0 ? in[n] : st->carry[32 + n]; }   // (n ≥ −32: the old carry, shifted)
-  __syncthreads();
-  if (t < 32) st->carry[t] = cv;
-  if (t == 0) { st->y_last = out[run.count - 1]; st->sub = sub; st->bin = bin; }
+  const long long F = cnt * kNfD;                            // the new read pointer, relative to `in`
+  if (t < 32) { const long long n = F - 32 + t; so->carry[t] = n >= 0 ? in[n] : st->carry[32 + n]; }   // (n ≥ −32: the old carry, shifted)
+  if (t == 0) { so->sub = sub; so->bin = bin; so->pad = 0; }
 }
 
 }  // namespace
@@ -1611,8 +1637,8 @@ struct lsdr_notch_fir {
   int wpc;
   unsigned long long F, A;          // stream positions: fir_filter's read pointer (= samples consumed), the notch's frontier (multiple of 4096)
   float *d_coeffs;
-  nf_state *d_state;
-  int *d_cand; float2 *d_spec; unsigned long long *d_offsets;
+  nf_state *d_state;               // [2]: a run reads one record and leaves the next run's in the other (run parity)
+  int *d_cand; float2 *d_spec;
   // per-run tables, two sets used alternately (run parity): with lsdr_notch_fir_set_overlap run k+1's detect chain and filter pass are
   // under way while run k's tail still reads its own
   unsigned *d_tile_first; int *d_ivbin; unsigned char *d_changed; float2 *d_ivP, *d_ivrho; float *d_ivtab;
@@ -1652,12 +1678,11 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   const size_t niv = kNfMaxDet + 1;
   LSDR_HIP(hipMalloc((void **)&h->d_coeffs, cfg->ncoeffs * sizeof(float)));
   LSDR_HIP(hipMemcpy(h->d_coeffs, cfg->coeffs_host, cfg->ncoeffs * sizeof(float), hipMemcpyHostToDevice));
-  LSDR_HIP(hipMalloc((void **)&h->d_state, sizeof(nf_state)));
-  nf_state s0; memset(&s0, 0, sizeof(s0)); s0.bin = -1;
-  LSDR_HIP(hipMemcpy(h->d_state, &s0, sizeof(s0), hipMemcpyHostToDevice));
+  LSDR_HIP(hipMalloc((void **)&h->d_state, 2 * sizeof(nf_state)));
+  nf_state s0[2]; memset(s0, 0, sizeof(s0)); s0[0].bin = s0[1].bin = -1;
+  LSDR_HIP(hipMemcpy(h->d_state, s0, sizeof(s0), hipMemcpyHostToDevice));
   LSDR_HIP(hipMalloc((void **)&h->d_cand, kNfMaxDet * kMaxSlots * sizeof(int)));
   LSDR_HIP(hipMalloc((void **)&h->d_spec, (size_t)kNfMaxDet * kN * sizeof(float2)));
-  LSDR_HIP(hipMalloc((void **)&h->d_offsets, kNfMaxDet * sizeof(unsigned long long)));
   LSDR_HIP(hipMalloc((void **)&h->d_tile_first, 2 * niv * sizeof(unsigned)));
   LSDR_HIP(hipMalloc((void **)&h->d_ivbin, 2 * niv * sizeof(int)));
   LSDR_HIP(hipMalloc((void **)&h->d_changed, 2 * (niv + 1)));
@@ -1690,7 +1715,7 @@ void lsdr_notch_fir_destroy(lsdr_notch_fir *h) {
     if (h->ev_tail[i]) (void)hipEventDestroy(h->ev_tail[i]);
   }
   (void)hipFree(h->d_bin_carry); (void)hipFree(h->d_r[1]);
-  (void)hipFree(h->d_coeffs); (void)hipFree(h->d_state); (void)hipFree(h->d_cand); (void)hipFree(h->d_spec); (void)hipFree(h->d_offsets);
+  (void)hipFree(h->d_coeffs); (void)hipFree(h->d_state); (void)hipFree(h->d_cand); (void)hipFree(h->d_spec);
   (void)hipFree(h->d_tile_first); (void)hipFree(h->d_ivbin); (void)hipFree(h->d_changed); (void)hipFree(h->d_ivP); (void)hipFree(h->d_ivrho);
   (void)hipFree(h->d_ivtab); (void)hipFree(h->d_r[0]);
   for (int i = 0; i < lsdr_notch_fir::kTimed; ++i) for (int j = 0; j < 2; ++j) if (h->tev[i][j]) (void)hipEventDestroy(h->tev[i][j]);
@@ -1733,7 +1758,7 @@ int lsdr_notch_fir_set_overlap(lsdr_notch_fir *h, int on) {
 int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h) {      // auto_notch's slot bin after the runs queued so far (waits for the stream)
   if (!h) return -1;
   int bin = -1;
-  if (hipMemcpyAsync(&bin, &h->d_state->bin, sizeof(int), hipMemcpyDeviceToHost, h->ctx->stream) != hipSuccess) return -1;
+  if (hipMemcpyAsync(&bin, &h->d_state[h->run_no & 1u].bin, sizeof(int), hipMemcpyDeviceToHost, h->ctx->stream) != hipSuccess) return -1;
   if (hipStreamSynchronize(h->ctx->stream) != hipSuccess) return -1;
   return bin;
 }
@@ -1819,15 +1844,13 @@ int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr
   hipStream_t st = c->stream, sd = h->overlap ? h->s_det : st, sp = h->overlap ? h->s_pass : st;
   // detect chain + taps (sd): the tables of this parity are free once the tail of the run two runs ago is through
   if (h->overlap && h->tail_recorded[par]) LSDR_HIP(hipStreamWaitEvent(sd, h->ev_tail[par], 0));
-  hipLaunchKernelGGL(k_nf_prep, dim3(1), dim3(64), 0, sd, run, (const float2 *)in, h->d_offsets, p_tile_first);
   if (run.ndet) {
-    hipLaunchKernelGGL(k_cfft_half, dim3(2u * run.ndet), dim3(256), 0, sd, (const float2 *)in, (const float2 *)h->fft.d_om, h->d_spec,
-                       (const unsigned long long *)h->d_offsets);
+    hipLaunchKernelGGL(k_nf_cfft_half, dim3(2u * run.ndet), dim3(256), 0, sd, run, (const float2 *)in, (const float2 *)h->fft.d_om, h->d_spec);
     hipLaunchKernelGGL(k_notch_peaks, dim3((unsigned)run.ndet), dim3(256), 0, sd, (const float2 *)h->d_spec, (const float2 *)h->fft.d_om,
                        (float)(1.0 / kN), 1, h->d_cand);
   }
-  hipLaunchKernelGGL(k_nf_taps, dim3((unsigned)run.ndet + 1), dim3(256), 0, sd, (const int *)(h->d_bin_carry + par), h->d_bin_carry + (par ^ 1u), run.ndet,
-                     (const int *)h->d_cand, (const float *)h->d_coeffs, C, p_ivbin, p_changed, p_ivP, p_ivrho, p_ivtab);
+  hipLaunchKernelGGL(k_nf_taps, dim3((unsigned)run.ndet + 1), dim3(256), 0, sd, run, (const int *)(h->d_bin_carry + par), h->d_bin_carry + (par ^ 1u),
+                     (const int *)h->d_cand, (const float *)h->d_coeffs, C, p_ivbin, p_changed, p_ivP, p_ivrho, p_ivtab, p_tile_first);
   LSDR_HIP(hipGetLastError());
   if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_taps[par], sd)); LSDR_HIP(hipStreamWaitEvent(sp, h->ev_taps[par], 0)); }
   // the filter pass (sp)
@@ -1841,15 +1864,14 @@ int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr
                                      (unsigned)run.ndet + 1, h->wpc, nullptr, sp));
   if (tp) { LSDR_HIP(hipEventRecord(tp[1], sp)); ++h->timed_runs; }
   if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_pass[par], sp)); LSDR_HIP(hipStreamWaitEvent(st, h->ev_pass[par], 0)); }
-  // the tail (the context's stream): r[0], the given outputs, the recurrence, the state for the next run
-  hipLaunchKernelGGL(k_nf_head, dim3(1), dim3(256), 0, st, (const float2 *)in, (const nf_state *)h->d_state, (const float2 *)p_ivrho, h->N, p_r);
+  // the tail (the context's stream): the given outputs; then r[0], the recurrence and the state for the next run in one launch
+  const nf_state *const st_in = h->d_state + par;
+  nf_state *const st_out = h->d_state + (par ^ 1u);
   if (run.ndet)
-    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, (const nf_state *)h->d_state, (const int *)p_ivbin,
+    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, st_in, (const int *)p_ivbin,
                        (const unsigned char *)p_changed, (const float *)h->d_coeffs, C, p_r);
-  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk)), dim3(256), 0, st, run, (const float2 *)p_r,
-                     (const nf_state *)h->d_state, (const float2 *)p_ivP, (const unsigned char *)p_changed, (float2 *)out);
-  hipLaunchKernelGGL(k_nf_state, dim3(1), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)out, (const int *)p_ivbin,
-                     (const unsigned char *)p_changed, C, h->d_state);
+  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk) + 1u), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)p_r, st_in,
+                     st_out, (const float2 *)p_ivP, (const float2 *)p_ivrho, (const int *)p_ivbin, (const unsigned char *)p_changed, C, (float2 *)out);
   LSDR_HIP(hipGetLastError());
   if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_tail[par], st)); h->tail_recorded[par] = true; }
   ++h->run_no;
