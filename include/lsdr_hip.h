@@ -210,6 +210,11 @@ typedef struct {
 int lsdr_notch_fir_create(lsdr_ctx *ctx, const lsdr_notch_fir_cfg *cfg, lsdr_notch_fir **h);
 void lsdr_notch_fir_destroy(lsdr_notch_fir *h);
 int lsdr_notch_fir_set(lsdr_notch_fir *h, int decimation, float k);
+/* fir_filter's carrier tracking (dsp.h:236-244,271-280) on the fused block: the taps are re-shifted (host libm, as lsdr_fir_filter_set_freq)
+ * and take effect with the next run; the decimated-rate recurrence is re-anchored under the new taps. */
+int lsdr_notch_fir_set_freq(lsdr_notch_fir *h, float freq);
+int lsdr_notch_fir_track(lsdr_notch_fir *h, float freq_tap, float tap_multiplier, float freq_tol, int *shifted);
+float lsdr_notch_fir_current_freq(const lsdr_notch_fir *h);
 int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed, size_t *produced);
 int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h);   /* waits for the stream; −1: nothing detected yet */
 /* Opt-in: run k+1's detect chain and filter pass on streams of the block's own, next to run k's tail (first output, fix-ups, recurrence,

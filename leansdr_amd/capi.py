@@ -125,6 +125,9 @@ _sig("lsdr_notch_fir_set", C.c_int, [vp, C.c_int, c_f])
 _sig("lsdr_notch_fir_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_notch_fir_slot_bin", C.c_int, [vp])
 _sig("lsdr_notch_fir_set_overlap", C.c_int, [vp, C.c_int])
+_sig("lsdr_notch_fir_set_freq", C.c_int, [vp, c_f])
+_sig("lsdr_notch_fir_track", C.c_int, [vp, c_f, c_f, c_f, C.POINTER(C.c_int)])
+_sig("lsdr_notch_fir_current_freq", c_f, [vp])
 _sig("lsdr_notch_fir_time", C.c_int, [vp, C.c_int, C.POINTER(c_f), C.POINTER(C.c_uint)])
 _sig("lsdr_cfft_host", C.c_int, [C.c_int, vp, C.c_int])
 _sig("lsdr_cnr_fft_create", C.c_int, [vp, c_f, C.c_int, C.POINTER(vp)])
@@ -955,6 +958,20 @@ class NotchFir:
 
     def bin(self):
         return lib.lsdr_notch_fir_slot_bin(self.h)
+
+    def set_freq(self, freq):
+        """fir_filter::set_freq (dsp.h:271-280): shifted taps from the next run on."""
+        check(lib.lsdr_notch_fir_set_freq(self.h, freq))
+
+    def track(self, freq_tap, tap_multiplier, freq_tol):
+        """fir_filter::run's tracking step (dsp.h:236-244); returns whether the taps were re-shifted."""
+        did = C.c_int()
+        check(lib.lsdr_notch_fir_track(self.h, freq_tap, tap_multiplier, freq_tol, C.byref(did)))
+        return bool(did.value)
+
+    @property
+    def current_freq(self):
+        return float(lib.lsdr_notch_fir_current_freq(self.h))
 
     def set_overlap(self, on=True):
         """Detect chain and filter pass of run k+1 on the block's own streams next to run k's tail (inputs must be complete at call time)."""

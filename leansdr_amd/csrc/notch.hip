@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void k_nf_cfft_half(nf_run r, const float2 *in
 // coefficient operand (lane (k = l>>4, q' = l&15) of step s: K slot e = 4·s + k of tap block q': tap D·q' + e/2 as (re, −im)).
 // The carried bin travels from one run's launch of this kernel to the next one's through a ping-pong word (bin_in / bin_out), not through
 // nf_state: with lsdr_notch_fir_set_overlap the detect chain of run k+1 runs while run k's tail still owns the state.
-__global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, int *bin_out, const int *cand /*[ndet][kMaxSlots]*/, const float *coeffs,
+__global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, int *bin_out, const int *cand /*[ndet][kMaxSlots]*/, const float2 *coeffs,
                                                  nf_consts C, int *ivbin, unsigned char *changed, float2 *ivP, float2 *ivrho /*[·][kNfTaps]*/,
                                                  float *ivtab /*[·][kNfKs·64]*/, unsigned *tile_first) {
   const int ndet = run.ndet;
@@ -695,8 +695,8 @@ __global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, 
     for (int j = 0; j <= kNfD; ++j) {
       const int i = tt - j;
       if (i < 0 || i >= C.N) continue;
-      const double cs = (double)(coeffs[i] * C.scale);      // the fused scaler rides on the taps: one f32 rounding per tap (as LSDR_FIR_MFMA_BLK)
-      re += kr[j] * cs; im += ki[j] * cs;
+      const float2 cs = coeffs[i];      // fir_filter's shifted taps (dsp.h:271-280) with the fused scaler on them: one f32 rounding per component
+      re += kr[j] * (double)cs.x - ki[j] * (double)cs.y; im += kr[j] * (double)cs.y + ki[j] * (double)cs.x;
     }
     rr[tt] = re; ri[tt] = im;
     ivrho[(size_t)q * kNfTaps + tt] = make_float2((float)re, (float)im);
@@ -718,7 +718,7 @@ __device__ __forceinline__ int nf_seg_start(const unsigned char *changed, int q)
 
 // Detect point q (interval q+1 begins at sample S) changed the bin: the outputs [m_lo, m_hi] directly.
 __global__ __launch_bounds__(256) void k_nf_fix(nf_run run, const float2 *in, const nf_state *st, const int *ivbin, const unsigned char *changed,
-                                                const float *coeffs, nf_consts C, float2 *r) {
+                                                const float2 *coeffs, nf_consts C, float2 *r) {
   __shared__ float2 xs[kNfFixSpan];
   __shared__ float2 sh[256];
   const int q = blockIdx.x, t = threadIdx.x;
@@ -777,12 +777,50 @@ __global__ __launch_bounds__(256) void k_nf_fix(nf_run run, const float2 *in, co
     const int top = (int)((long long)N + (long long)m * kNfD - n_first);
     float2 acc = make_float2(0.f, 0.f);
     for (int i = 0; i < N; ++i) {
-      const float cs = coeffs[i] * C.scale;
-      const float2 v = xs[top - i];
-      acc.x = fmaf(cs, v.x, acc.x); acc.y = fmaf(cs, v.y, acc.y);
+      const float2 cs = coeffs[i], v = xs[top - i];
+      acc.x = fmaf(cs.x, v.x, acc.x); acc.x = fmaf(-cs.y, v.y, acc.x);
+      acc.y = fmaf(cs.x, v.y, acc.y); acc.y = fmaf(cs.y, v.x, acc.y);
     }
     r[m] = acc;
   }
+}
+
+// fir_filter re-shifted its taps between two runs (dsp.h:236-244: the receiver's carrier estimate moved them): the recurrence wants the
+// output BEFORE this run's first one as the NEW taps would have given it — Σ_i c'[i]·out[N − D − i] over the notched samples, which reach
+// D − 1 samples back past `in` (the carried ones) and whose estimator is stepped BACKWARDS from its carried value at the notch's frontier
+// (sub[n−1] = (sub[n] − k·x[n]) / p; the frontier is 313–342 samples past `in`, the segment began at least a block earlier).  One workgroup.
+__global__ __launch_bounds__(256) void k_nf_retap(nf_run run, const float2 *in, nf_state *st, const float2 *coeffs, nf_consts C) {
+  __shared__ float2 xs[512];
+  __shared__ float2 sh[256];
+  const int t = threadIdx.x, N = C.N;
+  const int Ap = (int)run.a_prev_rel;                 // sub is known at sample Ap − 1
+  const int lo = -(kNfD - 1), span = Ap - lo;         // samples lo … Ap − 1
+  for (int i = t; i < span; i += 256) { const int n = lo + i; xs[i] = n >= 0 ? in[n] : st->carry[32 + n]; }
+  __syncthreads();
+  if (t == 0 && st->bin >= 0) {
+    const float2 p = nf_ppow(st->bin, C.omk, 1);
+    const float inv = 1.0f / (p.x * p.x + p.y * p.y);
+    const float2 ip = make_float2(p.x * inv, -p.y * inv);
+    float2 s = st->sub;
+    for (int i = span - 1; i >= 0; --i) {
+      const float2 x = xs[i];
+      xs[i] = make_float2(x.x - s.x, x.y - s.y);
+      s = nf_cmul(make_float2(s.x - C.k * x.x, s.y - C.k * x.y), ip);
+    }
+  }
+  __syncthreads();
+  float2 acc = make_float2(0.f, 0.f);
+  for (int i = t; i < N; i += 256) {
+    const float2 v = nf_cmul(coeffs[i], xs[(N - kNfD - i) - lo]);
+    acc.x += v.x; acc.y += v.y;
+  }
+  sh[t] = acc;
+  __syncthreads();
+  for (int d = 128; d >= 1; d >>= 1) {
+    if (t < d) { sh[t].x += sh[t + d].x; sh[t].y += sh[t + d].y; }
+    __syncthreads();
+  }
+  if (t == 0) st->y_last = sh[0];
 }
 
 // y[m] = A_m·y[m−1] + r[m] over the run: A_m = P of the interval that served output m's filter tile, 0 where r[m] is a given value.
@@ -1636,7 +1674,8 @@ struct lsdr_notch_fir {
   float k, scale;
   int wpc;
   unsigned long long F, A;          // stream positions: fir_filter's read pointer (= samples consumed), the notch's frontier (multiple of 4096)
-  float *d_coeffs;
+  std::vector<float> coeffs; float freq; bool retap;      // fir_filter's prototype taps, its current shift (dsp.h:271-280), "re-shifted since the last run"
+  float2 *d_coeffs;                 // the shifted taps, scaled
   nf_state *d_state;               // [2]: a run reads one record and leaves the next run's in the other (run parity)
   int *d_cand; float2 *d_spec;
   // per-run tables, two sets used alternately (run parity): with lsdr_notch_fir_set_overlap run k+1's detect chain and filter pass are
@@ -1653,6 +1692,17 @@ struct lsdr_notch_fir {
   static const int kTimed = 16;
   bool timing; hipEvent_t tev[kTimed][2]; unsigned timed_runs;
 };
+
+static int nf_sync_all(lsdr_notch_fir *h);
+// fir_filter::set_freq (dsp.h:271-280) for the fused block: shifted taps (host libm, as the reference), the fused scaler on them
+static int nf_upload_taps(lsdr_notch_fir *h) {
+  std::vector<lsdr_cf32> sc(h->coeffs.size());
+  lsdr::fir_shift_coeffs((unsigned)h->coeffs.size(), h->coeffs.data(), h->freq, sc.data());
+  for (auto &v : sc) { v.re *= h->scale; v.im *= h->scale; }
+  LSDR_TRY(nf_sync_all(h));                      // (rare: queued runs may still read the old taps)
+  LSDR_HIP(hipMemcpy(h->d_coeffs, sc.data(), sc.size() * sizeof(float2), hipMemcpyHostToDevice));
+  return LSDR_OK;
+}
 
 extern "C" {
 
@@ -1676,8 +1726,10 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   memset(h->ev_taps, 0, sizeof(h->ev_taps)); memset(h->ev_pass, 0, sizeof(h->ev_pass)); memset(h->ev_tail, 0, sizeof(h->ev_tail));
   memset(h->tev, 0, sizeof(h->tev));
   const size_t niv = kNfMaxDet + 1;
-  LSDR_HIP(hipMalloc((void **)&h->d_coeffs, cfg->ncoeffs * sizeof(float)));
-  LSDR_HIP(hipMemcpy(h->d_coeffs, cfg->coeffs_host, cfg->ncoeffs * sizeof(float), hipMemcpyHostToDevice));
+  h->coeffs.assign(cfg->coeffs_host, cfg->coeffs_host + cfg->ncoeffs);
+  h->freq = 0.f; h->retap = false;
+  LSDR_HIP(hipMalloc((void **)&h->d_coeffs, cfg->ncoeffs * sizeof(float2)));
+  { int rc0 = nf_upload_taps(h); if (rc0) return rc0; }
   LSDR_HIP(hipMalloc((void **)&h->d_state, 2 * sizeof(nf_state)));
   nf_state s0[2]; memset(s0, 0, sizeof(s0)); s0[0].bin = s0[1].bin = -1;
   LSDR_HIP(hipMemcpy(h->d_state, s0, sizeof(s0), hipMemcpyHostToDevice));
@@ -1697,12 +1749,32 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   return LSDR_OK;
 }
 
+}  // extern "C"
 static int nf_sync_all(lsdr_notch_fir *h) {
   if (h->s_det) LSDR_HIP(hipStreamSynchronize(h->s_det));
   if (h->s_pass) LSDR_HIP(hipStreamSynchronize(h->s_pass));
   LSDR_HIP(hipStreamSynchronize(h->ctx->stream));
   return LSDR_OK;
 }
+extern "C" {
+
+// fir_filter::set_freq / the tracking of fir_filter::run (dsp.h:236-244,271-280): the taps follow the receiver's carrier estimate.  Takes
+// effect with the next run (as the reference's: run() re-shifts before it filters).
+int lsdr_notch_fir_set_freq(lsdr_notch_fir *h, float freq) {
+  LSDR_ARG(h);
+  h->freq = freq;
+  h->retap = h->F != 0 || h->A != 0;             // outputs exist already: the recurrence must be re-anchored under the new taps
+  return nf_upload_taps(h);
+}
+int lsdr_notch_fir_track(lsdr_notch_fir *h, float freq_tap, float tap_multiplier, float freq_tol, int *shifted) {
+  LSDR_ARG(h);
+  const float new_freq = freq_tap * tap_multiplier;          // dsp.h:237-238
+  int did = 0;
+  if (fabs(h->freq - new_freq) > freq_tol) { LSDR_TRY(lsdr_notch_fir_set_freq(h, new_freq)); did = 1; }
+  if (shifted) *shifted = did;
+  return LSDR_OK;
+}
+float lsdr_notch_fir_current_freq(const lsdr_notch_fir *h) { return h ? h->freq : 0.f; }
 
 void lsdr_notch_fir_destroy(lsdr_notch_fir *h) {
   if (!h) return;
@@ -1850,7 +1922,7 @@ int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr
                        (float)(1.0 / kN), 1, h->d_cand);
   }
   hipLaunchKernelGGL(k_nf_taps, dim3((unsigned)run.ndet + 1), dim3(256), 0, sd, run, (const int *)(h->d_bin_carry + par), h->d_bin_carry + (par ^ 1u),
-                     (const int *)h->d_cand, (const float *)h->d_coeffs, C, p_ivbin, p_changed, p_ivP, p_ivrho, p_ivtab, p_tile_first);
+                     (const int *)h->d_cand, (const float2 *)h->d_coeffs, C, p_ivbin, p_changed, p_ivP, p_ivrho, p_ivtab, p_tile_first);
   LSDR_HIP(hipGetLastError());
   if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_taps[par], sd)); LSDR_HIP(hipStreamWaitEvent(sp, h->ev_taps[par], 0)); }
   // the filter pass (sp)
@@ -1865,12 +1937,13 @@ int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr
   if (tp) { LSDR_HIP(hipEventRecord(tp[1], sp)); ++h->timed_runs; }
   if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_pass[par], sp)); LSDR_HIP(hipStreamWaitEvent(st, h->ev_pass[par], 0)); }
   // the tail (the context's stream): the given outputs; then r[0], the recurrence and the state for the next run in one launch
-  const nf_state *const st_in = h->d_state + par;
+  nf_state *const st_in = h->d_state + par;
   nf_state *const st_out = h->d_state + (par ^ 1u);
+  if (h->retap) { hipLaunchKernelGGL(k_nf_retap, dim3(1), dim3(256), 0, st, run, (const float2 *)in, st_in, (const float2 *)h->d_coeffs, C); h->retap = false; }
   if (run.ndet)
-    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, st_in, (const int *)p_ivbin,
-                       (const unsigned char *)p_changed, (const float *)h->d_coeffs, C, p_r);
-  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk) + 1u), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)p_r, st_in,
+    hipLaunchKernelGGL(k_nf_fix, dim3((unsigned)run.ndet), dim3(256), 0, st, run, (const float2 *)in, (const nf_state *)st_in, (const int *)p_ivbin,
+                       (const unsigned char *)p_changed, (const float2 *)h->d_coeffs, C, p_r);
+  hipLaunchKernelGGL(k_nf_scan, dim3((unsigned)((count + kNfChunk - 1) / kNfChunk) + 1u), dim3(256), 0, st, run, (const float2 *)in, (const float2 *)p_r, (const nf_state *)st_in,
                      st_out, (const float2 *)p_ivP, (const float2 *)p_ivrho, (const int *)p_ivbin, (const unsigned char *)p_changed, C, (float2 *)out);
   LSDR_HIP(hipGetLastError());
   if (h->overlap) { LSDR_HIP(hipEventRecord(h->ev_tail[par], st)); h->tail_recorded[par] = true; }

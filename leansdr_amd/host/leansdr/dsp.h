@@ -95,6 +95,28 @@ struct scaler<float, complex<float>, complex<float> > : runnable {
 template <typename T, typename Tc>
 struct fir_filter;
 
+// What an auto_notch block (sdr.h) offers a fir_filter that reads its output — leandvb's default graph, leandvb.cc:296-301,353-382 — so that
+// the two can run as ONE block (lsdr_notch_fir: the notched stream never exists).  Opt-in (LSDR_FUSE_NOTCH=1): a tolerance mode.
+struct notch_tap_point {
+  virtual ~notch_tap_point() {}
+  virtual dev_reader<complex<float> > *raw_input() = 0;     // the notch's own input end: the fused block reads the raw stream there
+  virtual int notch_slots() const = 0;
+  virtual float notch_setpoint() const = 0;
+  virtual int notch_decimation() const = 0;
+  virtual float notch_k() const = 0;
+  bool fused_away;                                           // set by the fir_filter that took over: the notch's run() does nothing
+  notch_tap_point() : fused_away(false) {}
+};
+// A reader of the notched stream that only observes it (spectrum: leandvb.cc:335-343 instantiates one ALWAYS — `if (cfg.fd_spectrum)` with
+// a default of −1 — and nobody reads its rows unless --fd-spectrum is given): while nobody reads its output it can be switched off, and
+// the notched stream need not exist for its sake.
+struct passive_tap {
+  virtual ~passive_tap() {}
+  virtual bool tap_output_used() = 0;
+  bool tap_detached;
+  passive_tap() : tap_detached(false) {}
+};
+
 template <>
 struct fir_filter<complex<float>, float> : runnable {
   float *freq_tap;        // → cstln_receiver::freq_tap (leandvb.cc:506-510)
@@ -104,13 +126,44 @@ struct fir_filter<complex<float>, float> : runnable {
   fir_filter(scheduler *sch, int ncoeffs, float *coeffs, pipebuf<complex<float> > &i, pipebuf<complex<float> > &o,
              unsigned int decim = 1, float fuse_scale = 0)
       : runnable(sch, "fir_filter"), freq_tap(NULL), tap_multiplier(1), freq_tol(0.1),
-        ctx(pipe_ctx(i, o, "fir_filter: pipebufs of two device contexts")), n(ncoeffs), d(decim), in(i), out(o) {
+        ctx(pipe_ctx(i, o, "fir_filter: pipebufs of two device contexts")), n(ncoeffs), d(decim), in(i), out(o), h(NULL),
+        hf(NULL), notch(NULL), fused_pipe(&i), fused_ready(false) {
+    // LSDR_FUSE_NOTCH=1: the pipe's writer is an auto_notch the fused block exists for (one slot, no AGC set point, decimation 30,
+    // ncoeffs ≤ 330): take it over.  Anything else — and every graph without the variable — keeps the two blocks.
+    // The decision is prepare()'s: only then is every reader of the notched stream known.
+    const char *fe = getenv("LSDR_FUSE_NOTCH");
+    if (fe && atoi(fe) != 0 && i.fusable_producer) {
+      notch_tap_point *np = static_cast<notch_tap_point *>(i.fusable_producer);
+      lsdr_notch_fir_cfg fc;
+      fc.ncoeffs = ncoeffs; fc.coeffs_host = coeffs; fc.decim = decim; fc.in_scale = fuse_scale; fc.nslots = np->notch_slots();
+      fc.notch_decimation = 0; fc.k = 0;
+      if (np->notch_setpoint() == 0 && lsdr_notch_fir_create(ctx, &fc, &hf) == LSDR_OK) notch = np;
+      else hf = NULL;
+    }
     lsdr_fir_filter_cfg cfg;
     cfg.ncoeffs = ncoeffs; cfg.coeffs_host = coeffs; cfg.decim = decim;
     cfg.in_format = LSDR_IN_CF32; cfg.in_scale = fuse_scale; cfg.arith = LSDR_FIR_EXACT;
     lsdr_check(lsdr_fir_filter_create(ctx, &cfg, &h), name);
   }
+  void prepare() {
+    if (!hf) return;
+    // every other reader of the notched stream must be an observer nobody listens to; then they are switched off and the notch is ours
+    bool ok = !notch->fused_away;
+    for (size_t r = 0; ok && r < fused_pipe->n_readers(); ++r) {
+      if ((int)r == in.id) continue;
+      passive_tap *pt = static_cast<passive_tap *>(fused_pipe->reader_owner((int)r));
+      ok = pt != NULL && !pt->tap_output_used();
+    }
+    if (!ok) { lsdr_notch_fir_destroy(hf); hf = NULL; return; }
+    for (size_t r = 0; r < fused_pipe->n_readers(); ++r)
+      if ((int)r != in.id) static_cast<passive_tap *>(fused_pipe->reader_owner((int)r))->tap_detached = true;
+    notch->fused_away = true;
+    out.buf.need_room(4096 / d + 16);          // (the fused block produces a whole 4096-sample block's outputs or nothing)
+    lsdr_check(lsdr_notch_fir_set(hf, notch->notch_decimation(), notch->notch_k()), name);     // auto_notch's public tunables, as set by now
+    if (sch->verbose) fprintf(stderr, "fir_filter: fused with auto_notch (lsdr_notch_fir)\n");
+  }
   void run() {
+    if (hf) { run_fused(); return; }
     if (in.readable() < n) return;
     if (freq_tap) {  // dsp.h:236-244
       int shifted = 0;
@@ -127,11 +180,34 @@ struct fir_filter<complex<float>, float> : runnable {
   }
 
  private:
+  // auto_notch + fir_filter as one block: the raw stream is read at the notch's input end, at this filter's pace
+  void run_fused() {
+    if (freq_tap) {  // dsp.h:236-244
+      int shifted = 0;
+      float before = lsdr_notch_fir_current_freq(hf);
+      lsdr_check(lsdr_notch_fir_track(hf, *freq_tap, tap_multiplier, freq_tol, &shifted), name);
+      if (shifted && sch->verbose)
+        fprintf(stderr, "Shifting filter %f -> %f\n", before, lsdr_notch_fir_current_freq(hf));
+    }
+    dev_reader<complex<float> > *src = notch->raw_input();
+    unsigned long room = out.writable();
+    size_t consumed = 0, produced = 0;
+    lsdr_check(lsdr_notch_fir_run(hf, (const lsdr_cf32 *)src->rd(), src->readable(), (lsdr_cf32 *)out.wr(), room, &consumed, &produced), name);
+    if (sch->debug) fprintf(stderr, "fir_filter(fused): readable %lu room %lu -> consumed %lu produced %lu\n", (unsigned long)src->readable(), room,
+                            (unsigned long)consumed, (unsigned long)produced);
+    src->read(consumed);
+    out.written(produced);
+  }
+
   lsdr_ctx *ctx;
   unsigned n, d;
   dev_reader<complex<float> > in;
   dev_writer<complex<float> > out;
   lsdr_fir_filter *h;
+  lsdr_notch_fir *hf;               // non-NULL: fused with the auto_notch in front
+  notch_tap_point *notch;
+  pipebuf<complex<float> > *fused_pipe;
+  bool fused_ready;
 };
 
 // decimator<cf32> (generic.h:247-267 of the reference) on device pipebufs.

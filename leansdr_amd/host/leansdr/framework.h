@@ -83,7 +83,10 @@ namespace detail {
 // What the scheduler needs to know about a pipe and a block.
 struct pipe_base {
   const char *name;
-  explicit pipe_base(const char *n) : name(n) {}
+  // A block that writes this pipe and can be FUSED with the block that reads it (auto_notch → fir_filter, dsp.h / sdr.h) leaves
+  // itself here; NULL otherwise.  The reader decides (and checks that it is the pipe's only one).
+  void *fusable_producer;
+  explicit pipe_base(const char *n) : name(n), fusable_producer(NULL) {}
   virtual ~pipe_base() {}
   virtual unsigned long long traffic() const = 0;   // items written + items read so far
   virtual size_t bytes() const = 0;
@@ -95,18 +98,23 @@ struct block_base {
   virtual ~block_base() {}
   virtual void run() {}
   virtual void shutdown() {}
+  virtual void prepare() {}      // once, before the scheduler's first pass: the whole graph exists by then (every end is attached)
 };
 }  // namespace detail
 
 struct scheduler {
   bool verbose, debug;
   window_placement *windows;
-  scheduler() : verbose(false), debug(false), windows(NULL) {}
+  scheduler() : verbose(false), debug(false), windows(NULL), prepared_(false) {}
 
   void attach(detail::pipe_base *p) { pipes_.push_back(p); }
   void attach(detail::block_base *b) { blocks_.push_back(b); }
 
   void step() {
+    if (!prepared_) {            // decisions that need the complete graph (dsp.h: fir_filter taking over the auto_notch in front of it)
+      prepared_ = true;
+      for (size_t i = 0; i < blocks_.size(); ++i) blocks_[i]->prepare();
+    }
     for (size_t i = 0; i < blocks_.size(); ++i) blocks_[i]->run();
   }
   void run() {
@@ -131,6 +139,7 @@ struct scheduler {
  private:
   std::vector<detail::pipe_base *> pipes_;
   std::vector<detail::block_base *> blocks_;
+  bool prepared_;
   unsigned long long fingerprint() const {
     unsigned long long f = 0;
     for (size_t i = 0; i < pipes_.size(); ++i) f += (i + 1) * pipes_[i]->traffic();
@@ -200,10 +209,18 @@ struct pipebuf : detail::pipe_base {
     used_[side] = true;
     if (min_write > need_) need_ = min_write;
   }
+  size_t n_readers() const { return tails_.size(); }
+  // a writer that only works in larger steps than it said when it attached (dsp.h: the fused auto_notch + fir_filter produces a
+  // whole 4096-sample block's outputs or nothing): compaction is triggered while that much tail room is missing
+  void need_room(unsigned long items) { if (items > need_) need_ = items; }
+  // a reader may say what it is (dsp.h passive_tap: a reader that can be switched off when nobody reads ITS output)
+  void set_reader_owner(int r, void *owner) { owners_[r] = owner; }
+  void *reader_owner(int r) const { return owners_[r]; }
   int attach_reader(pipe_side side) {
     used_[side] = true;
     tails_.push_back(head_);
     rside_.push_back((char)side);
+    owners_.push_back(NULL);
     return (int)tails_.size() - 1;
   }
   // -- writer side
@@ -254,6 +271,7 @@ struct pipebuf : detail::pipe_base {
   unsigned long mirrored_;            // items below this index have been sent to the non-writer side
   bool h2d_unfenced_, d2h_inflight_;
   std::vector<unsigned long> tails_;
+  std::vector<void *> owners_;
   std::vector<char> rside_;
 
   lsdr_ctx *ctx() {

@@ -99,18 +99,27 @@ template <typename T>
 struct auto_notch;
 
 template <>
-struct auto_notch<f32> : runnable {
+struct auto_notch<f32> : runnable, notch_tap_point {
   int decimation;
   float k;
   auto_notch(scheduler *sch, pipebuf<cf32> &i, pipebuf<cf32> &o, int nslots, f32 agc_rms_setpoint)
       : runnable(sch, "auto_notch"), decimation(1024 * 4096), k(0.002),
-        ctx(pipe_ctx(i, o, "auto_notch: pipebufs of two device contexts")), in(i), out(o, 4096), h(NULL) {
+        ctx(pipe_ctx(i, o, "auto_notch: pipebufs of two device contexts")), in(i), out(o, 4096), h(NULL), nslots_(nslots),
+        setpoint_(agc_rms_setpoint) {
+    o.fusable_producer = static_cast<notch_tap_point *>(this);      // a fir_filter reading `o` may take this block over (dsp.h, LSDR_FUSE_NOTCH)
     lsdr_check(lsdr_auto_notch_create(ctx, nslots, agc_rms_setpoint, &h), name);
     // throughput mode (single-pass scan, detect() on the device) where it applies: leandvb's configuration (no AGC set point)
     if (env_flag("LSDR_TILED") && agc_rms_setpoint == 0 && nslots >= 1 && nslots <= 4) lsdr_check(lsdr_auto_notch_set_mode(h, LSDR_NOTCH_SCAN), name);
   }
   void set_throughput_mode() { lsdr_check(lsdr_auto_notch_set_mode(h, LSDR_NOTCH_SCAN), name); }
+  // notch_tap_point
+  dev_reader<cf32> *raw_input() { return &in; }
+  int notch_slots() const { return nslots_; }
+  float notch_setpoint() const { return setpoint_; }
+  int notch_decimation() const { return decimation; }
+  float notch_k() const { return k; }
   void run() {
+    if (fused_away) return;          // a fir_filter runs this block's work inside its own (lsdr_notch_fir)
     lsdr_check(lsdr_auto_notch_set(h, decimation, k), name);
     unsigned long room = out.writable();
     size_t consumed = 0, produced = 0;
@@ -124,6 +133,8 @@ struct auto_notch<f32> : runnable {
   dev_reader<cf32> in;
   dev_writer<cf32> out;
   lsdr_auto_notch *h;
+  int nslots_;
+  float setpoint_;
 };
 
 // cnr_fft<f32> (sdr.h:1273-1345): device input pipe, host float output pipe.
@@ -273,15 +284,18 @@ template <typename T>
 struct spectrum;
 
 template <>
-struct spectrum<f32> : runnable {
+struct spectrum<f32> : runnable, passive_tap {
   static const int nfft = 1024;
   int decimation;
   float kavg;
   spectrum(scheduler *sch, pipebuf<cf32> &i, pipebuf<float[nfft]> &o)
-      : runnable(sch, "spectrum"), decimation(1048576), kavg(0.1), ctx(pipe_ctx(i, "spectrum")), in(i), out(o), h(NULL) {
+      : runnable(sch, "spectrum"), decimation(1048576), kavg(0.1), ctx(pipe_ctx(i, "spectrum")), in(i), out(o), h(NULL), opipe(&o) {
     lsdr_check(lsdr_spectrum_create(ctx, &h), name);
+    i.set_reader_owner(in.id, static_cast<passive_tap *>(this));
   }
+  bool tap_output_used() { return opipe->n_readers() > 0; }
   void run() {
+    if (tap_detached) return;        // nobody reads the rows, and a fir_filter fused with the auto_notch in front (dsp.h): the stream is not there
     lsdr_check(lsdr_spectrum_set(h, decimation, kavg), name);
     unsigned long room = out.writable();
     size_t consumed = 0, produced = 0;
@@ -295,6 +309,7 @@ struct spectrum<f32> : runnable {
   dev_reader<cf32> in;
   pipewriter<float[nfft]> out;
   lsdr_spectrum *h;
+  pipebuf<float[nfft]> *opipe;
 };
 
 // Samplers: descriptors consumed by cstln_receiver (the interpolation itself runs on the GPU).

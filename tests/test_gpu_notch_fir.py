@@ -122,3 +122,37 @@ def test_overlapped_runs_give_the_same_bits(capi, ctx, oracle):
         nf.close()
     assert outs[0][1] == outs[1][1] and outs[0][2] == outs[1][2]
     assert np.array_equal(outs[0][0].view(np.uint64), outs[1][0].view(np.uint64))
+
+
+def test_taps_follow_the_carrier_like_fir_filter(capi, ctx, oracle):
+    """fir_filter's tracking (dsp.h:236-244): the taps are re-shifted between two runs — twice here, with a bin change in between — and
+    every output, the first ones after each shift included, is what the oracle's fir_filter with the same shift schedule gives over
+    the oracle's notched stream (the recurrence is re-anchored under the new taps; complex taps through k_nf_taps / k_nf_fix)."""
+    dec = 4096 * 4
+    n = 4096 * 48
+    x = signal(n, 21, [(0, 0.0021, 30.0), (4096 * 22 + 500, 0.0032, 38.0)])
+    c = c2_taps(capi)
+    xn, bins = oracle.auto_notch(x, 1, dec, 0.002, 0.0)
+    nf = capi.NotchFir(ctx, c, DECIM, decimation=dec)
+    din = ctx.upload(x)
+    dout = ctx.alloc((n // DECIM + 16) * 8)
+    sched = [(4096 * 15 + 77, 0.0), (4096 * 33, 0.0023), (n, -0.0011)]       # (feed up to here, with this shift)
+    pos = nout = 0
+    got_freqs = []
+    for upto, freq in sched:
+        if freq != nf.current_freq:
+            assert nf.track(freq * 4, 0.25, 1e-4) and abs(nf.current_freq - np.float32(freq * 4) * np.float32(0.25)) < 1e-9
+        got_freqs.append((nout, nf.current_freq))
+        cons, prod = nf.run_dev(din.at(pos * 8), upto - pos, dout.at(nout * 8), n // DECIM + 16 - nout)
+        pos += cons; nout += prod
+    y = ctx.download(dout, np.complex64, nout)
+    # the oracle: the same shift schedule by output index over the notched stream
+    ref = np.zeros(nout, np.complex64)
+    for k, (m0, f) in enumerate(got_freqs):
+        m1 = got_freqs[k + 1][0] if k + 1 < len(got_freqs) else nout
+        seg, _ = oracle.fir_filter(c, DECIM, xn[m0 * DECIM:], freq=f)
+        ref[m0:m1] = seg[:m1 - m0]
+    assert nout > 6000 and len(got_freqs) == 3 and got_freqs[1][0] > 0 and got_freqs[2][0] > got_freqs[1][0]
+    assert nf.bin() == bins[0]
+    assert rel_err(y, ref) <= 2e-5, rel_err(y, ref)
+    nf.close(); din.free(); dout.free()
