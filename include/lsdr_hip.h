@@ -277,6 +277,10 @@ typedef struct {
   int arith;                 /* LSDR_FIR_* */
 } lsdr_fir_filter_cfg;
 typedef struct lsdr_fir_filter lsdr_fir_filter;
+/* Precondition of the matrix-pipe arithmetics (LSDR_FIR_MFMA, LSDR_FIR_MFMA_BLK): FINITE input samples.  Their K padding and the zero band of
+ * the Toeplitz form multiply padding taps of 0.0 with real samples (fma(0, x, acc) = acc needs a finite x): one Inf or NaN sample reaches up to
+ * 15·decim more outputs than in LSDR_FIR_EXACT / LSDR_FIR_FMA, where it stays inside its own tap window.  The same holds for what lies up to
+ * 4 GiB behind the first tile of a stream longer than 4 GiB (read through a clamped buffer resource instead of zeros: finite, hence harmless). */
 int lsdr_fir_filter_create(lsdr_ctx *ctx, const lsdr_fir_filter_cfg *cfg, lsdr_fir_filter **f);
 void lsdr_fir_filter_destroy(lsdr_fir_filter *f);
 /* set_freq(f), dsp.h:271-280 (host libm cosf/sinf, then upload). */

@@ -317,7 +317,8 @@ __device__ __forceinline__ float2 scan_wait(const float2 *tot_slot, const unsign
   while (__hip_atomic_load(flag_slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != stamp) {
     __builtin_amdgcn_s_sleep(1);
     if (++spins > (1u << 21)) {      // ≈ 0.1 s: the predecessor is not coming (dispatch order?) — give up loudly
-      __hip_atomic_store(abort_flag, stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned expect = 0u;          // the FIRST run that gave up stays on record (later ones only inherit its garbage)
+      (void)__hip_atomic_compare_exchange_strong(abort_flag, &expect, stamp, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       break;
     }
   }
@@ -1342,6 +1343,10 @@ static int notch_scan_pull(lsdr_auto_notch *a) {
   LSDR_HIP(hipMemcpyAsync(a->bins, a->d_bins + a->scarry_cur * kMaxSlots, kMaxSlots * sizeof(int), hipMemcpyDeviceToHost, a->ctx->stream));
   LSDR_HIP(hipMemcpyAsync(&a->est, a->d_scarry[a->scarry_cur], sizeof(notch_est), hipMemcpyDeviceToHost, a->ctx->stream));
   LSDR_HIP(hipStreamSynchronize(a->ctx->stream));
+  if (a->h_abort && *a->h_abort) {     // every point where the host has waited for the stream anyway: say so NOW, not at the next run
+    lsdr_set_error("auto_notch(scan): a wave-block's look-back timed out in run %u — the output from that run on is not valid (use LSDR_NOTCH_EXACT)", *a->h_abort);
+    return LSDR_E_UNSUPPORTED;
+  }
   return LSDR_OK;
 }
 

@@ -188,20 +188,37 @@ __device__ __forceinline__ void rx_compact_body(const SYM *stage, unsigned stage
     __threadfence_system();
     if (sr.rot_final) rx_rotate_back(state, sr.rot_final, quad);
   }
-  const unsigned j1 = j0 + kCompactTiles < n_tiles ? j0 + kCompactTiles : n_tiles;
-  for (unsigned j = j0; j < j1; ++j) {
-    const rx_tile_fix f = fix[j];
-    const rx_tile_info_t<SYM> ti = info[j];
-    const uint8_t *map = relabel + ((f.rot + brot) & rmask) * 256;
-    const SYM *src = stage + (unsigned long long)j * stage_stride;
-    SYM *dst = out + base + f.out_offset;
-    if (f.insert_pre) {
-      if (threadIdx.x == 0) dst[0] = rx_relabel(ti.pre, map);
-      dst += 1;
+  // The workgroup's tiles side by side: lane t keeps tile j0 + t's records, every lane then has one symbol of EACH tile in flight (a
+  // tile after the other — its records, its symbols, their relabelling, each a dependent load — took 75 µs next to fir_filter for the
+  // C2 batch where one tile per workgroup had taken 59: the compaction is latency, not bytes).  A tile holds ≤ 64 body symbols at the
+  // C2 geometry: one pass, a second one only where a tile has more.
+  const unsigned nt = j0 + kCompactTiles < n_tiles ? kCompactTiles : n_tiles - j0;
+  const unsigned lane = threadIdx.x;
+  rx_tile_fix fl; fl.out_offset = 0; fl.rot = 0; fl.drop_first = 0; fl.insert_pre = 0;
+  unsigned cnt_l = 0;
+  if (lane < nt) { fl = fix[j0 + lane]; cnt_l = info[j0 + lane].count; }
+  if (lane < nt && fl.insert_pre) {      // the warm-up's last symbol belongs to this tile
+    const rx_tile_info_t<SYM> ti = info[j0 + lane];
+    out[base + fl.out_offset] = rx_relabel(ti.pre, relabel + ((fl.rot + brot) & rmask) * 256);
+  }
+  unsigned maxc = cnt_l;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const unsigned o = __shfl_xor(maxc, d, 64); maxc = o > maxc ? o : maxc; }
+  for (unsigned k0 = 0; k0 < maxc; k0 += 64) {
+    SYM v[kCompactTiles];
+    bool ok[kCompactTiles];
+#pragma unroll
+    for (unsigned t = 0; t < kCompactTiles; ++t) {
+      const unsigned cnt = __shfl(cnt_l, t, 64), skip = __shfl(fl.drop_first, t, 64) ? 1u : 0u;
+      const unsigned k = k0 + lane + skip;
+      ok[t] = t < nt && k < cnt;
+      if (ok[t]) v[t] = stage[(unsigned long long)(j0 + t) * stage_stride + k];
     }
-    const unsigned skip = f.drop_first ? 1u : 0u;
-    for (unsigned k = threadIdx.x + skip; k < ti.count; k += 64) {
-      dst[k - skip] = rx_relabel(src[k], map);
+#pragma unroll
+    for (unsigned t = 0; t < kCompactTiles; ++t) {
+      const unsigned long long off = __shfl(fl.out_offset, t, 64);
+      const unsigned rot = __shfl(fl.rot, t, 64), ins = __shfl(fl.insert_pre, t, 64) ? 1u : 0u;
+      if (ok[t]) out[base + off + ins + k0 + lane] = rx_relabel(v[t], relabel + ((rot + brot) & rmask) * 256);
     }
   }
 }

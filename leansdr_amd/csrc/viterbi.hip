@@ -928,16 +928,21 @@ int lsdr_viterbi_run(lsdr_viterbi *v, const lsdr_softsymbol *in, size_t n_in, ui
   if (((uintptr_t)out & 3u) == 0 || !out || !cap_out) return viterbi_run_aligned(v, in, n_in, out, cap_out, consumed, produced);
   lsdr_ctx *c = v->ctx;
   LSDR_HIP(hipSetDevice(c->device));
-  if (v->bounce_cap < cap_out) {
+  // (sized for what this run can produce — at most one byte per input symbol — not for the caller's whole capacity)
+  const size_t need = cap_out < n_in + 64 ? cap_out : n_in + 64;
+  if (v->bounce_cap < need) {
     LSDR_HIP(hipStreamSynchronize(c->stream));
     (void)hipFree(v->d_bounce);
     v->d_bounce = nullptr; v->bounce_cap = 0;
-    LSDR_HIP(hipMalloc((void **)&v->d_bounce, cap_out + 64));
-    v->bounce_cap = cap_out;
+    LSDR_HIP(hipMalloc((void **)&v->d_bounce, need + 64));
+    v->bounce_cap = need;
   }
-  const int rc = viterbi_run_aligned(v, in, n_in, v->d_bounce, cap_out, consumed, produced);
+  const int rc = viterbi_run_aligned(v, in, n_in, v->d_bounce, need, consumed, produced);
   if (rc) return rc;
-  if (*produced) LSDR_HIP(hipMemcpyAsync(out, v->d_bounce, *produced, hipMemcpyDeviceToDevice, c->stream));
+  if (*produced) {
+    LSDR_HIP(hipMemcpyAsync(out, v->d_bounce, *produced, hipMemcpyDeviceToDevice, c->stream));
+    LSDR_HIP(hipStreamSynchronize(c->stream));      // the aligned path has waited for its results too: `out` is complete on return
+  }
   return LSDR_OK;
 }
 

@@ -103,6 +103,7 @@ timeout 280 bash tools/nf_timeline.sh "gpurun_out/${1:-r05_prof}/anf1_timeline.t
 timeout 200 python tools/placement_probe.py > "$OUT/placement_probe.txt" 2>&1; cat "$OUT/placement_probe.txt"
 [ -x tools/membench ] && timeout 100 tools/membench > "$OUT/membench.txt" 2>&1; tail -4 "$OUT/membench.txt"
 timeout 900 python bench.py --workload c1 --steps 20 --warmup 2 > "$OUT/c1.json" 2> "$OUT/c1.err"; echo "c1 rc=$?"
+cp bench_full.json "$OUT/c1_full.json" 2>/dev/null
 cd /tmp; rm -rf /tmp/prof_c1
 GPU_MAX_HW_QUEUES=16 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_c1 -- python "$REPO/bench.py" --workload c1 --steps 5 --warmup 1 --no-cpu --no-verify > /tmp/prof_c1.log 2>&1
 f=$(find /tmp/prof_c1 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/c1_kernel_stats.csv"
