@@ -266,7 +266,7 @@ class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=12):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=16):
         self.capi = capi
         self.batch_hook = batch_hook          # called per batch after fir_filter was queued: hook(pipe, dec buffer index, outputs, done event)
         # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
@@ -346,9 +346,11 @@ class C2Pipeline:
             return ctx.event_elapsed_ms(e0, e1) / 6
 
         # (candidates are held until the choice is made — a freed buffer would be handed out again; the search stops early once one
-        # candidate is clearly in the fast group: at least four tried, the best 7 % under the slowest)
+        # candidate is clearly in the fast group: at least five tried, the best 8 % under their MEDIAN — the first measurements of a
+        # process run slow whatever the buffer, so the slowest one is no yardstick)
+        launch_ms(cp.d_in, cp.dec[0])          # (clocks, TLBs)
         ins, t_in = [cp.d_in], [launch_ms(cp.d_in, cp.dec[0])]
-        while len(ins) < candidates and not (len(ins) >= 4 and min(t_in) < 0.93 * max(t_in)):
+        while len(ins) < candidates and not (len(ins) >= 5 and min(t_in) < 0.92 * float(np.median(t_in))):
             d = ctx.alloc((g["B"] + g["period"]) * 8)
             capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.ptr, cp.d_in.ptr, (g["B"] + g["period"]) * 8))
             ctx.sync()

@@ -1576,7 +1576,8 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     static const char *const enq = getenv("LSDR_MFMA_NQT");
     const unsigned nqk = blk && !(enq && !atoi(enq)) ? f->bk[cp].nq : 0;
     fir_kernel_t k = stream ? pick_stream(D, cp != 0, f->bk[cp].nq) : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
-    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0) : blk ? f->bk[cp].lds : f->mf[cp].lds;
+    static const size_t lds_pad = getenv("LSDR_MFMA_SLDS") ? (size_t)atoi(getenv("LSDR_MFMA_SLDS")) : 0;   // tuning hook: extra LDS per stream workgroup (bounds the workgroups resident per CU)
+    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
     if (lds_bytes > 64 * 1024)
       LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;
