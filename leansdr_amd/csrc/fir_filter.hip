@@ -73,6 +73,7 @@ struct fir_args {
   // stream — mf_atab holds n_iv tables of KS·64 floats, table i serves the tiles from iv_tile_first[i] on (ascending, [0] = 0)
   const unsigned *iv_tile_first;
   unsigned n_iv;
+  unsigned xcd_rot;            // k_fir_mfma_stream: XCD x starts its walk x·xcd_rot tiles into its range (wrapping): see lsdr_fir_filter::stream_xrot
 };
 
 // Staging is split into the global load (raw bits kept in two VGPRs) and the
@@ -889,8 +890,12 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   const unsigned ROWZ = 2 * (NQ | 1u);
   char *const ring = smem_raw + ((REGB + 15) & ~15u);       // 64 rows + rows 0…15 once more as rows 64…79 (see k_fir_mfma_blk)
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  auto tile_of = [&](unsigned ti) { return xcd * a.tiles_per_xcd + ti; };
-  auto valid = [&](unsigned ti) { return ti < a.tiles_per_xcd && tile_of(ti) < a.n_tiles; };
+  // this XCD's tiles [xcd·tiles_per_xcd, + xcnt), walked from tile x·xcd_rot of the range on, wrapping (xcd_rot = 0: from its start)
+  const unsigned xbase = xcd * a.tiles_per_xcd;
+  const unsigned xcnt = xbase >= a.n_tiles ? 0u : (a.n_tiles - xbase < a.tiles_per_xcd ? a.n_tiles - xbase : a.tiles_per_xcd);
+  const unsigned xrot = xcnt ? (unsigned)(((unsigned long long)xcd * a.xcd_rot) % xcnt) : 0u;
+  auto tile_of = [&](unsigned ti) { const unsigned p = ti + xrot; return xbase + (p >= xcnt ? p - xcnt : p); };
+  auto valid = [&](unsigned ti) { return ti < xcnt; };
 
   float bco[KS];
   unsigned iv_cur = 0;
@@ -977,6 +982,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     if (IV) {
       unsigned iv = iv_cur;
       while (iv + 1 < a.n_iv && tile >= a.iv_tile_first[iv + 1]) ++iv;
+      while (iv > 0 && tile < a.iv_tile_first[iv]) --iv;       // (the walk wraps once when it does not start at the range's first tile)
       if (iv != iv_cur) {                    // (wave-uniform, a handful of times per launch)
         iv_cur = iv;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1308,6 +1314,7 @@ struct lsdr_fir_filter {
   bool blk_ok[2];
   bool stream;                      // k_fir_mfma_stream (one wavefront per workgroup, LDS-direct refill) instead of k_fir_mfma_blk
   int stream_wpc;                   // its workgroups (= wavefronts) per CU in the persistent grid
+  unsigned stream_xrot;             // tiles by which XCD x's walk through its range is rotated (× x): tuning hook LSDR_MFMA_XROT, 0 = off
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -1446,6 +1453,7 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
       // placement chosen (bench.py), three processes each: 3 → 602–612 GS/s, 48 → 627–635, 96 → 605–624, 192 → 585–601; 6 (two exact
       // rounds) → 465.  Complex taps: 4 → 402, 48 → 409.
       f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 48;
+      { const char *ex = getenv("LSDR_MFMA_XROT"); f->stream_xrot = ex ? (unsigned)strtoul(ex, nullptr, 0) : 0u; }      // (read per create: A/B in one process)
     }
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
@@ -1557,6 +1565,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
   a.in_scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
   a.mf_atab = nullptr; a.mf_alen = 0; a.mf_blocks = 0;
+  a.iv_tile_first = nullptr; a.n_iv = 0; a.xcd_rot = f->stream_xrot;
   a.trace = nullptr;
 #ifdef LSDR_FIR_TRACE
   {
