@@ -269,7 +269,7 @@ class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=16):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=40):
         self.capi = capi
         self.batch_hook = batch_hook          # called per batch after fir_filter was queued: hook(pipe, dec buffer index, outputs, done event)
         # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
@@ -329,9 +329,11 @@ class C2Pipeline:
     def place_buffers(self, candidates):
         """WHERE a resident buffer lands decides how fast fir_filter streams it: one process, six 2 GiB buffers allocated one after
         the other — the same launch takes 0.37 ms over some and 0.42 ms over others, reproducibly per buffer (profiles/r05_bench/
-        placement_probe.txt); the C2 headline moved ±8 % from process to process with it.  So the capture's input buffer and its
-        decimated-stream buffers are CHOSEN: `candidates` allocations of each are held at once, the filter launch is timed over every
-        one (HIP events, 3 + 6 launches), the fastest are kept, the rest freed.  Not timed; the data in the buffers is the same."""
+        placement_probe.txt); the C2 headline moved ±8 % from process to process with it.  It is the physical place, not the
+        allocation's flags (default / fine-grained / uncached / contiguous: placement_probe5.py), and later allocations of a process
+        are fast more often (28 in a row: numbers 4, 16, 23–28).  So the capture's input buffer and its decimated-stream buffers are
+        CHOSEN: up to `candidates` allocations are held at once (40 × 2 GiB of the 288), the filter launch is timed over every one
+        (HIP events, 3 + 6 launches), the fastest are kept, the rest freed.  Not timed; the data in the buffers is the same."""
         if candidates <= 1:
             return None
         capi, g, cp, ctx = self.capi, self.geo, self.caps[0], self.ctx
@@ -371,7 +373,7 @@ class C2Pipeline:
         for k, d in enumerate(ins):
             if k != best and not (two and k == order[1]):
                 d.free()
-        decs = list(cp.dec) + [ctx.alloc((n_dec) * 8) for _ in range(max(0, min(candidates, 6) - len(cp.dec)))]
+        decs = list(cp.dec) + [ctx.alloc((n_dec) * 8) for _ in range(max(0, min(candidates, 8) - len(cp.dec)))]
         t_dec = [launch_ms(cp.d_in, d) for d in decs]
         order = list(np.argsort(t_dec))
         keep = order[:len(cp.dec)]
