@@ -74,6 +74,7 @@ struct fir_args {
   const unsigned *iv_tile_first;
   unsigned n_iv;
   unsigned xcd_rot;            // k_fir_mfma_stream: XCD x starts its walk x·xcd_rot tiles into its range (wrapping): see lsdr_fir_filter::stream_xrot
+  unsigned chunked;            // k_fir_mfma_stream: a workgroup's tiles are CONSECUTIVE (one stretch of its XCD's range) instead of strided
 };
 
 // Staging is split into the global load (raw bits kept in two VGPRs) and the
@@ -895,7 +896,12 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   const unsigned xcnt = xbase >= a.n_tiles ? 0u : (a.n_tiles - xbase < a.tiles_per_xcd ? a.n_tiles - xbase : a.tiles_per_xcd);
   const unsigned xrot = xcnt ? (unsigned)(((unsigned long long)xcd * a.xcd_rot) % xcnt) : 0u;
   auto tile_of = [&](unsigned ti) { const unsigned p = ti + xrot; return xbase + (p >= xcnt ? p - xcnt : p); };
-  auto valid = [&](unsigned ti) { return ti < xcnt; };
+  // a workgroup's tile list: strided (slot, slot + slots, …: at any moment the XCD's workgroups read one narrow window of its range) or one
+  // consecutive stretch of ⌈xcnt/slots⌉ tiles (a workgroup stays inside one or two 2 MiB pages: see lsdr_fir_filter::stream_chunked)
+  const unsigned per = a.chunked ? (xcnt + slots - 1) / slots : 0u;
+  const unsigned t_first = a.chunked ? slot * per : slot, t_step = a.chunked ? 1u : slots;
+  const unsigned t_lim = a.chunked ? (t_first + per < xcnt ? t_first + per : xcnt) : xcnt;
+  auto valid = [&](unsigned ti) { return ti < t_lim; };
 
   float bco[KS];
   unsigned iv_cur = 0;
@@ -934,7 +940,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     }
   };
 
-  unsigned ti = slot;
+  unsigned ti = t_first;
   if (!valid(ti)) return;
 #ifdef LSDR_STREAM_PRIO
   __builtin_amdgcn_s_setprio(LSDR_STREAM_PRIO);
@@ -973,7 +979,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
 
   while (true) {
     const unsigned tile = tile_of(ti);
-    const unsigned tn = ti + slots;
+    const unsigned tn = ti + t_step;
     const bool more = valid(tn);
     const unsigned st = tile / a.tiles_per_stream;
     const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * MW;
@@ -1265,10 +1271,11 @@ int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf3
   a.in_scale = 1.0f;
   a.mf_atab = iv_tabs; a.mf_alen = 15 * 64; a.mf_blocks = nq;
   a.iv_tile_first = iv_tile_first; a.n_iv = n_iv;
+  { static const bool strided = getenv("LSDR_MFMA_CHUNK") && !atoi(getenv("LSDR_MFMA_CHUNK")); a.chunked = strided ? 0u : 1u; }
   fir_kernel_t k = k_fir_mfma_stream<30, 1, 12, 1>;
   const size_t lds_bytes = stream_lds(D, nq, true);
   unsigned grid = a.tiles_per_xcd * 8;
-  const unsigned pg = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 32) + 7) / 8 * 8;
+  const unsigned pg = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 64) + 7) / 8 * 8;
   if (grid > pg) grid = pg;
   hipLaunchKernelGGL(k, dim3(grid), dim3(64), lds_bytes, stream ? stream : c->stream, a);
   LSDR_HIP(hipGetLastError());
@@ -1315,6 +1322,7 @@ struct lsdr_fir_filter {
   bool stream;                      // k_fir_mfma_stream (one wavefront per workgroup, LDS-direct refill) instead of k_fir_mfma_blk
   int stream_wpc;                   // its workgroups (= wavefronts) per CU in the persistent grid
   unsigned stream_xrot;             // tiles by which XCD x's walk through its range is rotated (× x): tuning hook LSDR_MFMA_XROT, 0 = off
+  unsigned stream_chunked;          // a workgroup's tiles consecutive instead of strided (LSDR_MFMA_CHUNK, read per create)
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -1447,13 +1455,17 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
     {
       const char *es = getenv("LSDR_MFMA_STREAM"), *ew = getenv("LSDR_MFMA_SWPC");
       f->stream = pick_stream(D, false, 0) != nullptr && !(es && !atoi(es));
-      // OVERSUBSCRIBED: 48 workgroups per CU queued, each with a short tile list (6 tiles at the C2 batch), instead of a grid of exactly
+      // OVERSUBSCRIBED: 96 workgroups per CU queued, each with a short tile list (3 tiles at the C2 batch), instead of a grid of exactly
       // the resident workgroups (3 per CU) that own a 99-tile list each: the dispatcher deals the work, the wavefronts of a CU fall out
-      // of step, a workgroup that could not start next to the receiver's tiles costs 6 tiles, not a second round.  Same box, buffer
-      // placement chosen (bench.py), three processes each: 3 → 602–612 GS/s, 48 → 627–635, 96 → 605–624, 192 → 585–601; 6 (two exact
-      // rounds) → 465.  Complex taps: 4 → 402, 48 → 409.
-      f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 48;
+      // of step, a workgroup that could not start next to the receiver's tiles costs 3 tiles, not a second round.  Same box, buffer
+      // placement chosen (bench.py), strided lists, three processes each: 3 → 602–612 GS/s, 48 → 627–635, 96 → 605–624, 192 → 585–601; 6
+      // (two exact rounds) → 465.  Complex taps: 4 → 402, 48 → 409.
+      // CHUNKED lists (stream_chunked: a workgroup's tiles are consecutive — it stays inside one or two 2 MiB pages and re-reads its own
+      // halo — instead of `slots` tiles apart): alone 5.88 → 6.02 TB/s at 48 per CU, 6.11 at 96 (0.76 of the HBM peak); C2 pipeline, two
+      // processes each: strided 48: 609–644 GS/s; chunked 24 / 48 / 96 / 192: 606–634 / 619–667 / 644–651 / 602–610.
+      f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 96;
       { const char *ex = getenv("LSDR_MFMA_XROT"); f->stream_xrot = ex ? (unsigned)strtoul(ex, nullptr, 0) : 0u; }      // (read per create: A/B in one process)
+      { const char *ec = getenv("LSDR_MFMA_CHUNK"); f->stream_chunked = ec ? (unsigned)atoi(ec) : 1u; }
     }
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
@@ -1565,7 +1577,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
   a.in_scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
   a.mf_atab = nullptr; a.mf_alen = 0; a.mf_blocks = 0;
-  a.iv_tile_first = nullptr; a.n_iv = 0; a.xcd_rot = f->stream_xrot;
+  a.iv_tile_first = nullptr; a.n_iv = 0; a.xcd_rot = f->stream_xrot; a.chunked = f->stream_chunked;
   a.trace = nullptr;
 #ifdef LSDR_FIR_TRACE
   {

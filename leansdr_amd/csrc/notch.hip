@@ -1725,7 +1725,7 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   h->k = cfg->k > 0.f ? cfg->k : 0.002f;
   h->scale = cfg->in_scale != 0.f ? cfg->in_scale : 1.0f;
   h->phase = 0; h->F = 0; h->A = 0;
-  { const char *e = getenv("LSDR_NF_WPC"); h->wpc = e && atoi(e) > 0 ? atoi(e) : 32; }   // tuning hook: workgroups per CU queued for the filter pass (oversubscribed: see k_fir_mfma_stream)
+  { const char *e = getenv("LSDR_NF_WPC"); h->wpc = e && atoi(e) > 0 ? atoi(e) : 64; }   // tuning hook: workgroups per CU queued for the filter pass (oversubscribed: see k_fir_mfma_stream)
   h->d_r[0] = h->d_r[1] = nullptr; h->r_cap[0] = h->r_cap[1] = 0; h->timing = false; h->timed_runs = 0;
   h->run_no = 0; h->overlap = false; h->s_det = h->s_pass = nullptr; h->tail_recorded[0] = h->tail_recorded[1] = false;
   memset(h->ev_taps, 0, sizeof(h->ev_taps)); memset(h->ev_pass, 0, sizeof(h->ev_pass)); memset(h->ev_tail, 0, sizeof(h->ev_tail));

@@ -12,10 +12,11 @@ n = 256 << 20
 rng = np.random.default_rng(0)
 blk = ((rng.standard_normal(1 << 22) + 1j * rng.standard_normal(1 << 22)) * 0.7).astype(np.complex64)
 d_blk = ctx.upload(blk)
-rots = [0, 1, 37, 1187, 2371, 4739]
+rots = ["strided", "chunked", "chunked wpc24", "chunked wpc96", "strided wpc3"]
 firs = []
 for r in rots:
-    os.environ["LSDR_MFMA_XROT"] = str(r)
+    os.environ["LSDR_MFMA_CHUNK"] = "1" if "chunked" in r else "0"
+    os.environ["LSDR_MFMA_SWPC"] = r.split("wpc")[1] if "wpc" in r else "48"
     firs.append(capi.FirFilter(ctx, coeffs, decim, in_scale=75.0, arith=capi.FIR_MFMA_BLK))
 bufs = []
 for b in range(6):
@@ -39,7 +40,7 @@ f0 = firs[0]; f0.run_dev(bufs[0].ptr, n, out.ptr, n // decim); ref = ctx.downloa
 for f, r in zip(firs[1:], rots[1:]):
     f.run_dev(bufs[0].ptr, n, out.ptr, n // decim)
     assert np.array_equal(ctx.download(out, np.complex64, 1 << 20).view(np.uint64), ref.view(np.uint64)), r
-print("XROT", rots, "(TB/s on 8.03 B/sample; outputs identical)")
+print("walk", rots, "(TB/s on 8.03 B/sample; outputs identical)")
 for rnd in range(2):
     for k, d in enumerate(bufs):
         print(f"round {rnd} buffer {k}: " + " ".join(f"{t(f, d.ptr, n):.2f}" for f in firs), flush=True)
