@@ -599,7 +599,7 @@ constexpr int kNfD = 30, kNfNq = 12, kNfKs = 15, kNfTaps = kNfD * kNfNq;   // 36
 constexpr int kNfLook = 12288;            // samples an estimator remembers ((1−k)^12288 < 1e-8 is checked at run time, as in the scan mode)
 constexpr int kNfMaxDet = 64;             // detect points per run (the run is cut there)
 constexpr int kNfFixSpan = 4736;          // samples one fix-up stages (N + a tile and the transition outputs' windows)
-constexpr int kNfChunk = 2048, kNfWarm = 512, kNfPer = (kNfChunk + kNfWarm) / 256;   // k_nf_scan geometry
+constexpr int kNfChunk = 4096, kNfWarm = 512, kNfPer = (kNfChunk + kNfWarm) / 256;   // k_nf_scan geometry (18 elements per lane)
 
 struct nf_state {
   float2 y_last;          // output M0−1
@@ -671,7 +671,9 @@ __global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, 
   if (blockIdx.x == 0) for (int i = threadIdx.x; i <= ndet; i += 256) tile_first[i] = run.tile_first[i];     // (the filter pass reads them through a pointer)
   __shared__ double kr[kNfD + 1], ki[kNfD + 1];
   __shared__ double rr[kNfTaps], ri[kNfTaps];
+  __shared__ float2 cs_s[kNfTaps];                 // the filter's taps (a per-tap global load inside the convolution made this kernel 26 µs)
   const int q = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < kNfTaps; i += 256) cs_s[i] = i < C.N ? coeffs[i] : make_float2(0.f, 0.f);
   const int bin = q == 0 ? *bin_in : cand[(q - 1) * kMaxSlots];
   const int prev = q == 0 ? bin : (q == 1 ? *bin_in : cand[(q - 2) * kMaxSlots]);
   if (t == 0 && q == ndet) *bin_out = bin;
@@ -696,7 +698,7 @@ __global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, 
     for (int j = 0; j <= kNfD; ++j) {
       const int i = tt - j;
       if (i < 0 || i >= C.N) continue;
-      const float2 cs = coeffs[i];      // fir_filter's shifted taps (dsp.h:271-280) with the fused scaler on them: one f32 rounding per component
+      const float2 cs = cs_s[i];        // fir_filter's shifted taps (dsp.h:271-280) with the fused scaler on them: one f32 rounding per component
       re += kr[j] * (double)cs.x - ki[j] * (double)cs.y; im += kr[j] * (double)cs.y + ki[j] * (double)cs.x;
     }
     rr[tt] = re; ri[tt] = im;
