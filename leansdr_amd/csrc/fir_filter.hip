@@ -875,7 +875,9 @@ typedef __attribute__((address_space(3))) void *fir_lds_ptr;
 // exactly the resident workgroups is only resident in full while nothing else holds LDS — next to cstln_receiver's staged tiles (9 KB
 // per wavefront) some workgroups started when others ENDED and the launch took 1.19 ms instead of 0.76 (256 Mi samples); with 16–32 per CU
 // the dispatcher deals the work: 0.80 ms.  (Tiles dealt by a per-XCD atomic counter, one returned atomic per tile: 0.96 ms alone — dropped.)
-template <int DT, int CP, int NQT, int IV = 0>
+// NP = pairs of row tiles per wave tile (16 rows each): 8 → a region of 128 rows (39 KB of LDS with its ring: four wavefronts per CU, 117 outputs
+// per 128 rows at 12 tap blocks); 4 → 64 rows (24 KB: six per CU, 53 outputs per 64 rows).  The outputs do not depend on it.
+template <int DT, int CP, int NQT, int IV = 0, int NP = 8>
 __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr unsigned D = DT, SL = 1 + CP;
@@ -883,10 +885,12 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   constexpr unsigned KP = (D * SL + 3) / 4 * 4, KS = KP / 4;
   constexpr unsigned FP = ((KP / SL - D) + 1) & ~1u;              // samples in front of row 0 that the K padding reads
   constexpr unsigned ROWB = D * 8, PAIRG = 8 * D;                 // bytes per row; 16-byte granules per pair of row tiles
-  constexpr unsigned REGB = FP * 8 + 128 * ROWB;                  // region bytes
+  constexpr unsigned RW = 16 * NP;                                // rows (blocks of D samples) per wave tile
+  static_assert(NP >= 4 && NP % 2 == 0, "whole diagonal batches of two pairs; the wait counts assume NP >= 3");
+  constexpr unsigned REGB = FP * 8 + RW * ROWB;                   // region bytes
   constexpr unsigned NLI = (PAIRG + FP / 2 + 63) / 64;            // LDS-direct loads per refill group
   const unsigned l = threadIdx.x;
-  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks, MW = 128 - (NQ - 1);
+  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks, MW = RW - (NQ - 1);
   constexpr int NQR = NQT ? NQT : 16;
   const unsigned ROWZ = 2 * (NQ | 1u);
   char *const ring = smem_raw + ((REGB + 15) & ~15u);       // 64 rows + rows 0…15 once more as rows 64…79 (see k_fir_mfma_blk)
@@ -954,7 +958,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   }
   aim(tile_of(ti), true);
 #pragma unroll
-  for (int P = 0; P < 8; ++P) refill(P);
+  for (int P = 0; P < NP; ++P) refill(P);
 
   // per-lane cursors (see k_fir_mfma_blk); the sample operand of K slot r' of row ρ is the sample r' BEFORE the row's last one
   const unsigned kq = l >> 4 & 3u, i16 = l & 15u, beta = i16 >> 1, c = i16 & 1u;
@@ -970,11 +974,14 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   // (rows 0…15 are mirrored at 64…79) so that ρ − q needs no wrap; byte offset of term q = 15 for even / odd B, terms with
   // smaller q `dstep` bytes further on
   const unsigned dstep = ROWZ * 4 - 8;
-  unsigned dbase[2];
+  // NP = 4: a wave tile is exactly the ring's 64 rows, so the only reads that would wrap are those of rows 0 … NQ−2 — which are not outputs: no
+  // mirrored rows (the ring is 64 rows, 1.4 KB less: seven wavefronts per CU also with 12 tap blocks); those reads land in the region's tail
+  constexpr bool MIRROR = NP != 4;
+  int dbase[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
-    const unsigned rr = 32u * par + ro, rp = rr < 16 ? rr + 64 : rr;
-    dbase[par] = (rp * ROWZ + rc) * 4 - 15 * dstep;               // = ((rp − 15)·ROWZ + 2·15 + rc)·4
+    const unsigned rr = 32u * par + ro, rp = (MIRROR && rr < 16) ? rr + 64 : rr;
+    dbase[par] = (int)((rp * ROWZ + rc) * 4) - 15 * (int)dstep;   // = ((rp − 15)·ROWZ + 2·15 + rc)·4
   }
 
   while (true) {
@@ -1013,7 +1020,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
           const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
           *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
           *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
-          if (((16u * pair) & 63u) == 0) {
+          if (MIRROR && ((16u * pair) & 63u) == 0) {
             *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
             *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
           }
@@ -1022,7 +1029,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     };
     float zv[NQR];
     auto diag_read = [&](int batch, int q) {
-      zv[q] = *reinterpret_cast<const float *>(ring + dbase[batch & 1] + (unsigned)(15 - q) * dstep);
+      zv[q] = *reinterpret_cast<const float *>(ring + (dbase[batch & 1] + (15 - q) * (int)dstep));
     };
     float ysum = 0.f;
     auto diag_add = [&](int q) {
@@ -1039,17 +1046,17 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
 
     // Wait counts (vector-memory operations retire in order; the hidden output stores only make the counter larger, i.e. the
     // waits stricter).  Refill group j of the previous iteration must have landed before fetch(j).  Behind it in the queue:
-    // the previous iteration's groups j+1 … 7 and this iteration's groups issued so far (group P−1 goes out at the END of
-    // pair P, behind fetch(P+1)): fetch(0): 7 groups; fetch(1), during pair 0: 6; fetch(j ≥ 2), during pair j−1: 5.
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(7 * NLI) : "memory");
+    // the previous iteration's groups j+1 … NP−1 and this iteration's groups issued so far (group P−1 goes out at the END of
+    // pair P, behind fetch(P+1)): fetch(0): NP−1 groups; fetch(1), during pair 0: NP−2; fetch(j ≥ 2), during pair j−1: NP−3.
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 1) * NLI) : "memory");
 #pragma unroll
     for (unsigned s = 0; s < KS; ++s) { fetch1(0, 0, 0, s); fetch1(0, 0, 1, s); }
 #pragma unroll
-    for (int pair = 0; pair < 8; ++pair) {
+    for (int pair = 0; pair < NP; ++pair) {
       const int set = pair & 1;
-      if (pair < 7) {
-        if (pair == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * NLI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * NLI) : "memory");
+      if (pair < NP - 1) {
+        if (pair == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 2) * NLI) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 3) * NLI) : "memory");
       }
 #pragma unroll
       for (unsigned s = 0; s < KS; ++s) {
@@ -1066,7 +1073,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
           acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][s]), bco[s], acc[set][1], 0, 0, 0);
         }
 #endif
-        if (pair < 7 && !(s & 1)) {
+        if (pair < NP - 1 && !(s & 1)) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) { if (s + 1 < KS) fetch1(set ^ 1, pair + 1, h, s + 1); fetch1(set ^ 1, pair + 1, h, s); }
         }
@@ -1087,13 +1094,13 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    to_ring(1, 7);
-    refill(7);
+    to_ring((NP - 1) & 1, NP - 1);
+    refill(NP - 1);
 #pragma unroll
-    for (int q = 0; q < NQR; ++q) diag_read(3, q);
+    for (int q = 0; q < NQR; ++q) diag_read(NP / 2 - 1, q);
 #pragma unroll
     for (int q = 0; q < NQR; ++q) diag_add(q);
-    diag_store(3);
+    diag_store(NP / 2 - 1);
     if (!more) break;
     ti = tn;
   }
@@ -1148,8 +1155,12 @@ fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed, unsigned 
     default: return nullptr;
   }
 }
-fir_kernel_t pick_stream(unsigned D, bool cplx, unsigned nq) {
+// np = pairs of row tiles per wave tile (k_fir_mfma_stream NP): 4 exists for the C2 geometry's compile-time kernels only; nullptr = no such kernel
+fir_kernel_t pick_stream(unsigned D, bool cplx, unsigned nq, unsigned np = 8) {
   const char *e = getenv("LSDR_MFMA_NQT");                 // test hook: 0 forces the run-time-NQ kernels
+  if (np == 4) return D == 30 && nq == 11 && !(e && !atoi(e)) ? (cplx ? k_fir_mfma_stream<30, 1, 11, 0, 4> : k_fir_mfma_stream<30, 0, 11, 0, 4>) : nullptr;
+  if (np == 6) return D == 30 && nq == 11 && cplx && !(e && !atoi(e)) ? k_fir_mfma_stream<30, 1, 11, 0, 6> : nullptr;
+  if (np != 8) return nullptr;
   if (D == 30 && nq == 11 && !(e && !atoi(e))) return cplx ? k_fir_mfma_stream<30, 1, 11> : k_fir_mfma_stream<30, 0, 11>;
   switch (D) {
     case 10: return cplx ? k_fir_mfma_stream<10, 1, 0> : k_fir_mfma_stream<10, 0, 0>;
@@ -1157,10 +1168,10 @@ fir_kernel_t pick_stream(unsigned D, bool cplx, unsigned nq) {
     default: return nullptr;
   }
 }
-// LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 128 rows) + Z ring + the diagonal reads' overrun
-unsigned stream_lds(unsigned D, unsigned nq, bool cplx) {
+// LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 16·np rows) + Z ring + the diagonal reads' overrun
+unsigned stream_lds(unsigned D, unsigned nq, bool cplx, unsigned np = 8) {
   const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4, fp = ((kp / sl - D) + 1) & ~1u;
-  return ((fp * 8 + 128 * D * 8 + 15) & ~15u) + 80 * 2 * (nq | 1u) * 4 + 128;
+  return ((fp * 8 + 16 * np * D * 8 + 15) & ~15u) + (np == 4 ? 64 : 80) * 2 * (nq | 1u) * 4 + 128;
 }
 // geometry of a k_fir_mfma_blk launch (nb = tap blocks NQ, alen = coefficient operand floats, M = outputs per tile)
 struct blk_geom { unsigned nq, alen, U, lds, nl, nl_fixed, M, ks; };
@@ -1253,7 +1264,8 @@ fir_kernel_t pick_generic(int R, int mode) {
 int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf32 *out, size_t count, unsigned align_n, unsigned D, unsigned nq,
                               const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile, hipStream_t stream) {
   if (D != 30 || nq != 12) { lsdr_set_error("notch_fir: the fused matrix-pipe pass exists for decimation 30 with 12 tap blocks"); return LSDR_E_UNSUPPORTED; }
-  const unsigned M = 128u - (nq - 1);
+  static const unsigned np = getenv("LSDR_NF_NP") && atoi(getenv("LSDR_NF_NP")) == 8 ? 8u : getenv("LSDR_NF_NP") && atoi(getenv("LSDR_NF_NP")) == 6 ? 6u : 4u;   // tuning hook: rows per wave tile / 16
+  const unsigned M = 16u * np - (nq - 1);
   if (outputs_per_tile) *outputs_per_tile = M;
   if (!count) return LSDR_OK;
   fir_args a;
@@ -1272,8 +1284,8 @@ int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf3
   a.mf_atab = iv_tabs; a.mf_alen = 15 * 64; a.mf_blocks = nq;
   a.iv_tile_first = iv_tile_first; a.n_iv = n_iv;
   { static const bool strided = getenv("LSDR_MFMA_CHUNK") && !atoi(getenv("LSDR_MFMA_CHUNK")); a.chunked = strided ? 0u : 1u; }
-  fir_kernel_t k = k_fir_mfma_stream<30, 1, 12, 1>;
-  const size_t lds_bytes = stream_lds(D, nq, true);
+  fir_kernel_t k = np == 4 ? k_fir_mfma_stream<30, 1, 12, 1, 4> : np == 6 ? k_fir_mfma_stream<30, 1, 12, 1, 6> : k_fir_mfma_stream<30, 1, 12, 1>;
+  const size_t lds_bytes = stream_lds(D, nq, true, np);
   unsigned grid = a.tiles_per_xcd * 8;
   const unsigned pg = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 64) + 7) / 8 * 8;
   if (grid > pg) grid = pg;
@@ -1323,6 +1335,7 @@ struct lsdr_fir_filter {
   int stream_wpc;                   // its workgroups (= wavefronts) per CU in the persistent grid
   unsigned stream_xrot;             // tiles by which XCD x's walk through its range is rotated (× x): tuning hook LSDR_MFMA_XROT, 0 = off
   unsigned stream_chunked;          // a workgroup's tiles consecutive instead of strided (LSDR_MFMA_CHUNK, read per create)
+  unsigned stream_np[2];            // pairs of row tiles per wave tile, real / complex taps (k_fir_mfma_stream NP; LSDR_MFMA_NP / LSDR_MFMA_NP_CP, read per create)
 };
 
 static int fir_upload(lsdr_fir_filter *f) {
@@ -1466,6 +1479,7 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
       f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 96;
       { const char *ex = getenv("LSDR_MFMA_XROT"); f->stream_xrot = ex ? (unsigned)strtoul(ex, nullptr, 0) : 0u; }      // (read per create: A/B in one process)
       { const char *ec = getenv("LSDR_MFMA_CHUNK"); f->stream_chunked = ec ? (unsigned)atoi(ec) : 1u; }
+      { const char *e0 = getenv("LSDR_MFMA_NP"), *e1 = getenv("LSDR_MFMA_NP_CP"); f->stream_np[0] = e0 && atoi(e0) == 4 ? 4u : 8u; f->stream_np[1] = e1 && (atoi(e1) == 4 || atoi(e1) == 6 || atoi(e1) == 8) ? (unsigned)atoi(e1) : 4u; }
     }
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
@@ -1568,7 +1582,9 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.n_in = n_in;
   static const bool stream_cp = !(getenv("LSDR_MFMA_STREAM_CP") && !atoi(getenv("LSDR_MFMA_STREAM_CP")));   // A/B hook
   const bool stream = blk && f->stream && (real_taps || stream_cp);
-  const unsigned M = stream ? 128u - (f->bk[real_taps ? 0 : 1].nq - 1) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
+  // rows per wave tile / 16 of the stream kernel: the requested one if that kernel exists for this geometry
+  const unsigned snp = stream && pick_stream(D, !real_taps, f->bk[real_taps ? 0 : 1].nq, f->stream_np[real_taps ? 0 : 1]) ? f->stream_np[real_taps ? 0 : 1] : 8u;
+  const unsigned M = stream ? 16u * snp - (f->bk[real_taps ? 0 : 1].nq - 1) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
   a.tiles_per_stream = (unsigned)n_tiles;
@@ -1596,9 +1612,9 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     a.mf_blocks = blk ? f->bk[cp].nq : f->mf[cp].nb;
     static const char *const enq = getenv("LSDR_MFMA_NQT");
     const unsigned nqk = blk && !(enq && !atoi(enq)) ? f->bk[cp].nq : 0;
-    fir_kernel_t k = stream ? pick_stream(D, cp != 0, f->bk[cp].nq) : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
+    fir_kernel_t k = stream ? pick_stream(D, cp != 0, f->bk[cp].nq, snp) : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
     static const size_t lds_pad = getenv("LSDR_MFMA_SLDS") ? (size_t)atoi(getenv("LSDR_MFMA_SLDS")) : 0;   // tuning hook: extra LDS per stream workgroup (bounds the workgroups resident per CU)
-    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
+    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0, snp) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
     if (lds_bytes > 64 * 1024)
       LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;
