@@ -448,6 +448,10 @@ int lsdr_viterbi_set_resync_period(lsdr_viterbi *v, int period);   /* public mem
 int lsdr_viterbi_current_sync(const lsdr_viterbi *v);
 /* diagnostics of the last run: tiles decoded, seams that failed verification (re-decoded serially) */
 int lsdr_viterbi_stats(const lsdr_viterbi *v, unsigned *tiles, unsigned *bad_seams);
+/* since create: seams re-decoded by the repair round that runs on the device behind the main launch (no host round trip), and the
+ * launch -> readback rounds the host still had to add (a repaired tile whose end state changed fails the NEXT seam; anything that
+ * does not settle is re-decoded sequentially: the output is exact either way) */
+int lsdr_viterbi_repair_stats(const lsdr_viterbi *v, unsigned long long *device_repaired, unsigned long long *host_rounds);
 /* host only (no GPU, no context): 1 if the trellis of (constellation, code rate) — built as trellis::init_convolutional does,
  * viterbi.h:59-92 — has the structure the four-lanes-per-tile kernel relies on (long inputs of QPSK 1/2 and 8PSK 2/3 then
  * use it; same bytes as every other kernel), 0 if not, -1 if viterbi_sync does not support the combination (dvb.h:1234-1331). */

@@ -213,6 +213,7 @@ _sig("lsdr_viterbi_destroy", None, [vp])
 _sig("lsdr_viterbi_set_resync_period", C.c_int, [vp, C.c_int])
 _sig("lsdr_viterbi_current_sync", C.c_int, [vp])
 _sig("lsdr_viterbi_stats", C.c_int, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)])
+_sig("lsdr_viterbi_repair_stats", C.c_int, [vp, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)])
 _sig("lsdr_viterbi_q4_supported", C.c_int, [C.c_int, C.c_int])
 _sig("lsdr_viterbi_run", C.c_int, [vp, vp, c_sz, vp, c_sz, psz, psz])
 _sig("lsdr_mpeg_sync_create", C.c_int, [vp, C.c_int, C.POINTER(vp)])
@@ -755,6 +756,11 @@ class Viterbi:
         t, b = C.c_uint(), C.c_uint()
         check(lib.lsdr_viterbi_stats(self.h, C.byref(t), C.byref(b)))
         return dict(tiles=t.value, bad_seams=b.value)
+
+    def repair_stats(self):
+        d, h = C.c_ulonglong(), C.c_ulonglong()
+        check(lib.lsdr_viterbi_repair_stats(self.h, C.byref(d), C.byref(h)))
+        return dict(device_repaired=d.value, host_rounds=h.value)
 
     def run_dev(self, in_ptr, n_in, out_ptr, cap):
         cons, prod = c_sz(), c_sz()

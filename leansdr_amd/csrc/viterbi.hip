@@ -93,6 +93,9 @@ struct vit_args {
   unsigned totals_stride;
   vit_state *chunk_states;           // optional [njobs][totals_stride]: state after every chunk (sparse decoders)
   unsigned q4_n_main, q4_main_waves; // k_viterbi_q4: jobs [0, q4_n_main) fill the first q4_main_waves wavefronts, the rest the others
+  // k_viterbi as the device-side repair round: only the jobs whose seam flag cond[slot] is set run, each from the end state of the slot
+  // before its own (states_in = the slot array of end states), without warm-up; a job that starts a chain (from_state ≥ 0) has no seam
+  const int *cond;
 };
 
 // Minimum over the 64 lanes, returned wave-uniform: DPP steps inside the rows of 16 (quad swaps, half mirror, mirror), two
@@ -151,7 +154,11 @@ __global__ __launch_bounds__(kVitWaves * 64) void k_viterbi(vit_args a) {
   }
   const vit_tables &T = NUS == 0 ? *reinterpret_cast<const vit_tables *>(t_raw) : *a.T;
   if (jid >= a.njobs) return;
-  const vit_job job = a.jobs[jid];
+  vit_job job = a.jobs[jid];
+  if (a.cond) {
+    if (job.from_state >= 0 || !a.cond[job.slot]) return;
+    job.warm = 0; job.from_state = (int)job.slot - 1;
+  }
   const unsigned char *map = a.maps + job.sync * 256;
   const int shift = a.shifts[job.sync];
   const vit_code C = a.C;
@@ -663,6 +670,7 @@ struct lsdr_viterbi {
   vit_state *d_fix;                   // explicit start states of fix-up jobs
   size_t jobs_cap, totals_cap, chunk_cap, fix_cap, first_cap;
   unsigned last_tiles, last_bad;
+  unsigned long long dev_repaired = 0, host_rounds = 0;   // seams re-decoded by the device-side round / launch → readback rounds the host had to add (lsdr_viterbi_repair_stats)
   size_t budget_chunks;               // chunks attempted per call: shrinks after an alignment switch, regrows
   bool q4;                            // rate 1/2 QPSK / 2/3 8PSK may use the four-lanes-per-tile kernel (trellis structure checked at create)
   bool q4_call;                       // ... and the current lsdr_viterbi_run call does
@@ -751,7 +759,7 @@ static bool vit_q4_fits(const vit_code &C, int nshifts, const vit_tables *T) {
 static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, const std::vector<vit_job> &jobs,
                       unsigned stride, bool chunk_states, int phase0, const std::vector<vit_state> *start_states = nullptr,
                       const vit_state *dev_start_states = nullptr, bool keep_slots = false, size_t n_slots = 0,
-                      bool write_first = true, size_t n_main = (size_t)-1) {
+                      bool write_first = true, size_t n_main = (size_t)-1, vit_args *args_out = nullptr) {
   lsdr_ctx *c = v->ctx;
   const size_t nj = keep_slots ? (n_slots > jobs.size() ? n_slots : jobs.size()) : jobs.size();   // capacity of the slot arrays
   if (start_states && v->fix_cap < start_states->size()) {
@@ -764,7 +772,7 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
     LSDR_HIP(hipMalloc((void **)&v->d_jobs, nj * sizeof(vit_job)));
     LSDR_HIP(hipMalloc((void **)&v->d_begin, nj * sizeof(vit_state)));
     LSDR_HIP(hipMalloc((void **)&v->d_end, nj * sizeof(vit_state)));
-    LSDR_HIP(hipMalloc((void **)&v->d_bad, nj * sizeof(int)));
+    LSDR_HIP(hipMalloc((void **)&v->d_bad, 2 * nj * sizeof(int)));   // [0, nj): the current seam flags; [nj, 2·nj): those the device-side repair round acted on
     v->jobs_cap = nj;
   }
   // d_first belongs to the current alignment's tiles: it is read lazily after the other alignments have been launched,
@@ -801,6 +809,8 @@ static int vit_launch(lsdr_viterbi *v, const lsdr_softsymbol *in, uint8_t *out, 
   a.chunk_states = chunk_states ? v->d_chunk : nullptr;
   a.njobs = (unsigned)up.size();
   a.q4_n_main = a.njobs; a.q4_main_waves = 0;
+  a.cond = nullptr;
+  if (args_out) *args_out = a;
   const dim3 grid((unsigned)((up.size() + kVitWaves - 1) / kVitWaves)), block(kVitWaves * 64);
   // (test hooks, read at every call so that one process can exercise every kernel)
   const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;   // test hook: every mode through the generic path
@@ -909,6 +919,12 @@ void lsdr_viterbi_destroy(lsdr_viterbi *v) {
 
 int lsdr_viterbi_set_resync_period(lsdr_viterbi *v, int p) { LSDR_ARG(v && p >= 1); v->resync_period = p; return LSDR_OK; }
 int lsdr_viterbi_current_sync(const lsdr_viterbi *v) { return v ? v->current_sync : -1; }
+int lsdr_viterbi_repair_stats(const lsdr_viterbi *v, unsigned long long *device_repaired, unsigned long long *host_rounds) {
+  LSDR_ARG(v);
+  if (device_repaired) *device_repaired = v->dev_repaired;
+  if (host_rounds) *host_rounds = v->host_rounds;
+  return LSDR_OK;
+}
 int lsdr_viterbi_stats(const lsdr_viterbi *v, unsigned *tiles, unsigned *bad) {
   LSDR_ARG(v);
   if (tiles) *tiles = v->last_tiles;
@@ -1080,7 +1096,8 @@ static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_
   if (n_first && first_others.ostride > stride) stride = first_others.ostride;
   std::vector<vit_job> launch_jobs(jobs);
   launch_jobs.insert(launch_jobs.end(), first_others.oj.begin(), first_others.oj.end());
-  int rc = vit_launch(v, in, out, launch_jobs, stride, false, phase0, nullptr, nullptr, false, 0, true, n_main);
+  vit_args main_args;
+  int rc = vit_launch(v, in, out, launch_jobs, stride, false, phase0, nullptr, nullptr, false, 0, true, n_main, &main_args);
   if (rc) return rc;
   // ---- seam check and fix-up rounds, main and other alignments together.  A tile whose speculative start state differs
   // from its predecessor's end state is decoded again from that end state (read on the device from the slot array; results
@@ -1096,11 +1113,34 @@ static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_
   std::vector<vit_state> first_end(v->nsyncs);
   v->last_tiles = (unsigned)n_main; v->last_bad = 0;
   vt.tiles = (unsigned)n_total;
+  // The FIRST repair round runs on the device, behind the main launch, without the host: seam check into a second flag array, then the
+  // launch's own job list once more on the lane = state kernel with those flags as a predicate (vit_args::cond) — a wavefront whose seam
+  // holds leaves at once, one whose seam failed decodes its tile again from the end state of the slot before it.  What the host then
+  // reads is the state after that round: a call whose failed seams settle in one round (all of them, in the bench's streams) has ONE
+  // launch → readback, like a call without any.  The flags the round acted on come back with it (statistics, warm-up adaptation).
+  const bool dev_repair = n_total > 1 && getenv("LSDR_VIT_HOST_REPAIR") == nullptr;   // (test hook, read per call: every round through the host)
+  int *const d_bad0 = v->d_bad + v->jobs_cap;
+  std::vector<int> bad0;
+  if (dev_repair) {
+    LSDR_HIP(hipMemsetAsync(d_bad0, 0, n_total * sizeof(int), c->stream));
+    hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_total - 1)), dim3(64), 0, c->stream,
+                       (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_total, d_bad0);
+    vit_args fa = main_args;
+    fa.cond = d_bad0; fa.states_in = v->d_end; fa.chunk_states = nullptr;
+    const dim3 grid((unsigned)((n_total + kVitWaves - 1) / kVitWaves)), block(kVitWaves * 64);
+    const bool generic_only = getenv("LSDR_VIT_GENERIC") != nullptr;
+    if (fa.C.nus == 2 && fa.C.bits_out == 2 && !generic_only) hipLaunchKernelGGL(k_viterbi<2>, grid, block, 0, c->stream, fa);
+    else if (fa.C.nus == 4 && fa.C.bits_out == 3 && !generic_only) hipLaunchKernelGGL(k_viterbi<4>, grid, block, 0, c->stream, fa);
+    else hipLaunchKernelGGL(k_viterbi<0>, grid, block, 0, c->stream, fa);
+    LSDR_HIP(hipGetLastError());
+    bad0.resize(n_total);
+  }
   for (int round = 0;; ++round) {
     LSDR_HIP(hipMemsetAsync(v->d_bad, 0, n_total * sizeof(int), c->stream));
     if (n_total > 1) hipLaunchKernelGGL(k_vit_verify, dim3((unsigned)(n_total - 1)), dim3(64), 0, c->stream,
                                         (const vit_state *)v->d_begin, (const vit_state *)v->d_end, (unsigned)n_total, v->d_bad);
     LSDR_TRY(lsdr_stage_d2h(c, bad.data(), v->d_bad, n_total * sizeof(int)));
+    if (dev_repair && round == 0) LSDR_TRY(lsdr_stage_d2h(c, bad0.data(), d_bad0, n_total * sizeof(int)));
     LSDR_TRY(lsdr_stage_d2h(c, totals_all.data(), v->d_totals, n_total * stride * sizeof(int)));
     // end states the host needs if this round turns out to be the last (later launches reuse the slots): the main
     // alignment's last tile, each other alignment's last tile
@@ -1110,6 +1150,14 @@ static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_
         LSDR_TRY(lsdr_stage_d2h(c, &first_end[first_others.which[k]], v->d_end + (n_main + k), sizeof(vit_state)));
     VIT_SYNC(c, vt);
     for (size_t k = 0; k < n_total; ++k) if (!seam[k]) bad[k] = 0;
+    if (dev_repair && round == 0) {      // what the device-side round re-decoded
+      unsigned nrep = 0;
+      bool others = false;
+      for (size_t k = 1; k < n_total; ++k)
+        if (seam[k] && bad0[k]) { ++nrep; if (k >= n_main) others = true; }
+      v->last_bad += nrep; v->dev_repaired += nrep; vt.fixups += nrep;
+      if (others && v->warm_others < 16) v->warm_others += 4;
+    }
     if (round >= 6) break;
     std::vector<vit_job> fj;
     for (size_t k = 1; k < n_total; ++k)
@@ -1119,7 +1167,8 @@ static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_
         fj.push_back(j);
       }
     if (fj.empty()) break;
-    if (round == 0 && v->warm_others < 16)
+    ++v->host_rounds;
+    if (round == 0 && !dev_repair && v->warm_others < 16)
       for (const vit_job &j : fj) if (j.sync != cur) { v->warm_others += 4; break; }
     v->last_bad += (unsigned)fj.size();
     vt.fixups += (unsigned)fj.size();

@@ -387,6 +387,34 @@ def test_viterbi_long_call_picks_the_quad_kernel(capi, ctx, oracle, cstln, rate,
         assert st["tiles"] >= 1024          # (a locked stream goes through in one long call)
 
 
+@pytest.mark.parametrize("mode", ["device", "host"])
+@pytest.mark.parametrize("kernel", ["auto", "lane"])
+def test_viterbi_repair_round(capi, ctx, oracle, monkeypatch, mode, kernel):
+    """Failed seams (LSDR_VIT_WO=1: the other alignments' tiles warm up over ONE chunk, so many of their seams fail; 120 ‰ symbol errors
+    on top) are re-decoded by the round that runs on the device behind the main launch — no launch → readback round of the host's unless a
+    repaired tile's end state moved — or, with LSDR_VIT_HOST_REPAIR, by the host's rounds as before.  Same bytes as the sequential oracle
+    either way."""
+    for k in ("LSDR_VIT_Q4", "LSDR_VIT_LANE", "LSDR_VIT_GENERIC", "LSDR_VIT_HOST_REPAIR"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("LSDR_VIT_WO", "1")
+    if mode == "host":
+        monkeypatch.setenv("LSDR_VIT_HOST_REPAIR", "1")
+    if kernel == "lane":
+        monkeypatch.setenv("LSDR_VIT_LANE", "1")
+    sym = fec_input(np.tile(hard_symbols(), 41 if kernel == "auto" else 6), 120)
+    v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12)
+    got, cons = v.run_stream(sym)
+    cur, st, rs = v.current_sync, v.stats(), v.repair_stats()
+    v.close()
+    want, wcons, wcur = oracle.viterbi_sync(sym, 1, 0)
+    assert cons == wcons and cur == wcur and bits_equal(got, want)
+    if mode == "device":
+        assert rs["device_repaired"] > 0, (rs, st)
+    else:
+        assert rs["device_repaired"] == 0 and rs["host_rounds"] > 0, (rs, st)
+    print(mode, kernel, rs, st)
+
+
 def test_viterbi_resync_period_1(capi, ctx, oracle, vit_kernel):
     sym = fec_input(hard_symbols()[:80000], 40)
     v = capi.Viterbi(ctx, capi.QPSK, capi.FEC12, resync_period=1)
