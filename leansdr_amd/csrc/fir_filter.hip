@@ -974,13 +974,16 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   // (rows 0…15 are mirrored at 64…79) so that ρ − q needs no wrap; byte offset of term q = 15 for even / odd B, terms with
   // smaller q `dstep` bytes further on
   const unsigned dstep = ROWZ * 4 - 8;
-  // NP = 4: a wave tile is exactly the ring's 64 rows, so the only reads that would wrap are those of rows 0 … NQ−2 — which are not outputs: no
-  // mirrored rows (the ring is 64 rows, 1.4 KB less: seven wavefronts per CU also with 12 tap blocks); those reads land in the region's tail
-  constexpr bool MIRROR = NP != 4;
+  // NP = 4 (FOLD): a wave tile is 64 ring rows and nothing wraps except the reads of rows 0 … NQ−2, which are not outputs — no mirrored rows
+  // 64 … 79.  And the ring is FOLDED to 48 rows: rows 0 … 15 (pair 0) are dead once the first diagonal batch has read them (during pair 2), so
+  // pair 3's rows 48 … 63 go there; the rows in front of them that the second batch's sums reach back into (37 … 47, pair 2) are written a
+  // second time at rows −16 … −1, i.e. over the LAST sample rows of the region — pair 3's, whose operands are in registers by then and whose
+  // refill is issued after that batch's reads.  20 KB of LDS per wavefront instead of 21–22: EIGHT per CU.
+  constexpr bool MIRROR = NP != 4, FOLD = NP == 4;
   int dbase[2];
 #pragma unroll
   for (int par = 0; par < 2; ++par) {
-    const unsigned rr = 32u * par + ro, rp = (MIRROR && rr < 16) ? rr + 64 : rr;
+    const unsigned rr0 = 32u * par + ro, rr = (FOLD && rr0 >= 48) ? rr0 - 48 : rr0, rp = (MIRROR && rr < 16) ? rr + 64 : rr;
     dbase[par] = (int)((rp * ROWZ + rc) * 4) - 15 * (int)dstep;   // = ((rp − 15)·ROWZ + 2·15 + rc)·4
   }
 
@@ -1016,10 +1019,14 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
       if (zq < NQ) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const unsigned row = (16u * pair + 8u * h + zrow) & 63u;
+          const unsigned row0 = (16u * pair + 8u * h + zrow) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
           const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
           *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
           *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
+          if (FOLD && pair == 2) {            // rows 32 … 47 once more at −16 … −1 (inside the region's last rows: see FOLD)
+            *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = lo;
+            *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 47) * (int)ROWZ + 2 * (int)zq) * 4) = hi;
+          }
           if (MIRROR && ((16u * pair) & 63u) == 0) {
             *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
             *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
@@ -1095,11 +1102,15 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
       }
     }
     to_ring((NP - 1) & 1, NP - 1);
-    refill(NP - 1);
+    if (!FOLD) refill(NP - 1);
 #pragma unroll
     for (int q = 0; q < NQR; ++q) diag_read(NP / 2 - 1, q);
 #pragma unroll
     for (int q = 0; q < NQR; ++q) diag_add(q);
+    if (FOLD) {                                // the last rows' refill lands on the mirrored ring rows: only after the sums have their terms
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      refill(NP - 1);
+    }
     diag_store(NP / 2 - 1);
     if (!more) break;
     ti = tn;
@@ -1171,7 +1182,8 @@ fir_kernel_t pick_stream(unsigned D, bool cplx, unsigned nq, unsigned np = 8) {
 // LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 16·np rows) + Z ring + the diagonal reads' overrun
 unsigned stream_lds(unsigned D, unsigned nq, bool cplx, unsigned np = 8) {
   const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4, fp = ((kp / sl - D) + 1) & ~1u;
-  return ((fp * 8 + 16 * np * D * 8 + 15) & ~15u) + (np == 4 ? 64 : 80) * 2 * (nq | 1u) * 4 + 128;
+  if (np == 4) return ((fp * 8 + 16 * np * D * 8 + 15) & ~15u) + 48 * 2 * (nq | 1u) * 4;   // folded ring, compile-time tap blocks only (no overrun)
+  return ((fp * 8 + 16 * np * D * 8 + 15) & ~15u) + 80 * 2 * (nq | 1u) * 4 + 128;
 }
 // geometry of a k_fir_mfma_blk launch (nb = tap blocks NQ, alen = coefficient operand floats, M = outputs per tile)
 struct blk_geom { unsigned nq, alen, U, lds, nl, nl_fixed, M, ks; };
