@@ -246,8 +246,18 @@ def anf1(capi, synth, device, args):
     nf = capi.NotchFir(ctx, pipe.coeffs, D, in_scale=75.0)
     if os.environ.get("LSDR_NF_OVERLAP"):      # (the capture is resident: the promise lsdr_notch_fir_set_overlap asks for holds; gains 0–5 %
         nf.set_overlap(True)                   # depending on which hardware queues the runtime gives the block's two streams: off)
-    NB = 4
-    dec = [ctx.alloc((n_out + EXTRA + 64) * 8) for _ in range(NB)]
+    # the block's output pipe: a ring of NB batch slots in ONE allocation, so that the head of batch k sits behind batch k − 1 (the receiver's
+    # read-ahead) without a copy — except where the ring wraps (one batch in NB: its head is copied behind the last slot)
+    NB = 8
+    ring = ctx.alloc((NB * n_out + EXTRA + 64) * 8)
+
+    class _Slot:
+        def __init__(self, j):
+            self.ptr = ring.ptr + j * n_out * 8
+
+        def at(self, off):
+            return self.ptr + int(off)
+    dec = [_Slot(j) for j in range(NB)]
     ev_nf = [ctx.event() for _ in range(NB)]
     ev_rx = [cp.ctx_rx.event() for _ in range(NB)]
     st = dict(F=0, k=0)
@@ -273,7 +283,8 @@ def anf1(capi, synth, device, args):
             prod = nf_run(j)
             assert prod == n_out and st["F"] == (k + 1) * B - 330, (prod, st["F"])
             if k >= 2:       # batch k−1 is complete once the head of batch k sits behind it (the receiver's read-ahead)
-                capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, dec[jp].at(n_out * 8), dec[j].ptr, EXTRA * 8))
+                if j == 0:
+                    capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, dec[jp].at(n_out * 8), dec[j].ptr, EXTRA * 8))
                 ctx.event_record(ev_nf[jp])
                 cp.ctx_rx.wait_event(ev_nf[jp])
                 used = cp.rx.run_async(dec[jp].ptr, n_out + EXTRA, cp.d_sym.ptr, n_out + EXTRA + 256)
@@ -323,8 +334,7 @@ def anf1(capi, synth, device, args):
                          "note": "HIP events around the filter pass on its stream (lsdr_notch_fir_time), the receiver running next to it; the "
                                  "decimated-rate kernels (taps, head, scan, state) add 3 x 8/30 B per sample"})
     nf.close()
-    for d in dec:
-        d.free()
+    ring.free()
     d_x.free()
     pipe.close()
     return out
