@@ -14,7 +14,7 @@ rows.sort(key=lambda r: r[1])
 def key(n):
     m = re.search(r"(k_\w+|__amd\w+)", n)
     return m.group(1) if m else n[:28]
-pas = [(s, e, q) for n, s, e, q in rows if "k_fir_mfma_stream" in n and "ELi12ELi1" in n.replace(" ", "") or ("k_fir_mfma_stream<30, 1, 12, 1>" in n)]
+pas = [(s, e, q) for n, s, e, q in rows if "k_fir_mfma_stream" in n and "ELi12ELi1" in n.replace(" ", "") or ("k_fir_mfma_stream<30, 1, 12, 1" in n)]
 pas = [p for p in pas if p[1] - p[0] > 200000]
 pas = pas[len(pas) // 2:]
 o = open(sys.argv[2], "w")
