@@ -871,12 +871,14 @@ typedef __attribute__((address_space(3))) void *fir_lds_ptr;
 // IV = 1: the taps are a function of the position in the stream (fir_args::iv_tile_first): a wavefront walks its tiles in
 // ascending order, so it reloads the coefficient operand the (few) times it crosses into another interval — behind a vmcnt(0),
 // so that the hand-counted waits below never see these loads.  One stream per launch.
-// The IV launch is OVERSUBSCRIBED (32 workgroups per CU queued, each with a short tile list): with four 39 KB workgroups per CU a grid of
+// The IV launch is OVERSUBSCRIBED (64 workgroups per CU queued, each with a short tile list): with four 39 KB workgroups per CU a grid of
 // exactly the resident workgroups is only resident in full while nothing else holds LDS — next to cstln_receiver's staged tiles (9 KB
 // per wavefront) some workgroups started when others ENDED and the launch took 1.19 ms instead of 0.76 (256 Mi samples); with 16–32 per CU
 // the dispatcher deals the work: 0.80 ms.  (Tiles dealt by a per-XCD atomic counter, one returned atomic per tile: 0.96 ms alone — dropped.)
-// NP = pairs of row tiles per wave tile (16 rows each): 8 → a region of 128 rows (39 KB of LDS with its ring: four wavefronts per CU, 117 outputs
-// per 128 rows at 12 tap blocks); 4 → 64 rows (24 KB: six per CU, 53 outputs per 64 rows).  The outputs do not depend on it.
+// NP = pairs of row tiles per wave tile (16 rows each): 8 → a region of 128 rows (38–39 KB of LDS with its ring: four wavefronts per CU, 117
+// outputs per 128 rows at 12 tap blocks) — real taps, HBM-bound; 4 → 64 rows, 53 outputs per 64 rows, ring folded to 48 rows (FOLD below):
+// 19.6–20.4 KB, EIGHT per CU — complex taps and the IV pass, which are bound by what the wavefronts of a CU overlap (3.44 → 4.0 TB/s alone,
+// 0.65 ms per 256 Mi samples for the IV pass); 6 → 96 rows (30 KB, five per CU: 3.76).  The outputs do not depend on it.
 template <int DT, int CP, int NQT, int IV = 0, int NP = 8>
 __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
