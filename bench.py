@@ -265,6 +265,19 @@ class Capture:
             self.ctx_rx.close()
 
 
+class _Window:
+    """A stretch of one large device allocation, with what the pipeline uses of a DevBuf; it goes when the allocation goes."""
+
+    def __init__(self, capi, ptr):
+        self._vp, self.ptr = capi.vp, int(ptr)
+
+    def at(self, byte_offset):
+        return self._vp(self.ptr + int(byte_offset))
+
+    def free(self):
+        self.ptr = None
+
+
 class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
@@ -355,9 +368,33 @@ class C2Pipeline:
         # process run slow whatever the buffer, so the slowest one is no yardstick)
         launch_ms(cp.d_in, cp.dec[0])          # (clocks, TLBs)
         ins, t_in = [cp.d_in], [launch_ms(cp.d_in, cp.dec[0])]
-        while len(ins) < candidates and not (len(ins) >= 5 and min(t_in) < 0.92 * float(np.median(t_in))):
-            d = ctx.alloc((g["B"] + g["period"]) * 8)
-            capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.ptr, cp.d_in.ptr, (g["B"] + g["period"]) * 8))
+        nbytes = (g["B"] + g["period"]) * 8
+        done = lambda: len(ins) >= 5 and min(t_in) < 0.92 * float(np.median(t_in))
+        # First candidates: the 2 MiB-aligned windows of ONE large allocation (tools/placement_map.py, vmm_probe.py, va_align_probe.py: what makes
+        # a buffer slow goes with its physical backing, not with its address or the launch's shape — memory mapped chunk by chunk through
+        # hipMemCreate / hipMemMap is ALL of the slow kind, separate 2 GiB hipMallocs are of either, and the larger one allocation, the larger
+        # the share of fast windows in it: 96 GiB all fast, 48 GiB 5.6–5.9 TB/s, 16 GiB either).  Not when several ranks share this GPU.
+        arena_gib = int(os.environ.get("LSDR_BENCH_ARENA_GIB", 160)) if not os.environ.get("LSDR_RANK_DEVICES") else 0
+        self.arena, n_arena = None, 0
+        if arena_gib > 0:
+            try:
+                self.arena = ctx.alloc(arena_gib << 30)
+            except Exception:
+                self.arena = None
+        dec_step = -(-(n_dec * 8) // (2 << 20)) * (2 << 20)
+        n_dec_win = 64 if self.arena is not None else 0                    # windows for the decimated-stream buffers: the arena's tail
+        if self.arena is not None:
+            step = -(-nbytes // (2 << 20)) * (2 << 20)
+            for w in range(((arena_gib << 30) - n_dec_win * dec_step) // step):
+                if done():
+                    break
+                d = _Window(capi, self.arena.ptr + w * step)
+                capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.at(0), cp.d_in.ptr, nbytes))
+                ctx.sync()
+                ins.append(d); t_in.append(launch_ms(d, cp.dec[0])); n_arena += 1
+        while len(ins) < candidates and not done():
+            d = ctx.alloc(nbytes)
+            capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.ptr, cp.d_in.ptr, nbytes))
             ctx.sync()
             ins.append(d); t_in.append(launch_ms(d, cp.dec[0]))
         # The capture then lives in ONE buffer or in TWO read alternately (tools/placement_probe4.py: the same launch re-reading one
@@ -373,7 +410,13 @@ class C2Pipeline:
         for k, d in enumerate(ins):
             if k != best and not (two and k == order[1]):
                 d.free()
+        in_arena = [isinstance(d, _Window) for d in ([cp.d_in] + ([cp.d_in2] if two else []))]
+        # the decimated-stream buffers (70 MB each, written by the launch) matter as much: one launch over a fast input buffer took 0.367 ms into
+        # one of them and 0.412–0.430 into six others — candidates: the ones there are, a few more allocations, the windows of the arena's tail
         decs = list(cp.dec) + [ctx.alloc((n_dec) * 8) for _ in range(max(0, min(candidates, 8) - len(cp.dec)))]
+        if self.arena is not None:
+            tail = self.arena.ptr + (arena_gib << 30) - n_dec_win * dec_step
+            decs += [_Window(capi, tail + w * dec_step) for w in range(n_dec_win)]
         t_dec = [launch_ms(cp.d_in, d) for d in decs]
         order = list(np.argsort(t_dec))
         keep = order[:len(cp.dec)]
@@ -381,7 +424,11 @@ class C2Pipeline:
         for k, d in enumerate(decs):
             if k not in keep:
                 d.free()
-        return dict(candidates=candidates, input_buffers_in_use=2 if two else 1, filter_launch_ms_by_input_buffer=[round(float(v), 4) for v in t_in],
+        in_arena += [isinstance(d, _Window) for d in cp.dec]
+        if self.arena is not None and not any(in_arena):
+            self.arena.free(); self.arena = None
+        return dict(candidates=candidates, input_buffers_in_use=2 if two else 1, arena_gib=arena_gib, arena_windows_tried=n_arena,
+                    buffers_inside_the_arena=int(sum(in_arena)), filter_launch_ms_by_input_buffer=[round(float(v), 4) for v in t_in],
                     filter_launch_ms_by_decimated_buffer=[round(float(v), 4) for v in t_dec])
 
     def run(self, n_batches, timed, snapshot_last=False, track_tol=None):
@@ -612,6 +659,8 @@ class C2Pipeline:
             c.close()
         for cx in self.ctx_rxs:
             cx.close()
+        if getattr(self, "arena", None) is not None:
+            self.arena.free(); self.arena = None
         self.fir.close()
         self.ctx.close()
 
