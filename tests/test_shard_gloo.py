@@ -166,3 +166,19 @@ def test_numa_pinning_degrades_gracefully():
     before = os.sched_getaffinity(0)
     assert Shard().pin_to_gpu_numa("ffff:ff:1f.7") is None
     assert os.sched_getaffinity(0) == before
+
+
+def test_arena_window_is_a_buffer_view():
+    """bench._Window: what C2Pipeline.place_buffers hands the pipeline for a stretch of its one large allocation — the pointer, .at() as a
+    DevBuf's, free() a no-op for the allocation (it goes with the arena)."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class _Capi:
+        vp = ctypes.c_void_p
+    w = bench._Window(_Capi, 0x7000_0020_0000)
+    assert w.ptr == 0x7000_0020_0000 and isinstance(w.at(0), ctypes.c_void_p)
+    assert w.at(4096).value == 0x7000_0020_0000 + 4096
+    w.free()
+    assert w.ptr is None
