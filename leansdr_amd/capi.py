@@ -69,6 +69,12 @@ def _sig(name, restype, argtypes):
 
 
 _sig("lsdr_abi_version", C.c_int, [])
+# include/lsdr_hip.h LSDR_ABI_VERSION: 2 since lsdr_rx_run_multi_async writes one `consumed` PER receiver (round 5) — a caller
+# built against version 1 passed one size_t there.  A stale liblsdr_hip.so is refused at import, not discovered through memory damage.
+ABI_VERSION = 2
+if lib.lsdr_abi_version() != ABI_VERSION:
+    raise ImportError(f"liblsdr_hip.so reports ABI version {lib.lsdr_abi_version()}, leansdr_amd.capi is written for {ABI_VERSION}: "
+                      "rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
 _sig("lsdr_last_error", C.c_char_p, [])
 _sig("lsdr_device_count", C.c_int, [])
 _sig("lsdr_device_pci_bus_id", C.c_int, [C.c_int, C.c_char_p, C.c_int])

@@ -1701,6 +1701,7 @@ struct lsdr_notch_fir {
 };
 
 static int nf_sync_all(lsdr_notch_fir *h);
+static int nf_create_body(lsdr_notch_fir *h, const lsdr_notch_fir_cfg *cfg);
 // fir_filter::set_freq (dsp.h:271-280) for the fused block: shifted taps (host libm, as the reference), the fused scaler on them
 static int nf_upload_taps(lsdr_notch_fir *h) {
   std::vector<lsdr_cf32> sc(h->coeffs.size());
@@ -1721,8 +1722,17 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
     return LSDR_E_UNSUPPORTED;
   }
   LSDR_HIP(hipSetDevice(c->device));
-  lsdr_notch_fir *h = new lsdr_notch_fir();
-  h->ctx = c; h->N = (int)cfg->ncoeffs; h->D = (int)cfg->decim;
+  lsdr_notch_fir *h = new lsdr_notch_fir();   // value-initialised: every pointer / event null until nf_create_body sets it
+  h->ctx = c;
+  const int rc = nf_create_body(h, cfg);
+  if (rc) { lsdr_notch_fir_destroy(h); return rc; }   // every error exit frees what was allocated so far
+  *out = h;
+  return LSDR_OK;
+}
+
+}  // extern "C"
+static int nf_create_body(lsdr_notch_fir *h, const lsdr_notch_fir_cfg *cfg) {
+  h->N = (int)cfg->ncoeffs; h->D = (int)cfg->decim;
   h->decimation = cfg->notch_decimation > 0 ? cfg->notch_decimation : 1024 * 4096;   // sdr.h:56
   h->k = cfg->k > 0.f ? cfg->k : 0.002f;
   h->scale = cfg->in_scale != 0.f ? cfg->in_scale : 1.0f;
@@ -1736,7 +1746,7 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   h->coeffs.assign(cfg->coeffs_host, cfg->coeffs_host + cfg->ncoeffs);
   h->freq = 0.f; h->retap = false;
   LSDR_HIP(hipMalloc((void **)&h->d_coeffs, cfg->ncoeffs * sizeof(float2)));
-  { int rc0 = nf_upload_taps(h); if (rc0) return rc0; }
+  LSDR_TRY(nf_upload_taps(h));
   LSDR_HIP(hipMalloc((void **)&h->d_state, 2 * sizeof(nf_state)));
   nf_state s0[2]; memset(s0, 0, sizeof(s0)); s0[0].bin = s0[1].bin = -1;
   LSDR_HIP(hipMemcpy(h->d_state, s0, sizeof(s0), hipMemcpyHostToDevice));
@@ -1750,13 +1760,8 @@ int lsdr_notch_fir_create(lsdr_ctx *c, const lsdr_notch_fir_cfg *cfg, lsdr_notch
   LSDR_HIP(hipMalloc((void **)&h->d_ivtab, 2 * niv * kNfKs * 64 * sizeof(float)));
   LSDR_HIP(hipMalloc((void **)&h->d_bin_carry, 2 * sizeof(int)));
   { const int none[2] = {-1, -1}; LSDR_HIP(hipMemcpy(h->d_bin_carry, none, sizeof(none), hipMemcpyHostToDevice)); }
-  int rc = cfft_dev_init(&h->fft, kN, true);
-  if (rc) return rc;
-  *out = h;
-  return LSDR_OK;
+  return cfft_dev_init(&h->fft, kN, true);
 }
-
-}  // extern "C"
 static int nf_sync_all(lsdr_notch_fir *h) {
   if (h->s_det) LSDR_HIP(hipStreamSynchronize(h->s_det));
   if (h->s_pass) LSDR_HIP(hipStreamSynchronize(h->s_pass));

@@ -1118,6 +1118,15 @@ static int viterbi_run_aligned(lsdr_viterbi *v, const lsdr_softsymbol *in, size_
   // holds leaves at once, one whose seam failed decodes its tile again from the end state of the slot before it.  What the host then
   // reads is the state after that round: a call whose failed seams settle in one round (all of them, in the bench's streams) has ONE
   // launch → readback, like a call without any.  The flags the round acted on come back with it (statistics, warm-up adaptation).
+  // INVARIANTS this round relies on (advisor, round 5):
+  //  * one job per slot, in slot order: the grid below is sized from n_total, the kernel indexes main_args.jobs — so the launch's job
+  //    list must have exactly n_total entries (checked here, not assumed);
+  //  * ADJACENT failed seams run concurrently: job k reads d_end[k−1] while job k−1 may be rewriting it.  That is allowed because nothing
+  //    is trusted afterwards — every job records in d_begin[k] the state it ACTUALLY started from, the host's round 0 below re-runs
+  //    k_vit_verify over all seams (d_begin[k] against the FINAL d_end[k−1]) and decodes again, through the host, whatever still
+  //    disagrees; so a torn or stale read costs one more round, never a wrong byte.  `dev_repaired` therefore counts the tiles the device
+  //    round DECODED AGAIN, not the tiles it settled: what still needed the host shows in `host_rounds` (lsdr_viterbi_repair_stats).
+  if (launch_jobs.size() != n_total) { lsdr_set_error("viterbi_sync: %zu jobs for %zu slots", launch_jobs.size(), n_total); return LSDR_E_ARG; }
   const bool dev_repair = n_total > 1 && getenv("LSDR_VIT_HOST_REPAIR") == nullptr;   // (test hook, read per call: every round through the host)
   int *const d_bad0 = v->d_bad + v->jobs_cap;
   std::vector<int> bad0;

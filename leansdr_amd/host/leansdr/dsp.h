@@ -145,6 +145,11 @@ struct fir_filter<complex<float>, float> : runnable {
     cfg.in_format = LSDR_IN_CF32; cfg.in_scale = fuse_scale; cfg.arith = LSDR_FIR_EXACT;
     lsdr_check(lsdr_fir_filter_create(ctx, &cfg, &h), name);
   }
+  // (the reference's blocks live as long as the process; a graph that is torn down gives its device objects back)
+  ~fir_filter() {
+    if (hf) lsdr_notch_fir_destroy(hf);
+    if (h) lsdr_fir_filter_destroy(h);
+  }
   void prepare() {
     if (!hf) return;
     // every other reader of the notched stream must be an observer nobody listens to; then they are switched off and the notch is ours
@@ -158,6 +163,7 @@ struct fir_filter<complex<float>, float> : runnable {
     for (size_t r = 0; r < fused_pipe->n_readers(); ++r)
       if ((int)r != in.id) static_cast<passive_tap *>(fused_pipe->reader_owner((int)r))->tap_detached = true;
     notch->fused_away = true;
+    lsdr_fir_filter_destroy(h); h = NULL;       // fused: the stand-alone filter's tables and scratch are not needed any more
     out.buf.need_room(4096 / d + 16);          // (the fused block produces a whole 4096-sample block's outputs or nothing)
     lsdr_check(lsdr_notch_fir_set(hf, notch->notch_decimation(), notch->notch_k()), name);     // auto_notch's public tunables, as set by now
     if (sch->verbose) fprintf(stderr, "fir_filter: fused with auto_notch (lsdr_notch_fir)\n");

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 
 def test_abi_version(capi):
-    assert capi.lib.lsdr_abi_version() == 1
+    assert capi.lib.lsdr_abi_version() == 2
 
 
 def test_no_cpu_fallback(capi):
