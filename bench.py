@@ -780,8 +780,12 @@ def main():
                          "cu8 captures at 1.2 sps decoded to TS (bench_c1.py); with --gpus N that is config 4 (captures sharded over the GPUs)")
     ap.add_argument("--c1-captures", type=int, default=16, help="c1: independent captures resident per GPU (each decoded once per step)")
     ap.add_argument("--c1-msamples", type=int, default=128, help="c1: Mi samples per capture")
-    ap.add_argument("--c1-workers", type=int, default=16, help="c1: host threads / HIP streams decoding captures concurrently per GPU")
-    ap.add_argument("--c1-tile", type=int, default=2048)
+    ap.add_argument("--c1-workers", type=int, default=16, help="c1 --c1-mode chain: host threads / HIP streams decoding captures concurrently per GPU")
+    ap.add_argument("--c1-mode", choices=["batch", "chain"], default="batch",
+                    help="c1: batch = lsdr_capture_batch (shared launches, counts on the device, one host thread); chain = the C-ABI blocks one by one (rounds 2-5)")
+    ap.add_argument("--c1-groups", type=int, default=2, help="c1 batch: capture groups per GPU (one lsdr_capture_batch + stream each)")
+    ap.add_argument("--c1-anf", type=int, default=1, help="c1 batch: auto_notch slots (1 = leandvb's default, 0 = --anf 0)")
+    ap.add_argument("--c1-tile", type=int, default=0, help="c1: receiver tile length in samples (0: 4096 batch / 2048 chain)")
     ap.add_argument("--c1-warmup", type=int, default=512)
     args = resolve_defaults(ap.parse_args())
 
@@ -810,11 +814,11 @@ def main():
         return
 
     if args.workload == "c1":
-        # 16 worker streams: by default the HIP runtime multiplexes a process's streams onto 4 hardware queues, and two
-        # captures whose kernels share a queue run one after the other.  One queue per worker: 123 -> 139 GS/s.  (The C2 pipeline
-        # is the other way round — 5 streams, and 8 queues let the receivers crowd the filter: 495 -> 436 GS/s — so this is set
-        # for this workload only, before the runtime initialises.)
-        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+        if args.c1_mode == "chain":
+            # rounds 2-5: 16 worker streams — by default the HIP runtime multiplexes a process's streams onto 4 hardware queues, and two
+            # captures whose kernels share a queue run one after the other.  One queue per worker: 123 -> 139 GS/s.  The batch engine
+            # (two streams, one host thread) runs on the runtime's defaults.
+            os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
         import leansdr_amd.capi as capi
         import bench_c1
         if capi.lib.lsdr_device_count() <= local_rank:

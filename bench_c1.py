@@ -1,20 +1,26 @@
 """bench_c1.py — BASELINE config 1 / config 4: independent 2 MS/s-class QPSK 1/2 captures (cu8 IQ at 1.2 samples/symbol, the
-README's `leandvb --u8 -f 2400e3 --sr 2000e3 --cr 1/2` case) decoded from the first sample to transport-stream packets:
+README's `leandvb --u8 -f 2400e3 --sr 2000e3 --cr 1/2` case WITH ITS DEFAULTS: `--anf 1`, linear sampler, algebraic deconvolution)
+decoded from the first sample to transport-stream packets:
 
-    cconverter<u8> (fused) + cstln_receiver (linear sampler, tiled, packed hard decisions) → deconvol_sync → mpeg_sync →
-    deinterleaver → rs_decoder → derandomizer → TS packets in host memory
+    cconverter<u8> → auto_notch(1 slot) → cstln_receiver (linear sampler) → deconvol_sync → mpeg_sync → deinterleaver →
+    rs_decoder → derandomizer → TS packets in host memory
 
 Unit of work = one CAPTURE = one scheduler instance of the reference (leandvb.cc:163, 205-600): every decode starts from freshly
-reset blocks (acquisition included) and ends with the capture's TS in pinned host memory.  `captures` captures live in HBM per GPU;
-a step decodes each of them once.  Decodes are handed to `workers` host threads, each with its own context (HIP stream) and
-block handles — captures share nothing, so the chains of different captures overlap on the GPU; inside a chain the FEC tail's
-data-dependent calls wait for the host, which is what the other workers' kernels hide.  Multi-GPU = the same on every rank
-(bench.py --workload c1 --gpus N: one process per GPU, no collective).
+constructed blocks (acquisition included) and ends with the capture's TS in pinned host memory.  `captures` captures live in HBM per
+GPU; a step decodes each of them once.
 
-Verification after the clock stops (`verified`): the IQ of EVERY capture goes through the reference's own binary
-(oracle/_ref/leandvb --u8 … --anf 0, built from /root/reference by oracle/Makefile; it travels with the repo) on the host cores,
-and every packet the reference wrote after acquisition must be in this path's TS, byte for byte and in order; without the binary
-the check falls back to the transmitted packet sequence (and says so).
+C1Job (round 6): the captures of a GPU are decoded by lsdr_capture_batch objects (include/lsdr_hip.h) — ALL captures of a group share
+every launch (the notch's detect chain, the receiver's tiles with the notch inside, the seam pass, the compaction, the FEC tail), every
+data-dependent count stays on the device, the host reads one result record per capture and step.  Two groups on two streams, driven by
+ONE host thread: one group's FEC tail and TS download run under the other group's tiles.  No GPU_MAX_HW_QUEUES, no worker threads.
+
+ChainJob (rounds 2-5, `--c1-mode chain`): one host thread + stream per capture calling the blocks of the C ABI one by one — kept as the
+checker of the device-resident control flow (tests/test_gpu_capture_batch.py) and as a bench row.
+
+Verification after the clock stops (`verified`): the IQ of EVERY capture goes through the reference's own binary (oracle/_ref/leandvb
+--u8 -f 2400e3 --sr 2000e3 --cr 1/2 [--anf 0 only in the anf-0 variant], built from /root/reference by oracle/Makefile; it travels with
+the repo) on the host cores, and the TS must be the reference's, byte for byte; without the binary the check falls back to recorded
+hashes / the transmitted packet sequence (and says so).
 """
 import ctypes as C
 import hashlib
@@ -33,8 +39,16 @@ sys.path.insert(0, ROOT)
 FS, FM = 2400e3, 2000e3
 OMEGA = float(np.float32(FS / FM))
 ALG_BYTES_PER_SAMPLE = 2.0 + 188.0 / (204 * 8 * 1.2)       # cu8 in + TS out = 2.096
+# vector instructions k_rxb_tiles issues per symbol step and lane [without, with the notch]: counted from the kernel's ISA (the symbol
+# loop of `llvm-objdump -d`), confirmed by SQ_INSTS_VALU (profiles/r06_bench/c1_pmc_sq.txt); LSDR_C1_VALU_PER_SYMBOL overrides
+VALU_PER_SYMBOL_STEP = (96.0, 116.0)
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "leandvb")
-REF_ARGS = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2", "--anf", "0"]
+REF_ARGS_BASE = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"]       # the README example: everything else at its default (--anf 1)
+REF_ARGS = REF_ARGS_BASE + ["--anf", "0"]                                          # the variant rounds 2-5 measured
+
+
+def ref_args(anf):
+    return REF_ARGS_BASE if anf else REF_ARGS
 SKIP_ACQ = 16            # packets of the reference's output skipped before the comparison (lock instants may differ by a few packets)
 GOLDEN = os.path.join(ROOT, "tests", "golden", "c1_ts.json")   # recorded on an MI355X box with the reference binary next to it
 
@@ -231,10 +245,13 @@ def capture_seeds(rank, n_captures):
     return [1000 * (rank + 1) + k for k in range(n_captures)]
 
 
-class C1Job:
-    def __init__(self, capi, device, n_captures, msamples, workers, tile, warm, seed0):
+class JobBase:
+    """The captures of one GPU (generated on the device), their TS buffers in pinned host memory, and the check against the reference."""
+    anf = 0
+
+    def _make_captures(self, capi, device, n_captures, n_samples, seed0):
         self.capi, self.device = capi, device
-        self.n = (msamples << 20) // 128 * 128 + 1
+        self.n = n_samples
         ctx = self.ctx = capi.Ctx(device)
         gen = Generator(capi, ctx, self.n, n_captures)
         self.ts_sent = gen.ts
@@ -243,15 +260,26 @@ class C1Job:
             d, fp = gen.capture(k, seed0 + k)
             self.caps.append(d); self.first_pk.append(fp); self.seeds.append(seed0 + k)
         gen.close()
-        self.workers = [Worker(capi, device, self.n, tile, warm) for _ in range(max(1, workers))]
-        self.ts_cap = self.workers[0].pk_cap * 188
-        self.h_ts = []
-        for _ in range(n_captures):
-            p = C.c_void_p()
-            capi.check(capi.lib.lsdr_malloc_host(self.ts_cap, C.byref(p)))
-            self.h_ts.append(p)
         self.n_ts = [0] * n_captures
         self.counts = [[] for _ in range(n_captures)]
+
+    def _make_ts_buffers(self, ts_cap):
+        self.ts_cap = ts_cap
+        self.h_ts = []
+        for _ in range(len(self.caps)):
+            p = C.c_void_p()
+            self.capi.check(self.capi.lib.lsdr_malloc_host(self.ts_cap, C.byref(p)))
+            self.h_ts.append(p)
+
+
+class ChainJob(JobBase):
+    """Rounds 2-5: the blocks of the C ABI called one by one, one host thread + stream per capture in flight (`--anf 0` graph)."""
+    anf = 0
+
+    def __init__(self, capi, device, n_captures, msamples, workers, tile, warm, seed0):
+        self._make_captures(capi, device, n_captures, (msamples << 20) // 128 * 128 + 1, seed0)
+        self.workers = [Worker(capi, device, self.n, tile, warm) for _ in range(max(1, workers))]
+        self._make_ts_buffers(self.workers[0].pk_cap * 188)
         self.tile = (tile, warm)
 
     def run(self, steps, timed=False):
@@ -326,7 +354,7 @@ class C1Job:
         t0 = time.perf_counter()
         refs = [None] * len(self.caps)
         if have_ref:
-            out["checker"] = "oracle/_ref/leandvb " + " ".join(REF_ARGS) + " (the reference binary, one process per capture on the host cores)"
+            out["checker"] = "oracle/_ref/leandvb " + " ".join(ref_args(self.anf)) + " (the reference binary, one process per capture on the host cores)"
             tmp = tempfile.mkdtemp(prefix="lsdr_c1_")
             procs = []
             self.iq_sha = {}
@@ -336,7 +364,7 @@ class C1Job:
                 self.iq_sha[k] = hashlib.sha256(iq.tobytes()).hexdigest()
                 iq.tofile(f)
                 del iq
-                procs.append((k, f, subprocess.Popen([REFBIN] + REF_ARGS, stdin=open(f, "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)))
+                procs.append((k, f, subprocess.Popen([REFBIN] + ref_args(self.anf), stdin=open(f, "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)))
             for k, f, p in procs:
                 refs[k] = p.communicate()[0]
                 os.unlink(f)
@@ -386,13 +414,89 @@ class C1Job:
         return out
 
     def close(self):
-        for w in self.workers:
-            w.close()
+        self._close_engines()
         for p in self.h_ts:
             self.capi.lib.lsdr_free_host(p)
         for d in self.caps:
             d.free()
         self.ctx.close()
+
+    def _close_engines(self):
+        for w in self.workers:
+            w.close()
+
+
+class C1Job(ChainJob):
+    """Round 6: lsdr_capture_batch — the captures of a group share every launch, counts stay on the device, one host thread."""
+
+    def __init__(self, capi, device, n_captures, msamples, groups, tile, warm, seed0, anf=1):
+        self.anf = 1 if anf else 0
+        # auto_notch moves whole 4096-sample blocks: a capture of whole blocks is consumed entirely (but for the receiver's last chunk)
+        n = (msamples << 20) if self.anf else (msamples << 20) // 128 * 128 + 1
+        self._make_captures(capi, device, n_captures, n, seed0)
+        groups = max(1, min(int(groups), n_captures))
+        self.groups = []
+        per = (n_captures + groups - 1) // groups
+        for g in range(groups):
+            ks = list(range(g * per, min(n_captures, (g + 1) * per)))
+            if not ks:
+                continue
+            gctx = capi.Ctx(device)
+            cb = capi.CaptureBatch(gctx, len(ks), self.n, OMEGA, fec=capi.FEC12, anf=self.anf, tile_len=tile, tile_warmup=warm)
+            self.groups.append(dict(ctx=gctx, cb=cb, ks=ks, in_flight=False, ptrs=[self.caps[k].ptr for k in ks]))
+        pk_cap = int(self.n / OMEGA / 8 / 204) + 512
+        self._make_ts_buffers(pk_cap * 188)
+        self.tile = (tile, warm)
+        self.workers = []
+        self.results = [None] * n_captures
+        self.stats = dict(bits=0, errs=0, next_sync=0, jobs=0)
+
+    def _retire(self, g, timed):
+        res = g["cb"].wait()
+        g["in_flight"] = False
+        g["cb"].ts_download_async([self.h_ts[k] for k in g["ks"]], self.ts_cap)
+        tot = 0
+        for k, r in zip(g["ks"], res):
+            self.results[k] = r
+            self.n_ts[k] = r["ts_packets"]
+            if timed:
+                self.counts[k].append(r["ts_packets"])
+            tot += r["samples"]
+            self.stats["errs"] += r["rs_bit_errors"]; self.stats["bits"] += r["rs_packets"] * 204 * 8
+            self.stats["next_sync"] += r["next_sync_calls"]; self.stats["jobs"] += 1
+        return tot
+
+    def run(self, steps, timed=False):
+        """`steps` decodes of every capture.  Returns the samples consumed.  One host thread: a group's batch is queued as soon as its
+        previous one has been read back; the TS download of that one runs on a side stream under the new batch's kernels."""
+        total = 0
+        if timed:
+            for g in self.groups:
+                g["cb"].tile_time(True)
+        for _ in range(steps):
+            for g in self.groups:
+                if g["in_flight"]:
+                    total += self._retire(g, timed)
+                g["cb"].run_async(g["ptrs"], self.n)
+                g["in_flight"] = True
+        for g in self.groups:
+            if g["in_flight"]:
+                total += self._retire(g, timed)
+        for g in self.groups:
+            g["cb"].ts_wait()
+        return total
+
+    def tile_kernel_ms(self):
+        ms, n = 0.0, 0
+        for g in self.groups:
+            a, b = g["cb"].tile_time(False)
+            ms += a * b; n += b
+        return (ms / n if n else 0.0), n
+
+    def _close_engines(self):
+        for g in self.groups:
+            g["cb"].close()
+            g["ctx"].close()
 
 
 def cpu_reference(job, budget_s=20.0):
@@ -408,7 +512,7 @@ def cpu_reference(job, budget_s=20.0):
 
     def run(np_):
         t0 = time.perf_counter()
-        ps = [subprocess.Popen([REFBIN] + REF_ARGS, stdin=open(f.name, "rb"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(np_)]
+        ps = [subprocess.Popen([REFBIN] + ref_args(job.anf), stdin=open(f.name, "rb"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) for _ in range(np_)]
         for p in ps:
             p.wait()
         return np_ * n / (time.perf_counter() - t0) / 1e6
@@ -416,14 +520,25 @@ def cpu_reference(job, budget_s=20.0):
     allc = sorted(run(cores) for _ in range(3))[1] if cores > 1 else one
     os.unlink(f.name)
     return dict(value=round(allc, 3), unit="MS/s", cores=cores, kind="reference", one_core=round(one, 3),
-                sample=f"oracle/_ref/leandvb {' '.join(REF_ARGS)} on the first {n} samples of capture 0 (whole chain to TS): 1 process, then "
+                sample=f"oracle/_ref/leandvb {' '.join(ref_args(job.anf))} on the first {n} samples of capture 0 (whole chain to TS): 1 process, then "
                        f"{cores} processes (one per core); median of 3 passes each")
+
+
+# VALU issue slots of one MI355X: 256 CUs × 4 SIMDs, one wave64 vector instruction per 2 cycles and SIMD (SIMD-32:
+# /opt/skills/guides/MI355X_MICROARCH.md "Wave scheduling"; measured 0.94 ns per v_add_f32 and SIMD, profiles/NOTES.md) at the 2.4 GHz peak clock
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0
 
 
 def run_workload(capi, device, args, shard):
     """bench.py --workload c1.  Returns the JSON object of rank 0 (None on the other ranks)."""
     rank, world = shard.rank, shard.world
-    job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile, args.c1_warmup, seed0=capture_seeds(rank, 1)[0])
+    mode = getattr(args, "c1_mode", "batch")
+    anf = int(getattr(args, "c1_anf", 1))
+    seed0 = capture_seeds(rank, 1)[0]
+    if mode == "chain":
+        job = ChainJob(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile or 2048, args.c1_warmup, seed0=seed0)
+    else:
+        job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_groups, args.c1_tile or 4096, args.c1_warmup, seed0=seed0, anf=anf)
     job.run(max(1, args.warmup))
     shard.barrier()
     t0 = time.perf_counter()
@@ -442,30 +557,59 @@ def run_workload(capi, device, args, shard):
         job.close()
         return None, (3 if ver is not None and not ver["pass"] else 0)
     kms, klaunch = job.tile_kernel_ms()
-    alg = job.n * ALG_BYTES_PER_SAMPLE
-    W = len(job.workers)
-    stage = {k: round(sum(w.t_stage[k] for w in job.workers), 3) for k in job.workers[0].t_stage}
+    graph = ("cconverter<u8> -> auto_notch(1) -> cstln_receiver(linear) -> deconvol_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer"
+             if job.anf else "cconverter<u8> -> cstln_receiver(linear) -> deconvol_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer")
     out = {
         "metric": "IQ MSamples/s demodulated (leandvb QPSK 1/2)", "value": round(total / dt / 1e6, 3), "unit": "MS/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config 1 / config 4: independent QPSK 1/2 captures, cu8 IQ at 1.2 samples/symbol (leandvb --u8 -f 2400e3 "
-                               "--sr 2000e3 --cr 1/2 --anf 0), each decoded from its first sample to TS packets in host memory: cconverter<u8> (fused) + "
-                               "cstln_receiver(linear, tiled, packed decisions) -> deconvol_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
+        "config": {"workload": "BASELINE config 1 / config 4: independent QPSK 1/2 captures, cu8 IQ at 1.2 samples/symbol (leandvb " + " ".join(ref_args(job.anf)) +
+                               "), each decoded from its first sample to TS packets in host memory: " + graph,
                    "captures_per_gpu": len(job.caps), "samples_per_capture": job.n, "samples_per_step_per_gpu": job.n * len(job.caps),
-                   "workers_per_gpu": W, "rx_tile": {"tile_len": job.tile[0], "warmup": job.tile[1]},
+                   "rx_tile": {"tile_len": job.tile[0], "warmup": job.tile[1]},
                    "parallelism": f"{world * len(job.caps)} independent capture(s), {len(job.caps)} per GPU, no collectives, no RCCL",
-                   "ts_packets_per_capture": job.n_ts[0], "rs_byte_errors_corrected": sum(w.stats["errs"] for w in job.workers),
-                   "deconv_next_sync_calls": sum(w.stats["next_sync"] for w in job.workers),
-                   "host_seconds_per_stage_summed_over_workers": stage},
-        "roofline": {"kernel": "k_rx_tiles<linear, arithmetic QPSK, cu8, LDS-staged, packed> (cstln_receiver tolerance tiles)", "bound": "hbm",
-                     "achieved": round(alg / (kms * 1e-3) / 1e9, 2) if kms else None, "peak": 8000.0, "unit": "GB/s",
-                     "frac": round(alg / (kms * 1e-3) / 1e9 / 8000.0, 5) if kms else None, "avg_launch_ms": round(kms, 4), "launches_timed": klaunch,
-                     "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4), "traffic": None,
-                     "concurrent_launches": f"up to {W} (one per worker stream): a launch shares the chip, its duration is not the chip's rate",
-                     "whole_job_frac": round(total / dt * ALG_BYTES_PER_SAMPLE / 1e9 / 8000.0 / world, 5),
-                     "note": "latency/issue-bound decision-feedback recurrence (DESIGN §4.2): the HBM roofline is reported because SURVEY §8(d) asks for it"},
+                   "ts_packets_per_capture": job.n_ts[0]},
     }
+    if mode == "chain":
+        W = len(job.workers)
+        alg = job.n * ALG_BYTES_PER_SAMPLE
+        out["config"]["engine"] = f"C-ABI blocks one by one, {W} host threads / streams per GPU (rounds 2-5)"
+        out["config"]["host_seconds_per_stage_summed_over_workers"] = {k: round(sum(w.t_stage[k] for w in job.workers), 3) for k in job.workers[0].t_stage}
+        out["config"]["rs_byte_errors_corrected"] = sum(w.stats["errs"] for w in job.workers)
+        out["config"]["deconv_next_sync_calls"] = sum(w.stats["next_sync"] for w in job.workers)
+        out["roofline"] = {"kernel": "k_rx_tiles<linear, arithmetic QPSK, cu8, LDS-staged, packed> (cstln_receiver tolerance tiles)", "bound": "hbm",
+                           "achieved": round(alg / (kms * 1e-3) / 1e9, 2) if kms else None, "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(alg / (kms * 1e-3) / 1e9 / 8000.0, 5) if kms else None, "avg_launch_ms": round(kms, 4), "launches_timed": klaunch,
+                           "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4), "traffic": None,
+                           "concurrent_launches": f"up to {W} (one per worker stream): a launch shares the chip, its duration is not the chip's rate",
+                           "whole_job_frac": round(total / dt * ALG_BYTES_PER_SAMPLE / 1e9 / 8000.0 / world, 5)}
+    else:
+        per_launch = len(job.groups[0]["ks"])
+        alg = job.n * ALG_BYTES_PER_SAMPLE * per_launch
+        tiles = job.results[0]["tiles"] if job.results[0] else 0
+        # symbol steps a launch executes: every tile walks its warm-up and its body (tile 0 of a capture is one lane of exact arithmetic)
+        sym_steps = per_launch * max(tiles - 1, 0) * (job.tile[0] + job.tile[1]) / OMEGA
+        ipss = float(os.environ.get("LSDR_C1_VALU_PER_SYMBOL", VALU_PER_SYMBOL_STEP[1 if job.anf else 0]))
+        wave_inst = sym_steps / 64.0 * ipss
+        out["config"]["engine"] = (f"lsdr_capture_batch: {len(job.groups)} group(s) of {per_launch} capture(s) per GPU, shared launches, counts on the device, "
+                                   "ONE host thread, default hardware queues")
+        out["config"]["rs_bit_errors_corrected"] = job.stats["errs"]
+        out["config"]["deconv_next_sync_calls"] = job.stats["next_sync"]
+        out["config"]["receiver_seams"] = {k: sum(r[k] for r in job.results if r) for k in ("seam_dup", "seam_miss", "seam_bad")}
+        out["roofline"] = {"kernel": f"k_rxb_tiles<notch={bool(job.anf)}> (capture-batch tolerance tiles: cu8 LDS-staged, notch in the sample walk, QPSK by arithmetic, packed decisions)",
+                           "bound": "hbm", "achieved": round(alg / (kms * 1e-3) / 1e9, 2) if kms else None, "peak": 8000.0, "unit": "GB/s",
+                           "frac": round(alg / (kms * 1e-3) / 1e9 / 8000.0, 5) if kms else None, "avg_launch_ms": round(kms, 4), "launches_timed": klaunch,
+                           "algorithmic_bytes_per_launch": int(alg), "algorithmic_bytes_per_sample": round(ALG_BYTES_PER_SAMPLE, 4), "traffic": None,
+                           "captures_per_launch": per_launch,
+                           "concurrent_launches": f"{len(job.groups)} (one per group stream): a launch shares the chip with the other group's launches",
+                           "whole_job_frac": round(total / dt * ALG_BYTES_PER_SAMPLE / 1e9 / 8000.0 / world, 5),
+                           # the bound that applies: vector-instruction issue (a decision-feedback recurrence per tile)
+                           "valu_issue": {"bound": "valu issue", "symbol_steps_per_launch": int(sym_steps), "valu_instructions_per_symbol_step": ipss,
+                                          "instructions_source": "profiles/r06_bench/c1_pmc_sq.txt (SQ_INSTS_VALU per launch ÷ symbol steps ÷ 64 lanes)",
+                                          "wave_instructions_per_launch": int(wave_inst), "peak_wave_instructions_per_s": VALU_ISSUE_PEAK,
+                                          "achieved_wave_instructions_per_s": round(wave_inst / (kms * 1e-3), 1) if kms else None,
+                                          "frac": round(wave_inst / (kms * 1e-3) / VALU_ISSUE_PEAK, 4) if kms else None,
+                                          "whole_job_frac": round(total / dt / world / (job.n * per_launch) * wave_inst / VALU_ISSUE_PEAK, 4)}}
     rc = 0
     if ver is not None:
         out["verified"] = ver
@@ -473,17 +617,17 @@ def run_workload(capi, device, args, shard):
         out["verified"]["pass"] = bool(ver["pass"] and ranks_ok == ranks)
         if not out["verified"]["pass"]:
             rc = 3
-    if world == 1 and args.c1_captures > 1 and not getattr(args, "no_single", False):
-        # BASELINE config 4 as written — ONE capture per GPU: nothing hides the chain's data-dependent host waits, so this is a
-        # latency figure (ms from the first sample to the last TS packet of a 128 Mi-sample capture), not the GPU's rate
-        one = C1Job(capi, device, 1, args.c1_msamples, 1, args.c1_tile, args.c1_warmup, seed0=capture_seeds(rank, 1)[0])
+    if world == 1 and args.c1_captures > 1 and not getattr(args, "no_single", False) and mode != "chain":
+        # BASELINE config 4 as written — ONE capture per GPU: a latency figure (ms from the first sample to the last TS packet of a
+        # capture), not the GPU's rate
+        one = C1Job(capi, device, 1, args.c1_msamples, 1, args.c1_tile or 4096, args.c1_warmup, seed0=seed0, anf=anf)
         one.run(1)
         t1 = time.perf_counter()
         reps = 3
         n1 = one.run(reps, timed=True)
         d1 = time.perf_counter() - t1
         out["config4_one_capture_per_gpu"] = {"ms_per_capture": round(d1 / reps * 1e3, 3), "value": round(n1 / d1 / 1e6, 3), "unit": "MS/s",
-                                              "samples_per_capture": one.n, "note": "--c1-captures 1 --c1-workers 1: per-capture latency"}
+                                              "samples_per_capture": one.n, "note": "--c1-captures 1: per-capture latency"}
         one.close()
     if world == 1 and not args.no_cpu:
         cpu = cpu_reference(job, args.cpu_seconds)

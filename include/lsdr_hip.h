@@ -586,6 +586,66 @@ int lsdr_drifter_set_phases(lsdr_drifter *d, const long long a[3]);
  * the reference's output depends on how its 4096-sample pipes cut the stream; pass 4096 to reproduce leanchansim. */
 int lsdr_drifter_run(lsdr_drifter *d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *out, size_t chunk);
 
+/* ------------------------------------------------------------ capture batch
+ * BASELINE configs 1 and 4: B independent cu8 captures, each decoded from its FIRST SAMPLE to transport-stream packets by the blocks of
+ * leandvb's default `--u8` graph, freshly constructed per capture (leandvb.cc:157-600: one scheduler per capture):
+ *     cconverter<u8,128,f32,0,1,1> → auto_notch<f32>(anf slots, setpoint 0) → cstln_receiver<f32>(linear_sampler, QPSK) →
+ *     deconvol_sync<u8,0> → mpeg_sync<u8,0> → deinterleaver<u8> → rs_decoder<u8,0> → derandomizer          (leandvb.cc:211-217,
+ *     296-301, 425-510, 521-596; dsp.h:40-50, sdr.h:46-154, 697-938, dvb.h:122-513, 712-891, 926-948, 985-1058, 1107-1163)
+ * All captures of a batch share every launch (blockIdx.y = capture) and every data-dependent count stays on the device — the symbols the
+ * receiver produced, where mpeg_sync locked, the packets the derandomizer kept: the host reads one result record per capture and batch.
+ *  * front end: the time-tiled receiver of LSDR_RX_TILED with packed decisions (tolerance mode, same seam reconciliation), restated for
+ *    VALU issue (leansdr_amd/csrc/rxb_device.h), with the one-slot notch of sdr.h:119-138 INSIDE the tile's sample walk:
+ *    S[n] = p·S[n−1] + k·x[n], out = x − S, p = (1−k)·exp(j2π·bin/4096) — float32 with exact phases (lsdr_notch_fir's tolerance class);
+ *    detect() (sdr.h:76-118) is the reference's FFT bit for bit, at the reference's detect points, on the device.  auto_notch moves
+ *    whole 4096-sample blocks: with anf = 1 a capture's last n mod 4096 samples are not demodulated (as in the reference).
+ *  * FEC tail: the bit-exact blocks of this ABI, driven on the device the way a scheduler with 64 KiB byte pipes drives them while
+ *    mpeg_sync is unlocked (next_sync() included), then in one call each (leansdr_amd/csrc/tail_device.h).
+ * anf ∈ {0, 1}; omega = Fs/Fm ∈ [1, 8]; tile_len a multiple of 2048 (0: 4096), tile_warmup a multiple of 128 (0: 512).
+ * One batch in flight per object: run_async → wait → [ts_download_async → ts_wait]; the NEXT run_async may be queued while the
+ * download is in flight (its last kernel waits for it).  Use two objects on two contexts to overlap one batch's tail with the other's
+ * front end. */
+typedef struct lsdr_capture_batch lsdr_capture_batch;
+typedef struct {
+  int n_captures;            /* B */
+  size_t max_samples;        /* per capture */
+  float omega;               /* samples per symbol, cstln_receiver::set_omega(Fs/Fm), leandvb.cc:482 */
+  int fec;                   /* LSDR_FEC12 … (deconvol_sync's rate, leandvb.cc:521-531) */
+  int anf;                   /* auto_notch slots: 1 = leandvb's default (leandvb.cc:103), 0 = `--anf 0` */
+  unsigned tile_len, tile_warmup;
+  float notch_k;             /* auto_notch::k (0: 0.002, sdr.h:56) */
+  int notch_decimation;      /* auto_notch::decimation in samples (0: 1024·4096, sdr.h:56) */
+} lsdr_capture_batch_cfg;
+typedef struct {
+  uint64_t ts_packets;       /* packets in the capture's TS buffer */
+  uint64_t rs_packets, rs_bit_errors;   /* rs_decoder: packets decoded, bits corrected (dvb.h:1007-1040) */
+  uint64_t symbols;          /* decisions the receiver produced */
+  uint64_t samples;          /* samples the receiver consumed */
+  uint64_t bytes_deconv, bytes_mpeg, first_lock_byte;
+  uint32_t next_sync_calls, locked, alignment, bitphase;     /* deconvol_sync::next_sync() calls; mpeg_sync locked at the end; alignment in force */
+  uint32_t tiles, seam_dup, seam_miss, seam_bad;             /* receiver seams: duplicates dropped, symbols re-inserted, unreconciled */
+} lsdr_capture_result;
+int lsdr_capture_batch_create(lsdr_ctx *ctx, const lsdr_capture_batch_cfg *cfg, lsdr_capture_batch **b);
+void lsdr_capture_batch_destroy(lsdr_capture_batch *b);
+/* iq_dev: HOST array of B DEVICE pointers to lsdr_cu8 items (16-byte aligned), n_samples each.  Queues everything; returns at once. */
+int lsdr_capture_batch_run_async(lsdr_capture_batch *b, const lsdr_cu8 *const *iq_dev, size_t n_samples);
+/* waits for the batch's kernels; results[B] (may be NULL) */
+int lsdr_capture_batch_wait(lsdr_capture_batch *b, lsdr_capture_result *results);
+/* after wait: copies every capture's TS (ts_packets·188 bytes) to ts_host[i] (pinned memory recommended) on a side stream */
+int lsdr_capture_batch_ts_download_async(lsdr_capture_batch *b, uint8_t *const *ts_host, size_t cap_bytes);
+int lsdr_capture_batch_ts_wait(lsdr_capture_batch *b);
+const uint8_t *lsdr_capture_batch_ts_dev(const lsdr_capture_batch *b, int i);          /* device buffer of capture i's TS */
+const uint32_t *lsdr_capture_batch_words_dev(const lsdr_capture_batch *b, int i);     /* its packed decisions (16 per word, MSB first) */
+const uint8_t *lsdr_capture_batch_bytes_dev(const lsdr_capture_batch *b, int i);      /* deconvol_sync's output, mpeg_sync's output */
+const uint8_t *lsdr_capture_batch_mpeg_dev(const lsdr_capture_batch *b, int i);
+/* the notch's detected bins of capture i after a run (tests): bins[0 … *n) */
+int lsdr_capture_batch_bins(lsdr_capture_batch *b, int i, int *bins, unsigned cap, unsigned *n);
+/* tests: the NOTCHED stream of capture i exactly as the tiles of the last run saw it — the same start state per tile (from the estimator
+ * pre-pass), the same interval switches, the same recurrence — written to device memory as n cf32 items (anf = 1 only; synchronous) */
+int lsdr_capture_batch_notched(lsdr_capture_batch *b, int i, lsdr_cf32 *out_dev, size_t n);
+/* HIP events around the tile kernel of every run while enabled: mean duration since the previous call, then sets the switch */
+int lsdr_capture_batch_tile_time(lsdr_capture_batch *b, int enable, float *avg_ms, unsigned *launches);
+
 #ifdef __cplusplus
 }
 #endif

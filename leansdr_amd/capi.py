@@ -256,6 +256,36 @@ _sig("lsdr_rx_get_snapshot", C.c_int, [vp, C.POINTER(RxState)])
 _sig("lsdr_rx_snapshot_async_slot", C.c_int, [vp, C.c_uint])
 _sig("lsdr_rx_get_snapshot_slot", C.c_int, [vp, C.c_uint, C.POINTER(RxState)])
 
+
+class CaptureBatchCfg(C.Structure):
+    _fields_ = [("n_captures", C.c_int), ("max_samples", C.c_size_t), ("omega", C.c_float), ("fec", C.c_int), ("anf", C.c_int),
+                ("tile_len", C.c_uint), ("tile_warmup", C.c_uint), ("notch_k", C.c_float), ("notch_decimation", C.c_int)]
+
+
+class CaptureResult(C.Structure):
+    _fields_ = [("ts_packets", C.c_uint64), ("rs_packets", C.c_uint64), ("rs_bit_errors", C.c_uint64), ("symbols", C.c_uint64),
+                ("samples", C.c_uint64), ("bytes_deconv", C.c_uint64), ("bytes_mpeg", C.c_uint64), ("first_lock_byte", C.c_uint64),
+                ("next_sync_calls", C.c_uint32), ("locked", C.c_uint32), ("alignment", C.c_uint32), ("bitphase", C.c_uint32),
+                ("tiles", C.c_uint32), ("seam_dup", C.c_uint32), ("seam_miss", C.c_uint32), ("seam_bad", C.c_uint32)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+_sig("lsdr_capture_batch_create", C.c_int, [vp, C.POINTER(CaptureBatchCfg), C.POINTER(vp)])
+_sig("lsdr_capture_batch_destroy", None, [vp])
+_sig("lsdr_capture_batch_run_async", C.c_int, [vp, vp, c_sz])
+_sig("lsdr_capture_batch_wait", C.c_int, [vp, vp])
+_sig("lsdr_capture_batch_ts_download_async", C.c_int, [vp, vp, c_sz])
+_sig("lsdr_capture_batch_ts_wait", C.c_int, [vp])
+_sig("lsdr_capture_batch_ts_dev", vp, [vp, C.c_int])
+_sig("lsdr_capture_batch_words_dev", vp, [vp, C.c_int])
+_sig("lsdr_capture_batch_bytes_dev", vp, [vp, C.c_int])
+_sig("lsdr_capture_batch_mpeg_dev", vp, [vp, C.c_int])
+_sig("lsdr_capture_batch_bins", C.c_int, [vp, C.c_int, vp, C.c_uint, C.POINTER(C.c_uint)])
+_sig("lsdr_capture_batch_notched", C.c_int, [vp, C.c_int, vp, c_sz])
+_sig("lsdr_capture_batch_tile_time", C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint)])
+
 #: every symbol include/lsdr_hip.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [n for n in dir(lib) if n.startswith("lsdr_")]
 
@@ -660,6 +690,91 @@ class RxBatch:
         st = RxState()
         check(lib.lsdr_rx_batch_get_state(self.h, stream, C.byref(st)))
         return st
+
+
+class CaptureBatch:
+    """lsdr_capture_batch: B independent cu8 captures, each from its first sample to TS (leandvb's default `--u8` graph per capture),
+    in shared launches with the counts on the device."""
+
+    def __init__(self, ctx, n_captures, max_samples, omega, fec=FEC12, anf=1, tile_len=0, tile_warmup=0, notch_k=0.0, notch_decimation=0):
+        self.ctx, self.n = ctx, int(n_captures)
+        cfg = CaptureBatchCfg()
+        cfg.n_captures, cfg.max_samples, cfg.omega, cfg.fec, cfg.anf = self.n, int(max_samples), omega, fec, anf
+        cfg.tile_len, cfg.tile_warmup, cfg.notch_k, cfg.notch_decimation = tile_len, tile_warmup, notch_k, notch_decimation
+        h = vp()
+        check(lib.lsdr_capture_batch_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self._res = (CaptureResult * self.n)()
+
+    def close(self):
+        if self.h:
+            lib.lsdr_capture_batch_destroy(self.h)
+            self.h = None
+
+    def run_async(self, iq_ptrs, n_samples):
+        ins = (vp * self.n)(*[p if isinstance(p, vp) else vp(p) for p in iq_ptrs])
+        check(lib.lsdr_capture_batch_run_async(self.h, ins, int(n_samples)))
+
+    def wait(self, results=True):
+        check(lib.lsdr_capture_batch_wait(self.h, self._res if results else None))
+        return [r.as_dict() for r in self._res] if results else None
+
+    def ts_download_async(self, host_ptrs, cap_bytes):
+        outs = (vp * self.n)(*[p if isinstance(p, vp) else vp(p) for p in host_ptrs])
+        check(lib.lsdr_capture_batch_ts_download_async(self.h, outs, int(cap_bytes)))
+
+    def ts_wait(self):
+        check(lib.lsdr_capture_batch_ts_wait(self.h))
+
+    def decode(self, iq_ptrs, n_samples):
+        """One batch, synchronously: (results, [TS bytes per capture])."""
+        self.run_async(iq_ptrs, n_samples)
+        res = self.wait()
+        out = []
+        for i, r in enumerate(res):
+            nb = r["ts_packets"] * 188
+            a = np.empty(nb, np.uint8)
+            if nb:
+                check(lib.lsdr_memcpy_d2h(self.ctx.h, _np(a), lib.lsdr_capture_batch_ts_dev(self.h, i), nb))
+            out.append(a)
+        self.ctx.sync()
+        return res, [a.tobytes() for a in out]
+
+    def words(self, i, nsym):
+        """The packed decisions of capture i after a run, unpacked (host)."""
+        nw = (int(nsym) + 15) // 16
+        w = np.empty(nw, np.uint32)
+        if nw:
+            check(lib.lsdr_memcpy_d2h(self.ctx.h, _np(w), lib.lsdr_capture_batch_words_dev(self.h, i), nw * 4))
+            self.ctx.sync()
+        return hs2_unpack(w, int(nsym))
+
+    def stage_bytes(self, i, which, n):
+        fn = lib.lsdr_capture_batch_bytes_dev if which == "deconv" else lib.lsdr_capture_batch_mpeg_dev
+        a = np.empty(int(n), np.uint8)
+        if n:
+            check(lib.lsdr_memcpy_d2h(self.ctx.h, _np(a), fn(self.h, i), int(n)))
+            self.ctx.sync()
+        return a
+
+    def bins(self, i, cap=4096):
+        b = (C.c_int * cap)()
+        n = C.c_uint()
+        check(lib.lsdr_capture_batch_bins(self.h, i, b, cap, C.byref(n)))
+        return list(b[:min(n.value, cap)])
+
+    def notched(self, i, n):
+        """The notched stream of capture i as the tiles of the last run saw it (test hook), n complex64 items."""
+        d = self.ctx.alloc(int(n) * 8)
+        check(lib.lsdr_capture_batch_notched(self.h, i, d.ptr, int(n)))
+        out = self.ctx.download(d, np.complex64, int(n))
+        d.free()
+        return out
+
+    def tile_time(self, enable):
+        ms, n = C.c_float(), C.c_uint()
+        check(lib.lsdr_capture_batch_tile_time(self.h, 1 if enable else 0, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
 
 def hs2_pack(symbols, offset=0):

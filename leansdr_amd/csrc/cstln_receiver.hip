@@ -1174,6 +1174,9 @@ __global__ __launch_bounds__(64) void k_rx_batch(rx_batch_args a) {
   a.produced[sidx] = nout;
 }
 
+#include "notch_detect.h"
+#include "rxb_device.h"
+
 }  // namespace
 
 struct lsdr_rx {
@@ -2140,3 +2143,5 @@ int lsdr_rx_batch_get_state(lsdr_rx_batch *b, unsigned stream, lsdr_rx_state *st
 }
 
 }  // extern "C"
+
+#include "rxb_host.h"

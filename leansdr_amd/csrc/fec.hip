@@ -98,65 +98,72 @@ __device__ __forceinline__ unsigned long long deconv_window(const deconv_dev &D,
   return w;
 }
 
+// byte k of a call's output (readbyte, dvb.h:386-394, for every bit of the byte)
+template <bool PACKED>
+__device__ __forceinline__ unsigned char deconv_byte(const deconv_dev &D, const deconv_plan &P, unsigned long long in0, unsigned long long out0,
+                                                     unsigned long long k) {
+  unsigned v = 0;
+  long long g = (long long)(8 * k) - P.n_out0;   // index into the refill bit stream (negative: carried bits)
+  unsigned long long q_cached = ~0ull, w = 0;
+  // refill index and bit position of the first refill bit of this byte: ONE division per thread, then counted along
+  const long long g0 = g < 0 ? 0 : g;
+  unsigned long long q = (unsigned long long)g0 / (unsigned)D.pp;
+  int r = (int)((unsigned long long)g0 - q * (unsigned)D.pp);
+  for (int b = 0; b < 8; ++b, ++g) {
+    unsigned bit;
+    if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;   // carried bits, MSB first
+    else {
+      const int bi = D.pp - 1 - r;
+      if (q != q_cached) {
+        if (q_cached != ~0ull && q == q_cached + 1) {   // slide by one refill
+          const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);
+          for (int s = D.pw / 2; s > 0; --s) w = (w << 2) | D.lut[deconv_sym<PACKED>(P, nsym - s)];
+        } else w = deconv_window<PACKED>(D, P, in0, q);
+        q_cached = q;
+      }
+      bit = (unsigned)par64(w & D.deconv[bi]);
+      if (++r == D.pp) { r = 0; ++q; }
+    }
+    v = (v << 1) | bit;
+  }
+  return (unsigned char)v;
+}
+// sync_t state after the call (dvb.h:297-306): the shift register and the bits still pending
+template <bool PACKED>
+__device__ __forceinline__ deconv_carry deconv_carry_after(const deconv_dev &D, const deconv_plan &P, unsigned long long in0, unsigned long long out0) {
+  deconv_carry c;
+  if (P.refills) {
+    c.in = deconv_window<PACKED>(D, P, in0, P.refills - 1);
+    const unsigned long long w = c.in;
+    // bits still pending come from the tail of the last refill(s); n_out_end < pp + 8: rebuilt exactly — they are the last
+    // n_out_end bits of the stream
+    unsigned long long o = 0;
+    for (int t = P.n_out_end; t > 0; --t) {
+      const long long g = (long long)(P.refills * (unsigned)D.pp) - t;   // refill-stream index
+      unsigned bit;
+      if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;
+      else {
+        const unsigned long long q = (unsigned long long)g / (unsigned)D.pp;
+        const int bi = D.pp - 1 - (int)((unsigned long long)g % (unsigned)D.pp);
+        const unsigned long long wq = q == P.refills - 1 ? w : deconv_window<PACKED>(D, P, in0, q);
+        bit = (unsigned)par64(wq & D.deconv[bi]);
+      }
+      o = (o << 1) | bit;
+    }
+    c.out = o;
+  } else {
+    c.in = in0;
+    c.out = out0;
+  }
+  return c;
+}
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
   const unsigned long long in0 = P.carry->in, out0 = P.carry->out;
   const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  if (k < P.n_bytes) {
-    unsigned v = 0;
-    long long g = (long long)(8 * k) - P.n_out0;   // index into the refill bit stream (negative: carried bits)
-    unsigned long long q_cached = ~0ull, w = 0;
-    // refill index and bit position of the first refill bit of this byte: ONE division per thread, then counted along
-    const long long g0 = g < 0 ? 0 : g;
-    unsigned long long q = (unsigned long long)g0 / (unsigned)D.pp;
-    int r = (int)((unsigned long long)g0 - q * (unsigned)D.pp);
-    for (int b = 0; b < 8; ++b, ++g) {
-      unsigned bit;
-      if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;   // carried bits, MSB first
-      else {
-        const int bi = D.pp - 1 - r;
-        if (q != q_cached) {
-          if (q_cached != ~0ull && q == q_cached + 1) {   // slide by one refill
-            const unsigned long long nsym = P.m0 + q * (unsigned)(D.pw / 2);
-            for (int s = D.pw / 2; s > 0; --s) w = (w << 2) | D.lut[deconv_sym<PACKED>(P, nsym - s)];
-          } else w = deconv_window<PACKED>(D, P, in0, q);
-          q_cached = q;
-        }
-        bit = (unsigned)par64(w & D.deconv[bi]);
-        if (++r == D.pp) { r = 0; ++q; }
-      }
-      v = (v << 1) | bit;
-    }
-    P.out[k] = (unsigned char)v;
-  }
-  if (k == 0) {   // state for the next call
-    deconv_carry c;
-    if (P.refills) {
-      c.in = deconv_window<PACKED>(D, P, in0, P.refills - 1);
-      unsigned long long o = out0;   // only the low n_out_end bits matter afterwards
-      const unsigned long long w = c.in;
-      // bits still pending come from the tail of the last refill(s); n_out_end < pp + 8
-      // rebuild the pending bits exactly: they are the last n_out_end bits of the stream
-      o = 0;
-      for (int t = P.n_out_end; t > 0; --t) {
-        const long long g = (long long)(P.refills * (unsigned)D.pp) - t;   // refill-stream index
-        unsigned bit;
-        if (g < 0) bit = (unsigned)(out0 >> (unsigned)(-g - 1)) & 1u;
-        else {
-          const unsigned long long q = (unsigned long long)g / (unsigned)D.pp;
-          const int bi = D.pp - 1 - (int)((unsigned long long)g % (unsigned)D.pp);
-          const unsigned long long wq = q == P.refills - 1 ? w : deconv_window<PACKED>(D, P, in0, q);
-          bit = (unsigned)par64(wq & D.deconv[bi]);
-        }
-        o = (o << 1) | bit;
-      }
-      c.out = o;
-    } else {
-      c.in = in0;
-      c.out = out0;
-    }
-    *P.carry_next = c;
-  }
+  if (k < P.n_bytes) P.out[k] = deconv_byte<PACKED>(D, P, in0, out0, k);
+  if (k == 0) *P.carry_next = deconv_carry_after<PACKED>(D, P, in0, out0);   // state for the next call
 }
 
 // fastlock (dvb.h:428-452 + readerrors, dvb.h:396-417): for every alignment, the number of refills whose bit b
@@ -279,15 +286,16 @@ __device__ bool msync_search(msync_state &S, const unsigned char *in, unsigned l
   return true;
 }
 
-// One mpeg_sync::run() call (dvb.h:743-754).
-__global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsigned char *in, unsigned long long n_in,
-                                                   unsigned char *out, unsigned long long cap, msync_result *gR) {
-  __shared__ msync_state S;
-  __shared__ msync_result R;
-  __shared__ unsigned long long pos, nout;
-  __shared__ int s_best, s_stop;
-  const int tid = threadIdx.x;
-  if (tid == 0) { S = *gS; R.consumed = R.produced = 0; R.n_events = 0; R.call_next_sync = 0; pos = 0; nout = 0; s_stop = 0; }
+// One mpeg_sync::run() call (dvb.h:743-754) by one workgroup of 256: M.S holds the block's state (thread 0 put it there), the call's
+// outcome is left in M.R (consumed / produced / events / call_next_sync) and the state in M.S.
+struct msync_sh { msync_state S; msync_result R; unsigned long long pos, nout; int s_best, s_stop; };
+__device__ void msync_run_body(msync_sh &M, const unsigned char *in, unsigned long long n_in, unsigned char *out, unsigned long long cap, int tid) {
+  msync_state &S = M.S;
+  msync_result &R = M.R;
+  unsigned long long &pos = M.pos, &nout = M.nout;
+  int &s_best = M.s_best, &s_stop = M.s_stop;
+  __syncthreads();
+  if (tid == 0) { R.consumed = R.produced = 0; R.n_events = 0; R.call_next_sync = 0; pos = 0; nout = 0; s_stop = 0; }
   __syncthreads();
   const int chunk = kRS * S.scan_syncs;
   if (S.synchronized) {   // run_decoding, dvb.h:842-875
@@ -370,7 +378,16 @@ __global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsign
     }
   }
   __syncthreads();
-  if (tid == 0) { R.consumed = pos; R.produced = nout; *gS = S; *gR = R; }
+  if (tid == 0) { R.consumed = pos; R.produced = nout; }
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_mpeg_sync(msync_state *gS, const unsigned char *in, unsigned long long n_in,
+                                                   unsigned char *out, unsigned long long cap, msync_result *gR) {
+  __shared__ msync_sh M;
+  const int tid = threadIdx.x;
+  if (tid == 0) M.S = *gS;
+  msync_run_body(M, in, n_in, out, cap, tid);
+  if (tid == 0) { *gS = M.S; *gR = M.R; }
 }
 
 // Locked path for long inputs (dvb.h:842-875), split so that the byte work runs on the whole chip: while locked, bit phase
@@ -549,31 +566,21 @@ __device__ __forceinline__ unsigned char rs_eval(const gf_tables &g, const unsig
 // One wavefront per packet, 4 packets per workgroup.  Clean packets (all syndromes zero) cost the parallel syndrome pass only;
 // corrupted ones: key equation on lane 0, Chien search + Forney (rs.h:245-264) spread over the lanes (root α^i ↔ lane i mod 64:
 // every root touches its own byte, so the corrections commute), then the syndromes of the corrected packet (rs.h:266-269).
-__global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned long long n_packets, unsigned char *out,
-                                                   const gf_tables *gtab, unsigned long long *counters /*[0] errs*/) {
-  __shared__ gf_tables g;
-  __shared__ unsigned char pk[4][kRS + 4], po[4][kTS + 4], synd[4][16];
-  __shared__ rs_key key[4];
-  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-  for (int i = tid; i < 512; i += 256) g.exp[i] = gtab->exp[i];
-  g.log[tid] = gtab->log[tid];
-  const unsigned long long p = (unsigned long long)blockIdx.x * 4 + wv;
-  const bool live = p < n_packets;
-  if (live)
-    for (int i = lane; i < kRS; i += 64) pk[wv][i] = in[p * kRS + i];
-  __syncthreads();
-  if (!live) return;                                   // (no workgroup barrier below: the rest is per wavefront)
+// one packet by one wavefront: pk / po / synd / key are THIS wavefront's LDS scratch, the packet is in pk already
+__device__ __forceinline__ void rs_decode_wave(const gf_tables &g, unsigned char *pk, unsigned char *po, unsigned char *synd, rs_key *key,
+                                               unsigned char *in, unsigned char *out, unsigned long long p, int lane,
+                                               unsigned long long *counters /*[0] errs*/) {
   unsigned s[4];
-  rs_syndromes(g, pk[wv], lane, s);
+  rs_syndromes(g, pk, lane, s);
   const bool corrupted = (s[0] | s[1] | s[2] | s[3]) != 0u;      // wave-uniform
   bool still_bad = false;
   if (corrupted) {
-    for (int i = lane; i < kTS; i += 64) po[wv][i] = pk[wv][i];   // the message is the first 188 bytes
-    if (lane < 16) synd[wv][lane] = (unsigned char)(s[lane >> 2] >> (8 * (lane & 3)));
+    for (int i = lane; i < kTS; i += 64) po[i] = pk[i];   // the message is the first 188 bytes
+    if (lane < 16) synd[lane] = (unsigned char)(s[lane >> 2] >> (8 * (lane & 3)));
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) rs_solve_key(g, synd[wv], &key[wv]);
+    if (lane == 0) rs_solve_key(g, synd, key);
     __builtin_amdgcn_wave_barrier();
-    const rs_key &K = key[wv];
+    const rs_key &K = *key;
     // Berlekamp-Massey can end with L = 16 (more errors than the code corrects); C[] and omega[] have 16 coefficients —
     // the reference evaluates degree L regardless and reads one byte past them (rs.h:247,258) — such packets stay
     // uncorrectable either way, so the evaluation is capped at the arrays' degree.
@@ -588,8 +595,8 @@ __global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned l
           const unsigned char den = rs_eval(g, K.Cprime, 14, i);
           const unsigned char e = gdiv(g, num, den);
           nerrs += __popc((unsigned)e);
-          if (loc >= 16) po[wv][kRS - 1 - loc] ^= e;
-          pk[wv][kRS - 1 - loc] ^= e;
+          if (loc >= 16) po[kRS - 1 - loc] ^= e;
+          pk[kRS - 1 - loc] ^= e;
         }
       }
     }
@@ -597,24 +604,44 @@ __global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned l
     for (int d = 32; d >= 1; d >>= 1) nerrs += __shfl_xor(nerrs, d, 64);
     if (lane == 0 && nerrs) atomicAdd(&counters[0], (unsigned long long)nerrs);
     __builtin_amdgcn_wave_barrier();
-    rs_syndromes(g, pk[wv], lane, s);                  // correct() returns syndromes(pin), rs.h:266-269
+    rs_syndromes(g, pk, lane, s);                  // correct() returns syndromes(pin), rs.h:266-269
     still_bad = (s[0] | s[1] | s[2] | s[3]) != 0u;
-    if (lane == 0 && still_bad) po[wv][0] ^= kCorrupt;   // dvb.h:1045
+    if (lane == 0 && still_bad) po[0] ^= kCorrupt;   // dvb.h:1045
     __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = po[wv][i];
-    for (int i = lane; i < kRS; i += 64) in[p * kRS + i] = pk[wv][i];   // in-place correction like the reference
+    for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = po[i];
+    for (int i = lane; i < kRS; i += 64) in[p * kRS + i] = pk[i];   // in-place correction like the reference
   } else {
-    for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = pk[wv][i];
+    for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = pk[i];
   }
+}
+
+// One wavefront per packet, 4 packets per workgroup.  Clean packets (all syndromes zero) cost the parallel syndrome pass only;
+// corrupted ones: key equation on lane 0, Chien search + Forney (rs.h:245-264) spread over the lanes (root α^i ↔ lane i mod 64:
+// every root touches its own byte, so the corrections commute), then the syndromes of the corrected packet (rs.h:266-269).
+__global__ __launch_bounds__(256) void k_rs_decode(unsigned char *in, unsigned long long n_packets, unsigned char *out,
+                                                   const gf_tables *gtab, unsigned long long *counters /*[0] errs*/) {
+  __shared__ gf_tables g;
+  __shared__ unsigned char pk[4][kRS + 4], po[4][kTS + 4], synd[4][16];
+  __shared__ rs_key key[4];
+  const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+  for (int i = tid; i < 512; i += 256) g.exp[i] = gtab->exp[i];
+  g.log[tid] = gtab->log[tid];
+  const unsigned long long p = (unsigned long long)blockIdx.x * 4 + wv;
+  const bool live = p < n_packets;
+  if (live)
+    for (int i = lane; i < kRS; i += 64) pk[wv][i] = in[p * kRS + i];
+  __syncthreads();
+  if (!live) return;                                   // (no workgroup barrier below: the rest is per wavefront)
+  rs_decode_wave(g, pk[wv], po[wv], synd[wv], &key[wv], in, out, p, lane, counters);
 }
 
 // ======================================================================== derandomizer
 struct derand_result { unsigned long long produced; int pos_end; };
 
 // Single workgroup: per-packet PRBS offset (resets at 0xB8 / 0xB8^0x55), keep flags, output slots.
-__global__ __launch_bounds__(1024) void k_derand_scan(const unsigned char *in, unsigned n_packets, int pos0,
-                                                      const unsigned char *pattern, int *pkt_pos, long long *pkt_dst,
-                                                      derand_result *res) {
+__device__ __forceinline__ void derand_scan_body(const unsigned char *in, unsigned n_packets, int pos0,
+                                                 const unsigned char *pattern, int *pkt_pos, long long *pkt_dst,
+                                                 derand_result *res) {
   constexpr unsigned SEG = 8192, PER = 8;
   __shared__ int s_last[16];       // per wave: index of the last reset (-1: none)
   __shared__ unsigned s_cnt[16];
@@ -701,6 +728,11 @@ __global__ __launch_bounds__(1024) void k_derand_scan(const unsigned char *in, u
     res->pos_end = (int)pe;
   }
 }
+__global__ __launch_bounds__(1024) void k_derand_scan(const unsigned char *in, unsigned n_packets, int pos0,
+                                                      const unsigned char *pattern, int *pkt_pos, long long *pkt_dst,
+                                                      derand_result *res) {
+  derand_scan_body(in, n_packets, pos0, pattern, pkt_pos, pkt_dst, res);
+}
 
 __global__ __launch_bounds__(256) void k_derand_apply(const unsigned char *in, unsigned n_packets, const unsigned char *pattern,
                                                       const int *pkt_pos, const long long *pkt_dst, unsigned char *out) {
@@ -713,6 +745,8 @@ __global__ __launch_bounds__(256) void k_derand_apply(const unsigned char *in, u
   for (unsigned i = lane; i < (unsigned)kTS; i += 64)
     out[(unsigned long long)dst * kTS + i] = in[(unsigned long long)p * kTS + i] ^ pattern[pos + i];
 }
+
+#include "tail_device.h"
 
 }  // namespace
 
@@ -1250,3 +1284,5 @@ int lsdr_derandomizer_run(lsdr_derandomizer *d, const uint8_t *in, size_t n, uin
 }
 
 }  // extern "C"
+
+#include "tail_host.h"

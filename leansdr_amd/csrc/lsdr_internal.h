@@ -85,6 +85,38 @@ int lsdr_stage_sync(lsdr_ctx *c);
 int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf32 *out, size_t count, unsigned align_n, unsigned D, unsigned nq,
                               const float *iv_tabs, const unsigned *iv_tile_first, unsigned n_iv, int wpc, unsigned *outputs_per_tile, hipStream_t stream = nullptr);
 
+// ---- capture batch (capture_batch.hip): its two halves
+// cstln_receiver.hip (rxb_host.h): the front end — auto_notch + cstln_receiver of every capture in shared launches, packed decisions out
+struct lsdr_rxb;
+int lsdr_rxb_create(lsdr_ctx *c, const lsdr_capture_batch_cfg *cfg, lsdr_rxb **out);
+void lsdr_rxb_destroy(lsdr_rxb *b);
+int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t *consumed);
+const uint32_t *lsdr_rxb_words(const lsdr_rxb *b, unsigned i);
+size_t lsdr_rxb_words_cap(const lsdr_rxb *b);
+const void *lsdr_rxb_results_dev(const lsdr_rxb *b, size_t *stride);
+unsigned lsdr_rxb_tiles(const lsdr_rxb *b);
+unsigned lsdr_rxb_detects(const lsdr_rxb *b);
+int lsdr_rxb_bins(lsdr_rxb *b, unsigned i, int *bins, unsigned cap, unsigned *n);
+int lsdr_rxb_seam_stats(lsdr_rxb *b, unsigned i, unsigned long long *total, unsigned *dup, unsigned *miss, unsigned *bad);
+int lsdr_rxb_tile_time(lsdr_rxb *b, int enable, float *avg_ms, unsigned *launches);
+int lsdr_rxb_notched(lsdr_rxb *b, unsigned i, lsdr_cf32 *out_dev, size_t n);
+// fec.hip (tail_host.h): the FEC tail of every capture, counts on the device
+struct lsdr_tail;
+struct lsdr_tail_result {          // = tail_device.h's tail_result
+  unsigned long long n_ts, n_rs, rs_bit_errors, symbols, bytes_deconv, bytes_mpeg;
+  unsigned next_sync_calls, locked_at_end, alignment, bitphase;
+  unsigned long long first_lock_byte;
+};
+int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, lsdr_tail **out);
+void lsdr_tail_destroy(lsdr_tail *t);
+int lsdr_tail_bind(lsdr_tail *t, const uint32_t *const *words, const void *counts_dev, size_t count_stride);
+int lsdr_tail_launch(lsdr_tail *t, hipEvent_t before_ts);
+const lsdr_tail_result *lsdr_tail_results(const lsdr_tail *t);
+const uint8_t *lsdr_tail_ts_dev(const lsdr_tail *t, unsigned i);
+size_t lsdr_tail_ts_cap(const lsdr_tail *t);
+const uint8_t *lsdr_tail_bytes_dev(const lsdr_tail *t, unsigned i);
+const uint8_t *lsdr_tail_mpeg_dev(const lsdr_tail *t, unsigned i);
+
 // Host-side table builders (host_tables.cpp)
 namespace lsdr {
 void fir_shift_coeffs(unsigned ncoeffs, const float *coeffs, float freq, lsdr_cf32 *shifted);

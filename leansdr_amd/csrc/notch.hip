@@ -14,6 +14,7 @@
 #include "lsdr_internal.h"
 
 namespace {
+#include "notch_detect.h"
 
 constexpr int kN = 4096;          // fft.n of auto_notch (sdr.h:55)
 constexpr int kMaxSlots = 8;
@@ -230,12 +231,8 @@ static int cfft_dev_init(cfft_dev *f, int n, bool reverse) {
   (void)hipFree(f->d_om); (void)hipFree(f->d_out);
   f->n = n; f->reverse = reverse; f->logn = 0;
   for (int t = n; t > 1; t >>= 1) ++f->logn;
-  std::vector<float2> om(n);
-  for (int i = 0; i < n; ++i) {
-    float a = (float)(2.0 * M_PI * i / n);
-    om[i].x = cosf(a);
-    om[i].y = reverse ? -sinf(a) : sinf(a);
-  }
+  std::vector<float2> om;
+  notch_detect_twiddles(n, reverse, om);
   LSDR_HIP(hipMalloc((void **)&f->d_om, (size_t)n * sizeof(float2)));
   LSDR_HIP(hipMalloc((void **)&f->d_out, (size_t)n * sizeof(float2)));
   LSDR_HIP(hipMemcpy(f->d_om, om.data(), (size_t)n * sizeof(float2), hipMemcpyHostToDevice));
@@ -487,24 +484,7 @@ __global__ __launch_bounds__(64) void k_notch_args(notch_run_args r, int *d_ifir
 // half; the last stage (position p with p + 2048, twiddle om[p]) is done by k_notch_peaks on the fly.  Same butterflies, each
 // evaluated once with the same expression: bit-identical to k_cfft.
 __device__ __forceinline__ void cfft_half_body(const float2 *src, const float2 *om, float2 *halves /*[ndet][2][2048]*/) {
-  __shared__ float2 d[kN / 2];
-  const int h = blockIdx.x & 1, tid = threadIdx.x;
-  for (int p = tid; p < kN / 2; p += 256) d[p] = src[__brev((unsigned)(h * (kN / 2) + p)) >> 20];   // position P holds in[brev12(P)]
-  __syncthreads();
-  for (int st = 0; st < 11; ++st) {
-    const int hbs = 1 << st, dom = 1 << (11 - st);
-    for (int b = tid; b < kN / 4; b += 256) {
-      const int j = b >> st, k = b & (hbs - 1);
-      const int p = j * hbs * 2 + k, q = p + hbs;
-      const float2 w = om[k * dom], dd = d[q], dp = d[p];
-      const float xr = w.x * dd.x - w.y * dd.y;
-      const float xi = w.x * dd.y + w.y * dd.x;
-      d[q] = make_float2(dp.x - xr, dp.y - xi);
-      d[p] = make_float2(dp.x + xr, dp.y + xi);
-    }
-    __syncthreads();
-  }
-  for (int p = tid; p < kN / 2; p += 256) halves[(size_t)blockIdx.x * (kN / 2) + p] = d[p];
+  cfft_half_body_t([&](unsigned i) { return src[i]; }, om, halves, blockIdx.x);     // notch_detect.h
 }
 __global__ __launch_bounds__(256) void k_cfft_half(const float2 *in, const float2 *om, float2 *halves /*[ndet][2][2048]*/,
                                                    const unsigned long long *in_offsets) {
@@ -513,39 +493,7 @@ __global__ __launch_bounds__(256) void k_cfft_half(const float2 *in, const float
 
 __global__ __launch_bounds__(256) void k_notch_peaks(const float2 *halves, const float2 *om, float invn, int nslots,
                                                      int *cand /*[ndet][kMaxSlots]*/) {
-  __shared__ float amp[kN];
-  __shared__ float s_v[256];
-  __shared__ int s_i[256];
-  const float2 *he = halves + (size_t)blockIdx.x * kN, *ho = he + kN / 2;
-  for (int k = threadIdx.x; k < kN / 2; k += 256) {   // last radix-2 stage + the reverse transform's 1/n + |.|
-    const float2 w = om[k], dd = ho[k], dp = he[k];
-    const float xr = w.x * dd.x - w.y * dd.y;
-    const float xi = w.x * dd.y + w.y * dd.x;
-    amp[k + kN / 2] = hypotf((dp.x - xr) * invn, (dp.y - xi) * invn);
-    amp[k] = hypotf((dp.x + xr) * invn, (dp.y + xi) * invn);
-  }
-  __syncthreads();
-  for (int s = 0; s < nslots; ++s) {
-    float bv = -1.f; int bi = 0;
-    for (int i = threadIdx.x; i < kN; i += 256) if (amp[i] > bv) { bv = amp[i]; bi = i; }     // ascending i per lane: first max kept
-    s_v[threadIdx.x] = bv; s_i[threadIdx.x] = bi;
-    __syncthreads();
-    for (int d = 128; d >= 1; d >>= 1) {
-      if ((int)threadIdx.x < d) {
-        const float ov = s_v[threadIdx.x + d]; const int oi = s_i[threadIdx.x + d];
-        if (ov > s_v[threadIdx.x] || (ov == s_v[threadIdx.x] && oi < s_i[threadIdx.x])) { s_v[threadIdx.x] = ov; s_i[threadIdx.x] = oi; }
-      }
-      __syncthreads();
-    }
-    const int im = s_i[0];
-    if (threadIdx.x == 0) {
-      cand[blockIdx.x * kMaxSlots + s] = im;
-      amp[im] = 0;
-      if (im - 1 >= 0) amp[im - 1] = 0;
-      if (im + 1 < kN) amp[im + 1] = 0;
-    }
-    __syncthreads();
-  }
+  notch_peaks_body(halves, om, invn, nslots, cand, blockIdx.x);                      // notch_detect.h
 }
 
 // Interval q+1 of a run starts at detect point q with the slots' new bins (sdr.h:94-118): slot s of interval q uses

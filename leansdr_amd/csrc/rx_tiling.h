@@ -276,8 +276,8 @@ __device__ __forceinline__ unsigned hs2_fetch16(const unsigned *col, unsigned lo
   return sh ? (a << sh) | (b >> (32 - sh)) : a;
 }
 
-__global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
-                                                          int R, float quad, rx_seam_part *part, const uint8_t *relabel) {
+__device__ __forceinline__ void rx_seam_h_body(const rx_tile_info_h *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                               int R, float quad, rx_seam_part *part, const uint8_t *relabel) {
   const unsigned rmask = (unsigned)R - 1;
   const unsigned j = blockIdx.x * kSeamBlock + threadIdx.x;
   long long add = 0;
@@ -296,6 +296,10 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *
   }
   seam_block_scan(add, k, ins, drp, bad, j, n_tiles, rmask, fix, part);
 }
+__global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *info, rx_tile_fix *fix, unsigned n_tiles, float omega,
+                                                          int R, float quad, rx_seam_part *part, const uint8_t *relabel) {
+  rx_seam_h_body(info, fix, n_tiles, omega, R, quad, part, relabel);
+}
 
 // Compaction of the packed tile columns: one LANE per tile (64 consecutive tiles per wavefront: the transposed staging is
 // read coalesced) walks the output words that START inside its tile's symbol range [D, D + len) — word by word, so the lines
@@ -303,10 +307,10 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *
 // the later one, which takes the earlier tile's last symbols from that tile's column (no atomics, no pre-zeroing); the symbols
 // before out_sym_offset in the first word (a caller's leftover symbols) are preserved.
 template <typename STATE>
-__global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, unsigned long long pitch, const rx_tile_info_h *info,
-                                                     const rx_tile_fix *fix, const rx_seam_part *part, const uint8_t *relabel,
-                                                     unsigned n_tiles, int R, float quad, unsigned *out, unsigned long long out_sym_offset,
-                                                     STATE *state, rx_seam_result *res) {
+__device__ __forceinline__ void rx_compact_h_body(const unsigned *hstage, unsigned long long pitch, const rx_tile_info_h *info,
+                                                  const rx_tile_fix *fix, const rx_seam_part *part, const uint8_t *relabel,
+                                                  unsigned n_tiles, int R, float quad, unsigned *out, unsigned long long out_sym_offset,
+                                                  STATE *state, rx_seam_result *res) {
   const unsigned j = blockIdx.x * 64u + threadIdx.x;
   const unsigned rmask = (unsigned)R - 1;
   const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock;
@@ -375,6 +379,13 @@ __global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, uns
     }
     out[m] = word;
   }
+}
+template <typename STATE>
+__global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, unsigned long long pitch, const rx_tile_info_h *info,
+                                                     const rx_tile_fix *fix, const rx_seam_part *part, const uint8_t *relabel,
+                                                     unsigned n_tiles, int R, float quad, unsigned *out, unsigned long long out_sym_offset,
+                                                     STATE *state, rx_seam_result *res) {
+  rx_compact_h_body<STATE>(hstage, pitch, info, fix, part, relabel, n_tiles, R, quad, out, out_sym_offset, state, res);
 }
 
 #endif  // LSDR_RX_TILING_H

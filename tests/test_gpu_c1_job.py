@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def test_c1_job_decodes_every_capture_to_the_reference_ts(capi, tile, warm):
     sys.path.insert(0, ROOT)
     import bench_c1
-    job = bench_c1.C1Job(capi, 0, 3, 6, 2, tile, warm, seed0=4000)
+    job = bench_c1.ChainJob(capi, 0, 3, 6, 2, tile, warm, seed0=4000)        # (the round-6 engine: tests/test_gpu_capture_batch.py)
     try:
         job.run(1)
         consumed = job.run(2, timed=True)
