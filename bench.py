@@ -704,12 +704,16 @@ def compact_line(out):
     cfg = out.get("config") or {}
     line["config"] = {k: (_short(v, 200) if k == "workload" else _short(v, 60)) for k, v in cfg.items()
                       if k in ("workload", "fir_arith", "batches_per_step", "batch_samples_per_capture", "captures_per_gpu", "samples_per_step_per_gpu",
-                               "rx_mode", "rx_tile", "parallelism", "symbols_per_step", "c1_captures", "capture_samples")}
+                               "rx_mode", "rx_tile", "parallelism", "symbols_per_step", "c1_captures", "capture_samples", "engine")}
     r = out.get("roofline")
     if isinstance(r, dict):
         line["roofline"] = {k: _short(r[k], 80) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ceiling", "frac_of_ceiling", "traffic",
                                                           "traffic_source", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
                                                           "algorithmic_bytes_per_sample") if k in r}
+        if isinstance(r.get("valu_issue"), dict):      # c1: the bound that applies to the receiver's tiles (vector-instruction issue)
+            vi = r["valu_issue"]
+            line["roofline"]["valu_issue"] = {k: vi[k] for k in ("valu_instructions_per_symbol_step", "wave_instructions_per_launch", "peak_wave_instructions_per_s",
+                                                                 "achieved_wave_instructions_per_s", "frac", "whole_job_frac") if k in vi}
     c = out.get("cpu_baseline")
     if isinstance(c, dict):
         line["cpu_baseline"] = {k: _short(c[k], 230) for k in ("value", "unit", "cores", "kind", "one_core", "sample") if k in c}
@@ -778,12 +782,14 @@ def main():
     ap.add_argument("--workload", choices=["c2", "c1"], default="c2",
                     help="c2: BASELINE config 2 (the headline: cf32 at 120 sps, fir_filter + receiver); c1: BASELINE config 1 / 4 — independent "
                          "cu8 captures at 1.2 sps decoded to TS (bench_c1.py); with --gpus N that is config 4 (captures sharded over the GPUs)")
-    ap.add_argument("--c1-captures", type=int, default=16, help="c1: independent captures resident per GPU (each decoded once per step)")
+    ap.add_argument("--c1-captures", type=int, default=32, help="c1: independent captures resident per GPU (each decoded once per step)")
     ap.add_argument("--c1-msamples", type=int, default=128, help="c1: Mi samples per capture")
     ap.add_argument("--c1-workers", type=int, default=16, help="c1 --c1-mode chain: host threads / HIP streams decoding captures concurrently per GPU")
+    ap.add_argument("--no-single", action="store_true", help="c1: skip the one-capture-per-GPU latency figure")
     ap.add_argument("--c1-mode", choices=["batch", "chain"], default="batch",
                     help="c1: batch = lsdr_capture_batch (shared launches, counts on the device, one host thread); chain = the C-ABI blocks one by one (rounds 2-5)")
     ap.add_argument("--c1-groups", type=int, default=2, help="c1 batch: capture groups per GPU (one lsdr_capture_batch + stream each)")
+    ap.add_argument("--c1-aux-cus", type=int, default=0, help="c1 batch: compute units reserved for everything but the receiver's tiles (lsdr_capture_batch_cfg::aux_cus; 0: no partition)")
     ap.add_argument("--c1-anf", type=int, default=1, help="c1 batch: auto_notch slots (1 = leandvb's default, 0 = --anf 0)")
     ap.add_argument("--c1-tile", type=int, default=0, help="c1: receiver tile length in samples (0: 4096 batch / 2048 chain)")
     ap.add_argument("--c1-warmup", type=int, default=512)

@@ -41,7 +41,7 @@ OMEGA = float(np.float32(FS / FM))
 ALG_BYTES_PER_SAMPLE = 2.0 + 188.0 / (204 * 8 * 1.2)       # cu8 in + TS out = 2.096
 # vector instructions k_rxb_tiles issues per symbol step and lane [without, with the notch]: counted from the kernel's ISA (the symbol
 # loop of `llvm-objdump -d`), confirmed by SQ_INSTS_VALU (profiles/r06_bench/c1_pmc_sq.txt); LSDR_C1_VALU_PER_SYMBOL overrides
-VALU_PER_SYMBOL_STEP = (96.0, 116.0)
+VALU_PER_SYMBOL_STEP = (92.2, 112.7)
 REFBIN = os.path.join(ROOT, "oracle", "_ref", "leandvb")
 REF_ARGS_BASE = ["--u8", "-f", "2400e3", "--sr", "2000e3", "--cr", "1/2"]       # the README example: everything else at its default (--anf 1)
 REF_ARGS = REF_ARGS_BASE + ["--anf", "0"]                                          # the variant rounds 2-5 measured
@@ -429,8 +429,9 @@ class ChainJob(JobBase):
 class C1Job(ChainJob):
     """Round 6: lsdr_capture_batch — the captures of a group share every launch, counts stay on the device, one host thread."""
 
-    def __init__(self, capi, device, n_captures, msamples, groups, tile, warm, seed0, anf=1):
+    def __init__(self, capi, device, n_captures, msamples, groups, tile, warm, seed0, anf=1, aux_cus=0):
         self.anf = 1 if anf else 0
+        self.aux_cus = int(aux_cus)
         # auto_notch moves whole 4096-sample blocks: a capture of whole blocks is consumed entirely (but for the receiver's last chunk)
         n = (msamples << 20) if self.anf else (msamples << 20) // 128 * 128 + 1
         self._make_captures(capi, device, n_captures, n, seed0)
@@ -442,7 +443,7 @@ class C1Job(ChainJob):
             if not ks:
                 continue
             gctx = capi.Ctx(device)
-            cb = capi.CaptureBatch(gctx, len(ks), self.n, OMEGA, fec=capi.FEC12, anf=self.anf, tile_len=tile, tile_warmup=warm)
+            cb = capi.CaptureBatch(gctx, len(ks), self.n, OMEGA, fec=capi.FEC12, anf=self.anf, tile_len=tile, tile_warmup=warm, aux_cus=self.aux_cus)
             self.groups.append(dict(ctx=gctx, cb=cb, ks=ks, in_flight=False, ptrs=[self.caps[k].ptr for k in ks]))
         pk_cap = int(self.n / OMEGA / 8 / 204) + 512
         self._make_ts_buffers(pk_cap * 188)
@@ -538,7 +539,8 @@ def run_workload(capi, device, args, shard):
     if mode == "chain":
         job = ChainJob(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile or 2048, args.c1_warmup, seed0=seed0)
     else:
-        job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_groups, args.c1_tile or 4096, args.c1_warmup, seed0=seed0, anf=anf)
+        job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_groups, args.c1_tile or 4096, args.c1_warmup, seed0=seed0, anf=anf,
+                    aux_cus=getattr(args, "c1_aux_cus", 0))
     job.run(max(1, args.warmup))
     shard.barrier()
     t0 = time.perf_counter()

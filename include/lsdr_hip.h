@@ -599,7 +599,7 @@ int lsdr_drifter_run(lsdr_drifter *d, const lsdr_cf32 *in, size_t n, lsdr_cf32 *
  *    S[n] = p·S[n−1] + k·x[n], out = x − S, p = (1−k)·exp(j2π·bin/4096) — float32 with exact phases (lsdr_notch_fir's tolerance class);
  *    detect() (sdr.h:76-118) is the reference's FFT bit for bit, at the reference's detect points, on the device.  auto_notch moves
  *    whole 4096-sample blocks: with anf = 1 a capture's last n mod 4096 samples are not demodulated (as in the reference).
- *  * FEC tail: the bit-exact blocks of this ABI, driven on the device the way a scheduler with 64 KiB byte pipes drives them while
+ *  * FEC tail: the bit-exact blocks of this ABI, driven on the device the way a scheduler with `unlocked_window`-byte pipes drives them while
  *    mpeg_sync is unlocked (next_sync() included), then in one call each (leansdr_amd/csrc/tail_device.h).
  * anf ∈ {0, 1}; omega = Fs/Fm ∈ [1, 8]; tile_len a multiple of 2048 (0: 4096), tile_warmup a multiple of 128 (0: 512).
  * One batch in flight per object: run_async → wait → [ts_download_async → ts_wait]; the NEXT run_async may be queued while the
@@ -615,6 +615,15 @@ typedef struct {
   unsigned tile_len, tile_warmup;
   float notch_k;             /* auto_notch::k (0: 0.002, sdr.h:56) */
   int notch_decimation;      /* auto_notch::decimation in samples (0: 1024·4096, sdr.h:56) */
+  unsigned unlocked_window;  /* bytes deconvol_sync hands mpeg_sync per call while mpeg_sync is not locked = the byte pipe between them
+                              * (0: 8192 = leandvb's BUF_BYTES at its default --buf-factor 4, leandvb.cc:194); decides how far the
+                              * deconvolver runs ahead of a next_sync() */
+  unsigned aux_cus;          /* 0: every kernel on the context's stream.  N (a multiple of 8, < the device's CUs): the object runs on two
+                              * streams of its own with disjoint compute-unit masks — the receiver's TILES (vector-issue-bound, they fill
+                              * every wave slot they can get for milliseconds) on all CUs but N, everything else (the notch's detect chain
+                              * and estimator pre-pass, seam pass, compaction, the whole FEC tail: memory-bound kernels) on N/8 CUs of
+                              * every XCD, handed over by events.  Several objects made with the same N share the two partitions: one
+                              * batch's tail then runs beside another's tiles instead of waiting for their wave slots. */
 } lsdr_capture_batch_cfg;
 typedef struct {
   uint64_t ts_packets;       /* packets in the capture's TS buffer */

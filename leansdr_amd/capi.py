@@ -259,7 +259,8 @@ _sig("lsdr_rx_get_snapshot_slot", C.c_int, [vp, C.c_uint, C.POINTER(RxState)])
 
 class CaptureBatchCfg(C.Structure):
     _fields_ = [("n_captures", C.c_int), ("max_samples", C.c_size_t), ("omega", C.c_float), ("fec", C.c_int), ("anf", C.c_int),
-                ("tile_len", C.c_uint), ("tile_warmup", C.c_uint), ("notch_k", C.c_float), ("notch_decimation", C.c_int)]
+                ("tile_len", C.c_uint), ("tile_warmup", C.c_uint), ("notch_k", C.c_float), ("notch_decimation", C.c_int),
+                ("unlocked_window", C.c_uint), ("aux_cus", C.c_uint)]
 
 
 class CaptureResult(C.Structure):
@@ -696,11 +697,15 @@ class CaptureBatch:
     """lsdr_capture_batch: B independent cu8 captures, each from its first sample to TS (leandvb's default `--u8` graph per capture),
     in shared launches with the counts on the device."""
 
-    def __init__(self, ctx, n_captures, max_samples, omega, fec=FEC12, anf=1, tile_len=0, tile_warmup=0, notch_k=0.0, notch_decimation=0):
+    def __init__(self, ctx, n_captures, max_samples, omega, fec=FEC12, anf=1, tile_len=0, tile_warmup=0, notch_k=0.0, notch_decimation=0,
+                 unlocked_window=0, aux_cus=0):
         self.ctx, self.n = ctx, int(n_captures)
         cfg = CaptureBatchCfg()
         cfg.n_captures, cfg.max_samples, cfg.omega, cfg.fec, cfg.anf = self.n, int(max_samples), omega, fec, anf
         cfg.tile_len, cfg.tile_warmup, cfg.notch_k, cfg.notch_decimation = tile_len, tile_warmup, notch_k, notch_decimation
+        cfg.unlocked_window = unlocked_window
+        cfg.aux_cus = aux_cus
+        self.unlocked_window = unlocked_window or 8192
         h = vp()
         check(lib.lsdr_capture_batch_create(ctx.h, C.byref(cfg), C.byref(h)))
         self.h = h

@@ -6,7 +6,9 @@
 #include "lsdr_internal.h"
 
 struct lsdr_capture_batch {
-  lsdr_ctx *ctx;
+  lsdr_ctx *ctx;                   // the context the front end's tiles run on: the caller's, or (aux_cus) an own one on the tile partition
+  lsdr_ctx *ctx_aux;               // aux_cus: the own context of the auxiliary partition (null: everything on ctx)
+  lsdr_ctx *own_main;              // aux_cus: ctx is ours
   lsdr_capture_batch_cfg cfg;
   lsdr_rxb *rx;
   lsdr_tail *tail;
@@ -22,21 +24,39 @@ extern "C" {
 void lsdr_capture_batch_destroy(lsdr_capture_batch *b) {
   if (!b) return;
   if (b->dl) { (void)hipStreamSynchronize(b->dl); }
-  (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->ctx) (void)hipStreamSynchronize(b->ctx->stream);
+  if (b->ctx_aux) (void)hipStreamSynchronize(b->ctx_aux->stream);
   lsdr_tail_destroy(b->tail);
   lsdr_rxb_destroy(b->rx);
+  if (b->ctx_aux) lsdr_ctx_destroy(b->ctx_aux);
+  if (b->own_main) lsdr_ctx_destroy(b->own_main);
   if (b->ev_done) (void)hipEventDestroy(b->ev_done);
   if (b->ev_dl) (void)hipEventDestroy(b->ev_dl);
   if (b->dl) (void)hipStreamDestroy(b->dl);
   delete b;
 }
 
+// compute-unit masks of the two partitions: mask bit i = CU i % 32 of XCD i / 32 (8 XCDs of 32 CUs); the auxiliary partition takes the
+// first aux/8 CUs of every XCD, the tiles the rest
+static int capture_batch_partition(lsdr_capture_batch *b, lsdr_ctx *caller) {
+  const unsigned aux = b->cfg.aux_cus, ncu = (unsigned)caller->num_cu;
+  if (aux % 8 || aux >= ncu || ncu % 8 || ncu > 1024) { lsdr_set_error("capture_batch: aux_cus must be a multiple of 8 below the device's %u CUs (got %u)", ncu, aux); return LSDR_E_ARG; }
+  const unsigned per = ncu / 8, words = (ncu + 31) / 32;
+  std::vector<uint32_t> m_aux(words, 0u), m_main(words, 0u);
+  for (unsigned i = 0; i < ncu; ++i) ((i % per) < aux / 8 ? m_aux : m_main)[i / 32] |= 1u << (i % 32);
+  LSDR_TRY(lsdr_ctx_create_masked(caller->device, m_main.data(), words, &b->own_main));
+  LSDR_TRY(lsdr_ctx_create_masked(caller->device, m_aux.data(), words, &b->ctx_aux));
+  b->ctx = b->own_main;
+  return LSDR_OK;
+}
+
 static int capture_batch_build(lsdr_capture_batch *b) {
+  LSDR_HIP(hipSetDevice(b->ctx->device));
+  if (b->cfg.aux_cus) LSDR_TRY(capture_batch_partition(b, b->ctx));
   lsdr_ctx *c = b->ctx;
-  LSDR_HIP(hipSetDevice(c->device));
   LSDR_TRY(lsdr_rxb_create(c, &b->cfg, &b->rx));
   const size_t sym_cap = lsdr_rxb_words_cap(b->rx) * 16;
-  LSDR_TRY(lsdr_tail_create(c, (unsigned)b->cfg.n_captures, sym_cap, b->cfg.fec, &b->tail));
+  LSDR_TRY(lsdr_tail_create(b->ctx_aux ? b->ctx_aux : c, (unsigned)b->cfg.n_captures, sym_cap, b->cfg.fec, b->cfg.unlocked_window ? b->cfg.unlocked_window : 8192u, &b->tail));
   std::vector<const uint32_t *> words(b->cfg.n_captures);
   for (int i = 0; i < b->cfg.n_captures; ++i) words[i] = lsdr_rxb_words(b->rx, (unsigned)i);
   size_t stride = 0;
@@ -62,9 +82,9 @@ int lsdr_capture_batch_create(lsdr_ctx *c, const lsdr_capture_batch_cfg *cfg, ls
 int lsdr_capture_batch_run_async(lsdr_capture_batch *b, const lsdr_cu8 *const *iq_dev, size_t n_samples) {
   LSDR_ARG(b && iq_dev);
   if (b->in_flight) { lsdr_set_error("capture_batch: a batch is in flight (lsdr_capture_batch_wait first)"); return LSDR_E_ARG; }
-  LSDR_TRY(lsdr_rxb_launch(b->rx, reinterpret_cast<const void *const *>(iq_dev), n_samples, &b->consumed));
+  LSDR_TRY(lsdr_rxb_launch(b->rx, reinterpret_cast<const void *const *>(iq_dev), n_samples, &b->consumed, b->ctx_aux ? b->ctx_aux->stream : nullptr));
   LSDR_TRY(lsdr_tail_launch(b->tail, b->dl_pending ? b->ev_dl : nullptr));
-  LSDR_HIP(hipEventRecord(b->ev_done, b->ctx->stream));
+  LSDR_HIP(hipEventRecord(b->ev_done, (b->ctx_aux ? b->ctx_aux : b->ctx)->stream));
   b->in_flight = true; b->waited = false;
   return LSDR_OK;
 }

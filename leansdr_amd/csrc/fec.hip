@@ -158,12 +158,110 @@ __device__ __forceinline__ deconv_carry deconv_carry_after(const deconv_dev &D, 
   return c;
 }
 
+// ---- rate 1/2 on packed symbols, 32 output bits at a time ----------------------------------------------------------------------
+// pp = 1, pw = 2 (dvb.h:480-484): every refill shifts ONE symbol in and emits ONE bit, bit = parity(window & deconv[0]) with the
+// newest symbol in the window's low bits (dvb.h:378-394) — and the inverse polynomial of the DVB-S code is short (0x3ba: the last five
+// symbols).  So 32 consecutive output bits are a bit-parallel expression of the mapped I/Q bit stream X (newest symbol of the LAST of
+// the 32 bits at X[1:0]):  Y = XOR over the set bits j of deconv[0] of (X >> j),  bit t (t = 0 oldest) = Y[2·(31 − t)].
+// Same bits as deconv_byte (tests/test_gpu_fec.py compares the two paths); used where every symbol the 32 bits need belongs to this call.
+__device__ __forceinline__ unsigned deconv_map16(unsigned x, unsigned map4) {      // the alignment's symbol → I/Q map on 16 packed symbols
+  const unsigned M = 0x55555555u, b1 = (x >> 1) & M, b0 = x & M;
+  const unsigned sel[4] = {~b1 & ~b0 & M, ~b1 & b0, b1 & ~b0, b1 & b0};
+  unsigned o = 0;
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const unsigned m = (map4 >> (2 * v)) & 3u;
+    o |= (m & 1u ? sel[v] : 0u) | (m & 2u ? sel[v] << 1 : 0u);
+  }
+  return o;
+}
+__device__ __forceinline__ unsigned deconv_even16(unsigned y) {                     // bits 0, 2, …, 30 of y → bits 0 … 15
+  unsigned x = y & 0x55555555u;
+  x = (x | (x >> 1)) & 0x33333333u;
+  x = (x | (x >> 2)) & 0x0f0f0f0fu;
+  x = (x | (x >> 4)) & 0x00ff00ffu;
+  x = (x | (x >> 8)) & 0x0000ffffu;
+  return x;
+}
+__device__ __forceinline__ bool deconv_r12_ok(const deconv_dev &D, const deconv_plan &P) {
+  return D.pp == 1 && D.pw == 2 && (D.deconv[0] >> 32) == 0 && P.in_words != nullptr;
+}
+// bytes [k, k + 4) of the call: where their four packed words start (wi − 3 … wi) and the bit offset; false: not eligible here (the caller
+// takes deconv_byte)
+__device__ __forceinline__ bool deconv_r12_addr(const deconv_plan &P, unsigned long long k, unsigned long long &wi, int &sh) {
+  const long long q0 = (long long)(8 * k) - P.n_out0;                  // refill of the first of the 32 bits
+  if (q0 < 0 || k + 4 > P.n_bytes) return false;
+  const long long i0 = (long long)P.m0 + q0 - 1;                       // its newest symbol (index in this call)
+  if (i0 < 16) return false;
+  const unsigned long long g31 = P.in_off + (unsigned long long)i0 + 31;   // newest symbol of the last bit, in the packed stream
+  wi = g31 >> 4;
+  if (wi < 3) return false;
+  sh = 2 * (15 - (int)(g31 & 15));
+  return true;
+}
+// … and the 32 bits from the four words W0 (oldest) … W3.  The symbol → I/Q maps of the four alignments (init_syncs, dvb.h:309-366) are
+// bit permutations with inversions — rotations and conjugations of the constellation — i.e. on packed symbols "swap the two bits of every
+// symbol or not, then XOR a constant": five instructions per word instead of the generic four-way select.  POLY: the inverse polynomial
+// as a compile-time constant (0x3ba, DVB-S rate 1/2: seven shifts, no tests), 0 = the run-time one.
+__device__ __forceinline__ bool deconv_affine(const unsigned char *lut, bool &swap, unsigned &mask) {
+  const unsigned l0 = lut[0], l1 = lut[1], l2 = lut[2], l3 = lut[3];
+  swap = ((l0 ^ l1) & 3u) == 2u;
+  const unsigned p1 = swap ? 2u : 1u, p2 = swap ? 1u : 2u;
+  mask = (l0 & 3u) * 0x55555555u;
+  return ((l1 ^ l0) & 3u) == p1 && ((l2 ^ l0) & 3u) == p2 && ((l3 ^ l0) & 3u) == 3u;
+}
+__device__ __forceinline__ unsigned deconv_map16a(unsigned x, bool swap, unsigned mask) {
+  const unsigned y = swap ? ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1) : x;
+  return y ^ mask;
+}
+template <unsigned POLY>
+__device__ __forceinline__ unsigned deconv_r12_bits_t(const deconv_dev &D, unsigned W0, unsigned W1, unsigned W2, unsigned W3, int sh) {
+  bool swap; unsigned mask;
+  unsigned M0, M1, M2, M3;
+  if (deconv_affine(D.lut, swap, mask)) {       // (uniform)
+    M3 = deconv_map16a(W3, swap, mask); M2 = deconv_map16a(W2, swap, mask); M1 = deconv_map16a(W1, swap, mask); M0 = deconv_map16a(W0, swap, mask);
+  } else {
+    const unsigned map4 = (unsigned)D.lut[0] | ((unsigned)D.lut[1] << 2) | ((unsigned)D.lut[2] << 4) | ((unsigned)D.lut[3] << 6);
+    M3 = deconv_map16(W3, map4); M2 = deconv_map16(W2, map4); M1 = deconv_map16(W1, map4); M0 = deconv_map16(W0, map4);
+  }
+  const unsigned x0 = __builtin_amdgcn_alignbit(M2, M3, sh), x1 = __builtin_amdgcn_alignbit(M1, M2, sh), x2 = __builtin_amdgcn_alignbit(M0, M1, sh);
+  unsigned y0 = 0, y1 = 0;
+  const unsigned poly = POLY ? POLY : (unsigned)D.deconv[0];
+#pragma unroll
+  for (int j = 0; j < 32; ++j)
+    if ((poly >> j) & 1u) { y0 ^= __builtin_amdgcn_alignbit(x1, x0, j); y1 ^= __builtin_amdgcn_alignbit(x2, x1, j); }
+  return (deconv_even16(y1) << 16) | deconv_even16(y0);
+}
+__device__ __forceinline__ unsigned deconv_r12_bits(const deconv_dev &D, unsigned W0, unsigned W1, unsigned W2, unsigned W3, int sh) {
+  return (unsigned)D.deconv[0] == 0x3bau ? deconv_r12_bits_t<0x3bau>(D, W0, W1, W2, W3, sh) : deconv_r12_bits_t<0u>(D, W0, W1, W2, W3, sh);
+}
+__device__ __forceinline__ bool deconv_r12_word(const deconv_dev &D, const deconv_plan &P, unsigned long long k, unsigned &r) {
+  unsigned long long wi; int sh;
+  if (!deconv_r12_addr(P, k, wi, sh)) return false;
+  r = deconv_r12_bits(D, P.in_words[wi - 3], P.in_words[wi - 2], P.in_words[wi - 1], P.in_words[wi], sh);
+  return true;
+}
+__device__ __forceinline__ void deconv_store4(unsigned char *o, unsigned r) {
+  if (((unsigned long long)o & 3ull) == 0) *reinterpret_cast<unsigned *>(o) = __builtin_bswap32(r);      // (uniform: the call's output is 4-byte aligned or not)
+  else { o[0] = (unsigned char)(r >> 24); o[1] = (unsigned char)(r >> 16); o[2] = (unsigned char)(r >> 8); o[3] = (unsigned char)r; }
+}
+// the bytes [4·g, 4·g + 4) ∩ [0, n_bytes) of a call
+template <bool PACKED>
+__device__ __forceinline__ void deconv_group4(const deconv_dev &D, const deconv_plan &P, unsigned long long in0, unsigned long long out0,
+                                              unsigned long long g, bool r12) {
+  const unsigned long long k = 4 * g;
+  unsigned r;
+  if (PACKED && r12 && deconv_r12_word(D, P, k, r)) { deconv_store4(P.out + k, r); return; }
+  for (unsigned long long b = k; b < k + 4 && b < P.n_bytes; ++b) P.out[b] = deconv_byte<PACKED>(D, P, in0, out0, b);
+}
+
 template <bool PACKED>
 __global__ __launch_bounds__(256) void k_deconv(deconv_dev D, deconv_plan P) {
   const unsigned long long in0 = P.carry->in, out0 = P.carry->out;
-  const unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  if (k < P.n_bytes) P.out[k] = deconv_byte<PACKED>(D, P, in0, out0, k);
-  if (k == 0) *P.carry_next = deconv_carry_after<PACKED>(D, P, in0, out0);   // state for the next call
+  const unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  const bool r12 = PACKED && deconv_r12_ok(D, P);
+  if (4 * g < P.n_bytes) deconv_group4<PACKED>(D, P, in0, out0, g, r12);
+  if (g == 0) *P.carry_next = deconv_carry_after<PACKED>(D, P, in0, out0);   // state for the next call
 }
 
 // fastlock (dvb.h:428-452 + readerrors, dvb.h:396-417): for every alignment, the number of refills whose bit b
@@ -569,7 +667,7 @@ __device__ __forceinline__ unsigned char rs_eval(const gf_tables &g, const unsig
 // one packet by one wavefront: pk / po / synd / key are THIS wavefront's LDS scratch, the packet is in pk already
 __device__ __forceinline__ void rs_decode_wave(const gf_tables &g, unsigned char *pk, unsigned char *po, unsigned char *synd, rs_key *key,
                                                unsigned char *in, unsigned char *out, unsigned long long p, int lane,
-                                               unsigned long long *counters /*[0] errs*/) {
+                                               unsigned long long *counters /*[0] errs*/, unsigned char *first = nullptr) {
   unsigned s[4];
   rs_syndromes(g, pk, lane, s);
   const bool corrupted = (s[0] | s[1] | s[2] | s[3]) != 0u;      // wave-uniform
@@ -610,6 +708,7 @@ __device__ __forceinline__ void rs_decode_wave(const gf_tables &g, unsigned char
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = po[i];
     for (int i = lane; i < kRS; i += 64) in[p * kRS + i] = pk[i];   // in-place correction like the reference
+    if (first && lane == 0) first[p] = po[0];
   } else {
     for (int i = lane; i < kTS; i += 64) out[p * kTS + i] = pk[i];
   }
@@ -1048,8 +1147,9 @@ static int deconv_run(lsdr_deconv *d, const lsdr_softsymbol *in, const uint32_t 
   P.carry = d->d_carry[d->cur[a]] + a;
   P.carry_next = d->d_carry[d->cur[a] ^ 1] + a;
   P.n_out_end = (int)(n_out0 + (long long)R * H.pp - 8 * n);
-  if (in_words) hipLaunchKernelGGL(k_deconv<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->ctx->stream, D, P);
-  else hipLaunchKernelGGL(k_deconv<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, d->ctx->stream, D, P);
+  const unsigned dgrid = (unsigned)(((n + 3) / 4 + 255) / 256);     // a thread owns four consecutive bytes
+  if (in_words) hipLaunchKernelGGL(k_deconv<true>, dim3(dgrid), dim3(256), 0, d->ctx->stream, D, P);
+  else hipLaunchKernelGGL(k_deconv<false>, dim3(dgrid), dim3(256), 0, d->ctx->stream, D, P);
   LSDR_HIP(hipGetLastError());
   d->cur[a] ^= 1;
   if (R) d->n_in[a] = 64 - H.pw;

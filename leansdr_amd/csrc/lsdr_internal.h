@@ -90,7 +90,7 @@ int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf3
 struct lsdr_rxb;
 int lsdr_rxb_create(lsdr_ctx *c, const lsdr_capture_batch_cfg *cfg, lsdr_rxb **out);
 void lsdr_rxb_destroy(lsdr_rxb *b);
-int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t *consumed);
+int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t *consumed, hipStream_t aux = nullptr);
 const uint32_t *lsdr_rxb_words(const lsdr_rxb *b, unsigned i);
 size_t lsdr_rxb_words_cap(const lsdr_rxb *b);
 const void *lsdr_rxb_results_dev(const lsdr_rxb *b, size_t *stride);
@@ -107,7 +107,7 @@ struct lsdr_tail_result {          // = tail_device.h's tail_result
   unsigned next_sync_calls, locked_at_end, alignment, bitphase;
   unsigned long long first_lock_byte;
 };
-int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, lsdr_tail **out);
+int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, unsigned window, lsdr_tail **out);
 void lsdr_tail_destroy(lsdr_tail *t);
 int lsdr_tail_bind(lsdr_tail *t, const uint32_t *const *words, const void *counts_dev, size_t count_stride);
 int lsdr_tail_launch(lsdr_tail *t, hipEvent_t before_ts);

@@ -306,15 +306,17 @@ __global__ __launch_bounds__(kSeamBlock) void k_rx_seam_h(const rx_tile_info_h *
 // of its stretch of the output fill up within a few loop trips and leave L2 whole.  A word that two tiles share is written by
 // the later one, which takes the earlier tile's last symbols from that tile's column (no atomics, no pre-zeroing); the symbols
 // before out_sym_offset in the first word (a caller's leftover symbols) are preserved.
-template <typename STATE>
+// LPT lanes per tile (1, 2 or 4: a lane's trips are a chain of dependent loads, so a 4096-sample tile — 213 output words — is walked by
+// four lanes, a quarter each; the wavefront then holds 64 / LPT consecutive tiles).
+template <typename STATE, int LPT = 1>
 __device__ __forceinline__ void rx_compact_h_body(const unsigned *hstage, unsigned long long pitch, const rx_tile_info_h *info,
                                                   const rx_tile_fix *fix, const rx_seam_part *part, const uint8_t *relabel,
                                                   unsigned n_tiles, int R, float quad, unsigned *out, unsigned long long out_sym_offset,
                                                   STATE *state, rx_seam_result *res) {
-  const unsigned j = blockIdx.x * 64u + threadIdx.x;
+  const unsigned j = (blockIdx.x * 64u + threadIdx.x) / (unsigned)LPT, sub = threadIdx.x % (unsigned)LPT;
   const unsigned rmask = (unsigned)R - 1;
   const unsigned nparts = (n_tiles + kSeamBlock - 1) / kSeamBlock;
-  if (j == 0) {
+  if (j == 0 && sub == 0) {
     rx_seam_result sr; sr.total = 0; sr.rot_final = 0; sr.ndup = 0; sr.nmiss = 0; sr.nbad = 0; sr.freq_tap = rx_freq_tap(state);
     for (unsigned i = 0; i < nparts; ++i) {
       sr.total += part[i].cnt; sr.rot_final = (sr.rot_final + part[i].rot) & rmask;
@@ -325,8 +327,8 @@ __device__ __forceinline__ void rx_compact_h_body(const unsigned *hstage, unsign
     if (sr.rot_final) rx_rotate_back(state, sr.rot_final, quad);
   }
   // totals of the seam blocks before this wavefront's (kSeamBlock is a multiple of 64: one seam block per wavefront; only
-  // lane 0's predecessor can sit in the block before)
-  const unsigned mypart = (blockIdx.x * 64u) / kSeamBlock;
+  // the first tile's predecessor can sit in the block before)
+  const unsigned mypart = (blockIdx.x * (64u / (unsigned)LPT)) / kSeamBlock;
   unsigned long long base = 0;
   unsigned brot = 0;
   for (unsigned i = threadIdx.x; i < mypart; i += 64) { base += part[i].cnt; brot += part[i].rot; }
@@ -360,7 +362,7 @@ __device__ __forceinline__ void rx_compact_h_body(const unsigned *hstage, unsign
   }
   const long long end = D + len;
   const long long w_last = j == n_tiles - 1 ? (end + 15) >> 4 : end >> 4;  // exclusive; a partial last word belongs to the next tile
-  for (long long m = D >> 4; m < w_last; ++m) {
+  auto one = [&](long long m) {
     const long long s0 = m << 4;                                            // first symbol of the word
     // part from this tile: symbols u with D ≤ s0+u < end
     unsigned cur = hs2_fetch16(col, pitch, nw, s0 - Q);
@@ -378,7 +380,30 @@ __device__ __forceinline__ void rx_compact_h_body(const unsigned *hstage, unsign
       }
     }
     out[m] = word;
+  };
+  const long long m0 = D >> 4;
+  if (sub == 0 && m0 < w_last) one(m0);   // the first word: may be shared with the previous tile, may hold the re-inserted symbol
+  // Interior words — all 16 symbols from this tile's column, nothing to patch — four per trip with their five column words requested
+  // together (a lane's trips are a chain of dependent loads otherwise: 213 round trips per 4096-sample tile, 1.3 ms for 8 captures),
+  // the range cut into LPT stretches of whole trips.
+  const long long m1 = m0 + 1, m_end = (end >> 4) > m1 ? (end >> 4) : m1;       // words [m1, m_end) lie wholly inside [D, end)
+  constexpr int U = 8;                   // words per trip
+  const long long span = ((m_end - m1 + LPT - 1) / LPT + (U - 1)) / U * U;
+  long long m = m1 + (long long)sub * span;
+  const long long stop = m + span < m_end ? m + span : m_end;
+  {
+    const int sh = 2 * (int)(((m1 << 4) - Q) & 15);
+    for (; m + U <= stop; m += U) {
+      const long long wi = ((m << 4) - Q) >> 4;
+      unsigned w[U + 1];
+#pragma unroll
+      for (int i = 0; i <= U; ++i) w[i] = (wi + i < nw) ? col[(unsigned long long)(wi + i) * pitch] : 0u;
+#pragma unroll
+      for (int i = 0; i < U; ++i) out[m + i] = hs2_map_word(sh ? (w[i] << sh) | (w[i + 1] >> (32 - sh)) : w[i], map4);
+    }
   }
+  for (; m < stop; ++m) one(m);
+  if (sub == LPT - 1) for (m = m_end; m < w_last; ++m) one(m);                  // (the last tile's partial word)
 }
 template <typename STATE>
 __global__ __launch_bounds__(64) void k_rx_compact_h(const unsigned *hstage, unsigned long long pitch, const rx_tile_info_h *info,

@@ -223,9 +223,17 @@ __global__ __launch_bounds__(64) void k_rxb_notch_dump(rxb_args A, unsigned cap_
   }
 }
 
+// LDS staging of the lean tiles: 32 samples per stage + 16 of look-ahead (the next symbol's pair is read up to 3 samples ahead, a timing
+// excursion walks up to omega + 2 ≤ 10): 112-byte rows, 7 KiB per wavefront — 22 wavefronts per CU where the 64-sample stages of
+// rx_tile_tol (11 KiB) allow 14; this kernel lives on wavefronts per SIMD (VALU issue, a dependent chain per symbol).
+struct rxb_stage {
+  static constexpr int kStage = 32, kMargin = 16, kRowBytes = 2 * (kStage + kMargin) + 16;
+};
+static_assert(rxb_stage::kRowBytes % 16 == 0 && kChunk % rxb_stage::kStage == 0, "stage geometry");
+
 template <bool NOTCH>
 __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, unsigned j0, int lane, char *lds) {
-  typedef rx_stage<LSDR_IN_CU8> ST;
+  typedef rxb_stage ST;
   constexpr int kStage = ST::kStage, kRowBytes = ST::kRowBytes, kStageLoads = ST::kRowBytes / 16;
   const bool valid = j0 + (unsigned)lane < cap.n_tiles;
   const unsigned j = valid ? j0 + (unsigned)lane : j0;
@@ -262,7 +270,7 @@ __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, 
   const float kk = C.kest, k1 = 1 - C.kest;
   const float freq_alpha = C.freq_alpha, freq_beta = C.freq_beta, gain_mu = C.gain_mu, omega = C.omega;
   float mu = 0.f, phase = 0.f;
-  float h1pr = 0.f, h1pi = 0.f, h1cr = 0.f, h1ci = 0.f, h2pr = 0.f, h2pi = 0.f, h2cr = 0.f, h2ci = 0.f;
+  float h1pr = 0.f, h1pi = 0.f, h1cr = 0.f, h1ci = 0.f, mmA = 0.f, mmB = 0.f;      // Mueller & Müller: the previous symbol; p1·c2 and c1·p2
 
   // notch: pole / gain of the interval the tile is in, S in front of the tile's first sample from the pre-pass sums
   float npr = 0.f, npi = 0.f, nkk = 0.f, sr = 0.f, si = 0.f;
@@ -310,7 +318,9 @@ __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, 
 #pragma unroll
         for (int q = 0; q < kStageLoads; ++q)
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (rx_lds_ptr)(size_t)(unsigned)(unsigned long long)(lds + q * 1024), 16, src_off[q], soff, 0, 0);
+#ifndef RXB_NOWAIT                                // (measurement variant: what the stage wait costs; garbage results)
         __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0): the stage has landed (single-wave workgroup: no barrier)
+#endif
         asm volatile("" ::: "memory");
       }
       const char *ap = row + 2 * (n - s0);       // sample n in this lane's row
@@ -337,7 +347,7 @@ __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, 
         const float svr = __builtin_fmaf(g0r, ear, -(g0i * eai)), svi = __builtin_fmaf(g0r, eai, g0i * ear);
         // cstln_lut<256>::lookup (sdr.h:470-483): fold into range, truncate; the decision is the two sign bits
         float Ir = svr, Qr = svi;
-        lut_halve(Ir, Qr);
+        if (__builtin_fmaxf(__builtin_fabsf(svr), __builtin_fabsf(svi)) > 127.0f) lut_halve(Ir, Qr);     // (the exact test is lut_halve's own)
         const int Ii = (int)Ir, Qi = (int)Qr;
         hacc = __builtin_amdgcn_alignbit(hacc, (unsigned)Ii, 31);
         hacc = __builtin_amdgcn_alignbit(hacc, (unsigned)Qi, 31);
@@ -347,14 +357,14 @@ __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, 
         freqw = __builtin_amdgcn_fmed3f(freqw, f_lo, f_hi);
         // constellation point (±53, ±53) by the sign bits; modified Mueller & Müller, sdr.h:822-840
         float c0r, c0i;
-        { unsigned t = 0x42540000u | ((unsigned)Ii & 0x80000000u); __builtin_memcpy(&c0r, &t, 4);
-          t = 0x42540000u | ((unsigned)Qi & 0x80000000u); __builtin_memcpy(&c0i, &t, 4); }
-        float muerr = (svr - h2pr) * h1cr;
-        muerr = __builtin_fmaf(svi - h2pi, h1ci, muerr);
-        muerr = __builtin_fmaf(-(c0r - h2cr), h1pr, muerr);
-        muerr = __builtin_fmaf(-(c0i - h2ci), h1pi, muerr);
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c0r) : "s"(0x80000000u), "v"(Ii), "v"(0x42540000u));      // 53.0 with the coordinate's sign
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(c0i) : "s"(0x80000000u), "v"(Qi), "v"(0x42540000u));
+        // muerr = (p0 − p2)·c1 − (c0 − c2)·p1 (dot products) = A0 − B1 − B0 + A1 with A_k = p_k·c_{k−1}, B_k = c_k·p_{k−1}: the symbol before
+        // the previous one enters through two running products, not through four more history registers
+        const float A0 = __builtin_fmaf(svi, h1ci, svr * h1cr), B0 = __builtin_fmaf(c0i, h1pi, c0r * h1pr);
+        const float muerr = (A0 - mmB) + (mmA - B0);
         const float mucorr = __builtin_amdgcn_fmed3f(muerr * gain_mu, -0.1f, 0.1f);
-        h2pr = h1pr; h2pi = h1pi; h2cr = h1cr; h2ci = h1ci;
+        mmA = A0; mmB = B0;
         h1pr = svr; h1pi = svi; h1cr = c0r; h1ci = c0i;
         const float mu2 = (mu + mucorr) + omega;
         // the sample steps up to the next symbol instant: at least one (sdr.h:800-847: one symbol per sample step at most)
@@ -411,7 +421,7 @@ __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, 
 
 template <bool NOTCH>
 __global__ __launch_bounds__(64) void k_rxb_tiles(rxb_args A) {
-  __shared__ __attribute__((aligned(16))) char lds[64 * rx_stage<LSDR_IN_CU8>::kRowBytes];
+  __shared__ __attribute__((aligned(16))) char lds[64 * rxb_stage::kRowBytes];
   const rxb_cap &cap = A.caps[blockIdx.y];
   if (blockIdx.x == 0) {
     // tile 0: the reference's arithmetic from the constructed state over the first warm_chunks chunks (in front of the first detect
@@ -436,10 +446,11 @@ __global__ __launch_bounds__(kSeamBlock) void k_rxb_seam(rxb_args A, float omega
   if (blockIdx.x * kSeamBlock >= cap.n_tiles) return;
   rx_seam_h_body(cap.hinfo, cap.fix, cap.n_tiles, omega, R, quad, cap.part, relabel);
 }
+constexpr unsigned kRxbCompactLanes = 4;      // lanes per tile in the compaction (rx_tiling.h)
 __global__ __launch_bounds__(64) void k_rxb_compact(rxb_args A, int R, float quad, const uint8_t *relabel) {
   const rxb_cap &cap = A.caps[blockIdx.y];
-  if (blockIdx.x * 64u >= cap.n_tiles) return;
-  rx_compact_h_body<rx_state_dev>(cap.hstage, cap.hpitch, cap.hinfo, cap.fix, cap.part, relabel, cap.n_tiles, R, quad, cap.out_words, 0ull,
+  if (blockIdx.x * (64u / kRxbCompactLanes) >= cap.n_tiles) return;
+  rx_compact_h_body<rx_state_dev, (int)kRxbCompactLanes>(cap.hstage, cap.hpitch, cap.hinfo, cap.fix, cap.part, relabel, cap.n_tiles, R, quad, cap.out_words, 0ull,
                                   cap.state_end, cap.res);
 }
 

@@ -24,6 +24,7 @@ struct lsdr_rxb {
   size_t geom_samples;             // n_samples the detect-point tables on the device were built for
   unsigned n_det, n_pre, n_tiles; unsigned long long total_chunks;
   hipEvent_t tev0, tev1; bool timing; double time_ms; unsigned time_n; bool tev_pending;
+  hipEvent_t ev_pre, ev_tiles;      // hand-overs between the tile stream and the auxiliary stream (lsdr_rxb_launch with aux)
 };
 
 static int rxb_alloc(lsdr_rxb *b, void **p, size_t bytes) {
@@ -129,6 +130,7 @@ int lsdr_rxb_create(lsdr_ctx *c, const lsdr_capture_batch_cfg *cfg, lsdr_rxb **o
   }
   b->geom_samples = 0;
   LSDR_HIP(hipEventCreate(&b->tev0)); LSDR_HIP(hipEventCreate(&b->tev1));
+  LSDR_HIP(hipEventCreateWithFlags(&b->ev_pre, hipEventDisableTiming)); LSDR_HIP(hipEventCreateWithFlags(&b->ev_tiles, hipEventDisableTiming));
   b->timing = false; b->time_ms = 0; b->time_n = 0; b->tev_pending = false;
   return LSDR_OK;
 }
@@ -142,6 +144,8 @@ void lsdr_rxb_destroy(lsdr_rxb *b) {
   (void)hipFree(b->d_iv_of_block); (void)hipFree(b->d_det_block); (void)hipFree(b->d_om);
   if (b->tev0) (void)hipEventDestroy(b->tev0);
   if (b->tev1) (void)hipEventDestroy(b->tev1);
+  if (b->ev_pre) (void)hipEventDestroy(b->ev_pre);
+  if (b->ev_tiles) (void)hipEventDestroy(b->ev_tiles);
   lsdr_rx_destroy(b->proto);
   delete b;
 }
@@ -153,9 +157,11 @@ static void rxb_fill_args(const lsdr_rxb *b, rxb_args &A) {
   rx_fill_consts(b->proto, A.C, A.T);
 }
 
-// Queues the whole front end of a batch on the context's stream: detect chain, estimator pre-pass, tiles, seam pass, compaction.
-// The previous launch of this object must have completed (the argument records are single-buffered).
-int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t *consumed) {
+// Queues the whole front end of a batch: detect chain, estimator pre-pass, tiles, seam pass, compaction.  aux == nullptr: everything on
+// the context's stream.  aux: the TILES on the context's stream, everything else on `aux` (the caller's stream for the memory-bound
+// kernels — on its own compute units, lsdr_capture_batch_cfg::aux_cus), handed over by events; what follows the compaction (the FEC tail)
+// belongs on `aux` then.  The previous launch of this object must have completed (the argument records are single-buffered).
+int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t *consumed, hipStream_t aux) {
   LSDR_ARG(b && iq && consumed);
   if (n_samples > b->max_samples) { lsdr_set_error("capture_batch: %zu samples per capture, created for %zu", n_samples, b->max_samples); return LSDR_E_ARG; }
   lsdr_ctx *c = b->ctx;
@@ -175,6 +181,7 @@ int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t
       ivb[blk] = m;
     }
     LSDR_HIP(hipStreamSynchronize(c->stream));
+    if (aux) LSDR_HIP(hipStreamSynchronize(aux));
     LSDR_HIP(hipMemcpy(b->d_iv_of_block, ivb.data(), ivb.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     LSDR_HIP(hipMemcpy(b->d_det_block, det.data(), det.size() * sizeof(unsigned), hipMemcpyHostToDevice));
     b->geom_samples = n_samples;
@@ -186,10 +193,11 @@ int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t
     cp.total_chunks = g.chunks; cp.n_tiles = g.n_tiles; cp.n_det = g.n_det;
     b->h_caps[i] = cp;
   }
-  LSDR_HIP(hipMemcpyAsync(b->d_caps, b->h_caps, b->n * sizeof(rxb_cap), hipMemcpyHostToDevice, c->stream));
+  const hipStream_t sa = aux ? aux : c->stream, st = c->stream;      // auxiliary kernels / tiles
+  LSDR_HIP(hipMemcpyAsync(b->d_caps, b->h_caps, b->n * sizeof(rxb_cap), hipMemcpyHostToDevice, sa));
   if (!g.chunks) {
-    LSDR_HIP(hipMemsetAsync(b->d_res, 0, b->n * sizeof(rx_seam_result), c->stream));
-    LSDR_HIP(hipMemcpyAsync(b->h_res, b->d_res, b->n * sizeof(rx_seam_result), hipMemcpyDeviceToHost, c->stream));
+    LSDR_HIP(hipMemsetAsync(b->d_res, 0, b->n * sizeof(rx_seam_result), sa));
+    LSDR_HIP(hipMemcpyAsync(b->h_res, b->d_res, b->n * sizeof(rx_seam_result), hipMemcpyDeviceToHost, sa));
     return LSDR_OK;
   }
   rxb_args A;
@@ -198,24 +206,26 @@ int lsdr_rxb_launch(lsdr_rxb *b, const void *const *iq, size_t n_samples, size_t
   if (notch) {
     if (((unsigned long long)iq[0] & 15ull) != 0) { lsdr_set_error("capture_batch: with the notch the captures must be 16-byte aligned"); return LSDR_E_ARG; }
     for (unsigned i = 1; i < b->n; ++i) LSDR_ARG(((unsigned long long)iq[i] & 15ull) == 0);
-    hipLaunchKernelGGL(k_rxb_detect_fft, dim3(2 * g.n_det, b->n), dim3(256), 0, c->stream, A);
-    hipLaunchKernelGGL(k_rxb_detect_peaks, dim3(g.n_det, b->n), dim3(256), 0, c->stream, A);
-    hipLaunchKernelGGL(k_rxb_iv, dim3((b->n + 63) / 64), dim3(64), 0, c->stream, A, b->n);
-    hipLaunchKernelGGL(k_rxb_notch_pre, dim3(g.n_pre, b->n), dim3(256), 0, c->stream, A);
+    hipLaunchKernelGGL(k_rxb_detect_fft, dim3(2 * g.n_det, b->n), dim3(256), 0, sa, A);
+    hipLaunchKernelGGL(k_rxb_detect_peaks, dim3(g.n_det, b->n), dim3(256), 0, sa, A);
+    hipLaunchKernelGGL(k_rxb_iv, dim3((b->n + 63) / 64), dim3(64), 0, sa, A, b->n);
+    hipLaunchKernelGGL(k_rxb_notch_pre, dim3(g.n_pre, b->n), dim3(256), 0, sa, A);
     LSDR_HIP(hipGetLastError());
   }
   const unsigned blocks = 1 + (g.n_tiles - 1 + 63) / 64;
-  if (b->timing) { LSDR_HIP(hipEventRecord(b->tev0, c->stream)); }
-  if (notch) hipLaunchKernelGGL(k_rxb_tiles<true>, dim3(blocks, b->n), dim3(64), 0, c->stream, A);
-  else hipLaunchKernelGGL(k_rxb_tiles<false>, dim3(blocks, b->n), dim3(64), 0, c->stream, A);
-  if (b->timing) { LSDR_HIP(hipEventRecord(b->tev1, c->stream)); b->tev_pending = true; }
+  if (aux) { LSDR_HIP(hipEventRecord(b->ev_pre, sa)); LSDR_HIP(hipStreamWaitEvent(st, b->ev_pre, 0)); }
+  if (b->timing) { LSDR_HIP(hipEventRecord(b->tev0, st)); }
+  if (notch) hipLaunchKernelGGL(k_rxb_tiles<true>, dim3(blocks, b->n), dim3(64), 0, st, A);
+  else hipLaunchKernelGGL(k_rxb_tiles<false>, dim3(blocks, b->n), dim3(64), 0, st, A);
+  if (b->timing) { LSDR_HIP(hipEventRecord(b->tev1, st)); b->tev_pending = true; }
+  if (aux) { LSDR_HIP(hipEventRecord(b->ev_tiles, st)); LSDR_HIP(hipStreamWaitEvent(sa, b->ev_tiles, 0)); }
   const int R = r->tabs.nrotations;
   const float quad = 65536.0f / R;
-  hipLaunchKernelGGL(k_rxb_seam, dim3((g.n_tiles + kSeamBlock - 1) / kSeamBlock, b->n), dim3(kSeamBlock), 0, c->stream, A, r->omega, R, quad,
+  hipLaunchKernelGGL(k_rxb_seam, dim3((g.n_tiles + kSeamBlock - 1) / kSeamBlock, b->n), dim3(kSeamBlock), 0, sa, A, r->omega, R, quad,
                      (const uint8_t *)r->d_relabel);
-  hipLaunchKernelGGL(k_rxb_compact, dim3((g.n_tiles + 63) / 64, b->n), dim3(64), 0, c->stream, A, R, quad, (const uint8_t *)r->d_relabel);
+  hipLaunchKernelGGL(k_rxb_compact, dim3((g.n_tiles * kRxbCompactLanes + 63) / 64, b->n), dim3(64), 0, sa, A, R, quad, (const uint8_t *)r->d_relabel);
   LSDR_HIP(hipGetLastError());
-  LSDR_HIP(hipMemcpyAsync(b->h_res, b->d_res, b->n * sizeof(rx_seam_result), hipMemcpyDeviceToHost, c->stream));
+  LSDR_HIP(hipMemcpyAsync(b->h_res, b->d_res, b->n * sizeof(rx_seam_result), hipMemcpyDeviceToHost, sa));
   return LSDR_OK;
 }
 

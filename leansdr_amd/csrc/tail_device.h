@@ -4,7 +4,7 @@
 // mpeg_sync locked, packets kept — staying in a per-capture record in HBM.  blockIdx.y = capture everywhere; the host reads ONE result
 // record per capture when the last kernel has run.  Same kernels' bodies as the one-block-per-call C ABI above (bit-exact blocks):
 //
-//   k_tail_acquire    one workgroup per capture: the chain's unlocked phase exactly as a scheduler with 64 KiB byte pipes runs it —
+//   k_tail_acquire    one workgroup per capture: the chain's unlocked phase exactly as a scheduler with `window`-byte pipes (8 KiB: the reference's) runs it —
 //                     deconvolve a window with the alignment in force, let mpeg_sync search it (and decode what is left of it once it has
 //                     locked), next_sync() when mpeg_sync asks for it (dvb.h:185-193, 775-779) — until a window ends locked or the
 //                     symbols run out; then the PLAN of the bulk deconvolution (everything that is left, one call)
@@ -18,7 +18,6 @@
 #ifndef LSDR_TAIL_DEVICE_H
 #define LSDR_TAIL_DEVICE_H
 
-constexpr unsigned long long kTailWindow = 65536;   // bytes deconvolved per call while mpeg_sync is not locked
 
 struct tail_result {             // per capture, host-visible when the batch has run
   unsigned long long n_ts;        // TS packets written
@@ -34,6 +33,7 @@ struct tail_cap {
   const unsigned *words;                 // packed decisions
   const unsigned long long *nsym;        // → how many (device)
   unsigned char *bytes, *mpeg, *rs, *rts, *ts;
+  unsigned char *first;                  // [packets] first byte of every RS output packet (what the derandomizer's bookkeeping reads)
   int *pkt_pos; long long *pkt_dst;
   unsigned long long byte_cap, pk_cap;
   tail_result *res;                      // pinned host memory
@@ -58,7 +58,9 @@ struct tail_args {
   deconv_dev D;                          // polynomials, puncturing (lut filled per capture from `luts`)
   unsigned char luts[4][4];
   msync_state ms0;                       // mpeg_sync as constructed
+  unsigned long long window;             // bytes deconvolved per call while mpeg_sync is not locked (the byte pipe of the reference's graph)
   const gf_tables *gtab;
+  unsigned char rs_g[16];                // generator polynomial G(x) without its leading 1: coefficients of x^15 … x^0 (rs.h:93-105)
   const unsigned char *pattern;          // derandomizer PRBS (1504 + 188 bytes)
 };
 
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(256) void k_tail_acquire(tail_args A) {
     if (M.S.synchronized) break;                                            // (uniform: shared)
     if (tid == 0) {
       unsigned long long cap = tc.byte_cap - tc.bw;
-      if (cap > kTailWindow) cap = kTailWindow;
+      if (cap > A.window) cap = A.window;
       unsigned char lut[4];
       s_n = tail_plan_deconv(A, tc, nsym, cap, P, lut, &s_used);
       for (int s = 0; s < 4; ++s) D.lut[s] = lut[s];
@@ -131,7 +133,10 @@ __global__ __launch_bounds__(256) void k_tail_acquire(tail_args A) {
     }
     __syncthreads();
     if (!s_n) break;                                                        // the symbols have run out
-    for (unsigned long long k = tid; k < s_n; k += 256) P.out[k] = deconv_byte<true>(D, P, s_in0, s_out0, k);
+    {
+      const bool r12 = deconv_r12_ok(D, P);
+      for (unsigned long long g = tid; 4 * g < s_n; g += 256) deconv_group4<true>(D, P, s_in0, s_out0, g, r12);
+    }
     __syncthreads();
     if (tid == 0) {
       tc.carry[tc.locked] = deconv_carry_after<true>(D, P, s_in0, s_out0);
@@ -189,12 +194,32 @@ __global__ __launch_bounds__(256) void k_tail_acquire(tail_args A) {
 __global__ __launch_bounds__(256) void k_tail_deconv(tail_args A) {
   const tail_cap &tc = A.caps[blockIdx.y];
   const deconv_plan P = tc.plan;
-  if ((unsigned long long)blockIdx.x * 256 >= P.n_bytes) return;
+  if ((unsigned long long)blockIdx.x * 1024 >= P.n_bytes) return;
   deconv_dev D = A.D;
   for (int s = 0; s < 4; ++s) D.lut[s] = tc.plan_lut[s];
   const unsigned long long in0 = tc.plan_in0, out0 = tc.plan_out0;
-  for (unsigned long long k = (unsigned long long)blockIdx.x * 256 + threadIdx.x; k < P.n_bytes; k += (unsigned long long)gridDim.x * 256)
-    P.out[k] = deconv_byte<true>(D, P, in0, out0, k);
+  const bool r12 = deconv_r12_ok(D, P);
+  // four groups of four bytes per trip, their sixteen packed words requested together (a thread's trips are dependent round trips to
+  // memory otherwise: 0.5 ms for 16 captures at 32 waves per CU)
+  constexpr int U = 4;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256;
+  const unsigned *__restrict__ words = P.in_words;
+  for (unsigned long long g = (unsigned long long)blockIdx.x * 256 + threadIdx.x; 4 * g < P.n_bytes; g += U * stride) {
+    unsigned W[U][4];
+    unsigned long long wi[U]; int sh[U]; bool fast[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long gu = g + u * stride;
+      fast[u] = r12 && 4 * gu < P.n_bytes && deconv_r12_addr(P, 4 * gu, wi[u], sh[u]);
+      if (fast[u]) { W[u][0] = words[wi[u] - 3]; W[u][1] = words[wi[u] - 2]; W[u][2] = words[wi[u] - 1]; W[u][3] = words[wi[u]]; }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned long long gu = g + u * stride;
+      if (fast[u]) deconv_store4(P.out + 4 * gu, deconv_r12_bits(D, W[u][0], W[u][1], W[u][2], W[u][3], sh[u]));
+      else if (4 * gu < P.n_bytes) deconv_group4<true>(D, P, in0, out0, gu, false);
+    }
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) A.caps[blockIdx.y].carry[tc.locked] = deconv_carry_after<true>(D, P, in0, out0);
 }
 
@@ -213,7 +238,27 @@ __global__ __launch_bounds__(256) void k_tail_realign(tail_args A) {
   unsigned char *out = tc.mpeg + tc.mw;
   const unsigned long long nbytes = P * kRS, nthreads = (unsigned long long)gridDim.x * 256;
   const unsigned long long gid = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
-  for (unsigned long long i = gid; i < nbytes; i += nthreads) out[i] = (unsigned char)(shift_byte(in + i, bitphase) ^ polarity);
+  // four output bytes per trip from five input bytes (two or three aligned dwords), one dword store (the output of a locked run starts
+  // on a packet boundary of the 4-byte-aligned mpeg buffer)
+  if ((((unsigned long long)out) & 3ull) == 0) {
+    const unsigned pol4 = polarity * 0x01010101u;
+    for (unsigned long long g = gid; 4 * g < nbytes; g += nthreads) {
+      const unsigned long long a = (unsigned long long)(in + 4 * g);
+      const unsigned *ap = reinterpret_cast<const unsigned *>(a & ~3ull);
+      const int sh = (int)(a & 3ull) * 8;
+      const unsigned d0 = ap[0], d1 = ap[1], d2 = sh ? ap[2] : 0u;        // (bytes + byte_cap + 64: room behind the last byte)
+      const unsigned lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+      unsigned r = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned b0 = (lo >> (8 * j)) & 255u, b1 = j < 3 ? (lo >> (8 * j + 8)) & 255u : hi & 255u;
+        r |= ((((b0 << 8) | b1) >> bitphase) & 255u) << (8 * j);
+      }
+      reinterpret_cast<unsigned *>(out)[g] = r ^ pol4;
+    }
+  } else {
+    for (unsigned long long i = gid; i < nbytes; i += nthreads) out[i] = (unsigned char)(shift_byte(in + i, bitphase) ^ polarity);
+  }
   auto ok = [&](unsigned long long p) {
     const unsigned char b = (unsigned char)(shift_byte(in + p * kRS, bitphase) ^ polarity);
     return b == (((phase8 + (int)(p & 7)) & 7) ? kSync : kSyncInv);
@@ -302,54 +347,170 @@ __global__ __launch_bounds__(256) void k_tail_book(tail_args A) {
 __global__ __launch_bounds__(256) void k_tail_deint(tail_args A) {
   const tail_cap &tc = A.caps[blockIdx.y];
   const unsigned long long total = tc.n_pk * kRS;
-  const unsigned long long chunks = (total + 255) / 256, per_xcd = (chunks + 7) / 8;
+  const unsigned long long chunks = (total + 1023) / 1024, per_xcd = (chunks + 7) / 8;
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;      // (the grid is a multiple of 8)
   const unsigned char *in = tc.mpeg;
   unsigned char *out = tc.rs;
+  // four consecutive bytes of a packet per thread (a packet is 51 dwords): four gathered bytes, one dword store
   for (unsigned long long c = slot; c < per_xcd; c += slots) {
-    const unsigned long long i = (xcd * per_xcd + c) * 256 + threadIdx.x;
+    const unsigned long long i = ((xcd * per_xcd + c) * 256 + threadIdx.x) * 4;
     if (i >= total) continue;
     const unsigned long long p = i / kRS;
     const unsigned j = (unsigned)(i % kRS);
-    const unsigned delay = 17u * ((11u + 12u * 17u - j) % 12u);
-    out[i] = in[p * kRS + 2244 + j - 12ull * delay];
+    unsigned r = 0;
+#pragma unroll
+    for (unsigned u = 0; u < 4; ++u) {
+      const unsigned delay = 17u * ((11u + 12u * 17u - (j + u)) % 12u);
+      r |= (unsigned)in[p * kRS + 2244 + j + u - 12ull * delay] << (8 * u);
+    }
+    reinterpret_cast<unsigned *>(out)[i >> 2] = r;
   }
 }
 
-// rs_decoder<u8,0>::run (dvb.h:998-1053): one wavefront per packet, workgroups walk the capture's packets
+// rs_decoder<u8,0>::run (dvb.h:998-1053).  A packet is a codeword — all 16 syndromes zero (rs.h:116-129) — exactly when its polynomial
+// is divisible by the generator G(x) = Π (x − α^j) (rs.h:93-105), i.e. when the remainder of the systematic encoder's division is zero.
+// That division is a byte-wise LFSR: R ← (R·x^8) ⊕ T[b ⊕ top(R)], T[f] = f·(G − x^16), ONE 16-byte table row per byte where the
+// syndromes cost 16 log/exp look-ups.  So: a wavefront stages 64 consecutive packets in LDS (coalesced 16-byte loads), every LANE
+// divides its own packet (its bytes sit 204 apart: 51 dwords, odd — conflict-free), the 64 messages leave as one contiguous stretch,
+// and only packets with a non-zero remainder (channel errors) go through the syndrome / Berlekamp-Massey / Chien path of
+// rs_decode_wave, one at a time by the whole wavefront.  Same bytes and counters as k_rs_decode.
+constexpr int kRsChunk = 64;                              // packets per wavefront pass
 __global__ __launch_bounds__(256) void k_tail_rs(tail_args A) {
   tail_cap &tc = A.caps[blockIdx.y];
   const unsigned long long n = tc.n_pk;
-  if ((unsigned long long)blockIdx.x * 4 >= n) return;
+  if ((unsigned long long)blockIdx.x * 4 * kRsChunk >= n) return;
   __shared__ gf_tables g;
-  __shared__ unsigned char pk[4][kRS + 4], po[4][kTS + 4], synd[4][16];
+  __shared__ __attribute__((aligned(16))) uint4 T[4][256];          // T[k][f] = f·x^(16+k) mod G: four packet bytes per division step
+  __shared__ __attribute__((aligned(16))) unsigned char stage[4][kRsChunk * kRS];
+  __shared__ unsigned char po[4][kTS + 4], synd[4][16];
   __shared__ rs_key key[4];
   const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
   for (int i = tid; i < 512; i += 256) g.exp[i] = A.gtab->exp[i];
   g.log[tid] = A.gtab->log[tid];
   __syncthreads();
-  for (unsigned long long p = (unsigned long long)blockIdx.x * 4 + wv; p < n; p += (unsigned long long)gridDim.x * 4) {
+  {
+    // row f of the division table, laid out like R: R[m] (coefficient of x^(15−m)) is byte 15 − m of the 128-bit little-endian value
+    unsigned char row[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) row[15 - m] = gmul(g, (unsigned char)tid, A.rs_g[m]);
+    uint4 t;
+    __builtin_memcpy(&t, row, 16);
+    T[0][tid] = t;
+  }
+  __syncthreads();
+  for (int k = 1; k < 4; ++k) {                          // T[k][f] = T[k−1][f]·x mod G: one more step of the byte-wise division
+    const uint4 r = T[k - 1][tid], t0 = T[0][r.w >> 24];
+    uint4 n;
+    n.w = __builtin_amdgcn_alignbyte(r.w, r.z, 3) ^ t0.w; n.z = __builtin_amdgcn_alignbyte(r.z, r.y, 3) ^ t0.z;
+    n.y = __builtin_amdgcn_alignbyte(r.y, r.x, 3) ^ t0.y; n.x = (r.x << 8) ^ t0.x;
+    T[k][tid] = n;
+    __syncthreads();
+  }
+  unsigned char *const st = stage[wv];
+  for (unsigned long long c = (unsigned long long)blockIdx.x * 4 + wv; c * kRsChunk < n; c += (unsigned long long)gridDim.x * 4) {
+    const unsigned long long p0 = c * kRsChunk;
+    const unsigned np = n - p0 < (unsigned long long)kRsChunk ? (unsigned)(n - p0) : (unsigned)kRsChunk;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();                   // (the wavefront's previous packet is out of its LDS scratch)
-    for (int i = lane; i < kRS; i += 64) pk[wv][i] = tc.rs[p * kRS + i];
+    __builtin_amdgcn_wave_barrier();                   // (the wavefront's previous pass is out of its LDS)
+    const uint4 *src = reinterpret_cast<const uint4 *>(tc.rs + p0 * kRS);       // 64·204 bytes = 816 16-byte pieces; rs is 256-byte aligned
+    const unsigned pieces = (np * kRS + 15) / 16;      // (the buffer has room for whole chunks: pk_cap is padded)
+    for (unsigned i = lane; i < pieces; i += 64) reinterpret_cast<uint4 *>(st)[i] = src[i];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    rs_decode_wave(g, pk[wv], po[wv], synd[wv], &key[wv], tc.rs, tc.rts, p, lane, &tc.rs_errs);
+    unsigned r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    if ((unsigned)lane < np) {
+      // four bytes per step: the register's top four coefficients ⊕ the next four packet bytes leave through four INDEPENDENT table
+      // rows (R·x^4 + b0·x^19 + … + b3·x^16 mod G), 51 dependent steps per packet instead of 204
+      const unsigned *pk = reinterpret_cast<const unsigned *>(st + lane * kRS);
+#pragma unroll 3
+      for (int i = 0; i < kRS / 4; ++i) {
+        const unsigned t = __builtin_bswap32(pk[i]) ^ r3;
+        const uint4 a = T[3][t >> 24], b = T[2][(t >> 16) & 255u], c = T[1][(t >> 8) & 255u], d = T[0][t & 255u];
+        r3 = r2 ^ a.w ^ b.w ^ c.w ^ d.w;
+        r2 = r1 ^ a.z ^ b.z ^ c.z ^ d.z;
+        r1 = r0 ^ a.y ^ b.y ^ c.y ^ d.y;
+        r0 = a.x ^ b.x ^ c.x ^ d.x;
+      }
+    }
+    const unsigned long long bad = __ballot((r0 | r1 | r2 | r3) != 0u);
+    // the 64 messages: 188 = 47 dwords of every 51-dword packet, contiguous in the output
+    unsigned *dst = reinterpret_cast<unsigned *>(tc.rts + p0 * kTS);
+    const unsigned words = np * (kTS / 4);
+    for (unsigned o = lane; o < words; o += 64) {
+      const unsigned pkt = o / 47u, j = o - pkt * 47u;
+      const unsigned w = reinterpret_cast<const unsigned *>(st)[pkt * 51u + j];
+      dst[o] = w;
+      if (j == 0) tc.first[p0 + pkt] = (unsigned char)w;
+    }
+    for (unsigned long long m = bad; m; m &= m - 1) {  // wave-uniform: the packets the channel damaged, by the whole wavefront
+      const int q = __builtin_ctzll(m);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      rs_decode_wave(g, st + q * kRS, po[wv], synd[wv], &key[wv], tc.rs, tc.rts, p0 + q, lane, &tc.rs_errs, tc.first);
+    }
   }
 }
 
-// derandomizer::run (dvb.h:1131-1160) from a freshly constructed block: flags, offsets, then the XOR; the capture's result record
+// derandomizer::run (dvb.h:1131-1160) from a freshly constructed block.  The PRBS offset of packet p is 188·(p − r) mod 1504 with r the last
+// packet at or before p whose first byte is the inverted sync (0xB8, or 0xB8 ^ 0x55 where rs_decoder marked it uncorrectable) — 0 + 188·p
+// before the first one; a packet is kept when its restored first byte is 0x47.  One workgroup per capture, ONE pass: every thread owns a
+// run of consecutive packets (their first bytes were set aside by k_tail_rs: contiguous), the runs' "last reset" and "kept" totals are
+// scanned across the workgroup, then every thread walks its run again.  The capture's result record is written here.
 __global__ __launch_bounds__(1024) void k_tail_derand_scan(tail_args A) {
   tail_cap &tc = A.caps[blockIdx.y];
-  __shared__ derand_result r;
-  if (threadIdx.x == 0) { r.produced = 0; r.pos_end = 0; }
+  __shared__ long long s_last[16];
+  __shared__ unsigned s_cnt[16];
+  const unsigned n = (unsigned)tc.n_pk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned per = (n + 1023u) / 1024u, lo = tid * per < n ? tid * per : n, hi = lo + per < n ? lo + per : n;
+  const unsigned char *first = tc.first;
+  auto is_reset = [](unsigned char b) { return b == kSyncInv || b == (kSyncInv ^ kCorrupt); };
+  // pass 1: the last reset inside my run
+  long long last = -1;
+  for (unsigned p = lo; p < hi; ++p) if (is_reset(first[p])) last = (long long)p;
+  long long ilast = last;                                   // inclusive max-scan
+  for (int d = 1; d < 64; d <<= 1) { const long long o = __shfl_up(ilast, d, 64); if (lane >= (unsigned)d && o > ilast) ilast = o; }
+  if (lane == 63) s_last[wv] = ilast;
   __syncthreads();
-  derand_scan_body(tc.rts, (unsigned)tc.n_pk, 0, A.pattern, tc.pkt_pos, tc.pkt_dst, &r);
+  long long before = -1;                                    // last reset strictly in front of my run
+  for (unsigned i = 0; i < wv; ++i) if (s_last[i] > before) before = s_last[i];
+  { const long long up = __shfl_up(ilast, 1, 64); if (lane > 0 && up > before) before = up; }
+  // pass 2a: how many of my packets are kept
+  auto pos_of = [](unsigned p, long long r) { return (int)((r >= 0 ? (long long)(p - (unsigned)r) * kTS : (long long)p * kTS) % 1504); };
+  unsigned keep = 0;
+  {
+    long long r = before;
+    for (unsigned p = lo; p < hi; ++p) {
+      const unsigned char b0 = first[p];
+      if (is_reset(b0)) r = (long long)p;
+      keep += (unsigned char)(b0 ^ A.pattern[pos_of(p, r)]) == kSync ? 1u : 0u;
+    }
+  }
+  unsigned icnt = keep;
+  for (int d = 1; d < 64; d <<= 1) { const unsigned o = __shfl_up(icnt, d, 64); if (lane >= (unsigned)d) icnt += o; }
+  if (lane == 63) s_cnt[wv] = icnt;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    tc.n_ts = r.produced;
+  unsigned long long off = 0;
+  for (unsigned i = 0; i < wv; ++i) off += s_cnt[i];
+  off += icnt - keep;
+  // pass 2b: offsets and destinations
+  {
+    long long r = before;
+    for (unsigned p = lo; p < hi; ++p) {
+      const unsigned char b0 = first[p];
+      if (is_reset(b0)) r = (long long)p;
+      const int pos = pos_of(p, r);
+      const bool k = (unsigned char)(b0 ^ A.pattern[pos]) == kSync;
+      tc.pkt_pos[p] = pos;
+      tc.pkt_dst[p] = k ? (long long)off : -1;
+      off += k ? 1u : 0u;
+    }
+  }
+  if (tid == 1023) {
+    unsigned long long tot = 0;
+    for (int i = 0; i < 16; ++i) tot += s_cnt[i];
+    tc.n_ts = tot;
     tail_result o;
-    o.n_ts = r.produced; o.n_rs = tc.n_pk; o.rs_bit_errors = tc.rs_errs; o.symbols = *tc.nsym;
+    o.n_ts = tot; o.n_rs = tc.n_pk; o.rs_bit_errors = tc.rs_errs; o.symbols = *tc.nsym;
     o.bytes_deconv = tc.bw; o.bytes_mpeg = tc.mw;
     o.next_sync_calls = tc.next_sync_calls; o.locked_at_end = (unsigned)tc.ms.synchronized; o.alignment = (unsigned)tc.locked;
     o.bitphase = (unsigned)tc.ms.bitphase; o.first_lock_byte = tc.first_lock;
@@ -357,16 +518,18 @@ __global__ __launch_bounds__(1024) void k_tail_derand_scan(tail_args A) {
     __threadfence_system();
   }
 }
+// the XOR, 47 dwords per packet (packets, pattern offsets and destinations are all multiples of 4 bytes)
 __global__ __launch_bounds__(256) void k_tail_derand_apply(tail_args A) {
   const tail_cap &tc = A.caps[blockIdx.y];
   const unsigned n = (unsigned)tc.n_pk;
   const unsigned lane = threadIdx.x & 63;
+  const unsigned *in = reinterpret_cast<const unsigned *>(tc.rts);
+  unsigned *out = reinterpret_cast<unsigned *>(tc.ts);
   for (unsigned p = blockIdx.x * 4 + (threadIdx.x >> 6); p < n; p += gridDim.x * 4) {
     const long long dst = tc.pkt_dst[p];
     if (dst < 0) continue;   // restored sync != 0x47: TEI would be set in a slot that is never committed (dvb.h:1149-1156)
     const int pos = tc.pkt_pos[p];
-    for (unsigned i = lane; i < (unsigned)kTS; i += 64)
-      tc.ts[(unsigned long long)dst * kTS + i] = tc.rts[(unsigned long long)p * kTS + i] ^ A.pattern[pos + i];
+    if (lane < 47) out[(unsigned long long)dst * 47 + lane] = in[(unsigned long long)p * 47 + lane] ^ reinterpret_cast<const unsigned *>(A.pattern + pos)[lane];
   }
 }
 

@@ -22,8 +22,8 @@ static int tail_alloc(lsdr_tail *t, void **p, size_t bytes) {
   return LSDR_OK;
 }
 
-int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, lsdr_tail **out) {
-  LSDR_ARG(c && out && n >= 1 && sym_cap >= 1);
+int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, unsigned window, lsdr_tail **out) {
+  LSDR_ARG(c && out && n >= 1 && sym_cap >= 1 && window >= 2048);      // (mpeg_sync's search needs 204·8 + 1 bytes in one call)
   LSDR_HIP(hipSetDevice(c->device));
   lsdr_tail *t = new lsdr_tail();
   t->ctx = c; t->n = n; t->sym_cap = sym_cap;
@@ -43,6 +43,12 @@ int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, lsdr_tai
   memset(&t->A.ms0, 0, sizeof(t->A.ms0));
   t->A.ms0.scan_syncs = 8; t->A.ms0.want_syncs = 4; t->A.ms0.lock_timeout = 4; t->A.ms0.resync_period = 1;      // dvb.h:727-731
   t->A.gtab = tab;
+  t->A.window = window;
+  {
+    uint8_t G[17];
+    lsdr_rs_tables(nullptr, nullptr, G);                                // G[i] = coefficient of x^(16−i) (rs.h:93-105); G[0] = 1
+    for (int m = 0; m < 16; ++m) t->A.rs_g[m] = G[1 + m];
+  }
   t->A.pattern = t->der->d_pattern;
   t->caps.assign(n, tail_cap());
   LSDR_HIP(hipMalloc((void **)&t->d_caps, n * sizeof(tail_cap)));
@@ -54,9 +60,10 @@ int lsdr_tail_create(lsdr_ctx *c, unsigned n, size_t sym_cap, int rate, lsdr_tai
     memset(&tc, 0, sizeof(tc));
     LSDR_TRY(tail_alloc(t, (void **)&tc.bytes, t->byte_cap + 64));
     LSDR_TRY(tail_alloc(t, (void **)&tc.mpeg, t->byte_cap + 64));
-    LSDR_TRY(tail_alloc(t, (void **)&tc.rs, t->pk_cap * kRS));
+    LSDR_TRY(tail_alloc(t, (void **)&tc.rs, (t->pk_cap + kRsChunk) * kRS + 64));        // (k_tail_rs stages 16-byte pieces: room behind the last packet)
     LSDR_TRY(tail_alloc(t, (void **)&tc.rts, t->pk_cap * kTS));
     LSDR_TRY(tail_alloc(t, (void **)&tc.ts, t->pk_cap * kTS));
+    LSDR_TRY(tail_alloc(t, (void **)&tc.first, t->pk_cap + kRsChunk));
     LSDR_TRY(tail_alloc(t, (void **)&tc.pkt_pos, t->pk_cap * sizeof(int)));
     LSDR_TRY(tail_alloc(t, (void **)&tc.pkt_dst, t->pk_cap * sizeof(long long)));
     tc.byte_cap = t->byte_cap; tc.pk_cap = t->pk_cap;

@@ -52,7 +52,7 @@ def test_every_capture_decodes_to_the_reference_ts(capi, anf, tile):
         job.close()
 
 
-def _chain_reference(capi, ctx, words, nsym, byte_cap):
+def _chain_reference(capi, ctx, words, nsym, byte_cap, window):
     """The FEC tail driven by the HOST through the one-block-per-call C ABI (bench_c1.Worker.finish's loop): the checker of the
     device-resident control flow.  `words`: the packed decisions on the device.  Returns (deconvolved bytes, mpeg bytes, TS bytes, stats)."""
     lib = capi.lib
@@ -63,7 +63,7 @@ def _chain_reference(capi, ctx, words, nsym, byte_cap):
     pos = bw = br = mw = 0
     next_sync = 0
     while True:
-        cap = byte_cap - bw if msync.locked else min(65536, byte_cap - bw)
+        cap = byte_cap - bw if msync.locked else min(window, byte_cap - bw)
         c, p = dec.run_dev_hs2(words, pos, nsym - pos, d_bytes.at(bw), cap)
         if not p:
             break
@@ -101,7 +101,8 @@ def _rotate_u8(iq, quarter_turns):
     return np.ascontiguousarray(a).reshape(-1)
 
 
-def test_device_resident_tail_equals_the_host_driven_block_chain(capi, ctx):
+@pytest.mark.parametrize("window", [0, 65536])
+def test_device_resident_tail_equals_the_host_driven_block_chain(capi, ctx, window):
     import bench_c1
     n = 8 << 20
     gen = bench_c1.Generator(capi, ctx, n, 1)
@@ -120,14 +121,14 @@ def test_device_resident_tail_equals_the_host_driven_block_chain(capi, ctx):
     variants.append(("noise only (never locks)", rng.integers(96, 160, 2 * n, dtype=np.uint8).astype(np.uint8)))
     short = base[: 2 * 70000].copy()
     bufs = [ctx.upload(v) for _, v in variants]
-    cb = capi.CaptureBatch(ctx, len(variants), n, bench_c1.OMEGA, anf=0, tile_len=2048, tile_warmup=512)
+    cb = capi.CaptureBatch(ctx, len(variants), n, bench_c1.OMEGA, anf=0, tile_len=2048, tile_warmup=512, unlocked_window=window)
     try:
         res, ts = cb.decode([b.ptr for b in bufs], n)
         for i, (name, _) in enumerate(variants):
             r = res[i]
             words_dev = capi.lib.lsdr_capture_batch_words_dev(cb.h, i)
             byte_cap = int(n * 0.94 + 65536) // 8 + 65536
-            want_bytes, want_mpeg, want_ts, st = _chain_reference(capi, ctx, words_dev, r["symbols"], byte_cap)
+            want_bytes, want_mpeg, want_ts, st = _chain_reference(capi, ctx, words_dev, r["symbols"], byte_cap, cb.unlocked_window)
             got_bytes = cb.stage_bytes(i, "deconv", r["bytes_deconv"])
             got_mpeg = cb.stage_bytes(i, "mpeg", r["bytes_mpeg"])
             assert r["bytes_deconv"] == len(want_bytes) and got_bytes.tobytes() == want_bytes.tobytes(), name

@@ -58,3 +58,16 @@ def test_c1_four_ranks_on_one_gpu():
     assert j["n_gpus"] == 4 and j["value"] > 0
     v = j["verified"]
     assert v["ranks"] == 4 and v["ranks_passed"] == 4 and v["pass"], v
+
+
+def test_c1_eight_ranks_on_one_gpu():
+    """BASELINE config 4's process count — eight ranks, one lsdr_capture_batch engine each (two streams, ONE host thread, the runtime's
+    default hardware queues) — on GPU 0: what an 8-GPU node runs per GPU, eight times over on one; every rank verifies its captures' TS
+    against the reference binary's."""
+    if not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "leandvb")):
+        pytest.fail("oracle/_ref/leandvb is missing on the GPU box")
+    j = _run(["--workload", "c1", "--c1-captures", "2", "--c1-msamples", "8"], ranks=8)
+    assert j["n_gpus"] == 8 and j["value"] > 0 and j["config"]["captures_per_gpu"] == 2
+    assert "lsdr_capture_batch" in j["config"]["engine"]
+    v = j["verified"]
+    assert v["ranks"] == 8 and v["ranks_passed"] == 8 and v["pass"], v
