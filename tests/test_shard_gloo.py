@@ -71,7 +71,7 @@ def test_bench_c1_workload_self_launches_ranks():
     assert j["workload"] == "c1" and j["n_gpus"] == 2 and j["ranks"] == 2 and j["units"] == 3000.0
     # every rank gives its captures their own noise seeds (gathered from the ranks, computed by the function the real run calls)
     seeds = j["capture_seeds_by_rank"]
-    assert len(seeds) == 2 and all(len(s) == 16 for s in seeds)
+    assert len(seeds) == 2 and all(len(s) == 32 for s in seeds)      # --c1-captures defaults to 32 per GPU
     flat = [v for s in seeds for v in s]
     assert len(set(flat)) == len(flat) == 32 and seeds[0][0] == 1000 and seeds[1][0] == 2000
 
