@@ -73,7 +73,7 @@ def test_bench_c1_workload_self_launches_ranks():
     seeds = j["capture_seeds_by_rank"]
     assert len(seeds) == 2 and all(len(s) == 32 for s in seeds)      # --c1-captures defaults to 32 per GPU
     flat = [v for s in seeds for v in s]
-    assert len(set(flat)) == len(flat) == 32 and seeds[0][0] == 1000 and seeds[1][0] == 2000
+    assert len(set(flat)) == len(flat) == 64 and seeds[0][0] == 1000 and seeds[1][0] == 2000
 
 
 def test_c1_job_seeds_come_from_capture_seeds():
