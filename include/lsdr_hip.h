@@ -267,8 +267,8 @@ enum {
   LSDR_FIR_MFMA_BLK = 3 /* block-polyphase form on the matrix pipe (a dense product): the taps in blocks of `decim`, each block an
                        * fmaf chain from zero in tap order, the block sums added in block order, in_scale multiplied into the taps (one
                        * rounding per tap) instead of the samples — its own stated arithmetic (oracle lo_fir_filter_blk), same
-                       * error bound as LSDR_FIR_FMA.  cf32 input, even decimations with a
-                       * compile-time kernel, ncoeffs ≤ 16·decim; refused (LSDR_E_ARG) otherwise. */
+                       * error bound as LSDR_FIR_FMA.  cf32 input, every decimation 2 … 64 (whatever
+                       * Fs / (4·Fm) leandvb.cc:353-378 computes), ncoeffs ≤ 16·decim; refused (LSDR_E_ARG) otherwise. */
 };
 typedef struct {
   unsigned ncoeffs;          /* fir_filter ctor _ncoeffs */

@@ -711,12 +711,80 @@ static_assert(rx_stage<LSDR_IN_CU8>::kRowBytes % 16 == 0 && rx_stage<LSDR_IN_CF3
 static_assert(kChunk % rx_stage<LSDR_IN_CU8>::kStage == 0 && kChunk % rx_stage<LSDR_IN_CF32>::kStage == 0, "stage geometry");
 typedef __attribute__((address_space(3))) void *rx_lds_ptr;
 
+// ---- symbol timing of a wavefront's tiles, fed forward (tolerance tiles, omega ≥ 2) -------------------------------------------------
+// A tile starts in the middle of the stream and has only its warm-up to find the symbol timing; at ≈ 4 samples per symbol a start half a
+// symbol off sits on the Mueller & Müller detector's unstable point (sdr.h:822-840) and a few tiles in a thousand have not left it when
+// their body begins: unreconciled seams, lost packets.  The envelope knows the timing without any loop: |x|² of a pulse-shaped stream has
+// a line at the symbol rate whose phase is the symbol instants' position (Oerder & Meyr) — c = Σ w[n]·|x[n]|²·e^{−j2πn/omega} over kEstSpan
+// samples (Hann-weighted: the window's own leakage of the DC term is what a rectangular one would add), instants at n ≡ τ (mod omega),
+// τ = omega·arg(conj c)/2π.  One estimate at the wavefront's FIRST tile and one at its LAST, the 64 lanes sharing the samples of each
+// (coalesced loads, a wave reduction); every lane takes its own timing from the two — the nominal omega carries the first estimate to its
+// tile, the difference to the second one, spread evenly, is the clock error the nominal omega does not know.  Below 2 samples per symbol
+// the line is aliased — and the detector needs no help there (its pull-in range covers the ±0.6 samples a tile can be off).
+constexpr int kEstSpan = 512;
+template <typename SRC>
+__device__ __forceinline__ float rx_wave_timing(const SRC &src, long long first, long long end, float omega, int lane, float *quality) {
+  float cr = 0.f, sr = 0.f, pw = 0.f;
+  const float w = 1.0f / omega;
+#pragma unroll
+  for (int i = 0; i < kEstSpan / 64; ++i) {
+    const int idx = i * 64 + lane;                                  // (lanes side by side: 512 B per load)
+    if (first + idx < end) {
+      const float2 x = src[first + idx];
+      const float hann = 0.5f - 0.5f * __builtin_amdgcn_cosf((float)idx * (1.0f / kEstSpan));
+      const float p = (x.x * x.x + x.y * x.y) * hann;
+      const float rev = (float)idx * w;
+      const float fr = rev - __builtin_floorf(rev);
+      cr += p * __builtin_amdgcn_cosf(fr); sr += p * __builtin_amdgcn_sinf(fr); pw += p;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { cr += __shfl_xor(cr, d, 64); sr += __shfl_xor(sr, d, 64); pw += __shfl_xor(pw, d, 64); }
+  *quality = pw > 0.f ? __builtin_sqrtf(cr * cr + sr * sr) / pw : 0.f;
+  float rev = atan2f(sr, cr) * 0.15915494f;                          // power peaks where 2π·n/omega ≡ arg(Σ p·e^{+jθ})
+  rev -= __builtin_floorf(rev);
+  return rev * omega;                                                // first symbol instant at or behind `first`, in samples
+}
+
 template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane, char *lds) {
   const bool valid = lane < (int)a.lanes_per_wave && j0 + (unsigned)lane < a.n_tiles;
+  const rx_consts &C = a.C;
+  // fed-forward symbol timing (all 64 lanes take part): per GROUP of 32 consecutive tiles — tiles 1 + 32g … 32g + 32, whatever the
+  // lanes per wavefront, like the estimator maps: a run is the same bits with 32 or 64 tiles per wavefront — one estimate at the group's
+  // first tile and one at its last
+  float est_first = 0.f, est_step = 0.f;
+  bool est_ok = false;
+  unsigned est_j0 = j0;
+  if (SAMP != 2 && C.omega >= 2.0f && (a.lanes_per_wave == 32u || a.lanes_per_wave == 64u)) {
+    const long long end = (long long)a.total_chunks * kChunk + (SAMP == 1 ? 1 : 0);
+    const typename in_stream<FMT>::type all = in_make<FMT>(a.in);
+    for (unsigned g = 0; g < a.lanes_per_wave / 32u; ++g) {
+      const unsigned jf = j0 + 32u * g;
+      if (jf >= a.n_tiles) break;
+      const unsigned jl = jf + 31u < a.n_tiles - 1 ? jf + 31u : a.n_tiles - 1;
+      const long long wsf = ((long long)a.first_chunks + (long long)(jf - 1) * a.tile_chunks - a.warm_chunks) * kChunk;
+      const long long wsl = wsf + (long long)(jl - jf) * a.tile_chunks * kChunk;
+      float q0 = 0.f, q1 = 0.f, step = 0.f;
+      const float t0 = rx_wave_timing(all, wsf, end, C.omega, lane, &q0);
+      const bool ok = q0 > 0.02f && wsf + kEstSpan <= end;
+      if (ok && jl > jf && wsl + kEstSpan <= end) {
+        const float t1 = rx_wave_timing(all, wsl, end, C.omega, lane, &q1);
+        if (q1 > 0.02f) {
+          // what the nominal omega predicts at the last tile, against what is measured there: the difference (within half a symbol) is
+          // the clock error over the group's span
+          const double span = (double)(wsl - wsf), om = (double)C.omega;
+          double pred = (double)t0 - span; pred -= om * __builtin_floor(pred / om);
+          float d = t1 - (float)pred;
+          d -= C.omega * __builtin_rintf(d / C.omega);
+          step = d / (float)(jl - jf);
+        }
+      }
+      if ((unsigned)lane / 32u == g || a.lanes_per_wave == 32u) { est_first = t0; est_step = step; est_ok = ok; est_j0 = jf; }
+    }
+  }
   if (!LDS && !valid) return;                            // (LDS: every lane takes part in the stage loads)
   const unsigned j = valid ? j0 + (unsigned)lane : j0;
-  const rx_consts &C = a.C;
   const unsigned long long c0 = a.first_chunks + (unsigned long long)(j - 1) * a.tile_chunks;
   unsigned long long c1 = c0 + a.tile_chunks;
   if (c1 > a.total_chunks) c1 = a.total_chunks;
@@ -762,7 +830,31 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   float fwin = 65536.0f / C.omega / 2048.0f;
   if (fwin < 8.f) fwin = 8.f;
   const float f_lo = freqw - fwin, f_hi = freqw + fwin;
+  // Symbol timing at the tile's first sample, PREDICTED from the carried state: the run's first sample is S->mu samples in front of a symbol
+  // instant and the instants are omega apart (the loop holds omega fixed, sdr.h:738-743), so the first instant at or behind sample ws is
+  // omega − fmod(ws − S->mu, omega) away.  Exact for a stream at the nominal symbol rate — then a tile starts where the sequential loop is
+  // and its warm-up has nothing to acquire; with a clock error e the prediction is off by e·ws samples, i.e. for long runs as good as the
+  // mu = 0 every tile started with before (the warm-up acquires, as before).  Why: at ≈ 4 samples per symbol a tile that starts half a
+  // symbol off sits on the timing detector's unstable point and may not have left it when its body begins — 0.2 % of the tiles of the
+  // reference benchmark's 4.2-sps series (profiles/r06_sensitivity: unreconciled seams, lost packets); integer omega hid it.
   float mu = 0.f, phase = 0.f;
+  {
+    const double ws = (double)cb * kChunk - (double)S->mu, om = (double)C.omega;
+    const double r = ws - om * __builtin_floor(ws / om);
+    mu = (float)(r > 0.0 ? om - r : 0.0);
+    if (est_ok) {
+      // omega ≥ 2: the measured timing — unless the prediction agrees with it within a third of a sample: then the stream runs at the
+      // nominal rate and the prediction is the better figure (it has no estimation noise; what matters is only never to start near the
+      // detector's unstable point, half a symbol off)
+      const double off = (double)(j - est_j0) * a.tile_chunks * kChunk;      // this tile's start behind its group's first
+      double t = (double)est_first + (double)est_step * (double)(j - est_j0) - off;
+      t -= om * __builtin_floor(t / om);
+      float dm = (float)t - mu;
+      dm -= C.omega * __builtin_rintf(dm / C.omega);
+      if (__builtin_fabsf(dm) > 0.33f) mu = (float)t;
+    }
+    if (!(mu >= 0.f && mu < C.omega)) mu = 0.f;
+  }
   float h0pr = 0.f, h0pi = 0.f, h0cr = 0.f, h0ci = 0.f, h1pr = 0.f, h1pi = 0.f, h1cr = 0.f, h1ci = 0.f;
   float h2pr = 0.f, h2pi = 0.f, h2cr = 0.f, h2ci = 0.f;
   const float kk = C.kest, k1 = 1 - C.kest;

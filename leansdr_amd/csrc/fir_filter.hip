@@ -38,6 +38,21 @@
 // + 8/D written.  N/D·{4|8} VALU lane-ops and N/D LDS 8-byte reads per input
 // sample.
 #include "lsdr_internal.h"
+#define LSDR_STREAM_NS lsdr_fir_main
+#include "fir_stream.h"
+using namespace lsdr_fir;
+using namespace lsdr_fir_main;
+
+// fir_stream_sweep.hip, one translation unit per part: the stream kernel of decimation D ≡ part (mod 8), 2 … 64 without 10 and 30
+// (eleven: the form with 11 tap blocks as a compile-time constant)
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_0(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_1(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_2(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_3(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_4(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_5(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_6(unsigned D, bool cplx, bool eleven);
+lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_7(unsigned D, bool cplx, bool eleven);
 
 namespace {
 
@@ -46,36 +61,6 @@ namespace {
 #endif
 constexpr int kThreads = LSDR_FIR_THREADS;   // lanes (= outputs, R = 1) per workgroup tile
 
-struct fir_args {
-  const void *in;        // cf32 or cu8 samples
-  float2 *out;
-  const float2 *sc;      // shifted coefficients [N]   (complex kernels)
-  const float *rc;       // real coefficients   [N]   (real kernel)
-  const float2 *scp;     // zero-padded to ncols·D taps (persistent kernels)
-  const float *rcp;
-  unsigned ncols;
-  unsigned N, D;
-  unsigned S;            // LDS row stride in samples (odd)
-  unsigned long long count;      // outputs to produce
-  unsigned long long n_in;       // input samples available
-  unsigned n_tiles, tiles_per_xcd;
-  // lsdr_fir_filter_run_multi (persistent kernels): the same filter over n_streams equal-length buffers in one launch;
-  // global tile g = stream·tiles_per_stream + local tile.  n_streams = 1: in/out above.
-  unsigned n_streams, tiles_per_stream;
-  const void *ins[8];
-  float2 *outs[8];
-  float in_scale;        // 1.0f → none
-  // k_fir_mfma: coefficient operand table (zero-padded, lsdr_fir_filter::d_atab), its length, blocks of four MFMA steps
-  const float *mf_atab;
-  unsigned mf_alen, mf_blocks;
-  unsigned long long *trace;   // LSDR_FIR_TRACE builds: per-wave phase cycle sums
-  // k_fir_mfma_stream<…, IV = 1> (the fused auto_notch + fir_filter of notch.hip): the coefficient operand changes along the
-  // stream — mf_atab holds n_iv tables of KS·64 floats, table i serves the tiles from iv_tile_first[i] on (ascending, [0] = 0)
-  const unsigned *iv_tile_first;
-  unsigned n_iv;
-  unsigned xcd_rot;            // k_fir_mfma_stream: XCD x starts its walk x·xcd_rot tiles into its range (wrapping): see lsdr_fir_filter::stream_xrot
-  unsigned chunked;            // k_fir_mfma_stream: a workgroup's tiles are CONSECUTIVE (one stretch of its XCD's range) instead of strided
-};
 
 // Staging is split into the global load (raw bits kept in two VGPRs) and the
 // conversion applied just before the LDS write.
@@ -108,12 +93,6 @@ __device__ __forceinline__ float2 finish_sample(float2 raw, float scale) {
 // Coefficients are read through the CONSTANT address space: they are never written
 // while a kernel runs, and this guarantees wave-uniform scalar (s_load) access even in
 // the persistent kernel, where stores to `out` precede later coefficient loads.
-// cache policy of the streaming sample loads (buffer_load aux bits on gfx94x/gfx950: 1 = sc0, 2 = nt, 16 = sc1)
-#ifndef LSDR_FIR_LOAD_AUX
-#define LSDR_FIR_LOAD_AUX 2
-#endif
-typedef float lsdr_v2f __attribute__((ext_vector_type(2)));
-typedef unsigned lsdr_v2u __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) lsdr_v2f *cptr2;
 typedef const __attribute__((address_space(4))) float *cptr1;
 
@@ -415,8 +394,6 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(1, 2))
 //     re: fma(−ci, xi, fma(cr, xr, acc))     im: fma(ci, xr, fma(cr, xi, acc)) = fma(−ci, −xr, fma(cr, xi, acc)).
 // Staging, prefetch of the next tile into registers during the MFMA phase, persistence and the XCD-aware tile walk are
 // k_fir_persist's.  W = wavefronts per workgroup (tile = 128·W outputs; LDS ≈ 8·D·128·W bytes).
-typedef float lsdr_v4f __attribute__((ext_vector_type(4)));
-typedef unsigned lsdr_v4u __attribute__((ext_vector_type(4)));
 
 #ifndef LSDR_MFMA_PARTS
 #define LSDR_MFMA_PARTS 8
@@ -855,272 +832,6 @@ __global__ __launch_bounds__(64 * W) void k_fir_mfma_blk(fir_args a) {
 #endif
 }
 
-// ---- k_fir_mfma_stream: LSDR_FIR_MFMA_BLK without a staging phase ---------------------------------------------
-// k_fir_mfma_blk's trace: the MFMAs themselves are 43 % of a tile; the rest is the wave standing in the vector-memory queue
-// with the next tile's loads (in-order issue: a load that cannot be queued blocks the MFMAs behind it), then waiting for them,
-// writing 64 KB from registers to LDS, and two barriers.  None of that is needed.  A wavefront walks its 128 rows in order —
-// once the sample operands of a pair of row tiles are in registers those 16 rows of LDS are dead — so the NEXT tile's rows are
-// loaded straight into them (buffer_load … lds: no registers, no LDS-write instructions, the wave never waits for the queue's
-// data, only for its slots) while the wave goes on with the following pairs; they are read again seven pairs later.
-// Every wavefront is its own workgroup with a private region (128 rows + the K padding's read-ahead, natural sample order)
-// and a private Z ring: no barrier anywhere.  Samples reach the MFMA untouched (the fused scaler rides on the taps, as in
-// k_fir_mfma_blk), so the arithmetic is k_fir_mfma_blk's, bit for bit.
-// Decimations whose row stride needs no padding (2·D ≡ 4 mod 8: 10, 30) — LDS-direct loads write 1 KiB of consecutive bytes.
-typedef __attribute__((address_space(3))) void *fir_lds_ptr;
-
-// IV = 1: the taps are a function of the position in the stream (fir_args::iv_tile_first): a wavefront walks its tiles in
-// ascending order, so it reloads the coefficient operand the (few) times it crosses into another interval — behind a vmcnt(0),
-// so that the hand-counted waits below never see these loads.  One stream per launch.
-// The IV launch is OVERSUBSCRIBED (64 workgroups per CU queued, each with a short tile list): with four 39 KB workgroups per CU a grid of
-// exactly the resident workgroups is only resident in full while nothing else holds LDS — next to cstln_receiver's staged tiles (9 KB
-// per wavefront) some workgroups started when others ENDED and the launch took 1.19 ms instead of 0.76 (256 Mi samples); with 16–32 per CU
-// the dispatcher deals the work: 0.80 ms.  (Tiles dealt by a per-XCD atomic counter, one returned atomic per tile: 0.96 ms alone — dropped.)
-// NP = pairs of row tiles per wave tile (16 rows each): 8 → a region of 128 rows (38–39 KB of LDS with its ring: four wavefronts per CU, 117
-// outputs per 128 rows at 12 tap blocks) — real taps, HBM-bound; 4 → 64 rows, 53 outputs per 64 rows, ring folded to 48 rows (FOLD below):
-// 19.6–20.4 KB, EIGHT per CU — complex taps and the IV pass, which are bound by what the wavefronts of a CU overlap (3.44 → 4.0 TB/s alone,
-// 0.65 ms per 256 Mi samples for the IV pass); 6 → 96 rows (30 KB, five per CU: 3.76).  The outputs do not depend on it.
-template <int DT, int CP, int NQT, int IV = 0, int NP = 8>
-__global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr unsigned D = DT, SL = 1 + CP;
-  static_assert(DT % 2 == 0 && blk_padf(DT) == 0, "row stride must be bank-friendly without padding");
-  constexpr unsigned KP = (D * SL + 3) / 4 * 4, KS = KP / 4;
-  constexpr unsigned FP = ((KP / SL - D) + 1) & ~1u;              // samples in front of row 0 that the K padding reads
-  constexpr unsigned ROWB = D * 8, PAIRG = 8 * D;                 // bytes per row; 16-byte granules per pair of row tiles
-  constexpr unsigned RW = 16 * NP;                                // rows (blocks of D samples) per wave tile
-  static_assert(NP >= 4 && NP % 2 == 0, "whole diagonal batches of two pairs; the wait counts assume NP >= 3");
-  constexpr unsigned REGB = FP * 8 + RW * ROWB;                   // region bytes
-  constexpr unsigned NLI = (PAIRG + FP / 2 + 63) / 64;            // LDS-direct loads per refill group
-  const unsigned l = threadIdx.x;
-  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks, MW = RW - (NQ - 1);
-  constexpr int NQR = NQT ? NQT : 16;
-  const unsigned ROWZ = 2 * (NQ | 1u);
-  char *const ring = smem_raw + ((REGB + 15) & ~15u);       // 64 rows + rows 0…15 once more as rows 64…79 (see k_fir_mfma_blk)
-  const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-  // this XCD's tiles [xcd·tiles_per_xcd, + xcnt), walked from tile x·xcd_rot of the range on, wrapping (xcd_rot = 0: from its start)
-  const unsigned xbase = xcd * a.tiles_per_xcd;
-  const unsigned xcnt = xbase >= a.n_tiles ? 0u : (a.n_tiles - xbase < a.tiles_per_xcd ? a.n_tiles - xbase : a.tiles_per_xcd);
-  const unsigned xrot = xcnt ? (unsigned)(((unsigned long long)xcd * a.xcd_rot) % xcnt) : 0u;
-  auto tile_of = [&](unsigned ti) { const unsigned p = ti + xrot; return xbase + (p >= xcnt ? p - xcnt : p); };
-  // a workgroup's tile list: strided (slot, slot + slots, …: at any moment the XCD's workgroups read one narrow window of its range) or one
-  // consecutive stretch of ⌈xcnt/slots⌉ tiles (a workgroup stays inside one or two 2 MiB pages: see lsdr_fir_filter::stream_chunked)
-  const unsigned per = a.chunked ? (xcnt + slots - 1) / slots : 0u;
-  const unsigned t_first = a.chunked ? slot * per : slot, t_step = a.chunked ? 1u : slots;
-  const unsigned t_lim = a.chunked ? (t_first + per < xcnt ? t_first + per : xcnt) : xcnt;
-  auto valid = [&](unsigned ti) { return ti < t_lim; };
-
-  float bco[KS];
-  unsigned iv_cur = 0;
-  if (!IV) {
-#pragma unroll
-    for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[s * 64 + l];
-  }
-
-  // The region of wave tile `lt` of a stream: row ρ = output-row p = lt·MW − (NQ−1) + ρ, i.e. samples
-  // x[N + D·p − (D−1) … N + D·p]; region sample 0 is x[X0], X0 = N + 1 − D·NQ − FP + D·MW·lt (negative at the stream start:
-  // those samples meet zero taps — the clamped resource makes their offsets wrap out of range: zeros).
-  __amdgpu_buffer_rsrc_t rsrc;
-  unsigned adj = 0;
-  auto aim = [&](unsigned tile, bool live) {
-    const unsigned st = live ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
-    const long long j0 = (long long)a.N + 1 - (long long)(D * NQ) - (long long)FP + (long long)lt * MW * D;
-    const long long jb = j0 < 0 ? 0 : j0;
-    const unsigned long long bytes = live ? (a.n_in - (unsigned long long)jb) * 8ull : 0ull;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
-                                             (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
-    adj = (unsigned)((jb - j0) * 8);
-  };
-  // refill group P = the granules pair P reads first (its rows; pair 0 also the front padding)
-  auto refill = [&](int P) {
-    const unsigned g0 = P ? FP / 2 + (unsigned)P * PAIRG : 0u, g1 = FP / 2 + (unsigned)(P + 1) * PAIRG;
-#pragma unroll
-    for (unsigned i = 0; i < NLI; ++i) {
-      const unsigned g = g0 + 64 * i + l;
-#ifdef LSDR_STREAM_NOLOAD      // measurement build: the compute side alone (results are garbage)
-      if (g == 0xffffffffu)
-#else
-      if (g0 + 64 * i + 64 <= g1 || g < g1)      // (whole loads: no lane mask)
-#endif
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (fir_lds_ptr)(size_t)(unsigned)(unsigned long long)(smem_raw + 16 * (g0 + 64 * i)), 16,
-                                                 16 * g - adj, 0, 0, LSDR_FIR_LOAD_AUX);
-    }
-  };
-
-  unsigned ti = t_first;
-  if (!valid(ti)) return;
-#ifdef LSDR_STREAM_PRIO
-  __builtin_amdgcn_s_setprio(LSDR_STREAM_PRIO);
-#endif
-  if (IV) {      // the interval of the first tile
-    const unsigned t0 = tile_of(ti);
-    while (iv_cur + 1 < a.n_iv && t0 >= a.iv_tile_first[iv_cur + 1]) ++iv_cur;
-#pragma unroll
-    for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (KS * 64) + s * 64 + l];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
-  aim(tile_of(ti), true);
-#pragma unroll
-  for (int P = 0; P < NP; ++P) refill(P);
-
-  // per-lane cursors (see k_fir_mfma_blk); the sample operand of K slot r' of row ρ is the sample r' BEFORE the row's last one
-  const unsigned kq = l >> 4 & 3u, i16 = l & 15u, beta = i16 >> 1, c = i16 & 1u;
-  const unsigned sub = CP ? (kq & 1u) : 0u;
-  constexpr unsigned ASTEP = CP ? 16 : 32, ATILE = 8 * ROWB;
-  // float index of (row ρ, step s): 2·(FP + D·ρ + D − 1 − r') + comp, r' = CP ? 2·s + (k>>1) : 4·s + k  →  lane part at s = KS−1
-  const int rlast = CP ? 2 * (int)(KS - 1) + (int)(kq >> 1) : 4 * (int)(KS - 1) + (int)kq;
-  const unsigned a0 = (unsigned)(2 * ((int)FP + (int)(D * beta) + (int)D - 1 - rlast) + (int)(c ^ sub)) * 4u;   // bytes, ≥ 0 by FP
-  const unsigned sgn = (CP && sub && c) ? 0x80000000u : 0u;
-  const unsigned zq = l & 15u, zrow = 2 * kq;
-  const unsigned ro = l >> 1, rc = l & 1u;
-  // diagonal sum (rows ascend with the output index here): output of row ρ = 32·B + o is Σ_q Z[ρ − q][q]; its row as 16 … 79
-  // (rows 0…15 are mirrored at 64…79) so that ρ − q needs no wrap; byte offset of term q = 15 for even / odd B, terms with
-  // smaller q `dstep` bytes further on
-  const unsigned dstep = ROWZ * 4 - 8;
-  // NP = 4 (FOLD): a wave tile is 64 ring rows and nothing wraps except the reads of rows 0 … NQ−2, which are not outputs — no mirrored rows
-  // 64 … 79.  And the ring is FOLDED to 48 rows: rows 0 … 15 (pair 0) are dead once the first diagonal batch has read them (during pair 2), so
-  // pair 3's rows 48 … 63 go there; the rows in front of them that the second batch's sums reach back into (37 … 47, pair 2) are written a
-  // second time at rows −16 … −1, i.e. over the LAST sample rows of the region — pair 3's, whose operands are in registers by then and whose
-  // refill is issued after that batch's reads.  20 KB of LDS per wavefront instead of 21–22: EIGHT per CU.
-  constexpr bool MIRROR = NP != 4, FOLD = NP == 4;
-  int dbase[2];
-#pragma unroll
-  for (int par = 0; par < 2; ++par) {
-    const unsigned rr0 = 32u * par + ro, rr = (FOLD && rr0 >= 48) ? rr0 - 48 : rr0, rp = (MIRROR && rr < 16) ? rr + 64 : rr;
-    dbase[par] = (int)((rp * ROWZ + rc) * 4) - 15 * (int)dstep;   // = ((rp − 15)·ROWZ + 2·15 + rc)·4
-  }
-
-  while (true) {
-    const unsigned tile = tile_of(ti);
-    const unsigned tn = ti + t_step;
-    const bool more = valid(tn);
-    const unsigned st = tile / a.tiles_per_stream;
-    const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * MW;
-    float *const po = reinterpret_cast<float *>(a.outs[st]);
-    aim(more ? tile_of(tn) : 0u, more);      // the refills of this iteration fetch the NEXT tile (an empty resource at the end: no traffic)
-    if (IV) {
-      unsigned iv = iv_cur;
-      while (iv + 1 < a.n_iv && tile >= a.iv_tile_first[iv + 1]) ++iv;
-      while (iv > 0 && tile < a.iv_tile_first[iv]) --iv;       // (the walk wraps once when it does not start at the range's first tile)
-      if (iv != iv_cur) {                    // (wave-uniform, a handful of times per launch)
-        iv_cur = iv;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (KS * 64) + s * 64 + l];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-    }
-
-    const char *ap = smem_raw + a0;
-    unsigned pa[2][2][KS];
-    auto fetch1 = [&](int set, int pair, int h, unsigned s) {
-      pa[set][h][s] = *reinterpret_cast<const unsigned *>(ap + (2 * pair + h) * ATILE + (KS - 1 - s) * ASTEP);
-    };
-    auto opnd = [&](unsigned r) { return __uint_as_float(CP ? (r ^ sgn) : r); };
-    lsdr_v4f acc[2][2];
-    auto to_ring = [&](int set, int pair) {
-      if (zq < NQ) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned row0 = (16u * pair + 8u * h + zrow) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
-          const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
-          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
-          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
-          if (FOLD && pair == 2) {            // rows 32 … 47 once more at −16 … −1 (inside the region's last rows: see FOLD)
-            *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = lo;
-            *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 47) * (int)ROWZ + 2 * (int)zq) * 4) = hi;
-          }
-          if (MIRROR && ((16u * pair) & 63u) == 0) {
-            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
-            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
-          }
-        }
-      }
-    };
-    float zv[NQR];
-    auto diag_read = [&](int batch, int q) {
-      zv[q] = *reinterpret_cast<const float *>(ring + (dbase[batch & 1] + (15 - q) * (int)dstep));
-    };
-    float ysum = 0.f;
-    auto diag_add = [&](int q) {
-      const float t = ysum + zv[q];
-      ysum = q == 0 ? zv[0] : (NQT || (unsigned)q < NQ ? t : ysum);
-    };
-    auto diag_store = [&](int batch) {
-      const int rho = 32 * batch + (int)ro;
-      const unsigned long long m = m0 + (unsigned)(rho - (int)(NQ - 1));
-      if (rho >= (int)(NQ - 1) && m < a.count)
-        asm volatile("global_store_dword %0, %1, off" ::"v"(po + 2 * m + rc), "v"(ysum) : "memory");
-    };
-    auto at_step = [](int i, int n, int lo, int hi) { return hi > lo ? lo + i * (hi - lo) / n : lo; };
-
-    // Wait counts (vector-memory operations retire in order; the hidden output stores only make the counter larger, i.e. the
-    // waits stricter).  Refill group j of the previous iteration must have landed before fetch(j).  Behind it in the queue:
-    // the previous iteration's groups j+1 … NP−1 and this iteration's groups issued so far (group P−1 goes out at the END of
-    // pair P, behind fetch(P+1)): fetch(0): NP−1 groups; fetch(1), during pair 0: NP−2; fetch(j ≥ 2), during pair j−1: NP−3.
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 1) * NLI) : "memory");
-#pragma unroll
-    for (unsigned s = 0; s < KS; ++s) { fetch1(0, 0, 0, s); fetch1(0, 0, 1, s); }
-#pragma unroll
-    for (int pair = 0; pair < NP; ++pair) {
-      const int set = pair & 1;
-      if (pair < NP - 1) {
-        if (pair == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 2) * NLI) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 3) * NLI) : "memory");
-      }
-#pragma unroll
-      for (unsigned s = 0; s < KS; ++s) {
-#ifdef LSDR_STREAM_NOMFMA       // measurement build: the memory side alone (one VALU op stands in for each MFMA)
-        if (s == 0) { acc[set][0] = (lsdr_v4f){0.f, 0.f, 0.f, 0.f}; acc[set][1] = acc[set][0]; }
-        acc[set][0][s & 3] += opnd(pa[set][0][s]) * bco[s];
-        acc[set][1][s & 3] += opnd(pa[set][1][s]) * bco[s];
-#else
-        if (s == 0) {
-          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][0][0]), bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][0]), bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-        } else {
-          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][0][s]), bco[s], acc[set][0], 0, 0, 0);
-          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][s]), bco[s], acc[set][1], 0, 0, 0);
-        }
-#endif
-        if (pair < NP - 1 && !(s & 1)) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) { if (s + 1 < KS) fetch1(set ^ 1, pair + 1, h, s + 1); fetch1(set ^ 1, pair + 1, h, s); }
-        }
-        if (pair >= 1 && s == 0) to_ring(set ^ 1, pair - 1);
-        if (pair >= 2 && !(pair & 1)) {
-#pragma unroll
-          for (int q = 0; q < NQR; ++q)
-            if (at_step(q, NQR, KS > 1 ? 1 : 0, KS) == (int)s) diag_read(pair / 2 - 1, q);
-        }
-        if (pair >= 3 && (pair & 1)) {
-#pragma unroll
-          for (int q = 0; q < NQR; ++q)
-            if (at_step(q, NQR, 0, KS) == (int)s) diag_add(q);
-          if (s == KS - 1) diag_store((pair - 3) / 2);
-        }
-        // rows of pair P−1: every operand of them has been consumed by an MFMA by now (program order) — refill them
-        if (pair >= 1 && s == KS - 1) refill(pair - 1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    to_ring((NP - 1) & 1, NP - 1);
-    if (!FOLD) refill(NP - 1);
-#pragma unroll
-    for (int q = 0; q < NQR; ++q) diag_read(NP / 2 - 1, q);
-#pragma unroll
-    for (int q = 0; q < NQR; ++q) diag_add(q);
-    if (FOLD) {                                // the last rows' refill lands on the mirrored ring rows: only after the sums have their terms
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      refill(NP - 1);
-    }
-    diag_store(NP / 2 - 1);
-    if (!more) break;
-    ti = tn;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-typedef void (*fir_kernel_t)(fir_args);
 
 // k_fir_mfma instances: decimations with a compile-time kernel × {2, 4} wavefronts per workgroup × {real, complex} taps; the C2
 // decimation also with the compile-time load counts of its geometry (nl = 32 at W = 2, 31 at W = 4).
@@ -1168,24 +879,25 @@ fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed, unsigned 
     default: return nullptr;
   }
 }
-// np = pairs of row tiles per wave tile (k_fir_mfma_stream NP): 4 exists for the C2 geometry's compile-time kernels only; nullptr = no such kernel
-fir_kernel_t pick_stream(unsigned D, bool cplx, unsigned nq, unsigned np = 8) {
+// The stream kernel of a geometry.  want_np = pairs of row tiles per wave tile asked for (k_fir_mfma_stream NP; 0 = the geometry's
+// default): the C2 geometry (decimation 30, 11 tap blocks) has compile-time forms at 8 (real taps' default), 4 (folded ring: complex
+// taps' default) and 6; decimations 10 and 30 run-time tap blocks at 8; every other decimation 2 … 64 comes from the sweep
+// (fir_stream_sweep.hip: 8 up to D = 34, 4 unfolded above).  A want_np the geometry has no kernel for gets the default one.  k = nullptr:
+// no stream kernel (D = 1, D > 64).
+stream_kernel pick_stream(unsigned D, bool cplx, unsigned nq, unsigned want_np = 0) {
   const char *e = getenv("LSDR_MFMA_NQT");                 // test hook: 0 forces the run-time-NQ kernels
-  if (np == 4) return D == 30 && nq == 11 && !(e && !atoi(e)) ? (cplx ? k_fir_mfma_stream<30, 1, 11, 0, 4> : k_fir_mfma_stream<30, 0, 11, 0, 4>) : nullptr;
-  if (np == 6) return D == 30 && nq == 11 && cplx && !(e && !atoi(e)) ? k_fir_mfma_stream<30, 1, 11, 0, 6> : nullptr;
-  if (np != 8) return nullptr;
-  if (D == 30 && nq == 11 && !(e && !atoi(e))) return cplx ? k_fir_mfma_stream<30, 1, 11> : k_fir_mfma_stream<30, 0, 11>;
-  switch (D) {
-    case 10: return cplx ? k_fir_mfma_stream<10, 1, 0> : k_fir_mfma_stream<10, 0, 0>;
-    case 30: return cplx ? k_fir_mfma_stream<30, 1, 0> : k_fir_mfma_stream<30, 0, 0>;
-    default: return nullptr;
+  if (D == 30 && nq == 11 && !(e && !atoi(e))) {
+    if (want_np == 4) return {cplx ? k_fir_mfma_stream<30, 1, 11, 0, 4> : k_fir_mfma_stream<30, 0, 11, 0, 4>, 4u, true};
+    if (want_np == 6 && cplx) return {k_fir_mfma_stream<30, 1, 11, 0, 6>, 6u, false};
+    return {cplx ? k_fir_mfma_stream<30, 1, 11> : k_fir_mfma_stream<30, 0, 11>, 8u, false};
   }
-}
-// LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 16·np rows) + Z ring + the diagonal reads' overrun
-unsigned stream_lds(unsigned D, unsigned nq, bool cplx, unsigned np = 8) {
-  const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4, fp = ((kp / sl - D) + 1) & ~1u;
-  if (np == 4) return ((fp * 8 + 16 * np * D * 8 + 15) & ~15u) + 48 * 2 * (nq | 1u) * 4;   // folded ring, compile-time tap blocks only (no overrun)
-  return ((fp * 8 + 16 * np * D * 8 + 15) & ~15u) + 80 * 2 * (nq | 1u) * 4 + 128;
+  if (D == 10 && nq == 11 && !(e && !atoi(e))) return {cplx ? k_fir_mfma_stream<10, 1, 11> : k_fir_mfma_stream<10, 0, 11>, 8u, false};
+  if (D == 10) return {cplx ? k_fir_mfma_stream<10, 1, 0> : k_fir_mfma_stream<10, 0, 0>, 8u, false};
+  if (D == 30) return {cplx ? k_fir_mfma_stream<30, 1, 0> : k_fir_mfma_stream<30, 0, 0>, 8u, false};
+  if (D < 2 || D > kStreamMaxD) return {nullptr, 0u, false};
+  static fir_kernel_t (*const part[8])(unsigned, bool, bool) = {lsdr_fir_stream_sweep_0, lsdr_fir_stream_sweep_1, lsdr_fir_stream_sweep_2, lsdr_fir_stream_sweep_3,
+                                                          lsdr_fir_stream_sweep_4, lsdr_fir_stream_sweep_5, lsdr_fir_stream_sweep_6, lsdr_fir_stream_sweep_7};
+  return {part[D % 8](D, cplx, nq == 11 && !(e && !atoi(e))), stream_sweep_np(D, cplx), false};
 }
 // geometry of a k_fir_mfma_blk launch (nb = tap blocks NQ, alen = coefficient operand floats, M = outputs per tile)
 struct blk_geom { unsigned nq, alen, U, lds, nl, nl_fixed, M, ks; };
@@ -1196,6 +908,10 @@ blk_geom blk_geometry(unsigned N, unsigned D, int W, bool cplx) {
   g.nq = (N + D - 1) / D;
   g.alen = g.ks * 64;
   if (g.nq > 16 || g.nq < 1) { g.M = 0; g.U = g.lds = g.nl = g.nl_fixed = 0; return g; }
+  if (pick_blk(D, W, cplx, 0, 0) == nullptr) {      // no register-staged kernel for this decimation: tap blocks and the coefficient operand only (the stream kernel's)
+    g.M = W * (128 - (g.nq - 1)); g.U = g.nl = g.nl_fixed = 0; g.lds = ~0u;
+    return g;
+  }
   const unsigned MW = 128 - (g.nq - 1);
   g.M = W * MW;
   const unsigned R = g.M + g.nq - 1;
@@ -1476,12 +1192,17 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   f->d_btab[0] = f->d_btab[1] = nullptr;
   f->blk_ok[0] = f->blk_ok[1] = false;
   if (cfg->arith == LSDR_FIR_MFMA_BLK) {
-    // available for cf32 input, even compile-time decimations, N ≤ 16·D; anything else is refused at create time (the blocked
-    // sum is its own arithmetic: there is no other kernel with the same bits to fall back to)
-    LSDR_ARG(cfg->in_format == LSDR_IN_CF32 && pick_blk(D, f->mf_W, false, 0, 0) != nullptr);
+    // available for cf32 input, decimations 2 … 64 (k_fir_mfma_stream; LSDR_MFMA_STREAM=0: the register-staged k_fir_mfma_blk — 4, 8, 10,
+    // 16, 30), N ≤ 16·D; anything else is refused at create time (the blocked sum is its own arithmetic: there is no other kernel
+    // with the same bits to fall back to)
     {
       const char *es = getenv("LSDR_MFMA_STREAM"), *ew = getenv("LSDR_MFMA_SWPC");
-      f->stream = pick_stream(D, false, 0) != nullptr && !(es && !atoi(es));
+      f->stream = pick_stream(D, false, 0).k != nullptr && !(es && !atoi(es));
+      if (!(cfg->in_format == LSDR_IN_CF32 && (f->stream || pick_blk(D, f->mf_W, false, 0, 0) != nullptr))) {
+        lsdr_fir_filter_destroy(f);
+        lsdr_set_error("lsdr_fir_filter_create: LSDR_FIR_MFMA_BLK has no kernel for %u taps / decimation %u / input format %d", N, D, cfg->in_format);
+        return LSDR_E_ARG;
+      }
       // OVERSUBSCRIBED: 96 workgroups per CU queued, each with a short tile list (3 tiles at the C2 batch), instead of a grid of exactly
       // the resident workgroups (3 per CU) that own a 99-tile list each: the dispatcher deals the work, the wavefronts of a CU fall out
       // of step, a workgroup that could not start next to the receiver's tiles costs 3 tiles, not a second round.  Same box, buffer
@@ -1493,12 +1214,17 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
       f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 96;
       { const char *ex = getenv("LSDR_MFMA_XROT"); f->stream_xrot = ex ? (unsigned)strtoul(ex, nullptr, 0) : 0u; }      // (read per create: A/B in one process)
       { const char *ec = getenv("LSDR_MFMA_CHUNK"); f->stream_chunked = ec ? (unsigned)atoi(ec) : 1u; }
-      { const char *e0 = getenv("LSDR_MFMA_NP"), *e1 = getenv("LSDR_MFMA_NP_CP"); f->stream_np[0] = e0 && atoi(e0) == 4 ? 4u : 8u; f->stream_np[1] = e1 && (atoi(e1) == 4 || atoi(e1) == 6 || atoi(e1) == 8) ? (unsigned)atoi(e1) : 4u; }
+      { const char *e0 = getenv("LSDR_MFMA_NP"), *e1 = getenv("LSDR_MFMA_NP_CP"); f->stream_np[0] = e0 && atoi(e0) == 4 ? 4u : 8u; f->stream_np[1] = e1 && (atoi(e1) == 4 || atoi(e1) == 6 || atoi(e1) == 8) ? (unsigned)atoi(e1) : 4u; }   // (asked for; pick_stream gives the geometry's default where that form does not exist)
     }
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
-      f->blk_ok[cp] = f->bk[cp].M > 0 && f->bk[cp].nl <= 32 && f->bk[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2);
-      LSDR_ARG(f->blk_ok[cp]);
+      // (blk_ok: the coefficient operand exists — with the stream kernel that is all; the register-staged one also needs its tile to fit)
+      f->blk_ok[cp] = f->bk[cp].M > 0 && (f->stream || (f->bk[cp].nl <= 32 && f->bk[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2)));
+      if (!f->blk_ok[cp]) {
+        lsdr_fir_filter_destroy(f);
+        lsdr_set_error("lsdr_fir_filter_create: LSDR_FIR_MFMA_BLK has no kernel for %u taps / decimation %u / input format %d", N, D, cfg->in_format);
+        return LSDR_E_ARG;
+      }
       LSDR_HIP(hipMalloc((void **)&f->d_btab[cp], f->bk[cp].alen * sizeof(float)));
     }
   }
@@ -1597,7 +1323,8 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   static const bool stream_cp = !(getenv("LSDR_MFMA_STREAM_CP") && !atoi(getenv("LSDR_MFMA_STREAM_CP")));   // A/B hook
   const bool stream = blk && f->stream && (real_taps || stream_cp);
   // rows per wave tile / 16 of the stream kernel: the requested one if that kernel exists for this geometry
-  const unsigned snp = stream && pick_stream(D, !real_taps, f->bk[real_taps ? 0 : 1].nq, f->stream_np[real_taps ? 0 : 1]) ? f->stream_np[real_taps ? 0 : 1] : 8u;
+  const stream_kernel sk = stream ? pick_stream(D, !real_taps, f->bk[real_taps ? 0 : 1].nq, f->stream_np[real_taps ? 0 : 1]) : stream_kernel{nullptr, 8u, false};
+  const unsigned snp = sk.np;
   const unsigned M = stream ? 16u * snp - (f->bk[real_taps ? 0 : 1].nq - 1) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
   size_t n_tiles = (count + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
@@ -1626,9 +1353,9 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     a.mf_blocks = blk ? f->bk[cp].nq : f->mf[cp].nb;
     static const char *const enq = getenv("LSDR_MFMA_NQT");
     const unsigned nqk = blk && !(enq && !atoi(enq)) ? f->bk[cp].nq : 0;
-    fir_kernel_t k = stream ? pick_stream(D, cp != 0, f->bk[cp].nq, snp) : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
+    fir_kernel_t k = stream ? sk.k : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
     static const size_t lds_pad = getenv("LSDR_MFMA_SLDS") ? (size_t)atoi(getenv("LSDR_MFMA_SLDS")) : 0;   // tuning hook: extra LDS per stream workgroup (bounds the workgroups resident per CU)
-    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0, snp) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
+    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0, snp, sk.fold) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
     if (lds_bytes > 64 * 1024)
       LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;

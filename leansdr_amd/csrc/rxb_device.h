@@ -269,7 +269,14 @@ __device__ __forceinline__ void rxb_tile(const rxb_args &A, const rxb_cap &cap, 
   const float f_lo = freqw - fwin, f_hi = freqw + fwin;
   const float kk = C.kest, k1 = 1 - C.kest;
   const float freq_alpha = C.freq_alpha, freq_beta = C.freq_beta, gain_mu = C.gain_mu, omega = C.omega;
+  // symbol timing at the tile's first sample, predicted from the capture's first sample (mu = 0 there) at the nominal omega: see rx_tile_tol
   float mu = 0.f, phase = 0.f;
+  {
+    const double ws = (double)cb * kChunk - (double)S0->mu, om = (double)C.omega;
+    const double r = ws - om * __builtin_floor(ws / om);
+    mu = (float)(r > 0.0 ? om - r : 0.0);
+    if (!(mu >= 0.f && mu < C.omega)) mu = 0.f;
+  }
   float h1pr = 0.f, h1pi = 0.f, h1cr = 0.f, h1ci = 0.f, mmA = 0.f, mmB = 0.f;      // Mueller & Müller: the previous symbol; p1·c2 and c1·p2
 
   // notch: pole / gain of the interval the tile is in, S in front of the tile's first sample from the pre-pass sums

@@ -143,6 +143,19 @@ struct fir_filter<complex<float>, float> : runnable {
     lsdr_fir_filter_cfg cfg;
     cfg.ncoeffs = ncoeffs; cfg.coeffs_host = coeffs; cfg.decim = decim;
     cfg.in_format = LSDR_IN_CF32; cfg.in_scale = fuse_scale; cfg.arith = LSDR_FIR_EXACT;
+    // LSDR_FIR_ARITH=fma|mfma|blk: the filter's tolerance arithmetics (include/lsdr_hip.h; like LSDR_TILED an option the reference's
+    // config has no member for).  A geometry the chosen arithmetic has no kernel for keeps the exact filter.
+    const char *ae = getenv("LSDR_FIR_ARITH");
+    if (ae && *ae) {
+      const int want = !strcmp(ae, "fma") ? LSDR_FIR_FMA : !strcmp(ae, "mfma") ? LSDR_FIR_MFMA : !strcmp(ae, "blk") ? LSDR_FIR_MFMA_BLK : LSDR_FIR_EXACT;
+      cfg.arith = want;
+      if (want != LSDR_FIR_EXACT && lsdr_fir_filter_create(ctx, &cfg, &h) == LSDR_OK) {
+        if (sch->verbose) fprintf(stderr, "fir_filter: arithmetic %s\n", ae);
+        return;
+      }
+      h = NULL; cfg.arith = LSDR_FIR_EXACT;
+      if (want != LSDR_FIR_EXACT) fprintf(stderr, "fir_filter: no %s kernel for %d taps / decimation %u: exact arithmetic\n", ae, ncoeffs, decim);
+    }
     lsdr_check(lsdr_fir_filter_create(ctx, &cfg, &h), name);
   }
   // (the reference's blocks live as long as the process; a graph that is torn down gives its device objects back)

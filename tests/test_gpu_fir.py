@@ -277,18 +277,25 @@ def test_mfma_run_multi_and_short_inputs(capi, ctx, oracle):
     f.close()
 
 
-BLK_GEOMS = [(313, 30), (200, 30), (330, 30), (480, 30), (30, 30), (101, 10), (160, 10), (161, 16), (65, 8), (40, 4), (17, 16), (7, 8)]
+BLK_GEOMS = [(313, 30), (200, 30), (330, 30), (480, 30), (30, 30), (101, 10), (160, 10), (161, 16), (65, 8), (40, 4), (17, 16), (7, 8),
+             # the sweep (fir_stream_sweep.hip): every residue of D mod 8, odd D, padded rows of every size, both wave-tile shapes (D ≤ 34 / above),
+             # the shapes leandvb.cc:353-378 derives (order ≈ 10.4·D … 12·D), the extremes of N (1, 16·D) and of D (2, 64)
+             (21, 2), (32, 2), (1, 2), (37, 3), (48, 4), (53, 5), (67, 6), (81, 7), (89, 8), (97, 9), (115, 11), (127, 12), (150, 13), (161, 14),
+             (170, 15), (200, 17), (230, 20), (233, 21), (260, 24), (270, 25), (352, 32), (347, 33), (362, 34), (371, 35), (410, 36), (440, 40),
+             (495, 45), (530, 50), (633, 60), (960, 60), (660, 63), (676, 64), (1024, 64), (3, 64),
+             # leandvb's own designs (eleven tap blocks: the sweep's compile-time form) at the remaining residues
+             (43, 4), (63, 6), (73, 7), (85, 8), (157, 15), (167, 16), (209, 20), (251, 24), (105, 10)]
 
 
 @pytest.mark.parametrize("kern", ["stream", "blk_w2", "blk_w4"])
 @pytest.mark.parametrize("n,d", BLK_GEOMS, ids=[f"N{n}_D{d}" for n, d in BLK_GEOMS])
 def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, kern, n, d):
-    """LSDR_FIR_MFMA_BLK (block-polyphase dense product on the matrix pipe: k_fir_mfma_stream — LDS-direct refill, the default
-    where the decimation allows it — and k_fir_mfma_blk, register-staged, any even compile-time decimation) against its stated
+    """LSDR_FIR_MFMA_BLK (block-polyphase dense product on the matrix pipe: k_fir_mfma_stream — LDS-direct refill, the default,
+    every decimation 2 … 64 — and k_fir_mfma_blk, register-staged, decimations 4, 8, 10, 16, 30) against its stated
     arithmetic, oracle.fir_filter(fma="blk") — the reference's loop with the taps in blocks of D, an fmaf chain per block,
     block sums added in order — bit for bit, and against the reference's arithmetic under LSDR_FIR_FMA's error bound."""
-    if kern == "stream" and d not in (10, 30):
-        pytest.skip("k_fir_mfma_stream exists for decimations 10 and 30")
+    if kern != "stream" and d not in (4, 8, 10, 16, 30):
+        pytest.skip("k_fir_mfma_blk (register-staged) exists for decimations 4, 8, 10, 16, 30; k_fir_mfma_stream for 2 … 64")
     w = 4 if kern == "blk_w4" else 2
     os.environ["LSDR_MFMA_STREAM"] = "1" if kern == "stream" else "0"
     rng = np.random.default_rng(n * 37 + d)
@@ -312,6 +319,28 @@ def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, kern, 
     finally:
         del os.environ["LSDR_MFMA_W"]
         del os.environ["LSDR_MFMA_STREAM"]
+
+
+@pytest.mark.parametrize("n,d", [(313, 30), (105, 10), (85, 8), (251, 24), (417, 40)])
+def test_mfma_blk_run_time_and_compile_time_tap_blocks_give_the_same_bits(capi, ctx, oracle, n, d, monkeypatch):
+    """Eleven tap blocks (leandvb's own designs) run k_fir_mfma_stream's compile-time-NQ form; LSDR_MFMA_NQT=0 forces the run-time-NQ
+    kernel every other ncoeffs runs: same outputs, real and complex taps."""
+    rng = np.random.default_rng(n + d)
+    ns = 4096 * 40 + 31
+    x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 9).astype(np.complex64)
+    co = capi.lowpass(n - 1, 0.45 / d)
+    outs = []
+    for nqt in ("1", "0"):
+        monkeypatch.setenv("LSDR_MFMA_NQT", nqt)
+        for freq in (0.0, -0.021):
+            f = capi.FirFilter(ctx, co, d, in_scale=3.0, arith=capi.FIR_MFMA_BLK)
+            if freq:
+                f.set_freq(freq)
+            outs.append(f.run(x)[0])
+            f.close()
+    want = oracle.fir_filter(co, d, x, 0.0, fma="blk", scale=3.0)[0]
+    assert np.array_equal(outs[0], want) and np.array_equal(outs[2], want)
+    assert np.array_equal(outs[1], outs[3]) and np.array_equal(outs[1], oracle.fir_filter(co, d, x, -0.021, fma="blk", scale=3.0)[0])
 
 
 @pytest.mark.parametrize("stream", ["1", "0"])
@@ -342,6 +371,6 @@ def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle, stream,
         d.free()
     f.close()
     # its own arithmetic: no other kernel has the same bits, so geometries without a kernel are refused, not re-routed
-    for nn, dd, fmt in ((313, 7, capi.IN_CF32), (600, 30, capi.IN_CF32), (313, 30, capi.IN_CU8)):
+    for nn, dd, fmt in ((313, 65, capi.IN_CF32), (313, 1, capi.IN_CF32), (600, 30, capi.IN_CF32), (313, 30, capi.IN_CU8)) + (((81, 7, capi.IN_CF32),) if stream == "0" else ()):
         with pytest.raises(Exception):
             capi.FirFilter(ctx, capi.lowpass(nn - 1, 0.01), dd, in_format=fmt, arith=capi.FIR_MFMA_BLK)

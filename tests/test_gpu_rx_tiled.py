@@ -321,3 +321,38 @@ def test_staged_cf32_tiles_equal_direct_loads(tmp_path):
         assert sorted(a.files) == sorted(b.files)
         for k in a.files:
             assert a[k].tobytes() == b[k].tobytes(), k
+
+
+@pytest.mark.parametrize("ppm,snr_db,tile", [(30.0, 20.0, (0, 0)), (-50.0, 20.0, (256, 256)), (40.0, 15.0, (1024, 512))])
+def test_tiles_find_the_symbol_timing_wherever_they_start(capi, ctx, oracle, ppm, snr_db, tile):
+    """A receiver whose omega is `ppm` off the stream's symbol rate (a real sample clock): the symbol timing drifts against the tile
+    grid, so tiles start at EVERY timing phase — including half a symbol off, the unstable point of the timing detector, where a
+    few tiles in a thousand used to leave their warm-up unconverged (the reference benchmark's 4.2-sps series lost its lock in the
+    tiled mode: profiles/r06_sensitivity/README.md).  With the fed-forward estimate (rx_wave_timing) no seam stays unreconciled and the
+    decisions are the sequential loop's."""
+    x, _ = synth.qpsk_baseband(4 * 400000, 4, seed=21, rms=50.0, snr_db=snr_db)
+    omega = float(np.float32(4.0 * (1 + ppm * 1e-6)))
+    p = po.rx_params(sampler=1, cstln=1, omega=omega, meas_decimation=4096)
+    acq = 40960
+    a = oracle.rx(p, x[:acq + 1])
+    ref = oracle.rx(p, x[acq:], state_in=a["state"])
+    r = capi.CstlnReceiver(ctx, sampler=1, cstln=1, omega=omega, meas_decimation=4096, mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1])
+    st = capi.RxState()
+    for k, _ in st._fields_:
+        setattr(st, k, getattr(a["state"], k))
+    r.set_state(st)
+    # in runs of 256 Ki samples, like a scheduler with --buf-factor 64 pipes: the state a run leaves is the next one's start
+    syms, pos, bad, tiles = [], acq, 0, 0
+    while pos + 129 <= len(x):
+        out = r.run(x[pos:pos + 262144])
+        if not out["consumed"]:
+            break
+        syms.append(out["sym"]); pos += out["consumed"]
+        stt = r.tiled_stats(); bad += stt["bad_seams"]; tiles += stt["tiles"]
+    r.close()
+    got = np.concatenate(syms)
+    # the timing swept through more than a whole symbol over the stream
+    assert abs(ppm) * 1e-6 * len(x) > 4.0
+    rep = check_tiled(got, ref["sym"][: len(got)] if len(got) <= len(ref["sym"]) else ref["sym"], dict(tiles=tiles, bad_seams=bad, dup=0, miss=0),
+                      tol=TOL if snr_db >= 18 else LOW_SNR)
+    assert len(got) == len(ref["sym"]) and rep["pass"], rep

@@ -24,6 +24,8 @@ SERIES = {   # name: (ratio, SNRs, receiver flags) — test/leandvb_bench.sh:119
 
 
 RX_EXTRA = ""   # extra leandvb options (--rx-extra "--buf-factor 4": the reference's pipe sizes, hence its report cadence)
+ANF_ARG = "--anf 0"   # test/leandvb_bench.sh runs without the notch; "" = leandvb's default (--anf 1)
+RX_ENV = {}     # environment of the receiver process (LSDR_TILED=1, LSDR_FIR_ARITH=blk, LSDR_FUSE_NOTCH=1: the throughput modes)
 
 
 def commands(ratio, snr, flags, ref=False):
@@ -51,7 +53,7 @@ def commands(ratio, snr, flags, ref=False):
     cnr = "--cnr" if samprate > 3 * symbrate else ""
     c_tx = f"{tx} -f {ratio} --power {sigpow:g} --agc"
     c_ch = f"{ch} --awgn {noisepow:g} --deterministic {'--ou8' if hs else ''}"
-    c_rx = (f"{rx} {'' if hs else f'--f32 --float-scale {scale:.10f}'} -f {samprate} --sr {symbrate} --anf 0 {cnr} --fd-info 2 {flags} {'' if ref is True else RX_EXTRA}")
+    c_rx = (f"{rx} {'' if hs else f'--f32 --float-scale {scale:.10f}'} -f {samprate} --sr {symbrate} {ANF_ARG} {cnr} --fd-info 2 {flags} {'' if ref is True else RX_EXTRA}")
     return c_tx, c_ch, c_rx, sigpow - noisepow
 
 
@@ -66,7 +68,10 @@ def run_pipeline(ratio, snr, flags, npackets, ref=False):
         p = subprocess.run(f"{c_tx} | {c_ch} > {f.name}", shell=True, input=ts, stderr=subprocess.PIPE)
         if p.returncode:
             raise RuntimeError(p.stderr.decode()[-2000:])
-        p = subprocess.run(f"{c_rx} < {f.name}", shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        env = dict(os.environ)
+        if ref is not True:
+            env.update(RX_ENV)
+        p = subprocess.run(f"{c_rx} < {f.name}", shell=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
     if p.returncode:
         raise RuntimeError(p.stderr.decode()[-2000:])
     return p.stderr.decode(), p.stdout
