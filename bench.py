@@ -265,24 +265,11 @@ class Capture:
             self.ctx_rx.close()
 
 
-class _Window:
-    """A stretch of one large device allocation, with what the pipeline uses of a DevBuf; it goes when the allocation goes."""
-
-    def __init__(self, capi, ptr):
-        self._vp, self.ptr = capi.vp, int(ptr)
-
-    def at(self, byte_offset):
-        return self._vp(self.ptr + int(byte_offset))
-
-    def free(self):
-        self.ptr = None
-
-
 class C2Pipeline:
     """scaler(fused) -> fir_filter -> cstln_receiver(tiled) over `n_captures` endless captures on one GPU."""
 
     def __init__(self, capi, synth, device, n_captures, batch_msamples, period_msamples, tile, seed0, freq=0.0, rx_cus=0,
-                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=40):
+                 cu_pattern="xcd_major", rx_freq=0.0, fir_arith=None, cw=None, rx_multi=True, sampler="linear", batch_hook=None, rx_groups=1, placement_candidates=40, place=True):
         self.capi = capi
         self.batch_hook = batch_hook          # called per batch after fir_filter was queued: hook(pipe, dec buffer index, outputs, done event)
         # rx_multi: the receivers of all captures live on ONE stream and share their launches (lsdr_rx_run_multi_async): two
@@ -328,9 +315,11 @@ class C2Pipeline:
         self.ctx_rx = self.ctx_rxs[0] if self.ctx_rxs else None
         self.caps = [Capture(capi, synth, device, self.ctx, c, seed0 + 1000 * c, self.geo, self.rx_kw, tile, freq=freq, rx_cus=rx_mask, cw=cw,
                              shared_rx_ctx=self.ctx_rxs[c % self.rx_groups] if self.rx_multi else None, extra=self.extra) for c in range(n_captures)]
-        self.placement = self.place_buffers(int(os.environ.get("LSDR_BENCH_PLACEMENT", placement_candidates))) if len(self.caps) == 1 else None
+        self.arena, self.placement = None, None
         for cp in self.caps:
             cp.acquire(self.fir, self.rx_kw)
+        if len(self.caps) == 1 and place:
+            self.placement = self.place_buffers(int(os.environ.get("LSDR_BENCH_PLACEMENT", placement_candidates)))
         self.ev_fir = [self.ctx.event() for _ in range(self.geo["nbuf"])]
         self.ev_pool = []
         self.fir_ms = []
@@ -340,96 +329,51 @@ class C2Pipeline:
         self.snap_mid, self.last_k = None, -1
 
     def place_buffers(self, candidates):
-        """WHERE a resident buffer lands decides how fast fir_filter streams it: one process, six 2 GiB buffers allocated one after
-        the other — the same launch takes 0.37 ms over some and 0.42 ms over others, reproducibly per buffer (profiles/r05_bench/
-        placement_probe.txt); the C2 headline moved ±8 % from process to process with it.  It is the physical place, not the
-        allocation's flags (default / fine-grained / uncached / contiguous: placement_probe5.py), and later allocations of a process
-        are fast more often (28 in a row: numbers 4, 16, 23–28).  So the capture's input buffer and its decimated-stream buffers are
-        CHOSEN: up to `candidates` allocations are held at once (40 × 2 GiB of the 288), the filter launch is timed over every one
-        (HIP events, 3 + 6 launches), the fastest are kept, the rest freed.  Not timed; the data in the buffers is the same."""
+        """The capture's input buffer and its decimated-stream buffers become windows of an lsdr_arena (leansdr_amd/csrc/arena.hip — the
+        library's placed stream buffers: ONE large allocation, the fastest windows under a probe first).  WHERE a resident buffer lands
+        decides how fast fir_filter streams it (0.37 ms over one 2 GiB buffer, 0.42 over the next, reproducibly per buffer:
+        profiles/r05_bench/placement_probe.txt; ±8 % on the C2 headline from process to process).  The probe is the filter launch itself:
+        over each candidate input window (filled with the capture) into the first decimated buffer, then over the chosen input into each
+        candidate output window (the arena's tail).  Not timed; the data in the buffers is the same.  Returns the record for the JSON."""
         if candidates <= 1:
             return None
         capi, g, cp, ctx = self.capi, self.geo, self.caps[0], self.ctx
         n_in = g["B"] + self.extra * g["decim"] + g["N"]
         n_dec = g["n_out"] + self.extra
-        e0, e1 = ctx.event(), ctx.event()
-
-        def launch_ms(d_in, d_dec):
-            for _ in range(3):
-                self.fir.run_dev(d_in.ptr, n_in, d_dec.ptr, n_dec)
-            ctx.sync(); ctx.event_record(e0)
-            for _ in range(6):
-                self.fir.run_dev(d_in.ptr, n_in, d_dec.ptr, n_dec)
-            ctx.event_record(e1); ctx.sync()
-            return ctx.event_elapsed_ms(e0, e1) / 6
-
-        # (candidates are held until the choice is made — a freed buffer would be handed out again; the search stops early once one
-        # candidate is clearly in the fast group: at least five tried, the best 8 % under their MEDIAN — the first measurements of a
-        # process run slow whatever the buffer, so the slowest one is no yardstick)
-        launch_ms(cp.d_in, cp.dec[0])          # (clocks, TLBs)
-        ins, t_in = [cp.d_in], [launch_ms(cp.d_in, cp.dec[0])]
         nbytes = (g["B"] + g["period"]) * 8
-        done = lambda: len(ins) >= 5 and min(t_in) < 0.92 * float(np.median(t_in))
-        # First candidates: the 2 MiB-aligned windows of ONE large allocation (tools/placement_map.py, vmm_probe.py, va_align_probe.py: what makes
-        # a buffer slow goes with its physical backing, not with its address or the launch's shape — memory mapped chunk by chunk through
-        # hipMemCreate / hipMemMap is ALL of the slow kind, separate 2 GiB hipMallocs are of either, and the larger one allocation, the larger
-        # the share of fast windows in it: 96 GiB all fast, 48 GiB 5.6–5.9 TB/s, 16 GiB either).  Not when several ranks share this GPU.
+        # (not when several ranks share this GPU: 160 GiB each would not fit)
         arena_gib = int(os.environ.get("LSDR_BENCH_ARENA_GIB", 160)) if not os.environ.get("LSDR_RANK_DEVICES") else 0
-        self.arena, n_arena = None, 0
-        if arena_gib > 0:
-            try:
-                self.arena = ctx.alloc(arena_gib << 30)
-            except Exception:
-                self.arena = None
-        dec_step = -(-(n_dec * 8) // (2 << 20)) * (2 << 20)
-        n_dec_win = 64 if self.arena is not None else 0                    # windows for the decimated-stream buffers: the arena's tail
-        if self.arena is not None:
-            step = -(-nbytes // (2 << 20)) * (2 << 20)
-            for w in range(((arena_gib << 30) - n_dec_win * dec_step) // step):
-                if done():
-                    break
-                d = _Window(capi, self.arena.ptr + w * step)
-                capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.at(0), cp.d_in.ptr, nbytes))
-                ctx.sync()
-                ins.append(d); t_in.append(launch_ms(d, cp.dec[0])); n_arena += 1
-        while len(ins) < candidates and not done():
-            d = ctx.alloc(nbytes)
-            capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d.ptr, cp.d_in.ptr, nbytes))
-            ctx.sync()
-            ins.append(d); t_in.append(launch_ms(d, cp.dec[0]))
-        # The capture then lives in ONE buffer or in TWO read alternately (tools/placement_probe4.py: the same launch re-reading one
-        # buffer of the slow kind back to back streams 4.9–5.1 TB/s, alternating between two of them 5.4; a fast one 5.75 either way):
-        # TWO only when no candidate is of the fast kind (the best within 4 % of their median); a fast one is used alone (on a box with
-        # fast buffers both arrangements gave 621–634 GS/s).
-        # (A stream arriving over PCIe lands in alternating buffers anyway; the data in both is the same periodic signal.)
-        order = [int(k) for k in np.argsort(t_in)]
-        best = order[0]
-        two = len(order) > 1 and t_in[best] >= 0.96 * float(np.median(t_in)) and os.environ.get("LSDR_BENCH_ALTERNATE", "1") != "0"
-        cp.d_in = ins[best]
-        cp.d_in2 = ins[order[1]] if two else None
-        for k, d in enumerate(ins):
-            if k != best and not (two and k == order[1]):
-                d.free()
-        in_arena = [isinstance(d, _Window) for d in ([cp.d_in] + ([cp.d_in2] if two else []))]
-        # the decimated-stream buffers (70 MB each, written by the launch) matter as much: one launch over a fast input buffer took 0.367 ms into
-        # one of them and 0.412–0.430 into six others — candidates: the ones there are, a few more allocations, the windows of the arena's tail
-        decs = list(cp.dec) + [ctx.alloc((n_dec) * 8) for _ in range(max(0, min(candidates, 8) - len(cp.dec)))]
-        if self.arena is not None:
-            tail = self.arena.ptr + (arena_gib << 30) - n_dec_win * dec_step
-            decs += [_Window(capi, tail + w * dec_step) for w in range(n_dec_win)]
-        t_dec = [launch_ms(cp.d_in, d) for d in decs]
-        order = list(np.argsort(t_dec))
-        keep = order[:len(cp.dec)]
-        cp.dec = [decs[k] for k in keep]
-        for k, d in enumerate(decs):
-            if k not in keep:
-                d.free()
-        in_arena += [isinstance(d, _Window) for d in cp.dec]
-        if self.arena is not None and not any(in_arena):
-            self.arena.free(); self.arena = None
-        return dict(candidates=candidates, input_buffers_in_use=2 if two else 1, arena_gib=arena_gib, arena_windows_tried=n_arena,
-                    buffers_inside_the_arena=int(sum(in_arena)), filter_launch_ms_by_input_buffer=[round(float(v), 4) for v in t_in],
-                    filter_launch_ms_by_decimated_buffer=[round(float(v), 4) for v in t_dec])
+        if arena_gib <= 0:
+            return None
+        try:
+            self.arena = capi.Arena(ctx, arena_gib << 30)
+        except Exception as e:
+            return dict(arena_gib=arena_gib, error=str(e)[-200:])
+        # The capture lives in ONE window or in TWO read alternately (tools/placement_probe4.py: the same launch re-reading one buffer of the
+        # slow kind back to back streams 4.9–5.1 TB/s, alternating between two of them 5.4; a fast one 5.75 either way): TWO only when no
+        # candidate is of the fast kind (the best within 4 % of the candidates' median).  (A stream arriving over PCIe lands in alternating
+        # buffers anyway; the data in both is the same periodic signal.)
+        ins = self.arena.place(nbytes, n_best=2, max_windows=candidates, fill_from=cp.d_in.ptr,
+                               probe=lambda w: self.fir.run_dev(w, n_in, cp.dec[0].ptr, n_dec))
+        t_in = self.arena.probe_log()
+        two = ins[0].probe_ms >= 0.96 * float(np.median(t_in)) and os.environ.get("LSDR_BENCH_ALTERNATE", "1") != "0"
+        cp.d_in.free()
+        cp.d_in = ins[0]
+        if two:
+            cp.d_in2 = ins[1]
+        else:
+            ins[1].free()
+        # the decimated-stream buffers (70 MB each, written by the launch) matter as much: one launch over a fast input buffer took 0.367 ms
+        # into one of them and 0.412–0.430 into six others — candidates: windows from the arena's tail
+        decs = self.arena.place(n_dec * 8, n_best=len(cp.dec), max_windows=64, from_tail=True,
+                                probe=lambda w: self.fir.run_dev(cp.d_in.ptr, n_in, w, n_dec))
+        t_dec = self.arena.probe_log()
+        for d in cp.dec:
+            d.free()
+        cp.dec = decs
+        return dict(engine="lsdr_arena_place (include/lsdr_hip.h)", arena_gib=arena_gib, input_windows_tried=len(t_in), input_buffers_in_use=2 if two else 1,
+                    filter_launch_ms_by_input_window=[round(float(v), 4) for v in t_in],
+                    filter_launch_ms_by_decimated_window=[round(float(v), 4) for v in t_dec])
 
     def run(self, n_batches, timed, snapshot_last=False, track_tol=None):
         """Queue n_batches batches of every capture.  Per batch: fir_filter(k) of all captures in one launch on the fir
@@ -660,7 +604,7 @@ class C2Pipeline:
         for cx in self.ctx_rxs:
             cx.close()
         if getattr(self, "arena", None) is not None:
-            self.arena.free(); self.arena = None
+            self.arena.close(); self.arena = None
         self.fir.close()
         self.ctx.close()
 
@@ -707,13 +651,16 @@ def compact_line(out):
                                "rx_mode", "rx_tile", "parallelism", "symbols_per_step", "c1_captures", "capture_samples", "engine")}
     r = out.get("roofline")
     if isinstance(r, dict):
-        line["roofline"] = {k: _short(r[k], 80) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "ceiling", "frac_of_ceiling", "traffic",
+        line["roofline"] = {k: _short(r[k], 80) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_unplaced", "ceiling", "frac_of_ceiling", "traffic",
                                                           "traffic_source", "avg_launch_ms", "launches_timed", "algorithmic_bytes_per_launch",
                                                           "algorithmic_bytes_per_sample") if k in r}
         if isinstance(r.get("valu_issue"), dict):      # c1: the bound that applies to the receiver's tiles (vector-instruction issue)
             vi = r["valu_issue"]
             line["roofline"]["valu_issue"] = {k: vi[k] for k in ("valu_instructions_per_symbol_step", "wave_instructions_per_launch", "peak_wave_instructions_per_s",
                                                                  "achieved_wave_instructions_per_s", "frac", "whole_job_frac") if k in vi}
+    u = out.get("unplaced")
+    if isinstance(u, dict):      # the same pipeline over the buffers as hipMalloc returned them (before lsdr_arena_place chose the headline's)
+        line["unplaced"] = {k: u[k] for k in ("value", "unit", "ms_per_step", "avg_launch_ms", "frac") if k in u}
     c = out.get("cpu_baseline")
     if isinstance(c, dict):
         line["cpu_baseline"] = {k: _short(c[k], 230) for k in ("value", "unit", "cores", "kind", "one_core", "sample") if k in c}
@@ -856,8 +803,26 @@ def main():
     pipe = C2Pipeline(capi, synth, local_rank, args.captures, args.batch_msamples, args.period_msamples, tile,
                       seed0=shard.capture_seed(), rx_cus=args.rx_cus, cu_pattern=args.cu_pattern,
                       fir_arith={"exact": capi.FIR_EXACT, "fma": capi.FIR_FMA, "mfma": capi.FIR_MFMA, "blk": capi.FIR_MFMA_BLK}[args.fir_arith],
-                      rx_multi=not args.rx_per_stream)
+                      rx_multi=not args.rx_per_stream, place=False)
     bps = args.batches_per_step
+    # Buffer placement: the headline runs over windows of an lsdr_arena chosen by the library (C2Pipeline.place_buffers).  What the SAME
+    # pipeline does over the buffers as hipMalloc returns them is measured first, the same number of steps, and reported beside it
+    # (`unplaced`; roofline.frac_unplaced) — not part of the timed region below.
+    unplaced = None
+    n_cand = int(os.environ.get("LSDR_BENCH_PLACEMENT", 40))
+    if args.captures == 1 and n_cand > 1 and not os.environ.get("LSDR_RANK_DEVICES"):
+        if world == 1:
+            pipe.run(args.warmup * bps, False)
+            pipe.sync()
+            t0 = time.perf_counter()
+            c_un = pipe.run(args.steps * bps, True)
+            pipe.sync()
+            dt_un = time.perf_counter() - t0
+            r_un = pipe.roofline()
+            unplaced = {"value": round(c_un / dt_un / 1e6, 3), "unit": "MS/s", "ms_per_step": round(dt_un / args.steps * 1e3, 4),
+                        "avg_launch_ms": r_un["avg_launch_ms"], "frac": r_un["frac"], "what": "the same pipeline and step count over the buffers as hipMalloc returned them, before placement"}
+            pipe.fir_ms = []
+        pipe.placement = pipe.place_buffers(n_cand)
 
     pipe.run(args.warmup * bps, False)
     pipe.sync()
@@ -914,6 +879,9 @@ def main():
                        "symbols_per_step": nsym // max(1, args.steps)},
             "roofline": pipe.roofline(),
         }
+        if unplaced is not None:
+            out["unplaced"] = unplaced
+            out["roofline"]["frac_unplaced"] = unplaced["frac"]
         if verified is not None:
             out["verified"] = verified                              # rank 0's own captures, in full
             out["verified"]["ranks_passed"], out["verified"]["ranks"] = ranks_ok, ranks

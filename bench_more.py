@@ -74,6 +74,54 @@ def reference_ts(iq, flags, timeout=600):
         os.unlink(f.name)
 
 
+class ReferenceStream:
+    """The reference binary decoding `n_samples` of the periodic stream `period` (cf32, repeated) in the BACKGROUND — one host core, fed through
+    a pipe while the GPU chain is timed; result() joins and returns its TS bytes (None where oracle/_ref was not built)."""
+    def __init__(self, period, n_samples, flags):
+        import threading
+        self.proc = None
+        if not (os.path.exists(REFBIN) and os.access(REFBIN, os.X_OK)):
+            return
+        self.out = tempfile.NamedTemporaryFile(prefix="lsdr_ref_ts_", suffix=".ts", delete=False)
+        self.proc = subprocess.Popen([REFBIN] + flags, stdin=subprocess.PIPE, stdout=self.out, stderr=subprocess.DEVNULL)
+        raw = memoryview(np.ascontiguousarray(period).view(np.uint8))
+        self.n_samples = int(n_samples)
+
+        def feed():
+            left = self.n_samples * 8
+            try:
+                while left > 0:
+                    n = min(left, len(raw))
+                    self.proc.stdin.write(raw[:n])
+                    left -= n
+            except BrokenPipeError:
+                pass
+            finally:
+                try:
+                    self.proc.stdin.close()
+                except BrokenPipeError:
+                    pass
+        self.t0 = time.perf_counter()
+        self.th = threading.Thread(target=feed, daemon=True)
+        self.th.start()
+
+    def result(self, timeout=900):
+        if self.proc is None:
+            return None, 0.0
+        try:
+            self.proc.wait(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()
+        self.th.join(timeout=10)
+        dt = time.perf_counter() - self.t0
+        self.out.close()
+        try:
+            with open(self.out.name, "rb") as f:
+                return f.read(), dt
+        finally:
+            os.unlink(self.out.name)
+
+
 def ts_contains(got_packets, ref_bytes, skip=16, min_packets=24):
     """Every packet the reference wrote after its first `skip` is in `got_packets`, in order and without gaps."""
     rpk = [ref_bytes[i:i + 188] for i in range(0, len(ref_bytes) - 187, 188)]
@@ -526,12 +574,19 @@ def framed_period(capi, ctx, cstln, rate, sps, snr_db, seed, decim=1, groups=1):
     return x.astype(np.complex64), ts8
 
 
-def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamples, label, ref_flags):
+def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamples, label, ref_flags, ref_packets=0):
+    """ref_packets > 0: the reference binary decodes that many TS packets' worth of the SAME (periodic) stream from sample 0 on one host core
+    while the GPU chain is timed, and every packet it writes is compared; 0: a prefix of one batch (a few dozen packets)."""
     import bench
     lib = capi.lib
     ctx = capi.Ctx(device)
     x, ts8 = framed_period(capi, ctx, cstln, rate, sps, 20.0 if cstln == capi.QPSK else 24.0, seed=3)
     P = len(x)
+    ref_stream = None
+    if ref_packets:
+        # samples that carry ref_packets packets (204·8 coded bits each over bits-per-symbol × code rate data bits per symbol) + the head the reference spends locking
+        spp = 204 * 8 * sps / (capi.CSTLN_BITS[cstln] * {capi.FEC12: 1 / 2, capi.FEC23: 2 / 3}[rate])
+        ref_stream = ReferenceStream(x if use_fir else x * np.float32(75.0), int((ref_packets + 600) * spp), ref_flags)
     if use_fir:
         coeffs, decim = bench.c2_filter(capi)
         N = len(coeffs)
@@ -718,12 +773,19 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
         eq = (got == want).all(axis=1)
         ok, bad = int(eq.sum()), int(len(got) - eq.sum())
     # … and the reference's own leandvb binary decodes a prefix of the same IQ (from sample 0) to the same packets
-    n_pref = min(B, (24 << 20) if use_fir else (3 << 20))
-    pref = ctx.download(d_in, np.complex64, n_pref)
-    ref = reference_ts(pref, ref_flags)
     ref_check = None
-    if ref is not None:
-        ref_check = ts_contains([bytes(t) for t in got[:4096]], ref, skip=8, min_packets=16)
+    if ref_stream is not None:
+        ref, ref_dt = ref_stream.result()
+        n_pref = ref_stream.n_samples
+        if ref is not None:
+            ref_check = ts_contains([bytes(t) for t in got[:ref_packets + 4096]], ref, skip=8, min_packets=min(ref_packets, 16))
+            ref_check["reference_seconds_one_core"] = round(ref_dt, 1)
+    else:
+        n_pref = min(B, (24 << 20) if use_fir else (3 << 20))
+        pref = ctx.download(d_in, np.complex64, n_pref)
+        ref = reference_ts(pref, ref_flags)
+        if ref is not None:
+            ref_check = ts_contains([bytes(t) for t in got[:4096]], ref, skip=8, min_packets=16)
     out = dict(value=round(nb * B / dt / 1e6, 3), unit="MS/s", seconds=round(dt, 3), batches=nb, chain=label, samples_per_symbol=sps,
                symbols_per_s=round(nb * B / sps / dt / 1e6, 3), ts_packets=int(len(got)), ts_packets_per_s=round(len(got) / dt, 1),
                ts_check={"packets_equal_to_the_transmitted_sequence": ok, "different": bad, "pass": bool(bad == 0 and ok > 8),
@@ -786,7 +848,8 @@ def c3(capi, synth, device, args):
     # 4 Gi 307 (32 GB of input per batch, resident; 288 GB of HBM is what makes this the natural batch).
     return full_chain(capi, synth, device, args, capi.QPSK, capi.FEC12, 120, True, int(os.environ.get("LSDR_C3_BATCH_MSAMPLES", 4096)),
                       "QPSK 1/2 @ 120 sps cf32: scaler+fir_filter(313,/30) -> cstln_receiver(tiled) -> viterbi_sync -> mpeg_sync -> deinterleaver -> rs_decoder -> derandomizer",
-                      ["--f32", "--float-scale", "75", "-f", "240e6", "--sr", "2000e3", "--cr", "1/2", "--resample", "--anf", "0", "--viterbi"])
+                      ["--f32", "--float-scale", "75", "-f", "240e6", "--sr", "2000e3", "--cr", "1/2", "--resample", "--anf", "0", "--viterbi"],
+                      ref_packets=int(os.environ.get("LSDR_C3_REF_PACKETS", 10000)))
 
 
 def c5_rescoped(capi, synth, device, args):
@@ -799,8 +862,9 @@ def c5_rescoped(capi, synth, device, args):
 
 def c1(capi, synth, device, args):
     """BASELINE config 1 / 4 on one GPU = `bench.py --workload c1` (also its own line, and with --gpus N the multi-GPU form of
-    config 4), run as a process of its own: its 16 worker streams want 16 hardware queues (GPU_MAX_HW_QUEUES, read when the HIP
-    runtime initialises: 123 -> 139 GS/s), which this process — the C2 pipeline, best with the default 4 — cannot switch to."""
+    config 4), run as a process of its own so that its record is exactly what that command prints: lsdr_capture_batch — the
+    reference's default graph (--anf 1) for all captures of a GPU in shared launches, counts on the device, one host thread, the
+    runtime's default hardware queues."""
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--workload", "c1", "--no-cpu", "--steps", "45", "--warmup", "2"]
@@ -814,21 +878,22 @@ def c1(capi, synth, device, args):
             return dict(value=None, unit="MS/s", **{"pass": False}, error=(r.stderr or r.stdout)[-1500:])
         j = json.load(open(full))
     out = dict(value=j["value"], unit="MS/s", seconds=round(j["steps"] * j["ms_per_step"] / 1e3, 3), steps=j["steps"], ms_per_step=j["ms_per_step"],
-               captures=j["config"]["captures_per_gpu"], workers=j["config"]["workers_per_gpu"], samples_per_capture=j["config"]["samples_per_capture"],
-               ts_packets_per_capture=j["config"].get("ts_packets_per_capture"), rs_byte_errors_corrected=j["config"].get("rs_byte_errors_corrected"),
-               chain="cconverter<u8> (fused) + cstln_receiver(linear, tiled, packed decisions) -> deconvol_sync -> mpeg_sync -> deinterleaver -> rs_decoder "
-                     "-> derandomizer -> TS in host memory; every decode starts from reset blocks (acquisition included)",
-               mode="`bench.py --workload c1 --no-cpu --steps 45` in a process of its own (GPU_MAX_HW_QUEUES=16), exit code %d" % r.returncode)
+               captures=j["config"]["captures_per_gpu"], engine=j["config"].get("engine"), samples_per_capture=j["config"]["samples_per_capture"],
+               ts_packets_per_capture=j["config"].get("ts_packets_per_capture"), rs_bit_errors_corrected=j["config"].get("rs_bit_errors_corrected"),
+               receiver_seams=j["config"].get("receiver_seams"), config4_one_capture_per_gpu=j.get("config4_one_capture_per_gpu"),
+               chain=j["config"]["workload"],
+               mode="`bench.py --workload c1 --no-cpu --steps 45` in a process of its own, exit code %d" % r.returncode)
     rl = dict(j["roofline"])
     rl["tile_kernel_avg_launch_ms"] = rl.pop("avg_launch_ms", None)
     rl["achieved"] = round(j["value"] * 1e6 * bench_alg_c1() / 1e9, 2)
     rl["frac"] = rl["hbm_frac"] = hbm_frac(j["value"] * 1e6, bench_alg_c1())
-    rl["traffic_source"] = "profiles/r03_bench/c1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes)"
+    rl["traffic_source"] = "not collected for this kernel: it is bound by vector-instruction issue (valu_issue below, profiles/r06_bench/c1_pmc_sq.txt), 0.04 of the HBM rate"
     out["roofline"] = rl
     if "verified" in j:
         v = j["verified"]
         out["pass"] = bool(v["pass"]) and r.returncode == 0
-        v["per_capture"] = v["per_capture"][:2] + [{"...": f"{len(v['per_capture']) - 2} more, all in `pass`"}]
+        if len(v.get("per_capture", [])) > 2:
+            v["per_capture"] = v["per_capture"][:2] + [{"...": f"{len(v['per_capture']) - 2} more, all in `pass`"}]
         out["verified"] = v
     else:
         out["pass"] = r.returncode == 0
@@ -1215,6 +1280,9 @@ def run_all(capi, synth, device, args):
                      ("c2_cnr", c2_cnr), ("anf1", anf1), ("anf1_scan", anf1_scan),
                      ("c2_offset", c2_offset), ("c3", c3),
                      ("c5_rescoped", c5_rescoped), ("c1", c1), ("c1_hs", c1_hs_entry), ("exact_batch", exact_batch), ("end_to_end", end_to_end)):
+        only = os.environ.get("LSDR_BENCH_MORE_ONLY")       # development: a comma-separated subset
+        if only and name not in only.split(","):
+            continue
         t0 = time.perf_counter()
         try:
             more[name] = fn(capi, synth, device, args)

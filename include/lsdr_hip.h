@@ -77,6 +77,34 @@ int lsdr_malloc(lsdr_ctx *ctx, size_t bytes, void **dev_ptr);
 int lsdr_free(lsdr_ctx *ctx, void *dev_ptr);
 int lsdr_malloc_host(size_t bytes, void **pinned_ptr);   /* pinned staging for file_reader/writer */
 int lsdr_free_host(void *pinned_ptr);
+/* ---- placed stream buffers (arena.hip) ----
+ * WHERE a resident buffer lands in HBM decides how fast a streaming kernel reads it (the same fir_filter launch: 0.37 ms over one 2 GiB
+ * buffer, 0.42 ms over the next, reproducibly per buffer; it goes with the physical backing, and the windows of ONE large allocation are of
+ * the fast kind far more often than separate allocations).  An arena is one device allocation handed out in 2 MiB-aligned windows, the
+ * FASTEST free ones first: replaces, for the large stream buffers of a graph, the `new T[size]` of pipebuf (framework.h:141-143) that has no
+ * such concern on a CPU.
+ *   lsdr_arena_place   the n_best fastest of up to max_windows free candidate windows of `bytes` (from the arena's start, or from its end
+ *                      downwards with from_tail).  "Fastest" under `probe` — it queues, on the context's stream, the launch whose speed
+ *                      matters over the candidate it is given; the library times 6 calls after 3 untimed ones with events — or, with a null
+ *                      probe, under a built-in streaming read of the window.  fill_from (device pointer, may be null): every candidate is
+ *                      first filled with `bytes` bytes from there (a probe that reads samples needs samples).  The search ends early once
+ *                      the n-th best candidate is 8 % under the median of at least five.  out[n_best], ms[n_best] (may be null): the
+ *                      windows and their probe times, fastest first.
+ *   lsdr_arena_probe_log  the probe time of every candidate the last lsdr_arena_place tried, in the order tried.
+ *   lsdr_ctx_set_arena    from now on lsdr_malloc(ctx, ≥ 1 MiB) is served from the arena (built-in probe, ≤ 12 candidates; an ordinary
+ *                      allocation once the arena is full) and lsdr_free gives such windows back: a graph built on the host framework
+ *                      gets placed device pipes unchanged.  Null detaches.  The arena must outlive what was allocated from it. */
+typedef struct lsdr_arena lsdr_arena;
+typedef int (*lsdr_probe_fn)(void *user, void *candidate_window);
+int lsdr_arena_create(lsdr_ctx *ctx, size_t bytes, lsdr_arena **arena);   /* LSDR_E_NOMEM: no such piece of device memory */
+void lsdr_arena_destroy(lsdr_arena *arena);
+size_t lsdr_arena_bytes(const lsdr_arena *arena);
+int lsdr_arena_owns(const lsdr_arena *arena, const void *dev_ptr);
+int lsdr_arena_place(lsdr_arena *arena, size_t bytes, unsigned n_best, unsigned max_windows, int from_tail, const void *fill_from,
+                     lsdr_probe_fn probe, void *user, void **out, float *ms);
+int lsdr_arena_release(lsdr_arena *arena, void *window);
+int lsdr_arena_probe_log(const lsdr_arena *arena, float *ms, unsigned cap, unsigned *n);
+int lsdr_ctx_set_arena(lsdr_ctx *ctx, lsdr_arena *arena);
 int lsdr_memcpy_h2d(lsdr_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes); /* async on ctx stream */
 int lsdr_memcpy_d2h(lsdr_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes); /* async on ctx stream */
 int lsdr_memcpy_d2d(lsdr_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);  /* pipebuf::pack() memmove, framework.h:153-159 (overlap-safe) */
@@ -267,7 +295,7 @@ enum {
   LSDR_FIR_MFMA_BLK = 3 /* block-polyphase form on the matrix pipe (a dense product): the taps in blocks of `decim`, each block an
                        * fmaf chain from zero in tap order, the block sums added in block order, in_scale multiplied into the taps (one
                        * rounding per tap) instead of the samples — its own stated arithmetic (oracle lo_fir_filter_blk), same
-                       * error bound as LSDR_FIR_FMA.  cf32 input, every decimation 2 … 64 (whatever
+                       * error bound as LSDR_FIR_FMA.  cf32 input, every decimation 1 … 64 (whatever
                        * Fs / (4·Fm) leandvb.cc:353-378 computes), ncoeffs ≤ 16·decim; refused (LSDR_E_ARG) otherwise. */
 };
 typedef struct {

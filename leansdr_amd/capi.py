@@ -92,6 +92,15 @@ _sig("lsdr_ctx_stream", vp, [vp])
 _sig("lsdr_malloc", C.c_int, [vp, c_sz, C.POINTER(vp)])
 _sig("lsdr_free", C.c_int, [vp, vp])
 _sig("lsdr_malloc_host", C.c_int, [c_sz, C.POINTER(vp)])
+PROBE_FN = C.CFUNCTYPE(C.c_int, vp, vp)
+_sig("lsdr_arena_create", C.c_int, [vp, c_sz, C.POINTER(vp)])
+_sig("lsdr_arena_destroy", None, [vp])
+_sig("lsdr_arena_bytes", c_sz, [vp])
+_sig("lsdr_arena_owns", C.c_int, [vp, vp])
+_sig("lsdr_arena_place", C.c_int, [vp, c_sz, C.c_uint, C.c_uint, C.c_int, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_float)])
+_sig("lsdr_arena_release", C.c_int, [vp, vp])
+_sig("lsdr_arena_probe_log", C.c_int, [vp, C.POINTER(C.c_float), C.c_uint, C.POINTER(C.c_uint)])
+_sig("lsdr_ctx_set_arena", C.c_int, [vp, vp])
 _sig("lsdr_free_host", C.c_int, [vp])
 _sig("lsdr_memcpy_h2d", C.c_int, [vp, vp, vp, c_sz])
 _sig("lsdr_memcpy_d2h", C.c_int, [vp, vp, vp, c_sz])
@@ -358,6 +367,70 @@ class DevBuf:
 
     def at(self, byte_offset):
         return vp(self.ptr + int(byte_offset))
+
+
+class ArenaWindow:
+    """A window of an Arena, with what a pipeline uses of a DevBuf; free() gives it back to the arena."""
+
+    def __init__(self, arena, ptr, nbytes, probe_ms=None):
+        self.arena, self.ptr, self.nbytes, self.probe_ms = arena, int(ptr), int(nbytes), probe_ms
+
+    def at(self, byte_offset):
+        return vp(self.ptr + int(byte_offset))
+
+    def free(self):
+        if self.ptr and self.arena.h:
+            check(lib.lsdr_arena_release(self.arena.h, vp(self.ptr)))
+        self.ptr = None
+
+
+class Arena:
+    """lsdr_arena (include/lsdr_hip.h): one large device allocation handed out in windows, the fastest ones first."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        h = vp()
+        check(lib.lsdr_arena_create(ctx.h, int(nbytes), C.byref(h)))
+        self.h = h
+        self.nbytes = int(lib.lsdr_arena_bytes(h))
+
+    def place(self, nbytes, n_best=1, max_windows=64, from_tail=False, fill_from=None, probe=None):
+        """probe(window_ptr: int) queues the launch(es) to be timed on the context's stream (None: the built-in streaming read).
+        Returns the n_best windows, fastest first (.probe_ms = ms per probe call)."""
+        out = (vp * n_best)()
+        ms = (C.c_float * n_best)()
+        err = []
+
+        def _cb(user, window):
+            try:
+                probe(int(window))
+                return 0
+            except BaseException as e:      # never unwinds through the C caller
+                err.append(e)
+                return -2
+        cb = PROBE_FN(_cb) if probe is not None else C.cast(None, PROBE_FN)
+        rc = lib.lsdr_arena_place(self.h, int(nbytes), n_best, max_windows, int(bool(from_tail)), vp(fill_from) if fill_from else None,
+                                  C.cast(cb, vp), None, out, ms)
+        if err:
+            raise err[0]
+        check(rc)
+        return [ArenaWindow(self, out[k], nbytes, float(ms[k])) for k in range(n_best)]
+
+    def probe_log(self):
+        n = C.c_uint()
+        buf = (C.c_float * 4096)()
+        check(lib.lsdr_arena_probe_log(self.h, buf, 4096, C.byref(n)))
+        return [float(buf[i]) for i in range(min(n.value, 4096))]
+
+    def attach(self, on=True):
+        """lsdr_ctx_set_arena: lsdr_malloc of 1 MiB or more on this context is served from the arena from now on."""
+        check(lib.lsdr_ctx_set_arena(self.ctx.h, self.h if on else None))
+
+    def close(self):
+        if self.h:
+            lib.lsdr_ctx_set_arena(self.ctx.h, None)
+            lib.lsdr_arena_destroy(self.h)
+            self.h = None
 
 
 class Ctx:

@@ -191,12 +191,14 @@ extern "C" {
 int lsdr_malloc(lsdr_ctx *c, size_t bytes, void **p) {
   LSDR_ARG(c && p);
   LSDR_HIP(hipSetDevice(c->device));
+  if (c->arena && bytes >= ((size_t)1 << 20) && lsdr_arena_malloc(c->arena, bytes, p) == LSDR_OK) return LSDR_OK;   // (a full arena: an ordinary allocation)
   LSDR_HIP(hipMalloc(p, bytes ? bytes : 1));
   return LSDR_OK;
 }
 int lsdr_free(lsdr_ctx *c, void *p) {
   LSDR_ARG(c);
   if (!p) return LSDR_OK;
+  if (c->arena && lsdr_arena_owns(c->arena, p)) return lsdr_arena_release(c->arena, p);
   LSDR_HIP(hipStreamSynchronize(c->stream));
   LSDR_HIP(hipFree(p));
   return LSDR_OK;

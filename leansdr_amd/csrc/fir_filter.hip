@@ -881,9 +881,9 @@ fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed, unsigned 
 }
 // The stream kernel of a geometry.  want_np = pairs of row tiles per wave tile asked for (k_fir_mfma_stream NP; 0 = the geometry's
 // default): the C2 geometry (decimation 30, 11 tap blocks) has compile-time forms at 8 (real taps' default), 4 (folded ring: complex
-// taps' default) and 6; decimations 10 and 30 run-time tap blocks at 8; every other decimation 2 … 64 comes from the sweep
+// taps' default) and 6; decimations 10 and 30 run-time tap blocks at 8; every other decimation 1 … 64 comes from the sweep
 // (fir_stream_sweep.hip: 8 up to D = 34, 4 unfolded above).  A want_np the geometry has no kernel for gets the default one.  k = nullptr:
-// no stream kernel (D = 1, D > 64).
+// no stream kernel (D > 64).
 stream_kernel pick_stream(unsigned D, bool cplx, unsigned nq, unsigned want_np = 0) {
   const char *e = getenv("LSDR_MFMA_NQT");                 // test hook: 0 forces the run-time-NQ kernels
   if (D == 30 && nq == 11 && !(e && !atoi(e))) {
@@ -894,7 +894,7 @@ stream_kernel pick_stream(unsigned D, bool cplx, unsigned nq, unsigned want_np =
   if (D == 10 && nq == 11 && !(e && !atoi(e))) return {cplx ? k_fir_mfma_stream<10, 1, 11> : k_fir_mfma_stream<10, 0, 11>, 8u, false};
   if (D == 10) return {cplx ? k_fir_mfma_stream<10, 1, 0> : k_fir_mfma_stream<10, 0, 0>, 8u, false};
   if (D == 30) return {cplx ? k_fir_mfma_stream<30, 1, 0> : k_fir_mfma_stream<30, 0, 0>, 8u, false};
-  if (D < 2 || D > kStreamMaxD) return {nullptr, 0u, false};
+  if (D < 1 || D > kStreamMaxD) return {nullptr, 0u, false};
   static fir_kernel_t (*const part[8])(unsigned, bool, bool) = {lsdr_fir_stream_sweep_0, lsdr_fir_stream_sweep_1, lsdr_fir_stream_sweep_2, lsdr_fir_stream_sweep_3,
                                                           lsdr_fir_stream_sweep_4, lsdr_fir_stream_sweep_5, lsdr_fir_stream_sweep_6, lsdr_fir_stream_sweep_7};
   return {part[D % 8](D, cplx, nq == 11 && !(e && !atoi(e))), stream_sweep_np(D, cplx), false};
@@ -1192,7 +1192,7 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
   f->d_btab[0] = f->d_btab[1] = nullptr;
   f->blk_ok[0] = f->blk_ok[1] = false;
   if (cfg->arith == LSDR_FIR_MFMA_BLK) {
-    // available for cf32 input, decimations 2 … 64 (k_fir_mfma_stream; LSDR_MFMA_STREAM=0: the register-staged k_fir_mfma_blk — 4, 8, 10,
+    // available for cf32 input, decimations 1 … 64 (k_fir_mfma_stream; LSDR_MFMA_STREAM=0: the register-staged k_fir_mfma_blk — 4, 8, 10,
     // 16, 30), N ≤ 16·D; anything else is refused at create time (the blocked sum is its own arithmetic: there is no other kernel
     // with the same bits to fall back to)
     {

@@ -1,4 +1,4 @@
-// leansdr_amd/csrc/fir_stream_sweep.hip — k_fir_mfma_stream for every decimation 2 … 64, real and complex taps, with run-time tap blocks
+// leansdr_amd/csrc/fir_stream_sweep.hip — k_fir_mfma_stream for every decimation 1 … 64, real and complex taps, with run-time tap blocks
 // (any ncoeffs ≤ 16·D) and with ELEVEN as a compile-time constant — what leandvb's own filter design gives at every decimation with its
 // default --resample-rej 10 and roll-off 0.35 (order ≈ 10.39·Fs/Fm ∈ (10·D, 11·D], leandvb.cc:364-366): the diagonal sums' addresses
 // become immediates, 3–7 % at decimation 30:
@@ -27,7 +27,7 @@ fir_kernel_t sweep_pick(unsigned D, bool cplx, bool eleven) {
   if constexpr (DT > (int)kStreamMaxD) return nullptr;
   else {
     if (D == (unsigned)DT) {
-      if constexpr (DT >= 2 && DT != 10 && DT != 30) return sweep_kernel<DT>(cplx, eleven);    // (10, 30: fir_filter.hip)
+      if constexpr (DT >= 1 && DT != 10 && DT != 30) return sweep_kernel<DT>(cplx, eleven);    // (10, 30: fir_filter.hip)
       else return nullptr;
     }
     return sweep_pick<DT + 8>(D, cplx, eleven);

@@ -7,6 +7,7 @@
 #include <vector>
 #include "../../include/lsdr_hip.h"
 
+struct lsdr_arena;
 struct lsdr_ctx {
   int device;
   hipStream_t stream;
@@ -29,7 +30,10 @@ struct lsdr_ctx {
   struct stage_pend { void *dst; const char *src; size_t bytes; };
   std::vector<stage_pend> stage_pending;   // D2H results to hand to their host destinations at the next lsdr_stage_sync
   std::vector<char *> stage_retired;       // outgrown arenas, still referenced by copies in flight
+  // placed stream buffers (arena.hip): lsdr_malloc serves requests of 1 MiB or more from here while set (lsdr_ctx_set_arena)
+  lsdr_arena *arena;
 };
+int lsdr_arena_malloc(lsdr_arena *a, size_t bytes, void **p);      // (arena.hip; LSDR_E_NOMEM when the arena has no free window)
 
 struct lsdr_event {
   lsdr_ctx *ctx;

@@ -162,11 +162,20 @@ struct runnable : detail::block_base {
 
 // The process-default device context: what a pipebuf constructed the reference's way — pipebuf(sch, name, size) — uses
 // as soon as a GPU-backed block attaches to it.  LSDR_DEVICE selects the GPU (default 0).
+// LSDR_ARENA_GIB=n: the device storage of the pipes (the `new T[size]` of the reference's pipebuf, framework.h:141-143) comes out of ONE
+// allocation of n GiB, the fastest windows first (lsdr_arena, include/lsdr_hip.h: where a stream buffer lands in HBM is worth ±8 % on a
+// filter that streams it) — worth it with large pipes (--buf-factor in the thousands); unset: ordinary allocations.
 inline lsdr_ctx *default_ctx() {
   static lsdr_ctx *c = NULL;
   if (!c) {
     const char *e = getenv("LSDR_DEVICE");
     lsdr_check(lsdr_ctx_create(e ? atoi(e) : 0, NULL, &c), "default device context");
+    const char *ag = getenv("LSDR_ARENA_GIB");
+    if (ag && atoi(ag) > 0) {
+      static lsdr_arena *arena = NULL;          // lives as long as the process, like the context
+      if (lsdr_arena_create(c, (size_t)atoi(ag) << 30, &arena) == LSDR_OK) lsdr_check(lsdr_ctx_set_arena(c, arena), "LSDR_ARENA_GIB");
+      else fprintf(stderr, "LSDR_ARENA_GIB=%s: %s (ordinary allocations)\n", ag, lsdr_last_error());
+    }
   }
   return c;
 }

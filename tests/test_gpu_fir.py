@@ -284,18 +284,20 @@ BLK_GEOMS = [(313, 30), (200, 30), (330, 30), (480, 30), (30, 30), (101, 10), (1
              (170, 15), (200, 17), (230, 20), (233, 21), (260, 24), (270, 25), (352, 32), (347, 33), (362, 34), (371, 35), (410, 36), (440, 40),
              (495, 45), (530, 50), (633, 60), (960, 60), (660, 63), (676, 64), (1024, 64), (3, 64),
              # leandvb's own designs (eleven tap blocks: the sweep's compile-time form) at the remaining residues
-             (43, 4), (63, 6), (73, 7), (85, 8), (157, 15), (167, 16), (209, 20), (251, 24), (105, 10)]
+             (43, 4), (63, 6), (73, 7), (85, 8), (157, 15), (167, 16), (209, 20), (251, 24), (105, 10),
+             # no decimation at all (fir_filter with decim = 1: leandvb's --resample at Fs < 8·Fm)
+             (1, 1), (11, 1), (16, 1)]
 
 
 @pytest.mark.parametrize("kern", ["stream", "blk_w2", "blk_w4"])
 @pytest.mark.parametrize("n,d", BLK_GEOMS, ids=[f"N{n}_D{d}" for n, d in BLK_GEOMS])
 def test_mfma_blk_is_its_stated_arithmetic_bit_for_bit(capi, ctx, oracle, kern, n, d):
     """LSDR_FIR_MFMA_BLK (block-polyphase dense product on the matrix pipe: k_fir_mfma_stream — LDS-direct refill, the default,
-    every decimation 2 … 64 — and k_fir_mfma_blk, register-staged, decimations 4, 8, 10, 16, 30) against its stated
+    every decimation 1 … 64 — and k_fir_mfma_blk, register-staged, decimations 4, 8, 10, 16, 30) against its stated
     arithmetic, oracle.fir_filter(fma="blk") — the reference's loop with the taps in blocks of D, an fmaf chain per block,
     block sums added in order — bit for bit, and against the reference's arithmetic under LSDR_FIR_FMA's error bound."""
     if kern != "stream" and d not in (4, 8, 10, 16, 30):
-        pytest.skip("k_fir_mfma_blk (register-staged) exists for decimations 4, 8, 10, 16, 30; k_fir_mfma_stream for 2 … 64")
+        pytest.skip("k_fir_mfma_blk (register-staged) exists for decimations 4, 8, 10, 16, 30; k_fir_mfma_stream for 1 … 64")
     w = 4 if kern == "blk_w4" else 2
     os.environ["LSDR_MFMA_STREAM"] = "1" if kern == "stream" else "0"
     rng = np.random.default_rng(n * 37 + d)
@@ -371,6 +373,6 @@ def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle, stream,
         d.free()
     f.close()
     # its own arithmetic: no other kernel has the same bits, so geometries without a kernel are refused, not re-routed
-    for nn, dd, fmt in ((313, 65, capi.IN_CF32), (313, 1, capi.IN_CF32), (600, 30, capi.IN_CF32), (313, 30, capi.IN_CU8)) + (((81, 7, capi.IN_CF32),) if stream == "0" else ()):
+    for nn, dd, fmt in ((313, 65, capi.IN_CF32), (17, 1, capi.IN_CF32), (600, 30, capi.IN_CF32), (313, 30, capi.IN_CU8)) + (((81, 7, capi.IN_CF32),) if stream == "0" else ()):
         with pytest.raises(Exception):
             capi.FirFilter(ctx, capi.lowpass(nn - 1, 0.01), dd, in_format=fmt, arith=capi.FIR_MFMA_BLK)

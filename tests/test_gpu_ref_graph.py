@@ -132,6 +132,18 @@ def test_same_command_line_same_bytes_f32_resample_fd_pp(tmp_path):
 
 
 @need_both
+def test_same_bytes_with_placed_pipes(tmp_path):
+    """LSDR_ARENA_GIB: the host framework's device pipes come out of an lsdr_arena (the fastest windows of one allocation) instead of separate
+    allocations — lsdr_malloc behind pipebuf's storage.  Same command line (the default front end, --resample, large pipes), same bytes."""
+    from leansdr_amd import synth
+    x, _ = synth.qpsk_baseband(120 * 40000, 120, seed=4, rms=1.0, snr_db=15.0, circular=False)
+    flags = ["--f32", "--float-scale", "75", "-f", "240e6", "--sr", "2000e3", "--cr", "1/2", "--resample", "--fd-pp", "3", "--buf-factor", "64", "-v"]
+    (ts_ref, pp_ref, _), (ts_gpu, pp_gpu, err) = _run_both(flags, x.astype(np.complex64).tobytes(), tmp_path, extra_fd=True, gpu_env={"LSDR_ARENA_GIB": "3"})
+    assert "LSDR_ARENA_GIB" not in err, err[-500:]          # (the arena was there: no fallback message)
+    assert len(pp_ref) > 100000 * 8 and pp_gpu == pp_ref and ts_gpu == ts_ref
+
+
+@need_both
 @pytest.mark.parametrize("cw,amp", [(0.0137, 0.4), (-0.0137, 0.4), (-0.0027, 0.05)], ids=["strong_out_of_band_pos", "strong_out_of_band_neg", "weak_in_band"])
 def test_default_front_end_fused(tmp_path, cw, amp):
     """The DEFAULT front end (`--anf 1 --resample`) with LSDR_FUSE_NOTCH=1: the reference's unchanged leandvb.cc builds auto_notch,

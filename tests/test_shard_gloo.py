@@ -169,16 +169,16 @@ def test_numa_pinning_degrades_gracefully():
 
 
 def test_arena_window_is_a_buffer_view():
-    """bench._Window: what C2Pipeline.place_buffers hands the pipeline for a stretch of its one large allocation — the pointer, .at() as a
-    DevBuf's, free() a no-op for the allocation (it goes with the arena)."""
+    """capi.ArenaWindow: what lsdr_arena_place (Arena.place) hands a pipeline for a window of the arena — the pointer, .at() as a DevBuf's;
+    free() gives the window back to its arena (here a closed one: nothing to call)."""
     import ctypes
     sys.path.insert(0, ROOT)
-    import bench
+    import leansdr_amd.capi as capi
 
-    class _Capi:
-        vp = ctypes.c_void_p
-    w = bench._Window(_Capi, 0x7000_0020_0000)
-    assert w.ptr == 0x7000_0020_0000 and isinstance(w.at(0), ctypes.c_void_p)
+    class _Arena:
+        h = None
+    w = capi.ArenaWindow(_Arena, 0x7000_0020_0000, 4 << 20, probe_ms=0.36)
+    assert w.ptr == 0x7000_0020_0000 and isinstance(w.at(0), ctypes.c_void_p) and w.nbytes == 4 << 20 and w.probe_ms == 0.36
     assert w.at(4096).value == 0x7000_0020_0000 + 4096
     w.free()
     assert w.ptr is None
