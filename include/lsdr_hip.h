@@ -89,7 +89,9 @@ int lsdr_free_host(void *pinned_ptr);
  *                      probe, under a built-in streaming read of the window.  fill_from (device pointer, may be null): every candidate is
  *                      first filled with `bytes` bytes from there (a probe that reads samples needs samples).  The search ends early once
  *                      the n-th best candidate is 8 % under the median of at least five.  out[n_best], ms[n_best] (may be null): the
- *                      windows and their probe times, fastest first.
+ *                      windows and their probe times, fastest first.  The arena REMEMBERS every probed window (time relative to its call's
+ *                      median): later calls try free positions inside stretches known to be fast first, never-probed ones next, known-slow
+ *                      ones last (the slow kind comes in stretches of GiBs; small buffers fit into a fast large window that was not taken).
  *   lsdr_arena_probe_log  the probe time of every candidate the last lsdr_arena_place tried, in the order tried.
  *   lsdr_ctx_set_arena    from now on lsdr_malloc(ctx, ≥ 1 MiB) is served from the arena (built-in probe, ≤ 12 candidates; an ordinary
  *                      allocation once the arena is full) and lsdr_free gives such windows back: a graph built on the host framework
@@ -102,6 +104,7 @@ size_t lsdr_arena_bytes(const lsdr_arena *arena);
 int lsdr_arena_owns(const lsdr_arena *arena, const void *dev_ptr);
 int lsdr_arena_place(lsdr_arena *arena, size_t bytes, unsigned n_best, unsigned max_windows, int from_tail, const void *fill_from,
                      lsdr_probe_fn probe, void *user, void **out, float *ms);
+int lsdr_arena_time(lsdr_arena *arena, void *dev_ptr, lsdr_probe_fn probe, void *user, float *ms);   /* the probe over any buffer, timed like a candidate */
 int lsdr_arena_release(lsdr_arena *arena, void *window);
 int lsdr_arena_probe_log(const lsdr_arena *arena, float *ms, unsigned cap, unsigned *n);
 int lsdr_ctx_set_arena(lsdr_ctx *ctx, lsdr_arena *arena);

@@ -98,6 +98,7 @@ _sig("lsdr_arena_destroy", None, [vp])
 _sig("lsdr_arena_bytes", c_sz, [vp])
 _sig("lsdr_arena_owns", C.c_int, [vp, vp])
 _sig("lsdr_arena_place", C.c_int, [vp, c_sz, C.c_uint, C.c_uint, C.c_int, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_float)])
+_sig("lsdr_arena_time", C.c_int, [vp, vp, vp, vp, C.POINTER(C.c_float)])
 _sig("lsdr_arena_release", C.c_int, [vp, vp])
 _sig("lsdr_arena_probe_log", C.c_int, [vp, C.POINTER(C.c_float), C.c_uint, C.POINTER(C.c_uint)])
 _sig("lsdr_ctx_set_arena", C.c_int, [vp, vp])
@@ -415,6 +416,25 @@ class Arena:
             raise err[0]
         check(rc)
         return [ArenaWindow(self, out[k], nbytes, float(ms[k])) for k in range(n_best)]
+
+    def time(self, ptr, probe):
+        """ms per call of probe(ptr) over any device pointer, timed like a candidate window (3 untimed calls, 6 timed)."""
+        ms = C.c_float()
+        err = []
+
+        def _cb(user, window):
+            try:
+                probe(int(window))
+                return 0
+            except BaseException as e:
+                err.append(e)
+                return -2
+        cb = PROBE_FN(_cb)
+        rc = lib.lsdr_arena_time(self.h, vp(int(ptr)), C.cast(cb, vp), None, C.byref(ms))
+        if err:
+            raise err[0]
+        check(rc)
+        return float(ms.value)
 
     def probe_log(self):
         n = C.c_uint()

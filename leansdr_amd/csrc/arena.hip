@@ -26,6 +26,12 @@ struct lsdr_arena {
   struct span { size_t off, len; };
   std::vector<span> used;                // sorted by offset, disjoint
   std::vector<float> log;                // probe time of every candidate of the last lsdr_arena_place
+  // what the arena has LEARNT about itself: every probed window with its time relative to the median of its own lsdr_arena_place call
+  // (< 1: faster than typical).  Later calls try the free positions inside known-fast stretches first, unknown ones next, known-slow
+  // ones last: the slow kind comes in stretches of GiBs (one run: input windows 31–39 of 40 slow, and all 64 small windows of the tail
+  // beside them slow too — while 30 small windows fit into ONE fast 2 GiB window that was not chosen).
+  struct rec { size_t off, len; float rel; };
+  std::vector<rec> map;
   unsigned *d_sink;                      // the built-in probe's result words
   hipEvent_t e0, e1;
 };
@@ -106,9 +112,21 @@ int lsdr_arena_place(lsdr_arena *a, size_t bytes, unsigned n_best, unsigned max_
     std::sort(s.begin(), s.end());
     return s[n_best - 1] < 0.92f * s[s.size() / 2];          // the n-th best is clearly of the fast kind
   };
-  for (size_t g = 0; g < n_grid && cand.size() < max_windows && !stop(); ++g) {
+  // free grid positions, ordered: inside stretches known to be fast first (smallest relative time), never-probed ones as typical (1.0), known-slow
+  // ones last; ties in address order (from the end with from_tail)
+  struct pos { size_t off; float key; };
+  std::vector<pos> order_in;
+  for (size_t g = 0; g < n_grid; ++g) {
     const size_t off = from_tail ? a->bytes - (g + 1) * step : g * step;
     if (!span_free(a, off, step)) continue;
+    float key = -1.f;
+    for (const auto &r : a->map)
+      if (off < r.off + r.len && r.off < off + step) key = key < r.rel ? r.rel : key;      // (the slowest stretch it touches)
+    order_in.push_back({off, key < 0.f ? 1.0f : key});
+  }
+  std::stable_sort(order_in.begin(), order_in.end(), [](const pos &x, const pos &y) { return x.key < y.key; });
+  for (size_t gi = 0; gi < order_in.size() && cand.size() < max_windows && !stop(); ++gi) {
+    const size_t off = order_in[gi].off;
     char *w = a->base + off;
     if (fill_from) LSDR_HIP(hipMemcpyAsync(w, fill_from, bytes, hipMemcpyDeviceToDevice, c->stream));
     auto once = [&]() -> int {
@@ -126,6 +144,12 @@ int lsdr_arena_place(lsdr_arena *a, size_t bytes, unsigned n_best, unsigned max_
     cand.push_back(off); t.push_back(ms / 6); a->log.push_back(ms / 6);
   }
   if (cand.size() < n_best) { lsdr_set_error("lsdr_arena_place: %zu free window(s) of %zu bytes, %u asked for", cand.size(), step, n_best); return LSDR_E_NOMEM; }
+  {
+    std::vector<float> sm(t);
+    std::sort(sm.begin(), sm.end());
+    const float med = sm[sm.size() / 2] > 0.f ? sm[sm.size() / 2] : 1.f;
+    for (size_t i = 0; i < cand.size(); ++i) a->map.push_back({cand[i], step, t[i] / med});
+  }
   std::vector<size_t> order(cand.size());
   for (size_t i = 0; i < order.size(); ++i) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return t[x] < t[y]; });
@@ -134,6 +158,23 @@ int lsdr_arena_place(lsdr_arena *a, size_t bytes, unsigned n_best, unsigned max_
     out[k] = a->base + cand[order[k]];
     if (ms_out) ms_out[k] = t[order[k]];
   }
+  return LSDR_OK;
+}
+
+// The probe's time over ANY device pointer (a buffer the caller already has: is the incumbent faster than the arena's best window?), measured
+// like a candidate's: 3 untimed calls, 6 timed ones.
+int lsdr_arena_time(lsdr_arena *a, void *ptr, lsdr_probe_fn probe, void *user, float *ms_out) {
+  LSDR_ARG(a && ptr && probe && ms_out);
+  lsdr_ctx *c = a->ctx;
+  LSDR_HIP(hipSetDevice(c->device));
+  for (int i = 0; i < 3; ++i) LSDR_TRY(probe(user, ptr));
+  LSDR_HIP(hipEventRecord(a->e0, c->stream));
+  for (int i = 0; i < 6; ++i) LSDR_TRY(probe(user, ptr));
+  LSDR_HIP(hipEventRecord(a->e1, c->stream));
+  LSDR_HIP(hipEventSynchronize(a->e1));
+  float ms = 0.f;
+  LSDR_HIP(hipEventElapsedTime(&ms, a->e0, a->e1));
+  *ms_out = ms / 6;
   return LSDR_OK;
 }
 

@@ -23,23 +23,24 @@ def test_windows_are_disjoint_aligned_and_come_back(capi, ctx):
     capi.check(capi.lib.lsdr_memcpy_d2h(ctx.h, back.ctypes.data_as(capi.vp), ws[1].at(0), x.nbytes))
     ctx.sync()
     assert np.array_equal(x, back)
-    # from the tail: other addresses, no overlap with what is taken
+    # more windows (from the tail where the arena knows nothing better: it tries stretches it has measured fast first): no overlap with what is taken
     tail = a.place(10 << 20, n_best=2, max_windows=4, from_tail=True)
-    assert all(t.ptr > max(ptrs) for t in tail)
+    assert all(t.ptr + (10 << 20) <= p or t.ptr >= p + (64 << 20) for t in tail for p in ptrs) and tail[0].ptr != tail[1].ptr
     # a full arena says so; released windows are handed out again
     with pytest.raises(Exception):
         a.place(900 << 20, n_best=2)
     for w in ws:
         w.free()
-    again = a.place(64 << 20, n_best=3, max_windows=3)          # (the first three free grid positions: everything in front of the tail is free again)
-    assert len({w.ptr for w in again}) == 3 and min(w.ptr for w in again) <= min(ptrs) and all(w.ptr < min(t.ptr for t in tail) for w in again)
+    again = a.place(64 << 20, n_best=3, max_windows=3)
+    assert len({w.ptr for w in again}) == 3
+    assert all(w.ptr + (64 << 20) <= t.ptr or w.ptr >= t.ptr + (12 << 20) for w in again for t in tail)      # (10 MiB windows occupy 12 MiB: 2 MiB granules)
     a.close()
 
 
 def test_probe_callback_decides_and_errors_surface(capi, ctx):
     a = capi.Arena(ctx, 256 << 20)
     seen = []
-    src = ctx.upload(np.full(1 << 20, 7, np.uint8))
+    src = ctx.upload(np.full(32 << 20, 7, np.uint8))          # (fill_from must hold `bytes` bytes)
 
     def probe(w):      # "fast" = the third candidate: its probe queues nothing, the others a big memset
         seen.append(w)
@@ -49,6 +50,13 @@ def test_probe_callback_decides_and_errors_surface(capi, ctx):
     order = list(dict.fromkeys(seen))
     assert w.ptr == order[2] and len(seen) == 9 * len(order)          # 3 untimed + 6 timed calls per candidate
     assert ctx.download(w, np.uint8, 1 << 20).tobytes() == bytes([7]) * (1 << 20)      # fill_from reached the window the probe left alone
+
+    # the same probe over a buffer the caller already has (an incumbent to compare the arena's windows with)
+    other = ctx.alloc(32 << 20)
+    n0 = len(seen)
+    ms = a.time(other.ptr, lambda p: capi.check(capi.lib.lsdr_memset(ctx.h, capi.vp(p), 0, 32 << 20)) or seen.append(p))
+    assert ms > 0 and len(seen) == n0 + 9 and seen[-1] == other.ptr
+    other.free()
 
     def bad(w):
         raise RuntimeError("probe failed")
@@ -65,7 +73,7 @@ def test_attached_arena_serves_lsdr_malloc(capi, ctx):
     small = ctx.alloc(4096)             # small: an ordinary allocation
     assert capi.lib.lsdr_arena_owns(a.h, capi.vp(big.ptr)) and not capi.lib.lsdr_arena_owns(a.h, capi.vp(small.ptr))
     more = [ctx.alloc(100 << 20) for _ in range(5)]      # the arena runs full: the rest are ordinary allocations, no error
-    assert sum(bool(capi.lib.lsdr_arena_owns(a.h, capi.vp(m.ptr))) for m in more) == 3
+    assert sum(bool(capi.lib.lsdr_arena_owns(a.h, capi.vp(m.ptr))) for m in more) == 4          # five windows of 100 MiB fit into 512 MiB
     x = np.arange(1000, dtype=np.float32)
     capi.check(capi.lib.lsdr_memcpy_h2d(ctx.h, big.at(0), x.ctypes.data_as(capi.vp), x.nbytes))
     assert np.array_equal(ctx.download(big, np.float32, 1000), x)
