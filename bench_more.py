@@ -286,7 +286,11 @@ def anf1(capi, synth, device, args):
     B, period, n_out, N, D, EXTRA = g["B"], g["period"], g["n_out"], g["N"], g["decim"], bench.EXTRA
     ctx = pipe.ctx
     # the endless stream: reps + 2 periods resident, run k reads from stream position F (≡ F mod period) on
-    d_x = ctx.alloc((B + 2 * period) * 8)
+    # (the resident capture: a window of the pipeline's arena — the fastest of eight under a streaming read, lsdr_arena_place — where there is one)
+    if getattr(pipe, "arena", None) is not None and os.environ.get("LSDR_BENCH_PLACE_INPUT", "1") != "0":
+        d_x = pipe.arena.place((B + 2 * period) * 8, n_best=1, max_windows=8)[0]
+    else:
+        d_x = ctx.alloc((B + 2 * period) * 8)
     dp = ctx.upload(cp.x)
     for r in range(g["reps"] + 2):
         capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_x.at(r * period * 8), dp.ptr, period * 8))
@@ -597,7 +601,19 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     reps = max(1, (batch_msamples << 20) // P)
     B = P * reps
     n_out = B // decim
-    d_in = ctx.alloc((B + P) * 8)
+    # (the resident batch: a window of an lsdr_arena, the fastest under a streaming read, where the input is read by the filter — one 32 GB hipMalloc lands
+    # as it lands; LSDR_BENCH_PLACE_INPUT=0: an ordinary allocation)
+    c3_arena = None
+    if use_fir and os.environ.get("LSDR_BENCH_PLACE_INPUT", "1") != "0" and not os.environ.get("LSDR_RANK_DEVICES"):
+        try:
+            c3_arena = capi.Arena(ctx, int(os.environ.get("LSDR_BENCH_ARENA_GIB", 160)) << 30)
+            d_in = c3_arena.place((B + P) * 8, n_best=1, max_windows=4)[0]
+        except Exception:
+            if c3_arena is not None:
+                c3_arena.close()
+            c3_arena = None
+    if c3_arena is None:
+        d_in = ctx.alloc((B + P) * 8)
     dp = ctx.upload(x if use_fir else x * np.float32(75.0))
     for r in range(reps + 1):
         capi.check(lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * P * 8), dp.ptr, P * 8))
@@ -837,6 +853,8 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
         fir.close()
     if use_fir:
         d_decs[1].free()
+    if c3_arena is not None:
+        c3_arena.close()
     ctx_t.close(); ctx_rx.close(); ctx.close()
     return out
 
