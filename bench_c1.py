@@ -355,20 +355,30 @@ class ChainJob(JobBase):
         refs = [None] * len(self.caps)
         if have_ref:
             out["checker"] = "oracle/_ref/leandvb " + " ".join(ref_args(self.anf)) + " (the reference binary, one process per capture on the host cores)"
-            tmp = tempfile.mkdtemp(prefix="lsdr_c1_")
-            procs = []
+            # the captures are read back one after the other (one context); hashing them and running the reference on them — one single-threaded
+            # process per capture, fed through a pipe — goes to a pool of host threads (both release the interpreter lock), at most 12 captures in flight
+            import threading
+            from concurrent.futures import ThreadPoolExecutor
             self.iq_sha = {}
-            for k in range(len(self.caps)):
-                f = os.path.join(tmp, f"cap{k}.u8")
-                iq = self.iq_of(k)
-                self.iq_sha[k] = hashlib.sha256(iq.tobytes()).hexdigest()
-                iq.tofile(f)
-                del iq
-                procs.append((k, f, subprocess.Popen([REFBIN] + ref_args(self.anf), stdin=open(f, "rb"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)))
-            for k, f, p in procs:
-                refs[k] = p.communicate()[0]
-                os.unlink(f)
-            os.rmdir(tmp)
+            room = threading.Semaphore(12)
+
+            def ref_job(k, iq):
+                try:
+                    sha = hashlib.sha256(iq).hexdigest()
+                    p = subprocess.Popen([REFBIN] + ref_args(self.anf), stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                    ts = p.communicate(memoryview(iq).cast("B"))[0]
+                    return k, sha, ts
+                finally:
+                    room.release()
+            with ThreadPoolExecutor(max_workers=12) as ex:
+                futs = []
+                for k in range(len(self.caps)):
+                    room.acquire()
+                    futs.append(ex.submit(ref_job, k, np.ascontiguousarray(self.iq_of(k))))
+                for fu in futs:
+                    k, sha, ts = fu.result()
+                    self.iq_sha[k] = sha
+                    refs[k] = ts
         else:
             out["checker"] = ("tests/golden/c1_ts.json (TS hashes recorded where the reference binary decoded the same IQ), else the transmitted packet "
                               "sequence (oracle/_ref/leandvb not present on this machine)")
