@@ -9,6 +9,6 @@ d=json.load(open("bench_full.json"))
 bp=d["config"]["buffer_placement"] or {}
 ti=bp.get("filter_launch_ms_by_input_window",[]); td=[v for l in bp.get("filter_launch_ms_by_decimated_window",[]) for v in l] or [0]
 print("run $r:", d["value"], "frac", d["roofline"]["frac"], "launch ms", d["roofline"]["avg_launch_ms"], "unplaced", (d.get("unplaced") or {}).get("value"), (d.get("unplaced") or {}).get("frac"),
-      "| input windows: best %.4f median %.4f worst %.4f of %d | decimated windows: best %.4f median %.4f worst %.4f of %d" % (min(ti), sorted(ti)[len(ti)//2], max(ti), len(ti), min(td), sorted(td)[len(td)//2], max(td), len(td)), bp.get("input_windows_paired"), bp.get("chosen_pair_ms"), "verified", d["verified"]["pass"])
+      "| input windows: best %.4f median %.4f worst %.4f of %d | decimated windows: best %.4f median %.4f worst %.4f of %d" % (min(ti), sorted(ti)[len(ti)//2], max(ti), len(ti), min(td), sorted(td)[len(td)//2], max(td), len(td)), bp.get("input_windows_paired"), bp.get("chosen_pair_ms"), bp.get("pipeline_ms_per_batch_by_output_set"), bp.get("output_set_in_use"), "verified", d["verified"]["pass"])
 PY
 done
