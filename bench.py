@@ -51,7 +51,9 @@ EXTRA_RRC = 384            # ... with the RRC fir_sampler (read-ahead 166): the 
 
 from leansdr_amd.tolerance import TOL, check_tiled      # THE tolerance of the tiled receiver (stated once, shared with tests/)
 
-DEFAULT_TILE = (256, 256)  # receiver tile geometry of the headline (tile_len, warm-up), samples of the decimated stream
+DEFAULT_TILE = (512, 256)  # receiver tile geometry of the headline (tile_len, warm-up), samples of the decimated stream: 64 symbols of warm-up as in
+                           # rounds 2-5, tiles of 128 symbols instead of 64 (half the seams, 3/4 of the receiver's symbol steps: 669-672 -> 689-695 GS/s over six
+                           # processes each, profiles/r06_bench/headline_repeat_tiles.txt; longer tiles make the receiver the pacer: 640+ samples 590-620)
 ALG_BYTES_PER_SAMPLE_C2 = 8.0 + 4.0 / 120.0      # cf32 in + one softsymbol per 120 samples = 8.03
 
 
@@ -355,63 +357,52 @@ class C2Pipeline:
         t_in = self.arena.probe_log()
         # The decimated-stream buffers (70 MB each, WRITTEN by the launch) matter as much, and what is fast there goes with the input window it is
         # paired with: one process — the launch 0.353 ms over the chosen input window into the buffer hipMalloc had returned, 0.408–0.417 into
-        # every one of 64 arena windows; the next process all 64 at 0.352–0.362 (profiles/r06_bench/headline_repeat.txt).  So the pair is chosen: for the
-        # fastest input windows in turn, the buffers there are (the incumbents) and arena windows are timed under the launch over THAT input; the first
-        # input window whose three best outputs are within 3 % of its own figure is taken, else the best of the three.
-        nd = len(cp.dec)
-        inc = list(cp.dec)
-        options, t_dec_all = [], []
-        for w in ins:
-            probe_d = lambda p, w=w: self.fir.run_dev(w.ptr, n_in, p, n_dec)
-            pool = [(self.arena.time(d.ptr, probe_d), d, False) for d in inc]
-            good = lambda pl: sorted(m for m, _, _ in pl)[nd - 1] <= 1.03 * w.probe_ms
-            fresh = []
-            if not good(pool):
-                fresh = self.arena.place(n_dec * 8, n_best=nd, max_windows=32, from_tail=True, probe=probe_d)
-                t_dec_all.append([round(v, 4) for v in self.arena.probe_log()])
-                pool += [(d.probe_ms, d, True) for d in fresh]
-            pool.sort(key=lambda e: e[0])
-            options.append((pool[nd - 1][0], w, pool[:nd], fresh))
-            if good(pool):
-                break
-        score, w_best, chosen, _ = min(options, key=lambda o: o[0])
-        cp.d_in.free()
-        cp.d_in = w_best
+        # every one of 64 arena windows; the next process all 64 at 0.352–0.362 (profiles/r06_bench/headline_repeat_before_pairing.txt).  So the PAIR is
+        # chosen: for the fastest input windows in turn, the buffers there are (the incumbents) and arena windows are timed under the launch over THAT input
         # … and the launch alone is not the pipeline: the receiver reads decimated buffer k while the filter writes k + 1.  One run — input window 0.353 ms,
         # three arena output windows 0.352–0.353 each under the probe — had the launch at 0.414 ms in the pipeline where eight others (the buffers hipMalloc
-        # had returned, 0.355–0.363 under the probe) had 0.393.  So the output SETS play the pipeline itself: the probe's choice, the incumbents, and arena
-        # windows from the arena's other end, 24 batches each after 4 untimed; the fastest set stays.
-        sets = [("fastest under the launch alone", [d for _, d, _ in chosen])]
-        if any(f for _, _, f in chosen):
-            sets.append(("the buffers as allocated", list(inc)))
-        head = []
-        for name, from_tail in (("arena windows from its start", False), ("arena windows from its end", True)):
-            if from_tail and any(f for _, _, f in chosen):
-                continue          # (the probe's choice already came from there)
-            try:
-                ws = self.arena.place(n_dec * 8, n_best=nd, max_windows=8, from_tail=from_tail, probe=lambda p: self.fir.run_dev(w_best.ptr, n_in, p, n_dec))
-                sets.append((name, ws))
-                head += ws
-            except Exception:
-                pass
+        # had returned, 0.355–0.363 under the probe) had 0.393.  So per input window the output SETS play the pipeline itself — the three fastest under the
+        # probe, the incumbents, arena windows from its start and from its end — 24 batches each after 4 untimed; the next input window is tried only
+        # while the best set's batch takes more than 1.16 × the input window's launch alone (a good pair: ≈ 1.13–1.15 by this wall-clock measure).
+        nd = len(cp.dec)
+        inc = list(cp.dec)
+        orig_in = cp.d_in
+        made, played, t_dec_all = [], [], []           # arena windows handed out here; (ms, input window, set name, set)
 
-        def pipeline_ms(dset, nb=24):
-            cp.dec = list(dset)
+        def pipeline_ms(w, dset, nb=24):
+            cp.d_in, cp.dec = w, list(dset)
             self.run(4, False); self.sync()
             t0 = time.perf_counter()
             self.run(nb, False); self.sync()
             return (time.perf_counter() - t0) / nb * 1e3
-        played = [(pipeline_ms(dset), name, dset) for name, dset in sets]
-        _, best_name, best_set = min(played, key=lambda e: e[0])
+        for w in ins:
+            probe_d = lambda p, w=w: self.fir.run_dev(w.ptr, n_in, p, n_dec)
+            pool = [(self.arena.time(d.ptr, probe_d), d) for d in inc]
+            sets = [("the buffers as allocated", list(inc))]
+            for name, from_tail, nmax in (("arena windows from its end", True, 32), ("arena windows from its start", False, 8)):
+                try:
+                    ws = self.arena.place(n_dec * 8, n_best=nd, max_windows=nmax, from_tail=from_tail, probe=probe_d)
+                except Exception:
+                    continue
+                t_dec_all.append([round(v, 4) for v in self.arena.probe_log()])
+                made += ws
+                sets.append((name, ws))
+                pool += [(d.probe_ms, d) for d in ws]
+            pool.sort(key=lambda e: e[0])
+            fastest = [d for _, d in pool[:nd]]
+            if all({id(d) for d in fastest} != {id(d) for d in ds} for _, ds in sets):
+                sets.append(("fastest under the launch alone", fastest))
+            here = [(pipeline_ms(w, ds), w, name, ds) for name, ds in sets]
+            played += here
+            if min(h[0] for h in here) <= 1.16 * w.probe_ms:
+                break
+        best_ms, w_best, best_name, best_set = min(played, key=lambda e: e[0])
         keep = {id(d) for d in best_set}
-        for _, w, _, fresh in options:
-            for d in fresh:
-                if id(d) not in keep:
-                    d.free()
-        for d in list(inc) + list(head):
+        for d in inc + made:
             if id(d) not in keep:
                 d.free()
-        cp.dec = list(best_set)
+        orig_in.free()
+        cp.d_in, cp.dec = w_best, list(best_set)
         # The capture lives in ONE window — or in TWO read alternately where the candidates cannot be told apart (all within 4 %: none is known to be
         # of the fast kind; tools/placement_probe4.py: the same launch re-reading one buffer of the slow kind back to back streams 4.9–5.1 TB/s,
         # alternating between two of them 5.4; a fast one 5.75 either way).
@@ -423,9 +414,9 @@ class C2Pipeline:
             w.free()
         return dict(engine="lsdr_arena_place / lsdr_arena_time (include/lsdr_hip.h)", arena_gib=arena_gib, input_windows_tried=len(t_in), input_buffers_in_use=2 if two else 1,
                     filter_launch_ms_by_input_window=[round(float(v), 4) for v in t_in],
-                    input_windows_paired=len(options), chosen_pair_ms={"input_window_with_first_buffer": round(w_best.probe_ms, 4), "slowest_of_its_output_buffers": round(score, 4),
-                                                                       "output_buffers_from_the_arena": int(sum(1 for d in best_set if isinstance(d, capi.ArenaWindow)))},
-                    pipeline_ms_per_batch_by_output_set={name: round(ms, 4) for ms, name, _ in played}, output_set_in_use=best_name,
+                    input_windows_paired=len({id(e[1]) for e in played}), chosen_pair={"input_window_launch_ms_alone": round(w_best.probe_ms, 4), "pipeline_ms_per_batch": round(best_ms, 4),
+                                                                                       "output_buffers_from_the_arena": int(sum(1 for d in best_set if isinstance(d, capi.ArenaWindow)))},
+                    pipeline_ms_per_batch_by_output_set=[{"input_window": round(w.probe_ms, 4), "set": name, "ms": round(ms, 4)} for ms, w, name, _ in played], output_set_in_use=best_name,
                     filter_launch_ms_by_decimated_window=t_dec_all)
 
     def run(self, n_batches, timed, snapshot_last=False, track_tol=None):

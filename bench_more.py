@@ -141,7 +141,8 @@ def headline_arith(capi, args):
 def four_captures(capi, synth, device, args):
     import bench
     # four captures whose batches together are the headline's one (256 Mi samples per GPU and batch)
-    pipe = bench.C2Pipeline(capi, synth, device, 4, max(16, args.batch_msamples * args.captures // 4), args.period_msamples, (args.tile_len, args.tile_warmup),
+    # (tiles of 256 samples as in rounds 4-5: a quarter of the headline's samples per capture and launch leaves too few 512-sample tiles: 610 vs 592 GS/s)
+    pipe = bench.C2Pipeline(capi, synth, device, 4, max(16, args.batch_msamples * args.captures // 4), args.period_msamples, (256, args.tile_warmup),
                             seed0=77, rx_cus=args.rx_cus, cu_pattern=args.cu_pattern, fir_arith=headline_arith(capi, args))
     t0 = time.perf_counter()
     pipe.run(8, False)
@@ -184,7 +185,8 @@ def c2_rrc(capi, synth, device, args):
     of 16 steps per sample and 167 taps (sdr.h:635-689, leandvb.cc:440-458) in place of the linear interpolator; tiled, every capture
     verified against the oracle's exact fir_filter -> exact serial receiver with the same sampler under TOL."""
     import bench
-    tile = (int(os.environ.get("LSDR_RRC_TILE", args.tile_len)), int(os.environ.get("LSDR_RRC_WARMUP", max(args.tile_warmup, 512))))
+    tile = (int(os.environ.get("LSDR_RRC_TILE", 256)),      # (the RRC tiles pace this pipeline: 256-sample tiles 350 GS/s, 512 300)
+             int(os.environ.get("LSDR_RRC_WARMUP", max(args.tile_warmup, 512))))
     pipe = bench.C2Pipeline(capi, synth, device, args.captures, args.batch_msamples, args.period_msamples, tile, seed0=61,
                             fir_arith=headline_arith(capi, args), sampler="rrc")
     t0 = time.perf_counter()
@@ -627,7 +629,7 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     # the receiver has its own stream: fir_filter(k+1) runs while cstln_receiver(k) (queued) works on the other decimated buffer
     ctx_rx = capi.Ctx(device)
     ev_fir = [ctx.event() for _ in range(2)]
-    rx = capi.CstlnReceiver(ctx_rx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_CHAIN_TILE", 4 * args.tile_len)),
+    rx = capi.CstlnReceiver(ctx_rx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_CHAIN_TILE", 1024)),
                             tile_warmup=max(args.tile_warmup, 512), **rx_kw)
     # The FEC tail lives on its own context (stream) and its own host thread: every block of it returns data-dependent counts
     # (a host synchronisation per call), so the only way to keep the front end busy meanwhile is a second thread — the
@@ -1025,7 +1027,7 @@ def c1_hs(capi, synth, device, args, hs=True, streams=4):
             else:
                 st = self.rx.state()
                 self.rx.close()
-                self.rx = capi.CstlnReceiver(self.ctx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_C1_TILE", 4 * args.tile_len)),
+                self.rx = capi.CstlnReceiver(self.ctx, mode=capi.RX_TILED, tile_len=int(os.environ.get("LSDR_C1_TILE", 1024)),
                                              tile_warmup=max(args.tile_warmup, 512), **self.rx_kw)
                 self.rx.set_state(st)
 

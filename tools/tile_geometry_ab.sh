@@ -2,8 +2,8 @@
 # tools/tile_geometry_ab.sh — the C2 headline at several receiver tile geometries (tile_len / warm-up, samples of the decimated stream),
 # three rounds interleaved (placement and box state move a single run by ±2 %): GPU box
 cd "$(dirname "$0")/.."
-for r in 1 2 3; do
-for g in "256 256" "384 128" "512 128" "512 256" "768 128" "640 128"; do
+for r in 1 2; do
+for g in "256 256" "256 128" "384 128" "512 128" "512 256" "384 256"; do
   set -- $g
   timeout 300 python bench.py --no-more --no-cpu --tile-len $1 --tile-warmup $2 2>/dev/null | python -c "
 import json,sys
