@@ -878,6 +878,13 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   // LSDR_SYM_HARD2: the decisions only, packed (rx_tiling.h): the word being filled, the last 16 symbols, the row, the snapshot
   // of the tail at the end of the warm-up
   unsigned hacc = 0, htail = 0, hwarm = 0, hnwarm = 0, hcnt = 0;
+  // Soft symbols of the tile's BODY leave in groups of four (LDS-staged tiles): one 16-byte store per four symbol steps instead of four 4-byte
+  // ones.  A lane writes its own row of the staging buffer, so every store instruction of the wavefront touches 64 different cache lines whatever
+  // its width — the REQUESTS are what the filter next door pays for (no symbol stores at all: filter launch 0.399 → 0.389 ms in the C2
+  // pipeline, profiles/r06_bench/rx_ablation.txt), and this is a quarter of them.  (stage_stride is a multiple of four symbols: rows start on 16 bytes.)
+  unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;
+  unsigned *bp = po;
+  const bool quads = LDS && !HARD && !(a.dbg & 1u);
   unsigned *const hcol = HARD ? a.hstage + j : nullptr;      // this tile's column of the transposed staging
 
   int n = 0;                                              // current sample
@@ -994,6 +1001,12 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
             hacc = (hacc << 2) | hs;
             if ((++hcnt & 15u) == 0) hcol[(unsigned long long)((hcnt >> 4) - 1) * a.hpitch] = hacc;
           }
+        } else if (quads && body) {
+          q0 = q1; q1 = q2; q2 = q3; q3 = raw.x;
+          if (++qn == 4u) {
+            *reinterpret_cast<uint4 *>(bp) = make_uint4(q0, q1, q2, q3);
+            bp += 4; qn = 0;
+          }
         } else {
           *dp = raw.x; dp += keep;
         }
@@ -1052,6 +1065,10 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
     }
   }
   ti.mu_end = mu; ti.phase_end = phase; ti.count = cnt;
+  if (quads && qn) {      // the last one to three symbols (what lies behind them in the 16 bytes is never read: ti.count says how many there are)
+    const uint4 v = qn == 1u ? make_uint4(q3, 0u, 0u, 0u) : (qn == 2u ? make_uint4(q2, q3, 0u, 0u) : make_uint4(q1, q2, q3, 0u));
+    *reinterpret_cast<uint4 *>(bp) = v;
+  }
   if (valid) {
     if (HARD) {
       if (hcnt & 15u) hcol[(unsigned long long)(hcnt >> 4) * a.hpitch] = hacc << (2 * (16 - (hcnt & 15u)));
@@ -1456,7 +1473,7 @@ static int rx_tiled_plan(lsdr_rx *r, unsigned share, const void *in, size_t n_in
   const unsigned first = Wc;
   unsigned n_tiles = 1;
   if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
-  const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
+  const unsigned stage_stride = ((first > Lc ? first : Lc) * sym_per_chunk + 3u + 4u) & ~3u;      // (whole 16-byte groups, one spare: rx_tile_tol's last store)
 
   const bool hard = r->cfg.out_format == LSDR_SYM_HARD2;
   const unsigned hstride = stage_stride / 16 + 2;          // words per tile
