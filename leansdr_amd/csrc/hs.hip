@@ -231,7 +231,7 @@ __device__ __forceinline__ int fq_chunk(const fq_tiled_args &a, fq_state &st, co
   return cnt;
 }
 
-constexpr int kFqLanes = 32;   // tiles per wavefront
+constexpr int kFqLanes = 64;   // tiles per wavefront (32 until round 6: half the lanes idle; the kernel is bound by its dependent table look-ups per symbol, i.e. by lanes in flight)
 __global__ __launch_bounds__(64) void k_fastqpsk_tiles(fq_tiled_args a) {
   unsigned j;
   if (blockIdx.x == 0) { if (threadIdx.x != 0) return; j = 0; }
