@@ -878,13 +878,13 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
   // LSDR_SYM_HARD2: the decisions only, packed (rx_tiling.h): the word being filled, the last 16 symbols, the row, the snapshot
   // of the tail at the end of the warm-up
   unsigned hacc = 0, htail = 0, hwarm = 0, hnwarm = 0, hcnt = 0;
-  // Soft symbols of the tile's BODY leave in groups of four (LDS-staged tiles): one 16-byte store per four symbol steps instead of four 4-byte
-  // ones.  A lane writes its own row of the staging buffer, so every store instruction of the wavefront touches 64 different cache lines whatever
+  // Soft symbols of the tile's BODY leave in groups of four: one 16-byte store per four symbol steps instead of four 4-byte ones (staged and
+  // direct-load tiles alike: c3's direct-load tiles 576 → 609 GS/s).  A lane writes its own row of the staging buffer, so every store instruction of the wavefront touches 64 different cache lines whatever
   // its width — the REQUESTS are what the filter next door pays for (no symbol stores at all: filter launch 0.399 → 0.389 ms in the C2
   // pipeline, profiles/r06_bench/rx_ablation.txt), and this is a quarter of them.  (stage_stride is a multiple of four symbols: rows start on 16 bytes.)
   unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0, qn = 0;
   unsigned *bp = po;
-  const bool quads = LDS && !HARD && !(a.dbg & 1u);
+  const bool quads = !HARD && !(a.dbg & 1u);
   unsigned *const hcol = HARD ? a.hstage + j : nullptr;      // this tile's column of the transposed staging
 
   int n = 0;                                              // current sample
