@@ -625,6 +625,22 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=cstln, fec=rate, omega=omega, meas_decimation=1 << 22, pll_adjustment=1 / 6.0)
     fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0, arith=headline_arith(capi, args)) if use_fir else None
     d_decs = [ctx.alloc((n_out + bench.EXTRA) * 8) for _ in range(2)] if use_fir else None
+    if use_fir and c3_arena is not None:
+        # the decimated-stream buffers: the two hipMalloc returned, or two arena windows — whichever pair the filter launch over THIS input writes faster (the
+        # output side goes with the input window it is paired with, DESIGN §5: 549 against 600–607 GS/s on one box)
+        probe = lambda p: fir.run_dev(d_in.ptr, B + bench.EXTRA * decim + N, p, n_out + bench.EXTRA)
+        try:
+            t_alloc = max(c3_arena.time(d.ptr, probe) for d in d_decs)
+            wins = c3_arena.place((n_out + bench.EXTRA) * 8, n_best=2, max_windows=8, from_tail=True, probe=probe)
+            if max(w.probe_ms for w in wins) < t_alloc:
+                for d in d_decs:
+                    d.free()
+                d_decs = wins
+            else:
+                for w in wins:
+                    w.free()
+        except Exception:
+            pass
     d_dec = d_decs[0] if use_fir else None
     # the receiver has its own stream: fir_filter(k+1) runs while cstln_receiver(k) (queued) works on the other decimated buffer
     ctx_rx = capi.Ctx(device)
