@@ -344,7 +344,8 @@ class C2Pipeline:
         n_dec = g["n_out"] + self.extra
         nbytes = (g["B"] + g["period"]) * 8
         # (not when several ranks share this GPU: 160 GiB each would not fit)
-        arena_gib = int(os.environ.get("LSDR_BENCH_ARENA_GIB", 160)) if not os.environ.get("LSDR_RANK_DEVICES") else 0
+        shared = os.environ.get("LSDR_RANK_DEVICES") and not os.environ.get("LSDR_BENCH_PLACE_SHARED")      # (PLACE_SHARED: a test of the multi-rank placement path on one GPU, small arenas)
+        arena_gib = int(os.environ.get("LSDR_BENCH_ARENA_GIB", 160)) if not shared else 0
         if arena_gib <= 0:
             return None
         try:
@@ -858,7 +859,7 @@ def main():
     # (`unplaced`; roofline.frac_unplaced) — not part of the timed region below.
     unplaced = None
     n_cand = int(os.environ.get("LSDR_BENCH_PLACEMENT", 40))
-    if args.captures == 1 and n_cand > 1 and not os.environ.get("LSDR_RANK_DEVICES"):
+    if args.captures == 1 and n_cand > 1 and (not os.environ.get("LSDR_RANK_DEVICES") or os.environ.get("LSDR_BENCH_PLACE_SHARED")):
         if world == 1 and os.environ.get("LSDR_BENCH_UNPLACED", "1") != "0":      # (0: profiling runs — fewer launches that are not the timed region's)
             pipe.run(args.warmup * bps, False)
             pipe.sync()

@@ -11,9 +11,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra, ranks=2):
+def _run(extra, ranks=2, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["LSDR_RANK_DEVICES"] = ",".join(["0"] * ranks)
+    env.update(env_extra or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-more"] + extra,
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=900)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
@@ -29,6 +30,15 @@ def test_c2_two_ranks_on_one_gpu_every_rank_verifies():
     assert v["ranks"] == 2 and v["ranks_passed"] == 2 and v["pass"] and v["fir_bit_exact"] and v["captures_checked"] == 2
     # two ranks' samples, the slower rank's clock
     assert j["config"]["samples_per_step_per_gpu"] * 2 * j["steps"] == pytest.approx(j["value"] * 1e6 * j["ms_per_step"] * 1e-3 * j["steps"], rel=1e-3)
+
+
+def test_c2_two_ranks_place_their_buffers():
+    """The headline's shape (one capture per rank) with every rank placing its buffers through its own lsdr_arena — what the ranks of an 8-GPU
+    job do on their own GPUs; here two ranks with 24 GiB arenas on GPU 0 (LSDR_BENCH_PLACE_SHARED lifts the one-rank-per-GPU condition)."""
+    j = _run(["--batches-per-step", "4", "--batch-msamples", "32"], env_extra={"LSDR_BENCH_PLACE_SHARED": "1", "LSDR_BENCH_ARENA_GIB": "24", "LSDR_BENCH_PLACEMENT": "6"})
+    assert j["n_gpus"] == 2 and j["value"] > 0 and "unplaced" not in j          # (the unplaced pass is a one-rank extra)
+    v = j["verified"]
+    assert v["ranks"] == 2 and v["ranks_passed"] == 2 and v["pass"] and v["fir_bit_exact"]
 
 
 def test_c1_two_ranks_on_one_gpu_every_rank_verifies():
