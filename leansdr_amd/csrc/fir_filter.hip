@@ -43,7 +43,7 @@
 using namespace lsdr_fir;
 using namespace lsdr_fir_main;
 
-// fir_stream_sweep.hip, one translation unit per part: the stream kernel of decimation D ≡ part (mod 8), 2 … 64 without 10 and 30
+// fir_stream_sweep.hip, one translation unit per part: the stream kernel of decimation D ≡ part (mod 8), 1 … 64 without 10 and 30
 // (eleven: the form with 11 tap blocks as a compile-time constant)
 lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_0(unsigned D, bool cplx, bool eleven);
 lsdr_fir::fir_kernel_t lsdr_fir_stream_sweep_1(unsigned D, bool cplx, bool eleven);

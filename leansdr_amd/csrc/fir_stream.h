@@ -1,7 +1,7 @@
 // leansdr_amd/csrc/fir_stream.h — k_fir_mfma_stream (LSDR_FIR_MFMA_BLK's kernel, fir_filter<cf32,float>::run of dsp.h:233-280 on the
 // matrix pipe) and what its launches share: the argument block of every fir_filter kernel, the vector types, the LDS budget.
 // Included by fir_filter.hip (the benchmark geometry's compile-time forms, decimations 10 and 30) and by fir_stream_sweep.hip
-// (one translation unit per eighth of the decimations 2 … 64: every Fs/(4·Fm) leandvb.cc:353-378 can ask for).
+// (one translation unit per eighth of the decimations 1 … 64: every Fs/(4·Fm) leandvb.cc:353-378 can ask for).
 #pragma once
 #include "lsdr_internal.h"
 
