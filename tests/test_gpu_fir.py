@@ -345,6 +345,40 @@ def test_mfma_blk_run_time_and_compile_time_tap_blocks_give_the_same_bits(capi, 
     assert np.array_equal(outs[1], outs[3]) and np.array_equal(outs[1], oracle.fir_filter(co, d, x, -0.021, fma="blk", scale=3.0)[0])
 
 
+@pytest.mark.parametrize("n,d", [(81, 7), (343, 33), (16, 1), (625, 60)])
+def test_mfma_blk_sweep_kernels_short_inputs_capped_outputs_and_run_multi(capi, ctx, oracle, n, d):
+    """The sweep's kernels (padded LDS rows, 128- and 64-row wave tiles) at the edges: inputs shorter than one tile, one output, an output cap that
+    cuts a tile, three streams in one launch — against lo_fir_filter_blk, bit for bit."""
+    rng = np.random.default_rng(1000 * d + n)
+    co = capi.lowpass(n - 1, 0.4 / d) if n > 1 else np.array([0.5], np.float32)
+    f = capi.FirFilter(ctx, co, d, in_scale=0.5, arith=capi.FIR_MFMA_BLK)
+    big = 70000 * d // 7 + 13
+    xs = [((rng.standard_normal(big) + 1j * rng.standard_normal(big)) * 20).astype(np.complex64) for _ in range(3)]
+    for m in (0, n - 1, n, n + d - 1, n + d, n + 17 * d + 3, 5000, big):
+        m = min(max(m, 0), big)
+        y, cons = f.run(xs[0][:m])
+        want, wcons = oracle.fir_filter(co, d, xs[0][:m], fma="blk", scale=0.5)
+        assert cons == wcons and np.array_equal(y, want), m
+    cap = (big - n) // d
+    dins = [ctx.upload(x) for x in xs]
+    douts = [ctx.alloc(cap * 8 + 64) for _ in xs]
+    cons, prod = f.run_multi_dev([q.ptr for q in dins], big, [q.ptr for q in douts], cap)
+    assert prod == cap and cons == cap * d
+    for x, dout in zip(xs, douts):
+        want, _ = oracle.fir_filter(co, d, x, fma="blk", scale=0.5)
+        assert np.array_equal(ctx.download(dout, np.complex64, prod), want[:prod])
+    cons, prod = f.run_dev(dins[1].ptr, big, douts[1].ptr, 777)          # cap_out binds inside a tile
+    assert (cons, prod) == (777 * d, 777)
+    want, _ = oracle.fir_filter(co, d, xs[1], fma="blk", scale=0.5)
+    assert np.array_equal(ctx.download(douts[1], np.complex64, 777), want[:777])
+    f.set_freq(0.0371)                                                   # complex taps: the other kernel of the pair
+    y, _ = f.run(xs[2][:20000])
+    assert np.array_equal(y, oracle.fir_filter(co, d, xs[2][:20000], 0.0371, fma="blk", scale=0.5)[0])
+    for q in dins + douts:
+        q.free()
+    f.close()
+
+
 @pytest.mark.parametrize("stream", ["1", "0"])
 def test_mfma_blk_run_multi_short_inputs_and_refusals(capi, ctx, oracle, stream, monkeypatch):
     monkeypatch.setenv("LSDR_MFMA_STREAM", stream)
