@@ -178,17 +178,40 @@ struct fq_tiled_args {
 // starts from scratch next to the PLL's unstable equilibrium can otherwise pump its frequency integrator into a false
 // lock that outlasts the tile (seen once in ~3000 tiles at 18 dB: phase ramping through the whole tile).
 template <bool CLAMP, typename Emit>
-__device__ __forceinline__ int fq_chunk(const fq_tiled_args &a, fq_state &st, const unsigned short *pin, Emit emit,
+__device__ __forceinline__ int fq_chunk(const fq_tiled_args &a, fq_state &st, const unsigned short *pin, int avail, Emit emit,
                                         long long f_lo = 0, long long f_hi = 0) {
   float mu = st.mu;
   unsigned phase = st.phase & 0xffffu;
   long long freqw = st.freqw;
   int cnt = 0;
+  // The tile kernel is bound by the REQUESTS its lanes make (every lane walks its own tile: 64 cache lines per vector-memory instruction, six
+  // table look-ups per symbol): the samples therefore come eight at a time — one 16-byte load per ≈ 6 samples instead of two 2-byte loads per
+  // symbol — and a symbol whose first sample is the previous symbol's second one (4 of 5 at 1.2 samples per symbol) keeps that look-up.
+  typedef unsigned fq_v4u __attribute__((ext_vector_type(4)));
+  fq_v4u w = {0u, 0u, 0u, 0u};
+  int wb = -16, pn = -2;
+  unsigned pp1 = 0;
+  auto sample = [&](int k) -> unsigned {
+    const unsigned i = (unsigned)(k - wb);
+    const unsigned dw = i < 4u ? (i < 2u ? w.x : w.y) : (i < 6u ? w.z : w.w);
+    return (dw >> (16u * (i & 1u))) & 0xffffu;
+  };
   for (int n = 0; n < kChunk; ++n) {
     if (mu < 1) {
-      const unsigned x0 = pin[n], x1 = pin[n + 1];
-      const unsigned p0 = a.polar[(x0 & 255u) * 256u + (x0 >> 8)];
+      if (n + 1 > wb + 7) {
+        wb = n & ~1;
+        if (wb + 8 <= avail) w = *reinterpret_cast<const fq_v4u *>(pin + wb);
+        else {      // the input's last samples: nothing is read behind them (avail = samples readable from pin on)
+          unsigned e[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) e[i] = wb + i < avail ? (unsigned)pin[wb + i] : 0u;
+          w = (fq_v4u){e[0] | e[1] << 16, e[2] | e[3] << 16, e[4] | e[5] << 16, e[6] | e[7] << 16};
+        }
+      }
+      const unsigned x0 = sample(n), x1 = sample(n + 1);
+      const unsigned p0 = n == pn + 1 ? pp1 : a.polar[(x0 & 255u) * 256u + (x0 >> 8)];
       const unsigned p1 = a.polar[(x1 & 255u) * 256u + (x1 >> 8)];
+      pn = n; pp1 = p1;
       const unsigned a0 = (((p0 & 0xffffu) - phase) & 0xffffu) >> 8;
       const unsigned a1 = (unsigned)(((long long)(p1 & 0xffffu) - ((long long)phase + freqw)) & 0xffff) >> 8;
       const unsigned r0 = a.rect[a0 * 256u + ((p0 >> 16) >> 1)];
@@ -253,18 +276,27 @@ __global__ __launch_bounds__(64) void k_fastqpsk_tiles(fq_tiled_args a) {
   const long long f_lo = s.freqw - a.freq_window, f_hi = s.freqw + a.freq_window;
   unsigned char last = 0;
   unsigned char *po = a.stage + (unsigned long long)j * a.stage_stride;
-  unsigned cnt = 0, got = 0;
+  unsigned cnt = 0, got = 0, sacc = 0;
   const unsigned short *in16 = reinterpret_cast<const unsigned short *>(a.in);
   for (unsigned long long c = cb; c < c1; ++c) {
     const bool body = c >= c0;
     if (c == c0) { ti.mu_begin = s.mu; ti.phase_begin = (float)(s.phase & 0xffffu); ti.pre = last; ti.has_pre = got ? 1u : 0u; }
     const bool lastwarm = c + 1 == c0;
     unsigned nw = 0;
-    auto emit = [&](unsigned char v) { if (body) po[cnt++] = v; else { last = v; if (lastwarm) pw[nw++] = v; } };
-    const int n = j == 0 ? fq_chunk<false>(a, s, in16 + c * kChunk, emit) : fq_chunk<true>(a, s, in16 + c * kChunk, emit, f_lo, f_hi);
+    // (body symbols leave four at a time: a quarter of the scattered store requests)
+    auto emit = [&](unsigned char v) {
+      if (body) {
+        sacc |= (unsigned)v << (8u * (cnt & 3u));
+        if ((cnt & 3u) == 3u) { *reinterpret_cast<unsigned *>(po + (cnt & ~3u)) = sacc; sacc = 0u; }
+        ++cnt;
+      } else { last = v; if (lastwarm) pw[nw++] = v; }
+    };
+    const int avail = (int)((total - c) * kChunk + 1 < 1024 ? (total - c) * kChunk + 1 : 1024);
+    const int n = j == 0 ? fq_chunk<false>(a, s, in16 + c * kChunk, avail, emit) : fq_chunk<true>(a, s, in16 + c * kChunk, avail, emit, f_lo, f_hi);
     if (!body) got += (unsigned)n;
     if (lastwarm) ti.n_warm = nw;
   }
+  if (cnt & 3u) *reinterpret_cast<unsigned *>(po + (cnt & ~3u)) = sacc;
   ti.mu_end = s.mu; ti.phase_end = (float)(s.phase & 0xffffu); ti.count = cnt;
   a.info[j] = ti;
   if (j == a.n_tiles - 1) {
@@ -477,7 +509,7 @@ static int fq_run_tiled(lsdr_fastqpsk *r, const lsdr_cu8 *in, size_t n_in, uint8
   const unsigned first = Lc > Wc ? Lc : Wc;
   unsigned n_tiles = 1;
   if (chunks > first) n_tiles += (unsigned)((chunks - first + Lc - 1) / Lc);
-  const unsigned stage_stride = (first > Lc ? first : Lc) * sym_per_chunk;
+  const unsigned stage_stride = ((first > Lc ? first : Lc) * sym_per_chunk + 7u) & ~3u;      // (rows start on four bytes: the tiles store four symbols at a time)
   if (!r->d_relabel) {
     // quadrant step K of a tile's carrier frame against tile 0's: symbol_arg_tile = symbol_arg − K·16384, so the true
     // quadrant is the tile's + K; symbols are quadrant_to_symbol[] = {0,2,3,1} (sdr.h:1067).
