@@ -1142,7 +1142,7 @@ def c1_hs(capi, synth, device, args, hs=True, streams=4):
 
 
 def c1_hs_entry(capi, synth, device, args):
-    return c1_hs(capi, synth, device, args, hs=True, streams=int(os.environ.get("LSDR_HS_STREAMS", 4)))
+    return c1_hs(capi, synth, device, args, hs=True, streams=int(os.environ.get("LSDR_HS_STREAMS", 8)))      # (8 decoders: 40 GS/s; 4: 35.5; 2: 33 — the tile kernel is bound by its table look-ups per symbol)
 
 
 def exact_batch(capi, synth, device, args):

@@ -189,6 +189,7 @@ __device__ __forceinline__ int fq_chunk(const fq_tiled_args &a, fq_state &st, co
   // symbol — and a symbol whose first sample is the previous symbol's second one (4 of 5 at 1.2 samples per symbol) keeps that look-up.
   typedef unsigned fq_v4u __attribute__((ext_vector_type(4)));
   fq_v4u w = {0u, 0u, 0u, 0u};
+  const unsigned sq0 = a.sincos[8192u], sq1 = a.sincos[24576u], sq2 = a.sincos[40960u], sq3 = a.sincos[57344u];
   int wb = -16, pn = -2;
   unsigned pp1 = 0;
   auto sample = [&](int k) -> unsigned {
@@ -231,7 +232,8 @@ __device__ __forceinline__ int fq_chunk(const fq_tiled_args &a, fq_state &st, co
       st.hist_p[1][0] = st.hist_p[0][0]; st.hist_p[1][1] = st.hist_p[0][1];
       st.hist_c[1][0] = st.hist_c[0][0]; st.hist_c[1][1] = st.hist_c[0][1];
       st.hist_p[0][0] = (unsigned char)s_re; st.hist_p[0][1] = (unsigned char)s_im;
-      const unsigned c = a.sincos[((symbol_arg & 49152u) + 8192u) & 0xffffu];
+      const unsigned qd = symbol_arg >> 14;          // sincos[quadrant·16384 + 8192]: four entries in all, fetched once per chunk (sq0 … sq3)
+      const unsigned c = qd < 2u ? (qd == 0u ? sq0 : sq1) : (qd == 2u ? sq2 : sq3);
       st.hist_c[0][0] = (unsigned char)(c & 255u); st.hist_c[0][1] = (unsigned char)(c >> 8);
       const int muerr =
           ((int)(signed char)(st.hist_p[0][0] - st.hist_p[2][0]) * ((int)st.hist_c[1][0] - 128) +
