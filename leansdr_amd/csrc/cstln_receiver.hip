@@ -1270,14 +1270,33 @@ __global__ __launch_bounds__(64) void k_rx_batch(rx_batch_args a) {
   const typename in_stream<FMT>::type pin = in_make<FMT>(a.in[sidx]);
   lsdr_softsymbol *po = a.out[sidx];
   unsigned long long nout = 0;
+  // (a lane writes its own capture's symbols: 64 cache lines per store instruction — four symbols per 16-byte store where the capture's output
+  // starts on 16 bytes, a quarter of the requests)
+  const bool quads = ((size_t)po & 15u) == 0;
+  unsigned q0 = 0, q1 = 0, q2 = 0, q3 = 0;
   for (unsigned long long c = 0; c < a.chunks; ++c) {
     if (SAMP == 1) s.samp_freqw = s.freqw;     // sampler->update_freq(freqw), sdr.h:790
     bool wrote;
     unsigned cnt = 0;
-    rx_chunk<SAMP, ld_vec>(a.T, a.C, s, pin + c * kChunk, [&](lsdr_softsymbol ss) { po[nout + cnt++] = ss; }, nullptr, &wrote);
+    rx_chunk<SAMP, ld_vec>(a.T, a.C, s, pin + c * kChunk, [&](lsdr_softsymbol ss) {
+      if (quads) {
+        q0 = q1; q1 = q2; q2 = q3; q3 = *reinterpret_cast<const unsigned *>(&ss);
+        if (((nout + cnt) & 3ull) == 3ull) *reinterpret_cast<uint4 *>(po + (nout + cnt - 3)) = make_uint4(q0, q1, q2, q3);
+        ++cnt;
+      } else {
+        po[nout + cnt++] = ss;
+      }
+    }, nullptr, &wrote);
     nout += cnt;
     s.meas_count += kChunk;                    // sdr.h:905-913 (the measurement pipes are not wired in the batch form)
     while (s.meas_count >= a.C.meas_decimation) s.meas_count -= a.C.meas_decimation;
+  }
+  if (quads && (nout & 3ull)) {      // the last one to three symbols
+    unsigned *pu = reinterpret_cast<unsigned *>(po);
+    const unsigned r = (unsigned)(nout & 3ull);
+    if (r == 1u) pu[nout - 1] = q3;
+    else if (r == 2u) { pu[nout - 2] = q2; pu[nout - 1] = q3; }
+    else { pu[nout - 3] = q1; pu[nout - 2] = q2; pu[nout - 1] = q3; }
   }
   a.states[sidx] = s;
   a.produced[sidx] = nout;
