@@ -95,7 +95,8 @@ int lsdr_free_host(void *pinned_ptr);
  *   lsdr_arena_probe_log  the probe time of every candidate the last lsdr_arena_place tried, in the order tried.
  *   lsdr_ctx_set_arena    from now on lsdr_malloc(ctx, ≥ 1 MiB) is served from the arena (built-in probe, ≤ 12 candidates; an ordinary
  *                      allocation once the arena is full) and lsdr_free gives such windows back: a graph built on the host framework
- *                      gets placed device pipes unchanged.  Null detaches.  The arena must outlive what was allocated from it. */
+ *                      gets placed device pipes unchanged.  Null detaches.  The arena must outlive what was allocated from it.
+ * One thread per arena, like every object of a context. */
 typedef struct lsdr_arena lsdr_arena;
 typedef int (*lsdr_probe_fn)(void *user, void *candidate_window);
 int lsdr_arena_create(lsdr_ctx *ctx, size_t bytes, lsdr_arena **arena);   /* LSDR_E_NOMEM: no such piece of device memory */
