@@ -110,3 +110,25 @@ def test_fast_qpsk_tiled_tracks_like_serial(capi, ctx, oracle):
     assert bits_equal(got[:len(head["sym"])], want[:len(head["sym"])])          # acquisition part is the exact kernel
     same = (got == want).mean()
     assert same >= 0.999 and stats["tiles"] > 100 and stats["bad_seams"] == 0, (same, stats)
+
+
+def test_fast_qpsk_tiled_same_symbols_wherever_the_input_starts(capi, ctx):
+    """The tile kernel reads its samples eight at a time (16-byte loads at the sample's own address): the same stream at a 2-byte-aligned, a 4-byte-aligned
+    and a 16-byte-aligned device address, and cut so that the last chunk ends at the buffer's last readable sample, gives the same symbols."""
+    from leansdr_amd import synth_dvbs
+    iq, _ = synth_dvbs.capture_u8(n_packets=120, seed=3)
+    n = (len(iq) // 2 - 8) // 128 * 128 + 1          # whole chunks + the read-ahead sample: nothing readable behind it
+    x = np.ascontiguousarray(iq[: 2 * n])
+    outs = []
+    for off in (0, 1, 2, 8):                        # samples of padding in front: device address ≡ 0, 2, 4, 16 (mod 16)
+        buf = ctx.alloc(2 * (n + off) + 16)
+        capi.check(capi.lib.lsdr_memcpy_h2d(ctx.h, buf.at(2 * off), x.ctypes.data_as(capi.vp), x.nbytes))
+        ctx.sync()
+        r = capi.FastQpsk(ctx, 1.2)
+        r.set_tiled(True)
+        d_out = ctx.alloc(n + 4096)
+        cons, prod = r.run_dev(buf.at(2 * off), n, d_out.ptr, n + 4096)
+        outs.append((cons, ctx.download(d_out, np.uint8, prod).tobytes()))
+        r.close(); buf.free(); d_out.free()
+    assert outs[0][0] == n - 1 and len(outs[0][1]) > 0.8 * n / 1.2
+    assert all(o == outs[0] for o in outs[1:])

@@ -9,7 +9,7 @@ import bench
 import pyoracle as po
 ctx = capi.Ctx(0)
 coeffs, decim = bench.c2_filter(capi)
-n = 64 << 20
+n = int(os.environ.get("FIR_ALONE_MI", "64")) << 20      # Mi samples per launch
 rng = np.random.default_rng(0)
 blk = ((rng.standard_normal(1 << 22) + 1j * rng.standard_normal(1 << 22)) * 0.7).astype(np.complex64)
 d_in = ctx.alloc(n * 8); d_blk = ctx.upload(blk)
