@@ -603,19 +603,27 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     reps = max(1, (batch_msamples << 20) // P)
     B = P * reps
     n_out = B // decim
-    # (the resident batch: a window of an lsdr_arena, the fastest under a streaming read, where the input is read by the filter — one 32 GB hipMalloc lands
-    # as it lands; LSDR_BENCH_PLACE_INPUT=0: an ordinary allocation)
+    # (the resident batch: the buffer hipMalloc returns or a window of an lsdr_arena — whichever the filter launch reads faster; one 32 GB
+    # hipMalloc lands as it lands.  LSDR_BENCH_PLACE_INPUT=0: the ordinary allocation)
+    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0, arith=headline_arith(capi, args)) if use_fir else None
+    d_decs = [ctx.alloc((n_out + bench.EXTRA) * 8) for _ in range(2)] if use_fir else None
+    d_in = ctx.alloc((B + P) * 8)
     c3_arena = None
     if use_fir and os.environ.get("LSDR_BENCH_PLACE_INPUT", "1") != "0" and not os.environ.get("LSDR_RANK_DEVICES"):
         try:
             c3_arena = capi.Arena(ctx, int(os.environ.get("LSDR_BENCH_ARENA_GIB", 160)) << 30)
-            d_in = c3_arena.place((B + P) * 8, n_best=1, max_windows=4)[0]
+            probe_in = lambda p: fir.run_dev(p, B + bench.EXTRA * decim + N, d_decs[0].ptr, n_out + bench.EXTRA)      # (speed does not depend on the data)
+            t_alloc = c3_arena.time(d_in.ptr, probe_in)
+            w = c3_arena.place((B + P) * 8, n_best=1, max_windows=4, probe=probe_in)[0]
+            if w.probe_ms < t_alloc:
+                d_in.free()
+                d_in = w
+            else:
+                w.free()
         except Exception:
             if c3_arena is not None:
                 c3_arena.close()
             c3_arena = None
-    if c3_arena is None:
-        d_in = ctx.alloc((B + P) * 8)
     dp = ctx.upload(x if use_fir else x * np.float32(75.0))
     for r in range(reps + 1):
         capi.check(lib.lsdr_memcpy_d2d(ctx.h, d_in.at(r * P * 8), dp.ptr, P * 8))
@@ -623,8 +631,6 @@ def full_chain(capi, synth, device, args, cstln, rate, sps, use_fir, batch_msamp
     dp.free()
     omega = float(sps / decim)
     rx_kw = dict(sampler=capi.SAMP_LINEAR, cstln=cstln, fec=rate, omega=omega, meas_decimation=1 << 22, pll_adjustment=1 / 6.0)
-    fir = capi.FirFilter(ctx, coeffs, decim, in_scale=75.0, arith=headline_arith(capi, args)) if use_fir else None
-    d_decs = [ctx.alloc((n_out + bench.EXTRA) * 8) for _ in range(2)] if use_fir else None
     if use_fir and c3_arena is not None:
         # the decimated-stream buffers: the two hipMalloc returned, or two arena windows — whichever pair the filter launch over THIS input writes faster (the
         # output side goes with the input window it is paired with, DESIGN §5: 549 against 600–607 GS/s on one box)
