@@ -288,11 +288,23 @@ def anf1(capi, synth, device, args):
     B, period, n_out, N, D, EXTRA = g["B"], g["period"], g["n_out"], g["N"], g["decim"], bench.EXTRA
     ctx = pipe.ctx
     # the endless stream: reps + 2 periods resident, run k reads from stream position F (≡ F mod period) on
-    # (the resident capture: a window of the pipeline's arena — the fastest of eight under a streaming read, lsdr_arena_place — where there is one)
+    # (the resident capture: the buffer hipMalloc returns or a window of the pipeline's arena — whichever the pipeline's plain filter launch, as a stand-in for
+    # the fused block's pass, reads faster into the output ring)
+    NB = 8
+    ring = ctx.alloc((NB * n_out + EXTRA + 64) * 8)
+    d_x = ctx.alloc((B + 2 * period) * 8)
     if getattr(pipe, "arena", None) is not None and os.environ.get("LSDR_BENCH_PLACE_INPUT", "1") != "0":
-        d_x = pipe.arena.place((B + 2 * period) * 8, n_best=1, max_windows=8)[0]
-    else:
-        d_x = ctx.alloc((B + 2 * period) * 8)
+        try:
+            probe = lambda p: pipe.fir.run_dev(p, B + EXTRA * D + N, ring.ptr, n_out + EXTRA)
+            t_alloc = pipe.arena.time(d_x.ptr, probe)
+            w = pipe.arena.place((B + 2 * period) * 8, n_best=1, max_windows=8, probe=probe)[0]
+            if w.probe_ms < t_alloc:
+                d_x.free()
+                d_x = w
+            else:
+                w.free()
+        except Exception:
+            pass
     dp = ctx.upload(cp.x)
     for r in range(g["reps"] + 2):
         capi.check(capi.lib.lsdr_memcpy_d2d(ctx.h, d_x.at(r * period * 8), dp.ptr, period * 8))
@@ -302,8 +314,6 @@ def anf1(capi, synth, device, args):
         nf.set_overlap(True)                   # depending on which hardware queues the runtime gives the block's two streams: off)
     # the block's output pipe: a ring of NB batch slots in ONE allocation, so that the head of batch k sits behind batch k − 1 (the receiver's
     # read-ahead) without a copy — except where the ring wraps (one batch in NB: its head is copied behind the last slot)
-    NB = 8
-    ring = ctx.alloc((NB * n_out + EXTRA + 64) * 8)
 
     class _Slot:
         def __init__(self, j):
