@@ -251,8 +251,8 @@ int lsdr_notch_fir_track(lsdr_notch_fir *h, float freq_tap, float tap_multiplier
 float lsdr_notch_fir_current_freq(const lsdr_notch_fir *h);
 int lsdr_notch_fir_run(lsdr_notch_fir *h, const lsdr_cf32 *in, size_t n_in, lsdr_cf32 *out, size_t cap_out, size_t *consumed, size_t *produced);
 int lsdr_notch_fir_slot_bin(lsdr_notch_fir *h);   /* waits for the stream; −1: nothing detected yet */
-/* Opt-in: run k+1's detect chain and filter pass on streams of the block's own, next to run k's tail (first output, fix-ups, recurrence,
- * state) on the context's stream; the output is complete in the order of the context's stream, as always.  The own streams do NOT wait
+/* Opt-in: run k+1's detect chain and filter pass on ONE stream of the block's own, next to run k's tail (first output, fix-ups, recurrence,
+ * state) on the context's stream; the output is complete in the order of the context's stream, as always.  The own stream does NOT wait
  * for earlier work queued on the context: the caller promises that an input buffer is complete when lsdr_notch_fir_run is called with
  * it and stays untouched until that run has completed on the context's stream.  Same results, bit for bit. */
 int lsdr_notch_fir_set_overlap(lsdr_notch_fir *h, int on);

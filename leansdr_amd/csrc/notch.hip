@@ -1639,7 +1639,7 @@ struct lsdr_notch_fir {
   int *d_bin_carry;                 // [2] the carried bin, ping-pong between consecutive runs' k_nf_taps
   float2 *d_r[2]; size_t r_cap[2];
   unsigned run_no;
-  // lsdr_notch_fir_set_overlap: detect chain + taps on s_det, the filter pass on s_pass, the tail (head, fix-ups, scan, state) on the
+  // lsdr_notch_fir_set_overlap: detect chain + taps and the filter pass on s_det (= s_pass since round 6: one stream), the tail (head, fix-ups, scan, state) on the
   // context's stream; events hand over between them
   bool overlap; hipStream_t s_det, s_pass; hipEvent_t ev_taps[2], ev_pass[2], ev_tail[2]; bool tail_recorded[2];
   cfft_dev fft;
@@ -1740,7 +1740,7 @@ void lsdr_notch_fir_destroy(lsdr_notch_fir *h) {
   if (!h) return;
   (void)nf_sync_all(h);
   if (h->s_det) (void)hipStreamDestroy(h->s_det);
-  if (h->s_pass) (void)hipStreamDestroy(h->s_pass);
+  if (h->s_pass && h->s_pass != h->s_det) (void)hipStreamDestroy(h->s_pass);
   for (int i = 0; i < 2; ++i) {
     if (h->ev_taps[i]) (void)hipEventDestroy(h->ev_taps[i]);
     if (h->ev_pass[i]) (void)hipEventDestroy(h->ev_pass[i]);
@@ -1770,12 +1770,12 @@ int lsdr_notch_fir_set_overlap(lsdr_notch_fir *h, int on) {
   LSDR_HIP(hipSetDevice(h->ctx->device));
   LSDR_TRY(nf_sync_all(h));
   if (on && !h->s_det) {
-    // (two plain streams.  Measured, kernel traces of the C2 pipeline with auto_notch: when the runtime puts both on ONE hardware queue the
-    // chain of run k+1 runs between two passes, 306 GS/s against 292 without overlap; on queues of their own — GPU_MAX_HW_QUEUES=8, or the
-    // chain's stream at high priority — the tail's one-workgroup kernels wait 250–340 µs for a slot among the pass's 8192 queued
-    // workgroups: 268–272 GS/s.  Opt-in, and bench_more.anf1 leaves it off.)
+    // (ONE plain stream for the detect chain and the pass — the pass of run k + 1 needs its taps anyway — so that the two are back to back whatever hardware
+    // queues the runtime hands out, and the tail stays on the context's stream, where it runs beside the next pass like the receiver's kernels do.  Measured
+    // (bench_more.anf1, round 6): 356–358 GS/s without, 372–377 with.  Round 5 had two streams: +5 % when the runtime mapped them onto one hardware queue,
+    // −8 % on queues of their own (the chain's one-workgroup kernels waiting among the pass's queued workgroups); stream priorities: −17 %.)
     LSDR_HIP(hipStreamCreateWithFlags(&h->s_det, hipStreamNonBlocking));
-    LSDR_HIP(hipStreamCreateWithFlags(&h->s_pass, hipStreamNonBlocking));
+    h->s_pass = h->s_det;
     for (int i = 0; i < 2; ++i) {
       LSDR_HIP(hipEventCreateWithFlags(&h->ev_taps[i], hipEventDisableTiming));
       LSDR_HIP(hipEventCreateWithFlags(&h->ev_pass[i], hipEventDisableTiming));
