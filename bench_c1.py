@@ -546,11 +546,21 @@ def run_workload(capi, device, args, shard):
     mode = getattr(args, "c1_mode", "batch")
     anf = int(getattr(args, "c1_anf", 1))
     seed0 = capture_seeds(rank, 1)[0]
+    # The captures' TS goes back over PCIe into pinned host memory (412 MB per step at 32 captures = 29 GB/s at 300 GS/s): the job's buffers are allocated
+    # while the process sits on the CPUs next to its GPU, so that they are pinned on that NUMA node — boxes where `c1` came out at 260–267 instead of
+    # 300–308 GS/s had the tile kernel at the same 5.7 ms and 2 ms more per step outside it.  (With several ranks bench.py has pinned the rank already; with one, the
+    # affinity is given back afterwards: the CPU baseline uses every core.)
+    restore = None
+    if world == 1 and hasattr(os, "sched_getaffinity"):
+        restore = os.sched_getaffinity(0)
+        shard.pin_to_gpu_numa(capi.device_pci_bus_id(device))
     if mode == "chain":
         job = ChainJob(capi, device, args.c1_captures, args.c1_msamples, args.c1_workers, args.c1_tile or 2048, args.c1_warmup, seed0=seed0)
     else:
         job = C1Job(capi, device, args.c1_captures, args.c1_msamples, args.c1_groups, args.c1_tile or 4096, args.c1_warmup, seed0=seed0, anf=anf,
                     aux_cus=getattr(args, "c1_aux_cus", 0))
+    if restore is not None:
+        os.sched_setaffinity(0, restore)
     job.run(max(1, args.warmup))
     shard.barrier()
     t0 = time.perf_counter()
