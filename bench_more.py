@@ -185,8 +185,10 @@ def c2_rrc(capi, synth, device, args):
     of 16 steps per sample and 167 taps (sdr.h:635-689, leandvb.cc:440-458) in place of the linear interpolator; tiled, every capture
     verified against the oracle's exact fir_filter -> exact serial receiver with the same sampler under TOL."""
     import bench
-    tile = (int(os.environ.get("LSDR_RRC_TILE", 256)),      # (the RRC tiles pace this pipeline: 256-sample tiles 350 GS/s, 512 300)
-             int(os.environ.get("LSDR_RRC_WARMUP", max(args.tile_warmup, 512))))
+    # (the RRC tiles pace this pipeline.  Rounds 4-5: 256-sample tiles after 512 of warm-up — 3 symbol steps per symbol; with the taps in LDS and the samples in
+    # pairs (cstln_receiver.hip, round 6) 343–350 -> 406–414 GS/s, and at 384 / 256 — the warm-up of every other tiled receiver here, 64 symbols; deviations from the
+    # serial loop within a third of TOL either way — 442–479)
+    tile = (int(os.environ.get("LSDR_RRC_TILE", 384)), int(os.environ.get("LSDR_RRC_WARMUP", max(args.tile_warmup, 256))))
     pipe = bench.C2Pipeline(capi, synth, device, args.captures, args.batch_msamples, args.period_msamples, tile, seed0=61,
                             fir_arith=headline_arith(capi, args), sampler="rrc")
     t0 = time.perf_counter()

@@ -31,6 +31,7 @@
 namespace {
 
 constexpr int kChunk = 128;   // cstln_receiver::chunk_size, sdr.h:706
+constexpr int kRrcLdsTaps = 1024;   // fir_sampler taps the tolerance tiles keep in LDS (8 KiB per wavefront); longer filters read the table in HBM
 
 #ifdef LSDR_RX_TRACE   // instrumented builds only (tools/): per-phase cycle sums of the symbol body
 __device__ unsigned long long g_rx_probe[8];
@@ -750,6 +751,7 @@ template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0, int lane, char *lds) {
   const bool valid = lane < (int)a.lanes_per_wave && j0 + (unsigned)lane < a.n_tiles;
   const rx_consts &C = a.C;
+  const bool rrc_lds = SAMP == 2 && C.ncoeffs <= kRrcLdsTaps;
   // fed-forward symbol timing (all 64 lanes take part): per GROUP of 32 consecutive tiles — tiles 1 + 32g … 32g + 32, whatever the
   // lanes per wavefront, like the estimator maps: a run is the same bits with 32 or 64 tiles per wavefront — one estimate at the group's
   // first tile and one at its last
@@ -958,11 +960,25 @@ __device__ __forceinline__ void rx_tile_tol(const rx_tiled_args &a, unsigned j0,
         if (SAMP == 2) {
           // fir_sampler::interp (sdr.h:646-665): polyphase branch (1−mu)·S of the matched filter over the next ⌈N/S⌉ samples;
           // plain loads (an ⌈N/S⌉-sample window does not pay), taps from the per-run table
+          // Every lane walks its own tile: a vector-memory instruction of the wavefront touches 64 cache lines, and the tap loop made two of them per
+          // tap (22 per symbol at 11 taps).  The taps now come out of LDS (the per-run table, copied in once per wavefront: rrc_lds) and the samples
+          // two at a time (cf32: one 16-byte load per pair) — the same products added in the same order.
           float2 acc = make_float2(0.f, 0.f);
           const int SS = C.subsampling, N = C.ncoeffs;
           int px = n;
-          for (int pc = (int)((1 - mu) * SS); pc < N; pc += SS, ++px) {
-            const float2 tt = cmul(a.T.shifted_tol[pc], base[px]);
+          int pc = (int)((1 - mu) * SS);
+          auto tap = [&](int i) -> float2 { return rrc_lds ? reinterpret_cast<const float2 *>(lds)[i] : a.T.shifted_tol[i]; };
+          if (FMT == LSDR_IN_CF32) {
+            for (; pc + SS < N; pc += 2 * SS, px += 2) {
+              const float4 xx = *reinterpret_cast<const float4 *>(reinterpret_cast<const float2 *>(base.p) + px);
+              const float2 t0 = cmul(tap(pc), make_float2(xx.x, xx.y));
+              acc.x += t0.x; acc.y += t0.y;
+              const float2 t1 = cmul(tap(pc + SS), make_float2(xx.z, xx.w));
+              acc.x += t1.x; acc.y += t1.y;
+            }
+          }
+          for (; pc < N; pc += SS, ++px) {
+            const float2 tt = cmul(tap(pc), base[px]);
             acc.x += tt.x; acc.y += tt.y;
           }
           sg = cmul(ld_hwtrig::expi(a.T, trig_index(-phase)), acc);
@@ -1123,8 +1139,12 @@ constexpr int kRxMulti = 8;
 struct rx_tiled_multi { rx_tiled_args a[kRxMulti]; };
 template <int SAMP, bool ARITH, int FMT, bool LDS, bool HARD>
 __global__ __launch_bounds__(64) void k_rx_tiles(rx_tiled_multi m) {
-  __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * rx_stage<FMT>::kRowBytes : 16];
+  __shared__ __attribute__((aligned(16))) char lds[LDS ? 64 * rx_stage<FMT>::kRowBytes : (SAMP == 2 ? kRrcLdsTaps * 8 : 16)];
   const rx_tiled_args &a = m.a[blockIdx.y];
+  if (SAMP == 2 && a.C.ncoeffs <= kRrcLdsTaps) {      // fir_sampler: the run's shifted taps into LDS (rx_tile_tol reads them there)
+    for (int i = (int)threadIdx.x; i < a.C.ncoeffs; i += 64) reinterpret_cast<float2 *>(lds)[i] = a.T.shifted_tol[i];
+    __syncthreads();
+  }
   // LSDR_RX_PRIO=1 (tuning hook): raised issue priority.  Next to fir_filter's streaming wavefronts the tiles then take 201 instead of
   // 284 us per C2 batch — and the filter's launch, which paces that pipeline, not a microsecond less; next to viterbi_sync (C3), which
   // paces THAT chain, they cost it 15 %.  Off.
