@@ -205,6 +205,40 @@ def test_tiled_fir_sampler_vs_serial(capi, ctx, oracle):
     assert rep["pass"], (rep, TOL)
 
 
+@pytest.mark.parametrize("steps,tile,odd", [(16, (384, 256), False), (16, (384, 256), True), (128, (256, 512), False)])
+def test_tiled_fir_sampler_taps_in_lds_or_hbm_same_as_serial(capi, ctx, oracle, steps, tile, odd):
+    """The RRC tiles read their taps out of LDS (≤ 1024 taps) or, for longer filters, out of the table in HBM, and cf32 samples in pairs — at the bench's
+    tile geometry, from an input that starts on an odd sample (8-byte-aligned 16-byte loads), and with a 128-steps-per-sample filter (1329 taps: the HBM path):
+    the sequential loop's decisions under TOL."""
+    order = int(10 * 8e6 * steps / (22 * 1e6 * 0.35))
+    rrc = capi.root_raised_cosine(order, float(np.float32(2e6) / np.float32(8e6 * steps)), 0.35)
+    assert (len(rrc) > 1024) == (steps == 128)
+    x, _ = synth.qpsk_baseband(4 * 150000, 4, seed=17, rms=50.0, snr_db=20.0)
+    p = po.rx_params(sampler=2, coeffs=rrc, subsampling=steps, cstln=1, omega=4.0, meas_decimation=4096)
+    acq = 128 * 2400
+    a = oracle.rx(p, x[:acq + len(rrc) - 1])
+    ref = oracle.rx(p, x[acq:], state_in=a["state"])
+    r = capi.CstlnReceiver(ctx, sampler=2, coeffs=rrc, subsampling=steps, cstln=1, omega=4.0, meas_decimation=4096,
+                           mode=capi.RX_TILED, tile_len=tile[0], tile_warmup=tile[1])
+    st = capi.RxState()
+    for k, _ in st._fields_:
+        setattr(st, k, getattr(a["state"], k))
+    r.set_state(st)
+    tail = x[acq:]
+    d_in = ctx.alloc((len(tail) + 1) * 8)
+    off = 1 if odd else 0
+    capi.check(capi.lib.lsdr_memcpy_h2d(ctx.h, d_in.at(8 * off), np.ascontiguousarray(tail).ctypes.data_as(capi.vp), tail.nbytes))
+    ctx.sync()
+    d_out = ctx.alloc((len(tail) // 4 + 8192) * 4)
+    o = r.run_dev(d_in.at(8 * off), len(tail), d_out.ptr, len(tail) // 4 + 8192, meas=False)
+    sym = ctx.download(d_out, ref["sym"].dtype, o["produced"])
+    stats = r.tiled_stats()
+    r.close(); d_in.free(); d_out.free()
+    assert o["consumed"] == ref["consumed"] and len(sym) == len(ref["sym"]), (len(sym), len(ref["sym"]), stats)
+    rep = check_tiled(sym, ref["sym"], stats)
+    assert rep["pass"], (rep, TOL)
+
+
 @pytest.mark.parametrize("fmt", ["cf32", "cu8"])
 def test_multi_capture_runs_equal_separate_queued_runs(capi, ctx, oracle, fmt):
     """lsdr_rx_run_multi_async: three independent captures (own signal, own loop state) share their launches — same symbols,
