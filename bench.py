@@ -834,6 +834,9 @@ def main():
         sys.exit(rc)
 
     from leansdr_amd import synth
+    if rank == 0 and world == 1 and not args.no_more and (not os.environ.get("LSDR_BENCH_MORE_ONLY") or "c1" in os.environ["LSDR_BENCH_MORE_ONLY"].split(",")):
+        import bench_more
+        bench_more.c1_early(args)      # (the config-1/4 entry of `more`: a process of its own, before this one holds a context on the GPU)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:     # before the GPU is touched: the CPU workers are forked
         order, fcut, decim0 = c2_design()

@@ -6,5 +6,5 @@ for r in $(seq 1 ${1:-4}); do
   python -c "
 import json
 m=json.load(open('gpurun_out/c3ab.json'))['more']
-print('run $r', m[list(m)[0]].get('value'), m[list(m)[0]].get('pass'), m[list(m)[0]]['roofline']['avg_launch_ms'], m[list(m)[0]].get('error','')[:200])"
+print('run $r', m[list(m)[0]].get('value'), m[list(m)[0]].get('pass'), m[list(m)[0]]['roofline'].get('avg_launch_ms', m[list(m)[0]]['roofline'].get('tile_kernel_avg_launch_ms')), m[list(m)[0]].get('error','')[:200])"
 done
