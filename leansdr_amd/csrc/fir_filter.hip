@@ -855,27 +855,26 @@ fir_kernel_t pick_mfma(unsigned D, int W, bool cplx, unsigned nl_fixed) {
     default: return nullptr;
   }
 }
+// (real taps only: the complex-tap block product is k_fir_mfma_stream's — fir_stream.h; k_fir_mfma_blk's CP = 1 branch states the
+// arithmetic of rounds 3–5 — (re, −im) pairs of one tap side by side in K — and is not instantiated any more)
 template <int DT>
-fir_kernel_t pick_blk_d(int W, bool cplx) {
-  if (W == 4) return cplx ? k_fir_mfma_blk<DT, 4, 1, 0, 0> : k_fir_mfma_blk<DT, 4, 0, 0, 0>;
-  return cplx ? k_fir_mfma_blk<DT, 2, 1, 0, 0> : k_fir_mfma_blk<DT, 2, 0, 0, 0>;
+fir_kernel_t pick_blk_d(int W) {
+  if (W == 4) return k_fir_mfma_blk<DT, 4, 0, 0, 0>;
+  return k_fir_mfma_blk<DT, 2, 0, 0, 0>;
 }
 constexpr unsigned blk_fixed_nl(unsigned D, int W) { return D == 30 ? 29u : 0u; }
 fir_kernel_t pick_blk(unsigned D, int W, bool cplx, unsigned nl_fixed, unsigned nq) {
+  if (cplx) return nullptr;
   if (nl_fixed && nl_fixed == blk_fixed_nl(D, W)) {          // (nl = 29 at D = 30 implies 11 tap blocks: the C2 geometry)
-    if (nq == 11) {
-      if (W == 4) return cplx ? k_fir_mfma_blk<30, 4, 1, 29, 11> : k_fir_mfma_blk<30, 4, 0, 29, 11>;
-      return cplx ? k_fir_mfma_blk<30, 2, 1, 29, 11> : k_fir_mfma_blk<30, 2, 0, 29, 11>;
-    }
-    if (W == 4) return cplx ? k_fir_mfma_blk<30, 4, 1, 29, 0> : k_fir_mfma_blk<30, 4, 0, 29, 0>;
-    return cplx ? k_fir_mfma_blk<30, 2, 1, 29, 0> : k_fir_mfma_blk<30, 2, 0, 29, 0>;
+    if (nq == 11) return W == 4 ? k_fir_mfma_blk<30, 4, 0, 29, 11> : k_fir_mfma_blk<30, 2, 0, 29, 11>;
+    return W == 4 ? k_fir_mfma_blk<30, 4, 0, 29, 0> : k_fir_mfma_blk<30, 2, 0, 29, 0>;
   }
   switch (D) {
-    case 4: return pick_blk_d<4>(W, cplx);
-    case 8: return pick_blk_d<8>(W, cplx);
-    case 10: return pick_blk_d<10>(W, cplx);
-    case 16: return pick_blk_d<16>(W, cplx);
-    case 30: return pick_blk_d<30>(W, cplx);
+    case 4: return pick_blk_d<4>(W);
+    case 8: return pick_blk_d<8>(W);
+    case 10: return pick_blk_d<10>(W);
+    case 16: return pick_blk_d<16>(W);
+    case 30: return pick_blk_d<30>(W);
     default: return nullptr;
   }
 }
@@ -903,12 +902,14 @@ stream_kernel pick_stream(unsigned D, bool cplx, unsigned nq, unsigned want_np =
 struct blk_geom { unsigned nq, alen, U, lds, nl, nl_fixed, M, ks; };
 blk_geom blk_geometry(unsigned N, unsigned D, int W, bool cplx) {
   blk_geom g;
-  const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4;
+  // complex taps: the stream kernel's form only — K slots are the samples of a row as for real taps, three coefficient operands
+  // (re, −im, +im parts: fir_stream.h); the register-staged kernel serves real taps
+  const unsigned sl = 1, kp = (D + 3) / 4 * 4;
   g.ks = kp / 4;
   g.nq = (N + D - 1) / D;
-  g.alen = g.ks * 64;
+  g.alen = (cplx ? 3 : 1) * g.ks * 64;
   if (g.nq > 16 || g.nq < 1) { g.M = 0; g.U = g.lds = g.nl = g.nl_fixed = 0; return g; }
-  if (pick_blk(D, W, cplx, 0, 0) == nullptr) {      // no register-staged kernel for this decimation: tap blocks and the coefficient operand only (the stream kernel's)
+  if (cplx || pick_blk(D, W, cplx, 0, 0) == nullptr) {      // no register-staged kernel for this decimation: tap blocks and the coefficient operand only (the stream kernel's)
     g.M = W * (128 - (g.nq - 1)); g.U = g.nl = g.nl_fixed = 0; g.lds = ~0u;
     return g;
   }
@@ -1011,7 +1012,7 @@ int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf3
   a.n_tiles = (unsigned)n_tiles;
   a.tiles_per_xcd = (unsigned)((n_tiles + 7) / 8);
   a.in_scale = 1.0f;
-  a.mf_atab = iv_tabs; a.mf_alen = 15 * 64; a.mf_blocks = nq;
+  a.mf_atab = iv_tabs; a.mf_alen = 3 * 8 * 64; a.mf_blocks = nq;
   a.iv_tile_first = iv_tile_first; a.n_iv = n_iv;
   { static const bool strided = getenv("LSDR_MFMA_CHUNK") && !atoi(getenv("LSDR_MFMA_CHUNK")); a.chunked = strided ? 0u : 1u; }
   fir_kernel_t k = np == 4 ? k_fir_mfma_stream<30, 1, 12, 1, 4> : np == 6 ? k_fir_mfma_stream<30, 1, 12, 1, 6> : k_fir_mfma_stream<30, 1, 12, 1>;
@@ -1099,18 +1100,24 @@ static int fir_upload(lsdr_fir_filter *f) {
     LSDR_HIP(hipMemcpyAsync(f->d_atab[cp], at.data(), at.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     LSDR_HIP(hipStreamSynchronize(c->stream));   // `at` is pageable and dies here
   }
-  // k_fir_mfma_blk's coefficient operand: lane (k = l>>4, q = l&15) of step s holds K slot e = 4·s + k of tap block q —
-  // tap D·q + e (real taps), or tap D·q + e/2 as (re, −im) pairs (complex taps); zero outside the block / the filter
+  // The block product's coefficient operand: lane (k = l>>4, q = l&15) of step s holds tap D·q + 4·s + k of tap block q — real taps: one
+  // table of ks steps; complex taps: three (re parts, −im parts, +im parts: k_fir_mfma_stream's four MFMAs per step); zero outside the
+  // block / the filter
   const float scale = f->cfg.in_scale != 0.f ? f->cfg.in_scale : 1.0f;
   for (int cp = 0; cp < 2; ++cp) {
     if (!f->blk_ok[cp]) continue;
     std::vector<float> bt(f->bk[cp].alen, 0.f);
-    for (unsigned s = 0; s < f->bk[cp].ks; ++s)
+    const unsigned ks = f->bk[cp].ks;
+    for (unsigned s = 0; s < ks; ++s)
       for (unsigned ln = 0; ln < 64; ++ln) {
-        const unsigned e = 4 * s + (ln >> 4), q = ln & 15, r = cp ? e >> 1 : e;
+        const unsigned r = 4 * s + (ln >> 4), q = ln & 15;
         if (q >= f->bk[cp].nq || r >= D || D * q + r >= N) continue;
-        const float tap = cp == 0 ? rc[D * q + r] : ((e & 1) ? -f->shifted[D * q + r].im : f->shifted[D * q + r].re);
-        bt[s * 64 + ln] = tap * scale;         // the fused scaler rides on the taps: one f32 rounding per tap
+        // the fused scaler rides on the taps: one f32 rounding per tap (component)
+        if (cp == 0) bt[s * 64 + ln] = rc[D * q + r] * scale;
+        else {
+          const float re = f->shifted[D * q + r].re * scale, im = f->shifted[D * q + r].im * scale;
+          bt[s * 64 + ln] = re; bt[(ks + s) * 64 + ln] = -im; bt[(2 * ks + s) * 64 + ln] = im;
+        }
       }
     LSDR_HIP(hipMemcpyAsync(f->d_btab[cp], bt.data(), bt.size() * sizeof(float), hipMemcpyHostToDevice, c->stream));
     LSDR_HIP(hipStreamSynchronize(c->stream));
@@ -1219,7 +1226,7 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
     for (int cp = 0; cp < 2; ++cp) {
       f->bk[cp] = blk_geometry(N, D, f->mf_W, cp != 0);
       // (blk_ok: the coefficient operand exists — with the stream kernel that is all; the register-staged one also needs its tile to fit)
-      f->blk_ok[cp] = f->bk[cp].M > 0 && (f->stream || (f->bk[cp].nl <= 32 && f->bk[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2)));
+      f->blk_ok[cp] = f->bk[cp].M > 0 && (f->stream || cp == 1 || (f->bk[cp].nl <= 32 && f->bk[cp].lds <= (size_t)160 * 1024 / (f->mf_W == 4 ? 1 : 2)));
       if (!f->blk_ok[cp]) {
         lsdr_fir_filter_destroy(f);
         lsdr_set_error("lsdr_fir_filter_create: LSDR_FIR_MFMA_BLK has no kernel for %u taps / decimation %u / input format %d", N, D, cfg->in_format);
@@ -1320,8 +1327,7 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   a.N = N; a.D = D; a.S = f->S;
   a.count = count;
   a.n_in = n_in;
-  static const bool stream_cp = !(getenv("LSDR_MFMA_STREAM_CP") && !atoi(getenv("LSDR_MFMA_STREAM_CP")));   // A/B hook
-  const bool stream = blk && f->stream && (real_taps || stream_cp);
+  const bool stream = blk && (f->stream || !real_taps);      // (complex taps: the stream kernel, whatever LSDR_MFMA_STREAM says)
   // rows per wave tile / 16 of the stream kernel: the requested one if that kernel exists for this geometry
   const stream_kernel sk = stream ? pick_stream(D, !real_taps, f->bk[real_taps ? 0 : 1].nq, f->stream_np[real_taps ? 0 : 1]) : stream_kernel{nullptr, 8u, false};
   const unsigned snp = sk.np;

@@ -92,10 +92,11 @@ constexpr unsigned stream_padf(unsigned D) { return (12u - (2u * D) % 8u) % 8u; 
 template <int DT, int CP, int NQT, int IV = 0, int NP = 8, bool FOLDT = (NP == 4)>
 __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr unsigned D = DT, SL = 1 + CP;
+  constexpr unsigned D = DT;
   constexpr unsigned PADF = stream_padf(D);
-  constexpr unsigned KP = (D * SL + 3) / 4 * 4, KS = KP / 4;
-  constexpr unsigned FP = ((KP / SL - D) + 1) & ~1u;              // samples in front of row 0 that the K padding reads
+  constexpr unsigned KP = (D + 3) / 4 * 4, KS = KP / 4;           // K slots = the samples of a row, four per MFMA step (both tap kinds)
+  constexpr unsigned NB = CP ? 3 * KS : KS;                       // coefficient operand registers (CP: re, −im, +im parts — see the lane cursors)
+  constexpr unsigned FP = ((KP - D) + 1) & ~1u;                   // samples in front of row 0 that the K padding reads
   constexpr unsigned ROWB = D * 8 + PADF * 4;                     // bytes per row
   constexpr unsigned PAIRG = 16 * ROWB / 16;                      // 16-byte granules per pair of row tiles (16 rows)
   static_assert(ROWB % 16 == 0 && (ROWB / 4) % 8 == 4, "a row starts on a granule and is ≡ 4 (mod 8) floats long");
@@ -124,24 +125,30 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   const unsigned t_lim = a.chunked ? (t_first + per < xcnt ? t_first + per : xcnt) : xcnt;
   auto valid = [&](unsigned ti) { return ti < t_lim; };
 
-  float bco[KS];
-  unsigned iv_cur = 0;
+  float bco[NB];
+  unsigned iv_cur = 0, iv_lo = 0, iv_hi = ~0u;      // IV: the interval of the current tile and the tiles [iv_lo, iv_hi) it serves
   if (!IV) {
 #pragma unroll
-    for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[s * 64 + l];
+    for (unsigned s = 0; s < NB; ++s) bco[s] = a.mf_atab[s * 64 + l];
   }
 
   // The region of wave tile `lt` of a stream: row ρ = output-row p = lt·MW − (NQ−1) + ρ, i.e. samples
   // x[N + D·p − (D−1) … N + D·p]; region sample 0 is x[X0], X0 = N + 1 − D·NQ − FP + D·MW·lt (negative at the stream start:
   // those samples meet zero taps — the clamped resource makes their offsets wrap out of range: zeros).
+  // One stream per launch (everything but lsdr_fir_filter_run_multi): its pointers are read ONCE — a scalar load from the argument block
+  // per tile, with the lgkmcnt(0) it needs in front of the tile's first LDS reads, stalled the wavefront for the load's latency every tile
+  // (the IV pass lost 10 % to two such loads per tile: profiles/r06_bench/README.md)
+  const bool one = a.n_streams == 1;
+  const char *const in0 = reinterpret_cast<const char *>(a.ins[0]);
+  float *const out0 = reinterpret_cast<float *>(a.outs[0]);
   __amdgpu_buffer_rsrc_t rsrc;
   unsigned adj = 0;
   auto aim = [&](unsigned tile, bool live) {
-    const unsigned st = live ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
+    const unsigned st = live && !one ? tile / a.tiles_per_stream : 0u, lt = tile - st * a.tiles_per_stream;
     const long long j0 = (long long)a.N + 1 - (long long)(D * NQ) - (long long)(PADF ? 0u : FP) + (long long)lt * MW * D;   // PADF: row 0's first sample
     const long long jb = j0 < 0 ? 0 : j0;
     const unsigned long long bytes = live ? (a.n_in - (unsigned long long)jb) * 8ull : 0ull;
-    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
+    rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(one ? in0 : reinterpret_cast<const char *>(a.ins[st])) + (live ? jb * 8 : 0), 0,
                                              (int)(bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes), 0x00020000);
     adj = (unsigned)((jb - j0) * 8);
   };
@@ -192,22 +199,30 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   if (IV) {      // the interval of the first tile
     const unsigned t0 = tile_of(ti);
     while (iv_cur + 1 < a.n_iv && t0 >= a.iv_tile_first[iv_cur + 1]) ++iv_cur;
+    iv_lo = a.iv_tile_first[iv_cur]; iv_hi = iv_cur + 1 < a.n_iv ? a.iv_tile_first[iv_cur + 1] : ~0u;
 #pragma unroll
-    for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (KS * 64) + s * 64 + l];
+    for (unsigned s = 0; s < NB; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (NB * 64) + s * 64 + l];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
   aim(tile_of(ti), true);
 #pragma unroll
   for (int P = 0; P < NP; ++P) refill(P);
 
-  // per-lane cursors (see k_fir_mfma_blk); the sample operand of K slot r' of row ρ is the sample r' BEFORE the row's last one
-  const unsigned kq = l >> 4 & 3u, i16 = l & 15u, beta = i16 >> 1, c = i16 & 1u;
-  const unsigned sub = CP ? (kq & 1u) : 0u;
-  constexpr unsigned ASTEP = CP ? 16 : 32, ATILE = 8 * ROWB;
-  // float index of (row ρ, step s): 2·(FP + D·ρ + D − 1 − r') + comp, r' = CP ? 2·s + (k>>1) : 4·s + k  →  lane part at s = KS−1
-  const int rlast = CP ? 2 * (int)(KS - 1) + (int)(kq >> 1) : 4 * (int)(KS - 1) + (int)kq;
-  const unsigned a0 = (unsigned)(2 * ((int)FP + (int)D - 1 - rlast) + (int)(c ^ sub)) * 4u + beta * ROWB;   // bytes, ≥ 0 by FP
-  const unsigned sgn = (CP && sub && c) ? 0x80000000u : 0u;
+  // per-lane cursors (see k_fir_mfma_blk); the sample operand of K slot r' = 4·s + k of row ρ is the sample r' BEFORE the row's last one.
+  // Real taps (CP = 0): the 16 operand rows of an MFMA are 8 rows × {re, im} — a pair of row tiles is two MFMA row tiles (h), one
+  // 4-byte operand per lane and step, Z[(ρ, comp)][q] += x_comp · c.
+  // Complex taps (CP = 1): the 16 operand rows are the pair's 16 rows and a lane reads BOTH components of its sample in one 8-byte
+  // ds_read (32 lanes × 8 B on 64 banks: conflict-free under the same row rule); two accumulators, four MFMAs per step:
+  //   Zre += xr·cr,  Zim += xi·cr,  Zre += xi·(−ci),  Zim += xr·(+ci)
+  // — the operands reach the matrix pipe as loaded (no sign flips on the vector ALUs: a VALU result in front of every MFMA cost 40 % of
+  // the pipe, profiles/r06_bench/fir_bound.txt), the signs live in the coefficient operand (bco[KS + s] = −ci, bco[2·KS + s] = +ci).
+  // Per block and component that is the chain lo_fir_filter_blk states: groups of four taps, the re-part products of a group, then
+  // its im-part products.
+  const unsigned kq = l >> 4 & 3u, i16 = l & 15u, beta = CP ? i16 : i16 >> 1, c = CP ? 0u : i16 & 1u;
+  constexpr unsigned ASTEP = 32, ATILE = 8 * ROWB;
+  // float index of (row ρ, step s): 2·(FP + D·ρ + D − 1 − r') + comp, r' = 4·s + k  →  lane part at s = KS−1
+  const int rlast = 4 * (int)(KS - 1) + (int)kq;
+  const unsigned a0 = (unsigned)(2 * ((int)FP + (int)D - 1 - rlast) + (int)c) * 4u + beta * ROWB;   // bytes, ≥ 0 by FP
   const unsigned zq = l & 15u, zrow = 2 * kq;
   const unsigned ro = l >> 1, rc = l & 1u;
   // diagonal sum (rows ascend with the output index here): output of row ρ = 32·B + o is Σ_q Z[ρ − q][q]; its row as 16 … 79
@@ -231,31 +246,49 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     const unsigned tile = tile_of(ti);
     const unsigned tn = ti + t_step;
     const bool more = valid(tn);
-    const unsigned st = tile / a.tiles_per_stream;
+    const unsigned st = one ? 0u : tile / a.tiles_per_stream;
     const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * MW;
-    float *const po = reinterpret_cast<float *>(a.outs[st]);
+    float *const po = one ? out0 : reinterpret_cast<float *>(a.outs[st]);
     aim(more ? tile_of(tn) : 0u, more);      // the refills of this iteration fetch the NEXT tile (an empty resource at the end: no traffic)
-    if (IV) {
+    if (IV && (tile >= iv_hi || tile < iv_lo)) {      // (wave-uniform, a handful of times per launch: the bounds of the current interval stay in registers)
       unsigned iv = iv_cur;
       while (iv + 1 < a.n_iv && tile >= a.iv_tile_first[iv + 1]) ++iv;
       while (iv > 0 && tile < a.iv_tile_first[iv]) --iv;       // (the walk wraps once when it does not start at the range's first tile)
-      if (iv != iv_cur) {                    // (wave-uniform, a handful of times per launch)
+      iv_lo = a.iv_tile_first[iv]; iv_hi = iv + 1 < a.n_iv ? a.iv_tile_first[iv + 1] : ~0u;
+      if (iv != iv_cur) {
         iv_cur = iv;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (unsigned s = 0; s < KS; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (KS * 64) + s * 64 + l];
+        for (unsigned s = 0; s < NB; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (NB * 64) + s * 64 + l];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
     }
 
     const char *ap = smem_raw + a0;
-    unsigned pa[2][2][KS];
+    unsigned pa[2][2][CP ? 1 : KS];
+    lsdr_v2f pc[2][CP ? KS : 1];
     auto fetch1 = [&](int set, int pair, int h, unsigned s) {
       pa[set][h][s] = *reinterpret_cast<const unsigned *>(ap + (2 * pair + h) * ATILE + (KS - 1 - s) * ASTEP);
     };
-    auto opnd = [&](unsigned r) { return __uint_as_float(CP ? (r ^ sgn) : r); };
-    lsdr_v4f acc[2][2];
+    auto fetch2 = [&](int set, int pair, unsigned s) {      // CP: (re, im) of the lane's sample of step s
+      pc[set][s] = *reinterpret_cast<const lsdr_v2f *>(ap + 2 * pair * ATILE + (KS - 1 - s) * ASTEP);
+    };
+    auto opnd = [&](unsigned r) { return __uint_as_float(r); };
+    lsdr_v4f acc[2][2];      // CP = 0: [set][h];  CP = 1: [set][re / im]
     auto to_ring = [&](int set, int pair) {
+      if (CP) {
+        if (zq < NQ) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {      // the accumulators' rows 4·kq + i of the pair, column zq: (re, im) side by side as the ring holds them
+            const unsigned row0 = (16u * pair + 4u * kq + i) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
+            const lsdr_v2f v = {acc[set][0][i], acc[set][1][i]};
+            *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = v;
+            if (FOLD && pair == 2) *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = v;
+            if (MIRROR && ((16u * pair) & 63u) == 0) *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = v;
+          }
+        }
+        return;
+      }
       if (zq < NQ) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -297,7 +330,7 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     // pair P, behind fetch(P+1)): fetch(0): NP−1 groups; fetch(1), during pair 0: NP−2; fetch(j ≥ 2), during pair j−1: NP−3.
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 1) * NLI) : "memory");
 #pragma unroll
-    for (unsigned s = 0; s < KS; ++s) { fetch1(0, 0, 0, s); fetch1(0, 0, 1, s); }
+    for (unsigned s = 0; s < KS; ++s) { if (CP) fetch2(0, 0, s); else { fetch1(0, 0, 0, s); fetch1(0, 0, 1, s); } }
 #pragma unroll
     for (int pair = 0; pair < NP; ++pair) {
       const int set = pair & 1;
@@ -309,10 +342,26 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
       for (unsigned s = 0; s < KS; ++s) {
 #ifdef LSDR_STREAM_NOMFMA       // measurement build: the memory side alone (one VALU op stands in for each MFMA)
         if (s == 0) { acc[set][0] = (lsdr_v4f){0.f, 0.f, 0.f, 0.f}; acc[set][1] = acc[set][0]; }
-        acc[set][0][s & 3] += opnd(pa[set][0][s]) * bco[s];
-        acc[set][1][s & 3] += opnd(pa[set][1][s]) * bco[s];
+        if (CP) {
+          acc[set][0][s & 3] += pc[set][s][0] * bco[s]; acc[set][1][s & 3] += pc[set][s][1] * bco[s];
+          acc[set][0][s & 3] += pc[set][s][1] * bco[KS + s]; acc[set][1][s & 3] += pc[set][s][0] * bco[2 * KS + s];
+        } else {
+          acc[set][0][s & 3] += opnd(pa[set][0][s]) * bco[s];
+          acc[set][1][s & 3] += opnd(pa[set][1][s]) * bco[s];
+        }
 #else
-        if (s == 0) {
+        if (CP) {
+          const float xr = pc[set][s][0], xi = pc[set][s][1];
+          if (s == 0) {
+            acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+          } else {
+            acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, bco[s], acc[set][0], 0, 0, 0);
+            acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, bco[s], acc[set][1], 0, 0, 0);
+          }
+          acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, bco[KS + s], acc[set][0], 0, 0, 0);
+          acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, bco[2 * KS + s], acc[set][1], 0, 0, 0);
+        } else if (s == 0) {
           acc[set][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][0][0]), bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
           acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][0]), bco[0], (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         } else {
@@ -320,7 +369,9 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
           acc[set][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[set][1][s]), bco[s], acc[set][1], 0, 0, 0);
         }
 #endif
-        if (pair < NP - 1 && !(s & 1)) {
+        if (CP) {
+          if (pair < NP - 1) fetch2(set ^ 1, pair + 1, s);
+        } else if (pair < NP - 1 && !(s & 1)) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) { if (s + 1 < KS) fetch1(set ^ 1, pair + 1, h, s + 1); fetch1(set ^ 1, pair + 1, h, s); }
         }
@@ -360,7 +411,8 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
 
 // LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 16·np padded rows) + Z ring + the diagonal reads' overrun
 unsigned stream_lds(unsigned D, unsigned nq, bool cplx, unsigned np = 8, bool fold = true) {
-  const unsigned sl = cplx ? 2 : 1, kp = (D * sl + 3) / 4 * 4, fp = ((kp / sl - D) + 1) & ~1u;
+  (void)cplx;      // (the region is the same for both tap kinds: four samples of a row per MFMA step)
+  const unsigned kp = (D + 3) / 4 * 4, fp = ((kp - D) + 1) & ~1u;
   const unsigned region = (fp * 8 + 16 * np * (D * 8 + stream_padf(D) * 4) + 15) & ~15u;
   if (np == 4 && fold) return region + 48 * 2 * (nq | 1u) * 4;   // folded ring, compile-time tap blocks only (no overrun)
   return region + (np == 4 ? 64 : 80) * 2 * (nq | 1u) * 4 + 128;

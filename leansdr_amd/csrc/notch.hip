@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_notch_tables(const int *cand /*[ndet][k
 // State between runs: the last output, the last D raw samples before the read pointer (the ρ window reaches D samples further back than
 // fir_filter's), the bin, and sub at the notch's frontier (so that a later bin change can reconstruct the old segment's estimator).
 // Arithmetic: float32 with exact phases — NOT the reference's rounding sequence: a tolerance mode (include/lsdr_hip.h states the bound).
-constexpr int kNfD = 30, kNfNq = 12, kNfKs = 15, kNfTaps = kNfD * kNfNq;   // 360 tap slots, N + D ≤ 360
+constexpr int kNfD = 30, kNfNq = 12, kNfKx = 8, kNfKs = 3 * kNfKx /* operand rows: re, −im, +im parts of 8 steps */, kNfTaps = kNfD * kNfNq;   // 360 tap slots, N + D ≤ 360
 constexpr int kNfLook = 12288;            // samples an estimator remembers ((1−k)^12288 < 1e-8 is checked at run time, as in the scan mode)
 constexpr int kNfMaxDet = 64;             // detect points per run (the run is cut there)
 constexpr int kNfFixSpan = 4736;          // samples one fix-up stages (N + a tile and the transition outputs' windows)
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) void k_nf_cfft_half(nf_run r, const float2 *in
 
 // Interval q of a run (q = 0: up to the first detect point of the run, carried bin; q ≥ 1: from detect point q−1 on): its bin, whether
 // it differs from the interval before, P = p^D and the taps ρ = (scale·c) ∗ κ — in natural order (k_nf_scan computes r[0] with them) and as the filter pass's
-// coefficient operand (lane (k = l>>4, q' = l&15) of step s: K slot e = 4·s + k of tap block q': tap D·q' + e/2 as (re, −im)).
+// coefficient operand (lane (k = l>>4, q' = l&15) of step s: tap D·q' + 4·s + k of tap block q' — its re part in table row s, −im in row 8 + s, +im in row 16 + s: fir_stream.h).
 // The carried bin travels from one run's launch of this kernel to the next one's through a ping-pong word (bin_in / bin_out), not through
 // nf_state: with lsdr_notch_fir_set_overlap the detect chain of run k+1 runs while run k's tail still owns the state.
 __global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, int *bin_out, const int *cand /*[ndet][kMaxSlots]*/, const float2 *coeffs,
@@ -654,9 +654,9 @@ __global__ __launch_bounds__(256) void k_nf_taps(nf_run run, const int *bin_in, 
   }
   __syncthreads();
   for (int idx = t; idx < kNfKs * 64; idx += 256) {
-    const int s = idx >> 6, ln = idx & 63, e = 4 * s + (ln >> 4), qq = ln & 15, r = e >> 1;
+    const int row = idx >> 6, part = row / kNfKx, s = row - part * kNfKx, ln = idx & 63, r = 4 * s + (ln >> 4), qq = ln & 15;
     float v = 0.f;
-    if (qq < kNfNq && r < kNfD) v = (e & 1) ? (float)-ri[kNfD * qq + r] : (float)rr[kNfD * qq + r];
+    if (qq < kNfNq && r < kNfD) v = part == 0 ? (float)rr[kNfD * qq + r] : part == 1 ? (float)-ri[kNfD * qq + r] : (float)ri[kNfD * qq + r];
     ivtab[(size_t)q * (kNfKs * 64) + idx] = v;
   }
 }

@@ -75,7 +75,8 @@ size_t lo_fir_filter(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
 size_t lo_fir_filter_fma(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
                      const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
                      size_t *consumed);
-/* blocks of `decim` taps: an fmaf chain per block, block sums added in order — the stated arithmetic of LSDR_FIR_MFMA_BLK */
+/* blocks of `decim` taps: an fmaf chain per block, block sums added in order — the stated arithmetic of LSDR_FIR_MFMA_BLK
+ * (complex taps: a chain takes its taps four at a time, the re-part products of a group before its im-part products) */
 size_t lo_fir_filter_blk(unsigned ncoeffs, const lo_cf32 *shifted, unsigned decim,
                      const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
                      size_t *consumed);

@@ -102,10 +102,12 @@ size_t lo_fir_filter_fma(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
   return count;
 }
 
-/* The arithmetic of LSDR_FIR_MFMA_BLK (k_fir_mfma_blk), stated once: the reference's loop (dsp.h:246-262) with the taps cut
- * into blocks of `decim` consecutive taps — each block an fmaf chain from zero in tap order, the block sums added in block
+/* The arithmetic of LSDR_FIR_MFMA_BLK (k_fir_mfma_stream / k_fir_mfma_blk), stated once: the reference's loop (dsp.h:246-262) with the
+ * taps cut into blocks of `decim` consecutive taps — each block an fmaf chain from zero in tap order, the block sums added in block
  * order with plain float adds.  (What a block-polyphase evaluation on fused hardware computes; same error class as
- * lo_fir_filter_fma.) */
+ * lo_fir_filter_fma.)  Complex taps (current_freq != 0): a block's chain takes its taps in groups of four (one step of the matrix
+ * pipe) — the four re-part products of a group, then its four im-part products:
+ *    re: fma(cr, xr) x 4, fma(-ci, xi) x 4, next group ...      im: fma(cr, xi) x 4, fma(ci, xr) x 4, next group ... */
 size_t lo_fir_filter_blk(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
                          const lo_cf32 *in, size_t n_in, lo_cf32 *out, size_t cap,
                          size_t *consumed) {
@@ -120,14 +122,18 @@ size_t lo_fir_filter_blk(unsigned ncoeffs, const lo_cf32 *sc, unsigned decim,
     float yr = 0, yi = 0;
     for (unsigned q = 0; q * decim < ncoeffs; ++q) {
       float zr = 0, zi = 0;
-      for (unsigned i = q * decim; i < (q + 1) * decim && i < ncoeffs; ++i) {
-        const lo_cf32 *pi = p0 - i;
-        zr = fmaf(sc[i].re, pi->re, zr);
-        zi = fmaf(sc[i].re, pi->im, zi);
-        if (!all_real) {
-          zr = fmaf(-sc[i].im, pi->im, zr);
-          zi = fmaf(sc[i].im, pi->re, zi);
+      const unsigned i1 = (q + 1) * decim < ncoeffs ? (q + 1) * decim : ncoeffs;
+      for (unsigned g = q * decim; g < i1; g += 4) {
+        const unsigned g1 = g + 4 < i1 ? g + 4 : i1;
+        for (unsigned i = g; i < g1; ++i) {
+          zr = fmaf(sc[i].re, (p0 - i)->re, zr);
+          zi = fmaf(sc[i].re, (p0 - i)->im, zi);
         }
+        if (!all_real)
+          for (unsigned i = g; i < g1; ++i) {
+            zr = fmaf(-sc[i].im, (p0 - i)->im, zr);
+            zi = fmaf(sc[i].im, (p0 - i)->re, zi);
+          }
       }
       yr = q ? yr + zr : zr;
       yi = q ? yi + zi : zi;
