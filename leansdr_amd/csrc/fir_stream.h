@@ -85,8 +85,9 @@ constexpr unsigned stream_padf(unsigned D) { return (12u - (2u * D) % 8u) % 8u; 
 // the dispatcher deals the work: 0.80 ms.  (Tiles dealt by a per-XCD atomic counter, one returned atomic per tile: 0.96 ms alone — dropped.)
 // NP = pairs of row tiles per wave tile (16 rows each): 8 → a region of 128 rows (38–39 KB of LDS with its ring: four wavefronts per CU, 117
 // outputs per 128 rows at 12 tap blocks) — real taps, HBM-bound; 4 → 64 rows, 53 outputs per 64 rows, ring folded to 48 rows (FOLD below):
-// 19.6–20.4 KB, EIGHT per CU — complex taps and the IV pass, which are bound by what the wavefronts of a CU overlap (3.44 → 4.0 TB/s alone,
-// 0.65 ms per 256 Mi samples for the IV pass); 6 → 96 rows (30 KB, five per CU: 3.76).  The outputs do not depend on it.
+// 19.6–20.4 KB, EIGHT per CU — complex taps and the IV pass, whose matrix side and memory side take about the same time (0.40 / 0.39–0.44 ms per
+// 256 Mi samples alone, 0.48–0.50 together: profiles/r06_bench/fir_bound.txt) and overlap better from two wavefronts per SIMD; 6 → 96 rows (30 KB,
+// five per CU): 0.506.  The outputs do not depend on it.
 // FOLDT (NP = 4 only): the folded 48-row ring below — its mirrored rows lie over the region's last sample rows, which must be at least
 // as many bytes (decimation 30: yes; the small decimations of the sweep: no — they run NP = 8, the large ones NP = 4 unfolded).
 template <int DT, int CP, int NQT, int IV = 0, int NP = 8, bool FOLDT = (NP == 4)>
