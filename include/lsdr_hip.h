@@ -297,7 +297,8 @@ enum {
                        * k-ordered fmaf chain): the taps as a banded Toeplitz block, sixteen outputs per row group.  cf32 input
                        * at the decimations with a compile-time kernel; anything else runs LSDR_FIR_FMA's kernels (same bits). */
   LSDR_FIR_MFMA_BLK = 3 /* block-polyphase form on the matrix pipe (a dense product): the taps in blocks of `decim`, each block an
-                       * fmaf chain from zero in tap order, the block sums added in block order, in_scale multiplied into the taps (one
+                       * fmaf chain from zero in tap order (complex taps, set_freq != 0: four taps at a time — their re-part products, then
+                       * their im-part products), the block sums added in block order, in_scale multiplied into the taps (one
                        * rounding per tap) instead of the samples — its own stated arithmetic (oracle lo_fir_filter_blk), same
                        * error bound as LSDR_FIR_FMA.  cf32 input, every decimation 1 … 64 (whatever
                        * Fs / (4·Fm) leandvb.cc:353-378 computes), ncoeffs ≤ 16·decim; refused (LSDR_E_ARG) otherwise. */
