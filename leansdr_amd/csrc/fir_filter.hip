@@ -1016,7 +1016,7 @@ int lsdr_fir_stream_iv_launch(lsdr_ctx *c, const void *in, size_t n_in, lsdr_cf3
   a.iv_tile_first = iv_tile_first; a.n_iv = n_iv;
   { static const bool strided = getenv("LSDR_MFMA_CHUNK") && !atoi(getenv("LSDR_MFMA_CHUNK")); a.chunked = strided ? 0u : 1u; }
   fir_kernel_t k = np == 4 ? k_fir_mfma_stream<30, 1, 12, 1, 4> : np == 6 ? k_fir_mfma_stream<30, 1, 12, 1, 6> : k_fir_mfma_stream<30, 1, 12, 1>;
-  const size_t lds_bytes = stream_lds(D, nq, true, np);
+  const size_t lds_bytes = stream_lds(D, nq, true, np, true, true);
   unsigned grid = a.tiles_per_xcd * 8;
   const unsigned pg = (unsigned)(c->num_cu * (wpc > 0 ? wpc : 64) + 7) / 8 * 8;
   if (grid > pg) grid = pg;
@@ -1064,6 +1064,7 @@ struct lsdr_fir_filter {
   bool blk_ok[2];
   bool stream;                      // k_fir_mfma_stream (one wavefront per workgroup, LDS-direct refill) instead of k_fir_mfma_blk
   int stream_wpc;                   // its workgroups (= wavefronts) per CU in the persistent grid
+  int stream_wpc_carry;             // the same for the tiles that carry their ring rows (fir_stream.h CARRY): longer lists, one warm-up pair each
   unsigned stream_xrot;             // tiles by which XCD x's walk through its range is rotated (× x): tuning hook LSDR_MFMA_XROT, 0 = off
   unsigned stream_chunked;          // a workgroup's tiles consecutive instead of strided (LSDR_MFMA_CHUNK, read per create)
   unsigned stream_np[2];            // pairs of row tiles per wave tile, real / complex taps (k_fir_mfma_stream NP; LSDR_MFMA_NP / LSDR_MFMA_NP_CP, read per create)
@@ -1219,6 +1220,9 @@ int lsdr_fir_filter_create(lsdr_ctx *c, const lsdr_fir_filter_cfg *cfg, lsdr_fir
       // halo — instead of `slots` tiles apart): alone 5.88 → 6.02 TB/s at 48 per CU, 6.11 at 96 (0.76 of the HBM peak); C2 pipeline, two
       // processes each: strided 48: 609–644 GS/s; chunked 24 / 48 / 96 / 192: 606–634 / 619–667 / 644–651 / 602–610.
       f->stream_wpc = ew && atoi(ew) > 0 ? atoi(ew) : 96;
+      // CARRY tiles (complex taps at the C2 geometry): a list starts with a warm-up pair, so longer lists — c2_offset, workgroups per CU queued
+      // 32 / 48 / 64 / 96 / 128 / 192: 584 / 587 / 582 / 575.5 / 571 / 544 GS/s
+      f->stream_wpc_carry = ew && atoi(ew) > 0 ? atoi(ew) : 48;
       { const char *ex = getenv("LSDR_MFMA_XROT"); f->stream_xrot = ex ? (unsigned)strtoul(ex, nullptr, 0) : 0u; }      // (read per create: A/B in one process)
       { const char *ec = getenv("LSDR_MFMA_CHUNK"); f->stream_chunked = ec ? (unsigned)atoi(ec) : 1u; }
       { const char *e0 = getenv("LSDR_MFMA_NP"), *e1 = getenv("LSDR_MFMA_NP_CP"); f->stream_np[0] = e0 && atoi(e0) == 4 ? 4u : 8u; f->stream_np[1] = e1 && (atoi(e1) == 4 || atoi(e1) == 6 || atoi(e1) == 8) ? (unsigned)atoi(e1) : 4u; }   // (asked for; pick_stream gives the geometry's default where that form does not exist)
@@ -1331,8 +1335,12 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
   // rows per wave tile / 16 of the stream kernel: the requested one if that kernel exists for this geometry
   const stream_kernel sk = stream ? pick_stream(D, !real_taps, f->bk[real_taps ? 0 : 1].nq, f->stream_np[real_taps ? 0 : 1]) : stream_kernel{nullptr, 8u, false};
   const unsigned snp = sk.np;
-  const unsigned M = stream ? 16u * snp - (f->bk[real_taps ? 0 : 1].nq - 1) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
-  size_t n_tiles = (count + M - 1) / M;
+  // the stream kernel's tiles: 16·np rows; with CARRY (fir_stream.h) every row of a tile is an output and the first tile of a stream starts
+  // nq − 1 rows in front of output 0, without it a tile re-reads the nq − 1 rows in front of its outputs
+  const unsigned snq = f->bk[real_taps ? 0 : 1].nq;
+  const bool carry = stream && sk.carry();
+  const unsigned M = stream ? (carry ? 16u * snp : 16u * snp - (snq - 1)) : blk ? f->bk[real_taps ? 0 : 1].M : mfma ? 128u * f->mf_W : kThreads * f->R;
+  size_t n_tiles = (count + (carry ? snq - 1 : 0) + M - 1) / M;
   LSDR_ARG(n_tiles * n_streams < (1ull << 31));
   a.tiles_per_stream = (unsigned)n_tiles;
   n_tiles *= n_streams;
@@ -1361,14 +1369,14 @@ static int fir_run_streams(lsdr_fir_filter *f, unsigned n_streams, const void *c
     const unsigned nqk = blk && !(enq && !atoi(enq)) ? f->bk[cp].nq : 0;
     fir_kernel_t k = stream ? sk.k : blk ? pick_blk(D, f->mf_W, cp != 0, f->bk[cp].nl_fixed, nqk) : pick_mfma(D, f->mf_W, cp != 0, f->mf[cp].nl_fixed);
     static const size_t lds_pad = getenv("LSDR_MFMA_SLDS") ? (size_t)atoi(getenv("LSDR_MFMA_SLDS")) : 0;   // tuning hook: extra LDS per stream workgroup (bounds the workgroups resident per CU)
-    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0, snp, sk.fold) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
+    const size_t lds_bytes = stream ? stream_lds(D, f->bk[cp].nq, cp != 0, snp, sk.fold, false) + lds_pad : blk ? f->bk[cp].lds : f->mf[cp].lds;
     if (lds_bytes > 64 * 1024)
       LSDR_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     unsigned grid = a.tiles_per_xcd * 8;
     // (complex taps on the register-staged kernels: three workgroups per CU queued — two resident ones that start together stay in
     // step and leave the memory idle while both compute: 0.345 ms per 64 Mi against 0.157)
     static const bool wpc_env = getenv("LSDR_MFMA_WPC") != nullptr;
-    const int wpc = stream ? f->stream_wpc : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
+    const int wpc = stream ? (carry ? f->stream_wpc_carry : f->stream_wpc) : (!wpc_env && cp && f->mf_W == 2 ? 3 : f->mf_wpc);
     const unsigned pg = (unsigned)(f->ctx->num_cu * wpc + 7) / 8 * 8;
     if (grid > pg) grid = pg;
     {

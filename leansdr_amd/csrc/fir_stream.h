@@ -74,6 +74,12 @@ using namespace lsdr_fir;
 // of granule p of row ρ fetches stream bytes 16·(granule) − 4·PADF·ρ — the padding is filled with the samples that follow the row
 // (finite, and only ever multiplied by the K padding's zero taps).  Same arithmetic, bit for bit, for every D.
 typedef __attribute__((address_space(3))) void *fir_lds_ptr;
+// (128-row tiles could carry too — their ring keeps rows 112 … 127 in slots 48 … 63 until pair 3 is written — and were measured: the headline's launch alone
+// 5.37 → 5.38 TB/s, in its pipeline 704–706 → 697–702 GS/s: its halo rows come out of L2 and the launch is HBM-bound; the warm-up pair is all it adds)
+#ifndef LSDR_STREAM_CARRY8
+#define LSDR_STREAM_CARRY8 0
+#endif
+constexpr bool stream_carry(int iv, int np, bool fold) { return !iv && ((LSDR_STREAM_CARRY8 && np == 8) || (np == 4 && fold)); }
 constexpr unsigned stream_padf(unsigned D) { return (12u - (2u * D) % 8u) % 8u; }      // (2·D + PADF) ≡ 4 (mod 8), PADF < 8
 
 // IV = 1: the taps are a function of the position in the stream (fir_args::iv_tile_first): a wavefront walks its tiles in
@@ -103,27 +109,36 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
   static_assert(ROWB % 16 == 0 && (ROWB / 4) % 8 == 4, "a row starts on a granule and is ≡ 4 (mod 8) floats long");
   constexpr unsigned RW = 16 * NP;                                // rows (blocks of D samples) per wave tile
   static_assert(NP >= 4 && NP % 2 == 0, "whole diagonal batches of two pairs; the wait counts assume NP >= 3");
-  static_assert(!FOLDT || (NP == 4 && 16 * ROWB >= 16 * 2 * 17 * 4), "the folded ring's mirrored rows must fit in the last pair's sample rows");
+  static_assert(!FOLDT || (NP == 4 && (stream_carry(IV, NP, FOLDT) || 16 * ROWB >= 16 * 2 * 17 * 4)), "the folded ring's mirrored rows must fit in the last pair's sample rows");
   constexpr unsigned REGB = FP * 8 + RW * ROWB;                   // region bytes
   // LDS-direct loads per refill group.  PADF = 0: group 0 also fetches the FP samples in front of row 0.  PADF > 0: all groups alike —
   // the front is never fetched (it is zeroed once: what the K padding of row 0 reads there only has to be finite).
   constexpr unsigned NLI = PADF ? (PAIRG + 63) / 64 : (PAIRG + FP / 2 + 63) / 64;
   const unsigned l = threadIdx.x;
-  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks, MW = RW - (NQ - 1);
+  // CARRY (the folded 64-row tiles: complex taps at the C2 geometry): the Z rows that the first NQ − 1 outputs of a tile reach back into are the
+  // LAST rows of the tile before it — and a workgroup walks consecutive tiles, so they can stay in its ring: tiles are RW rows apart (not
+  // RW − (NQ − 1): no halo re-read, no halo MFMAs — 64 rows per 64 outputs instead of per 54) and the first tile of a workgroup's list warms the
+  // ring up with the last pair of the tile in front of it (below).  The ring keeps those rows in a GAP of NQ − 1 rows in front of slot 0 (see
+  // FOLD) until the next tile's first diagonal batch has read them.  c2_offset 537 → 575–587 GS/s.  The IV pass keeps the halo (its intervals
+  // are cut by tiles of MW outputs: notch.hip); so do the 128-row tiles (stream_carry).
+  constexpr bool CARRY = stream_carry(IV, NP, FOLDT);
+  const unsigned NQ = NQT ? (unsigned)NQT : a.mf_blocks, MW = CARRY ? RW : RW - (NQ - 1);
   constexpr int NQR = NQT ? NQT : 16;
   const unsigned ROWZ = 2 * (NQ | 1u);
-  char *const ring = smem_raw + ((REGB + 15) & ~15u);       // 64 rows + rows 0…15 once more as rows 64…79 (see k_fir_mfma_blk)
+  // 64 rows + rows 0…15 once more as rows 64…79 (see k_fir_mfma_blk); folded ring with CARRY: NQ − 1 rows in front of slot 0 (the gap)
+  char *const ring = smem_raw + ((REGB + 15) & ~15u) + ((CARRY && FOLDT) ? (NQ - 1) * ROWZ * 4 : 0u);
   const unsigned xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
   // this XCD's tiles [xcd·tiles_per_xcd, + xcnt), walked from tile x·xcd_rot of the range on, wrapping (xcd_rot = 0: from its start)
   const unsigned xbase = xcd * a.tiles_per_xcd;
   const unsigned xcnt = xbase >= a.n_tiles ? 0u : (a.n_tiles - xbase < a.tiles_per_xcd ? a.n_tiles - xbase : a.tiles_per_xcd);
-  const unsigned xrot = xcnt ? (unsigned)(((unsigned long long)xcd * a.xcd_rot) % xcnt) : 0u;
+  const bool chunked = CARRY || a.chunked;      // (CARRY: consecutive tiles, walked from the range's start)
+  const unsigned xrot = (!CARRY && xcnt) ? (unsigned)(((unsigned long long)xcd * a.xcd_rot) % xcnt) : 0u;
   auto tile_of = [&](unsigned ti) { const unsigned p = ti + xrot; return xbase + (p >= xcnt ? p - xcnt : p); };
   // a workgroup's tile list: strided (slot, slot + slots, …: at any moment the XCD's workgroups read one narrow window of its range) or one
   // consecutive stretch of ⌈xcnt/slots⌉ tiles (a workgroup stays inside one or two 2 MiB pages: see lsdr_fir_filter::stream_chunked)
-  const unsigned per = a.chunked ? (xcnt + slots - 1) / slots : 0u;
-  const unsigned t_first = a.chunked ? slot * per : slot, t_step = a.chunked ? 1u : slots;
-  const unsigned t_lim = a.chunked ? (t_first + per < xcnt ? t_first + per : xcnt) : xcnt;
+  const unsigned per = chunked ? (xcnt + slots - 1) / slots : 0u;
+  const unsigned t_first = chunked ? slot * per : slot, t_step = chunked ? 1u : slots;
+  const unsigned t_lim = chunked ? (t_first + per < xcnt ? t_first + per : xcnt) : xcnt;
   auto valid = [&](unsigned ti) { return ti < t_lim; };
 
   float bco[NB];
@@ -205,10 +220,6 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     for (unsigned s = 0; s < NB; ++s) bco[s] = a.mf_atab[(size_t)iv_cur * (NB * 64) + s * 64 + l];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  aim(tile_of(ti), true);
-#pragma unroll
-  for (int P = 0; P < NP; ++P) refill(P);
-
   // per-lane cursors (see k_fir_mfma_blk); the sample operand of K slot r' = 4·s + k of row ρ is the sample r' BEFORE the row's last one.
   // Real taps (CP = 0): the 16 operand rows of an MFMA are 8 rows × {re, im} — a pair of row tiles is two MFMA row tiles (h), one
   // 4-byte operand per lane and step, Z[(ρ, comp)][q] += x_comp · c.
@@ -243,12 +254,126 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     dbase[par] = (int)((rp * ROWZ + rc) * 4) - 15 * (int)dstep;   // = ((rp − 15)·ROWZ + 2·15 + rc)·4
   }
 
+  const char *ap = smem_raw + a0;
+  unsigned pa[2][2][CP ? 1 : KS];
+  lsdr_v2f pc[2][CP ? KS : 1];
+  auto fetch1 = [&](int set, int pair, int h, unsigned s) {
+    pa[set][h][s] = *reinterpret_cast<const unsigned *>(ap + (2 * pair + h) * ATILE + (KS - 1 - s) * ASTEP);
+  };
+  auto fetch2 = [&](int set, int pair, unsigned s) {      // CP: (re, im) of the lane's sample of step s
+    pc[set][s] = *reinterpret_cast<const lsdr_v2f *>(ap + 2 * pair * ATILE + (KS - 1 - s) * ASTEP);
+  };
+  auto opnd = [&](unsigned r) { return __uint_as_float(r); };
+  lsdr_v4f acc[2][2];      // CP = 0: [set][h];  CP = 1: [set][re / im]
+  auto to_ring = [&](int set, int pair) {
+    if (CP) {
+      if (zq < NQ) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {      // the accumulators' rows 4·kq + i of the pair, column zq: (re, im) side by side as the ring holds them
+          const unsigned row0 = (16u * pair + 4u * kq + i) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
+          const lsdr_v2f v = {acc[set][0][i], acc[set][1][i]};
+          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = v;
+          if (FOLD && pair == 2 && (!CARRY || 4u * kq + i + NQ >= 17u)) *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = v;
+          if (MIRROR && ((16u * pair) & 63u) == 0) *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = v;
+        }
+      }
+      return;
+    }
+    if (zq < NQ) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned row0 = (16u * pair + 8u * h + zrow) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
+        const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
+        *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
+        *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
+        if (FOLD && pair == 2) {            // rows 32 … 47 once more at −16 … −1 (!CARRY: inside the region's last rows; CARRY: the rows the gap has — see FOLD)
+          if (!CARRY || 8u * h + zrow + NQ >= 17u) *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = lo;
+          if (!CARRY || 8u * h + zrow + 1u + NQ >= 17u) *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 47) * (int)ROWZ + 2 * (int)zq) * 4) = hi;
+        }
+        if (MIRROR && ((16u * pair) & 63u) == 0) {
+          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
+          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
+        }
+      }
+    }
+  };
+  // FOLD with CARRY: the last NQ − 1 rows of the tile (pair 3's) once more in the gap in front of slot 0, where the NEXT tile's first diagonal
+  // batch finds them — written after this tile's last batch has read the gap (it held rows 38 … 47 for it)
+  auto carry_write = [&](int set) {
+    if (zq < NQ) {
+      if (CP) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4u * kq + i + NQ >= 17u) {
+            const lsdr_v2f v = {acc[set][0][i], acc[set][1][i]};
+            *reinterpret_cast<lsdr_v2f *>(ring + (((int)(4u * kq + i) - 16) * (int)ROWZ + 2 * (int)zq) * 4) = v;
+          }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
+          if (8u * h + zrow + NQ >= 17u) *reinterpret_cast<lsdr_v2f *>(ring + (((int)(8u * h + zrow) - 16) * (int)ROWZ + 2 * (int)zq) * 4) = lo;
+          if (8u * h + zrow + 1u + NQ >= 17u) *reinterpret_cast<lsdr_v2f *>(ring + (((int)(8u * h + zrow) - 15) * (int)ROWZ + 2 * (int)zq) * 4) = hi;
+        }
+      }
+    }
+  };
+
+  // Start: the first tile's rows on their way.  CARRY, first tile of the list not the first of its stream: the ring has to hold the last
+  // NQ − 1 rows of the tile in FRONT of it — its last pair is loaded (with the pair before it: the K padding reads that one's last samples),
+  // multiplied and written to the ring while the first tile's other rows are already coming; then its two places are refilled in order,
+  // so that the loop below finds the NP groups of its first tile outstanding, oldest first, as without the warm-up.
+  {
+    const unsigned t0 = tile_of(ti);
+    const unsigned lt0 = one ? t0 : t0 % a.tiles_per_stream;
+    if (CARRY && lt0 > 0) {
+      aim(t0 - 1, true);
+      refill(NP - 2); refill(NP - 1);
+      aim(t0, true);
+#pragma unroll
+      for (int P = 0; P < NP - 2; ++P) refill(P);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NP - 2) * NLI) : "memory");
+      if (CP) {
+#pragma unroll
+        for (unsigned s = 0; s < KS; ++s) fetch2(0, NP - 1, s);
+#pragma unroll
+        for (unsigned s = 0; s < KS; ++s) {
+          const float xr = pc[0][s][0], xi = pc[0][s][1];
+          const lsdr_v4f z0 = s ? acc[0][0] : (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, z1 = s ? acc[0][1] : (lsdr_v4f){0.f, 0.f, 0.f, 0.f};
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, bco[s], z0, 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, bco[s], z1, 0, 0, 0);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi, bco[KS + s], acc[0][0], 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(xr, bco[2 * KS + s], acc[0][1], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (unsigned s = 0; s < KS; ++s) { fetch1(0, NP - 1, 0, s); fetch1(0, NP - 1, 1, s); }
+#pragma unroll
+        for (unsigned s = 0; s < KS; ++s) {
+          const lsdr_v4f z0 = s ? acc[0][0] : (lsdr_v4f){0.f, 0.f, 0.f, 0.f}, z1 = s ? acc[0][1] : (lsdr_v4f){0.f, 0.f, 0.f, 0.f};
+          acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[0][0][s]), bco[s], z0, 0, 0, 0);
+          acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(opnd(pa[0][1][s]), bco[s], z1, 0, 0, 0);
+        }
+      }
+      to_ring(0, NP - 1);
+      if (FOLD) carry_write(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      refill(NP - 2); refill(NP - 1);
+    } else {
+      aim(t0, true);
+#pragma unroll
+      for (int P = 0; P < NP; ++P) refill(P);
+    }
+  }
+
   while (true) {
     const unsigned tile = tile_of(ti);
     const unsigned tn = ti + t_step;
     const bool more = valid(tn);
     const unsigned st = one ? 0u : tile / a.tiles_per_stream;
-    const unsigned long long m0 = (unsigned long long)(tile - st * a.tiles_per_stream) * MW;
+    const unsigned lt = tile - st * a.tiles_per_stream;
+    const unsigned long long m0 = (unsigned long long)lt * MW;
+    const bool low_rows = CARRY && lt > 0;      // the outputs of rows 0 … NQ − 2 exist: their Z terms of the tile in front are in the ring
     float *const po = one ? out0 : reinterpret_cast<float *>(a.outs[st]);
     aim(more ? tile_of(tn) : 0u, more);      // the refills of this iteration fetch the NEXT tile (an empty resource at the end: no traffic)
     if (IV && (tile >= iv_hi || tile < iv_lo)) {      // (wave-uniform, a handful of times per launch: the bounds of the current interval stay in registers)
@@ -265,49 +390,6 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
       }
     }
 
-    const char *ap = smem_raw + a0;
-    unsigned pa[2][2][CP ? 1 : KS];
-    lsdr_v2f pc[2][CP ? KS : 1];
-    auto fetch1 = [&](int set, int pair, int h, unsigned s) {
-      pa[set][h][s] = *reinterpret_cast<const unsigned *>(ap + (2 * pair + h) * ATILE + (KS - 1 - s) * ASTEP);
-    };
-    auto fetch2 = [&](int set, int pair, unsigned s) {      // CP: (re, im) of the lane's sample of step s
-      pc[set][s] = *reinterpret_cast<const lsdr_v2f *>(ap + 2 * pair * ATILE + (KS - 1 - s) * ASTEP);
-    };
-    auto opnd = [&](unsigned r) { return __uint_as_float(r); };
-    lsdr_v4f acc[2][2];      // CP = 0: [set][h];  CP = 1: [set][re / im]
-    auto to_ring = [&](int set, int pair) {
-      if (CP) {
-        if (zq < NQ) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {      // the accumulators' rows 4·kq + i of the pair, column zq: (re, im) side by side as the ring holds them
-            const unsigned row0 = (16u * pair + 4u * kq + i) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
-            const lsdr_v2f v = {acc[set][0][i], acc[set][1][i]};
-            *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = v;
-            if (FOLD && pair == 2) *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = v;
-            if (MIRROR && ((16u * pair) & 63u) == 0) *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = v;
-          }
-        }
-        return;
-      }
-      if (zq < NQ) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const unsigned row0 = (16u * pair + 8u * h + zrow) & 63u, row = (FOLD && pair == 3) ? row0 - 48u : row0;
-          const lsdr_v2f lo = {acc[set][h][0], acc[set][h][1]}, hi = {acc[set][h][2], acc[set][h][3]};
-          *reinterpret_cast<lsdr_v2f *>(ring + (row * ROWZ + 2 * zq) * 4) = lo;
-          *reinterpret_cast<lsdr_v2f *>(ring + ((row + 1) * ROWZ + 2 * zq) * 4) = hi;
-          if (FOLD && pair == 2) {            // rows 32 … 47 once more at −16 … −1 (inside the region's last rows: see FOLD)
-            *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 48) * (int)ROWZ + 2 * (int)zq) * 4) = lo;
-            *reinterpret_cast<lsdr_v2f *>(ring + (((int)row - 47) * (int)ROWZ + 2 * (int)zq) * 4) = hi;
-          }
-          if (MIRROR && ((16u * pair) & 63u) == 0) {
-            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 64) * ROWZ + 2 * zq) * 4) = lo;
-            *reinterpret_cast<lsdr_v2f *>(ring + ((row + 65) * ROWZ + 2 * zq) * 4) = hi;
-          }
-        }
-      }
-    };
     float zv[NQR];
     auto diag_read = [&](int batch, int q) {
       zv[q] = *reinterpret_cast<const float *>(ring + (dbase[batch & 1] + (15 - q) * (int)dstep));
@@ -319,8 +401,8 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     };
     auto diag_store = [&](int batch) {
       const int rho = 32 * batch + (int)ro;
-      const unsigned long long m = m0 + (unsigned)(rho - (int)(NQ - 1));
-      if (rho >= (int)(NQ - 1) && m < a.count)
+      const unsigned long long m = (unsigned long long)((long long)m0 + (rho - (int)(NQ - 1)));      // (rho < NQ − 1 in the first tile of a stream: wraps past count — not stored)
+      if ((rho >= (int)(NQ - 1) || low_rows) && m < a.count)
         asm volatile("global_store_dword %0, %1, off" ::"v"(po + 2 * m + rc), "v"(ysum) : "memory");
     };
     auto at_step = [](int i, int n, int lo, int hi) { return hi > lo ? lo + i * (hi - lo) / n : lo; };
@@ -399,8 +481,9 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
     for (int q = 0; q < NQR; ++q) diag_read(NP / 2 - 1, q);
 #pragma unroll
     for (int q = 0; q < NQR; ++q) diag_add(q);
-    if (FOLD) {                                // the last rows' refill lands on the mirrored ring rows: only after the sums have their terms
+    if (FOLD) {                                // (!CARRY: the last rows' refill lands on the mirrored ring rows: only after the sums have their terms)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (CARRY) carry_write((NP - 1) & 1);
       refill(NP - 1);
     }
     diag_store(NP / 2 - 1);
@@ -411,16 +494,16 @@ __global__ __launch_bounds__(64) void k_fir_mfma_stream(fir_args a) {
 }
 
 // LDS bytes of one k_fir_mfma_stream wavefront: region (front padding + 16·np padded rows) + Z ring + the diagonal reads' overrun
-unsigned stream_lds(unsigned D, unsigned nq, bool cplx, unsigned np = 8, bool fold = true) {
+unsigned stream_lds(unsigned D, unsigned nq, bool cplx, unsigned np = 8, bool fold = true, bool iv = false) {
   (void)cplx;      // (the region is the same for both tap kinds: four samples of a row per MFMA step)
   const unsigned kp = (D + 3) / 4 * 4, fp = ((kp - D) + 1) & ~1u;
   const unsigned region = (fp * 8 + 16 * np * (D * 8 + stream_padf(D) * 4) + 15) & ~15u;
-  if (np == 4 && fold) return region + 48 * 2 * (nq | 1u) * 4;   // folded ring, compile-time tap blocks only (no overrun)
+  if (np == 4 && fold) return region + (48 + (iv ? 0u : nq - 1)) * 2 * (nq | 1u) * 4;   // folded ring (CARRY: + the gap), compile-time tap blocks only (no overrun)
   return region + (np == 4 ? 64 : 80) * 2 * (nq | 1u) * 4 + 128;
 }
 
 // What a launch needs to know about the kernel picked for a geometry: np = pairs of row tiles per wave tile, fold = the folded ring
-struct stream_kernel { fir_kernel_t k; unsigned np; bool fold; };
+struct stream_kernel { fir_kernel_t k; unsigned np; bool fold; bool carry() const { return stream_carry(0, (int)np, fold); } };
 // The sweep's shape per decimation and tap kind: 128-row wave tiles while five or more wavefronts per CU find their LDS (≤ 32 KB each), 64-row ones
 // (unfolded ring) above — real taps D ≤ LSDR_SWEEP_NP8_REAL, complex taps (twice the matrix work per row: more wavefronts to overlap it) D ≤ LSDR_SWEEP_NP8_CPLX
 #ifndef LSDR_SWEEP_NP8_REAL

@@ -345,6 +345,36 @@ def test_mfma_blk_run_time_and_compile_time_tap_blocks_give_the_same_bits(capi, 
     assert np.array_equal(outs[1], outs[3]) and np.array_equal(outs[1], oracle.fir_filter(co, d, x, -0.021, fma="blk", scale=3.0)[0])
 
 
+@pytest.mark.parametrize("swpc", ["1", "48", "192"])
+def test_mfma_blk_carried_ring_rows_do_not_depend_on_where_the_lists_are_cut(capi, ctx, oracle, swpc, monkeypatch):
+    """Complex taps at the C2 geometry run the folded 64-row tiles that CARRY the ring's last rows into the next tile of a workgroup's list
+    (fir_stream.h): no halo, a warm-up pair at the head of every list.  Output counts around one tile, two tiles, and many — with one
+    workgroup per CU queued (long lists: the steady state), the default, and 192 (lists of one or two tiles: warm-ups everywhere) — and three
+    streams in one launch (a list that crosses into the next stream): the oracle's bits each time."""
+    monkeypatch.setenv("LSDR_MFMA_SWPC", swpc)
+    rng = np.random.default_rng(int(swpc))
+    co = capi.lowpass(312, 0.45 / 30)
+    f = capi.FirFilter(ctx, co, 30, in_scale=75.0, arith=capi.FIR_MFMA_BLK)
+    f.set_freq(0.0123)
+    for nout in (1, 53, 54, 55, 64, 65, 118, 129, 1100, 40000):
+        ns = nout * 30 + len(co) + 11
+        x = ((rng.standard_normal(ns) + 1j * rng.standard_normal(ns)) * 0.7).astype(np.complex64)
+        y, cons = f.run(x)
+        want = oracle.fir_filter(co, 30, x, f.current_freq, fma="blk", scale=75.0)[0]
+        assert len(y) == len(want) == nout and cons == 30 * nout and np.array_equal(y, want), nout
+    n = 30 * 700 + len(co)
+    xs = [((rng.standard_normal(n) + 1j * rng.standard_normal(n)) * 0.7).astype(np.complex64) for _ in range(3)]
+    dins = [ctx.upload(x) for x in xs]
+    douts = [ctx.alloc(700 * 8 + 64) for _ in xs]
+    cons, prod = f.run_multi_dev([d.ptr for d in dins], n, [d.ptr for d in douts], 700)
+    assert prod == 700 and cons == 700 * 30
+    for x, dout in zip(xs, douts):
+        assert np.array_equal(ctx.download(dout, np.complex64, prod), oracle.fir_filter(co, 30, x, f.current_freq, fma="blk", scale=75.0)[0][:prod])
+    for d in dins + douts:
+        d.free()
+    f.close()
+
+
 @pytest.mark.parametrize("n,d", [(81, 7), (343, 33), (16, 1), (625, 60)])
 def test_mfma_blk_sweep_kernels_short_inputs_capped_outputs_and_run_multi(capi, ctx, oracle, n, d):
     """The sweep's kernels (padded LDS rows, 128- and 64-row wave tiles) at the edges: inputs shorter than one tile, one output, an output cap that
